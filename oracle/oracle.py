@@ -1,0 +1,249 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+ctypes wrapper over oracle/_build/liboracle.so (the CPU restatement of diffsol's BDF / SDIRK path).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+MODEL_EXPONENTIAL_DECAY = 0
+MODEL_EXPONENTIAL_DECAY_ALGEBRAIC = 1
+MODEL_EXPONENTIAL_DECAY_ALGEBRAIC_BATCHED = 2
+MODEL_ROBERTSON_ODE = 3
+MODEL_ROBERTSON_DAE = 4
+MODEL_DYDT_Y2 = 5
+MODEL_GAUSSIAN_DECAY = 6
+MODEL_HEAT1D = 7
+MODEL_RLC = 8
+MODEL_EXPONENTIAL_DECAY_ROOT = 9
+
+METHOD_BDF = 0
+METHOD_TR_BDF2 = 1
+METHOD_ESDIRK34 = 2
+
+STAT_NAMES = [
+    "number_of_linear_solver_setups", "number_of_steps", "number_of_error_test_failures",
+    "number_of_nonlinear_solver_iterations", "number_of_nonlinear_solver_fails",
+    "number_of_linear_solver_setups_from_checkpoint", "number_of_linear_solver_setups_from_first_convergence_fail",
+    "number_of_linear_solver_setups_from_second_convergence_fail", "number_of_linear_solver_setups_from_error_test_fail",
+    "number_of_linear_solver_setups_from_step_success", "number_of_calls", "number_of_jac_muls", "number_of_matrix_evals",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_long)
+
+
+def build(force=False):
+    """Compile the C++ restatement (g++, a few seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp"))
+    ):
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_solver_create.restype = C.c_void_p
+        L.orc_solver_create.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.orc_solver_destroy.argtypes = [C.c_void_p]
+        L.orc_nstates.argtypes = [C.c_void_p]
+        L.orc_nbatch.argtypes = [C.c_void_p]
+        L.orc_step.argtypes = [C.c_void_p]
+        L.orc_set_stop_time.argtypes = [C.c_void_p, C.c_double]
+        L.orc_interpolate.argtypes = [C.c_void_p, C.c_double, _dp]
+        L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp, _ip, _dp, _dp]
+        L.orc_bdf_get_diff.argtypes = [C.c_void_p, _dp]
+        L.orc_root_info.argtypes = [C.c_void_p, _dp, _ip]
+        L.orc_stats.argtypes = [C.c_void_p, _lp]
+        L.orc_solve_to_points.argtypes = [C.c_void_p, _dp, C.c_int, _dp]
+        L.orc_solve.restype = C.c_long
+        L.orc_solve.argtypes = [C.c_void_p, C.c_double, _dp]
+        L.orc_solve_ensemble_independent.restype = C.c_double
+        L.orc_solve_ensemble_independent.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp, C.c_int, C.c_double, C.c_double,
+                                                     C.c_int, C.c_double, C.c_int, _dp, _lp]
+        L.orc_compute_r.argtypes = [C.c_int, C.c_double, _dp]
+        L.orc_lu_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+        L.orc_squared_norm.restype = C.c_double
+        L.orc_squared_norm.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double]
+        L.orc_convergence_trace.argtypes = [C.c_double, C.c_double, C.c_int, _dp, C.c_int, _ip, _dp]
+        L.orc_model_rhs.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
+        L.orc_model_jac_mul.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class OracleSolver:
+    """One (possibly batched, lock-step) solver instance of the CPU restatement."""
+
+    def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF):
+        L = lib()
+        p_arr, p_ptr = _d(np.asarray(p, dtype=np.float64).reshape(-1))
+        a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
+        self._h = L.orc_solver_create(model, model_size, nbatch, p_ptr, p_arr.size, rtol, a_ptr, a_arr.size, t0, h0, method)
+        if not self._h:
+            raise OracleError(L.orc_last_error().decode())
+        self.n = L.orc_nstates(self._h)
+        self.nbatch = L.orc_nbatch(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_solver_destroy(self._h)
+            self._h = None
+
+    def step(self):
+        """Returns 0 InternalTimestep, 1 RootFound, 2 TstopReached; raises on solver error."""
+        r = lib().orc_step(self._h)
+        if r < 0:
+            raise OracleError(f"oracle step failed with OdeErr {-r}")
+        return r
+
+    def set_stop_time(self, t):
+        r = lib().orc_set_stop_time(self._h, t)
+        if r < 0:
+            raise OracleError(f"oracle set_stop_time failed with OdeErr {-r}")
+
+    def state(self):
+        t = C.c_double()
+        h = C.c_double()
+        order = C.c_int()
+        y = np.empty((self.nbatch, self.n))
+        dy = np.empty((self.nbatch, self.n))
+        lib().orc_get_state(self._h, C.byref(t), C.byref(h), C.byref(order), y.ctypes.data_as(_dp), dy.ctypes.data_as(_dp))
+        return dict(t=t.value, h=h.value, order=order.value, y=y, dy=dy)
+
+    def diff(self):
+        out = np.empty((self.nbatch, 8, self.n))
+        if lib().orc_bdf_get_diff(self._h, out.ctypes.data_as(_dp)) != 0:
+            raise OracleError("not a BDF solver")
+        return out
+
+    def interpolate(self, t):
+        y = np.empty((self.nbatch, self.n))
+        r = lib().orc_interpolate(self._h, t, y.ctypes.data_as(_dp))
+        if r < 0:
+            raise OracleError(f"oracle interpolate failed with OdeErr {-r}")
+        return y
+
+    def root_info(self):
+        t = C.c_double()
+        i = C.c_int()
+        lib().orc_root_info(self._h, C.byref(t), C.byref(i))
+        return t.value, i.value
+
+    def stats(self):
+        out = (C.c_long * 13)()
+        lib().orc_stats(self._h, out)
+        return dict(zip(STAT_NAMES, [int(v) for v in out]))
+
+    def solve_to_points(self, t_points):
+        """The reference's test_ode_solver loop (use_tstop=False): step past each point, interpolate there."""
+        tp, tp_ptr = _d(t_points)
+        out = np.empty((tp.size, self.nbatch, self.n))
+        r = lib().orc_solve_to_points(self._h, tp_ptr, tp.size, out.ctypes.data_as(_dp))
+        if r < 0:
+            raise OracleError(f"oracle solve_to_points failed with OdeErr {-r}")
+        return out, r
+
+    def solve(self, t_final):
+        """OdeSolverMethod::solve: returns (final state.y [nbatch, n], number of output columns)."""
+        y = np.empty((self.nbatch, self.n))
+        r = lib().orc_solve(self._h, t_final, y.ctypes.data_as(_dp))
+        if r < 0:
+            raise OracleError(f"oracle solve failed with OdeErr {-r}")
+        return y, int(r)
+
+
+def solve_ensemble_independent(model, p, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, t_final=1.0,
+                               nthreads=1, want_y=True):
+    """CPU baseline: one independent IVP per parameter set (the reference's CPU usage pattern), over `nthreads` threads."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    nsys, np_ = p.shape
+    a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
+    # nstates via a throw-away solver
+    s = OracleSolver(model, p[0], model_size=model_size, rtol=rtol, atol=atol, t0=t0, h0=h0, method=method)
+    n = s.n
+    del s
+    y = np.empty((nsys, n)) if want_y else None
+    counters = (C.c_long * 4)()
+    secs = lib().orc_solve_ensemble_independent(model, model_size, nsys, p.ctypes.data_as(_dp), np_, rtol, a_ptr, a_arr.size, t0, h0, method,
+                                                t_final, nthreads, y.ctypes.data_as(_dp) if want_y else None, counters)
+    return dict(seconds=secs, steps=int(counters[0]), newton_iterations=int(counters[1]), lu_setups=int(counters[2]),
+                failed=int(counters[3]), y=y)
+
+
+def compute_r(order, factor):
+    out = np.empty((order + 1) * (order + 1))
+    lib().orc_compute_r(order, factor, out.ctypes.data_as(_dp))
+    return out.reshape(order + 1, order + 1).T.copy()  # column-major -> [i, j]
+
+
+def lu_solve(a, b):
+    """a: [nbatch, n, n] (row, col), b: [nbatch, n]. Returns x, lu [nbatch, n, n], piv [nbatch, n], singular flag."""
+    a = np.asarray(a, dtype=np.float64)
+    nb, n, _ = a.shape
+    a_cm = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+    x = np.ascontiguousarray(b, dtype=np.float64).copy()
+    lu = np.empty_like(a_cm)
+    piv = np.empty((nb, n), dtype=np.int32)
+    rc = lib().orc_lu_solve(n, nb, a_cm.ctypes.data_as(_dp), x.ctypes.data_as(_dp), lu.ctypes.data_as(_dp), piv.ctypes.data_as(_ip))
+    return x, np.transpose(lu, (0, 2, 1)).copy(), piv, rc
+
+
+def squared_norm(x, y, atol, rtol):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    nb, n = x.shape
+    xa, xp = _d(x)
+    ya, yp = _d(y)
+    aa, ap = _d(atol)
+    return lib().orc_squared_norm(n, nb, xp, yp, ap, rtol)
+
+
+def convergence_trace(norms, rtol=1e-6, tol=0.2, max_iter=10):
+    na, npx = _d(norms)
+    status = np.empty(na.size, dtype=np.int32)
+    eta = np.empty(na.size)
+    lib().orc_convergence_trace(rtol, tol, max_iter, npx, na.size, status.ctypes.data_as(_ip), eta.ctypes.data_as(_dp))
+    return status, eta
+
+
+def model_rhs(model, x, p, t=0.0, model_size=0):
+    xa, xp = _d(x)
+    pa, pp = _d(p)
+    y = np.empty_like(xa)
+    lib().orc_model_rhs(model, model_size, xp, pp, t, y.ctypes.data_as(_dp))
+    return y
+
+
+def model_jac_mul(model, x, p, v, t=0.0, model_size=0):
+    xa, xp = _d(x)
+    pa, pp = _d(p)
+    va, vp = _d(v)
+    y = np.empty_like(xa)
+    lib().orc_model_jac_mul(model, model_size, xp, pp, t, vp, y.ctypes.data_as(_dp))
+    return y

@@ -1,0 +1,241 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// C ABI over the CPU restatement (oracle_*.hpp) so tests/ and bench.py's cpu_baseline leg can drive it
+// through ctypes.  Vectors cross this boundary batch-major ([b][i]) like the reference API.
+#include "oracle_ode.hpp"
+#include "oracle_sdirk.hpp"
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+using namespace orc;
+
+namespace {
+struct Handle {
+  Problem problem;
+  std::unique_ptr<SolverBase> solver;
+  int init_error = 0;
+};
+thread_local std::string g_last_error;
+
+enum Method : int { METHOD_BDF = 0, METHOD_TR_BDF2 = 1, METHOD_ESDIRK34 = 2 };
+
+std::unique_ptr<Handle> make_handle(int model_id, int model_size, int nbatch, const double* p, int np_total, double rtol, const double* atol,
+                                    int natol, double t0, double h0, int method) {
+  auto h = std::make_unique<Handle>();
+  std::vector<double> pv(p, p + np_total);
+  auto model = make_model(model_id, model_size);
+  h->problem.eqn = std::make_unique<Eqn>(std::move(model), nbatch, pv);
+  int n = h->problem.n();
+  h->problem.rtol = rtol;
+  h->problem.atol = V(n, 1);
+  if (natol == 1) for (int i = 0; i < n; ++i) h->problem.atol.d[i] = atol[0];
+  else if (natol == n) for (int i = 0; i < n; ++i) h->problem.atol.d[i] = atol[i];
+  else throw std::runtime_error("oracle: atol must have length 1 or nstates");
+  h->problem.t0 = t0;
+  h->problem.h0 = h0;
+  if (method == METHOD_BDF) {
+    auto s = std::make_unique<Bdf>(&h->problem);
+    h->init_error = (int)s->init_error;
+    h->solver = std::move(s);
+  } else {
+    auto s = std::make_unique<Sdirk>(&h->problem, method == METHOD_TR_BDF2 ? Tableau::tr_bdf2() : Tableau::esdirk34());
+    h->init_error = (int)s->init_error;
+    h->solver = std::move(s);
+  }
+  return h;
+}
+}  // namespace
+
+extern "C" {
+
+const char* orc_last_error() { return g_last_error.c_str(); }
+
+// returns nullptr on failure (message via orc_last_error)
+void* orc_solver_create(int model_id, int model_size, int nbatch, const double* p, int np_total, double rtol, const double* atol, int natol,
+                        double t0, double h0, int method) {
+  try {
+    auto h = make_handle(model_id, model_size, nbatch, p, np_total, rtol, atol, natol, t0, h0, method);
+    if (h->init_error != 0) { g_last_error = "oracle: initialisation failed with OdeErr " + std::to_string(h->init_error); return nullptr; }
+    return h.release();
+  } catch (const std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+void orc_solver_destroy(void* hv) { delete (Handle*)hv; }
+
+int orc_nstates(void* hv) { return ((Handle*)hv)->problem.n(); }
+int orc_nbatch(void* hv) { return ((Handle*)hv)->problem.nb(); }
+
+// step: returns OdeErr (<0 => -err) or StopReason (>=0)
+int orc_step(void* hv) {
+  Handle* h = (Handle*)hv;
+  StopReason r = StopReason::InternalTimestep;
+  OdeErr e = h->solver->step(r);
+  if (e != OdeErr::Ok) return -(int)e;
+  return (int)r;
+}
+int orc_set_stop_time(void* hv, double t) { return -(int)((Handle*)hv)->solver->set_stop_time(t); }
+int orc_interpolate(void* hv, double t, double* y) {
+  Handle* h = (Handle*)hv;
+  V out(h->problem.n(), h->problem.nb());
+  OdeErr e = h->solver->interpolate_inplace(t, out);
+  if (e != OdeErr::Ok) return -(int)e;
+  std::memcpy(y, out.d.data(), out.d.size() * sizeof(double));
+  return 0;
+}
+void orc_get_state(void* hv, double* t, double* hstep, int* order, double* y, double* dy) {
+  Handle* h = (Handle*)hv;
+  if (t) *t = h->solver->t();
+  if (hstep) *hstep = h->solver->h();
+  if (order) *order = h->solver->order();
+  if (y) std::memcpy(y, h->solver->y().d.data(), h->solver->y().d.size() * sizeof(double));
+  if (dy) std::memcpy(dy, h->solver->dy().d.data(), h->solver->dy().d.size() * sizeof(double));
+}
+// BDF only: difference array, batch-major [b][col][row], 8 columns
+int orc_bdf_get_diff(void* hv, double* out) {
+  Bdf* s = dynamic_cast<Bdf*>(((Handle*)hv)->solver.get());
+  if (!s) return -1;
+  std::memcpy(out, s->diff.d.data(), s->diff.d.size() * sizeof(double));
+  return 0;
+}
+void orc_root_info(void* hv, double* t_root, int* idx) {
+  Handle* h = (Handle*)hv;
+  *t_root = h->solver->root_time;
+  *idx = h->solver->root_index;
+}
+// out[0..10) = OdeSolverStatistics fields in declaration order; out[10..13) = rhs OpStatistics (calls, jac_muls, matrix_evals)
+void orc_stats(void* hv, long* out) {
+  Handle* h = (Handle*)hv;
+  const Stats& s = h->solver->stats();
+  out[0] = s.number_of_linear_solver_setups; out[1] = s.number_of_steps; out[2] = s.number_of_error_test_failures;
+  out[3] = s.number_of_nonlinear_solver_iterations; out[4] = s.number_of_nonlinear_solver_fails;
+  out[5] = s.setups_from_checkpoint; out[6] = s.setups_from_first_convergence_fail; out[7] = s.setups_from_second_convergence_fail;
+  out[8] = s.setups_from_error_test_fail; out[9] = s.setups_from_step_success;
+  const OpStats& o = h->problem.eqn->rhs_stats;
+  out[10] = o.calls; out[11] = o.jac_muls; out[12] = o.matrix_evals;
+}
+
+// The reference's test harness loop (crates/diffsol/src/ode_solver/mod.rs:104-194, use_tstop=false):
+// for each point: while |t| < |t_point| step(); y = interpolate(t_point).  Returns 0 or -OdeErr / root stop = 1.
+int orc_solve_to_points(void* hv, const double* t_points, int npoints, double* y_out) {
+  Handle* h = (Handle*)hv;
+  size_t len = (size_t)h->problem.n() * h->problem.nb();
+  for (int k = 0; k < npoints; ++k) {
+    while (std::fabs(h->solver->t()) < std::fabs(t_points[k])) {
+      StopReason r;
+      OdeErr e = h->solver->step(r);
+      if (e != OdeErr::Ok) return -(int)e;
+      if (r == StopReason::RootFound) {
+        V out(h->problem.n(), h->problem.nb());
+        h->solver->interpolate_inplace(h->solver->root_time, out);
+        std::memcpy(y_out + k * len, out.d.data(), len * sizeof(double));
+        return 1;
+      }
+    }
+    V out(h->problem.n(), h->problem.nb());
+    OdeErr e = h->solver->interpolate_inplace(t_points[k], out);
+    if (e != OdeErr::Ok) return -(int)e;
+    std::memcpy(y_out + k * len, out.d.data(), len * sizeof(double));
+  }
+  return 0;
+}
+
+// OdeSolverMethod::solve (crates/diffsol/src/ode_solver/method.rs:227-258, :881-964): set_stop_time(final), step until TstopReached /
+// RootFound.  Writes the final state.y; returns number of output columns (accepted steps + 1) or -OdeErr.
+long orc_solve(void* hv, double t_final, double* y_final) {
+  Handle* h = (Handle*)hv;
+  OdeErr e = h->solver->set_stop_time(t_final);
+  if (e != OdeErr::Ok) return -(long)e;
+  long ncols = 1;
+  while (true) {
+    StopReason r;
+    e = h->solver->step(r);
+    if (e != OdeErr::Ok) return -(long)e;
+    ncols++;
+    if (r != StopReason::InternalTimestep) break;
+  }
+  if (y_final) std::memcpy(y_final, h->solver->y().d.data(), h->solver->y().d.size() * sizeof(double));
+  return ncols;
+}
+
+// CPU baseline: the reference's CPU usage pattern — one independent IVP per solve (nbatch = 1, own adaptive step sequence) —
+// over an ensemble of `nsys` parameter sets, statically partitioned over `nthreads` std::threads.
+// p: [nsys][np]; y_out: [nsys][n] final state.y (may be null); counters_out[0..3) = total steps, total newton iterations, total LU setups.
+// Returns wall seconds (negative on error).
+double orc_solve_ensemble_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol,
+                                      double t0, double h0, int method, double t_final, int nthreads, double* y_out, long* counters_out) {
+  std::atomic<long> steps{0}, iters{0}, setups{0};
+  std::atomic<int> failed{0};
+  auto t_start = std::chrono::steady_clock::now();
+  auto work = [&](int tid) {
+    long ls = 0, li = 0, lu = 0;
+    for (int s = tid; s < nsys; s += nthreads) {
+      try {
+        auto h = make_handle(model_id, model_size, 1, p + (size_t)s * np, np, rtol, atol, natol, t0, h0, method);
+        if (h->init_error != 0) { failed++; continue; }
+        int n = h->problem.n();
+        long rc = orc_solve(h.get(), t_final, y_out ? y_out + (size_t)s * n : nullptr);
+        if (rc < 0) { failed++; continue; }
+        const Stats& st = h->solver->stats();
+        ls += st.number_of_steps; li += st.number_of_nonlinear_solver_iterations; lu += st.number_of_linear_solver_setups;
+      } catch (...) { failed++; }
+    }
+    steps += ls; iters += li; setups += lu;
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
+  for (auto& t : th) t.join();
+  double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (counters_out) { counters_out[0] = steps; counters_out[1] = iters; counters_out[2] = setups; counters_out[3] = failed; }
+  return secs;
+}
+
+// --- small KAT entry points for the LA / NL restatement ---
+void orc_compute_r(int order, double factor, double* out) {
+  M r = Bdf::compute_r(order, factor);
+  std::memcpy(out, r.d.data(), r.d.size() * sizeof(double));
+}
+// LU factor+solve of nbatch n x n systems (batch-major, column-major per system); returns 0 / 1 if singular
+int orc_lu_solve(int n, int nbatch, const double* a, double* b_inout, double* lu_out, int* piv_out) {
+  M m(n, n, nbatch);
+  std::memcpy(m.d.data(), a, m.d.size() * sizeof(double));
+  DenseLU lu; lu.factor(m);
+  V v(n, nbatch);
+  std::memcpy(v.d.data(), b_inout, v.d.size() * sizeof(double));
+  bool ok = lu.solve(v);
+  std::memcpy(b_inout, v.d.data(), v.d.size() * sizeof(double));
+  if (lu_out) std::memcpy(lu_out, lu.lu.data(), lu.lu.size() * sizeof(double));
+  if (piv_out) std::memcpy(piv_out, lu.piv.data(), lu.piv.size() * sizeof(int));
+  return ok ? 0 : 1;
+}
+double orc_squared_norm(int n, int nbatch, const double* x, const double* y, const double* atol, double rtol) {
+  V xv(n, nbatch), yv(n, nbatch), av(n, 1);
+  std::memcpy(xv.d.data(), x, xv.d.size() * sizeof(double));
+  std::memcpy(yv.d.data(), y, yv.d.size() * sizeof(double));
+  std::memcpy(av.d.data(), atol, av.d.size() * sizeof(double));
+  return squared_norm(xv, yv, av, rtol);
+}
+// Convergence state machine driven by a sequence of norms; returns status codes per norm (0 converged, 1 diverged, 2 continue)
+void orc_convergence_trace(double rtol, double tol, int max_iter, const double* norms, int nnorms, int* status_out, double* eta_out) {
+  V atol(1, 1, 1.0);
+  Convergence c(rtol, &atol, tol);
+  c.max_iter = max_iter;
+  c.reset();
+  for (int i = 0; i < nnorms; ++i) {
+    ConvergenceStatus s = c.check_new_iteration(norms[i]);
+    status_out[i] = s == ConvergenceStatus::Converged ? 0 : (s == ConvergenceStatus::Diverged ? 1 : 2);
+    eta_out[i] = c.eta;
+  }
+}
+// model evaluation KATs: rhs and jac_mul for one system
+void orc_model_rhs(int model_id, int model_size, const double* x, const double* p, double t, double* y) {
+  auto m = make_model(model_id, model_size);
+  m->rhs(x, p, t, y);
+}
+void orc_model_jac_mul(int model_id, int model_size, const double* x, const double* p, double t, const double* v, double* y) {
+  auto m = make_model(model_id, model_size);
+  m->jac_mul(x, p, t, v, y);
+}
+// BdfCallable / SdirkCallable KATs (op/bdf.rs:318-361, op/sdirk.rs:316-389) live in tests via the solver-level API.
+
+}  // extern "C"
