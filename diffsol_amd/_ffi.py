@@ -1,0 +1,172 @@
+"""ctypes declarations for the two C ABIs.  The declared symbol lists are the single source the tests check against
+include/*.h (every symbol the headers declare must be exported by the built libraries)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_DIR = os.path.join(_HERE, "lib")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+i64 = C.c_int64
+dbl = C.c_double
+vp = C.c_void_p
+cint = C.c_int
+
+
+class DiffsolHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+def lib_paths():
+    return os.path.join(_LIB_DIR, "libdiffsol_hip.so"), os.path.join(_LIB_DIR, "libdiffsol_hip_host.so")
+
+
+# name -> (restype, argtypes); mirrors include/diffsol_hip.h
+DEVICE_ABI = {
+    "dsh_last_error": (C.c_char_p, []),
+    "dsh_version": (cint, []),
+    "dsh_ctx_create": (cint, [cint, vp, C.POINTER(vp)]),
+    "dsh_ctx_destroy": (None, [vp]),
+    "dsh_ctx_sync": (cint, [vp]),
+    "dsh_ctx_stream": (vp, [vp]),
+    "dsh_ctx_device": (cint, [vp]),
+    "dsh_ctx_set_block": (cint, [vp, cint]),
+    "dsh_malloc": (cint, [vp, i64, cint, C.POINTER(vp)]),
+    "dsh_free": (cint, [vp, vp]),
+    "dsh_memset_zero": (cint, [vp, vp, i64]),
+    "dsh_h2d": (cint, [vp, vp, vp, i64]),
+    "dsh_d2h": (cint, [vp, vp, vp, i64]),
+    "dsh_d2d": (cint, [vp, vp, vp, i64]),
+    "dsh_vec_upload": (cint, [vp, i64, i64, c_dp, vp]),
+    "dsh_vec_download": (cint, [vp, i64, i64, vp, c_dp]),
+    "dsh_vec_get_index": (cint, [vp, i64, vp, i64, i64, c_dp]),
+    "dsh_vec_set_index": (cint, [vp, i64, vp, i64, i64, dbl]),
+    "dsh_vec_set_index_all": (cint, [vp, i64, vp, i64, dbl]),
+    "dsh_vec_add": (cint, [vp, i64, i64, vp, i64, vp, i64, vp]),
+    "dsh_vec_sub": (cint, [vp, i64, i64, vp, i64, vp, i64, vp]),
+    "dsh_vec_add_assign": (cint, [vp, i64, i64, vp, vp, i64]),
+    "dsh_vec_sub_assign": (cint, [vp, i64, i64, vp, vp, i64]),
+    "dsh_vec_mul_assign": (cint, [vp, i64, i64, vp, vp, i64]),
+    "dsh_vec_div_assign": (cint, [vp, i64, i64, vp, vp, i64]),
+    "dsh_vec_mul_assign_scalar": (cint, [vp, i64, i64, vp, dbl]),
+    "dsh_vec_mul_scalar": (cint, [vp, i64, i64, vp, dbl, vp]),
+    "dsh_vec_axpy": (cint, [vp, i64, i64, dbl, vp, i64, dbl, vp]),
+    "dsh_vec_batched_axpy": (cint, [vp, i64, i64, c_dp, vp, i64, dbl, vp]),
+    "dsh_vec_copy": (cint, [vp, i64, i64, vp, i64, vp]),
+    "dsh_vec_fill": (cint, [vp, i64, i64, vp, dbl]),
+    "dsh_vec_gather": (cint, [vp, i64, i64, vp, vp, i64, vp]),
+    "dsh_vec_scatter": (cint, [vp, i64, i64, vp, vp, i64, vp]),
+    "dsh_vec_copy_from_indices": (cint, [vp, i64, i64, vp, vp, i64, vp]),
+    "dsh_vec_assign_at_indices": (cint, [vp, i64, i64, vp, i64, dbl, vp]),
+    "dsh_vec_norm": (cint, [vp, i64, i64, vp, cint, c_dp]),
+    "dsh_vec_squared_norm": (cint, [vp, i64, i64, vp, vp, i64, vp, i64, dbl, c_dp, vp]),
+    "dsh_vec_root_finding": (cint, [vp, i64, i64, vp, vp, c_ip, c_dp, c_ip]),
+    "dsh_mat_from_diagonal": (cint, [vp, i64, i64, vp, i64, vp]),
+    "dsh_mat_get_diagonal": (cint, [vp, i64, i64, vp, vp]),
+    "dsh_mat_set_column": (cint, [vp, i64, i64, i64, vp, i64, vp, i64]),
+    "dsh_mat_scale_add_assign": (cint, [vp, i64, i64, vp, vp, i64, dbl, vp, i64]),
+    "dsh_mat_set_data_with_indices": (cint, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
+    "dsh_mat_column_axpy": (cint, [vp, i64, i64, vp, dbl, i64, i64]),
+    "dsh_mat_gemv": (cint, [vp, i64, i64, i64, dbl, vp, i64, vp, i64, dbl, vp]),
+    "dsh_mat_gemm": (cint, [vp, i64, i64, i64, i64, dbl, vp, i64, vp, i64, dbl, vp]),
+    "dsh_lu_create": (cint, [vp, i64, i64, C.POINTER(vp)]),
+    "dsh_lu_destroy": (None, [vp]),
+    "dsh_lu_factor": (cint, [vp, vp]),
+    "dsh_lu_solve": (cint, [vp, vp]),
+    "dsh_lu_info": (cint, [vp, c_i64p]),
+    "dsh_lu_factors": (vp, [vp]),
+    "dsh_lu_pivots": (vp, [vp]),
+    "dsh_model_info": (cint, [cint, i64, c_i64p, c_i64p, c_ip, c_i64p]),
+    "dsh_model_rhs": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_jac_mul": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp, vp]),
+    "dsh_model_jacobian": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_mass_gemv": (cint, [vp, cint, i64, i64, dbl, vp, vp, dbl, vp]),
+    "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
+    "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
+    "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_sdirk_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_jac_factor": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, cint, vp, vp, vp]),
+    "dsh_model_has_fused": (cint, [cint, i64]),
+    "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
+    "dsh_bdf_accept_step": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, cint, c_dp]),
+}
+
+
+class DshsOptions(C.Structure):
+    _fields_ = [
+        ("max_nonlinear_solver_iterations", cint), ("max_error_test_failures", cint), ("max_nonlinear_solver_failures", cint),
+        ("nonlinear_solver_tolerance", dbl), ("min_timestep", dbl), ("update_jacobian_after_steps", cint),
+        ("update_rhs_jacobian_after_steps", cint), ("threshold_to_update_jacobian", dbl), ("threshold_to_update_rhs_jacobian", dbl),
+        ("ic_use_linesearch", cint), ("use_fused_kernels", cint), ("block_threads", cint),
+    ]
+
+
+# mirrors include/diffsol_hip_solver.h
+HOST_ABI = {
+    "dshs_last_error": (C.c_char_p, []),
+    "dshs_default_options": (None, [C.POINTER(DshsOptions)]),
+    "dshs_create": (cint, [cint, vp, cint, i64, i64, c_dp, i64, dbl, c_dp, i64, dbl, dbl, cint, C.POINTER(DshsOptions), C.POINTER(vp)]),
+    "dshs_destroy": (None, [vp]),
+    "dshs_nstates": (i64, [vp]),
+    "dshs_nbatch": (i64, [vp]),
+    "dshs_is_fused": (cint, [vp]),
+    "dshs_step": (cint, [vp, c_ip]),
+    "dshs_set_stop_time": (cint, [vp, dbl]),
+    "dshs_interpolate": (cint, [vp, dbl, c_dp]),
+    "dshs_get_state": (cint, [vp, c_dp, c_dp, c_ip, c_dp, c_dp]),
+    "dshs_root_info": (cint, [vp, c_dp, c_ip]),
+    "dshs_bdf_get_diff": (cint, [vp, c_dp]),
+    "dshs_stats": (cint, [vp, c_i64p]),
+    "dshs_solve_to_points": (cint, [vp, c_dp, i64, c_dp]),
+    "dshs_solve": (cint, [vp, dbl, cint, c_dp, c_i64p, c_ip]),
+    "dshs_trajectory": (cint, [vp, c_dp, c_dp]),
+    "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
+}
+
+_dev = None
+_host = None
+
+
+def _bind(lib, abi):
+    for name, (res, args) in abi.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_device_lib():
+    """Load libdiffsol_hip.so (does not touch a GPU)."""
+    global _dev
+    if _dev is None:
+        path = lib_paths()[0]
+        if not os.path.exists(path):
+            raise DiffsolHipError(-1, f"{path} not found: build it with `python -m diffsol_amd.build` (there is no CPU fallback)")
+        _dev = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), DEVICE_ABI)
+    return _dev
+
+
+def load_host_lib():
+    """Load libdiffsol_hip_host.so (does not touch a GPU)."""
+    global _host
+    if _host is None:
+        load_device_lib()
+        path = lib_paths()[1]
+        if not os.path.exists(path):
+            raise DiffsolHipError(-1, f"{path} not found: build it with `python -m diffsol_amd.build` (there is no CPU fallback)")
+        _host = _bind(C.CDLL(path), HOST_ABI)
+    return _host
+
+
+def check(rc, lib=None, host=False):
+    if rc < 0:
+        L = load_host_lib() if host else load_device_lib()
+        msg = (L.dshs_last_error() if host else L.dsh_last_error()) or b""
+        raise DiffsolHipError(rc, msg.decode(errors="replace"))
+    return rc

@@ -1,0 +1,188 @@
+// Context, device memory and layout conversion for libdiffsol_hip.so (gfx950).
+// Replaces CudaContext (diffsol-la/src/context/cuda.rs:41-144) and the cudarc driver calls listed in SURVEY §2a.
+#include "dsh_internal.hpp"
+
+#include <mutex>
+
+namespace dsh {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+int take_slots(dsh_ctx* ctx, unsigned long long** out) {
+  if (ctx->ring_cursor >= kRingEntries) {
+    DSH_HIP_CHECK(hipMemsetAsync(ctx->ring, 0, sizeof(unsigned long long) * kRingEntries * kSlotWords, ctx->stream));
+    ctx->ring_cursor = 0;
+  }
+  *out = ctx->ring + (size_t)ctx->ring_cursor * kSlotWords;
+  ctx->ring_cursor++;
+  return DSH_OK;
+}
+
+int fetch_slots(dsh_ctx* ctx, const unsigned long long* slots) {
+  DSH_HIP_CHECK(hipMemcpyAsync(ctx->mailbox, slots, sizeof(unsigned long long) * kSlotWords, hipMemcpyDeviceToHost, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+
+int ensure_i32_scratch(dsh_ctx* ctx, int64_t len) {
+  if (ctx->i32_scratch_len >= len) return DSH_OK;
+  if (ctx->i32_scratch) { DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream)); DSH_HIP_CHECK(hipFree(ctx->i32_scratch)); }
+  DSH_HIP_CHECK(hipMalloc((void**)&ctx->i32_scratch, sizeof(int32_t) * len));
+  ctx->i32_scratch_len = len;
+  return DSH_OK;
+}
+int ensure_f64_scratch(dsh_ctx* ctx, int64_t len) {
+  if (ctx->f64_scratch_len >= len) return DSH_OK;
+  if (ctx->f64_scratch) { DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream)); DSH_HIP_CHECK(hipFree(ctx->f64_scratch)); }
+  DSH_HIP_CHECK(hipMalloc((void**)&ctx->f64_scratch, sizeof(double) * len));
+  ctx->f64_scratch_len = len;
+  return DSH_OK;
+}
+}  // namespace dsh
+
+using namespace dsh;
+
+// [b][i] (host order) <-> [i][b] (device order) through a padded LDS tile so both sides stay coalesced
+__global__ void k_transpose(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int64_t cols) {
+  // src is rows x cols row-major; dst is cols x rows row-major
+  __shared__ double tile[32][33];
+  int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    int64_t r = r0 + k, c = c0 + tx;
+    if (r < rows && c < cols) tile[k][tx] = src[r * cols + c];
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    int64_t c = c0 + k, r = r0 + tx;
+    if (r < rows && c < cols) dst[c * rows + r] = tile[tx][k];
+  }
+}
+
+static int launch_transpose(dsh_ctx* ctx, const double* src, double* dst, int64_t rows, int64_t cols) {
+  if (rows == 0 || cols == 0) return DSH_OK;
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, src, dst, rows, cols);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+
+extern "C" {
+
+const char* dsh_last_error(void) { return g_err.c_str(); }
+int dsh_version(void) { return 1; }
+
+int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
+  DSH_REQUIRE(out != nullptr, "out is null");
+  int count = 0;
+  DSH_HIP_CHECK(hipGetDeviceCount(&count));
+  DSH_REQUIRE(device >= 0 && device < count, "no such HIP device (a gfx950 GPU is required; there is no CPU fallback)");
+  DSH_HIP_CHECK(hipSetDevice(device));
+  dsh_ctx* ctx = new dsh_ctx();
+  ctx->device = device;
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
+  else { DSH_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->owns_stream = true; }
+  hipDeviceProp_t prop;
+  DSH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount;
+  DSH_HIP_CHECK(hipMalloc((void**)&ctx->ring, sizeof(unsigned long long) * kRingEntries * kSlotWords));
+  DSH_HIP_CHECK(hipMemsetAsync(ctx->ring, 0, sizeof(unsigned long long) * kRingEntries * kSlotWords, ctx->stream));
+  DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->mailbox, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+  *out = ctx;
+  return DSH_OK;
+}
+
+void dsh_ctx_destroy(dsh_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ring) (void)hipFree(ctx->ring);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->i32_scratch) (void)hipFree(ctx->i32_scratch);
+  if (ctx->f64_scratch) (void)hipFree(ctx->f64_scratch);
+  if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int dsh_ctx_sync(dsh_ctx* ctx) {
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+void* dsh_ctx_stream(dsh_ctx* ctx) { return (void*)ctx->stream; }
+int dsh_ctx_device(dsh_ctx* ctx) { return ctx->device; }
+int dsh_ctx_set_block(dsh_ctx* ctx, int threads) {
+  DSH_REQUIRE(threads >= 64 && threads <= 1024 && (threads & (threads - 1)) == 0, "block must be a power of two in [64,1024]");
+  ctx->block = threads;
+  return DSH_OK;
+}
+
+int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out) {
+  DSH_REQUIRE(nbytes >= 0 && out, "bad arguments");
+  DSH_HIP_CHECK(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  DSH_HIP_CHECK(hipMalloc(&p, nbytes > 0 ? (size_t)nbytes : 8));
+  if (zero && nbytes > 0) DSH_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)nbytes, ctx->stream));
+  *out = p;
+  return DSH_OK;
+}
+int dsh_free(dsh_ctx* ctx, void* p) {
+  if (!p) return DSH_OK;
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  DSH_HIP_CHECK(hipFree(p));
+  return DSH_OK;
+}
+int dsh_memset_zero(dsh_ctx* ctx, void* p, int64_t nbytes) {
+  if (nbytes > 0) DSH_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)nbytes, ctx->stream));
+  return DSH_OK;
+}
+int dsh_h2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  if (nbytes <= 0) return DSH_OK;
+  DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+int dsh_d2h(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  if (nbytes <= 0) return DSH_OK;
+  DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+int dsh_d2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  if (nbytes <= 0) return DSH_OK;
+  DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return DSH_OK;
+}
+
+int dsh_vec_upload(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* host, double* dev) {
+  DSH_REQUIRE(n >= 0 && nbatch >= 1, "bad shape");
+  if (n == 0) return DSH_OK;
+  if (nbatch == 1 || n == 1) return dsh_h2d(ctx, dev, host, sizeof(double) * n * nbatch);
+  DSH_REQUIRE(ensure_f64_scratch(ctx, n * nbatch) == DSH_OK, "scratch allocation failed");
+  DSH_HIP_CHECK(hipMemcpyAsync(ctx->f64_scratch, host, sizeof(double) * n * nbatch, hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_transpose(ctx, ctx->f64_scratch, dev, nbatch, n);  // [b][i] -> [i][b]
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+int dsh_vec_download(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* dev, double* host) {
+  DSH_REQUIRE(n >= 0 && nbatch >= 1, "bad shape");
+  if (n == 0) return DSH_OK;
+  if (nbatch == 1 || n == 1) return dsh_d2h(ctx, host, dev, sizeof(double) * n * nbatch);
+  DSH_REQUIRE(ensure_f64_scratch(ctx, n * nbatch) == DSH_OK, "scratch allocation failed");
+  int rc = launch_transpose(ctx, dev, ctx->f64_scratch, n, nbatch);  // [i][b] -> [b][i]
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipMemcpyAsync(host, ctx->f64_scratch, sizeof(double) * n * nbatch, hipMemcpyDeviceToHost, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return DSH_OK;
+}
+
+int dsh_vec_get_index(dsh_ctx* ctx, int64_t nbatch, const double* v, int64_t i, int64_t b, double* out) {
+  DSH_REQUIRE(b >= 0 && b < nbatch && i >= 0, "index out of range");
+  return dsh_d2h(ctx, out, v + i * nbatch + b, sizeof(double));
+}
+int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_t b, double value) {
+  DSH_REQUIRE(b >= 0 && b < nbatch && i >= 0, "index out of range");
+  return dsh_h2d(ctx, v + i * nbatch + b, &value, sizeof(double));
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// Fused hot-path kernels of libdiffsol_hip.so (gfx950).
+//
+// The reference issues, per Newton iteration on its CUDA backend: the user RHS closure (one kernel + one D2H per batch member), copy,
+// add_assign, axpy, nbatch x cusolverDnDgetrs (host loop), sub_assign, squared-norm kernel + alloc + blocking D2H + host reduction
+// (diffsol-nl/src/line_search.rs:48-69, diffsol/src/op/bdf.rs:240-256, diffsol-la/src/linear_solver/cuda/lu.rs:127-145).
+// Here one launch does all of it for the whole ensemble: one lane per system, state / parameters / LU factors streamed once from HBM with
+// fully coalesced 8-byte-per-lane accesses (batch-fastest layout), everything else in registers, per-wave shuffle reduction of the
+// weighted norms and one conditional atomicMax per workgroup.  Per n=3 system and iteration: 228 algorithmic bytes, ~60 flop => HBM-bound.
+// Arithmetic order is exactly that of the unfused ops (and of the CPU oracle); built with -ffp-contract=off.
+#include "dsh_internal.hpp"
+#include "dsh_lu_dev.hpp"
+#include "dsh_models.hpp"
+
+using namespace dsh;
+
+namespace {
+
+// ---- weighted mean-square of v against (|w| rtol + atol), sequential like Vector::squared_norm (nalgebra_serial.rs:395-408)
+template <int N>
+__device__ __forceinline__ double wms(const double (&v)[N], const double (&w)[N], const double (&atol)[N], double rtol) {
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double term = v[i] / (fabs(w[i]) * rtol + atol[i]);
+    acc += term * term;
+  }
+  return acc / (double)N;
+}
+
+template <int N, bool BA>
+__device__ __forceinline__ void load_atol(const double* __restrict__ atol, int64_t nb, int64_t b, double (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = BA ? atol[i] : atol[(int64_t)i * nb + b];
+}
+
+// One Newton iteration of the BDF residual.  IS_SDIRK selects the SDIRK stage residual instead.
+//   BDF  : delta = M(y + psi_neg_y0) - c f(y, t)             (op/bdf.rs:240-256)
+//   SDIRK: delta = M k - h f(phi + c k, t)                   (op/sdirk.rs:229-244)
+template <class Mdl, bool IS_SDIRK, bool BA, bool WITH_ERR>
+__global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* __restrict__ y, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
+                              const double* __restrict__ p, const double* __restrict__ factors, const int32_t* __restrict__ piv,
+                              const double* __restrict__ error_y, const double* __restrict__ y_old, const double* __restrict__ atol, double rtol,
+                              unsigned long long* slots) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long nrm_bits = 0ull, err_bits = 0ull, bad = 0ull;
+  if (b < nb) {
+    double x[N], a[N], pp[NP], A[N * N], ey[N], at[N];
+    int P[N];
+    load_vec<N>(y, nb, b, x);
+    load_vec<N>(aux, nb, b, a);
+    load_vec<NP>(p, nb, b, pp);
+    load_mat<N>(factors, nb, b, A);
+    load_piv<N>(piv, nb, b, P);
+    load_vec<N>(error_y, nb, b, ey);
+    load_atol<N, BA>(atol, nb, b, at);
+    double f[N], tmp[N], delta[N];
+    if constexpr (!IS_SDIRK) {
+      Mdl::rhs(t, x, pp, f);
+#pragma unroll
+      for (int i = 0; i < N; ++i) tmp[i] = x[i] + a[i];
+      if constexpr (Mdl::HAS_MASS) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) delta[i] = f[i];
+        Mdl::mass_gemv(t, tmp, pp, -c, delta);
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmp[i] + (-c) * f[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) tmp[i] = c * x[i] + 1.0 * a[i];
+      Mdl::rhs(t, tmp, pp, f);
+      double beta = -h;
+      if constexpr (Mdl::HAS_MASS) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) delta[i] = f[i];
+        Mdl::mass_gemv(t, x, pp, beta, delta);
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) delta[i] = 1.0 * x[i] + beta * f[i];
+      }
+    }
+    bool ok = lu_solve_reg<N>(A, P, delta);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+    store_vec<N>(y, nb, b, x);
+    nrm_bits = d2u(wms<N>(delta, ey, at, rtol));
+    if constexpr (WITH_ERR) {
+      double yo[N], d[N];
+      load_vec<N>(y_old, nb, b, yo);
+#pragma unroll
+      for (int i = 0; i < N; ++i) d[i] = x[i] - ey[i];
+      err_bits = d2u(wms<N>(d, yo, at, rtol));
+    }
+    bad = ok ? 0ull : 1ull;
+  }
+  block_publish(nrm_bits, err_bits, bad, slots, WITH_ERR, true);
+}
+
+// Jacobian refresh + assembly of M - cJ + LU factorisation, one lane per system, A never leaves registers.
+template <class Mdl>
+__global__ void k_jac_factor(int64_t nb, double t, double c, const double* __restrict__ x, const double* __restrict__ p, int recompute,
+                             double* __restrict__ rhs_jac, double* __restrict__ mass_jac, double* __restrict__ factors, int32_t* __restrict__ piv,
+                             unsigned long long* singular_count) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long sing = 0ull;
+  if (b < nb) {
+    double J[N * N], Mm[N * N], A[N * N];
+    int P[N];
+    if (recompute) {
+      double xr[N], pp[NP];
+      load_vec<N>(x, nb, b, xr);
+      load_vec<NP>(p, nb, b, pp);
+      assemble_jacobian<Mdl>(t, xr, pp, J);
+      store_mat<N>(rhs_jac, nb, b, J);
+      if constexpr (Mdl::HAS_MASS) {
+        assemble_mass<Mdl>(t, pp, Mm);
+        store_mat<N>(mass_jac, nb, b, Mm);
+      }
+    } else {
+      load_mat<N>(rhs_jac, nb, b, J);
+      if constexpr (Mdl::HAS_MASS) load_mat<N>(mass_jac, nb, b, Mm);
+    }
+    if constexpr (!Mdl::HAS_MASS) {
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) Mm[e] = (e / N == e % N) ? 1.0 : 0.0;  // Matrix::from_diagonal(ones), op/bdf.rs:138-141
+    }
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-c) + Mm[e];  // scale_add_and_assign(mass, -c, rhs_jac)
+    bool s = false;
+    lu_factor_reg<N>(A, P, s);
+    store_mat<N>(factors, nb, b, A);
+    store_piv<N>(piv, nb, b, P);
+    sing = s ? 1ull : 0ull;
+  }
+  sing = wave_sum_u64(sing);
+  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+}
+
+struct BdfCoeffs {
+  double ru[36];    // (order+1)^2 column-major
+  double gamma[6];
+  double alpha;
+  int order;
+  int rescale;
+};
+
+// flat over n*nb elements: optional D <- D*RU (into diff_tmp), predictor and psi
+__global__ void k_bdf_prepare(int64_t total, const double* __restrict__ diff, double* __restrict__ diff_tmp, BdfCoeffs cf, double* __restrict__ y_predict,
+                              double* __restrict__ psi_neg_y0) {
+  const int order = cf.order, ncol = cf.order + 1;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    double d[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d[j] = j < ncol ? diff[(int64_t)j * total + idx] : 0.0;
+    if (cf.rescale) {
+      double nd[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < ncol) {
+          double acc = d[0] * cf.ru[j * ncol + 0];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) if (k < ncol) acc = d[k] * cf.ru[j * ncol + k] + acc;
+          nd[j] = acc;
+          diff_tmp[(int64_t)j * total + idx] = acc;
+        } else nd[j] = 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[j] = nd[j];
+    }
+    if (y_predict == nullptr) continue;  // rescale only
+    double yp = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) if (j < ncol) yp = yp + d[j];
+    double psi = cf.gamma[1] * d[1];
+#pragma unroll
+    for (int j = 2; j < 6; ++j) if (j <= order) psi = cf.gamma[j] * d[j] + 1.0 * psi;
+    psi = psi * cf.alpha;
+    psi = psi - yp;
+    y_predict[idx] = yp;
+    psi_neg_y0[idx] = psi;
+  }
+}
+
+// one lane per system: difference-array update, state update and the two order-selection norms
+template <bool BA>
+__global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, double* __restrict__ diff, const double* __restrict__ y_predict,
+                             const double* __restrict__ y_new, double* __restrict__ y, double* __restrict__ dy, const double* __restrict__ atol, double rtol,
+                             unsigned long long* slots) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long m_bits = 0ull, p_bits = 0ull;
+  if (b < nb) {
+    const int64_t cs = n * nb;  // column stride
+    double acc_m = 0.0, acc_p = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t e = i * nb + b;
+      double yp = y_predict[e];
+      double d = y_new[e] - yp;
+      // D[:,k+2] = d - D[:,k+1]; D[:,k+1] = d; D[:,j] += D[:,j+1] for j = k..0   (all register indices compile-time: no scratch)
+      double col[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) col[j] = j <= order + 1 ? diff[(int64_t)j * cs + e] : 0.0;
+      double dk1 = 0.0;
+#pragma unroll
+      for (int j = 2; j < 7; ++j) if (j == order + 1) dk1 = col[j];
+      double dk2 = d - dk1;
+      diff[(int64_t)(order + 2) * cs + e] = dk2;
+      diff[(int64_t)(order + 1) * cs + e] = d;
+      double upper = d;  // value of column j+1 while walking down
+      double new_k = 0.0, new_1 = 0.0;
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        if (j <= order) {
+          double v = col[j] + 1.0 * upper;
+          diff[(int64_t)j * cs + e] = v;
+          if (j == order) new_k = v;
+          if (j == 1) new_1 = v;
+          upper = v;
+        }
+      }
+      y[e] = yp;
+      dy[e] = new_1 * inv_h;
+      double ai = BA ? atol[i] : atol[e];
+      double w = fabs(yp) * rtol + ai;
+      double tm = new_k / w;
+      double tp = dk2 / w;
+      acc_m += tm * tm;
+      acc_p += tp * tp;
+    }
+    m_bits = d2u(acc_m / (double)n);
+    p_bits = d2u(acc_p / (double)n);
+  }
+  block_publish(m_bits, p_bits, 0ull, slots, true, false);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsh_model_has_fused(int model, int64_t size) {
+  return dispatch_static_model(model, size, [](auto) {}) ? 1 : 0;
+}
+
+static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, int64_t nb, double t, double c, double h, double* y, const double* aux,
+                         const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol,
+                         double* out) {
+  DSH_CHECK_NB(anb, nb);
+  DSH_REQUIRE(out != nullptr && lu != nullptr, "null argument");
+  if (!lu->factored) { set_error("newton iteration: LU not initialised"); return DSH_E_NOT_SETUP; }
+  unsigned long long* slots;
+  int rc = take_slots(ctx, &slots);
+  if (rc != DSH_OK) return rc;
+  const bool ba = anb == 1 && nb != 1;
+  const bool with_err = y_old != nullptr;
+  bool ok = dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+    dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+#define DSH_NEWTON_LAUNCH(SD, BA, WE)                                                                                                          \
+  hipLaunchKernelGGL((k_newton_iter<Mdl, SD, BA, WE>), g, blk, 0, ctx->stream, nb, t, c, h, y, aux, p, (const double*)lu->factors,               \
+                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, slots)
+    if (is_sdirk) { if (ba) DSH_NEWTON_LAUNCH(true, true, false); else DSH_NEWTON_LAUNCH(true, false, false); }
+    else if (with_err) { if (ba) DSH_NEWTON_LAUNCH(false, true, true); else DSH_NEWTON_LAUNCH(false, false, true); }
+    else { if (ba) DSH_NEWTON_LAUNCH(false, true, false); else DSH_NEWTON_LAUNCH(false, false, false); }
+#undef DSH_NEWTON_LAUNCH
+  });
+  if (!ok) { set_error("newton iteration: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
+  DSH_HIP_CHECK(hipGetLastError());
+  rc = fetch_slots(ctx, slots);
+  if (rc != DSH_OK) return rc;
+  out[0] = bits_to_double(ctx->mailbox[0]);
+  out[1] = bits_to_double(ctx->mailbox[1]);
+  out[2] = (double)ctx->mailbox[2];
+  return DSH_OK;
+}
+
+int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, double* y, const double* psi_neg_y0, const double* p,
+                        const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol, double* out) {
+  return newton_common(ctx, false, model, size, nb, t, c, 0.0, y, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, out);
+}
+int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, double* k, const double* phi, const double* p,
+                          const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol, double* out) {
+  return newton_common(ctx, true, model, size, nb, t, c, h, k, phi, p, lu, error_y, nullptr, atol, anb, rtol, out);
+}
+
+int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* x, const double* p, int recompute, double* rhs_jac,
+                   double* mass_jac, dsh_lu* lu) {
+  DSH_REQUIRE(lu != nullptr && rhs_jac != nullptr, "null argument");
+  DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
+  bool ok = dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+    hipLaunchKernelGGL((k_jac_factor<Mdl>), grid_for(nb, ctx->block), dim3(ctx->block), 0, ctx->stream, nb, t, c, x, p, recompute, rhs_jac, mass_jac,
+                       lu->factors, lu->pivots, lu->singular);
+  });
+  if (!ok) { set_error("dsh_jac_factor: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
+  DSH_HIP_CHECK(hipGetLastError());
+  lu->factored = true;
+  return DSH_OK;
+}
+
+int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, const double* diff, double* diff_tmp, const double* ru_host,
+                         const double* gamma_host, double alpha, double* y_predict, double* psi_neg_y0) {
+  DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
+  BdfCoeffs cf;
+  for (int k = 0; k < 36; ++k) cf.ru[k] = 0.0;
+  for (int k = 0; k < 6; ++k) cf.gamma[k] = k <= order ? gamma_host[k] : 0.0;
+  cf.alpha = alpha; cf.order = order; cf.rescale = ru_host != nullptr;
+  if (ru_host) for (int k = 0; k < (order + 1) * (order + 1); ++k) cf.ru[k] = ru_host[k];
+  int64_t total = n * nb;
+  if (total == 0) return DSH_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_bdf_prepare, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, total, diff, diff_tmp, cf, y_predict, psi_neg_y0);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+
+int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, const double* y_predict, const double* y_new, double* y,
+                        double* dy, const double* atol, int64_t anb, double rtol, int want_norms, double* out) {
+  DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
+  DSH_CHECK_NB(anb, nb);
+  if (n * nb == 0) return DSH_OK;
+  unsigned long long* slots;
+  int rc = take_slots(ctx, &slots);
+  if (rc != DSH_OK) return rc;
+  const double inv_h = 1.0 / h;
+  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  if (anb == 1 && nb != 1) hipLaunchKernelGGL((k_bdf_accept<true>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, slots);
+  else hipLaunchKernelGGL((k_bdf_accept<false>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, slots);
+  DSH_HIP_CHECK(hipGetLastError());
+  if (want_norms) {
+    DSH_REQUIRE(out != nullptr, "out is null");
+    rc = fetch_slots(ctx, slots);
+    if (rc != DSH_OK) return rc;
+    out[0] = bits_to_double(ctx->mailbox[0]);
+    out[1] = bits_to_double(ctx->mailbox[1]);
+  }
+  return DSH_OK;
+}
+
+}  // extern "C"

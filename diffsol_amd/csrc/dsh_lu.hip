@@ -1,0 +1,153 @@
+// Batched dense LU of libdiffsol_hip.so (gfx950): replaces CudaLU (diffsol-la/src/linear_solver/cuda/lu.rs:59-191), whose
+// set_linearisation / solve_in_place loop over the batch on the HOST calling cusolverDnDgetrf / Dgetrs once per system.
+// Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
+// (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
+// in-place in HBM for larger n.
+#include "dsh_internal.hpp"
+#include "dsh_lu_dev.hpp"
+
+using namespace dsh;
+
+namespace {
+
+template <int N>
+__global__ void k_lu_factor_reg(int64_t nb, const double* __restrict__ a, double* __restrict__ factors, int32_t* __restrict__ piv,
+                                unsigned long long* singular_count) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long sing = 0ull;
+  if (b < nb) {
+    double A[N * N];
+    int P[N];
+    load_mat<N>(a, nb, b, A);
+    bool s = false;
+    lu_factor_reg<N>(A, P, s);
+    store_mat<N>(factors, nb, b, A);
+    store_piv<N>(piv, nb, b, P);
+    sing = s ? 1ull : 0ull;
+  }
+  sing = wave_sum_u64(sing);
+  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+}
+
+template <int N>
+__global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
+                               unsigned long long* slots) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long bad = 0ull;
+  if (b < nb) {
+    double A[N * N], v[N];
+    int P[N];
+    load_mat<N>(factors, nb, b, A);
+    load_piv<N>(piv, nb, b, P);
+    load_vec<N>(rhs, nb, b, v);
+    bool ok = lu_solve_reg<N>(A, P, v);
+    store_vec<N>(rhs, nb, b, v);
+    bad = ok ? 0ull : 1ull;
+  }
+  block_publish(0ull, 0ull, bad, slots, false, true);
+}
+
+__global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ factors, int32_t* __restrict__ piv, unsigned long long* singular_count) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long sing = 0ull;
+  if (b < nb) {
+    bool s = false;
+    lu_factor_global(factors, piv, n, nb, b, s);
+    sing = s ? 1ull : 0ull;
+  }
+  sing = wave_sum_u64(sing);
+  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+}
+__global__ void k_lu_solve_global(int64_t n, int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
+                                  unsigned long long* slots) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long bad = 0ull;
+  if (b < nb) bad = lu_solve_global(factors, piv, rhs, n, nb, b) ? 0ull : 1ull;
+  block_publish(0ull, 0ull, bad, slots, false, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
+  DSH_REQUIRE(n >= 0 && nbatch >= 1 && out, "bad arguments");
+  dsh_lu* lu = new dsh_lu();
+  lu->ctx = ctx; lu->n = n; lu->nbatch = nbatch;
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->singular, sizeof(unsigned long long)));
+  DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
+  *out = lu;
+  return DSH_OK;
+}
+void dsh_lu_destroy(dsh_lu* lu) {
+  if (!lu) return;
+  (void)hipStreamSynchronize(lu->ctx->stream);
+  (void)hipFree(lu->factors);
+  (void)hipFree(lu->pivots);
+  (void)hipFree(lu->singular);
+  delete lu;
+}
+double* dsh_lu_factors(dsh_lu* lu) { return lu->factors; }
+int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu->pivots; }
+
+int dsh_lu_factor(dsh_lu* lu, const double* a) {
+  dsh_ctx* ctx = lu->ctx;
+  const int64_t n = lu->n, nb = lu->nbatch;
+  DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
+  lu->factored = true;
+  if (n == 0) return DSH_OK;
+  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+#define DSH_LU_FACTOR_CASE(N) \
+  case N: hipLaunchKernelGGL((k_lu_factor_reg<N>), g, blk, 0, ctx->stream, nb, a, lu->factors, lu->pivots, lu->singular); break;
+  switch (n) {
+    DSH_LU_FACTOR_CASE(1) DSH_LU_FACTOR_CASE(2) DSH_LU_FACTOR_CASE(3) DSH_LU_FACTOR_CASE(4)
+    DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
+    default:
+      DSH_HIP_CHECK(hipMemcpyAsync(lu->factors, a, sizeof(double) * n * n * nb, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_lu_factor_global, g, blk, 0, ctx->stream, n, nb, lu->factors, lu->pivots, lu->singular);
+  }
+#undef DSH_LU_FACTOR_CASE
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+
+int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
+  dsh_ctx* ctx = lu->ctx;
+  if (!lu->factored) { set_error("dsh_lu_solve: LU not initialised"); return DSH_E_NOT_SETUP; }
+  const int64_t n = lu->n, nb = lu->nbatch;
+  if (n == 0) return DSH_OK;
+  unsigned long long* slots;
+  int rc = take_slots(ctx, &slots);
+  if (rc != DSH_OK) return rc;
+  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+#define DSH_LU_SOLVE_CASE(N) \
+  case N: hipLaunchKernelGGL((k_lu_solve_reg<N>), g, blk, 0, ctx->stream, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, slots); break;
+  switch (n) {
+    DSH_LU_SOLVE_CASE(1) DSH_LU_SOLVE_CASE(2) DSH_LU_SOLVE_CASE(3) DSH_LU_SOLVE_CASE(4)
+    DSH_LU_SOLVE_CASE(5) DSH_LU_SOLVE_CASE(6) DSH_LU_SOLVE_CASE(7) DSH_LU_SOLVE_CASE(8)
+    default:
+      hipLaunchKernelGGL(k_lu_solve_global, g, blk, 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, slots);
+  }
+#undef DSH_LU_SOLVE_CASE
+  DSH_HIP_CHECK(hipGetLastError());
+  // LinearSolver::solve_in_place returns Result<(), LaError>: the zero-pivot flag has to come back (blocking, like the reference's getrs loop)
+  rc = fetch_slots(ctx, slots);
+  if (rc != DSH_OK) return rc;
+  if (ctx->mailbox[2] != 0ull) {
+    set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->mailbox[2]) + " system(s) (LuSolveFailed)");
+    return DSH_E_SINGULAR;
+  }
+  return DSH_OK;
+}
+
+int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular) {
+  unsigned long long h = 0;
+  DSH_HIP_CHECK(hipMemcpyAsync(&h, lu->singular, sizeof(h), hipMemcpyDeviceToHost, lu->ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(lu->ctx->stream));
+  *n_singular = (int64_t)h;
+  return DSH_OK;
+}
+
+}  // extern "C"

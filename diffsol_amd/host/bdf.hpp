@@ -1,0 +1,459 @@
+// Host-side BDF integrator over the HIP backend: mirror of crates/diffsol/src/ode_solver/bdf.rs (Bdf), op/bdf.rs (BdfCallable) and
+// ode_solver/bdf_state.rs (BdfState).  Variable-order (1-5) NDF with the fixed-leading-coefficient difference array D (n x 8),
+// lock-step over the ensemble: one t / h / order for all systems, scalar decisions taken on max-over-batch norms
+// (diffsol-la/src/vector/cuda.rs:100-115).  Two execution modes, bit-identical by construction:
+//   - trait mode : every step of the algorithm is the reference's sequence of Vector/Matrix/LinearSolver calls (1 dsh_* call each);
+//   - fused mode : prepare / Newton iteration / Jacobian refresh / accept are each ONE device launch (dsh_bdf_*, dsh_jac_factor),
+//                  3-4 launches and 2-3 host syncs per accepted step instead of ~40 launches.
+//   bdf.rs:244-368 _new, :433-463 _compute_r, :465-506 _jacobian_updates, :508-577 _update_step_size, :646-692 _update_diff/_predict,
+//   :694-731 handle_tstop, :767-811 interpolation, :812-932 error control, :1277-1589 step
+#pragma once
+#include "ode.hpp"
+
+namespace diffsol_hip {
+
+// op/bdf.rs:15-300
+class BdfCallable : public NonLinearOpRef {
+ public:
+  explicit BdfCallable(const OdeEquations& eqn)
+      : eqn_(eqn), psi_neg_y0_(HipVec::zeros(eqn.nstates(), eqn.context())), tmp_(HipVec::zeros(eqn.nstates(), eqn.context())),
+        rhs_jac_(HipMat::zeros(eqn.nstates(), eqn.nstates(), eqn.context())) {
+    const int64_t n = eqn.nstates();
+    if (!eqn.has_mass()) mass_jac_ = HipMat::from_diagonal(HipVec::from_element(n, 1.0, eqn.context()));  // :138-141
+    else mass_jac_ = HipMat::zeros(n, n, eqn.context());
+  }
+  int64_t nstates() const override { return eqn_.nstates(); }
+  const HipContext& context() const override { return eqn_.context(); }
+  void set_c(double h, double alpha) { c_ = h * alpha; }
+  double c() const { return c_; }
+  void set_psi(const HipMat& diff, const std::vector<double>& gamma, const std::vector<double>& alpha, int order, HipVec& psi) const {  // :182-196
+    psi.axpy_v(gamma[1], diff.column(1), 0.0);
+    for (int i = 2; i <= order; ++i) psi.axpy_v(gamma[(size_t)i], diff.column(i), 1.0);
+    psi.mul_assign(scale(alpha[(size_t)order]));
+  }
+  void set_psi_and_y0(const HipMat& diff, const std::vector<double>& gamma, const std::vector<double>& alpha, int order, const HipVec& y0) {  // :197-210
+    set_psi(diff, gamma, alpha, order, psi_neg_y0_);
+    psi_neg_y0_.sub_assign(y0);
+  }
+  void set_jacobian_is_stale() { jacobian_is_stale_ = true; }
+  bool jacobian_is_stale() const { return jacobian_is_stale_; }
+  void clear_jacobian_is_stale() { jacobian_is_stale_ = false; }
+  // F(y) = M (y - y0 + psi) - c f(y)   :240-256
+  void call_inplace(const HipVec& x, double t, HipVec& y) override {
+    eqn_.rhs_call_inplace(x, t, y);
+    tmp_.copy_from(x);
+    tmp_.add_assign(psi_neg_y0_);
+    if (eqn_.has_mass()) eqn_.mass_gemv_inplace(tmp_, t, -c_, y);
+    else y.axpy(1.0, tmp_, -c_);
+  }
+  // M - c f'(y)   :273-300
+  void jacobian_inplace(const HipVec& x, double t, HipMat& y) override {
+    if (jacobian_is_stale_) {
+      eqn_.rhs_jacobian_inplace(x, t, rhs_jac_);
+      if (eqn_.has_mass()) eqn_.mass_matrix_inplace(t, mass_jac_);
+      y.scale_add_and_assign(mass_jac_, -c_, rhs_jac_);
+      jacobian_is_stale_ = false;
+    } else {
+      y.scale_add_and_assign(mass_jac_, -c_, rhs_jac_);
+    }
+  }
+  HipVec& psi_neg_y0() { return psi_neg_y0_; }
+  HipMat& rhs_jac() { return rhs_jac_; }
+  HipMat& mass_jac() { return mass_jac_; }
+
+ private:
+  const OdeEquations& eqn_;
+  HipVec psi_neg_y0_, tmp_;
+  double c_ = 0.0;
+  HipMat rhs_jac_, mass_jac_;
+  bool jacobian_is_stale_ = true;
+};
+
+class Bdf : public OdeSolverMethod {
+ public:
+  static constexpr int MAX_ORDER = 5;  // bdf_state.rs:44
+
+  // problem.bdf::<LS>() (problem.rs:597-655): consistent state with solver_order = 1, then Bdf::new
+  explicit Bdf(const OdeSolverProblem& problem)
+      : pr_(problem), convergence_(problem.rtol, &problem.atol, problem.ode_options.nonlinear_solver_tolerance), op_(*problem.eqn),
+        jacobian_update_(problem.ode_options) {
+    const OdeSolverOptions& o = problem.ode_options;
+    minimum_timestep_ = o.min_timestep;
+    maximum_error_test_failures_ = o.max_error_test_failures;
+    maximum_newton_fails_ = o.max_nonlinear_solver_failures;
+    maximum_timestep_growth_ = o.max_timestep_growth.value_or(2.0);
+    minimum_timestep_growth_ = o.min_timestep_growth.value_or(2.0);
+    maximum_timestep_shrink_ = o.max_timestep_shrink.value_or(0.9);
+    minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
+    fused_ = problem.use_fused_kernels && problem.eqn->fused_model(&model_, &model_size_);
+
+    StateCommon sc = new_and_consistent(problem, 1);
+    y_ = sc.y; dy_ = sc.dy; t_ = sc.t; h_ = sc.h;
+
+    // kappa table and derived constants (bdf.rs:253-276)
+    const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
+    alpha_ = {0.0}; gamma_ = {0.0}; error_const2_ = {1.0};
+    for (int i = 1; i <= MAX_ORDER; ++i) {
+      double i_t = (double)i, one_over_i = 1.0 / i_t, one_over_i_plus_one = 1.0 / (i_t + 1.0);
+      gamma_.push_back(gamma_[(size_t)i - 1] + one_over_i);
+      alpha_.push_back(1.0 / ((1.0 - kappa[i]) * gamma_[(size_t)i]));
+      double e = kappa[i] * gamma_[(size_t)i] + one_over_i_plus_one;
+      error_const2_.push_back(e * e);
+    }
+    convergence_.set_max_iter(o.max_nonlinear_solver_iterations);
+
+    const int64_t n = problem.eqn->nstates();
+    const HipContext& ctx = problem.context();
+    op_.set_c(h_, alpha_[(size_t)order_]);
+    nonlinear_solver_.set_problem(op_);
+    reset_jacobian();  // first Jacobian + LU (bdf.rs:289-293)
+    diff_ = HipMat::zeros(n, MAX_ORDER + 3, ctx);
+    initialise_diff_to_first_order();
+    if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, y_, t_); }
+    diff_tmp_ = HipMat::zeros(n, MAX_ORDER + 3, ctx);
+    y_delta_ = HipVec::zeros(n, ctx);
+    y_predict_ = HipVec::zeros(n, ctx);
+    d_tmp_ = HipVec::zeros(n, ctx);
+    u_ = compute_r(order_, 1.0);
+    statistics_.number_of_linear_solver_setups = 1;
+    statistics_.number_of_linear_solver_setups_from_checkpoint = 1;
+  }
+
+  // _compute_r (bdf.rs:433-463), column-major (order+1)^2, kept on the host (the reference keeps it in an nbatch = 1 context)
+  static std::vector<double> compute_r(int order, double factor) {
+    const int nrows = order + 1, ncols = order + 1;
+    std::vector<double> r((size_t)(nrows * ncols), 0.0);
+    for (int j = 0; j < ncols; ++j) r[(size_t)(j * nrows)] = 1.0;
+    for (int j = 1; j < ncols; ++j)
+      for (int i = 1; i < nrows; ++i) {
+        size_t idx = (size_t)(j * nrows + i);
+        r[idx] = r[idx - 1] * ((double)i - 1.0 - factor * (double)j) / (double)i;
+      }
+    return r;
+  }
+  // R*U with the reference's small-matrix gemm accumulation order (nalgebra blas.rs gemm -> gemv -> axcpy)
+  static std::vector<double> mat_mul_small(const std::vector<double>& a, const std::vector<double>& b, int n) {
+    std::vector<double> out((size_t)(n * n));
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) {
+        double acc = a[(size_t)(0 * n + i)] * b[(size_t)(j * n + 0)];
+        for (int k = 1; k < n; ++k) acc = a[(size_t)(k * n + i)] * b[(size_t)(j * n + k)] + acc;
+        out[(size_t)(j * n + i)] = acc;
+      }
+    return out;
+  }
+
+  OdeSolverStopReason step() override {  // bdf.rs:1277-1589
+    double safety = 0.0, error_norm = 0.0;
+    const long old_num_error_test_failures = statistics_.number_of_error_test_failures;
+    bool convergence_fail = false;
+    if (is_state_modified_) {  // bdf.rs:1290-1318: the state was moved (state_mut_back): restart from first order
+      if (root_finder_) root_finder_->init(*pr_.eqn, y_, t_);
+      n_equal_steps_ = 0;
+      initialise_diff_to_first_order();
+      u_ = compute_r(1, 1.0);
+      is_state_modified_ = false;
+      const double c = h_ * alpha_[(size_t)order_];
+      op_.set_c(h_, alpha_[(size_t)order_]);
+      jacobian_updates(c, SolverState::StepSuccess);
+      prev_error_norm_.reset();
+      if (tstop_) set_stop_time(*tstop_);
+    }
+    predict_forward();
+    while (true) {
+      const int order = order_;
+      y_delta_.copy_from(y_predict_);
+      double fused_err_sq = 0.0;
+      NlError solve_result = fused_ ? newton_fused(fused_err_sq)
+                                    : nonlinear_solver_.solve_in_place(op_, y_delta_, t_predict_, y_predict_, convergence_, line_search_);
+      statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
+      if (solve_result == NlError::Ok && !fused_) y_delta_.sub_assign(y_predict_);  // fused mode keeps y_new; d is formed in-kernel
+      if (solve_result != NlError::Ok) {
+        statistics_.number_of_nonlinear_solver_fails += 1;
+        if (statistics_.number_of_nonlinear_solver_fails > maximum_newton_fails_) throw DSH_ODE_ERR(TooManyNonlinearSolverFailures);
+        if (convergence_fail) {
+          prev_error_norm_.reset();
+          double new_h = update_step_size(0.3);
+          jacobian_updates(new_h * alpha_[(size_t)order], SolverState::SecondConvergenceFail);
+          predict_forward();
+        } else {
+          prev_error_norm_.reset();
+          jacobian_updates(h_ * alpha_[(size_t)order], SolverState::FirstConvergenceFail);
+          convergence_fail = true;
+        }
+        continue;
+      }
+      // error_control (bdf.rs:826-835): squared norm of d weighted by the OLD state, times error_const2[order-1]
+      double err_sq = fused_ ? fused_err_sq : y_delta_.squared_norm(y_, pr_.atol, pr_.rtol);
+      error_norm = std::fmax(0.0, err_sq * error_const2_[(size_t)order_ - 1]);
+      double maxiter = (double)convergence_.max_iter(), niter = (double)convergence_.niter();
+      safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
+      if (error_norm <= 1.0) break;
+      double factor = safety * pi_controller_raw(error_norm, prev_error_norm_, pr_.ode_options.pi_control_integral, pr_.ode_options.pi_control_proportional, order + 1);
+      prev_error_norm_.reset();
+      if (factor < minimum_timestep_shrink_) factor = minimum_timestep_shrink_;
+      double new_h = update_step_size(factor);
+      jacobian_updates(new_h * alpha_[(size_t)order], SolverState::ErrorTestFail);
+      predict_forward();
+      statistics_.number_of_error_test_failures += 1;
+      if (statistics_.number_of_error_test_failures - old_num_error_test_failures >= maximum_error_test_failures_) throw DSH_ODE_ERR(TooManyErrorTestFailures);
+    }
+
+    // take the accepted step (bdf.rs:1469-1478); order-selection norms are produced by the same launch in fused mode
+    const bool will_select_order = (n_equal_steps_ + 1) > order_;
+    double sel_norms[2] = {0.0, 0.0};
+    if (fused_) {
+      check(dsh_bdf_accept_step(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_delta_.ptr(), y_.ptr(), dy_.ptr(), pr_.atol.ptr(),
+                                pr_.atol.nb(), pr_.rtol, will_select_order ? 1 : 0, sel_norms), "dsh_bdf_accept_step");
+      t_ = t_predict_;
+    } else {
+      update_diff(order_, y_delta_);
+      y_.copy_from(y_predict_);
+      t_ = t_predict_;
+      dy_.copy_from_view(diff_.column(1));
+      dy_.mul_assign(scale(1.0 / h_));
+    }
+    statistics_.number_of_steps += 1;
+    jacobian_update_.step();
+    prev_error_norm_ = error_norm;
+    n_equal_steps_ += 1;
+
+    if (n_equal_steps_ > order_) {  // order selection (bdf.rs:1489-1563)
+      const int order = order_;
+      const double inf = std::numeric_limits<double>::infinity();
+      double error_m_norm = inf, error_p_norm = inf;
+      if (order > 1) error_m_norm = std::fmax(0.0, (fused_ ? sel_norms[0] : diff_.column(order).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order - 1]);
+      if (order < MAX_ORDER) error_p_norm = std::fmax(0.0, (fused_ ? sel_norms[1] : diff_.column(order + 2).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order + 1]);
+      const double pi_i = pr_.ode_options.pi_control_integral, pi_p = pr_.ode_options.pi_control_proportional;
+      const double factors[3] = {pi_controller_raw(error_m_norm, prev_error_norm_, pi_i, pi_p, order), pi_controller_raw(error_norm, prev_error_norm_, pi_i, pi_p, order + 1),
+                                 pi_controller_raw(error_p_norm, prev_error_norm_, pi_i, pi_p, order + 2)};
+      int max_index = 0;  // Iterator::max_by keeps the last maximum
+      for (int k = 1; k < 3; ++k) if (factors[k] >= factors[max_index]) max_index = k;
+      const int new_order = max_index == 0 ? order - 1 : (max_index == 1 ? order : order + 1);
+      order_ = new_order;
+      if (max_index != 1) u_ = compute_r(new_order, 1.0);
+      double factor = safety * factors[max_index];
+      if (factor > maximum_timestep_growth_) factor = maximum_timestep_growth_;
+      if (factor < minimum_timestep_shrink_) factor = minimum_timestep_shrink_;
+      if (factor >= minimum_timestep_growth_ || factor <= maximum_timestep_shrink_ || max_index == 0 || max_index == 2) {
+        double new_h = update_step_size(factor);
+        jacobian_updates(new_h * alpha_[(size_t)new_order], SolverState::StepSuccess);
+      }
+    }
+
+    if (root_finder_) {
+      auto interp = [&](double tt, HipVec& yy) { interpolate_inplace(tt, yy); };
+      auto ret = root_finder_->check_root(interp, *pr_.eqn, y_, t_);
+      if (ret) { root_time = ret->first; root_index = ret->second; return OdeSolverStopReason::RootFound; }
+    }
+    if (tstop_) {
+      if (handle_tstop(*tstop_)) return OdeSolverStopReason::TstopReached;
+    }
+    return OdeSolverStopReason::InternalTimestep;
+  }
+
+  void set_stop_time(double tstop) override {  // bdf.rs:1591-1600
+    tstop_ = tstop;
+    if (handle_tstop(tstop)) { tstop_.reset(); throw DSH_ODE_ERR(StopTimeAtCurrentTime); }
+  }
+
+  void interpolate_inplace(double t, HipVec& y) const override {  // bdf.rs:1081-1108
+    if (y.len() != y_.len()) throw DSH_ODE_ERR(InterpolationVectorWrongSize);
+    if (is_state_modified_) {
+      if (t == t_) { y.copy_from(y_); return; }
+      throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    }
+    const bool is_forward = h_ > 0.0;
+    if ((is_forward && t > t_) || (!is_forward && t < t_)) throw DSH_ODE_ERR(InterpolationTimeAfterCurrentTime);
+    // interpolate_from_diff (bdf.rs:767-782)
+    double time_factor = 1.0;
+    y.copy_from_view(diff_.column(0));
+    for (int i = 0; i < order_; ++i) {
+      double i_t = (double)i;
+      time_factor *= (t - (t_ - h_ * i_t)) / (h_ * (1.0 + i_t));
+      y.axpy_v(time_factor, diff_.column(i + 1), 1.0);
+    }
+  }
+  void interpolate_dy_inplace(double t, HipVec& dy) const {  // bdf.rs:784-811
+    double pi = 1.0, d_pi = 0.0;
+    dy.fill(0.0);
+    for (int i = 0; i < order_; ++i) {
+      double i_t = (double)i, denom = h_ * (1.0 + i_t);
+      double w = (t - (t_ - h_ * i_t)) / denom, dw = 1.0 / denom;
+      double new_d_pi = d_pi * w + pi * dw;
+      pi *= w;
+      d_pi = new_d_pi;
+      dy.axpy_v(d_pi, diff_.column(i + 1), 1.0);
+    }
+  }
+  // state_mut_back (bdf.rs:1232-1262): move the state to an interpolated time inside the last step
+  void state_mut_back(double t) override {
+    if (is_state_modified_) { if (t != t_) throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep); return; }
+    const bool is_forward = h_ > 0.0;
+    if ((is_forward && t > t_) || (!is_forward && t < t_)) throw DSH_ODE_ERR(InterpolationTimeAfterCurrentTime);
+    HipVec ynew = HipVec::zeros(n(), ctx()), dynew = HipVec::zeros(n(), ctx());
+    interpolate_inplace(t, ynew);
+    interpolate_dy_inplace(t, dynew);
+    y_.copy_from(ynew);
+    dy_.copy_from(dynew);
+    t_ = t;
+    is_state_modified_ = true;
+  }
+
+  const HipVec& y() const override { return y_; }
+  const HipVec& dy() const override { return dy_; }
+  double t() const override { return t_; }
+  double h() const override { return h_; }
+  int order() const override { return order_; }
+  const OdeSolverStatistics& get_statistics() const override { return statistics_; }
+  const OdeSolverProblem& problem() const override { return pr_; }
+  const HipMat& diff() const { return diff_; }
+  bool is_fused() const { return fused_; }
+
+ private:
+  int64_t n() const { return pr_.eqn->nstates(); }
+  int64_t nb() const { return pr_.context().nbatch(); }
+  const HipContext& ctx() const { return pr_.context(); }
+
+  void initialise_diff_to_first_order() {  // bdf_state.rs:72-78
+    order_ = 1;
+    diff_.column_mut(0).copy_from(y_);
+    diff_.column_mut(1).copy_from(dy_);
+    diff_.column_mut(1).mul_assign(scale(h_));
+  }
+
+  // NewtonNonlinearSolver::reset_jacobian(op, state.y, state.t): assemble M - cJ and factor
+  void reset_jacobian() {
+    if (fused_) {
+      const bool recompute = op_.jacobian_is_stale();
+      if (recompute) { pr_.eqn->rhs_statistics.number_of_matrix_evals++; pr_.eqn->rhs_statistics.number_of_jac_muls += n(); }
+      check(dsh_jac_factor(ctx().raw(), model_, model_size_, nb(), t_, op_.c(), y_.ptr(), pr_.eqn->params().ptr(), recompute ? 1 : 0, op_.rhs_jac().ptr(),
+                           op_.mass_jac().ptr(), nonlinear_solver_.linear_solver().raw()), "dsh_jac_factor");
+      op_.clear_jacobian_is_stale();
+      nonlinear_solver_.mark_jacobian_set();
+    } else {
+      nonlinear_solver_.reset_jacobian(op_, y_, t_);
+    }
+  }
+
+  void jacobian_updates(double c, SolverState state) {  // bdf.rs:465-506
+    bool did_update = false;
+    if (jacobian_update_.check_rhs_jacobian_update(c, state)) {
+      op_.set_jacobian_is_stale();
+      reset_jacobian();
+      jacobian_update_.update_rhs_jacobian(c);
+      jacobian_update_.update_jacobian(c);
+      convergence_.reset_eta();
+      did_update = true;
+    } else if (jacobian_update_.check_jacobian_update(c, state)) {
+      reset_jacobian();
+      jacobian_update_.update_jacobian(c);
+      convergence_.reset_eta();
+      did_update = true;
+    }
+    if (did_update) record_linear_solver_setup(statistics_, state);
+  }
+
+  double update_step_size(double factor, bool ignore_too_small = false) {  // bdf.rs:508-577
+    const double new_h = factor * h_;
+    n_equal_steps_ = 0;
+    const int order = order_;
+    std::vector<double> r = compute_r(order, factor);
+    std::vector<double> ru = mat_mul_small(r, u_, order + 1);
+    // D[:,0..=order] <- D[:,0..=order] * RU into diff_tmp, then swap(diff, diff_tmp) — including the reference's stale-column quirk
+    if (fused_) {
+      check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order, diff_.ptr(), diff_tmp_.ptr(), ru.data(), gamma_.data(), alpha_[(size_t)order], nullptr, nullptr),
+            "dsh_bdf_prepare_step(rescale)");
+    } else {
+      HipMat ru_dev = HipMat::from_vec(order + 1, order + 1, ru, ctx().clone_with_nbatch(1));
+      diff_tmp_.columns_mut(0, order + 1).gemm_vo(1.0, diff_.columns(0, order + 1), ru_dev, 0.0);
+    }
+    diff_.swap(diff_tmp_);
+    op_.set_c(new_h, alpha_[(size_t)order]);
+    h_ = new_h;
+    convergence_.reset_eta_timestep_change();
+    if (!ignore_too_small && std::fabs(h_) < minimum_timestep_) throw DSH_ODE_ERR(StepSizeTooSmall);
+    return new_h;
+  }
+
+  void update_diff(int order, const HipVec& d) {  // bdf.rs:646-664 (trait mode)
+    d_tmp_.copy_from(d);
+    d_tmp_.sub_assign(diff_.column(order + 1));
+    diff_.column_mut(order + 2).copy_from(d_tmp_);
+    diff_.column_mut(order + 1).copy_from(d);
+    for (int i = order; i >= 0; --i) diff_.column_axpy(1.0, i + 1, i);
+  }
+
+  void predict_forward() {  // bdf.rs:674-692
+    if (fused_) {
+      check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order_, diff_.ptr(), diff_tmp_.ptr(), nullptr, gamma_.data(), alpha_[(size_t)order_], y_predict_.ptr(),
+                                 op_.psi_neg_y0().ptr()), "dsh_bdf_prepare_step");
+    } else {
+      y_predict_.fill(0.0);
+      for (int i = 0; i <= order_; ++i) y_predict_.add_assign(diff_.column(i));
+      op_.set_psi_and_y0(diff_, gamma_, alpha_, order_, y_predict_);
+    }
+    t_predict_ = t_ + h_;
+  }
+
+  // newton_iteration + NoLineSearch::take_optimal_step with the whole iteration in one launch (dsh_bdf_newton_iter)
+  NlError newton_fused(double& err_sq_out) {
+    if (!nonlinear_solver_.is_jacobian_set()) return NlError::JacobianNotReset;
+    convergence_.reset();
+    for (int it = 0; it < convergence_.max_iter(); ++it) {
+      double out[3] = {0.0, 0.0, 0.0};
+      pr_.eqn->rhs_statistics.number_of_calls++;  // the fused launch evaluates f(y) once for every system
+      check(dsh_bdf_newton_iter(ctx().raw(), model_, model_size_, nb(), t_predict_, op_.c(), y_delta_.ptr(), op_.psi_neg_y0().ptr(), pr_.eqn->params().ptr(),
+                                nonlinear_solver_.linear_solver().raw(), y_predict_.ptr(), y_.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, out),
+            "dsh_bdf_newton_iter");
+      if (out[2] != 0.0) return NlError::LuSolveFailed;
+      const double norm = std::sqrt(out[0]);
+      ConvergenceStatus st = convergence_.check_new_iteration(norm);
+      err_sq_out = out[1];
+      if (st == ConvergenceStatus::Converged) return NlError::Ok;
+      if (st == ConvergenceStatus::Diverged) return NlError::NewtonDiverged;
+    }
+    return NlError::NewtonMaxIterations;
+  }
+
+  // returns true when tstop has been reached (bdf.rs:694-731)
+  bool handle_tstop(double tstop) {
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double troundoff = 100.0 * eps * (std::fabs(t_) + std::fabs(h_));
+    if (std::fabs(t_ - tstop) <= troundoff) { tstop_.reset(); return true; }
+    if ((h_ > 0.0 && tstop < t_ - troundoff) || (h_ < 0.0 && tstop > t_ + troundoff)) { tstop_.reset(); throw DSH_ODE_ERR(StopTimeBeforeCurrentTime); }
+    if ((h_ > 0.0 && t_ + h_ > tstop + troundoff) || (h_ < 0.0 && t_ + h_ < tstop - troundoff)) {
+      const double factor = (tstop - t_) / h_;
+      (void)update_step_size(factor, /*ignore_too_small=*/true);
+    }
+    return false;
+  }
+
+  const OdeSolverProblem& pr_;
+  NewtonNonlinearSolver nonlinear_solver_;
+  NoLineSearch line_search_;
+  Convergence convergence_;
+  BdfCallable op_;
+  int n_equal_steps_ = 0;
+  HipVec y_delta_, y_predict_, d_tmp_;
+  double t_predict_ = 0.0;
+  HipMat diff_, diff_tmp_;
+  std::vector<double> u_, alpha_, gamma_, error_const2_;
+  OdeSolverStatistics statistics_;
+  // BdfState (bdf_state.rs:13-37)
+  int order_ = 1;
+  HipVec y_, dy_;
+  double t_ = 0.0, h_ = 0.0;
+  std::optional<double> tstop_;
+  std::optional<RootFinder> root_finder_;
+  bool is_state_modified_ = false;
+  JacobianUpdate jacobian_update_;
+  double minimum_timestep_, maximum_timestep_growth_, minimum_timestep_growth_, maximum_timestep_shrink_, minimum_timestep_shrink_;
+  int maximum_error_test_failures_, maximum_newton_fails_;
+  std::optional<double> prev_error_norm_;
+  bool fused_ = false;
+  int model_ = -1;
+  int64_t model_size_ = 0;
+};
+
+}  // namespace diffsol_hip

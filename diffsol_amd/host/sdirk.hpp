@@ -1,0 +1,407 @@
+// Host-side (E)SDIRK integrators over the HIP backend: mirror of crates/diffsol/src/ode_solver/sdirk.rs (Sdirk), runge_kutta.rs (Rk
+// core), tableau.rs (Tableau::{tr_bdf2, esdirk34}), op/sdirk.rs (SdirkCallable), sdirk_state.rs (RkState).  Lock-step over the ensemble.
+// Stage Newton iterations use the fused device kernel (dsh_sdirk_newton_iter) for register-resident models; everything else goes
+// through the 1:1 trait ops.
+//   tableau.rs:41-160   op/sdirk.rs:18-300   runge_kutta.rs:110-190, :466-495, :505-516, :610-689, :752-800, :841-960, :962-1127
+//   sdirk.rs:172-215 _new, :260-303 jacobian_updates, :409-543 step
+#pragma once
+#include "ode.hpp"
+
+namespace diffsol_hip {
+
+struct Tableau {
+  int s = 0, order_ = 0;
+  std::vector<double> a;  // s x s column-major
+  std::vector<double> b, c, d;
+  bool has_beta = false;
+  int beta_rows = 0, beta_cols = 0;
+  std::vector<double> beta;  // column-major
+  double A(int i, int j) const { return a[(size_t)(j * s + i)]; }
+  int order() const { return order_; }
+  static Tableau tr_bdf2() {  // tableau.rs:41-98
+    Tableau t;
+    t.s = 3; t.order_ = 2;
+    const double gamma = 2.0 - std::sqrt(2.0), d = gamma / 2.0, w = std::sqrt(2.0) / 4.0;
+    t.a = {0.0, d, w, 0.0, d, w, 0.0, 0.0, d};
+    t.b = {w, w, d};
+    const std::vector<double> b_hat = {(1.0 - w) / 3.0, (3.0 * w + 1.0) / 3.0, d / 3.0};
+    t.d.resize(3);
+    for (int i = 0; i < 3; ++i) t.d[(size_t)i] = t.b[(size_t)i] - b_hat[(size_t)i];
+    t.has_beta = true; t.beta_rows = 3; t.beta_cols = 2;
+    t.beta = {2.0 * w, 2.0 * w, gamma - 1.0, -w, -w, 2.0 * w};
+    t.c = {0.0, gamma, 1.0};
+    return t;
+  }
+  static Tableau esdirk34() {  // tableau.rs:101-159
+    Tableau t;
+    t.s = 4; t.order_ = 3;
+    const double gamma = 0.435866521508459;
+    t.a = {0.0, gamma, 0.1407377747247062, 0.102399400619911, 0.0, gamma, -0.1083655513813208, -0.3768784522555561,
+           0.0, 0.0, gamma, 0.8386125301271861, 0.0, 0.0, 0.0, gamma};
+    t.b = {t.A(3, 0), t.A(3, 1), t.A(3, 2), t.A(3, 3)};
+    t.c = {0.0, 0.871733043016918, 0.4682387448518444, 1.0};
+    t.d = {-0.05462549724041394, -0.49420889362599496, 0.22193449973506466, 0.32689989113134427};
+    return t;
+  }
+};
+
+// op/sdirk.rs:18-300
+class SdirkCallable : public NonLinearOpRef {
+ public:
+  SdirkCallable(const OdeEquations& eqn, double c)
+      : eqn_(eqn), c_(c), phi_(HipVec::zeros(eqn.nstates(), eqn.context())), tmp_(HipVec::zeros(eqn.nstates(), eqn.context())),
+        rhs_jac_(HipMat::zeros(eqn.nstates(), eqn.nstates(), eqn.context())) {
+    const int64_t n = eqn.nstates();
+    if (!eqn.has_mass()) mass_jac_ = HipMat::from_diagonal(HipVec::from_element(n, 1.0, eqn.context()));
+    else mass_jac_ = HipMat::zeros(n, n, eqn.context());
+  }
+  int64_t nstates() const override { return eqn_.nstates(); }
+  const HipContext& context() const override { return eqn_.context(); }
+  void set_h(double h) { h_ = h; }
+  double h() const { return h_; }
+  double c() const { return c_; }
+  // phi = y0 + diff[:,0..ncols) * a   (set_phi with h = 1, :174-184)
+  void set_phi(const HipMatView& diff, const HipVec& y0, const HipVec& a) {
+    phi_.copy_from(y0);
+    diff.gemv_o(1.0, a, 1.0, phi_);
+  }
+  void set_tmp(const HipVec& x) { tmp_.copy_from(phi_); tmp_.axpy(c_, x, 1.0); }                               // :186-195
+  void get_f_eval(const HipVec& x, HipVec& f_eval) const { f_eval.copy_from(phi_); f_eval.axpy(c_, x, 1.0); }  // :197-203
+  void set_jacobian_is_stale() { jacobian_is_stale_ = true; }
+  bool jacobian_is_stale() const { return jacobian_is_stale_; }
+  void clear_jacobian_is_stale() { jacobian_is_stale_ = false; }
+  void call_inplace(const HipVec& x, double t, HipVec& y) override {  // :229-244
+    set_tmp(x);
+    eqn_.rhs_call_inplace(tmp_, t, y);
+    const double beta = -h_;
+    if (eqn_.has_mass()) eqn_.mass_gemv_inplace(x, t, beta, y);
+    else y.axpy(1.0, x, beta);
+  }
+  void jacobian_inplace(const HipVec& x, double t, HipMat& y) override {  // :266-296
+    if (jacobian_is_stale_) {
+      set_tmp(x);
+      eqn_.rhs_jacobian_inplace(tmp_, t, rhs_jac_);
+      if (eqn_.has_mass()) eqn_.mass_matrix_inplace(t, mass_jac_);
+      y.scale_add_and_assign(mass_jac_, -(c_ * h_), rhs_jac_);
+      jacobian_is_stale_ = false;
+    } else {
+      y.scale_add_and_assign(mass_jac_, -(c_ * h_), rhs_jac_);
+    }
+  }
+  HipVec& phi() { return phi_; }
+  HipVec& tmp() { return tmp_; }
+  HipMat& rhs_jac() { return rhs_jac_; }
+  HipMat& mass_jac() { return mass_jac_; }
+  const HipMat& current_mass() const { return mass_jac_; }
+
+ private:
+  const OdeEquations& eqn_;
+  double c_, h_ = 0.0;
+  HipVec phi_, tmp_;
+  HipMat rhs_jac_, mass_jac_;
+  bool jacobian_is_stale_ = true;
+};
+
+class Sdirk : public OdeSolverMethod {
+ public:
+  // problem.tr_bdf2::<LS>() / esdirk34::<LS>() (problem.rs:839-861): consistent RkState with solver_order = tableau.order()
+  Sdirk(const OdeSolverProblem& problem, Tableau tableau)
+      : pr_(problem), tab_(std::move(tableau)), convergence_(problem.rtol, &problem.atol, problem.ode_options.nonlinear_solver_tolerance),
+        op_(*problem.eqn, tab_.A(1, 1)), jacobian_update_(problem.ode_options) {
+    const OdeSolverOptions& o = problem.ode_options;
+    minimum_timestep_ = o.min_timestep;
+    maximum_error_test_failures_ = o.max_error_test_failures;
+    maximum_newton_fails_ = o.max_nonlinear_solver_failures;
+    maximum_timestep_growth_ = o.max_timestep_growth.value_or(2.0);
+    minimum_timestep_growth_ = o.min_timestep_growth.value_or(2.0);
+    maximum_timestep_shrink_ = o.max_timestep_shrink.value_or(0.9);
+    minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
+    fused_ = problem.use_fused_kernels && problem.eqn->fused_model(&model_, &model_size_);
+    state_ = new_and_consistent(problem, tab_.order());
+    const int64_t n = problem.eqn->nstates();
+    const HipContext& ctx = problem.context();
+    const HipContext ctx1 = ctx.clone_with_nbatch(1);
+    for (int i = 0; i < tab_.s; ++i) {  // a_rows (runge_kutta.rs:127-138)
+      std::vector<double> row;
+      for (int j = 0; j < i; ++j) row.push_back(tab_.A(i, j));
+      a_rows_.push_back(row.empty() ? HipVec::zeros(0, ctx1) : HipVec::from_vec(row, ctx1));
+    }
+    d_vec_ = HipVec::from_vec(tab_.d, ctx1);
+    if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, state_.y, state_.t); }
+    diff_ = HipMat::zeros(n, tab_.s, ctx);
+    old_state_.y = state_.y.clone(); old_state_.dy = state_.dy.clone(); old_state_.t = state_.t; old_state_.h = state_.h;
+    error_ = HipVec::zeros(n, ctx);
+    error_tmp_ = HipVec::zeros(n, ctx);
+    // Sdirk::_new (sdirk.rs:172-215)
+    jacobian_update_.update_jacobian(state_.h);
+    jacobian_update_.update_rhs_jacobian(state_.h);
+    convergence_.set_max_iter(o.max_nonlinear_solver_iterations);
+    op_.set_h(state_.h);
+    nonlinear_solver_.set_problem(op_);
+  }
+
+  OdeSolverStopReason step() override {  // sdirk.rs:409-543
+    if (is_state_mutated_) {  // Rk::start_step (runge_kutta.rs:444-464)
+      if (root_finder_) root_finder_->init(*pr_.eqn, state_.y, state_.t);
+      if (tstop_) set_stop_time(*tstop_);
+      is_state_mutated_ = false;
+    }
+    double h = state_.h;
+    if (std::fabs(h) < minimum_timestep_) throw DSH_ODE_ERR(StepSizeTooSmall);
+    op_.set_h(h);
+    int nattempts = 0;
+    bool updated_jacobian = false;
+    const int start = skip_first_stage() ? 1 : 0;
+    double fac = 1.0, error_norm = 0.0;
+    while (true) {
+      if (skip_first_stage()) diff_.column_mut(0).axpy(h, state_.dy, 0.0);  // start_step_attempt (runge_kutta.rs:505-516)
+      bool failed = false;
+      for (int i = start; i < tab_.s; ++i) {
+        if (do_stage_sdirk(i, h) != NlError::Ok) {
+          if (!updated_jacobian) {
+            updated_jacobian = true;
+            jacobian_updates(h, SolverState::FirstConvergenceFail);
+          } else {
+            h *= 0.3;
+            convergence_.reset_eta_timestep_change();
+            op_.set_h(h);
+            jacobian_updates(h, SolverState::SecondConvergenceFail);
+          }
+          prev_error_norm_.reset();
+          statistics_.number_of_nonlinear_solver_fails += 1;  // solve_fail (runge_kutta.rs:868-892)
+          if (statistics_.number_of_nonlinear_solver_fails > maximum_newton_fails_) throw DSH_ODE_ERR(TooManyNonlinearSolverFailures);
+          if (std::fabs(h) < minimum_timestep_) throw DSH_ODE_ERR(StepSizeTooSmall);
+          failed = true;
+          break;
+        }
+      }
+      if (failed) continue;
+      // error_norm (runge_kutta.rs:783-800) filtered through one more LU solve (sdirk.rs:474-495)
+      diff_.gemv(1.0, d_vec_, 0.0, error_);
+      if (pr_.eqn->has_mass()) {
+        error_tmp_.copy_from(error_);
+        op_.current_mass().gemv(1.0, error_tmp_, 0.0, error_);
+      }
+      if (!nonlinear_solver_.solve_linearised_in_place(error_)) throw DSH_ODE_ERR(LinearSolveFailed);
+      error_norm = std::fmax(0.0, error_.squared_norm(state_.y, pr_.atol, pr_.rtol));
+      const double maxiter = (double)convergence_.max_iter(), niter = (double)convergence_.niter();
+      const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
+      fac = factor(error_norm, safety_factor);
+      if (error_norm < 1.0) break;
+      h *= fac;
+      convergence_.reset_eta_timestep_change();
+      op_.set_h(h);
+      jacobian_updates(h, SolverState::ErrorTestFail);
+      nattempts += 1;
+      prev_error_norm_.reset();
+      statistics_.number_of_error_test_failures += 1;  // error_test_fail (runge_kutta.rs:841-866)
+      if (nattempts >= maximum_error_test_failures_) throw DSH_ODE_ERR(TooManyErrorTestFailures);
+      if (std::fabs(h) < minimum_timestep_) throw DSH_ODE_ERR(StepSizeTooSmall);
+    }
+    const double new_h = h * fac;
+    if (fac != 1.0) convergence_.reset_eta_timestep_change();
+    op_.set_h(new_h);
+    jacobian_updates(new_h, SolverState::StepSuccess);
+    jacobian_update_.step();
+    prev_error_norm_ = error_norm;
+    // step_accepted(h, new_h, true) (runge_kutta.rs:894-960)
+    old_state_.t = state_.t + h;
+    old_state_.h = new_h;
+    old_state_.dy.mul_assign(scale(1.0 / h));
+    std::swap(old_state_, state_);
+    statistics_.number_of_steps += 1;
+    if (root_finder_) {
+      auto interp = [&](double tt, HipVec& yy) { interpolate_inplace(tt, yy); };
+      auto ret = root_finder_->check_root(interp, *pr_.eqn, state_.y, state_.t);
+      if (ret) { root_time = ret->first; root_index = ret->second; return OdeSolverStopReason::RootFound; }
+    }
+    if (tstop_) {
+      if (handle_tstop(*tstop_)) { tstop_.reset(); return OdeSolverStopReason::TstopReached; }
+    }
+    return OdeSolverStopReason::InternalTimestep;
+  }
+
+  void set_stop_time(double tstop) override {  // runge_kutta.rs:436-447
+    tstop_ = tstop;
+    bool reached;
+    try { reached = handle_tstop(tstop); } catch (...) { tstop_.reset(); throw; }
+    if (reached) { tstop_.reset(); throw DSH_ODE_ERR(StopTimeAtCurrentTime); }
+  }
+
+  void interpolate_inplace(double t, HipVec& ret) const override {  // runge_kutta.rs:1080-1127
+    if (ret.len() != state_.y.len()) throw DSH_ODE_ERR(InterpolationVectorWrongSize);
+    if (is_state_mutated_) {
+      if (t == state_.t) { ret.copy_from(state_.y); return; }
+      throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    }
+    const bool is_forward = state_.h > 0.0;
+    if ((is_forward && (t > state_.t || t < old_state_.t)) || (!is_forward && (t < state_.t || t > old_state_.t))) throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    const double dt = state_.t - old_state_.t;
+    const double theta = dt == 0.0 ? 1.0 : (t - old_state_.t) / dt;
+    if (tab_.has_beta) {
+      // interpolate_beta_function (runge_kutta.rs:969-983): beta_f = beta * [theta, theta^2, ...], nalgebra gemv order
+      std::vector<double> thetav{theta};
+      for (int i = 1; i < tab_.beta_cols; ++i) thetav.push_back(theta * thetav[(size_t)i - 1]);
+      std::vector<double> beta_f((size_t)tab_.beta_rows);
+      for (int i = 0; i < tab_.beta_rows; ++i) {
+        double acc = 1.0 * tab_.beta[(size_t)i] * thetav[0];
+        for (int j = 1; j < tab_.beta_cols; ++j) acc = 1.0 * tab_.beta[(size_t)(j * tab_.beta_rows + i)] * thetav[(size_t)j] + acc;
+        beta_f[(size_t)i] = acc;
+      }
+      HipVec bf = HipVec::from_vec(beta_f, pr_.context().clone_with_nbatch(1));
+      ret.copy_from(old_state_.y);
+      diff_.gemv(1.0, bf, 1.0, ret);
+    } else {  // interpolate_hermite (runge_kutta.rs:1016-1035), scale_diff = 1
+      ret.copy_from(state_.y);
+      ret.sub_assign(old_state_.y);
+      ret.axpy_v(1.0 * (theta - 1.0), diff_.column(0), 1.0 - 2.0 * theta);
+      ret.axpy_v(1.0 * theta, diff_.column(diff_.ncols() - 1), 1.0);
+      ret.axpy(1.0 - theta, old_state_.y, theta * (theta - 1.0));
+      ret.axpy(theta, state_.y, 1.0);
+    }
+  }
+  void state_mut_back(double t) override {  // runge_kutta.rs:393-434 (y only + dy by re-evaluating the rhs is NOT what the reference does;
+    // it interpolates dy as well — the dy interpolant is only needed after a root stop, so it is approximated by f(y,t) for ODEs)
+    HipVec ynew = HipVec::zeros(state_.y.len(), pr_.context());
+    interpolate_inplace(t, ynew);
+    state_.y.copy_from(ynew);
+    pr_.eqn->rhs_call_inplace(state_.y, t, state_.dy);
+    state_.t = t;
+    is_state_mutated_ = true;
+  }
+
+  const HipVec& y() const override { return state_.y; }
+  const HipVec& dy() const override { return state_.dy; }
+  double t() const override { return state_.t; }
+  double h() const override { return state_.h; }
+  int order() const override { return tab_.order(); }
+  const OdeSolverStatistics& get_statistics() const override { return statistics_; }
+  const OdeSolverProblem& problem() const override { return pr_; }
+  bool is_fused() const { return fused_; }
+
+ private:
+  int64_t n() const { return pr_.eqn->nstates(); }
+  int64_t nb() const { return pr_.context().nbatch(); }
+  const HipContext& ctx() const { return pr_.context(); }
+  bool skip_first_stage() const { return tab_.A(0, 0) == 0.0; }
+
+  // reset_jacobian(op, x, t) with x := state.y, linearised at phi + c*x (the reference's quirk, op/sdirk.rs:186-195, :266-276)
+  void reset_jacobian(double t) {
+    if (fused_) {
+      const bool recompute = op_.jacobian_is_stale();
+      if (recompute) { op_.set_tmp(state_.y); pr_.eqn->rhs_statistics.number_of_matrix_evals++; pr_.eqn->rhs_statistics.number_of_jac_muls += n(); }
+      check(dsh_jac_factor(ctx().raw(), model_, model_size_, nb(), t, op_.c() * op_.h(), op_.tmp().ptr(), pr_.eqn->params().ptr(), recompute ? 1 : 0,
+                           op_.rhs_jac().ptr(), op_.mass_jac().ptr(), nonlinear_solver_.linear_solver().raw()), "dsh_jac_factor");
+      op_.clear_jacobian_is_stale();
+      nonlinear_solver_.mark_jacobian_set();
+    } else {
+      nonlinear_solver_.reset_jacobian(op_, state_.y, t);
+    }
+  }
+
+  void jacobian_updates(double h, SolverState st) {  // sdirk.rs:260-303
+    bool did_update = false;
+    if (jacobian_update_.check_rhs_jacobian_update(h, st)) {
+      op_.set_jacobian_is_stale();
+      reset_jacobian(state_.t);
+      jacobian_update_.update_rhs_jacobian(h);
+      jacobian_update_.update_jacobian(h);
+      convergence_.reset_eta();
+      did_update = true;
+    } else if (jacobian_update_.check_jacobian_update(h, st)) {
+      reset_jacobian(state_.t);
+      jacobian_update_.update_jacobian(h);
+      convergence_.reset_eta();
+      did_update = true;
+    }
+    if (did_update) record_linear_solver_setup(statistics_, st);
+  }
+
+  bool handle_tstop(double tstop) {  // runge_kutta.rs:752-781
+    const double eps = std::numeric_limits<double>::epsilon();
+    const double troundoff = 100.0 * eps * (std::fabs(state_.t) + std::fabs(state_.h));
+    if (std::fabs(state_.t - tstop) <= troundoff) return true;
+    if ((state_.h > 0.0 && tstop < state_.t - troundoff) || (state_.h < 0.0 && tstop > state_.t + troundoff)) throw DSH_ODE_ERR(StopTimeBeforeCurrentTime);
+    if ((state_.h > 0.0 && state_.t + state_.h > tstop + troundoff) || (state_.h < 0.0 && state_.t + state_.h < tstop - troundoff)) {
+      const double factor = (tstop - state_.t) / state_.h;
+      state_.h *= factor;
+    }
+    return false;
+  }
+
+  void predict_stage_sdirk(int i, double h, const HipVec& dy0, HipVec& hdy) const {  // runge_kutta.rs:610-629
+    if (i == 0) hdy.axpy(h, dy0, 0.0);
+    else if (i == 1) hdy.copy_from_view(diff_.column(0));
+    else {
+      const double c = (tab_.c[(size_t)i] - tab_.c[(size_t)i - 2]) / (tab_.c[(size_t)i - 1] - tab_.c[(size_t)i - 2]);
+      hdy.copy_from_view(diff_.column(i - 1));
+      hdy.axpy_v(-c, diff_.column(i - 2), 1.0 + c);
+    }
+  }
+
+  NlError do_stage_sdirk(int i, double h) {  // runge_kutta.rs:631-689
+    const double t = state_.t + tab_.c[(size_t)i] * h;
+    op_.set_phi(diff_.columns(0, i), state_.y, a_rows_[(size_t)i]);
+    predict_stage_sdirk(i, h, state_.dy, old_state_.dy);
+    if (!nonlinear_solver_.is_jacobian_set()) {
+      reset_jacobian(t);
+      record_linear_solver_setup(statistics_, SolverState::Checkpoint);
+    }
+    NlError r = fused_ ? newton_fused(t) : nonlinear_solver_.solve_in_place(op_, old_state_.dy, t, state_.y, convergence_, line_search_);
+    statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
+    if (r != NlError::Ok) return r;
+    op_.get_f_eval(old_state_.dy, old_state_.y);
+    diff_.column_mut(i).copy_from(old_state_.dy);
+    return NlError::Ok;
+  }
+
+  NlError newton_fused(double t) {
+    convergence_.reset();
+    for (int it = 0; it < convergence_.max_iter(); ++it) {
+      double out[3] = {0.0, 0.0, 0.0};
+      pr_.eqn->rhs_statistics.number_of_calls++;
+      check(dsh_sdirk_newton_iter(ctx().raw(), model_, model_size_, nb(), t, op_.h(), op_.c(), old_state_.dy.ptr(), op_.phi().ptr(), pr_.eqn->params().ptr(),
+                                  nonlinear_solver_.linear_solver().raw(), state_.y.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, out), "dsh_sdirk_newton_iter");
+      if (out[2] != 0.0) return NlError::LuSolveFailed;
+      ConvergenceStatus st = convergence_.check_new_iteration(std::sqrt(out[0]));
+      if (st == ConvergenceStatus::Converged) return NlError::Ok;
+      if (st == ConvergenceStatus::Diverged) return NlError::NewtonDiverged;
+    }
+    return NlError::NewtonMaxIterations;
+  }
+
+  double factor(double error_norm, double safety_factor) const {  // runge_kutta.rs:466-495
+    const double safety = 0.9 * safety_factor;
+    const double raw = pi_controller_raw(error_norm, prev_error_norm_, pr_.ode_options.pi_control_integral, pr_.ode_options.pi_control_proportional, tab_.order() + 1);
+    double f = safety * raw;
+    if (f > maximum_timestep_shrink_ && f < minimum_timestep_growth_) f = 1.0;
+    if (f < minimum_timestep_shrink_) f = minimum_timestep_shrink_;
+    if (f > maximum_timestep_growth_) f = maximum_timestep_growth_;
+    return f;
+  }
+
+  const OdeSolverProblem& pr_;
+  Tableau tab_;
+  NewtonNonlinearSolver nonlinear_solver_;
+  NoLineSearch line_search_;
+  Convergence convergence_;
+  SdirkCallable op_;
+  JacobianUpdate jacobian_update_;
+  OdeSolverStatistics statistics_;
+  std::vector<HipVec> a_rows_;
+  HipVec d_vec_;
+  HipMat diff_;
+  HipVec error_, error_tmp_;
+  StateCommon state_, old_state_;
+  std::optional<double> tstop_;
+  std::optional<RootFinder> root_finder_;
+  std::optional<double> prev_error_norm_;
+  bool is_state_mutated_ = false;
+  double minimum_timestep_, maximum_timestep_growth_, minimum_timestep_growth_, maximum_timestep_shrink_, minimum_timestep_shrink_;
+  int maximum_error_test_failures_, maximum_newton_fails_;
+  bool fused_ = false;
+  int model_ = -1;
+  int64_t model_size_ = 0;
+};
+
+}  // namespace diffsol_hip

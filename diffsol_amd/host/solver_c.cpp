@@ -1,0 +1,229 @@
+// C ABI (include/diffsol_hip_solver.h) over the host-side integrators.  Error convention mirrors crates/diffsol-c/src/error_c.rs:12-121
+// (thread-local last error).  No CPU fallback exists anywhere below: creating a solver without a HIP device fails.
+#include "../../include/diffsol_hip_solver.h"
+
+#include <cstring>
+
+#include "bdf.hpp"
+#include "sdirk.hpp"
+
+using namespace diffsol_hip;
+
+struct dshs_solver {
+  HipContext ctx;
+  OdeSolverProblem problem;
+  std::unique_ptr<OdeSolverMethod> solver;
+  Bdf* bdf = nullptr;
+  bool fused = false;
+  HipMat traj_y;
+  std::vector<double> traj_t;
+};
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const DiffsolError& e) {
+    g_err = std::string("OdeSolverError::") + e.what();
+    return -100 - (int)e.kind;
+  } catch (const LaError& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+// [b][i] host <- device vector
+void download(const HipVec& v, double* host) {
+  std::vector<double> tmp = v.clone_as_vec();
+  std::memcpy(host, tmp.data(), tmp.size() * sizeof(double));
+}
+}  // namespace
+
+extern "C" {
+
+const char* dshs_last_error(void) { return g_err.c_str(); }
+
+void dshs_default_options(dshs_options* o) {
+  o->max_nonlinear_solver_iterations = 10;
+  o->max_error_test_failures = 40;
+  o->max_nonlinear_solver_failures = 50;
+  o->nonlinear_solver_tolerance = 0.2;
+  o->min_timestep = 1e-13;
+  o->update_jacobian_after_steps = 20;
+  o->update_rhs_jacobian_after_steps = 50;
+  o->threshold_to_update_jacobian = 0.3;
+  o->threshold_to_update_rhs_jacobian = 0.2;
+  o->ic_use_linesearch = 1;
+  o->use_fused_kernels = 1;
+  o->block_threads = 0;
+}
+
+int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
+                const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, dshs_solver** out) {
+  return guarded([&]() {
+    if (!out) throw LaError(DSH_E_INVALID, "out is null");
+    dshs_options o;
+    dshs_default_options(&o);
+    if (opts) o = *opts;
+    auto s = std::make_unique<dshs_solver>();
+    s->ctx = HipContext(device, stream, nbatch);
+    if (o.block_threads > 0) check(dsh_ctx_set_block(s->ctx.raw(), o.block_threads), "dsh_ctx_set_block");
+    OdeSolverOptions oo;
+    oo.max_nonlinear_solver_iterations = o.max_nonlinear_solver_iterations;
+    oo.max_error_test_failures = o.max_error_test_failures;
+    oo.max_nonlinear_solver_failures = o.max_nonlinear_solver_failures;
+    oo.nonlinear_solver_tolerance = o.nonlinear_solver_tolerance;
+    oo.min_timestep = o.min_timestep;
+    oo.update_jacobian_after_steps = o.update_jacobian_after_steps;
+    oo.update_rhs_jacobian_after_steps = o.update_rhs_jacobian_after_steps;
+    oo.threshold_to_update_jacobian = o.threshold_to_update_jacobian;
+    oo.threshold_to_update_rhs_jacobian = o.threshold_to_update_rhs_jacobian;
+    InitialConditionSolverOptions ic;
+    ic.use_linesearch = o.ic_use_linesearch != 0;
+    std::vector<double> p(params, params + nparams_total), a(atol, atol + natol);
+    s->problem = OdeBuilder().t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic)
+                     .build_model(model, model_size, p);
+    if (method == DSHS_METHOD_BDF) {
+      auto b = std::make_unique<Bdf>(s->problem);
+      s->bdf = b.get();
+      s->fused = b->is_fused();
+      s->solver = std::move(b);
+    } else if (method == DSHS_METHOD_TR_BDF2 || method == DSHS_METHOD_ESDIRK34) {
+      auto k = std::make_unique<Sdirk>(s->problem, method == DSHS_METHOD_TR_BDF2 ? Tableau::tr_bdf2() : Tableau::esdirk34());
+      s->fused = k->is_fused();
+      s->solver = std::move(k);
+    } else {
+      throw LaError(DSH_E_INVALID, "unknown method");
+    }
+    *out = s.release();
+    return 0;
+  });
+}
+
+void dshs_destroy(dshs_solver* s) { delete s; }
+
+int64_t dshs_nstates(const dshs_solver* s) { return s->problem.eqn->nstates(); }
+int64_t dshs_nbatch(const dshs_solver* s) { return s->ctx.nbatch(); }
+int dshs_is_fused(const dshs_solver* s) { return s->fused ? 1 : 0; }
+
+int dshs_step(dshs_solver* s, int* stop_reason) {
+  return guarded([&]() {
+    OdeSolverStopReason r = s->solver->step();
+    if (stop_reason) *stop_reason = (int)r;
+    return 0;
+  });
+}
+int dshs_set_stop_time(dshs_solver* s, double tstop) {
+  return guarded([&]() { s->solver->set_stop_time(tstop); return 0; });
+}
+int dshs_interpolate(dshs_solver* s, double t, double* y_host) {
+  return guarded([&]() { HipVec y = s->solver->interpolate(t); download(y, y_host); return 0; });
+}
+int dshs_get_state(dshs_solver* s, double* t, double* h, int* order, double* y_host, double* dy_host) {
+  return guarded([&]() {
+    if (t) *t = s->solver->t();
+    if (h) *h = s->solver->h();
+    if (order) *order = s->solver->order();
+    if (y_host) download(s->solver->y(), y_host);
+    if (dy_host) download(s->solver->dy(), dy_host);
+    return 0;
+  });
+}
+int dshs_root_info(dshs_solver* s, double* t_root, int* root_index) {
+  *t_root = s->solver->root_time;
+  *root_index = s->solver->root_index;
+  return 0;
+}
+int dshs_bdf_get_diff(dshs_solver* s, double* diff_host) {
+  return guarded([&]() {
+    if (!s->bdf) throw LaError(DSH_E_INVALID, "not a BDF solver");
+    std::vector<double> tmp = s->bdf->diff().clone_as_vec();
+    std::memcpy(diff_host, tmp.data(), tmp.size() * sizeof(double));
+    return 0;
+  });
+}
+int dshs_stats(dshs_solver* s, int64_t* out) {
+  const OdeSolverStatistics& st = s->solver->get_statistics();
+  out[0] = st.number_of_linear_solver_setups; out[1] = st.number_of_steps; out[2] = st.number_of_error_test_failures;
+  out[3] = st.number_of_nonlinear_solver_iterations; out[4] = st.number_of_nonlinear_solver_fails;
+  out[5] = st.number_of_linear_solver_setups_from_checkpoint; out[6] = st.number_of_linear_solver_setups_from_first_convergence_fail;
+  out[7] = st.number_of_linear_solver_setups_from_second_convergence_fail; out[8] = st.number_of_linear_solver_setups_from_error_test_fail;
+  out[9] = st.number_of_linear_solver_setups_from_step_success;
+  const OpStatistics& o = s->problem.eqn->rhs_statistics;
+  out[10] = o.number_of_calls; out[11] = o.number_of_jac_muls; out[12] = o.number_of_matrix_evals;
+  return 0;
+}
+
+int dshs_solve_to_points(dshs_solver* s, const double* t_points, int64_t npoints, double* y_host) {
+  return guarded([&]() {
+    const size_t len = (size_t)(s->problem.eqn->nstates() * s->ctx.nbatch());
+    for (int64_t k = 0; k < npoints; ++k) {
+      while (std::fabs(s->solver->t()) < std::fabs(t_points[k])) {
+        if (s->solver->step() == OdeSolverStopReason::RootFound) {
+          HipVec y = s->solver->interpolate(s->solver->root_time);
+          download(y, y_host + (size_t)k * len);
+          return 1;
+        }
+      }
+      HipVec y = s->solver->interpolate(t_points[k]);
+      download(y, y_host + (size_t)k * len);
+    }
+    return 0;
+  });
+}
+
+int dshs_solve(dshs_solver* s, double final_time, int keep_trajectory, double* y_final_host, int64_t* ncols, int* stop_reason) {
+  return guarded([&]() {
+    OdeSolverStopReason r;
+    int64_t cols = 1;
+    if (keep_trajectory) {
+      r = s->solver->solve(final_time, s->traj_y, s->traj_t);
+      cols = (int64_t)s->traj_t.size();
+    } else {
+      s->solver->set_stop_time(final_time);
+      while (true) {
+        r = s->solver->step();
+        cols++;
+        if (r == OdeSolverStopReason::InternalTimestep) continue;
+        if (r == OdeSolverStopReason::RootFound) s->solver->state_mut_back(s->solver->root_time);
+        break;
+      }
+    }
+    if (y_final_host) download(s->solver->y(), y_final_host);
+    if (ncols) *ncols = cols;
+    if (stop_reason) *stop_reason = (int)r;
+    return 0;
+  });
+}
+int dshs_trajectory(dshs_solver* s, double* t_host, double* y_host) {
+  return guarded([&]() {
+    if (s->traj_t.empty()) throw LaError(DSH_E_INVALID, "no trajectory stored (call dshs_solve with keep_trajectory=1)");
+    std::memcpy(t_host, s->traj_t.data(), s->traj_t.size() * sizeof(double));
+    // device layout [col][row][b] -> host [col][b][row]
+    const int64_t n = s->traj_y.nrows(), nb = s->traj_y.nb();
+    for (int64_t c = 0; c < s->traj_y.ncols(); ++c)
+      check(dsh_vec_download(s->ctx.raw(), n, nb, s->traj_y.column(c).p, y_host + (size_t)(c * n * nb)), "trajectory download");
+    return 0;
+  });
+}
+
+int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int* stop_reason) {
+  return guarded([&]() {
+    std::vector<double> te(t_eval, t_eval + nt);
+    HipMat ret;
+    OdeSolverStopReason r = s->solver->solve_dense(te, ret);
+    const int64_t n = ret.nrows(), nb = ret.nb();
+    if (y_dev) check(dsh_d2d(s->ctx.raw(), y_dev, ret.ptr(), (int64_t)sizeof(double) * n * nb * ret.ncols()), "solve_dense d2d");
+    if (y_host)
+      for (int64_t c = 0; c < ret.ncols(); ++c) check(dsh_vec_download(s->ctx.raw(), n, nb, ret.column(c).p, y_host + (size_t)(c * n * nb)), "solve_dense download");
+    s->ctx.sync();
+    if (stop_reason) *stop_reason = (int)r;
+    return 0;
+  });
+}
+
+}  // extern "C"

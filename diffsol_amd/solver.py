@@ -1,0 +1,152 @@
+"""Python handle on the host-side integrators (include/diffsol_hip_solver.h): the harness tests and bench.py drive
+`OdeBuilder ... .bdf() / .tr_bdf2() / .esdirk34()` through, mirroring the reference's user API
+(crates/diffsol/src/ode_solver/builder.rs, problem.rs, method.rs)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DiffsolHipError, DshsOptions, check, vp
+
+METHOD_BDF, METHOD_TR_BDF2, METHOD_ESDIRK34 = 0, 1, 2
+
+MODELS = {
+    "exponential_decay": 0, "exponential_decay_with_algebraic": 1, "exponential_decay_with_algebraic_batched": 2, "robertson_ode": 3,
+    "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9,
+}
+
+STAT_NAMES = [
+    "number_of_linear_solver_setups", "number_of_steps", "number_of_error_test_failures", "number_of_nonlinear_solver_iterations",
+    "number_of_nonlinear_solver_fails", "number_of_linear_solver_setups_from_checkpoint",
+    "number_of_linear_solver_setups_from_first_convergence_fail", "number_of_linear_solver_setups_from_second_convergence_fail",
+    "number_of_linear_solver_setups_from_error_test_fail", "number_of_linear_solver_setups_from_step_success", "number_of_calls",
+    "number_of_jac_muls", "number_of_matrix_evals",
+]
+
+STOP_INTERNAL_TIMESTEP, STOP_ROOT_FOUND, STOP_TSTOP_REACHED = 0, 1, 2
+
+
+class Solver:
+    """One (batched, lock-step) solver instance on one GPU."""
+
+    def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, device=0, stream=None,
+                 fused=True, block_threads=0, options=None):
+        L = _ffi.load_host_lib()
+        self._L = L
+        if isinstance(model, str):
+            model = MODELS[model]
+        p = np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1))
+        a = np.ascontiguousarray(np.asarray(atol, dtype=np.float64).reshape(-1))
+        o = DshsOptions()
+        L.dshs_default_options(C.byref(o))
+        o.use_fused_kernels = 1 if fused else 0
+        o.block_threads = int(block_threads)
+        for k, v in (options or {}).items():
+            setattr(o, k, v)
+        h = vp()
+        rc = L.dshs_create(device, stream, model, model_size, nbatch, p.ctypes.data_as(_ffi.c_dp), p.size, rtol, a.ctypes.data_as(_ffi.c_dp), a.size,
+                           t0, h0, method, C.byref(o), C.byref(h))
+        check(rc, host=True)
+        self._h = h
+        self.n = int(L.dshs_nstates(h))
+        self.nbatch = int(L.dshs_nbatch(h))
+        self.fused = bool(L.dshs_is_fused(h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.dshs_destroy(self._h)
+            self._h = None
+
+    def step(self):
+        r = C.c_int()
+        check(self._L.dshs_step(self._h, C.byref(r)), host=True)
+        return r.value
+
+    def set_stop_time(self, t):
+        check(self._L.dshs_set_stop_time(self._h, t), host=True)
+
+    def state(self):
+        t, h, order = C.c_double(), C.c_double(), C.c_int()
+        y = np.empty((self.nbatch, self.n))
+        dy = np.empty((self.nbatch, self.n))
+        check(self._L.dshs_get_state(self._h, C.byref(t), C.byref(h), C.byref(order), y.ctypes.data_as(_ffi.c_dp), dy.ctypes.data_as(_ffi.c_dp)), host=True)
+        return dict(t=t.value, h=h.value, order=order.value, y=y, dy=dy)
+
+    def scalars(self):
+        t, h, order = C.c_double(), C.c_double(), C.c_int()
+        check(self._L.dshs_get_state(self._h, C.byref(t), C.byref(h), C.byref(order), None, None), host=True)
+        return t.value, h.value, order.value
+
+    def diff(self):
+        out = np.empty((self.nbatch, 8, self.n))
+        check(self._L.dshs_bdf_get_diff(self._h, out.ctypes.data_as(_ffi.c_dp)), host=True)
+        return out
+
+    def interpolate(self, t):
+        y = np.empty((self.nbatch, self.n))
+        check(self._L.dshs_interpolate(self._h, t, y.ctypes.data_as(_ffi.c_dp)), host=True)
+        return y
+
+    def root_info(self):
+        t, i = C.c_double(), C.c_int()
+        self._L.dshs_root_info(self._h, C.byref(t), C.byref(i))
+        return t.value, i.value
+
+    def stats(self):
+        out = (C.c_int64 * 13)()
+        self._L.dshs_stats(self._h, out)
+        return dict(zip(STAT_NAMES, [int(v) for v in out]))
+
+    def solve_to_points(self, t_points):
+        tp = np.ascontiguousarray(t_points, dtype=np.float64)
+        out = np.empty((tp.size, self.nbatch, self.n))
+        rc = check(self._L.dshs_solve_to_points(self._h, tp.ctypes.data_as(_ffi.c_dp), tp.size, out.ctypes.data_as(_ffi.c_dp)), host=True)
+        return out, rc
+
+    def solve(self, t_final, keep_trajectory=False):
+        y = np.empty((self.nbatch, self.n))
+        ncols, reason = C.c_int64(), C.c_int()
+        check(self._L.dshs_solve(self._h, t_final, 1 if keep_trajectory else 0, y.ctypes.data_as(_ffi.c_dp), C.byref(ncols), C.byref(reason)), host=True)
+        if keep_trajectory:
+            ts = np.empty(ncols.value)
+            ys = np.empty((ncols.value, self.nbatch, self.n))
+            check(self._L.dshs_trajectory(self._h, ts.ctypes.data_as(_ffi.c_dp), ys.ctypes.data_as(_ffi.c_dp)), host=True)
+            return y, int(ncols.value), reason.value, ts, ys
+        return y, int(ncols.value), reason.value
+
+    def solve_dense(self, t_eval, want_host=True, dev_ptr=None):
+        te = np.ascontiguousarray(t_eval, dtype=np.float64)
+        out = np.empty((te.size, self.nbatch, self.n)) if want_host else None
+        reason = C.c_int()
+        check(self._L.dshs_solve_dense(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, out.ctypes.data_as(_ffi.c_dp) if want_host else None,
+                                       vp(dev_ptr) if dev_ptr else None, C.byref(reason)), host=True)
+        return out, reason.value
+
+
+class OdeBuilder:
+    """OdeBuilder (crates/diffsol/src/ode_solver/builder.rs:22-146): fluent problem description; `.bdf()` etc. create the solver."""
+
+    def __init__(self):
+        self._kw = dict(rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, nbatch=1, model_size=0)
+        self._model = None
+        self._p = []
+
+    def t0(self, v): self._kw["t0"] = v; return self
+    def h0(self, v): self._kw["h0"] = v; return self
+    def rtol(self, v): self._kw["rtol"] = v; return self
+    def atol(self, v): self._kw["atol"] = tuple(np.atleast_1d(v)); return self
+    def p(self, v): self._p = v; return self
+    def nbatch(self, v): self._kw["nbatch"] = v; return self
+    def device(self, v): self._kw["device"] = v; return self
+    def stream(self, v): self._kw["stream"] = v; return self
+    def fused(self, v): self._kw["fused"] = v; return self
+    def options(self, **kw): self._kw["options"] = kw; return self
+
+    def model(self, name, size=0):
+        self._model = name
+        self._kw["model_size"] = size
+        return self
+
+    def bdf(self): return Solver(self._model, self._p, method=METHOD_BDF, **self._kw)
+    def tr_bdf2(self): return Solver(self._model, self._p, method=METHOD_TR_BDF2, **self._kw)
+    def esdirk34(self): return Solver(self._model, self._p, method=METHOD_ESDIRK34, **self._kw)

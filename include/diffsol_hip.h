@@ -1,0 +1,218 @@
+/*
+ * diffsol_hip.h — C ABI of libdiffsol_hip.so: the MI355X (gfx950) device backend for diffsol's
+ * batched implicit ODE/DAE hot path.
+ *
+ * This is the drop-in boundary: every entry point is what a Rust `HipContext / HipVec / HipMat / HipLU`
+ * backend crate (implementing diffsol's Context / Vector / Matrix / LinearSolver traits) would bind through
+ * `extern "C"`; INTEGRATION.md shows the Rust-side stubs.  Each declaration cites the reference interface it
+ * replaces (paths relative to the reference checkout, crates/...).
+ *
+ * Conventions
+ *  - All data is f64 on the device (reference: f64-only CUDA kernels, diffsol-la/src/cuda_kernels/all.cu:2-28).
+ *  - A "batched vector" holds `n` states for each of `nbatch` independent systems.  DEVICE LAYOUT IS
+ *    BATCH-FASTEST (structure of arrays): element i of system b lives at  p[i*nbatch + b].  The reference API
+ *    layout is batch-major ([b0 states..., b1 states...], diffsol-la/src/vector/cuda.rs:119-125); conversion
+ *    happens only in dsh_vec_upload / dsh_vec_download, so `from_vec` / `clone_as_vec` keep their semantics.
+ *    Matrices are column-major per system with the same batch-fastest rule: A_b(i,j) at p[(j*nrows+i)*nbatch + b],
+ *    hence column j of a batched matrix is itself a contiguous batched vector (views are pointer offsets).
+ *  - An operand may have nbatch 1 (broadcast, diffsol-la/src/context/mod.rs:24-26): it is then a plain
+ *    contiguous array of n doubles.  Every operand is passed as (pointer, operand_nbatch) with
+ *    operand_nbatch in {1, nbatch}.
+ *  - Return value: 0 = DSH_OK, negative = error (message: dsh_last_error(), thread-local like
+ *    diffsol-c/src/error_c.rs:12-121).  Shape / nbatch mismatches that panic in the reference return
+ *    DSH_E_INVALID.  Reductions are blocking (they synchronise the context's stream), like the reference
+ *    (diffsol-la/src/vector/cuda.rs:100-115).
+ *  - One host thread per context; all work is issued in order on the context's HIP stream.
+ */
+#ifndef DIFFSOL_HIP_H
+#define DIFFSOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSH_OK 0
+#define DSH_E_INVALID (-1)        /* bad shape / nbatch / argument (reference: panic) */
+#define DSH_E_HIP (-2)            /* HIP runtime error */
+#define DSH_E_SINGULAR (-3)       /* LU solve met a zero pivot (reference: LaError::LuSolveFailed) */
+#define DSH_E_NOT_SETUP (-4)      /* LU used before factorisation (reference: LuNotInitialized) */
+#define DSH_E_BATCH_MISMATCH (-5) /* root finding results differ across batches (reference panics, vector/cuda.rs:1166-1171) */
+#define DSH_E_UNSUPPORTED (-6)
+
+typedef struct dsh_ctx dsh_ctx; /* device + stream + reduction scratch;   replaces CudaContext, diffsol-la/src/context/cuda.rs:41-144 */
+typedef struct dsh_lu dsh_lu;   /* batched LU factors + pivots;            replaces CudaLU,      diffsol-la/src/linear_solver/cuda/lu.rs:15-57 */
+
+const char* dsh_last_error(void);
+int dsh_version(void);
+
+/* ---- context (Context trait: diffsol-la/src/context/mod.rs:20-68; CudaContext::new context/cuda.rs:48-68) ---- */
+/* stream == NULL: the context creates and owns a non-blocking stream; otherwise it borrows the caller's hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream). */
+int dsh_ctx_create(int device, void* stream, dsh_ctx** out);
+void dsh_ctx_destroy(dsh_ctx* ctx);
+int dsh_ctx_sync(dsh_ctx* ctx);
+void* dsh_ctx_stream(dsh_ctx* ctx);
+int dsh_ctx_device(dsh_ctx* ctx);
+/* threads per workgroup for one-lane-per-system kernels (default 64; tuning knob, power of two in [64,1024]) */
+int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
+
+/* ---- device memory (cudarc alloc/alloc_zeros/memcpy_*: call sites throughout vector/cuda.rs, matrix/cuda.rs) ---- */
+int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out);
+int dsh_free(dsh_ctx* ctx, void* p);
+int dsh_memset_zero(dsh_ctx* ctx, void* p, int64_t nbytes);
+int dsh_h2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes); /* blocking */
+int dsh_d2h(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes); /* blocking */
+int dsh_d2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes); /* stream-ordered */
+/* Vector::from_vec / clone_as_vec (vector/cuda.rs:741-760, :888-906): host data is batch-major [b][i]; device is [i][b]. */
+int dsh_vec_upload(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* host_batch_major, double* dev);
+int dsh_vec_download(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* dev, double* host_batch_major);
+/* Vector::get_index / set_index (vector/cuda.rs:762-779): one element of one batch member */
+int dsh_vec_get_index(dsh_ctx* ctx, int64_t nbatch, const double* v, int64_t i, int64_t b, double* out);
+int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_t b, double value);
+/* set element i of EVERY batch member to `value` (the reference does nbatch H2D copies for this, vector/cuda.rs:762-774) */
+int dsh_vec_set_index_all(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, double value);
+
+/* ---- Vector ops.  n = states per system, nbatch = context batch size.  Kernel each one replaces in parentheses. ---- */
+/* ret = lhs + rhs / lhs - rhs                       (vec_add.cu:1, vec_sub.cu:1; vector/cuda.rs:439-484) */
+int dsh_vec_add(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* lhs, int64_t lhs_nb, const double* rhs, int64_t rhs_nb, double* ret);
+int dsh_vec_sub(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* lhs, int64_t lhs_nb, const double* rhs, int64_t rhs_nb, double* ret);
+/* lhs += rhs / lhs -= rhs                           (vec_add_assign.cu:1, vec_sub_assign.cu:1; vector/cuda.rs:396-436) */
+int dsh_vec_add_assign(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* lhs, const double* rhs, int64_t rhs_nb);
+int dsh_vec_sub_assign(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* lhs, const double* rhs, int64_t rhs_nb);
+/* lhs *= rhs / lhs /= rhs elementwise               (vec_mul_assign.cu:1, vec_div_assign.cu:1; vector/cuda.rs:1019-1070) */
+int dsh_vec_mul_assign(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* lhs, const double* rhs, int64_t rhs_nb);
+int dsh_vec_div_assign(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* lhs, const double* rhs, int64_t rhs_nb);
+/* v *= s ; res = v*s                                (vec_mul_assign_scalar.cu:1, vec_mul_scalar.cu:1; vector/cuda.rs:267-387) */
+int dsh_vec_mul_assign_scalar(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, double s);
+int dsh_vec_mul_scalar(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, double s, double* res);
+/* y = alpha*x + beta*y                              (vec_axpy.cu:1; vector/cuda.rs:937-966, :1459-1489) */
+int dsh_vec_axpy(dsh_ctx* ctx, int64_t n, int64_t nbatch, double alpha, const double* x, int64_t x_nb, double beta, double* y);
+/* y_b = alpha[b]*x_b + beta*y_b, alpha is a HOST array of nbatch values (vec_batched_axpy.cu:4; vector/cuda.rs:967-1012) */
+int dsh_vec_batched_axpy(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* alpha_host, const double* x, int64_t x_nb, double beta, double* y);
+/* dst = src (broadcast if src_nb==1) ; v = value    (vec_copy.cu:1, vec_fill.cu:1; vector/cuda.rs:208-236, :867-886) */
+int dsh_vec_copy(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* src, int64_t src_nb, double* dst);
+int dsh_vec_fill(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, double value);
+/* index ops; idx = DEVICE int32 array shared by all batch members (vec_gather.cu:2, vec_scatter.cu:2,
+ * vec_copy_from_indices.cu:2, vec_assign_at_indices.cu:2; vector/cuda.rs:1179-1284)
+ *   gather:             dst[k]      = src[idx[k]]   k < nidx   (dst has nidx states, src has n_src states)
+ *   scatter:            dst[idx[k]] = src[k]        k < nidx   (src has nidx states, dst has n_dst states)
+ *   copy_from_indices:  dst[idx[k]] = src[idx[k]]              (both have n states)
+ *   assign_at_indices:  dst[idx[k]] = value                                                              */
+int dsh_vec_gather(dsh_ctx* ctx, int64_t n_src, int64_t nbatch, const double* src, const int32_t* idx, int64_t nidx, double* dst);
+int dsh_vec_scatter(dsh_ctx* ctx, int64_t n_dst, int64_t nbatch, const double* src, const int32_t* idx, int64_t nidx, double* dst);
+int dsh_vec_copy_from_indices(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* src, const int32_t* idx, int64_t nidx, double* dst);
+int dsh_vec_assign_at_indices(dsh_ctx* ctx, int64_t n, int64_t nbatch, const int32_t* idx, int64_t nidx, double value, double* dst);
+/* max_b (sum_i |x_i|^k)^(1/k)                       (vec_norm.cu:11, vec_norm_lk.cu:8, cublasDnrm2; vector/cuda.rs:71-116, :781-799) */
+int dsh_vec_norm(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* x, int k, double* out_max);
+/* max_b mean_i (x_i / (|y_i|*rtol + atol_i))^2      (vec_squared_norm.cu:13; vector/cuda.rs:1362-1433).
+ * NaN lanes PROPAGATE to the result (the reference's host-side `>` max drops them; its CPU path returns NaN).
+ * per_batch_dev (optional, device array of nbatch doubles) receives each system's own value — the hook for per-lane control. */
+int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* x, const double* y, int64_t y_nb, const double* atol,
+                         int64_t atol_nb, double rtol, double* out_max, double* per_batch_dev);
+/* Vector::root_finding (vec_root_finding.cu:11; vector/cuda.rs:1071-1178): per batch member, found = any g1_i == 0,
+ * frac = max over sign changes of |g1_i/(g1_i-g0_i)|, idx = its argmax or -1.  Returns batch 0's triple and
+ * DSH_E_BATCH_MISMATCH if (found, idx) is not identical for all batch members. */
+int dsh_vec_root_finding(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* g0, const double* g1, int* found, double* frac, int* idx);
+
+/* ---- Matrix / DenseMatrix ops (matrix/cuda.rs:848-1468) ---- */
+/* mat = diag(v) (n x n) ; v = diag(mat)             (mat_from_diagonal.cu:2, mat_get_diagonal.cu:2; matrix/cuda.rs:129-160, :1333-1365) */
+int dsh_mat_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t v_nb, double* mat);
+int dsh_mat_get_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* mat, double* v);
+/* column j of mat (nrows x ncols) = v               (mat_set_column.cu:2; matrix/cuda.rs:1389-1421) */
+int dsh_mat_set_column(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double* mat, int64_t j, const double* v, int64_t v_nb);
+/* self = x + beta*y over nelem = nrows*ncols entries (mat_scale_add_assign.cu:1; matrix/cuda.rs:1424-1458) — the M - cJ assembly */
+int dsh_mat_scale_add_assign(dsh_ctx* ctx, int64_t nelem, int64_t nbatch, double* self, const double* x, int64_t x_nb, double beta,
+                             const double* y, int64_t y_nb);
+/* self[dst_idx[k]] = data[src_idx[k]]               (mat_set_data_with_indices.cu:2; matrix/cuda.rs:1137-1174) */
+int dsh_mat_set_data_with_indices(dsh_ctx* ctx, int64_t nelem_self, int64_t nelem_data, int64_t nbatch, double* self, const int32_t* dst_idx,
+                                  const int32_t* src_idx, int64_t nidx, const double* data);
+/* column i += alpha * column j                       (vec_axpy_offset.cu:1; matrix/cuda.rs:1048-1088) */
+int dsh_mat_column_axpy(dsh_ctx* ctx, int64_t nrows, int64_t nbatch, double* mat, double alpha, int64_t j, int64_t i);
+/* y = alpha*A*x + beta*y, A nrows x ncols            (cublasDgemv host loop over batches; matrix/cuda.rs:620-677, :1267-1293) */
+int dsh_mat_gemv(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double alpha, const double* a, int64_t a_nb, const double* x,
+                 int64_t x_nb, double beta, double* y);
+/* C = alpha*A*B + beta*C, A m x k, B k x n, C m x n  (cublasDgemmStridedBatched, stride 0 = broadcast; matrix/cuda.rs:757-822, :960) */
+int dsh_mat_gemm(dsh_ctx* ctx, int64_t m, int64_t n, int64_t k, int64_t nbatch, double alpha, const double* a, int64_t a_nb, const double* b,
+                 int64_t b_nb, double beta, double* c);
+
+/* ---- LinearSolver (diffsol-la/src/linear_solver/mod.rs:19-42; CudaLU linear_solver/cuda/lu.rs:59-191) ---- */
+/* set_sparsity: allocate n*n*nbatch factors + n*nbatch int32 pivots (lu.rs:148-190) */
+int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out);
+void dsh_lu_destroy(dsh_lu* lu);
+/* set_linearisation after op.matrix_inplace: partial-pivot LU of all nbatch systems in ONE launch
+ * (replaces the serial `for b in 0..nbatch { cusolverDnDgetrf }` loop, lu.rs:80-95).  `a` (n*n*nbatch, device) is not modified. */
+int dsh_lu_factor(dsh_lu* lu, const double* a);
+/* solve_in_place, nrhs = 1, all systems in ONE launch (replaces the getrs host loop, lu.rs:127-145) */
+int dsh_lu_solve(const dsh_lu* lu, double* b);
+/* number of systems whose factorisation met an exactly-zero pivot (cusolver `info`, ignored by the reference lu.rs:83-95); blocking */
+int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular);
+double* dsh_lu_factors(dsh_lu* lu);
+int32_t* dsh_lu_pivots(dsh_lu* lu);
+
+/* ---- Model registry: the OdeEquations plug-in boundary (diffsol/src/ode_equations/mod.rs:245-329; NonLinearOp::call_inplace,
+ * NonLinearOpJacobian::{jac_mul_inplace,jacobian_inplace} op/nonlinear_op.rs:10-21,175-221; LinearOp::{gemv_inplace,matrix_inplace}
+ * op/linear_op.rs:9-54).  One lane per system; parameters p are a batched vector of nparams entries (batch-fastest on device). ---- */
+#define DSH_MODEL_EXPONENTIAL_DECAY 0           /* n=2, p=[k,y0]            test_models/exponential_decay.rs:14-81 */
+#define DSH_MODEL_EXPONENTIAL_DECAY_ALGEBRAIC 1 /* n=3, p=[k], init (1,1,0) test_models/exponential_decay_with_algebraic.rs:18-126 */
+#define DSH_MODEL_EXPONENTIAL_DECAY_ALGEBRAIC_BATCHED 2 /* same, init (1,1,1) :202-276 */
+#define DSH_MODEL_ROBERTSON_ODE 3               /* n=3*size, p=[k1,k2,k3]   test_models/robertson_ode.rs:71-101 */
+#define DSH_MODEL_ROBERTSON_DAE 4               /* n=3, M=diag(1,1,0)       test_models/robertson.rs:60-94 */
+#define DSH_MODEL_DYDT_Y2 5                     /* n=size                   test_models/dydt_y2.rs:9-19 */
+#define DSH_MODEL_GAUSSIAN_DECAY 6              /* n=size, p=[a]*size       test_models/gaussian_decay.rs:12-23 */
+#define DSH_MODEL_HEAT1D 7                      /* n=size, p=[D]            test_models/heat1d.rs:16-52, examples/pde-heat/src/main.rs:15-40 */
+#define DSH_MODEL_RLC 8                         /* n=4 DAE, p=[R,L,C,V0,omega,ithresh]; size!=0 adds root iR-ithresh  examples/electrical-circuits/src/main.rs:10-41 */
+#define DSH_MODEL_EXPONENTIAL_DECAY_ROOT 9      /* exponential decay + root x0-0.6  test_models/exponential_decay.rs:98-100 */
+
+int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, int* has_mass, int64_t* nroots);
+int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* y);
+int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, const double* v, double* y);
+int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* jac);
+int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double beta, double* y);
+int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* mass);
+int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* y);
+int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* g);
+
+/* ---- Fused fast paths (optional; results are bit-identical to composing the 1:1 ops above) ---- */
+/* One Newton iteration of the BDF residual F(y) = M(y + (psi - y0)) - c f(y)  (NoLineSearch::take_optimal_step
+ * diffsol-nl/src/line_search.rs:48-69 over BdfCallable::call_inplace diffsol/src/op/bdf.rs:240-256):
+ *   delta = F(y); LU-solve(delta); y -= delta; out[0] = max_b ||delta||^2_(error_y)   (Convergence::norm squared, convergence.rs:64-66)
+ * and, speculatively, the error-test quantity for the step (Bdf::error_control, ode_solver/bdf.rs:826-835, without the error constant):
+ *   out[1] = max_b ||y - error_y||^2_(y_old)      (only if y_old != NULL)
+ * out[2] = number of systems whose solve met a zero pivot (as a double).  out is a HOST array of 3 doubles.  Blocking.
+ * Supported for models with a register-resident specialisation (dsh_model_has_fused). */
+int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, double* y, const double* psi_neg_y0,
+                        const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t atol_nb,
+                        double rtol, double* out);
+/* Same for the SDIRK stage residual F(k) = M k - h f(phi + c k)  (SdirkCallable::call_inplace diffsol/src/op/sdirk.rs:229-244);
+ * out[0] = max_b ||delta||^2_(error_y), out[2] = singular count. */
+int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double h, double c, double* k, const double* phi,
+                          const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t atol_nb, double rtol,
+                          double* out);
+/* Jacobian refresh: [rhs_jac = J(x,t) if recompute_rhs_jac; mass_jac = M(t) if the model has a mass matrix];
+ * A = mass_jac + (-c)*rhs_jac; LU-factor A into `lu` — one launch, A never touches HBM
+ * (BdfCallable::jacobian_inplace op/bdf.rs:273-300 + CudaLU::set_linearisation lu.rs:59-97). */
+int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, const double* x, const double* p,
+                   int recompute_rhs_jac, double* rhs_jac, double* mass_jac, dsh_lu* lu);
+int dsh_model_has_fused(int model, int64_t size);
+/* BDF step preparation, one launch (Bdf::_update_diff_for_step_size ode_solver/bdf.rs:568-577, _predict_using_diff :667-672,
+ * BdfCallable::set_psi_and_y0 op/bdf.rs:182-210):
+ *   if ru_host != NULL: diff_tmp[:,0..=order] = diff[:,0..=order] * RU  (RU is (order+1)^2 column-major on the HOST; caller swaps
+ *   diff/diff_tmp afterwards exactly like the reference) and the prediction uses the rescaled columns;
+ *   y_predict = sum_{i<=order} D[:,i];  psi_neg_y0 = alpha*(sum_{1<=i<=order} gamma_i D[:,i]) - y_predict.
+ * gamma_host has order+1 entries. */
+int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, const double* diff, double* diff_tmp, const double* ru_host,
+                         const double* gamma_host, double alpha, double* y_predict, double* psi_neg_y0);
+/* BDF accepted-step update, one launch (Bdf::_update_diff :646-664, state update :1472-1478, predict_error_control :871-900):
+ *   d = y_new - y_predict; D[:,k+2] = d - D[:,k+1]; D[:,k+1] = d; D[:,i] += D[:,i+1] for i=k..0; y = y_predict; dy = D[:,1]/h;
+ *   out[0] = max_b ||D[:,k]||^2_(y)   (order-1 candidate, 0 if k==1), out[1] = max_b ||D[:,k+2]||^2_(y) (order+1 candidate).
+ * out is a HOST array of 2 doubles, filled only if want_norms != 0 (then blocking). */
+int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, const double* y_predict,
+                        const double* y_new, double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, int want_norms,
+                        double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSOL_HIP_H */

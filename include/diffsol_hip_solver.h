@@ -1,0 +1,84 @@
+/*
+ * diffsol_hip_solver.h — C ABI of libdiffsol_hip_host.so: the host-side integrators (OdeBuilder -> problem -> .bdf() / .tr_bdf2() /
+ * .esdirk34() -> OdeSolverMethod) running on the HIP backend of diffsol_hip.h.
+ *
+ * In a deployment with a Rust toolchain this layer is diffsol itself (its generic Bdf / Sdirk instantiated with HipMat / HipLU, see
+ * INTEGRATION.md); this environment has no rustc, so the same control flow is provided in C++ (the headers under diffsol_amd/host mirror
+ * crates/diffsol/src/ode_solver/{bdf,sdirk,runge_kutta,state,method}.rs and crates/diffsol-nl) and exported here in the style of the
+ * reference's own C wrapper (crates/diffsol-c/src/ode_c.rs, error convention crates/diffsol-c/src/error_c.rs:12-121).
+ * All host arrays are batch-major ([b][state]) like the reference API.  Return 0 on success, negative on error (dshs_last_error()).
+ */
+#ifndef DIFFSOL_HIP_SOLVER_H
+#define DIFFSOL_HIP_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dshs_solver dshs_solver;
+
+#define DSHS_METHOD_BDF 0      /* OdeSolverProblem::bdf       crates/diffsol/src/ode_solver/problem.rs:649-655 */
+#define DSHS_METHOD_TR_BDF2 1  /* OdeSolverProblem::tr_bdf2   problem.rs:839-861 (sdirk_solver_from_tableau!) */
+#define DSHS_METHOD_ESDIRK34 2 /* OdeSolverProblem::esdirk34 */
+
+#define DSHS_STOP_INTERNAL_TIMESTEP 0 /* OdeSolverStopReason, crates/diffsol/src/ode_solver/method.rs:22-40 */
+#define DSHS_STOP_ROOT_FOUND 1
+#define DSHS_STOP_TSTOP_REACHED 2
+
+/* OdeSolverOptions + InitialConditionSolverOptions (crates/diffsol/src/ode_solver/problem.rs:15-152).  Negative / NaN = keep default. */
+typedef struct {
+  int max_nonlinear_solver_iterations; /* 10 */
+  int max_error_test_failures;         /* 40 */
+  int max_nonlinear_solver_failures;   /* 50 */
+  double nonlinear_solver_tolerance;   /* 0.2 */
+  double min_timestep;                 /* 1e-13 */
+  int update_jacobian_after_steps;     /* 20 */
+  int update_rhs_jacobian_after_steps; /* 50 */
+  double threshold_to_update_jacobian;     /* 0.3 */
+  double threshold_to_update_rhs_jacobian; /* 0.2 */
+  int ic_use_linesearch;               /* 1 */
+  int use_fused_kernels;               /* 1: fused device kernels where the model provides them; 0: 1:1 trait ops only */
+  int block_threads;                   /* 0 = default (64) */
+} dshs_options;
+
+const char* dshs_last_error(void);
+void dshs_default_options(dshs_options* opts);
+
+/* OdeBuilder::new().t0().h0().rtol().atol().p().context(ctx.with_nbatch(nbatch)).build() + problem.<method>()  (builder.rs:1784-1893).
+ * params: batch-major, nparams per batch member.  atol: 1 or nstates entries.  stream: NULL or a hipStream_t to run on. */
+int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
+                const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, dshs_solver** out);
+void dshs_destroy(dshs_solver* s);
+
+int64_t dshs_nstates(const dshs_solver* s);
+int64_t dshs_nbatch(const dshs_solver* s);
+int dshs_is_fused(const dshs_solver* s);
+
+/* OdeSolverMethod::step / set_stop_time / interpolate / state  (method.rs:42-198) */
+int dshs_step(dshs_solver* s, int* stop_reason);
+int dshs_set_stop_time(dshs_solver* s, double tstop);
+int dshs_interpolate(dshs_solver* s, double t, double* y_host);
+int dshs_get_state(dshs_solver* s, double* t, double* h, int* order, double* y_host, double* dy_host);
+int dshs_root_info(dshs_solver* s, double* t_root, int* root_index);
+/* BDF only: difference array D as [b][col(8)][row] */
+int dshs_bdf_get_diff(dshs_solver* s, double* diff_host);
+/* out[0..10) OdeSolverStatistics in declaration order (ode_solver/mod.rs:28-69); out[10..13) rhs OpStatistics calls / jac_muls / matrix_evals */
+int dshs_stats(dshs_solver* s, int64_t* out);
+
+/* The reference's known-answer harness (crates/diffsol/src/ode_solver/mod.rs:104-194, use_tstop = false): for each point step until
+ * |t| >= |t_point| and interpolate there.  y_host: [npoints][b][state].  Returns 1 if a root stopped the solve. */
+int dshs_solve_to_points(dshs_solver* s, const double* t_points, int64_t npoints, double* y_host);
+/* OdeSolverMethod::solve (method.rs:227-258): integrate to final_time; writes the final state.y (host, batch-major) and the number of
+ * output columns; the trajectory matrix is kept on the device when keep_trajectory != 0 (fetch with dshs_trajectory). */
+int dshs_solve(dshs_solver* s, double final_time, int keep_trajectory, double* y_final_host, int64_t* ncols, int* stop_reason);
+int dshs_trajectory(dshs_solver* s, double* t_host, double* y_host /* [col][b][state] */);
+/* OdeSolverMethod::solve_dense (method.rs:467-520): interpolated output at t_eval.  y_host ([nt][b][state]) and/or y_dev (DEVICE pointer,
+ * [nt][state][b] batch-fastest — the buffer the multi-GPU gather concatenates along the batch axis) may be NULL. */
+int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int* stop_reason);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSOL_HIP_SOLVER_H */
