@@ -1,0 +1,80 @@
+"""Multi-GPU ensembles: one process per GPU, contiguous shards of the ensemble, no data-path collective during integration.
+
+The reference has no distributed layer (no NCCL/MPI/threads); systems of an ensemble are independent, so the ensemble
+partitions trivially: rank g integrates systems [g*N/G, (g+1)*N/G) with its own lock-step (t, h, order) sequence on its own GPU
+and stream.  The only exchange is the final trajectory collection: one all-gather (RCCL over xGMI; `gloo` in the CPU tests) of the
+`solve_dense` output along the batch axis.  torch.distributed is used purely as the collective transport.
+"""
+import numpy as np
+
+
+def shard_bounds(n_total, rank, world):
+    """Contiguous range [lo, hi) of ensemble members owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(n_total), int(world))
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def max_shard(n_total, world):
+    return (int(n_total) + int(world) - 1) // int(world)
+
+
+def gather_batch_axis(local, n_total, rank, world, group=None):
+    """All-gather `local` ([..., nb_local], batch-fastest like the device layout) along its last axis into [..., n_total] on every rank.
+
+    Shards may differ in size by one: each rank pads to the maximum shard size, one all_gather_into_tensor moves the data, the padding is
+    dropped on the way out.  `local` may be a CUDA tensor (RCCL) or a CPU tensor (gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    lo, hi = shard_bounds(n_total, rank, world)
+    assert local.shape[-1] == hi - lo, (local.shape, lo, hi)
+    if world == 1:
+        return local
+    m = max_shard(n_total, world)
+    lead = tuple(local.shape[:-1])
+    padded = local.new_zeros(lead + (m,))
+    padded[..., : hi - lo] = local
+    flat_in = padded.contiguous().view(-1)
+    flat_out = local.new_empty(world * flat_in.numel())  # 1-D in / 1-D out is accepted by both RCCL and gloo
+    dist.all_gather_into_tensor(flat_out, flat_in, group=group)
+    out = flat_out.view((world,) + lead + (m,))
+    pieces = []
+    for r in range(world):
+        l, h = shard_bounds(n_total, r, world)
+        pieces.append(out[r][..., : h - l])
+    return torch.cat(pieces, dim=-1)
+
+
+def solve_ensemble_sharded(model, params, t_eval, *, rank, world, device, method=0, model_size=0, gather=True, group=None, solver_factory=None,
+                           **solver_kw):
+    """Integrate this rank's shard of the ensemble and (optionally) gather the interpolated trajectories.
+
+    params: [n_total, nparams] on every rank (the parameter sweep is generated deterministically from a seed, so nothing is scattered).
+    Returns (y, stats) with y a torch tensor [nt, nstates, n_total] if gather else [nt, nstates, nb_local] (batch-fastest)."""
+    import torch
+
+    params = np.asarray(params, dtype=np.float64)
+    n_total = params.shape[0]
+    lo, hi = shard_bounds(n_total, rank, world)
+    if solver_factory is None:
+        from .solver import Solver
+
+        def solver_factory(p_local):
+            return Solver(model, p_local, nbatch=p_local.shape[0], model_size=model_size, method=method, device=device, **solver_kw)
+
+    s = solver_factory(params[lo:hi])
+    nt = len(t_eval)
+    on_gpu = torch.cuda.is_available() and not getattr(s, "cpu_stub", False)
+    if on_gpu:
+        out = torch.empty((nt, s.n, hi - lo), dtype=torch.float64, device=f"cuda:{device}")
+        s.solve_dense(t_eval, want_host=False, dev_ptr=out.data_ptr())
+        torch.cuda.synchronize(device)
+    else:
+        y_host, _ = s.solve_dense(t_eval)  # [nt, nb, n]
+        out = torch.from_numpy(np.ascontiguousarray(np.transpose(y_host, (0, 2, 1))))
+    stats = s.stats()
+    if gather:
+        out = gather_batch_axis(out, n_total, rank, world, group=group)
+    return out, stats

@@ -1,0 +1,220 @@
+"""GPU parity tests: batched LU (row a5), model registry (row a16) and the fused kernels (rows a7, a9-a11) against the CPU oracle and
+against compositions of the 1:1 trait ops.  Integer/bit-level equality wherever the arithmetic order is identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import ORACLE_MODEL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import diffsol_amd
+    return diffsol_amd
+
+
+@pytest.fixture(scope="module")
+def ctx1(H):
+    return H.HipContext(0, nbatch=1)
+
+
+@pytest.mark.parametrize("n,nb", [(1, 5), (2, 2), (3, 1), (3, 1000), (4, 67), (5, 64), (8, 129), (12, 33), (42, 70)])
+def test_lu_factor_and_solve_match_oracle_bitwise(H, O, ctx1, n, nb):
+    rng = np.random.default_rng(n * 100 + nb)
+    c = ctx1.clone_with_nbatch(nb)
+    a = rng.standard_normal((nb, n, n))
+    a[:, 0, 0] *= 1e-6  # force pivoting
+    b = rng.standard_normal((nb, n))
+    lu = H.HipLU(c, n)
+    lu.factor(H.HipMat.from_array(a, c))
+    x = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x)
+    x_ref, lu_ref, piv_ref, rc = O.lu_solve(a, b)
+    assert rc == 0 and lu.n_singular() == 0
+    got_lu, got_piv = lu.factors()
+    assert np.array_equal(got_piv, piv_ref)
+    assert np.array_equal(got_lu, lu_ref)
+    assert np.array_equal(x.clone_as_vec(), x_ref)
+    assert np.allclose(np.einsum("bij,bj->bi", a, x_ref), b, atol=1e-6)
+
+
+def test_lu_reference_diagonal_kat_and_singular_reporting(H, ctx1):
+    """2x2 diagonal solve incl. the batched variant (diffsol/src/linear_solver/mod.rs:283-321); zero pivot -> LuSolveFailed."""
+    c2 = ctx1.clone_with_nbatch(2)
+    a = np.array([[[2.0, 0.0], [0.0, 2.0]], [[4.0, 0.0], [0.0, 4.0]]])
+    lu = H.HipLU(c2, 2)
+    lu.factor(H.HipMat.from_array(a, c2))
+    x = H.HipVec.from_vec([[2.0, 4.0], [2.0, 4.0]], c2)
+    lu.solve_in_place(x)
+    assert x.clone_as_vec().tolist() == [[1.0, 2.0], [0.5, 1.0]]
+    a[1] = [[1.0, 2.0], [2.0, 4.0]]
+    lu.factor(H.HipMat.from_array(a, c2))
+    assert lu.n_singular() == 1
+    with pytest.raises(H.DiffsolHipError) as e:
+        lu.solve_in_place(H.HipVec.from_vec([[1.0, 1.0], [1.0, 1.0]], c2))
+    assert e.value.code == -3
+    unfactored = H.HipLU(c2, 2)
+    with pytest.raises(H.DiffsolHipError) as e:
+        unfactored.solve_in_place(H.HipVec.zeros(2, c2))
+    assert e.value.code == -4  # LuNotInitialized
+
+
+MODEL_CASES = [("exponential_decay", 0, 2), ("exponential_decay_with_algebraic", 0, 1), ("robertson_ode", 1, 3), ("robertson_ode", 3, 3), ("robertson", 0, 3),
+               ("dydt_y2", 10, 0), ("gaussian_decay", 10, 10), ("heat1d", 16, 1), ("rlc", 0, 6)]
+
+
+@pytest.mark.parametrize("name,size,np_", MODEL_CASES)
+def test_model_rhs_jac_mul_jacobian_match_oracle(H, O, ctx1, name, size, np_):
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb = 37
+    c = ctx1.clone_with_nbatch(nb)
+    mid = H.MODELS[name]
+    n64, p64 = C.c_int64(), C.c_int64()
+    assert L.dsh_model_info(mid, size, C.byref(n64), C.byref(p64), None, None) == 0
+    n = n64.value
+    rng = np.random.default_rng(n + size)
+    x, v = rng.uniform(0.1, 1.0, (nb, n)), rng.standard_normal((nb, n))
+    p = rng.uniform(0.5, 2.0, (nb, max(np_, 1)))[:, :np_]
+    t = 0.7
+    X, Vv, Y = H.HipVec.from_vec(x, c), H.HipVec.from_vec(v, c), H.HipVec.zeros(n, c)
+    P = H.HipVec.from_vec(p, c) if np_ else H.HipVec.zeros(0, c)
+    assert L.dsh_model_rhs(c._h, mid, size, nb, t, X.ptr, P.ptr, Y.ptr) == 0
+    ref = np.stack([O.model_rhs(ORACLE_MODEL[name], x[b], p[b], t, size) for b in range(nb)])
+    tol = 0 if name != "rlc" else 1e-15  # rlc evaluates sin() on the device (ocml) vs libm on the host
+    assert np.array_equal(Y.clone_as_vec(), ref) if tol == 0 else np.allclose(Y.clone_as_vec(), ref, rtol=1e-14, atol=tol)
+    assert L.dsh_model_jac_mul(c._h, mid, size, nb, t, X.ptr, P.ptr, Vv.ptr, Y.ptr) == 0
+    ref = np.stack([O.model_jac_mul(ORACLE_MODEL[name], x[b], p[b], v[b], t, size) for b in range(nb)])
+    assert np.array_equal(Y.clone_as_vec(), ref)
+    J = H.HipMat.zeros(n, n, c)
+    assert L.dsh_model_jacobian(c._h, mid, size, nb, t, X.ptr, P.ptr, J.ptr) == 0
+    jref = np.empty((nb, n, n))
+    for b in range(nb):
+        for j in range(n):
+            e = np.zeros(n); e[j] = 1.0
+            jref[b, :, j] = O.model_jac_mul(ORACLE_MODEL[name], x[b], p[b], e, t, size)
+    assert np.array_equal(J.to_array(), jref)
+    Y0 = H.HipVec.zeros(n, c)
+    assert L.dsh_model_init(c._h, mid, size, nb, 0.0, P.ptr, Y0.ptr) == 0
+    assert Y0.clone_as_vec().shape == (nb, n)
+
+
+def test_bdf_callable_kat_through_trait_ops_and_fused_kernel(H, ctx1, kats):
+    """op/bdf.rs:318-361: F(y) and J = M - c f'(y) for exponential decay, c=0.1, psi_neg_y0=(1.1,1.2), y=(1,1): composed from the 1:1 ops
+    exactly like BdfCallable::call_inplace / jacobian_inplace, and via the fused kernels."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    k = kats["bdf_callable_kat"]
+    mid, c = H.MODELS[k["model"]], k["c"]
+    y, psi, p = H.HipVec.from_vec(k["y"], ctx1), H.HipVec.from_vec(k["psi_neg_y0"], ctx1), H.HipVec.from_vec(k["p"], ctx1)
+    out, tmp = H.HipVec.zeros(2, ctx1), H.HipVec.zeros(2, ctx1)
+    L.dsh_model_rhs(ctx1._h, mid, 0, 1, k["t"], y.ptr, p.ptr, out.ptr)
+    tmp.copy_from(y); tmp.add_assign(psi); out.axpy(1.0, tmp, -c)
+    assert np.allclose(out.clone_as_vec()[0], k["F"], atol=k["tol"])
+    J, A = H.HipMat.zeros(2, 2, ctx1), H.HipMat.zeros(2, 2, ctx1)
+    L.dsh_model_jacobian(ctx1._h, mid, 0, 1, k["t"], y.ptr, p.ptr, J.ptr)
+    A.scale_add_and_assign(H.HipMat.from_diagonal(H.HipVec.from_element(2, 1.0, ctx1)), -c, J)
+    assert A.to_array()[0].tolist() == k["J"]
+    # fused: jac_factor then one Newton iteration solves J delta = F, y -= delta
+    lu = H.HipLU(ctx1, 2)
+    rhs_jac = H.HipMat.zeros(2, 2, ctx1)
+    assert L.dsh_jac_factor(ctx1._h, mid, 0, 1, k["t"], c, y.ptr, p.ptr, 1, rhs_jac.ptr, None, lu._h) == 0
+    assert np.array_equal(rhs_jac.to_array(), J.to_array())
+    atol = H.HipVec.from_vec([1e-6, 1e-6], ctx1)
+    res = (C.c_double * 3)()
+    ynew = y.clone()
+    assert L.dsh_bdf_newton_iter(ctx1._h, mid, 0, 1, k["t"], c, ynew.ptr, psi.ptr, p.ptr, lu._h, y.ptr, y.ptr, atol.ptr, 1, 1e-6, res) == 0
+    delta = np.array(k["F"]) / 1.01
+    assert np.allclose(ynew.clone_as_vec()[0], np.array(k["y"]) - delta, atol=1e-12)
+    w = np.abs(np.array(k["y"])) * 1e-6 + 1e-6
+    assert np.isclose(res[0], np.mean((delta / w) ** 2), rtol=1e-12) and res[2] == 0.0
+
+
+def test_sdirk_callable_and_robertson_jacobian_kats(H, ctx1, kats):
+    """op/sdirk.rs:338-389 (F(k) = k - h f(phi + c k)) and :316-336 (dense Jacobian * v == jac_mul)."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    k = kats["sdirk_callable_kat"]
+    mid = H.MODELS[k["model"]]
+    y, phi, p = H.HipVec.from_vec(k["y"], ctx1), H.HipVec.from_vec(k["phi"], ctx1), H.HipVec.from_vec(k["p"], ctx1)
+    tmp, out = phi.clone(), H.HipVec.zeros(2, ctx1)
+    tmp.axpy(k["c"], y, 1.0)
+    L.dsh_model_rhs(ctx1._h, mid, 0, 1, k["t"], tmp.ptr, p.ptr, out.ptr)
+    out.axpy(1.0, y, -k["h"])
+    assert np.allclose(out.clone_as_vec()[0], k["F"], atol=k["tol"])
+    r = kats["sdirk_robertson_jacobian_kat"]
+    mid = H.MODELS[r["model"]]
+    y, phi, p, v = (H.HipVec.from_vec(r[q], ctx1) for q in ("y", "phi", "p", "v"))
+    tmp = phi.clone()
+    tmp.axpy(r["c"], y, 1.0)
+    J, Mm, A = H.HipMat.zeros(3, 3, ctx1), H.HipMat.zeros(3, 3, ctx1), H.HipMat.zeros(3, 3, ctx1)
+    L.dsh_model_jacobian(ctx1._h, mid, 0, 1, r["t"], tmp.ptr, p.ptr, J.ptr)
+    L.dsh_model_mass_matrix(ctx1._h, mid, 0, 1, r["t"], p.ptr, Mm.ptr)
+    assert Mm.to_array()[0].tolist() == [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]
+    A.scale_add_and_assign(Mm, -(r["c"] * r["h"]), J)
+    Av = H.HipVec.zeros(3, ctx1)
+    A.gemv(1.0, v, 0.0, Av)
+    jv = H.HipVec.zeros(3, ctx1)
+    L.dsh_model_jac_mul(ctx1._h, mid, 0, 1, r["t"], tmp.ptr, p.ptr, v.ptr, jv.ptr)
+    L.dsh_model_mass_gemv(ctx1._h, mid, 0, 1, r["t"], v.ptr, p.ptr, -(r["c"] * r["h"]), jv.ptr)
+    assert np.allclose(Av.clone_as_vec(), jv.clone_as_vec(), atol=r["tol"])
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 5])
+@pytest.mark.parametrize("n,nb", [(3, 1), (3, 130), (7, 65)])
+def test_fused_bdf_prepare_and_accept_match_trait_op_composition(H, ctx1, order, n, nb):
+    """dsh_bdf_prepare_step / dsh_bdf_accept_step vs the reference's op-by-op sequences (bdf.rs:568-577, :646-692, :1472-1478, :871-900)."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    rng = np.random.default_rng(order * 10 + n + nb)
+    c = ctx1.clone_with_nbatch(nb)
+    d = rng.standard_normal((nb, n, 8))
+    gamma = np.concatenate([[0.0], np.cumsum(1.0 / np.arange(1, 6))])
+    alpha = 0.77
+    ru = rng.standard_normal((order + 1, order + 1))
+    D, Dt = H.HipMat.from_array(d, c), H.HipMat.zeros(n, 8, c)
+    yp, psi = H.HipVec.zeros(n, c), H.HipVec.zeros(n, c)
+    ru_cm = np.ascontiguousarray(ru.T)
+    assert L.dsh_bdf_prepare_step(c._h, n, nb, order, D.ptr, Dt.ptr, ru_cm.ctypes.data_as(_ffi.c_dp), gamma.ctypes.data_as(_ffi.c_dp), alpha, yp.ptr, psi.ptr) == 0
+    nd = np.zeros_like(d)
+    for j in range(order + 1):
+        acc = d[:, :, 0] * ru[0, j]
+        for kk in range(1, order + 1):
+            acc = d[:, :, kk] * ru[kk, j] + acc
+        nd[:, :, j] = acc
+    assert np.array_equal(Dt.to_array()[:, :, : order + 1], nd[:, :, : order + 1])
+    ypr = np.zeros((nb, n))
+    for j in range(order + 1):
+        ypr = ypr + nd[:, :, j]
+    ps = gamma[1] * nd[:, :, 1]
+    for j in range(2, order + 1):
+        ps = gamma[j] * nd[:, :, j] + 1.0 * ps
+    ps = ps * alpha - ypr
+    assert np.array_equal(yp.clone_as_vec(), ypr) and np.array_equal(psi.clone_as_vec(), ps)
+    # accept
+    ynew = ypr + 1e-3 * rng.standard_normal((nb, n))
+    atol = np.abs(rng.standard_normal(n)) * 1e-3 + 1e-6
+    h, rtol = 0.37, 1e-4
+    Ynew, Y, DY, AT = H.HipVec.from_vec(ynew, c), H.HipVec.zeros(n, c), H.HipVec.zeros(n, c), H.HipVec.from_vec(atol, ctx1)
+    Dn = H.HipMat.from_array(nd, c)
+    res = (C.c_double * 2)()
+    assert L.dsh_bdf_accept_step(c._h, n, nb, order, h, Dn.ptr, yp.ptr, Ynew.ptr, Y.ptr, DY.ptr, AT.ptr, 1, rtol, 1, res) == 0
+    e = nd.copy()
+    dd = ynew - ypr
+    e[:, :, order + 2] = dd - e[:, :, order + 1]
+    e[:, :, order + 1] = dd
+    for i in range(order, -1, -1):
+        e[:, :, i] = e[:, :, i] + 1.0 * e[:, :, i + 1]
+    assert np.array_equal(Dn.to_array(), e)
+    assert np.array_equal(Y.clone_as_vec(), ypr) and np.array_equal(DY.clone_as_vec(), e[:, :, 1] * (1.0 / h))
+    w = np.abs(ypr) * rtol + atol
+    def sq(v):
+        acc = np.zeros(nb)
+        for i in range(n):
+            term = v[:, i] / w[:, i]
+            acc = acc + term * term
+        return (acc / n).max()
+    assert res[0] == sq(e[:, :, order]) and res[1] == sq(e[:, :, order + 2])

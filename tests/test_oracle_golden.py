@@ -1,0 +1,200 @@
+"""Pins the CPU oracle (oracle/) against every golden vector the reference's own tests hold for the hot path:
+integer work counters of the insta snapshots, SUNDIALS solution tables, analytic solutions, and unit KATs of the building blocks."""
+import numpy as np
+import pytest
+
+from helpers import METHOD, ORACLE_MODEL, times_of, weighted_error_norm
+
+BDF_CASES = ["bdf_test_nalgebra_exponential_decay", "test_bdf_nalgebra_exponential_decay_algebraic", "test_bdf_nalgebra_robertson",
+             "test_bdf_nalgebra_robertson_ode", "test_bdf_nalgebra_dydt_y2", "test_bdf_nalgebra_gaussian_decay"]
+SDIRK_CASES = ["test_tr_bdf2_nalgebra_exponential_decay2", "test_esdirk34_nalgebra_exponential_decay",
+               "test_esdirk34_nalgebra_exponential_decay_algebraic", "test_tr_bdf2_nalgebra_robertson", "test_esdirk34_nalgebra_robertson",
+               "test_tr_bdf2_nalgebra_robertson_ode"]
+
+
+def run_case(O, kats, name):
+    spec = dict(kats["snapshot_problems"][name])
+    if spec["model"] == "robertson_ode":
+        spec["atol"] = list(np.tile(spec["atol"], spec.get("size", 1)))  # atol cycled over the groups (robertson_ode.rs:58-66)
+    s = O.OracleSolver(ORACLE_MODEL[spec["model"]], spec["p"], model_size=spec.get("size", 0), rtol=spec["rtol"], atol=spec["atol"], h0=spec["h0"],
+                       method=METHOD[spec["method"]])
+    t = times_of(kats, spec["t"])
+    y, _ = s.solve_to_points(t)
+    return spec, s, np.array(t), y
+
+
+@pytest.mark.parametrize("name", BDF_CASES + SDIRK_CASES)
+def test_oracle_reproduces_reference_work_counters_exactly(O, kats, name):
+    """All 13 counters of each insta snapshot (bdf.rs:1740-2420, sdirk.rs:687-995): the oracle follows the reference's step sequence exactly."""
+    _, s, _, _ = run_case(O, kats, name)
+    expected = kats["bdf_snapshots" if name in BDF_CASES else "sdirk_snapshots"][name]
+    assert s.stats() == expected
+
+
+@pytest.mark.parametrize("name", ["test_bdf_nalgebra_robertson", "test_tr_bdf2_nalgebra_robertson", "test_esdirk34_nalgebra_robertson"])
+def test_oracle_robertson_dae_table(O, kats, name):
+    spec, _, t, y = run_case(O, kats, name)
+    tab = kats["robertson_dae_table"]
+    for k, pt in enumerate(tab["points"]):
+        assert weighted_error_norm(y[k, 0], pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+
+
+@pytest.mark.parametrize("name", ["test_bdf_nalgebra_robertson_ode", "test_tr_bdf2_nalgebra_robertson_ode"])
+def test_oracle_robertson_ode_table(O, kats, name):
+    spec, _, t, y = run_case(O, kats, name)
+    tab = kats["robertson_ode_table"]
+    ngroups = spec.get("size", 1)
+    for k, pt in enumerate(tab["points"]):
+        yref = np.tile(pt["y"], ngroups)
+        assert weighted_error_norm(y[k, 0], yref, np.tile(tab["atol"], ngroups), tab["rtol"]) < 20.0, pt
+
+
+@pytest.mark.parametrize("name", ["bdf_test_nalgebra_exponential_decay", "test_tr_bdf2_nalgebra_exponential_decay2", "test_esdirk34_nalgebra_exponential_decay"])
+def test_oracle_exponential_decay_analytic(O, kats, name):
+    spec, _, t, y = run_case(O, kats, name)
+    for k in range(len(t)):
+        yref = np.full(2, spec["p"][1] * np.exp(-spec["p"][0] * t[k]))
+        assert weighted_error_norm(y[k, 0], yref, spec["atol"], spec["rtol"]) < 20.0
+
+
+@pytest.mark.parametrize("name", ["test_bdf_nalgebra_exponential_decay_algebraic", "test_esdirk34_nalgebra_exponential_decay_algebraic"])
+def test_oracle_exponential_decay_algebraic_analytic(O, kats, name):
+    spec, _, t, y = run_case(O, kats, name)
+    for k in range(len(t)):
+        yref = np.full(3, np.exp(-spec["p"][0] * t[k]))
+        assert weighted_error_norm(y[k, 0], yref, spec["atol"], spec["rtol"]) < 20.0
+
+
+def test_oracle_dydt_y2_and_gaussian_analytic(O, kats):
+    spec, _, t, y = run_case(O, kats, "test_bdf_nalgebra_dydt_y2")
+    for k in range(len(t)):
+        yref = np.full(10, -200.0 / (1.0 + 200.0 * t[k]))
+        assert weighted_error_norm(y[k, 0], yref, spec["atol"], spec["rtol"]) < 20.0
+    spec, _, t, y = run_case(O, kats, "test_bdf_nalgebra_gaussian_decay")
+    for k in range(len(t)):
+        yref = np.full(10, np.exp(-0.1 * t[k] ** 2 / 2.0))
+        assert weighted_error_norm(y[k, 0], yref, spec["atol"], spec["rtol"]) < 20.0
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2"])
+def test_oracle_batched_exponential_decay(O, method):
+    """exponential_decay_problem_batched (test_models/exponential_decay.rs:293-331; bdf.rs:2497-2503, sdirk.rs:1011-1018): k_b=0.1(b+1), y0_b=b+1."""
+    nb = 2
+    p = [[0.1 * (b + 1), float(b + 1)] for b in range(nb)]
+    s = O.OracleSolver(ORACLE_MODEL["exponential_decay"], p, nbatch=nb, h0=1.0, method=METHOD[method])
+    t = np.arange(10.0)
+    y, _ = s.solve_to_points(t)
+    for k in range(10):
+        for b in range(nb):
+            yref = np.full(2, (b + 1) * np.exp(-0.1 * (b + 1) * t[k]))
+            assert weighted_error_norm(y[k, b], yref, [1e-6], 1e-6) < 20.0
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2"])
+def test_oracle_batched_exponential_decay_with_algebraic(O, method):
+    """exponential_decay_with_algebraic_problem_batched (:309-346; bdf.rs:2625-2631, sdirk.rs:1020-1026)."""
+    nb = 2
+    p = [[0.1 * (b + 1)] for b in range(nb)]
+    s = O.OracleSolver(ORACLE_MODEL["exponential_decay_with_algebraic_batched"], p, nbatch=nb, method=METHOD[method])
+    t = np.arange(10.0) / 10.0
+    y, _ = s.solve_to_points(t)
+    for k in range(10):
+        for b in range(nb):
+            yref = np.full(3, np.exp(-0.1 * (b + 1) * t[k]))
+            assert weighted_error_norm(y[k, b], yref, [1e-6], 1e-6) < 20.0
+
+
+def test_oracle_heat1d_fourier_series(O):
+    """heat1d: triangle IC, D=1, Fourier-series reference at t=0.5..0.54, tolerance 1e-4 (test_models/heat1d.rs:62-96)."""
+    mgrid = 10
+    n = mgrid + 1
+    h = 1.0 / (mgrid + 2)
+    s = O.OracleSolver(ORACLE_MODEL["heat1d"], [1.0], model_size=n, rtol=1e-6, atol=[1e-6])
+    times = [0.5 + 0.01 * i for i in range(5)]
+    y, _ = s.solve_to_points(times)
+    for k, t in enumerate(times):
+        x = (np.arange(n) + 1) * h
+        ref = np.zeros(n)
+        for m in range(1, 100):
+            q = 2 * m - 1
+            ref += np.sin(q * np.pi * x) * np.exp(-q ** 2 * np.pi ** 2 * t) / q ** 2
+        ref *= 8.0 / np.pi ** 2
+        assert weighted_error_norm(y[k, 0], ref, [1e-4], 1e-4) < 20.0
+
+
+def test_oracle_bdf_callable_kat(O, kats):
+    """op/bdf.rs:318-361 through the model + LA restatement: F = (y + psi_neg_y0) - c f(y), J = I - c f'."""
+    k = kats["bdf_callable_kat"]
+    y = np.array(k["y"])
+    f = O.model_rhs(ORACLE_MODEL[k["model"]], y, k["p"])
+    F = (y + np.array(k["psi_neg_y0"])) + (-k["c"]) * f
+    assert np.allclose(F, k["F"], atol=k["tol"])
+    Jv = np.array(k["v"]) + (-k["c"]) * O.model_jac_mul(ORACLE_MODEL[k["model"]], y, k["p"], k["v"])
+    assert np.allclose(Jv, k["Jv"], atol=k["tol"])
+
+
+def test_oracle_sdirk_callable_kat(O, kats):
+    k = kats["sdirk_callable_kat"]
+    y = np.array(k["y"])
+    f = O.model_rhs(ORACLE_MODEL[k["model"]], np.array(k["phi"]) + k["c"] * y, k["p"])
+    assert np.allclose(y - k["h"] * f, k["F"], atol=k["tol"])
+
+
+def test_oracle_compute_r(O):
+    """_compute_r (bdf.rs:433-463): R[0,j]=1, R[i,j]=R[i-1,j](i-1-factor*j)/i; U = R(factor=1) satisfies U*U = I (Byrne & Hindmarsh)."""
+    for order in range(1, 6):
+        U = O.compute_r(order, 1.0)
+        assert np.allclose(U @ U, np.eye(order + 1), atol=1e-12)
+        R = O.compute_r(order, 0.5)
+        assert np.all(R[0] == 1.0)
+        for i in range(1, order + 1):
+            for j in range(1, order + 1):
+                assert R[i, j] == R[i - 1, j] * (i - 1 - 0.5 * j) / i
+
+
+def test_oracle_lu_matches_scipy(O):
+    import scipy.linalg
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 4, 8, 17):
+        a = rng.standard_normal((5, n, n))
+        b = rng.standard_normal((5, n))
+        x, lu, piv, rc = O.lu_solve(a, b)
+        assert rc == 0
+        for k in range(5):
+            assert np.allclose(a[k] @ x[k], b[k], atol=1e-9)
+            lu_ref, piv_ref = scipy.linalg.lu_factor(a[k])
+            assert np.array_equal(piv[k], piv_ref)
+            assert np.allclose(lu[k], lu_ref, rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_lu_diagonal_kat_and_singular(O):
+    """2x2 diagonal solve of the reference's linear-solver tests (linear_solver/nalgebra/lu.rs:71-83, diffsol/src/linear_solver/mod.rs:283-321)."""
+    a = np.array([[[2.0, 0.0], [0.0, 2.0]]])
+    x, _, _, rc = O.lu_solve(a, np.array([[2.0, 4.0]]))
+    assert rc == 0 and np.array_equal(x, [[1.0, 2.0]])
+    _, _, _, rc = O.lu_solve(np.array([[[1.0, 2.0], [2.0, 4.0]]]), np.array([[1.0, 1.0]]))
+    assert rc == 1
+
+
+def test_oracle_squared_norm_semantics(O):
+    """mean of squares, max over batches (vector/nalgebra_serial.rs:395-408, vector/cuda.rs:1421-1432)."""
+    x = np.array([[1.0, 2.0], [3.0, -4.0]])
+    y = np.array([[1.0, 1.0], [2.0, 2.0]])
+    atol = np.array([0.5, 0.25])
+    rtol = 0.5
+    per = [np.mean((x[b] / (np.abs(y[b]) * rtol + atol)) ** 2) for b in range(2)]
+    assert O.squared_norm(x, y, atol, rtol) == max(per)
+    xn = x.copy(); xn[0, 0] = np.nan
+    assert np.isnan(O.squared_norm(xn, y, atol, rtol))
+
+
+def test_oracle_convergence_state_machine(O):
+    """Convergence (diffsol-nl/src/convergence.rs:68-139): eta_0 = 20^1.25 -> ^0.8 on the first iteration; rate test afterwards."""
+    status, eta = O.convergence_trace([1.0, 0.1, 0.01])
+    assert np.isclose(eta[0], (20.0 ** 1.25) ** 0.8)
+    assert status[0] == 2  # continue: eta*norm = 20 > 0.2
+    assert np.isclose(eta[1], 0.1 / 0.9) and status[1] == 0  # rate 0.1 -> eta*norm = 0.0111 < 0.2
+    status, _ = O.convergence_trace([1.0, 0.95])
+    assert status[1] == 1  # rate > 0.9 => diverged
+    status, _ = O.convergence_trace([1.0, 0.8])
+    assert status[1] == 1  # 0.8^8/(0.2)*0.8 = 0.67 > 0.2 => will not converge in max_iter
