@@ -181,7 +181,13 @@ def test_reductions_match_numpy(H, ctx1, n, nb):
     x, y = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
     atol = np.abs(rng.standard_normal(n)) + 1e-3
     rtol = 1e-2
-    per = np.array([sum(((x[b, i] / (abs(y[b, i]) * rtol + atol[i])) ** 2 for i in range(n)), 0.0) / n for b in range(min(nb, 300))])
+    def one(b):
+        acc = 0.0
+        for i in range(n):
+            term = x[b, i] / (abs(y[b, i]) * rtol + atol[i])
+            acc += term * term
+        return acc / n
+    per = np.array([one(b) for b in range(min(nb, 300))])
     got, got_per = V(H, x, c).squared_norm(V(H, y, c), V(H, atol, ctx1), rtol, per_batch=True)
     assert np.array_equal(got_per[: len(per)], per)  # same sequential summation order -> bit-exact
     assert got == got_per.max()
