@@ -36,6 +36,8 @@ DEVICE_ABI = {
     "dsh_ctx_stream": (vp, [vp]),
     "dsh_ctx_device": (cint, [vp]),
     "dsh_ctx_set_block": (cint, [vp, cint]),
+    "dsh_ctx_set_timing": (cint, [vp, cint]),
+    "dsh_ctx_get_timing": (cint, [vp, c_i64p, c_dp]),
     "dsh_malloc": (cint, [vp, i64, cint, C.POINTER(vp)]),
     "dsh_free": (cint, [vp, vp]),
     "dsh_memset_zero": (cint, [vp, vp, i64]),
@@ -113,6 +115,9 @@ HOST_ABI = {
     "dshs_default_options": (None, [C.POINTER(DshsOptions)]),
     "dshs_create": (cint, [cint, vp, cint, i64, i64, c_dp, i64, dbl, c_dp, i64, dbl, dbl, cint, C.POINTER(DshsOptions), C.POINTER(vp)]),
     "dshs_destroy": (None, [vp]),
+    "dshs_reset": (cint, [vp]),
+    "dshs_set_kernel_timing": (cint, [vp, cint]),
+    "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),
     "dshs_nstates": (i64, [vp]),
     "dshs_nbatch": (i64, [vp]),
     "dshs_is_fused": (cint, [vp]),

@@ -100,6 +100,7 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->i32_scratch) (void)hipFree(ctx->i32_scratch);
   if (ctx->f64_scratch) (void)hipFree(ctx->f64_scratch);
+  if (ctx->ev_start) { (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop); }
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -113,6 +114,23 @@ int dsh_ctx_device(dsh_ctx* ctx) { return ctx->device; }
 int dsh_ctx_set_block(dsh_ctx* ctx, int threads) {
   DSH_REQUIRE(threads >= 64 && threads <= 1024 && (threads & (threads - 1)) == 0, "block must be a power of two in [64,1024]");
   ctx->block = threads;
+  return DSH_OK;
+}
+
+int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
+  if (enable && !ctx->ev_start) {
+    DSH_HIP_CHECK(hipEventCreate(&ctx->ev_start));
+    DSH_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
+  }
+  ctx->timing = enable != 0;
+  ctx->ev_pending = false;
+  ctx->timed_ms = 0.0;
+  ctx->timed_launches = 0;
+  return DSH_OK;
+}
+int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms) {
+  if (launches) *launches = ctx->timed_launches;
+  if (total_ms) *total_ms = ctx->timed_ms;
   return DSH_OK;
 }
 

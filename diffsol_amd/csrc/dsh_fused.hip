@@ -254,6 +254,7 @@ static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   if (rc != DSH_OK) return rc;
   const bool ba = anb == 1 && nb != 1;
   const bool with_err = y_old != nullptr;
+  if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
@@ -267,8 +268,15 @@ static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   });
   if (!ok) { set_error("newton iteration: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipGetLastError());
+  if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
   rc = fetch_slots(ctx, slots);
   if (rc != DSH_OK) return rc;
+  if (ctx->timing) {  // the stream is idle after fetch_slots: both events have completed
+    float ms = 0.f;
+    DSH_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    ctx->timed_ms += (double)ms;
+    ctx->timed_launches += 1;
+  }
   out[0] = bits_to_double(ctx->mailbox[0]);
   out[1] = bits_to_double(ctx->mailbox[1]);
   out[2] = (double)ctx->mailbox[2];

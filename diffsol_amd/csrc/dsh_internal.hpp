@@ -55,6 +55,12 @@ struct dsh_ctx {
   int64_t i32_scratch_len = 0;
   double* f64_scratch = nullptr;
   int64_t f64_scratch_len = 0;
+  // optional HIP-event timing of the dominant (fused Newton iteration) kernel on this context's stream
+  bool timing = false;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool ev_pending = false;
+  double timed_ms = 0.0;
+  int64_t timed_launches = 0;
 };
 
 struct dsh_lu {

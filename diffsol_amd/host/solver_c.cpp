@@ -15,6 +15,24 @@ struct dshs_solver {
   std::unique_ptr<OdeSolverMethod> solver;
   Bdf* bdf = nullptr;
   bool fused = false;
+  int method = 0;
+  void make_solver() {
+    solver.reset();
+    bdf = nullptr;
+    problem.eqn->rhs_statistics = OpStatistics();
+    if (method == DSHS_METHOD_BDF) {
+      auto b = std::make_unique<Bdf>(problem);
+      bdf = b.get();
+      fused = b->is_fused();
+      solver = std::move(b);
+    } else if (method == DSHS_METHOD_TR_BDF2 || method == DSHS_METHOD_ESDIRK34) {
+      auto k = std::make_unique<Sdirk>(problem, method == DSHS_METHOD_TR_BDF2 ? Tableau::tr_bdf2() : Tableau::esdirk34());
+      fused = k->is_fused();
+      solver = std::move(k);
+    } else {
+      throw LaError(DSH_E_INVALID, "unknown method");
+    }
+  }
   HipMat traj_y;
   std::vector<double> traj_t;
 };
@@ -87,24 +105,20 @@ int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t
     std::vector<double> p(params, params + nparams_total), a(atol, atol + natol);
     s->problem = OdeBuilder().t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic)
                      .build_model(model, model_size, p);
-    if (method == DSHS_METHOD_BDF) {
-      auto b = std::make_unique<Bdf>(s->problem);
-      s->bdf = b.get();
-      s->fused = b->is_fused();
-      s->solver = std::move(b);
-    } else if (method == DSHS_METHOD_TR_BDF2 || method == DSHS_METHOD_ESDIRK34) {
-      auto k = std::make_unique<Sdirk>(s->problem, method == DSHS_METHOD_TR_BDF2 ? Tableau::tr_bdf2() : Tableau::esdirk34());
-      s->fused = k->is_fused();
-      s->solver = std::move(k);
-    } else {
-      throw LaError(DSH_E_INVALID, "unknown method");
-    }
+    s->method = method;
+    s->make_solver();
     *out = s.release();
     return 0;
   });
 }
 
 void dshs_destroy(dshs_solver* s) { delete s; }
+
+int dshs_reset(dshs_solver* s) {
+  return guarded([&]() { s->make_solver(); return 0; });
+}
+int dshs_set_kernel_timing(dshs_solver* s, int enable) { return dsh_ctx_set_timing(s->ctx.raw(), enable); }
+int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms) { return dsh_ctx_get_timing(s->ctx.raw(), launches, total_ms); }
 
 int64_t dshs_nstates(const dshs_solver* s) { return s->problem.eqn->nstates(); }
 int64_t dshs_nbatch(const dshs_solver* s) { return s->ctx.nbatch(); }

@@ -57,6 +57,18 @@ class Solver:
             self._L.dshs_destroy(self._h)
             self._h = None
 
+    def reset(self):
+        """Re-create the solver state from the (device-resident) problem: a fresh `.bdf()` / `.tr_bdf2()` / `.esdirk34()`."""
+        check(self._L.dshs_reset(self._h), host=True)
+
+    def set_kernel_timing(self, enable=True):
+        check(self._L.dshs_set_kernel_timing(self._h, 1 if enable else 0), host=True)
+
+    def kernel_timing(self):
+        n, ms = C.c_int64(), C.c_double()
+        check(self._L.dshs_get_kernel_timing(self._h, C.byref(n), C.byref(ms)), host=True)
+        return int(n.value), float(ms.value)
+
     def step(self):
         r = C.c_int()
         check(self._L.dshs_step(self._h, C.byref(r)), host=True)

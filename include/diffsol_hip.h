@@ -58,6 +58,12 @@ int dsh_ctx_device(dsh_ctx* ctx);
 /* threads per workgroup for one-lane-per-system kernels (default 64; tuning knob, power of two in [64,1024]) */
 int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
 
+/* HIP-event timing of the fused Newton-iteration kernel (the dominant kernel) on the context's own stream: when enabled every
+ * dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch is bracketed by two events; get_timing returns the number of launches and
+ * the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figure. */
+int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
+int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms);
+
 /* ---- device memory (cudarc alloc/alloc_zeros/memcpy_*: call sites throughout vector/cuda.rs, matrix/cuda.rs) ---- */
 int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out);
 int dsh_free(dsh_ctx* ctx, void* p);

@@ -52,6 +52,13 @@ int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t
                 const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, dshs_solver** out);
 void dshs_destroy(dshs_solver* s);
 
+/* Re-create the solver state from the problem (parameters stay resident on the device): OdeSolverProblem::bdf()/... again —
+ * initial state, consistent initialisation, initial step size, first Jacobian + LU.  Lets a benchmark time whole solves back to back. */
+int dshs_reset(dshs_solver* s);
+/* forwarders to dsh_ctx_set_timing / dsh_ctx_get_timing of the solver's context */
+int dshs_set_kernel_timing(dshs_solver* s, int enable);
+int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms);
+
 int64_t dshs_nstates(const dshs_solver* s);
 int64_t dshs_nbatch(const dshs_solver* s);
 int dshs_is_fused(const dshs_solver* s);
