@@ -37,6 +37,7 @@ DEVICE_ABI = {
     "dsh_ctx_device": (cint, [vp]),
     "dsh_ctx_set_block": (cint, [vp, cint]),
     "dsh_ctx_set_timing": (cint, [vp, cint]),
+    "dsh_ctx_set_poll": (cint, [vp, cint]),
     "dsh_ctx_get_timing": (cint, [vp, c_i64p, c_dp]),
     "dsh_malloc": (cint, [vp, i64, cint, C.POINTER(vp)]),
     "dsh_free": (cint, [vp, vp]),
@@ -91,12 +92,12 @@ DEVICE_ABI = {
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
-    "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, cint, c_dp]),
     "dsh_sdirk_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_jac_factor": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, cint, vp, vp, vp]),
     "dsh_model_has_fused": (cint, [cint, i64]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
-    "dsh_bdf_accept_step": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, cint, c_dp]),
+    "dsh_bdf_accept_step": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, cint, c_dp]),
 }
 
 

@@ -2,25 +2,61 @@
 // Replaces CudaContext (diffsol-la/src/context/cuda.rs:41-144) and the cudarc driver calls listed in SURVEY §2a.
 #include "dsh_internal.hpp"
 
+#include <cstdlib>
+
+#include <cstring>
 #include <mutex>
 
 namespace dsh {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
-int take_slots(dsh_ctx* ctx, unsigned long long** out) {
-  if (ctx->ring_cursor >= kRingEntries) {
-    DSH_HIP_CHECK(hipMemsetAsync(ctx->ring, 0, sizeof(unsigned long long) * kRingEntries * kSlotWords, ctx->stream));
-    ctx->ring_cursor = 0;
+int begin_records(dsh_ctx* ctx, int64_t nblocks, unsigned long long** rec_dev, unsigned int* seq) {
+  if (nblocks > ctx->rec_capacity) {
+    int64_t cap = ctx->rec_capacity > 0 ? ctx->rec_capacity : 1024;
+    while (cap < nblocks) cap *= 2;
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->rec_host) DSH_HIP_CHECK(hipHostFree(ctx->rec_host));
+    DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->rec_host, sizeof(unsigned long long) * kRecWords * cap, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(ctx->rec_host, 0, sizeof(unsigned long long) * kRecWords * cap);
+    DSH_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->rec_dev, ctx->rec_host, 0));
+    ctx->rec_capacity = cap;
   }
-  *out = ctx->ring + (size_t)ctx->ring_cursor * kSlotWords;
-  ctx->ring_cursor++;
+  ctx->seq += 1;
+  if (ctx->seq == 0) ctx->seq = 1;  // tag 0 is "never written"
+  *rec_dev = ctx->rec_dev;
+  *seq = ctx->seq;
   return DSH_OK;
 }
 
-int fetch_slots(dsh_ctx* ctx, const unsigned long long* slots) {
-  DSH_HIP_CHECK(hipMemcpyAsync(ctx->mailbox, slots, sizeof(unsigned long long) * kSlotWords, hipMemcpyDeviceToHost, ctx->stream));
-  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq) {
+  volatile unsigned long long* rec = ctx->rec_host;
+  if (!ctx->poll) DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  unsigned long long m0 = 0, m1 = 0, cnt = 0;
+  const unsigned long long want = (unsigned long long)seq;
+  long spins = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    volatile unsigned long long* r = rec + (size_t)b * kRecWords;
+    unsigned long long t0, t1;
+    while (((t0 = r[1]) >> 32) != want || ((t1 = r[3]) >> 32) != want) {
+      // a launch that failed never tags its records: fall back to the runtime to surface the error instead of spinning forever
+      if (++spins > 2000000) {
+        hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipSuccess && e != hipErrorNotReady) { DSH_HIP_CHECK(e); }
+        if (e == hipSuccess && ((r[1] >> 32) != want || (r[3] >> 32) != want)) {
+          set_error("reduction records were not written by the kernel (stream idle)");
+          return DSH_E_HIP;
+        }
+        spins = 0;
+      }
+      __builtin_ia32_pause();
+    }
+    unsigned long long a = r[0], c = r[2];
+    if (a > m0) m0 = a;
+    if (c > m1) m1 = c;
+    cnt += (t0 & 0xffffffffull);
+  }
+  ctx->res_m0 = m0; ctx->res_m1 = m1; ctx->res_cnt = cnt;
   return DSH_OK;
 }
 
@@ -85,9 +121,10 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   hipDeviceProp_t prop;
   DSH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;
-  DSH_HIP_CHECK(hipMalloc((void**)&ctx->ring, sizeof(unsigned long long) * kRingEntries * kSlotWords));
-  DSH_HIP_CHECK(hipMemsetAsync(ctx->ring, 0, sizeof(unsigned long long) * kRingEntries * kSlotWords, ctx->stream));
-  DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->mailbox, sizeof(unsigned long long) * 16, hipHostMallocDefault));
+  {
+    const char* env = std::getenv("DSH_SYNC_MODE");  // "poll" (default) or "sync"
+    ctx->poll = !(env && std::string(env) == "sync");
+  }
   *out = ctx;
   return DSH_OK;
 }
@@ -96,8 +133,7 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->ring) (void)hipFree(ctx->ring);
-  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
+  if (ctx->rec_host) (void)hipHostFree(ctx->rec_host);
   if (ctx->i32_scratch) (void)hipFree(ctx->i32_scratch);
   if (ctx->f64_scratch) (void)hipFree(ctx->f64_scratch);
   if (ctx->ev_start) { (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop); }
@@ -122,10 +158,14 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
     DSH_HIP_CHECK(hipEventCreate(&ctx->ev_start));
     DSH_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
   }
-  ctx->timing = enable != 0;
+  ctx->timing = enable != 0;  // note: event timing needs completed events, so timed launches synchronise the stream
   ctx->ev_pending = false;
   ctx->timed_ms = 0.0;
   ctx->timed_launches = 0;
+  return DSH_OK;
+}
+int dsh_ctx_set_poll(dsh_ctx* ctx, int poll) {
+  ctx->poll = poll != 0;
   return DSH_OK;
 }
 int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms) {

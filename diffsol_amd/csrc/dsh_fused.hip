@@ -37,23 +37,27 @@ __device__ __forceinline__ void load_atol(const double* __restrict__ atol, int64
 //   BDF  : delta = M(y + psi_neg_y0) - c f(y, t)             (op/bdf.rs:240-256)
 //   SDIRK: delta = M k - h f(phi + c k, t)                   (op/sdirk.rs:229-244)
 template <class Mdl, bool IS_SDIRK, bool BA, bool WITH_ERR>
-__global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* __restrict__ y, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
+__global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* y, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
                               const double* __restrict__ p, const double* __restrict__ factors, const int32_t* __restrict__ piv,
                               const double* __restrict__ error_y, const double* __restrict__ y_old, const double* __restrict__ atol, double rtol,
-                              unsigned long long* slots) {
+                              int init_from_error_y, unsigned long long* rec, unsigned int seq) {
   constexpr int N = Mdl::N, NP = Mdl::NP;
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long nrm_bits = 0ull, err_bits = 0ull, bad = 0ull;
   if (b < nb) {
-    double x[N], a[N], pp[NP], A[N * N], ey[N], at[N];
+    double x[N], a[N], pp[NP], A[N * N], ey[N], at[N], yo[N];
     int P[N];
-    load_vec<N>(y, nb, b, x);
+    // first iteration: the iterate starts from the predictor (y_delta.copy_from(y_predict), bdf.rs:1326) — selected through the source
+    // POINTER so that every load of the kernel is issued before the first wait (one HBM round trip, not two)
+    const double* xsrc = init_from_error_y ? error_y : y;
+    load_vec<N>(xsrc, nb, b, x);
+    load_vec<N>(error_y, nb, b, ey);
     load_vec<N>(aux, nb, b, a);
     load_vec<NP>(p, nb, b, pp);
     load_mat<N>(factors, nb, b, A);
     load_piv<N>(piv, nb, b, P);
-    load_vec<N>(error_y, nb, b, ey);
     load_atol<N, BA>(atol, nb, b, at);
+    if constexpr (WITH_ERR) load_vec<N>(y_old, nb, b, yo);
     double f[N], tmp[N], delta[N];
     if constexpr (!IS_SDIRK) {
       Mdl::rhs(t, x, pp, f);
@@ -87,15 +91,14 @@ __global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* 
     store_vec<N>(y, nb, b, x);
     nrm_bits = d2u(wms<N>(delta, ey, at, rtol));
     if constexpr (WITH_ERR) {
-      double yo[N], d[N];
-      load_vec<N>(y_old, nb, b, yo);
+      double d[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) d[i] = x[i] - ey[i];
       err_bits = d2u(wms<N>(d, yo, at, rtol));
     }
     bad = ok ? 0ull : 1ull;
   }
-  block_publish(nrm_bits, err_bits, bad, slots, WITH_ERR, true);
+  block_publish(nrm_bits, err_bits, bad, rec, seq);
 }
 
 // Jacobian refresh + assembly of M - cJ + LU factorisation, one lane per system, A never leaves registers.
@@ -186,9 +189,9 @@ __global__ void k_bdf_prepare(int64_t total, const double* __restrict__ diff, do
 
 // one lane per system: difference-array update, state update and the two order-selection norms
 template <bool BA>
-__global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, double* __restrict__ diff, const double* __restrict__ y_predict,
+__global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, double* __restrict__ diff, double* y_predict,
                              const double* __restrict__ y_new, double* __restrict__ y, double* __restrict__ dy, const double* __restrict__ atol, double rtol,
-                             unsigned long long* slots) {
+                             BdfCoeffs cf, double* __restrict__ psi_next, unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m_bits = 0ull, p_bits = 0ull;
   if (b < nb) {
@@ -210,11 +213,14 @@ __global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, dou
       diff[(int64_t)(order + 1) * cs + e] = d;
       double upper = d;  // value of column j+1 while walking down
       double new_k = 0.0, new_1 = 0.0;
+      double nd[6];  // updated columns 0..order
 #pragma unroll
       for (int j = 5; j >= 0; --j) {
+        nd[j] = 0.0;
         if (j <= order) {
           double v = col[j] + 1.0 * upper;
           diff[(int64_t)j * cs + e] = v;
+          nd[j] = v;
           if (j == order) new_k = v;
           if (j == 1) new_1 = v;
           upper = v;
@@ -222,6 +228,20 @@ __global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, dou
       }
       y[e] = yp;
       dy[e] = new_1 * inv_h;
+      if (psi_next != nullptr) {
+        // speculative prediction for the NEXT step at unchanged order and step size (same arithmetic as k_bdf_prepare):
+        // y_predict = sum_{j<=k} D_j ; psi_neg_y0 = alpha*(sum_{1<=j<=k} gamma_j D_j) - y_predict
+        double ypn = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (j <= order) ypn = ypn + nd[j];
+        double psi = cf.gamma[1] * nd[1];
+#pragma unroll
+        for (int j = 2; j < 6; ++j) if (j <= order) psi = cf.gamma[j] * nd[j] + 1.0 * psi;
+        psi = psi * cf.alpha;
+        psi = psi - ypn;
+        y_predict[e] = ypn;
+        psi_next[e] = psi;
+      }
       double ai = BA ? atol[i] : atol[e];
       double w = fabs(yp) * rtol + ai;
       double tm = new_k / w;
@@ -232,7 +252,7 @@ __global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, dou
     m_bits = d2u(acc_m / (double)n);
     p_bits = d2u(acc_p / (double)n);
   }
-  block_publish(m_bits, p_bits, 0ull, slots, true, false);
+  block_publish(m_bits, p_bits, 0ull, rec, seq);
 }
 
 }  // namespace
@@ -245,22 +265,22 @@ int dsh_model_has_fused(int model, int64_t size) {
 
 static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, int64_t nb, double t, double c, double h, double* y, const double* aux,
                          const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol,
-                         double* out) {
+                         int init_from_error_y, double* out) {
   DSH_CHECK_NB(anb, nb);
   DSH_REQUIRE(out != nullptr && lu != nullptr, "null argument");
   if (!lu->factored) { set_error("newton iteration: LU not initialised"); return DSH_E_NOT_SETUP; }
-  unsigned long long* slots;
-  int rc = take_slots(ctx, &slots);
+  unsigned long long* rec; unsigned int seq;
+  const dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
   const bool ba = anb == 1 && nb != 1;
   const bool with_err = y_old != nullptr;
   if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
-    dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
 #define DSH_NEWTON_LAUNCH(SD, BA, WE)                                                                                                          \
   hipLaunchKernelGGL((k_newton_iter<Mdl, SD, BA, WE>), g, blk, 0, ctx->stream, nb, t, c, h, y, aux, p, (const double*)lu->factors,               \
-                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, slots)
+                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, init_from_error_y, rec, seq)
     if (is_sdirk) { if (ba) DSH_NEWTON_LAUNCH(true, true, false); else DSH_NEWTON_LAUNCH(true, false, false); }
     else if (with_err) { if (ba) DSH_NEWTON_LAUNCH(false, true, true); else DSH_NEWTON_LAUNCH(false, false, true); }
     else { if (ba) DSH_NEWTON_LAUNCH(false, true, false); else DSH_NEWTON_LAUNCH(false, false, false); }
@@ -268,28 +288,30 @@ static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   });
   if (!ok) { set_error("newton iteration: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipGetLastError());
-  if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
-  rc = fetch_slots(ctx, slots);
-  if (rc != DSH_OK) return rc;
-  if (ctx->timing) {  // the stream is idle after fetch_slots: both events have completed
+  if (ctx->timing) {
+    DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+    DSH_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
     float ms = 0.f;
     DSH_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->timed_ms += (double)ms;
     ctx->timed_launches += 1;
   }
-  out[0] = bits_to_double(ctx->mailbox[0]);
-  out[1] = bits_to_double(ctx->mailbox[1]);
-  out[2] = (double)ctx->mailbox[2];
+  rc = fetch_records(ctx, g.x, seq);
+  if (rc != DSH_OK) return rc;
+  out[0] = bits_to_double(ctx->res_m0);
+  out[1] = bits_to_double(ctx->res_m1);
+  out[2] = (double)ctx->res_cnt;
   return DSH_OK;
 }
 
 int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, double* y, const double* psi_neg_y0, const double* p,
-                        const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol, double* out) {
-  return newton_common(ctx, false, model, size, nb, t, c, 0.0, y, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, out);
+                        const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol, int init_from_error_y,
+                        double* out) {
+  return newton_common(ctx, false, model, size, nb, t, c, 0.0, y, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, init_from_error_y, out);
 }
 int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, double* k, const double* phi, const double* p,
                           const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol, double* out) {
-  return newton_common(ctx, true, model, size, nb, t, c, h, k, phi, p, lu, error_y, nullptr, atol, anb, rtol, out);
+  return newton_common(ctx, true, model, size, nb, t, c, h, k, phi, p, lu, error_y, nullptr, atol, anb, rtol, 0, out);
 }
 
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* x, const double* p, int recompute, double* rhs_jac,
@@ -324,25 +346,30 @@ int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, const d
   return DSH_OK;
 }
 
-int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, const double* y_predict, const double* y_new, double* y,
-                        double* dy, const double* atol, int64_t anb, double rtol, int want_norms, double* out) {
+int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
+                        double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
+                        int want_norms, double* out) {
   DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
   DSH_CHECK_NB(anb, nb);
   if (n * nb == 0) return DSH_OK;
-  unsigned long long* slots;
-  int rc = take_slots(ctx, &slots);
+  unsigned long long* rec; unsigned int seq;
+  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
   const double inv_h = 1.0 / h;
-  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
-  if (anb == 1 && nb != 1) hipLaunchKernelGGL((k_bdf_accept<true>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, slots);
-  else hipLaunchKernelGGL((k_bdf_accept<false>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, slots);
+  BdfCoeffs cf;
+  for (int k = 0; k < 36; ++k) cf.ru[k] = 0.0;
+  for (int k = 0; k < 6; ++k) cf.gamma[k] = (psi_neg_y0_next && k <= order) ? gamma_host[k] : 0.0;
+  cf.alpha = alpha; cf.order = order; cf.rescale = 0;
+  if (anb == 1 && nb != 1) hipLaunchKernelGGL((k_bdf_accept<true>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf, psi_neg_y0_next, rec, seq);
+  else hipLaunchKernelGGL((k_bdf_accept<false>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf, psi_neg_y0_next, rec, seq);
   DSH_HIP_CHECK(hipGetLastError());
   if (want_norms) {
     DSH_REQUIRE(out != nullptr, "out is null");
-    rc = fetch_slots(ctx, slots);
+    rc = fetch_records(ctx, g.x, seq);
     if (rc != DSH_OK) return rc;
-    out[0] = bits_to_double(ctx->mailbox[0]);
-    out[1] = bits_to_double(ctx->mailbox[1]);
+    out[0] = bits_to_double(ctx->res_m0);
+    out[1] = bits_to_double(ctx->res_m1);
   }
   return DSH_OK;
 }

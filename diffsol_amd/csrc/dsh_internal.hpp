@@ -32,13 +32,14 @@ void set_error(const std::string& msg);
 // operand nbatch must be 1 (broadcast) or the context batch size
 #define DSH_CHECK_NB(nb_op, nb) DSH_REQUIRE((nb_op) == 1 || (nb_op) == (nb), "operand nbatch must be 1 or nbatch")
 
-// Reduction slots: each reducing launch gets 4 zero-initialised 64-bit words
-//   [0] max of f64 bit patterns (non-negative values and NaN order correctly as unsigned integers: NaN > +inf > finite)
-//   [1] second max   [2] counter   [3] flags
-// taken from a ring in device memory that is re-zeroed (stream-ordered memset) each time it wraps; results come back to
-// the host through one 32-byte D2H copy into pinned memory + a stream synchronise.
-constexpr int kSlotWords = 4;
-constexpr int kRingEntries = 512;
+// Reduction records.  Every reducing launch writes ONE 32-byte record per workgroup straight into pinned, device-mapped host memory:
+//   word0 = max of f64 bit patterns (non-negative values and NaN order correctly as unsigned integers: NaN > +inf > finite)
+//   word1 = (sequence << 32) | count        word2 = second max        word3 = (sequence << 32) | count
+// i.e. two self-validating 16-byte granules {payload, tag}, each written by a single 16-byte store.  No atomics, no device-side
+// zeroing, no D2H copy kernel: the host reduces the (few hundred) records itself, either after a stream synchronise or — in polling
+// mode — as soon as every record carries the launch's sequence tag (the granules travel as single PCIe writes, so a tag that has
+// arrived implies its payload has).
+constexpr int kRecWords = 4;
 
 }  // namespace dsh
 
@@ -48,9 +49,12 @@ struct dsh_ctx {
   bool owns_stream = false;
   int block = 64;   // threads per workgroup for one-lane-per-system kernels
   int num_cu = 256;
-  unsigned long long* ring = nullptr;      // device, kRingEntries * kSlotWords
-  unsigned long long* mailbox = nullptr;   // pinned host, kSlotWords (+ spare)
-  int ring_cursor = 0;
+  unsigned long long* rec_host = nullptr;  // pinned + mapped host memory, rec_capacity * kRecWords
+  unsigned long long* rec_dev = nullptr;   // device view of rec_host
+  int64_t rec_capacity = 0;                // records (= max workgroups of a reducing launch)
+  unsigned int seq = 0;                    // sequence tag of the last reducing launch
+  bool poll = true;                        // true: spin on the record tags; false: hipStreamSynchronize then read
+  unsigned long long res_m0 = 0, res_m1 = 0, res_cnt = 0;  // host-side reduction of the last fetched launch
   int32_t* i32_scratch = nullptr;          // device scratch for root finding results etc.
   int64_t i32_scratch_len = 0;
   double* f64_scratch = nullptr;
@@ -74,10 +78,11 @@ struct dsh_lu {
 
 namespace dsh {
 
-// next zeroed slot group (device pointer); enqueues a memset when the ring wraps
-int take_slots(dsh_ctx* ctx, unsigned long long** out);
-// copy a slot group to the host mailbox and wait; afterwards ctx->mailbox[0..4) is valid
-int fetch_slots(dsh_ctx* ctx, const unsigned long long* slots);
+// Start a reducing launch of `nblocks` workgroups: makes sure the record buffer is large enough and returns the device pointer the
+// kernel writes to plus the sequence tag it must stamp.
+int begin_records(dsh_ctx* ctx, int64_t nblocks, unsigned long long** rec_dev, unsigned int* seq);
+// Wait for the launch's records and reduce them on the host into ctx->res_m0 / res_m1 / res_cnt.
+int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq);
 int ensure_i32_scratch(dsh_ctx* ctx, int64_t len);
 int ensure_f64_scratch(dsh_ctx* ctx, int64_t len);
 
@@ -111,41 +116,31 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
-// publish a per-wave maximum: skip the atomic when the slot already holds a value >= ours (device-scope relaxed load first;
-// the slot only ever grows, so a stale read can only cause a redundant atomic, never a lost update)
-__device__ __forceinline__ void publish_max(unsigned long long* slot, unsigned long long v) {
-  if (v == 0ull) return;
-  unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (v > cur) atomicMax(slot, v);
-}
-
-// Block-level reduction of up to 3 quantities (two maxima + one count) and publication to the slot group.
-// Works for any block size that is a multiple of 64 up to 1024.
-__device__ __forceinline__ void block_publish(unsigned long long m0, unsigned long long m1, unsigned long long cnt, unsigned long long* slots,
-                                              bool use_m1, bool use_cnt) {
+// Block-level reduction of two maxima and one count, then ONE record (two 16-byte stores by thread 0) to host-mapped memory.
+// Works for any block size that is a multiple of 64 up to 1024.  Every thread of the block must call it.
+__device__ __forceinline__ void block_publish(unsigned long long m0, unsigned long long m1, unsigned long long cnt, unsigned long long* rec,
+                                              unsigned int seq) {
   m0 = wave_max_u64(m0);
-  if (use_m1) m1 = wave_max_u64(m1);
-  if (use_cnt) cnt = wave_sum_u64(cnt);
+  m1 = wave_max_u64(m1);
+  cnt = wave_sum_u64(cnt);
   const int lane = threadIdx.x & 63;
   const int nwaves = blockDim.x >> 6;
-  if (nwaves == 1) {
-    if (lane == 0) {
-      publish_max(slots + 0, m0);
-      if (use_m1) publish_max(slots + 1, m1);
-      if (use_cnt && cnt) atomicAdd(slots + 2, cnt);
+  if (nwaves > 1) {
+    __shared__ unsigned long long sh[3][16];
+    const int w = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][w] = m0; sh[1][w] = m1; sh[2][w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < nwaves; ++k) { m0 = umax64(m0, sh[0][k]); m1 = umax64(m1, sh[1][k]); cnt += sh[2][k]; }
     }
-    return;
   }
-  __shared__ unsigned long long sh[3][16];
-  const int w = threadIdx.x >> 6;
-  if (lane == 0) { sh[0][w] = m0; sh[1][w] = m1; sh[2][w] = cnt; }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long a = sh[0][0], b = sh[1][0], c = sh[2][0];
-    for (int k = 1; k < nwaves; ++k) { a = umax64(a, sh[0][k]); b = umax64(b, sh[1][k]); c += sh[2][k]; }
-    publish_max(slots + 0, a);
-    if (use_m1) publish_max(slots + 1, b);
-    if (use_cnt && c) atomicAdd(slots + 2, c);
+    const unsigned long long tag = ((unsigned long long)seq << 32) | (cnt & 0xffffffffull);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2* r = reinterpret_cast<u64x2*>(rec + (size_t)blockIdx.x * kRecWords);
+    u64x2 g0 = {m0, tag}, g1 = {m1, tag};
+    r[0] = g0;  // one global_store_dwordx4 each: {payload, tag} granules
+    r[1] = g1;
   }
 }
 

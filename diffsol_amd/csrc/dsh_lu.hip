@@ -31,7 +31,7 @@ __global__ void k_lu_factor_reg(int64_t nb, const double* __restrict__ a, double
 
 template <int N>
 __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
-                               unsigned long long* slots) {
+                               unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bad = 0ull;
   if (b < nb) {
@@ -44,7 +44,7 @@ __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, c
     store_vec<N>(rhs, nb, b, v);
     bad = ok ? 0ull : 1ull;
   }
-  block_publish(0ull, 0ull, bad, slots, false, true);
+  block_publish(0ull, 0ull, bad, rec, seq);
 }
 
 __global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ factors, int32_t* __restrict__ piv, unsigned long long* singular_count) {
@@ -59,11 +59,11 @@ __global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ f
   if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
 }
 __global__ void k_lu_solve_global(int64_t n, int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
-                                  unsigned long long* slots) {
+                                  unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bad = 0ull;
   if (b < nb) bad = lu_solve_global(factors, piv, rhs, n, nb, b) ? 0ull : 1ull;
-  block_publish(0ull, 0ull, bad, slots, false, true);
+  block_publish(0ull, 0ull, bad, rec, seq);
 }
 
 }  // namespace
@@ -118,25 +118,25 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   if (!lu->factored) { set_error("dsh_lu_solve: LU not initialised"); return DSH_E_NOT_SETUP; }
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) return DSH_OK;
-  unsigned long long* slots;
-  int rc = take_slots(ctx, &slots);
-  if (rc != DSH_OK) return rc;
+  unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
+  if (rc != DSH_OK) return rc;
 #define DSH_LU_SOLVE_CASE(N) \
-  case N: hipLaunchKernelGGL((k_lu_solve_reg<N>), g, blk, 0, ctx->stream, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, slots); break;
+  case N: hipLaunchKernelGGL((k_lu_solve_reg<N>), g, blk, 0, ctx->stream, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
   switch (n) {
     DSH_LU_SOLVE_CASE(1) DSH_LU_SOLVE_CASE(2) DSH_LU_SOLVE_CASE(3) DSH_LU_SOLVE_CASE(4)
     DSH_LU_SOLVE_CASE(5) DSH_LU_SOLVE_CASE(6) DSH_LU_SOLVE_CASE(7) DSH_LU_SOLVE_CASE(8)
     default:
-      hipLaunchKernelGGL(k_lu_solve_global, g, blk, 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, slots);
+      hipLaunchKernelGGL(k_lu_solve_global, g, blk, 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq);
   }
 #undef DSH_LU_SOLVE_CASE
   DSH_HIP_CHECK(hipGetLastError());
   // LinearSolver::solve_in_place returns Result<(), LaError>: the zero-pivot flag has to come back (blocking, like the reference's getrs loop)
-  rc = fetch_slots(ctx, slots);
+  rc = fetch_records(ctx, g.x, seq);
   if (rc != DSH_OK) return rc;
-  if (ctx->mailbox[2] != 0ull) {
-    set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->mailbox[2]) + " system(s) (LuSolveFailed)");
+  if (ctx->res_cnt != 0ull) {
+    set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
     return DSH_E_SINGULAR;
   }
   return DSH_OK;

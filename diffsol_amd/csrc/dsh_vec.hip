@@ -125,7 +125,7 @@ __global__ void k_assign_at_indices(int64_t nidx, int64_t nb, const int32_t* __r
 // wave shuffle max -> conditional atomicMax into the slot group.  Loads are coalesced: lane b reads p[i*nb + b].
 template <bool BY, bool BA>
 __global__ void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
-                               double rtol, unsigned long long* slots, double* __restrict__ per_batch) {
+                               double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bits = 0ull;
   if (b < nb) {
@@ -140,10 +140,10 @@ __global__ void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__
     if (per_batch) per_batch[b] = nrm;
     bits = d2u(nrm);
   }
-  block_publish(bits, 0ull, 0ull, slots, false, false);
+  block_publish(bits, 0ull, 0ull, rec, seq);
 }
 
-__global__ void k_norm(int64_t n, int64_t nb, const double* __restrict__ x, int k, unsigned long long* slots) {
+__global__ void k_norm(int64_t n, int64_t nb, const double* __restrict__ x, int k, unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bits = 0ull;
   if (b < nb) {
@@ -153,12 +153,12 @@ __global__ void k_norm(int64_t n, int64_t nb, const double* __restrict__ x, int 
     else { for (int64_t i = 0; i < n; ++i) acc += pow(fabs(x[i * nb + b]), (double)k); acc = pow(acc, 1.0 / (double)k); }
     bits = d2u(acc);
   }
-  block_publish(bits, 0ull, 0ull, slots, false, false);
+  block_publish(bits, 0ull, 0ull, rec, seq);
 }
 
 // per-system root finding triple; results to three device arrays of nbatch entries
 __global__ void k_root_finding(int64_t n, int64_t nb, const double* __restrict__ g0, const double* __restrict__ g1, int32_t* __restrict__ found,
-                               int32_t* __restrict__ midx, double* __restrict__ frac, unsigned long long* slots) {
+                               int32_t* __restrict__ midx, double* __restrict__ frac, unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long mism = 0ull;
   int f = 0, mi = -1;
@@ -182,7 +182,7 @@ __global__ void k_root_finding(int64_t n, int64_t nb, const double* __restrict__
     }
   }
   if (b < nb && (f != f0 || mi != mi0)) mism = 1ull;
-  block_publish(0ull, 0ull, mism, slots, false, true);
+  block_publish(0ull, 0ull, mism, rec, seq);
 }
 
 }  // namespace
@@ -294,14 +294,15 @@ int dsh_vec_assign_at_indices(dsh_ctx* ctx, int64_t n, int64_t nb, const int32_t
 int dsh_vec_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, int k, double* out_max) {
   DSH_REQUIRE(k >= 1 && out_max, "bad arguments");
   if (n == 0) { *out_max = 0.0; return DSH_OK; }
-  unsigned long long* slots;
-  int rc = take_slots(ctx, &slots);
+  unsigned long long* rec; unsigned int seq;
+  dim3 g = grid_for(nb, ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
-  hipLaunchKernelGGL(k_norm, grid_for(nb, ctx->block), dim3(ctx->block), 0, ctx->stream, n, nb, x, k, slots);
+  hipLaunchKernelGGL(k_norm, g, dim3(ctx->block), 0, ctx->stream, n, nb, x, k, rec, seq);
   DSH_HIP_CHECK(hipGetLastError());
-  rc = fetch_slots(ctx, slots);
+  rc = fetch_records(ctx, g.x, seq);
   if (rc != DSH_OK) return rc;
-  *out_max = bits_to_double(ctx->mailbox[0]);
+  *out_max = bits_to_double(ctx->res_m0);
   return DSH_OK;
 }
 
@@ -310,19 +311,19 @@ int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, c
   DSH_CHECK_NB(ynb, nb); DSH_CHECK_NB(anb, nb);
   DSH_REQUIRE(out_max != nullptr, "out_max is null");
   if (n == 0) { *out_max = 0.0; return DSH_OK; }  // vector/cuda.rs:1365-1367
-  unsigned long long* slots;
-  int rc = take_slots(ctx, &slots);
+  unsigned long long* rec; unsigned int seq;
+  dim3 g = grid_for(nb, ctx->block), b(ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
   bool by = ynb == 1 && nb != 1, ba = anb == 1 && nb != 1;
-  dim3 g = grid_for(nb, ctx->block), b(ctx->block);
-  if (!by && !ba) hipLaunchKernelGGL((k_squared_norm<false, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, slots, per_batch_dev);
-  else if (by && !ba) hipLaunchKernelGGL((k_squared_norm<true, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, slots, per_batch_dev);
-  else if (!by && ba) hipLaunchKernelGGL((k_squared_norm<false, true>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, slots, per_batch_dev);
-  else hipLaunchKernelGGL((k_squared_norm<true, true>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, slots, per_batch_dev);
+  if (!by && !ba) hipLaunchKernelGGL((k_squared_norm<false, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+  else if (by && !ba) hipLaunchKernelGGL((k_squared_norm<true, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+  else if (!by && ba) hipLaunchKernelGGL((k_squared_norm<false, true>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+  else hipLaunchKernelGGL((k_squared_norm<true, true>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
   DSH_HIP_CHECK(hipGetLastError());
-  rc = fetch_slots(ctx, slots);
+  rc = fetch_records(ctx, g.x, seq);
   if (rc != DSH_OK) return rc;
-  *out_max = bits_to_double(ctx->mailbox[0]);
+  *out_max = bits_to_double(ctx->res_m0);
   return DSH_OK;
 }
 
@@ -333,22 +334,23 @@ int dsh_vec_root_finding(dsh_ctx* ctx, int64_t n, int64_t nb, const double* g0, 
   if (rc != DSH_OK) return rc;
   rc = ensure_f64_scratch(ctx, nb);
   if (rc != DSH_OK) return rc;
-  unsigned long long* slots;
-  rc = take_slots(ctx, &slots);
+  unsigned long long* rec; unsigned int seq;
+  dim3 g = grid_for(nb, ctx->block);
+  rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
-  hipLaunchKernelGGL(k_root_finding, grid_for(nb, ctx->block), dim3(ctx->block), 0, ctx->stream, n, nb, g0, g1, ctx->i32_scratch,
-                     ctx->i32_scratch + nb, ctx->f64_scratch, slots);
+  hipLaunchKernelGGL(k_root_finding, g, dim3(ctx->block), 0, ctx->stream, n, nb, g0, g1, ctx->i32_scratch, ctx->i32_scratch + nb, ctx->f64_scratch, rec, seq);
   DSH_HIP_CHECK(hipGetLastError());
   int32_t h_found = 0, h_idx = -1;
   double h_frac = 0.0;
   DSH_HIP_CHECK(hipMemcpyAsync(&h_found, ctx->i32_scratch, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipMemcpyAsync(&h_idx, ctx->i32_scratch + nb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipMemcpyAsync(&h_frac, ctx->f64_scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  rc = fetch_slots(ctx, slots);
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  rc = fetch_records(ctx, g.x, seq);
   if (rc != DSH_OK) return rc;
   *found = h_found; *idx = h_idx; *frac = h_frac;
-  if (ctx->mailbox[2] != 0ull) {
-    set_error("dsh_vec_root_finding: root finding results differ across batches (" + std::to_string((long long)ctx->mailbox[2]) + " of " +
+  if (ctx->res_cnt != 0ull) {
+    set_error("dsh_vec_root_finding: root finding results differ across batches (" + std::to_string((long long)ctx->res_cnt) + " of " +
               std::to_string((long long)nb) + " batch members disagree with member 0)");
     return DSH_E_BATCH_MISMATCH;
   }

@@ -150,6 +150,7 @@ class Bdf : public OdeSolverMethod {
     if (is_state_modified_) {  // bdf.rs:1290-1318: the state was moved (state_mut_back): restart from first order
       if (root_finder_) root_finder_->init(*pr_.eqn, y_, t_);
       n_equal_steps_ = 0;
+      prediction_valid_ = false;
       initialise_diff_to_first_order();
       u_ = compute_r(1, 1.0);
       is_state_modified_ = false;
@@ -162,7 +163,7 @@ class Bdf : public OdeSolverMethod {
     predict_forward();
     while (true) {
       const int order = order_;
-      y_delta_.copy_from(y_predict_);
+      if (!fused_) y_delta_.copy_from(y_predict_);  // fused mode: the first Newton launch reads the predictor directly
       double fused_err_sq = 0.0;
       NlError solve_result = fused_ ? newton_fused(fused_err_sq)
                                     : nonlinear_solver_.solve_in_place(op_, y_delta_, t_predict_, y_predict_, convergence_, line_search_);
@@ -204,8 +205,10 @@ class Bdf : public OdeSolverMethod {
     double sel_norms[2] = {0.0, 0.0};
     if (fused_) {
       check(dsh_bdf_accept_step(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_delta_.ptr(), y_.ptr(), dy_.ptr(), pr_.atol.ptr(),
-                                pr_.atol.nb(), pr_.rtol, will_select_order ? 1 : 0, sel_norms), "dsh_bdf_accept_step");
+                                pr_.atol.nb(), pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(), will_select_order ? 1 : 0, sel_norms),
+            "dsh_bdf_accept_step");
       t_ = t_predict_;
+      prediction_valid_ = true;  // y_predict / psi now hold the next step's prediction for (order_, h_)
     } else {
       update_diff(order_, y_delta_);
       y_.copy_from(y_predict_);
@@ -231,7 +234,7 @@ class Bdf : public OdeSolverMethod {
       for (int k = 1; k < 3; ++k) if (factors[k] >= factors[max_index]) max_index = k;
       const int new_order = max_index == 0 ? order - 1 : (max_index == 1 ? order : order + 1);
       order_ = new_order;
-      if (max_index != 1) u_ = compute_r(new_order, 1.0);
+      if (max_index != 1) { u_ = compute_r(new_order, 1.0); prediction_valid_ = false; }
       double factor = safety * factors[max_index];
       if (factor > maximum_timestep_growth_) factor = maximum_timestep_growth_;
       if (factor < minimum_timestep_shrink_) factor = minimum_timestep_shrink_;
@@ -357,6 +360,7 @@ class Bdf : public OdeSolverMethod {
   double update_step_size(double factor, bool ignore_too_small = false) {  // bdf.rs:508-577
     const double new_h = factor * h_;
     n_equal_steps_ = 0;
+    prediction_valid_ = false;
     const int order = order_;
     std::vector<double> r = compute_r(order, factor);
     std::vector<double> ru = mat_mul_small(r, u_, order + 1);
@@ -385,7 +389,9 @@ class Bdf : public OdeSolverMethod {
   }
 
   void predict_forward() {  // bdf.rs:674-692
-    if (fused_) {
+    if (fused_ && prediction_valid_) {
+      prediction_valid_ = false;  // produced by the accept launch of the previous step (same D, order and h => same bits)
+    } else if (fused_) {
       check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order_, diff_.ptr(), diff_tmp_.ptr(), nullptr, gamma_.data(), alpha_[(size_t)order_], y_predict_.ptr(),
                                  op_.psi_neg_y0().ptr()), "dsh_bdf_prepare_step");
     } else {
@@ -404,7 +410,7 @@ class Bdf : public OdeSolverMethod {
       double out[3] = {0.0, 0.0, 0.0};
       pr_.eqn->rhs_statistics.number_of_calls++;  // the fused launch evaluates f(y) once for every system
       check(dsh_bdf_newton_iter(ctx().raw(), model_, model_size_, nb(), t_predict_, op_.c(), y_delta_.ptr(), op_.psi_neg_y0().ptr(), pr_.eqn->params().ptr(),
-                                nonlinear_solver_.linear_solver().raw(), y_predict_.ptr(), y_.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, out),
+                                nonlinear_solver_.linear_solver().raw(), y_predict_.ptr(), y_.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, it == 0 ? 1 : 0, out),
             "dsh_bdf_newton_iter");
       if (out[2] != 0.0) return NlError::LuSolveFailed;
       const double norm = std::sqrt(out[0]);
@@ -452,6 +458,7 @@ class Bdf : public OdeSolverMethod {
   int maximum_error_test_failures_, maximum_newton_fails_;
   std::optional<double> prev_error_norm_;
   bool fused_ = false;
+  bool prediction_valid_ = false;
   int model_ = -1;
   int64_t model_size_ = 0;
 };

@@ -62,6 +62,9 @@ int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
  * dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch is bracketed by two events; get_timing returns the number of launches and
  * the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figure. */
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
+/* How blocking reductions wait for the device: poll != 0 (default; env DSH_SYNC_MODE=sync flips it) spins on the sequence tags of the
+ * per-workgroup result records the kernels write into pinned host memory; poll == 0 uses hipStreamSynchronize. */
+int dsh_ctx_set_poll(dsh_ctx* ctx, int poll);
 int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms);
 
 /* ---- device memory (cudarc alloc/alloc_zeros/memcpy_*: call sites throughout vector/cuda.rs, matrix/cuda.rs) ---- */
@@ -187,10 +190,12 @@ int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double
  * and, speculatively, the error-test quantity for the step (Bdf::error_control, ode_solver/bdf.rs:826-835, without the error constant):
  *   out[1] = max_b ||y - error_y||^2_(y_old)      (only if y_old != NULL)
  * out[2] = number of systems whose solve met a zero pivot (as a double).  out is a HOST array of 3 doubles.  Blocking.
+ * init_from_error_y != 0: the iterate is read from error_y instead of y (first iteration: `y_delta.copy_from(&y_predict)`, bdf.rs:1326,
+ * without a separate copy launch); y is written either way.
  * Supported for models with a register-resident specialisation (dsh_model_has_fused). */
 int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, double* y, const double* psi_neg_y0,
                         const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t atol_nb,
-                        double rtol, double* out);
+                        double rtol, int init_from_error_y, double* out);
 /* Same for the SDIRK stage residual F(k) = M k - h f(phi + c k)  (SdirkCallable::call_inplace diffsol/src/op/sdirk.rs:229-244);
  * out[0] = max_b ||delta||^2_(error_y), out[2] = singular count. */
 int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double h, double c, double* k, const double* phi,
@@ -213,10 +218,13 @@ int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, con
 /* BDF accepted-step update, one launch (Bdf::_update_diff :646-664, state update :1472-1478, predict_error_control :871-900):
  *   d = y_new - y_predict; D[:,k+2] = d - D[:,k+1]; D[:,k+1] = d; D[:,i] += D[:,i+1] for i=k..0; y = y_predict; dy = D[:,1]/h;
  *   out[0] = max_b ||D[:,k]||^2_(y)   (order-1 candidate, 0 if k==1), out[1] = max_b ||D[:,k+2]||^2_(y) (order+1 candidate).
- * out is a HOST array of 2 doubles, filled only if want_norms != 0 (then blocking). */
-int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, const double* y_predict,
-                        const double* y_new, double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, int want_norms,
-                        double* out);
+ * out is a HOST array of 2 doubles, filled only if want_norms != 0 (then blocking).
+ * If psi_neg_y0_next != NULL the same launch also writes the prediction for the NEXT step at unchanged order / step size
+ * (y_predict and psi_neg_y0_next exactly as dsh_bdf_prepare_step would from the updated D, gamma_host / alpha as there); the caller
+ * uses it when the controller leaves h and the order alone and otherwise overwrites it with dsh_bdf_prepare_step. */
+int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, double* y_predict, const double* y_new,
+                        double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
+                        double* psi_neg_y0_next, int want_norms, double* out);
 
 #ifdef __cplusplus
 }

@@ -126,7 +126,7 @@ def test_bdf_callable_kat_through_trait_ops_and_fused_kernel(H, ctx1, kats):
     atol = H.HipVec.from_vec([1e-6, 1e-6], ctx1)
     res = (C.c_double * 3)()
     ynew = y.clone()
-    assert L.dsh_bdf_newton_iter(ctx1._h, mid, 0, 1, k["t"], c, ynew.ptr, psi.ptr, p.ptr, lu._h, y.ptr, y.ptr, atol.ptr, 1, 1e-6, res) == 0
+    assert L.dsh_bdf_newton_iter(ctx1._h, mid, 0, 1, k["t"], c, ynew.ptr, psi.ptr, p.ptr, lu._h, y.ptr, y.ptr, atol.ptr, 1, 1e-6, 0, res) == 0
     delta = np.array(k["F"]) / 1.01
     assert np.allclose(ynew.clone_as_vec()[0], np.array(k["y"]) - delta, atol=1e-12)
     w = np.abs(np.array(k["y"])) * 1e-6 + 1e-6
@@ -201,7 +201,9 @@ def test_fused_bdf_prepare_and_accept_match_trait_op_composition(H, ctx1, order,
     Ynew, Y, DY, AT = H.HipVec.from_vec(ynew, c), H.HipVec.zeros(n, c), H.HipVec.zeros(n, c), H.HipVec.from_vec(atol, ctx1)
     Dn = H.HipMat.from_array(nd, c)
     res = (C.c_double * 2)()
-    assert L.dsh_bdf_accept_step(c._h, n, nb, order, h, Dn.ptr, yp.ptr, Ynew.ptr, Y.ptr, DY.ptr, AT.ptr, 1, rtol, 1, res) == 0
+    psi_next = H.HipVec.zeros(n, c)
+    assert L.dsh_bdf_accept_step(c._h, n, nb, order, h, Dn.ptr, yp.ptr, Ynew.ptr, Y.ptr, DY.ptr, AT.ptr, 1, rtol, gamma.ctypes.data_as(_ffi.c_dp), alpha,
+                                 psi_next.ptr, 1, res) == 0
     e = nd.copy()
     dd = ynew - ypr
     e[:, :, order + 2] = dd - e[:, :, order + 1]
@@ -218,3 +220,7 @@ def test_fused_bdf_prepare_and_accept_match_trait_op_composition(H, ctx1, order,
             acc = acc + term * term
         return (acc / n).max()
     assert res[0] == sq(e[:, :, order]) and res[1] == sq(e[:, :, order + 2])
+    # speculative prediction for the next step == what dsh_bdf_prepare_step computes from the updated D
+    yp2, psi2 = H.HipVec.zeros(n, c), H.HipVec.zeros(n, c)
+    assert L.dsh_bdf_prepare_step(c._h, n, nb, order, Dn.ptr, Dt.ptr, None, gamma.ctypes.data_as(_ffi.c_dp), alpha, yp2.ptr, psi2.ptr) == 0
+    assert np.array_equal(yp.clone_as_vec(), yp2.clone_as_vec()) and np.array_equal(psi_next.clone_as_vec(), psi2.clone_as_vec())
