@@ -92,11 +92,15 @@ DEVICE_ABI = {
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
-    "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, cint, c_dp]),
-    "dsh_sdirk_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_bdf_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
+    "dsh_reduction_wait": (cint, [vp, i64, c_dp]),
+    "dsh_sdirk_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
+    "dsh_sdirk_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_jac_factor": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, cint, vp, vp, vp]),
     "dsh_model_has_fused": (cint, [cint, i64]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
+    "dsh_bdf_accept_step_async": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, c_i64p]),
     "dsh_bdf_accept_step": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, cint, c_dp]),
 }
 

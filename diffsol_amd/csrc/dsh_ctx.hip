@@ -17,20 +17,20 @@ int begin_records(dsh_ctx* ctx, int64_t nblocks, unsigned long long** rec_dev, u
     while (cap < nblocks) cap *= 2;
     DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->rec_host) DSH_HIP_CHECK(hipHostFree(ctx->rec_host));
-    DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->rec_host, sizeof(unsigned long long) * kRecWords * cap, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(ctx->rec_host, 0, sizeof(unsigned long long) * kRecWords * cap);
+    DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->rec_host, sizeof(unsigned long long) * kRecWords * cap * kRecRegions, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(ctx->rec_host, 0, sizeof(unsigned long long) * kRecWords * cap * kRecRegions);
     DSH_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->rec_dev, ctx->rec_host, 0));
     ctx->rec_capacity = cap;
   }
   ctx->seq += 1;
   if (ctx->seq == 0) ctx->seq = 1;  // tag 0 is "never written"
-  *rec_dev = ctx->rec_dev;
+  *rec_dev = ctx->rec_dev + (size_t)(ctx->seq % kRecRegions) * ctx->rec_capacity * kRecWords;
   *seq = ctx->seq;
   return DSH_OK;
 }
 
-int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq) {
-  volatile unsigned long long* rec = ctx->rec_host;
+int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq, int64_t first_record) {
+  volatile unsigned long long* rec = ctx->rec_host + ((size_t)(seq % kRecRegions) * ctx->rec_capacity + (size_t)first_record) * kRecWords;
   if (!ctx->poll) DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   unsigned long long m0 = 0, m1 = 0, cnt = 0;
   const unsigned long long want = (unsigned long long)seq;
@@ -121,6 +121,8 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   hipDeviceProp_t prop;
   DSH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;
+  ctx->pool = new std::multimap<size_t, void*>();
+  ctx->live = new std::map<void*, size_t>();
   {
     const char* env = std::getenv("DSH_SYNC_MODE");  // "poll" (default) or "sync"
     ctx->poll = !(env && std::string(env) == "sync");
@@ -133,6 +135,8 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->pool) { for (auto& kv : *ctx->pool) (void)hipFree(kv.second); delete ctx->pool; }
+  if (ctx->live) { for (auto& kv : *ctx->live) (void)hipFree(kv.first); delete ctx->live; }
   if (ctx->rec_host) (void)hipHostFree(ctx->rec_host);
   if (ctx->i32_scratch) (void)hipFree(ctx->i32_scratch);
   if (ctx->f64_scratch) (void)hipFree(ctx->f64_scratch);
@@ -176,17 +180,40 @@ int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms) {
 
 int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out) {
   DSH_REQUIRE(nbytes >= 0 && out, "bad arguments");
-  DSH_HIP_CHECK(hipSetDevice(ctx->device));
+  const size_t want = nbytes > 0 ? (size_t)nbytes : 8;
   void* p = nullptr;
-  DSH_HIP_CHECK(hipMalloc(&p, nbytes > 0 ? (size_t)nbytes : 8));
+  auto it = ctx->pool->find(want);
+  if (it != ctx->pool->end()) {
+    p = it->second;
+    ctx->pool->erase(it);
+    ctx->pool_bytes -= want;
+  } else {
+    DSH_HIP_CHECK(hipSetDevice(ctx->device));
+    DSH_HIP_CHECK(hipMalloc(&p, want));
+  }
+  (*ctx->live)[p] = want;
   if (zero && nbytes > 0) DSH_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)nbytes, ctx->stream));
   *out = p;
   return DSH_OK;
 }
 int dsh_free(dsh_ctx* ctx, void* p) {
   if (!p) return DSH_OK;
-  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  DSH_HIP_CHECK(hipFree(p));
+  auto it = ctx->live->find(p);
+  if (it == ctx->live->end()) {  // not ours (or already freed): fall back to the runtime
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    DSH_HIP_CHECK(hipFree(p));
+    return DSH_OK;
+  }
+  const size_t sz = it->second;
+  ctx->live->erase(it);
+  constexpr size_t kMaxPoolBytes = (size_t)64 << 30;  // 288 GB of HBM: keep up to 64 GiB parked per context
+  if (ctx->pool_bytes + sz > kMaxPoolBytes) {
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    DSH_HIP_CHECK(hipFree(p));
+    return DSH_OK;
+  }
+  ctx->pool->emplace(sz, p);
+  ctx->pool_bytes += sz;
   return DSH_OK;
 }
 int dsh_memset_zero(dsh_ctx* ctx, void* p, int64_t nbytes) {

@@ -33,31 +33,37 @@ __device__ __forceinline__ void load_atol(const double* __restrict__ atol, int64
   for (int i = 0; i < N; ++i) a[i] = BA ? atol[i] : atol[(int64_t)i * nb + b];
 }
 
-// One Newton iteration of the BDF residual.  IS_SDIRK selects the SDIRK stage residual instead.
+// NIT consecutive Newton iterations of the BDF residual in one launch (IS_SDIRK selects the SDIRK stage residual instead).
 //   BDF  : delta = M(y + psi_neg_y0) - c f(y, t)             (op/bdf.rs:240-256)
 //   SDIRK: delta = M k - h f(phi + c k, t)                   (op/sdirk.rs:229-244)
-template <class Mdl, bool IS_SDIRK, bool BA, bool WITH_ERR>
-__global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* y, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
+// The convergence decision stays on the host (it needs the max over ALL systems), so the launch is speculative by construction: it
+// writes every intermediate iterate (y_out + i*n*nb) and one result record group per iteration; the host runs the reference's
+// Convergence state machine over the NIT norms in order and takes the first iterate that converged.  Iterations 2..NIT reuse the
+// factors / parameters / psi already in registers: they cost flops and 8n bytes of stores each, not another HBM pass nor another
+// launch + host round trip.
+template <class Mdl, bool IS_SDIRK, bool BA, bool WITH_ERR, int NIT>
+__global__ void k_newton_iter(int64_t nb, double t, double c, double h, const double* y_in, double* y_out, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
                               const double* __restrict__ p, const double* __restrict__ factors, const int32_t* __restrict__ piv,
-                              const double* __restrict__ error_y, const double* __restrict__ y_old, const double* __restrict__ atol, double rtol,
-                              int init_from_error_y, unsigned long long* rec, unsigned int seq) {
+                              const double* error_y, const double* __restrict__ y_old, const double* __restrict__ atol, double rtol,
+                              unsigned long long* rec, unsigned int seq) {
   constexpr int N = Mdl::N, NP = Mdl::NP;
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long nrm_bits = 0ull, err_bits = 0ull, bad = 0ull;
-  if (b < nb) {
-    double x[N], a[N], pp[NP], A[N * N], ey[N], at[N], yo[N];
-    int P[N];
-    // first iteration: the iterate starts from the predictor (y_delta.copy_from(y_predict), bdf.rs:1326) — selected through the source
-    // POINTER so that every load of the kernel is issued before the first wait (one HBM round trip, not two)
-    const double* xsrc = init_from_error_y ? error_y : y;
-    load_vec<N>(xsrc, nb, b, x);
-    load_vec<N>(error_y, nb, b, ey);
-    load_vec<N>(aux, nb, b, a);
-    load_vec<NP>(p, nb, b, pp);
-    load_mat<N>(factors, nb, b, A);
-    load_piv<N>(piv, nb, b, P);
-    load_atol<N, BA>(atol, nb, b, at);
-    if constexpr (WITH_ERR) load_vec<N>(y_old, nb, b, yo);
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = b < nb;
+  const int64_t bb = active ? b : 0;  // inactive lanes shadow system 0 (loads only) so that every lane reaches the block reductions
+  double x[N], a[N], pp[NP], A[N * N], ey[N], at[N], yo[N];
+  int P[N];
+  // The iterate is read from y_in (first iteration of a step: the predictor — y_delta.copy_from(y_predict), bdf.rs:1326, without a copy
+  // launch).  All loads are issued before the first use: one HBM round trip per launch.
+  load_vec<N>(y_in, nb, bb, x);
+  load_vec<N>(error_y, nb, bb, ey);
+  load_vec<N>(aux, nb, bb, a);
+  load_vec<NP>(p, nb, bb, pp);
+  load_mat<N>(factors, nb, bb, A);
+  load_piv<N>(piv, nb, bb, P);
+  load_atol<N, BA>(atol, nb, bb, at);
+  if constexpr (WITH_ERR) load_vec<N>(y_old, nb, bb, yo);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
     double f[N], tmp[N], delta[N];
     if constexpr (!IS_SDIRK) {
       Mdl::rhs(t, x, pp, f);
@@ -85,27 +91,30 @@ __global__ void k_newton_iter(int64_t nb, double t, double c, double h, double* 
         for (int i = 0; i < N; ++i) delta[i] = 1.0 * x[i] + beta * f[i];
       }
     }
-    bool ok = lu_solve_reg<N>(A, P, delta);
+    const bool ok = lu_solve_reg<N>(A, P, delta);
 #pragma unroll
     for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
-    store_vec<N>(y, nb, b, x);
-    nrm_bits = d2u(wms<N>(delta, ey, at, rtol));
-    if constexpr (WITH_ERR) {
-      double d[N];
+    unsigned long long nrm_bits = 0ull, err_bits = 0ull, bad = 0ull;
+    if (active) {
+      store_vec<N>(y_out + (int64_t)it * N * nb, nb, b, x);
+      nrm_bits = d2u(wms<N>(delta, ey, at, rtol));
+      if constexpr (WITH_ERR) {
+        double d[N];
 #pragma unroll
-      for (int i = 0; i < N; ++i) d[i] = x[i] - ey[i];
-      err_bits = d2u(wms<N>(d, yo, at, rtol));
+        for (int i = 0; i < N; ++i) d[i] = x[i] - ey[i];
+        err_bits = d2u(wms<N>(d, yo, at, rtol));
+      }
+      bad = ok ? 0ull : 1ull;
     }
-    bad = ok ? 0ull : 1ull;
+    block_publish(nrm_bits, err_bits, bad, rec + (size_t)it * gridDim.x * kRecWords, seq);
   }
-  block_publish(nrm_bits, err_bits, bad, rec, seq);
 }
 
 // Jacobian refresh + assembly of M - cJ + LU factorisation, one lane per system, A never leaves registers.
 template <class Mdl>
 __global__ void k_jac_factor(int64_t nb, double t, double c, const double* __restrict__ x, const double* __restrict__ p, int recompute,
                              double* __restrict__ rhs_jac, double* __restrict__ mass_jac, double* __restrict__ factors, int32_t* __restrict__ piv,
-                             unsigned long long* singular_count) {
+                             unsigned long long* singular_count, unsigned int epoch) {
   constexpr int N = Mdl::N, NP = Mdl::NP;
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long sing = 0ull;
@@ -139,7 +148,7 @@ __global__ void k_jac_factor(int64_t nb, double t, double c, const double* __res
     sing = s ? 1ull : 0ull;
   }
   sing = wave_sum_u64(sing);
-  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+  if ((threadIdx.x & 63) == 0 && sing) publish_singular(singular_count, sing, epoch);
 }
 
 struct BdfCoeffs {
@@ -187,16 +196,19 @@ __global__ void k_bdf_prepare(int64_t total, const double* __restrict__ diff, do
   }
 }
 
-// one lane per system: difference-array update, state update and the two order-selection norms
-template <bool BA>
-__global__ void k_bdf_accept(int64_t n, int64_t nb, int order, double inv_h, double* __restrict__ diff, double* y_predict,
+// one lane per system: difference-array update, state update and the two order-selection norms.  NS > 0: compile-time number of
+// states, the loop over the states is fully unrolled so that all loads of the launch are in flight together (one HBM round trip).
+template <bool BA, int NS>
+__global__ void k_bdf_accept(int64_t n_rt, int64_t nb, int order, double inv_h, double* __restrict__ diff, double* y_predict,
                              const double* __restrict__ y_new, double* __restrict__ y, double* __restrict__ dy, const double* __restrict__ atol, double rtol,
                              BdfCoeffs cf, double* __restrict__ psi_next, unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long m_bits = 0ull, p_bits = 0ull;
   if (b < nb) {
+    const int64_t n = NS > 0 ? NS : n_rt;
     const int64_t cs = n * nb;  // column stride
     double acc_m = 0.0, acc_p = 0.0;
+#pragma unroll
     for (int64_t i = 0; i < n; ++i) {
       const int64_t e = i * nb + b;
       double yp = y_predict[e];
@@ -263,32 +275,41 @@ int dsh_model_has_fused(int model, int64_t size) {
   return dispatch_static_model(model, size, [](auto) {}) ? 1 : 0;
 }
 
-static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, int64_t nb, double t, double c, double h, double* y, const double* aux,
-                         const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol,
-                         int init_from_error_y, double* out) {
+static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, int64_t nb, double t, double c, double h, int nit, const double* y_in,
+                         double* y_out, const double* aux, const double* p, const dsh_lu* lu, const double* error_y, const double* y_old,
+                         const double* atol, int64_t anb, double rtol, int64_t* ticket) {
   DSH_CHECK_NB(anb, nb);
-  DSH_REQUIRE(out != nullptr && lu != nullptr, "null argument");
+  DSH_REQUIRE(ticket != nullptr && lu != nullptr, "null argument");
+  DSH_REQUIRE(nit >= 1 && nit <= 4, "nit must be in 1..4");
   if (!lu->factored) { set_error("newton iteration: LU not initialised"); return DSH_E_NOT_SETUP; }
   unsigned long long* rec; unsigned int seq;
   const dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
-  int rc = begin_records(ctx, g.x, &rec, &seq);
+  int rc = begin_records(ctx, (int64_t)g.x * nit, &rec, &seq);
   if (rc != DSH_OK) return rc;
   const bool ba = anb == 1 && nb != 1;
   const bool with_err = y_old != nullptr;
   if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
-#define DSH_NEWTON_LAUNCH(SD, BA, WE)                                                                                                          \
-  hipLaunchKernelGGL((k_newton_iter<Mdl, SD, BA, WE>), g, blk, 0, ctx->stream, nb, t, c, h, y, aux, p, (const double*)lu->factors,               \
-                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, init_from_error_y, rec, seq)
-    if (is_sdirk) { if (ba) DSH_NEWTON_LAUNCH(true, true, false); else DSH_NEWTON_LAUNCH(true, false, false); }
-    else if (with_err) { if (ba) DSH_NEWTON_LAUNCH(false, true, true); else DSH_NEWTON_LAUNCH(false, false, true); }
-    else { if (ba) DSH_NEWTON_LAUNCH(false, true, false); else DSH_NEWTON_LAUNCH(false, false, false); }
+#define DSH_NEWTON_LAUNCH(SD, BA, WE, NIT)                                                                                                      \
+  hipLaunchKernelGGL((k_newton_iter<Mdl, SD, BA, WE, NIT>), g, blk, 0, ctx->stream, nb, t, c, h, y_in, y_out, aux, p, (const double*)lu->factors, \
+                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, rec, seq)
+#define DSH_NEWTON_NIT(SD, BA, WE)                                                                           \
+  switch (nit) {                                                                                             \
+    case 1: DSH_NEWTON_LAUNCH(SD, BA, WE, 1); break;                                                          \
+    case 2: DSH_NEWTON_LAUNCH(SD, BA, WE, 2); break;                                                          \
+    case 3: DSH_NEWTON_LAUNCH(SD, BA, WE, 3); break;                                                          \
+    default: DSH_NEWTON_LAUNCH(SD, BA, WE, 4);                                                                \
+  }
+    if (is_sdirk) { if (ba) { DSH_NEWTON_NIT(true, true, false) } else { DSH_NEWTON_NIT(true, false, false) } }
+    else if (with_err) { if (ba) { DSH_NEWTON_NIT(false, true, true) } else { DSH_NEWTON_NIT(false, false, true) } }
+    else { if (ba) { DSH_NEWTON_NIT(false, true, false) } else { DSH_NEWTON_NIT(false, false, false) } }
+#undef DSH_NEWTON_NIT
 #undef DSH_NEWTON_LAUNCH
   });
   if (!ok) { set_error("newton iteration: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipGetLastError());
-  if (ctx->timing) {
+  if (ctx->timing) {  // event timing needs completed events: timed launches are synchronous
     DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
     DSH_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
     float ms = 0.f;
@@ -296,32 +317,62 @@ static int newton_common(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
     ctx->timed_ms += (double)ms;
     ctx->timed_launches += 1;
   }
-  rc = fetch_records(ctx, g.x, seq);
-  if (rc != DSH_OK) return rc;
-  out[0] = bits_to_double(ctx->res_m0);
-  out[1] = bits_to_double(ctx->res_m1);
-  out[2] = (double)ctx->res_cnt;
+  *ticket = ((int64_t)seq << 32) | ((int64_t)nit << 24) | (int64_t)g.x;
   return DSH_OK;
 }
 
-int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, double* y, const double* psi_neg_y0, const double* p,
-                        const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol, int init_from_error_y,
-                        double* out) {
-  return newton_common(ctx, false, model, size, nb, t, c, 0.0, y, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, init_from_error_y, out);
+// ticket = seq << 32 | groups << 24 | workgroups; out receives 3 doubles per record group
+int dsh_reduction_wait(dsh_ctx* ctx, int64_t ticket, double* out) {
+  DSH_REQUIRE(out != nullptr, "out is null");
+  const unsigned int seq = (unsigned int)((uint64_t)ticket >> 32);
+  const int groups = (int)((ticket >> 24) & 0xff);
+  const int64_t nblocks = ticket & 0xffffffll;
+  if (ctx->seq - seq >= (unsigned int)kRecRegions) { set_error("dsh_reduction_wait: ticket is too old, its result records have been reused"); return DSH_E_STALE; }
+  for (int gi = 0; gi < (groups > 0 ? groups : 1); ++gi) {
+    int rc = fetch_records(ctx, nblocks, seq, gi * nblocks);
+    if (rc != DSH_OK) return rc;
+    out[3 * gi + 0] = bits_to_double(ctx->res_m0);
+    out[3 * gi + 1] = bits_to_double(ctx->res_m1);
+    out[3 * gi + 2] = (double)ctx->res_cnt;
+  }
+  return DSH_OK;
 }
-int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, double* k, const double* phi, const double* p,
-                          const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol, double* out) {
-  return newton_common(ctx, true, model, size, nb, t, c, h, k, phi, p, lu, error_y, nullptr, atol, anb, rtol, 0, out);
+
+int dsh_bdf_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, int nit, const double* y_in, double* y_out,
+                              const double* psi_neg_y0, const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol,
+                              int64_t anb, double rtol, int64_t* ticket) {
+  return newton_launch(ctx, false, model, size, nb, t, c, 0.0, nit, y_in, y_out, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, ticket);
+}
+int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* y_in, double* y_out, const double* psi_neg_y0,
+                        const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol,
+                        double* out) {
+  int64_t ticket = 0;
+  int rc = newton_launch(ctx, false, model, size, nb, t, c, 0.0, 1, y_in, y_out, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, &ticket);
+  if (rc != DSH_OK) return rc;
+  return dsh_reduction_wait(ctx, ticket, out);
+}
+int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, int nit, const double* k_in, double* k_out,
+                                const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
+                                int64_t* ticket) {
+  return newton_launch(ctx, true, model, size, nb, t, c, h, nit, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, ticket);
+}
+int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, const double* k_in, double* k_out,
+                          const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
+                          double* out) {
+  int64_t ticket = 0;
+  int rc = newton_launch(ctx, true, model, size, nb, t, c, h, 1, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, &ticket);
+  if (rc != DSH_OK) return rc;
+  return dsh_reduction_wait(ctx, ticket, out);
 }
 
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* x, const double* p, int recompute, double* rhs_jac,
                    double* mass_jac, dsh_lu* lu) {
   DSH_REQUIRE(lu != nullptr && rhs_jac != nullptr, "null argument");
-  DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
+  lu->singular_epoch += 1;  // the kernel adds (epoch << 32 | 1) per singular system: no reset launch needed between factorisations
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     hipLaunchKernelGGL((k_jac_factor<Mdl>), grid_for(nb, ctx->block), dim3(ctx->block), 0, ctx->stream, nb, t, c, x, p, recompute, rhs_jac, mass_jac,
-                       lu->factors, lu->pivots, lu->singular);
+                       lu->factors, lu->pivots, lu->singular, lu->singular_epoch);
   });
   if (!ok) { set_error("dsh_jac_factor: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipGetLastError());
@@ -346,12 +397,10 @@ int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, const d
   return DSH_OK;
 }
 
-int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
-                        double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
-                        int want_norms, double* out) {
+static int accept_launch(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y, double* dy,
+                         const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next, int64_t* ticket) {
   DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
   DSH_CHECK_NB(anb, nb);
-  if (n * nb == 0) return DSH_OK;
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
   int rc = begin_records(ctx, g.x, &rec, &seq);
@@ -361,15 +410,43 @@ int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h
   for (int k = 0; k < 36; ++k) cf.ru[k] = 0.0;
   for (int k = 0; k < 6; ++k) cf.gamma[k] = (psi_neg_y0_next && k <= order) ? gamma_host[k] : 0.0;
   cf.alpha = alpha; cf.order = order; cf.rescale = 0;
-  if (anb == 1 && nb != 1) hipLaunchKernelGGL((k_bdf_accept<true>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf, psi_neg_y0_next, rec, seq);
-  else hipLaunchKernelGGL((k_bdf_accept<false>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf, psi_neg_y0_next, rec, seq);
+  const bool ba = anb == 1 && nb != 1;
+#define DSH_ACCEPT_LAUNCH(BA, NS) \
+  hipLaunchKernelGGL((k_bdf_accept<BA, NS>), g, blk, 0, ctx->stream, n, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf, psi_neg_y0_next, rec, seq)
+#define DSH_ACCEPT_CASE(NS) case NS: if (ba) DSH_ACCEPT_LAUNCH(true, NS); else DSH_ACCEPT_LAUNCH(false, NS); break;
+  switch (n) {
+    DSH_ACCEPT_CASE(1) DSH_ACCEPT_CASE(2) DSH_ACCEPT_CASE(3) DSH_ACCEPT_CASE(4)
+    default: if (ba) DSH_ACCEPT_LAUNCH(true, 0); else DSH_ACCEPT_LAUNCH(false, 0);
+  }
+#undef DSH_ACCEPT_CASE
+#undef DSH_ACCEPT_LAUNCH
   DSH_HIP_CHECK(hipGetLastError());
+  *ticket = ((int64_t)seq << 32) | ((int64_t)1 << 24) | (int64_t)g.x;
+  return DSH_OK;
+}
+
+int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
+                              double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
+                              int64_t* ticket) {
+  DSH_REQUIRE(ticket != nullptr, "ticket is null");
+  if (n * nb == 0) { *ticket = 0; return DSH_OK; }
+  return accept_launch(ctx, n, nb, order, h, diff, y_predict, y_new, y, dy, atol, anb, rtol, gamma_host, alpha, psi_neg_y0_next, ticket);
+}
+
+int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
+                        double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
+                        int want_norms, double* out) {
+  if (n * nb == 0) return DSH_OK;
+  int64_t ticket = 0;
+  int rc = accept_launch(ctx, n, nb, order, h, diff, y_predict, y_new, y, dy, atol, anb, rtol, gamma_host, alpha, psi_neg_y0_next, &ticket);
+  if (rc != DSH_OK) return rc;
   if (want_norms) {
     DSH_REQUIRE(out != nullptr, "out is null");
-    rc = fetch_records(ctx, g.x, seq);
+    double r[3];
+    rc = dsh_reduction_wait(ctx, ticket, r);
     if (rc != DSH_OK) return rc;
-    out[0] = bits_to_double(ctx->res_m0);
-    out[1] = bits_to_double(ctx->res_m1);
+    out[0] = r[0];
+    out[1] = r[1];
   }
   return DSH_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 
 #include "../../include/diffsol_hip.h"
@@ -40,6 +41,9 @@ void set_error(const std::string& msg);
 // mode — as soon as every record carries the launch's sequence tag (the granules travel as single PCIe writes, so a tag that has
 // arrived implies its payload has).
 constexpr int kRecWords = 4;
+// Records of the last kRecRegions reducing launches stay readable (launch seq uses region seq % kRecRegions), so a caller may keep
+// a few reducing launches in flight and collect their results later (speculative Newton pipelining).
+constexpr int kRecRegions = 8;
 
 }  // namespace dsh
 
@@ -59,6 +63,12 @@ struct dsh_ctx {
   int64_t i32_scratch_len = 0;
   double* f64_scratch = nullptr;
   int64_t f64_scratch_len = 0;
+  // Stream-ordered allocation cache: dsh_free parks blocks here (keyed by size) and dsh_malloc reuses them.  All users of a context
+  // issue work on its one in-order stream, so handing a parked block to a new owner is safe without synchronising: every kernel
+  // of the old owner was enqueued before any kernel of the new one.  (hipMalloc/hipFree cost 50-200 us each and hipFree synchronises.)
+  std::multimap<size_t, void*>* pool = nullptr;
+  std::map<void*, size_t>* live = nullptr;
+  size_t pool_bytes = 0;
   // optional HIP-event timing of the dominant (fused Newton iteration) kernel on this context's stream
   bool timing = false;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -72,7 +82,11 @@ struct dsh_lu {
   int64_t n = 0, nbatch = 0;
   double* factors = nullptr;   // (j*n+i)*nbatch + b
   int32_t* pivots = nullptr;   // k*nbatch + b : row swapped with row k at elimination step k
-  unsigned long long* singular = nullptr;  // device counter of systems with a zero pivot in the last factorisation
+  // device word: (epoch << 32) | number of systems with a zero pivot found by the factorisation launch of that epoch.  A launch of a
+  // newer epoch replaces an older word (CAS loop, only executed by waves that actually found a singular system), so no reset
+  // launch is needed between factorisations.
+  unsigned long long* singular = nullptr;
+  unsigned int singular_epoch = 0;
   bool factored = false;
 };
 
@@ -82,7 +96,7 @@ namespace dsh {
 // kernel writes to plus the sequence tag it must stamp.
 int begin_records(dsh_ctx* ctx, int64_t nblocks, unsigned long long** rec_dev, unsigned int* seq);
 // Wait for the launch's records and reduce them on the host into ctx->res_m0 / res_m1 / res_cnt.
-int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq);
+int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq, int64_t first_record = 0);
 int ensure_i32_scratch(dsh_ctx* ctx, int64_t len);
 int ensure_f64_scratch(dsh_ctx* ctx, int64_t len);
 
@@ -116,6 +130,17 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
+__device__ __forceinline__ void publish_singular(unsigned long long* word, unsigned long long count, unsigned int epoch) {
+  unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned long long base = (old >> 32) == epoch ? (old & 0xffffffffull) : 0ull;
+    const unsigned long long desired = ((unsigned long long)epoch << 32) | (base + count);
+    const unsigned long long prev = atomicCAS(word, old, desired);
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
 // Block-level reduction of two maxima and one count, then ONE record (two 16-byte stores by thread 0) to host-mapped memory.
 // Works for any block size that is a multiple of 64 up to 1024.  Every thread of the block must call it.
 __device__ __forceinline__ void block_publish(unsigned long long m0, unsigned long long m1, unsigned long long cnt, unsigned long long* rec,
@@ -142,6 +167,7 @@ __device__ __forceinline__ void block_publish(unsigned long long m0, unsigned lo
     r[0] = g0;  // one global_store_dwordx4 each: {payload, tag} granules
     r[1] = g1;
   }
+  if (nwaves > 1) __syncthreads();  // the LDS staging array may be reused by another reduction of the same launch
 }
 
 #endif  // __HIPCC__

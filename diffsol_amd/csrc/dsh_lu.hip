@@ -12,7 +12,7 @@ namespace {
 
 template <int N>
 __global__ void k_lu_factor_reg(int64_t nb, const double* __restrict__ a, double* __restrict__ factors, int32_t* __restrict__ piv,
-                                unsigned long long* singular_count) {
+                                unsigned long long* singular_count, unsigned int epoch) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long sing = 0ull;
   if (b < nb) {
@@ -26,7 +26,7 @@ __global__ void k_lu_factor_reg(int64_t nb, const double* __restrict__ a, double
     sing = s ? 1ull : 0ull;
   }
   sing = wave_sum_u64(sing);
-  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+  if ((threadIdx.x & 63) == 0 && sing) publish_singular(singular_count, sing, epoch);
 }
 
 template <int N>
@@ -47,7 +47,8 @@ __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, c
   block_publish(0ull, 0ull, bad, rec, seq);
 }
 
-__global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ factors, int32_t* __restrict__ piv, unsigned long long* singular_count) {
+__global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ factors, int32_t* __restrict__ piv, unsigned long long* singular_count,
+                                   unsigned int epoch) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long sing = 0ull;
   if (b < nb) {
@@ -56,7 +57,7 @@ __global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ f
     sing = s ? 1ull : 0ull;
   }
   sing = wave_sum_u64(sing);
-  if ((threadIdx.x & 63) == 0 && sing) atomicAdd(singular_count, sing);
+  if ((threadIdx.x & 63) == 0 && sing) publish_singular(singular_count, sing, epoch);
 }
 __global__ void k_lu_solve_global(int64_t n, int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
                                   unsigned long long* rec, unsigned int seq) {
@@ -95,18 +96,18 @@ int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu->pivots; }
 int dsh_lu_factor(dsh_lu* lu, const double* a) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
-  DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
+  lu->singular_epoch += 1;
   lu->factored = true;
   if (n == 0) return DSH_OK;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
 #define DSH_LU_FACTOR_CASE(N) \
-  case N: hipLaunchKernelGGL((k_lu_factor_reg<N>), g, blk, 0, ctx->stream, nb, a, lu->factors, lu->pivots, lu->singular); break;
+  case N: hipLaunchKernelGGL((k_lu_factor_reg<N>), g, blk, 0, ctx->stream, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
   switch (n) {
     DSH_LU_FACTOR_CASE(1) DSH_LU_FACTOR_CASE(2) DSH_LU_FACTOR_CASE(3) DSH_LU_FACTOR_CASE(4)
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
     default:
       DSH_HIP_CHECK(hipMemcpyAsync(lu->factors, a, sizeof(double) * n * n * nb, hipMemcpyDeviceToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_lu_factor_global, g, blk, 0, ctx->stream, n, nb, lu->factors, lu->pivots, lu->singular);
+      hipLaunchKernelGGL(k_lu_factor_global, g, blk, 0, ctx->stream, n, nb, lu->factors, lu->pivots, lu->singular, lu->singular_epoch);
   }
 #undef DSH_LU_FACTOR_CASE
   DSH_HIP_CHECK(hipGetLastError());
@@ -146,7 +147,7 @@ int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular) {
   unsigned long long h = 0;
   DSH_HIP_CHECK(hipMemcpyAsync(&h, lu->singular, sizeof(h), hipMemcpyDeviceToHost, lu->ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(lu->ctx->stream));
-  *n_singular = (int64_t)h;
+  *n_singular = (unsigned int)(h >> 32) == lu->singular_epoch ? (int64_t)(h & 0xffffffffull) : 0;
   return DSH_OK;
 }
 

@@ -8,9 +8,40 @@
 //   bdf.rs:244-368 _new, :433-463 _compute_r, :465-506 _jacobian_updates, :508-577 _update_step_size, :646-692 _update_diff/_predict,
 //   :694-731 handle_tstop, :767-811 interpolation, :812-932 error control, :1277-1589 step
 #pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "ode.hpp"
 
 namespace diffsol_hip {
+
+// Optional host-side wall-clock accounting of the fused step loop (DSH_PROFILE_HOST=1 prints it when the solver is destroyed).
+struct HostProfile {
+  bool on = false;
+  double t_launch_newton = 0, t_wait_newton = 0, t_launch_accept = 0, t_wait_accept = 0, t_jac = 0, t_prepare = 0;
+  long n_launch_newton = 0, n_wait_newton = 0, n_launch_accept = 0, n_wait_accept = 0, n_jac = 0, n_prepare = 0;
+  static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  ~HostProfile() {
+    if (!on) return;
+    std::fprintf(stderr, "[host profile] launch_newton %ld x %.2f us | wait_newton %ld x %.2f us | launch_accept %ld x %.2f us | wait_accept %ld x %.2f us | jac %ld x %.2f us | prepare %ld x %.2f us\n",
+                 n_launch_newton, 1e6 * t_launch_newton / std::max(1L, n_launch_newton), n_wait_newton, 1e6 * t_wait_newton / std::max(1L, n_wait_newton),
+                 n_launch_accept, 1e6 * t_launch_accept / std::max(1L, n_launch_accept), n_wait_accept, 1e6 * t_wait_accept / std::max(1L, n_wait_accept),
+                 n_jac, 1e6 * t_jac / std::max(1L, n_jac), n_prepare, 1e6 * t_prepare / std::max(1L, n_prepare));
+  }
+};
+#define DSH_PROF(field, stmt)                                  \
+  do {                                                         \
+    if (prof_.on) {                                            \
+      double _t0 = HostProfile::now();                         \
+      stmt;                                                    \
+      prof_.t_##field += HostProfile::now() - _t0;             \
+      prof_.n_##field += 1;                                    \
+    } else {                                                   \
+      stmt;                                                    \
+    }                                                          \
+  } while (0)
 
 // op/bdf.rs:15-300
 class BdfCallable : public NonLinearOpRef {
@@ -112,7 +143,12 @@ class Bdf : public OdeSolverMethod {
     if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, y_, t_); }
     diff_tmp_ = HipMat::zeros(n, MAX_ORDER + 3, ctx);
     y_delta_ = HipVec::zeros(n, ctx);
+    if (const char* env = std::getenv("DSH_PROFILE_HOST")) prof_.on = std::string(env) == "1";
+    if (const char* env = std::getenv("DSH_NEWTON_NIT")) nit_ = std::max(1, std::min(4, std::atoi(env)));
+    if (fused_) { ybuf_[0] = HipVec::zeros(n * nit_, ctx); ybuf_[1] = HipVec::zeros(n * nit_, ctx); }
+    y_new_ = y_delta_.ptr();
     y_predict_ = HipVec::zeros(n, ctx);
+    if (const char* env = std::getenv("DSH_NEWTON_PIPELINE")) pipeline_ = std::string(env) != "0";
     d_tmp_ = HipVec::zeros(n, ctx);
     u_ = compute_r(order_, 1.0);
     statistics_.number_of_linear_solver_setups = 1;
@@ -151,6 +187,7 @@ class Bdf : public OdeSolverMethod {
       if (root_finder_) root_finder_->init(*pr_.eqn, y_, t_);
       n_equal_steps_ = 0;
       prediction_valid_ = false;
+      prelaunch_valid_ = false;
       initialise_diff_to_first_order();
       u_ = compute_r(1, 1.0);
       is_state_modified_ = false;
@@ -204,11 +241,26 @@ class Bdf : public OdeSolverMethod {
     const bool will_select_order = (n_equal_steps_ + 1) > order_;
     double sel_norms[2] = {0.0, 0.0};
     if (fused_) {
-      check(dsh_bdf_accept_step(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_delta_.ptr(), y_.ptr(), dy_.ptr(), pr_.atol.ptr(),
-                                pr_.atol.nb(), pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(), will_select_order ? 1 : 0, sel_norms),
-            "dsh_bdf_accept_step");
+      int64_t accept_ticket = 0;
+      DSH_PROF(launch_accept, check(dsh_bdf_accept_step_async(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_new_, y_.ptr(), dy_.ptr(), pr_.atol.ptr(),
+                                      pr_.atol.nb(), pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(), &accept_ticket),
+            "dsh_bdf_accept_step_async"));
       t_ = t_predict_;
       prediction_valid_ = true;  // y_predict / psi now hold the next step's prediction for (order_, h_)
+      if (pipeline_) {
+        // Speculatively enqueue the first Newton launch of the NEXT step (valid if the controller leaves h, the order and the LU
+        // factors alone — the common case) before waiting for this step's order-selection norms: the GPU stays busy across the step.
+        // The accept launch above reads y_new_ (possibly in group buffer 0) and is stream-ordered before this launch overwrites it.
+        prelaunch_nit_ = std::min(nit_, convergence_.max_iter());
+        launch_newton(prelaunch_nit_, y_predict_.ptr(), 0, t_ + h_, &prelaunch_ticket_);
+        prelaunch_valid_ = true;
+      }
+      if (will_select_order) {
+        double r[3];
+        DSH_PROF(wait_accept, check(dsh_reduction_wait(ctx().raw(), accept_ticket, r), "dsh_reduction_wait(accept)"));
+        sel_norms[0] = r[0];
+        sel_norms[1] = r[1];
+      }
     } else {
       update_diff(order_, y_delta_);
       y_.copy_from(y_predict_);
@@ -234,7 +286,7 @@ class Bdf : public OdeSolverMethod {
       for (int k = 1; k < 3; ++k) if (factors[k] >= factors[max_index]) max_index = k;
       const int new_order = max_index == 0 ? order - 1 : (max_index == 1 ? order : order + 1);
       order_ = new_order;
-      if (max_index != 1) { u_ = compute_r(new_order, 1.0); prediction_valid_ = false; }
+      if (max_index != 1) { u_ = compute_r(new_order, 1.0); prediction_valid_ = false; prelaunch_valid_ = false; }
       double factor = safety * factors[max_index];
       if (factor > maximum_timestep_growth_) factor = maximum_timestep_growth_;
       if (factor < minimum_timestep_shrink_) factor = minimum_timestep_shrink_;
@@ -327,11 +379,12 @@ class Bdf : public OdeSolverMethod {
 
   // NewtonNonlinearSolver::reset_jacobian(op, state.y, state.t): assemble M - cJ and factor
   void reset_jacobian() {
+    prelaunch_valid_ = false;  // a pre-launched Newton iteration used the old factors
     if (fused_) {
       const bool recompute = op_.jacobian_is_stale();
       if (recompute) { pr_.eqn->rhs_statistics.number_of_matrix_evals++; pr_.eqn->rhs_statistics.number_of_jac_muls += n(); }
-      check(dsh_jac_factor(ctx().raw(), model_, model_size_, nb(), t_, op_.c(), y_.ptr(), pr_.eqn->params().ptr(), recompute ? 1 : 0, op_.rhs_jac().ptr(),
-                           op_.mass_jac().ptr(), nonlinear_solver_.linear_solver().raw()), "dsh_jac_factor");
+      DSH_PROF(jac, check(dsh_jac_factor(ctx().raw(), model_, model_size_, nb(), t_, op_.c(), y_.ptr(), pr_.eqn->params().ptr(), recompute ? 1 : 0, op_.rhs_jac().ptr(),
+                           op_.mass_jac().ptr(), nonlinear_solver_.linear_solver().raw()), "dsh_jac_factor"));
       op_.clear_jacobian_is_stale();
       nonlinear_solver_.mark_jacobian_set();
     } else {
@@ -361,6 +414,7 @@ class Bdf : public OdeSolverMethod {
     const double new_h = factor * h_;
     n_equal_steps_ = 0;
     prediction_valid_ = false;
+    prelaunch_valid_ = false;
     const int order = order_;
     std::vector<double> r = compute_r(order, factor);
     std::vector<double> ru = mat_mul_small(r, u_, order + 1);
@@ -392,8 +446,8 @@ class Bdf : public OdeSolverMethod {
     if (fused_ && prediction_valid_) {
       prediction_valid_ = false;  // produced by the accept launch of the previous step (same D, order and h => same bits)
     } else if (fused_) {
-      check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order_, diff_.ptr(), diff_tmp_.ptr(), nullptr, gamma_.data(), alpha_[(size_t)order_], y_predict_.ptr(),
-                                 op_.psi_neg_y0().ptr()), "dsh_bdf_prepare_step");
+      DSH_PROF(prepare, check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order_, diff_.ptr(), diff_tmp_.ptr(), nullptr, gamma_.data(), alpha_[(size_t)order_], y_predict_.ptr(),
+                                 op_.psi_neg_y0().ptr()), "dsh_bdf_prepare_step"));
     } else {
       y_predict_.fill(0.0);
       for (int i = 0; i <= order_; ++i) y_predict_.add_assign(diff_.column(i));
@@ -403,21 +457,62 @@ class Bdf : public OdeSolverMethod {
   }
 
   // newton_iteration + NoLineSearch::take_optimal_step with the whole iteration in one launch (dsh_bdf_newton_iter)
+  // newton_iteration + NoLineSearch::take_optimal_step with each iteration in ONE launch (dsh_bdf_newton_iter), pipelined: while the host
+  // evaluates the convergence test of iteration k, iteration k+1 is already running speculatively into the other iterate buffer
+  // (it k reads buf[(k-1)%2] — the predictor for k = 1 — and writes buf[k%2]).  If iteration k turns out to have converged / diverged
+  // the speculative launch is simply ignored; otherwise its result is the next one needed.  Every iterate is the same function of the
+  // same inputs as in the sequential algorithm, so results stay bit-identical; only the GPU idle time of the host round trip goes away.
+  // Enqueue one launch of `nit` consecutive Newton iterations for the step ending at t_pred, starting from `y_in`; the iterates go to
+  // group buffer `g` (nit_ * n * nb doubles each).
+  void launch_newton(int nit, const double* y_in, int g, double t_pred, int64_t* ticket) {
+    DSH_PROF(launch_newton, check(dsh_bdf_newton_iter_async(ctx().raw(), model_, model_size_, nb(), t_pred, op_.c(), nit, y_in, ybuf_[g].ptr(), op_.psi_neg_y0().ptr(),
+                                    pr_.eqn->params().ptr(), nonlinear_solver_.linear_solver().raw(), y_predict_.ptr(), y_.ptr(), pr_.atol.ptr(),
+                                    pr_.atol.nb(), pr_.rtol, ticket), "dsh_bdf_newton_iter_async"));
+  }
+
+  // newton_iteration + NoLineSearch::take_optimal_step (diffsol-nl/src/newton.rs:13-36, line_search.rs:48-69) with nit_ iterations per
+  // launch.  The host walks the returned norms through the reference's Convergence state machine in order and stops at the first
+  // Converged / Diverged verdict; iterates computed beyond that point are discarded speculative work.  Every iterate is the same function
+  // of the same inputs as in the one-iteration-at-a-time algorithm, so results and counters stay bit-identical.
   NlError newton_fused(double& err_sq_out) {
     if (!nonlinear_solver_.is_jacobian_set()) return NlError::JacobianNotReset;
     convergence_.reset();
-    for (int it = 0; it < convergence_.max_iter(); ++it) {
-      double out[3] = {0.0, 0.0, 0.0};
-      pr_.eqn->rhs_statistics.number_of_calls++;  // the fused launch evaluates f(y) once for every system
-      check(dsh_bdf_newton_iter(ctx().raw(), model_, model_size_, nb(), t_predict_, op_.c(), y_delta_.ptr(), op_.psi_neg_y0().ptr(), pr_.eqn->params().ptr(),
-                                nonlinear_solver_.linear_solver().raw(), y_predict_.ptr(), y_.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, it == 0 ? 1 : 0, out),
-            "dsh_bdf_newton_iter");
-      if (out[2] != 0.0) return NlError::LuSolveFailed;
-      const double norm = std::sqrt(out[0]);
-      ConvergenceStatus st = convergence_.check_new_iteration(norm);
-      err_sq_out = out[1];
-      if (st == ConvergenceStatus::Converged) return NlError::Ok;
-      if (st == ConvergenceStatus::Diverged) return NlError::NewtonDiverged;
+    const int max_iter = convergence_.max_iter();
+    const int64_t stride = n() * nb();
+    int done = 0, g = 0;
+    const double* src = y_predict_.ptr();
+    bool use_prelaunch = prelaunch_valid_;
+    prelaunch_valid_ = false;
+    while (done < max_iter) {
+      const int nit = std::min(nit_, max_iter - done);
+      int64_t ticket = 0;
+      double out[12];
+      int rc;
+      if (use_prelaunch && nit == prelaunch_nit_) {  // enqueued right after the previous step's accept launch (group buffer 0)
+        ticket = prelaunch_ticket_;
+        DSH_PROF(wait_newton, rc = dsh_reduction_wait(ctx().raw(), ticket, out));
+        if (rc == DSH_E_STALE) {  // its records were recycled by other reductions (e.g. root finding): redo it — same inputs, same bits
+          launch_newton(nit, src, g, t_predict_, &ticket);
+          rc = dsh_reduction_wait(ctx().raw(), ticket, out);
+        }
+      } else {
+        launch_newton(nit, src, g, t_predict_, &ticket);
+        DSH_PROF(wait_newton, rc = dsh_reduction_wait(ctx().raw(), ticket, out));
+      }
+      use_prelaunch = false;
+      check(rc, "dsh_reduction_wait");
+      for (int i = 0; i < nit; ++i) {
+        pr_.eqn->rhs_statistics.number_of_calls++;  // iteration i evaluated f(y) once for every system
+        if (out[3 * i + 2] != 0.0) return NlError::LuSolveFailed;
+        ConvergenceStatus st = convergence_.check_new_iteration(std::sqrt(out[3 * i + 0]));
+        err_sq_out = out[3 * i + 1];
+        y_new_ = ybuf_[g].ptr() + (int64_t)i * stride;
+        if (st == ConvergenceStatus::Converged) return NlError::Ok;
+        if (st == ConvergenceStatus::Diverged) return NlError::NewtonDiverged;
+      }
+      done += nit;
+      src = ybuf_[g].ptr() + (int64_t)(nit - 1) * stride;
+      g ^= 1;
     }
     return NlError::NewtonMaxIterations;
   }
@@ -442,6 +537,14 @@ class Bdf : public OdeSolverMethod {
   BdfCallable op_;
   int n_equal_steps_ = 0;
   HipVec y_delta_, y_predict_, d_tmp_;
+  HipVec ybuf_[2];                 // fused mode: two groups of nit_ Newton iterates each (ping-pong between launches)
+  int nit_ = 3;                    // Newton iterations per launch (DSH_NEWTON_NIT = 1..4)
+  int prelaunch_nit_ = 0;
+  const double* y_new_ = nullptr;  // fused mode: buffer holding the converged iterate
+  HostProfile prof_;
+  bool pipeline_ = true;           // speculative Newton pipelining (DSH_NEWTON_PIPELINE=0 disables)
+  bool prelaunch_valid_ = false;   // iteration 1 of the next step is already in flight (ticket below)
+  int64_t prelaunch_ticket_ = 0;
   double t_predict_ = 0.0;
   HipMat diff_, diff_tmp_;
   std::vector<double> u_, alpha_, gamma_, error_const2_;

@@ -360,7 +360,7 @@ class Sdirk : public OdeSolverMethod {
     for (int it = 0; it < convergence_.max_iter(); ++it) {
       double out[3] = {0.0, 0.0, 0.0};
       pr_.eqn->rhs_statistics.number_of_calls++;
-      check(dsh_sdirk_newton_iter(ctx().raw(), model_, model_size_, nb(), t, op_.h(), op_.c(), old_state_.dy.ptr(), op_.phi().ptr(), pr_.eqn->params().ptr(),
+      check(dsh_sdirk_newton_iter(ctx().raw(), model_, model_size_, nb(), t, op_.h(), op_.c(), old_state_.dy.ptr(), old_state_.dy.ptr(), op_.phi().ptr(), pr_.eqn->params().ptr(),
                                   nonlinear_solver_.linear_solver().raw(), state_.y.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, out), "dsh_sdirk_newton_iter");
       if (out[2] != 0.0) return NlError::LuSolveFailed;
       ConvergenceStatus st = convergence_.check_new_iteration(std::sqrt(out[0]));

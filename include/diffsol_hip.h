@@ -40,6 +40,7 @@ extern "C" {
 #define DSH_E_NOT_SETUP (-4)      /* LU used before factorisation (reference: LuNotInitialized) */
 #define DSH_E_BATCH_MISMATCH (-5) /* root finding results differ across batches (reference panics, vector/cuda.rs:1166-1171) */
 #define DSH_E_UNSUPPORTED (-6)
+#define DSH_E_STALE (-7)          /* dsh_reduction_wait: the ticket's result records have been reused by newer launches */
 
 typedef struct dsh_ctx dsh_ctx; /* device + stream + reduction scratch;   replaces CudaContext, diffsol-la/src/context/cuda.rs:41-144 */
 typedef struct dsh_lu dsh_lu;   /* batched LU factors + pivots;            replaces CudaLU,      diffsol-la/src/linear_solver/cuda/lu.rs:15-57 */
@@ -186,21 +187,33 @@ int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double
 /* ---- Fused fast paths (optional; results are bit-identical to composing the 1:1 ops above) ---- */
 /* One Newton iteration of the BDF residual F(y) = M(y + (psi - y0)) - c f(y)  (NoLineSearch::take_optimal_step
  * diffsol-nl/src/line_search.rs:48-69 over BdfCallable::call_inplace diffsol/src/op/bdf.rs:240-256):
- *   delta = F(y); LU-solve(delta); y -= delta; out[0] = max_b ||delta||^2_(error_y)   (Convergence::norm squared, convergence.rs:64-66)
+ *   y = y_in; delta = F(y); LU-solve(delta); y_out = y - delta; out[0] = max_b ||delta||^2_(error_y)  (Convergence::norm squared, convergence.rs:64-66)
  * and, speculatively, the error-test quantity for the step (Bdf::error_control, ode_solver/bdf.rs:826-835, without the error constant):
- *   out[1] = max_b ||y - error_y||^2_(y_old)      (only if y_old != NULL)
+ *   out[1] = max_b ||y_out - error_y||^2_(y_old)      (only if y_old != NULL)
  * out[2] = number of systems whose solve met a zero pivot (as a double).  out is a HOST array of 3 doubles.  Blocking.
- * init_from_error_y != 0: the iterate is read from error_y instead of y (first iteration: `y_delta.copy_from(&y_predict)`, bdf.rs:1326,
- * without a separate copy launch); y is written either way.
+ * y_in may equal y_out (in place) or error_y (first iteration: `y_delta.copy_from(&y_predict)`, bdf.rs:1326, without a copy launch).
+ * The _async form only enqueues the launch and returns a ticket; dsh_reduction_wait(ticket) collects the three results later.  Up to 7
+ * further reducing launches may be issued before a ticket is redeemed, which lets the host keep one speculative iteration (writing to a
+ * second iterate buffer) in flight while it evaluates the convergence test of the previous one — no idle GPU during the host round trip.
  * Supported for models with a register-resident specialisation (dsh_model_has_fused). */
-int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, double* y, const double* psi_neg_y0,
-                        const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t atol_nb,
-                        double rtol, int init_from_error_y, double* out);
+int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, const double* y_in, double* y_out,
+                        const double* psi_neg_y0, const double* p, const dsh_lu* lu, const double* error_y, const double* y_old,
+                        const double* atol, int64_t atol_nb, double rtol, double* out);
+/* nit in 1..4 consecutive iterations in ONE launch: iterate i (0-based) is written to y_out + i*n*nbatch, and dsh_reduction_wait fills
+ * out[3*i .. 3*i+3) with that iteration's (norm^2, error^2, singular count).  The host evaluates the convergence test over the nit norms
+ * in order and uses the first iterate that converged; later iterates are speculative work that reused the registers of the launch. */
+int dsh_bdf_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, int nit, const double* y_in,
+                              double* y_out, const double* psi_neg_y0, const double* p, const dsh_lu* lu, const double* error_y,
+                              const double* y_old, const double* atol, int64_t atol_nb, double rtol, int64_t* ticket);
+int dsh_reduction_wait(dsh_ctx* ctx, int64_t ticket, double* out);
 /* Same for the SDIRK stage residual F(k) = M k - h f(phi + c k)  (SdirkCallable::call_inplace diffsol/src/op/sdirk.rs:229-244);
  * out[0] = max_b ||delta||^2_(error_y), out[2] = singular count. */
-int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double h, double c, double* k, const double* phi,
-                          const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t atol_nb, double rtol,
-                          double* out);
+int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double h, double c, const double* k_in, double* k_out,
+                          const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t atol_nb,
+                          double rtol, double* out);
+int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double h, double c, int nit, const double* k_in,
+                                double* k_out, const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol,
+                                int64_t atol_nb, double rtol, int64_t* ticket);
 /* Jacobian refresh: [rhs_jac = J(x,t) if recompute_rhs_jac; mass_jac = M(t) if the model has a mass matrix];
  * A = mass_jac + (-c)*rhs_jac; LU-factor A into `lu` — one launch, A never touches HBM
  * (BdfCallable::jacobian_inplace op/bdf.rs:273-300 + CudaLU::set_linearisation lu.rs:59-97). */
@@ -225,6 +238,10 @@ int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, con
 int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, double* y_predict, const double* y_new,
                         double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
                         double* psi_neg_y0_next, int want_norms, double* out);
+/* enqueue only; redeem the two norms with dsh_reduction_wait(ticket, out3) (out[0], out[1]) if and when they are needed */
+int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, double* y_predict, const double* y_new,
+                              double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
+                              double* psi_neg_y0_next, int64_t* ticket);
 
 #ifdef __cplusplus
 }

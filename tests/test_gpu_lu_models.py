@@ -126,7 +126,7 @@ def test_bdf_callable_kat_through_trait_ops_and_fused_kernel(H, ctx1, kats):
     atol = H.HipVec.from_vec([1e-6, 1e-6], ctx1)
     res = (C.c_double * 3)()
     ynew = y.clone()
-    assert L.dsh_bdf_newton_iter(ctx1._h, mid, 0, 1, k["t"], c, ynew.ptr, psi.ptr, p.ptr, lu._h, y.ptr, y.ptr, atol.ptr, 1, 1e-6, 0, res) == 0
+    assert L.dsh_bdf_newton_iter(ctx1._h, mid, 0, 1, k["t"], c, y.ptr, ynew.ptr, psi.ptr, p.ptr, lu._h, y.ptr, y.ptr, atol.ptr, 1, 1e-6, res) == 0
     delta = np.array(k["F"]) / 1.01
     assert np.allclose(ynew.clone_as_vec()[0], np.array(k["y"]) - delta, atol=1e-12)
     w = np.abs(np.array(k["y"])) * 1e-6 + 1e-6
