@@ -27,7 +27,9 @@ if ROOT not in sys.path:
 NB_PER_GPU = 100_000
 T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]  # 0.4 ... 4e5
 RTOL, ATOL = 1e-4, [1e-8, 1e-14, 1e-6]
-BYTES_PER_NEWTON_ITER = 228  # n=3, np=3: 8n^2 + 4n + 8(5n + np)  (SURVEY §8(d)): LU 72 + piv 12 + y,psi,err_y,y_old read + y write 120 + p 24
+# Algorithmic bytes of one fused Newton launch per system, n=3, np=3: reads 8n^2+4n (LU+piv) + 8(4n+np) (y, psi-y0, y_predict, y_old, p) = 204 B,
+# writes 8n per iteration it performs; NIT=1 gives SURVEY §8(d)'s 228 B "fused Newton iteration".
+NEWTON_READ_BYTES, NEWTON_WRITE_BYTES_PER_ITER = 204, 24
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -61,7 +63,7 @@ def main():
     ap.add_argument("--nb", type=int, default=NB_PER_GPU)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the Newton kernel with HIP events (measures their overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
     args = ap.parse_args()
 
     import torch
@@ -105,7 +107,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver.set_kernel_timing(not args.no_kernel_events)
     barrier()
     t0 = time.perf_counter()
     steps = newton = setups = 0
@@ -116,7 +117,20 @@ def main():
         setups += st["number_of_linear_solver_setups"]
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = solver.kernel_timing()
+
+    # Roofline pass: the same K solves again with every launch of the dominant kernel bracketed by HIP events on the solver's stream.
+    # Bracketed launches are synchronous (the events must complete), so this pass is NOT the one `value` is taken from.
+    launches, kernel_ms, events_elapsed = 0, 0.0, 0.0
+    if not args.no_kernel_events:
+        solver.set_kernel_timing(True)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        events_elapsed = time.perf_counter() - t1
+        launches, kernel_ms = solver.kernel_timing()
+        solver.set_kernel_timing(False)
 
     # whole-job aggregates: max time over ranks, units summed over ranks
     agg = torch.tensor([elapsed, (hi - lo) * steps, (hi - lo) * newton, (hi - lo) * setups], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -145,13 +159,15 @@ def main():
                             "batched dense LU, t in [0, 4e5], rtol 1e-4, atol (1e-8,1e-14,1e-6), output at 7 decades",
                 "members_per_gpu": nb, "members_total": n_total, "t_final": T_EVAL[-1], "method": "bdf", "lockstep_steps_per_solve": steps / args.steps,
                 "newton_iterations_per_solve": newton / args.steps, "block_threads": args.block, "parallelism": f"ensemble-shard x{world}",
-                "kernel_events": not args.no_kernel_events,
+                "newton_iterations_per_launch": int(os.environ.get("DSH_NEWTON_NIT", "3")),
             },
             "checks": {"finite": finite, "max_mass_conservation_error": mass_err},
         }
         if launches > 0:
+            nit = int(os.environ.get("DSH_NEWTON_NIT", "3"))
+            bytes_per_launch = (NEWTON_READ_BYTES + NEWTON_WRITE_BYTES_PER_ITER * nit) * (hi - lo)
             avg_s = kernel_ms * 1e-3 / launches
-            achieved = BYTES_PER_NEWTON_ITER * (hi - lo) / avg_s / 1e9
+            achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_newton_iter.json")
             if os.path.exists(pmc):
@@ -159,10 +175,11 @@ def main():
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            rec["roofline"] = {"bound": "hbm", "kernel": "k_newton_iter<RobertsonOde1> (fused BDF Newton iteration)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": BYTES_PER_NEWTON_ITER * (hi - lo),
-                               "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
-                               "kernel_time_share_of_wall": (kernel_ms * 1e-3) / elapsed_max}
+            rec["roofline"] = {"bound": "hbm", "kernel": f"k_newton_iter<RobertsonOde1,...,NIT={nit}> (fused BDF Newton launch, {nit} iterations)", "achieved": achieved,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
+                               "measured": "HIP events on the solver stream, second pass over the same K solves (bracketed launches are synchronous)",
+                               "events_pass_ms_per_step": 1e3 * events_elapsed / args.steps}
         else:
             rec["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
