@@ -120,7 +120,7 @@ def main():
 
     # Roofline pass: the same K solves again with every launch of the dominant kernel bracketed by HIP events on the solver's stream.
     # Bracketed launches are synchronous (the events must complete), so this pass is NOT the one `value` is taken from.
-    launches, kernel_ms, events_elapsed = 0, 0.0, 0.0
+    launches, kernel_ms, events_elapsed, bracket_ms, clock_ms = 0, 0.0, 0.0, 0.0, 0.0
     if not args.no_kernel_events:
         solver.set_kernel_timing(True)
         barrier()
@@ -130,6 +130,7 @@ def main():
         barrier()
         events_elapsed = time.perf_counter() - t1
         launches, kernel_ms = solver.kernel_timing()
+        bracket_ms, clock_ms = solver.kernel_timing_overhead_ms()
         solver.set_kernel_timing(False)
 
     # whole-job aggregates: max time over ranks, units summed over ranks
@@ -166,7 +167,11 @@ def main():
         if launches > 0:
             nit = int(os.environ.get("DSH_NEWTON_NIT", "3"))
             bytes_per_launch = (NEWTON_READ_BYTES + NEWTON_WRITE_BYTES_PER_ITER * nit) * (hi - lo)
+            # HIP-event bracket = kernel + part of the marker-packet processing (an EMPTY bracket measures `empty_bracket_us`); the in-kernel
+            # device clock (max workgroup end - min workgroup start) is the quantity rocprofv3's kernel trace reports.  `achieved` uses the
+            # raw HIP-event figure (conservative); both other figures are reported next to it.
             avg_s = kernel_ms * 1e-3 / launches
+            clock_avg_s = clock_ms * 1e-3 / launches
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_newton_iter.json")
@@ -177,7 +182,9 @@ def main():
                     traffic = None
             rec["roofline"] = {"bound": "hbm", "kernel": f"k_newton_iter<RobertsonOde1,...,NIT={nit}> (fused BDF Newton launch, {nit} iterations)", "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "launches_timed": launches,
+                               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "empty_bracket_us": bracket_ms * 1e3,
+                               "avg_launch_us_device_clock": clock_avg_s * 1e6, "achieved_device_clock": bytes_per_launch / max(clock_avg_s, 1e-12) / 1e9,
+                               "frac_device_clock": bytes_per_launch / max(clock_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "launches_timed": launches,
                                "measured": "HIP events on the solver stream, second pass over the same K solves (bracketed launches are synchronous)",
                                "events_pass_ms_per_step": 1e3 * events_elapsed / args.steps}
         else:

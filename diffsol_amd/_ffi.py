@@ -39,6 +39,7 @@ DEVICE_ABI = {
     "dsh_ctx_set_timing": (cint, [vp, cint]),
     "dsh_ctx_set_poll": (cint, [vp, cint]),
     "dsh_ctx_get_timing": (cint, [vp, c_i64p, c_dp]),
+    "dsh_ctx_get_timing_overhead": (cint, [vp, c_dp, c_dp]),
     "dsh_malloc": (cint, [vp, i64, cint, C.POINTER(vp)]),
     "dsh_free": (cint, [vp, vp]),
     "dsh_memset_zero": (cint, [vp, vp, i64]),
@@ -123,6 +124,7 @@ HOST_ABI = {
     "dshs_reset": (cint, [vp]),
     "dshs_set_kernel_timing": (cint, [vp, cint]),
     "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),
+    "dshs_get_kernel_timing_overhead": (cint, [vp, c_dp, c_dp]),
     "dshs_nstates": (i64, [vp]),
     "dshs_nbatch": (i64, [vp]),
     "dshs_is_fused": (cint, [vp]),

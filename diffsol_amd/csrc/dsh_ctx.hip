@@ -165,7 +165,28 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
   ctx->timing = enable != 0;  // note: event timing needs completed events, so timed launches synchronise the stream
   ctx->ev_pending = false;
   ctx->timed_ms = 0.0;
+  ctx->timed_clock_ms = 0.0;
   ctx->timed_launches = 0;
+  if (enable) {
+    // calibrate the cost of the bracket itself: elapsed time between two back-to-back event records with nothing in between
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double acc = 0.0;
+    const int reps = 200;
+    for (int i = 0; i < reps; ++i) {
+      DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+      DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+      DSH_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
+      float ms = 0.f;
+      DSH_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+      acc += (double)ms;
+    }
+    ctx->bracket_overhead_ms = acc / reps;
+  }
+  return DSH_OK;
+}
+int dsh_ctx_get_timing_overhead(dsh_ctx* ctx, double* empty_bracket_ms, double* device_clock_total_ms) {
+  if (empty_bracket_ms) *empty_bracket_ms = ctx->bracket_overhead_ms;
+  if (device_clock_total_ms) *device_clock_total_ms = ctx->timed_clock_ms;
   return DSH_OK;
 }
 int dsh_ctx_set_poll(dsh_ctx* ctx, int poll) {

@@ -7,6 +7,9 @@
 // fully coalesced 8-byte-per-lane accesses (batch-fastest layout), everything else in registers, per-wave shuffle reduction of the
 // weighted norms and one conditional atomicMax per workgroup.  Per n=3 system and iteration: 228 algorithmic bytes, ~60 flop => HBM-bound.
 // Arithmetic order is exactly that of the unfused ops (and of the CPU oracle); built with -ffp-contract=off.
+#include <algorithm>
+#include <vector>
+
 #include "dsh_internal.hpp"
 #include "dsh_lu_dev.hpp"
 #include "dsh_models.hpp"
@@ -45,8 +48,9 @@ template <class Mdl, bool IS_SDIRK, bool BA, bool WITH_ERR, int NIT>
 __global__ void k_newton_iter(int64_t nb, double t, double c, double h, const double* y_in, double* y_out, const double* __restrict__ aux /*psi_neg_y0 | phi*/,
                               const double* __restrict__ p, const double* __restrict__ factors, const int32_t* __restrict__ piv,
                               const double* error_y, const double* __restrict__ y_old, const double* __restrict__ atol, double rtol,
-                              unsigned long long* rec, unsigned int seq) {
+                              unsigned long long* rec, unsigned int seq, unsigned long long* clk) {
   constexpr int N = Mdl::N, NP = Mdl::NP;
+  if (clk != nullptr && threadIdx.x == 0) clk[2 * blockIdx.x] = wall_clock64();  // timing mode only: 100 MHz device clock at block start
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = b < nb;
   const int64_t bb = active ? b : 0;  // inactive lanes shadow system 0 (loads only) so that every lane reaches the block reductions
@@ -108,6 +112,7 @@ __global__ void k_newton_iter(int64_t nb, double t, double c, double h, const do
     }
     block_publish(nrm_bits, err_bits, bad, rec + (size_t)it * gridDim.x * kRecWords, seq);
   }
+  if (clk != nullptr && threadIdx.x == 0) clk[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // Jacobian refresh + assembly of M - cJ + LU factorisation, one lane per system, A never leaves registers.
@@ -288,12 +293,18 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   if (rc != DSH_OK) return rc;
   const bool ba = anb == 1 && nb != 1;
   const bool with_err = y_old != nullptr;
-  if (ctx->timing) DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+  unsigned long long* clk = nullptr;
+  if (ctx->timing) {
+    rc = ensure_i32_scratch(ctx, 4 * (int64_t)g.x);  // 2 x u64 per workgroup
+    if (rc != DSH_OK) return rc;
+    clk = reinterpret_cast<unsigned long long*>(ctx->i32_scratch);
+    DSH_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+  }
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
 #define DSH_NEWTON_LAUNCH(SD, BA, WE, NIT)                                                                                                      \
   hipLaunchKernelGGL((k_newton_iter<Mdl, SD, BA, WE, NIT>), g, blk, 0, ctx->stream, nb, t, c, h, y_in, y_out, aux, p, (const double*)lu->factors, \
-                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, rec, seq)
+                     (const int32_t*)lu->pivots, error_y, y_old, atol, rtol, rec, seq, clk)
 #define DSH_NEWTON_NIT(SD, BA, WE)                                                                           \
   switch (nit) {                                                                                             \
     case 1: DSH_NEWTON_LAUNCH(SD, BA, WE, 1); break;                                                          \
@@ -316,6 +327,12 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
     DSH_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->timed_ms += (double)ms;
     ctx->timed_launches += 1;
+    // device-clock span of the launch: max(block end) - min(block start), 100 MHz ticks
+    std::vector<unsigned long long> h((size_t)2 * g.x);
+    DSH_HIP_CHECK(hipMemcpy(h.data(), clk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    unsigned long long t_min = ~0ull, t_max = 0ull;
+    for (unsigned i = 0; i < g.x; ++i) { t_min = std::min(t_min, h[2 * i]); t_max = std::max(t_max, h[2 * i + 1]); }
+    ctx->timed_clock_ms += (double)(t_max - t_min) * 1e-5;  // 10 ns per tick
   }
   *ticket = ((int64_t)seq << 32) | ((int64_t)nit << 24) | (int64_t)g.x;
   return DSH_OK;

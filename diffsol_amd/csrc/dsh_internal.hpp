@@ -74,6 +74,8 @@ struct dsh_ctx {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool ev_pending = false;
   double timed_ms = 0.0;
+  double timed_clock_ms = 0.0;       // same launches measured with the in-kernel 100 MHz device clock (max block end - min block start)
+  double bracket_overhead_ms = 0.0;  // elapsed time of an empty event bracket (calibrated when timing is enabled)
   int64_t timed_launches = 0;
 };
 

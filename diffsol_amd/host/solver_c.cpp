@@ -119,6 +119,9 @@ int dshs_reset(dshs_solver* s) {
 }
 int dshs_set_kernel_timing(dshs_solver* s, int enable) { return dsh_ctx_set_timing(s->ctx.raw(), enable); }
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms) { return dsh_ctx_get_timing(s->ctx.raw(), launches, total_ms); }
+int dshs_get_kernel_timing_overhead(dshs_solver* s, double* empty_bracket_ms, double* device_clock_total_ms) {
+  return dsh_ctx_get_timing_overhead(s->ctx.raw(), empty_bracket_ms, device_clock_total_ms);
+}
 
 int64_t dshs_nstates(const dshs_solver* s) { return s->problem.eqn->nstates(); }
 int64_t dshs_nbatch(const dshs_solver* s) { return s->ctx.nbatch(); }

@@ -69,6 +69,11 @@ class Solver:
         check(self._L.dshs_get_kernel_timing(self._h, C.byref(n), C.byref(ms)), host=True)
         return int(n.value), float(ms.value)
 
+    def kernel_timing_overhead_ms(self):
+        ms, clk = C.c_double(), C.c_double()
+        check(self._L.dshs_get_kernel_timing_overhead(self._h, C.byref(ms), C.byref(clk)), host=True)
+        return float(ms.value), float(clk.value)
+
     def step(self):
         r = C.c_int()
         check(self._L.dshs_step(self._h, C.byref(r)), host=True)

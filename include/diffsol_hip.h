@@ -67,6 +67,10 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
  * per-workgroup result records the kernels write into pinned host memory; poll == 0 uses hipStreamSynchronize. */
 int dsh_ctx_set_poll(dsh_ctx* ctx, int poll);
 int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms);
+/* elapsed time of an EMPTY event bracket on this stream (mean of 200, measured when timing was enabled): the part of every bracketed
+ * measurement that is not the kernel; and the summed duration of the same timed launches measured inside the kernel with the 100 MHz
+ * device clock (max workgroup end - min workgroup start), which is what rocprofv3's kernel trace reports */
+int dsh_ctx_get_timing_overhead(dsh_ctx* ctx, double* empty_bracket_ms, double* device_clock_total_ms);
 
 /* ---- device memory (cudarc alloc/alloc_zeros/memcpy_*: call sites throughout vector/cuda.rs, matrix/cuda.rs) ---- */
 int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out);

@@ -58,6 +58,7 @@ int dshs_reset(dshs_solver* s);
 /* forwarders to dsh_ctx_set_timing / dsh_ctx_get_timing of the solver's context */
 int dshs_set_kernel_timing(dshs_solver* s, int enable);
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms);
+int dshs_get_kernel_timing_overhead(dshs_solver* s, double* empty_bracket_ms, double* device_clock_total_ms);
 
 int64_t dshs_nstates(const dshs_solver* s);
 int64_t dshs_nbatch(const dshs_solver* s);
