@@ -85,6 +85,8 @@ DEVICE_ABI = {
     "dsh_lu_info": (cint, [vp, c_i64p]),
     "dsh_lu_factors": (vp, [vp]),
     "dsh_lu_pivots": (vp, [vp]),
+    "dsh_lu_system_major": (cint, [vp]),
+    "dsh_lu_download": (cint, [vp, c_dp, c_i32p]),
     "dsh_model_info": (cint, [cint, i64, c_i64p, c_i64p, c_ip, c_i64p]),
     "dsh_model_rhs": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_jac_mul": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp, vp]),

@@ -82,8 +82,11 @@ struct dsh_ctx {
 struct dsh_lu {
   dsh_ctx* ctx = nullptr;
   int64_t n = 0, nbatch = 0;
-  double* factors = nullptr;   // (j*n+i)*nbatch + b
-  int32_t* pivots = nullptr;   // k*nbatch + b : row swapped with row k at elimination step k
+  // n <= 8 (register kernels): batch-fastest, factors (j*n+i)*nbatch + b, pivots k*nbatch + b.
+  // n  > 8 (cooperative kernels): system-major, factors b*n*n + j*n + i, pivots b*n + k.   pivots[k] = row swapped with row k at step k.
+  double* factors = nullptr;
+  int32_t* pivots = nullptr;
+  bool system_major = false;
   // device word: (epoch << 32) | number of systems with a zero pivot found by the factorisation launch of that epoch.  A launch of a
   // newer epoch replaces an older word (CAS loop, only executed by waves that actually found a singular system), so no reset
   // launch is needed between factorisations.

@@ -3,8 +3,11 @@
 // Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
 // (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
 // in-place in HBM for larger n.
+#include <vector>
+
 #include "dsh_internal.hpp"
 #include "dsh_lu_dev.hpp"
+#include "dsh_lu_coop.hpp"
 
 using namespace dsh;
 
@@ -47,24 +50,17 @@ __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, c
   block_publish(0ull, 0ull, bad, rec, seq);
 }
 
-__global__ void k_lu_factor_global(int64_t n, int64_t nb, double* __restrict__ factors, int32_t* __restrict__ piv, unsigned long long* singular_count,
-                                   unsigned int epoch) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long sing = 0ull;
-  if (b < nb) {
-    bool s = false;
-    lu_factor_global(factors, piv, n, nb, b, s);
-    sing = s ? 1ull : 0ull;
-  }
-  sing = wave_sum_u64(sing);
-  if ((threadIdx.x & 63) == 0 && sing) publish_singular(singular_count, sing, epoch);
-}
-__global__ void k_lu_solve_global(int64_t n, int64_t nb, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
-                                  unsigned long long* rec, unsigned int seq) {
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long bad = 0ull;
-  if (b < nb) bad = lu_solve_global(factors, piv, rhs, n, nb, b) ? 0ull : 1ull;
-  block_publish(0ull, 0ull, bad, rec, seq);
+// Geometry of the LDS-resident cooperative kernels: G systems per 256-thread workgroup (power of two, <= 8, each system n x ld doubles
+// with ld odd), or G = 0 when not even one system fits the LDS budget.
+inline void coop_geometry(int64_t n, int* g_per_wg, int* ld, size_t* lds_bytes) {
+  const int l = (int)(n | 1);
+  const size_t per_system = sizeof(double) * (size_t)l * n + sizeof(double) * n + sizeof(int) * n;  // matrix + rhs/pivot staging
+  const size_t budget = 150 * 1024;
+  int g = 8;
+  while (g > 0 && per_system * g > budget) g >>= 1;
+  *g_per_wg = g;
+  *ld = l;
+  *lds_bytes = per_system * (g > 0 ? g : 1);
 }
 
 }  // namespace
@@ -75,6 +71,7 @@ int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
   DSH_REQUIRE(n >= 0 && nbatch >= 1 && out, "bad arguments");
   dsh_lu* lu = new dsh_lu();
   lu->ctx = ctx; lu->n = n; lu->nbatch = nbatch;
+  lu->system_major = n > 8;
   DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->singular, sizeof(unsigned long long)));
@@ -92,6 +89,26 @@ void dsh_lu_destroy(dsh_lu* lu) {
 }
 double* dsh_lu_factors(dsh_lu* lu) { return lu->factors; }
 int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu->pivots; }
+int dsh_lu_system_major(const dsh_lu* lu) { return lu->system_major ? 1 : 0; }
+
+int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
+  dsh_ctx* ctx = lu->ctx;
+  const int64_t n = lu->n, nb = lu->nbatch;
+  if (n == 0) return DSH_OK;
+  if (lu->system_major) {  // already [b][col][row] / [b][k]
+    if (factors_host) { int rc = dsh_d2h(ctx, factors_host, lu->factors, sizeof(double) * n * n * nb); if (rc != DSH_OK) return rc; }
+    if (pivots_host) { int rc = dsh_d2h(ctx, pivots_host, lu->pivots, sizeof(int32_t) * n * nb); if (rc != DSH_OK) return rc; }
+    return DSH_OK;
+  }
+  if (factors_host) { int rc = dsh_vec_download(ctx, n * n, nb, lu->factors, factors_host); if (rc != DSH_OK) return rc; }
+  if (pivots_host) {
+    std::vector<int32_t> tmp((size_t)(n * nb));
+    int rc = dsh_d2h(ctx, tmp.data(), lu->pivots, sizeof(int32_t) * n * nb);
+    if (rc != DSH_OK) return rc;
+    for (int64_t b = 0; b < nb; ++b) for (int64_t k = 0; k < n; ++k) pivots_host[b * n + k] = tmp[(size_t)(k * nb + b)];
+  }
+  return DSH_OK;
+}
 
 int dsh_lu_factor(dsh_lu* lu, const double* a) {
   dsh_ctx* ctx = lu->ctx;
@@ -105,9 +122,23 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
   switch (n) {
     DSH_LU_FACTOR_CASE(1) DSH_LU_FACTOR_CASE(2) DSH_LU_FACTOR_CASE(3) DSH_LU_FACTOR_CASE(4)
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
-    default:
-      DSH_HIP_CHECK(hipMemcpyAsync(lu->factors, a, sizeof(double) * n * n * nb, hipMemcpyDeviceToDevice, ctx->stream));
-      hipLaunchKernelGGL(k_lu_factor_global, g, blk, 0, ctx->stream, n, nb, lu->factors, lu->pivots, lu->singular, lu->singular_epoch);
+    default: {
+      int g_per_wg = 0, ld = 0;
+      size_t lds_bytes = 0;
+      coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
+      if (g_per_wg > 0) {
+        static bool attr_set = false;
+        if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
+        const unsigned blocks = (unsigned)((nb + g_per_wg - 1) / g_per_wg);
+        hipLaunchKernelGGL(k_lu_factor_lds, dim3(blocks), dim3(kCoopThreads), lds_bytes, ctx->stream, (int)n, ld, nb, g_per_wg, a, lu->factors, lu->pivots,
+                           lu->singular, lu->singular_epoch);
+      } else {
+        dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
+        hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
+        hipLaunchKernelGGL(k_lu_factor_global_coop, dim3((unsigned)nb), dim3(kCoopThreads), 0, ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular,
+                           lu->singular_epoch);
+      }
+    }
   }
 #undef DSH_LU_FACTOR_CASE
   DSH_HIP_CHECK(hipGetLastError());
@@ -121,6 +152,12 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   if (n == 0) return DSH_OK;
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  if (n > 8) {
+    int g_per_wg = 0, ld = 0;
+    size_t lds_bytes = 0;
+    coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
+    g = g_per_wg > 0 ? dim3((unsigned)((nb + g_per_wg - 1) / g_per_wg)) : dim3((unsigned)nb);
+  }
   int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
 #define DSH_LU_SOLVE_CASE(N) \
@@ -128,8 +165,20 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   switch (n) {
     DSH_LU_SOLVE_CASE(1) DSH_LU_SOLVE_CASE(2) DSH_LU_SOLVE_CASE(3) DSH_LU_SOLVE_CASE(4)
     DSH_LU_SOLVE_CASE(5) DSH_LU_SOLVE_CASE(6) DSH_LU_SOLVE_CASE(7) DSH_LU_SOLVE_CASE(8)
-    default:
-      hipLaunchKernelGGL(k_lu_solve_global, g, blk, 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq);
+    default: {
+      int g_per_wg = 0, ld = 0;
+      size_t lds_bytes = 0;
+      coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
+      if (g_per_wg > 0) {
+        static bool attr_set = false;
+        if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
+        hipLaunchKernelGGL(k_lu_solve_lds, g, dim3(kCoopThreads), lds_bytes, ctx->stream, (int)n, ld, nb, g_per_wg, (const double*)lu->factors,
+                           (const int32_t*)lu->pivots, rhs, rec, seq);
+      } else {
+        hipLaunchKernelGGL(k_lu_solve_global_coop, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
+                           (const int32_t*)lu->pivots, rhs, rec, seq);
+      }
+    }
   }
 #undef DSH_LU_SOLVE_CASE
   DSH_HIP_CHECK(hipGetLastError());

@@ -346,10 +346,7 @@ class HipLU:
 
     def factors(self):
         """[nbatch, n, n] packed LU and [nbatch, n] pivot rows."""
-        lu = np.empty((self.ctx.nbatch, self.n, self.n))
-        fp = self.ctx._L.dsh_lu_factors(self._h)
-        check(self.ctx._L.dsh_vec_download(self.ctx._h, self.n * self.n, self.ctx.nbatch, vp(fp), lu.ctypes.data_as(_ffi.c_dp)))
-        piv = np.empty((self.n, self.ctx.nbatch), dtype=np.int32)
-        pp = self.ctx._L.dsh_lu_pivots(self._h)
-        check(self.ctx._L.dsh_d2h(self.ctx._h, piv.ctypes.data_as(vp), vp(pp), 4 * piv.size))
-        return np.transpose(lu, (0, 2, 1)).copy(), piv.T.copy()
+        lu = np.empty((self.ctx.nbatch, self.n, self.n))  # [b][col][row]
+        piv = np.empty((self.ctx.nbatch, self.n), dtype=np.int32)
+        check(self.ctx._L.dsh_lu_download(self._h, lu.ctypes.data_as(_ffi.c_dp), piv.ctypes.data_as(_ffi.c_i32p)))
+        return np.transpose(lu, (0, 2, 1)).copy(), piv

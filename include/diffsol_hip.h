@@ -162,8 +162,12 @@ int dsh_lu_factor(dsh_lu* lu, const double* a);
 int dsh_lu_solve(const dsh_lu* lu, double* b);
 /* number of systems whose factorisation met an exactly-zero pivot (cusolver `info`, ignored by the reference lu.rs:83-95); blocking */
 int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular);
+/* raw device pointers of the factor storage: batch-fastest for n <= 8, system-major for n > 8 (dsh_lu_system_major) */
 double* dsh_lu_factors(dsh_lu* lu);
 int32_t* dsh_lu_pivots(dsh_lu* lu);
+int dsh_lu_system_major(const dsh_lu* lu);
+/* packed LU factors as [b][col][row] and pivot rows as [b][k] on the host, whatever the device layout; blocking */
+int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 
 /* ---- Model registry: the OdeEquations plug-in boundary (diffsol/src/ode_equations/mod.rs:245-329; NonLinearOp::call_inplace,
  * NonLinearOpJacobian::{jac_mul_inplace,jacobian_inplace} op/nonlinear_op.rs:10-21,175-221; LinearOp::{gemv_inplace,matrix_inplace}

@@ -21,7 +21,7 @@ def ctx1(H):
     return H.HipContext(0, nbatch=1)
 
 
-@pytest.mark.parametrize("n,nb", [(1, 5), (2, 2), (3, 1), (3, 1000), (4, 67), (5, 64), (8, 129), (12, 33), (42, 70)])
+@pytest.mark.parametrize("n,nb", [(1, 5), (2, 2), (3, 1), (3, 1000), (4, 67), (5, 64), (8, 129), (9, 3), (12, 33), (16, 257), (42, 70), (64, 19), (100, 9), (137, 5), (150, 6), (256, 3)])
 def test_lu_factor_and_solve_match_oracle_bitwise(H, O, ctx1, n, nb):
     rng = np.random.default_rng(n * 100 + nb)
     c = ctx1.clone_with_nbatch(nb)
@@ -60,6 +60,28 @@ def test_lu_reference_diagonal_kat_and_singular_reporting(H, ctx1):
     with pytest.raises(H.DiffsolHipError) as e:
         unfactored.solve_in_place(H.HipVec.zeros(2, c2))
     assert e.value.code == -4  # LuNotInitialized
+
+
+@pytest.mark.parametrize("n", [12, 150])
+def test_lu_cooperative_kernels_report_singular_members(H, ctx1, n):
+    """n > 8 goes through the LDS-resident (n=12) / one-workgroup-per-system (n=150) kernels: same zero-pivot reporting as the register path."""
+    nb = 5
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((nb, n, n))
+    a[3, :, 4] = 0.0  # a zero column stays exactly zero through the elimination: exact zero pivot at step 4
+    lu = H.HipLU(c, n)
+    lu.factor(H.HipMat.from_array(a, c))
+    assert lu.n_singular() == 1
+    with pytest.raises(H.DiffsolHipError) as e:
+        lu.solve_in_place(H.HipVec.from_vec(np.ones((nb, n)), c))
+    assert e.value.code == -3
+    a[3] = np.eye(n)
+    lu.factor(H.HipMat.from_array(a, c))
+    assert lu.n_singular() == 0
+    x = H.HipVec.from_vec(np.ones((nb, n)), c)
+    lu.solve_in_place(x)
+    assert np.array_equal(x.clone_as_vec()[3], np.ones(n))
 
 
 MODEL_CASES = [("exponential_decay", 0, 2), ("exponential_decay_with_algebraic", 0, 1), ("robertson_ode", 1, 3), ("robertson_ode", 3, 3), ("robertson", 0, 3),
