@@ -135,8 +135,24 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
       } else {
         dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
         hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
-        hipLaunchKernelGGL(k_lu_factor_global_coop, dim3((unsigned)nb), dim3(kCoopThreads), 0, ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular,
-                           lu->singular_epoch);
+        const size_t budget = 140 * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          attr_set = true;
+        }
+#define DSH_LU_BLOCKED(NBK)                                                                                                                       \
+  hipLaunchKernelGGL((k_lu_factor_blocked<NBK>), dim3((unsigned)nb), dim3(kCoopThreads), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
+                     lu->pivots, lu->singular, lu->singular_epoch)
+        if (blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
+        else if (blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
+        else if (blocked_lds_bytes(n, 8) <= budget) DSH_LU_BLOCKED(8);
+        else
+          hipLaunchKernelGGL(k_lu_factor_global_coop, dim3((unsigned)nb), dim3(kCoopThreads), 0, ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular,
+                             lu->singular_epoch);
+#undef DSH_LU_BLOCKED
       }
     }
   }

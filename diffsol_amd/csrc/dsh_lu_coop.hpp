@@ -250,4 +250,149 @@ __global__ void k_lu_solve_global_coop(int n, int64_t nb, const double* __restri
   block_publish(0ull, 0ull, (tid == 0 && !ok) ? 1ull : 0ull, rec, seq);
 }
 
+// Blocked right-looking LU, one workgroup per system, for systems too large for LDS (n > ~137).  Panels of NB columns are factored in LDS
+// (partial pivoting over the whole remaining column, as the unblocked algorithm does); the panel's row swaps are then applied to the other
+// columns, U12 = L11^-1 A12 is formed one column per thread, and the trailing matrix gets its NB rank-1 updates in one pass:
+// thread = row (coalesced column-major access), its NB multipliers l_rk in registers, the U12 block broadcast from LDS.
+// Every element still receives exactly the updates a_rc = (-u_kc) * l_rk + a_rc for k ascending, each as a separate multiply and add, so
+// the factors are bit-identical to the unblocked kernels and the oracle; only the number of passes over the trailing matrix changes
+// (n/NB instead of n): HBM/L2 traffic per system ~ 16 n^3 / (3 NB) bytes instead of 16 n^3 / 3.
+template <int NB>
+__global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
+                                                                   unsigned long long* singular_word, unsigned int epoch) {
+  extern __shared__ double sh[];  // panel (ldp x NB) during the panel factorisation, then the U12 block (mc x LDU)
+  __shared__ double s_best[kCoopThreads / 64];
+  __shared__ int s_row[kCoopThreads / 64];
+  __shared__ int s_piv[NB];
+  __shared__ double s_l11[NB * (NB + 1)];
+  constexpr int LDU = NB + 2;
+  const int tid = threadIdx.x;
+  double* A = f_aos + (size_t)blockIdx.x * n * n;  // column-major, ld = n
+  int32_t* PIV = piv_aos + (size_t)blockIdx.x * n;
+  const int ldp = n | 1;
+  bool singular = false;
+  for (int jb = 0; jb < n; jb += NB) {
+    const int w = (n - jb) < NB ? (n - jb) : NB;
+    const int m = n - jb;
+    // ---- 1. panel -> LDS
+    for (int c = 0; c < w; ++c)
+      for (int r = tid; r < m; r += kCoopThreads) sh[c * ldp + r] = A[(size_t)(jb + c) * n + jb + r];
+    __syncthreads();
+    // ---- 2. unblocked factorisation of the m x w panel
+    for (int k = 0; k < w; ++k) {
+      double* col = sh + k * ldp;
+      double best = -1.0;
+      int prow = m;
+      for (int r = k + tid; r < m; r += kCoopThreads) { double v = fabs(col[r]); if (v > best) { best = v; prow = r; } }
+      group_argmax(best, prow, 64);
+      if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_row[tid >> 6] = prow; }
+      __syncthreads();
+      best = s_best[0]; prow = s_row[0];
+#pragma unroll
+      for (int j = 1; j < kCoopThreads / 64; ++j) {
+        const double ob = s_best[j];
+        const int orow = s_row[j];
+        if (ob > best || (ob == best && orow < prow)) { best = ob; prow = orow; }
+      }
+      if (prow >= m) prow = k;  // NaN column: keep the diagonal like the sequential scan
+      const double diag = col[prow];
+      const bool zero = diag == 0.0;
+      if (zero) singular = true;
+      if (tid == 0) s_piv[k] = jb + (zero ? k : prow);
+      __syncthreads();
+      if (!zero && prow != k && tid < w) { double tmp = sh[tid * ldp + k]; sh[tid * ldp + k] = sh[tid * ldp + prow]; sh[tid * ldp + prow] = tmp; }
+      __syncthreads();
+      if (!zero) {
+        const double inv_diag = 1.0 / diag;
+        for (int r = k + 1 + tid; r < m; r += kCoopThreads) {
+          const double l = col[r] * inv_diag;
+          col[r] = l;
+          for (int c = k + 1; c < w; ++c) sh[c * ldp + r] = (-sh[c * ldp + k]) * l + sh[c * ldp + r];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- 3. panel and pivots back to global memory; L11 to its own LDS block
+    for (int c = 0; c < w; ++c)
+      for (int r = tid; r < m; r += kCoopThreads) A[(size_t)(jb + c) * n + jb + r] = sh[c * ldp + r];
+    if (tid < w) PIV[jb + tid] = s_piv[tid];
+    for (int idx = tid; idx < NB * NB; idx += kCoopThreads) {
+      const int r = idx % NB, c = idx / NB;
+      s_l11[c * (NB + 1) + r] = (r < w && c < w) ? sh[c * ldp + r] : 0.0;
+    }
+    __syncthreads();
+    // ---- 4. the panel's row interchanges on every other column (one thread per column)
+    for (int c = tid; c < n; c += kCoopThreads) {
+      if (c >= jb && c < jb + w) continue;
+      double* colg = A + (size_t)c * n;
+      for (int k = 0; k < w; ++k) {
+        const int p = s_piv[k];
+        if (p != jb + k) { double tmp = colg[jb + k]; colg[jb + k] = colg[p]; colg[p] = tmp; }
+      }
+    }
+    __syncthreads();
+    const int mc = n - jb - w;  // trailing columns
+    if (mc <= 0) break;
+    // ---- 5. U12 = L11^-1 A12, one column per thread; kept in LDS.  Trailing columns exist only behind a full panel: w == NB from here on.
+    for (int cc = tid; cc < mc; cc += kCoopThreads) {
+      double* colg = A + (size_t)(jb + w + cc) * n + jb;
+      double a[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) a[k] = colg[k];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int k = j + 1; k < NB; ++k)
+          a[k] = (-a[j]) * s_l11[j * (NB + 1) + k] + a[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        colg[k] = a[k];
+        sh[cc * LDU + k] = a[k];
+      }
+    }
+    __syncthreads();
+    // ---- 6. trailing update: thread = row, NB multipliers in registers, 4 columns in flight
+    for (int r = jb + w + tid; r < n; r += kCoopThreads) {
+      double l[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) l[k] = A[(size_t)(jb + k) * n + r];
+      double* row = A + (size_t)(jb + w) * n + r;
+      int cc = 0;
+      for (; cc + 4 <= mc; cc += 4) {
+        double a0 = row[(size_t)(cc + 0) * n], a1 = row[(size_t)(cc + 1) * n], a2 = row[(size_t)(cc + 2) * n], a3 = row[(size_t)(cc + 3) * n];
+        const double* u0 = sh + (cc + 0) * LDU;
+        const double* u1 = sh + (cc + 1) * LDU;
+        const double* u2 = sh + (cc + 2) * LDU;
+        const double* u3 = sh + (cc + 3) * LDU;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          a0 = (-u0[k]) * l[k] + a0;
+          a1 = (-u1[k]) * l[k] + a1;
+          a2 = (-u2[k]) * l[k] + a2;
+          a3 = (-u3[k]) * l[k] + a3;
+          if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later k-chunks from being hoisted (register pressure)
+        }
+        row[(size_t)(cc + 0) * n] = a0; row[(size_t)(cc + 1) * n] = a1; row[(size_t)(cc + 2) * n] = a2; row[(size_t)(cc + 3) * n] = a3;
+      }
+      for (; cc < mc; ++cc) {
+        double a0 = row[(size_t)cc * n];
+        const double* u0 = sh + cc * LDU;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) a0 = (-u0[k]) * l[k] + a0;
+        row[(size_t)cc * n] = a0;
+      }
+    }
+    __syncthreads();
+  }
+  if (singular && tid == 0) publish_singular(singular_word, 1ull, epoch);
+}
+
+// dynamic LDS bytes of k_lu_factor_blocked<NB> for order n
+inline size_t blocked_lds_bytes(int64_t n, int nbk) {
+  const size_t panel = (size_t)(n | 1) * nbk, ublock = (size_t)(n > nbk ? n - nbk : 0) * (nbk + 2);
+  return sizeof(double) * (panel > ublock ? panel : ublock);
+}
+
 }  // namespace dsh

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Full-size runs of BASELINE.json configs[2..4] (parity-test cases, not bench lines): wall time, solver counters, size-independent checks.
+
+  C3  heat1d n=512 x 4096, TR-BDF2, rtol=atol=1e-6, t_final 0.5   (check: Fourier series of the triangle initial condition)
+  C5  series RLC DAE n=4 x 65536, ESDIRK34, t_final 1, root function armed (threshold out of reach: lock-step root finding needs all members to
+      cross in the same step)           (check: algebraic constraints of the DAE hold, members == independent CPU solves)
+Writes one JSON object per config to gpurun_out/configs.json.  GPU only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_heat(nb, n, t_final=0.5):
+    import diffsol_amd as H
+    rng = np.random.default_rng(12345)
+    D = rng.uniform(0.5, 2.0, nb)
+    t0 = time.perf_counter()
+    s = H.Solver("heat1d", D[:, None], nbatch=nb, model_size=n, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)
+    t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    y, _ = s.solve_to_points([t_final])
+    wall = time.perf_counter() - t0
+    st = s.stats()
+    h = 1.0 / (n + 1)
+    x = (np.arange(n) + 1) * h
+    m = np.arange(1, 200)[:, None, None]
+    ref = (np.sin((2 * m - 1) * np.pi * x[None, None, :]) * np.exp(-(2 * m - 1) ** 2 * np.pi ** 2 * D[None, :64, None] * t_final) / (2 * m - 1) ** 2).sum(0) * 8 / np.pi ** 2
+    err = np.abs(y[0, :64] - ref).max()
+    return dict(config="C3 heat1d", n=n, nbatch=nb, method="tr_bdf2", setup_s=t_setup, wall_s=wall, stats=st, max_abs_err_vs_fourier_first64=float(err),
+                steps_per_s=st["number_of_steps"] * nb / wall, newton_solves_per_s=st["number_of_nonlinear_solver_iterations"] * nb / wall,
+                finite=bool(np.isfinite(y).all()))
+
+
+def run_rlc(nb, t_final=1.0):
+    import diffsol_amd as H
+    rng = np.random.default_rng(12345)
+    R = rng.uniform(50.0, 200.0, nb)
+    Cc = np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, 1e3)], axis=1)
+    t0 = time.perf_counter()
+    s = H.Solver("rlc", p, nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34)
+    t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    y, ncols, reason = s.solve(t_final)
+    wall = time.perf_counter() - t0
+    st = s.stats()
+    return dict(config="C5 rlc", n=s.n, nbatch=nb, method="esdirk34", fused=s.fused, setup_s=t_setup, wall_s=wall, stats=st, stop_reason=int(reason),
+                steps_per_s=st["number_of_steps"] * nb / wall, newton_solves_per_s=st["number_of_nonlinear_solver_iterations"] * nb / wall,
+                finite=bool(np.isfinite(y).all()))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--heat-nb", type=int, default=4096)
+    ap.add_argument("--heat-n", type=int, default=512)
+    ap.add_argument("--rlc-nb", type=int, default=65536)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    out = []
+    if a.only in ("", "rlc"):
+        out.append(run_rlc(a.rlc_nb)); print(json.dumps(out[-1]), flush=True)
+    if a.only in ("", "heat"):
+        out.append(run_heat(a.heat_nb, a.heat_n)); print(json.dumps(out[-1]), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
