@@ -3,11 +3,13 @@
 // Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
 // (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
 // in-place in HBM for larger n.
+#include <cstdlib>
 #include <vector>
 
 #include "dsh_internal.hpp"
 #include "dsh_lu_dev.hpp"
 #include "dsh_lu_coop.hpp"
+#include "dsh_lu_wave.hpp"
 
 using namespace dsh;
 
@@ -58,6 +60,8 @@ inline void coop_geometry(int64_t n, int* g_per_wg, int* ld, size_t* lds_bytes) 
   const size_t budget = 150 * 1024;
   int g = 8;
   while (g > 0 && per_system * g > budget) g >>= 1;
+  static const int lds_max_n = [] { const char* e = getenv("DSH_LU_LDS_MAX_N"); return e ? atoi(e) : 1 << 30; }();  // tuning knob: larger n goes to the blocked kernel
+  if (n > lds_max_n) g = 0;
   *g_per_wg = g;
   *ld = l;
   *lds_bytes = per_system * (g > 0 ? g : 1);
@@ -126,7 +130,18 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
       int g_per_wg = 0, ld = 0;
       size_t lds_bytes = 0;
       coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
-      if (g_per_wg > 0) {
+      if (n <= 64) {  // one system per (part of a) wavefront, rows in registers
+        dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
+        hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
+#define DSH_LU_WAVE(NP, GW)                                                                                                               \
+  hipLaunchKernelGGL((k_lu_factor_wave<NP, GW>), dim3((unsigned)((nb + kWaveLuThreads / GW - 1) / (kWaveLuThreads / GW))), dim3(kWaveLuThreads), 0, \
+                     ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular, lu->singular_epoch)
+        if (n <= 16) DSH_LU_WAVE(16, 16);
+        else if (n <= 32) DSH_LU_WAVE(32, 32);
+        else if (n <= 48) DSH_LU_WAVE(48, 64);
+        else DSH_LU_WAVE(64, 64);
+#undef DSH_LU_WAVE
+      } else if (g_per_wg > 0) {
         static bool attr_set = false;
         if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
         const unsigned blocks = (unsigned)((nb + g_per_wg - 1) / g_per_wg);
@@ -173,6 +188,10 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
     size_t lds_bytes = 0;
     coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
     g = g_per_wg > 0 ? dim3((unsigned)((nb + g_per_wg - 1) / g_per_wg)) : dim3((unsigned)nb);
+    if (n <= 64) {
+      const int per_block = kWaveLuThreads / (n <= 16 ? 16 : n <= 32 ? 32 : 64);
+      g = dim3((unsigned)((nb + per_block - 1) / per_block));
+    }
   }
   int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
@@ -185,7 +204,16 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
       int g_per_wg = 0, ld = 0;
       size_t lds_bytes = 0;
       coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
-      if (g_per_wg > 0) {
+      if (n <= 64) {
+#define DSH_LU_WAVE(NP, GW)                                                                                                                  \
+  hipLaunchKernelGGL((k_lu_solve_wave<NP, GW>), g, dim3(kWaveLuThreads), 0, ctx->stream, (int)n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, \
+                     rhs, rec, seq)
+        if (n <= 16) DSH_LU_WAVE(16, 16);
+        else if (n <= 32) DSH_LU_WAVE(32, 32);
+        else if (n <= 48) DSH_LU_WAVE(48, 64);
+        else DSH_LU_WAVE(64, 64);
+#undef DSH_LU_WAVE
+      } else if (g_per_wg > 0) {
         static bool attr_set = false;
         if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
         hipLaunchKernelGGL(k_lu_solve_lds, g, dim3(kCoopThreads), lds_bytes, ctx->stream, (int)n, ld, nb, g_per_wg, (const double*)lu->factors,

@@ -359,22 +359,30 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
 #pragma unroll
       for (int k = 0; k < NB; ++k) l[k] = A[(size_t)(jb + k) * n + r];
       double* row = A + (size_t)(jb + w) * n + r;
+      // CW columns per group, the next group's loads issued before this group's arithmetic (one wave per SIMD: nothing else hides HBM latency)
+      constexpr int CW = 8;
+      double a[CW], nx[CW];
       int cc = 0;
-      for (; cc + 4 <= mc; cc += 4) {
-        double a0 = row[(size_t)(cc + 0) * n], a1 = row[(size_t)(cc + 1) * n], a2 = row[(size_t)(cc + 2) * n], a3 = row[(size_t)(cc + 3) * n];
-        const double* u0 = sh + (cc + 0) * LDU;
-        const double* u1 = sh + (cc + 1) * LDU;
-        const double* u2 = sh + (cc + 2) * LDU;
-        const double* u3 = sh + (cc + 3) * LDU;
+      const int full = mc - mc % CW;
+      if (full > 0) {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) nx[q] = row[(size_t)q * n];
+      }
+      for (; cc < full; cc += CW) {
+#pragma unroll
+        for (int q = 0; q < CW; ++q) a[q] = nx[q];
+        if (cc + CW < full) {
+#pragma unroll
+          for (int q = 0; q < CW; ++q) nx[q] = row[(size_t)(cc + CW + q) * n];
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-          a0 = (-u0[k]) * l[k] + a0;
-          a1 = (-u1[k]) * l[k] + a1;
-          a2 = (-u2[k]) * l[k] + a2;
-          a3 = (-u3[k]) * l[k] + a3;
-          if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of later k-chunks from being hoisted (register pressure)
+#pragma unroll
+          for (int q = 0; q < CW; ++q) a[q] = (-sh[(cc + q) * LDU + k]) * l[k] + a[q];
+          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep later LDS reads from being hoisted (register pressure)
         }
-        row[(size_t)(cc + 0) * n] = a0; row[(size_t)(cc + 1) * n] = a1; row[(size_t)(cc + 2) * n] = a2; row[(size_t)(cc + 3) * n] = a3;
+#pragma unroll
+        for (int q = 0; q < CW; ++q) row[(size_t)(cc + q) * n] = a[q];
       }
       for (; cc < mc; ++cc) {
         double a0 = row[(size_t)cc * n];

@@ -21,7 +21,7 @@ def ctx1(H):
     return H.HipContext(0, nbatch=1)
 
 
-@pytest.mark.parametrize("n,nb", [(1, 5), (2, 2), (3, 1), (3, 1000), (4, 67), (5, 64), (8, 129), (9, 3), (12, 33), (16, 257), (42, 70), (64, 19), (100, 9), (137, 5), (138, 4), (150, 6), (256, 3), (300, 2), (512, 2), (600, 2), (1100, 1)])
+@pytest.mark.parametrize("n,nb", [(1, 5), (2, 2), (3, 1), (3, 1000), (4, 67), (5, 64), (8, 129), (9, 3), (12, 33), (16, 257), (17, 40), (31, 65), (32, 9), (33, 21), (42, 70), (48, 10), (49, 9), (64, 19), (65, 7), (100, 9), (137, 5), (138, 4), (150, 6), (256, 3), (300, 2), (512, 2), (600, 2), (1100, 1)])
 def test_lu_factor_and_solve_match_oracle_bitwise(H, O, ctx1, n, nb):
     rng = np.random.default_rng(n * 100 + nb)
     c = ctx1.clone_with_nbatch(nb)
