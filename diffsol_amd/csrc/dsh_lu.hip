@@ -2,7 +2,7 @@
 // set_linearisation / solve_in_place loop over the batch on the HOST calling cusolverDnDgetrf / Dgetrs once per system.
 // Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
 // (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
-// in-place in HBM for larger n.
+// one wavefront per system for n <= 64 (dsh_lu_wave.hpp), one workgroup per system with a blocked factorisation beyond (dsh_lu_coop.hpp).
 #include <cstdlib>
 #include <vector>
 
@@ -50,21 +50,6 @@ __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, c
     bad = ok ? 0ull : 1ull;
   }
   block_publish(0ull, 0ull, bad, rec, seq);
-}
-
-// Geometry of the LDS-resident cooperative kernels: G systems per 256-thread workgroup (power of two, <= 8, each system n x ld doubles
-// with ld odd), or G = 0 when not even one system fits the LDS budget.
-inline void coop_geometry(int64_t n, int* g_per_wg, int* ld, size_t* lds_bytes) {
-  const int l = (int)(n | 1);
-  const size_t per_system = sizeof(double) * (size_t)l * n + sizeof(double) * n + sizeof(int) * n;  // matrix + rhs/pivot staging
-  const size_t budget = 150 * 1024;
-  int g = 8;
-  while (g > 0 && per_system * g > budget) g >>= 1;
-  static const int lds_max_n = [] { const char* e = getenv("DSH_LU_LDS_MAX_N"); return e ? atoi(e) : 1 << 30; }();  // tuning knob: larger n goes to the blocked kernel
-  if (n > lds_max_n) g = 0;
-  *g_per_wg = g;
-  *ld = l;
-  *lds_bytes = per_system * (g > 0 ? g : 1);
 }
 
 }  // namespace
@@ -127,12 +112,10 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
     DSH_LU_FACTOR_CASE(1) DSH_LU_FACTOR_CASE(2) DSH_LU_FACTOR_CASE(3) DSH_LU_FACTOR_CASE(4)
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
     default: {
-      int g_per_wg = 0, ld = 0;
-      size_t lds_bytes = 0;
-      coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
+      // system-major copy of the operand, then factor in place
+      dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
+      hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
       if (n <= 64) {  // one system per (part of a) wavefront, rows in registers
-        dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
-        hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
 #define DSH_LU_WAVE(NP, GW)                                                                                                               \
   hipLaunchKernelGGL((k_lu_factor_wave<NP, GW>), dim3((unsigned)((nb + kWaveLuThreads / GW - 1) / (kWaveLuThreads / GW))), dim3(kWaveLuThreads), 0, \
                      ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular, lu->singular_epoch)
@@ -141,15 +124,7 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
         else if (n <= 48) DSH_LU_WAVE(48, 64);
         else DSH_LU_WAVE(64, 64);
 #undef DSH_LU_WAVE
-      } else if (g_per_wg > 0) {
-        static bool attr_set = false;
-        if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
-        const unsigned blocks = (unsigned)((nb + g_per_wg - 1) / g_per_wg);
-        hipLaunchKernelGGL(k_lu_factor_lds, dim3(blocks), dim3(kCoopThreads), lds_bytes, ctx->stream, (int)n, ld, nb, g_per_wg, a, lu->factors, lu->pivots,
-                           lu->singular, lu->singular_epoch);
-      } else {
-        dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
-        hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
+      } else {  // one workgroup per system
         const size_t budget = 140 * 1024;
         static bool attr_set = false;
         if (!attr_set) {
@@ -183,15 +158,10 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   if (n == 0) return DSH_OK;
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
-  if (n > 8) {
-    int g_per_wg = 0, ld = 0;
-    size_t lds_bytes = 0;
-    coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
-    g = g_per_wg > 0 ? dim3((unsigned)((nb + g_per_wg - 1) / g_per_wg)) : dim3((unsigned)nb);
-    if (n <= 64) {
-      const int per_block = kWaveLuThreads / (n <= 16 ? 16 : n <= 32 ? 32 : 64);
-      g = dim3((unsigned)((nb + per_block - 1) / per_block));
-    }
+  if (n > 64) g = dim3((unsigned)nb);  // one workgroup per system
+  else if (n > 8) {
+    const int per_block = kWaveLuThreads / (n <= 16 ? 16 : n <= 32 ? 32 : 64);
+    g = dim3((unsigned)((nb + per_block - 1) / per_block));
   }
   int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
@@ -201,9 +171,6 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
     DSH_LU_SOLVE_CASE(1) DSH_LU_SOLVE_CASE(2) DSH_LU_SOLVE_CASE(3) DSH_LU_SOLVE_CASE(4)
     DSH_LU_SOLVE_CASE(5) DSH_LU_SOLVE_CASE(6) DSH_LU_SOLVE_CASE(7) DSH_LU_SOLVE_CASE(8)
     default: {
-      int g_per_wg = 0, ld = 0;
-      size_t lds_bytes = 0;
-      coop_geometry(n, &g_per_wg, &ld, &lds_bytes);
       if (n <= 64) {
 #define DSH_LU_WAVE(NP, GW)                                                                                                                  \
   hipLaunchKernelGGL((k_lu_solve_wave<NP, GW>), g, dim3(kWaveLuThreads), 0, ctx->stream, (int)n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, \
@@ -213,11 +180,6 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
         else if (n <= 48) DSH_LU_WAVE(48, 64);
         else DSH_LU_WAVE(64, 64);
 #undef DSH_LU_WAVE
-      } else if (g_per_wg > 0) {
-        static bool attr_set = false;
-        if (!attr_set) { DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL(k_lu_solve_lds, g, dim3(kCoopThreads), lds_bytes, ctx->stream, (int)n, ld, nb, g_per_wg, (const double*)lu->factors,
-                           (const int32_t*)lu->pivots, rhs, rec, seq);
       } else {
         hipLaunchKernelGGL(k_lu_solve_global_coop, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
                            (const int32_t*)lu->pivots, rhs, rec, seq);

@@ -1,15 +1,13 @@
-// Cooperative dense LU for 8 < n: several lanes per system (gfx950).
+// Workgroup-per-system dense LU for n > 64 (gfx950).
 //
-// For n <= 8 a whole system lives in one lane's registers (dsh_lu_dev.hpp).  Beyond that the factors no longer fit a lane, and the
-// batch-fastest layout — ideal for lane-per-system streaming — is the wrong layout for many lanes sharing one matrix.  The LU object owns
-// its factor storage, so for n > 8 it keeps the factors SYSTEM-MAJOR (contiguous n*n column-major block per system: coalesced for a group
-// of lanes working on one system) and transposes on the way in: the public operands (A, rhs) stay batch-fastest.
+// For n <= 8 a whole system lives in one lane's registers (dsh_lu_dev.hpp), for n <= 64 in the registers of one wavefront (dsh_lu_wave.hpp).
+// Beyond that a system gets a whole 256-thread workgroup.  The LU object owns its factor storage and keeps it SYSTEM-MAJOR (a contiguous
+// n*n column-major block per system: coalesced for a workgroup working on one system); the public operands (A, rhs) stay batch-fastest and
+// are transposed on the way in (k_soa_to_aos).
 //
-//   * LDS-resident variant (system fits LDS, n <= ~128): a workgroup of 256 threads handles G systems with TPS = 256/G threads each; the
-//     matrices of its G systems are staged in LDS (leading dimension n|1: odd, so column walks do not hit one bank), factored there with the
-//     same element-wise arithmetic as the register kernels, then written out once.  HBM traffic = the algorithmic 16n^2+4n bytes per system.
-//   * global variant (any n): one workgroup per system, factors updated in place in HBM/L2 (correct for any n; the LDS-panel + FP64-MFMA
-//     blocked kernel for n = 512 replaces it in a later round).
+//   * k_lu_factor_blocked<NB>: right-looking blocked factorisation, panel in LDS, register-tiled trailing update (see below).
+//   * k_lu_factor_global_coop: unblocked, factors updated in place in HBM/L2 — fallback for n beyond the LDS panel budget (n > ~2000).
+//   * k_lu_solve_global_coop: rhs in LDS, factors streamed once from HBM.
 //
 // Arithmetic per element is identical to lu_factor_reg / the oracle (l = a*(1/pivot); a_rc = (-a_kc)*l_rk + a_rc; first-max pivot), each
 // element being updated by exactly one thread per step, so results stay bit-identical to the CPU path regardless of the thread mapping.
@@ -29,129 +27,6 @@ __device__ __forceinline__ void group_argmax(double& best, int& row, int tps) {
     int orow = __shfl_xor(row, off, 64);
     if (ob > best || (ob == best && orow < row)) { best = ob; row = orow; }
   }
-}
-
-// Factor G systems per workgroup with the matrices resident in LDS.  a_soa: batch-fastest input; f_aos / piv_aos: system-major output.
-__global__ void k_lu_factor_lds(int n, int ld, int64_t nb, int g_per_wg, const double* __restrict__ a_soa, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
-                                unsigned long long* singular_word, unsigned int epoch) {
-  extern __shared__ double sh[];
-  __shared__ double s_best[kCoopThreads / 64];
-  __shared__ int s_row[kCoopThreads / 64];
-  const int tps = kCoopThreads / g_per_wg;
-  const int g = threadIdx.x / tps, lane = threadIdx.x % tps;
-  const int64_t b0 = (int64_t)blockIdx.x * g_per_wg;
-  const int64_t b = b0 + g;
-  const bool live = b < nb;
-  double* A = sh + (size_t)g * ld * n;  // column-major, leading dimension ld
-  int* piv_sh = reinterpret_cast<int*>(sh + (size_t)g_per_wg * ld * n) + g * n;
-  // ---- stage in: element e of the G systems is contiguous in the batch-fastest input (G*8 bytes per segment)
-  for (int64_t t = threadIdx.x; t < (int64_t)n * n * g_per_wg; t += kCoopThreads) {
-    const int64_t e = t / g_per_wg;
-    const int gg = (int)(t % g_per_wg);
-    const int64_t bb = b0 + gg;
-    if (bb < nb) sh[(size_t)gg * ld * n + (e / n) * ld + (e % n)] = a_soa[e * nb + bb];
-  }
-  __syncthreads();
-  bool singular = false;
-  for (int k = 0; k < n; ++k) {
-    // pivot search in column k, rows k..n-1
-    double best = -1.0;
-    int prow = n;
-    for (int r = k + lane; r < n; r += tps) {
-      double v = fabs(A[k * ld + r]);
-      if (v > best) { best = v; prow = r; }   // rows ascend within a lane: keeps the first maximum
-    }
-    group_argmax(best, prow, tps < 64 ? tps : 64);
-    if (tps > 64) {  // a system spans several waves (uniform over the workgroup): finish the arg-max through LDS
-      const int wps = tps >> 6, w = threadIdx.x >> 6;
-      if ((threadIdx.x & 63) == 0) { s_best[w] = best; s_row[w] = prow; }
-      __syncthreads();
-      best = s_best[g * wps];
-      prow = s_row[g * wps];
-      for (int j = 1; j < wps; ++j) {
-        const double ob = s_best[g * wps + j];
-        const int orow = s_row[g * wps + j];
-        if (ob > best || (ob == best && orow < prow)) { best = ob; prow = orow; }
-      }
-    }
-    // NaN columns: fabs(NaN) > best is false everywhere => prow stays n; fall back to the diagonal like the sequential scan (p = k)
-    if (prow >= n) prow = k;
-    const double diag = live ? A[k * ld + prow] : 1.0;
-    const bool zero = diag == 0.0;
-    if (zero) singular = true;
-    if (lane == 0) piv_sh[k] = zero ? k : prow;
-    __syncthreads();
-    if (!zero && prow != k)
-      for (int c = lane; c < n; c += tps) { double tmp = A[c * ld + k]; A[c * ld + k] = A[c * ld + prow]; A[c * ld + prow] = tmp; }
-    __syncthreads();
-    if (!zero) {
-      const double inv_diag = 1.0 / diag;
-      for (int r = k + 1 + lane; r < n; r += tps) A[k * ld + r] = A[k * ld + r] * inv_diag;
-    }
-    __syncthreads();
-    if (!zero) {
-      const int m = n - k - 1;
-      for (int idx = lane; idx < m * m; idx += tps) {
-        const int r = k + 1 + idx % m, c = k + 1 + idx / m;
-        A[c * ld + r] = (-A[c * ld + k]) * A[k * ld + r] + A[c * ld + r];
-      }
-    }
-    __syncthreads();
-  }
-  // ---- stage out: system-major, contiguous per system
-  if (live) {
-    double* F = f_aos + (size_t)b * n * n;
-    for (int e = lane; e < n * n; e += tps) F[e] = A[(e / n) * ld + (e % n)];
-    for (int k = lane; k < n; k += tps) piv_aos[(size_t)b * n + k] = piv_sh[k];
-    if (singular && lane == 0) publish_singular(singular_word, 1ull, epoch);
-  }
-}
-
-// Solve with the factors of G systems per workgroup staged in LDS; rhs is batch-fastest (in place).
-__global__ void k_lu_solve_lds(int n, int ld, int64_t nb, int g_per_wg, const double* __restrict__ f_aos, const int32_t* __restrict__ piv_aos, double* __restrict__ rhs,
-                               unsigned long long* rec, unsigned int seq) {
-  extern __shared__ double sh[];
-  const int tps = kCoopThreads / g_per_wg;
-  const int g = threadIdx.x / tps, lane = threadIdx.x % tps;
-  const int64_t b = (int64_t)blockIdx.x * g_per_wg + g;
-  const bool live = b < nb;
-  double* A = sh + (size_t)g * ld * n;
-  double* v = sh + (size_t)g_per_wg * ld * n + (size_t)g * n;
-  if (live) {
-    const double* F = f_aos + (size_t)b * n * n;
-    for (int e = lane; e < n * n; e += tps) A[(e / n) * ld + (e % n)] = F[e];
-    for (int r = lane; r < n; r += tps) v[r] = rhs[(int64_t)r * nb + b];
-  }
-  __syncthreads();
-  if (live && lane == 0) {  // row swaps are sequentially dependent: n cheap LDS operations by one lane
-    const int32_t* P = piv_aos + (size_t)b * n;
-    for (int i = 0; i < n; ++i) { int p = P[i]; if (p != i) { double tmp = v[i]; v[i] = v[p]; v[p] = tmp; } }
-  }
-  __syncthreads();
-  for (int i = 0; i + 1 < n; ++i) {
-    if (live) {
-      const double coeff = v[i];
-      for (int r = i + 1 + lane; r < n; r += tps) v[r] = (-coeff) * A[i * ld + r] + v[r];
-    }
-    __syncthreads();
-  }
-  bool ok = true;
-  for (int i = n - 1; i >= 0; --i) {
-    double coeff = 0.0;
-    if (live) {
-      const double diag = A[i * ld + i];
-      if (diag == 0.0) ok = false;
-      coeff = v[i] / diag;  // every lane of the group computes the same quotient from the same LDS words
-    }
-    __syncthreads();  // barriers stay outside divergent code: a wave may hold live and dead groups
-    if (live) {
-      if (lane == 0) v[i] = coeff;
-      for (int r = lane; r < i; r += tps) v[r] = (-coeff) * A[i * ld + r] + v[r];
-    }
-    __syncthreads();
-  }
-  if (live) for (int r = lane; r < n; r += tps) rhs[(int64_t)r * nb + b] = v[r];
-  block_publish(0ull, 0ull, (live && lane == 0 && !ok) ? 1ull : 0ull, rec, seq);
 }
 
 // batch-fastest -> system-major copy of the matrices (one thread per element, tiled through LDS by the generic transpose in dsh_ctx.hip is

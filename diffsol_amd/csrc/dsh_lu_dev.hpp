@@ -124,44 +124,5 @@ __device__ __forceinline__ void store_vec(double* __restrict__ p, int64_t nb, in
   for (int k = 0; k < N; ++k) p[(int64_t)k * nb + b] = v[k];
 }
 
-// ---- generic (run-time n) versions: one lane per system working in place in HBM; every access is coalesced across the wave
-// (lane b touches p[e*nb + b]).  Used for n > 8 until the LDS-tiled wave-per-system kernels land.
-__device__ inline void lu_factor_global(double* __restrict__ A, int32_t* __restrict__ P, int64_t n, int64_t nb, int64_t b, bool& singular) {
-  auto at = [&](int64_t r, int64_t c) -> double& { return A[(c * n + r) * nb + b]; };
-  for (int64_t i = 0; i < n; ++i) {
-    int64_t p = i;
-    double best = fabs(at(i, i));
-    for (int64_t r = i + 1; r < n; ++r) { double v = fabs(at(r, i)); if (v > best) { best = v; p = r; } }
-    double diag = at(p, i);
-    if (diag == 0.0) { P[i * nb + b] = (int32_t)i; singular = true; continue; }
-    P[i * nb + b] = (int32_t)p;
-    if (p != i) for (int64_t c = 0; c < n; ++c) { double tmp = at(i, c); at(i, c) = at(p, c); at(p, c) = tmp; }
-    double inv_diag = 1.0 / diag;
-    for (int64_t r = i + 1; r < n; ++r) at(r, i) = at(r, i) * inv_diag;
-    for (int64_t c = i + 1; c < n; ++c) {
-      double pr = at(i, c);
-      for (int64_t r = i + 1; r < n; ++r) at(r, c) = (-pr) * at(r, i) + at(r, c);
-    }
-  }
-}
-__device__ inline bool lu_solve_global(const double* __restrict__ A, const int32_t* __restrict__ P, double* __restrict__ v, int64_t n, int64_t nb,
-                                       int64_t b) {
-  auto at = [&](int64_t r, int64_t c) { return A[(c * n + r) * nb + b]; };
-  auto V = [&](int64_t r) -> double& { return v[r * nb + b]; };
-  for (int64_t i = 0; i < n; ++i) { int64_t p = P[i * nb + b]; if (p != i) { double tmp = V(i); V(i) = V(p); V(p) = tmp; } }
-  for (int64_t i = 0; i + 1 < n; ++i) {
-    double coeff = V(i);
-    for (int64_t r = i + 1; r < n; ++r) V(r) = (-coeff) * at(r, i) + V(r);
-  }
-  bool ok = true;
-  for (int64_t i = n - 1; i >= 0; --i) {
-    double diag = at(i, i);
-    if (diag == 0.0) ok = false;
-    double coeff = V(i) / diag;
-    V(i) = coeff;
-    for (int64_t r = 0; r < i; ++r) V(r) = (-coeff) * at(r, i) + V(r);
-  }
-  return ok;
-}
 
 }  // namespace dsh

@@ -182,6 +182,7 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 #define DSH_MODEL_HEAT1D 7                      /* n=size, p=[D]            test_models/heat1d.rs:16-52, examples/pde-heat/src/main.rs:15-40 */
 #define DSH_MODEL_RLC 8                         /* n=4 DAE, p=[R,L,C,V0,omega,ithresh]; size!=0 adds root iR-ithresh  examples/electrical-circuits/src/main.rs:10-41 */
 #define DSH_MODEL_EXPONENTIAL_DECAY_ROOT 9      /* exponential decay + root x0-0.6  test_models/exponential_decay.rs:98-100 */
+#define DSH_MODEL_SPM 10                        /* single-particle battery model, n=2+2*size (size=0 -> 20 shells), p=[I], roots V-3.105, 4.1-V  book/src/primer/src/spm.ds */
 
 int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, int* has_mass, int64_t* nroots);
 int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* y);

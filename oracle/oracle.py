@@ -22,6 +22,7 @@ MODEL_GAUSSIAN_DECAY = 6
 MODEL_HEAT1D = 7
 MODEL_RLC = 8
 MODEL_EXPONENTIAL_DECAY_ROOT = 9
+MODEL_SPM = 10
 
 METHOD_BDF = 0
 METHOD_TR_BDF2 = 1

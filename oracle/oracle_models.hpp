@@ -29,6 +29,7 @@ enum ModelId : int {
   MODEL_HEAT1D = 7,                       // n=size(mgrid+1), p=[D], finite differences, triangle IC
   MODEL_RLC = 8,                          // n=4 DAE, p=[R,L,C,V0,omega,ithresh]
   MODEL_EXPONENTIAL_DECAY_ROOT = 9,       // exponential decay with root x0-0.6
+  MODEL_SPM = 10,                         // single-particle battery model, n=2+2*size (size shells per particle, 20 in spm.ds), p=[I]
 };
 
 struct Model {
@@ -183,6 +184,84 @@ struct Rlc : Model {
   void root(const double* x, const double* p, double, double* g) const override { g[0] = x[0] - p[5]; }
 };
 
+// Single-particle lithium-ion model of book/src/primer/src/spm.ds (used by examples/physics-based-battery-simulation/src/main.rs:12-45):
+//   u = (discharge capacity, throughput capacity, x_neg[0..m), x_pos[0..m))   m = 20 radial finite volumes per particle
+//   F = (I/3600, |I|/3600, A_neg x_neg + flux_neg(I) e_{m-1}, A_pos x_pos + flux_pos(I) e_{m-1}),  identity mass,
+//   stop = (V - 3.105, 4.1 - V),  V(u, I) = terminal voltage from the surface concentrations (linear extrapolation of the two outer shells).
+// spm.ds lists the discretisation as literal sparse tensors (constant6_ij, constant7_ij, ...); they are the spherical finite-volume
+// Laplacian on m uniform shells scaled by D/R^2 and are generated here from that formula (lower_i = 3 i^2 / ((i+1)^3 - i^3) / dr^2,
+// upper_i = 3 (i+1)^2 / ((i+1)^3 - i^3) / dr^2, no outer flux) — equal to the file's literals to rounding (<= 2 ulp).  The scalar
+// coefficients (flux scalings, exchange-current prefactors, open-circuit-potential fits, voltage cut-offs) are the file's values.
+struct SpmCoeffs {
+  static constexpr double kInvHour = 0.0002777777777777778;          // constant4 / F_i rows 0,1
+  static constexpr double kDiffNeg = 0.39e-3, kDiffPos = 1.0e-3;      // D/R^2 of constant7_ij / constant6_ij
+  static constexpr double kFluxNeg = 3.2835305549534856e-12 * -520607810.21082705;  // constant0_i * (constant3 * I)
+  static constexpr double kFluxPos = 4.106800547504748e-12 * 243644455.17866704;    // constant1_i * (constant2 * I)
+  static constexpr double kSurfIn = -0.4999999999999983, kSurfOutPos = 1.4999999999999982, kSurfOutNeg = 1.4999999999999984;  // constant5_ij / constant9_ij
+  static constexpr double kCmaxPos = 51217.9257309275, kCmaxNeg = 24983.2619938437;
+  static constexpr double kThermal2 = 0.05138515824298745;            // 2RT/F
+};
+template <class T> inline T spm_clamp(T v, T lo, T hi) { return v < hi ? (v > lo ? v : lo) : hi; }  // max(min(v, hi), lo)
+// open-circuit potentials (the tanh fits written out in spm.ds out_i)
+inline double spm_ocp_pos(double s) {
+  return 2.16216 + 0.07645 * std::tanh(30.834 - 57.858397200000006 * s) + 2.1581 * std::tanh(52.294 - 53.412228 * s) - 0.14169 * std::tanh(11.0923 - 21.0852666 * s) +
+         0.2051 * std::tanh(1.4684 - 5.829105600000001 * s) + 0.2531 * std::tanh(4.291641337386018 - 8.069908814589667 * s) - 0.02167 * std::tanh(-87.5 + 177.0 * s) +
+         1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
+}
+inline double spm_ocp_neg(double s) {
+  return 0.194 + 1.5 * std::exp(-120.0 * s) + 0.0351 * std::tanh(-3.44578313253012 + 12.048192771084336 * s) - 0.0045 * std::tanh(-7.1344537815126055 + 8.403361344537815 * s) -
+         0.035 * std::tanh(-18.466 + 20.0 * s) - 0.0147 * std::tanh(-14.705882352941176 + 29.41176470588235 * s) - 0.102 * std::tanh(-1.3661971830985917 + 7.042253521126761 * s) -
+         0.022 * std::tanh(-54.8780487804878 + 60.975609756097555 * s) - 0.011 * std::tanh(-5.486725663716814 + 44.24778761061947 * s) +
+         0.0155 * std::tanh(-3.6206896551724133 + 34.48275862068965 * s) + 1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
+}
+// terminal voltage from the two outer shells of each particle (spm.ds varying2..5 and out_i)
+inline double spm_voltage(double neg_in, double neg_out, double pos_in, double pos_out, double current) {
+  using C = SpmCoeffs;
+  const double sp = C::kSurfIn * pos_in + C::kSurfOutPos * pos_out, sn = C::kSurfIn * neg_in + C::kSurfOutNeg * neg_out;
+  const double cp = spm_clamp(-25608.96286546366 * pos_in + 76826.88859639116 * pos_out, 0.000512179257309275, 51217.92521874824);  // constant10_ij
+  const double cn = spm_clamp(-12491.630996921805 * neg_in + 37474.892990765504 * neg_out, 0.000249832619938437, 24983.261744011077);  // constant8_ij
+  const double stp = spm_clamp(sp, 1e-10, 0.9999999999), stn = spm_clamp(sn, 1e-10, 0.9999999999);
+  const double eta_p = C::kThermal2 * std::asinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * std::sqrt(cp)) * std::sqrt(C::kCmaxPos - cp))));
+  const double eta_n = C::kThermal2 * std::asinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * std::sqrt(cn)) * std::sqrt(C::kCmaxNeg - cn))));
+  return (eta_p + spm_ocp_pos(stp)) - (eta_n + spm_ocp_neg(stn));
+}
+struct Spm : Model {
+  int m;
+  explicit Spm(int shells) : m(shells <= 0 ? 20 : shells) { n = 2 + 2 * m; np = 1; nroots = 2; }
+  // row i of the spherical finite-volume Laplacian applied to x (m shells), scaled by s
+  double diffusion(const double* x, int i, double s) const {
+    const double dr = 1.0 / (double)m, i0 = (double)i, i1 = (double)(i + 1);
+    const double vol = i1 * i1 * i1 - i0 * i0 * i0;
+    const double lower = 3.0 * i0 * i0 / vol / (dr * dr) * s, upper = i + 1 < m ? 3.0 * i1 * i1 / vol / (dr * dr) * s : 0.0;
+    double acc = (-(lower + upper)) * x[i];
+    if (i > 0) acc += lower * x[i - 1];
+    if (i + 1 < m) acc += upper * x[i + 1];
+    return acc;
+  }
+  void apply(const double* x, const double* p, bool jac, double* y) const {
+    using C = SpmCoeffs;
+    y[0] = jac ? 0.0 : C::kInvHour * p[0];
+    y[1] = jac ? 0.0 : C::kInvHour * std::fabs(p[0]);
+    for (int i = 0; i < m; ++i) {
+      double fn = diffusion(x + 2, i, C::kDiffNeg), fp = diffusion(x + 2 + m, i, C::kDiffPos);
+      if (!jac && i == m - 1) { fn += C::kFluxNeg * p[0]; fp += C::kFluxPos * p[0]; }
+      y[2 + i] = fn;
+      y[2 + m + i] = fp;
+    }
+  }
+  void rhs(const double* x, const double* p, double, double* y) const override { apply(x, p, false, y); }
+  void jac_mul(const double*, const double* p, double, const double* v, double* y) const override { apply(v, p, true, y); }
+  void init(const double*, double, double* y) const override {
+    y[0] = y[1] = 0.0;
+    for (int i = 0; i < m; ++i) { y[2 + i] = 0.8000000000000016; y[2 + m + i] = 0.6000000000000001; }
+  }
+  void root(const double* x, const double* p, double, double* g) const override {
+    const double v = spm_voltage(x[2 + m - 2], x[2 + m - 1], x[2 + 2 * m - 2], x[2 + 2 * m - 1], p[0]);
+    g[0] = -3.105 + v;
+    g[1] = 4.1 - v;
+  }
+};
+
 inline std::unique_ptr<Model> make_model(int id, int size) {
   switch (id) {
     case MODEL_EXPONENTIAL_DECAY: return std::make_unique<ExponentialDecay>(false);
@@ -195,6 +274,7 @@ inline std::unique_ptr<Model> make_model(int id, int size) {
     case MODEL_GAUSSIAN_DECAY: return std::make_unique<GaussianDecay>(size);
     case MODEL_HEAT1D: return std::make_unique<Heat1d>(size);
     case MODEL_RLC: return std::make_unique<Rlc>(size != 0);
+    case MODEL_SPM: return std::make_unique<Spm>(size);
     default: throw std::runtime_error("oracle: unknown model id");
   }
 }

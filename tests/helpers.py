@@ -1,7 +1,7 @@
 import numpy as np
 
 ORACLE_MODEL = {"exponential_decay": 0, "exponential_decay_with_algebraic": 1, "exponential_decay_with_algebraic_batched": 2, "robertson_ode": 3,
-                "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9}
+                "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9, "spm": 10}
 METHOD = {"bdf": 0, "tr_bdf2": 1, "esdirk34": 2}
 
 

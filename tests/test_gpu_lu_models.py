@@ -64,7 +64,7 @@ def test_lu_reference_diagonal_kat_and_singular_reporting(H, ctx1):
 
 @pytest.mark.parametrize("n", [12, 150])
 def test_lu_cooperative_kernels_report_singular_members(H, ctx1, n):
-    """n > 8 goes through the LDS-resident (n=12) / one-workgroup-per-system (n=150) kernels: same zero-pivot reporting as the register path."""
+    """n > 8 goes through the wavefront-per-system (n=12) / workgroup-per-system blocked (n=150) kernels: same zero-pivot reporting as the register path."""
     nb = 5
     c = ctx1.clone_with_nbatch(nb)
     rng = np.random.default_rng(n)
@@ -85,7 +85,7 @@ def test_lu_cooperative_kernels_report_singular_members(H, ctx1, n):
 
 
 MODEL_CASES = [("exponential_decay", 0, 2), ("exponential_decay_with_algebraic", 0, 1), ("robertson_ode", 1, 3), ("robertson_ode", 3, 3), ("robertson", 0, 3),
-               ("dydt_y2", 10, 0), ("gaussian_decay", 10, 10), ("heat1d", 16, 1), ("rlc", 0, 6)]
+               ("dydt_y2", 10, 0), ("gaussian_decay", 10, 10), ("heat1d", 16, 1), ("rlc", 0, 6), ("spm", 20, 1), ("spm", 5, 1)]
 
 
 @pytest.mark.parametrize("name,size,np_", MODEL_CASES)

@@ -184,6 +184,28 @@ def test_rlc_dae_tracks_oracle_within_libm_difference(H, O):
     assert np.allclose(y, yo, rtol=1e-9, atol=1e-12)
 
 
+def test_spm_battery_ensemble_matches_oracle_bitwise_and_stops_at_the_voltage_cutoff(H, O):
+    """Single-particle battery model (book/src/primer/src/spm.ds, n=42): the right-hand side is linear, so the lock-step ensemble is
+    bit-identical to the oracle up to any t before an event; the stop condition V < 3.105 (tanh/asinh/exp through ocml on the device, libm on
+    the host) is located within 1e-9 relative of the oracle's root time when all members cross in the same step."""
+    cur = np.linspace(0.6, 1.4, 9)[:, None]
+    s = H.Solver("spm", cur, nbatch=9, model_size=20, rtol=1e-6, atol=[1e-6])
+    assert s.n == 42 and not s.fused
+    o = O.OracleSolver(ORACLE_MODEL["spm"], cur, nbatch=9, model_size=20, rtol=1e-6, atol=[1e-6])
+    times = [60.0, 300.0, 900.0]
+    y, _ = s.solve_to_points(times)
+    yo, _ = o.solve_to_points(times)
+    assert np.array_equal(y, yo)
+    assert np.allclose(y[-1][:, 0], cur[:, 0] * 900.0 / 3600.0, rtol=1e-6)  # discharge capacity [Ah] = I t
+    same = np.full((4, 1), 1.0)
+    s2 = H.Solver("spm", same, nbatch=4, model_size=20, rtol=1e-6, atol=[1e-6])
+    o2 = O.OracleSolver(ORACLE_MODEL["spm"], same, nbatch=4, model_size=20, rtol=1e-6, atol=[1e-6])
+    _, _, reason = s2.solve(3600.0)
+    o2.solve(3600.0)
+    (t_root, idx), (t_ref, idx_ref) = s2.root_info(), o2.root_info()
+    assert reason == 1 and idx == idx_ref == 0 and abs(t_root - t_ref) < 1e-9 * t_ref and 2000.0 < t_root < 3000.0
+
+
 # ------------------------------------------------------------------ BASELINE.json config 2 at full size: size-independent properties
 @pytest.fixture(scope="module")
 def full_size_run(H):
