@@ -3,6 +3,7 @@
 // Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
 // (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
 // one wavefront per system for n <= 64 (dsh_lu_wave.hpp), one workgroup per system with a blocked factorisation beyond (dsh_lu_coop.hpp).
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -133,9 +134,12 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
           DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
           attr_set = true;
         }
+        static const bool phase_profile = [] { const char* e = getenv("DSH_LU_PHASE_PROFILE"); return e && atoi(e) != 0; }();
+        unsigned long long* phase_clocks = nullptr;
+        if (phase_profile) { DSH_HIP_CHECK(hipMalloc(&phase_clocks, 8 * sizeof(unsigned long long))); DSH_HIP_CHECK(hipMemset(phase_clocks, 0, 8 * sizeof(unsigned long long))); }
 #define DSH_LU_BLOCKED(NBK)                                                                                                                       \
   hipLaunchKernelGGL((k_lu_factor_blocked<NBK>), dim3((unsigned)nb), dim3(kCoopThreads), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
-                     lu->pivots, lu->singular, lu->singular_epoch)
+                     lu->pivots, lu->singular, lu->singular_epoch, phase_clocks)
         if (blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
         else if (blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
         else if (blocked_lds_bytes(n, 8) <= budget) DSH_LU_BLOCKED(8);
@@ -143,6 +147,14 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
           hipLaunchKernelGGL(k_lu_factor_global_coop, dim3((unsigned)nb), dim3(kCoopThreads), 0, ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular,
                              lu->singular_epoch);
 #undef DSH_LU_BLOCKED
+        if (phase_profile) {  // diagnostic only: synchronises
+          unsigned long long h[8];
+          DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          DSH_HIP_CHECK(hipMemcpy(h, phase_clocks, sizeof(h), hipMemcpyDeviceToHost));
+          DSH_HIP_CHECK(hipFree(phase_clocks));
+          fprintf(stderr, "[dsh_lu phase us, workgroup 0] load %.1f  panel %.1f  writeback %.1f  swaps %.1f  u12 %.1f  update %.1f\n", h[0] / 100.0, h[1] / 100.0,
+                  h[2] / 100.0, h[3] / 100.0, h[4] / 100.0, h[5] / 100.0);
+        }
       }
     }
   }

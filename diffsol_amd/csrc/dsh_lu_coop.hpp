@@ -134,7 +134,13 @@ __global__ void k_lu_solve_global_coop(int n, int64_t nb, const double* __restri
 // (n/NB instead of n): HBM/L2 traffic per system ~ 16 n^3 / (3 NB) bytes instead of 16 n^3 / 3.
 template <int NB>
 __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
-                                                                   unsigned long long* singular_word, unsigned int epoch) {
+                                                                   unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
+  // optional phase profile (DSH_LU_PHASE_PROFILE=1): workgroup 0 accumulates the 100 MHz wall clock per phase
+  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long tprev = prof ? wall_clock64() : 0ull;
+  auto mark = [&](int phase) {
+    if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
+  };
   extern __shared__ double sh[];  // panel (ldp x NB) during the panel factorisation, then the U12 block (mc x LDU)
   __shared__ double s_best[kCoopThreads / 64];
   __shared__ int s_row[kCoopThreads / 64];
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     for (int c = 0; c < w; ++c)
       for (int r = tid; r < m; r += kCoopThreads) sh[c * ldp + r] = A[(size_t)(jb + c) * n + jb + r];
     __syncthreads();
+    mark(0);
     // ---- 2. unblocked factorisation of the m x w panel
     for (int k = 0; k < w; ++k) {
       double* col = sh + k * ldp;
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       }
       __syncthreads();
     }
+    mark(1);
     // ---- 3. panel and pivots back to global memory; L11 to its own LDS block
     for (int c = 0; c < w; ++c)
       for (int r = tid; r < m; r += kCoopThreads) A[(size_t)(jb + c) * n + jb + r] = sh[c * ldp + r];
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       s_l11[c * (NB + 1) + r] = (r < w && c < w) ? sh[c * ldp + r] : 0.0;
     }
     __syncthreads();
+    mark(2);
     // ---- 4. the panel's row interchanges on every other column (one thread per column)
     for (int c = tid; c < n; c += kCoopThreads) {
       if (c >= jb && c < jb + w) continue;
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       }
     }
     __syncthreads();
+    mark(3);
     const int mc = n - jb - w;  // trailing columns
     if (mc <= 0) break;
     // ---- 5. U12 = L11^-1 A12, one column per thread; kept in LDS.  Trailing columns exist only behind a full panel: w == NB from here on.
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       }
     }
     __syncthreads();
+    mark(4);
     // ---- 6. trailing update: thread = row, NB multipliers in registers, 4 columns in flight
     for (int r = jb + w + tid; r < n; r += kCoopThreads) {
       double l[NB];
@@ -268,6 +279,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       }
     }
     __syncthreads();
+    mark(5);
   }
   if (singular && tid == 0) publish_singular(singular_word, 1ull, epoch);
 }
