@@ -1,0 +1,581 @@
+// Device-resident, per-member adaptive BDF for ensembles of small systems (gfx950) — SURVEY §8(f) row 1.
+//
+// The trait-boundary path (host/bdf.hpp over dsh_fused.hip) advances the whole ensemble in lock-step: one (t, h, order) sequence, the
+// max over all members in every convergence / error test, ~3 launches and ~1.3 host round trips per accepted step.  That is what the
+// reference's Context/Vector/LinearSolver boundary implies for a batched backend, but it is NOT how diffsol's CPU path treats a parameter
+// sweep: there every member is an independent IVP with its own step-size and order history.  This kernel restores exactly that semantics on
+// the device: ONE launch integrates the whole ensemble, one lane per member, the complete solver state in registers —
+//   difference array D (n x 8) and its swap partner, cached Jacobian, LU factors + pivots, Newton iterate, Convergence state (eta carry-over),
+//   JacobianUpdate counters, PI-controller memory, statistics —
+// and every scalar decision of Bdf::step (crates/diffsol/src/ode_solver/bdf.rs:1277-1589), NewtonNonlinearSolver / NoLineSearch / Convergence
+// (crates/diffsol-nl/src/{newton,line_search,convergence}.rs), JacobianUpdate (jacobian_update.rs:12-79), set_step_size
+// (state.rs:1209-1277), handle_tstop (bdf.rs:694-731) and solve_dense (method.rs:467-520) taken per lane.  No host round trip, no
+// reduction, no HBM traffic besides parameters in and the requested save points out.  Lanes of a wavefront diverge where their members do
+// (different Newton iteration counts, rejected steps, refactorisations); a wavefront is done when its slowest member is.
+//
+// Arithmetic is the oracle's, operation for operation (-ffp-contract=off); the one difference to a CPU run of the reference is libm: pow()
+// in the step-size controller, the convergence-rate estimate and the initial step is ocml's here — results agree with independent CPU solves
+// to rounding of h, not bitwise (tests/test_gpu_adaptive.py states the tolerance).
+//
+// Scope this round: static register models (n <= 4) without mass matrix and without root functions (Robertson ODE, exponential decay).
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "dsh_internal.hpp"
+#include "dsh_lu_dev.hpp"
+#include "dsh_models.hpp"
+
+using namespace dsh;
+
+namespace {
+
+constexpr int kMaxOrder = 5;
+constexpr int kNC = kMaxOrder + 3;  // columns of the difference array
+
+struct AdaptiveConsts {
+  double rtol, t0, h0;
+  double alpha[6], gamma[6], ec2[6];  // Bdf::_new tables (bdf.rs:286-306), computed on the host
+  double eta_reset, eta_reset_ts;     // 20^1.25, 100^1.25 (convergence.rs:36-42), computed on the host
+  double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
+  dsh_adaptive_options o;
+  int n_eval;
+};
+
+enum LaneStatus : int32_t {
+  kOk = 0, kStepSizeTooSmall = 1, kTooManyErrorTestFailures = 2, kTooManyNonlinearSolverFailures = 3, kStopTimeBeforeCurrentTime = 5,
+  kStopTimeAtCurrentTime = 6, kMaxStepsExceeded = 99
+};
+enum class JState { StepSuccess, FirstConvergenceFail, SecondConvergenceFail, ErrorTestFail };
+
+// weighted mean square, sequential like Vector::squared_norm (nalgebra_serial.rs:395-408)
+template <int N>
+__device__ __forceinline__ double wms(const double (&v)[N], const double (&w)[N], const double (&atol)[N], double rtol) {
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double term = v[i] / (fabs(w[i]) * rtol + atol[i]);
+    acc += term * term;
+  }
+  return acc / (double)N;
+}
+
+// compiler-rt __powidf2 (what f64::powi lowers to; convergence.rs:85)
+__device__ __forceinline__ double powi_rt(double a, int b) {
+  const bool recip = b < 0;
+  double r = 1.0;
+  while (true) {
+    if (b & 1) r *= a;
+    b /= 2;
+    if (b == 0) break;
+    a *= a;
+  }
+  return recip ? 1.0 / r : r;
+}
+
+// runge_kutta.rs:1313-1336
+__device__ __forceinline__ double pi_controller_raw(double error_norm, bool has_prev, double prev, double pi_i, double pi_p, int eff_order) {
+  const double order_f = (double)eff_order;
+  const double ki = pi_i / order_f;
+  if (pi_p == 0.0) return pow(error_norm, -ki);
+  if (has_prev) {
+    const double kp = pi_p / order_f;
+    return pow(error_norm, -(ki + kp)) * pow(prev, kp);
+  }
+  return pow(error_norm, -ki);
+}
+
+template <class Mdl, bool BA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
+                                                    const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
+                                                    int32_t* __restrict__ status_out, unsigned long long* __restrict__ totals) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  static_assert(!Mdl::HAS_MASS && Mdl::NROOTS == 0, "adaptive kernel: ODE models without roots only");
+  const AdaptiveConsts& C = *Cp;
+  const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = bglobal < nb;  // lanes past the ensemble shadow member 0 (no stores) so that the whole wavefront reaches the final reduction
+  const int64_t b = active ? bglobal : 0;
+  const dsh_adaptive_options& o = C.o;
+  const double rtol = C.rtol;
+  double p[NP], atol[N];
+  load_vec<NP>(p_g, nb, b, p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
+
+  // ------------------------------------------------------------ OdeSolverState::new_and_consistent (state.rs:969-997, :1086-1124)
+  double t = C.t0, h;
+  double y[N], f0[N];
+  Mdl::init(t, p, y);
+  Mdl::rhs(t, y, p, f0);
+  {  // set_step_size (state.rs:1209-1277), solver_order = 1
+    const bool is_neg_h = C.h0 < 0.0;
+    const double d0 = sqrt(wms<N>(y, y, atol, rtol)), d1 = sqrt(wms<N>(f0, y, atol, rtol));
+    const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+    const double hh = is_neg_h ? -h0 : h0;
+    double y1[N], f1[N], df[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) y1[i] = f0[i] * hh + y[i];
+    Mdl::rhs(is_neg_h ? t - h0 : t + h0, y1, p, f1);
+#pragma unroll
+    for (int i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
+    const double d2 = sqrt(wms<N>(df, y, atol, rtol)) / fabs(h0);
+    double max_d = d2;
+    if (max_d < d1) max_d = d1;
+    double h1;
+    if (max_d < 1e-15) { h1 = h0 * 1e-3; if (h1 < 1e-6) h1 = 1e-6; }
+    else h1 = pow(0.01 / max_d, 1.0 / (1.0 + 1.0));
+    h = 100.0 * h0;
+    if (h > h1) h = h1;
+    if (is_neg_h) h = -h;
+  }
+
+  // ------------------------------------------------------------ Bdf::_new (bdf.rs:244-368) + BdfState::initialise_diff_to_first_order
+  int order = 1;
+  // D lives in registers; its swap partner (bdf.rs `diff_tmp`, touched only when the step size changes) and the cached Jacobian (touched only
+  // when refactoring) live in LDS, one column of 64 lanes per value: that keeps the kernel at two wavefronts per SIMD.
+  __shared__ double sDt[kNC * N][64];
+  __shared__ double sJ[N * N][64];
+  const int ln = threadIdx.x;
+  double D[kNC][N];
+#pragma unroll
+  for (int j = 0; j < kNC; ++j)
+#pragma unroll
+    for (int i = 0; i < N; ++i) { D[j][i] = 0.0; sDt[j * N + i][ln] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
+  double opc = h * C.alpha[1];  // BdfCallable::c
+  double A[N * N];
+  int P[N];
+  bool jac_stale = true;
+  // statistics (ode_solver/mod.rs:28-69)
+  int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
+  // NonLinearSolver::reset_jacobian: M - c f'(x)  (op/bdf.rs:273-300) + LU
+  auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
+    double J[N * N];
+    if (jac_stale) {
+      assemble_jacobian<Mdl>(tt, xx, p, J);
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) sJ[e][ln] = J[e];
+      jac_stale = false;
+    } else {
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) J[e] = sJ[e][ln];
+    }
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + ((e / N == e % N) ? 1.0 : 0.0);
+    bool sing = false;
+    lu_factor_reg<N>(A, P, sing);
+  };
+  reset_jacobian(y, t);
+  n_setups = 1;
+  // JacobianUpdate (jacobian_update.rs:12-36)
+  int steps_since_jac = 0, steps_since_rhs_jac = 0;
+  double h_at_last_jac = 1.0;
+  // Convergence (convergence.rs:7-57)
+  double eta = C.eta_reset;
+  int n_equal_steps = 0;
+  bool has_prev_err = false;
+  double prev_err = 0.0;
+  double yp[N], psi[N];
+  double t_predict = t;
+
+  // _update_step_size (bdf.rs:508-566) with _update_diff_for_step_size (:568-577): diff_tmp[:, 0..=order] = diff[:, 0..=order] * (R U); swap
+  auto update_step_size = [&](double factor, double& new_h_out) __attribute__((always_inline)) -> bool {
+    const double new_h = factor * h;
+    n_equal_steps = 0;
+    double R[6][6];  // R[j][i] = element (row i, col j) of compute_r(order, factor)   (bdf.rs:433-463)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      R[j][0] = 1.0;
+#pragma unroll
+      for (int i = 1; i < 6; ++i) R[j][i] = (j == 0) ? 0.0 : R[j][i - 1] * ((double)i - 1.0 - factor * (double)j) / (double)i;
+    }
+    const double* U = C.u[order - 1];  // element (row k, col j) at U[j*6 + k]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j <= order) {
+        // column j of RU: ru[k] = sum_m R(k,m) U(m,j), gemm order: first term, then acc = a*b + acc
+        double ru[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double acc = R[0][k] * U[j * 6 + 0];
+#pragma unroll
+          for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
+          ru[k] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          double acc = D[0][i] * ru[0];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) if (k <= order) acc = D[k][i] * ru[k] + acc;
+          sDt[j * N + i][ln] = acc;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kNC; ++j)
+#pragma unroll
+      for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = sDt[j * N + i][ln]; sDt[j * N + i][ln] = tmp; }
+    opc = new_h * C.alpha[order];
+    h = new_h;
+    eta = C.eta_reset_ts;  // reset_eta_timestep_change
+    new_h_out = new_h;
+    return fabs(h) < o.min_timestep;  // true = StepSizeTooSmall
+  };
+
+  // _predict_forward (bdf.rs:674-692): y_predict = sum_{j<=order} D_j ; psi_neg_y0 = alpha_order * sum_{1<=j<=order} gamma_j D_j - y_predict
+  auto predict_forward = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) if (j <= order) s = s + D[j][i];
+      double q = C.gamma[1] * D[1][i];
+#pragma unroll
+      for (int j = 2; j < 6; ++j) if (j <= order) q = C.gamma[j] * D[j][i] + 1.0 * q;
+      q = q * C.alpha[order];
+      q = q - s;
+      yp[i] = s;
+      psi[i] = q;
+    }
+    t_predict = t + h;
+  };
+
+  // _jacobian_updates (bdf.rs:465-506) over JacobianUpdate::check_* (jacobian_update.rs:38-79)
+  auto jacobian_updates = [&](double c, JState st) __attribute__((always_inline)) {
+    bool check_rhs = false, check_jac = true;
+    const double rel = fabs(c / h_at_last_jac - 1.0);
+    switch (st) {
+      case JState::StepSuccess:
+        check_rhs = steps_since_rhs_jac >= o.update_rhs_jacobian_after_steps;
+        check_jac = steps_since_jac >= o.update_jacobian_after_steps || rel > o.threshold_to_update_jacobian;
+        break;
+      case JState::FirstConvergenceFail: check_rhs = rel < o.threshold_to_update_rhs_jacobian; break;
+      case JState::SecondConvergenceFail: check_rhs = steps_since_rhs_jac > 0; break;
+      case JState::ErrorTestFail: check_rhs = false; break;
+    }
+    if (check_rhs) {
+      jac_stale = true;
+      reset_jacobian(y, t);
+      steps_since_rhs_jac = 0; steps_since_jac = 0; h_at_last_jac = c;  // update_rhs_jacobian, then update_jacobian
+      eta = C.eta_reset;
+      n_setups++;
+    } else if (check_jac) {
+      reset_jacobian(y, t);
+      steps_since_jac = 0; h_at_last_jac = c;
+      eta = C.eta_reset;
+      n_setups++;
+    }
+  };
+
+  // handle_tstop (bdf.rs:694-731): 0 = nothing, 1 = TstopReached, 2 = StopTimeBeforeCurrentTime
+  bool has_tstop = true;
+  const double tstop = t_eval[C.n_eval - 1];
+  auto handle_tstop = [&]() __attribute__((always_inline)) -> int {
+    const double eps = 2.220446049250313e-16;
+    const double troundoff = 100.0 * eps * (fabs(t) + fabs(h));
+    if (fabs(t - tstop) <= troundoff) { has_tstop = false; return 1; }
+    if ((h > 0.0 && tstop < t - troundoff) || (h < 0.0 && tstop > t + troundoff)) { has_tstop = false; return 2; }
+    if ((h > 0.0 && t + h > tstop + troundoff) || (h < 0.0 && t + h < tstop - troundoff)) {
+      const double factor = (tstop - t) / h;
+      double nh;
+      (void)update_step_size(factor, nh);  // "step size too small" is ignored here like in the reference
+    }
+    return 0;
+  };
+
+  int32_t status = kOk;
+  int col = 0;
+  // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
+  {
+    const int r = handle_tstop();
+    if (r == 1) status = kStopTimeAtCurrentTime;
+    else if (r == 2) status = kStopTimeBeforeCurrentTime;
+  }
+
+  long guard = 0;
+  bool done = status != kOk || !active;
+  while (!done) {
+    if (++guard > o.max_steps) { status = kMaxStepsExceeded; break; }
+    // ================================================================ Bdf::step (bdf.rs:1277-1589)
+    double safety = 0.0, error_norm = 0.0;
+    const int old_err_fails = n_err_fails;
+    bool convergence_fail = false;
+    double x[N];
+    int niter = 0;
+    predict_forward();
+    while (true) {
+      // ---- NewtonNonlinearSolver::solve_in_place over NoLineSearch (newton.rs:13-36, line_search.rs:46-72)
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = yp[i];
+      niter = 0;
+      bool has_old = false;
+      double old_norm = 0.0;
+      bool solved = false;
+      for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
+        double f[N], delta[N];
+        Mdl::rhs(t_predict, x, p, f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { const double tmp = x[i] + psi[i]; delta[i] = 1.0 * tmp + (-opc) * f[i]; }  // F(y) = (y - y0 + psi) - c f(y)
+        const bool lu_ok = lu_solve_reg<N>(A, P, delta);
+        if (!lu_ok) break;  // LuSolveFailed
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+        const double norm = sqrt(wms<N>(delta, yp, atol, rtol));
+        // Convergence::check_new_iteration (convergence.rs:68-139)
+        niter += 1;
+        bool diverged = false;
+        if (has_old) {
+          // pow(x, 1.0) == x exactly: the common second iteration needs no libm call
+          const double rate = niter == 2 ? norm / old_norm : pow(norm / old_norm, 1.0 / (double)(niter - 1));
+          if (rate > 0.9) diverged = true;
+          else if (powi_rt(rate, o.max_nonlinear_solver_iterations - niter) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
+          else eta = rate / (1.0 - rate);
+        } else {
+          const double min_eta = 1e4 * 2.220446049250313e-16;
+          if (eta < min_eta) eta = min_eta;
+          eta = pow(eta, 0.8);
+        }
+        const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
+        if (niter == 1) { has_old = true; old_norm = norm; }
+        if (diverged) break;
+        if (converged) { solved = true; break; }
+      }
+      n_newton += niter;
+      if (!solved) {
+        n_nl_fails += 1;
+        if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kTooManyNonlinearSolverFailures; break; }
+        has_prev_err = false;
+        if (convergence_fail) {
+          double new_h;
+          if (update_step_size(0.3, new_h)) { status = kStepSizeTooSmall; break; }
+          jacobian_updates(new_h * C.alpha[order], JState::SecondConvergenceFail);
+          predict_forward();
+        } else {
+          jacobian_updates(h * C.alpha[order], JState::FirstConvergenceFail);
+          convergence_fail = true;
+        }
+        continue;
+      }
+      double ydelta[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
+      // error_control (bdf.rs:812-843): norm against the CURRENT state y
+      error_norm = fmax(0.0, wms<N>(ydelta, y, atol, rtol) * C.ec2[order - 1]);
+      const double maxiter = (double)o.max_nonlinear_solver_iterations;
+      safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
+      if (error_norm <= 1.0) {
+        // ---- accepted: _update_diff (bdf.rs:646-664), state update
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          double dk1 = 0.0;
+#pragma unroll
+          for (int j = 2; j < 7; ++j) if (j == order + 1) dk1 = D[j][i];
+          const double dk2 = ydelta[i] - dk1;
+#pragma unroll
+          for (int j = 2; j < kNC; ++j) { if (j == order + 2) D[j][i] = dk2; if (j == order + 1) D[j][i] = ydelta[i]; }
+          double upper = ydelta[i];
+#pragma unroll
+          for (int j = 5; j >= 0; --j) if (j <= order) { const double v = D[j][i] + 1.0 * upper; D[j][i] = v; upper = v; }
+          y[i] = yp[i];
+        }
+        t = t_predict;
+        break;
+      }
+      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1);
+      has_prev_err = false;
+      if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
+      double new_h;
+      if (update_step_size(factor, new_h)) { status = kStepSizeTooSmall; break; }
+      jacobian_updates(new_h * C.alpha[order], JState::ErrorTestFail);
+      predict_forward();
+      n_err_fails += 1;
+      if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kTooManyErrorTestFailures; break; }
+    }
+    if (status != kOk) break;
+    n_steps += 1;
+    steps_since_jac += 1; steps_since_rhs_jac += 1;  // JacobianUpdate::step
+    prev_err = error_norm; has_prev_err = true;
+    n_equal_steps += 1;
+    if (n_equal_steps > order) {
+      // order selection (bdf.rs:1494-1560): predict_error_control(order-1) / (order+1) on the updated differences
+      double col_m[N], col_p[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double vm = 0.0, vp = 0.0;
+#pragma unroll
+        for (int j = 1; j < kNC; ++j) { if (j == order) vm = D[j][i]; if (j == order + 2) vp = D[j][i]; }
+        col_m[i] = vm; col_p[i] = vp;
+      }
+      const double inf = __builtin_huge_val();
+      const double error_m_norm = order > 1 ? wms<N>(col_m, y, atol, rtol) * C.ec2[order - 1] : inf;
+      const double error_p_norm = order < kMaxOrder ? wms<N>(col_p, y, atol, rtol) * C.ec2[order + 1] : inf;
+      const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
+      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order);
+      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1);
+      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2);
+      int max_index = 0;  // Iterator::max_by keeps the LAST maximum
+      double fmaxv = f0c;
+      if (f1c >= fmaxv) { max_index = 1; fmaxv = f1c; }
+      if (f2c >= fmaxv) { max_index = 2; fmaxv = f2c; }
+      const int new_order = max_index == 0 ? order - 1 : (max_index == 1 ? order : order + 1);
+      order = new_order;
+      double factor = safety * fmaxv;
+      if (factor > o.max_timestep_growth) factor = o.max_timestep_growth;
+      if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
+      if (factor >= o.min_timestep_growth || factor <= o.max_timestep_shrink || max_index == 0 || max_index == 2) {
+        double new_h;
+        if (update_step_size(factor, new_h)) { status = kStepSizeTooSmall; break; }
+        jacobian_updates(new_h * C.alpha[new_order], JState::StepSuccess);
+      }
+    }
+    int reason = 0;
+    if (has_tstop) reason = handle_tstop();
+    // ================================================================ solve_dense: interpolated output (interpolate_from_diff, bdf.rs:767-782)
+    while (col < C.n_eval && t_eval[col] <= t) {
+      const double te = t_eval[col];
+      double time_factor = 1.0;
+      double yv[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) yv[i] = D[0][i];
+#pragma unroll
+      for (int j = 0; j < kMaxOrder; ++j) {
+        if (j < order) {
+          const double jt = (double)j;
+          time_factor *= (te - (t - h * jt)) / (h * (1.0 + jt));
+#pragma unroll
+          for (int i = 0; i < N; ++i) yv[i] = time_factor * D[j + 1][i] + 1.0 * yv[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+      col++;
+    }
+    if (reason == 1) done = true;
+  }
+  if (active) {
+    // columns that were never reached (error exit): NaN
+    for (; col < C.n_eval; ++col)
+#pragma unroll
+      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
+    if (status_out != nullptr) status_out[b] = status;
+    if (stats_out != nullptr) {
+      stats_out[0 * nb + b] = n_steps;
+      stats_out[1 * nb + b] = n_newton;
+      stats_out[2 * nb + b] = n_setups;
+      stats_out[3 * nb + b] = n_err_fails;
+      stats_out[4 * nb + b] = n_nl_fails;
+    }
+  }
+  // ensemble totals: wavefront sums, one atomic per wavefront and counter
+  const unsigned long long mine[6] = {active ? (unsigned long long)n_steps : 0ull, active ? (unsigned long long)n_newton : 0ull,
+                                      active ? (unsigned long long)n_setups : 0ull, active ? (unsigned long long)n_err_fails : 0ull,
+                                      active ? (unsigned long long)n_nl_fails : 0ull, (active && status != kOk) ? 1ull : 0ull};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const unsigned long long sum = wave_sum_u64(mine[k]);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&totals[k], sum);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void dsh_adaptive_default_options(dsh_adaptive_options* o) {
+  if (!o) return;
+  // OdeSolverOptions defaults (problem.rs:132-152) + BdfConfig (config.rs:53-74)
+  o->max_nonlinear_solver_iterations = 10;
+  o->max_error_test_failures = 40;
+  o->max_nonlinear_solver_failures = 50;
+  o->nonlinear_solver_tolerance = 0.2;
+  o->min_timestep = 1e-13;
+  o->max_timestep_growth = 2.0;
+  o->min_timestep_growth = 2.0;
+  o->max_timestep_shrink = 0.9;
+  o->min_timestep_shrink = 0.5;
+  o->update_jacobian_after_steps = 20;
+  o->update_rhs_jacobian_after_steps = 50;
+  o->threshold_to_update_jacobian = 0.3;
+  o->threshold_to_update_rhs_jacobian = 0.2;
+  o->pi_control_proportional = 0.0;
+  o->pi_control_integral = 0.5;
+  o->max_steps = 10000000;
+}
+
+int dsh_model_has_adaptive(int model, int64_t size) {
+  bool ok = false;
+  dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+    ok = !Mdl::HAS_MASS && Mdl::NROOTS == 0 && Mdl::N <= 4;
+  });
+  return ok ? 1 : 0;
+}
+
+int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                           double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
+                           int64_t* totals_host) {
+  DSH_REQUIRE(ctx != nullptr, "ctx is null");
+  DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
+  DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
+  for (int64_t k = 0; k + 1 < n_eval; ++k) DSH_REQUIRE(t_eval_host[k] <= t_eval_host[k + 1], "t_eval must be increasing (InvalidTEval)");
+  DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
+  if (!dsh_model_has_adaptive(model, size)) { set_error("dsh_bdf_solve_adaptive: model has no device-resident adaptive kernel (needs a static ODE model, n <= 4, no roots)"); return DSH_E_UNSUPPORTED; }
+  if (nb == 0) return DSH_OK;
+  AdaptiveConsts C;
+  C.rtol = rtol; C.t0 = t0; C.h0 = h0; C.n_eval = (int)n_eval;
+  if (opts) C.o = *opts; else dsh_adaptive_default_options(&C.o);
+  if (C.o.max_steps <= 0) C.o.max_steps = 10000000;
+  {  // Bdf::_new tables (bdf.rs:286-306)
+    const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
+    C.alpha[0] = 0.0; C.gamma[0] = 0.0; C.ec2[0] = 1.0;
+    for (int i = 1; i <= kMaxOrder; ++i) {
+      const double i_t = (double)i, one_over_i = 1.0 / i_t, one_over_i_plus_one = 1.0 / (i_t + 1.0);
+      C.gamma[i] = C.gamma[i - 1] + one_over_i;
+      C.alpha[i] = 1.0 / ((1.0 - kappa[i]) * C.gamma[i]);
+      const double e = kappa[i] * C.gamma[i] + one_over_i_plus_one;
+      C.ec2[i] = e * e;
+    }
+    C.eta_reset = std::pow(20.0, 1.25);
+    C.eta_reset_ts = std::pow(100.0, 1.25);
+    for (int ord = 1; ord <= kMaxOrder; ++ord) {  // compute_r(order, 1.0) (bdf.rs:433-463), stored 6x6 column-major
+      double* U = C.u[ord - 1];
+      for (int k = 0; k < 36; ++k) U[k] = 0.0;
+      for (int j = 0; j <= ord; ++j) U[j * 6 + 0] = 1.0;
+      for (int j = 1; j <= ord; ++j)
+        for (int i = 1; i <= ord; ++i) U[j * 6 + i] = U[j * 6 + i - 1] * ((double)i - 1.0 - 1.0 * (double)j) / (double)i;
+    }
+  }
+  double* t_eval_dev = nullptr;
+  unsigned long long* totals_dev = nullptr;
+  AdaptiveConsts* consts_dev = nullptr;
+  int rc = dsh_malloc(ctx, (int64_t)sizeof(AdaptiveConsts), 0, (void**)&consts_dev);
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipMemcpyAsync(consts_dev, &C, sizeof(AdaptiveConsts), hipMemcpyHostToDevice, ctx->stream));
+  rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * n_eval), 0, (void**)&t_eval_dev);
+  if (rc != DSH_OK) return rc;
+  rc = dsh_malloc(ctx, (int64_t)(sizeof(unsigned long long) * 8), 1, (void**)&totals_dev);
+  if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); return rc; }
+  DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
+  const bool ba = atol_nb == 1 && nb != 1;
+  const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
+  bool launched = dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+    if constexpr (!Mdl::HAS_MASS && Mdl::NROOTS == 0 && Mdl::N <= 4) {
+      if (ba) hipLaunchKernelGGL((k_bdf_adaptive<Mdl, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev);
+      else hipLaunchKernelGGL((k_bdf_adaptive<Mdl, false>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev);
+    }
+  });
+  (void)launched;
+  DSH_HIP_CHECK(hipGetLastError());
+  unsigned long long totals[8] = {0};
+  DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  dsh_free(ctx, t_eval_dev);
+  dsh_free(ctx, totals_dev);
+  dsh_free(ctx, consts_dev);
+  if (totals_host) for (int k = 0; k < 6; ++k) totals_host[k] = (int64_t)totals[k];
+  return DSH_OK;
+}
+
+}  // extern "C"

@@ -243,4 +243,53 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
   });
 }
 
+// Per-member adaptive BDF, whole solve in one device launch (dsh_bdf_solve_adaptive); the problem (model, parameters, tolerances, options,
+// t0, h0) is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int32_t* stats_host, int32_t* status_host,
+                              int64_t* totals) {
+  return guarded([&]() {
+    int model = 0;
+    int64_t size = 0;
+    if (s->method != DSHS_METHOD_BDF || !s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_adaptive(model, size))
+      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: needs the BDF method and a static ODE model (n <= 4, no mass, no roots)");
+    const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
+    const OdeSolverOptions& oo = s->problem.ode_options;
+    dsh_adaptive_options o;
+    dsh_adaptive_default_options(&o);
+    o.max_nonlinear_solver_iterations = oo.max_nonlinear_solver_iterations;
+    o.max_error_test_failures = oo.max_error_test_failures;
+    o.max_nonlinear_solver_failures = oo.max_nonlinear_solver_failures;
+    o.nonlinear_solver_tolerance = oo.nonlinear_solver_tolerance;
+    o.min_timestep = oo.min_timestep;
+    o.max_timestep_growth = oo.max_timestep_growth.value_or(2.0);
+    o.min_timestep_growth = oo.min_timestep_growth.value_or(2.0);
+    o.max_timestep_shrink = oo.max_timestep_shrink.value_or(0.9);
+    o.min_timestep_shrink = oo.min_timestep_shrink.value_or(0.5);
+    o.update_jacobian_after_steps = oo.update_jacobian_after_steps;
+    o.update_rhs_jacobian_after_steps = oo.update_rhs_jacobian_after_steps;
+    o.threshold_to_update_jacobian = oo.threshold_to_update_jacobian;
+    o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
+    o.pi_control_proportional = oo.pi_control_proportional;
+    o.pi_control_integral = oo.pi_control_integral;
+    dsh_ctx* c = s->ctx.raw();
+    double* out = y_dev;
+    void* tmp_out = nullptr;
+    if (!out) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &tmp_out), "adaptive out"); out = (double*)tmp_out; }
+    void *stats_dev = nullptr, *status_dev = nullptr;
+    if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
+    if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
+    int rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                    t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, totals);
+    if (rc == DSH_OK && y_host)
+      for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
+    if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
+    if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
+    if (tmp_out) dsh_free(c, tmp_out);
+    if (stats_dev) dsh_free(c, stats_dev);
+    if (status_dev) dsh_free(c, status_dev);
+    check(rc, "solve_dense_adaptive");
+    return 0;
+  });
+}
+
 }  // extern "C"

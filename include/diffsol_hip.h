@@ -252,6 +252,29 @@ int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order
                               double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
                               double* psi_neg_y0_next, int64_t* ticket);
 
+/* ---- device-resident per-member adaptive BDF: the whole ensemble solve in ONE launch, one lane per member, each with its own
+ * step-size / order history — the semantics of diffsol's CPU path for a parameter sweep (one independent IVP per member), i.e. of
+ * Bdf::step (ode_solver/bdf.rs:1277-1589) + NewtonNonlinearSolver (diffsol-nl/src/newton.rs) + solve_dense (method.rs:467-520) per member.
+ * Static ODE models with n <= 4, no mass matrix, no roots (dsh_model_has_adaptive). */
+typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) + BdfConfig (config.rs:53-74) */
+  int max_nonlinear_solver_iterations, max_error_test_failures, max_nonlinear_solver_failures;
+  double nonlinear_solver_tolerance, min_timestep;
+  double max_timestep_growth, min_timestep_growth, max_timestep_shrink, min_timestep_shrink;
+  int update_jacobian_after_steps, update_rhs_jacobian_after_steps;
+  double threshold_to_update_jacobian, threshold_to_update_rhs_jacobian;
+  double pi_control_proportional, pi_control_integral;
+  int64_t max_steps; /* per-member guard against a runaway loop (status 99) */
+} dsh_adaptive_options;
+void dsh_adaptive_default_options(dsh_adaptive_options* opts);
+int dsh_model_has_adaptive(int model, int64_t size);
+/* p: np x nb (batch-fastest, device); atol: n (atol_nb == 1) or n x nb; t_eval_host: n_eval increasing times, the last one is the stop time;
+ * y_out: n_eval x n x nb (device, batch-fastest per save point); stats: 5 x nb int32 (steps, Newton iterations, LU setups, error-test failures,
+ * Newton failures) or NULL; status: nb int32 (0 ok, else the OdeSolverError ordinal, 99 = max_steps) or NULL;
+ * totals_host[6]: the five counters summed over members + number of failed members.  Blocking. */
+int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                           double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                           int32_t* status, int64_t* totals_host);
+
 #ifdef __cplusplus
 }
 #endif

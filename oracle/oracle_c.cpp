@@ -190,6 +190,50 @@ double orc_solve_ensemble_independent(int model_id, int model_size, int nsys, co
   return secs;
 }
 
+// OdeSolverMethod::solve_dense (method.rs:467-520) for every member as its own IVP (nbatch = 1): interpolated output at t_eval, the last
+// t_eval is the stop time.  y_out: [nsys][nt][n]; stats_out: [nsys][5] = steps, Newton iterations, LU setups, error-test failures, Newton
+// failures (all may be null).  Returns the number of members that failed.
+int orc_solve_dense_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
+                                double h0, int method, const double* t_eval, int nt, int nthreads, double* y_out, long* stats_out) {
+  std::atomic<int> failed{0};
+  auto work = [&](int tid) {
+    for (int s = tid; s < nsys; s += nthreads) {
+      try {
+        auto h = make_handle(model_id, model_size, 1, p + (size_t)s * np, np, rtol, atol, natol, t0, h0, method);
+        if (h->init_error != 0) { failed++; continue; }
+        const int n = h->problem.n();
+        SolverBase& sv = *h->solver;
+        if (sv.set_stop_time(t_eval[nt - 1]) != OdeErr::Ok) { failed++; continue; }
+        int col = 0;
+        V tmp(n, 1);
+        bool ok = true;
+        while (true) {
+          StopReason r;
+          if (sv.step(r) != OdeErr::Ok) { ok = false; break; }
+          while (col < nt && t_eval[col] <= sv.t()) {
+            (void)sv.interpolate_inplace(t_eval[col], tmp);
+            if (y_out) std::memcpy(y_out + ((size_t)s * nt + col) * n, tmp.d.data(), sizeof(double) * n);
+            col++;
+          }
+          if (r == StopReason::TstopReached) break;
+          if (r == StopReason::RootFound) break;
+        }
+        if (!ok) failed++;
+        if (stats_out) {
+          const Stats& st = sv.stats();
+          long* o = stats_out + (size_t)s * 5;
+          o[0] = st.number_of_steps; o[1] = st.number_of_nonlinear_solver_iterations; o[2] = st.number_of_linear_solver_setups;
+          o[3] = st.number_of_error_test_failures; o[4] = st.number_of_nonlinear_solver_fails;
+        }
+      } catch (...) { failed++; }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
+  for (auto& t : th) t.join();
+  return failed;
+}
+
 // --- small KAT entry points for the LA / NL restatement ---
 void orc_compute_r(int order, double factor, double* out) {
   M r = Bdf::compute_r(order, factor);

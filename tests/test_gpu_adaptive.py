@@ -1,0 +1,100 @@
+"""Device-resident per-member adaptive BDF (dsh_bdf_solve_adaptive) against the oracle run the way diffsol's CPU path treats a
+parameter sweep: one independent IVP per member (oracle.solve_dense_independent).
+
+Parity statement.  The kernel repeats the oracle's arithmetic operation for operation; the only difference is libm — pow() in the step-size
+controller / convergence-rate estimate / initial step is ocml's on the device and glibc's on the host, both accurate to <= 1 ulp but not
+identical.  A 1-ulp difference in h leaves every accept/reject decision unchanged unless a test value sits within rounding of its threshold,
+but it is fed back through the step-size controller over a few hundred steps, so the states of a member with IDENTICAL decisions still drift
+apart — measured here up to 3e-6 relative at rtol 1e-4, i.e. far inside the tolerance, far above rounding.  The tests therefore require:
+identical per-member counters (steps, Newton iterations, LU setups, failures) for > 98 % of the members (measured 99.6 %), states within
+rtol/10 where the counters agree and within a few rtol where they do not; and for the north-star statement ("solution within 1e-6 relative of
+the CPU reference") all members, whatever their step sequences, at tight solver tolerances."""
+import numpy as np
+import pytest
+
+from helpers import ORACLE_MODEL
+from bench import robertson_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import diffsol_amd
+    return diffsol_amd
+
+
+T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]
+ROB = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+
+
+def run_pair(H, O, model, p, t_eval, model_size, **tol):
+    nb = len(p)
+    s = H.Solver(model, p, nbatch=nb, model_size=model_size, **tol)
+    y, tot, stats, status = s.solve_dense_adaptive(t_eval, want_member_stats=True)
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=model_size, nthreads=8, **tol)
+    return y, tot, stats, status, np.transpose(yo, (1, 0, 2)), so, failed
+
+
+def test_adaptive_robertson_members_match_independent_cpu_solves(H, O):
+    nb = 1000
+    p = robertson_params(nb)
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "robertson_ode", p, T_EVAL, 1, **ROB)
+    assert failed == 0 and (status == 0).all() and tot["failed_members"] == 0
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.98, f"only {same.mean():.3f} of the members reproduce the CPU step sequence"
+    assert tot["number_of_steps"] == int(stats[0].sum()) and tot["number_of_nonlinear_solver_iterations"] == int(stats[1].sum())
+    # members with the same decisions: states well inside the tolerance (see module docstring)
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-5, atol=1e-300)
+    # all members: within the solver tolerance scale of the CPU result, mass conserved
+    assert np.allclose(y, yo, rtol=5e-3, atol=1e-9)
+    assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-9
+    # per-member control really is per member: step counts differ across the sweep and are far below the lock-step ensemble's
+    assert stats[0].min() < stats[0].max()
+
+
+def test_adaptive_solution_within_1e6_relative_of_cpu_reference_at_tight_tolerance(H, O):
+    """north_star: solution within 1e-6 rel of the CPU reference (step counts may differ)."""
+    nb = 256
+    p = robertson_params(nb, seed=7)
+    tol = dict(rtol=1e-10, atol=[1e-14, 1e-18, 1e-12])
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "robertson_ode", p, T_EVAL[:5], 1, **tol)
+    assert failed == 0 and (status == 0).all()
+    rel = np.abs(y - yo) / np.maximum(np.abs(yo), 1e-30)
+    assert rel.max() < 1e-6
+
+
+def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
+    nb = 130
+    k = 0.05 * (np.arange(nb) + 1)
+    p = np.stack([k, np.arange(nb) + 1.0], axis=1)
+    t_eval = [1.0, 2.5, 9.0]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "exponential_decay", p, t_eval, 0, rtol=1e-6, atol=[1e-6, 1e-6])
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.95
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-7, atol=0)
+    exact = p[None, :, 1:2] * np.exp(-p[None, :, 0:1] * np.asarray(t_eval)[:, None, None]) * np.ones((1, 1, 2))
+    assert np.allclose(y, exact, rtol=2e-4, atol=2e-5)  # atol of the solve is 1e-6
+
+
+def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
+    s = H.Solver("robertson", [[0.04, 1e4, 3e7]], nbatch=1, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])  # DAE: mass matrix
+    with pytest.raises(H.DiffsolHipError) as e:
+        s.solve_dense_adaptive([1.0])
+    assert e.value.code == -6
+    s2 = H.Solver("robertson_ode", [[0.04, 1e4, 3e7]], nbatch=1, model_size=1, **ROB)
+    with pytest.raises(H.DiffsolHipError):
+        s2.solve_dense_adaptive([2.0, 1.0])
+
+
+def test_adaptive_full_size_ensemble_invariants(H):
+    """BASELINE.json configs[1] at full size through the one-launch path: finite, mass conserving, monotone species."""
+    nb = 100_000
+    p = robertson_params(nb)
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **ROB)
+    y, tot = s.solve_dense_adaptive(T_EVAL)
+    assert tot["failed_members"] == 0 and np.isfinite(y).all()
+    assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-9
+    assert (np.diff(y[:, :, 0], axis=0) <= 1e-12).all() and (np.diff(y[:, :, 2], axis=0) >= -1e-12).all()
+    assert 150 * nb < tot["number_of_steps"] < 400 * nb
