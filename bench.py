@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--nb", type=int, default=NB_PER_GPU)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the Newton kernel with HIP events (measures their overhead)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-adaptive", action="store_true", help="skip the extra pass through the per-member adaptive kernel")
+    ap.add_argument("--no-adaptive", action="store_true", help="skip the extra passes through the device-resident kernel")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     args = ap.parse_args()
 
@@ -134,16 +134,16 @@ def main():
         bracket_ms, clock_ms = solver.kernel_timing_overhead_ms()
         solver.set_kernel_timing(False)
 
-    # Third pass (not `value`): the same K solves through the device-resident per-member adaptive kernel — one launch per
-    # ensemble solve, every member its own step-size/order history like on diffsol's CPU path.
-    adaptive = None
-    if not args.no_adaptive:
-        solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
+    # Extra passes (not `value`): the same K solves through the device-resident kernel — one launch per ensemble solve, no host
+    # in the loop — in both control granularities: every member its own step-size/order history (diffsol's CPU semantics for a sweep), and
+    # wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64 per group).
+    def device_resident_pass(group):
+        solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr(), group=group)
         barrier()
         t2 = time.perf_counter()
         a_steps = a_newton = 0
         for _ in range(args.steps):
-            _, tot = solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
+            _, tot = solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr(), group=group)
             if world > 1:
                 gather_batch_axis(out, n_total, rank, world)
             a_steps += tot["number_of_steps"]
@@ -157,10 +157,14 @@ def main():
             dist.all_reduce(a, op=dist.ReduceOp.SUM)
             a[0] = amax[0]
         a_el, a_st, a_nw, a_failed = (float(v) for v in a.tolist())
-        adaptive = {"ms_per_step": 1e3 * a_el / args.steps, "ode_steps_per_sec": a_st / a_el, "newton_solves_per_sec": a_nw / a_el,
-                    "mean_steps_per_member": a_st / args.steps / n_total, "failed_members": int(a_failed),
-                    "note": "dsh_bdf_solve_adaptive: one kernel launch per ensemble solve, per-member step/order control (the CPU path's semantics); "
-                            "same job as `value` (same members, tolerances, save points), fewer steps per member because no member waits for the stiffest one"}
+        return {"ms_per_step": 1e3 * a_el / args.steps, "ode_steps_per_sec": a_st / a_el, "newton_solves_per_sec": a_nw / a_el,
+                "mean_steps_per_member": a_st / args.steps / n_total, "failed_members": int(a_failed)}
+
+    adaptive = None
+    if not args.no_adaptive:
+        adaptive = {"note": "dsh_bdf_solve_adaptive: one kernel launch per ensemble solve, solver state in registers/LDS, no host round trips; same job as "
+                            "`value` (same members, tolerances, save points)",
+                    "per_member": device_resident_pass(1), "wavefront_lockstep_64": device_resident_pass(64)}
 
     # whole-job aggregates: max time over ranks, units summed over ranks
     agg = torch.tensor([elapsed, (hi - lo) * steps, (hi - lo) * newton, (hi - lo) * setups], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -218,7 +222,7 @@ def main():
                                "events_pass_ms_per_step": 1e3 * events_elapsed / args.steps}
         else:
             rec["roofline"] = None
-        rec["adaptive_per_member"] = adaptive
+        rec["device_resident"] = adaptive
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(params, min(args.cpu_sample, n_total))
         print(json.dumps(rec))

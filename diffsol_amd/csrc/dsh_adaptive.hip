@@ -17,6 +17,11 @@
 // in the step-size controller, the convergence-rate estimate and the initial step is ocml's here — results agree with independent CPU solves
 // to rounding of h, not bitwise (tests/test_gpu_adaptive.py states the tolerance).
 //
+// Two control granularities (dsh_adaptive_options.group):
+//   1  : every member its own (t, h, order) history — diffsol's CPU semantics for a sweep of independent IVPs; wavefronts diverge.
+//   64 : the 64 members of a wavefront advance in lock-step, norms reduced with a max over the wavefront — the reference's batched semantics
+//        (nbatch = 64) per group; no divergence at all, every control scalar is wavefront-uniform, no host round trip.
+//
 // Scope this round: static register models (n <= 4) without mass matrix and without root functions (Robertson ODE, exponential decay).
 #include <cmath>
 #include <cstdio>
@@ -85,7 +90,20 @@ __device__ __forceinline__ double pi_controller_raw(double error_norm, bool has_
   return pow(error_norm, -ki);
 }
 
-template <class Mdl, bool BA>
+// Group reduction of a mean-square norm: the member's own value (per-member control) or the max over the 64 members of the wavefront
+// (wavefront lock-step: Vector::squared_norm's max over the batch, vector/cuda.rs:1421-1432, for a batch of 64; NaN wins like in the oracle).
+template <bool WAVE>
+__device__ __forceinline__ double group_norm(double v) {
+  if constexpr (WAVE) return __longlong_as_double((long long)wave_max_u64(d2u(v)));
+  else return v;
+}
+template <bool WAVE>
+__device__ __forceinline__ bool group_all(bool ok) {
+  if constexpr (WAVE) return __all(ok);
+  else return ok;
+}
+
+template <class Mdl, bool BA, bool WAVE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, unsigned long long* __restrict__ totals) {
@@ -93,8 +111,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   static_assert(!Mdl::HAS_MASS && Mdl::NROOTS == 0, "adaptive kernel: ODE models without roots only");
   const AdaptiveConsts& C = *Cp;
   const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = bglobal < nb;  // lanes past the ensemble shadow member 0 (no stores) so that the whole wavefront reaches the final reduction
-  const int64_t b = active ? bglobal : 0;
+  const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
+  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
   const dsh_adaptive_options& o = C.o;
   const double rtol = C.rtol;
   double p[NP], atol[N];
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   Mdl::rhs(t, y, p, f0);
   {  // set_step_size (state.rs:1209-1277), solver_order = 1
     const bool is_neg_h = C.h0 < 0.0;
-    const double d0 = sqrt(wms<N>(y, y, atol, rtol)), d1 = sqrt(wms<N>(f0, y, atol, rtol));
+    const double d0 = sqrt(group_norm<WAVE>(wms<N>(y, y, atol, rtol))), d1 = sqrt(group_norm<WAVE>(wms<N>(f0, y, atol, rtol)));
     const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
     const double hh = is_neg_h ? -h0 : h0;
     double y1[N], f1[N], df[N];
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     Mdl::rhs(is_neg_h ? t - h0 : t + h0, y1, p, f1);
 #pragma unroll
     for (int i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
-    const double d2 = sqrt(wms<N>(df, y, atol, rtol)) / fabs(h0);
+    const double d2 = sqrt(group_norm<WAVE>(wms<N>(df, y, atol, rtol))) / fabs(h0);
     double max_d = d2;
     if (max_d < d1) max_d = d1;
     double h1;
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 
   long guard = 0;
-  bool done = status != kOk || !active;
+  bool done = status != kOk || (!WAVE && !active);  // wavefront lock-step: shadow lanes run along (their reductions must not be masked off)
   while (!done) {
     if (++guard > o.max_steps) { status = kMaxStepsExceeded; break; }
     // ================================================================ Bdf::step (bdf.rs:1277-1589)
@@ -317,11 +335,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         Mdl::rhs(t_predict, x, p, f);
 #pragma unroll
         for (int i = 0; i < N; ++i) { const double tmp = x[i] + psi[i]; delta[i] = 1.0 * tmp + (-opc) * f[i]; }  // F(y) = (y - y0 + psi) - c f(y)
-        const bool lu_ok = lu_solve_reg<N>(A, P, delta);
+        const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
         if (!lu_ok) break;  // LuSolveFailed
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
-        const double norm = sqrt(wms<N>(delta, yp, atol, rtol));
+        const double norm = sqrt(group_norm<WAVE>(wms<N>(delta, yp, atol, rtol)));
         // Convergence::check_new_iteration (convergence.rs:68-139)
         niter += 1;
         bool diverged = false;
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
       // error_control (bdf.rs:812-843): norm against the CURRENT state y
-      error_norm = fmax(0.0, wms<N>(ydelta, y, atol, rtol) * C.ec2[order - 1]);
+      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * C.ec2[order - 1]);
       const double maxiter = (double)o.max_nonlinear_solver_iterations;
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
@@ -408,8 +426,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         col_m[i] = vm; col_p[i] = vp;
       }
       const double inf = __builtin_huge_val();
-      const double error_m_norm = order > 1 ? wms<N>(col_m, y, atol, rtol) * C.ec2[order - 1] : inf;
-      const double error_p_norm = order < kMaxOrder ? wms<N>(col_p, y, atol, rtol) * C.ec2[order + 1] : inf;
+      const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * C.ec2[order - 1] : inf;
+      const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * C.ec2[order + 1] : inf;
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
       const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order);
       const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1);
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
 #pragma unroll
-      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+      for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
       col++;
     }
     if (reason == 1) done = true;
@@ -501,6 +519,7 @@ void dsh_adaptive_default_options(dsh_adaptive_options* o) {
   o->pi_control_proportional = 0.0;
   o->pi_control_integral = 0.5;
   o->max_steps = 10000000;
+  o->group = 1;
 }
 
 int dsh_model_has_adaptive(int model, int64_t size) {
@@ -526,6 +545,7 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   C.rtol = rtol; C.t0 = t0; C.h0 = h0; C.n_eval = (int)n_eval;
   if (opts) C.o = *opts; else dsh_adaptive_default_options(&C.o);
   if (C.o.max_steps <= 0) C.o.max_steps = 10000000;
+  DSH_REQUIRE(C.o.group == 1 || C.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
   {  // Bdf::_new tables (bdf.rs:286-306)
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
     C.alpha[0] = 0.0; C.gamma[0] = 0.0; C.ec2[0] = 1.0;
@@ -562,8 +582,11 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   bool launched = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     if constexpr (!Mdl::HAS_MASS && Mdl::NROOTS == 0 && Mdl::N <= 4) {
-      if (ba) hipLaunchKernelGGL((k_bdf_adaptive<Mdl, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev);
-      else hipLaunchKernelGGL((k_bdf_adaptive<Mdl, false>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev);
+#define DSH_ADAPTIVE_LAUNCH(BA, WAVE) \
+  hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev)
+      if (C.o.group == 64) { if (ba) DSH_ADAPTIVE_LAUNCH(true, true); else DSH_ADAPTIVE_LAUNCH(false, true); }
+      else { if (ba) DSH_ADAPTIVE_LAUNCH(true, false); else DSH_ADAPTIVE_LAUNCH(false, false); }
+#undef DSH_ADAPTIVE_LAUNCH
     }
   });
   (void)launched;

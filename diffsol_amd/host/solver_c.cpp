@@ -245,8 +245,8 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
 
 // Per-member adaptive BDF, whole solve in one device launch (dsh_bdf_solve_adaptive); the problem (model, parameters, tolerances, options,
 // t0, h0) is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
-int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int32_t* stats_host, int32_t* status_host,
-                              int64_t* totals) {
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group, double* y_host, double* y_dev, int32_t* stats_host,
+                              int32_t* status_host, int64_t* totals) {
   return guarded([&]() {
     int model = 0;
     int64_t size = 0;
@@ -271,6 +271,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
     o.pi_control_proportional = oo.pi_control_proportional;
     o.pi_control_integral = oo.pi_control_integral;
+    o.group = group;
     dsh_ctx* c = s->ctx.raw();
     double* out = y_dev;
     void* tmp_out = nullptr;

@@ -143,15 +143,16 @@ class Solver:
     ADAPTIVE_TOTALS = ["number_of_steps", "number_of_nonlinear_solver_iterations", "number_of_linear_solver_setups", "number_of_error_test_failures",
                        "number_of_nonlinear_solver_fails", "failed_members"]
 
-    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False):
-        """solve_dense with per-member step-size/order control, the whole ensemble in ONE device launch (dshs_solve_dense_adaptive).
+    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1):
+        """solve_dense with device-resident step-size/order control, the whole ensemble in ONE launch (dshs_solve_dense_adaptive):
+        group=1 every member its own history (CPU semantics of a sweep), group=64 wavefront-sized lock-step groups (batched semantics, nbatch 64).
         Returns (y [nt, nbatch, n] or None, totals dict[, stats [5, nbatch], status [nbatch]])."""
         te = np.ascontiguousarray(t_eval, dtype=np.float64)
         out = np.empty((te.size, self.nbatch, self.n)) if want_host else None
         totals = (C.c_int64 * 6)()
         stats = np.empty((5, self.nbatch), dtype=np.int32) if want_member_stats else None
         status = np.empty(self.nbatch, dtype=np.int32) if want_member_stats else None
-        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, out.ctypes.data_as(_ffi.c_dp) if want_host else None,
+        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), out.ctypes.data_as(_ffi.c_dp) if want_host else None,
                                                 vp(dev_ptr) if dev_ptr else None, stats.ctypes.data_as(_ffi.c_i32p) if want_member_stats else None,
                                                 status.ctypes.data_as(_ffi.c_i32p) if want_member_stats else None, totals), host=True)
         tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))

@@ -264,6 +264,8 @@ typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) +
   double threshold_to_update_jacobian, threshold_to_update_rhs_jacobian;
   double pi_control_proportional, pi_control_integral;
   int64_t max_steps; /* per-member guard against a runaway loop (status 99) */
+  int group;         /* control granularity: 1 = every member its own step/order history; 64 = the 64 members of a wavefront in lock-step
+                        (the reference's batched semantics with nbatch = 64 per group, max-norms over the wavefront) */
 } dsh_adaptive_options;
 void dsh_adaptive_default_options(dsh_adaptive_options* opts);
 int dsh_model_has_adaptive(int model, int64_t size);

@@ -89,8 +89,8 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
  * every member is integrated as the independent IVP it is on diffsol's CPU path.  BDF + static ODE models (dsh_model_has_adaptive) only.
  * stats_host: [5][b] int32 (steps, Newton iterations, LU setups, error-test failures, Newton failures) or NULL; status_host: [b] or NULL;
  * totals[6]: counters summed over members + number of failed members. */
-int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int32_t* stats_host, int32_t* status_host,
-                              int64_t* totals);
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64, see dsh_adaptive_options.group */, double* y_host,
+                              double* y_dev, int32_t* stats_host, int32_t* status_host, int64_t* totals);
 
 #ifdef __cplusplus
 }

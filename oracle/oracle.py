@@ -198,8 +198,8 @@ def solve_ensemble_independent(model, p, *, model_size=0, rtol=1e-6, atol=(1e-6,
                 failed=int(counters[3]), y=y)
 
 
-def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1):
-    """solve_dense per member (each its own IVP).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""
+def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1, group=1):
+    """solve_dense per member (each its own IVP; group > 1: consecutive groups of `group` members as one lock-step batched problem each).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""
     p = np.ascontiguousarray(p, dtype=np.float64)
     nsys, np_ = p.shape
     a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
@@ -212,7 +212,7 @@ def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(
     f = lib().orc_solve_dense_independent
     f.restype = C.c_int
     failed = f(C.c_int(model), C.c_int(model_size), C.c_int(nsys), p.ctypes.data_as(_dp), C.c_int(np_), C.c_double(rtol), a_ptr, C.c_int(a_arr.size),
-               C.c_double(t0), C.c_double(h0), C.c_int(method), te_ptr, C.c_int(te.size), C.c_int(nthreads), y.ctypes.data_as(_dp),
+               C.c_double(t0), C.c_double(h0), C.c_int(method), te_ptr, C.c_int(te.size), C.c_int(nthreads), C.c_int(group), y.ctypes.data_as(_dp),
                stats.ctypes.data_as(C.POINTER(C.c_long)))
     return y, stats, int(failed)
 

@@ -194,38 +194,46 @@ double orc_solve_ensemble_independent(int model_id, int model_size, int nsys, co
 // t_eval is the stop time.  y_out: [nsys][nt][n]; stats_out: [nsys][5] = steps, Newton iterations, LU setups, error-test failures, Newton
 // failures (all may be null).  Returns the number of members that failed.
 int orc_solve_dense_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
-                                double h0, int method, const double* t_eval, int nt, int nthreads, double* y_out, long* stats_out) {
+                                double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out) {
+  // group = 1: every member its own IVP.  group = G > 1: consecutive groups of G members (the last one may be smaller) solved as one
+  // lock-step batched problem each (the reference's batched semantics with nbatch = G); stats are the group's, repeated per member.
   std::atomic<int> failed{0};
+  if (group < 1) group = 1;
+  const int ngroups = (nsys + group - 1) / group;
   auto work = [&](int tid) {
-    for (int s = tid; s < nsys; s += nthreads) {
+    for (int g = tid; g < ngroups; g += nthreads) {
+      const int s0 = g * group, cnt = std::min(group, nsys - s0);
       try {
-        auto h = make_handle(model_id, model_size, 1, p + (size_t)s * np, np, rtol, atol, natol, t0, h0, method);
-        if (h->init_error != 0) { failed++; continue; }
+        auto h = make_handle(model_id, model_size, cnt, p + (size_t)s0 * np, np * cnt, rtol, atol, natol, t0, h0, method);
+        if (h->init_error != 0) { failed += cnt; continue; }
         const int n = h->problem.n();
         SolverBase& sv = *h->solver;
-        if (sv.set_stop_time(t_eval[nt - 1]) != OdeErr::Ok) { failed++; continue; }
+        if (sv.set_stop_time(t_eval[nt - 1]) != OdeErr::Ok) { failed += cnt; continue; }
         int col = 0;
-        V tmp(n, 1);
+        V tmp(n, cnt);
         bool ok = true;
         while (true) {
           StopReason r;
           if (sv.step(r) != OdeErr::Ok) { ok = false; break; }
           while (col < nt && t_eval[col] <= sv.t()) {
             (void)sv.interpolate_inplace(t_eval[col], tmp);
-            if (y_out) std::memcpy(y_out + ((size_t)s * nt + col) * n, tmp.d.data(), sizeof(double) * n);
+            if (y_out)
+              for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
             col++;
           }
           if (r == StopReason::TstopReached) break;
           if (r == StopReason::RootFound) break;
         }
-        if (!ok) failed++;
+        if (!ok) failed += cnt;
         if (stats_out) {
           const Stats& st = sv.stats();
-          long* o = stats_out + (size_t)s * 5;
-          o[0] = st.number_of_steps; o[1] = st.number_of_nonlinear_solver_iterations; o[2] = st.number_of_linear_solver_setups;
-          o[3] = st.number_of_error_test_failures; o[4] = st.number_of_nonlinear_solver_fails;
+          for (int b = 0; b < cnt; ++b) {
+            long* o = stats_out + (size_t)(s0 + b) * 5;
+            o[0] = st.number_of_steps; o[1] = st.number_of_nonlinear_solver_iterations; o[2] = st.number_of_linear_solver_setups;
+            o[3] = st.number_of_error_test_failures; o[4] = st.number_of_nonlinear_solver_fails;
+          }
         }
-      } catch (...) { failed++; }
+      } catch (...) { failed += cnt; }
     }
   };
   std::vector<std::thread> th;

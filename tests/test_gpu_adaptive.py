@@ -28,11 +28,11 @@ T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]
 ROB = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
 
 
-def run_pair(H, O, model, p, t_eval, model_size, **tol):
+def run_pair(H, O, model, p, t_eval, model_size, group=1, **tol):
     nb = len(p)
     s = H.Solver(model, p, nbatch=nb, model_size=model_size, **tol)
-    y, tot, stats, status = s.solve_dense_adaptive(t_eval, want_member_stats=True)
-    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=model_size, nthreads=8, **tol)
+    y, tot, stats, status = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=model_size, nthreads=8, group=group, **tol)
     return y, tot, stats, status, np.transpose(yo, (1, 0, 2)), so, failed
 
 
@@ -51,6 +51,23 @@ def test_adaptive_robertson_members_match_independent_cpu_solves(H, O):
     assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-9
     # per-member control really is per member: step counts differ across the sweep and are far below the lock-step ensemble's
     assert stats[0].min() < stats[0].max()
+
+
+def test_wavefront_lockstep_groups_match_the_batched_oracle_with_nbatch_64(H, O):
+    """group=64: each wavefront integrates its 64 members in lock-step (max-norms over the wavefront) — the reference's batched semantics with
+    nbatch = 64 per group, with no host in the loop.  Compared with the oracle's lock-step batched run of every group (the last group is ragged:
+    1000 = 15 x 64 + 40).  Same libm caveat as the per-member mode."""
+    nb = 1000
+    p = robertson_params(nb)
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "robertson_ode", p, T_EVAL, 1, group=64, **ROB)
+    assert failed == 0 and (status == 0).all() and tot["failed_members"] == 0
+    for g in range(0, nb, 64):  # counters are per group
+        assert (stats[:, g:g + 64] == stats[:, g:g + 1]).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9, f"only {same.mean():.3f} of the members sit in a group that reproduces the CPU step sequence"
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-5, atol=1e-300)
+    assert np.allclose(y, yo, rtol=5e-3, atol=1e-9)
+    assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-9
 
 
 def test_adaptive_solution_within_1e6_relative_of_cpu_reference_at_tight_tolerance(H, O):
