@@ -104,6 +104,8 @@ DEVICE_ABI = {
     "dsh_model_has_fused": (cint, [cint, i64]),
     "dsh_model_has_adaptive": (cint, [cint, i64]),
     "dsh_adaptive_default_options": (None, [vp]),
+    "dsh_model_has_resident": (cint, [cint, cint, i64]),
+    "dsh_sdirk_solve_resident": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, c_i64p]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
     "dsh_bdf_accept_step_async": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, c_i64p]),
@@ -144,7 +146,7 @@ HOST_ABI = {
     "dshs_solve": (cint, [vp, dbl, cint, c_dp, c_i64p, c_ip]),
     "dshs_trajectory": (cint, [vp, c_dp, c_dp]),
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
-    "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, c_dp, vp, c_i32p, c_i32p, c_i64p]),
+    "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
 }
 
 _dev = None

@@ -518,6 +518,12 @@ void dsh_adaptive_default_options(dsh_adaptive_options* o) {
   o->threshold_to_update_rhs_jacobian = 0.2;
   o->pi_control_proportional = 0.0;
   o->pi_control_integral = 0.5;
+  o->ic_use_linesearch = 1;
+  o->ic_max_linesearch_iterations = 10;
+  o->ic_max_linear_solver_setups = 4;
+  o->ic_max_newton_iterations = 10;
+  o->ic_step_reduction_factor = 0.5;
+  o->ic_armijo_constant = 1e-4;
   o->max_steps = 10000000;
   o->group = 1;
 }

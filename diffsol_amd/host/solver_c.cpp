@@ -1,5 +1,6 @@
 // C ABI (include/diffsol_hip_solver.h) over the host-side integrators.  Error convention mirrors crates/diffsol-c/src/error_c.rs:12-121
 // (thread-local last error).  No CPU fallback exists anywhere below: creating a solver without a HIP device fails.
+#include <cmath>
 #include "../../include/diffsol_hip_solver.h"
 
 #include <cstring>
@@ -243,17 +244,19 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
   });
 }
 
-// Per-member adaptive BDF, whole solve in one device launch (dsh_bdf_solve_adaptive); the problem (model, parameters, tolerances, options,
-// t0, h0) is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
+// Device-resident integration, whole ensemble solve in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident); the problem (model,
+// parameters, tolerances, options, t0, h0) is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
 int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group, double* y_host, double* y_dev, int32_t* stats_host,
-                              int32_t* status_host, int64_t* totals) {
+                              int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
   return guarded([&]() {
     int model = 0;
     int64_t size = 0;
-    if (s->method != DSHS_METHOD_BDF || !s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_adaptive(model, size))
-      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: needs the BDF method and a static ODE model (n <= 4, no mass, no roots)");
+    const int method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
+    if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size))
+      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models, n <= 4; BDF: ODE without roots)");
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
     const OdeSolverOptions& oo = s->problem.ode_options;
+    const InitialConditionSolverOptions& ic = s->problem.ic_options;
     dsh_adaptive_options o;
     dsh_adaptive_default_options(&o);
     o.max_nonlinear_solver_iterations = oo.max_nonlinear_solver_iterations;
@@ -261,6 +264,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     o.max_nonlinear_solver_failures = oo.max_nonlinear_solver_failures;
     o.nonlinear_solver_tolerance = oo.nonlinear_solver_tolerance;
     o.min_timestep = oo.min_timestep;
+    // BdfConfig / SdirkConfig defaults (config.rs:53-109) are identical
     o.max_timestep_growth = oo.max_timestep_growth.value_or(2.0);
     o.min_timestep_growth = oo.min_timestep_growth.value_or(2.0);
     o.max_timestep_shrink = oo.max_timestep_shrink.value_or(0.9);
@@ -271,23 +275,47 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
     o.pi_control_proportional = oo.pi_control_proportional;
     o.pi_control_integral = oo.pi_control_integral;
+    o.ic_use_linesearch = ic.use_linesearch ? 1 : 0;
+    o.ic_max_linesearch_iterations = ic.max_linesearch_iterations;
+    o.ic_max_linear_solver_setups = ic.max_linear_solver_setups;
+    o.ic_max_newton_iterations = ic.max_newton_iterations;
+    o.ic_step_reduction_factor = ic.step_reduction_factor;
+    o.ic_armijo_constant = ic.armijo_constant;
     o.group = group;
     dsh_ctx* c = s->ctx.raw();
     double* out = y_dev;
     void* tmp_out = nullptr;
     if (!out) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &tmp_out), "adaptive out"); out = (double*)tmp_out; }
-    void *stats_dev = nullptr, *status_dev = nullptr;
+    void *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
     if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
     if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
-    int rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
-                                    t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, totals);
+    if (method != 0) {
+      if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "adaptive t_root");
+      if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
+      if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
+    }
+    int rc;
+    if (method == 0)
+      rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                  t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, totals);
+    else
+      rc = dsh_sdirk_solve_resident(c, method, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0,
+                                    s->problem.h0, &o, t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
+                                    (int32_t*)ncols_dev, totals);
     if (rc == DSH_OK && y_host)
       for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
     if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
     if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
-    if (tmp_out) dsh_free(c, tmp_out);
-    if (stats_dev) dsh_free(c, stats_dev);
-    if (status_dev) dsh_free(c, status_dev);
+    if (method != 0) {
+      if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
+      if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
+      if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
+    } else {  // BDF kernel: no root functions
+      if (t_root_host) for (int64_t b = 0; b < nb; ++b) t_root_host[b] = std::nan("");
+      if (root_idx_host) for (int64_t b = 0; b < nb; ++b) root_idx_host[b] = -1;
+      if (ncols_host) for (int64_t b = 0; b < nb; ++b) ncols_host[b] = (int32_t)nt;
+    }
+    for (void* q : {tmp_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
     check(rc, "solve_dense_adaptive");
     return 0;
   });

@@ -145,18 +145,22 @@ class Solver:
 
     def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1):
         """solve_dense with device-resident step-size/order control, the whole ensemble in ONE launch (dshs_solve_dense_adaptive):
-        group=1 every member its own history (CPU semantics of a sweep), group=64 wavefront-sized lock-step groups (batched semantics, nbatch 64).
-        Returns (y [nt, nbatch, n] or None, totals dict[, stats [5, nbatch], status [nbatch]])."""
+        group=1 every member its own history and event time (CPU semantics of a sweep), group=64 wavefront-sized lock-step groups (batched
+        semantics, nbatch 64).  Returns (y [nt, nbatch, n] or None, totals dict[, member dict(stats [5, nbatch], status, t_root, root_idx, ncols)])."""
         te = np.ascontiguousarray(t_eval, dtype=np.float64)
         out = np.empty((te.size, self.nbatch, self.n)) if want_host else None
         totals = (C.c_int64 * 6)()
-        stats = np.empty((5, self.nbatch), dtype=np.int32) if want_member_stats else None
-        status = np.empty(self.nbatch, dtype=np.int32) if want_member_stats else None
+        m = None
+        if want_member_stats:
+            m = dict(stats=np.empty((5, self.nbatch), dtype=np.int32), status=np.empty(self.nbatch, dtype=np.int32), t_root=np.empty(self.nbatch),
+                     root_idx=np.empty(self.nbatch, dtype=np.int32), ncols=np.empty(self.nbatch, dtype=np.int32))
+        i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
         check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), out.ctypes.data_as(_ffi.c_dp) if want_host else None,
-                                                vp(dev_ptr) if dev_ptr else None, stats.ctypes.data_as(_ffi.c_i32p) if want_member_stats else None,
-                                                status.ctypes.data_as(_ffi.c_i32p) if want_member_stats else None, totals), host=True)
+                                                vp(dev_ptr) if dev_ptr else None, i32(m["stats"]) if m else None, i32(m["status"]) if m else None,
+                                                m["t_root"].ctypes.data_as(_ffi.c_dp) if m else None, i32(m["root_idx"]) if m else None,
+                                                i32(m["ncols"]) if m else None, totals), host=True)
         tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))
-        return (out, tot, stats, status) if want_member_stats else (out, tot)
+        return (out, tot, m) if want_member_stats else (out, tot)
 
 
 class OdeBuilder:

@@ -263,6 +263,9 @@ typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) +
   int update_jacobian_after_steps, update_rhs_jacobian_after_steps;
   double threshold_to_update_jacobian, threshold_to_update_rhs_jacobian;
   double pi_control_proportional, pi_control_integral;
+  /* InitialConditionSolverOptions (problem.rs:15-45): consistent initialisation of DAEs */
+  int ic_use_linesearch, ic_max_linesearch_iterations, ic_max_linear_solver_setups, ic_max_newton_iterations;
+  double ic_step_reduction_factor, ic_armijo_constant;
   int64_t max_steps; /* per-member guard against a runaway loop (status 99) */
   int group;         /* control granularity: 1 = every member its own step/order history; 64 = the 64 members of a wavefront in lock-step
                         (the reference's batched semantics with nbatch = 64 per group, max-norms over the wavefront) */
@@ -276,6 +279,16 @@ int dsh_model_has_adaptive(int model, int64_t size);
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                            int32_t* status, int64_t* totals_host);
+/* Device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): Sdirk::step (ode_solver/sdirk.rs:409-543) + Rk core (runge_kutta.rs) + consistent DAE initialisation
+ * (state.rs:84-162) + RootFinder (nonlinear_solver/root.rs) + solve_dense (method.rs:467-520) per member, one launch per ensemble solve.  Static models with
+ * n <= 4, mass matrices and root functions included (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds
+ * the state at the root (solve_dense's return), ncols[b] counts its valid columns, later columns are NaN.  t_root / root_idx / ncols (nb each) may be NULL.
+ * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
+int dsh_model_has_resident(int method, int model, int64_t size);
+int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                             double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                             int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
+
 
 #ifdef __cplusplus
 }

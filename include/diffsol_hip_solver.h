@@ -85,12 +85,15 @@ int dshs_trajectory(dshs_solver* s, double* t_host, double* y_host /* [col][b][s
 /* OdeSolverMethod::solve_dense (method.rs:467-520): interpolated output at t_eval.  y_host ([nt][b][state]) and/or y_dev (DEVICE pointer,
  * [nt][state][b] batch-fastest — the buffer the multi-GPU gather concatenates along the batch axis) may be NULL. */
 int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int* stop_reason);
-/* solve_dense with PER-MEMBER step-size / order control, the whole ensemble in one device launch (dsh_bdf_solve_adaptive):
- * every member is integrated as the independent IVP it is on diffsol's CPU path.  BDF + static ODE models (dsh_model_has_adaptive) only.
- * stats_host: [5][b] int32 (steps, Newton iterations, LU setups, error-test failures, Newton failures) or NULL; status_host: [b] or NULL;
- * totals[6]: counters summed over members + number of failed members. */
-int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64, see dsh_adaptive_options.group */, double* y_host,
-                              double* y_dev, int32_t* stats_host, int32_t* status_host, int64_t* totals);
+/* solve_dense entirely on the device, the whole ensemble in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident).
+ * group = 1: every member is integrated as the independent IVP it is on diffsol's CPU path, with its own step sizes, orders and EVENT TIMES;
+ * group = 64: wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64).  Static models with n <= 4; BDF: ODEs without
+ * roots; TR-BDF2 / ESDIRK34: also mass matrices and root functions.
+ * stats_host: [5][b] int32 (steps, Newton iterations, LU setups, error-test failures, Newton failures); status_host: [b] (0 ok, else OdeSolverError
+ * ordinal, 20 root batch mismatch, 99 runaway guard); t_root_host / root_idx_host / ncols_host: [b] root time (NaN if none), root index (-1),
+ * number of valid output columns; any of them may be NULL.  totals[6]: counters summed over members + number of failed members. */
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64 */, double* y_host, double* y_dev, int32_t* stats_host,
+                              int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals);
 
 #ifdef __cplusplus
 }

@@ -199,7 +199,8 @@ def solve_ensemble_independent(model, p, *, model_size=0, rtol=1e-6, atol=(1e-6,
 
 
 def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1, group=1):
-    """solve_dense per member (each its own IVP; group > 1: consecutive groups of `group` members as one lock-step batched problem each).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""
+    """solve_dense per member (each its own IVP; group > 1: consecutive groups of `group` members as one lock-step batched problem each); a member
+    that finds a root stops there (its next column is the state at the root, later columns NaN; see solve_dense_independent.last_roots).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""
     p = np.ascontiguousarray(p, dtype=np.float64)
     nsys, np_ = p.shape
     a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
@@ -209,11 +210,16 @@ def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(
     del s
     y = np.empty((nsys, te.size, n))
     stats = np.zeros((nsys, 5), dtype=np.int64)
+    root_t = np.full(nsys, np.nan)
+    root_idx = np.full(nsys, -1, dtype=np.int32)
+    ncols = np.zeros(nsys, dtype=np.int32)
     f = lib().orc_solve_dense_independent
     f.restype = C.c_int
     failed = f(C.c_int(model), C.c_int(model_size), C.c_int(nsys), p.ctypes.data_as(_dp), C.c_int(np_), C.c_double(rtol), a_ptr, C.c_int(a_arr.size),
                C.c_double(t0), C.c_double(h0), C.c_int(method), te_ptr, C.c_int(te.size), C.c_int(nthreads), C.c_int(group), y.ctypes.data_as(_dp),
-               stats.ctypes.data_as(C.POINTER(C.c_long)))
+               stats.ctypes.data_as(C.POINTER(C.c_long)), root_t.ctypes.data_as(_dp), root_idx.ctypes.data_as(C.POINTER(C.c_int)),
+               ncols.ctypes.data_as(C.POINTER(C.c_int)))
+    solve_dense_independent.last_roots = dict(t_root=root_t, root_idx=root_idx, ncols=ncols)
     return y, stats, int(failed)
 
 

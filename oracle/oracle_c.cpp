@@ -194,7 +194,8 @@ double orc_solve_ensemble_independent(int model_id, int model_size, int nsys, co
 // t_eval is the stop time.  y_out: [nsys][nt][n]; stats_out: [nsys][5] = steps, Newton iterations, LU setups, error-test failures, Newton
 // failures (all may be null).  Returns the number of members that failed.
 int orc_solve_dense_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
-                                double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out) {
+                                double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out,
+                                double* root_t_out, int* root_idx_out, int* ncols_out) {
   // group = 1: every member its own IVP.  group = G > 1: consecutive groups of G members (the last one may be smaller) solved as one
   // lock-step batched problem each (the reference's batched semantics with nbatch = G); stats are the group's, repeated per member.
   std::atomic<int> failed{0};
@@ -215,15 +216,37 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
         while (true) {
           StopReason r;
           if (sv.step(r) != OdeErr::Ok) { ok = false; break; }
-          while (col < nt && t_eval[col] <= sv.t()) {
+          while (r != StopReason::RootFound && col < nt && t_eval[col] <= sv.t()) {
             (void)sv.interpolate_inplace(t_eval[col], tmp);
             if (y_out)
               for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
             col++;
           }
           if (r == StopReason::TstopReached) break;
-          if (r == StopReason::RootFound) break;
+          if (r == StopReason::RootFound) {
+            // solve_dense (method.rs:498-516): drain up to the root, then the column after holds the state moved back to the root time
+            const double rt = sv.root_time;
+            while (col < nt && t_eval[col] <= rt) {
+              (void)sv.interpolate_inplace(t_eval[col], tmp);
+              if (y_out)
+                for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
+              col++;
+            }
+            if (col < nt) {
+              (void)sv.interpolate_inplace(rt, tmp);
+              if (y_out)
+                for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
+              col++;
+            }
+            for (int b = 0; b < cnt; ++b) { if (root_t_out) root_t_out[s0 + b] = rt; if (root_idx_out) root_idx_out[s0 + b] = sv.root_index; }
+            break;
+          }
         }
+        for (int b = 0; b < cnt; ++b) if (ncols_out) ncols_out[s0 + b] = col;
+        if (y_out)
+          for (int b = 0; b < cnt; ++b)
+            for (int c2 = col; c2 < nt; ++c2)
+              for (int i = 0; i < n; ++i) y_out[((size_t)(s0 + b) * nt + c2) * n + i] = std::numeric_limits<double>::quiet_NaN();
         if (!ok) failed += cnt;
         if (stats_out) {
           const Stats& st = sv.stats();

@@ -28,12 +28,14 @@ T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]
 ROB = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
 
 
-def run_pair(H, O, model, p, t_eval, model_size, group=1, **tol):
+def run_pair(H, O, model, p, t_eval, model_size, group=1, method=0, **tol):
     nb = len(p)
-    s = H.Solver(model, p, nbatch=nb, model_size=model_size, **tol)
-    y, tot, stats, status = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
-    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=model_size, nthreads=8, group=group, **tol)
-    return y, tot, stats, status, np.transpose(yo, (1, 0, 2)), so, failed
+    s = H.Solver(model, p, nbatch=nb, model_size=model_size, method=method, **tol)
+    y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=model_size, nthreads=8, group=group,
+                                               method=method, **tol)
+    run_pair.member, run_pair.oracle_roots = m, O.solve_dense_independent.last_roots
+    return y, tot, m["stats"], m["status"], np.transpose(yo, (1, 0, 2)), so, failed
 
 
 def test_adaptive_robertson_members_match_independent_cpu_solves(H, O):
@@ -96,10 +98,13 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s = H.Solver("robertson", [[0.04, 1e4, 3e7]], nbatch=1, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])  # DAE: mass matrix
+    s = H.Solver("robertson", [[0.04, 1e4, 3e7]], nbatch=1, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])  # DAE: mass matrix, BDF kernel is ODE-only
     with pytest.raises(H.DiffsolHipError) as e:
         s.solve_dense_adaptive([1.0])
     assert e.value.code == -6
+    s3 = H.Solver("heat1d", [[1.0]], nbatch=1, model_size=16, method=1)  # run-time sized model: no register kernel
+    with pytest.raises(H.DiffsolHipError):
+        s3.solve_dense_adaptive([0.1])
     s2 = H.Solver("robertson_ode", [[0.04, 1e4, 3e7]], nbatch=1, model_size=1, **ROB)
     with pytest.raises(H.DiffsolHipError):
         s2.solve_dense_adaptive([2.0, 1.0])
@@ -115,3 +120,90 @@ def test_adaptive_full_size_ensemble_invariants(H):
     assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-9
     assert (np.diff(y[:, :, 0], axis=0) <= 1e-12).all() and (np.diff(y[:, :, 2], axis=0) >= -1e-12).all()
     assert 150 * nb < tot["number_of_steps"] < 400 * nb
+
+
+# ------------------------------------------------------------------ device-resident TR-BDF2 / ESDIRK34 (dsh_sdirk_solve_resident)
+@pytest.mark.parametrize("group", [1, 64])
+@pytest.mark.parametrize("method", [1, 2])
+def test_resident_sdirk_exponential_decay_matches_oracle(H, O, method, group):
+    nb = 130
+    k = 0.05 * (np.arange(nb) + 1)
+    p = np.stack([k, np.arange(nb) + 1.0], axis=1)
+    t_eval = [1.0, 2.5, 9.0]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "exponential_decay", p, t_eval, 0, group=group, method=method, rtol=1e-6, atol=[1e-6, 1e-6])
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-7, atol=0)
+    exact = p[None, :, 1:2] * np.exp(-p[None, :, 0:1] * np.asarray(t_eval)[:, None, None]) * np.ones((1, 1, 2))
+    assert np.allclose(y, exact, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_resident_sdirk_dae_with_consistent_initialisation(H, O, group):
+    """Mass-matrix models: Robertson DAE (consistent initial values) and exponential decay with an algebraic equation whose initial value is
+    INCONSISTENT (y = (1, 1, 0) but 0 = y2 - y1): the device runs InitOp's Newton with the backtracking line search per member / per group."""
+    p = robertson_params(70)
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "robertson", p, [0.4, 4.0, 40.0], 0, group=group, method=1, **tol)
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9 and np.allclose(y[:, same], yo[:, same], rtol=1e-5, atol=1e-300) and np.allclose(y, yo, rtol=5e-3, atol=1e-9)
+    assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-7  # the algebraic constraint
+    pk = (0.1 * (np.arange(40) + 1))[:, None]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "exponential_decay_with_algebraic", pk, [1.0, 5.0], 0, group=group, method=2, rtol=1e-6,
+                                                     atol=[1e-6] * 3)
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9 and np.allclose(y[:, same], yo[:, same], rtol=1e-7, atol=1e-12)
+    assert np.allclose(y[..., 2], y[..., 1], atol=1e-9) and np.allclose(y[..., 0], np.exp(-pk[None, :, 0] * np.asarray([1.0, 5.0])[:, None]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_resident_sdirk_per_member_events(H, O, method):
+    """BASELINE config 5's point: every member stops at ITS OWN event.  exponential_decay_with_root (g = y0 - 0.6) with a different decay rate per
+    member: root times -ln(0.6)/k_b differ by 20x across the ensemble; the lock-step backend refuses this (batch mismatch), the per-member kernel
+    returns each member's root time, root index, number of valid columns and the state at the root."""
+    nb = 100
+    k = 0.05 * (np.arange(nb) + 1)
+    p = np.stack([k, np.ones(nb)], axis=1)
+    t_eval = [0.5, 1.0, 2.0, 4.0, 8.0, 16.0]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "exponential_decay_with_root", p, t_eval, 0, group=1, method=method, rtol=1e-6, atol=[1e-6, 1e-6])
+    m, ref = run_pair.member, run_pair.oracle_roots
+    assert failed == 0 and (status == 0).all()
+    t_exact = -np.log(0.6) / k
+    hit = t_exact < t_eval[-1]
+    assert (m["root_idx"][hit] == 0).all() and (m["root_idx"][~hit] == -1).all()
+    assert np.allclose(m["t_root"][hit], t_exact[hit], rtol=2e-4)
+    assert np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    assert np.allclose(m["t_root"][hit], ref["t_root"][hit], rtol=1e-7)
+    for b in np.flatnonzero(hit):
+        nc = m["ncols"][b]
+        assert abs(y[nc - 1, b, 0] - 0.6) < 1e-5 and np.isnan(y[nc:, b]).all()  # last valid column = state at the root
+    ok = np.isfinite(yo)
+    assert np.array_equal(np.isfinite(y), ok) and np.allclose(y[ok], yo[ok], rtol=1e-6, atol=1e-12)
+    # the wavefront lock-step mode reports the disagreement instead of following member 0
+    s = H.Solver("exponential_decay_with_root", p, nbatch=nb, method=method, rtol=1e-6, atol=[1e-6, 1e-6])
+    _, tot64, m64 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=64)
+    assert (m64["status"] == 20).all() and tot64["failed_members"] == nb
+
+
+def test_resident_esdirk34_rlc_config5_members_track_independent_cpu_solves(H, O):
+    """Config 5 (RLC DAE, ESDIRK34, root iR - i_thresh) at reduced size, per-member control: every member against its own CPU solve.  sin() is
+    ocml's on the device: tolerance, not bits."""
+    nb = 200
+    rng = np.random.default_rng(5)
+    R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, 0.03)], axis=1)
+    t_eval = [0.002, 0.005, 0.01, 0.02, 0.05]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "rlc", p, t_eval, 1, group=1, method=2, rtol=1e-6, atol=[1e-6] * 4)
+    m, ref = run_pair.member, run_pair.oracle_roots
+    assert failed == 0 and (status == 0).all()
+    assert np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    hit = m["root_idx"] >= 0
+    assert 0 < hit.sum() < nb  # some members reach the threshold current, at different times; others never do
+    assert np.allclose(m["t_root"][hit], ref["t_root"][hit], rtol=1e-6) and np.ptp(m["t_root"][hit]) > 1e-3
+    ok = np.isfinite(yo)
+    assert np.array_equal(np.isfinite(y), ok) and np.allclose(y[ok], yo[ok], rtol=1e-5, atol=1e-9)
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9
