@@ -22,14 +22,13 @@
 //   64 : the 64 members of a wavefront advance in lock-step, norms reduced with a max over the wavefront — the reference's batched semantics
 //        (nbatch = 64) per group; no divergence at all, every control scalar is wavefront-uniform, no host round trip.
 //
-// Scope this round: static register models (n <= 4) without mass matrix and without root functions (Robertson ODE, exponential decay).
+// Scope: static register models (n <= 4), with or without mass matrix (consistent initialisation on the device) and root functions
+// (per-member event stops); shared pieces in dsh_resident.hpp, the (E)SDIRK counterpart in dsh_sdirk_resident.hip.
 #include <cmath>
 #include <cstdio>
 #include <vector>
 
-#include "dsh_internal.hpp"
-#include "dsh_lu_dev.hpp"
-#include "dsh_models.hpp"
+#include "dsh_resident.hpp"
 
 using namespace dsh;
 
@@ -39,113 +38,37 @@ constexpr int kMaxOrder = 5;
 constexpr int kNC = kMaxOrder + 3;  // columns of the difference array
 
 struct AdaptiveConsts {
-  double rtol, t0, h0;
+  ResidentConsts r;
   double alpha[6], gamma[6], ec2[6];  // Bdf::_new tables (bdf.rs:286-306), computed on the host
-  double eta_reset, eta_reset_ts;     // 20^1.25, 100^1.25 (convergence.rs:36-42), computed on the host
   double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
-  dsh_adaptive_options o;
-  int n_eval;
 };
-
-enum LaneStatus : int32_t {
-  kOk = 0, kStepSizeTooSmall = 1, kTooManyErrorTestFailures = 2, kTooManyNonlinearSolverFailures = 3, kStopTimeBeforeCurrentTime = 5,
-  kStopTimeAtCurrentTime = 6, kMaxStepsExceeded = 99
-};
-enum class JState { StepSuccess, FirstConvergenceFail, SecondConvergenceFail, ErrorTestFail };
-
-// weighted mean square, sequential like Vector::squared_norm (nalgebra_serial.rs:395-408)
-template <int N>
-__device__ __forceinline__ double wms(const double (&v)[N], const double (&w)[N], const double (&atol)[N], double rtol) {
-  double acc = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    const double term = v[i] / (fabs(w[i]) * rtol + atol[i]);
-    acc += term * term;
-  }
-  return acc / (double)N;
-}
-
-// compiler-rt __powidf2 (what f64::powi lowers to; convergence.rs:85)
-__device__ __forceinline__ double powi_rt(double a, int b) {
-  const bool recip = b < 0;
-  double r = 1.0;
-  while (true) {
-    if (b & 1) r *= a;
-    b /= 2;
-    if (b == 0) break;
-    a *= a;
-  }
-  return recip ? 1.0 / r : r;
-}
-
-// runge_kutta.rs:1313-1336
-__device__ __forceinline__ double pi_controller_raw(double error_norm, bool has_prev, double prev, double pi_i, double pi_p, int eff_order) {
-  const double order_f = (double)eff_order;
-  const double ki = pi_i / order_f;
-  if (pi_p == 0.0) return pow(error_norm, -ki);
-  if (has_prev) {
-    const double kp = pi_p / order_f;
-    return pow(error_norm, -(ki + kp)) * pow(prev, kp);
-  }
-  return pow(error_norm, -ki);
-}
-
-// Group reduction of a mean-square norm: the member's own value (per-member control) or the max over the 64 members of the wavefront
-// (wavefront lock-step: Vector::squared_norm's max over the batch, vector/cuda.rs:1421-1432, for a batch of 64; NaN wins like in the oracle).
-template <bool WAVE>
-__device__ __forceinline__ double group_norm(double v) {
-  if constexpr (WAVE) return __longlong_as_double((long long)wave_max_u64(d2u(v)));
-  else return v;
-}
-template <bool WAVE>
-__device__ __forceinline__ bool group_all(bool ok) {
-  if constexpr (WAVE) return __all(ok);
-  else return ok;
-}
 
 template <class Mdl, bool BA, bool WAVE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
-                                                    int32_t* __restrict__ status_out, unsigned long long* __restrict__ totals) {
+                                                    int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
+                                                    int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
   constexpr int N = Mdl::N, NP = Mdl::NP;
-  static_assert(!Mdl::HAS_MASS && Mdl::NROOTS == 0, "adaptive kernel: ODE models without roots only");
+  constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
   const AdaptiveConsts& C = *Cp;
   const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
   const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
-  const dsh_adaptive_options& o = C.o;
-  const double rtol = C.rtol;
+  const dsh_adaptive_options& o = C.r.o;
+  const double rtol = C.r.rtol;
   double p[NP], atol[N];
   load_vec<NP>(p_g, nb, b, p);
 #pragma unroll
   for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
 
   // ------------------------------------------------------------ OdeSolverState::new_and_consistent (state.rs:969-997, :1086-1124)
-  double t = C.t0, h;
+  double t = C.r.t0, h;
   double y[N], f0[N];
   Mdl::init(t, p, y);
   Mdl::rhs(t, y, p, f0);
-  {  // set_step_size (state.rs:1209-1277), solver_order = 1
-    const bool is_neg_h = C.h0 < 0.0;
-    const double d0 = sqrt(group_norm<WAVE>(wms<N>(y, y, atol, rtol))), d1 = sqrt(group_norm<WAVE>(wms<N>(f0, y, atol, rtol)));
-    const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
-    const double hh = is_neg_h ? -h0 : h0;
-    double y1[N], f1[N], df[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) y1[i] = f0[i] * hh + y[i];
-    Mdl::rhs(is_neg_h ? t - h0 : t + h0, y1, p, f1);
-#pragma unroll
-    for (int i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
-    const double d2 = sqrt(group_norm<WAVE>(wms<N>(df, y, atol, rtol))) / fabs(h0);
-    double max_d = d2;
-    if (max_d < d1) max_d = d1;
-    double h1;
-    if (max_d < 1e-15) { h1 = h0 * 1e-3; if (h1 < 1e-6) h1 = 1e-6; }
-    else h1 = pow(0.01 / max_d, 1.0 / (1.0 + 1.0));
-    h = 100.0 * h0;
-    if (h > h1) h = h1;
-    if (is_neg_h) h = -h;
-  }
+  int32_t status = kRsOk;
+  if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, f0, atol, rtol, C.r))) status = kRsInitialConditionDidNotConverge;
+  h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1);
 
   // ------------------------------------------------------------ Bdf::_new (bdf.rs:244-368) + BdfState::initialise_diff_to_first_order
   int order = 1;
@@ -179,18 +102,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
       for (int e = 0; e < N * N; ++e) J[e] = sJ[e][ln];
     }
+    double Mm[N * N];
+    if constexpr (Mdl::HAS_MASS) assemble_mass<Mdl>(tt, p, Mm);
+    else {
 #pragma unroll
-    for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + ((e / N == e % N) ? 1.0 : 0.0);
+      for (int e = 0; e < N * N; ++e) Mm[e] = (e / N == e % N) ? 1.0 : 0.0;  // Matrix::from_diagonal(ones), op/bdf.rs:138-141
+    }
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + Mm[e];
     bool sing = false;
     lu_factor_reg<N>(A, P, sing);
   };
   reset_jacobian(y, t);
   n_setups = 1;
+  // RootFinder::init (root.rs:44-49)
+  double g0[NR] = {0.0};
+  double rf_t0 = t;
+  if constexpr (Mdl::NROOTS > 0) Mdl::root(t, y, p, g0);
+  double t_root = 0.0;
+  int root_idx = -1;
   // JacobianUpdate (jacobian_update.rs:12-36)
   int steps_since_jac = 0, steps_since_rhs_jac = 0;
   double h_at_last_jac = 1.0;
   // Convergence (convergence.rs:7-57)
-  double eta = C.eta_reset;
+  double eta = C.r.eta_reset;
   int n_equal_steps = 0;
   bool has_prev_err = false;
   double prev_err = 0.0;
@@ -236,7 +171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = sDt[j * N + i][ln]; sDt[j * N + i][ln] = tmp; }
     opc = new_h * C.alpha[order];
     h = new_h;
-    eta = C.eta_reset_ts;  // reset_eta_timestep_change
+    eta = C.r.eta_reset_ts;  // reset_eta_timestep_change
     new_h_out = new_h;
     return fabs(h) < o.min_timestep;  // true = StepSizeTooSmall
   };
@@ -276,19 +211,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       jac_stale = true;
       reset_jacobian(y, t);
       steps_since_rhs_jac = 0; steps_since_jac = 0; h_at_last_jac = c;  // update_rhs_jacobian, then update_jacobian
-      eta = C.eta_reset;
+      eta = C.r.eta_reset;
       n_setups++;
     } else if (check_jac) {
       reset_jacobian(y, t);
       steps_since_jac = 0; h_at_last_jac = c;
-      eta = C.eta_reset;
+      eta = C.r.eta_reset;
       n_setups++;
     }
   };
 
   // handle_tstop (bdf.rs:694-731): 0 = nothing, 1 = TstopReached, 2 = StopTimeBeforeCurrentTime
   bool has_tstop = true;
-  const double tstop = t_eval[C.n_eval - 1];
+  const double tstop = t_eval[C.r.n_eval - 1];
   auto handle_tstop = [&]() __attribute__((always_inline)) -> int {
     const double eps = 2.220446049250313e-16;
     const double troundoff = 100.0 * eps * (fabs(t) + fabs(h));
@@ -302,19 +237,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     return 0;
   };
 
-  int32_t status = kOk;
   int col = 0;
   // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
   {
     const int r = handle_tstop();
-    if (r == 1) status = kStopTimeAtCurrentTime;
-    else if (r == 2) status = kStopTimeBeforeCurrentTime;
+    if (r == 1) status = kRsStopTimeAtCurrentTime;
+    else if (r == 2) status = kRsStopTimeBeforeCurrentTime;
   }
 
   long guard = 0;
-  bool done = status != kOk || (!WAVE && !active);  // wavefront lock-step: shadow lanes run along (their reductions must not be masked off)
+  bool done = status != kRsOk || (!WAVE && !active);  // wavefront lock-step: shadow lanes run along (their reductions must not be masked off)
   while (!done) {
-    if (++guard > o.max_steps) { status = kMaxStepsExceeded; break; }
+    if (++guard > o.max_steps) { status = kRsMaxStepsExceeded; break; }
     // ================================================================ Bdf::step (bdf.rs:1277-1589)
     double safety = 0.0, error_norm = 0.0;
     const int old_err_fails = n_err_fails;
@@ -331,10 +265,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       double old_norm = 0.0;
       bool solved = false;
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
-        double f[N], delta[N];
+        double f[N], delta[N], tmpv[N];
         Mdl::rhs(t_predict, x, p, f);
 #pragma unroll
-        for (int i = 0; i < N; ++i) { const double tmp = x[i] + psi[i]; delta[i] = 1.0 * tmp + (-opc) * f[i]; }  // F(y) = (y - y0 + psi) - c f(y)
+        for (int i = 0; i < N; ++i) tmpv[i] = x[i] + psi[i];
+        // F(y) = M (y - y0 + psi) - c f(y)   (op/bdf.rs:240-256)
+        if constexpr (Mdl::HAS_MASS) {
+#pragma unroll
+          for (int i = 0; i < N; ++i) delta[i] = f[i];
+          Mdl::mass_gemv(t_predict, tmpv, p, -opc, delta);
+        } else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmpv[i] + (-opc) * f[i];
+        }
         const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
         if (!lu_ok) break;  // LuSolveFailed
 #pragma unroll
@@ -362,11 +305,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       n_newton += niter;
       if (!solved) {
         n_nl_fails += 1;
-        if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kTooManyNonlinearSolverFailures; break; }
+        if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kRsTooManyNonlinearSolverFailures; break; }
         has_prev_err = false;
         if (convergence_fail) {
           double new_h;
-          if (update_step_size(0.3, new_h)) { status = kStepSizeTooSmall; break; }
+          if (update_step_size(0.3, new_h)) { status = kRsStepSizeTooSmall; break; }
           jacobian_updates(new_h * C.alpha[order], JState::SecondConvergenceFail);
           predict_forward();
         } else {
@@ -404,13 +347,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       has_prev_err = false;
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
       double new_h;
-      if (update_step_size(factor, new_h)) { status = kStepSizeTooSmall; break; }
+      if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
       jacobian_updates(new_h * C.alpha[order], JState::ErrorTestFail);
       predict_forward();
       n_err_fails += 1;
-      if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kTooManyErrorTestFailures; break; }
+      if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kRsTooManyErrorTestFailures; break; }
     }
-    if (status != kOk) break;
+    if (status != kRsOk) break;
     n_steps += 1;
     steps_since_jac += 1; steps_since_rhs_jac += 1;  // JacobianUpdate::step
     prev_err = error_norm; has_prev_err = true;
@@ -443,17 +386,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
       if (factor >= o.min_timestep_growth || factor <= o.max_timestep_shrink || max_index == 0 || max_index == 2) {
         double new_h;
-        if (update_step_size(factor, new_h)) { status = kStepSizeTooSmall; break; }
+        if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
         jacobian_updates(new_h * C.alpha[new_order], JState::StepSuccess);
       }
     }
-    int reason = 0;
-    if (has_tstop) reason = handle_tstop();
-    // ================================================================ solve_dense: interpolated output (interpolate_from_diff, bdf.rs:767-782)
-    while (col < C.n_eval && t_eval[col] <= t) {
-      const double te = t_eval[col];
+    // interpolate_from_diff (bdf.rs:767-782)
+    auto interpolate = [&](double te, double (&yv)[N]) __attribute__((always_inline)) {
       double time_factor = 1.0;
-      double yv[N];
 #pragma unroll
       for (int i = 0; i < N; ++i) yv[i] = D[0][i];
 #pragma unroll
@@ -465,15 +404,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           for (int i = 0; i < N; ++i) yv[i] = time_factor * D[j + 1][i] + 1.0 * yv[i];
         }
       }
+    };
+    int reason = 0;  // 0 internal, 1 tstop, 3 root
+    if constexpr (Mdl::NROOTS > 0) {
+      const int rr = check_root<Mdl, WAVE>(g0, rf_t0, y, t, p, interpolate, t_root, root_idx);
+      if (rr == 2) { status = kRsRootBatchMismatch; break; }
+      if (rr == 1) reason = 3;
+    }
+    if (reason == 0 && has_tstop) reason = handle_tstop();
+    if (reason == 2) reason = 0;  // the reference unwraps / ignores this inside step()
+    // ================================================================ solve_dense (method.rs:467-520): interpolated output
+    const double upto = reason == 3 ? t_root : t;
+    while (col < C.r.n_eval && t_eval[col] <= upto) {
+      double yv[N];
+      interpolate(t_eval[col], yv);
 #pragma unroll
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
       col++;
     }
+    if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
+      if (col < C.r.n_eval) {
+        double yv[N];
+        interpolate(t_root, yv);
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+        col++;
+      }
+      done = true;
+    }
     if (reason == 1) done = true;
   }
   if (active) {
-    // columns that were never reached (error exit): NaN
-    for (; col < C.n_eval; ++col)
+    if (ncols_out != nullptr) ncols_out[b] = col;
+    if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
+    if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
+    // columns that were never reached (root stop or error exit): NaN
+    for (; col < C.r.n_eval; ++col)
 #pragma unroll
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
     if (status_out != nullptr) status_out[b] = status;
@@ -488,7 +454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // ensemble totals: wavefront sums, one atomic per wavefront and counter
   const unsigned long long mine[6] = {active ? (unsigned long long)n_steps : 0ull, active ? (unsigned long long)n_newton : 0ull,
                                       active ? (unsigned long long)n_setups : 0ull, active ? (unsigned long long)n_err_fails : 0ull,
-                                      active ? (unsigned long long)n_nl_fails : 0ull, (active && status != kOk) ? 1ull : 0ull};
+                                      active ? (unsigned long long)n_nl_fails : 0ull, (active && status != kRsOk) ? 1ull : 0ull};
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const unsigned long long sum = wave_sum_u64(mine[k]);
@@ -532,26 +498,27 @@ int dsh_model_has_adaptive(int model, int64_t size) {
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
-    ok = !Mdl::HAS_MASS && Mdl::NROOTS == 0 && Mdl::N <= 4;
+    ok = Mdl::N <= 4;
   });
   return ok ? 1 : 0;
 }
 
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
-                           int64_t* totals_host) {
+                           double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t k = 0; k + 1 < n_eval; ++k) DSH_REQUIRE(t_eval_host[k] <= t_eval_host[k + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  if (!dsh_model_has_adaptive(model, size)) { set_error("dsh_bdf_solve_adaptive: model has no device-resident adaptive kernel (needs a static ODE model, n <= 4, no roots)"); return DSH_E_UNSUPPORTED; }
+  if (!dsh_model_has_adaptive(model, size)) { set_error("dsh_bdf_solve_adaptive: model has no device-resident kernel (needs a static model, n <= 4)"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   AdaptiveConsts C;
-  C.rtol = rtol; C.t0 = t0; C.h0 = h0; C.n_eval = (int)n_eval;
-  if (opts) C.o = *opts; else dsh_adaptive_default_options(&C.o);
-  if (C.o.max_steps <= 0) C.o.max_steps = 10000000;
-  DSH_REQUIRE(C.o.group == 1 || C.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
+  C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
+  C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+  if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
+  if (C.r.o.max_steps <= 0) C.r.o.max_steps = 10000000;
+  DSH_REQUIRE(C.r.o.group == 1 || C.r.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
   {  // Bdf::_new tables (bdf.rs:286-306)
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
     C.alpha[0] = 0.0; C.gamma[0] = 0.0; C.ec2[0] = 1.0;
@@ -562,8 +529,8 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
       const double e = kappa[i] * C.gamma[i] + one_over_i_plus_one;
       C.ec2[i] = e * e;
     }
-    C.eta_reset = std::pow(20.0, 1.25);
-    C.eta_reset_ts = std::pow(100.0, 1.25);
+    C.r.eta_reset = std::pow(20.0, 1.25);
+    C.r.eta_reset_ts = std::pow(100.0, 1.25);
     for (int ord = 1; ord <= kMaxOrder; ++ord) {  // compute_r(order, 1.0) (bdf.rs:433-463), stored 6x6 column-major
       double* U = C.u[ord - 1];
       for (int k = 0; k < 36; ++k) U[k] = 0.0;
@@ -587,10 +554,10 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   bool launched = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
-    if constexpr (!Mdl::HAS_MASS && Mdl::NROOTS == 0 && Mdl::N <= 4) {
+    if constexpr (Mdl::N <= 4) {
 #define DSH_ADAPTIVE_LAUNCH(BA, WAVE) \
-  hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, totals_dev)
-      if (C.o.group == 64) { if (ba) DSH_ADAPTIVE_LAUNCH(true, true); else DSH_ADAPTIVE_LAUNCH(false, true); }
+  hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+      if (C.r.o.group == 64) { if (ba) DSH_ADAPTIVE_LAUNCH(true, true); else DSH_ADAPTIVE_LAUNCH(false, true); }
       else { if (ba) DSH_ADAPTIVE_LAUNCH(true, false); else DSH_ADAPTIVE_LAUNCH(false, false); }
 #undef DSH_ADAPTIVE_LAUNCH
     }

@@ -253,7 +253,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int64_t size = 0;
     const int method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
     if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size))
-      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models, n <= 4; BDF: ODE without roots)");
+      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4 only)");
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
     const OdeSolverOptions& oo = s->problem.ode_options;
     const InitialConditionSolverOptions& ic = s->problem.ic_options;
@@ -289,7 +289,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     void *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
     if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
     if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
-    if (method != 0) {
+    {
       if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "adaptive t_root");
       if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
       if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
@@ -297,7 +297,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int rc;
     if (method == 0)
       rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
-                                  t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, totals);
+                                  t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
     else
       rc = dsh_sdirk_solve_resident(c, method, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0,
                                     s->problem.h0, &o, t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
@@ -306,15 +306,9 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
       for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
     if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
     if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
-    if (method != 0) {
-      if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
-      if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
-      if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
-    } else {  // BDF kernel: no root functions
-      if (t_root_host) for (int64_t b = 0; b < nb; ++b) t_root_host[b] = std::nan("");
-      if (root_idx_host) for (int64_t b = 0; b < nb; ++b) root_idx_host[b] = -1;
-      if (ncols_host) for (int64_t b = 0; b < nb; ++b) ncols_host[b] = (int32_t)nt;
-    }
+    if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
+    if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
+    if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
     for (void* q : {tmp_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
     check(rc, "solve_dense_adaptive");
     return 0;

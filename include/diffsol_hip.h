@@ -255,7 +255,7 @@ int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order
 /* ---- device-resident per-member adaptive BDF: the whole ensemble solve in ONE launch, one lane per member, each with its own
  * step-size / order history — the semantics of diffsol's CPU path for a parameter sweep (one independent IVP per member), i.e. of
  * Bdf::step (ode_solver/bdf.rs:1277-1589) + NewtonNonlinearSolver (diffsol-nl/src/newton.rs) + solve_dense (method.rs:467-520) per member.
- * Static ODE models with n <= 4, no mass matrix, no roots (dsh_model_has_adaptive). */
+ * Static models with n <= 4 (dsh_model_has_adaptive), mass matrices (consistent initialisation on the device) and root functions included. */
 typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) + BdfConfig (config.rs:53-74) */
   int max_nonlinear_solver_iterations, max_error_test_failures, max_nonlinear_solver_failures;
   double nonlinear_solver_tolerance, min_timestep;
@@ -275,10 +275,11 @@ int dsh_model_has_adaptive(int model, int64_t size);
 /* p: np x nb (batch-fastest, device); atol: n (atol_nb == 1) or n x nb; t_eval_host: n_eval increasing times, the last one is the stop time;
  * y_out: n_eval x n x nb (device, batch-fastest per save point); stats: 5 x nb int32 (steps, Newton iterations, LU setups, error-test failures,
  * Newton failures) or NULL; status: nb int32 (0 ok, else the OdeSolverError ordinal, 99 = max_steps) or NULL;
- * totals_host[6]: the five counters summed over members + number of failed members.  Blocking. */
+ * t_root / root_idx / ncols (nb each, may be NULL): see dsh_sdirk_solve_resident.  totals_host[6]: the five counters summed over members + number of
+ * failed members.  Blocking. */
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                           int32_t* status, int64_t* totals_host);
+                           int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* Device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): Sdirk::step (ode_solver/sdirk.rs:409-543) + Rk core (runge_kutta.rs) + consistent DAE initialisation
  * (state.rs:84-162) + RootFinder (nonlinear_solver/root.rs) + solve_dense (method.rs:467-520) per member, one launch per ensemble solve.  Static models with
  * n <= 4, mass matrices and root functions included (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds

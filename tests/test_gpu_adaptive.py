@@ -98,13 +98,10 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s = H.Solver("robertson", [[0.04, 1e4, 3e7]], nbatch=1, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])  # DAE: mass matrix, BDF kernel is ODE-only
-    with pytest.raises(H.DiffsolHipError) as e:
-        s.solve_dense_adaptive([1.0])
-    assert e.value.code == -6
     s3 = H.Solver("heat1d", [[1.0]], nbatch=1, model_size=16, method=1)  # run-time sized model: no register kernel
-    with pytest.raises(H.DiffsolHipError):
+    with pytest.raises(H.DiffsolHipError) as e:
         s3.solve_dense_adaptive([0.1])
+    assert e.value.code == -6
     s2 = H.Solver("robertson_ode", [[0.04, 1e4, 3e7]], nbatch=1, model_size=1, **ROB)
     with pytest.raises(H.DiffsolHipError):
         s2.solve_dense_adaptive([2.0, 1.0])
@@ -140,6 +137,25 @@ def test_resident_sdirk_exponential_decay_matches_oracle(H, O, method, group):
 
 
 @pytest.mark.parametrize("group", [1, 64])
+def test_resident_bdf_dae_with_consistent_initialisation(H, O, group):
+    """The BDF kernel on mass-matrix models: Robertson DAE (SUNDIALS reference problem) and the inconsistent algebraic exponential decay."""
+    p = robertson_params(70)
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "robertson", p, T_EVAL[:5], 0, group=group, method=0, **tol)
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9 and np.allclose(y[:, same], yo[:, same], rtol=1e-5, atol=1e-300) and np.allclose(y, yo, rtol=5e-3, atol=1e-9)
+    assert np.abs(y.sum(axis=2) - 1.0).max() < 1e-7
+    pk = (0.1 * (np.arange(40) + 1))[:, None]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "exponential_decay_with_algebraic", pk, [1.0, 5.0], 0, group=group, method=0, rtol=1e-6,
+                                                     atol=[1e-6] * 3)
+    assert failed == 0 and (status == 0).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9 and np.allclose(y[:, same], yo[:, same], rtol=1e-7, atol=1e-12)
+    assert np.allclose(y[..., 2], y[..., 1], atol=1e-9)
+
+
+@pytest.mark.parametrize("group", [1, 64])
 def test_resident_sdirk_dae_with_consistent_initialisation(H, O, group):
     """Mass-matrix models: Robertson DAE (consistent initial values) and exponential decay with an algebraic equation whose initial value is
     INCONSISTENT (y = (1, 1, 0) but 0 = y2 - y1): the device runs InitOp's Newton with the backtracking line search per member / per group."""
@@ -159,7 +175,7 @@ def test_resident_sdirk_dae_with_consistent_initialisation(H, O, group):
     assert np.allclose(y[..., 2], y[..., 1], atol=1e-9) and np.allclose(y[..., 0], np.exp(-pk[None, :, 0] * np.asarray([1.0, 5.0])[:, None]), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("method", [0, 1, 2])
 def test_resident_sdirk_per_member_events(H, O, method):
     """BASELINE config 5's point: every member stops at ITS OWN event.  exponential_decay_with_root (g = y0 - 0.6) with a different decay rate per
     member: root times -ln(0.6)/k_b differ by 20x across the ensemble; the lock-step backend refuses this (batch mismatch), the per-member kernel
