@@ -108,6 +108,7 @@ DEVICE_ABI = {
     "dsh_sdirk_solve_resident": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
+    "dsh_bdf_accept_newton_async": (cint, [vp, cint, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, dbl, dbl, cint, vp, vp, vp, c_i64p, c_i64p]),
     "dsh_bdf_accept_step_async": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, c_i64p]),
     "dsh_bdf_accept_step": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, cint, c_dp]),
 }

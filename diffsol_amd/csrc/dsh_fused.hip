@@ -272,6 +272,108 @@ __global__ void k_bdf_accept(int64_t n_rt, int64_t nb, int order, double inv_h, 
   block_publish(m_bits, p_bits, 0ull, rec, seq);
 }
 
+// Accepted-step bookkeeping of step k AND the first NIT Newton iterations of step k+1 in ONE launch (the common case: the controller keeps the
+// order, the step size and the LU factors): k_bdf_accept followed by k_newton_iter<..., WITH_ERR = true, NIT>, the new state, prediction and psi
+// handed over in registers instead of through HBM.  Record group 0 = the accept launch's order-selection norms, groups 1..NIT = the Newton
+// iterations'.  Every value is the same function of the same inputs as in the two separate launches.
+template <class Mdl, bool BA, int NIT>
+__global__ void k_accept_newton(int64_t nb, int order, double inv_h, double* __restrict__ diff, double* __restrict__ y_predict, const double* y_new /* may alias y_out */,
+                                double* __restrict__ y, double* __restrict__ dy, const double* __restrict__ atol, double rtol, BdfCoeffs cf,
+                                double* __restrict__ psi_next, double t_next, double c, double* y_out, const double* __restrict__ p,
+                                const double* __restrict__ factors, const int32_t* __restrict__ piv, unsigned long long* rec, unsigned int seq) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = b < nb;
+  const int64_t bb = active ? b : 0;
+  const int64_t cs = (int64_t)N * nb;  // column stride of the difference array
+  double x[N], a[N], ey[N], yo[N], at[N], pp[NP], A[N * N];
+  int P[N];
+  load_vec<NP>(p, nb, bb, pp);
+  load_mat<N>(factors, nb, bb, A);
+  load_piv<N>(piv, nb, bb, P);
+  load_atol<N, BA>(atol, nb, bb, at);
+  unsigned long long m_bits = 0ull, p_bits = 0ull;
+  {
+    double acc_m = 0.0, acc_p = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int64_t e = (int64_t)i * nb + bb;
+      const double yp = y_predict[e];
+      const double d = y_new[e] - yp;
+      double col[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) col[j] = j <= order + 1 ? diff[(int64_t)j * cs + e] : 0.0;
+      double dk1 = 0.0;
+#pragma unroll
+      for (int j = 2; j < 7; ++j) if (j == order + 1) dk1 = col[j];
+      const double dk2 = d - dk1;
+      if (active) { diff[(int64_t)(order + 2) * cs + e] = dk2; diff[(int64_t)(order + 1) * cs + e] = d; }
+      double upper = d, new_k = 0.0, new_1 = 0.0;
+      double nd[6];
+#pragma unroll
+      for (int j = 5; j >= 0; --j) {
+        nd[j] = 0.0;
+        if (j <= order) {
+          const double v = col[j] + 1.0 * upper;
+          if (active) diff[(int64_t)j * cs + e] = v;
+          nd[j] = v;
+          if (j == order) new_k = v;
+          if (j == 1) new_1 = v;
+          upper = v;
+        }
+      }
+      double ypn = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) if (j <= order) ypn = ypn + nd[j];
+      double psi = cf.gamma[1] * nd[1];
+#pragma unroll
+      for (int j = 2; j < 6; ++j) if (j <= order) psi = cf.gamma[j] * nd[j] + 1.0 * psi;
+      psi = psi * cf.alpha;
+      psi = psi - ypn;
+      if (active) { y[e] = yp; dy[e] = new_1 * inv_h; y_predict[e] = ypn; psi_next[e] = psi; }
+      const double w = fabs(yp) * rtol + at[i];
+      const double tm = new_k / w, tp = dk2 / w;
+      acc_m += tm * tm;
+      acc_p += tp * tp;
+      yo[i] = yp;   // the new state
+      ey[i] = ypn;  // the new prediction = error_y = first iterate
+      x[i] = ypn;
+      a[i] = psi;
+    }
+    if (active) { m_bits = d2u(acc_m / (double)N); p_bits = d2u(acc_p / (double)N); }
+  }
+  block_publish(m_bits, p_bits, 0ull, rec, seq);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    double f[N], tmp[N], delta[N];
+    Mdl::rhs(t_next, x, pp, f);
+#pragma unroll
+    for (int i = 0; i < N; ++i) tmp[i] = x[i] + a[i];
+    if constexpr (Mdl::HAS_MASS) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) delta[i] = f[i];
+      Mdl::mass_gemv(t_next, tmp, pp, -c, delta);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmp[i] + (-c) * f[i];
+    }
+    const bool ok = lu_solve_reg<N>(A, P, delta);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+    unsigned long long nrm_bits = 0ull, err_bits = 0ull, bad = 0ull;
+    if (active) {
+      store_vec<N>(y_out + (int64_t)it * N * nb, nb, b, x);
+      nrm_bits = d2u(wms<N>(delta, ey, at, rtol));
+      double dd[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) dd[i] = x[i] - ey[i];
+      err_bits = d2u(wms<N>(dd, yo, at, rtol));
+      bad = ok ? 0ull : 1ull;
+    }
+    block_publish(nrm_bits, err_bits, bad, rec + (size_t)(1 + it) * gridDim.x * kRecWords, seq);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -338,15 +440,15 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   return DSH_OK;
 }
 
-// ticket = seq << 32 | groups << 24 | workgroups; out receives 3 doubles per record group
+// ticket = seq << 32 | first group << 28 | groups << 24 | workgroups; out receives 3 doubles per record group
 int dsh_reduction_wait(dsh_ctx* ctx, int64_t ticket, double* out) {
   DSH_REQUIRE(out != nullptr, "out is null");
   const unsigned int seq = (unsigned int)((uint64_t)ticket >> 32);
-  const int groups = (int)((ticket >> 24) & 0xff);
+  const int groups = (int)((ticket >> 24) & 0xf), first = (int)((ticket >> 28) & 0xf);
   const int64_t nblocks = ticket & 0xffffffll;
   if (ctx->seq - seq >= (unsigned int)kRecRegions) { set_error("dsh_reduction_wait: ticket is too old, its result records have been reused"); return DSH_E_STALE; }
   for (int gi = 0; gi < (groups > 0 ? groups : 1); ++gi) {
-    int rc = fetch_records(ctx, nblocks, seq, gi * nblocks);
+    int rc = fetch_records(ctx, nblocks, seq, (int64_t)(first + gi) * nblocks);
     if (rc != DSH_OK) return rc;
     out[3 * gi + 0] = bits_to_double(ctx->res_m0);
     out[3 * gi + 1] = bits_to_double(ctx->res_m1);
@@ -448,6 +550,44 @@ int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nb, int order, do
   DSH_REQUIRE(ticket != nullptr, "ticket is null");
   if (n * nb == 0) { *ticket = 0; return DSH_OK; }
   return accept_launch(ctx, n, nb, order, h, diff, y_predict, y_new, y, dy, atol, anb, rtol, gamma_host, alpha, psi_neg_y0_next, ticket);
+}
+
+int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new,
+                                double* y, double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha,
+                                double* psi_neg_y0_next, double t_next, double c, int nit, double* y_out, const double* p, const dsh_lu* lu,
+                                int64_t* accept_ticket, int64_t* newton_ticket) {
+  DSH_REQUIRE(accept_ticket != nullptr && newton_ticket != nullptr && lu != nullptr && psi_neg_y0_next != nullptr, "null argument");
+  DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
+  DSH_REQUIRE(nit >= 1 && nit <= 4, "nit must be in 1..4");
+  DSH_CHECK_NB(anb, nb);
+  if (!lu->factored) { set_error("accept+newton: LU not initialised"); return DSH_E_NOT_SETUP; }
+  if (nb == 0) { *accept_ticket = 0; *newton_ticket = 0; return DSH_OK; }
+  unsigned long long* rec; unsigned int seq;
+  const dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  int rc = begin_records(ctx, (int64_t)g.x * (nit + 1), &rec, &seq);
+  if (rc != DSH_OK) return rc;
+  BdfCoeffs cf;
+  for (int k = 0; k < 36; ++k) cf.ru[k] = 0.0;
+  for (int k = 0; k < 6; ++k) cf.gamma[k] = k <= order ? gamma_host[k] : 0.0;
+  cf.alpha = alpha; cf.order = order; cf.rescale = 0;
+  const double inv_h = 1.0 / h;
+  const bool ba = anb == 1 && nb != 1;
+  bool ok = dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+#define DSH_AN_LAUNCH(BA, NIT)                                                                                                                          \
+  hipLaunchKernelGGL((k_accept_newton<Mdl, BA, NIT>), g, blk, 0, ctx->stream, nb, order, inv_h, diff, y_predict, y_new, y, dy, atol, rtol, cf,        \
+                     psi_neg_y0_next, t_next, c, y_out, p, (const double*)lu->factors, (const int32_t*)lu->pivots, rec, seq)
+#define DSH_AN_NIT(BA)                                                                                                                                  \
+  switch (nit) { case 1: DSH_AN_LAUNCH(BA, 1); break; case 2: DSH_AN_LAUNCH(BA, 2); break; case 3: DSH_AN_LAUNCH(BA, 3); break; default: DSH_AN_LAUNCH(BA, 4); }
+    if (ba) { DSH_AN_NIT(true) } else { DSH_AN_NIT(false) }
+#undef DSH_AN_NIT
+#undef DSH_AN_LAUNCH
+  });
+  if (!ok) { set_error("accept+newton: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
+  DSH_HIP_CHECK(hipGetLastError());
+  *accept_ticket = ((int64_t)seq << 32) | ((int64_t)0 << 28) | ((int64_t)1 << 24) | (int64_t)g.x;
+  *newton_ticket = ((int64_t)seq << 32) | ((int64_t)1 << 28) | ((int64_t)nit << 24) | (int64_t)g.x;
+  return DSH_OK;
 }
 
 int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,

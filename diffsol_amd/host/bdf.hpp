@@ -149,6 +149,7 @@ class Bdf : public OdeSolverMethod {
     y_new_ = y_delta_.ptr();
     y_predict_ = HipVec::zeros(n, ctx);
     if (const char* env = std::getenv("DSH_NEWTON_PIPELINE")) pipeline_ = std::string(env) != "0";
+    if (const char* env = std::getenv("DSH_FUSE_ACCEPT")) fuse_accept_ = std::string(env) != "0";
     d_tmp_ = HipVec::zeros(n, ctx);
     u_ = compute_r(order_, 1.0);
     statistics_.number_of_linear_solver_setups = 1;
@@ -242,12 +243,27 @@ class Bdf : public OdeSolverMethod {
     double sel_norms[2] = {0.0, 0.0};
     if (fused_) {
       int64_t accept_ticket = 0;
+      if (pipeline_ && fuse_accept_) {
+        // accept + the first Newton launch of the NEXT step in one launch (see the comment below): state, prediction and psi stay in registers.
+        // y_new_ may live in group buffer 0, which the Newton part overwrites: every lane reads its y_new before it stores an iterate, and a
+        // lane only touches its own member, so the aliasing is harmless.
+        prelaunch_nit_ = std::min(nit_, convergence_.max_iter());
+        DSH_PROF(launch_accept, check(dsh_bdf_accept_newton_async(ctx().raw(), model_, model_size_, nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_new_, y_.ptr(),
+                                        dy_.ptr(), pr_.atol.ptr(), pr_.atol.nb(), pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(),
+                                        t_predict_ + h_, op_.c(), prelaunch_nit_, ybuf_[0].ptr(), pr_.eqn->params().ptr(),
+                                        nonlinear_solver_.linear_solver().raw(), &accept_ticket, &prelaunch_ticket_),
+              "dsh_bdf_accept_newton_async"));
+        t_ = t_predict_;
+        prediction_valid_ = true;
+        prelaunch_valid_ = true;
+      } else {
       DSH_PROF(launch_accept, check(dsh_bdf_accept_step_async(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_new_, y_.ptr(), dy_.ptr(), pr_.atol.ptr(),
                                       pr_.atol.nb(), pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(), &accept_ticket),
             "dsh_bdf_accept_step_async"));
       t_ = t_predict_;
       prediction_valid_ = true;  // y_predict / psi now hold the next step's prediction for (order_, h_)
-      if (pipeline_) {
+      }
+      if (pipeline_ && !fuse_accept_) {
         // Speculatively enqueue the first Newton launch of the NEXT step (valid if the controller leaves h, the order and the LU
         // factors alone — the common case) before waiting for this step's order-selection norms: the GPU stays busy across the step.
         // The accept launch above reads y_new_ (possibly in group buffer 0) and is stream-ordered before this launch overwrites it.
@@ -364,6 +380,7 @@ class Bdf : public OdeSolverMethod {
   const OdeSolverProblem& problem() const override { return pr_; }
   const HipMat& diff() const { return diff_; }
   bool is_fused() const { return fused_; }
+  void set_fuse_accept(bool v) { fuse_accept_ = v; }
 
  private:
   int64_t n() const { return pr_.eqn->nstates(); }
@@ -543,6 +560,7 @@ class Bdf : public OdeSolverMethod {
   const double* y_new_ = nullptr;  // fused mode: buffer holding the converged iterate
   HostProfile prof_;
   bool pipeline_ = true;           // speculative Newton pipelining (DSH_NEWTON_PIPELINE=0 disables)
+  bool fuse_accept_ = true;        // accept + prelaunched Newton iterations in one launch (DSH_FUSE_ACCEPT=0 disables)
   bool prelaunch_valid_ = false;   // iteration 1 of the next step is already in flight (ticket below)
   int64_t prelaunch_ticket_ = 0;
   double t_predict_ = 0.0;

@@ -251,6 +251,15 @@ int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, doub
 int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nbatch, int order, double h, double* diff, double* y_predict, const double* y_new,
                               double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
                               double* psi_neg_y0_next, int64_t* ticket);
+/* The accepted-step launch of step k fused with the first `nit` Newton iterations of step k+1 (valid when the controller then keeps order, step size
+ * and LU factors — the caller discards the Newton part otherwise): dsh_bdf_accept_step_async + dsh_bdf_newton_iter_async in one launch, the new
+ * state / prediction / psi passed in registers.  Two tickets over the same launch: accept_ticket (1 group: order-selection norms) and newton_ticket
+ * (nit groups).  Fused static models only. */
+int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new,
+                                double* y, double* dy, const double* atol, int64_t atol_nb, double rtol, const double* gamma_host, double alpha,
+                                double* psi_neg_y0_next, double t_next, double c, int nit, double* y_out, const double* p, const dsh_lu* lu,
+                                int64_t* accept_ticket, int64_t* newton_ticket);
+
 
 /* ---- device-resident per-member adaptive BDF: the whole ensemble solve in ONE launch, one lane per member, each with its own
  * step-size / order history — the semantics of diffsol's CPU path for a parameter sweep (one independent IVP per member), i.e. of
