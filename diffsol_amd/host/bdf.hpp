@@ -560,7 +560,7 @@ class Bdf : public OdeSolverMethod {
   const double* y_new_ = nullptr;  // fused mode: buffer holding the converged iterate
   HostProfile prof_;
   bool pipeline_ = true;           // speculative Newton pipelining (DSH_NEWTON_PIPELINE=0 disables)
-  bool fuse_accept_ = true;        // accept + prelaunched Newton iterations in one launch (DSH_FUSE_ACCEPT=0 disables)
+  bool fuse_accept_ = false;       // accept + prelaunched Newton iterations in one launch (DSH_FUSE_ACCEPT=1 enables; pays only when GPU-bound)
   bool prelaunch_valid_ = false;   // iteration 1 of the next step is already in flight (ticket below)
   int64_t prelaunch_ticket_ = 0;
   double t_predict_ = 0.0;

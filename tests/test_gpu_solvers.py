@@ -206,6 +206,26 @@ def test_spm_battery_ensemble_matches_oracle_bitwise_and_stops_at_the_voltage_cu
     assert reason == 1 and idx == idx_ref == 0 and abs(t_root - t_ref) < 1e-9 * t_ref and 2000.0 < t_root < 3000.0
 
 
+@pytest.mark.parametrize("env", [{"DSH_FUSE_ACCEPT": "1"}, {"DSH_NEWTON_NIT": "1"}, {"DSH_NEWTON_NIT": "4", "DSH_FUSE_ACCEPT": "1"}, {"DSH_NEWTON_PIPELINE": "0"},
+                                 {"DSH_SYNC_MODE": "sync"}])
+def test_launch_structure_knobs_do_not_change_a_single_bit(H, O, monkeypatch, env):
+    """Iterations per Newton launch, cross-step prelaunch, the fused accept+Newton launch and polling vs stream synchronisation only change how
+    the work is cut into launches: states, difference array and all counters stay bit-identical to the oracle's lock-step run."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nb = 300
+    p = robertson_params(nb)
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **ROB)
+    o = O.OracleSolver(ORACLE_MODEL["robertson_ode"], p, nbatch=nb, model_size=1, **ROB)
+    times = [0.4, 4.0, 400.0, 4e4]
+    y, _ = s.solve_to_points(times)
+    yo, _ = o.solve_to_points(times)
+    assert np.array_equal(y, yo) and np.array_equal(s.diff(), o.diff())
+    so, ss = o.stats(), s.stats()
+    assert all(ss[k] == so[k] for k in ("number_of_steps", "number_of_nonlinear_solver_iterations", "number_of_linear_solver_setups",
+                                        "number_of_error_test_failures", "number_of_nonlinear_solver_fails"))
+
+
 # ------------------------------------------------------------------ BASELINE.json config 2 at full size: size-independent properties
 @pytest.fixture(scope="module")
 def full_size_run(H):
