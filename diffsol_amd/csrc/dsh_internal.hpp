@@ -31,7 +31,14 @@ void set_error(const std::string& msg);
   } while (0)
 
 // operand nbatch must be 1 (broadcast) or the context batch size
-#define DSH_CHECK_NB(nb_op, nb) DSH_REQUIRE((nb_op) == 1 || (nb_op) == (nb), "operand nbatch must be 1 or nbatch")
+// incompatible batch sizes: the reference panics (Context::check_compatible, context/mod.rs:49-62); here a distinct error code
+#define DSH_CHECK_NB(nb_op, nb)                                                              \
+  do {                                                                                       \
+    if (!((nb_op) == 1 || (nb_op) == (nb))) {                                                \
+      ::dsh::set_error(std::string(__func__) + ": operand nbatch must be 1 or nbatch");     \
+      return DSH_E_BATCH_MISMATCH;                                                           \
+    }                                                                                        \
+  } while (0)
 
 // Reduction records.  Every reducing launch writes ONE 32-byte record per workgroup straight into pinned, device-mapped host memory:
 //   word0 = max of f64 bit patterns (non-negative values and NaN order correctly as unsigned integers: NaN > +inf > finite)

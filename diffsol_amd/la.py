@@ -36,9 +36,12 @@ class HipContext:
 
 class _CtxOwner:
     def __init__(self, L, h):
-        self.L, self.h = L, h
+        self.L, self.h, self.alive = L, h, True
 
     def __del__(self):
+        # the cyclic collector may finalise a context before buffers that still point at it (e.g. objects kept alive by a traceback):
+        # mark it dead so that their finalisers leave the (already released) device memory alone
+        self.alive = False
         try:
             self.L.dsh_ctx_destroy(self.h)
         except Exception:
@@ -54,7 +57,8 @@ class _Buf:
 
     def __del__(self):
         try:
-            self.ctx._L.dsh_free(self.ctx._h, self.p)
+            if self.ctx._owner.alive:
+                self.ctx._L.dsh_free(self.ctx._h, self.p)
         except Exception:
             pass
 
@@ -309,9 +313,89 @@ class HipMat:
             raise DiffsolHipError(-1, "gemm: shape mismatch")
         check(self.ctx._L.dsh_mat_gemm(self.ctx._h, self.nrows, self.ncols, a.ncols, self.nb, alpha, a.ptr, a.nb, b.ptr, b.nb, beta, self.ptr))
 
+    # -- the rest of the DenseMatrix surface, composed from the same C-ABI entry points the Rust shim would use
+    def flat(self):
+        """All entries as one batched vector (column after column): Matrix ops that are element-wise act on this view."""
+        return HipVec(self.ctx, self.nrows * self.ncols, _buf=self._buf, _off=0)
+
+    def copy_from(self, other):
+        self.flat().copy_from(other.flat())
+
+    def columns(self, start, end):
+        """DenseMatrix::columns(start, end): a non-owning view of columns [start, end) — contiguous in the batch-fastest layout."""
+        if not 0 <= start <= end <= self.ncols:
+            raise DiffsolHipError(-1, "Column range out of bounds")
+        return HipMatView(self, start, end)
+
+    def add_column_to_vector(self, j, v):
+        v.add_assign(self.column(j))
+
+    def mul_scalar(self, s):
+        out = HipMat(self.ctx, self.nrows, self.ncols, zero=False)
+        out.flat().copy_from(self.flat().mul(s))
+        return out
+
+    def gather(self, other, idx):
+        self.flat().gather(other.flat(), idx)
+
+    def mat_mul(self, b):
+        ctx = self.ctx if self.nb >= b.nb else b.ctx
+        c = HipMat(ctx, self.nrows, b.ncols)
+        c.gemm(1.0, self, b, 0.0)
+        return c
+
+    def resize_cols(self, ncols):
+        """DenseMatrix::resize_cols (matrix/mod.rs:399-402): keep the leading columns, zero-fill new ones."""
+        new = HipMat(self.ctx, self.nrows, ncols)
+        keep = min(ncols, self.ncols)
+        if keep:
+            HipVec(self.ctx, self.nrows * keep, _buf=new._buf).copy_from(HipVec(self.ctx, self.nrows * keep, _buf=self._buf))
+        self._buf, self.ncols = new._buf, int(ncols)
+
+    def partition_indices_by_zero_diagonal(self):
+        """Matrix::partition_indices_by_zero_diagonal (matrix/mod.rs:319-330): decided on batch member 0 like the reference."""
+        d = self.diagonal().clone_as_vec().reshape(self.nb, self.nrows)[0]
+        return [i for i in range(self.nrows) if d[i] == 0.0], [i for i in range(self.nrows) if d[i] != 0.0]
+
     def set_data_with_indices(self, dst_idx, src_idx, data):
         check(self.ctx._L.dsh_mat_set_data_with_indices(self.ctx._h, self.nrows * self.ncols, data.n, self.nb, self.ptr, dst_idx._buf.p, src_idx._buf.p,
                                                         len(dst_idx), data.ptr))
+
+
+class HipMatView:
+    """MatrixView over a column range (matrix/mod.rs:98-167): (parent buffer, first column, ncols)."""
+
+    def __init__(self, parent, start, end):
+        self.parent, self.start, self.ncols, self.nrows, self.ctx = parent, int(start), int(end - start), parent.nrows, parent.ctx
+
+    @property
+    def ptr(self):
+        return self.parent.column(self.start).ptr if self.ncols else self.parent.ptr
+
+    @property
+    def nb(self):
+        return self.parent.nb
+
+    def into_owned(self):
+        m = HipMat(self.ctx, self.nrows, self.ncols, zero=False)
+        HipVec(self.ctx, self.nrows * self.ncols, _buf=m._buf).copy_from(HipVec(self.ctx, self.nrows * self.ncols, _buf=self.parent._buf,
+                                                                                _off=self.start * self.nrows * self.nb))
+        return m
+
+    def gemv_o(self, alpha, x, beta, y):
+        if x.n != self.ncols or y.n != self.nrows:
+            raise DiffsolHipError(-1, "gemv: shape mismatch")
+        check(self.ctx._L.dsh_mat_gemv(y.ctx._h, self.nrows, self.ncols, y.nb, alpha, self.ptr, self.nb, x.ptr, x.nb, beta, y.ptr))
+
+    gemv_v = gemv_o
+
+    def gemm_vo(self, alpha, a_view, b, beta):
+        """self (a mutable column-range view) = alpha * a_view * b + beta * self"""
+        if a_view.nrows != self.nrows or b.ncols != self.ncols or a_view.ncols != b.nrows:
+            raise DiffsolHipError(-1, "gemm: shape mismatch")
+        check(self.ctx._L.dsh_mat_gemm(self.ctx._h, self.nrows, self.ncols, a_view.ncols, self.nb, alpha, a_view.ptr, a_view.nb, b.ptr, b.nb, beta, self.ptr))
+
+    gemm_oo = gemm_vo
 
 
 class HipLU:
@@ -325,7 +409,8 @@ class HipLU:
 
     def __del__(self):
         try:
-            self.ctx._L.dsh_lu_destroy(self._h)
+            if self.ctx._owner.alive:
+                self.ctx._L.dsh_lu_destroy(self._h)
         except Exception:
             pass
 
