@@ -191,3 +191,73 @@ def test_strided_column_views_of_a_larger_matrix(H, ctx1):  # make_strided_matri
     s = H.HipMat.zeros(nr, 2, ctx3)
     s.flat().copy_from(owned.flat().add(m.columns(0, 2).into_owned().flat()))
     assert np.array_equal(np.transpose(s.to_array(), (0, 2, 1)), ref + np.asarray(data).reshape(nb, nc, nr)[:, 0:2, :])
+
+
+# ------------------------------------------------------------------ vector ops on matrix-column views (vector/mod.rs:1222-1540, test_strided_view_*)
+def strided(H, ctx1, nb=2):
+    ctx = ctx1.clone_with_nbatch(nb)
+    data = np.asarray([r + c * 10.0 + b * 100.0 for b in range(nb) for c in range(4) for r in range(3)])
+    return from_vec(H, 3, 4, data, ctx), data.reshape(nb, 4, 3), ctx  # ref[b][col][row]
+
+
+def col(m, j):
+    return m.column(j).clone_as_vec()  # [b][row]
+
+
+def test_strided_view_set_index_copy_from_axpy_scale(H, ctx1):  # :1238-1304
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).set_index(1, 99.0)
+    assert col(m, 1)[:, 1].tolist() == [99.0, 99.0] and np.array_equal(col(m, 0), ref[:, 0]) and np.array_equal(col(m, 2), ref[:, 2])
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).copy_from(vec(H, [50, 51, 52], ctx1))  # broadcast owned vector into the view
+    assert col(m, 1).tolist() == [[50.0, 51.0, 52.0]] * 2
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).axpy(2.0, vec(H, [10, 10, 10], ctx1), 1.0)
+    assert col(m, 1)[1].tolist() == [130.0, 131.0, 132.0] and col(m, 1)[0].tolist() == [30.0, 31.0, 32.0]
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).mul_assign(2.0)
+    assert np.array_equal(col(m, 1), 2.0 * ref[:, 1]) and np.array_equal(col(m, 3), ref[:, 3])
+
+
+def test_strided_view_add_sub_assign_and_broadcast(H, ctx1):  # :1306-1393
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).add_assign(m.column(2))  # view += view of the same matrix
+    assert np.array_equal(col(m, 1), ref[:, 1] + ref[:, 2])
+    m.column(3).sub_assign(m.column(0))
+    assert np.array_equal(col(m, 3), ref[:, 3] - ref[:, 0])
+    m, ref, ctx = strided(H, ctx1)
+    m.column(2).add_assign(vec(H, [1, 2, 3], ctx1))  # broadcast operand
+    assert np.array_equal(col(m, 2), ref[:, 2] + np.array([1.0, 2.0, 3.0]))
+    s = m.column(0).add(vec(H, np.ones(6), ctx))  # view + owned -> owned
+    assert np.array_equal(s.clone_as_vec(), ref[:, 0] + 1.0)
+
+
+def test_strided_view_norms_component_ops_fill_and_index_ops(H, ctx1):  # :1395-1540
+    m, ref, ctx = strided(H, ctx1)
+    atol = vec(H, [1e-3, 1e-3, 1e-3], ctx1)
+    y = vec(H, np.ones(6), ctx)
+    expect = max(np.mean((ref[b, 1] / (1.0 * 0.1 + 1e-3)) ** 2) for b in range(2))
+    assert np.isclose(m.column(1).squared_norm(y, atol, 0.1), expect, rtol=1e-14)
+    assert np.array_equal(m.column(2).clone().clone_as_vec(), ref[:, 2])  # into_owned
+    m.column(1).component_mul_assign(m.column(3))
+    assert np.array_equal(col(m, 1), ref[:, 1] * ref[:, 3])
+    m.column(3).component_div_assign(vec(H, [2, 4, 8], ctx1))
+    assert np.array_equal(col(m, 3), ref[:, 3] / np.array([2.0, 4.0, 8.0]))
+    assert np.array_equal(m.column(2).mul(3.0).clone_as_vec(), 3.0 * ref[:, 2])
+    m.column(0).fill(7.0)
+    assert (col(m, 0) == 7.0).all() and np.array_equal(col(m, 2), ref[:, 2])
+    m, ref, ctx = strided(H, ctx1)
+    m.column(1).assign_at_indices(H.HipIndex([0, 2], ctx1), -1.0)
+    assert col(m, 1).tolist() == [[-1.0, 11.0, -1.0], [-1.0, 111.0, -1.0]]
+    m.column(2).copy_from_indices(m.column(3), H.HipIndex([1], ctx1))
+    assert col(m, 2).tolist() == [[20.0, 31.0, 22.0], [120.0, 131.0, 122.0]]
+    g = H.HipVec.zeros(2, ctx)
+    g.gather(m.column(3), H.HipIndex([2, 0], ctx1))
+    assert g.clone_as_vec().tolist() == [[32.0, 30.0], [132.0, 130.0]]
+    m, ref, ctx = strided(H, ctx1)
+    result = H.HipVec.zeros(3, ctx)
+    m.column(1).clone().scatter(H.HipIndex([0, 1, 2], ctx1), result)  # other[idx[i]] = self[i]
+    assert result.clone_as_vec().tolist() == [[10.0, 11.0, 12.0], [110.0, 111.0, 112.0]]
+    result2 = H.HipVec.zeros(3, ctx)
+    m.column(3).scatter(H.HipIndex([2, 0], ctx1), result2)  # a view as the source, permuting indices
+    assert result2.clone_as_vec().tolist() == [[31.0, 0.0, 30.0], [131.0, 0.0, 130.0]]
