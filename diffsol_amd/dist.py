@@ -48,10 +48,12 @@ def gather_batch_axis(local, n_total, rank, world, group=None):
 
 
 def solve_ensemble_sharded(model, params, t_eval, *, rank, world, device, method=0, model_size=0, gather=True, group=None, solver_factory=None,
-                           **solver_kw):
+                           resident=None, **solver_kw):
     """Integrate this rank's shard of the ensemble and (optionally) gather the interpolated trajectories.
 
     params: [n_total, nparams] on every rank (the parameter sweep is generated deterministically from a seed, so nothing is scattered).
+    resident: None = host-driven lock-step solve_dense; 1 / 64 = the device-resident kernel with per-member / wavefront lock-step control
+    (Solver.solve_dense_adaptive; `stats` are then the shard's totals).
     Returns (y, stats) with y a torch tensor [nt, nstates, n_total] if gather else [nt, nstates, nb_local] (batch-fastest)."""
     import torch
 
@@ -67,14 +69,22 @@ def solve_ensemble_sharded(model, params, t_eval, *, rank, world, device, method
     s = solver_factory(params[lo:hi])
     nt = len(t_eval)
     on_gpu = torch.cuda.is_available() and not getattr(s, "cpu_stub", False)
+    stats = None
     if on_gpu:
         out = torch.empty((nt, s.n, hi - lo), dtype=torch.float64, device=f"cuda:{device}")
-        s.solve_dense(t_eval, want_host=False, dev_ptr=out.data_ptr())
+        if resident:
+            _, stats = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=out.data_ptr(), group=resident)
+        else:
+            s.solve_dense(t_eval, want_host=False, dev_ptr=out.data_ptr())
         torch.cuda.synchronize(device)
     else:
-        y_host, _ = s.solve_dense(t_eval)  # [nt, nb, n]
+        if resident:
+            y_host, stats = s.solve_dense_adaptive(t_eval, group=resident)  # [nt, nb, n]
+        else:
+            y_host, _ = s.solve_dense(t_eval)
         out = torch.from_numpy(np.ascontiguousarray(np.transpose(y_host, (0, 2, 1))))
-    stats = s.stats()
+    if stats is None:
+        stats = s.stats()
     if gather:
         out = gather_batch_axis(out, n_total, rank, world, group=group)
     return out, stats

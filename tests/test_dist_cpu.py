@@ -45,6 +45,10 @@ class _StubSolver:
         y = self.p[None, :, 1:2] * np.exp(-self.p[None, :, 0:1] * t) * np.ones((1, 1, 2))
         return y, 2
 
+    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, group=1):
+        y, _ = self.solve_dense(t_eval)
+        return y, {"number_of_steps": 5 * self.nbatch * group, "number_of_nonlinear_solver_iterations": 9 * self.nbatch}
+
     def stats(self):
         return {"number_of_steps": 7, "number_of_nonlinear_solver_iterations": 11}
 
@@ -60,6 +64,11 @@ def _worker(rank, world, port, n_total, q):
         ref = params[None, :, 1:2] * np.exp(-params[None, :, 0:1] * np.asarray(t_eval)[:, None, None]) * np.ones((1, 1, 2))
         ref = np.transpose(ref, (0, 2, 1))  # [nt, n, N] batch-fastest
         ok = tuple(y.shape) == (3, 2, n_total) and np.array_equal(y.numpy(), ref)
+        # the device-resident modes go through the same shard / gather path
+        lo_, hi_ = shard_bounds(n_total, rank, world)
+        for g_ in (1, 64):
+            y2, st2 = solve_ensemble_sharded("exponential_decay", params, t_eval, rank=rank, world=world, device=0, solver_factory=_StubSolver, resident=g_)
+            ok = ok and np.array_equal(y2.numpy(), ref) and st2["number_of_steps"] == 5 * (hi_ - lo_) * g_
         # plain gather of a ragged last axis
         lo, hi = shard_bounds(n_total, rank, world)
         local = torch.arange(lo, hi, dtype=torch.float64).repeat(4, 1)
