@@ -198,3 +198,50 @@ def test_oracle_convergence_state_machine(O):
     assert status[1] == 1  # rate > 0.9 => diverged
     status, _ = O.convergence_trace([1.0, 0.8])
     assert status[1] == 1  # 0.8^8/(0.2)*0.8 = 0.67 > 0.2 => will not converge in max_iter
+
+
+# ------------------------------------------------------------------ per-member / grouped solve_dense (checker of the device-resident kernels)
+def test_oracle_solve_dense_independent_matches_single_solver_runs(O):
+    """solve_dense_independent(group=1) is N separate OracleSolver runs; group=G is one lock-step batched run per group of G (ragged tail)."""
+    rng = np.random.default_rng(3)
+    p = np.stack([np.exp(rng.uniform(np.log(0.02), np.log(0.08), 10)), np.exp(rng.uniform(np.log(0.5e4), np.log(2e4), 10)),
+                  np.exp(rng.uniform(np.log(1.5e7), np.log(6e7), 10))], axis=1)
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    t_eval = [0.4, 4.0, 40.0]
+    y, stats, failed = O.solve_dense_independent(O.MODEL_ROBERTSON_ODE, p, t_eval, model_size=1, nthreads=2, **tol)
+    assert failed == 0 and y.shape == (10, 3, 3)
+    for b in (0, 7):
+        s = O.OracleSolver(O.MODEL_ROBERTSON_ODE, p[b], model_size=1, **tol)
+        s.set_stop_time(t_eval[-1])
+        col, out = 0, np.full((3, 3), np.nan)
+        while col < 3:
+            r = s.step()
+            while col < 3 and t_eval[col] <= s.state()["t"]:
+                out[col] = s.interpolate(t_eval[col])[0]
+                col += 1
+            if r == 2:
+                break
+        assert np.array_equal(out, y[b]) and stats[b, 0] == s.stats()["number_of_steps"]
+    yg, sg, failed = O.solve_dense_independent(O.MODEL_ROBERTSON_ODE, p, t_eval, model_size=1, nthreads=2, group=4, **tol)
+    assert failed == 0
+    assert (sg[0:4] == sg[0]).all() and (sg[4:8] == sg[4]).all() and (sg[8:10] == sg[8]).all()  # groups 4 + 4 + 2 share their counters
+    assert sg[0, 0] >= stats[0:4, 0].max() - 5  # a lock-step group takes about as many steps as its stiffest member (not fewer, give or take)
+    assert np.allclose(yg, y, rtol=5e-3, atol=1e-9)
+
+
+def test_oracle_solve_dense_stops_each_member_at_its_own_root(O):
+    """solve_dense's stop-at-root contract (method.rs:498-516), per member: drained save points, then the state at the root, then NaN."""
+    k = np.array([0.05, 0.2, 1.0, 2.0])
+    p = np.stack([k, np.ones(4)], axis=1)
+    t_eval = [0.5, 1.0, 2.0, 4.0, 8.0]
+    y, stats, failed = O.solve_dense_independent(O.MODEL_EXPONENTIAL_DECAY_ROOT, p, t_eval, rtol=1e-6, atol=[1e-6, 1e-6], nthreads=1)
+    roots = O.solve_dense_independent.last_roots
+    assert failed == 0
+    t_exact = -np.log(0.6) / k  # 10.2 (never reached), 2.55, 0.51, 0.255
+    assert roots["root_idx"].tolist() == [-1, 0, 0, 0] and np.isnan(roots["t_root"][0])
+    assert np.allclose(roots["t_root"][1:], t_exact[1:], rtol=1e-4)
+    assert roots["ncols"].tolist() == [5, 4, 2, 1]
+    for b in (1, 2, 3):
+        nc = roots["ncols"][b]
+        assert abs(y[b, nc - 1, 0] - 0.6) < 1e-5 and np.isnan(y[b, nc:]).all() and np.isfinite(y[b, :nc]).all()
+    assert np.isfinite(y[0]).all()
