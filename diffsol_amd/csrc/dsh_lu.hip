@@ -128,18 +128,30 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
       } else {  // one workgroup per system
         const size_t budget = 140 * 1024;
         static bool attr_set = false;
+        static const int wg_threads = [] { const char* e = getenv("DSH_LU_BLOCKED_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob: 256 | 512
+        // measured (profiles/r01_lu_bench.md): 512 threads win for n around 512 (58 vs 71 ms at 512 x 4096), lose below 384 and at 1024
+        const int threads = wg_threads == 256 || wg_threads == 512 ? wg_threads : (n >= 384 && n < 900 ? 512 : 256);
         if (!attr_set) {
-          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
-          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
-          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<16, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
           attr_set = true;
         }
         static const bool phase_profile = [] { const char* e = getenv("DSH_LU_PHASE_PROFILE"); return e && atoi(e) != 0; }();
         unsigned long long* phase_clocks = nullptr;
         if (phase_profile) { DSH_HIP_CHECK(hipMalloc(&phase_clocks, 8 * sizeof(unsigned long long))); DSH_HIP_CHECK(hipMemset(phase_clocks, 0, 8 * sizeof(unsigned long long))); }
-#define DSH_LU_BLOCKED(NBK)                                                                                                                       \
-  hipLaunchKernelGGL((k_lu_factor_blocked<NBK>), dim3((unsigned)nb), dim3(kCoopThreads), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
-                     lu->pivots, lu->singular, lu->singular_epoch, phase_clocks)
+#define DSH_LU_BLOCKED(NBK)                                                                                                                             \
+  do {                                                                                                                                                  \
+    if (threads == 512)                                                                                                                                 \
+      hipLaunchKernelGGL((k_lu_factor_blocked<NBK, 512>), dim3((unsigned)nb), dim3(512), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
+                         lu->pivots, lu->singular, lu->singular_epoch, phase_clocks);                                                                   \
+    else                                                                                                                                                \
+      hipLaunchKernelGGL((k_lu_factor_blocked<NBK, 256>), dim3((unsigned)nb), dim3(256), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
+                         lu->pivots, lu->singular, lu->singular_epoch, phase_clocks);                                                                   \
+  } while (0)
         if (blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
         else if (blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
         else if (blocked_lds_bytes(n, 8) <= budget) DSH_LU_BLOCKED(8);

@@ -128,12 +128,14 @@ __global__ void k_lu_solve_global_coop(int n, int64_t nb, const double* __restri
 // Blocked right-looking LU, one workgroup per system, for systems too large for LDS (n > ~137).  Panels of NB columns are factored in LDS
 // (partial pivoting over the whole remaining column, as the unblocked algorithm does); the panel's row swaps are then applied to the other
 // columns, U12 = L11^-1 A12 is formed one column per thread, and the trailing matrix gets its NB rank-1 updates in one pass:
-// thread = row (coalesced column-major access), its NB multipliers l_rk in registers, the U12 block broadcast from LDS.
+// thread = row (coalesced column-major access), its NB multipliers l_rk in registers, the U12 block broadcast from LDS.  THREADS = 256 or 512:
+// 62 % of the wave cycles of the 256-thread version are s_waitcnt stalls (LDS broadcast / global latency with ONE wavefront per SIMD,
+// profiles/r01_lu_bench.md), so larger systems run two wavefronts per SIMD.
 // Every element still receives exactly the updates a_rc = (-u_kc) * l_rk + a_rc for k ascending, each as a separate multiply and add, so
 // the factors are bit-identical to the unblocked kernels and the oracle; only the number of passes over the trailing matrix changes
 // (n/NB instead of n): HBM/L2 traffic per system ~ 16 n^3 / (3 NB) bytes instead of 16 n^3 / 3.
-template <int NB>
-__global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
+template <int NB, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_lu_factor_blocked(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
                                                                    unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
   // optional phase profile (DSH_LU_PHASE_PROFILE=1): workgroup 0 accumulates the 100 MHz wall clock per phase
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
   extern __shared__ double sh[];  // panel (ldp x NB) during the panel factorisation, then the U12 block (mc x LDU)
-  __shared__ double s_best[kCoopThreads / 64];
-  __shared__ int s_row[kCoopThreads / 64];
+  __shared__ double s_best[THREADS / 64];
+  __shared__ int s_row[THREADS / 64];
   __shared__ int s_piv[NB];
   __shared__ double s_l11[NB * (NB + 1)];
   constexpr int LDU = NB + 2;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     const int m = n - jb;
     // ---- 1. panel -> LDS
     for (int c = 0; c < w; ++c)
-      for (int r = tid; r < m; r += kCoopThreads) sh[c * ldp + r] = A[(size_t)(jb + c) * n + jb + r];
+      for (int r = tid; r < m; r += THREADS) sh[c * ldp + r] = A[(size_t)(jb + c) * n + jb + r];
     __syncthreads();
     mark(0);
     // ---- 2. unblocked factorisation of the m x w panel
@@ -165,13 +167,13 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       double* col = sh + k * ldp;
       double best = -1.0;
       int prow = m;
-      for (int r = k + tid; r < m; r += kCoopThreads) { double v = fabs(col[r]); if (v > best) { best = v; prow = r; } }
+      for (int r = k + tid; r < m; r += THREADS) { double v = fabs(col[r]); if (v > best) { best = v; prow = r; } }
       group_argmax(best, prow, 64);
       if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_row[tid >> 6] = prow; }
       __syncthreads();
       best = s_best[0]; prow = s_row[0];
 #pragma unroll
-      for (int j = 1; j < kCoopThreads / 64; ++j) {
+      for (int j = 1; j < THREADS / 64; ++j) {
         const double ob = s_best[j];
         const int orow = s_row[j];
         if (ob > best || (ob == best && orow < prow)) { best = ob; prow = orow; }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
       __syncthreads();
       if (!zero) {
         const double inv_diag = 1.0 / diag;
-        for (int r = k + 1 + tid; r < m; r += kCoopThreads) {
+        for (int r = k + 1 + tid; r < m; r += THREADS) {
           const double l = col[r] * inv_diag;
           col[r] = l;
           for (int c = k + 1; c < w; ++c) sh[c * ldp + r] = (-sh[c * ldp + k]) * l + sh[c * ldp + r];
@@ -197,16 +199,16 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     mark(1);
     // ---- 3. panel and pivots back to global memory; L11 to its own LDS block
     for (int c = 0; c < w; ++c)
-      for (int r = tid; r < m; r += kCoopThreads) A[(size_t)(jb + c) * n + jb + r] = sh[c * ldp + r];
+      for (int r = tid; r < m; r += THREADS) A[(size_t)(jb + c) * n + jb + r] = sh[c * ldp + r];
     if (tid < w) PIV[jb + tid] = s_piv[tid];
-    for (int idx = tid; idx < NB * NB; idx += kCoopThreads) {
+    for (int idx = tid; idx < NB * NB; idx += THREADS) {
       const int r = idx % NB, c = idx / NB;
       s_l11[c * (NB + 1) + r] = (r < w && c < w) ? sh[c * ldp + r] : 0.0;
     }
     __syncthreads();
     mark(2);
     // ---- 4. the panel's row interchanges on every other column (one thread per column)
-    for (int c = tid; c < n; c += kCoopThreads) {
+    for (int c = tid; c < n; c += THREADS) {
       if (c >= jb && c < jb + w) continue;
       double* colg = A + (size_t)c * n;
       for (int k = 0; k < w; ++k) {
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     const int mc = n - jb - w;  // trailing columns
     if (mc <= 0) break;
     // ---- 5. U12 = L11^-1 A12, one column per thread; kept in LDS.  Trailing columns exist only behind a full panel: w == NB from here on.
-    for (int cc = tid; cc < mc; cc += kCoopThreads) {
+    for (int cc = tid; cc < mc; cc += THREADS) {
       double* colg = A + (size_t)(jb + w + cc) * n + jb;
       double a[NB];
 #pragma unroll
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_factor_blocked(int n, int64
     __syncthreads();
     mark(4);
     // ---- 6. trailing update: thread = row, NB multipliers in registers, 4 columns in flight
-    for (int r = jb + w + tid; r < n; r += kCoopThreads) {
+    for (int r = jb + w + tid; r < n; r += THREADS) {
       double l[NB];
 #pragma unroll
       for (int k = 0; k < NB; ++k) l[k] = A[(size_t)(jb + k) * n + r];
