@@ -205,8 +205,13 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
         else DSH_LU_WAVE(64, 64);
 #undef DSH_LU_WAVE
       } else {
-        hipLaunchKernelGGL(k_lu_solve_global_coop, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
-                           (const int32_t*)lu->pivots, rhs, rec, seq);
+        static const bool blocked_solve = [] { const char* e = getenv("DSH_LU_BLOCKED_SOLVE"); return !e || atoi(e) != 0; }();
+        if (blocked_solve)
+          hipLaunchKernelGGL(k_lu_solve_blocked, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
+                             (const int32_t*)lu->pivots, rhs, rec, seq);
+        else
+          hipLaunchKernelGGL(k_lu_solve_global_coop, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
+                             (const int32_t*)lu->pivots, rhs, rec, seq);
       }
     }
   }

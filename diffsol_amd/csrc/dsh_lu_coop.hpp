@@ -292,4 +292,90 @@ inline size_t blocked_lds_bytes(int64_t n, int nbk) {
   return sizeof(double) * (panel > ublock ? panel : ublock);
 }
 
+// Blocked triangular solves for n > 64, one workgroup per system, rhs in LDS, factors streamed once from HBM.  The unblocked kernel above needs two
+// workgroup barriers per column (2n for L, 2n for U); here the B = 8 columns of a block are eliminated together: the 8 x 8 diagonal block by eight
+// lanes of the first wavefront (shuffles), then every other row takes its eight updates v_r = (-v_k) * a_rk + v_r in the same k order as the
+// column-by-column algorithm — bit-identical — with the eight loads of the row in flight together.  n/4 barriers instead of 4n.
+constexpr int kSolveBlock = 8;
+__global__ __launch_bounds__(kCoopThreads) void k_lu_solve_blocked(int n, int64_t nb, const double* __restrict__ f_aos, const int32_t* __restrict__ piv_aos,
+                                                                  double* __restrict__ rhs, unsigned long long* rec, unsigned int seq) {
+  extern __shared__ double v[];
+  constexpr int B = kSolveBlock;
+  const int64_t b = blockIdx.x;
+  const double* A = f_aos + (size_t)b * n * n;
+  const int tid = threadIdx.x;
+  for (int r = tid; r < n; r += kCoopThreads) v[r] = rhs[(int64_t)r * nb + b];
+  __syncthreads();
+  if (tid == 0) {  // the recorded interchanges, in order (sequentially dependent: n cheap LDS operations by one lane)
+    const int32_t* P = piv_aos + (size_t)b * n;
+    for (int i = 0; i < n; ++i) { const int p = P[i]; if (p != i) { const double tmp = v[i]; v[i] = v[p]; v[p] = tmp; } }
+  }
+  __syncthreads();
+  // ---- L y = P b (unit lower triangle)
+  for (int kb = 0; kb < n; kb += B) {
+    const int w = (n - kb) < B ? (n - kb) : B;
+    if (tid < 64) {  // diagonal block: lane j owns row kb + j
+      const int j = tid;
+      double a[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) a[i] = (j < w && i < j) ? A[(size_t)(kb + i) * n + kb + j] : 0.0;
+      double vj = j < w ? v[kb + j] : 0.0;
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        const double vi = __shfl(vj, i, 64);
+        if (i < j && j < w) vj = (-vi) * a[i] + vj;
+      }
+      if (j < w) v[kb + j] = vj;
+    }
+    __syncthreads();
+    for (int r = kb + w + tid; r < n; r += kCoopThreads) {
+      double a[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) a[i] = i < w ? A[(size_t)(kb + i) * n + r] : 0.0;
+      double vr = v[r];
+#pragma unroll
+      for (int i = 0; i < B; ++i) if (i < w) vr = (-v[kb + i]) * a[i] + vr;
+      v[r] = vr;
+    }
+    __syncthreads();
+  }
+  // ---- U x = y
+  bool ok = true;
+  const int last = ((n - 1) / B) * B;
+  for (int kb = last; kb >= 0; kb -= B) {
+    const int w = (n - kb) < B ? (n - kb) : B;
+    if (tid < 64) {  // diagonal block, columns kb+w-1 down to kb: lane j owns row kb + j
+      const int j = tid;
+      double a[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) a[i] = (j < w && i < w && i >= j) ? A[(size_t)(kb + i) * n + kb + j] : 1.0;
+      double vj = j < w ? v[kb + j] : 0.0;
+#pragma unroll
+      for (int i = B - 1; i >= 0; --i) {
+        if (i < w) {
+          const double diag = __shfl(a[i], i, 64);  // U(kb+i, kb+i), held by lane i
+          if (diag == 0.0) ok = false;
+          const double coeff = __shfl(vj, i, 64) / diag;
+          if (j == i) vj = coeff;
+          else if (j < i) vj = (-coeff) * a[i] + vj;
+        }
+      }
+      if (j < w) v[kb + j] = vj;
+    }
+    __syncthreads();
+    for (int r = tid; r < kb; r += kCoopThreads) {
+      double a[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) a[i] = i < w ? A[(size_t)(kb + i) * n + r] : 0.0;
+      double vr = v[r];
+#pragma unroll
+      for (int i = B - 1; i >= 0; --i) if (i < w) vr = (-v[kb + i]) * a[i] + vr;
+      v[r] = vr;
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += kCoopThreads) rhs[(int64_t)r * nb + b] = v[r];
+  block_publish(0ull, 0ull, (tid == 0 && !ok) ? 1ull : 0ull, rec, seq);
+}
+
 }  // namespace dsh
