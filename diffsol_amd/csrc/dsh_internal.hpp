@@ -128,18 +128,36 @@ __device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned l
 // NaN-propagating maximum in the bit-pattern domain (inputs are squares / counts: never negative zero or negative)
 __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 
+// Wavefront reductions without the LDS crossbar: four DPP butterfly stages inside each row of 16 lanes (quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror — after every stage the lanes of a 2/4/8/16-group hold the same value, so the mirrors act as xor 4 / xor 8), then the
+// four row results are read with v_readlane and combined as scalars.  ~35 VALU instructions instead of six dependent ds_bpermute round trips.
+// All 64 lanes must be active (every caller reduces over whole wavefronts).
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v) {
+  int lo = (int)(unsigned int)v, hi = (int)(unsigned int)(v >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(unsigned int)v, lane), hi = __builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), lane);
+  return ((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo;
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140;
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    unsigned long long o = __shfl_xor(v, off, 64);
-    v = umax64(v, o);
-  }
-  return v;
+  v = umax64(v, dpp_move_u64<kDppQuadXor1>(v));
+  v = umax64(v, dpp_move_u64<kDppQuadXor2>(v));
+  v = umax64(v, dpp_move_u64<kDppRowHalfMirror>(v));
+  v = umax64(v, dpp_move_u64<kDppRowMirror>(v));
+  return umax64(umax64(readlane_u64(v, 0), readlane_u64(v, 16)), umax64(readlane_u64(v, 32), readlane_u64(v, 48)));
 }
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_move_u64<kDppQuadXor1>(v);
+  v += dpp_move_u64<kDppQuadXor2>(v);
+  v += dpp_move_u64<kDppRowHalfMirror>(v);
+  v += dpp_move_u64<kDppRowMirror>(v);
+  return (readlane_u64(v, 0) + readlane_u64(v, 16)) + (readlane_u64(v, 32) + readlane_u64(v, 48));
 }
 
 __device__ __forceinline__ void publish_singular(unsigned long long* word, unsigned long long count, unsigned int epoch) {

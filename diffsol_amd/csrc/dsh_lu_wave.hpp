@@ -44,11 +44,27 @@ template <int K, int NP, int GW>
 __device__ __forceinline__ void elim_step(double (&a)[NP], double l, bool below, int P, double& nextcol) {
   // Broadcasts stay outside predicated code: reading a lane that is masked off (the pivot lane is never `below`) is undefined.
   if (below) a[K] = l;
+  if constexpr (GW == 64) {
+    // chunks of 8 columns: the pivot-row entries of a chunk are read into scalar registers with all lanes active, then the rows below the pivot
+    // update under ONE predicate per chunk (2 v_readlane + v_mul + v_add per element instead of + 2 v_cndmask)
+    constexpr int CH = 8;
 #pragma unroll
-  for (int c = K + 1; c < NP; ++c) {
-    const double u = group_bcast<GW>(a[c], P);
-    const double upd = (-u) * l + a[c];
-    a[c] = below ? upd : a[c];
+    for (int c0 = K + 1; c0 < NP; c0 += CH) {
+      double u[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) u[q] = (c0 + q < NP) ? group_bcast<GW>(a[(c0 + q < NP) ? c0 + q : K], P) : 0.0;
+      if (below) {
+#pragma unroll
+        for (int q = 0; q < CH; ++q) if (c0 + q < NP) a[(c0 + q < NP) ? c0 + q : K] = (-u[q]) * l + a[(c0 + q < NP) ? c0 + q : K];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = K + 1; c < NP; ++c) {
+      const double u = group_bcast<GW>(a[c], P);
+      const double upd = (-u) * l + a[c];
+      a[c] = below ? upd : a[c];
+    }
   }
   if constexpr (K + 1 < NP) nextcol = a[K + 1];
 }
