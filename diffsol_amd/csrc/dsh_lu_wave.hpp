@@ -72,20 +72,13 @@ __device__ __forceinline__ void elim_step(double (&a)[NP], double l, bool below,
 // Rows never move between lanes: `pos` is the position the lane's row currently has in the (conceptually) interchanged matrix.  A pivot step
 // picks the candidate with the largest |a| — smallest position on ties, i.e. the first maximum of the sequential scan — and exchanges two
 // position numbers instead of two rows; a row's final position is the step at which it became the pivot row, and that is where it is stored.
+// The factorisation itself, on rows already in registers (used by the kernel below and by the wavefront-per-member integrator): on return lane L's
+// row holds its L and U entries, `pos` the row's final position (P A = L U with row pos^-1(k) of A at position k), `mypiv` the LAPACK-style pivot
+// record of position `pos`.  `live` / `rowlive`: this group holds a system / this lane holds one of its rows.
 template <int NP, int GW>
-__global__ __launch_bounds__(kWaveLuThreads) void k_lu_factor_wave(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
-                                                                   unsigned long long* singular_word, unsigned int epoch) {
-  const int gl = threadIdx.x % GW;
-  const int gbase = (threadIdx.x & 63) - gl;  // first lane of this group inside the wavefront
-  const int64_t b = ((int64_t)blockIdx.x * kWaveLuThreads + threadIdx.x) / GW;
-  const bool live = b < nb, rowlive = live && gl < n;
-  double* F = f_aos + (size_t)(live ? b : 0) * n * n;
-  double a[NP];
-#pragma unroll
-  for (int c = 0; c < NP; ++c) a[c] = (rowlive && c < n) ? F[(size_t)c * n + gl] : 0.0;
+__device__ __forceinline__ void wave_lu_factor_rows(double (&a)[NP], int n, bool live, bool rowlive, int gl, int gbase, int& pos, int& mypiv, bool& singular) {
   double colk = a[0];
-  int pos = gl, mypiv = gl;
-  bool singular = false;
+  pos = gl; mypiv = gl;
   for (int k = 0; k < n; ++k) {
     double best = -1.0;
     int p = n;
@@ -122,6 +115,51 @@ __global__ __launch_bounds__(kWaveLuThreads) void k_lu_factor_wave(int n, int64_
 #undef DSH_ELIM_CASE
     colk = nextcol;
   }
+}
+
+// Solve with the rows where the factorisation left them (whole-wavefront groups): lane L keeps ITS right-hand-side entry — it travels with the
+// lane's row, i.e. it sits at position pos[L] of P b without any data movement.  Positions are eliminated in order; the lane holding position k is
+// found with a ballot and read with v_readlane.  On return lane L holds the unknown number pos[L]; `unknown_of_lane` moves x_i to lane i.
+// Arithmetic and order are those of lu_solve_reg / the oracle (column-oriented substitutions).
+template <int NP>
+__device__ __forceinline__ bool wave_lu_solve_rows(const double (&a)[NP], int n, bool rowlive, int pos, double& v) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {  // L y = P b (unit lower triangle)
+    if (k + 1 < n) {
+      const int holder = __ffsll((unsigned long long)__ballot(rowlive && pos == k)) - 1;
+      const double coeff = group_bcast<64>(v, holder);
+      if (rowlive && pos > k) v = (-coeff) * a[k] + v;
+    }
+  }
+#pragma unroll
+  for (int k = NP - 1; k >= 0; --k) {  // U x = y
+    if (k < n) {
+      const int holder = __ffsll((unsigned long long)__ballot(rowlive && pos == k)) - 1;
+      const double diag = group_bcast<64>(a[k], holder);
+      if (diag == 0.0) ok = false;
+      const double coeff = group_bcast<64>(v, holder) / diag;
+      if (rowlive && pos == k) v = coeff;
+      else if (rowlive && pos < k) v = (-coeff) * a[k] + v;
+    }
+  }
+  return ok;
+}
+
+template <int NP, int GW>
+__global__ __launch_bounds__(kWaveLuThreads) void k_lu_factor_wave(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
+                                                                   unsigned long long* singular_word, unsigned int epoch) {
+  const int gl = threadIdx.x % GW;
+  const int gbase = (threadIdx.x & 63) - gl;  // first lane of this group inside the wavefront
+  const int64_t b = ((int64_t)blockIdx.x * kWaveLuThreads + threadIdx.x) / GW;
+  const bool live = b < nb, rowlive = live && gl < n;
+  double* F = f_aos + (size_t)(live ? b : 0) * n * n;
+  double a[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) a[c] = (rowlive && c < n) ? F[(size_t)c * n + gl] : 0.0;
+  int pos, mypiv;
+  bool singular = false;
+  wave_lu_factor_rows<NP, GW>(a, n, live, rowlive, gl, gbase, pos, mypiv, singular);
   if (rowlive) {
 #pragma unroll
     for (int c = 0; c < NP; ++c) if (c < n) F[(size_t)c * n + pos] = a[c];
