@@ -160,6 +160,40 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return (readlane_u64(v, 0) + readlane_u64(v, 16)) + (readlane_u64(v, 32) + readlane_u64(v, 48));
 }
 
+// (|value|, row) arg-max with smallest row on ties, reduced over the `tps` consecutive lanes of a system (tps is a power of two <= 64
+// and the group is aligned inside a wave, so xor-shuffles below tps stay inside the group)
+// The four stages inside a row of 16 lanes are DPP moves (no LDS crossbar, see wave_max_u64); wider groups finish with shuffles (32) or with four
+// v_readlane per value (64).  All lanes of the wavefront must be active.
+__device__ __forceinline__ void argmax_take(double& best, int& row, double ob, int orow) {
+  if (ob > best || (ob == best && orow < row)) { best = ob; row = orow; }
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp_stage(double& best, int& row) {
+  const double ob = __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(best)));
+  const int orow = __builtin_amdgcn_update_dpp(row, row, CTRL, 0xf, 0xf, false);
+  argmax_take(best, row, ob, orow);
+}
+__device__ __forceinline__ void group_argmax(double& best, int& row, int tps) {
+  if (tps >= 16) {
+    argmax_dpp_stage<kDppQuadXor1>(best, row);
+    argmax_dpp_stage<kDppQuadXor2>(best, row);
+    argmax_dpp_stage<kDppRowHalfMirror>(best, row);
+    argmax_dpp_stage<kDppRowMirror>(best, row);
+    if (tps == 32) {
+      argmax_take(best, row, __shfl_xor(best, 16, 64), __shfl_xor(row, 16, 64));
+    } else if (tps == 64) {
+      double b0 = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(best), 0));
+      int r0 = __builtin_amdgcn_readlane(row, 0);
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        argmax_take(b0, r0, __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(best), 16 * q)), __builtin_amdgcn_readlane(row, 16 * q));
+      best = b0; row = r0;
+    }
+    return;
+  }
+  for (int off = tps >> 1; off > 0; off >>= 1) argmax_take(best, row, __shfl_xor(best, off, 64), __shfl_xor(row, off, 64));
+}
+
 __device__ __forceinline__ void publish_singular(unsigned long long* word, unsigned long long count, unsigned int epoch) {
   unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (true) {

@@ -69,6 +69,8 @@ class OdeEquations {
   virtual void init_call_inplace(double t, HipVec& y) const = 0;
   virtual void root_call_inplace(const HipVec& x, double t, HipVec& g) const = 0;
   virtual bool fused_model(int* model, int64_t* size) const { (void)model; (void)size; return false; }
+  // registry id of the model when it is one of libdiffsol_hip's built-in device models (fused or not)
+  virtual bool registry_model(int*, int64_t*) const { return false; }
   virtual const HipVec& params() const = 0;
   mutable OpStatistics rhs_statistics;
 };
@@ -116,6 +118,7 @@ class HipKernelEquations : public OdeEquations {
     check(dsh_model_root(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), g.ptr()), "root");
   }
   bool fused_model(int* model, int64_t* size) const override { if (!fused_) return false; *model = model_; *size = size_; return true; }
+  bool registry_model(int* model, int64_t* size) const override { *model = model_; *size = size_; return true; }
   const HipVec& params() const override { return p_; }
   void count_fused_rhs_call() const { rhs_statistics.number_of_calls++; }
 

@@ -259,8 +259,14 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int model = 0;
     int64_t size = 0;
     const int method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
-    if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size))
-      throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4 only)");
+    bool wave_member = false;
+    if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size)) {
+      // run-time-sized models: one wavefront per member (BDF, identity mass, n <= 64)
+      wave_member = method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size) && !s->problem.eqn->has_mass();
+      if (!wave_member)
+        throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
+                                         "run-time-sized ODE models with n <= 64: BDF)");
+    }
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
     const OdeSolverOptions& oo = s->problem.ode_options;
     const InitialConditionSolverOptions& ic = s->problem.ic_options;
@@ -302,7 +308,10 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
       if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
     }
     int rc;
-    if (method == 0)
+    if (wave_member)
+      rc = dsh_bdf_solve_wave_member(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                     t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
+    else if (method == 0)
       rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
                                   t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
     else

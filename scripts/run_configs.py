@@ -99,6 +99,26 @@ def run_spm(nb, t_final=1200.0):
                 finite=bool(np.isfinite(y).all()))
 
 
+def run_spm_resident(nb, t_final=3600.0):
+    """C4 through the wavefront-per-member kernel (dsh_bdf_solve_wave_member): full one-hour discharge with the stop conditions armed — every member
+    integrates with its own step sizes and stops at ITS OWN voltage cut-off."""
+    import diffsol_amd as H
+    rng = np.random.default_rng(12345)
+    cur = rng.uniform(0.6, 1.4, nb)
+    s = H.Solver("spm", cur[:, None], nbatch=nb, model_size=20, rtol=1e-6, atol=[1e-6])
+    t_eval = np.linspace(360.0, t_final, 10)
+    s.solve_dense_adaptive(t_eval, want_host=False)  # warm-up
+    t0 = time.perf_counter()
+    y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True)
+    wall = time.perf_counter() - t0
+    hit = m["root_idx"] >= 0
+    return dict(config="C4 spm device-resident (one wavefront per member, events armed)", n=s.n, nbatch=nb, method="bdf", wall_s=wall, totals=tot,
+                members_stopped_by_event=int(hit.sum()), event_time_min=float(np.nanmin(m["t_root"])) if hit.any() else None,
+                event_time_max=float(np.nanmax(m["t_root"])) if hit.any() else None, status_nonzero=int((m["status"] != 0).sum()),
+                steps_per_s=tot["number_of_steps"] / wall, newton_solves_per_s=tot["number_of_nonlinear_solver_iterations"] / wall,
+                mean_steps_per_member=tot["number_of_steps"] / nb, stats={})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--heat-nb", type=int, default=4096)
@@ -114,6 +134,8 @@ if __name__ == "__main__":
         out.append(run_rlc_resident(a.rlc_nb, group=1, i_thresh=0.03)); print(json.dumps(out[-1]), flush=True)
         out.append(run_rlc_resident(a.rlc_nb, group=1, i_thresh=1e3)); print(json.dumps(out[-1]), flush=True)
         out.append(run_rlc_resident(a.rlc_nb, group=64, i_thresh=1e3)); print(json.dumps(out[-1]), flush=True)
+    if a.only in ("", "spm", "spm_resident"):
+        out.append(run_spm_resident(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "spm"):
         out.append(run_spm(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "heat"):

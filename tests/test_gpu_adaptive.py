@@ -223,3 +223,67 @@ def test_resident_esdirk34_rlc_config5_members_track_independent_cpu_solves(H, O
     assert np.array_equal(np.isfinite(y), ok) and np.allclose(y[ok], yo[ok], rtol=1e-5, atol=1e-9)
     same = (stats.T == so).all(axis=1)
     assert same.mean() > 0.9
+
+
+# ------------------------------------------------------------------ one wavefront per member: run-time-sized models, n <= 64 (dsh_bdf_solve_wave_member)
+def test_wave_member_spm_config4_members_match_cpu_solves_and_stop_at_their_own_cutoff(H, O):
+    """BASELINE config 4 at reduced size: the single-particle battery model (n = 42), one member per wavefront, each with its own step sizes and its
+    own voltage cut-off event.  The right-hand side is linear, so without events states match the CPU solves to rounding of h (pow is ocml's)."""
+    nb = 40
+    cur = np.linspace(0.6, 1.4, nb)[:, None]
+    t_eval = [60.0, 600.0, 1200.0]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "spm", cur, t_eval, 20, group=1, method=0, rtol=1e-6, atol=[1e-6])
+    m, ref = run_pair.member, run_pair.oracle_roots
+    assert failed == 0 and (status == 0).all() and (m["root_idx"] == -1).all() and (m["ncols"] == 3).all()
+    same = (stats.T == so).all(axis=1)
+    assert same.mean() > 0.9
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-9, atol=1e-13) and np.allclose(y, yo, rtol=1e-5, atol=1e-9)
+    assert np.allclose(y[-1][:, 0], cur[:, 0] * 1200.0 / 3600.0, rtol=1e-6)  # discharge capacity = I t
+    # full discharge: members with I > ~0.68 A hit V = 3.105 V before t = 3600 s, each at its own time
+    t_eval = [600.0, 1800.0, 3600.0]
+    y, tot, stats, status, yo, so, failed = run_pair(H, O, "spm", cur, t_eval, 20, group=1, method=0, rtol=1e-6, atol=[1e-6])
+    m, ref = run_pair.member, run_pair.oracle_roots
+    assert failed == 0 and (status == 0).all()
+    assert np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    hit = m["root_idx"] >= 0
+    assert 10 < hit.sum() < nb and (m["root_idx"][hit] == 0).all()
+    assert np.allclose(m["t_root"][hit], ref["t_root"][hit], rtol=1e-6) and np.all(np.diff(m["t_root"][hit]) < 0)  # higher current, earlier cut-off
+    ok = np.isfinite(yo)
+    assert np.array_equal(np.isfinite(y), ok) and np.allclose(y[ok], yo[ok], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("model,size,n", [("heat1d", 20, 20), ("heat1d", 64, 64), ("robertson_ode", 3, 9), ("gaussian_decay", 12, 12), ("dydt_y2", 10, 10)])
+def test_wave_member_other_runtime_sized_models(H, O, model, size, n):
+    nb = 12
+    rng = np.random.default_rng(n)
+    if model == "heat1d":
+        p, t_eval, tol = rng.uniform(0.5, 2.0, (nb, 1)), [0.01, 0.1], dict(rtol=1e-6, atol=[1e-6])
+    elif model == "robertson_ode":
+        p, t_eval, tol = robertson_params(nb), [0.4, 4.0, 40.0], dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
+    elif model == "gaussian_decay":
+        p, t_eval, tol = rng.uniform(0.5, 2.0, (nb, n)), [0.5, 2.0], dict(rtol=1e-6, atol=[1e-6])
+    else:
+        p, t_eval, tol = np.zeros((nb, 0)), [0.001, 0.003], dict(rtol=1e-6, atol=[1e-6])
+    s = H.Solver(model, p, nbatch=nb, model_size=size, **tol)
+    assert s.n == n
+    y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True)
+    if p.shape[1] == 0:  # the oracle wants at least a dummy parameter block: one solve serves all (identical) members
+        o = O.OracleSolver(ORACLE_MODEL[model], [], model_size=size, **tol)
+        o.set_stop_time(t_eval[-1])
+        col, ref = 0, np.zeros((len(t_eval), n))
+        while col < len(t_eval):
+            r = o.step()
+            while col < len(t_eval) and t_eval[col] <= o.state()["t"]:
+                ref[col] = o.interpolate(t_eval[col])[0]
+                col += 1
+            if r == 2:
+                break
+        assert (m["status"] == 0).all() and np.allclose(y, ref[:, None, :], rtol=1e-9, atol=1e-12)
+        assert (m["stats"][0] == o.stats()["number_of_steps"]).all()
+        return
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], p, t_eval, model_size=size, nthreads=4, **tol)
+    yo = np.transpose(yo, (1, 0, 2))
+    assert failed == 0 and (m["status"] == 0).all()
+    same = (m["stats"].T == so).all(axis=1)
+    assert same.mean() > 0.8
+    assert np.allclose(y[:, same], yo[:, same], rtol=1e-5, atol=1e-12) and np.allclose(y, yo, rtol=5e-3, atol=1e-9)
