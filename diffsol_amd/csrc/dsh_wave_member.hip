@@ -109,6 +109,11 @@ __global__ __launch_bounds__(64) void k_bdf_wave_member(int64_t nb, const double
   double a[NP];  // my row of the LU factors of M - c J
   int pos = ln, myinv = ln;
   bool jac_stale = true;
+  // The factorisation is by far the largest piece of code of this kernel: every request for a new linearisation only records what the reference
+  // would have used (the value of c at that moment; state and time do not change before the next Newton solve) and the one inlined copy of
+  // reset_jacobian runs at the top of the next solve attempt.
+  bool reset_pending = true;
+  double c_reset = opc;
   int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
   // reset_jacobian: J(x, t) row by row into LDS when stale, A = J * (-c) + I, LU in registers
   auto reset_jacobian = [&](double x_mine, double tt) __attribute__((always_inline)) {
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(64) void k_bdf_wave_member(int64_t nb, const double
       jac_stale = false;
     }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * (-opc) + (j == ln ? 1.0 : 0.0) : 0.0;
+    for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0) : 0.0;
     bool sing = false;
     int mypiv;
     wave_lu_factor_rows<NP, 64>(a, n, true, rowlive, ln, 0, pos, mypiv, sing);
@@ -133,7 +138,6 @@ __global__ __launch_bounds__(64) void k_bdf_wave_member(int64_t nb, const double
       if (ln == k) myinv = holder;
     }
   };
-  reset_jacobian(y, t);
   n_setups = 1;
   // RootFinder::init
   double g0[2] = {1.0, 1.0};
@@ -223,12 +227,12 @@ __global__ __launch_bounds__(64) void k_bdf_wave_member(int64_t nb, const double
     }
     if (check_rhs) {
       jac_stale = true;
-      reset_jacobian(y, t);
+      reset_pending = true; c_reset = opc;
       steps_since_rhs_jac = 0; steps_since_jac = 0; h_at_last_jac = c;
       eta = C.r.eta_reset;
       n_setups++;
     } else if (check_jac) {
-      reset_jacobian(y, t);
+      reset_pending = true; c_reset = opc;
       steps_since_jac = 0; h_at_last_jac = c;
       eta = C.r.eta_reset;
       n_setups++;
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(64) void k_bdf_wave_member(int64_t nb, const double
     int niter = 0;
     predict_forward();
     while (true) {
+      if (reset_pending) { reset_jacobian(y, t); reset_pending = false; }
       x = yp;
       niter = 0;
       bool has_old = false;
