@@ -129,8 +129,22 @@ __global__ void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bits = 0ull;
   if (b < nb) {
+    // one lane per system, the sum in index order (the reference's sequential accumulation).  For large n only nb lanes are busy, so the loop is
+    // latency-bound: 16 independent loads / divisions are kept in flight, only the additions are a dependent chain.
     double acc = 0.0;
-    for (int64_t i = 0; i < n; ++i) {
+    int64_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+      double term[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const double yi = BY ? y[i + q] : y[(i + q) * nb + b];
+        const double ai = BA ? atol[i + q] : atol[(i + q) * nb + b];
+        term[q] = x[(i + q) * nb + b] / (fabs(yi) * rtol + ai);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += term[q] * term[q];
+    }
+    for (; i < n; ++i) {
       double yi = BY ? y[i] : y[i * nb + b];
       double ai = BA ? atol[i] : atol[i * nb + b];
       double term = x[i * nb + b] / (fabs(yi) * rtol + ai);
