@@ -149,7 +149,7 @@ HOST_ABI = {
     "dshs_solve": (cint, [vp, dbl, cint, c_dp, c_i64p, c_ip]),
     "dshs_trajectory": (cint, [vp, c_dp, c_dp]),
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
-    "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
+    "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
 }
 
 _dev = None

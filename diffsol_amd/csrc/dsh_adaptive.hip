@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
   const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
   const dsh_adaptive_options& o = C.r.o;
+  const bool det = o.deterministic_pow != 0;
   const double rtol = C.r.rtol;
   double p[NP], atol[N];
   load_vec<NP>(p_g, nb, b, p);
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   Mdl::rhs(t, y, p, f0);
   int32_t status = kRsOk;
   if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, f0, atol, rtol, C.r))) status = kRsInitialConditionDidNotConverge;
-  h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1);
+  h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1, det);
 
   // ------------------------------------------------------------ Bdf::_new (bdf.rs:244-368) + BdfState::initialise_diff_to_first_order
   int order = 1;
@@ -288,14 +289,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         bool diverged = false;
         if (has_old) {
           // pow(x, 1.0) == x exactly: the common second iteration needs no libm call
-          const double rate = niter == 2 ? norm / old_norm : pow(norm / old_norm, 1.0 / (double)(niter - 1));
+          const double rate = niter == 2 ? norm / old_norm : rpow(norm / old_norm, 1.0 / (double)(niter - 1), det);
           if (rate > 0.9) diverged = true;
           else if (powi_rt(rate, o.max_nonlinear_solver_iterations - niter) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
           else eta = rate / (1.0 - rate);
         } else {
           const double min_eta = 1e4 * 2.220446049250313e-16;
           if (eta < min_eta) eta = min_eta;
-          eta = pow(eta, 0.8);
+          eta = rpow(eta, 0.8, det);
         }
         const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
         if (niter == 1) { has_old = true; old_norm = norm; }
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         t = t_predict;
         break;
       }
-      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1);
+      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1, det);
       has_prev_err = false;
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
       double new_h;
@@ -372,9 +373,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * C.ec2[order - 1] : inf;
       const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * C.ec2[order + 1] : inf;
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
-      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order);
-      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1);
-      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2);
+      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
+      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
+      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2, det);
       int max_index = 0;  // Iterator::max_by keeps the LAST maximum
       double fmaxv = f0c;
       if (f1c >= fmaxv) { max_index = 1; fmaxv = f1c; }
@@ -491,6 +492,7 @@ void dsh_adaptive_default_options(dsh_adaptive_options* o) {
   o->ic_step_reduction_factor = 0.5;
   o->ic_armijo_constant = 1e-4;
   o->max_steps = 10000000;
+  o->deterministic_pow = 0;
   o->group = 1;
 }
 

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "../../include/diffsol_detpow.h"
 #include "dsh_internal.hpp"
 #include "dsh_lu_dev.hpp"
 #include "dsh_models.hpp"
@@ -77,6 +78,9 @@ __device__ __forceinline__ int group_first_i(int v) {
   else return v;
 }
 
+// pow as the kernels use it: ocml's, or the deterministic one of diffsol_detpow.h (dsh_adaptive_options.deterministic_pow)
+__device__ __forceinline__ double rpow(double x, double y, bool det) { return det ? dsh_det_pow(x, y) : pow(x, y); }
+
 // compiler-rt __powidf2 (what f64::powi lowers to; convergence.rs:85)
 __device__ __forceinline__ double powi_rt(double a, int b) {
   const bool recip = b < 0;
@@ -91,15 +95,15 @@ __device__ __forceinline__ double powi_rt(double a, int b) {
 }
 
 // runge_kutta.rs:1313-1336
-__device__ __forceinline__ double pi_controller_raw(double error_norm, bool has_prev, double prev, double pi_i, double pi_p, int eff_order) {
+__device__ __forceinline__ double pi_controller_raw(double error_norm, bool has_prev, double prev, double pi_i, double pi_p, int eff_order, bool det) {
   const double order_f = (double)eff_order;
   const double ki = pi_i / order_f;
-  if (pi_p == 0.0) return pow(error_norm, -ki);
+  if (pi_p == 0.0) return rpow(error_norm, -ki, det);
   if (has_prev) {
     const double kp = pi_p / order_f;
-    return pow(error_norm, -(ki + kp)) * pow(prev, kp);
+    return rpow(error_norm, -(ki + kp), det) * rpow(prev, kp, det);
   }
-  return pow(error_norm, -ki);
+  return rpow(error_norm, -ki, det);
 }
 
 // convergence.rs:7-140
@@ -108,6 +112,7 @@ struct ConvState {
   double eta;
   double tol;
   int max_iter;
+  bool det = false;
   int niter = 0;
   bool has_old = false;
   double old_norm = 0.0;
@@ -116,14 +121,14 @@ struct ConvState {
     niter += 1;
     if (has_old) {
       // pow(x, 1.0) == x exactly: the common second iteration needs no libm call
-      const double rate = niter == 2 ? norm / old_norm : pow(norm / old_norm, 1.0 / (double)(niter - 1));
+      const double rate = niter == 2 ? norm / old_norm : rpow(norm / old_norm, 1.0 / (double)(niter - 1), det);
       if (rate > 0.9) return ConvStatus::Diverged;
       if (powi_rt(rate, max_iter - niter) / (1.0 - rate) * norm > tol) return ConvStatus::Diverged;
       eta = rate / (1.0 - rate);
     } else {
       const double min_eta = 1e4 * kEps;
       if (eta < min_eta) eta = min_eta;
-      eta = pow(eta, 0.8);
+      eta = rpow(eta, 0.8, det);
     }
     if (eta * norm < tol) return ConvStatus::Converged;
     return ConvStatus::Continue;
@@ -161,7 +166,7 @@ struct JacUpdateState {
 // set_step_size (state.rs:1209-1277)
 template <class Mdl, bool WAVE>
 __device__ __forceinline__ double initial_step_size(double t, double h0_in, const double (&y)[Mdl::N], const double (&f0)[Mdl::N], const double (&p)[Mdl::NP],
-                                                    const double (&atol)[Mdl::N], double rtol, int solver_order) {
+                                                    const double (&atol)[Mdl::N], double rtol, int solver_order, bool det) {
   constexpr int N = Mdl::N;
   const bool is_neg_h = h0_in < 0.0;
   const double d0 = sqrt(group_norm<WAVE>(wms<N>(y, y, atol, rtol))), d1 = sqrt(group_norm<WAVE>(wms<N>(f0, y, atol, rtol)));
@@ -178,7 +183,7 @@ __device__ __forceinline__ double initial_step_size(double t, double h0_in, cons
   if (max_d < d1) max_d = d1;
   double h1;
   if (max_d < 1e-15) { h1 = h0 * 1e-3; if (h1 < 1e-6) h1 = 1e-6; }
-  else h1 = pow(0.01 / max_d, 1.0 / (1.0 + (double)solver_order));
+  else h1 = rpow(0.01 / max_d, 1.0 / (1.0 + (double)solver_order), det);
   double h = 100.0 * h0;
   if (h > h1) h = h1;
   if (is_neg_h) h = -h;
@@ -238,6 +243,7 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
     conv.eta = C.eta_reset;
     conv.tol = o.nonlinear_solver_tolerance;
     conv.max_iter = o.ic_max_newton_iterations;
+    conv.det = o.deterministic_pow != 0;
     bool ok = false;
     for (int k = 0; k < o.ic_max_linear_solver_setups; ++k) {
       // reset_jacobian: the InitOp Jacobian is constant

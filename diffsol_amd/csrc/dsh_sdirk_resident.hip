@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
   Mdl::init(t, p, y);
   Mdl::rhs(t, y, p, dy);
   if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, dy, atol, rtol, C))) status = kRsInitialConditionDidNotConverge;
-  h = initial_step_size<Mdl, WAVE>(t, C.h0, y, dy, p, atol, rtol, T.order);
+  const bool det = o.deterministic_pow != 0;
+  h = initial_step_size<Mdl, WAVE>(t, C.h0, y, dy, p, atol, rtol, T.order, det);
 
   // ------------------------------------------------------------ Rk::_new (runge_kutta.rs:110-190) + Sdirk::_new (sdirk.rs:172-215)
   double diff[S][N];
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
   conv.eta = C.eta_reset;
   conv.tol = o.nonlinear_solver_tolerance;
   conv.max_iter = o.max_nonlinear_solver_iterations;
+  conv.det = det;
   double op_h = h;
   const double op_c = T.gamma;
   double phi[N];
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
       const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       {  // Rk::factor (runge_kutta.rs:466-495)
         const double safety = 0.9 * safety_factor;
-        double f = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, T.order + 1);
+        double f = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, T.order + 1, det);
         if (f > o.max_timestep_shrink && f < o.min_timestep_growth) f = 1.0;
         if (f < o.min_timestep_shrink) f = o.min_timestep_shrink;
         if (f > o.max_timestep_growth) f = o.max_timestep_growth;

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* sJ = lds + 128;
   const WaveMemberConsts& C = *Cp;
   const dsh_adaptive_options& o = C.r.o;
+  const bool det = o.deterministic_pow != 0;
   const int n = C.n, model = C.model;
   const int64_t b = blockIdx.x;
   const int ln = threadIdx.x;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (max_d < d1) max_d = d1;
     double h1;
     if (max_d < 1e-15) { h1 = h0 * 1e-3; if (h1 < 1e-6) h1 = 1e-6; }
-    else h1 = pow(0.01 / max_d, 1.0 / (1.0 + 1.0));
+    else h1 = rpow(0.01 / max_d, 1.0 / (1.0 + 1.0), det);
     h = 100.0 * h0;
     if (h > h1) h = h1;
     if (is_neg_h) h = -h;
@@ -300,14 +301,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         niter += 1;
         bool diverged = false;
         if (has_old) {
-          const double rate = niter == 2 ? norm / old_norm : pow(norm / old_norm, 1.0 / (double)(niter - 1));
+          const double rate = niter == 2 ? norm / old_norm : rpow(norm / old_norm, 1.0 / (double)(niter - 1), det);
           if (rate > 0.9) diverged = true;
           else if (powi_rt(rate, o.max_nonlinear_solver_iterations - niter) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
           else eta = rate / (1.0 - rate);
         } else {
           const double min_eta = 1e4 * kEps;
           if (eta < min_eta) eta = min_eta;
-          eta = pow(eta, 0.8);
+          eta = rpow(eta, 0.8, det);
         }
         const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
         if (niter == 1) { has_old = true; old_norm = norm; }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         t = t_predict;
         break;
       }
-      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1);
+      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1, det);
       has_prev_err = false;
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
       double new_h;
@@ -371,9 +372,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const double error_m_norm = order > 1 ? wms_wave(vm, y) * C.ec2[order - 1] : inf;
       const double error_p_norm = order < kMaxOrder ? wms_wave(vp, y) * C.ec2[order + 1] : inf;
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
-      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order);
-      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1);
-      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2);
+      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
+      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
+      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2, det);
       int max_index = 0;
       double fmaxv = f0c;
       if (f1c >= fmaxv) { max_index = 1; fmaxv = f1c; }

@@ -253,7 +253,7 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
 
 // Device-resident integration, whole ensemble solve in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident); the problem (model,
 // parameters, tolerances, options, t0, h0) is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
-int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group, double* y_host, double* y_dev, int32_t* stats_host,
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
   return guarded([&]() {
     int model = 0;
@@ -295,6 +295,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     o.ic_step_reduction_factor = ic.step_reduction_factor;
     o.ic_armijo_constant = ic.armijo_constant;
     o.group = group;
+    o.deterministic_pow = deterministic_pow;
     dsh_ctx* c = s->ctx.raw();
     double* out = y_dev;
     void* tmp_out = nullptr;

@@ -143,10 +143,11 @@ class Solver:
     ADAPTIVE_TOTALS = ["number_of_steps", "number_of_nonlinear_solver_iterations", "number_of_linear_solver_setups", "number_of_error_test_failures",
                        "number_of_nonlinear_solver_fails", "failed_members"]
 
-    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1):
+    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1, deterministic_pow=False):
         """solve_dense with device-resident step-size/order control, the whole ensemble in ONE launch (dshs_solve_dense_adaptive):
         group=1 every member its own history and event time (CPU semantics of a sweep), group=64 wavefront-sized lock-step groups (batched
-        semantics, nbatch 64).  Returns (y [nt, nbatch, n] or None, totals dict[, member dict(stats [5, nbatch], status, t_root, root_idx, ncols)])."""
+        semantics, nbatch 64).  deterministic_pow=True replaces ocml's pow() by include/diffsol_detpow.h (bit-comparable with the oracle in the same mode).
+        Returns (y [nt, nbatch, n] or None, totals dict[, member dict(stats [5, nbatch], status, t_root, root_idx, ncols)])."""
         te = np.ascontiguousarray(t_eval, dtype=np.float64)
         out = np.empty((te.size, self.nbatch, self.n)) if want_host else None
         totals = (C.c_int64 * 6)()
@@ -155,7 +156,8 @@ class Solver:
             m = dict(stats=np.empty((5, self.nbatch), dtype=np.int32), status=np.empty(self.nbatch, dtype=np.int32), t_root=np.empty(self.nbatch),
                      root_idx=np.empty(self.nbatch, dtype=np.int32), ncols=np.empty(self.nbatch, dtype=np.int32))
         i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
-        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), out.ctypes.data_as(_ffi.c_dp) if want_host else None,
+        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), 1 if deterministic_pow else 0,
+                                                out.ctypes.data_as(_ffi.c_dp) if want_host else None,
                                                 vp(dev_ptr) if dev_ptr else None, i32(m["stats"]) if m else None, i32(m["status"]) if m else None,
                                                 m["t_root"].ctypes.data_as(_ffi.c_dp) if m else None, i32(m["root_idx"]) if m else None,
                                                 i32(m["ncols"]) if m else None, totals), host=True)

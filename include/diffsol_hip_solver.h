@@ -92,7 +92,8 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
  * stats_host: [5][b] int32 (steps, Newton iterations, LU setups, error-test failures, Newton failures); status_host: [b] (0 ok, else OdeSolverError
  * ordinal, 20 root batch mismatch, 99 runaway guard); t_root_host / root_idx_host / ncols_host: [b] root time (NaN if none), root index (-1),
  * number of valid output columns; any of them may be NULL.  totals[6]: counters summed over members + number of failed members. */
-int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64 */, double* y_host, double* y_dev, int32_t* stats_host,
+int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64 */, int deterministic_pow /* diffsol_detpow.h */,
+                              double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals);
 
 #ifdef __cplusplus

@@ -223,6 +223,18 @@ def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(
     return y, stats, int(failed)
 
 
+def set_det_pow(on):
+    """Switch the oracle's pow() between libm (default: the reference's arithmetic) and include/diffsol_detpow.h (bit-comparable with the
+    device-resident kernels run with deterministic_pow=True)."""
+    lib().orc_set_det_pow(C.c_int(1 if on else 0))
+
+
+def det_pow(x, y):
+    f = lib().orc_det_pow
+    f.restype = C.c_double
+    return f(C.c_double(x), C.c_double(y))
+
+
 def compute_r(order, factor):
     out = np.empty((order + 1) * (order + 1))
     lib().orc_compute_r(order, factor, out.ctypes.data_as(_dp))

@@ -265,6 +265,10 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
   return failed;
 }
 
+// libm pow (default, the reference's arithmetic) or the deterministic pow shared with the device kernels (verification of the resident kernels)
+void orc_set_det_pow(int on) { det_pow_flag() = on != 0; }
+double orc_det_pow(double x, double y) { return dsh_det_pow(x, y); }
+
 // --- small KAT entry points for the LA / NL restatement ---
 void orc_compute_r(int order, double factor, double* out) {
   M r = Bdf::compute_r(order, factor);

@@ -16,6 +16,7 @@
 // so that the operation order below *is* the arithmetic.
 #pragma once
 #include <cmath>
+#include "../include/diffsol_detpow.h"
 #include <cstddef>
 #include <cstdint>
 #include <limits>
@@ -178,6 +179,12 @@ struct DenseLU {
     return ok;
   }
 };
+
+// pow as the integrators use it: libm's (what Rust's f64::powf calls), or — for bit-for-bit comparison with the device-resident kernels, which
+// cannot call libm — the deterministic pow of include/diffsol_detpow.h on both sides (orc_set_det_pow).  Constants (20^1.25, eps^(2/3), ...) always
+// come from libm: the device receives them from the host.
+inline bool& det_pow_flag() { static bool f = false; return f; }
+inline double rpow(double x, double y) { return det_pow_flag() ? dsh_det_pow(x, y) : std::pow(x, y); }
 
 // compiler-rt __powidf2 (what Rust's f64::powi lowers to) — convergence.rs:85 uses `rate.pow(i32)`.
 inline double powi(double a, int b) {

@@ -31,14 +31,14 @@ struct Convergence {
   ConvergenceStatus check_norm(double norm) {                         // :68-131
     niter += 1;
     if (has_old_norm) {
-      double rate = std::pow(norm / old_norm, 1.0 / (double)(niter - 1));
+      double rate = rpow(norm / old_norm, 1.0 / (double)(niter - 1));
       if (rate > 0.9) return ConvergenceStatus::Diverged;
       if (powi(rate, max_iter - niter) / (1.0 - rate) * norm > tol) return ConvergenceStatus::Diverged;
       eta = rate / (1.0 - rate);
     } else {
       double min_eta = 1e4 * std::numeric_limits<double>::epsilon();
       if (eta < min_eta) eta = min_eta;
-      eta = std::pow(eta, 0.8);
+      eta = rpow(eta, 0.8);
     }
     if (eta * norm < tol) return ConvergenceStatus::Converged;
     return ConvergenceStatus::Continue;
