@@ -31,6 +31,29 @@ def test_oracle_reproduces_reference_work_counters_exactly(O, kats, name):
     assert s.stats() == expected
 
 
+@pytest.mark.parametrize("name", BDF_CASES + SDIRK_CASES)
+def test_reference_work_counters_also_reproduce_with_the_deterministic_pow(O, kats, name):
+    """include/diffsol_detpow.h (the pow shared with the device-resident kernels in verification mode) is within 1 ulp of libm; with it the oracle
+    STILL reproduces all 13 counters of every reference snapshot — so the bitwise GPU-vs-oracle comparisons made in that mode
+    (tests/test_gpu_adaptive.py) are anchored on the reference's pinned step sequences as well."""
+    O.set_det_pow(True)
+    try:
+        _, s, _, _ = run_case(O, kats, name)
+        expected = kats["bdf_snapshots" if name in BDF_CASES else "sdirk_snapshots"][name]
+        assert s.stats() == expected
+    finally:
+        O.set_det_pow(False)
+
+
+def test_deterministic_pow_within_one_ulp_of_libm(O):
+    rng = np.random.default_rng(0)
+    x, y = np.exp(rng.uniform(-30, 30, 5000)), rng.uniform(-1.3, 1.3, 5000)
+    got = np.array([O.det_pow(a, b) for a, b in zip(x, y)])
+    ref = np.power(x, y)
+    assert np.max(np.abs(got - ref) / np.spacing(ref)) <= 1.0
+    assert O.det_pow(0.0, -0.5) == np.inf and O.det_pow(4.0, 0.5) == 2.0 and O.det_pow(7.0, 0.0) == 1.0 and np.isnan(O.det_pow(np.nan, 0.5))
+
+
 @pytest.mark.parametrize("name", ["test_bdf_nalgebra_robertson", "test_tr_bdf2_nalgebra_robertson", "test_esdirk34_nalgebra_robertson"])
 def test_oracle_robertson_dae_table(O, kats, name):
     spec, _, t, y = run_case(O, kats, name)
