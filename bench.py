@@ -163,7 +163,7 @@ def main():
     adaptive = None
     if not args.no_adaptive:
         adaptive = {"note": "dsh_bdf_solve_adaptive: one kernel launch per ensemble solve, solver state in registers/LDS, no host round trips; same job as "
-                            "`value` (same members, tolerances, save points)",
+                            "`value` (same members, tolerances, save points); pow() = include/diffsol_detpow.h, i.e. results bit-identical to the CPU oracle",
                     "per_member": device_resident_pass(1), "wavefront_lockstep_64": device_resident_pass(64)}
 
     # whole-job aggregates: max time over ranks, units summed over ranks

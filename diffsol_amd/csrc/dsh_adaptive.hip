@@ -492,7 +492,7 @@ void dsh_adaptive_default_options(dsh_adaptive_options* o) {
   o->ic_step_reduction_factor = 0.5;
   o->ic_armijo_constant = 1e-4;
   o->max_steps = 10000000;
-  o->deterministic_pow = 0;
+  o->deterministic_pow = 1;
   o->group = 1;
 }
 

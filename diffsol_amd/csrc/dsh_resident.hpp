@@ -79,7 +79,8 @@ __device__ __forceinline__ int group_first_i(int v) {
 }
 
 // pow as the kernels use it: ocml's, or the deterministic one of diffsol_detpow.h (dsh_adaptive_options.deterministic_pow)
-__device__ __forceinline__ double rpow(double x, double y, bool det) { return det ? dsh_det_pow(x, y) : pow(x, y); }
+// (not inlined: the kernels call it from a dozen sites and both implementations are a few hundred instructions)
+__device__ __attribute__((noinline)) double rpow(double x, double y, bool det) { return det ? dsh_det_pow(x, y) : pow(x, y); }
 
 // compiler-rt __powidf2 (what f64::powi lowers to; convergence.rs:85)
 __device__ __forceinline__ double powi_rt(double a, int b) {

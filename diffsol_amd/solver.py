@@ -143,10 +143,10 @@ class Solver:
     ADAPTIVE_TOTALS = ["number_of_steps", "number_of_nonlinear_solver_iterations", "number_of_linear_solver_setups", "number_of_error_test_failures",
                        "number_of_nonlinear_solver_fails", "failed_members"]
 
-    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1, deterministic_pow=False):
+    def solve_dense_adaptive(self, t_eval, want_host=True, dev_ptr=None, want_member_stats=False, group=1, deterministic_pow=True):
         """solve_dense with device-resident step-size/order control, the whole ensemble in ONE launch (dshs_solve_dense_adaptive):
         group=1 every member its own history and event time (CPU semantics of a sweep), group=64 wavefront-sized lock-step groups (batched
-        semantics, nbatch 64).  deterministic_pow=True replaces ocml's pow() by include/diffsol_detpow.h (bit-comparable with the oracle in the same mode).
+        semantics, nbatch 64).  deterministic_pow=True (default) uses the pow() of include/diffsol_detpow.h: bit-identical to the oracle in the same mode; False: ocml's pow().
         Returns (y [nt, nbatch, n] or None, totals dict[, member dict(stats [5, nbatch], status, t_root, root_idx, ncols)])."""
         te = np.ascontiguousarray(t_eval, dtype=np.float64)
         out = np.empty((te.size, self.nbatch, self.n)) if want_host else None
