@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "../../include/diffsol_hip.h"
+#include "../../include/diffsol_detpow.h"
 
 namespace dsh {
 
@@ -117,7 +118,7 @@ struct RlcT {
   static constexpr int N = 4, NP = 6, NROOTS = WITH_ROOT ? 1 : 0;
   static constexpr bool HAS_MASS = true;
   __device__ static void rhs(double t, const double (&x)[N], const double (&p)[NP], double (&y)[N]) {
-    double vs = p[3] * sin(p[4] * t);
+    double vs = p[3] * dsh_det_sin(p[4] * t);
     y[0] = x[3] - p[0] * x[0];
     y[1] = (vs - x[3]) / p[1];
     y[2] = x[1] - x[0] - x[2];

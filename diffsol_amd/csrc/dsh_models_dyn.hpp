@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "../../include/diffsol_hip.h"
+#include "../../include/diffsol_detpow.h"
 
 namespace dsh {
 
@@ -70,23 +71,23 @@ __device__ __forceinline__ double dyn_init_value(int model, int64_t n, int64_t i
 // ---- terminal voltage of the single-particle model (spm.ds varying2..5, out_i) and its two stop conditions
 __device__ __forceinline__ double spm_clamp(double v, double lo, double hi) { return v < hi ? (v > lo ? v : lo) : hi; }
 __device__ inline double spm_ocp_pos(double s) {
-  return 2.16216 + 0.07645 * tanh(30.834 - 57.858397200000006 * s) + 2.1581 * tanh(52.294 - 53.412228 * s) - 0.14169 * tanh(11.0923 - 21.0852666 * s) +
-         0.2051 * tanh(1.4684 - 5.829105600000001 * s) + 0.2531 * tanh(4.291641337386018 - 8.069908814589667 * s) - 0.02167 * tanh(-87.5 + 177.0 * s) +
+  return 2.16216 + 0.07645 * dsh_det_tanh(30.834 - 57.858397200000006 * s) + 2.1581 * dsh_det_tanh(52.294 - 53.412228 * s) - 0.14169 * dsh_det_tanh(11.0923 - 21.0852666 * s) +
+         0.2051 * dsh_det_tanh(1.4684 - 5.829105600000001 * s) + 0.2531 * dsh_det_tanh(4.291641337386018 - 8.069908814589667 * s) - 0.02167 * dsh_det_tanh(-87.5 + 177.0 * s) +
          1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
 }
 __device__ inline double spm_ocp_neg(double s) {
-  return 0.194 + 1.5 * exp(-120.0 * s) + 0.0351 * tanh(-3.44578313253012 + 12.048192771084336 * s) - 0.0045 * tanh(-7.1344537815126055 + 8.403361344537815 * s) -
-         0.035 * tanh(-18.466 + 20.0 * s) - 0.0147 * tanh(-14.705882352941176 + 29.41176470588235 * s) - 0.102 * tanh(-1.3661971830985917 + 7.042253521126761 * s) -
-         0.022 * tanh(-54.8780487804878 + 60.975609756097555 * s) - 0.011 * tanh(-5.486725663716814 + 44.24778761061947 * s) +
-         0.0155 * tanh(-3.6206896551724133 + 34.48275862068965 * s) + 1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
+  return 0.194 + 1.5 * dsh_det_exp(-120.0 * s) + 0.0351 * dsh_det_tanh(-3.44578313253012 + 12.048192771084336 * s) - 0.0045 * dsh_det_tanh(-7.1344537815126055 + 8.403361344537815 * s) -
+         0.035 * dsh_det_tanh(-18.466 + 20.0 * s) - 0.0147 * dsh_det_tanh(-14.705882352941176 + 29.41176470588235 * s) - 0.102 * dsh_det_tanh(-1.3661971830985917 + 7.042253521126761 * s) -
+         0.022 * dsh_det_tanh(-54.8780487804878 + 60.975609756097555 * s) - 0.011 * dsh_det_tanh(-5.486725663716814 + 44.24778761061947 * s) +
+         0.0155 * dsh_det_tanh(-3.6206896551724133 + 34.48275862068965 * s) + 1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
 }
 __device__ inline double spm_voltage(double neg_in, double neg_out, double pos_in, double pos_out, double current) {
   const double sp = -0.4999999999999983 * pos_in + 1.4999999999999982 * pos_out, sn = -0.4999999999999983 * neg_in + 1.4999999999999984 * neg_out;
   const double cp = spm_clamp(-25608.96286546366 * pos_in + 76826.88859639116 * pos_out, 0.000512179257309275, 51217.92521874824);
   const double cn = spm_clamp(-12491.630996921805 * neg_in + 37474.892990765504 * neg_out, 0.000249832619938437, 24983.261744011077);
   const double stp = spm_clamp(sp, 1e-10, 0.9999999999), stn = spm_clamp(sn, 1e-10, 0.9999999999);
-  const double eta_p = 0.05138515824298745 * asinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * sqrt(cp)) * sqrt(51217.9257309275 - cp))));
-  const double eta_n = 0.05138515824298745 * asinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * sqrt(cn)) * sqrt(24983.2619938437 - cn))));
+  const double eta_p = 0.05138515824298745 * dsh_det_asinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * sqrt(cp)) * sqrt(51217.9257309275 - cp))));
+  const double eta_n = 0.05138515824298745 * dsh_det_asinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * sqrt(cn)) * sqrt(24983.2619938437 - cn))));
   return (eta_p + spm_ocp_pos(stp)) - (eta_n + spm_ocp_neg(stn));
 }
 

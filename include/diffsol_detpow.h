@@ -5,7 +5,12 @@
  * decision on the GPU, where pow() is ocml's, while the CPU restatement of the reference uses libm's — equal to within an ulp, not bitwise.  With
  * dsh_adaptive_options.deterministic_pow = 1 the kernels call this function instead, and the oracle can be switched to it too (orc_set_det_pow): then the
  * two must agree BIT FOR BIT, which verifies every line of the device-side control logic against the restatement.  It is a verification vehicle, not a
- * better pow: accuracy is a few ulp (|y ln x| <~ 50), special cases are handled only as far as the integrators need them (0, inf, NaN, x = 1, y = 0).
+ * better pow: accuracy is <= 1 ulp against libm (|y ln x| <~ 50), special cases are handled only as far as the integrators need them (0, inf, NaN,
+ * x = 1, y = 0).
+ *
+ * The same construction gives dsh_det_exp / _log / _tanh / _asinh / _sin (a few ulp): the elementary functions the registry MODELS call (RLC source
+ * term, single-particle-model terminal voltage).  Oracle models and device models both use them unconditionally, which makes those configurations
+ * bit-identical too, host-driven and device-resident, events included.
  */
 #ifndef DIFFSOL_DETPOW_H
 #define DIFFSOL_DETPOW_H
@@ -33,15 +38,8 @@ DSH_DETPOW_FN double dsh_detpow_floor_half(double z) {
   return f;
 }
 
-DSH_DETPOW_FN double dsh_det_pow(double x, double y) {
-  if (y == 0.0 || x == 1.0) return 1.0;
-  if (x != x || y != y) return x + y; /* NaN */
-  const double inf = dsh_detpow_from_bits(0x7ff0000000000000ull);
-  if (x < 0.0) return dsh_detpow_from_bits(0x7ff8000000000000ull);
-  if (x == 0.0) return y > 0.0 ? 0.0 : inf;
-  if (x == inf) return y > 0.0 ? inf : 0.0;
-  if (y == inf) return x > 1.0 ? inf : 0.0;
-  if (y == -inf) return x > 1.0 ? 0.0 : inf;
+/* ln x for finite x > 0 as an unevaluated sum hi + lo (about 100 bits) */
+DSH_DETPOW_FN void dsh_detpow_log_dd(double x, double* hi, double* lo) {
   /* x = m 2^e, m in [sqrt(1/2), sqrt(2)) */
   uint64_t u = dsh_detpow_bits(x);
   int e = (int)((u >> 52) & 0x7ff);
@@ -74,8 +72,7 @@ DSH_DETPOW_FN double dsh_det_pow(double x, double y) {
   const double ln2_hi = 0.69314718036912382, ln2_lo = 1.9082149292705877e-10;
   const double ed = (double)e;
   const double a1 = ed * ln2_hi;
-  /* two_sum(a1, two_s) */
-  double l_hi = a1 + two_s;
+  double l_hi = a1 + two_s; /* two_sum(a1, two_s) */
   double bb = l_hi - a1;
   double l_lo = (a1 - (l_hi - bb)) + (two_s - bb);
   l_lo = l_lo + (c + ed * ln2_lo);
@@ -89,16 +86,18 @@ DSH_DETPOW_FN double dsh_det_pow(double x, double y) {
     const double s_err = ((num - prod) - perr) / den;
     l_lo = l_lo + 2.0 * s_err;
   }
-  /* z = y (l_hi + l_lo) as a hi/lo pair (Dekker product for y l_hi) */
-  const double yp = 134217729.0 * y, y_h = yp - (yp - y), y_l = y - y_h;
-  const double lp = 134217729.0 * l_hi, lh_h = lp - (lp - l_hi), lh_l = l_hi - lh_h;
-  const double z_hi = y * l_hi;
-  const double z_lo = (((y_h * lh_h - z_hi) + y_h * lh_l + y_l * lh_h) + y_l * lh_l) + y * l_lo;
-  const double z = z_hi;
-  if (z > 709.0) return inf;
-  if (z < -745.0) return 0.0;
+  *hi = l_hi;
+  *lo = l_lo;
+}
+
+/* exp(z_hi + z_lo) */
+DSH_DETPOW_FN double dsh_detpow_exp_dd(double z_hi, double z_lo) {
+  const double inf = dsh_detpow_from_bits(0x7ff0000000000000ull);
+  if (z_hi > 709.0) return inf;
+  if (z_hi < -745.0) return 0.0;
+  const double ln2_hi = 0.69314718036912382, ln2_lo = 1.9082149292705877e-10;
   /* exp z = 2^k exp r, r = z - k ln2, |r| <= 0.35 */
-  const double kf = dsh_detpow_floor_half(z);
+  const double kf = dsh_detpow_floor_half(z_hi);
   const int k = (int)kf;
   const double r = ((z_hi - kf * ln2_hi) - kf * ln2_lo) + z_lo;
   double q = 1.0 / 6227020800.0; /* 1/13! */
@@ -117,6 +116,139 @@ DSH_DETPOW_FN double dsh_det_pow(double x, double y) {
   /* scale in two exact steps so that k may leave the normal exponent range of one factor */
   const int k1 = k / 2, k2 = k - k1;
   return (er * dsh_detpow_exp2i(k1)) * dsh_detpow_exp2i(k2);
+}
+
+DSH_DETPOW_FN double dsh_det_pow(double x, double y) {
+  if (y == 0.0 || x == 1.0) return 1.0;
+  if (x != x || y != y) return x + y; /* NaN */
+  const double inf = dsh_detpow_from_bits(0x7ff0000000000000ull);
+  if (x < 0.0) return dsh_detpow_from_bits(0x7ff8000000000000ull);
+  if (x == 0.0) return y > 0.0 ? 0.0 : inf;
+  if (x == inf) return y > 0.0 ? inf : 0.0;
+  if (y == inf) return x > 1.0 ? inf : 0.0;
+  if (y == -inf) return x > 1.0 ? 0.0 : inf;
+  double l_hi, l_lo;
+  dsh_detpow_log_dd(x, &l_hi, &l_lo);
+  /* z = y (l_hi + l_lo) as a hi/lo pair (Dekker product for y l_hi) */
+  const double yp = 134217729.0 * y, y_h = yp - (yp - y), y_l = y - y_h;
+  const double lp = 134217729.0 * l_hi, lh_h = lp - (lp - l_hi), lh_l = l_hi - lh_h;
+  const double z_hi = y * l_hi;
+  const double z_lo = (((y_h * lh_h - z_hi) + y_h * lh_l + y_l * lh_h) + y_l * lh_l) + y * l_lo;
+  return dsh_detpow_exp_dd(z_hi, z_lo);
+}
+
+/* ---- the elementary functions the registry models use (RLC source term, single-particle-model voltage), same construction: a few ulp, identical
+ * bits on host and device.  They define those MODELS (the oracle's and the device's alike); no solver arithmetic depends on them. */
+DSH_DETPOW_FN double dsh_det_exp(double x) {
+  if (x != x) return x;
+  return dsh_detpow_exp_dd(x, 0.0);
+}
+DSH_DETPOW_FN double dsh_det_log(double x) {
+  if (x != x || x < 0.0) return dsh_detpow_from_bits(0x7ff8000000000000ull);
+  if (x == 0.0) return -dsh_detpow_from_bits(0x7ff0000000000000ull);
+  if (x == dsh_detpow_from_bits(0x7ff0000000000000ull)) return x;
+  double hi, lo;
+  dsh_detpow_log_dd(x, &hi, &lo);
+  return hi + lo;
+}
+/* exp(r) - 1 for |r| <= 0.35 (the kernel of dsh_detpow_exp_dd without the leading 1) */
+DSH_DETPOW_FN double dsh_detpow_expm1_small(double r) {
+  double q = 1.0 / 6227020800.0;
+  q = q * r + 1.0 / 479001600.0;
+  q = q * r + 1.0 / 39916800.0;
+  q = q * r + 1.0 / 3628800.0;
+  q = q * r + 1.0 / 362880.0;
+  q = q * r + 1.0 / 40320.0;
+  q = q * r + 1.0 / 5040.0;
+  q = q * r + 1.0 / 720.0;
+  q = q * r + 1.0 / 120.0;
+  q = q * r + 1.0 / 24.0;
+  q = q * r + 1.0 / 6.0;
+  q = q * r + 0.5;
+  return r + (r * r) * q;
+}
+DSH_DETPOW_FN double dsh_det_tanh(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  double t;
+  if (ax > 20.0) t = 1.0;
+  else if (ax < 0.17) { /* tanh = (e^{2x} - 1) / (e^{2x} + 1) without the cancellation of the large-argument form */
+    const double em1 = dsh_detpow_expm1_small(2.0 * ax);
+    t = em1 / (em1 + 2.0);
+  } else {
+    const double e2 = dsh_detpow_exp_dd(2.0 * ax, 0.0);
+    t = 1.0 - 2.0 / (e2 + 1.0);
+  }
+  return x < 0.0 ? -t : t;
+}
+DSH_DETPOW_FN double dsh_det_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dsqrt_rn(x);
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+DSH_DETPOW_FN double dsh_det_asinh(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  double r;
+  if (ax < 0.125) { /* sum_n (-1)^n (2n)! / (4^n n!^2 (2n+1)) x^(2n+1), to n = 10 */
+    const double x2 = ax * ax;
+    double q = 46189.0 / 5505024.0;
+    q = q * x2 - 12155.0 / 1245184.0;
+    q = q * x2 + 6435.0 / 557056.0;
+    q = q * x2 - 143.0 / 10240.0;
+    q = q * x2 + 231.0 / 13312.0;
+    q = q * x2 - 63.0 / 2816.0;
+    q = q * x2 + 35.0 / 1152.0;
+    q = q * x2 - 5.0 / 112.0;
+    q = q * x2 + 3.0 / 40.0;
+    q = q * x2 - 1.0 / 6.0;
+    r = ax + ax * (x2 * q);
+  } else if (ax > 1e150) {
+    r = dsh_det_log(ax) + 0.69314718055994531;
+  } else {
+    r = dsh_det_log(ax + dsh_det_sqrt(ax * ax + 1.0));
+  }
+  return x < 0.0 ? -r : r;
+}
+/* sin x for |x| up to ~1e6: Cody-Waite reduction by pi/2 in three parts, Taylor kernels on [-pi/4, pi/4] */
+DSH_DETPOW_FN double dsh_det_sin(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull); /* outside the supported range */
+  const double t = ax * 0.63661977236758138 + 0.5;
+  const double kf = (double)(long long)t; /* ax >= 0: truncation is floor */
+  const long long k = (long long)kf;
+  /* pi/2 = c1 + c2 + c3, c1 and c2 with trailing zero bits so that k*c1, k*c2 are exact for k < 2^20 */
+  const double c1 = 1.5707963267341256, c2 = 6.07710050630396597660e-11, c3 = 2.02226624879595063154e-21;
+  const double r = ((ax - kf * c1) - kf * c2) - kf * c3;
+  const double r2 = r * r;
+  double sn = -1.0 / 355687428096000.0; /* r^17/17! */
+  sn = sn * r2 + 1.0 / 1307674368000.0;
+  sn = sn * r2 - 1.0 / 6227020800.0;
+  sn = sn * r2 + 1.0 / 39916800.0;
+  sn = sn * r2 - 1.0 / 362880.0;
+  sn = sn * r2 + 1.0 / 5040.0;
+  sn = sn * r2 - 1.0 / 120.0;
+  sn = sn * r2 + 1.0 / 6.0;
+  const double s_r = r - r * (r2 * sn);
+  double cs = 1.0 / 20922789888000.0; /* r^16/16! */
+  cs = cs * r2 - 1.0 / 87178291200.0;
+  cs = cs * r2 + 1.0 / 479001600.0;
+  cs = cs * r2 - 1.0 / 3628800.0;
+  cs = cs * r2 + 1.0 / 40320.0;
+  cs = cs * r2 - 1.0 / 720.0;
+  cs = cs * r2 + 1.0 / 24.0;
+  const double c_r = (1.0 - 0.5 * r2) + (r2 * r2) * cs;
+  double v;
+  switch ((int)(k & 3)) {
+    case 0: v = s_r; break;
+    case 1: v = c_r; break;
+    case 2: v = -s_r; break;
+    default: v = -c_r; break;
+  }
+  return x < 0.0 ? -v : v;
 }
 
 #endif /* DIFFSOL_DETPOW_H */

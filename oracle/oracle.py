@@ -86,6 +86,10 @@ def lib():
         L.orc_convergence_trace.argtypes = [C.c_double, C.c_double, C.c_int, _dp, C.c_int, _ip, _dp]
         L.orc_model_rhs.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
         L.orc_model_jac_mul.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp]
+        L.orc_model_root.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
+        L.orc_model_root.restype = C.c_int
+        L.orc_det_fn.argtypes = [C.c_int, C.c_double]
+        L.orc_det_fn.restype = C.c_double
         _lib = L
     return _lib
 
@@ -285,3 +289,20 @@ def model_jac_mul(model, x, p, v, t=0.0, model_size=0):
     y = np.empty_like(xa)
     lib().orc_model_jac_mul(model, model_size, xp, pp, t, vp, y.ctypes.data_as(_dp))
     return y
+
+
+def model_root(model, x, p, t=0.0, model_size=0, max_roots=4):
+    xa, xp = _d(x)
+    pa, pp = _d(p)
+    g = np.zeros(max_roots)
+    k = lib().orc_model_root(model, model_size, xp, pp, t, g.ctypes.data_as(_dp))
+    return g[:k]
+
+
+DET_FN = {"exp": 0, "log": 1, "tanh": 2, "asinh": 3, "sin": 4}
+
+
+def det_fn(name, x):
+    """include/diffsol_detpow.h's elementary functions (the ones the RLC / single-particle registry models are written with)."""
+    f = lib().orc_det_fn
+    return np.array([f(DET_FN[name], float(v)) for v in np.atleast_1d(x)])

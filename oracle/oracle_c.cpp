@@ -315,6 +315,21 @@ void orc_model_jac_mul(int model_id, int model_size, const double* x, const doub
   auto m = make_model(model_id, model_size);
   m->jac_mul(x, p, t, v, y);
 }
+int orc_model_root(int model_id, int model_size, const double* x, const double* p, double t, double* g) {
+  auto m = make_model(model_id, model_size);
+  m->root(x, p, t, g);
+  return m->nroots;
+}
+// the deterministic elementary functions of include/diffsol_detpow.h the registry models are written with: 0 exp, 1 log, 2 tanh, 3 asinh, 4 sin
+double orc_det_fn(int which, double x) {
+  switch (which) {
+    case 0: return dsh_det_exp(x);
+    case 1: return dsh_det_log(x);
+    case 2: return dsh_det_tanh(x);
+    case 3: return dsh_det_asinh(x);
+    default: return dsh_det_sin(x);
+  }
+}
 // BdfCallable / SdirkCallable KATs (op/bdf.rs:318-361, op/sdirk.rs:316-389) live in tests via the solver-level API.
 
 }  // extern "C"

@@ -162,7 +162,7 @@ struct Heat1d : Model {
 struct Rlc : Model {
   explicit Rlc(bool with_root) { n = 4; np = 6; has_mass = true; nroots = with_root ? 1 : 0; }
   void rhs(const double* x, const double* p, double t, double* y) const override {
-    double vs = p[3] * std::sin(p[4] * t);
+    double vs = p[3] * dsh_det_sin(p[4] * t);
     y[0] = x[3] - p[0] * x[0];
     y[1] = (vs - x[3]) / p[1];
     y[2] = x[1] - x[0] - x[2];
@@ -204,15 +204,15 @@ struct SpmCoeffs {
 template <class T> inline T spm_clamp(T v, T lo, T hi) { return v < hi ? (v > lo ? v : lo) : hi; }  // max(min(v, hi), lo)
 // open-circuit potentials (the tanh fits written out in spm.ds out_i)
 inline double spm_ocp_pos(double s) {
-  return 2.16216 + 0.07645 * std::tanh(30.834 - 57.858397200000006 * s) + 2.1581 * std::tanh(52.294 - 53.412228 * s) - 0.14169 * std::tanh(11.0923 - 21.0852666 * s) +
-         0.2051 * std::tanh(1.4684 - 5.829105600000001 * s) + 0.2531 * std::tanh(4.291641337386018 - 8.069908814589667 * s) - 0.02167 * std::tanh(-87.5 + 177.0 * s) +
+  return 2.16216 + 0.07645 * dsh_det_tanh(30.834 - 57.858397200000006 * s) + 2.1581 * dsh_det_tanh(52.294 - 53.412228 * s) - 0.14169 * dsh_det_tanh(11.0923 - 21.0852666 * s) +
+         0.2051 * dsh_det_tanh(1.4684 - 5.829105600000001 * s) + 0.2531 * dsh_det_tanh(4.291641337386018 - 8.069908814589667 * s) - 0.02167 * dsh_det_tanh(-87.5 + 177.0 * s) +
          1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
 }
 inline double spm_ocp_neg(double s) {
-  return 0.194 + 1.5 * std::exp(-120.0 * s) + 0.0351 * std::tanh(-3.44578313253012 + 12.048192771084336 * s) - 0.0045 * std::tanh(-7.1344537815126055 + 8.403361344537815 * s) -
-         0.035 * std::tanh(-18.466 + 20.0 * s) - 0.0147 * std::tanh(-14.705882352941176 + 29.41176470588235 * s) - 0.102 * std::tanh(-1.3661971830985917 + 7.042253521126761 * s) -
-         0.022 * std::tanh(-54.8780487804878 + 60.975609756097555 * s) - 0.011 * std::tanh(-5.486725663716814 + 44.24778761061947 * s) +
-         0.0155 * std::tanh(-3.6206896551724133 + 34.48275862068965 * s) + 1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
+  return 0.194 + 1.5 * dsh_det_exp(-120.0 * s) + 0.0351 * dsh_det_tanh(-3.44578313253012 + 12.048192771084336 * s) - 0.0045 * dsh_det_tanh(-7.1344537815126055 + 8.403361344537815 * s) -
+         0.035 * dsh_det_tanh(-18.466 + 20.0 * s) - 0.0147 * dsh_det_tanh(-14.705882352941176 + 29.41176470588235 * s) - 0.102 * dsh_det_tanh(-1.3661971830985917 + 7.042253521126761 * s) -
+         0.022 * dsh_det_tanh(-54.8780487804878 + 60.975609756097555 * s) - 0.011 * dsh_det_tanh(-5.486725663716814 + 44.24778761061947 * s) +
+         0.0155 * dsh_det_tanh(-3.6206896551724133 + 34.48275862068965 * s) + 1e-06 * (1.0 / s + 1.0 / (-1.0 + s));
 }
 // terminal voltage from the two outer shells of each particle (spm.ds varying2..5 and out_i)
 inline double spm_voltage(double neg_in, double neg_out, double pos_in, double pos_out, double current) {
@@ -221,8 +221,8 @@ inline double spm_voltage(double neg_in, double neg_out, double pos_in, double p
   const double cp = spm_clamp(-25608.96286546366 * pos_in + 76826.88859639116 * pos_out, 0.000512179257309275, 51217.92521874824);  // constant10_ij
   const double cn = spm_clamp(-12491.630996921805 * neg_in + 37474.892990765504 * neg_out, 0.000249832619938437, 24983.261744011077);  // constant8_ij
   const double stp = spm_clamp(sp, 1e-10, 0.9999999999), stn = spm_clamp(sn, 1e-10, 0.9999999999);
-  const double eta_p = C::kThermal2 * std::asinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * std::sqrt(cp)) * std::sqrt(C::kCmaxPos - cp))));
-  const double eta_n = C::kThermal2 * std::asinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * std::sqrt(cn)) * std::sqrt(C::kCmaxNeg - cn))));
+  const double eta_p = C::kThermal2 * dsh_det_asinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * std::sqrt(cp)) * std::sqrt(C::kCmaxPos - cp))));
+  const double eta_n = C::kThermal2 * dsh_det_asinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * std::sqrt(cn)) * std::sqrt(C::kCmaxNeg - cn))));
   return (eta_p + spm_ocp_pos(stp)) - (eta_n + spm_ocp_neg(stn));
 }
 struct Spm : Model {

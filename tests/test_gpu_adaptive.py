@@ -207,8 +207,8 @@ def test_resident_sdirk_per_member_events(H, O, method):
 
 
 def test_resident_esdirk34_rlc_config5_members_track_independent_cpu_solves(H, O):
-    """Config 5 (RLC DAE, ESDIRK34, root iR - i_thresh) at reduced size, per-member control: every member against its own CPU solve.  sin() is
-    ocml's on the device: tolerance, not bits."""
+    """Config 5 (RLC DAE, ESDIRK34, root iR - i_thresh) at reduced size, per-member control: every member against its own CPU solve (ocml pow on
+    the device, libm pow in the oracle: tolerance; the bitwise statement is in the deterministic tests below)."""
     nb = 200
     rng = np.random.default_rng(5)
     R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
@@ -342,10 +342,30 @@ def test_with_a_shared_deterministic_pow_the_resident_sdirk_is_bit_identical_to_
 
 def test_with_a_shared_deterministic_pow_the_wavefront_per_member_bdf_is_bit_identical_to_the_oracle(H, O, det_pow):
     cur = np.linspace(0.6, 1.4, 24)[:, None]
-    _bitwise_pair(H, O, "spm", cur, [60.0, 600.0, 1200.0], 20, 1, 0, rtol=1e-6, atol=[1e-6])  # before any voltage cut-off (the root function uses tanh)
+    _bitwise_pair(H, O, "spm", cur, [60.0, 600.0, 1200.0], 20, 1, 0, rtol=1e-6, atol=[1e-6])  # before any voltage cut-off
+    # full discharge, BASELINE config 4: every member's own cut-off time (the terminal voltage's tanh / asinh / exp are diffsol_detpow.h's on both sides)
+    m, ref = _bitwise_pair(H, O, "spm", cur, [600.0, 1800.0, 3600.0], 20, 1, 0, rtol=1e-6, atol=[1e-6])
+    assert (m["root_idx"] >= 0).sum() > 10 and np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    assert np.array_equal(m["t_root"], ref["t_root"], equal_nan=True)
     rng = np.random.default_rng(1)
     _bitwise_pair(H, O, "heat1d", rng.uniform(0.5, 2.0, (12, 1)), [0.01, 0.1], 64, 1, 0, rtol=1e-6, atol=[1e-6])
     _bitwise_pair(H, O, "robertson_ode", robertson_params(12), [0.4, 4.0, 40.0], 3, 1, 0, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_rlc_config5_esdirk34_with_threshold_events_is_bit_identical_to_the_oracle(H, O, det_pow, group):
+    """BASELINE config 5 at reduced size: RLC DAE (singular mass, sin source term), ESDIRK34, root iR - i_thresh.  States, counters, root times,
+    root indices and column counts of every member (group=1) / of every 64-member lock-step group (group=64, no events there) bitwise."""
+    nb = 200
+    rng = np.random.default_rng(5)
+    R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    thresh = 0.03 if group == 1 else 10.0  # lock-step groups stop as a whole in the host-driven path; the resident group mode runs event-free
+    p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, thresh)], axis=1)
+    m, ref = _bitwise_pair(H, O, "rlc", p, [0.002, 0.005, 0.01, 0.02, 0.05], 1, group, 2, rtol=1e-6, atol=[1e-6] * 4)
+    assert np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    assert np.array_equal(m["t_root"], ref["t_root"], equal_nan=True)
+    if group == 1:
+        assert 0 < (m["root_idx"] >= 0).sum() < nb
 
 
 def test_deterministic_pow_is_the_same_function_on_host_and_device_and_close_to_libm(H, O):

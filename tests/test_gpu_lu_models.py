@@ -106,8 +106,7 @@ def test_model_rhs_jac_mul_jacobian_match_oracle(H, O, ctx1, name, size, np_):
     P = H.HipVec.from_vec(p, c) if np_ else H.HipVec.zeros(0, c)
     assert L.dsh_model_rhs(c._h, mid, size, nb, t, X.ptr, P.ptr, Y.ptr) == 0
     ref = np.stack([O.model_rhs(ORACLE_MODEL[name], x[b], p[b], t, size) for b in range(nb)])
-    tol = 0 if name != "rlc" else 1e-15  # rlc evaluates sin() on the device (ocml) vs libm on the host
-    assert np.array_equal(Y.clone_as_vec(), ref) if tol == 0 else np.allclose(Y.clone_as_vec(), ref, rtol=1e-14, atol=tol)
+    assert np.array_equal(Y.clone_as_vec(), ref)  # rlc included: its sin() is include/diffsol_detpow.h's on both sides
     assert L.dsh_model_jac_mul(c._h, mid, size, nb, t, X.ptr, P.ptr, Vv.ptr, Y.ptr) == 0
     ref = np.stack([O.model_jac_mul(ORACLE_MODEL[name], x[b], p[b], v[b], t, size) for b in range(nb)])
     assert np.array_equal(Y.clone_as_vec(), ref)
@@ -122,6 +121,15 @@ def test_model_rhs_jac_mul_jacobian_match_oracle(H, O, ctx1, name, size, np_):
     Y0 = H.HipVec.zeros(n, c)
     assert L.dsh_model_init(c._h, mid, size, nb, 0.0, P.ptr, Y0.ptr) == 0
     assert Y0.clone_as_vec().shape == (nb, n)
+    nroots = len(O.model_root(ORACLE_MODEL[name], x[0], p[0], t, size))
+    if nroots:  # stop conditions (spm: the terminal voltage, tanh / asinh / exp / sqrt): same bits as the oracle's
+        if name == "spm":  # concentrations inside the physical range
+            x = np.concatenate([rng.uniform(0.0, 1.0, (nb, 1)), rng.uniform(0.0, 1.0, (nb, 1)), rng.uniform(2e4, 4.5e4, (nb, size)), rng.uniform(2e3, 2e4, (nb, size))], axis=1)
+            X = H.HipVec.from_vec(x, c)
+        G = H.HipVec.zeros(nroots, c)
+        assert L.dsh_model_root(c._h, mid, size, nb, t, X.ptr, P.ptr, G.ptr) == 0
+        gref = np.stack([O.model_root(ORACLE_MODEL[name], x[b], p[b], t, size) for b in range(nb)])
+        assert np.isfinite(gref).all() and np.array_equal(G.clone_as_vec(), gref)
 
 
 def test_bdf_callable_kat_through_trait_ops_and_fused_kernel(H, ctx1, kats):

@@ -268,3 +268,18 @@ def test_oracle_solve_dense_stops_each_member_at_its_own_root(O):
         nc = roots["ncols"][b]
         assert abs(y[b, nc - 1, 0] - 0.6) < 1e-5 and np.isnan(y[b, nc:]).all() and np.isfinite(y[b, :nc]).all()
     assert np.isfinite(y[0]).all()
+
+
+def test_deterministic_elementary_functions_are_within_a_few_ulp_of_libm(O):
+    """include/diffsol_detpow.h's exp / log / tanh / asinh / sin define the RLC source term and the single-particle voltage on BOTH sides (oracle and
+    device); they must be the functions they claim to be: a few ulp from libm over the ranges the models use."""
+    rng = np.random.default_rng(3)
+    cases = {"exp": (np.exp, rng.uniform(-50, 50, 20000), 1), "log": (np.log, np.exp(rng.uniform(-14, 14, 20000)), 1),
+             "tanh": (np.tanh, np.concatenate([rng.uniform(-25, 25, 15000), rng.uniform(-0.3, 0.3, 5000)]), 8),
+             "asinh": (np.arcsinh, np.concatenate([rng.uniform(-100, 100, 15000), rng.uniform(-0.2, 0.2, 5000)]), 20)}
+    for name, (f, x, ulps) in cases.items():
+        got, ref = O.det_fn(name, x), f(x)
+        assert np.max(np.abs(got - ref) / np.spacing(np.abs(ref))) <= ulps, name
+    x = rng.uniform(-2000.0, 2000.0, 20000)
+    assert np.max(np.abs(O.det_fn("sin", x) - np.sin(x))) <= 2.3e-16  # absolute: sin has zeros
+    assert O.det_fn("sin", [0.0])[0] == 0.0 and O.det_fn("tanh", [0.0, 30.0, -30.0]).tolist() == [0.0, 1.0, -1.0] and O.det_fn("asinh", [0.0])[0] == 0.0
