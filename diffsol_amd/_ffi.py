@@ -95,6 +95,10 @@ DEVICE_ABI = {
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_out": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_compile": (cint, [C.c_char_p, cint, i64, i64, i64, i64, cint, c_ip]),
+    "dsh_model_release": (cint, [cint]),
+    "dsh_model_precompile": (cint, [cint, cint]),
     "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_bdf_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_reduction_wait": (cint, [vp, i64, c_dp]),
@@ -149,6 +153,8 @@ HOST_ABI = {
     "dshs_solve": (cint, [vp, dbl, cint, c_dp, c_i64p, c_ip]),
     "dshs_trajectory": (cint, [vp, c_dp, c_dp]),
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
+    "dshs_diffsl_generate": (cint, [C.c_char_p, cint, C.POINTER(vp), c_i64p, c_dp, i64]),
+    "dshs_free_string": (None, [vp]),
     "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
 }
 

@@ -1,0 +1,437 @@
+// Device-resident variable-order BDF integrator (launch code and documentation: dsh_adaptive.hip).  In a header so that run-time-compiled model
+// modules (dsh_jit.hip) instantiate the same kernel for user models.
+#pragma once
+#include "dsh_resident.hpp"
+
+namespace dsh {
+
+constexpr int kMaxOrder = 5;
+constexpr int kNC = kMaxOrder + 3;  // columns of the difference array
+
+struct AdaptiveConsts {
+  ResidentConsts r;
+  double alpha[6], gamma[6], ec2[6];  // Bdf::_new tables (bdf.rs:286-306), computed on the host
+  double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
+};
+
+template <class Mdl, bool BA, bool WAVE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
+                                                    const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
+                                                    int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
+                                                    int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
+  const AdaptiveConsts& C = *Cp;
+  const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
+  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
+  const dsh_adaptive_options& o = C.r.o;
+  const bool det = o.deterministic_pow != 0;
+  const double rtol = C.r.rtol;
+  double p[NP], atol[N];
+  load_vec<NP>(p_g, nb, b, p);
+#pragma unroll
+  for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
+
+  // ------------------------------------------------------------ OdeSolverState::new_and_consistent (state.rs:969-997, :1086-1124)
+  double t = C.r.t0, h;
+  double y[N], f0[N];
+  Mdl::init(t, p, y);
+  Mdl::rhs(t, y, p, f0);
+  int32_t status = kRsOk;
+  if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, f0, atol, rtol, C.r))) status = kRsInitialConditionDidNotConverge;
+  h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1, det);
+
+  // ------------------------------------------------------------ Bdf::_new (bdf.rs:244-368) + BdfState::initialise_diff_to_first_order
+  int order = 1;
+  // D lives in registers; its swap partner (bdf.rs `diff_tmp`, touched only when the step size changes) and the cached Jacobian (touched only
+  // when refactoring) live in LDS, one column of 64 lanes per value: that keeps the kernel at two wavefronts per SIMD.
+  __shared__ double sDt[kNC * N][64];
+  __shared__ double sJ[N * N][64];
+  const int ln = threadIdx.x;
+  double D[kNC][N];
+#pragma unroll
+  for (int j = 0; j < kNC; ++j)
+#pragma unroll
+    for (int i = 0; i < N; ++i) { D[j][i] = 0.0; sDt[j * N + i][ln] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
+  double opc = h * C.alpha[1];  // BdfCallable::c
+  double A[N * N];
+  int P[N];
+  bool jac_stale = true;
+  // statistics (ode_solver/mod.rs:28-69)
+  int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
+  // NonLinearSolver::reset_jacobian: M - c f'(x)  (op/bdf.rs:273-300) + LU
+  auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
+    double J[N * N];
+    if (jac_stale) {
+      assemble_jacobian<Mdl>(tt, xx, p, J);
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) sJ[e][ln] = J[e];
+      jac_stale = false;
+    } else {
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) J[e] = sJ[e][ln];
+    }
+    double Mm[N * N];
+    if constexpr (Mdl::HAS_MASS) assemble_mass<Mdl>(tt, p, Mm);
+    else {
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) Mm[e] = (e / N == e % N) ? 1.0 : 0.0;  // Matrix::from_diagonal(ones), op/bdf.rs:138-141
+    }
+#pragma unroll
+    for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + Mm[e];
+    bool sing = false;
+    lu_factor_reg<N>(A, P, sing);
+  };
+  reset_jacobian(y, t);
+  n_setups = 1;
+  // RootFinder::init (root.rs:44-49)
+  double g0[NR] = {0.0};
+  double rf_t0 = t;
+  if constexpr (Mdl::NROOTS > 0) Mdl::root(t, y, p, g0);
+  double t_root = 0.0;
+  int root_idx = -1;
+  // JacobianUpdate (jacobian_update.rs:12-36)
+  int steps_since_jac = 0, steps_since_rhs_jac = 0;
+  double h_at_last_jac = 1.0;
+  // Convergence (convergence.rs:7-57)
+  double eta = C.r.eta_reset;
+  int n_equal_steps = 0;
+  bool has_prev_err = false;
+  double prev_err = 0.0;
+  double yp[N], psi[N];
+  double t_predict = t;
+
+  // _update_step_size (bdf.rs:508-566) with _update_diff_for_step_size (:568-577): diff_tmp[:, 0..=order] = diff[:, 0..=order] * (R U); swap
+  auto update_step_size = [&](double factor, double& new_h_out) __attribute__((always_inline)) -> bool {
+    const double new_h = factor * h;
+    n_equal_steps = 0;
+    double R[6][6];  // R[j][i] = element (row i, col j) of compute_r(order, factor)   (bdf.rs:433-463)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      R[j][0] = 1.0;
+#pragma unroll
+      for (int i = 1; i < 6; ++i) R[j][i] = (j == 0) ? 0.0 : R[j][i - 1] * ((double)i - 1.0 - factor * (double)j) / (double)i;
+    }
+    const double* U = C.u[order - 1];  // element (row k, col j) at U[j*6 + k]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j <= order) {
+        // column j of RU: ru[k] = sum_m R(k,m) U(m,j), gemm order: first term, then acc = a*b + acc
+        double ru[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double acc = R[0][k] * U[j * 6 + 0];
+#pragma unroll
+          for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
+          ru[k] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          double acc = D[0][i] * ru[0];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) if (k <= order) acc = D[k][i] * ru[k] + acc;
+          sDt[j * N + i][ln] = acc;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kNC; ++j)
+#pragma unroll
+      for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = sDt[j * N + i][ln]; sDt[j * N + i][ln] = tmp; }
+    opc = new_h * C.alpha[order];
+    h = new_h;
+    eta = C.r.eta_reset_ts;  // reset_eta_timestep_change
+    new_h_out = new_h;
+    return fabs(h) < o.min_timestep;  // true = StepSizeTooSmall
+  };
+
+  // _predict_forward (bdf.rs:674-692): y_predict = sum_{j<=order} D_j ; psi_neg_y0 = alpha_order * sum_{1<=j<=order} gamma_j D_j - y_predict
+  auto predict_forward = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) if (j <= order) s = s + D[j][i];
+      double q = C.gamma[1] * D[1][i];
+#pragma unroll
+      for (int j = 2; j < 6; ++j) if (j <= order) q = C.gamma[j] * D[j][i] + 1.0 * q;
+      q = q * C.alpha[order];
+      q = q - s;
+      yp[i] = s;
+      psi[i] = q;
+    }
+    t_predict = t + h;
+  };
+
+  // _jacobian_updates (bdf.rs:465-506) over JacobianUpdate::check_* (jacobian_update.rs:38-79)
+  auto jacobian_updates = [&](double c, JState st) __attribute__((always_inline)) {
+    bool check_rhs = false, check_jac = true;
+    const double rel = fabs(c / h_at_last_jac - 1.0);
+    switch (st) {
+      case JState::StepSuccess:
+        check_rhs = steps_since_rhs_jac >= o.update_rhs_jacobian_after_steps;
+        check_jac = steps_since_jac >= o.update_jacobian_after_steps || rel > o.threshold_to_update_jacobian;
+        break;
+      case JState::FirstConvergenceFail: check_rhs = rel < o.threshold_to_update_rhs_jacobian; break;
+      case JState::SecondConvergenceFail: check_rhs = steps_since_rhs_jac > 0; break;
+      case JState::ErrorTestFail: check_rhs = false; break;
+    }
+    if (check_rhs) {
+      jac_stale = true;
+      reset_jacobian(y, t);
+      steps_since_rhs_jac = 0; steps_since_jac = 0; h_at_last_jac = c;  // update_rhs_jacobian, then update_jacobian
+      eta = C.r.eta_reset;
+      n_setups++;
+    } else if (check_jac) {
+      reset_jacobian(y, t);
+      steps_since_jac = 0; h_at_last_jac = c;
+      eta = C.r.eta_reset;
+      n_setups++;
+    }
+  };
+
+  // handle_tstop (bdf.rs:694-731): 0 = nothing, 1 = TstopReached, 2 = StopTimeBeforeCurrentTime
+  bool has_tstop = true;
+  const double tstop = t_eval[C.r.n_eval - 1];
+  auto handle_tstop = [&]() __attribute__((always_inline)) -> int {
+    const double eps = 2.220446049250313e-16;
+    const double troundoff = 100.0 * eps * (fabs(t) + fabs(h));
+    if (fabs(t - tstop) <= troundoff) { has_tstop = false; return 1; }
+    if ((h > 0.0 && tstop < t - troundoff) || (h < 0.0 && tstop > t + troundoff)) { has_tstop = false; return 2; }
+    if ((h > 0.0 && t + h > tstop + troundoff) || (h < 0.0 && t + h < tstop - troundoff)) {
+      const double factor = (tstop - t) / h;
+      double nh;
+      (void)update_step_size(factor, nh);  // "step size too small" is ignored here like in the reference
+    }
+    return 0;
+  };
+
+  int col = 0;
+  // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
+  {
+    const int r = handle_tstop();
+    if (r == 1) status = kRsStopTimeAtCurrentTime;
+    else if (r == 2) status = kRsStopTimeBeforeCurrentTime;
+  }
+
+  long guard = 0;
+  bool done = status != kRsOk || (!WAVE && !active);  // wavefront lock-step: shadow lanes run along (their reductions must not be masked off)
+  while (!done) {
+    if (++guard > o.max_steps) { status = kRsMaxStepsExceeded; break; }
+    // ================================================================ Bdf::step (bdf.rs:1277-1589)
+    double safety = 0.0, error_norm = 0.0;
+    const int old_err_fails = n_err_fails;
+    bool convergence_fail = false;
+    double x[N];
+    int niter = 0;
+    predict_forward();
+    while (true) {
+      // ---- NewtonNonlinearSolver::solve_in_place over NoLineSearch (newton.rs:13-36, line_search.rs:46-72)
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[i] = yp[i];
+      niter = 0;
+      bool has_old = false;
+      double old_norm = 0.0;
+      bool solved = false;
+      for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
+        double f[N], delta[N], tmpv[N];
+        Mdl::rhs(t_predict, x, p, f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) tmpv[i] = x[i] + psi[i];
+        // F(y) = M (y - y0 + psi) - c f(y)   (op/bdf.rs:240-256)
+        if constexpr (Mdl::HAS_MASS) {
+#pragma unroll
+          for (int i = 0; i < N; ++i) delta[i] = f[i];
+          Mdl::mass_gemv(t_predict, tmpv, p, -opc, delta);
+        } else {
+#pragma unroll
+          for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmpv[i] + (-opc) * f[i];
+        }
+        const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
+        if (!lu_ok) break;  // LuSolveFailed
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+        const double norm = sqrt(group_norm<WAVE>(wms<N>(delta, yp, atol, rtol)));
+        // Convergence::check_new_iteration (convergence.rs:68-139)
+        niter += 1;
+        bool diverged = false;
+        if (has_old) {
+          // pow(x, 1.0) == x exactly: the common second iteration needs no libm call
+          const double rate = niter == 2 ? norm / old_norm : rpow(norm / old_norm, 1.0 / (double)(niter - 1), det);
+          if (rate > 0.9) diverged = true;
+          else if (powi_rt(rate, o.max_nonlinear_solver_iterations - niter) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
+          else eta = rate / (1.0 - rate);
+        } else {
+          const double min_eta = 1e4 * 2.220446049250313e-16;
+          if (eta < min_eta) eta = min_eta;
+          eta = rpow(eta, 0.8, det);
+        }
+        const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
+        if (niter == 1) { has_old = true; old_norm = norm; }
+        if (diverged) break;
+        if (converged) { solved = true; break; }
+      }
+      n_newton += niter;
+      if (!solved) {
+        n_nl_fails += 1;
+        if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kRsTooManyNonlinearSolverFailures; break; }
+        has_prev_err = false;
+        if (convergence_fail) {
+          double new_h;
+          if (update_step_size(0.3, new_h)) { status = kRsStepSizeTooSmall; break; }
+          jacobian_updates(new_h * C.alpha[order], JState::SecondConvergenceFail);
+          predict_forward();
+        } else {
+          jacobian_updates(h * C.alpha[order], JState::FirstConvergenceFail);
+          convergence_fail = true;
+        }
+        continue;
+      }
+      double ydelta[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
+      // error_control (bdf.rs:812-843): norm against the CURRENT state y
+      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * C.ec2[order - 1]);
+      const double maxiter = (double)o.max_nonlinear_solver_iterations;
+      safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
+      if (error_norm <= 1.0) {
+        // ---- accepted: _update_diff (bdf.rs:646-664), state update
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          double dk1 = 0.0;
+#pragma unroll
+          for (int j = 2; j < 7; ++j) if (j == order + 1) dk1 = D[j][i];
+          const double dk2 = ydelta[i] - dk1;
+#pragma unroll
+          for (int j = 2; j < kNC; ++j) { if (j == order + 2) D[j][i] = dk2; if (j == order + 1) D[j][i] = ydelta[i]; }
+          double upper = ydelta[i];
+#pragma unroll
+          for (int j = 5; j >= 0; --j) if (j <= order) { const double v = D[j][i] + 1.0 * upper; D[j][i] = v; upper = v; }
+          y[i] = yp[i];
+        }
+        t = t_predict;
+        break;
+      }
+      double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1, det);
+      has_prev_err = false;
+      if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
+      double new_h;
+      if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
+      jacobian_updates(new_h * C.alpha[order], JState::ErrorTestFail);
+      predict_forward();
+      n_err_fails += 1;
+      if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kRsTooManyErrorTestFailures; break; }
+    }
+    if (status != kRsOk) break;
+    n_steps += 1;
+    steps_since_jac += 1; steps_since_rhs_jac += 1;  // JacobianUpdate::step
+    prev_err = error_norm; has_prev_err = true;
+    n_equal_steps += 1;
+    if (n_equal_steps > order) {
+      // order selection (bdf.rs:1494-1560): predict_error_control(order-1) / (order+1) on the updated differences
+      double col_m[N], col_p[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double vm = 0.0, vp = 0.0;
+#pragma unroll
+        for (int j = 1; j < kNC; ++j) { if (j == order) vm = D[j][i]; if (j == order + 2) vp = D[j][i]; }
+        col_m[i] = vm; col_p[i] = vp;
+      }
+      const double inf = __builtin_huge_val();
+      const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * C.ec2[order - 1] : inf;
+      const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * C.ec2[order + 1] : inf;
+      const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
+      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
+      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
+      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2, det);
+      int max_index = 0;  // Iterator::max_by keeps the LAST maximum
+      double fmaxv = f0c;
+      if (f1c >= fmaxv) { max_index = 1; fmaxv = f1c; }
+      if (f2c >= fmaxv) { max_index = 2; fmaxv = f2c; }
+      const int new_order = max_index == 0 ? order - 1 : (max_index == 1 ? order : order + 1);
+      order = new_order;
+      double factor = safety * fmaxv;
+      if (factor > o.max_timestep_growth) factor = o.max_timestep_growth;
+      if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
+      if (factor >= o.min_timestep_growth || factor <= o.max_timestep_shrink || max_index == 0 || max_index == 2) {
+        double new_h;
+        if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
+        jacobian_updates(new_h * C.alpha[new_order], JState::StepSuccess);
+      }
+    }
+    // interpolate_from_diff (bdf.rs:767-782)
+    auto interpolate = [&](double te, double (&yv)[N]) __attribute__((always_inline)) {
+      double time_factor = 1.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i) yv[i] = D[0][i];
+#pragma unroll
+      for (int j = 0; j < kMaxOrder; ++j) {
+        if (j < order) {
+          const double jt = (double)j;
+          time_factor *= (te - (t - h * jt)) / (h * (1.0 + jt));
+#pragma unroll
+          for (int i = 0; i < N; ++i) yv[i] = time_factor * D[j + 1][i] + 1.0 * yv[i];
+        }
+      }
+    };
+    int reason = 0;  // 0 internal, 1 tstop, 3 root
+    if constexpr (Mdl::NROOTS > 0) {
+      const int rr = check_root<Mdl, WAVE>(g0, rf_t0, y, t, p, interpolate, t_root, root_idx);
+      if (rr == 2) { status = kRsRootBatchMismatch; break; }
+      if (rr == 1) reason = 3;
+    }
+    if (reason == 0 && has_tstop) reason = handle_tstop();
+    if (reason == 2) reason = 0;  // the reference unwraps / ignores this inside step()
+    // ================================================================ solve_dense (method.rs:467-520): interpolated output
+    const double upto = reason == 3 ? t_root : t;
+    while (col < C.r.n_eval && t_eval[col] <= upto) {
+      double yv[N];
+      interpolate(t_eval[col], yv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+      col++;
+    }
+    if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
+      if (col < C.r.n_eval) {
+        double yv[N];
+        interpolate(t_root, yv);
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+        col++;
+      }
+      done = true;
+    }
+    if (reason == 1) done = true;
+  }
+  if (active) {
+    if (ncols_out != nullptr) ncols_out[b] = col;
+    if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
+    if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
+    // columns that were never reached (root stop or error exit): NaN
+    for (; col < C.r.n_eval; ++col)
+#pragma unroll
+      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
+    if (status_out != nullptr) status_out[b] = status;
+    if (stats_out != nullptr) {
+      stats_out[0 * nb + b] = n_steps;
+      stats_out[1 * nb + b] = n_newton;
+      stats_out[2 * nb + b] = n_setups;
+      stats_out[3 * nb + b] = n_err_fails;
+      stats_out[4 * nb + b] = n_nl_fails;
+    }
+  }
+  // ensemble totals: wavefront sums, one atomic per wavefront and counter
+  const unsigned long long mine[6] = {active ? (unsigned long long)n_steps : 0ull, active ? (unsigned long long)n_newton : 0ull,
+                                      active ? (unsigned long long)n_setups : 0ull, active ? (unsigned long long)n_err_fails : 0ull,
+                                      active ? (unsigned long long)n_nl_fails : 0ull, (active && status != kRsOk) ? 1ull : 0ull};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const unsigned long long sum = wave_sum_u64(mine[k]);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&totals[k], sum);
+  }
+}
+
+}  // namespace dsh

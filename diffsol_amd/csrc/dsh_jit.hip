@@ -1,0 +1,274 @@
+// Run-time-compiled models of libdiffsol_hip.so (gfx950): dsh_model_compile / dsh_model_release and the per-model module cache.
+//
+// The reference compiles a DiffSL model to host machine code at run time (Cranelift / LLVM back ends of the external `diffsl` crate behind
+// OdeBuilder::build_from_diffsl, crates/diffsol/src/ode_equations/diffsl.rs) and calls it through function pointers.  The device-side equivalent:
+// the generated model (diffsol_amd/host/diffsl.hpp: `struct dsh::JitModel` or the jit_* component functions) is compiled by hiprtc TOGETHER WITH
+// the library's own kernel templates — the same headers the built-in models are instantiated from — so a user model gets the fused Newton
+// kernels, the device-resident integrators and the 1:1 operator kernels, not a slower generic path.  One hiprtc program per (model, kernel family),
+// compiled on first use and cached for the life of the model.
+#include <dlfcn.h>
+#include <glob.h>
+#include <hip/hiprtc.h>
+
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "dsh_jit.hpp"
+
+using namespace dsh;
+
+namespace {
+
+struct JitModule {
+  std::vector<char> code;
+  std::map<std::string, std::string> lowered;  // name expression -> symbol
+  hipModule_t module = nullptr;
+  std::map<std::string, hipFunction_t> functions;
+};
+struct JitModelRec {
+  JitInfo info;
+  std::string source;
+  std::map<std::string, std::unique_ptr<JitModule>> modules;  // by header + group key
+};
+
+std::mutex g_mu;
+std::map<int, std::unique_ptr<JitModelRec>> g_models;
+int g_next_id = DSH_MODEL_JIT_BASE;
+
+std::string lib_dir() {
+  Dl_info info;
+  if (dladdr((const void*)&dsh_model_compile, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.rfind('/');
+    return k == std::string::npos ? std::string(".") : p.substr(0, k);
+  }
+  return ".";
+}
+
+std::vector<std::string> include_options() {
+  std::vector<std::string> opts;
+  const char* over = std::getenv("DSH_JIT_INCLUDE");  // colon-separated directories holding dsh_*.hpp and diffsol_detpow.h
+  if (over && *over) {
+    std::string s(over);
+    size_t a = 0;
+    while (a <= s.size()) {
+      size_t b = s.find(':', a);
+      if (b == std::string::npos) b = s.size();
+      if (b > a) opts.push_back("-I" + s.substr(a, b - a));
+      a = b + 1;
+    }
+  } else {
+    const std::string d = lib_dir();  // <pkg>/lib -> <pkg>/csrc and <repo>/include
+    opts.push_back("-I" + d + "/../csrc");
+    opts.push_back("-I" + d + "/../../include");
+  }
+  const char* rocm = std::getenv("ROCM_PATH");
+  const std::string r = rocm && *rocm ? rocm : "/opt/rocm";
+  opts.push_back("-I" + r + "/include");
+  glob_t g;
+  if (glob((r + "/lib/llvm/lib/clang/*/include").c_str(), 0, nullptr, &g) == 0) {
+    for (size_t i = 0; i < g.gl_pathc; ++i) opts.push_back(std::string("-I") + g.gl_pathv[i]);
+    globfree(&g);
+  }
+  return opts;
+}
+
+int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out) {
+  std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
+  tu += rec.source;
+  tu += std::string("\n#include \"") + header + "\"\n";
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, tu.c_str(), "dsh_jit_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    set_error("hiprtcCreateProgram failed");
+    return DSH_E_HIP;
+  }
+  for (const std::string& e : group) hiprtcAddNameExpression(prog, e.c_str());
+  // same code generation switches as the library's own objects (Makefile): no FMA contraction, so the arithmetic order in the source is the arithmetic
+  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
+  for (const std::string& o : include_options()) opts.push_back(o);
+  std::vector<const char*> copts;
+  for (const std::string& o : opts) copts.push_back(o.c_str());
+  hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, log.data());
+    if (log.size() > 4000) log.resize(4000);
+    set_error(std::string("model compilation failed (") + hiprtcGetErrorString(r) + ", " + header + "):\n" + log);
+    hiprtcDestroyProgram(&prog);
+    return DSH_E_INVALID;
+  }
+  for (const std::string& e : group) {
+    const char* low = nullptr;
+    if (hiprtcGetLoweredName(prog, e.c_str(), &low) != HIPRTC_SUCCESS || !low) {
+      set_error("hiprtcGetLoweredName failed for " + e);
+      hiprtcDestroyProgram(&prog);
+      return DSH_E_HIP;
+    }
+    out->lowered[e] = low;
+  }
+  size_t sz = 0;
+  hiprtcGetCodeSize(prog, &sz);
+  out->code.resize(sz);
+  hiprtcGetCode(prog, out->code.data());
+  hiprtcDestroyProgram(&prog);
+  return DSH_OK;
+}
+
+JitModelRec* find_model(int model) {
+  auto it = g_models.find(model);
+  return it == g_models.end() ? nullptr : it->second.get();
+}
+
+const char* ops_header(int form) { return form == DSH_JIT_FORM_STATIC ? "dsh_model_kernels.hpp" : "dsh_jit_dyn_kernels.hpp"; }
+
+}  // namespace
+
+namespace dsh {
+
+const std::vector<std::string>& jit_static_op_names() {
+  static const std::vector<std::string> v = {"dsh::k_static_model<dsh::JitModel, dsh::Op::Rhs>",        "dsh::k_static_model<dsh::JitModel, dsh::Op::JacMul>",
+                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::Jacobian>",   "dsh::k_static_model<dsh::JitModel, dsh::Op::MassGemv>",
+                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::MassMatrix>", "dsh::k_static_model<dsh::JitModel, dsh::Op::Init>",
+                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::Root>",       "dsh::k_static_model<dsh::JitModel, dsh::Op::Out>"};
+  return v;
+}
+
+const JitInfo* jit_info(int model) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model);
+  if (!rec) { set_error("unknown run-time-compiled model id " + std::to_string(model)); return nullptr; }
+  return &rec->info;
+}
+
+int jit_get_function(int model, const char* header, const std::string& group_key, const std::vector<std::string>& group, const std::string& name,
+                     hipFunction_t* f) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model);
+  if (!rec) { set_error("unknown run-time-compiled model id " + std::to_string(model)); return DSH_E_INVALID; }
+  const std::string key = std::string(header) + "|" + group_key;
+  auto& slot = rec->modules[key];
+  if (!slot) {
+    auto m = std::make_unique<JitModule>();
+    int rc = compile_module(*rec, header, group, m.get());
+    if (rc != DSH_OK) { rec->modules.erase(key); return rc; }
+    slot = std::move(m);
+  }
+  JitModule& m = *slot;
+  if (!m.module) DSH_HIP_CHECK(hipModuleLoadData(&m.module, m.code.data()));
+  auto it = m.functions.find(name);
+  if (it == m.functions.end()) {
+    auto low = m.lowered.find(name);
+    const std::string sym = low == m.lowered.end() ? name : low->second;
+    hipFunction_t fn = nullptr;
+    DSH_HIP_CHECK(hipModuleGetFunction(&fn, m.module, sym.c_str()));
+    it = m.functions.emplace(name, fn).first;
+  }
+  *f = it->second;
+  return DSH_OK;
+}
+
+}  // namespace dsh
+
+extern "C" {
+
+int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id) {
+  DSH_REQUIRE(source != nullptr && model_id != nullptr, "null argument");
+  DSH_REQUIRE(form == DSH_JIT_FORM_STATIC || form == DSH_JIT_FORM_DYNAMIC, "unknown model form");
+  DSH_REQUIRE(n >= 1 && nparams >= 1 && nroots >= 0 && nout >= 0, "bad model dimensions");
+  if (form == DSH_JIT_FORM_STATIC) {
+    DSH_REQUIRE(n <= 8, "the register-resident form needs n <= 8");
+    DSH_REQUIRE(nroots <= 1, "the register-resident form supports at most one root function; use the dynamic form");
+  }
+  auto rec = std::make_unique<JitModelRec>();
+  rec->info.form = form; rec->info.n = n; rec->info.np = nparams; rec->info.nroots = nroots; rec->info.nout = nout; rec->info.has_mass = has_mass ? 1 : 0;
+  rec->source = source;
+  // the stated dimensions must be the ones the source was generated with
+  if (form == DSH_JIT_FORM_STATIC)
+    rec->source += "\nstatic_assert(dsh::JitModel::N == " + std::to_string(n) + " && dsh::JitModel::NP == " + std::to_string(nparams) + " && dsh::JitModel::NROOTS == " +
+                   std::to_string(nroots) + " && dsh::JitModel::NOUT == " + std::to_string(nout) + " && dsh::JitModel::HAS_MASS == " + (has_mass ? "true" : "false") +
+                   ", \"dsh_model_compile: dimensions do not match the model source\");\n";
+  else
+    rec->source += "\nstatic_assert(dsh::kJitN == " + std::to_string(n) + " && dsh::kJitNP == " + std::to_string(nparams) + " && dsh::kJitNRoots == " + std::to_string(nroots) +
+                   " && dsh::kJitNOut == " + std::to_string(nout) + " && dsh::kJitHasMass == " + (has_mass ? "true" : "false") +
+                   ", \"dsh_model_compile: dimensions do not match the model source\");\n";
+  // compile the operator kernels now: a model that does not compile is rejected here, not at the first launch
+  auto m = std::make_unique<JitModule>();
+  const std::vector<std::string> none;
+  int rc = compile_module(*rec, ops_header(form), form == DSH_JIT_FORM_STATIC ? jit_static_op_names() : none, m.get());
+  if (rc != DSH_OK) return rc;
+  rec->modules[std::string(ops_header(form)) + "|ops"] = std::move(m);
+  std::lock_guard<std::mutex> lk(g_mu);
+  *model_id = g_next_id++;
+  g_models[*model_id] = std::move(rec);
+  return DSH_OK;
+}
+
+int dsh_model_release(int model_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_models.find(model_id);
+  if (it == g_models.end()) { set_error("dsh_model_release: unknown model id"); return DSH_E_INVALID; }
+  for (auto& kv : it->second->modules)
+    if (kv.second && kv.second->module) (void)hipModuleUnload(kv.second->module);
+  g_models.erase(it);
+  return DSH_OK;
+}
+
+// compile (not load) one kernel family of a run-time-compiled model: 0 operators, 1 fused Newton kernels, 2 resident BDF, 3 resident SDIRK.
+// Needs no GPU; used by the build check and by callers that want to pay the compilation before the first solve.
+int dsh_model_precompile(int model_id, int family) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  if (!rec) { set_error("dsh_model_precompile: unknown model id"); return DSH_E_INVALID; }
+  struct Unit { const char* header; std::string key; std::vector<std::string> group; };
+  std::vector<Unit> units;
+  const bool st = rec->info.form == DSH_JIT_FORM_STATIC;
+  auto tf = [](bool b) { return b ? "true" : "false"; };
+  if (family == 0) units.push_back({ops_header(rec->info.form), "ops", st ? jit_static_op_names() : std::vector<std::string>()});
+  else if (!st) { set_error("dsh_model_precompile: only the operator kernels exist for run-time-sized models"); return DSH_E_UNSUPPORTED; }
+  else if (family == 1) {
+    units.push_back({"dsh_fused_kernels.hpp", "jac_factor", {"dsh::k_jac_factor<dsh::JitModel>"}});
+    for (int sd = 0; sd < 2; ++sd)
+      for (int ba = 0; ba < 2; ++ba)
+        for (int we = 0; we < 2; ++we) {
+          if (sd && we) continue;
+          Unit u{"dsh_fused_kernels.hpp", std::string("newton") + tf(sd) + tf(ba) + tf(we), {}};
+          for (int nit = 1; nit <= 4; ++nit)
+            u.group.push_back(std::string("dsh::k_newton_iter<dsh::JitModel, ") + tf(sd) + ", " + tf(ba) + ", " + tf(we) + ", " + std::to_string(nit) + ">");
+          units.push_back(u);
+        }
+    for (int ba = 0; ba < 2; ++ba) {
+      Unit u{"dsh_fused_kernels.hpp", std::string("accept") + tf(ba), {}};
+      for (int nit = 1; nit <= 4; ++nit) u.group.push_back(std::string("dsh::k_accept_newton<dsh::JitModel, ") + tf(ba) + ", " + std::to_string(nit) + ">");
+      units.push_back(u);
+    }
+  } else if (family == 2 || family == 3) {
+    if (rec->info.n > 4) { set_error("dsh_model_precompile: the device-resident integrators need n <= 4"); return DSH_E_UNSUPPORTED; }
+    for (int ba = 0; ba < 2; ++ba)
+      for (int wave = 0; wave < 2; ++wave) {
+        if (family == 2) {
+          const std::string name = std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + tf(ba) + ", " + tf(wave) + ">";
+          units.push_back({"dsh_adaptive_kernel.hpp", name, {name}});
+        } else {
+          for (int s = 3; s <= 4; ++s) {
+            const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + tf(ba) + ", " + tf(wave) + ", " + std::to_string(s) + ">";
+            units.push_back({"dsh_sdirk_kernel.hpp", name, {name}});
+          }
+        }
+      }
+  } else { set_error("dsh_model_precompile: unknown kernel family"); return DSH_E_INVALID; }
+  for (const Unit& u : units) {
+    const std::string key = std::string(u.header) + "|" + u.key;
+    if (rec->modules.count(key) && rec->modules[key]) continue;
+    auto m = std::make_unique<JitModule>();
+    int rc = compile_module(*rec, u.header, u.group, m.get());
+    if (rc != DSH_OK) return rc;
+    rec->modules[key] = std::move(m);
+  }
+  return DSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Element-wise kernels of a run-time-compiled, run-time-sized model: one thread per (component, system), the layout of the built-in dynamic
+// models (dsh_models.hip k_dyn_*).  Included ONLY by the hiprtc translation unit of a model, after the generated jit_* functions
+// (diffsol_amd/host/diffsl.hpp, Target::HipDynamic).  Batch-fastest layout: element (i, b) at i * nb + b, so a wavefront shares `i` and the
+// generated switch (i) does not diverge.
+#pragma once
+#include "dsh_device.hpp"
+
+namespace dsh {
+
+extern "C" __global__ void k_jit_dyn_rhs(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
+                                         double* __restrict__ y) {
+  const int64_t total = (int64_t)kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto V = [&](int64_t k) { return v[k * nb + b]; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    y[idx] = jit_component(t, (long)i, X, V, P, v != nullptr);
+  }
+}
+// dense Jacobian entry (i, j) = component i of J e_j: the arithmetic of jac_mul with a unit vector, like the built-in models
+extern "C" __global__ void k_jit_dyn_jacobian(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, double* __restrict__ jac) {
+  const int64_t total = (int64_t)kJitN * kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, b = idx % nb;
+    const int64_t i = e % kJitN, j = e / kJitN;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    jac[idx] = jit_component(t, (long)i, X, V, P, true);
+  }
+}
+extern "C" __global__ void k_jit_dyn_init(int64_t nb, double t, const double* __restrict__ p, double* __restrict__ y) {
+  const int64_t total = (int64_t)kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    y[idx] = jit_init_component(t, (long)i, P);
+  }
+}
+// y = M x + beta y
+extern "C" __global__ void k_jit_dyn_mass_gemv(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, double beta, double* __restrict__ y) {
+  const int64_t total = (int64_t)kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    y[idx] = jit_mass_component(t, (long)i, X, P) + beta * y[idx];
+  }
+}
+// dense mass matrix entry (i, j) = component i of M e_j
+extern "C" __global__ void k_jit_dyn_mass_matrix(int64_t nb, double t, const double* __restrict__ p, double* __restrict__ mass) {
+  const int64_t total = (int64_t)kJitN * kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, b = idx % nb;
+    const int64_t i = e % kJitN, j = e / kJitN;
+    auto X = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    mass[idx] = jit_mass_component(t, (long)i, X, P);
+  }
+}
+// which = 0: stop_i (roots), 1: out_i; g is count x nb, batch-fastest
+extern "C" __global__ void k_jit_dyn_root_out(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, int which, double* __restrict__ g) {
+  const int64_t count = which == 0 ? kJitNRoots : kJitNOut, total = count * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    g[idx] = which == 0 ? jit_root_component(t, (long)i, X, P) : jit_out_component(t, (long)i, X, P);
+  }
+}
+
+}  // namespace dsh

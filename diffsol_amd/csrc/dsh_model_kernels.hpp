@@ -1,0 +1,70 @@
+// One-launch-per-operator kernels of the OdeEquations boundary for the register-resident ("static") models (launch code: dsh_models.hip).
+// In a header so that run-time-compiled model modules (dsh_jit.hip) instantiate the same kernel for user models.
+#pragma once
+#include "dsh_device.hpp"
+#include "dsh_lu_dev.hpp"
+#include "dsh_models.hpp"
+
+namespace dsh {
+
+enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root, Out };
+
+template <class Mdl, Op OP>
+__global__ void k_static_model(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
+                               double beta, double* __restrict__ y) {
+  constexpr int N = Mdl::N, NP = Mdl::NP;
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  double pp[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) pp[k] = p[(int64_t)k * nb + b];
+  if constexpr (OP == Op::Rhs) {
+    double xr[N], yr[N];
+    load_vec<N>(x, nb, b, xr);
+    Mdl::rhs(t, xr, pp, yr);
+    store_vec<N>(y, nb, b, yr);
+  } else if constexpr (OP == Op::JacMul) {
+    double xr[N], vr[N], yr[N];
+    load_vec<N>(x, nb, b, xr);
+    load_vec<N>(v, nb, b, vr);
+    Mdl::jac_mul(t, xr, pp, vr, yr);
+    store_vec<N>(y, nb, b, yr);
+  } else if constexpr (OP == Op::Jacobian) {
+    double xr[N], J[N * N];
+    load_vec<N>(x, nb, b, xr);
+    assemble_jacobian<Mdl>(t, xr, pp, J);
+    store_mat<N>(y, nb, b, J);
+  } else if constexpr (OP == Op::MassGemv) {
+    double xr[N], yr[N];
+    load_vec<N>(x, nb, b, xr);
+    load_vec<N>(y, nb, b, yr);
+    Mdl::mass_gemv(t, xr, pp, beta, yr);
+    store_vec<N>(y, nb, b, yr);
+  } else if constexpr (OP == Op::MassMatrix) {
+    double Mm[N * N];
+    assemble_mass<Mdl>(t, pp, Mm);
+    store_mat<N>(y, nb, b, Mm);
+  } else if constexpr (OP == Op::Init) {
+    double yr[N];
+    Mdl::init(t, pp, yr);
+    store_vec<N>(y, nb, b, yr);
+  } else if constexpr (OP == Op::Root) {
+    if constexpr (Mdl::NROOTS > 0) {
+      double xr[N], g[1];
+      load_vec<N>(x, nb, b, xr);
+      Mdl::root(t, xr, pp, g);
+      y[b] = g[0];
+    }
+  } else if constexpr (OP == Op::Out) {  // out_i of a DiffSL model (calc_out): nout x nb, batch-fastest
+    constexpr int NO = model_nout<Mdl>::value;
+    if constexpr (NO > 0) {
+      double xr[N], g[NO];
+      load_vec<N>(x, nb, b, xr);
+      Mdl::out(t, xr, pp, g);
+#pragma unroll
+      for (int k = 0; k < NO; ++k) y[(int64_t)k * nb + b] = g[k];
+    }
+  }
+}
+
+}  // namespace dsh

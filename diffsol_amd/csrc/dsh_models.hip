@@ -7,61 +7,12 @@
 #include "dsh_lu_dev.hpp"
 #include "dsh_models.hpp"
 #include "dsh_models_dyn.hpp"
+#include "dsh_model_kernels.hpp"
+#include "dsh_jit.hpp"
 
 using namespace dsh;
 
 namespace {
-
-enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root };
-
-template <class Mdl, Op OP>
-__global__ void k_static_model(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
-                               double beta, double* __restrict__ y) {
-  constexpr int N = Mdl::N, NP = Mdl::NP;
-  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  double pp[NP];
-#pragma unroll
-  for (int k = 0; k < NP; ++k) pp[k] = p[(int64_t)k * nb + b];
-  if constexpr (OP == Op::Rhs) {
-    double xr[N], yr[N];
-    load_vec<N>(x, nb, b, xr);
-    Mdl::rhs(t, xr, pp, yr);
-    store_vec<N>(y, nb, b, yr);
-  } else if constexpr (OP == Op::JacMul) {
-    double xr[N], vr[N], yr[N];
-    load_vec<N>(x, nb, b, xr);
-    load_vec<N>(v, nb, b, vr);
-    Mdl::jac_mul(t, xr, pp, vr, yr);
-    store_vec<N>(y, nb, b, yr);
-  } else if constexpr (OP == Op::Jacobian) {
-    double xr[N], J[N * N];
-    load_vec<N>(x, nb, b, xr);
-    assemble_jacobian<Mdl>(t, xr, pp, J);
-    store_mat<N>(y, nb, b, J);
-  } else if constexpr (OP == Op::MassGemv) {
-    double xr[N], yr[N];
-    load_vec<N>(x, nb, b, xr);
-    load_vec<N>(y, nb, b, yr);
-    Mdl::mass_gemv(t, xr, pp, beta, yr);
-    store_vec<N>(y, nb, b, yr);
-  } else if constexpr (OP == Op::MassMatrix) {
-    double Mm[N * N];
-    assemble_mass<Mdl>(t, pp, Mm);
-    store_mat<N>(y, nb, b, Mm);
-  } else if constexpr (OP == Op::Init) {
-    double yr[N];
-    Mdl::init(t, pp, yr);
-    store_vec<N>(y, nb, b, yr);
-  } else if constexpr (OP == Op::Root) {
-    if constexpr (Mdl::NROOTS > 0) {
-      double xr[N], g[1];
-      load_vec<N>(x, nb, b, xr);
-      Mdl::root(t, xr, pp, g);
-      y[b] = g[0];
-    }
-  }
-}
 
 template <Op OP>
 int launch_static(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, const double* v, double beta,
@@ -130,6 +81,42 @@ bool is_dynamic_model(int model, int64_t size) {
          (model == DSH_MODEL_ROBERTSON_ODE && size > 1);
 }
 
+// ------------------------------------------------------------------ run-time-compiled models (dsh_jit.hip)
+const char* static_op_name(Op op) {
+  switch (op) {
+    case Op::Rhs: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Rhs>";
+    case Op::JacMul: return "dsh::k_static_model<dsh::JitModel, dsh::Op::JacMul>";
+    case Op::Jacobian: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Jacobian>";
+    case Op::MassGemv: return "dsh::k_static_model<dsh::JitModel, dsh::Op::MassGemv>";
+    case Op::MassMatrix: return "dsh::k_static_model<dsh::JitModel, dsh::Op::MassMatrix>";
+    case Op::Init: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Init>";
+    case Op::Root: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Root>";
+    default: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Out>";
+  }
+}
+int jit_model_op(dsh_ctx* ctx, int model, Op op, int64_t nb, double t, const double* x, const double* p, const double* v, double beta, double* y) {
+  const JitInfo* ji = jit_info(model);
+  if (!ji) return DSH_E_INVALID;
+  if (op == Op::Root) DSH_REQUIRE(ji->nroots > 0, "model has no root function");
+  if (op == Op::Out) DSH_REQUIRE(ji->nout > 0, "model has no out_i");
+  if (ji->form == DSH_JIT_FORM_STATIC)
+    return jit_launch(ctx, model, "dsh_model_kernels.hpp", "ops", jit_static_op_names(), static_op_name(op), grid_for(nb, ctx->block), dim3(ctx->block), 0, nb, t, x, p,
+                      v, beta, y);
+  static const std::vector<std::string> none;
+  const char* hdr = "dsh_jit_dyn_kernels.hpp";
+  const int64_t n = ji->n;
+  switch (op) {
+    case Op::Rhs:
+    case Op::JacMul: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_rhs", ew_grid(n * nb), dim3(kBlock), 0, nb, t, x, p, op == Op::JacMul ? v : (const double*)nullptr, y);
+    case Op::Jacobian: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_jacobian", ew_grid(n * n * nb), dim3(kBlock), 0, nb, t, x, p, y);
+    case Op::MassGemv: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_mass_gemv", ew_grid(n * nb), dim3(kBlock), 0, nb, t, x, p, beta, y);
+    case Op::MassMatrix: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_mass_matrix", ew_grid(n * n * nb), dim3(kBlock), 0, nb, t, p, y);
+    case Op::Init: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_init", ew_grid(n * nb), dim3(kBlock), 0, nb, t, p, y);
+    case Op::Root: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nroots * nb), dim3(kBlock), 0, nb, t, x, p, (int)0, y);
+    default: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nout * nb), dim3(kBlock), 0, nb, t, x, p, (int)1, y);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,6 +124,15 @@ extern "C" {
 int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, int* has_mass, int64_t* nroots) {
   int64_t n = 0, np = 0, nr = 0;
   int hm = 0;
+  if (is_jit_model(model)) {
+    const JitInfo* ji = jit_info(model);
+    if (!ji) return DSH_E_INVALID;
+    if (nstates) *nstates = ji->n;
+    if (nparams) *nparams = ji->np;
+    if (has_mass) *has_mass = ji->has_mass;
+    if (nroots) *nroots = ji->nroots;
+    return DSH_OK;
+  }
   bool ok = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     n = Mdl::N; np = Mdl::NP; hm = Mdl::HAS_MASS ? 1 : 0; nr = Mdl::NROOTS;
@@ -160,6 +156,7 @@ int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, 
 }
 
 int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* y) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Rhs, nb, t, x, p, nullptr, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::Rhs>(ctx, model, size, nb, t, x, p, nullptr, 0.0, y, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -170,6 +167,7 @@ int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, c
   return DSH_OK;
 }
 int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, const double* v, double* y) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::JacMul, nb, t, x, p, v, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::JacMul>(ctx, model, size, nb, t, x, p, v, 0.0, y, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -180,6 +178,7 @@ int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double 
   return DSH_OK;
 }
 int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* jac) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Jacobian, nb, t, x, p, nullptr, 0.0, jac);
   bool handled = false;
   int rc = launch_static<Op::Jacobian>(ctx, model, size, nb, t, x, p, nullptr, 0.0, jac, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -190,6 +189,7 @@ int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double
   return DSH_OK;
 }
 int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double beta, double* y) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::MassGemv, nb, t, x, p, nullptr, beta, y);
   bool handled = false;
   int rc = launch_static<Op::MassGemv>(ctx, model, size, nb, t, x, p, nullptr, beta, y, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -199,6 +199,7 @@ int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, doubl
   return dsh_vec_axpy(ctx, n, nb, 1.0, x, nb, beta, y);
 }
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* mass) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::MassMatrix, nb, t, nullptr, p, nullptr, 0.0, mass);
   bool handled = false;
   int rc = launch_static<Op::MassMatrix>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, mass, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -206,6 +207,7 @@ int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, dou
   return DSH_E_UNSUPPORTED;
 }
 int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* y) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Init, nb, t, nullptr, p, nullptr, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::Init>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, y, &handled);
   if (rc != DSH_OK || handled) return rc;
@@ -216,6 +218,7 @@ int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, 
   return DSH_OK;
 }
 int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* g) {
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Root, nb, t, x, p, nullptr, 0.0, g);
   int64_t nroots = 0;
   int rc = dsh_model_info(model, size, nullptr, nullptr, nullptr, &nroots);
   if (rc != DSH_OK) return rc;
@@ -228,6 +231,14 @@ int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, 
   hipLaunchKernelGGL(k_dyn_root, grid_for(nb, ctx->block), dim3(ctx->block), 0, ctx->stream, model, n, nb, t, x, p, g);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
+}
+
+// out_i of a DiffSL model (calc_out): out is nout x nb, batch-fastest.  The registry models have no out_i (their output is the state).
+int dsh_model_out(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* out) {
+  (void)size;
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Out, nb, t, x, p, nullptr, 0.0, out);
+  set_error("dsh_model_out: the built-in models have no out_i");
+  return DSH_E_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -140,6 +140,11 @@ struct RlcT {
   __device__ static void root(double, const double (&x)[N], const double (&p)[NP], double (&g)[1]) { g[0] = x[0] - p[5]; }
 };
 
+// number of outputs of a model (out_i of DiffSL models; the built-in registry models return their state)
+template <class...> using model_void_t = void;
+template <class M, class = void> struct model_nout { static constexpr int value = 0; };
+template <class M> struct model_nout<M, model_void_t<decltype(M::NOUT)>> { static constexpr int value = M::NOUT; };
+
 // Column-by-column dense assembly from jac_mul / mass_gemv with unit vectors (see header comment).  Column-major A[j*N+i].
 template <class Mdl>
 __device__ __forceinline__ void assemble_jacobian(double t, const double (&x)[Mdl::N], const double (&p)[Mdl::NP], double (&J)[Mdl::N * Mdl::N]) {

@@ -18,7 +18,7 @@
 #include <cstdint>
 
 #include "../../include/diffsol_detpow.h"
-#include "dsh_internal.hpp"
+#include "dsh_device.hpp"
 #include "dsh_lu_dev.hpp"
 #include "dsh_models.hpp"
 

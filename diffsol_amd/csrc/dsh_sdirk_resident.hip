@@ -13,446 +13,21 @@
 #include <cmath>
 #include <vector>
 
+#include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
+
+#include "dsh_sdirk_kernel.hpp"
+#include "dsh_jit.hpp"
 
 using namespace dsh;
 
-namespace {
-
-constexpr int kMaxStages = 4, kMaxPoly = 2;
-
-struct SdirkConsts {
-  ResidentConsts r;
-  int s, order, has_beta, poly_order;
-  double a[kMaxStages * kMaxStages];  // column-major s x s
-  double b[kMaxStages], c[kMaxStages], d[kMaxStages];
-  double beta[kMaxStages * kMaxPoly];  // column-major s x poly_order
-  double gamma;                        // a(1,1)
-};
-
-template <class Mdl, bool BA, bool WAVE, int S>
-__global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const SdirkConsts* __restrict__ Cp,
-                                                       const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
-                                                       int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
-                                                       int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
-  constexpr int N = Mdl::N, NP = Mdl::NP, NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
-  const SdirkConsts& T = *Cp;
-  const ResidentConsts& C = T.r;
-  const dsh_adaptive_options& o = C.o;
-  const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = bglobal < nb;  // lanes past the ensemble shadow the wavefront's first member (no stores): invisible in the group reductions
-  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;
-  const int ln = threadIdx.x;
-  const double rtol = C.rtol;
-  double p[NP], atol[N];
-  load_vec<NP>(p_g, nb, b, p);
-#pragma unroll
-  for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
-  __shared__ double sJ[N * N][64];
-
-  // ------------------------------------------------------------ RkState::new_and_consistent(problem, tableau.order())
-  int32_t status = kRsOk;
-  double t = C.t0, h = 0.0;
-  double y[N], dy[N];
-  Mdl::init(t, p, y);
-  Mdl::rhs(t, y, p, dy);
-  if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, dy, atol, rtol, C))) status = kRsInitialConditionDidNotConverge;
-  const bool det = o.deterministic_pow != 0;
-  h = initial_step_size<Mdl, WAVE>(t, C.h0, y, dy, p, atol, rtol, T.order, det);
-
-  // ------------------------------------------------------------ Rk::_new (runge_kutta.rs:110-190) + Sdirk::_new (sdirk.rs:172-215)
-  double diff[S][N];
-#pragma unroll
-  for (int j = 0; j < S; ++j)
-#pragma unroll
-    for (int i = 0; i < N; ++i) diff[j][i] = 0.0;
-  double old_y[N], old_dy[N], old_t = t;  // old_state (its h is never read)
-#pragma unroll
-  for (int i = 0; i < N; ++i) { old_y[i] = y[i]; old_dy[i] = dy[i]; }
-  double g0[NR] = {0.0};
-  double rf_t0 = t;
-  if constexpr (Mdl::NROOTS > 0) Mdl::root(t, y, p, g0);
-  JacUpdateState ju;
-  ju.update_jacobian(h);
-  ju.update_rhs_jacobian(h);
-  ConvState conv;
-  conv.eta = C.eta_reset;
-  conv.tol = o.nonlinear_solver_tolerance;
-  conv.max_iter = o.max_nonlinear_solver_iterations;
-  conv.det = det;
-  double op_h = h;
-  const double op_c = T.gamma;
-  double phi[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) phi[i] = 0.0;  // V::zeros until the first set_phi
-  double A[N * N];
-  int P[N];
-  bool is_jacobian_set = false, jac_stale = true;
-  bool has_prev_err = false;
-  double prev_err = 0.0;
-  int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
-
-  // SdirkCallable::jacobian_inplace (op/sdirk.rs:266-296) + LU: M - (c h) f'(phi + c x)
-  auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
-    double J[N * N], Mm[N * N];
-    if (jac_stale) {
-      double tmp[N];
-#pragma unroll
-      for (int i = 0; i < N; ++i) tmp[i] = op_c * xx[i] + 1.0 * phi[i];
-      assemble_jacobian<Mdl>(tt, tmp, p, J);
-#pragma unroll
-      for (int e = 0; e < N * N; ++e) sJ[e][ln] = J[e];
-      jac_stale = false;
-    } else {
-#pragma unroll
-      for (int e = 0; e < N * N; ++e) J[e] = sJ[e][ln];
-    }
-    if constexpr (Mdl::HAS_MASS) assemble_mass<Mdl>(tt, p, Mm);
-    else {
-#pragma unroll
-      for (int e = 0; e < N * N; ++e) Mm[e] = (e / N == e % N) ? 1.0 : 0.0;
-    }
-    const double beta = -(op_c * op_h);
-#pragma unroll
-    for (int e = 0; e < N * N; ++e) A[e] = J[e] * beta + Mm[e];
-    bool sing = false;
-    lu_factor_reg<N>(A, P, sing);
-    is_jacobian_set = true;
-  };
-  // Sdirk::_jacobian_updates (sdirk.rs:260-303)
-  auto jacobian_updates = [&](double hh, JState st) __attribute__((always_inline)) {
-    if (ju.check_rhs_jacobian_update(hh, st, o)) {
-      jac_stale = true;
-      reset_jacobian(y, t);
-      ju.update_rhs_jacobian(hh);
-      ju.update_jacobian(hh);
-      conv.eta = C.eta_reset;
-      n_setups++;
-    } else if (ju.check_jacobian_update(hh, st, o)) {
-      reset_jacobian(y, t);
-      ju.update_jacobian(hh);
-      conv.eta = C.eta_reset;
-      n_setups++;
-    }
-  };
-  // handle_tstop (runge_kutta.rs:752-781): 0 nothing, 1 reached, 2 StopTimeBeforeCurrentTime
-  bool has_tstop = true;
-  const double tstop = t_eval[C.n_eval - 1];
-  auto handle_tstop = [&]() __attribute__((always_inline)) -> int {
-    const double troundoff = 100.0 * kEps * (fabs(t) + fabs(h));
-    if (fabs(t - tstop) <= troundoff) return 1;
-    if ((h > 0.0 && tstop < t - troundoff) || (h < 0.0 && tstop > t + troundoff)) return 2;
-    if ((h > 0.0 && t + h > tstop + troundoff) || (h < 0.0 && t + h < tstop - troundoff)) {
-      const double factor = (tstop - t) / h;
-      h *= factor;
-    }
-    return 0;
-  };
-  // interpolate_inplace (runge_kutta.rs:1080-1127) inside the last step [old_t, t]
-  auto interpolate = [&](double tt, double (&ret)[N]) __attribute__((always_inline)) {
-    const double dt = t - old_t;
-    const double theta = dt == 0.0 ? 1.0 : (tt - old_t) / dt;
-    if (T.has_beta) {
-      double thetav[kMaxPoly];
-      thetav[0] = theta;
-#pragma unroll
-      for (int q = 1; q < kMaxPoly; ++q) thetav[q] = theta * thetav[q - 1];
-      double bf[S];
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        double acc = 1.0 * T.beta[0 * S + i] * thetav[0];
-#pragma unroll
-        for (int q = 1; q < kMaxPoly; ++q) if (q < T.poly_order) acc = 1.0 * T.beta[q * S + i] * thetav[q] + acc;
-        bf[i] = acc;
-      }
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double acc = 1.0 * diff[0][i] * bf[0] + 1.0 * old_y[i];
-#pragma unroll
-        for (int j = 1; j < S; ++j) acc = 1.0 * diff[j][i] * bf[j] + acc;
-        ret[i] = acc;
-      }
-    } else {  // interpolate_hermite (runge_kutta.rs:1016-1035)
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        double r = y[i] - old_y[i];
-        r = (1.0 * (theta - 1.0)) * diff[0][i] + (1.0 - 2.0 * theta) * r;
-        r = (1.0 * theta) * diff[S - 1][i] + 1.0 * r;
-        r = (1.0 - theta) * old_y[i] + (theta * (theta - 1.0)) * r;
-        r = theta * y[i] + 1.0 * r;
-        ret[i] = r;
-      }
-    }
-  };
-
-  int col = 0;
-  double t_root = 0.0;
-  int root_idx = -1;
-  {  // set_stop_time (runge_kutta.rs:436-447); t_eval[0] >= t0 is checked on the host
-    const int r = handle_tstop();
-    if (r == 1 && status == kRsOk) status = kRsStopTimeAtCurrentTime;
-    else if (r == 2 && status == kRsOk) status = kRsStopTimeBeforeCurrentTime;
-  }
-
-  long guard = 0;
-  bool done = status != kRsOk || (!WAVE && !active);
-  while (!done) {
-    if (++guard > o.max_steps) { status = kRsMaxStepsExceeded; break; }
-    // ================================================================ Sdirk::step (sdirk.rs:409-543)
-    double hh = h;
-    if (fabs(hh) < o.min_timestep) { status = kRsStepSizeTooSmall; break; }
-    op_h = hh;
-    int nattempts = 0;
-    bool updated_jacobian = false;
-    const bool skip_first = T.a[0] == 0.0;
-    double fac = 1.0, error_norm = 0.0;
-    double k[N];  // old_state.dy: the stage increment being solved for
-    while (true) {
-      if (skip_first) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) diff[0][i] = hh * dy[i];  // start_step_attempt (runge_kutta.rs:505-516)
-      }
-      bool failed = false;
-#pragma unroll
-      for (int i = 0; i < S; ++i) {
-        if (failed || (skip_first && i == 0)) continue;
-        // ---- do_stage_sdirk (runge_kutta.rs:631-689)
-        const double ts = t + T.c[i] * hh;
-        // set_phi: phi = y0 + diff[:, 0..i] a_row_i   (nalgebra gemv order)
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-          if (i == 0) phi[r] = y[r] * 1.0;
-          else {
-            double acc = 1.0 * diff[0][r] * T.a[0 * S + i] + 1.0 * y[r];
-#pragma unroll
-            for (int j = 1; j < i; ++j) acc = 1.0 * diff[j][r] * T.a[j * S + i] + acc;
-            phi[r] = acc;
-          }
-        }
-        // predict_stage_sdirk (:610-629)
-        if (i == 0) {
-#pragma unroll
-          for (int r = 0; r < N; ++r) k[r] = hh * dy[r];
-        } else if (i == 1) {
-#pragma unroll
-          for (int r = 0; r < N; ++r) k[r] = diff[0][r];
-        } else {
-          const double cc = (T.c[i] - T.c[i - 2]) / (T.c[i - 1] - T.c[i - 2]);
-#pragma unroll
-          for (int r = 0; r < N; ++r) k[r] = (-cc) * diff[i - 2][r] + (1.0 + cc) * diff[i - 1][r];
-        }
-        if (!is_jacobian_set) { reset_jacobian(y, ts); n_setups++; }  // Checkpoint
-        // Newton (newton.rs:13-36 over NoLineSearch); error_y = state.y
-        conv.reset();
-        bool solved = false;
-        for (int it = 0; it < conv.max_iter; ++it) {
-          double tmp[N], f[N], delta[N];
-#pragma unroll
-          for (int r = 0; r < N; ++r) tmp[r] = op_c * k[r] + 1.0 * phi[r];
-          Mdl::rhs(ts, tmp, p, f);
-          const double beta = -op_h;
-          if constexpr (Mdl::HAS_MASS) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) delta[r] = f[r];
-            Mdl::mass_gemv(ts, k, p, beta, delta);
-          } else {
-#pragma unroll
-            for (int r = 0; r < N; ++r) delta[r] = 1.0 * k[r] + beta * f[r];
-          }
-          if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) break;  // LuSolveFailed
-#pragma unroll
-          for (int r = 0; r < N; ++r) k[r] = k[r] - delta[r];
-          const ConvStatus st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, y, atol, rtol))));
-          if (st == ConvStatus::Converged) { solved = true; break; }
-          if (st == ConvStatus::Diverged) break;
-        }
-        n_newton += conv.niter;
-        if (solved) {
-#pragma unroll
-          for (int r = 0; r < N; ++r) { old_y[r] = op_c * k[r] + 1.0 * phi[r]; diff[i][r] = k[r]; }  // get_f_eval; diff.column_mut(i)
-        } else {
-          if (!updated_jacobian) {
-            updated_jacobian = true;
-            jacobian_updates(hh, JState::FirstConvergenceFail);
-          } else {
-            hh *= 0.3;
-            conv.eta = C.eta_reset_ts;
-            op_h = hh;
-            jacobian_updates(hh, JState::SecondConvergenceFail);
-          }
-          has_prev_err = false;
-          n_nl_fails += 1;  // solve_fail (runge_kutta.rs:868-892)
-          if (n_nl_fails > o.max_nonlinear_solver_failures) status = kRsTooManyNonlinearSolverFailures;
-          else if (fabs(hh) < o.min_timestep) status = kRsStepSizeTooSmall;
-          failed = true;
-        }
-      }
-      if (status != kRsOk) break;
-      if (failed) continue;
-      // ---- error estimate (runge_kutta.rs:783-800, sdirk.rs:474-495): diff d, through the mass matrix and one LU solve
-      double err[N];
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        double acc = 1.0 * diff[0][r] * T.d[0];
-#pragma unroll
-        for (int j = 1; j < S; ++j) acc = 1.0 * diff[j][r] * T.d[j] + acc;
-        err[r] = acc;
-      }
-      if constexpr (Mdl::HAS_MASS) {
-        double Mm[N * N], e2[N];
-        assemble_mass<Mdl>(t, p, Mm);
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-          double acc = 1.0 * Mm[0 * N + r] * err[0];
-#pragma unroll
-          for (int j = 1; j < N; ++j) acc = 1.0 * Mm[j * N + r] * err[j] + acc;
-          e2[r] = acc;
-        }
-#pragma unroll
-        for (int r = 0; r < N; ++r) err[r] = e2[r];
-      }
-      if (!group_all<WAVE>(lu_solve_reg<N>(A, P, err))) { status = kRsTooManyNonlinearSolverFailures; break; }
-      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(err, y, atol, rtol)));
-      const double maxiter = (double)conv.max_iter, niter = (double)conv.niter;
-      const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
-      {  // Rk::factor (runge_kutta.rs:466-495)
-        const double safety = 0.9 * safety_factor;
-        double f = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, T.order + 1, det);
-        if (f > o.max_timestep_shrink && f < o.min_timestep_growth) f = 1.0;
-        if (f < o.min_timestep_shrink) f = o.min_timestep_shrink;
-        if (f > o.max_timestep_growth) f = o.max_timestep_growth;
-        fac = f;
-      }
-      if (error_norm < 1.0) break;
-      hh *= fac;
-      conv.eta = C.eta_reset_ts;
-      op_h = hh;
-      jacobian_updates(hh, JState::ErrorTestFail);
-      nattempts += 1;
-      has_prev_err = false;
-      n_err_fails += 1;  // error_test_fail (runge_kutta.rs:841-866)
-      if (nattempts >= o.max_error_test_failures) { status = kRsTooManyErrorTestFailures; break; }
-      if (fabs(hh) < o.min_timestep) { status = kRsStepSizeTooSmall; break; }
-    }
-    if (status != kRsOk) break;
-    const double new_h = hh * fac;
-    if (fac != 1.0) conv.eta = C.eta_reset_ts;
-    op_h = new_h;
-    jacobian_updates(new_h, JState::StepSuccess);
-    ju.step();
-    prev_err = error_norm; has_prev_err = true;
-    // ---- step_accepted (runge_kutta.rs:894-960): old_state <- (f_eval of the last stage, k/h, t+h, new_h); swap
-    {
-      const double inv_h = 1.0 / hh;
-#pragma unroll
-      for (int r = 0; r < N; ++r) {
-        const double ny = old_y[r], ndy = k[r] * inv_h;
-        old_y[r] = y[r]; old_dy[r] = dy[r];
-        y[r] = ny; dy[r] = ndy;
-      }
-      const double nt = t + hh;
-      old_t = t;
-      t = nt;
-      h = new_h;
-    }
-    n_steps += 1;
-    int reason = 0;  // 0 internal, 1 tstop, 3 root
-    if constexpr (Mdl::NROOTS > 0) {
-      const int rr = check_root<Mdl, WAVE>(g0, rf_t0, y, t, p, interpolate, t_root, root_idx);
-      if (rr == 2) { status = kRsRootBatchMismatch; break; }
-      if (rr == 1) reason = 3;
-    }
-    if (reason == 0 && has_tstop) {
-      const int r = handle_tstop();
-      if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; }
-      if (r == 1) { has_tstop = false; reason = 1; }
-    }
-    // ================================================================ solve_dense (method.rs:467-520)
-    const double upto = reason == 3 ? t_root : t;
-    while (col < C.n_eval && t_eval[col] <= upto) {
-      double yv[N];
-      interpolate(t_eval[col], yv);
-#pragma unroll
-      for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
-      col++;
-    }
-    if (reason == 3) {  // state_mut_back(root_time); the column after the drained ones holds the state at the root
-      if (col < C.n_eval) {
-        double yv[N];
-        interpolate(t_root, yv);
-#pragma unroll
-        for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
-        col++;
-      }
-      done = true;
-    }
-    if (reason == 1) done = true;
-  }
-  if (active) {
-    if (ncols_out != nullptr) ncols_out[b] = col;
-    for (; col < C.n_eval; ++col)  // columns that were never reached (root stop or error exit): NaN
-#pragma unroll
-      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
-    if (status_out != nullptr) status_out[b] = status;
-    if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
-    if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
-    if (stats_out != nullptr) {
-      stats_out[0 * nb + b] = n_steps;
-      stats_out[1 * nb + b] = n_newton;
-      stats_out[2 * nb + b] = n_setups;
-      stats_out[3 * nb + b] = n_err_fails;
-      stats_out[4 * nb + b] = n_nl_fails;
-    }
-  }
-  const unsigned long long mine[6] = {active ? (unsigned long long)n_steps : 0ull, active ? (unsigned long long)n_newton : 0ull,
-                                      active ? (unsigned long long)n_setups : 0ull, active ? (unsigned long long)n_err_fails : 0ull,
-                                      active ? (unsigned long long)n_nl_fails : 0ull, (active && status != kRsOk) ? 1ull : 0ull};
-#pragma unroll
-  for (int q = 0; q < 6; ++q) {
-    const unsigned long long sum = wave_sum_u64(mine[q]);
-    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&totals[q], sum);
-  }
-}
-
-// Tableau::tr_bdf2 / esdirk34 (tableau.rs:41-160), column-major a
-void fill_tableau(int method, SdirkConsts& T) {
-  for (double& v : T.a) v = 0.0;
-  for (double& v : T.beta) v = 0.0;
-  if (method == 1) {
-    T.s = 3; T.order = 2;
-    const double gamma = 2.0 - std::sqrt(2.0), d = gamma / 2.0, w = std::sqrt(2.0) / 4.0;
-    const double a[9] = {0.0, d, w, 0.0, d, w, 0.0, 0.0, d};
-    for (int i = 0; i < 9; ++i) T.a[i] = a[i];
-    T.b[0] = w; T.b[1] = w; T.b[2] = d;
-    const double b_hat[3] = {(1.0 - w) / 3.0, (3.0 * w + 1.0) / 3.0, d / 3.0};
-    for (int i = 0; i < 3; ++i) T.d[i] = T.b[i] - b_hat[i];
-    T.has_beta = 1; T.poly_order = 2;
-    const double beta[6] = {2.0 * w, 2.0 * w, gamma - 1.0, -w, -w, 2.0 * w};
-    for (int i = 0; i < 6; ++i) T.beta[i] = beta[i];
-    T.c[0] = 0.0; T.c[1] = gamma; T.c[2] = 1.0;
-    T.gamma = T.a[1 * 3 + 1];
-  } else {
-    T.s = 4; T.order = 3;
-    const double gamma = 0.435866521508459;
-    const double a[16] = {0.0, gamma, 0.1407377747247062, 0.102399400619911, 0.0, gamma, -0.1083655513813208, -0.3768784522555561,
-                          0.0, 0.0, gamma, 0.8386125301271861, 0.0, 0.0, 0.0, gamma};
-    for (int i = 0; i < 16; ++i) T.a[i] = a[i];
-    for (int j = 0; j < 4; ++j) T.b[j] = T.a[j * 4 + 3];
-    const double c[4] = {0.0, 0.871733043016918, 0.4682387448518444, 1.0};
-    const double d[4] = {-0.05462549724041394, -0.49420889362599496, 0.22193449973506466, 0.32689989113134427};
-    for (int i = 0; i < 4; ++i) { T.c[i] = c[i]; T.d[i] = d[i]; }
-    T.has_beta = 0; T.poly_order = 0;
-    T.gamma = T.a[1 * 4 + 1];
-  }
-}
-
-}  // namespace
 
 extern "C" {
 
 int dsh_model_has_resident(int method, int model, int64_t size) {
   if (method == 0) return dsh_model_has_adaptive(model, size);
   if (method != 1 && method != 2) return 0;
+  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 ? 1 : 0; }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
@@ -495,6 +70,12 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   const bool ba = atol_nb == 1 && nb != 1;
   const bool wave = T.r.o.group == 64;
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
+  if (is_jit_model(model)) {
+    const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (wave ? "true" : "false") + ", " + (method == 1 ? "3" : "4") + ">";
+    rc = jit_launch(ctx, model, "dsh_sdirk_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
+                    status, t_root, root_idx, ncols, totals_dev);
+    if (rc != DSH_OK) return rc;
+  } else
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     if constexpr (Mdl::N <= 4) {

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <vector>
 
+#include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
 #include "dsh_lu_wave.hpp"
 #include "dsh_models_dyn.hpp"

@@ -1,0 +1,61 @@
+"""DiffSL models on the GPU: `OdeBuilder::build_from_diffsl` of the reference (crates/diffsol/src/ode_solver/builder.rs,
+crates/diffsol/src/ode_equations/diffsl.rs) for the HIP backend.
+
+    m = DiffslModel(code)                # DiffSL text -> model source (host front end) -> hiprtc -> model id usable wherever a registry id is
+    s = Solver(m, p, nbatch=..., ...)    # p: [nbatch][ninputs] in the order of `in = [...]`
+
+n <= 8 with at most one stop condition compiles to the register-resident form (fused Newton kernels, device-resident integrators); anything else to
+the run-time-sized form (one thread per component and system)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, vp
+
+TARGET_HIP_STATIC, TARGET_HIP_DYNAMIC, TARGET_HOST_C = 0, 1, 2
+FORM_STATIC, FORM_DYNAMIC = 0, 1
+FAMILY_OPERATORS, FAMILY_FUSED, FAMILY_RESIDENT_BDF, FAMILY_RESIDENT_SDIRK = 0, 1, 2, 3
+
+
+def generate(code, target):
+    """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate."""
+    L = _ffi.load_host_lib()
+    out = vp()
+    dims = (C.c_int64 * 6)()
+    defaults = (C.c_double * 256)()
+    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, defaults, 256), host=True)
+    try:
+        src = C.string_at(out).decode()
+    finally:
+        L.dshs_free_string(out)
+    d = dict(n=int(dims[0]), nparams=int(dims[1]), nroots=int(dims[2]), nout=int(dims[3]), has_mass=bool(dims[4]), no_inputs=bool(dims[5]))
+    return src, d, np.array(defaults[: d["nparams"]])
+
+
+class DiffslModel:
+    def __init__(self, code, form=None):
+        self.code = code
+        _, d, self.defaults = generate(code, TARGET_HOST_C)
+        if form is None:
+            form = FORM_STATIC if d["n"] <= 8 and d["nroots"] <= 1 else FORM_DYNAMIC
+        self.form = form
+        self.source, d, _ = generate(code, TARGET_HIP_STATIC if form == FORM_STATIC else TARGET_HIP_DYNAMIC)
+        self.n, self.nparams, self.nroots, self.nout, self.has_mass, self.no_inputs = (d[k] for k in ("n", "nparams", "nroots", "nout", "has_mass", "no_inputs"))
+        self._L = _ffi.load_device_lib()
+        mid = C.c_int()
+        check(self._L.dsh_model_compile(self.source.encode(), form, self.n, self.nparams, self.nroots, self.nout, 1 if self.has_mass else 0, C.byref(mid)))
+        self.model_id = mid.value
+
+    def precompile(self, family):
+        """Compile a kernel family now instead of at its first launch (needs no GPU)."""
+        check(self._L.dsh_model_precompile(self.model_id, family))
+
+    def release(self):
+        if getattr(self, "model_id", None) is not None:
+            self._L.dsh_model_release(self.model_id)
+            self.model_id = None
+
+    def host_source(self):
+        """The same model as an `extern "C"` CPU library source (dsl_rhs, dsl_jac_mul, ...): what the parity tests hand to the CPU oracle."""
+        return generate(self.code, TARGET_HOST_C)[0]

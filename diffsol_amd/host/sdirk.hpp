@@ -260,12 +260,53 @@ class Sdirk : public OdeSolverMethod {
       ret.axpy(theta, state_.y, 1.0);
     }
   }
-  void state_mut_back(double t) override {  // runge_kutta.rs:393-434 (y only + dy by re-evaluating the rhs is NOT what the reference does;
-    // it interpolates dy as well — the dy interpolant is only needed after a root stop, so it is approximated by f(y,t) for ODEs)
-    HipVec ynew = HipVec::zeros(state_.y.len(), pr_.context());
+  void interpolate_dy_inplace(double t, HipVec& dy) const {  // runge_kutta.rs:1129-1181
+    if (dy.len() != state_.y.len()) throw DSH_ODE_ERR(InterpolationVectorWrongSize);
+    if (is_state_mutated_) {
+      if (t == state_.t) { dy.copy_from(state_.dy); return; }
+      throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    }
+    const bool is_forward = state_.h > 0.0;
+    if ((is_forward && (t > state_.t || t < old_state_.t)) || (!is_forward && (t < state_.t || t > old_state_.t))) throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    const double dt = state_.t - old_state_.t;
+    if (dt == 0.0) { dy.copy_from(state_.dy); return; }
+    const double theta = (t - old_state_.t) / dt;
+    const double scale_diff = 1.0;
+    if (tab_.has_beta) {
+      // interpolate_beta_function_deriv (runge_kutta.rs:985-1002): d_beta_f = beta * [1, 2 theta, 3 theta^2, ...], nalgebra gemv order
+      std::vector<double> d_thetav{1.0};
+      double theta_pow = theta;
+      for (int i = 1; i < tab_.beta_cols; ++i) { d_thetav.push_back(((double)i + 1.0) * theta_pow); theta_pow *= theta; }
+      std::vector<double> d_beta_f((size_t)tab_.beta_rows);
+      for (int i = 0; i < tab_.beta_rows; ++i) {
+        double acc = 1.0 * tab_.beta[(size_t)i] * d_thetav[0];
+        for (int j = 1; j < tab_.beta_cols; ++j) acc = 1.0 * tab_.beta[(size_t)(j * tab_.beta_rows + i)] * d_thetav[(size_t)j] + acc;
+        d_beta_f[(size_t)i] = acc;
+      }
+      HipVec bf = HipVec::from_vec(d_beta_f, pr_.context().clone_with_nbatch(1));
+      diff_.gemv(scale_diff / dt, bf, 0.0, dy);
+    } else {  // interpolate_hermite_deriv (runge_kutta.rs:1037-1078)
+      HipVec q = HipVec::zeros(dy.len(), pr_.context());
+      q.copy_from(state_.y);
+      q.sub_assign(old_state_.y);
+      q.axpy_v(scale_diff * (theta - 1.0), diff_.column(0), 1.0 - 2.0 * theta);
+      q.axpy_v(scale_diff * theta, diff_.column(diff_.ncols() - 1), 1.0);
+      dy.copy_from(state_.y);
+      dy.sub_assign(old_state_.y);
+      dy.axpy((2.0 * theta - 1.0) / dt, q, 1.0 / dt);
+      q.copy_from(old_state_.y);
+      q.sub_assign(state_.y);
+      q.axpy_v(scale_diff, diff_.column(0), 2.0);
+      q.axpy_v(scale_diff, diff_.column(diff_.ncols() - 1), 1.0);
+      dy.axpy(theta * (theta - 1.0) / dt, q, 1.0);
+    }
+  }
+  void state_mut_back(double t) override {  // runge_kutta.rs:396-434: y and dy from the step's interpolants
+    HipVec ynew = HipVec::zeros(state_.y.len(), pr_.context()), dynew = HipVec::zeros(state_.y.len(), pr_.context());
     interpolate_inplace(t, ynew);
+    interpolate_dy_inplace(t, dynew);
     state_.y.copy_from(ynew);
-    pr_.eqn->rhs_call_inplace(state_.y, t, state_.dy);
+    state_.dy.copy_from(dynew);
     state_.t = t;
     is_state_mutated_ = true;
   }

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "bdf.hpp"
+#include "diffsl.hpp"
 #include "sdirk.hpp"
 
 using namespace diffsol_hip;
@@ -67,6 +68,24 @@ void download(const HipVec& v, double* host) {
 extern "C" {
 
 const char* dshs_last_error(void) { return g_err.c_str(); }
+
+int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap) {
+  return guarded([&] {
+    if (!code || !source_out) throw LaError(DSH_E_INVALID, "dshs_diffsl_generate: null argument");
+    if (target < 0 || target > 2) throw LaError(DSH_E_INVALID, "dshs_diffsl_generate: unknown target");
+    diffsl::Compiled c = diffsl::compile(code);
+    const diffsl::Target t = target == DSHS_DIFFSL_HIP_STATIC ? diffsl::Target::HipStatic : target == DSHS_DIFFSL_HIP_DYNAMIC ? diffsl::Target::HipDynamic : diffsl::Target::HostC;
+    std::string src = diffsl::generate(c, t);
+    char* out = (char*)std::malloc(src.size() + 1);
+    if (!out) throw LaError(DSH_E_INVALID, "out of memory");
+    std::memcpy(out, src.c_str(), src.size() + 1);
+    *source_out = out;
+    if (dims) { dims[0] = c.n; dims[1] = c.np; dims[2] = c.nroots; dims[3] = c.nout; dims[4] = c.has_mass ? 1 : 0; dims[5] = c.dummy_param ? 1 : 0; }
+    if (defaults_out) for (int64_t k = 0; k < defaults_cap && k < (int64_t)c.input_defaults.size(); ++k) defaults_out[k] = c.input_defaults[k];
+    return 0;
+  });
+}
+void dshs_free_string(char* s) { std::free(s); }
 
 void dshs_default_options(dshs_options* o) {
   o->max_nonlinear_solver_iterations = 10;

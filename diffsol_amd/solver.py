@@ -35,6 +35,11 @@ class Solver:
         self._L = L
         if isinstance(model, str):
             model = MODELS[model]
+        elif hasattr(model, "model_id"):  # diffsl.DiffslModel: a run-time-compiled model (kept alive by this solver)
+            self._jit_model = model
+            if p is None:
+                p = np.tile(model.defaults, (nbatch, 1))
+            model, model_size = model.model_id, 0
         p = np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1))
         a = np.ascontiguousarray(np.asarray(atol, dtype=np.float64).reshape(-1))
         o = DshsOptions()

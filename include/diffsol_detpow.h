@@ -212,14 +212,11 @@ DSH_DETPOW_FN double dsh_det_asinh(double x) {
   }
   return x < 0.0 ? -r : r;
 }
-/* sin x for |x| up to ~1e6: Cody-Waite reduction by pi/2 in three parts, Taylor kernels on [-pi/4, pi/4] */
-DSH_DETPOW_FN double dsh_det_sin(double x) {
-  if (x != x) return x;
-  const double ax = x < 0.0 ? -x : x;
-  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull); /* outside the supported range */
+/* sin(x + shift pi/2) for |x| up to ~1e6: Cody-Waite reduction by pi/2 in three parts, Taylor kernels on [-pi/4, pi/4] */
+DSH_DETPOW_FN double dsh_detpow_sincos(double ax, int shift) {
   const double t = ax * 0.63661977236758138 + 0.5;
   const double kf = (double)(long long)t; /* ax >= 0: truncation is floor */
-  const long long k = (long long)kf;
+  const long long k = (long long)kf + shift;
   /* pi/2 = c1 + c2 + c3, c1 and c2 with trailing zero bits so that k*c1, k*c2 are exact for k < 2^20 */
   const double c1 = 1.5707963267341256, c2 = 6.07710050630396597660e-11, c3 = 2.02226624879595063154e-21;
   const double r = ((ax - kf * c1) - kf * c2) - kf * c3;
@@ -241,14 +238,56 @@ DSH_DETPOW_FN double dsh_det_sin(double x) {
   cs = cs * r2 - 1.0 / 720.0;
   cs = cs * r2 + 1.0 / 24.0;
   const double c_r = (1.0 - 0.5 * r2) + (r2 * r2) * cs;
-  double v;
   switch ((int)(k & 3)) {
-    case 0: v = s_r; break;
-    case 1: v = c_r; break;
-    case 2: v = -s_r; break;
-    default: v = -c_r; break;
+    case 0: return s_r;
+    case 1: return c_r;
+    case 2: return -s_r;
+    default: return -c_r;
   }
+}
+DSH_DETPOW_FN double dsh_det_sin(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull); /* outside the supported range */
+  const double v = dsh_detpow_sincos(ax, 0);
   return x < 0.0 ? -v : v;
+}
+DSH_DETPOW_FN double dsh_det_cos(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull);
+  return dsh_detpow_sincos(ax, 1);
+}
+DSH_DETPOW_FN double dsh_det_tan(double x) { return dsh_det_sin(x) / dsh_det_cos(x); }
+DSH_DETPOW_FN double dsh_det_log10(double x) { return dsh_det_log(x) / 2.302585092994046; }
+DSH_DETPOW_FN double dsh_det_abs(double x) { return x < 0.0 ? -x : (x == 0.0 ? 0.0 : x); }
+DSH_DETPOW_FN double dsh_det_sigmoid(double x) { return 1.0 / (1.0 + dsh_det_exp(-x)); }
+DSH_DETPOW_FN double dsh_det_heaviside(double x) { return x >= 0.0 ? 1.0 : 0.0; }
+DSH_DETPOW_FN double dsh_det_sinh(double x) {
+  const double ax = x < 0.0 ? -x : x;
+  double r;
+  if (ax < 0.17) { const double em1 = dsh_detpow_expm1_small(ax); r = 0.5 * (em1 + em1 / (em1 + 1.0)); }
+  else { const double e = dsh_det_exp(ax); r = 0.5 * (e - 1.0 / e); }
+  return x < 0.0 ? -r : r;
+}
+DSH_DETPOW_FN double dsh_det_cosh(double x) { const double e = dsh_det_exp(x < 0.0 ? -x : x); return 0.5 * (e + 1.0 / e); }
+DSH_DETPOW_FN double dsh_det_acosh(double x) { return dsh_det_log(x + dsh_det_sqrt(x * x - 1.0)); }
+DSH_DETPOW_FN double dsh_det_min(double a, double b) { return a < b ? a : b; }
+DSH_DETPOW_FN double dsh_det_max(double a, double b) { return a < b ? b : a; }
+DSH_DETPOW_FN double dsh_det_copysign(double a, double b) {
+  return dsh_detpow_from_bits((dsh_detpow_bits(a) & 0x7fffffffffffffffull) | (dsh_detpow_bits(b) & 0x8000000000000000ull));
+}
+/* pow for any base: small integer exponents by repeated multiplication (any sign of x), everything else through dsh_det_pow (x >= 0) */
+DSH_DETPOW_FN double dsh_det_powg(double x, double y) {
+  if (y == 0.5) return dsh_det_sqrt(x);
+  const double ay = y < 0.0 ? -y : y;
+  if (ay <= 64.0 && ay == (double)(int)ay) {
+    int e = (int)ay;
+    double r = 1.0, b = x;
+    while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; }
+    return y < 0.0 ? 1.0 / r : r;
+  }
+  return dsh_det_pow(x, y);
 }
 
 #endif /* DIFFSOL_DETPOW_H */

@@ -184,6 +184,22 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 #define DSH_MODEL_EXPONENTIAL_DECAY_ROOT 9      /* exponential decay + root x0-0.6  test_models/exponential_decay.rs:98-100 */
 #define DSH_MODEL_SPM 10                        /* single-particle battery model, n=2+2*size (size=0 -> 20 shells), p=[I], roots V-3.105, 4.1-V  book/src/primer/src/spm.ds */
 
+/* ---- Run-time-compiled models: the device side of OdeBuilder::build_from_diffsl (crates/diffsol/src/ode_equations/diffsl.rs —
+ * the reference JIT-compiles DiffSL to host code with Cranelift/LLVM).  `source` is the model as generated by dshs_diffsl_generate
+ * (diffsol_hip_solver.h): `struct dsh::JitModel` (DSH_JIT_FORM_STATIC, n <= 8, at most one root function) or the jit_* component functions
+ * (DSH_JIT_FORM_DYNAMIC).  It is compiled with hiprtc together with the library's own kernel templates, so the returned model id (>= DSH_MODEL_JIT_BASE)
+ * works wherever a registry id does: dsh_model_*, the fused Newton kernels (static form), the device-resident integrators (static form), and the
+ * host-side integrators of diffsol_hip_solver.h.  Kernel families are compiled on first use; dsh_model_precompile (family 0 operators, 1 fused Newton,
+ * 2 resident BDF, 3 resident SDIRK) pays that cost up front and needs no GPU.  `model_size` arguments are ignored for these ids. */
+#define DSH_MODEL_JIT_BASE 1000
+#define DSH_JIT_FORM_STATIC 0
+#define DSH_JIT_FORM_DYNAMIC 1
+int dsh_model_compile(const char* source, int form, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id);
+int dsh_model_release(int model_id);
+int dsh_model_precompile(int model_id, int family);
+/* out_i of a run-time-compiled model (DiffSl::out, calc_out): out is nout x nbatch, batch-fastest */
+int dsh_model_out(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* out);
+
 int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, int* has_mass, int64_t* nroots);
 int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* y);
 int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, const double* v, double* y);

@@ -96,6 +96,20 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
                               double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals);
 
+/* ---- DiffSL front end: what OdeBuilder::build_from_diffsl does with the external `diffsl` compiler
+ * (crates/diffsol/src/ode_solver/builder.rs, crates/diffsol/src/ode_equations/diffsl.rs): DiffSL text -> source code of the model.
+ * target DSHS_DIFFSL_HIP_STATIC: `struct dsh::JitModel` (n <= 8, register-resident; feeds dsh_model_compile);
+ *        DSHS_DIFFSL_HIP_DYNAMIC: per-component device functions for run-time-sized models (feeds dsh_model_compile);
+ *        DSHS_DIFFSL_HOST_C: an extern "C" CPU model (dsl_dims, dsl_rhs, dsl_jac_mul, dsl_mass_gemv, dsl_init, dsl_root, dsl_out) — the shape of the
+ *        reference's external-model ABI (crates/diffsol-c/tests/external-dynamic-logistic/src/lib.rs:123-161).
+ * *source_out is malloc'ed (free with dshs_free_string).  dims[6] = n, nparams, nroots, nout, has_mass, declared-no-inputs (1 = the single
+ * parameter is an unused placeholder).  defaults_out (may be NULL) receives nparams default values. */
+#define DSHS_DIFFSL_HIP_STATIC 0
+#define DSHS_DIFFSL_HIP_DYNAMIC 1
+#define DSHS_DIFFSL_HOST_C 2
+int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap);
+void dshs_free_string(char* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ def lib():
         L.orc_step.argtypes = [C.c_void_p]
         L.orc_set_stop_time.argtypes = [C.c_void_p, C.c_double]
         L.orc_interpolate.argtypes = [C.c_void_p, C.c_double, _dp]
+        L.orc_interpolate_dy.argtypes = [C.c_void_p, C.c_double, _dp]
         L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp, _ip, _dp, _dp]
         L.orc_bdf_get_diff.argtypes = [C.c_void_p, _dp]
         L.orc_root_info.argtypes = [C.c_void_p, _dp, _ip]
@@ -87,6 +88,13 @@ def lib():
         L.orc_model_rhs.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
         L.orc_model_jac_mul.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp]
         L.orc_model_root.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
+        L.orc_load_external_model.argtypes = [C.c_char_p]
+        L.orc_load_external_model.restype = C.c_int
+        L.orc_model_dims.argtypes = [C.c_int, C.c_int, _ip]
+        L.orc_model_init.argtypes = [C.c_int, C.c_int, _dp, C.c_double, _dp]
+        L.orc_model_mass_gemv.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp]
+        L.orc_model_out.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, _dp]
+        L.orc_model_out.restype = C.c_int
         L.orc_model_root.restype = C.c_int
         L.orc_det_fn.argtypes = [C.c_int, C.c_double]
         L.orc_det_fn.restype = C.c_double
@@ -160,6 +168,13 @@ class OracleSolver:
         i = C.c_int()
         lib().orc_root_info(self._h, C.byref(t), C.byref(i))
         return t.value, i.value
+
+    def interpolate_dy(self, t):
+        dy = np.empty((self.nbatch, self.n))
+        r = lib().orc_interpolate_dy(self._h, C.c_double(t), dy.ctypes.data_as(_dp))
+        if r < 0:
+            raise OracleError(f"oracle interpolate_dy failed with OdeErr {-r}")
+        return dy
 
     def stats(self):
         out = (C.c_long * 13)()
@@ -306,3 +321,41 @@ def det_fn(name, x):
     """include/diffsol_detpow.h's elementary functions (the ones the RLC / single-particle registry models are written with)."""
     f = lib().orc_det_fn
     return np.array([f(DET_FN[name], float(v)) for v in np.atleast_1d(x)])
+
+
+def load_external_model(so_path):
+    """Register a CPU model library with the external-model C ABI (dsl_dims, dsl_rhs, ...; generated from DiffSL by the product's front end and
+    compiled by the test) and return its oracle model id."""
+    mid = lib().orc_load_external_model(str(so_path).encode())
+    if mid < 0:
+        raise OracleError(f"cannot load external model {so_path}")
+    return mid
+
+
+def model_dims(model, model_size=0):
+    out = (C.c_int * 5)()
+    lib().orc_model_dims(model, model_size, out)
+    return dict(n=out[0], nparams=out[1], nroots=out[2], nout=out[3], has_mass=bool(out[4]))
+
+
+def model_init(model, p, t=0.0, model_size=0):
+    pa, pp = _d(p)
+    y = np.empty(model_dims(model, model_size)["n"])
+    lib().orc_model_init(model, model_size, pp, t, y.ctypes.data_as(_dp))
+    return y
+
+
+def model_mass_gemv(model, x, p, y, beta, t=0.0, model_size=0):
+    xa, xp = _d(x)
+    pa, pp = _d(p)
+    out = np.array(y, dtype=np.float64)
+    lib().orc_model_mass_gemv(model, model_size, xp, pp, t, beta, out.ctypes.data_as(_dp))
+    return out
+
+
+def model_out(model, x, p, t=0.0, model_size=0):
+    xa, xp = _d(x)
+    pa, pp = _d(p)
+    g = np.zeros(max(model_dims(model, model_size)["nout"], 1))
+    k = lib().orc_model_out(model, model_size, xp, pp, t, g.ctypes.data_as(_dp))
+    return g[:k]

@@ -2,6 +2,7 @@
 //
 // C ABI over the CPU restatement (oracle_*.hpp) so tests/ and bench.py's cpu_baseline leg can drive it
 // through ctypes.  Vectors cross this boundary batch-major ([b][i]) like the reference API.
+#include <dlfcn.h>
 #include "oracle_ode.hpp"
 #include "oracle_sdirk.hpp"
 #include <atomic>
@@ -81,6 +82,15 @@ int orc_interpolate(void* hv, double t, double* y) {
   OdeErr e = h->solver->interpolate_inplace(t, out);
   if (e != OdeErr::Ok) return -(int)e;
   std::memcpy(y, out.d.data(), out.d.size() * sizeof(double));
+  return 0;
+}
+// interpolate_dy_inplace: the value state_mut_back (bdf.rs:1232-1262, runge_kutta.rs:396-434) stores in state.dy after a root stop
+int orc_interpolate_dy(void* hv, double t, double* dy) {
+  Handle* h = (Handle*)hv;
+  V out(h->problem.n(), h->problem.nb());
+  OdeErr e = h->solver->interpolate_dy_inplace(t, out);
+  if (e != OdeErr::Ok) return -(int)e;
+  std::memcpy(dy, out.d.data(), out.d.size() * sizeof(double));
   return 0;
 }
 void orc_get_state(void* hv, double* t, double* hstep, int* order, double* y, double* dy) {
@@ -314,6 +324,42 @@ void orc_model_rhs(int model_id, int model_size, const double* x, const double* 
 void orc_model_jac_mul(int model_id, int model_size, const double* x, const double* p, double t, const double* v, double* y) {
   auto m = make_model(model_id, model_size);
   m->jac_mul(x, p, t, v, y);
+}
+// load a model library generated from DiffSL (diffsol_amd/host/diffsl.hpp, Target::HostC) and register it; returns its model id (>= 1000) or -1
+int orc_load_external_model(const char* path) {
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) { std::fprintf(stderr, "oracle: dlopen(%s) failed: %s\n", path, dlerror()); return -1; }
+  ExternalFns f;
+  f.dims = (decltype(f.dims))dlsym(h, "dsl_dims");
+  f.rhs = (decltype(f.rhs))dlsym(h, "dsl_rhs");
+  f.jac_mul = (decltype(f.jac_mul))dlsym(h, "dsl_jac_mul");
+  f.mass_gemv = (decltype(f.mass_gemv))dlsym(h, "dsl_mass_gemv");
+  f.init = (decltype(f.init))dlsym(h, "dsl_init");
+  f.root = (decltype(f.root))dlsym(h, "dsl_root");
+  f.out = (decltype(f.out))dlsym(h, "dsl_out");
+  if (!f.dims || !f.rhs || !f.jac_mul || !f.mass_gemv || !f.init || !f.root || !f.out) { std::fprintf(stderr, "oracle: %s lacks a dsl_* symbol\n", path); return -1; }
+  external_models().push_back(f);
+  return MODEL_EXTERNAL_BASE + (int)external_models().size() - 1;
+}
+void orc_model_dims(int model_id, int model_size, int* out5) {
+  auto m = make_model(model_id, model_size);
+  out5[0] = m->n; out5[1] = m->np; out5[2] = m->nroots; out5[3] = 0; out5[4] = m->has_mass ? 1 : 0;
+  if (auto* e = dynamic_cast<ExternalModel*>(m.get())) out5[3] = e->nout;
+}
+void orc_model_init(int model_id, int model_size, const double* p, double t, double* y) {
+  auto m = make_model(model_id, model_size);
+  m->init(p, t, y);
+}
+void orc_model_mass_gemv(int model_id, int model_size, const double* x, const double* p, double t, double beta, double* y) {
+  auto m = make_model(model_id, model_size);
+  m->mass(x, p, t, beta, y);
+}
+int orc_model_out(int model_id, int model_size, const double* x, const double* p, double t, double* g) {
+  auto m = make_model(model_id, model_size);
+  auto* e = dynamic_cast<ExternalModel*>(m.get());
+  if (!e) return 0;
+  e->f.out(t, x, p, g);
+  return e->nout;
 }
 int orc_model_root(int model_id, int model_size, const double* x, const double* p, double t, double* g) {
   auto m = make_model(model_id, model_size);

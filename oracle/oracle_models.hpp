@@ -262,7 +262,44 @@ struct Spm : Model {
   }
 };
 
+// A user model compiled to a shared library with the external-model C ABI (dsl_dims, dsl_rhs, dsl_jac_mul, dsl_mass_gemv, dsl_init, dsl_root):
+// the CPU twin of a run-time-compiled device model, so the oracle can integrate exactly the model the GPU integrates.  This is the role of the
+// reference's compiled DiffSL module behind DiffSl<M, CG> (crates/diffsol/src/ode_equations/diffsl.rs: rhs, rhs_grad, mass, set_u0, calc_stop).
+struct ExternalFns {
+  void (*dims)(int*, int*, int*, int*, int*) = nullptr;
+  void (*rhs)(double, const double*, const double*, double*) = nullptr;
+  void (*jac_mul)(double, const double*, const double*, const double*, double*) = nullptr;
+  void (*mass_gemv)(double, const double*, const double*, double, double*) = nullptr;
+  void (*init)(double, const double*, double*) = nullptr;
+  void (*root)(double, const double*, const double*, double*) = nullptr;
+  void (*out)(double, const double*, const double*, double*) = nullptr;
+};
+constexpr int MODEL_EXTERNAL_BASE = 1000;
+inline std::vector<ExternalFns>& external_models() {
+  static std::vector<ExternalFns> v;
+  return v;
+}
+struct ExternalModel : Model {
+  ExternalFns f;
+  int nout = 0;
+  explicit ExternalModel(const ExternalFns& fns) : f(fns) {
+    int hm = 0;
+    f.dims(&n, &np, &nroots, &nout, &hm);
+    has_mass = hm != 0;
+  }
+  void rhs(const double* x, const double* p, double t, double* y) const override { f.rhs(t, x, p, y); }
+  void jac_mul(const double* x, const double* p, double t, const double* v, double* y) const override { f.jac_mul(t, x, p, v, y); }
+  void mass(const double* x, const double* p, double t, double beta, double* y) const override { f.mass_gemv(t, x, p, beta, y); }
+  void init(const double* p, double t, double* y) const override { f.init(t, p, y); }
+  void root(const double* x, const double* p, double t, double* g) const override { f.root(t, x, p, g); }
+};
+
 inline std::unique_ptr<Model> make_model(int id, int size) {
+  if (id >= MODEL_EXTERNAL_BASE) {
+    const size_t k = (size_t)(id - MODEL_EXTERNAL_BASE);
+    if (k >= external_models().size()) throw std::runtime_error("oracle: unknown external model id");
+    return std::make_unique<ExternalModel>(external_models()[k]);
+  }
   switch (id) {
     case MODEL_EXPONENTIAL_DECAY: return std::make_unique<ExponentialDecay>(false);
     case MODEL_EXPONENTIAL_DECAY_ROOT: return std::make_unique<ExponentialDecay>(true);

@@ -407,6 +407,7 @@ struct SolverBase {
   virtual OdeErr step(StopReason& reason) = 0;
   virtual OdeErr set_stop_time(double tstop) = 0;
   virtual OdeErr interpolate_inplace(double t, V& y) const = 0;
+  virtual OdeErr interpolate_dy_inplace(double t, V& dy) const = 0;  // what state_mut_back stores in state.dy after a root stop
   virtual const V& y() const = 0;
   virtual const V& dy() const = 0;
   virtual double t() const = 0;
@@ -583,6 +584,21 @@ struct Bdf : SolverBase {
     }
   }
 
+  static void interpolate_derivative_from_diff(double t, const M& diff, double t1, double h, int order, V& dy) {  // :784-811
+    double pi = 1.0, d_pi = 0.0;
+    fill(dy, 0.0);
+    for (int i = 0; i < order; ++i) {
+      double i_t = (double)i;
+      double denom = h * (1.0 + i_t);
+      double w = (t - (t1 - h * i_t)) / denom;
+      double dw = 1.0 / denom;
+      double new_d_pi = d_pi * w + pi * dw;
+      pi *= w;
+      d_pi = new_d_pi;
+      axpy(dy, d_pi, diff.column(i + 1), 1.0);
+    }
+  }
+
   double error_control() const {  // :812-843 (main equations only)
     double err = squared_norm(y_delta, y_, pr->atol, pr->rtol) * error_const2[order_ - 1];
     return std::fmax(0.0, err);  // `error_norm.max(err)` starting from zero (f64::max drops NaN like fmax)
@@ -698,6 +714,12 @@ struct Bdf : SolverBase {
     bool is_forward = h_ > 0.0;
     if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
     interpolate_from_diff(t, diff, t_, h_, order_, y);
+    return OdeErr::Ok;
+  }
+  OdeErr interpolate_dy_inplace(double t, V& dy) const override {  // :1108-1132
+    bool is_forward = h_ > 0.0;
+    if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
+    interpolate_derivative_from_diff(t, diff, t_, h_, order_, dy);
     return OdeErr::Ok;
   }
   const V& y() const override { return y_; }

@@ -349,6 +349,39 @@ struct Sdirk : SolverBase {
     }
     return OdeErr::Ok;
   }
+  OdeErr interpolate_dy_inplace(double t, V& dy) const override {  // runge_kutta.rs:1129-1181
+    bool is_forward = state.h > 0.0;
+    if ((is_forward && (t > state.t || t < old_state.t)) || (!is_forward && (t < state.t || t > old_state.t)))
+      return OdeErr::InterpolationTimeOutsideCurrentStep;
+    double dt = state.t - old_state.t;
+    if (dt == 0.0) { copy_from(dy, state.dy); return OdeErr::Ok; }
+    double theta = (t - old_state.t) / dt;
+    const double scale_diff = 1.0;
+    if (tab.has_beta) {  // interpolate_beta_function_deriv (:985-1002): d_thetav = [1, 2 theta, 3 theta^2, ...]
+      int poly_order = tab.beta.nc, s_star = tab.beta.nr;
+      std::vector<double> d_thetav{1.0};
+      double theta_pow = theta;
+      for (int i = 1; i < poly_order; ++i) { d_thetav.push_back(((double)i + 1.0) * theta_pow); theta_pow *= theta; }
+      V d_beta_f(s_star, 1);
+      gemv_cols(tab.beta, poly_order, 1.0, d_thetav.data(), 0.0, d_beta_f);
+      gemv_cols(diff, s_star, scale_diff / dt, d_beta_f.d.data(), 0.0, dy);
+    } else {  // interpolate_hermite_deriv (:1037-1078)
+      V f0 = diff.column(0), f1 = diff.column(diff.nc - 1);
+      V q = state.y;
+      sub_assign(q, old_state.y);
+      axpy(q, scale_diff * (theta - 1.0), f0, 1.0 - 2.0 * theta);
+      axpy(q, scale_diff * theta, f1, 1.0);
+      copy_from(dy, state.y);
+      sub_assign(dy, old_state.y);
+      axpy(dy, (2.0 * theta - 1.0) / dt, q, 1.0 / dt);
+      copy_from(q, old_state.y);
+      sub_assign(q, state.y);
+      axpy(q, scale_diff, f0, 2.0);
+      axpy(q, scale_diff, f1, 1.0);
+      axpy(dy, theta * (theta - 1.0) / dt, q, 1.0);
+    }
+    return OdeErr::Ok;
+  }
   const V& y() const override { return state.y; }
   const V& dy() const override { return state.dy; }
   double t() const override { return state.t; }

@@ -1,0 +1,194 @@
+"""DiffSL texts used by the DiffSL tests, and the glue that gives the CPU oracle the same user model the GPU gets.
+
+The texts are written here (the reference's own DiffSL sources are not copied): the expressions follow the arithmetic order of the built-in registry
+models (csrc/dsh_models.hpp, oracle/oracle_models.hpp), which in turn follow the reference closures, so `DiffSL model == built-in model` can be
+asserted bit for bit wherever the front end adds no arithmetic of its own."""
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ROBERTSON_ODE = """
+in = [k1, k2, k3]
+k1 { 0.04 } k2 { 10000 } k3 { 30000000 }
+u_i { x = 1, y = 0, z = 0 }
+F_i {
+  -k1 * x + k2 * y * z,
+  k1 * x - k2 * y * z - k3 * y * y,
+  k3 * y * y,
+}
+"""
+
+ROBERTSON_DAE = """
+in = [k1, k2, k3]
+k1 { 0.04 } k2 { 10000 } k3 { 30000000 }
+u_i { x = 1, y = 0, z = 0 }
+dudt_i { dxdt = 0, dydt = 0, dzdt = 0 }
+M_i { dxdt, dydt, 0 }
+F_i {
+  -k1 * x + k2 * y * z,
+  k1 * x - k2 * y * z - k3 * y * y,
+  x + y + z - 1,
+}
+out_i { x, y, z, x + y + z }
+"""
+
+# the electrical-circuits primer model with per-member inputs and a threshold event (BASELINE config 5)
+RLC = """
+in = [R, L, C, V0, omega, ithresh]
+R { 100.0 } L { 1.0 } C { 0.001 } V0 { 10 } omega { 100.0 } ithresh { 0.05 }
+Vs { V0 * sin(omega * t) }
+u_i { iR = 0, iL = 0, iC = 0, V = 0 }
+dudt_i { diRdt = 0, diLdt = 0, diCdt = 0, dVdt = 0 }
+M_i { 0, diLdt, 0, dVdt }
+F_i {
+  V - R * iR,
+  (Vs - V) / L,
+  iL - iR - iC,
+  iC / C,
+}
+stop_i { iR - ithresh }
+out_i { V, iR }
+"""
+
+LOGISTIC = """
+in = [r, k]
+r { 1 } k { 1 }
+u_i { y = 0.1 }
+F_i { r * y * (1 - y / k) }
+stop_i { y - 0.9 * k }
+"""
+
+# every function of the language once, smooth at the evaluation points used by the derivative check
+ZOO = """
+in = [a, b]
+a { 0.7 } b { 1.3 }
+u_i { x = 0.4, y = 0.9, z = 1.7 }
+F_i {
+  sin(a * x) * cos(y) + tan(0.3 * z) - exp(-x * y) + log(z + b) + log10(y + 2),
+  sqrt(x + y * y) * abs(x - z) + sigmoid(a * y) + tanh(x * z) + sinh(0.5 * y) - cosh(0.3 * x),
+  arcsinh(x * y) + arccosh(z + 1) + pow(y, b) + pow(x + 2, 3) + min(x * x, y) * max(z, a * x) + copysign(y, -z) + heaviside(x) * z / (b + t),
+}
+"""
+
+
+def heat1d(n):
+    """test_models/heat1d.rs as DiffSL: D (A u) / h^2, A = tridiag(1, -2, 1), h = 1/(n+1), triangle initial condition."""
+    ic = []
+    for i in range(n):
+        xx = (i + 1) * (1.0 / (n + 1))
+        ic.append(repr(2.0 * xx if xx < 0.5 else 2.0 * (1.0 - xx)))
+    init = ",\n".join(f"  ({i}): {v}" for i, v in enumerate(ic))
+    return f"""
+in = [D]
+D {{ 1.0 }}
+h {{ 1.0 / {float(n + 1)!r} }}
+A_ij {{
+  (1..{n}, 0..{n - 1}): 1.0,
+  (0..{n}, 0..{n}): -2.0,
+  (0..{n - 1}, 1..{n}): 1.0,
+}}
+u_i {{
+{init}
+}}
+heat_i {{ A_ij * u_j }}
+F_i {{ D * heat_i / (h * h) }}
+"""
+
+
+def spm(m=20):
+    """The single-particle model of the battery primer (n = 2 + 2m) written as DiffSL from its formulas: spherical finite-volume Laplacians as sparse
+    matrices, flux terms on the outer shells, terminal-voltage stop conditions.  Constants as in the built-in model (oracle_models.hpp Spm)."""
+    def lap(scale):
+        rows = []
+        dr = 1.0 / m
+        for k in range(m):
+            i0, i1 = float(k), float(k + 1)
+            vol = i1 * i1 * i1 - i0 * i0 * i0
+            lower = 3.0 * i0 * i0 / vol / (dr * dr) * scale
+            upper = 3.0 * i1 * i1 / vol / (dr * dr) * scale if k + 1 < m else 0.0
+            if k > 0:
+                rows.append(f"  ({k},{k - 1}): {lower!r}")
+            rows.append(f"  ({k},{k}): {-(lower + upper)!r}")
+            if k + 1 < m:
+                rows.append(f"  ({k},{k + 1}): {upper!r}")
+        return ",\n".join(rows)
+    a, b = 2 + m, 2 + 2 * m
+    surf = lambda name: f"{name}_ij {{ ({0},{m - 2}): -0.5, ({0},{m - 1}): 1.5 }}"
+    ocp_p = ("2.16216 + 0.07645 * tanh(30.834 - 57.858397200000006 * sp) + 2.1581 * tanh(52.294 - 53.412228 * sp) - 0.14169 * tanh(11.0923 - 21.0852666 * sp) + "
+             "0.2051 * tanh(1.4684 - 5.829105600000001 * sp) + 0.2531 * tanh(4.291641337386018 - 8.069908814589667 * sp) - 0.02167 * tanh(-87.5 + 177.0 * sp)")
+    return f"""
+in = [current]
+current {{ 1.0 }}
+Aneg_ij {{
+{lap(0.39e-3)}
+}}
+Apos_ij {{
+{lap(1.0e-3)}
+}}
+eneg_i {{ (0:{m - 1}): 0.0, ({m - 1}): {3.2835305549534856e-12 * -520607810.21082705!r} }}
+epos_i {{ (0:{m - 1}): 0.0, ({m - 1}): {4.106800547504748e-12 * 243644455.17866704!r} }}
+{surf("S")}
+u_i {{
+  q = 0.0,
+  thr = 0.0,
+  (2:{a}): cn = 0.8000000000000016,
+  ({a}:{b}): cp = 0.6000000000000001,
+}}
+ln_i {{ Aneg_ij * cn_j }}
+lp_i {{ Apos_ij * cp_j }}
+sn_i {{ S_ij * cn_j }}
+sp_i {{ S_ij * cp_j }}
+F_i {{
+  0.0002777777777777778 * current,
+  0.0002777777777777778 * abs(current),
+  ln_i + eneg_i * current,
+  lp_i + epos_i * current,
+}}
+stop_i {{
+  sn_i - 0.05,
+  sp_i - 0.99,
+}}
+out_i {{ sn_i, sp_i, {ocp_p.replace("sp", "sp_i")} }}
+"""
+
+
+_cache = {}
+
+
+def host_model(O, code):
+    """DiffSL text -> CPU model library (product front end, Target::HostC) -> compiled with g++ -> registered with the oracle.  Returns the oracle id."""
+    key = hashlib.sha1(code.encode()).hexdigest()
+    if key in _cache:
+        return _cache[key]
+    from diffsol_amd import diffsl
+    src, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C)
+    d = tempfile.mkdtemp(prefix="dsl_host_")
+    cpp, so = os.path.join(d, "model.cpp"), os.path.join(d, "libmodel.so")
+    with open(cpp, "w") as f:
+        f.write(src)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-o", so, cpp], check=True)
+    mid = O.load_external_model(so)
+    assert O.model_dims(mid)["n"] == dims["n"]
+    _cache[key] = mid
+    return mid
+
+
+# run-time-sized DAE: heat conduction on 10 interior nodes with the two boundary values as algebraic states (singular mass matrix, n = 12)
+HEAT_DAE = """
+in = [D]
+D { 1.0 }
+A_ij { (1..10, 0..9): 1.0, (0..10, 0..10): -2.0, (0..9, 1..10): 1.0 }
+eleft_i { (0): 1.0, (1:10): 0.0 }
+eright_i { (0:9): 0.0, (9): 1.0 }
+u_i { a = 0, (1:11): y = 1, b = 0 }
+dudt_i { dadt = 0, (1:11): dydt = 0, dbdt = 0 }
+lap_i { A_ij * y_j }
+M_i { 0, dydt_i, 0 }
+F_i { a, D * (lap_i + eleft_i * a + eright_i * b) * 121.0, b }
+out_i { y_i * y_i }
+"""

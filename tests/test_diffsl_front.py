@@ -1,0 +1,147 @@
+"""DiffSL front end (diffsol_amd/host/diffsl.hpp) on the CPU: the generated HOST model against the hand-written oracle models and against finite
+differences, the language rules, and that the generated DEVICE models compile for gfx950 with hiprtc (no GPU needed for any of this)."""
+import numpy as np
+import pytest
+
+import diffsl_models as D
+from helpers import ORACLE_MODEL
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from diffsol_amd import diffsl
+    return diffsl
+
+
+@pytest.mark.parametrize("name,code,builtin,size,bitwise_jac", [
+    ("robertson_ode", D.ROBERTSON_ODE, "robertson_ode", 1, False),   # d(k3 y y) is written 2 k3 y v by hand, (k3 v) y + (k3 y) v by the generator
+    ("robertson", D.ROBERTSON_DAE, "robertson", 0, False),
+    ("rlc", D.RLC, "rlc", 1, True),
+    ("heat1d", D.heat1d(16), "heat1d", 16, True),
+])
+def test_generated_host_model_equals_the_hand_written_oracle_model(O, fe, name, code, builtin, size, bitwise_jac):
+    """rhs / init / mass / root of the DiffSL model are BIT-identical to the independent hand-written restatement of the same reference model;
+    J v too where forward-mode differentiation yields the hand-written operation order, else to rounding."""
+    mid, ref = D.host_model(O, code), ORACLE_MODEL[builtin]
+    dims, rdims = O.model_dims(mid), O.model_dims(ref, size)
+    assert (dims["n"], dims["nparams"], dims["nroots"], dims["has_mass"]) == (rdims["n"], rdims["nparams"], rdims["nroots"], rdims["has_mass"])
+    rng = np.random.default_rng(dims["n"])
+    for _ in range(5):
+        x, v, p, t = rng.uniform(0.1, 1.0, dims["n"]), rng.standard_normal(dims["n"]), rng.uniform(0.5, 2.0, dims["nparams"]), rng.uniform(0.0, 2.0)
+        assert np.array_equal(O.model_rhs(mid, x, p, t), O.model_rhs(ref, x, p, t, size))
+        a, b = O.model_jac_mul(mid, x, p, v, t), O.model_jac_mul(ref, x, p, v, t, size)
+        assert np.array_equal(a, b) if bitwise_jac else np.allclose(a, b, rtol=1e-14, atol=1e-14 * np.abs(b).max())
+        assert np.array_equal(O.model_init(mid, p), O.model_init(ref, p, 0.0, size))
+        if dims["has_mass"]:
+            y = rng.standard_normal(dims["n"])
+            assert np.array_equal(O.model_mass_gemv(mid, x, p, y, 0.7), O.model_mass_gemv(ref, x, p, y, 0.7, model_size=size))
+        if dims["nroots"]:
+            assert np.array_equal(O.model_root(mid, x, p, t), O.model_root(ref, x, p, t, size))
+
+
+def test_spm_written_as_diffsl_matches_the_built_in_single_particle_model(O, fe):
+    """n = 42, sparse Laplacians as matrix-vector contractions: same coefficients as the built-in model, summation order of a row differs
+    (diagonal first there, column order here), so equality is to rounding."""
+    mid, ref = D.host_model(O, D.spm(20)), ORACLE_MODEL["spm"]
+    assert O.model_dims(mid)["n"] == 42 and O.model_dims(mid)["nroots"] == 2 and O.model_dims(mid)["nout"] == 3
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(0, 1, 2), rng.uniform(2e3, 2e4, 20), rng.uniform(2e4, 4.5e4, 20)])
+    p, v = np.array([1.1]), rng.standard_normal(42)
+    a, b = O.model_rhs(mid, x, p), O.model_rhs(ref, x, p, 0.0, 20)
+    assert np.allclose(a, b, rtol=1e-13, atol=1e-13 * np.abs(b).max())
+    a, b = O.model_jac_mul(mid, x, p, v), O.model_jac_mul(ref, x, p, v, 0.0, 20)
+    assert np.allclose(a, b, rtol=1e-13, atol=1e-13 * np.abs(b).max())
+    assert np.array_equal(O.model_init(mid, p), O.model_init(ref, p, 0.0, 20))
+    out = O.model_out(mid, x, p)
+    assert out[0] == 1.5 * x[21] - 0.5 * x[20] and out[1] == 1.5 * x[41] - 0.5 * x[40]
+
+
+def test_forward_mode_jacobian_of_every_language_function_against_central_differences(O, fe):
+    mid = D.host_model(O, D.ZOO)
+    x, p, t = np.array([0.4, 0.9, 1.7]), np.array([0.7, 1.3]), 0.25
+    rng = np.random.default_rng(2)
+    for _ in range(4):
+        v = rng.standard_normal(3)
+        eps = 1e-6
+        fd = (O.model_rhs(mid, x + eps * v, p, t) - O.model_rhs(mid, x - eps * v, p, t)) / (2 * eps)
+        assert np.allclose(O.model_jac_mul(mid, x, p, v, t), fd, rtol=2e-8, atol=1e-8)
+    # and the values themselves against numpy
+    a, b = p
+    xx, y, z = x
+    ref = [np.sin(a * xx) * np.cos(y) + np.tan(0.3 * z) - np.exp(-xx * y) + np.log(z + b) + np.log10(y + 2),
+           np.sqrt(xx + y * y) * abs(xx - z) + 1 / (1 + np.exp(-a * y)) + np.tanh(xx * z) + np.sinh(0.5 * y) - np.cosh(0.3 * xx),
+           np.arcsinh(xx * y) + np.arccosh(z + 1) + y ** b + (xx + 2) ** 3 + min(xx * xx, y) * max(z, a * xx) + np.copysign(y, -z) + 1.0 * z / (b + t)]
+    assert np.allclose(O.model_rhs(mid, x, p, t), ref, rtol=1e-14)
+
+
+def test_oracle_solves_the_diffsl_robertson_like_the_built_in_one(O, fe, kats):
+    """The reference's Robertson known-answer table through a DiffSL model on the CPU: same acceptance norm as ode_solver/mod.rs:164-173."""
+    from helpers import weighted_error_norm
+    mid = D.host_model(O, D.ROBERTSON_ODE)
+    pts = kats["robertson_ode_table"]["points"]
+    times = [pt["t"] for pt in pts][1:8]
+    o = O.OracleSolver(mid, [[0.04, 1e4, 3e7]], nbatch=1, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    y, _ = o.solve_to_points(times)
+    for k, pt in enumerate(pts[1:8]):
+        assert weighted_error_norm(y[k, 0], pt["y"][:3], [1e-8, 1e-14, 1e-6], 1e-4) < 20.0
+
+
+@pytest.mark.parametrize("code,msg", [
+    ("u_i { x = 1 } F_i { y }", "unknown name 'y'"),
+    ("u_i { x = 1, y = 2 } F_i { x }", "F_i has 1 components but u_i has 2"),
+    ("F_i { 1 }", "must follow u_i"),
+    ("u_i { x = 1 } F_i { foo(x) }", "unknown function 'foo'"),
+    ("a_i { 1, 2, 3 } b_i { 1, 2 } u_i { x = 1 } c_i { a_i + b_i } F_i { x }", "extent"),
+    ("u_i { x = 1 } dudt_i { dxdt = 0 } M_i { x * dxdt } F_i { x }", "must be linear in dudt"),
+    ("u_i { x = 1 } F_i { x ", "expected"),
+    ("A_ij { (0,0): 1, (1,1): 2 } b_i { 1, 2 } u_i { x = 1, y = 1 } F_i { A_ij * u_j + b_i }", "does not appear in every term"),
+    ("A_ij { (0,0): 1, (1,1): 2 } u_i { x = 1, y = 1 } F_i { A_i * u_i }", "has rank 2"),
+])
+def test_front_end_rejects_malformed_models_with_a_located_message(fe, code, msg):
+    from diffsol_amd import DiffsolHipError
+    with pytest.raises(DiffsolHipError) as e:
+        fe.generate(code, fe.TARGET_HOST_C)
+    assert msg in str(e.value) and "diffsl:" in str(e.value)
+
+
+def test_language_rules_ranges_labels_broadcast_contraction_and_defaults(O, fe):
+    code = """
+    in { k = 2.5, q = -1 }
+    c { 3 }
+    A_ij { (0:2, 0:2): c, (2,2): k, (0..2, 1..3): 7 }
+    w_i { (0:2): 1, (2): q }
+    u_i { (0:2): a = 1, b = c + k }
+    s { w_i * u_i }            // contraction of a whole expression to a scalar
+    Au_i { A_ij * u_j }
+    F_i { Au_i + s * w_i }
+    out_i { a_i, s }
+    """
+    src, dims, defaults = fe.generate(code, fe.TARGET_HOST_C)
+    assert dims["n"] == 3 and dims["nparams"] == 2 and dims["nout"] == 3 and defaults.tolist() == [2.5, -1.0]
+    mid = D.host_model(O, code)
+    p, x = np.array([2.5, -1.0]), np.array([0.5, -2.0, 4.0])
+    A = np.array([[3, 3 + 7, 0], [3, 3, 7], [0, 0, 2.5]], dtype=float)
+    A[0, 1] = 7.0  # the later diagonal element overwrites the dense block entry
+    w = np.array([1, 1, -1.0])
+    s = w @ x
+    assert np.allclose(O.model_rhs(mid, x, p), A @ x + s * w, rtol=1e-15)
+    assert np.array_equal(O.model_init(mid, p), [1.0, 1.0, 5.5])
+    assert np.allclose(O.model_out(mid, x, p), [0.5, -2.0, s])
+
+
+def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
+    """hiprtc cross-compiles: the register-resident form with its fused Newton kernels and a device-resident integrator, and the run-time-sized form."""
+    m = fe.DiffslModel(D.RLC)
+    assert m.form == fe.FORM_STATIC and (m.n, m.nparams, m.nroots, m.nout, m.has_mass) == (4, 6, 1, 2, True)
+    m.precompile(fe.FAMILY_FUSED)
+    m.precompile(fe.FAMILY_RESIDENT_SDIRK)
+    m.release()
+    h = fe.DiffslModel(D.heat1d(24))
+    assert h.form == fe.FORM_DYNAMIC and h.n == 24
+    with pytest.raises(Exception) as e:
+        h.precompile(fe.FAMILY_FUSED)
+    assert "run-time-sized" in str(e.value)
+    h.release()
+    s = fe.DiffslModel(D.spm(20))
+    assert s.form == fe.FORM_DYNAMIC and s.n == 42 and s.nroots == 2
+    s.release()

@@ -1,0 +1,206 @@
+"""DiffSL models on the GPU: DiffSL text -> front end -> hiprtc -> the library's own kernel templates instantiated for the user's model.
+
+Oracle: the SAME DiffSL text through the front end's host target, compiled with g++ and loaded into the CPU restatement as an external model
+(tests/diffsl_models.py host_model).  Both sides evaluate the generated expressions in the same order with the same deterministic elementary functions,
+so every comparison below is bit for bit.  The front end itself is checked independently on the CPU (tests/test_diffsl_front.py: generated model ==
+hand-written model)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import diffsl_models as D
+from helpers import METHOD, robertson_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import diffsol_amd
+    return diffsol_amd
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from diffsol_amd import diffsl
+    return diffsl
+
+
+@pytest.fixture
+def det_pow(O):
+    O.set_det_pow(True)
+    yield
+    O.set_det_pow(False)
+
+
+CASES = {"robertson": D.ROBERTSON_DAE, "rlc": D.RLC, "logistic": D.LOGISTIC, "zoo": D.ZOO, "heat16": D.heat1d(16), "spm": D.spm(20), "heat_dae": D.HEAT_DAE}
+
+
+def _sample(name, dims, rng, nb):
+    n = dims["n"]
+    if name == "spm":
+        x = np.concatenate([rng.uniform(0, 1, (nb, 2)), rng.uniform(2e3, 2e4, (nb, 20)), rng.uniform(2e4, 4.5e4, (nb, 20))], axis=1)
+    else:
+        x = rng.uniform(0.2, 1.5, (nb, n))
+    return x, rng.standard_normal((nb, n)), rng.uniform(0.5, 2.0, (nb, dims["nparams"]))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_every_operator_of_a_compiled_model_matches_the_cpu_model_bitwise(H, O, fe, name):
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    m = fe.DiffslModel(CASES[name])
+    mid = D.host_model(O, CASES[name])
+    dims = O.model_dims(mid)
+    assert (m.n, m.nparams, m.nroots, m.nout, m.has_mass) == (dims["n"], dims["nparams"], dims["nroots"], dims["nout"], dims["has_mass"])
+    assert m.form == (fe.FORM_STATIC if m.n <= 8 and m.nroots <= 1 else fe.FORM_DYNAMIC)
+    nb, n, t = 70, m.n, 0.37
+    c = H.HipContext(nbatch=nb)
+    rng = np.random.default_rng(n)
+    x, v, p = _sample(name, dims, rng, nb)
+    X, V, P, Y = H.HipVec.from_vec(x, c), H.HipVec.from_vec(v, c), H.HipVec.from_vec(p, c), H.HipVec.zeros(n, c)
+    i64, i32 = C.c_int64(), C.c_int()
+    assert L.dsh_model_info(m.model_id, 0, C.byref(i64), None, C.byref(i32), None) == 0 and i64.value == n and bool(i32.value) == m.has_mass
+    assert L.dsh_model_rhs(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, Y.ptr) == 0
+    assert np.array_equal(Y.clone_as_vec(), np.stack([O.model_rhs(mid, x[b], p[b], t) for b in range(nb)]))
+    assert L.dsh_model_jac_mul(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, V.ptr, Y.ptr) == 0
+    assert np.array_equal(Y.clone_as_vec(), np.stack([O.model_jac_mul(mid, x[b], p[b], v[b], t) for b in range(nb)]))
+    J = H.HipMat.zeros(n, n, c)
+    assert L.dsh_model_jacobian(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, J.ptr) == 0
+    jref = np.empty((nb, n, n))
+    for b in range(nb):
+        for j in range(n):
+            e = np.zeros(n); e[j] = 1.0
+            jref[b, :, j] = O.model_jac_mul(mid, x[b], p[b], e, t)
+    assert np.array_equal(J.to_array(), jref)
+    assert L.dsh_model_init(c._h, m.model_id, 0, nb, 0.0, P.ptr, Y.ptr) == 0
+    assert np.array_equal(Y.clone_as_vec(), np.stack([O.model_init(mid, p[b]) for b in range(nb)]))
+    y0 = rng.standard_normal((nb, n))
+    Y = H.HipVec.from_vec(y0, c)
+    assert L.dsh_model_mass_gemv(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, 0.6, Y.ptr) == 0
+    assert np.array_equal(Y.clone_as_vec(), np.stack([O.model_mass_gemv(mid, x[b], p[b], y0[b], 0.6, t) for b in range(nb)]))
+    if m.has_mass:
+        Mm = H.HipMat.zeros(n, n, c)
+        assert L.dsh_model_mass_matrix(c._h, m.model_id, 0, nb, t, P.ptr, Mm.ptr) == 0
+        mref = np.stack([np.stack([O.model_mass_gemv(mid, np.eye(n)[j], p[b], np.zeros(n), 0.0, t) for j in range(n)], axis=1) for b in range(nb)])
+        assert np.array_equal(Mm.to_array(), mref)
+    if m.nroots:
+        G = H.HipVec.zeros(m.nroots, c)
+        assert L.dsh_model_root(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, G.ptr) == 0
+        assert np.array_equal(G.clone_as_vec(), np.stack([O.model_root(mid, x[b], p[b], t, 0, max_roots=8) for b in range(nb)]))
+    if m.nout:
+        G = H.HipVec.zeros(m.nout, c)
+        assert L.dsh_model_out(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, G.ptr) == 0
+        assert np.array_equal(G.clone_as_vec(), np.stack([O.model_out(mid, x[b], p[b], t) for b in range(nb)]))
+    else:
+        assert L.dsh_model_out(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, Y.ptr) < 0
+    old_id = m.model_id
+    m.release()
+    assert L.dsh_model_rhs(c._h, old_id, 0, nb, t, X.ptr, P.ptr, Y.ptr) < 0  # released id: loud error, not a stale kernel
+
+
+def _pair(H, O, fe, code, p, method, **tol):
+    m = fe.DiffslModel(code)
+    mid = D.host_model(O, code)
+    nb = len(p)
+    s = H.Solver(m, p, nbatch=nb, method=METHOD[method], **tol)
+    o = O.OracleSolver(mid, p, nbatch=nb, method=METHOD[method], **tol)
+    return m, s, o
+
+
+def test_lockstep_bdf_on_a_compiled_robertson_uses_the_fused_kernels_and_matches_the_oracle_bitwise(H, O, fe):
+    p = robertson_params(64, seed=3)
+    m, s, o = _pair(H, O, fe, D.ROBERTSON_ODE, p, "bdf", rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    assert s.fused and m.form == fe.FORM_STATIC
+    times = [0.4, 4.0, 40.0, 400.0, 4000.0]
+    y, _ = s.solve_to_points(times)
+    yo, _ = o.solve_to_points(times)
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    # and the built-in model gives the same trajectories to rounding (its hand-written J v orders one product differently)
+    yb, _ = H.Solver("robertson_ode", p, nbatch=64, model_size=1, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6]).solve_to_points(times)
+    assert np.allclose(y, yb, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_lockstep_dae_with_mass_matrix_and_consistent_initialisation(H, O, fe, method):
+    p = robertson_params(16, seed=4)
+    m, s, o = _pair(H, O, fe, D.ROBERTSON_DAE, p, method, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+    y, _ = s.solve_to_points([0.4, 4.0, 40.0])
+    yo, _ = o.solve_to_points([0.4, 4.0, 40.0])
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    assert np.allclose(y.sum(axis=2), 1.0, atol=1e-5)
+
+
+def test_lockstep_rlc_with_event_from_diffsl(H, O, fe):
+    p = np.tile([100.0, 1.0, 1e-3, 10.0, 100.0, 0.01], (4, 1))
+    m, s, o = _pair(H, O, fe, D.RLC, p, "esdirk34", rtol=1e-6, atol=[1e-6] * 4)
+    _, _, reason = s.solve(1.0)
+    o.solve(1.0)
+    assert reason == 1 and s.root_info() == o.root_info() and s.stats() == o.stats()
+    st, t_root = s.state(), s.root_info()[0]  # the solver moved its state back to the root time (state_mut_back): y and dy from the step's interpolants
+    assert st["t"] == t_root and np.array_equal(st["y"], o.interpolate(t_root)) and np.array_equal(st["dy"], o.interpolate_dy(t_root))
+
+
+@pytest.mark.parametrize("name,method,times", [("heat16", "tr_bdf2", [0.01, 0.05]), ("heat_dae", "bdf", [0.005, 0.02]), ("spm", "bdf", [60.0, 600.0])])
+def test_lockstep_run_time_sized_models_from_diffsl(H, O, fe, name, method, times):
+    rng = np.random.default_rng(7)
+    p = rng.uniform(0.6, 1.4, (9, 1))
+    m, s, o = _pair(H, O, fe, CASES[name], p, method, rtol=1e-6, atol=[1e-6])
+    assert m.form == fe.FORM_DYNAMIC and not s.fused
+    y, _ = s.solve_to_points(times)
+    yo, _ = o.solve_to_points(times)
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    if name == "heat_dae":
+        assert np.all(np.abs(y[..., 0]) < 1e-12) and np.all(np.abs(y[..., -1]) < 1e-12) and np.all(y[..., 1:-1] > 0.0)
+
+
+def test_spm_from_diffsl_stops_at_its_surface_concentration_limit_like_the_oracle(H, O, fe):
+    p = np.full((3, 1), 1.2)
+    m, s, o = _pair(H, O, fe, D.spm(20), p, "bdf", rtol=1e-6, atol=[1e-6])
+    _, _, reason = s.solve(20000.0)
+    o.solve(20000.0)
+    assert reason == 1 and s.root_info() == o.root_info() and s.root_info()[0] < 20000.0
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_device_resident_bdf_on_a_compiled_model_is_bit_identical_to_independent_cpu_solves(H, O, fe, det_pow, group):
+    p = robertson_params(300, seed=8)
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    m = fe.DiffslModel(D.ROBERTSON_ODE)
+    mid = D.host_model(O, D.ROBERTSON_ODE)
+    s = H.Solver(m, p, nbatch=len(p), **tol)
+    t_eval = [0.4, 4.0, 40.0, 400.0, 4000.0, 40000.0]
+    y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=group, method=0, **tol)
+    assert failed == 0 and (mem["status"] == 0).all()
+    assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+
+
+def test_device_resident_esdirk34_with_per_member_events_on_the_compiled_rlc(H, O, fe, det_pow):
+    nb = 120
+    rng = np.random.default_rng(5)
+    R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, 0.03)], axis=1)
+    tol = dict(rtol=1e-6, atol=[1e-6] * 4)
+    m = fe.DiffslModel(D.RLC)
+    mid = D.host_model(O, D.RLC)
+    s = H.Solver(m, p, nbatch=nb, method=METHOD["esdirk34"], **tol)
+    t_eval = [0.002, 0.005, 0.01, 0.02, 0.05]
+    y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=1, method=2, **tol)
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and (mem["status"] == 0).all() and 0 < (mem["root_idx"] >= 0).sum() < nb
+    assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+    assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+
+
+def test_a_model_that_does_not_compile_is_rejected_with_the_compiler_log(H, fe):
+    from diffsol_amd import _ffi, DiffsolHipError
+    L = _ffi.load_device_lib()
+    mid = C.c_int()
+    rc = L.dsh_model_compile(b"namespace dsh { struct JitModel { static constexpr int N = 2; this is not C++ }; }", 0, 2, 1, 0, 0, 0, C.byref(mid))
+    assert rc < 0 and b"error" in L.dsh_last_error()
+    good = fe.generate(D.LOGISTIC, fe.TARGET_HIP_STATIC)[0]
+    rc = L.dsh_model_compile(good.encode(), 0, 3, 2, 1, 0, 0, C.byref(mid))  # wrong n for this source
+    assert rc < 0 and b"dimensions do not match" in L.dsh_last_error()

@@ -281,3 +281,20 @@ def test_tight_tolerance_ensemble_within_1e6_relative_of_independent_cpu_referen
     for b in range(0, nb, 8):
         yo, _ = O.OracleSolver(ORACLE_MODEL["robertson_ode"], p[b], model_size=1, **kw).solve(40.0)
         assert np.max(np.abs(y[b] - yo[0]) / np.abs(yo[0])) < 1e-6
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_after_a_root_stop_the_state_sits_at_the_root_with_interpolated_y_and_dy(H, O, method):
+    """OdeSolverMethod::solve on RootFound calls state_mut_back(t_root) (method.rs, bdf.rs:1232-1262, runge_kutta.rs:396-434): state.y and state.dy
+    become the step's interpolants at the root time (BDF difference polynomial and its derivative; TR-BDF2 beta polynomial; ESDIRK34 Hermite) —
+    no extra right-hand-side evaluation, so the call counters stay the reference's."""
+    p = [[0.1, 1.0], [0.1, 1.0], [0.1, 1.0]]
+    s = H.Solver("exponential_decay_with_root", p, nbatch=3, method=METHOD[method], rtol=1e-6, atol=[1e-6, 1e-6])
+    o = O.OracleSolver(ORACLE_MODEL["exponential_decay_with_root"], p, nbatch=3, method=METHOD[method], rtol=1e-6, atol=[1e-6, 1e-6])
+    _, _, reason = s.solve(50.0)
+    o.solve(50.0)
+    t_root = s.root_info()[0]
+    assert reason == 1 and s.root_info() == o.root_info() and abs(t_root - np.log(1.0 / 0.6) / 0.1) < 1e-4 and s.stats() == o.stats()
+    st = s.state()
+    assert st["t"] == t_root and np.array_equal(st["y"], o.interpolate(t_root)) and np.array_equal(st["dy"], o.interpolate_dy(t_root))
+    assert np.allclose(st["dy"], -0.1 * st["y"], rtol=1e-3)
