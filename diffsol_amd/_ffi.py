@@ -126,6 +126,8 @@ class DshsOptions(C.Structure):
         ("nonlinear_solver_tolerance", dbl), ("min_timestep", dbl), ("update_jacobian_after_steps", cint),
         ("update_rhs_jacobian_after_steps", cint), ("threshold_to_update_jacobian", dbl), ("threshold_to_update_rhs_jacobian", dbl),
         ("ic_use_linesearch", cint), ("use_fused_kernels", cint), ("block_threads", cint),
+        ("ic_max_linesearch_iterations", cint), ("ic_max_linear_solver_setups", cint), ("ic_max_newton_iterations", cint),
+        ("ic_step_reduction_factor", dbl), ("ic_armijo_constant", dbl),
     ]
 
 

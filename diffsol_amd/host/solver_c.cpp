@@ -100,6 +100,11 @@ void dshs_default_options(dshs_options* o) {
   o->ic_use_linesearch = 1;
   o->use_fused_kernels = 1;
   o->block_threads = 0;
+  o->ic_max_linesearch_iterations = 10;
+  o->ic_max_linear_solver_setups = 4;
+  o->ic_max_newton_iterations = 10;
+  o->ic_step_reduction_factor = 0.5;
+  o->ic_armijo_constant = 1e-4;
 }
 
 int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
@@ -124,6 +129,11 @@ int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t
     oo.threshold_to_update_rhs_jacobian = o.threshold_to_update_rhs_jacobian;
     InitialConditionSolverOptions ic;
     ic.use_linesearch = o.ic_use_linesearch != 0;
+    ic.max_linesearch_iterations = o.ic_max_linesearch_iterations;
+    ic.max_linear_solver_setups = o.ic_max_linear_solver_setups;
+    ic.max_newton_iterations = o.ic_max_newton_iterations;
+    ic.step_reduction_factor = o.ic_step_reduction_factor;
+    ic.armijo_constant = o.ic_armijo_constant;
     std::vector<double> p(params, params + nparams_total), a(atol, atol + natol);
     s->problem = OdeBuilder().t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic)
                      .build_model(model, model_size, p);

@@ -41,6 +41,11 @@ typedef struct {
   int ic_use_linesearch;               /* 1 */
   int use_fused_kernels;               /* 1: fused device kernels where the model provides them; 0: 1:1 trait ops only */
   int block_threads;                   /* 0 = default (64) */
+  int ic_max_linesearch_iterations;    /* 10   InitialConditionSolverOptions (problem.rs:15-45) */
+  int ic_max_linear_solver_setups;     /* 4 */
+  int ic_max_newton_iterations;        /* 10 */
+  double ic_step_reduction_factor;     /* 0.5 */
+  double ic_armijo_constant;           /* 1e-4 */
 } dshs_options;
 
 const char* dshs_last_error(void);

@@ -82,3 +82,51 @@ def test_product_never_references_the_oracle():
         txt = open(os.path.join(ROOT, "include", f)).read()
         assert "#include \"../oracle" not in txt
     assert not [o for o in offenders if "imports oracle" in o], offenders
+
+
+def test_diffsol_c_api_of_the_hip_backend_exports_every_declared_symbol_and_keeps_the_reference_conventions(built):
+    """include/diffsol_c_hip.h mirrors crates/diffsol-c: names, status codes, last-error slots, HostArray accessors and runtime enums work without a GPU."""
+    from diffsol_amd import capi
+    names = declared_functions("diffsol_c_hip.h", "diffsol_")
+    names -= {"diffsol_ode_wrapper", "diffsol_host_array", "diffsol_solution_wrapper", "diffsol_ode_solver_options", "diffsol_ic_solver_options", "diffsol_ode_options", "diffsol_ic_options"}
+    L = capi.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), f"{n} declared in include/diffsol_c_hip.h but not exported"
+    assert names <= set(capi.C_ABI) and len(capi.C_ABI) >= 85  # the option accessors are macro-declared in the header
+    # enums keep the reference's numbering (matrix_type_c.rs:13-15, ode_solver_type_c.rs:14-17, ...) with the HIP variants appended
+    assert [L.diffsol_matrix_type_name(i) for i in range(L.diffsol_matrix_type_count())] == [b"nalgebra_dense", b"faer_dense", b"faer_sparse", b"hip_dense"]
+    assert [L.diffsol_matrix_type_is_valid(i) for i in range(5)] == [0, 0, 0, 1, 0]
+    assert [L.diffsol_ode_solver_type_name(i) for i in range(L.diffsol_ode_solver_type_count())] == [b"bdf", b"esdirk34", b"tr_bdf2", b"tsit45"]
+    assert [L.diffsol_ode_solver_type_is_valid(i) for i in range(4)] == [1, 1, 1, 0]
+    assert [L.diffsol_linear_solver_type_name(i) for i in range(3)] == [b"default", b"lu", b"klu"] and L.diffsol_linear_solver_type_is_valid(2) == 0
+    assert L.diffsol_scalar_type_name(1) == b"f64" and L.diffsol_scalar_type_is_valid(0) == 0
+    assert L.diffsol_jit_backend_type_name(2) == b"hiprtc" and L.diffsol_jit_backend_type_is_valid(2) == 1 and L.diffsol_jit_backend_type_is_valid(0) == 0
+    # error slots (error_c.rs): empty -> NULL / 0; a bad argument records message, file and line and returns DIFFSOL_BAD_ARG
+    L.diffsol_clear_last_error()
+    assert L.diffsol_error_code() == 0 and L.diffsol_last_error_message() is None and L.diffsol_last_error_line() == 0
+    assert L.diffsol_matrix_type_name(17) is None and L.diffsol_error_code() == 1 and b"matrix_type" in L.diffsol_last_error_message()
+    assert L.diffsol_last_error_file().endswith(b"diffsol_c.cpp") and L.diffsol_last_error_line() > 0
+    assert L.diffsol_ode_solve(None, None, 0, 1.0, None) == capi.BAD_ARG
+    assert L.diffsol_ode_new_jit(b"u_i { x = 1 } F_i { -x }", capi.JIT_HIPRTC, 0, 0, 0) is None and b"hip_dense" in L.diffsol_last_error_message()  # nalgebra_dense is not in this library
+    assert L.diffsol_ode_new_jit(b"u_i { x = 1 } F_i { -y }", capi.JIT_HIPRTC, capi.MATRIX_HIP_DENSE, 0, 0) is None and b"unknown name 'y'" in L.diffsol_last_error_message()
+    L.diffsol_clear_last_error()
+    assert L.diffsol_error_code() == 0
+    # host arrays
+    a = L.diffsol_host_array_alloc_vector(5, capi.SCALAR_F64)
+    assert L.diffsol_host_array_ndim(a) == 1 and L.diffsol_host_array_dim(a, 0) == 5 and L.diffsol_host_array_stride(a, 0) == 8 and L.diffsol_host_array_dtype(a) == 1
+    L.diffsol_host_array_free(a)
+    assert L.diffsol_host_array_alloc_vector(5, 0) is None  # f32 is not provided
+    # a model compiles (hiprtc needs no GPU) and carries the reference's defaults; options are shared with the handle they came from
+    ode = capi.Ode("in = [r, k] r { 1 } k { 1 } u_i { y = 0.1 } F_i { r * y * (1 - y / k) }", ode_solver=capi.ODE_SOLVER_TR_BDF2)
+    assert ode.dims() == dict(nstates=1, nparams=2, nout=0, nroots=0) and ode.matrix_type == capi.MATRIX_HIP_DENSE and ode.ode_solver == capi.ODE_SOLVER_TR_BDF2
+    assert (ode.rtol, ode.atol, ode.t0, ode.h0) == (1e-6, 1e-6, 0.0, 1.0)
+    ode.rtol, ode.ode_solver = 1e-8, capi.ODE_SOLVER_BDF
+    assert ode.rtol == 1e-8 and ode.ode_solver == capi.ODE_SOLVER_BDF
+    with pytest.raises(capi.DiffsolCError):
+        ode.ode_solver = capi.ODE_SOLVER_TSIT45
+    o, ic = ode.options, ode.ic_options
+    assert (o.max_nonlinear_solver_iterations, o.max_error_test_failures, o.update_jacobian_after_steps, o.update_rhs_jacobian_after_steps) == (10, 40, 20, 50)
+    assert (o.threshold_to_update_jacobian, o.threshold_to_update_rhs_jacobian, o.min_timestep) == (0.3, 0.2, 1e-13)
+    assert (ic.use_linesearch, ic.max_linesearch_iterations, ic.max_newton_iterations, ic.max_linear_solver_setups, ic.step_reduction_factor, ic.armijo_constant) == (1, 10, 10, 4, 0.5, 1e-4)
+    o.max_error_test_failures = 7
+    assert ode.options.max_error_test_failures == 7

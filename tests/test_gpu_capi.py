@@ -1,0 +1,121 @@
+"""include/diffsol_c_hip.h on the GPU: the reference's runtime-typed C API (crates/diffsol-c, what pydiffsol binds) driving the HIP
+backend — DiffSL text in, HostArray solutions out — for one parameter set exactly as in the reference and for ensembles.  Checked against the CPU
+oracle integrating the same DiffSL model (bit for bit) and against analytic solutions."""
+import numpy as np
+import pytest
+
+import diffsl_models as D
+from helpers import robertson_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from diffsol_amd import capi
+    return capi
+
+
+@pytest.fixture
+def det_pow(O):
+    O.set_det_pow(True)
+    yield
+    O.set_det_pow(False)
+
+
+def test_single_parameter_set_behaves_like_the_reference_api(capi, O):
+    """examples/diffsol-c-logistic: new_jit -> solve -> ys (nstates x ncols, column-major), ts; y0 / rhs / rhs_jac_mul on host arrays."""
+    ode = capi.Ode(D.LOGISTIC)
+    mid = D.host_model(O, D.LOGISTIC)
+    p = [1.3, 2.0]
+    assert np.array_equal(ode.y0(p), O.model_init(mid, p)) and ode.y0(p).shape == (1,)
+    assert np.array_equal(ode.rhs(p, 0.0, [0.3]), O.model_rhs(mid, [0.3], p))
+    assert np.array_equal(ode.rhs_jac_mul(p, 0.0, [0.3], [2.0]), O.model_jac_mul(mid, [0.3], p, [2.0]))
+    ode.rtol, ode.atol = 1e-8, 1e-10
+    sol = ode.solve(p, 1.0)  # stop_i { y - 0.9 k } is not reached before t = 1
+    ys, ts = sol.ys, sol.ts
+    assert ys.ndim == 2 and ys.shape == (1, ts.size) and ts[0] == 0.0 and ts[-1] == 1.0 and np.all(np.diff(ts) > 0)
+    exact = 2.0 / (1.0 + (2.0 / 0.1 - 1.0) * np.exp(-1.3 * ts))
+    assert np.allclose(ys[0], exact, rtol=1e-6)
+    o = O.OracleSolver(mid, [p], nbatch=1, rtol=1e-8, atol=[1e-10])
+    yo, ncols = o.solve(1.0)
+    assert ncols == ts.size and ys[0, -1] == yo[0, 0]
+    # the stop condition ends the solve at the root, with the state moved back to it
+    sol = ode.solve(p, 20.0)
+    info = sol.member_info()
+    assert info["root_index"][0] == 0 and abs(info["t_root"][0] - np.log((2.0 / 0.1 - 1.0) / (1.0 / 0.9 - 1.0)) / 1.3) < 1e-5  # y(t) = 0.9 k
+    assert sol.ts[-1] == info["t_root"][0] and abs(sol.ys[0, -1] - 1.8) < 1e-6
+    with pytest.raises(capi.DiffsolCError) as e:
+        ode.solve([1.0, 2.0, 3.0], 1.0)
+    assert "expected 2 parameters per member, got 3" in str(e.value)
+
+
+def test_lockstep_ensemble_solve_dense_with_out_i_matches_the_batched_oracle_bitwise(capi, O):
+    nb = 12
+    p = robertson_params(nb, seed=9)
+    ode = capi.Ode(D.ROBERTSON_DAE)
+    ode.rtol = 1e-4
+    ode.set_atol_vector([1e-8, 1e-6, 1e-6])
+    assert ode.dims() == dict(nstates=3, nparams=3, nout=4, nroots=0)
+    t_eval = [0.4, 4.0, 40.0, 400.0]
+    sol = ode.solve_dense(p, t_eval)
+    ys = sol.ys
+    assert ys.shape == (4, 4, nb) and np.array_equal(sol.ts, t_eval)
+    mid = D.host_model(O, D.ROBERTSON_DAE)
+    yo, _, failed = O.solve_dense_independent(mid, p, t_eval, group=nb, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])  # one lock-step batched problem of nb members
+    assert failed == 0
+    for b in range(nb):
+        for c in range(4):
+            assert np.array_equal(ys[:, c, b], O.model_out(mid, yo[b, c], p[b], t_eval[c]))
+    assert np.allclose(ys[3], 1.0, atol=1e-5)
+    # every ODE solver type of the reference that is implicit
+    for solver in (capi.ODE_SOLVER_TR_BDF2, capi.ODE_SOLVER_ESDIRK34):
+        ode.ode_solver = solver
+        y2 = ode.solve_dense(p, t_eval).ys
+        assert np.allclose(y2, ys, rtol=2e-3, atol=1e-7)
+
+
+def test_ensemble_solve_returns_every_lockstep_step_with_a_batch_axis(capi, O):
+    p = robertson_params(5, seed=10)
+    ode = capi.Ode(D.ROBERTSON_ODE)
+    ode.rtol = 1e-4
+    ode.set_atol_vector([1e-8, 1e-14, 1e-6])
+    sol = ode.solve(p, 40.0)
+    ys, ts = sol.ys, sol.ts
+    assert ys.shape == (3, ts.size, 5) and ts[-1] == 40.0
+    o = O.OracleSolver(D.host_model(O, D.ROBERTSON_ODE), p, nbatch=5, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    yo, ncols = o.solve(40.0)
+    assert ncols == ts.size and np.array_equal(ys[:, -1, :].T, yo)
+    assert np.array_equal(ys[:, 0, :].T, np.tile([1.0, 0.0, 0.0], (5, 1)))
+
+
+@pytest.mark.parametrize("mode", [1, 64])
+def test_device_resident_ensemble_modes_through_the_c_api(capi, O, det_pow, mode):
+    """DIFFSOL_ENSEMBLE_PER_MEMBER / _WAVEFRONT: solve_dense in one launch; per member: own event time, NaN after its stop, member info."""
+    nb = 130
+    rng = np.random.default_rng(5)
+    R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    thresh = 0.03 if mode == 1 else 10.0
+    p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, thresh)], axis=1)
+    ode = capi.Ode(D.RLC, ode_solver=capi.ODE_SOLVER_ESDIRK34)
+    ode.set_atol_vector([1e-6] * 4)
+    ode.ensemble_mode = mode
+    t_eval = [0.002, 0.005, 0.01, 0.02, 0.05]
+    sol = ode.solve_dense(p, t_eval)
+    ys, info = sol.ys, sol.member_info()
+    assert ys.shape == (2, 5, nb) and (info["status"] == 0).all()
+    mid = D.host_model(O, D.RLC)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=mode, method=2, rtol=1e-6, atol=[1e-6] * 4)
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and np.array_equal(info["root_index"], ref["root_idx"]) and np.array_equal(info["ncols"], ref["ncols"])
+    assert np.array_equal(info["t_root"], ref["t_root"], equal_nan=True)
+    for b in range(0, nb, 7):
+        for c in range(5):
+            if np.isfinite(yo[b, c, 0]):
+                assert np.array_equal(ys[:, c, b], [yo[b, c, 3], yo[b, c, 0]])  # out_i { V, iR }
+            else:
+                assert np.isnan(ys[:, c, b]).all()
+    if mode == 1:
+        assert 0 < (info["root_index"] >= 0).sum() < nb
+    with pytest.raises(capi.DiffsolCError):
+        ode.solve(p, 0.05)  # every-step output only exists for the lock-step ensemble
