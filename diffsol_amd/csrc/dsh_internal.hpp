@@ -99,6 +99,13 @@ struct dsh_lu {
   unsigned long long* singular = nullptr;
   unsigned int singular_epoch = 0;
   bool factored = false;
+  // Banded matrices in dense containers (dsh_lu_band.hpp): structure 0 = probe the bandwidth of every operand and use the banded kernels when
+  // max(kl, ku) <= 4 (results are bit-identical to the dense kernels'), 1 = always dense.  band_k = K of the current factorisation (0: dense
+  // factors).  Banded factors live in `factors` too: U(r, r+d) at (d*n + r)*nbatch + b (d <= 2K), multipliers at ((2K+1+r-1)*n + j)*nbatch + b,
+  // pivots batch-fastest.
+  int structure = 0;
+  int band_k = 0;
+  int* band_probe = nullptr;
 };
 
 namespace dsh {

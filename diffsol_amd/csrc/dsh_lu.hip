@@ -3,7 +3,9 @@
 // Here every system of the ensemble is factored / solved by ONE launch: one lane per system, factors in registers for n <= 8
 // (18 flop and 132 algorithmic bytes per n=3 solve: purely HBM-bound, so the job of the kernel is to keep every access coalesced),
 // one wavefront per system for n <= 64 (dsh_lu_wave.hpp), one workgroup per system with a blocked factorisation beyond (dsh_lu_coop.hpp).
+#include <algorithm>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <vector>
 
@@ -11,6 +13,7 @@
 #include "dsh_lu_dev.hpp"
 #include "dsh_lu_coop.hpp"
 #include "dsh_lu_wave.hpp"
+#include "dsh_lu_band.hpp"
 
 using namespace dsh;
 
@@ -65,6 +68,9 @@ int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
   DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->singular, sizeof(unsigned long long)));
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->band_probe, 2 * sizeof(int)));
+  static const int default_structure = [] { const char* e = getenv("DSH_LU_STRUCTURE"); return e && std::string(e) == "dense" ? 1 : 0; }();
+  lu->structure = default_structure;
   DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
   *out = lu;
   return DSH_OK;
@@ -75,16 +81,24 @@ void dsh_lu_destroy(dsh_lu* lu) {
   (void)hipFree(lu->factors);
   (void)hipFree(lu->pivots);
   (void)hipFree(lu->singular);
+  (void)hipFree(lu->band_probe);
   delete lu;
 }
 double* dsh_lu_factors(dsh_lu* lu) { return lu->factors; }
 int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu->pivots; }
 int dsh_lu_system_major(const dsh_lu* lu) { return lu->system_major ? 1 : 0; }
+int dsh_lu_set_structure(dsh_lu* lu, int structure) {
+  DSH_REQUIRE(lu != nullptr && (structure == DSH_LU_STRUCTURE_AUTO || structure == DSH_LU_STRUCTURE_DENSE), "bad arguments");
+  lu->structure = structure;
+  return DSH_OK;
+}
+int dsh_lu_band_width(const dsh_lu* lu) { return lu->band_k; }
 
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) return DSH_OK;
+  if (lu->band_k > 0) { set_error("dsh_lu_download: the current factors are banded (dsh_lu_band_width); factor with DSH_LU_STRUCTURE_DENSE to download dense factors"); return DSH_E_UNSUPPORTED; }
   if (lu->system_major) {  // already [b][col][row] / [b][k]
     if (factors_host) { int rc = dsh_d2h(ctx, factors_host, lu->factors, sizeof(double) * n * n * nb); if (rc != DSH_OK) return rc; }
     if (pivots_host) { int rc = dsh_d2h(ctx, pivots_host, lu->pivots, sizeof(int32_t) * n * nb); if (rc != DSH_OK) return rc; }
@@ -113,6 +127,28 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
     DSH_LU_FACTOR_CASE(1) DSH_LU_FACTOR_CASE(2) DSH_LU_FACTOR_CASE(3) DSH_LU_FACTOR_CASE(4)
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
     default: {
+      lu->band_k = 0;
+      if (lu->structure == DSH_LU_STRUCTURE_AUTO && n >= 16) {  // dense container of a narrow band?  one read of the operand decides
+        DSH_HIP_CHECK(hipMemsetAsync(lu->band_probe, 0, 2 * sizeof(int), ctx->stream));
+        int64_t pblocks = (n * n * nb + 255) / 256;
+        if (pblocks > 8192) pblocks = 8192;
+        hipLaunchKernelGGL(k_band_probe, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, n, nb, a, lu->band_probe);
+        int h[2] = {0, 0};
+        DSH_HIP_CHECK(hipMemcpyAsync(h, lu->band_probe, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int k = std::max(1, std::max(h[0], h[1]));
+        if (k <= 4) {
+          lu->band_k = k;
+          const dim3 bg = grid_for(nb, 64), bblk(64);
+          switch (k) {
+            case 1: hipLaunchKernelGGL((k_lu_band_factor<1>), bg, bblk, 0, ctx->stream, n, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
+            case 2: hipLaunchKernelGGL((k_lu_band_factor<2>), bg, bblk, 0, ctx->stream, n, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
+            case 3: hipLaunchKernelGGL((k_lu_band_factor<3>), bg, bblk, 0, ctx->stream, n, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
+            default: hipLaunchKernelGGL((k_lu_band_factor<4>), bg, bblk, 0, ctx->stream, n, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
+          }
+          break;
+        }
+      }
       // system-major copy of the operand, then factor in place
       dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
       hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
@@ -182,6 +218,25 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   if (n == 0) return DSH_OK;
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  if (n > 8 && lu->band_k > 0) {  // banded factors: one lane per system
+    g = grid_for(nb, 64);
+    int rc = begin_records(ctx, g.x, &rec, &seq);
+    if (rc != DSH_OK) return rc;
+    switch (lu->band_k) {
+      case 1: hipLaunchKernelGGL((k_lu_band_solve<1>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+      case 2: hipLaunchKernelGGL((k_lu_band_solve<2>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+      case 3: hipLaunchKernelGGL((k_lu_band_solve<3>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+      default: hipLaunchKernelGGL((k_lu_band_solve<4>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+    }
+    DSH_HIP_CHECK(hipGetLastError());
+    rc = fetch_records(ctx, g.x, seq);
+    if (rc != DSH_OK) return rc;
+    if (ctx->res_cnt != 0ull) {
+      set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+      return DSH_E_SINGULAR;
+    }
+    return DSH_OK;
+  }
   if (n > 64) g = dim3((unsigned)nb);  // one workgroup per system
   else if (n > 8) {
     const int per_block = kWaveLuThreads / (n <= 16 ? 16 : n <= 32 ? 32 : 64);

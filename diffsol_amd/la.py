@@ -424,6 +424,13 @@ class HipLU:
             raise DiffsolHipError(-1, "LinearSolverMatrixVectorNotCompatible")
         check(self.ctx._L.dsh_lu_solve(self._h, v.ptr))
 
+    def set_structure(self, dense):
+        """DSH_LU_STRUCTURE_DENSE (True) / _AUTO (False): banded operands in dense containers are detected and solved by the banded kernels."""
+        check(self.ctx._L.dsh_lu_set_structure(self._h, 1 if dense else 0))
+
+    def band_width(self):
+        return int(self.ctx._L.dsh_lu_band_width(self._h))
+
     def n_singular(self):
         out = C.c_int64()
         check(self.ctx._L.dsh_lu_info(self._h, C.byref(out)))

@@ -166,6 +166,15 @@ int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular);
 double* dsh_lu_factors(dsh_lu* lu);
 int32_t* dsh_lu_pivots(dsh_lu* lu);
 int dsh_lu_system_major(const dsh_lu* lu);
+/* Banded matrices in dense containers (PDE-type and compartment models; SURVEY 8(f) row 4 — the reference has no banded solver,
+ * book/src/benchmarks/sundials.md:27-28).  With DSH_LU_STRUCTURE_AUTO (default for n >= 16; env DSH_LU_STRUCTURE=dense switches the default)
+ * dsh_lu_factor reads the operand once to find its bandwidth over all systems and, if max(kl, ku) <= 4, factors and solves only the band
+ * (LAPACK dgbtrf-style partial pivoting, one lane per system).  Every non-trivial operation of the dense elimination is performed in the same
+ * order, so solutions are BIT-IDENTICAL to the dense kernels'; only time and traffic change.  dsh_lu_band_width: K of the current factors, 0 = dense. */
+#define DSH_LU_STRUCTURE_AUTO 0
+#define DSH_LU_STRUCTURE_DENSE 1
+int dsh_lu_set_structure(dsh_lu* lu, int structure);
+int dsh_lu_band_width(const dsh_lu* lu);
 /* packed LU factors as [b][col][row] and pivot rows as [b][k] on the host, whatever the device layout; blocking */
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 

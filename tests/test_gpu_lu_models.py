@@ -254,3 +254,72 @@ def test_fused_bdf_prepare_and_accept_match_trait_op_composition(H, ctx1, order,
     yp2, psi2 = H.HipVec.zeros(n, c), H.HipVec.zeros(n, c)
     assert L.dsh_bdf_prepare_step(c._h, n, nb, order, Dn.ptr, Dt.ptr, None, gamma.ctypes.data_as(_ffi.c_dp), alpha, yp2.ptr, psi2.ptr) == 0
     assert np.array_equal(yp.clone_as_vec(), yp2.clone_as_vec()) and np.array_equal(psi_next.clone_as_vec(), psi2.clone_as_vec())
+
+
+def _banded(rng, nb, n, kl, ku, dominant):
+    a = np.zeros((nb, n, n))
+    for d in range(-kl, ku + 1):
+        idx = np.arange(max(0, -d), min(n, n - d))
+        a[:, idx, idx + d] = rng.standard_normal((nb, idx.size))
+    if dominant:
+        a[:, np.arange(n), np.arange(n)] += 4.0 * (kl + ku + 1)
+    return a
+
+
+@pytest.mark.parametrize("n,kl,ku", [(16, 1, 1), (42, 1, 1), (100, 2, 1), (64, 0, 3), (77, 3, 3), (512, 1, 1), (130, 4, 2), (33, 4, 4)])
+@pytest.mark.parametrize("dominant", [True, False])
+def test_banded_operands_in_dense_containers_are_solved_by_the_banded_kernels_with_the_bits_of_the_dense_lu(H, O, n, kl, ku, dominant):
+    """dsh_lu_factor probes the bandwidth and eliminates only the band (LAPACK dgbtrf-style pivoting): the solution must equal, BIT FOR BIT, the dense
+    kernels' and the oracle's dense partial-pivoting LU — with and without diagonal dominance (i.e. with real row interchanges and fill-in)."""
+    nb = 70 if n < 500 else 9
+    c = H.HipContext(nbatch=nb)
+    rng = np.random.default_rng(1000 * n + 10 * kl + ku)
+    a = _banded(rng, nb, n, kl, ku, dominant)
+    b = rng.standard_normal((nb, n))
+    A = H.HipMat.from_array(a, c)
+    lu = H.HipLU(c, n)
+    lu.factor(A)
+    assert lu.band_width() == max(kl, ku) and lu.n_singular() == 0
+    x = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x)
+    xo, _, _, rc = O.lu_solve(a, b)
+    assert rc == 0 and np.array_equal(x.clone_as_vec(), xo)
+    dense = H.HipLU(c, n)
+    dense.set_structure(True)
+    dense.factor(A)
+    assert dense.band_width() == 0
+    xd = H.HipVec.from_vec(b, c)
+    dense.solve_in_place(xd)
+    assert np.array_equal(xd.clone_as_vec(), xo)
+    with pytest.raises(H.DiffsolHipError):
+        lu.factors()  # banded factors have no dense image
+    # a second right-hand side, and re-factoring a wider operand with the same handle falls back to the dense kernels
+    b2 = rng.standard_normal((nb, n))
+    x2 = H.HipVec.from_vec(b2, c)
+    lu.solve_in_place(x2)
+    assert np.array_equal(x2.clone_as_vec(), O.lu_solve(a, b2)[0])
+    wide = _banded(rng, nb, n, 5, 0, True)
+    lu.factor(H.HipMat.from_array(wide, c))
+    assert lu.band_width() == 0
+    x3 = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x3)
+    assert np.array_equal(x3.clone_as_vec(), O.lu_solve(wide, b)[0])
+
+
+def test_banded_lu_reports_singular_systems_like_the_dense_one(H, O):
+    nb, n = 40, 30
+    c = H.HipContext(nbatch=nb)
+    rng = np.random.default_rng(3)
+    a = _banded(rng, nb, n, 1, 2, True)
+    a[7, :, 11] = 0.0  # a zero column: exact zero pivot at step 11 of system 7
+    a[21, :, 0] = 0.0
+    lu = H.HipLU(c, n)
+    lu.factor(H.HipMat.from_array(a, c))
+    assert lu.band_width() == 2 and lu.n_singular() == 2
+    x = H.HipVec.from_vec(np.ones((nb, n)), c)
+    with pytest.raises(H.DiffsolHipError) as e:
+        lu.solve_in_place(x)
+    assert "LuSolveFailed" in str(e.value) and "2 system" in str(e.value)
+    ok = [b for b in range(nb) if b not in (7, 21)]
+    xo = O.lu_solve(a[ok], np.ones((len(ok), n)))[0]
+    assert np.array_equal(x.clone_as_vec()[ok], xo)
