@@ -101,6 +101,10 @@ DEVICE_ABI = {
     "dsh_model_compile": (cint, [C.c_char_p, cint, i64, i64, i64, i64, cint, c_ip]),
     "dsh_model_release": (cint, [cint]),
     "dsh_model_precompile": (cint, [cint, cint]),
+    "dsh_model_set_band": (cint, [cint, cint, cint, cint, cint]),
+    "dsh_model_band": (cint, [cint, i64, c_ip, c_ip, c_ip, c_ip]),
+    "dsh_lu_factor_banded": (cint, [vp, vp, cint, cint]),
+    "dsh_mat_scale_add_assign_banded": (cint, [vp, i64, i64, cint, cint, vp, vp, i64, dbl, vp, i64]),
     "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_bdf_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_reduction_wait": (cint, [vp, i64, c_dp]),

@@ -207,6 +207,14 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   return DSH_OK;
 }
 
+int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int mass_ku) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  if (!rec) { set_error("dsh_model_set_band: unknown model id"); return DSH_E_INVALID; }
+  rec->info.jac_kl = jac_kl; rec->info.jac_ku = jac_ku; rec->info.mass_kl = mass_kl; rec->info.mass_ku = mass_ku;
+  return DSH_OK;
+}
+
 int dsh_model_release(int model_id) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_models.find(model_id);

@@ -11,6 +11,7 @@ struct JitInfo {
   int form = 0;  // DSH_JIT_FORM_*
   int64_t n = 0, np = 0, nroots = 0, nout = 0;
   int has_mass = 0;
+  int jac_kl = -1, jac_ku = -1, mass_kl = -1, mass_ku = -1;  // structural bandwidths declared with dsh_model_set_band (-1: dense / unknown)
 };
 inline bool is_jit_model(int model) { return model >= DSH_MODEL_JIT_BASE; }
 // nullptr (+ error set) if `model` is not a live run-time-compiled model

@@ -114,7 +114,15 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   return DSH_OK;
 }
 
-int dsh_lu_factor(dsh_lu* lu, const double* a) {
+static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k);
+
+int dsh_lu_factor(dsh_lu* lu, const double* a) { return lu_factor_impl(lu, a, -1); }
+int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku) {
+  DSH_REQUIRE(kl >= 0 && ku >= 0, "bandwidths must be non-negative");
+  return lu_factor_impl(lu, a, std::max(1, std::max(kl, ku)));
+}
+
+static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
   lu->singular_epoch += 1;
@@ -128,15 +136,21 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) {
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
     default: {
       lu->band_k = 0;
-      if (lu->structure == DSH_LU_STRUCTURE_AUTO && n >= 16) {  // dense container of a narrow band?  one read of the operand decides
-        DSH_HIP_CHECK(hipMemsetAsync(lu->band_probe, 0, 2 * sizeof(int), ctx->stream));
-        int64_t pblocks = (n * n * nb + 255) / 256;
-        if (pblocks > 8192) pblocks = 8192;
-        hipLaunchKernelGGL(k_band_probe, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, n, nb, a, lu->band_probe);
-        int h[2] = {0, 0};
-        DSH_HIP_CHECK(hipMemcpyAsync(h, lu->band_probe, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const int k = std::max(1, std::max(h[0], h[1]));
+      static const bool check_declared = [] { const char* e = getenv("DSH_CHECK_BAND"); return e && atoi(e) != 0; }();
+      if (lu->structure == DSH_LU_STRUCTURE_AUTO && n >= 16) {  // dense container of a narrow band?
+        int k = declared_k;
+        if (k < 0 || k > 4 || check_declared) {  // not declared by the caller (or declared too wide — a declaration is an upper bound): one read of the operand decides
+          DSH_HIP_CHECK(hipMemsetAsync(lu->band_probe, 0, 2 * sizeof(int), ctx->stream));
+          int64_t pblocks = (n * n * nb + 255) / 256;
+          if (pblocks > 8192) pblocks = 8192;
+          hipLaunchKernelGGL(k_band_probe, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, n, nb, a, lu->band_probe);
+          int h[2] = {0, 0};
+          DSH_HIP_CHECK(hipMemcpyAsync(h, lu->band_probe, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+          DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+          const int probed = std::max(1, std::max(h[0], h[1]));
+          if (k >= 0 && probed > k) { set_error("dsh_lu_factor_banded: the operand has entries outside the declared band (DSH_CHECK_BAND)"); return DSH_E_INVALID; }
+          if (k < 0 || k > 4) k = probed;
+        }
         if (k <= 4) {
           lu->band_k = k;
           const dim3 bg = grid_for(nb, 64), bblk(64);

@@ -42,6 +42,20 @@ __global__ void k_scale_add_assign(int64_t total, int64_t nb, double* __restrict
     self[idx] = yv * beta + xv;
   }
 }
+// the same on the band |i - j| <= (kl below, ku above) of n x n matrices only: thread (d, i, b) handles entry (i, i + d - kl) — the entries outside the
+// band are not touched (callers guarantee they are structural zeros of all three operands)
+template <bool BX, bool BY>
+__global__ void k_scale_add_assign_banded(int64_t n, int64_t nb, int kl, int ku, double* __restrict__ self, const double* __restrict__ x, double beta,
+                                          const double* __restrict__ y) {
+  const int64_t w = kl + ku + 1, total = w * n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx % nb, r = idx / nb, i = r % n, j = i + r / n - kl;
+    if (j < 0 || j >= n) continue;
+    const int64_t e = j * n + i;
+    const double xv = x[BX ? e : e * nb + b], yv = y[BY ? e : e * nb + b];
+    self[e * nb + b] = yv * beta + xv;
+  }
+}
 __global__ void k_set_data_with_indices(int64_t nidx, int64_t nb, double* __restrict__ self, const int32_t* __restrict__ dst_idx,
                                         const int32_t* __restrict__ src_idx, const double* __restrict__ data) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nidx * nb; t += (int64_t)gridDim.x * blockDim.x) {
@@ -121,6 +135,21 @@ int dsh_mat_scale_add_assign(dsh_ctx* ctx, int64_t nelem, int64_t nb, double* se
   else if (bx && !by) hipLaunchKernelGGL((k_scale_add_assign<true, false>), g, b, 0, ctx->stream, total, nb, self, x, beta, y);
   else if (!bx && by) hipLaunchKernelGGL((k_scale_add_assign<false, true>), g, b, 0, ctx->stream, total, nb, self, x, beta, y);
   else hipLaunchKernelGGL((k_scale_add_assign<true, true>), g, b, 0, ctx->stream, total, nb, self, x, beta, y);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+int dsh_mat_scale_add_assign_banded(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, double* self, const double* x, int64_t xnb, double beta, const double* y,
+                                    int64_t ynb) {
+  DSH_CHECK_NB(xnb, nb); DSH_CHECK_NB(ynb, nb);
+  DSH_REQUIRE(kl >= 0 && ku >= 0 && kl < n && ku < n, "bandwidths out of range");
+  const int64_t total = (int64_t)(kl + ku + 1) * n * nb;
+  if (total == 0) return DSH_OK;
+  bool bx = xnb == 1 && nb != 1, by = ynb == 1 && nb != 1;
+  dim3 g = ew_grid(total), b(kBlock);
+  if (!bx && !by) hipLaunchKernelGGL((k_scale_add_assign_banded<false, false>), g, b, 0, ctx->stream, n, nb, kl, ku, self, x, beta, y);
+  else if (bx && !by) hipLaunchKernelGGL((k_scale_add_assign_banded<true, false>), g, b, 0, ctx->stream, n, nb, kl, ku, self, x, beta, y);
+  else if (!bx && by) hipLaunchKernelGGL((k_scale_add_assign_banded<false, true>), g, b, 0, ctx->stream, n, nb, kl, ku, self, x, beta, y);
+  else hipLaunchKernelGGL((k_scale_add_assign_banded<true, true>), g, b, 0, ctx->stream, n, nb, kl, ku, self, x, beta, y);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }

@@ -233,6 +233,31 @@ int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, 
   return DSH_OK;
 }
 
+// Structural bandwidth of the Jacobian f_y and of the mass matrix of a model: entries (i, j) with i - j > kl or j - i > ku are never non-zero.
+// -1 = not declared (treat as dense).  Built-in run-time-sized models: heat1d and the single-particle model are tridiagonal, dydt_y2 / gaussian_decay
+// diagonal, robertson_ode block diagonal 3 x 3; their mass matrix is the identity.
+int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_kl, int* mass_ku) {
+  int jl = -1, ju = -1, ml = -1, mu = -1;
+  if (is_jit_model(model)) {
+    const JitInfo* ji = jit_info(model);
+    if (!ji) return DSH_E_INVALID;
+    jl = ji->jac_kl; ju = ji->jac_ku; ml = ji->mass_kl; mu = ji->mass_ku;
+  } else if (is_dynamic_model(model, size)) {
+    ml = mu = 0;
+    switch (model) {
+      case DSH_MODEL_HEAT1D: case DSH_MODEL_SPM: jl = ju = 1; break;
+      case DSH_MODEL_DYDT_Y2: case DSH_MODEL_GAUSSIAN_DECAY: jl = ju = 0; break;
+      case DSH_MODEL_ROBERTSON_ODE: jl = ju = 2; break;
+      default: break;
+    }
+  }
+  if (jac_kl) *jac_kl = jl;
+  if (jac_ku) *jac_ku = ju;
+  if (mass_kl) *mass_kl = ml;
+  if (mass_ku) *mass_ku = mu;
+  return DSH_OK;
+}
+
 // out_i of a DiffSL model (calc_out): out is nout x nb, batch-fastest.  The registry models have no out_i (their output is the state).
 int dsh_model_out(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* out) {
   (void)size;

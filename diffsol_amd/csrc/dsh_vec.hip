@@ -124,7 +124,7 @@ __global__ void k_assign_at_indices(int64_t nidx, int64_t nb, const int32_t* __r
 // ---- reductions: one lane per system, sequential over the n states (same summation order as the CPU path), then
 // wave shuffle max -> conditional atomicMax into the slot group.  Loads are coalesced: lane b reads p[i*nb + b].
 template <bool BY, bool BA>
-__global__ void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
+__global__ __launch_bounds__(256) void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
                                double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bits = 0ull;
@@ -133,16 +133,33 @@ __global__ void k_squared_norm(int64_t n, int64_t nb, const double* __restrict__
     // latency-bound: 16 independent loads / divisions are kept in flight, only the additions are a dependent chain.
     double acc = 0.0;
     int64_t i = 0;
-    for (; i + 16 <= n; i += 16) {
-      double term[16];
+    if (n >= 32) {
+      // software-pipelined: the operands of chunk c+1 are requested before the divisions of chunk c are issued, so the memory latency of one
+      // chunk hides behind the arithmetic of the previous one
+      double xa[16], ya[16], aa[16];
+      auto fetch = [&](int64_t base, double (&xs)[16], double (&ys)[16], double (&as)[16]) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const double yi = BY ? y[i + q] : y[(i + q) * nb + b];
-        const double ai = BA ? atol[i + q] : atol[(i + q) * nb + b];
-        term[q] = x[(i + q) * nb + b] / (fabs(yi) * rtol + ai);
+        for (int q = 0; q < 16; ++q) {
+          xs[q] = x[(base + q) * nb + b];
+          ys[q] = BY ? y[base + q] : y[(base + q) * nb + b];
+          as[q] = BA ? atol[base + q] : atol[(base + q) * nb + b];
+        }
+      };
+      fetch(0, xa, ya, aa);
+      for (; i + 16 <= n; i += 16) {
+        double xn[16], yn[16], an[16];
+        const bool more = i + 32 <= n;
+        if (more) fetch(i + 16, xn, yn, an);
+        double term[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) term[q] = xa[q] / (fabs(ya[q]) * rtol + aa[q]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += term[q] * term[q];
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { xa[q] = xn[q]; ya[q] = yn[q]; aa[q] = an[q]; }
+        }
       }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc += term[q] * term[q];
     }
     for (; i < n; ++i) {
       double yi = BY ? y[i] : y[i * nb + b];
@@ -326,7 +343,8 @@ int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, c
   DSH_REQUIRE(out_max != nullptr, "out_max is null");
   if (n == 0) { *out_max = 0.0; return DSH_OK; }  // vector/cuda.rs:1365-1367
   unsigned long long* rec; unsigned int seq;
-  dim3 g = grid_for(nb, ctx->block), b(ctx->block);
+  const int threads = ctx->block < 256 ? ctx->block : 256;  // the kernel is compiled for at most 256 threads (register budget of its pipelined loop)
+  dim3 g = grid_for(nb, threads), b(threads);
   int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
   bool by = ynb == 1 && nb != 1, ba = anb == 1 && nb != 1;

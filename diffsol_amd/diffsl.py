@@ -22,14 +22,15 @@ def generate(code, target):
     """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate."""
     L = _ffi.load_host_lib()
     out = vp()
-    dims = (C.c_int64 * 6)()
+    dims = (C.c_int64 * 10)()
     defaults = (C.c_double * 256)()
     check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, defaults, 256), host=True)
     try:
         src = C.string_at(out).decode()
     finally:
         L.dshs_free_string(out)
-    d = dict(n=int(dims[0]), nparams=int(dims[1]), nroots=int(dims[2]), nout=int(dims[3]), has_mass=bool(dims[4]), no_inputs=bool(dims[5]))
+    d = dict(n=int(dims[0]), nparams=int(dims[1]), nroots=int(dims[2]), nout=int(dims[3]), has_mass=bool(dims[4]), no_inputs=bool(dims[5]),
+             band=(int(dims[6]), int(dims[7]), int(dims[8]), int(dims[9])))
     return src, d, np.array(defaults[: d["nparams"]])
 
 
@@ -46,6 +47,8 @@ class DiffslModel:
         mid = C.c_int()
         check(self._L.dsh_model_compile(self.source.encode(), form, self.n, self.nparams, self.nroots, self.nout, 1 if self.has_mass else 0, C.byref(mid)))
         self.model_id = mid.value
+        self.band = d["band"]  # (jac_kl, jac_ku, mass_kl, mass_ku): structural bandwidths, declared so that banded models are assembled / factored on the band
+        check(self._L.dsh_model_set_band(self.model_id, *self.band))
 
     def precompile(self, family):
         """Compile a kernel family now instead of at its first launch (needs no GPU)."""

@@ -263,7 +263,7 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   dshs_default_options(&ode->settings->o);
   // dimensions first (any target), then the form that fits them
   char* src = nullptr;
-  int64_t dims[6];
+  int64_t dims[10];
   std::vector<double> defaults(256, 0.0);
   if (dshs_diffsl_generate(code, DSHS_DIFFSL_HOST_C, &src, dims, defaults.data(), (int64_t)defaults.size()) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
   dshs_free_string(src);
@@ -277,6 +277,7 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   dshs_free_string(src);
   if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
   ode->model = id;
+  dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
   return ode.release();
 }
 void diffsol_ode_free(OdeWrapper* ode) {

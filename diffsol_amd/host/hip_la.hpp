@@ -10,6 +10,7 @@
 //   DenseMatrix  diffsol-la/src/matrix/mod.rs:169-424     -> HipMat
 //   LinearSolver diffsol-la/src/linear_solver/mod.rs:19-42 -> HipLU
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -261,7 +262,7 @@ struct HipMatViewMut {
 class HipMat {
  public:
   HipMat() = default;
-  static HipMat zeros(int64_t nrows, int64_t ncols, const HipContext& ctx) { return HipMat(nrows, ncols, ctx, true); }
+  static HipMat zeros(int64_t nrows, int64_t ncols, const HipContext& ctx) { HipMat m(nrows, ncols, ctx, true); m.set_band(0, 0); return m; }
   // data: batch-major, column-major per batch member ([b][col][row], matrix/cuda.rs:20-31)
   static HipMat from_vec(int64_t nrows, int64_t ncols, const std::vector<double>& data, const HipContext& ctx) {
     if ((int64_t)data.size() != nrows * ncols * ctx.nbatch()) throw LaError(DSH_E_INVALID, "from_vec: wrong data length");
@@ -272,6 +273,7 @@ class HipMat {
   static HipMat from_diagonal(const HipVec& v) {
     HipMat m(v.len(), v.len(), v.context(), false);
     check(dsh_mat_from_diagonal(v.context().raw(), v.len(), v.nb(), v.ptr(), v.nb(), m.ptr()), "from_diagonal");
+    m.set_band(0, 0);
     return m;
   }
   std::vector<double> clone_as_vec() const {
@@ -283,7 +285,15 @@ class HipMat {
   int64_t ncols() const { return ncols_; }
   int64_t nb() const { return ctx_.nbatch(); }
   const HipContext& context() const { return ctx_; }
-  double* ptr() { return data_.get(); }
+  // Structure tag of the CONTENT: every entry outside |i - j| <= (kl below, ku above) is exactly zero.  Set by writers that know it (zeros, from_diagonal,
+  // a model that declares the bandwidth of its Jacobian / mass matrix, the banded scale_add_and_assign); any other write access clears it.  It lets
+  // M - cJ be assembled and factored on the band only (dsh_mat_scale_add_assign_banded, dsh_lu_factor_banded) — same arithmetic per entry.
+  void set_band(int kl, int ku) { band_kl_ = kl; band_ku_ = ku; }
+  void clear_band() { band_kl_ = band_ku_ = -1; }
+  bool has_band() const { return band_kl_ >= 0 && band_ku_ >= 0; }
+  int band_kl() const { return band_kl_; }
+  int band_ku() const { return band_ku_; }
+  double* ptr() { clear_band(); return data_.get(); }  // write access from outside: the content is no longer known to be banded
   const double* ptr() const { return data_.get(); }
   int64_t col_stride() const { return nrows_ * nb(); }
 
@@ -298,7 +308,15 @@ class HipMat {
   // self = x + beta*y  (matrix/cuda.rs:1424-1458)
   void scale_add_and_assign(const HipMat& x, double beta, const HipMat& y) {
     same_shape(x); same_shape(y);
-    check(dsh_mat_scale_add_assign(ctx_.raw(), nrows_ * ncols_, nb(), ptr(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign");
+    const bool tagged = x.has_band() && y.has_band() && nrows_ == ncols_;
+    const int kl = tagged ? std::max(x.band_kl(), y.band_kl()) : -1, ku = tagged ? std::max(x.band_ku(), y.band_ku()) : -1;
+    // banded assembly: the result's band must cover what this container holds now (else stale entries outside it would survive)
+    if (tagged && has_band() && band_kl_ <= kl && band_ku_ <= ku && nrows_ >= 16 && (int64_t)(kl + ku + 1) * 2 <= nrows_) {
+      check(dsh_mat_scale_add_assign_banded(ctx_.raw(), nrows_, nb(), kl, ku, data_.get(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign (banded)");
+    } else {
+      check(dsh_mat_scale_add_assign(ctx_.raw(), nrows_ * ncols_, nb(), data_.get(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign");
+    }
+    band_kl_ = kl; band_ku_ = ku;
   }
   // column i += alpha * column j  (matrix/cuda.rs:1048-1088)
   void column_axpy(double alpha, int64_t j, int64_t i) { bounds(i); bounds(j); check(dsh_mat_column_axpy(ctx_.raw(), nrows_, nb(), ptr(), alpha, j, i), "column_axpy"); }
@@ -320,6 +338,7 @@ class HipMat {
   void swap(HipMat& o) { std::swap(*this, o); }
 
  private:
+  int band_kl_ = -1, band_ku_ = -1;
   HipMat(int64_t nrows, int64_t ncols, const HipContext& ctx, bool zero) : nrows_(nrows), ncols_(ncols), ctx_(ctx) {
     void* d = nullptr;
     check(dsh_malloc(ctx.raw(), (int64_t)sizeof(double) * nrows * ncols * ctx.nbatch(), zero ? 1 : 0, &d), "HipMat alloc");
@@ -363,7 +382,9 @@ class HipLU {
   void set_linearisation(const LinearOpRef& op) {  // lu.rs:59-97
     if (!lu_) throw LaError(DSH_E_NOT_SETUP, "LinearSolverNotSetup");
     op.matrix_inplace(matrix_);
-    check(dsh_lu_factor(lu_.get(), matrix_.ptr()), "HipLU::set_linearisation");
+    const HipMat& m = matrix_;  // const access keeps the structure tag
+    if (m.has_band()) check(dsh_lu_factor_banded(lu_.get(), m.ptr(), m.band_kl(), m.band_ku()), "HipLU::set_linearisation (declared band)");
+    else check(dsh_lu_factor(lu_.get(), m.ptr()), "HipLU::set_linearisation");
     factored_ = true;
   }
   // returns false on LuSolveFailed (zero pivot), throws LuNotInitialized

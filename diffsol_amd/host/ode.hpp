@@ -86,6 +86,7 @@ class HipKernelEquations : public OdeEquations {
     if ((int64_t)p.size() != np_ * ctx.nbatch()) throw LaError(DSH_E_INVALID, "parameter vector must have nparams*nbatch entries");
     p_ = np_ > 0 ? HipVec::from_vec(p, ctx) : HipVec::zeros(0, ctx);
     fused_ = dsh_model_has_fused(model, size) != 0;
+    check(dsh_model_band(model, size, &jac_kl_, &jac_ku_, &mass_kl_, &mass_ku_), "HipKernelEquations (band)");
   }
   int64_t nstates() const override { return n_; }
   int64_t nparams() const override { return np_; }
@@ -106,12 +107,14 @@ class HipKernelEquations : public OdeEquations {
     rhs_statistics.number_of_matrix_evals++;
     rhs_statistics.number_of_jac_muls += n_;
     check(dsh_model_jacobian(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), y.ptr()), "jacobian");
+    if (jac_kl_ >= 0 && jac_ku_ >= 0) y.set_band(jac_kl_, jac_ku_);  // the model declares the structure of f_y (dsh_model_band)
   }
   void mass_gemv_inplace(const HipVec& x, double t, double beta, HipVec& y) const override {
     check(dsh_model_mass_gemv(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), beta, y.ptr()), "mass_gemv");
   }
   void mass_matrix_inplace(double t, HipMat& y) const override {
     check(dsh_model_mass_matrix(ctx_.raw(), model_, size_, ctx_.nbatch(), t, p_.ptr(), y.ptr()), "mass_matrix");
+    if (mass_kl_ >= 0 && mass_ku_ >= 0) y.set_band(mass_kl_, mass_ku_);
   }
   void init_call_inplace(double t, HipVec& y) const override { check(dsh_model_init(ctx_.raw(), model_, size_, ctx_.nbatch(), t, p_.ptr(), y.ptr()), "init"); }
   void root_call_inplace(const HipVec& x, double t, HipVec& g) const override {
@@ -126,6 +129,7 @@ class HipKernelEquations : public OdeEquations {
   int model_;
   int64_t size_, n_ = 0, np_ = 0, nroots_ = 0;
   bool has_mass_ = false, fused_ = false;
+  int jac_kl_ = -1, jac_ku_ = -1, mass_kl_ = -1, mass_ku_ = -1;
   HipContext ctx_;
   HipVec p_;
 };

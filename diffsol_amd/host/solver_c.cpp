@@ -80,7 +80,7 @@ int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_
     if (!out) throw LaError(DSH_E_INVALID, "out of memory");
     std::memcpy(out, src.c_str(), src.size() + 1);
     *source_out = out;
-    if (dims) { dims[0] = c.n; dims[1] = c.np; dims[2] = c.nroots; dims[3] = c.nout; dims[4] = c.has_mass ? 1 : 0; dims[5] = c.dummy_param ? 1 : 0; }
+    if (dims) { dims[0] = c.n; dims[1] = c.np; dims[2] = c.nroots; dims[3] = c.nout; dims[4] = c.has_mass ? 1 : 0; dims[5] = c.dummy_param ? 1 : 0; dims[6] = c.jac_kl; dims[7] = c.jac_ku; dims[8] = c.mass_kl; dims[9] = c.mass_ku; }
     if (defaults_out) for (int64_t k = 0; k < defaults_cap && k < (int64_t)c.input_defaults.size(); ++k) defaults_out[k] = c.input_defaults[k];
     return 0;
   });

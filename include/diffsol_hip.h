@@ -137,6 +137,10 @@ int dsh_mat_get_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* 
 /* column j of mat (nrows x ncols) = v               (mat_set_column.cu:2; matrix/cuda.rs:1389-1421) */
 int dsh_mat_set_column(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double* mat, int64_t j, const double* v, int64_t v_nb);
 /* self = x + beta*y over nelem = nrows*ncols entries (mat_scale_add_assign.cu:1; matrix/cuda.rs:1424-1458) — the M - cJ assembly */
+/* scale_add_and_assign restricted to the band of n x n matrices (entry (i, j) with -ku <= i - j <= kl): for operands whose structure is declared
+ * (dsh_model_band) the dense M - cJ assembly touches (kl+ku+1) n entries per system instead of n^2; same arithmetic per entry */
+int dsh_mat_scale_add_assign_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int kl, int ku, double* self, const double* x, int64_t x_nb, double beta,
+                                    const double* y, int64_t y_nb);
 int dsh_mat_scale_add_assign(dsh_ctx* ctx, int64_t nelem, int64_t nbatch, double* self, const double* x, int64_t x_nb, double beta,
                              const double* y, int64_t y_nb);
 /* self[dst_idx[k]] = data[src_idx[k]]               (mat_set_data_with_indices.cu:2; matrix/cuda.rs:1137-1174) */
@@ -174,6 +178,9 @@ int dsh_lu_system_major(const dsh_lu* lu);
 #define DSH_LU_STRUCTURE_AUTO 0
 #define DSH_LU_STRUCTURE_DENSE 1
 int dsh_lu_set_structure(dsh_lu* lu, int structure);
+/* the same with the band DECLARED by the caller (a model that knows the structure of its Jacobian, dsh_model_band): no probe pass.  Entries with
+ * |i - j| > max(kl, ku) are not read.  DSH_CHECK_BAND=1 (debug) probes anyway and fails if the declaration is wrong. */
+int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku);
 int dsh_lu_band_width(const dsh_lu* lu);
 /* packed LU factors as [b][col][row] and pivot rows as [b][k] on the host, whatever the device layout; blocking */
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
@@ -206,6 +213,9 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 int dsh_model_compile(const char* source, int form, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id);
 int dsh_model_release(int model_id);
 int dsh_model_precompile(int model_id, int family);
+/* structural bandwidths of f_y and of the mass matrix (dshs_diffsl_generate reports them for a DiffSL model): -1 = dense / unknown */
+int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int mass_ku);
+int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_kl, int* mass_ku);
 /* out_i of a run-time-compiled model (DiffSl::out, calc_out): out is nout x nbatch, batch-fastest */
 int dsh_model_out(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* out);
 

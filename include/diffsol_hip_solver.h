@@ -107,8 +107,9 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
  *        DSHS_DIFFSL_HIP_DYNAMIC: per-component device functions for run-time-sized models (feeds dsh_model_compile);
  *        DSHS_DIFFSL_HOST_C: an extern "C" CPU model (dsl_dims, dsl_rhs, dsl_jac_mul, dsl_mass_gemv, dsl_init, dsl_root, dsl_out) — the shape of the
  *        reference's external-model ABI (crates/diffsol-c/tests/external-dynamic-logistic/src/lib.rs:123-161).
- * *source_out is malloc'ed (free with dshs_free_string).  dims[6] = n, nparams, nroots, nout, has_mass, declared-no-inputs (1 = the single
- * parameter is an unused placeholder).  defaults_out (may be NULL) receives nparams default values. */
+ * *source_out is malloc'ed (free with dshs_free_string).  dims[10] = n, nparams, nroots, nout, has_mass, declared-no-inputs (1 = the single
+ * parameter is an unused placeholder), then the structural bandwidths jac_kl, jac_ku, mass_kl, mass_ku of f_y and of the mass matrix (for
+ * dsh_model_set_band: banded models are assembled and factored on the band only).  defaults_out (may be NULL) receives nparams default values. */
 #define DSHS_DIFFSL_HIP_STATIC 0
 #define DSHS_DIFFSL_HIP_DYNAMIC 1
 #define DSHS_DIFFSL_HOST_C 2

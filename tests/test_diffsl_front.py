@@ -129,6 +129,15 @@ def test_language_rules_ranges_labels_broadcast_contraction_and_defaults(O, fe):
     assert np.allclose(O.model_out(mid, x, p), [0.5, -2.0, s])
 
 
+def test_front_end_reports_the_structural_bandwidth_of_jacobian_and_mass_matrix(fe):
+    """dims[6..9] of dshs_diffsl_generate: what lets the integrators assemble and factor M - cJ on the band only (dsh_model_set_band)."""
+    band = lambda code: fe.generate(code, fe.TARGET_HOST_C)[1]["band"]
+    assert band(D.heat1d(32)) == (1, 1, 0, 0) and band(D.spm(20)) == (1, 1, 0, 0)
+    assert band(D.ROBERTSON_DAE) == (2, 2, 0, 0) and band(D.RLC) == (2, 3, 0, 0)
+    assert band("u_i { x = 1, y = 2, z = 3 } dudt_i { dx = 0, dy = 0, dz = 0 } M_i { dx + dy, dy, dz + dx } F_i { x, y + z, z }") == (0, 1, 2, 1)
+    assert band(D.HEAT_DAE)[:2] == (10, 10)  # literal 0.0 coefficients keep the dependency: a declaration is an upper bound, the LU probes when it is wide
+
+
 def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
     """hiprtc cross-compiles: the register-resident form with its fused Newton kernels and a device-resident integrator, and the run-time-sized form."""
     m = fe.DiffslModel(D.RLC)

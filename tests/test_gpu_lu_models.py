@@ -323,3 +323,35 @@ def test_banded_lu_reports_singular_systems_like_the_dense_one(H, O):
     ok = [b for b in range(nb) if b not in (7, 21)]
     xo = O.lu_solve(a[ok], np.ones((len(ok), n)))[0]
     assert np.array_equal(x.clone_as_vec()[ok], xo)
+
+
+def test_declared_band_assembly_and_factorisation_touch_only_the_band_and_give_the_same_bits(H, O, ctx1):
+    """dsh_mat_scale_add_assign_banded + dsh_lu_factor_banded: what the host-side integrators use when a model declares the structure of its Jacobian
+    (dsh_model_band).  Entries outside the declared band are neither read nor written."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb, n, kl, ku = 33, 40, 2, 1
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(8)
+    jac, mass = _banded(rng, nb, n, kl, ku, False), _banded(rng, nb, n, 0, 0, True)
+    J, M = H.HipMat.from_array(jac, c), H.HipMat.from_array(mass, c)
+    poison = np.full((nb, n, n), 7.0)
+    A = H.HipMat.from_array(poison, c)
+    assert L.dsh_mat_scale_add_assign_banded(c._h, n, nb, kl, ku, A.ptr, M.ptr, nb, -0.3, J.ptr, nb) == 0
+    got = A.to_array()
+    i, j = np.indices((n, n))
+    band = (i - j <= kl) & (j - i <= ku)
+    assert np.array_equal(got[:, band], (jac * -0.3 + mass)[:, band]) and np.all(got[:, ~band] == 7.0)
+    # factorisation with the declared band: nothing outside |i - j| <= max(kl, ku) is read (poison there), inside it the operand must be exact
+    exact = jac * -0.3 + mass
+    sym = np.abs(i - j) <= max(kl, ku)
+    A2 = H.HipMat.from_array(np.where(sym, exact, 7.0), c)
+    lu = H.HipLU(c, n)
+    assert L.dsh_lu_factor_banded(lu._h, A2.ptr, kl, ku) == 0 and lu.band_width() == 2
+    b = rng.standard_normal((nb, n))
+    x = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x)
+    assert np.array_equal(x.clone_as_vec(), O.lu_solve(jac * -0.3 + mass, b)[0])
+    for model, size, expect in [("heat1d", 64, (1, 1, 0, 0)), ("spm", 20, (1, 1, 0, 0)), ("robertson_ode", 4, (2, 2, 0, 0)), ("gaussian_decay", 10, (0, 0, 0, 0)), ("rlc", 0, (-1, -1, -1, -1))]:
+        out = [C.c_int() for _ in range(4)]
+        assert L.dsh_model_band(H.MODELS[model], size, *[C.byref(o) for o in out]) == 0 and tuple(o.value for o in out) == expect
