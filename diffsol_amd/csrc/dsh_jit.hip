@@ -236,7 +236,12 @@ int dsh_model_precompile(int model_id, int family) {
   const bool st = rec->info.form == DSH_JIT_FORM_STATIC;
   auto tf = [](bool b) { return b ? "true" : "false"; };
   if (family == 0) units.push_back({ops_header(rec->info.form), "ops", st ? jit_static_op_names() : std::vector<std::string>()});
-  else if (!st) { set_error("dsh_model_precompile: only the operator kernels exist for run-time-sized models"); return DSH_E_UNSUPPORTED; }
+  else if (!st && family == 2 && rec->info.n <= 64 && !rec->info.has_mass && rec->info.nroots <= 2) {  // wavefront-per-member BDF
+    const int64_t n = rec->info.n;
+    const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
+    units.push_back({"dsh_jit_wave_member.hpp", name, {name}});
+  }
+  else if (!st) { set_error("dsh_model_precompile: run-time-sized models have the operator kernels and (n <= 64, identity mass) the wavefront-per-member BDF"); return DSH_E_UNSUPPORTED; }
   else if (family == 1) {
     units.push_back({"dsh_fused_kernels.hpp", "jac_factor", {"dsh::k_jac_factor<dsh::JitModel>"}});
     for (int sd = 0; sd < 2; ++sd)

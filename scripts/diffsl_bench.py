@@ -50,4 +50,5 @@ for label, model, size in (("builtin", "spm", 20), ("diffsl", ms, 0)):
     def run():
         s.reset(); s.solve_dense([60.0, 600.0], want_host=False)
     out[f"spm_{label}_lockstep_s"] = timed(run, reps=2)
+    out[f"spm_{label}_wave_member_resident_s"] = timed(lambda: s.solve_dense_adaptive([600.0, 1800.0, 3600.0], want_host=False, group=1), reps=2)
 print(json.dumps(out, indent=1))

@@ -150,6 +150,7 @@ def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
     with pytest.raises(Exception) as e:
         h.precompile(fe.FAMILY_FUSED)
     assert "run-time-sized" in str(e.value)
+    h.precompile(fe.FAMILY_RESIDENT_BDF)  # the wavefront-per-member BDF, instantiated for the DiffSL model
     h.release()
     s = fe.DiffslModel(D.spm(20))
     assert s.form == fe.FORM_DYNAMIC and s.n == 42 and s.nroots == 2

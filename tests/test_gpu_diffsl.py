@@ -195,6 +195,32 @@ def test_device_resident_esdirk34_with_per_member_events_on_the_compiled_rlc(H, 
     assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
 
 
+def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_member_events(H, O, fe, det_pow):
+    """n <= 64, identity mass: one wavefront per member, the kernel of BASELINE config 4 instantiated by hiprtc for the DiffSL model (its components
+    behind a switch on the lane's component).  States, counters, event times bit-identical to independent CPU solves of the same model."""
+    cur = np.linspace(0.6, 1.4, 24)[:, None]
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    code = D.spm(20)
+    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    s = H.Solver(m, cur, nbatch=24, **tol)
+    t_eval = [600.0, 3000.0, 9000.0, 15000.0]
+    y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    yo, so, failed = O.solve_dense_independent(mid, cur, t_eval, nthreads=8, group=1, method=0, **tol)
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and (mem["status"] == 0).all() and (mem["root_idx"] >= 0).sum() > 3 and np.nanmax(mem["t_root"]) - np.nanmin(mem["t_root"]) > 100.0
+    assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+    assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+    code = D.heat1d(24)
+    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    p = np.random.default_rng(2).uniform(0.5, 2.0, (10, 1))
+    s = H.Solver(m, p, nbatch=10, **tol)
+    y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=1)
+    yo, so, failed = O.solve_dense_independent(mid, p, [0.01, 0.1], nthreads=4, group=1, method=0, **tol)
+    assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    with pytest.raises(H.DiffsolHipError):  # a DAE of that size has no device-resident kernel yet
+        H.Solver(fe.DiffslModel(D.HEAT_DAE), np.ones((2, 1)), nbatch=2, **tol).solve_dense_adaptive([0.01])
+
+
 def test_a_model_that_does_not_compile_is_rejected_with_the_compiler_log(H, fe):
     from diffsol_amd import _ffi, DiffsolHipError
     L = _ffi.load_device_lib()
