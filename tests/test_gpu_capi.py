@@ -119,3 +119,17 @@ def test_device_resident_ensemble_modes_through_the_c_api(capi, O, det_pow, mode
         assert 0 < (info["root_index"] >= 0).sum() < nb
     with pytest.raises(capi.DiffsolCError):
         ode.solve(p, 0.05)  # every-step output only exists for the lock-step ensemble
+
+
+def test_a_plain_c_program_against_the_header_compiles_and_runs(tmp_path):
+    """examples/logistic_c/main.c: gcc + include/diffsol_c_hip.h + the two shared libraries, no Python in the loop (the reference ships the same kind of
+    program for its C API, examples/diffsol-c-logistic)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "logistic_c")
+    lib = os.path.join(root, "diffsol_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "logistic_c", "main.c"), "-L", lib, "-ldiffsol_hip_host",
+                    "-ldiffsol_hip", f"-Wl,-rpath,{lib}", "-lm", "-o", exe], check=True)
+    out = subprocess.run([exe, "5000"], check=True, capture_output=True, text=True).stdout
+    assert "single solve" in out and "ensemble of 5000 members" in out
