@@ -14,8 +14,13 @@ struct AdaptiveConsts {
   double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
 };
 
+// wavefronts per SIMD the kernel is compiled for: 2 for the register-resident models (256 VGPRs hold the whole BDF state); the run-time-compiled banded
+// form, whose state lives in per-lane memory anyway, overrides it (dsh_jit.hip) to trade registers for latency hiding
+#ifndef DSH_ADAPTIVE_WAVES_PER_EU
+#define DSH_ADAPTIVE_WAVES_PER_EU 2
+#endif
 template <class Mdl, bool BA, bool WAVE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE_WAVES_PER_EU, DSH_ADAPTIVE_WAVES_PER_EU))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
                                                     int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
@@ -46,24 +51,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   int order = 1;
   // D lives in registers; its swap partner (bdf.rs `diff_tmp`, touched only when the step size changes) and the cached Jacobian (touched only
   // when refactoring) live in LDS, one column of 64 lanes per value: that keeps the kernel at two wavefronts per SIMD.
-  __shared__ double sDt[kNC * N][64];
-  __shared__ double sJ[N * N][64];
+  // Banded models (Mdl::BAND_K, n up to 64): nothing of that fits registers / LDS — D, its swap partner, the band of the Jacobian and the banded LU
+  // factors are per-lane arrays (scratch memory: the hardware interleaves it by lane, so every access is a coalesced 512-byte transaction).
+  constexpr int BK = model_band_k<Mdl>::value;
+  constexpr bool BANDED = BK > 0;
+  static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
+  constexpr int LN = BANDED ? 1 : N;
+  __shared__ double sDt[kNC * LN][64];
+  __shared__ double sJ[LN * LN][64];
   const int ln = threadIdx.x;
+  double Dt_p[BANDED ? kNC : 1][BANDED ? N : 1];
+  double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
+  auto dt_get = [&](int j, int i) __attribute__((always_inline)) -> double { if constexpr (BANDED) return Dt_p[j][i]; else return sDt[j * N + i][ln]; };
+  auto dt_set = [&](int j, int i, double v) __attribute__((always_inline)) { if constexpr (BANDED) Dt_p[j][i] = v; else sDt[j * N + i][ln] = v; };
   double D[kNC][N];
 #pragma unroll
   for (int j = 0; j < kNC; ++j)
 #pragma unroll
-    for (int i = 0; i < N; ++i) { D[j][i] = 0.0; sDt[j * N + i][ln] = 0.0; }
+    for (int i = 0; i < N; ++i) { D[j][i] = 0.0; dt_set(j, i, 0.0); }
 #pragma unroll
   for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
   double opc = h * C.alpha[1];  // BdfCallable::c
-  double A[N * N];
+  double A[BANDED ? 1 : N * N];
   int P[N];
   bool jac_stale = true;
   // statistics (ode_solver/mod.rs:28-69)
   int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
   // NonLinearSolver::reset_jacobian: M - c f'(x)  (op/bdf.rs:273-300) + LU
   auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
+    if constexpr (BANDED) {
+      if (jac_stale) { Mdl::jac_band(tt, xx, p, Jb); jac_stale = false; }
+      bool sing = false;
+      band_factor_lane<N, BK>(Jb, opc, Lf, Uf, P, sing);
+    } else {
     double J[N * N];
     if (jac_stale) {
       assemble_jacobian<Mdl>(tt, xx, p, J);
@@ -84,6 +104,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + Mm[e];
     bool sing = false;
     lu_factor_reg<N>(A, P, sing);
+    }
   };
   reset_jacobian(y, t);
   n_setups = 1;
@@ -133,14 +154,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           double acc = D[0][i] * ru[0];
 #pragma unroll
           for (int k = 1; k < 6; ++k) if (k <= order) acc = D[k][i] * ru[k] + acc;
-          sDt[j * N + i][ln] = acc;
+          dt_set(j, i, acc);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < kNC; ++j)
 #pragma unroll
-      for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = sDt[j * N + i][ln]; sDt[j * N + i][ln] = tmp; }
+      for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = dt_get(j, i); dt_set(j, i, tmp); }
     opc = new_h * C.alpha[order];
     h = new_h;
     eta = C.r.eta_reset_ts;  // reset_eta_timestep_change
@@ -250,7 +271,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
           for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmpv[i] + (-opc) * f[i];
         }
-        const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
+        bool solved_ok;
+        if constexpr (BANDED) solved_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
+        else solved_ok = lu_solve_reg<N>(A, P, delta);
+        const bool lu_ok = group_all<WAVE>(solved_ok);
         if (!lu_ok) break;  // LuSolveFailed
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];

@@ -77,6 +77,10 @@ std::vector<std::string> include_options() {
 
 int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out) {
   std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
+  if (rec.info.form == DSH_JIT_FORM_STATIC_BANDED) {
+    const char* w = std::getenv("DSH_BANDED_WAVES_PER_EU");  // tuning knob
+    tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4")  /* measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8 */ + "\n";
+  }
   tu += rec.source;
   tu += std::string("\n#include \"") + header + "\"\n";
   hiprtcProgram prog;
@@ -177,8 +181,9 @@ extern "C" {
 
 int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id) {
   DSH_REQUIRE(source != nullptr && model_id != nullptr, "null argument");
-  DSH_REQUIRE(form == DSH_JIT_FORM_STATIC || form == DSH_JIT_FORM_DYNAMIC, "unknown model form");
+  DSH_REQUIRE(form == DSH_JIT_FORM_STATIC || form == DSH_JIT_FORM_DYNAMIC || form == DSH_JIT_FORM_STATIC_BANDED, "unknown model form");
   DSH_REQUIRE(n >= 1 && nparams >= 1 && nroots >= 0 && nout >= 0, "bad model dimensions");
+  if (form == DSH_JIT_FORM_STATIC_BANDED) DSH_REQUIRE(n <= 64 && !has_mass && nroots <= 8, "the lane-per-member banded form needs n <= 64, an identity mass matrix and at most 8 stop conditions");
   if (form == DSH_JIT_FORM_STATIC) {
     DSH_REQUIRE(n <= 8, "the register-resident form needs n <= 8");
     DSH_REQUIRE(nroots <= 1, "the register-resident form supports at most one root function; use the dynamic form");
@@ -187,7 +192,7 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   rec->info.form = form; rec->info.n = n; rec->info.np = nparams; rec->info.nroots = nroots; rec->info.nout = nout; rec->info.has_mass = has_mass ? 1 : 0;
   rec->source = source;
   // the stated dimensions must be the ones the source was generated with
-  if (form == DSH_JIT_FORM_STATIC)
+  if (form != DSH_JIT_FORM_DYNAMIC)
     rec->source += "\nstatic_assert(dsh::JitModel::N == " + std::to_string(n) + " && dsh::JitModel::NP == " + std::to_string(nparams) + " && dsh::JitModel::NROOTS == " +
                    std::to_string(nroots) + " && dsh::JitModel::NOUT == " + std::to_string(nout) + " && dsh::JitModel::HAS_MASS == " + (has_mass ? "true" : "false") +
                    ", \"dsh_model_compile: dimensions do not match the model source\");\n";
@@ -195,12 +200,15 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
     rec->source += "\nstatic_assert(dsh::kJitN == " + std::to_string(n) + " && dsh::kJitNP == " + std::to_string(nparams) + " && dsh::kJitNRoots == " + std::to_string(nroots) +
                    " && dsh::kJitNOut == " + std::to_string(nout) + " && dsh::kJitHasMass == " + (has_mass ? "true" : "false") +
                    ", \"dsh_model_compile: dimensions do not match the model source\");\n";
-  // compile the operator kernels now: a model that does not compile is rejected here, not at the first launch
-  auto m = std::make_unique<JitModule>();
-  const std::vector<std::string> none;
-  int rc = compile_module(*rec, ops_header(form), form == DSH_JIT_FORM_STATIC ? jit_static_op_names() : none, m.get());
-  if (rc != DSH_OK) return rc;
-  rec->modules[std::string(ops_header(form)) + "|ops"] = std::move(m);
+  // compile the operator kernels now: a model that does not compile is rejected here, not at the first launch.  (The banded lane-per-member form only
+  // exists for the device-resident BDF, compiled on first use: its operators are those of the run-time-sized twin it belongs to.)
+  if (form != DSH_JIT_FORM_STATIC_BANDED) {
+    auto m = std::make_unique<JitModule>();
+    const std::vector<std::string> none;
+    int rc = compile_module(*rec, ops_header(form), form == DSH_JIT_FORM_STATIC ? jit_static_op_names() : none, m.get());
+    if (rc != DSH_OK) return rc;
+    rec->modules[std::string(ops_header(form)) + "|ops"] = std::move(m);
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   *model_id = g_next_id++;
   g_models[*model_id] = std::move(rec);
@@ -213,6 +221,20 @@ int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int ma
   if (!rec) { set_error("dsh_model_set_band: unknown model id"); return DSH_E_INVALID; }
   rec->info.jac_kl = jac_kl; rec->info.jac_ku = jac_ku; rec->info.mass_kl = mass_kl; rec->info.mass_ku = mass_ku;
   return DSH_OK;
+}
+
+int dsh_model_set_twin(int model_id, int twin_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  if (!rec || (twin_id >= 0 && !find_model(twin_id))) { set_error("dsh_model_set_twin: unknown model id"); return DSH_E_INVALID; }
+  rec->info.twin = twin_id;
+  return DSH_OK;
+}
+int dsh_model_twin(int model_id) {
+  if (!is_jit_model(model_id)) return -1;
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  return rec ? rec->info.twin : -1;
 }
 
 int dsh_model_release(int model_id) {
@@ -234,6 +256,21 @@ int dsh_model_precompile(int model_id, int family) {
   struct Unit { const char* header; std::string key; std::vector<std::string> group; };
   std::vector<Unit> units;
   const bool st = rec->info.form == DSH_JIT_FORM_STATIC;
+  if (rec->info.form == DSH_JIT_FORM_STATIC_BANDED) {
+    if (family != 2) { set_error("dsh_model_precompile: the banded lane-per-member form only has the device-resident BDF (family 2)"); return DSH_E_UNSUPPORTED; }
+    std::vector<std::string> names;
+    for (int ba = 0; ba < 2; ++ba) names.push_back(std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", false>");
+    for (const std::string& name : names) {
+      const std::string key = std::string("dsh_adaptive_kernel.hpp|") + name;
+      if (rec->modules.count(key) && rec->modules[key]) continue;
+      auto m = std::make_unique<JitModule>();
+      int rc = compile_module(*rec, "dsh_adaptive_kernel.hpp", {name}, m.get());
+      if (rc != DSH_OK) return rc;
+      rec->modules[key] = std::move(m);
+      break;  // one variant (per-member atol) is enough to pay the cost up front
+    }
+    return DSH_OK;
+  }
   auto tf = [](bool b) { return b ? "true" : "false"; };
   if (family == 0) units.push_back({ops_header(rec->info.form), "ops", st ? jit_static_op_names() : std::vector<std::string>()});
   else if (!st && family == 2 && rec->info.n <= 64 && !rec->info.has_mass && rec->info.nroots <= 2) {  // wavefront-per-member BDF

@@ -11,7 +11,8 @@ struct JitInfo {
   int form = 0;  // DSH_JIT_FORM_*
   int64_t n = 0, np = 0, nroots = 0, nout = 0;
   int has_mass = 0;
-  int jac_kl = -1, jac_ku = -1, mass_kl = -1, mass_ku = -1;  // structural bandwidths declared with dsh_model_set_band (-1: dense / unknown)
+  int jac_kl = -1, jac_ku = -1, mass_kl = -1, mass_ku = -1;
+  int twin = -1;  // the same model in the banded lane-per-member form (dsh_model_set_twin): used for device-resident per-member solves  // structural bandwidths declared with dsh_model_set_band (-1: dense / unknown)
 };
 inline bool is_jit_model(int model) { return model >= DSH_MODEL_JIT_BASE; }
 // nullptr (+ error set) if `model` is not a live run-time-compiled model

@@ -125,4 +125,118 @@ __device__ __forceinline__ void store_vec(double* __restrict__ p, int64_t nb, in
 }
 
 
+// ---- banded LU on per-lane arrays (device-resident integrators for banded models): the algorithm of dsh_lu_band.hpp — LAPACK dgbtrf-style partial
+// pivoting with a (K+1) x (2K+1) register window, the non-trivial operations of the dense elimination in the same order — on the matrix
+// A = Jb * (-c) + I, where Jb holds the band of the Jacobian: entry (i, col) at Jb[(col - i + K) * N + i].  Factors: U(r, r+d) at Uf[d*N + r] (d <= 2K),
+// multiplier of row j+r at step j at Lf[(r-1)*N + j].
+template <int N, int K>
+__device__ __forceinline__ void band_factor_lane(const double* Jb, double c, double* Lf, double* Uf, int* P, bool& singular) {
+  constexpr int R = K + 1, C = 2 * K + 1;
+  auto in = [&](int i, int col) -> double {
+    if (i >= N || col >= N) return 0.0;
+    return Jb[(col - i + K) * N + i] * (-c) + (i == col ? 1.0 : 0.0);  // J * (-c) + M with M = from_diagonal(ones) (op/bdf.rs:138-141, :273-300)
+  };
+  double W[R][C];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int q = 0; q < C; ++q) W[r][q] = (q - r <= K && r - q <= K) ? in(r, q) : 0.0;
+  for (int j = 0; j < N; ++j) {
+    int p = 0;
+    double best = fabs(W[0][0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const double v = fabs(W[r][0]);
+      if (v > best) { best = v; p = r; }
+    }
+    double diag = W[0][0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) diag = (r == p) ? W[r][0] : diag;
+    if (diag == 0.0) {
+      P[j] = j;
+      singular = true;
+    } else {
+      P[j] = j + p;
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        const double top = W[0][q];
+        double picked = top;
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const bool sel = (r == p);
+          const double cur = W[r][q];
+          picked = sel ? cur : picked;
+          W[r][q] = sel ? top : cur;
+        }
+        W[0][q] = picked;
+      }
+      const double inv_diag = 1.0 / diag;
+#pragma unroll
+      for (int r = 1; r < R; ++r) W[r][0] = W[r][0] * inv_diag;
+#pragma unroll
+      for (int q = 1; q < C; ++q) {
+        const double pr = W[0][q];
+#pragma unroll
+        for (int r = 1; r < R; ++r) W[r][q] = (-pr) * W[r][0] + W[r][q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < C; ++q) Uf[q * N + j] = W[0][q];
+#pragma unroll
+    for (int r = 1; r < R; ++r) Lf[(r - 1) * N + j] = W[r][0];
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) {
+#pragma unroll
+      for (int q = 0; q + 1 < C; ++q) W[r][q] = W[r + 1][q + 1];
+      W[r][C - 1] = 0.0;
+    }
+    const int i = j + 1 + K;
+#pragma unroll
+    for (int q = 0; q < C; ++q) W[R - 1][q] = in(i, i - K + q);
+  }
+}
+
+// returns false if a zero diagonal of U was met (LuSolveFailed)
+template <int N, int K>
+__device__ __forceinline__ bool band_solve_lane(const double* Lf, const double* Uf, const int* P, double* v) {
+  constexpr int R = K + 1, C = 2 * K + 1;
+  double w[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) w[r] = r < N ? v[r] : 0.0;
+  for (int j = 0; j < N; ++j) {
+    const int pv = P[j] - j;
+    const double top = w[0];
+    double x = top;
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+      const bool sel = (r == pv);
+      const double cur = w[r];
+      x = sel ? cur : x;
+      w[r] = sel ? top : cur;
+    }
+    v[j] = x;
+#pragma unroll
+    for (int r = 1; r < R; ++r) w[r] = (-x) * Lf[(r - 1) * N + j] + w[r];
+#pragma unroll
+    for (int r = 0; r + 1 < R; ++r) w[r] = w[r + 1];
+    w[R - 1] = j + 1 + K < N ? v[j + 1 + K] : 0.0;
+  }
+  bool ok = true;
+  double u[C];
+#pragma unroll
+  for (int q = 0; q < C; ++q) { const int r = N - 1 - (C - 1) + q; u[q] = r >= 0 ? v[r] : 0.0; }
+  for (int i = N - 1; i >= 0; --i) {
+    const double diag = Uf[i];
+    if (diag == 0.0) ok = false;
+    const double x = u[C - 1] / diag;
+    v[i] = x;
+#pragma unroll
+    for (int d = 1; d < C; ++d) u[C - 1 - d] = (i - d >= 0) ? (-x) * Uf[d * N + (i - d)] + u[C - 1 - d] : u[C - 1 - d];
+#pragma unroll
+    for (int q = C - 1; q > 0; --q) u[q] = u[q - 1];
+    u[0] = i - C >= 0 ? v[i - C] : 0.0;
+  }
+  return ok;
+}
+
 }  // namespace dsh

@@ -50,10 +50,11 @@ __global__ void k_static_model(int64_t nb, double t, const double* __restrict__ 
     store_vec<N>(y, nb, b, yr);
   } else if constexpr (OP == Op::Root) {
     if constexpr (Mdl::NROOTS > 0) {
-      double xr[N], g[1];
+      double xr[N], g[Mdl::NROOTS];
       load_vec<N>(x, nb, b, xr);
       Mdl::root(t, xr, pp, g);
-      y[b] = g[0];
+#pragma unroll
+      for (int k = 0; k < Mdl::NROOTS; ++k) y[(int64_t)k * nb + b] = g[k];
     }
   } else if constexpr (OP == Op::Out) {  // out_i of a DiffSL model (calc_out): nout x nb, batch-fastest
     constexpr int NO = model_nout<Mdl>::value;

@@ -145,6 +145,11 @@ template <class...> using model_void_t = void;
 template <class M, class = void> struct model_nout { static constexpr int value = 0; };
 template <class M> struct model_nout<M, model_void_t<decltype(M::NOUT)>> { static constexpr int value = M::NOUT; };
 
+// a model may declare that its Jacobian is banded (BAND_K = max(kl, ku) <= 4) and provide the band directly (jac_band): the device-resident BDF then keeps
+// the state in per-lane memory and factors the band only, which lifts its size limit from the register budget (n <= 4) to n <= 64
+template <class M, class = void> struct model_band_k { static constexpr int value = 0; };
+template <class M> struct model_band_k<M, model_void_t<decltype(M::BAND_K)>> { static constexpr int value = M::BAND_K; };
+
 // Column-by-column dense assembly from jac_mul / mass_gemv with unit vectors (see header comment).  Column-major A[j*N+i].
 template <class Mdl>
 __device__ __forceinline__ void assemble_jacobian(double t, const double (&x)[Mdl::N], const double (&p)[Mdl::NP], double (&J)[Mdl::N * Mdl::N]) {

@@ -14,7 +14,7 @@ from . import _ffi
 from ._ffi import check, vp
 
 TARGET_HIP_STATIC, TARGET_HIP_DYNAMIC, TARGET_HOST_C = 0, 1, 2
-FORM_STATIC, FORM_DYNAMIC = 0, 1
+FORM_STATIC, FORM_DYNAMIC, FORM_STATIC_BANDED = 0, 1, 2
 FAMILY_OPERATORS, FAMILY_FUSED, FAMILY_RESIDENT_BDF, FAMILY_RESIDENT_SDIRK = 0, 1, 2, 3
 
 
@@ -35,7 +35,7 @@ def generate(code, target):
 
 
 class DiffslModel:
-    def __init__(self, code, form=None):
+    def __init__(self, code, form=None, lane_resident=True):
         self.code = code
         _, d, self.defaults = generate(code, TARGET_HOST_C)
         if form is None:
@@ -47,6 +47,15 @@ class DiffslModel:
         mid = C.c_int()
         check(self._L.dsh_model_compile(self.source.encode(), form, self.n, self.nparams, self.nroots, self.nout, 1 if self.has_mass else 0, C.byref(mid)))
         self.model_id = mid.value
+        self.lane_model_id = None
+        jkl, jku = d["band"][0], d["band"][1]
+        if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and not self.has_mass and max(jkl, jku) <= 4 and self.nroots <= 8:
+            # banded Jacobian: the same model once more in the lane-per-member form; per-member device-resident BDF solves run on it (compiled on first use)
+            lane_src = generate(code, TARGET_HIP_STATIC)[0]
+            lid = C.c_int()
+            check(self._L.dsh_model_compile(lane_src.encode(), FORM_STATIC_BANDED, self.n, self.nparams, self.nroots, self.nout, 0, C.byref(lid)))
+            self.lane_model_id = lid.value
+            check(self._L.dsh_model_set_twin(self.model_id, self.lane_model_id))
         self.band = d["band"]  # (jac_kl, jac_ku, mass_kl, mass_ku): structural bandwidths, declared so that banded models are assembled / factored on the band
         check(self._L.dsh_model_set_band(self.model_id, *self.band))
 
@@ -58,6 +67,9 @@ class DiffslModel:
         if getattr(self, "model_id", None) is not None:
             self._L.dsh_model_release(self.model_id)
             self.model_id = None
+        if getattr(self, "lane_model_id", None) is not None:
+            self._L.dsh_model_release(self.lane_model_id)
+            self.lane_model_id = None
 
     def host_source(self):
         """The same model as an `extern "C"` CPU library source (dsl_rhs, dsl_jac_mul, ...): what the parity tests hand to the CPU oracle."""

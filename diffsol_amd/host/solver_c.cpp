@@ -289,7 +289,10 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int64_t size = 0;
     const int method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
     bool wave_member = false;
-    if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size)) {
+    int twin = -1;  // a run-time-compiled model may carry its banded lane-per-member form: per-member BDF solves use it
+    if (method == 0 && group == 1 && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_twin(model)) >= 0 && dsh_model_has_adaptive(twin, 0)) {
+      model = twin; size = 0;
+    } else if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size)) {
       // run-time-sized models: one wavefront per member (BDF, identity mass, n <= 64)
       wave_member = method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size) && !s->problem.eqn->has_mass();
       if (!wave_member)

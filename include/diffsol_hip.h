@@ -210,9 +210,14 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 #define DSH_MODEL_JIT_BASE 1000
 #define DSH_JIT_FORM_STATIC 0
 #define DSH_JIT_FORM_DYNAMIC 1
+#define DSH_JIT_FORM_STATIC_BANDED 2 /* `struct dsh::JitModel` with BAND_K and jac_band (n <= 64, identity mass, Jacobian bandwidth <= 4): only the lane-per-member
+                                      * device-resident BDF is instantiated for it (state in per-lane memory, banded LU in registers); attach it to the
+                                      * run-time-sized form of the same model with dsh_model_set_twin and per-member solve_dense uses it */
 int dsh_model_compile(const char* source, int form, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id);
 int dsh_model_release(int model_id);
 int dsh_model_precompile(int model_id, int family);
+int dsh_model_set_twin(int model_id, int twin_id);
+int dsh_model_twin(int model_id); /* -1: none */
 /* structural bandwidths of f_y and of the mass matrix (dshs_diffsl_generate reports them for a DiffSL model): -1 = dense / unknown */
 int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int mass_ku);
 int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_kl, int* mass_ku);

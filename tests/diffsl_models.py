@@ -100,8 +100,9 @@ F_i {{ D * heat_i / (h * h) }}
 """
 
 
-def spm(m=20):
-    """The single-particle model of the battery primer (n = 2 + 2m) written as DiffSL from its formulas: spherical finite-volume Laplacians as sparse
+def spm(m=20, voltage=False):
+    """voltage=True: the stop conditions of the battery primer (terminal voltage leaves [3.105, 4.1] V) instead of the cheap surface-concentration limits.
+    The single-particle model of the battery primer (n = 2 + 2m) written as DiffSL from its formulas: spherical finite-volume Laplacians as sparse
     matrices, flux terms on the outer shells, terminal-voltage stop conditions.  Constants as in the built-in model (oracle_models.hpp Spm)."""
     def lap(scale):
         rows = []
@@ -121,6 +122,40 @@ def spm(m=20):
     surf = lambda name: f"{name}_ij {{ ({0},{m - 2}): -0.5, ({0},{m - 1}): 1.5 }}"
     ocp_p = ("2.16216 + 0.07645 * tanh(30.834 - 57.858397200000006 * sp) + 2.1581 * tanh(52.294 - 53.412228 * sp) - 0.14169 * tanh(11.0923 - 21.0852666 * sp) + "
              "0.2051 * tanh(1.4684 - 5.829105600000001 * sp) + 0.2531 * tanh(4.291641337386018 - 8.069908814589667 * sp) - 0.02167 * tanh(-87.5 + 177.0 * sp)")
+    if voltage:  # the terminal voltage as the built-in model writes it (oracle_models.hpp spm_voltage): Butler-Volmer overpotentials + open-circuit fits
+        clamp = lambda v, lo, hi: f"max(min({v}, {hi!r}), {lo!r})"
+        ocp_n = ("0.194 + 1.5 * exp(-120.0 * stn) + 0.0351 * tanh(-3.44578313253012 + 12.048192771084336 * stn) - 0.0045 * tanh(-7.1344537815126055 + 8.403361344537815 * stn) - "
+                 "0.035 * tanh(-18.466 + 20.0 * stn) - 0.0147 * tanh(-14.705882352941176 + 29.41176470588235 * stn) - 0.102 * tanh(-1.3661971830985917 + 7.042253521126761 * stn) - "
+                 "0.022 * tanh(-54.8780487804878 + 60.975609756097555 * stn) - 0.011 * tanh(-5.486725663716814 + 44.24778761061947 * stn) + "
+                 "0.0155 * tanh(-3.6206896551724133 + 34.48275862068965 * stn) + 0.000001 * (1.0 / stn + 1.0 / (-1.0 + stn))")
+        ocp_pv = ocp_p.replace("sp", "stp") + " + 0.000001 * (1.0 / stp + 1.0 / (-1.0 + stp))"
+        stops = f"""
+SP_ij {{ (0,{m - 2}): -0.4999999999999983, (0,{m - 1}): 1.4999999999999982 }}
+SN_ij {{ (0,{m - 2}): -0.4999999999999983, (0,{m - 1}): 1.4999999999999984 }}
+CP_ij {{ (0,{m - 2}): -25608.96286546366, (0,{m - 1}): 76826.88859639116 }}
+CN_ij {{ (0,{m - 2}): -12491.630996921805, (0,{m - 1}): 37474.892990765504 }}
+spr_i {{ SP_ij * cp_j }}
+snr_i {{ SN_ij * cn_j }}
+cpr_i {{ CP_ij * cp_j }}
+cnr_i {{ CN_ij * cn_j }}
+stp {{ {clamp("spr_i", 1e-10, 0.9999999999)} }}
+stn {{ {clamp("snr_i", 1e-10, 0.9999999999)} }}
+cps {{ {clamp("cpr_i", 0.000512179257309275, 51217.92521874824)} }}
+cns {{ {clamp("cnr_i", 0.000249832619938437, 24983.261744011077)} }}
+etap {{ 0.05138515824298745 * arcsinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * sqrt(cps)) * sqrt(51217.9257309275 - cps)))) }}
+etan {{ 0.05138515824298745 * arcsinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * sqrt(cns)) * sqrt(24983.2619938437 - cns)))) }}
+volt {{ (etap + ({ocp_pv})) - (etan + ({ocp_n})) }}
+stop_i {{ -3.105 + volt, 4.1 - volt }}
+out_i {{ volt }}
+"""
+    else:
+        stops = f"""
+stop_i {{
+  sn_i - 0.05,
+  sp_i - 0.99,
+}}
+out_i {{ sn_i, sp_i, {ocp_p.replace("sp", "sp_i")} }}
+"""
     return f"""
 in = [current]
 current {{ 1.0 }}
@@ -149,12 +184,7 @@ F_i {{
   ln_i + eneg_i * current,
   lp_i + epos_i * current,
 }}
-stop_i {{
-  sn_i - 0.05,
-  sp_i - 0.99,
-}}
-out_i {{ sn_i, sp_i, {ocp_p.replace("sp", "sp_i")} }}
-"""
+{stops}"""
 
 
 _cache = {}

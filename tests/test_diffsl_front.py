@@ -151,7 +151,14 @@ def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
         h.precompile(fe.FAMILY_FUSED)
     assert "run-time-sized" in str(e.value)
     h.precompile(fe.FAMILY_RESIDENT_BDF)  # the wavefront-per-member BDF, instantiated for the DiffSL model
+    # tridiagonal Jacobian, identity mass: the model is also compiled in the lane-per-member banded form (BAND_K, jac_band)
+    assert h.lane_model_id is not None and "BAND_K = 1" in fe.generate(D.heat1d(24), fe.TARGET_HIP_STATIC)[0]
+    from diffsol_amd import _ffi
+    assert _ffi.load_device_lib().dsh_model_precompile(h.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0
     h.release()
+    with pytest.raises(Exception) as e:
+        fe.generate(D.HEAT_DAE, fe.TARGET_HIP_STATIC)  # n = 12 with a mass matrix: no lane-per-member form
+    assert "identity mass" in str(e.value)
     s = fe.DiffslModel(D.spm(20))
     assert s.form == fe.FORM_DYNAMIC and s.n == 42 and s.nroots == 2
     s.release()

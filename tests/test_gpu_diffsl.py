@@ -201,7 +201,8 @@ def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_membe
     cur = np.linspace(0.6, 1.4, 24)[:, None]
     tol = dict(rtol=1e-6, atol=[1e-6])
     code = D.spm(20)
-    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    m, mid = fe.DiffslModel(code, lane_resident=False), D.host_model(O, code)  # lane_resident=False: no banded twin, the wavefront-per-member kernel runs
+    assert m.lane_model_id is None
     s = H.Solver(m, cur, nbatch=24, **tol)
     t_eval = [600.0, 3000.0, 9000.0, 15000.0]
     y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
@@ -211,7 +212,7 @@ def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_membe
     assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
     assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
     code = D.heat1d(24)
-    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    m, mid = fe.DiffslModel(code, lane_resident=False), D.host_model(O, code)
     p = np.random.default_rng(2).uniform(0.5, 2.0, (10, 1))
     s = H.Solver(m, p, nbatch=10, **tol)
     y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=1)
@@ -219,6 +220,34 @@ def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_membe
     assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
     with pytest.raises(H.DiffsolHipError):  # a DAE of that size has no device-resident kernel yet
         H.Solver(fe.DiffslModel(D.HEAT_DAE), np.ones((2, 1)), nbatch=2, **tol).solve_dense_adaptive([0.01])
+
+
+def test_banded_models_get_the_lane_per_member_bdf_with_state_in_memory_and_a_banded_lu(H, O, fe, det_pow):
+    """8 < n <= 64, identity mass, Jacobian bandwidth <= 4: the DiffSL model is compiled a second time in the lane-per-member form (BAND_K, jac_band) and
+    per-member device-resident solves run on k_bdf_adaptive with the BDF state in per-lane memory and the banded LU in registers — the kernel of the
+    n <= 4 models, not the wavefront-per-member one.  Same bits as independent CPU solves: states, counters, event times (terminal-voltage cut-off)."""
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    saw_events = False
+    for code, p, t_eval in [(D.spm(5, voltage=True), np.linspace(0.6, 1.4, 70)[:, None], [600.0, 3000.0, 9000.0, 20000.0]),
+                            (D.heat1d(12), np.random.default_rng(2).uniform(0.5, 2.0, (70, 1)), [0.01, 0.1])]:
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is not None
+        s = H.Solver(m, p, nbatch=len(p), **tol)
+        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=1, method=0, **tol)
+        ref = O.solve_dense_independent.last_roots
+        assert failed == 0 and (mem["status"] == 0).all()
+        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+        assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+        # the host-driven lock-step path of the same model object is untouched by the twin
+        O.set_det_pow(False)  # the host-side integrators call libm's pow like the reference; the deterministic pow belongs to the device-resident kernels
+        yl, _ = H.Solver(m, p[:5], nbatch=5, **tol).solve_to_points(t_eval[:1])
+        ol, _ = O.OracleSolver(mid, p[:5], nbatch=5, **tol).solve_to_points(t_eval[:1])
+        O.set_det_pow(True)
+        assert np.array_equal(yl, ol)
+        if mem["root_idx"].max() >= 0:
+            saw_events = True
+    assert saw_events  # the battery members reach a cut-off voltage, each at its own time
 
 
 def test_a_model_that_does_not_compile_is_rejected_with_the_compiler_log(H, fe):
