@@ -8,8 +8,10 @@
 // compiled on first use and cached for the life of the model.
 #include <dlfcn.h>
 #include <glob.h>
+#include <unistd.h>
 #include <hip/hiprtc.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -75,23 +77,121 @@ std::vector<std::string> include_options() {
   return opts;
 }
 
+// ---- on-disk cache of compiled modules (DSH_JIT_CACHE=<dir>, default <package>/_jit_cache next to the library; DSH_JIT_CACHE=off disables): key = FNV-1a of the translation
+// unit, the options, the requested instantiations and every header of the library the unit can include
+uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+uint64_t headers_fingerprint() {
+  static const uint64_t fp = [] {
+    uint64_t h = 1469598103934665603ull;
+    const std::string d = lib_dir();
+    for (const std::string& pat : {d + "/../csrc/*.hpp", d + "/../../include/*.h"}) {
+      glob_t g;
+      if (glob(pat.c_str(), 0, nullptr, &g) != 0) continue;
+      for (size_t i = 0; i < g.gl_pathc; ++i) {
+        FILE* f = fopen(g.gl_pathv[i], "rb");
+        if (!f) continue;
+        char buf[65536];
+        size_t k;
+        while ((k = fread(buf, 1, sizeof buf, f)) > 0) h = fnv1a(buf, k, h);
+        fclose(f);
+      }
+      globfree(&g);
+    }
+    return h;
+  }();
+  return fp;
+}
+std::string cache_dir() {
+  const char* e = std::getenv("DSH_JIT_CACHE");
+  if (e && std::string(e) == "off") return "";
+  if (e && *e) return e;
+  return lib_dir() + "/../_jit_cache";  // next to the library, inside the package tree
+}
+bool cache_load(const std::string& path, const std::vector<std::string>& group, JitModule* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  uint64_t nnames = 0, sz = 0;
+  if (fread(&nnames, 8, 1, f) == 1 && nnames == group.size()) {
+    ok = true;
+    for (size_t i = 0; i < group.size() && ok; ++i) {
+      uint64_t len = 0;
+      ok = fread(&len, 8, 1, f) == 1 && len < 4096;
+      std::string low(len, '\0');
+      ok = ok && (len == 0 || fread(low.data(), 1, len, f) == len);
+      if (ok) out->lowered[group[i]] = low;
+    }
+    ok = ok && fread(&sz, 8, 1, f) == 1 && sz > 0 && sz < (1ull << 31);
+    if (ok) { out->code.resize(sz); ok = fread(out->code.data(), 1, sz, f) == sz; }
+  }
+  fclose(f);
+  if (!ok) { out->lowered.clear(); out->code.clear(); }
+  return ok;
+}
+void cache_store(const std::string& dir, const std::string& path, const std::vector<std::string>& group, const JitModule& m) {
+  (void)!system(("mkdir -p '" + dir + "'").c_str());
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  uint64_t nnames = group.size();
+  fwrite(&nnames, 8, 1, f);
+  for (const std::string& e : group) {
+    const std::string& low = m.lowered.at(e);
+    uint64_t len = low.size();
+    fwrite(&len, 8, 1, f);
+    fwrite(low.data(), 1, len, f);
+  }
+  uint64_t sz = m.code.size();
+  fwrite(&sz, 8, 1, f);
+  fwrite(m.code.data(), 1, sz, f);
+  fclose(f);
+  (void)rename(tmp.c_str(), path.c_str());  // atomic: concurrent processes (one per GPU) may compile the same model
+}
+
+int compile_module_uncached(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, const std::vector<std::string>& opts,
+                            JitModule* out);
+
 int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out) {
   std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
   if (rec.info.form == DSH_JIT_FORM_STATIC_BANDED) {
     const char* w = std::getenv("DSH_BANDED_WAVES_PER_EU");  // tuning knob
-    tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4")  /* measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8 */ + "\n";
+    tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }
   tu += rec.source;
   tu += std::string("\n#include \"") + header + "\"\n";
+  // same code generation switches as the library's own objects (Makefile): no FMA contraction, so the arithmetic order in the source is the arithmetic
+  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
+  const std::string dir = cache_dir();
+  std::string path;
+  if (!dir.empty()) {
+    uint64_t h = headers_fingerprint();
+    h = fnv1a(tu.data(), tu.size(), h);
+    for (const std::string& o : opts) h = fnv1a(o.data(), o.size() + 1, h);
+    for (const std::string& e : group) h = fnv1a(e.data(), e.size() + 1, h);
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+    path = dir + name;
+    if (cache_load(path, group, out)) return DSH_OK;
+  }
+  for (const std::string& o : include_options()) opts.push_back(o);
+  int rc = compile_module_uncached(rec, tu, header, group, opts, out);
+  if (rc == DSH_OK && !path.empty()) cache_store(dir, path, group, *out);
+  return rc;
+}
+
+int compile_module_uncached(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, const std::vector<std::string>& opts,
+                            JitModule* out) {
+  (void)rec;
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, tu.c_str(), "dsh_jit_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
     set_error("hiprtcCreateProgram failed");
     return DSH_E_HIP;
   }
   for (const std::string& e : group) hiprtcAddNameExpression(prog, e.c_str());
-  // same code generation switches as the library's own objects (Makefile): no FMA contraction, so the arithmetic order in the source is the arithmetic
-  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
-  for (const std::string& o : include_options()) opts.push_back(o);
   std::vector<const char*> copts;
   for (const std::string& o : opts) copts.push_back(o.c_str());
   hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());

@@ -205,7 +205,8 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
  * (diffsol_hip_solver.h): `struct dsh::JitModel` (DSH_JIT_FORM_STATIC, n <= 8, at most one root function) or the jit_* component functions
  * (DSH_JIT_FORM_DYNAMIC).  It is compiled with hiprtc together with the library's own kernel templates, so the returned model id (>= DSH_MODEL_JIT_BASE)
  * works wherever a registry id does: dsh_model_*, the fused Newton kernels (static form), the device-resident integrators (static form), and the
- * host-side integrators of diffsol_hip_solver.h.  Kernel families are compiled on first use; dsh_model_precompile (family 0 operators, 1 fused Newton,
+ * host-side integrators of diffsol_hip_solver.h.  Kernel families are compiled on first use and cached on disk (DSH_JIT_CACHE=<dir> | off; default <package>/_jit_cache, keyed by the
+ * translation unit, the options and the library's headers); dsh_model_precompile (family 0 operators, 1 fused Newton,
  * 2 resident BDF, 3 resident SDIRK) pays that cost up front and needs no GPU.  `model_size` arguments are ignored for these ids. */
 #define DSH_MODEL_JIT_BASE 1000
 #define DSH_JIT_FORM_STATIC 0
