@@ -103,6 +103,7 @@ DEVICE_ABI = {
     "dsh_model_precompile": (cint, [cint, cint]),
     "dsh_model_set_twin": (cint, [cint, cint]),
     "dsh_model_twin": (cint, [cint]),
+    "dsh_model_lane_twin": (cint, [cint, i64]),
     "dsh_model_set_band": (cint, [cint, cint, cint, cint, cint]),
     "dsh_model_band": (cint, [cint, i64, c_ip, c_ip, c_ip, c_ip]),
     "dsh_lu_factor_banded": (cint, [vp, vp, cint, cint]),

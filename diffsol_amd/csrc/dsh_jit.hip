@@ -323,6 +323,29 @@ int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int ma
   return DSH_OK;
 }
 
+// The banded lane-per-member form of a built-in run-time-sized model (dsh_models_lane.hpp), created on first request and kept for the life of the process.
+// -1 if the model has none (not a registry model with n <= 64, identity mass, declared bandwidth <= 4, at most 2 stop conditions and parameters that fit).
+int dsh_model_lane_twin(int model, int64_t size) {
+  if (is_jit_model(model)) return dsh_model_twin(model);
+  static std::map<std::pair<int, int64_t>, int> twins;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = twins.find({model, size});
+  if (it != twins.end()) return it->second;
+  int id = -1;
+  int64_t n = 0, np = 0, nroots = 0;
+  int has_mass = 0, jl = -1, ju = -1, ml = -1, mu2 = -1;
+  if (dsh_model_info(model, size, &n, &np, &has_mass, &nroots) == DSH_OK && dsh_model_band(model, size, &jl, &ju, &ml, &mu2) == DSH_OK && !dsh_model_has_fused(model, size) &&
+      n > 8 && n <= 64 && !has_mass && jl >= 0 && ju >= 0 && std::max(jl, ju) <= 4 && nroots <= 2 && np >= 1 && np <= 8) {
+    const int k = std::max(1, std::max(jl, ju));
+    const std::string src = "#include \"dsh_models_lane.hpp\"\nnamespace dsh { using JitModel = DynLane<" + std::to_string(model) + ", " + std::to_string(n) + ", " + std::to_string(np) +
+                            ", " + std::to_string(nroots) + ", " + std::to_string(k) + ">; }\n";
+    if (dsh_model_compile(src.c_str(), DSH_JIT_FORM_STATIC_BANDED, n, np, nroots, 0, 0, &id) != DSH_OK) id = -1;
+  }
+  twins[{model, size}] = id;
+  return id;
+}
+
 int dsh_model_set_twin(int model_id, int twin_id) {
   std::lock_guard<std::mutex> lk(g_mu);
   JitModelRec* rec = find_model(model_id);
@@ -359,7 +382,7 @@ int dsh_model_precompile(int model_id, int family) {
   if (rec->info.form == DSH_JIT_FORM_STATIC_BANDED) {
     if (family != 2) { set_error("dsh_model_precompile: the banded lane-per-member form only has the device-resident BDF (family 2)"); return DSH_E_UNSUPPORTED; }
     std::vector<std::string> names;
-    for (int ba = 0; ba < 2; ++ba) names.push_back(std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", false>");
+    for (int ba = 1; ba >= 0; --ba) names.push_back(std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", false>");
     for (const std::string& name : names) {
       const std::string key = std::string("dsh_adaptive_kernel.hpp|") + name;
       if (rec->modules.count(key) && rec->modules[key]) continue;
@@ -367,7 +390,7 @@ int dsh_model_precompile(int model_id, int family) {
       int rc = compile_module(*rec, "dsh_adaptive_kernel.hpp", {name}, m.get());
       if (rc != DSH_OK) return rc;
       rec->modules[key] = std::move(m);
-      break;  // one variant (per-member atol) is enough to pay the cost up front
+      break;  // the variant with shared tolerances (what the host-side problem passes) is enough to pay the cost up front
     }
     return DSH_OK;
   }

@@ -219,6 +219,9 @@ int dsh_model_release(int model_id);
 int dsh_model_precompile(int model_id, int family);
 int dsh_model_set_twin(int model_id, int twin_id);
 int dsh_model_twin(int model_id); /* -1: none */
+/* the same for any model id: a run-time-compiled model's twin, or — created on first request — the banded lane-per-member form of a built-in
+ * run-time-sized model (heat1d, the single-particle model, ...; csrc/dsh_models_lane.hpp).  -1: the model has no such form. */
+int dsh_model_lane_twin(int model, int64_t size);
 /* structural bandwidths of f_y and of the mass matrix (dshs_diffsl_generate reports them for a DiffSL model): -1 = dense / unknown */
 int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int mass_ku);
 int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_kl, int* mass_ku);

@@ -100,8 +100,9 @@ def run_spm(nb, t_final=1200.0):
 
 
 def run_spm_resident(nb, t_final=3600.0):
-    """C4 through the wavefront-per-member kernel (dsh_bdf_solve_wave_member): full one-hour discharge with the stop conditions armed — every member
-    integrates with its own step sizes and stops at ITS OWN voltage cut-off."""
+    """C4 device-resident with per-member control: full one-hour discharge with the stop conditions armed — every member integrates with its own step sizes and
+    stops at ITS OWN voltage cut-off.  The model's Jacobian is tridiagonal, so the lane-per-member banded BDF runs (DynLane<spm, 42, ..> instantiated by hiprtc);
+    DSH_RESIDENT_LANE=0 selects the wavefront-per-member kernel (dsh_bdf_solve_wave_member) instead."""
     import diffsol_amd as H
     rng = np.random.default_rng(12345)
     cur = rng.uniform(0.6, 1.4, nb)
@@ -112,7 +113,7 @@ def run_spm_resident(nb, t_final=3600.0):
     y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True)
     wall = time.perf_counter() - t0
     hit = m["root_idx"] >= 0
-    return dict(config="C4 spm device-resident (one wavefront per member, events armed)", n=s.n, nbatch=nb, method="bdf", wall_s=wall, totals=tot,
+    return dict(config="C4 spm device-resident (%s, events armed)" % ("one wavefront per member" if os.environ.get("DSH_RESIDENT_LANE", "1")[:1] == "0" else "one lane per member, banded LU"), n=s.n, nbatch=nb, method="bdf", wall_s=wall, totals=tot,
                 members_stopped_by_event=int(hit.sum()), event_time_min=float(np.nanmin(m["t_root"])) if hit.any() else None,
                 event_time_max=float(np.nanmax(m["t_root"])) if hit.any() else None, status_nonzero=int((m["status"] != 0).sum()),
                 steps_per_s=tot["number_of_steps"] / wall, newton_solves_per_s=tot["number_of_nonlinear_solver_iterations"] / wall,

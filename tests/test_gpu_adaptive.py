@@ -340,7 +340,14 @@ def test_with_a_shared_deterministic_pow_the_resident_sdirk_is_bit_identical_to_
         assert np.array_equal(m["t_root"], ref["t_root"], equal_nan=True)
 
 
-def test_with_a_shared_deterministic_pow_the_wavefront_per_member_bdf_is_bit_identical_to_the_oracle(H, O, det_pow):
+@pytest.mark.parametrize("lane", ["1", "0"])
+def test_with_a_shared_deterministic_pow_the_wavefront_per_member_bdf_is_bit_identical_to_the_oracle(H, O, det_pow, monkeypatch, lane):
+    """Run-time-sized built-in models, per-member control.  lane = "1" (default): models with a banded Jacobian run the lane-per-member BDF with the state in
+    per-lane memory and a banded LU (their static form DynLane<...> of csrc/dsh_models_lane.hpp, instantiated by hiprtc for the size at hand);
+    lane = "0" (DSH_RESIDENT_LANE=0): the wavefront-per-member kernel.  Both must give the oracle's bits."""
+    monkeypatch.setenv("DSH_RESIDENT_LANE", lane)
+    from diffsol_amd import _ffi
+    assert _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["spm"], 20) >= 1000 and _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["gaussian_decay"], 12) == -1
     cur = np.linspace(0.6, 1.4, 24)[:, None]
     _bitwise_pair(H, O, "spm", cur, [60.0, 600.0, 1200.0], 20, 1, 0, rtol=1e-6, atol=[1e-6])  # before any voltage cut-off
     # full discharge, BASELINE config 4: every member's own cut-off time (the terminal voltage's tanh / asinh / exp are diffsol_detpow.h's on both sides)
