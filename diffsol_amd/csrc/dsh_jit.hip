@@ -380,17 +380,18 @@ int dsh_model_precompile(int model_id, int family) {
   std::vector<Unit> units;
   const bool st = rec->info.form == DSH_JIT_FORM_STATIC;
   if (rec->info.form == DSH_JIT_FORM_STATIC_BANDED) {
-    if (family != 2) { set_error("dsh_model_precompile: the banded lane-per-member form only has the device-resident BDF (family 2)"); return DSH_E_UNSUPPORTED; }
-    std::vector<std::string> names;
-    for (int ba = 1; ba >= 0; --ba) names.push_back(std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", false>");
-    for (const std::string& name : names) {
-      const std::string key = std::string("dsh_adaptive_kernel.hpp|") + name;
+    if (family != 2 && family != 3) { set_error("dsh_model_precompile: the banded lane-per-member form only has the device-resident integrators (families 2, 3)"); return DSH_E_UNSUPPORTED; }
+    // the variants with shared tolerances and per-member control (what the host-side problem uses) are enough to pay the cost up front
+    std::vector<std::pair<const char*, std::string>> units;
+    if (family == 2) units.push_back({"dsh_adaptive_kernel.hpp", "dsh::k_bdf_adaptive<dsh::JitModel, true, false>"});
+    else for (int s = 3; s <= 4; ++s) units.push_back({"dsh_sdirk_kernel.hpp", "dsh::k_sdirk_resident<dsh::JitModel, true, false, " + std::to_string(s) + ">"});
+    for (const auto& u : units) {
+      const std::string key = std::string(u.first) + "|" + u.second;
       if (rec->modules.count(key) && rec->modules[key]) continue;
       auto m = std::make_unique<JitModule>();
-      int rc = compile_module(*rec, "dsh_adaptive_kernel.hpp", {name}, m.get());
+      int rc = compile_module(*rec, u.first, {u.second}, m.get());
       if (rc != DSH_OK) return rc;
       rec->modules[key] = std::move(m);
-      break;  // the variant with shared tolerances (what the host-side problem passes) is enough to pay the cost up front
     }
     return DSH_OK;
   }

@@ -19,8 +19,14 @@ struct SdirkConsts {
   double gamma;                        // a(1,1)
 };
 
+// the run-time-compiled banded form (state in per-lane memory) is built for a fixed occupancy like the BDF kernel (dsh_jit.hip defines the macro)
+#ifdef DSH_ADAPTIVE_WAVES_PER_EU
+#define DSH_SDIRK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE_WAVES_PER_EU, DSH_ADAPTIVE_WAVES_PER_EU)))
+#else
+#define DSH_SDIRK_OCCUPANCY
+#endif
 template <class Mdl, bool BA, bool WAVE, int S>
-__global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const SdirkConsts* __restrict__ Cp,
+__global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const SdirkConsts* __restrict__ Cp,
                                                        const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                        int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
                                                        int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
@@ -37,7 +43,13 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
   load_vec<NP>(p_g, nb, b, p);
 #pragma unroll
   for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
-  __shared__ double sJ[N * N][64];
+  // banded models (Mdl::BAND_K, n up to 64): Jacobian band and banded LU factors in per-lane memory, see dsh_adaptive_kernel.hpp
+  constexpr int BK = model_band_k<Mdl>::value;
+  constexpr bool BANDED = BK > 0;
+  static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
+  constexpr int LN = BANDED ? 1 : N;
+  __shared__ double sJ[LN * LN][64];
+  double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
 
   // ------------------------------------------------------------ RkState::new_and_consistent(problem, tableau.order())
   int32_t status = kRsOk;
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
   double phi[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) phi[i] = 0.0;  // V::zeros until the first set_phi
-  double A[N * N];
+  double A[BANDED ? 1 : N * N];
   int P[N];
   bool is_jacobian_set = false, jac_stale = true;
   bool has_prev_err = false;
@@ -83,6 +95,18 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
 
   // SdirkCallable::jacobian_inplace (op/sdirk.rs:266-296) + LU: M - (c h) f'(phi + c x)
   auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
+    if constexpr (BANDED) {
+      if (jac_stale) {
+        double tmp[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) tmp[i] = op_c * xx[i] + 1.0 * phi[i];
+        Mdl::jac_band(tt, tmp, p, Jb);
+        jac_stale = false;
+      }
+      bool sing = false;
+      band_factor_lane<N, BK>(Jb, op_c * op_h, Lf, Uf, P, sing);  // J * (-(c h)) + I
+      is_jacobian_set = true;
+    } else {
     double J[N * N], Mm[N * N];
     if (jac_stale) {
       double tmp[N];
@@ -107,6 +131,7 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
     bool sing = false;
     lu_factor_reg<N>(A, P, sing);
     is_jacobian_set = true;
+    }
   };
   // Sdirk::_jacobian_updates (sdirk.rs:260-303)
   auto jacobian_updates = [&](double hh, JState st) __attribute__((always_inline)) {
@@ -248,7 +273,10 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
 #pragma unroll
             for (int r = 0; r < N; ++r) delta[r] = 1.0 * k[r] + beta * f[r];
           }
-          if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) break;  // LuSolveFailed
+          bool solved_ok;
+          if constexpr (BANDED) solved_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
+          else solved_ok = lu_solve_reg<N>(A, P, delta);
+          if (!group_all<WAVE>(solved_ok)) break;  // LuSolveFailed
 #pragma unroll
           for (int r = 0; r < N; ++r) k[r] = k[r] - delta[r];
           const ConvStatus st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, y, atol, rtol))));
@@ -300,7 +328,10 @@ __global__ __launch_bounds__(64) void k_sdirk_resident(int64_t nb, const double*
 #pragma unroll
         for (int r = 0; r < N; ++r) err[r] = e2[r];
       }
-      if (!group_all<WAVE>(lu_solve_reg<N>(A, P, err))) { status = kRsTooManyNonlinearSolverFailures; break; }
+      bool err_ok;
+      if constexpr (BANDED) err_ok = band_solve_lane<N, BK>(Lf, Uf, P, err);
+      else err_ok = lu_solve_reg<N>(A, P, err);
+      if (!group_all<WAVE>(err_ok)) { status = kRsTooManyNonlinearSolverFailures; break; }
       error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(err, y, atol, rtol)));
       const double maxiter = (double)conv.max_iter, niter = (double)conv.niter;
       const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);

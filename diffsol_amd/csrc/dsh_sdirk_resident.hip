@@ -27,7 +27,11 @@ extern "C" {
 int dsh_model_has_resident(int method, int model, int64_t size) {
   if (method == 0) return dsh_model_has_adaptive(model, size);
   if (method != 1 && method != 2) return 0;
-  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 ? 1 : 0; }
+  if (is_jit_model(model)) {
+    const JitInfo* ji = jit_info(model);
+    if (!ji) return 0;
+    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || (ji->form == DSH_JIT_FORM_STATIC_BANDED && ji->n <= 64) ? 1 : 0;
+  }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);

@@ -162,3 +162,20 @@ def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
     s = fe.DiffslModel(D.spm(20))
     assert s.form == fe.FORM_DYNAMIC and s.n == 42 and s.nroots == 2
     s.release()
+
+
+def test_the_device_resident_kernel_families_of_the_diffsl_test_models_compile_without_a_gpu(fe):
+    """hiprtc needs no GPU: the lane-per-member integrators the GPU tests run (register form for n <= 4, banded per-lane-memory form for the battery and heat
+    models) are compiled here; the code objects go to the in-tree cache (diffsol_amd/_jit_cache/) that travels to the GPU box with the tree."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    for code in (D.ROBERTSON_ODE, D.RLC):
+        m = fe.DiffslModel(code)
+        assert m.form == fe.FORM_STATIC and m.lane_model_id is None
+        m.precompile(fe.FAMILY_FUSED)
+        m.precompile(fe.FAMILY_RESIDENT_BDF)
+        m.precompile(fe.FAMILY_RESIDENT_SDIRK)
+    for code in (D.heat1d(12), D.spm(5, voltage=True)):
+        m = fe.DiffslModel(code)
+        assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is not None
+        assert L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0 and L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_SDIRK) == 0, L.dsh_last_error()

@@ -100,7 +100,7 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s3 = H.Solver("heat1d", [[1.0]], nbatch=1, model_size=16, method=1)  # run-time sized model: no register kernel
+    s3 = H.Solver("gaussian_decay", [[1.0] * 12], nbatch=1, model_size=12, method=1)  # run-time sized, 12 parameters: no lane-per-member form, and the wavefront-per-member kernel is BDF only
     with pytest.raises(H.DiffsolHipError) as e:
         s3.solve_dense_adaptive([0.1])
     assert e.value.code == -6

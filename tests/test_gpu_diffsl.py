@@ -250,6 +250,28 @@ def test_banded_models_get_the_lane_per_member_bdf_with_state_in_memory_and_a_ba
     assert saw_events  # the battery members reach a cut-off voltage, each at its own time
 
 
+@pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
+def test_banded_models_also_get_the_lane_per_member_sdirk_integrators(H, O, fe, det_pow, method):
+    """TR-BDF2 / ESDIRK34 per member on the device for a banded run-time-sized model (k_sdirk_resident in its banded form), with stop conditions."""
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    for code, p, t_eval in [(D.heat1d(12), np.random.default_rng(2).uniform(0.5, 2.0, (40, 1)), [0.01, 0.1]),
+                            (D.spm(5, voltage=True), np.linspace(0.6, 1.4, 40)[:, None], [600.0, 3000.0, 9000.0, 20000.0])]:
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        s = H.Solver(m, p, nbatch=len(p), method=METHOD[method], **tol)
+        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=1, method=METHOD[method], **tol)
+        ref = O.solve_dense_independent.last_roots
+        assert failed == 0 and (mem["status"] == 0).all()
+        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+        assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+    # the built-in heat model takes the same route (DynLane<heat1d, 20, ...>)
+    p = np.random.default_rng(3).uniform(0.5, 2.0, (20, 1))
+    s = H.Solver("heat1d", p, nbatch=20, model_size=20, method=METHOD[method], **tol)
+    y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=1)
+    yo, so, failed = O.solve_dense_independent(7, p, [0.01, 0.1], model_size=20, nthreads=4, group=1, method=METHOD[method], **tol)
+    assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+
+
 def test_a_model_that_does_not_compile_is_rejected_with_the_compiler_log(H, fe):
     from diffsol_amd import _ffi, DiffsolHipError
     L = _ffi.load_device_lib()
