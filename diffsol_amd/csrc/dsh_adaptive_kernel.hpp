@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
   const double rtol = C.r.rtol;
   double p[NP], atol[N];
   load_vec<NP>(p_g, nb, b, p);
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
 
   // ------------------------------------------------------------ OdeSolverState::new_and_consistent (state.rs:969-997, :1086-1124)
@@ -67,9 +67,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
   double D[kNC][N];
 #pragma unroll
   for (int j = 0; j < kNC; ++j)
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) { D[j][i] = 0.0; dt_set(j, i, 0.0); }
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
   double opc = h * C.alpha[1];  // BdfCallable::c
   double A[BANDED ? 1 : N * N];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
           for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
           ru[k] = acc;
         }
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) {
           double acc = D[0][i] * ru[0];
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     }
 #pragma unroll
     for (int j = 0; j < kNC; ++j)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = dt_get(j, i); dt_set(j, i, tmp); }
     opc = new_h * C.alpha[order];
     h = new_h;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
 
   // _predict_forward (bdf.rs:674-692): y_predict = sum_{j<=order} D_j ; psi_neg_y0 = alpha_order * sum_{1<=j<=order} gamma_j D_j - y_predict
   auto predict_forward = [&]() __attribute__((always_inline)) {
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     predict_forward();
     while (true) {
       // ---- NewtonNonlinearSolver::solve_in_place over NoLineSearch (newton.rs:13-36, line_search.rs:46-72)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) x[i] = yp[i];
       niter = 0;
       bool has_old = false;
@@ -260,15 +260,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
         double f[N], delta[N], tmpv[N];
         Mdl::rhs(t_predict, x, p, f);
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) tmpv[i] = x[i] + psi[i];
         // F(y) = M (y - y0 + psi) - c f(y)   (op/bdf.rs:240-256)
         if constexpr (Mdl::HAS_MASS) {
-#pragma unroll
+DSH_UNROLL_N
           for (int i = 0; i < N; ++i) delta[i] = f[i];
           Mdl::mass_gemv(t_predict, tmpv, p, -opc, delta);
         } else {
-#pragma unroll
+DSH_UNROLL_N
           for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmpv[i] + (-opc) * f[i];
         }
         bool solved_ok;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
         else solved_ok = lu_solve_reg<N>(A, P, delta);
         const bool lu_ok = group_all<WAVE>(solved_ok);
         if (!lu_ok) break;  // LuSolveFailed
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
         const double norm = sqrt(group_norm<WAVE>(wms<N>(delta, yp, atol, rtol)));
         // Convergence::check_new_iteration (convergence.rs:68-139)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
         continue;
       }
       double ydelta[N];
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
       // error_control (bdf.rs:812-843): norm against the CURRENT state y
       error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * C.ec2[order - 1]);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
         // ---- accepted: _update_diff (bdf.rs:646-664), state update
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) {
           double dk1 = 0.0;
 #pragma unroll
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     if (n_equal_steps > order) {
       // order selection (bdf.rs:1494-1560): predict_error_control(order-1) / (order+1) on the updated differences
       double col_m[N], col_p[N];
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         double vm = 0.0, vp = 0.0;
 #pragma unroll
@@ -389,14 +389,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     // interpolate_from_diff (bdf.rs:767-782)
     auto interpolate = [&](double te, double (&yv)[N]) __attribute__((always_inline)) {
       double time_factor = 1.0;
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) yv[i] = D[0][i];
 #pragma unroll
       for (int j = 0; j < kMaxOrder; ++j) {
         if (j < order) {
           const double jt = (double)j;
           time_factor *= (te - (t - h * jt)) / (h * (1.0 + jt));
-#pragma unroll
+DSH_UNROLL_N
           for (int i = 0; i < N; ++i) yv[i] = time_factor * D[j + 1][i] + 1.0 * yv[i];
         }
       }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     while (col < C.r.n_eval && t_eval[col] <= upto) {
       double yv[N];
       interpolate(t_eval[col], yv);
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
       col++;
     }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
       if (col < C.r.n_eval) {
         double yv[N];
         interpolate(t_root, yv);
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
         col++;
       }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
     // columns that were never reached (root stop or error exit): NaN
     for (; col < C.r.n_eval; ++col)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
     if (status_out != nullptr) status_out[b] = status;
     if (stats_out != nullptr) {

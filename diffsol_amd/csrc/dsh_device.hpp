@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+// loops over the n state components: fully unrolled (the state of the register-resident models lives in registers); the run-time-compiled banded form,
+// whose state is in per-lane memory anyway, may keep them rolled (DSH_NOUNROLL_N, dsh_jit.hip)
+#ifdef DSH_NOUNROLL_N
+#define DSH_UNROLL_N _Pragma("nounroll")
+#else
+#define DSH_UNROLL_N _Pragma("unroll")
+#endif
+
 namespace dsh {
 
 // Result records: kRecWords u64 per workgroup (layout in dsh_internal.hpp); kRecRegions reducing launches may be in flight before a region is reused.

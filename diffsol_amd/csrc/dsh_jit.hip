@@ -159,6 +159,10 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
   std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
   if (rec.info.form == DSH_JIT_FORM_STATIC_BANDED) {
     const char* w = std::getenv("DSH_BANDED_WAVES_PER_EU");  // tuning knob
+    // loops over the state components stay rolled (the arrays live in per-lane memory anyway): the 42-state battery model compiles in 13 s instead of 43 s
+    // and integrates 262 144 members in 0.245 s instead of 0.308 s.  DSH_BANDED_NOUNROLL=0 unrolls them like the register-resident kernels.
+    const char* nu = std::getenv("DSH_BANDED_NOUNROLL");
+    if (!(nu && nu[0] == '0')) tu += "#define DSH_NOUNROLL_N 1\n";
     tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }
   tu += rec.source;

@@ -3,6 +3,7 @@
 // single-particle battery model with 20 shells.  Every entry is the registry's own per-component function, so the arithmetic — and with it the parity with
 // the CPU oracle, whose Jacobian is J e_j column by column — is that of the other kernels.
 #pragma once
+#include "dsh_device.hpp"
 #include "dsh_models_dyn.hpp"
 
 namespace dsh {
@@ -15,14 +16,14 @@ struct DynLane {
     auto X = [&](int64_t k) { return x[k]; };
     auto V = [&](int64_t) { return 0.0; };
     auto P = [&](int64_t k) { return p[k]; };
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) y[i] = dyn_component(MODEL, (int64_t)N, t, (int64_t)i, X, V, P, false);
   }
   __device__ static void jac_mul(double t, const double (&x)[N], const double (&p)[NP], const double (&v)[N], double (&y)[N]) {
     auto X = [&](int64_t k) { return x[k]; };
     auto V = [&](int64_t k) { return v[k]; };
     auto P = [&](int64_t k) { return p[k]; };
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) y[i] = dyn_component(MODEL, (int64_t)N, t, (int64_t)i, X, V, P, true);
   }
   // d f_i / d u_col at [(col - i + K) * N + i]: row i of J e_col
@@ -31,7 +32,7 @@ struct DynLane {
     auto P = [&](int64_t k) { return p[k]; };
 #pragma unroll
     for (int d = 0; d < 2 * K + 1; ++d)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         const int col = i + d - K;
         auto E = [&](int64_t k) { return k == col ? 1.0 : 0.0; };
@@ -39,11 +40,11 @@ struct DynLane {
       }
   }
   __device__ static void mass_gemv(double, const double (&x)[N], const double (&)[NP], double beta, double (&y)[N]) {
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) y[i] = 1.0 * x[i] + beta * y[i];
   }
   __device__ static void init(double, const double (&)[NP], double (&y)[N]) {
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) y[i] = dyn_init_value(MODEL, (int64_t)N, (int64_t)i);
   }
   __device__ static void root(double t, const double (&x)[N], const double (&p)[NP], double (&g)[NROOT > 0 ? NROOT : 1]) {

@@ -44,7 +44,7 @@ struct ResidentConsts {
 template <int N>
 __device__ __forceinline__ double wms(const double (&v)[N], const double (&w)[N], const double (&atol)[N], double rtol) {
   double acc = 0.0;
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) {
     const double term = v[i] / (fabs(w[i]) * rtol + atol[i]);
     acc += term * term;
@@ -174,10 +174,10 @@ __device__ __forceinline__ double initial_step_size(double t, double h0_in, cons
   const double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
   const double hh = is_neg_h ? -h0 : h0;
   double y1[N], f1[N], df[N];
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) y1[i] = f0[i] * hh + y[i];
   Mdl::rhs(is_neg_h ? t - h0 : t + h0, y1, p, f1);
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) df[i] = f1[i] - f0[i];
   const double d2 = sqrt(group_norm<WAVE>(wms<N>(df, y, atol, rtol))) / fabs(h0);
   double max_d = d2;
@@ -205,15 +205,15 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
     assemble_mass<Mdl>(t0, p, Mm);
     bool is_alg[N];
     bool any_alg = false;
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) { is_alg[i] = Mm[i * N + i] == 0.0; any_alg = any_alg || is_alg[i]; }  // partition_indices_by_zero_diagonal
     if (!any_alg) return true;
     // InitOp::new: jac = (-M_u, df/dv; 0, dg/dv), neg_mass = (-M_u, 0; 0, 0) in the original ordering
     double rj[N * N], jac[N * N], neg_mass[N * N];
     assemble_jacobian<Mdl>(t0, y, p, rj);
-#pragma unroll
+DSH_UNROLL_N
     for (int j = 0; j < N; ++j)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         if (!is_alg[j]) {
           const double v = is_alg[i] ? 0.0 : Mm[j * N + i] * (-1.0);
@@ -225,14 +225,14 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
         }
       }
     double y0[N], x[N], yerr[N], delta[N];
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) { y0[i] = y[i]; x[i] = is_alg[i] ? y[i] : dy[i]; yerr[i] = x[i]; delta[i] = 0.0; }
     // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0) ; out = neg_mass x + out  (nalgebra gemv order)
     auto fun = [&](const double (&xx)[N], double (&out)[N]) __attribute__((always_inline)) {
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (is_alg[i]) y0[i] = xx[i];
       Mdl::rhs(t0, y0, p, out);
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         double acc = 1.0 * neg_mass[0 * N + i] * xx[0] + 1.0 * out[i];
 #pragma unroll
@@ -265,7 +265,7 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
           fun(x, delta);
           if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) { fatal = true; }
           else {
-#pragma unroll
+DSH_UNROLL_N
             for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
             st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, yerr, atol, rtol))));
           }
@@ -277,7 +277,7 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
             else {
               ls_norm = sqrt(group_norm<WAVE>(wms<N>(delta, yerr, atol, rtol)));
               if (conv.check_norm(ls_norm) == ConvStatus::Converged) {
-#pragma unroll
+DSH_UNROLL_N
                 for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
                 st = ConvStatus::Converged;
                 returned = true;
@@ -286,14 +286,14 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
           }
           if (!returned) {
             double x0[N], delta0[N];
-#pragma unroll
+DSH_UNROLL_N
             for (int i = 0; i < N; ++i) { x0[i] = x[i]; delta0[i] = delta[i]; }
             const double nrm = ls_norm;
             const double phi0 = nrm * nrm * 0.5, two_phi0 = nrm * nrm, min_alpha = C.ls_steptol / nrm;
             double alpha = 1.0;
             bool found = false;
             for (int i = 0; i < o.ic_max_linesearch_iterations; ++i) {
-#pragma unroll
+DSH_UNROLL_N
               for (int q = 0; q < N; ++q) x[q] = (-alpha) * delta0[q] + 1.0 * x[q];
               fun(x, delta);
               if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) { fatal = true; break; }
@@ -307,7 +307,7 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
               }
               if (alpha < min_alpha) { fatal = true; break; }  // LinesearchFailedMinStep
               alpha *= o.ic_step_reduction_factor;
-#pragma unroll
+DSH_UNROLL_N
               for (int q = 0; q < N; ++q) x[q] = x0[q];
             }
             if (!found) fatal = true;  // incl. LinesearchFailedMaxIterations
@@ -319,12 +319,12 @@ __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl:
       }
       if (result == 0) { ok = true; break; }
       if (result != 2) return false;  // anything but NewtonMaxIterations is fatal (state.rs:131-140)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) yerr[i] = x[i];
     }
     if (!ok) return false;
     // scatter_soln (:76-81) + zero the algebraic derivatives (state.rs:155-158)
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) {
       if (is_alg[i]) { y[i] = x[i]; dy[i] = 0.0; }
       else dy[i] = x[i];

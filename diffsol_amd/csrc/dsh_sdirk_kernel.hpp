@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
   const double rtol = C.rtol;
   double p[NP], atol[N];
   load_vec<NP>(p_g, nb, b, p);
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
   // banded models (Mdl::BAND_K, n up to 64): Jacobian band and banded LU factors in per-lane memory, see dsh_adaptive_kernel.hpp
   constexpr int BK = model_band_k<Mdl>::value;
@@ -65,10 +65,10 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
   double diff[S][N];
 #pragma unroll
   for (int j = 0; j < S; ++j)
-#pragma unroll
+DSH_UNROLL_N
     for (int i = 0; i < N; ++i) diff[j][i] = 0.0;
   double old_y[N], old_dy[N], old_t = t;  // old_state (its h is never read)
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) { old_y[i] = y[i]; old_dy[i] = dy[i]; }
   double g0[NR] = {0.0};
   double rf_t0 = t;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
   double op_h = h;
   const double op_c = T.gamma;
   double phi[N];
-#pragma unroll
+DSH_UNROLL_N
   for (int i = 0; i < N; ++i) phi[i] = 0.0;  // V::zeros until the first set_phi
   double A[BANDED ? 1 : N * N];
   int P[N];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
     if constexpr (BANDED) {
       if (jac_stale) {
         double tmp[N];
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) tmp[i] = op_c * xx[i] + 1.0 * phi[i];
         Mdl::jac_band(tt, tmp, p, Jb);
         jac_stale = false;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
     double J[N * N], Mm[N * N];
     if (jac_stale) {
       double tmp[N];
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) tmp[i] = op_c * xx[i] + 1.0 * phi[i];
       assemble_jacobian<Mdl>(tt, tmp, p, J);
 #pragma unroll
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         for (int q = 1; q < kMaxPoly; ++q) if (q < T.poly_order) acc = 1.0 * T.beta[q * S + i] * thetav[q] + acc;
         bf[i] = acc;
       }
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         double acc = 1.0 * diff[0][i] * bf[0] + 1.0 * old_y[i];
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         ret[i] = acc;
       }
     } else {  // interpolate_hermite (runge_kutta.rs:1016-1035)
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         double r = y[i] - old_y[i];
         r = (1.0 * (theta - 1.0)) * diff[0][i] + (1.0 - 2.0 * theta) * r;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
     double k[N];  // old_state.dy: the stage increment being solved for
     while (true) {
       if (skip_first) {
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) diff[0][i] = hh * dy[i];  // start_step_attempt (runge_kutta.rs:505-516)
       }
       bool failed = false;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         // ---- do_stage_sdirk (runge_kutta.rs:631-689)
         const double ts = t + T.c[i] * hh;
         // set_phi: phi = y0 + diff[:, 0..i] a_row_i   (nalgebra gemv order)
-#pragma unroll
+DSH_UNROLL_N
         for (int r = 0; r < N; ++r) {
           if (i == 0) phi[r] = y[r] * 1.0;
           else {
@@ -245,14 +245,14 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         }
         // predict_stage_sdirk (:610-629)
         if (i == 0) {
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) k[r] = hh * dy[r];
         } else if (i == 1) {
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) k[r] = diff[0][r];
         } else {
           const double cc = (T.c[i] - T.c[i - 2]) / (T.c[i - 1] - T.c[i - 2]);
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) k[r] = (-cc) * diff[i - 2][r] + (1.0 + cc) * diff[i - 1][r];
         }
         if (!is_jacobian_set) { reset_jacobian(y, ts); n_setups++; }  // Checkpoint
@@ -261,23 +261,23 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         bool solved = false;
         for (int it = 0; it < conv.max_iter; ++it) {
           double tmp[N], f[N], delta[N];
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) tmp[r] = op_c * k[r] + 1.0 * phi[r];
           Mdl::rhs(ts, tmp, p, f);
           const double beta = -op_h;
           if constexpr (Mdl::HAS_MASS) {
-#pragma unroll
+DSH_UNROLL_N
             for (int r = 0; r < N; ++r) delta[r] = f[r];
             Mdl::mass_gemv(ts, k, p, beta, delta);
           } else {
-#pragma unroll
+DSH_UNROLL_N
             for (int r = 0; r < N; ++r) delta[r] = 1.0 * k[r] + beta * f[r];
           }
           bool solved_ok;
           if constexpr (BANDED) solved_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
           else solved_ok = lu_solve_reg<N>(A, P, delta);
           if (!group_all<WAVE>(solved_ok)) break;  // LuSolveFailed
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) k[r] = k[r] - delta[r];
           const ConvStatus st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, y, atol, rtol))));
           if (st == ConvStatus::Converged) { solved = true; break; }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
         }
         n_newton += conv.niter;
         if (solved) {
-#pragma unroll
+DSH_UNROLL_N
           for (int r = 0; r < N; ++r) { old_y[r] = op_c * k[r] + 1.0 * phi[r]; diff[i][r] = k[r]; }  // get_f_eval; diff.column_mut(i)
         } else {
           if (!updated_jacobian) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
       if (failed) continue;
       // ---- error estimate (runge_kutta.rs:783-800, sdirk.rs:474-495): diff d, through the mass matrix and one LU solve
       double err[N];
-#pragma unroll
+DSH_UNROLL_N
       for (int r = 0; r < N; ++r) {
         double acc = 1.0 * diff[0][r] * T.d[0];
 #pragma unroll
@@ -318,14 +318,14 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
       if constexpr (Mdl::HAS_MASS) {
         double Mm[N * N], e2[N];
         assemble_mass<Mdl>(t, p, Mm);
-#pragma unroll
+DSH_UNROLL_N
         for (int r = 0; r < N; ++r) {
           double acc = 1.0 * Mm[0 * N + r] * err[0];
 #pragma unroll
           for (int j = 1; j < N; ++j) acc = 1.0 * Mm[j * N + r] * err[j] + acc;
           e2[r] = acc;
         }
-#pragma unroll
+DSH_UNROLL_N
         for (int r = 0; r < N; ++r) err[r] = e2[r];
       }
       bool err_ok;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
     // ---- step_accepted (runge_kutta.rs:894-960): old_state <- (f_eval of the last stage, k/h, t+h, new_h); swap
     {
       const double inv_h = 1.0 / hh;
-#pragma unroll
+DSH_UNROLL_N
       for (int r = 0; r < N; ++r) {
         const double ny = old_y[r], ndy = k[r] * inv_h;
         old_y[r] = y[r]; old_dy[r] = dy[r];
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
     while (col < C.n_eval && t_eval[col] <= upto) {
       double yv[N];
       interpolate(t_eval[col], yv);
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
       col++;
     }
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
       if (col < C.n_eval) {
         double yv[N];
         interpolate(t_root, yv);
-#pragma unroll
+DSH_UNROLL_N
         for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
         col++;
       }
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
   if (active) {
     if (ncols_out != nullptr) ncols_out[b] = col;
     for (; col < C.n_eval; ++col)  // columns that were never reached (root stop or error exit): NaN
-#pragma unroll
+DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
     if (status_out != nullptr) status_out[b] = status;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
