@@ -293,7 +293,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int twin = -1;  // a run-time-compiled model may carry its banded lane-per-member form: per-member BDF solves use it
     const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
     const bool lane_ok = !(lane_env && lane_env[0] == '0');
-    if (lane_ok && group == 1 && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(method, twin, 0)) {
+    if (lane_ok && (group == 1 || group == 64) && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(method, twin, 0)) {
       model = twin; size = 0;
     } else if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size)) {
       // run-time-sized models: one wavefront per member (BDF, identity mass, n <= 64)

@@ -264,6 +264,14 @@ def test_banded_models_also_get_the_lane_per_member_sdirk_integrators(H, O, fe, 
         assert failed == 0 and (mem["status"] == 0).all()
         assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
         assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+    # wavefront lock-step groups (the reference's batched semantics with nbatch = 64) on the same banded kernels
+    code = D.heat1d(12)
+    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    p = np.random.default_rng(4).uniform(0.5, 2.0, (150, 1))
+    s = H.Solver(m, p, nbatch=150, method=METHOD[method], **tol)
+    y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=64)
+    yo, so, failed = O.solve_dense_independent(mid, p, [0.01, 0.1], nthreads=4, group=64, method=METHOD[method], **tol)
+    assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
     # the built-in heat model takes the same route (DynLane<heat1d, 20, ...>)
     p = np.random.default_rng(3).uniform(0.5, 2.0, (20, 1))
     s = H.Solver("heat1d", p, nbatch=20, model_size=20, method=METHOD[method], **tol)
