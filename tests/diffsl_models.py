@@ -190,7 +190,7 @@ F_i {{
 _cache = {}
 
 
-def host_model(O, code):
+def host_model(O, code, opt="-O2"):
     """DiffSL text -> CPU model library (product front end, Target::HostC) -> compiled with g++ -> registered with the oracle.  Returns the oracle id."""
     key = hashlib.sha1(code.encode()).hexdigest()
     if key in _cache:
@@ -201,7 +201,7 @@ def host_model(O, code):
     cpp, so = os.path.join(d, "model.cpp"), os.path.join(d, "libmodel.so")
     with open(cpp, "w") as f:
         f.write(src)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-o", so, cpp], check=True)
+    subprocess.run(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-o", so, cpp], check=True)
     mid = O.load_external_model(so)
     assert O.model_dims(mid)["n"] == dims["n"]
     _cache[key] = mid

@@ -1,5 +1,7 @@
 """DiffSL front end (diffsol_amd/host/diffsl.hpp) on the CPU: the generated HOST model against the hand-written oracle models and against finite
 differences, the language rules, and that the generated DEVICE models compile for gfx950 with hiprtc (no GPU needed for any of this)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,3 +181,49 @@ def test_the_device_resident_kernel_families_of_the_diffsl_test_models_compile_w
         m = fe.DiffslModel(code)
         assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is not None
         assert L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0 and L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_SDIRK) == 0, L.dsh_last_error()
+
+
+REF_SPM = "/root/reference/book/src/primer/src/spm.ds"
+REF_DFN = "/root/reference/crates/diffsol/benches/pybamm_dfn.diffsl"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SPM), reason="the reference checkout is only present in the build container")
+def test_the_references_own_spm_ds_goes_through_the_front_end_and_equals_the_built_in_model(O, fe):
+    """book/src/primer/src/spm.ds read from the reference checkout at test time (not copied): same dimensions, structure, initial state, right-hand side,
+    J v and stop conditions as the built-in single-particle model, which was written from the same file."""
+    code = open(REF_SPM).read()
+    src, dims, defaults = fe.generate(code, fe.TARGET_HOST_C)
+    assert (dims["n"], dims["nparams"], dims["nroots"], dims["nout"], dims["has_mass"], dims["band"]) == (42, 1, 2, 1, False, (1, 1, 0, 0)) and defaults.tolist() == [1.0]
+    mid, ref = D.host_model(O, code), ORACLE_MODEL["spm"]
+    rng = np.random.default_rng(4)
+    for _ in range(4):
+        x = np.concatenate([rng.uniform(0, 1, 2), rng.uniform(0.2, 0.9, 20), rng.uniform(0.3, 0.95, 20)])
+        p, v = rng.uniform(0.6, 1.4, 1), rng.standard_normal(42)
+        a, b = O.model_rhs(mid, x, p), O.model_rhs(ref, x, p, 0.0, 20)
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(b).max())  # the file's Laplacian literals differ from the formula by <= 2 ulp
+        a, b = O.model_jac_mul(mid, x, p, v), O.model_jac_mul(ref, x, p, v, 0.0, 20)
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(b).max())
+        assert np.allclose(O.model_root(mid, x, p), O.model_root(ref, x, p, 0.0, 20), rtol=1e-12)
+    assert np.array_equal(O.model_init(mid, [1.0]), O.model_init(ref, [1.0], 0.0, 20))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DFN), reason="the reference checkout is only present in the build container")
+def test_the_references_dfn_benchmark_model_parses_and_differentiates(O, fe):
+    """crates/diffsol/benches/pybamm_dfn.diffsl (Doyle-Fuller-Newman battery model, 962 states, singular mass matrix, vector slices, no inputs): the front end
+    accepts it, and its forward-mode J v agrees with central differences of its own right-hand side."""
+    code = open(REF_DFN).read()
+    src, dims, _ = fe.generate(code, fe.TARGET_HOST_C)
+    assert dims["n"] == 962 and dims["has_mass"] and dims["nroots"] == 2 and dims["no_inputs"]
+    mid = D.host_model(O, code, opt="-O0")
+    y0 = O.model_init(mid, [0.0])
+    f0 = O.model_rhs(mid, y0, [0.0])
+    assert np.isfinite(y0).all() and np.isfinite(f0).all()
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(962) * np.maximum(np.abs(y0), 1e-3)
+    eps = 1e-7
+    fd = (O.model_rhs(mid, y0 + eps * v, [0.0]) - O.model_rhs(mid, y0 - eps * v, [0.0])) / (2 * eps)
+    jv = O.model_jac_mul(mid, y0, [0.0], v)
+    assert np.allclose(jv, fd, rtol=1e-4, atol=1e-6 * np.abs(fd).max())
+    # mass matrix: differential rows are 1, algebraic rows 0 (M_i is linear in dudt)
+    m = O.model_mass_gemv(mid, np.ones(962), [0.0], np.zeros(962), 0.0)
+    assert set(np.unique(m)) <= {0.0, 1.0} and 0 < m.sum() < 962
