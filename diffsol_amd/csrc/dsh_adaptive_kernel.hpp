@@ -260,8 +260,10 @@ DSH_UNROLL_N
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
         double f[N], delta[N], tmpv[N];
         Mdl::rhs(t_predict, x, p, f);
+        if constexpr (Mdl::HAS_MASS) {
 DSH_UNROLL_N
-        for (int i = 0; i < N; ++i) tmpv[i] = x[i] + psi[i];
+          for (int i = 0; i < N; ++i) tmpv[i] = x[i] + psi[i];
+        }
         // F(y) = M (y - y0 + psi) - c f(y)   (op/bdf.rs:240-256)
         if constexpr (Mdl::HAS_MASS) {
 DSH_UNROLL_N
@@ -269,16 +271,26 @@ DSH_UNROLL_N
           Mdl::mass_gemv(t_predict, tmpv, p, -opc, delta);
         } else {
 DSH_UNROLL_N
-          for (int i = 0; i < N; ++i) delta[i] = 1.0 * tmpv[i] + (-opc) * f[i];
+          for (int i = 0; i < N; ++i) delta[i] = 1.0 * (x[i] + psi[i]) + (-opc) * f[i];  // one pass: the sum is not stored (it matters when the vectors live in memory)
         }
         bool solved_ok;
         if constexpr (BANDED) solved_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
         else solved_ok = lu_solve_reg<N>(A, P, delta);
         const bool lu_ok = group_all<WAVE>(solved_ok);
         if (!lu_ok) break;  // LuSolveFailed
+        double delta_ms;  // Convergence::norm of the update (wms) fused with the update itself: one pass over the vectors
+        {
+          double acc = 0.0;
 DSH_UNROLL_N
-        for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
-        const double norm = sqrt(group_norm<WAVE>(wms<N>(delta, yp, atol, rtol)));
+          for (int i = 0; i < N; ++i) {
+            const double d = delta[i];
+            x[i] = x[i] - d;
+            const double term = d / (fabs(yp[i]) * rtol + atol[i]);
+            acc += term * term;
+          }
+          delta_ms = acc / (double)N;
+        }
+        const double norm = sqrt(group_norm<WAVE>(delta_ms));
         // Convergence::check_new_iteration (convergence.rs:68-139)
         niter += 1;
         bool diverged = false;
