@@ -13,6 +13,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -133,7 +134,8 @@ bool cache_load(const std::string& path, const std::vector<std::string>& group, 
   return ok;
 }
 void cache_store(const std::string& dir, const std::string& path, const std::vector<std::string>& group, const JitModule& m) {
-  (void)!system(("mkdir -p '" + dir + "'").c_str());
+  std::error_code ec;
+  std::filesystem::create_directories(dir, ec);
   const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;

@@ -3,6 +3,7 @@
 // for the parameter sets it was handed, like OdeWrapper::solve does in the reference (crates/diffsol-c/src/ode.rs:457-499, solve.rs).
 #include "../../include/diffsol_c_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -46,7 +47,7 @@ struct diffsol_ode_solver_options { std::shared_ptr<Settings> s; };
 struct diffsol_ic_solver_options { std::shared_ptr<Settings> s; };
 struct diffsol_ode_wrapper {
   std::string code;
-  int model = -1;
+  int model = -1, lane_model = -1;
   int64_t n = 0, np = 0, nroots = 0, nout = 0;
   bool has_mass = false, no_inputs = false;
   std::vector<double> defaults;
@@ -54,7 +55,10 @@ struct diffsol_ode_wrapper {
   double rtol = 1e-6, t0 = 0.0, h0 = 1.0;
   std::vector<double> atol{1e-6};
   std::shared_ptr<Settings> settings;
-  ~diffsol_ode_wrapper() { if (model >= 0) dsh_model_release(model); }
+  ~diffsol_ode_wrapper() {
+    if (model >= 0) dsh_model_release(model);
+    if (lane_model >= 0) dsh_model_release(lane_model);
+  }
 };
 struct diffsol_solution_wrapper {
   int64_t nrows = 0, ncols = 0, nb = 1;
@@ -125,6 +129,10 @@ int32_t apply_out(const OdeWrapper* ode, int64_t nb, const std::vector<double>& 
       check(dsh_h2d(ctx.raw(), x.ptr(), ys.data() + c * in_col, (int64_t)(in_col * sizeof(double))), "h2d");
       check(dsh_model_out(ctx.raw(), ode->model, 0, nb, ts[c], x.ptr(), p.ptr(), g.ptr()), "out");
       check(dsh_d2h(ctx.raw(), out.data() + c * out_col, g.ptr(), (int64_t)(out_col * sizeof(double))), "d2h");
+      // columns past a member's own stop hold NaN states: so do its outputs (min / max in an out_i expression would turn NaN into a number)
+      for (int64_t b = 0; b < nb; ++b)
+        if (std::isnan(ys[c * in_col + (size_t)b]))
+          for (int64_t k = 0; k < ode->nout; ++k) out[c * out_col + (size_t)(k * nb + b)] = std::numeric_limits<double>::quiet_NaN();
     }
     ys.swap(out);
   } catch (const std::exception& e) {
@@ -278,6 +286,13 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
   ode->model = id;
   dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
+  // banded run-time-sized model: the same text once more in the lane-per-member form, which per-member / wavefront device-resident solves run on
+  if (!is_static && ode->n <= 64 && !ode->has_mass && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4 &&
+      dshs_diffsl_generate(code, DSHS_DIFFSL_HIP_STATIC, &src, nullptr, nullptr, 0) == 0) {
+    int lane = -1;
+    if (dsh_model_compile(src, DSH_JIT_FORM_STATIC_BANDED, ode->n, ode->np, ode->nroots, ode->nout, 0, &lane) == 0 && dsh_model_set_twin(id, lane) == 0) ode->lane_model = lane;
+    dshs_free_string(src);
+  }
   return ode.release();
 }
 void diffsol_ode_free(OdeWrapper* ode) {

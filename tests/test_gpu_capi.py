@@ -133,3 +133,22 @@ def test_a_plain_c_program_against_the_header_compiles_and_runs(tmp_path):
                     "-ldiffsol_hip", f"-Wl,-rpath,{lib}", "-lm", "-o", exe], check=True)
     out = subprocess.run([exe, "5000"], check=True, capture_output=True, text=True).stdout
     assert "single solve" in out and "ensemble of 5000 members" in out
+
+
+def test_banded_diffsl_models_run_their_lane_per_member_form_through_the_c_api(capi, O, det_pow):
+    """A 12-state battery model through diffsol_ode_new_jit: per-member solve_dense with voltage cut-offs, the banded lane-per-member kernel behind it."""
+    nb = 50
+    cur = np.linspace(0.6, 1.4, nb)
+    ode = capi.Ode(D.spm(5, voltage=True))
+    ode.ensemble_mode = capi.ENSEMBLE_PER_MEMBER
+    t_eval = [600.0, 3000.0, 9000.0, 20000.0]
+    sol = ode.solve_dense(cur, t_eval)
+    ys, info = sol.ys, sol.member_info()
+    mid = D.host_model(O, D.spm(5, voltage=True))
+    yo, so, failed = O.solve_dense_independent(mid, cur[:, None], t_eval, nthreads=8, group=1, method=0, rtol=1e-6, atol=[1e-6])
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and (info["status"] == 0).all() and ys.shape == (1, 4, nb)  # out_i { volt }
+    assert np.array_equal(info["t_root"], ref["t_root"], equal_nan=True) and np.array_equal(info["ncols"], ref["ncols"]) and (info["root_index"] >= 0).any()
+    b = int(np.argmax(info["root_index"] >= 0))
+    c = info["ncols"][b] - 1  # the column holding the state at the member's own cut-off: the voltage there is the cut-off voltage
+    assert abs(ys[0, c, b] - (3.105 if info["root_index"][b] == 0 else 4.1)) < 1e-6 and np.isnan(ys[0, c + 1:, b]).all()
