@@ -94,6 +94,7 @@ DEVICE_ABI = {
     "dsh_model_mass_gemv": (cint, [vp, cint, i64, i64, dbl, vp, vp, dbl, vp]),
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
+    "dsh_lu_solve_multi": (cint, [vp, vp, i64]),
     "dsh_lu_set_structure": (cint, [vp, cint]),
     "dsh_lu_band_width": (cint, [vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),

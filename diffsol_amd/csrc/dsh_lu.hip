@@ -56,6 +56,28 @@ __global__ void k_lu_solve_reg(int64_t nb, const double* __restrict__ factors, c
   block_publish(0ull, 0ull, bad, rec, seq);
 }
 
+// several right-hand sides per system with the factors loaded once (forward-sensitivity columns: Bdf::sensitivity_solve, bdf.rs:934-989, solves one
+// system per parameter with the SAME LU): column r of system b at rhs[(r*n + i)*nb + b], i.e. an n x nrhs matrix in the library's matrix layout
+template <int N>
+__global__ void k_lu_solve_multi_reg(int64_t nb, int64_t nrhs, const double* __restrict__ factors, const int32_t* __restrict__ piv, double* __restrict__ rhs,
+                                     unsigned long long* rec, unsigned int seq) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long bad = 0ull;
+  if (b < nb) {
+    double A[N * N];
+    int P[N];
+    load_mat<N>(factors, nb, b, A);
+    load_piv<N>(piv, nb, b, P);
+    for (int64_t r = 0; r < nrhs; ++r) {
+      double v[N];
+      load_vec<N>(rhs + r * N * nb, nb, b, v);
+      if (!lu_solve_reg<N>(A, P, v)) bad = 1ull;
+      store_vec<N>(rhs + r * N * nb, nb, b, v);
+    }
+  }
+  block_publish(0ull, 0ull, bad, rec, seq);
+}
+
 }  // namespace
 
 extern "C" {
@@ -291,6 +313,40 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   if (rc != DSH_OK) return rc;
   if (ctx->res_cnt != 0ull) {
     set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+    return DSH_E_SINGULAR;
+  }
+  return DSH_OK;
+}
+
+int dsh_lu_solve_multi(const dsh_lu* lu, double* rhs, int64_t nrhs) {
+  DSH_REQUIRE(lu != nullptr && nrhs >= 0, "bad arguments");
+  if (!lu->factored) { set_error("dsh_lu_solve_multi: LU not initialised"); return DSH_E_NOT_SETUP; }
+  const int64_t n = lu->n, nb = lu->nbatch;
+  if (n == 0 || nrhs == 0) return DSH_OK;
+  if (n > 8) {  // wavefront / workgroup / banded kernels: one solve launch per column (each reads the factors once anyway)
+    for (int64_t r = 0; r < nrhs; ++r) {
+      int rc = dsh_lu_solve(lu, rhs + r * n * nb);
+      if (rc != DSH_OK) return rc;
+    }
+    return DSH_OK;
+  }
+  dsh_ctx* ctx = lu->ctx;
+  unsigned long long* rec; unsigned int seq;
+  dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
+  if (rc != DSH_OK) return rc;
+#define DSH_LU_MULTI_CASE(N) \
+  case N: hipLaunchKernelGGL((k_lu_solve_multi_reg<N>), g, blk, 0, ctx->stream, nb, nrhs, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+  switch (n) {
+    DSH_LU_MULTI_CASE(1) DSH_LU_MULTI_CASE(2) DSH_LU_MULTI_CASE(3) DSH_LU_MULTI_CASE(4)
+    DSH_LU_MULTI_CASE(5) DSH_LU_MULTI_CASE(6) DSH_LU_MULTI_CASE(7) DSH_LU_MULTI_CASE(8)
+  }
+#undef DSH_LU_MULTI_CASE
+  DSH_HIP_CHECK(hipGetLastError());
+  rc = fetch_records(ctx, g.x, seq);
+  if (rc != DSH_OK) return rc;
+  if (ctx->res_cnt != 0ull) {
+    set_error("dsh_lu_solve_multi: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
     return DSH_E_SINGULAR;
   }
   return DSH_OK;

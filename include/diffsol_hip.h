@@ -164,6 +164,10 @@ void dsh_lu_destroy(dsh_lu* lu);
 int dsh_lu_factor(dsh_lu* lu, const double* a);
 /* solve_in_place, nrhs = 1, all systems in ONE launch (replaces the getrs host loop, lu.rs:127-145) */
 int dsh_lu_solve(const dsh_lu* lu, double* b);
+/* nrhs right-hand sides per system with the same factors (the linear algebra of forward sensitivities: Bdf::sensitivity_solve, bdf.rs:934-989, solves one
+ * system per parameter with the LU of the state equations): b is an n x nrhs matrix in the library's layout, column r at b + r*n*nbatch.  For n <= 8 one launch
+ * loads the factors once for all columns; every column's solution equals dsh_lu_solve's bit for bit. */
+int dsh_lu_solve_multi(const dsh_lu* lu, double* b, int64_t nrhs);
 /* number of systems whose factorisation met an exactly-zero pivot (cusolver `info`, ignored by the reference lu.rs:83-95); blocking */
 int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular);
 /* raw device pointers of the factor storage: batch-fastest for n <= 8, system-major for n > 8 (dsh_lu_system_major) */

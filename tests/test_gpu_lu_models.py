@@ -355,3 +355,22 @@ def test_declared_band_assembly_and_factorisation_touch_only_the_band_and_give_t
     for model, size, expect in [("heat1d", 64, (1, 1, 0, 0)), ("spm", 20, (1, 1, 0, 0)), ("robertson_ode", 4, (2, 2, 0, 0)), ("gaussian_decay", 10, (0, 0, 0, 0)), ("rlc", 0, (-1, -1, -1, -1))]:
         out = [C.c_int() for _ in range(4)]
         assert L.dsh_model_band(H.MODELS[model], size, *[C.byref(o) for o in out]) == 0 and tuple(o.value for o in out) == expect
+
+
+@pytest.mark.parametrize("n,nrhs", [(3, 5), (8, 3), (42, 4), (100, 2)])
+def test_lu_solve_with_several_right_hand_sides_equals_separate_solves_bitwise(H, O, ctx1, n, nrhs):
+    """dsh_lu_solve_multi: the factors serve nrhs columns per system (forward-sensitivity solves); same bits as one dsh_lu_solve per column and as the oracle."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb = 70
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(n * nrhs)
+    a = rng.standard_normal((nb, n, n)) + 3.0 * np.eye(n)
+    rhs = rng.standard_normal((nb, n, nrhs))
+    lu = H.HipLU(c, n)
+    lu.factor(H.HipMat.from_array(a, c))
+    B = H.HipMat.from_array(rhs, c)
+    assert L.dsh_lu_solve_multi(lu._h, B.ptr, nrhs) == 0
+    got = B.to_array()
+    for r in range(nrhs):
+        assert np.array_equal(got[:, :, r], O.lu_solve(a, rhs[:, :, r])[0])
