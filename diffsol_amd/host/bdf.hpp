@@ -117,6 +117,13 @@ class Bdf : public OdeSolverMethod {
     maximum_timestep_shrink_ = o.max_timestep_shrink.value_or(0.9);
     minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
     fused_ = problem.use_fused_kernels && problem.eqn->fused_model(&model_, &model_size_);
+    // Run-time-sized models have no fused Newton kernel, but the difference-array kernels (rescale, predict, accept + order-selection norms) are model
+    // independent: with enough members to fill the chip with one lane per system they replace ~20 vector launches per step (same bits, tested against
+    // the trait composition).  DSH_FUSE_LA=0 keeps the 1:1 trait operations.
+    {
+      const char* e = std::getenv("DSH_FUSE_LA");
+      fused_la_ = problem.use_fused_kernels && !fused_ && problem.context().nbatch() >= 8192 && !(e && e[0] == '0');
+    }
 
     StateCommon sc = new_and_consistent(problem, 1);
     y_ = sc.y; dy_ = sc.dy; t_ = sc.t; h_ = sc.h;
@@ -206,7 +213,8 @@ class Bdf : public OdeSolverMethod {
       NlError solve_result = fused_ ? newton_fused(fused_err_sq)
                                     : nonlinear_solver_.solve_in_place(op_, y_delta_, t_predict_, y_predict_, convergence_, line_search_);
       statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
-      if (solve_result == NlError::Ok && !fused_) y_delta_.sub_assign(y_predict_);  // fused mode keeps y_new; d is formed in-kernel
+      if (solve_result == NlError::Ok && fused_la_) { d_tmp_.copy_from(y_delta_); d_tmp_.sub_assign(y_predict_); }  // y_delta_ keeps y_new for the accept kernel
+      else if (solve_result == NlError::Ok && !fused_) y_delta_.sub_assign(y_predict_);  // fused mode keeps y_new; d is formed in-kernel
       if (solve_result != NlError::Ok) {
         statistics_.number_of_nonlinear_solver_fails += 1;
         if (statistics_.number_of_nonlinear_solver_fails > maximum_newton_fails_) throw DSH_ODE_ERR(TooManyNonlinearSolverFailures);
@@ -223,7 +231,7 @@ class Bdf : public OdeSolverMethod {
         continue;
       }
       // error_control (bdf.rs:826-835): squared norm of d weighted by the OLD state, times error_const2[order-1]
-      double err_sq = fused_ ? fused_err_sq : y_delta_.squared_norm(y_, pr_.atol, pr_.rtol);
+      double err_sq = fused_ ? fused_err_sq : (fused_la_ ? d_tmp_.squared_norm(y_, pr_.atol, pr_.rtol) : y_delta_.squared_norm(y_, pr_.atol, pr_.rtol));
       error_norm = std::fmax(0.0, err_sq * error_const2_[(size_t)order_ - 1]);
       double maxiter = (double)convergence_.max_iter(), niter = (double)convergence_.niter();
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
@@ -277,6 +285,19 @@ class Bdf : public OdeSolverMethod {
         sel_norms[0] = r[0];
         sel_norms[1] = r[1];
       }
+    } else if (fused_la_) {
+      int64_t accept_ticket = 0;
+      check(dsh_bdf_accept_step_async(ctx().raw(), n(), nb(), order_, h_, diff_.ptr(), y_predict_.ptr(), y_delta_.ptr(), y_.ptr(), dy_.ptr(), pr_.atol.ptr(), pr_.atol.nb(),
+                                      pr_.rtol, gamma_.data(), alpha_[(size_t)order_], op_.psi_neg_y0().ptr(), &accept_ticket),
+            "dsh_bdf_accept_step_async");
+      t_ = t_predict_;
+      prediction_valid_ = true;  // y_predict / psi now hold the next step's prediction for (order_, h_)
+      if (will_select_order) {
+        double r[3];
+        check(dsh_reduction_wait(ctx().raw(), accept_ticket, r), "dsh_reduction_wait(accept)");
+        sel_norms[0] = r[0];
+        sel_norms[1] = r[1];
+      }
     } else {
       update_diff(order_, y_delta_);
       y_.copy_from(y_predict_);
@@ -293,8 +314,8 @@ class Bdf : public OdeSolverMethod {
       const int order = order_;
       const double inf = std::numeric_limits<double>::infinity();
       double error_m_norm = inf, error_p_norm = inf;
-      if (order > 1) error_m_norm = std::fmax(0.0, (fused_ ? sel_norms[0] : diff_.column(order).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order - 1]);
-      if (order < MAX_ORDER) error_p_norm = std::fmax(0.0, (fused_ ? sel_norms[1] : diff_.column(order + 2).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order + 1]);
+      if (order > 1) error_m_norm = std::fmax(0.0, ((fused_ || fused_la_) ? sel_norms[0] : diff_.column(order).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order - 1]);
+      if (order < MAX_ORDER) error_p_norm = std::fmax(0.0, ((fused_ || fused_la_) ? sel_norms[1] : diff_.column(order + 2).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order + 1]);
       const double pi_i = pr_.ode_options.pi_control_integral, pi_p = pr_.ode_options.pi_control_proportional;
       const double factors[3] = {pi_controller_raw(error_m_norm, prev_error_norm_, pi_i, pi_p, order), pi_controller_raw(error_norm, prev_error_norm_, pi_i, pi_p, order + 1),
                                  pi_controller_raw(error_p_norm, prev_error_norm_, pi_i, pi_p, order + 2)};
@@ -436,7 +457,7 @@ class Bdf : public OdeSolverMethod {
     std::vector<double> r = compute_r(order, factor);
     std::vector<double> ru = mat_mul_small(r, u_, order + 1);
     // D[:,0..=order] <- D[:,0..=order] * RU into diff_tmp, then swap(diff, diff_tmp) — including the reference's stale-column quirk
-    if (fused_) {
+    if (fused_ || fused_la_) {
       check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order, diff_.ptr(), diff_tmp_.ptr(), ru.data(), gamma_.data(), alpha_[(size_t)order], nullptr, nullptr),
             "dsh_bdf_prepare_step(rescale)");
     } else {
@@ -460,9 +481,9 @@ class Bdf : public OdeSolverMethod {
   }
 
   void predict_forward() {  // bdf.rs:674-692
-    if (fused_ && prediction_valid_) {
+    if ((fused_ || fused_la_) && prediction_valid_) {
       prediction_valid_ = false;  // produced by the accept launch of the previous step (same D, order and h => same bits)
-    } else if (fused_) {
+    } else if (fused_ || fused_la_) {
       DSH_PROF(prepare, check(dsh_bdf_prepare_step(ctx().raw(), n(), nb(), order_, diff_.ptr(), diff_tmp_.ptr(), nullptr, gamma_.data(), alpha_[(size_t)order_], y_predict_.ptr(),
                                  op_.psi_neg_y0().ptr()), "dsh_bdf_prepare_step"));
     } else {
@@ -579,6 +600,7 @@ class Bdf : public OdeSolverMethod {
   int maximum_error_test_failures_, maximum_newton_fails_;
   std::optional<double> prev_error_norm_;
   bool fused_ = false;
+  bool fused_la_ = false;  // model-independent difference-array kernels for run-time-sized models (large ensembles)
   bool prediction_valid_ = false;
   int model_ = -1;
   int64_t model_size_ = 0;

@@ -298,3 +298,25 @@ def test_after_a_root_stop_the_state_sits_at_the_root_with_interpolated_y_and_dy
     st = s.state()
     assert st["t"] == t_root and np.array_equal(st["y"], o.interpolate(t_root)) and np.array_equal(st["dy"], o.interpolate_dy(t_root))
     assert np.allclose(st["dy"], -0.1 * st["y"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("model,size,times", [("spm", 5, [30.0, 200.0]), ("heat1d", 16, [0.005, 0.03]), ("robertson_ode", 3, [0.4, 4.0, 40.0])])
+def test_large_ensembles_of_run_time_sized_models_use_the_difference_array_kernels_with_the_same_bits(H, O, monkeypatch, model, size, times):
+    """nbatch >= 8192, no fused Newton kernel: Bdf still runs rescale / predict / accept + order-selection norms as single launches (one lane per
+    system).  Same states and counters as the oracle's lock-step run and as the 1:1 trait composition (DSH_FUSE_LA=0)."""
+    nb = 8192
+    rng = np.random.default_rng(11)
+    if model == "robertson_ode":
+        p, tol = robertson_params(nb, seed=11), dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
+    else:
+        p, tol = rng.uniform(0.6, 0.9, (nb, 1)), dict(rtol=1e-6, atol=[1e-6])  # (battery: well before any member's voltage cut-off)
+    s = H.Solver(model, p, nbatch=nb, model_size=size, **tol)
+    assert not s.fused
+    y, _ = s.solve_to_points(times)
+    o = O.OracleSolver(ORACLE_MODEL[model], p, nbatch=nb, model_size=size, **tol)
+    yo, _ = o.solve_to_points(times)
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    monkeypatch.setenv("DSH_FUSE_LA", "0")
+    s0 = H.Solver(model, p, nbatch=nb, model_size=size, **tol)
+    y0, _ = s0.solve_to_points(times)
+    assert np.array_equal(y0, y) and s0.stats() == s.stats()
