@@ -166,7 +166,7 @@ if __name__ == "__main__":
         out.append(run_spm_resident(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "spm", "spm_lane"):
         out.append(run_spm_lane(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
-    if a.only in ("", "spm"):
+    if a.only in ("", "spm", "spm_host"):
         out.append(run_spm(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "heat"):
         out.append(run_heat(a.heat_nb, a.heat_n)); print(json.dumps(out[-1]), flush=True)
