@@ -229,41 +229,13 @@ def test_the_references_dfn_benchmark_model_parses_and_differentiates(O, fe):
     assert set(np.unique(m)) <= {0.0, 1.0} and 0 < m.sum() < 962
 
 
-def _random_expr(rng, depth, names):
-    """(DiffSL text, python callable on a dict of values) of a random expression that stays smooth and finite for positive inputs."""
-    if depth == 0 or rng.random() < 0.25:
-        if rng.random() < 0.3:
-            c = float(np.round(rng.uniform(0.2, 3.0), 3))
-            return repr(c), (lambda env, c=c: c)
-        nm = names[int(rng.integers(len(names)))]
-        return nm, (lambda env, nm=nm: env[nm])
-    kind = rng.choice(["+", "-", "*", "/", "neg", "f1", "f2"])
-    a_s, a_f = _random_expr(rng, depth - 1, names)
-    if kind in "+-*/":
-        b_s, b_f = _random_expr(rng, depth - 1, names)
-        if kind == "/":  # keep the denominator away from zero
-            return f"({a_s} / (1.5 + abs({b_s})))", (lambda env: a_f(env) / (1.5 + abs(b_f(env))))
-        op = {"+": np.add, "-": np.subtract, "*": np.multiply}[kind]
-        return f"({a_s} {kind} {b_s})", (lambda env: op(a_f(env), b_f(env)))
-    if kind == "neg":
-        return f"(-{a_s})", (lambda env: -a_f(env))
-    if kind == "f1":
-        name, fn, wrap = [("sin", np.sin, "{}"), ("cos", np.cos, "{}"), ("tanh", np.tanh, "{}"), ("exp", np.exp, "0.1 * {}"), ("sqrt", np.sqrt, "1.0 + abs({})"),
-                          ("log", np.log, "1.0 + abs({})"), ("arcsinh", np.arcsinh, "{}"), ("sigmoid", lambda v: 1.0 / (1.0 + np.exp(-v)), "{}")][int(rng.integers(8))]
-        inner = {"{}": a_f, "0.1 * {}": (lambda env: 0.1 * a_f(env)), "1.0 + abs({})": (lambda env: 1.0 + abs(a_f(env)))}[wrap]
-        return f"{name}({wrap.format(a_s)})", (lambda env: fn(inner(env)))
-    b_s, b_f = _random_expr(rng, depth - 1, names)
-    name, fn = [("min", min), ("max", max)][int(rng.integers(2))]
-    return f"{name}({a_s}, {b_s})", (lambda env: fn(a_f(env), b_f(env)))
-
-
 def test_random_models_evaluate_like_numpy_and_differentiate_like_finite_differences(O, fe):
     """Differential test of the front end: 25 random three-state models (every operator, eight functions, min / max, nesting depth 4) — the generated host code
     must reproduce a direct Python evaluation of the same expressions to rounding, and its forward-mode J v central differences of its own right-hand side."""
     rng = np.random.default_rng(2024)
     names = ["x", "y", "z", "a", "b", "t"]
     for k in range(25):
-        exprs = [_random_expr(rng, 4, names) for _ in range(3)]
+        exprs = [D.random_expr(rng, 4, names) for _ in range(3)]
         code = "in = [a, b]\na { 1 } b { 1 }\nu_i { x = 0.4, y = 0.9, z = 1.7 }\nF_i {\n" + ",\n".join(e[0] for e in exprs) + "\n}\n"
         mid = D.host_model(O, code, opt="-O1")
         xv, pv, t = rng.uniform(0.3, 2.0, 3), rng.uniform(0.5, 1.5, 2), float(rng.uniform(0.0, 1.0))
