@@ -312,7 +312,9 @@ int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
 /* ---- device-resident per-member adaptive BDF: the whole ensemble solve in ONE launch, one lane per member, each with its own
  * step-size / order history — the semantics of diffsol's CPU path for a parameter sweep (one independent IVP per member), i.e. of
  * Bdf::step (ode_solver/bdf.rs:1277-1589) + NewtonNonlinearSolver (diffsol-nl/src/newton.rs) + solve_dense (method.rs:467-520) per member.
- * Static models with n <= 4 (dsh_model_has_adaptive), mass matrices (consistent initialisation on the device) and root functions included. */
+ * Static models with n <= 4 (dsh_model_has_adaptive), mass matrices (consistent initialisation on the device) and root functions included; and run-time-compiled
+ * models in the banded lane-per-member form (DSH_JIT_FORM_STATIC_BANDED, dsh_model_lane_twin: n <= 64, identity mass, Jacobian bandwidth <= 4), whose state lives in
+ * per-lane memory and whose LU is banded. */
 typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) + BdfConfig (config.rs:53-74) */
   int max_nonlinear_solver_iterations, max_error_test_failures, max_nonlinear_solver_failures;
   double nonlinear_solver_tolerance, min_timestep;
@@ -340,10 +342,10 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
                            int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* Device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): Sdirk::step (ode_solver/sdirk.rs:409-543) + Rk core (runge_kutta.rs) + consistent DAE initialisation
  * (state.rs:84-162) + RootFinder (nonlinear_solver/root.rs) + solve_dense (method.rs:467-520) per member, one launch per ensemble solve.  Static models with
- * n <= 4, mass matrices and root functions included (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds
+ * n <= 4, mass matrices and root functions included, and the banded lane-per-member form as above (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds
  * the state at the root (solve_dense's return), ncols[b] counts its valid columns, later columns are NaN.  t_root / root_idx / ncols (nb each) may be NULL.
  * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
-/* Device-resident BDF for run-time-sized registry models with n <= 64 (heat1d, SPM, ...): ONE WAVEFRONT per member, lane = state component, the LU of
+/* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
  * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).  Identity mass only.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
 int dsh_model_has_wave_member(int model, int64_t size);
