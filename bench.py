@@ -2,19 +2,27 @@
 """bench.py — BASELINE.json's metric on BASELINE.json's config, on N MI355X of one node.
 
 Workload (config.workload): configs[1] — a 100 000-member Robertson (n=3, fp64) parameter sweep per GPU, integrated with BDF from t=0 to
-4e5 by the lock-step ensemble solver (host-side step control, fused HIP kernels), interpolated output at 7 decades, trajectories gathered
-with one RCCL all-gather when N>1 (weak scaling: every rank owns its own 100 000 members; no collective inside the integration).
-One bench "step" = one whole ensemble solve (fresh `.bdf()` state -> t_final) with the parameters already resident in HBM.
+4e5, interpolated output at 7 decades, trajectories gathered with one RCCL all-gather when N>1 (weak scaling: every rank owns its own
+100 000 members; no collective inside the integration).  One bench "step" = one whole ensemble solve — `OdeSolverMethod::solve_dense`
+(method.rs:467-520) through the drop-in boundary `dshs_solve_dense` in its default ensemble mode, i.e. the device-resident integrator
+(one launch: state initialisation, initial step size, first Jacobian, every BDF step, interpolation) with the parameters resident in HBM.
+
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run, RCCL) when it is not already running under a launcher.
 
 Prints ONE JSON line: metric = accepted ODE steps/s summed over the ensemble (newton_solves_per_sec alongside), plus
-  roofline     — the dominant kernel (fused Newton iteration): algorithmic bytes per launch / mean launch duration measured live with
-                 HIP events on the solver's stream during the timed region; HBM traffic from the committed rocprofv3 PMC summary if present
-  cpu_baseline — the CPU oracle (restatement of the reference's algorithm, one independent IVP per solve like diffsol's CPU path) timed
-                 on this box's host cores over a bounded sample of the same sweep (rank 0, N=1 only).
+  roofline     — the dominant (only) kernel of the timed region, k_bdf_adaptive: bound by VALU issue (state in registers, no HBM traffic besides
+                 parameters in / save points out).  achieved = VALU lane-operations per launch (SQ_INSTS_VALU x 64, counters in profiles/) /
+                 launch duration measured live with HIP events on the solver's stream; peak = 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz.
+  cpu_baseline — the CPU oracle (restatement of the reference's algorithm, one independent IVP per solve like diffsol's CPU path) timed on
+                 this box's host cores over a bounded sample of the same sweep (rank 0, N=1 only): all cores, one core, and the
+                 reference's published single-solve time beside them.
+Extra keys (not `value`): the same job host-driven over the trait operations (lock-step over the whole ensemble), per-member control,
+and a 1.6M-member ensemble that fills the chip.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,10 +35,15 @@ if ROOT not in sys.path:
 NB_PER_GPU = 100_000
 T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]  # 0.4 ... 4e5
 RTOL, ATOL = 1e-4, [1e-8, 1e-14, 1e-6]
-# Algorithmic bytes of one fused Newton launch per system, n=3, np=3: reads 8n^2+4n (LU+piv) + 8(4n+np) (y, psi-y0, y_predict, y_old, p) = 204 B,
-# writes 8n per iteration it performs; NIT=1 gives SURVEY §8(d)'s 228 B "fused Newton iteration".
+N_STATES, N_PARAMS = 3, 3
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz — a wavefront's VALU instruction issues over 2 cycles (32 lanes/clk), an FP64 one over 4
+# (78.6 TFLOP/s FP64 vector = 16 lanes/clk x 2 flop); HBM3E 8.0 TB/s spec.
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+HBM_PEAK_GBS = 8000.0
+PUBLISHED_SINGLE_SOLVE_S = 3.115e-05  # /root/reference book/src/benchmarks/python_results.csv:2 (robertson_ode n=3, BDF, rtol=atol=1e-4, EPYC 7343)
+# Host-driven fused Newton launch (extra key `host_lockstep`): reads 8n^2+4n (LU+piv) + 8(4n+np) = 204 B per member, writes 8n per iteration.
 NEWTON_READ_BYTES, NEWTON_WRITE_BYTES_PER_ITER = 204, 24
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def robertson_params(nb, seed=12345):
@@ -41,31 +54,83 @@ def robertson_params(nb, seed=12345):
 
 
 def cpu_baseline(params, sample):
+    """Reference algorithm on the host cores, one independent IVP per member (how diffsol's CPU path runs a sweep).  The timed code is
+    oracle/oracle_fast.hpp — the oracle's BDF with fixed-size stack arrays (no per-operation allocation, -O3), verified bit for bit against
+    the line-by-line restatement oracle_ode.hpp by tests/test_oracle_golden.py — on a bounded sample of the same sweep."""
     from oracle import oracle as O
     O.build()
     cores = os.cpu_count() or 1
     p = params[:sample]
-    r = O.solve_ensemble_independent(O.MODEL_ROBERTSON_ODE, p, model_size=1, rtol=RTOL, atol=ATOL, t_final=T_EVAL[-1], nthreads=cores, want_y=False)
-    return {
+    kw = dict(model_size=1, rtol=RTOL, atol=ATOL, t_final=T_EVAL[-1], want_y=False)
+    fast = hasattr(O, "solve_ensemble_independent_fast")
+    run = O.solve_ensemble_independent_fast if fast else O.solve_ensemble_independent
+    r = run(O.MODEL_ROBERTSON_ODE, p, nthreads=cores, **kw)
+    n1 = max(1, min(sample, 2000 if fast else 200))
+    r1 = run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
+    rec = {
         "value": r["steps"] / r["seconds"], "unit": "ODE steps/s", "cores": cores, "kind": "port",
         "newton_solves_per_sec": r["newton_iterations"] / r["seconds"], "seconds": r["seconds"],
         "sample": f"first {sample} members of the same Robertson sweep, one independent BDF solve per member to t={T_EVAL[-1]:g} "
-                  f"(oracle = C++ restatement of diffsol Bdf+NalgebraLU), {cores} std::threads, static partition",
+                  f"({'oracle_fast.hpp: stack-array build of the' if fast else ''} C++ restatement of diffsol Bdf+NalgebraLU), {cores} std::threads, static partition",
+        "single_core": {"value": r1["steps"] / r1["seconds"], "unit": "ODE steps/s", "cores": 1, "seconds_per_solve": r1["seconds"] / n1,
+                        "newton_solves_per_sec": r1["newton_iterations"] / r1["seconds"], "sample": f"first {n1} members, one thread"},
+        "reference_published": {"seconds_per_solve": PUBLISHED_SINGLE_SOLVE_S,
+                                "what": "diffsol BDF+nalgebra LU via pydiffsol, robertson_ode n=3, rtol=atol=1e-4, one EPYC 7343 core "
+                                        "(book/src/benchmarks/python_results.csv:2); t_final/output grid of that benchmark are defined outside the "
+                                        "reference tree, so the point is indicative, not the same job"},
     }
+    if fast:
+        rs = O.solve_ensemble_independent(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
+        rec["fidelity_build_single_core_seconds_per_solve"] = rs["seconds"] / n1
+    return rec
+
+
+class _CpuStub:
+    """TEST HOOK (--cpu-stub, used by tests/test_bench_cli.py): stands in for the HIP solver on a box without a GPU so that the argument /
+    launcher / aggregation path of this file can be exercised under gloo.  Never a measurement: the JSON line says data = "cpu-stub"."""
+    n = N_STATES
+
+    def __init__(self, p):
+        self.p = p
+        self.nbatch = p.shape[0]
+
+    def solve_dense_into(self, out):
+        t = np.asarray(T_EVAL)[:, None, None]
+        y = np.exp(-self.p.T[None, :, :] * 1e-9 * t)
+        out.copy_(__import__("torch").from_numpy(y))
+        return {"number_of_steps": 300 * self.nbatch, "number_of_nonlinear_solver_iterations": 700 * self.nbatch,
+                "number_of_linear_solver_setups": 70 * self.nbatch, "failed_members": 0}
+
+
+def _relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` outside a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--block", type=int, default=256, help="threads per workgroup of the one-lane-per-system kernels")
-    ap.add_argument("--nb", type=int, default=NB_PER_GPU)
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the Newton kernel with HIP events (measures their overhead)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nb", type=int, default=NB_PER_GPU, help="ensemble members per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-adaptive", action="store_true", help="skip the extra passes through the device-resident kernel")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (host-driven lock-step, per-member control, 1.6M members)")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--large-nb", type=int, default=1_600_000)
+    ap.add_argument("--cpu-stub", action="store_true", help="TEST HOOK: no GPU, gloo backend, stub solver (exercises launcher + aggregation only)")
     args = ap.parse_args()
+    assert args.gpus >= 1 and args.steps >= 1 and args.warmup >= 0
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_under_torchrun(args)  # does not return
 
     import torch
     import torch.distributed as dist
@@ -73,110 +138,154 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, (world, args.gpus)
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+    stub = args.cpu_stub
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    dev = "cpu" if stub else f"cuda:{local_rank}"
+    if not stub:
+        torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        dist.init_process_group("gloo" if stub else "nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    import diffsol_amd
     from diffsol_amd.dist import gather_batch_axis, shard_bounds
 
     nb = args.nb
     n_total = nb * world
     params = robertson_params(n_total)
     lo, hi = shard_bounds(n_total, rank, world)
-    solver = diffsol_amd.Solver("robertson_ode", params[lo:hi], nbatch=hi - lo, model_size=1, rtol=RTOL, atol=ATOL, device=local_rank,
-                                block_threads=args.block)
-    assert solver.fused, "fused HIP kernels not active"
-    out = torch.empty((len(T_EVAL), solver.n, hi - lo), dtype=torch.float64, device=f"cuda:{local_rank}")
+    out = torch.empty((len(T_EVAL), N_STATES, hi - lo), dtype=torch.float64, device=dev)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    def allreduce(vals, maxfirst=True):
+        """[time, counters...] -> max over ranks of the time, sum over ranks of the counters."""
+        a = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if world > 1:
+            tmax = a[:1].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(a, op=dist.ReduceOp.SUM)
+            a[0] = tmax[0]
+        return [float(v) for v in a.tolist()]
+
+    if stub:
+        solver = _CpuStub(params[lo:hi])
+        resolved = 64
+
+        def solve_once():
+            return solver.solve_dense_into(out)
+    else:
+        import diffsol_amd
+        from diffsol_amd.solver import ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT, ENSEMBLE_AUTO
+        solver = diffsol_amd.Solver("robertson_ode", params[lo:hi], nbatch=hi - lo, model_size=1, rtol=RTOL, atol=ATOL, device=local_rank, block_threads=256)
+        assert solver.fused, "fused HIP kernels not active"
+        _, resolved = solver.ensemble_mode()
+        assert resolved == ENSEMBLE_WAVEFRONT, f"solve_dense did not resolve to the device-resident integrator (mode {resolved})"
+
+        def solve_once():
+            solver.solve_dense(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
+            mode, tot = solver.last_solve_info()
+            assert mode == resolved
+            return tot
 
     def one_step():
-        solver.reset()
-        solver.solve_dense(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
-        st = solver.stats()
+        tot = solve_once()
         y = gather_batch_axis(out, n_total, rank, world) if world > 1 else out
-        return st, y
+        return tot, y
+
+    def timed(k, step):
+        barrier()
+        t0 = time.perf_counter()
+        acc = {}
+        for _ in range(k):
+            tot, y = step()
+            for key, v in tot.items():
+                acc[key] = acc.get(key, 0) + v
+        barrier()
+        return time.perf_counter() - t0, acc, y
 
     for _ in range(args.warmup):
         one_step()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    steps = newton = setups = 0
-    for _ in range(args.steps):
-        st, y = one_step()
-        steps += st["number_of_steps"]
-        newton += st["number_of_nonlinear_solver_iterations"]
-        setups += st["number_of_linear_solver_setups"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # Roofline pass: the same K solves again with every launch of the dominant kernel bracketed by HIP events on the solver's stream.
-    # Bracketed launches are synchronous (the events must complete), so this pass is NOT the one `value` is taken from.
-    launches, kernel_ms, events_elapsed, bracket_ms, clock_ms = 0, 0.0, 0.0, 0.0, 0.0
-    if not args.no_kernel_events:
-        solver.set_kernel_timing(True)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-        barrier()
-        events_elapsed = time.perf_counter() - t1
-        launches, kernel_ms = solver.kernel_timing()
-        bracket_ms, clock_ms = solver.kernel_timing_overhead_ms()
+    if not stub:
+        solver.set_kernel_timing(True)  # HIP events around the one launch of every solve (the launch is synchronous anyway: the counters come back)
+    elapsed, acc, y = timed(args.steps, one_step)
+    launches, kernel_ms = (0, 0.0) if stub else solver.kernel_timing()
+    bracket_ms = 0.0 if stub else solver.kernel_timing_overhead_ms()[0]
+    if not stub:
         solver.set_kernel_timing(False)
-
-    # Extra passes (not `value`): the same K solves through the device-resident kernel — one launch per ensemble solve, no host
-    # in the loop — in both control granularities: every member its own step-size/order history (diffsol's CPU semantics for a sweep), and
-    # wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64 per group).
-    def device_resident_pass(group):
-        solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr(), group=group)
-        barrier()
-        t2 = time.perf_counter()
-        a_steps = a_newton = 0
-        for _ in range(args.steps):
-            _, tot = solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr(), group=group)
-            if world > 1:
-                gather_batch_axis(out, n_total, rank, world)
-            a_steps += tot["number_of_steps"]
-            a_newton += tot["number_of_nonlinear_solver_iterations"]
-        barrier()
-        a_elapsed = time.perf_counter() - t2
-        a = torch.tensor([a_elapsed, a_steps, a_newton, tot["failed_members"]], dtype=torch.float64, device=f"cuda:{local_rank}")
-        if world > 1:
-            amax = a[:1].clone()
-            dist.all_reduce(amax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(a, op=dist.ReduceOp.SUM)
-            a[0] = amax[0]
-        a_el, a_st, a_nw, a_failed = (float(v) for v in a.tolist())
-        return {"ms_per_step": 1e3 * a_el / args.steps, "ode_steps_per_sec": a_st / a_el, "newton_solves_per_sec": a_nw / a_el,
-                "mean_steps_per_member": a_st / args.steps / n_total, "failed_members": int(a_failed)}
-
-    adaptive = None
-    if not args.no_adaptive:
-        adaptive = {"note": "dsh_bdf_solve_adaptive: one kernel launch per ensemble solve, solver state in registers/LDS, no host round trips; same job as "
-                            "`value` (same members, tolerances, save points); pow() = include/diffsol_detpow.h, i.e. results bit-identical to the CPU oracle",
-                    "per_member": device_resident_pass(1), "wavefront_lockstep_64": device_resident_pass(64)}
-
-    # whole-job aggregates: max time over ranks, units summed over ranks
-    agg = torch.tensor([elapsed, (hi - lo) * steps, (hi - lo) * newton, (hi - lo) * setups], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
-        tmax = agg[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        agg[0] = tmax[0]
-    elapsed_max, member_steps, member_newton, member_setups = (float(v) for v in agg.tolist())
-
+    elapsed_max, member_steps, member_newton, member_setups, failed = allreduce(
+        [elapsed, acc["number_of_steps"], acc["number_of_nonlinear_solver_iterations"], acc["number_of_linear_solver_setups"], acc["failed_members"]])
     finite = bool(torch.isfinite(y).all().item())
-    mass_err = float((y.sum(dim=1) - 1.0).abs().max().item())
+    mass_err = float((y.sum(dim=1) - 1.0).abs().max().item()) if not stub else 0.0
+
+    # ------------------------------------------------------------------ extra passes (never `value`)
+    extras = {}
+    if not stub and not args.no_extras:
+        k_x = min(args.steps, 5)
+
+        def mode_pass(mode, with_reset):
+            solver.set_ensemble_mode(mode)
+
+            def step():
+                if with_reset:
+                    solver.reset()  # host-driven: a fresh .bdf() state (the device-resident integrators initialise the state inside the launch)
+                return one_step()
+            step()
+            el, a, _ = timed(k_x, step)
+            solver.set_ensemble_mode(ENSEMBLE_AUTO)
+            el, st, nw, fl = allreduce([el, a["number_of_steps"], a["number_of_nonlinear_solver_iterations"], a["failed_members"]])
+            return {"ms_per_step": 1e3 * el / k_x, "ode_steps_per_sec": st / el, "newton_solves_per_sec": nw / el,
+                    "mean_steps_per_member": st / k_x / n_total, "failed_members": int(fl)}
+
+        extras["per_member"] = dict(mode_pass(ENSEMBLE_PER_MEMBER, False), note="every member its own step-size/order history (diffsol's CPU semantics for a sweep)")
+        hl = mode_pass(ENSEMBLE_LOCKSTEP, True)
+        hl["note"] = ("DSHS_ENSEMBLE_LOCKSTEP: host-driven, one (t, h, order) for all members over the trait-boundary operations (fused Newton / accept kernels); "
+                      "round 1's `value` path")
+        # its dominant kernel, the fused 3-iteration Newton launch, is HBM-bound: bracketed pass for its roofline (bracketed launches are synchronous)
+        solver.set_ensemble_mode(ENSEMBLE_LOCKSTEP)
+        solver.set_kernel_timing(True)
+        solver.reset(); one_step()
+        nl, nms = solver.kernel_timing()
+        solver.set_kernel_timing(False)
+        solver.set_ensemble_mode(ENSEMBLE_AUTO)
+        if nl > 0:
+            nit = int(os.environ.get("DSH_NEWTON_NIT", "3"))
+            bpl = (NEWTON_READ_BYTES + NEWTON_WRITE_BYTES_PER_ITER * nit) * (hi - lo)
+            hl["newton_kernel_roofline"] = {"bound": "hbm", "kernel": f"k_newton_iter<RobertsonOde1,...,NIT={nit}>", "algorithmic_bytes_per_launch": bpl,
+                                            "avg_launch_us": 1e3 * nms / nl, "achieved": bpl / (nms * 1e-3 / nl) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": bpl / (nms * 1e-3 / nl) / 1e9 / HBM_PEAK_GBS, "launches_timed": nl}
+        extras["host_lockstep"] = hl
+        # chip-filling ensemble: 25 000 wavefronts (2 per SIMD is the kernel's occupancy), same job per member
+        nbl = args.large_nb
+        pl = robertson_params(nbl * world, seed=54321)[rank * nbl:(rank + 1) * nbl]
+        big = diffsol_amd.Solver("robertson_ode", pl, nbatch=nbl, model_size=1, rtol=RTOL, atol=ATOL, device=local_rank, block_threads=256)
+        outl = torch.empty((len(T_EVAL), N_STATES, nbl), dtype=torch.float64, device=dev)
+
+        def big_step():
+            big.solve_dense(T_EVAL, want_host=False, dev_ptr=outl.data_ptr())
+            return big.last_solve_info()[1], outl
+        big_step()
+        big.set_kernel_timing(True)
+        el, a, yl = timed(2, big_step)
+        bl, bms = big.kernel_timing()
+        big.set_kernel_timing(False)
+        el, st, nw, fl = allreduce([el, a["number_of_steps"], a["number_of_nonlinear_solver_iterations"], a["failed_members"]])
+        extras["large_ensemble"] = {"members_per_gpu": nbl, "ms_per_step": 1e3 * el / 2, "ode_steps_per_sec": st / el, "newton_solves_per_sec": nw / el,
+                                    "kernel_ms": bms / max(bl, 1), "failed_members": int(fl), "finite": bool(torch.isfinite(yl).all().item()),
+                                    "hbm_algorithmic_gbs": 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * nbl / (bms * 1e-3 / max(bl, 1)) / 1e9,
+                                    "note": "same job per member on a chip-filling ensemble (wavefront lock-step groups of 64); the kernel stays VALU-issue bound — "
+                                            "its HBM traffic is parameters in + save points out"}
+        del big, outl
 
     if rank == 0:
         rec = {
@@ -185,48 +294,68 @@ def main():
             "unit": "accepted ODE steps/s summed over ensemble members",
             "newton_solves_per_sec": member_newton / elapsed_max,
             "lu_refactors_per_sec": member_setups / elapsed_max,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "cpu-stub (test hook: launcher/aggregation path only, not a measurement)" if stub else "synthetic",
             "config": {
                 "workload": "BASELINE.json configs[1]: Robertson stiff ODE (n=3, fp64) ensemble, 100k parameter-sweep members per GPU, BDF, "
                             "batched dense LU, t in [0, 4e5], rtol 1e-4, atol (1e-8,1e-14,1e-6), output at 7 decades",
-                "members_per_gpu": nb, "members_total": n_total, "t_final": T_EVAL[-1], "method": "bdf", "lockstep_steps_per_solve": steps / args.steps,
-                "newton_iterations_per_solve": newton / args.steps, "block_threads": args.block, "parallelism": f"ensemble-shard x{world}",
-                "newton_iterations_per_launch": int(os.environ.get("DSH_NEWTON_NIT", "3")),
+                "members_per_gpu": nb, "members_total": n_total, "t_final": T_EVAL[-1], "method": "bdf",
+                "path": "dshs_solve_dense, default ensemble mode -> device-resident BDF (dsh_bdf_solve_adaptive), wavefront lock-step groups of 64 members "
+                        "(the reference's batched semantics with nbatch = 64 per group)",
+                "ensemble_mode": resolved, "mean_steps_per_member": member_steps / args.steps / n_total,
+                "mean_newton_iterations_per_member": member_newton / args.steps / n_total, "parallelism": f"ensemble-shard x{world}",
+                "backend": "gloo" if stub else ("nccl" if world > 1 else "none"),
             },
-            "checks": {"finite": finite, "max_mass_conservation_error": mass_err},
+            "checks": {"finite": finite, "max_mass_conservation_error": mass_err, "failed_members": int(failed)},
         }
         if launches > 0:
-            nit = int(os.environ.get("DSH_NEWTON_NIT", "3"))
-            bytes_per_launch = (NEWTON_READ_BYTES + NEWTON_WRITE_BYTES_PER_ITER * nit) * (hi - lo)
-            # HIP-event bracket = kernel + part of the marker-packet processing (an EMPTY bracket measures `empty_bracket_us`); the in-kernel
-            # device clock (max workgroup end - min workgroup start) is the quantity rocprofv3's kernel trace reports.  `achieved` uses the
-            # raw HIP-event figure (conservative); both other figures are reported next to it.
             avg_s = kernel_ms * 1e-3 / launches
-            clock_avg_s = clock_ms * 1e-3 / launches
-            achieved = bytes_per_launch / avg_s / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_newton_iter.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            rec["roofline"] = {"bound": "hbm", "kernel": f"k_newton_iter<RobertsonOde1,...,NIT={nit}> (fused BDF Newton launch, {nit} iterations)", "achieved": achieved,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6, "empty_bracket_us": bracket_ms * 1e3,
-                               "avg_launch_us_device_clock": clock_avg_s * 1e6, "achieved_device_clock": bytes_per_launch / max(clock_avg_s, 1e-12) / 1e9,
-                               "frac_device_clock": bytes_per_launch / max(clock_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS, "launches_timed": launches,
-                               "measured": "HIP events on the solver stream, second pass over the same K solves (bracketed launches are synchronous)",
-                               "events_pass_ms_per_step": 1e3 * events_elapsed / args.steps}
+            pmc = {}
+            for name in ("r02_pmc_resident.json", "pmc_resident.json"):
+                path = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(path):
+                    try:
+                        pmc = json.load(open(path)).get("bench_kernel", {}) or {}
+                    except Exception:
+                        pmc = {}
+                    if pmc:
+                        pmc["file"] = "profiles/" + name
+                        break
+            algo_hbm = 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * (hi - lo)
+            roof = {"bound": "valu", "kernel": "dsh::k_bdf_adaptive<RobertsonOde1, BA=true, WAVE=true> (the whole ensemble solve, one launch)",
+                    "avg_launch_us": avg_s * 1e6, "launches_timed": launches, "empty_bracket_us": bracket_ms * 1e3,
+                    "measured": "HIP events on the solver stream around the launch of every timed solve (same pass as `value`)",
+                    "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                    "hbm": {"algorithmic_bytes_per_launch": algo_hbm, "achieved_gbs": algo_hbm / avg_s / 1e9, "frac_of_8TBs": algo_hbm / avg_s / 1e9 / HBM_PEAK_GBS,
+                            "note": "parameters in + save points out; the solver state never leaves registers/LDS, so HBM does not bound this kernel"}}
+            valu = pmc.get("valu_insts_per_launch") if nb == pmc.get("members", NB_PER_GPU) else None
+            if valu:
+                roof["achieved"] = valu * 64 / avg_s / 1e12
+                roof["frac"] = roof["achieved"] / VALU_PEAK_TLANEOPS
+                roof["valu_wave_instructions_per_launch"] = valu
+                f64 = pmc.get("f64_insts_per_launch")
+                if f64:  # issue-slot utilisation: an FP64 VALU instruction occupies the SIMD for 4 cycles, any other for 2
+                    roof["fp64_wave_instructions_per_launch"] = f64
+                    roof["issue_slot_frac"] = (4 * f64 + 2 * (valu - f64)) / (SIMD_CYCLES_PER_S * avg_s)
+                    roof["fp64_flop_per_launch"] = pmc.get("f64_flop_per_launch")
+                    if pmc.get("f64_flop_per_launch"):
+                        roof["fp64_tflops"] = pmc["f64_flop_per_launch"] / avg_s / 1e12
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["counters_from"] = pmc.get("file")
+            else:
+                roof.update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC summary for this ensemble size under profiles/"})
+            rec["roofline"] = roof
         else:
             rec["roofline"] = None
-        rec["device_resident"] = adaptive
-        if world == 1 and not args.no_cpu_baseline:
+        rec.update(extras)
+        if world == 1 and not args.no_cpu_baseline and not stub:
             rec["cpu_baseline"] = cpu_baseline(params, min(args.cpu_sample, n_total))
         print(json.dumps(rec))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -154,6 +154,10 @@ HOST_ABI = {
     "dshs_nstates": (i64, [vp]),
     "dshs_nbatch": (i64, [vp]),
     "dshs_is_fused": (cint, [vp]),
+    "dshs_set_ensemble_mode": (cint, [vp, cint]),
+    "dshs_set_deterministic_pow": (cint, [cint]),
+    "dshs_get_ensemble_mode": (cint, [vp, c_ip, c_ip]),
+    "dshs_last_solve_info": (cint, [vp, c_ip, c_i64p]),
     "dshs_step": (cint, [vp, c_ip]),
     "dshs_set_stop_time": (cint, [vp, dbl]),
     "dshs_interpolate": (cint, [vp, dbl, c_dp]),

@@ -12,7 +12,7 @@ LINEAR_SOLVER_DEFAULT, LINEAR_SOLVER_LU, LINEAR_SOLVER_KLU = 0, 1, 2
 ODE_SOLVER_BDF, ODE_SOLVER_ESDIRK34, ODE_SOLVER_TR_BDF2, ODE_SOLVER_TSIT45 = 0, 1, 2, 3
 SCALAR_F64 = 1
 JIT_HIPRTC = 2
-ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT = 0, 1, 64
+ENSEMBLE_AUTO, ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT = -1, 0, 1, 64
 
 _vp, _i32, _sz, _dbl, _dp = C.c_void_p, C.c_int32, C.c_size_t, C.c_double, C.POINTER(C.c_double)
 _ODE_OPTS = [("max_nonlinear_solver_iterations", _sz), ("max_error_test_failures", _sz), ("update_jacobian_after_steps", _sz), ("update_rhs_jacobian_after_steps", _sz),

@@ -132,6 +132,7 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   const bool ba = atol_nb == 1 && nb != 1;
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   bool launched = false;
+  DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
     const std::string name = std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
     rc = jit_launch(ctx, model, "dsh_adaptive_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
@@ -151,9 +152,11 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   });
   (void)launched;
   DSH_HIP_CHECK(hipGetLastError());
+  DSH_HIP_CHECK(timing_end(ctx));
   unsigned long long totals[8] = {0};
   DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  DSH_HIP_CHECK(timing_collect(ctx));
   dsh_free(ctx, t_eval_dev);
   dsh_free(ctx, totals_dev);
   dsh_free(ctx, consts_dev);

@@ -124,6 +124,22 @@ inline double bits_to_double(unsigned long long b) {
   return d;
 }
 
+// HIP-event bracket around ONE launch on the context's stream (dsh_ctx_set_timing): record before / after the launch, collect after the stream
+// has been synchronised.  Used by the device-resident integrators, whose single launch per ensemble solve is the whole timed region.
+inline hipError_t timing_begin(dsh_ctx* ctx) { return ctx->timing ? hipEventRecord(ctx->ev_start, ctx->stream) : hipSuccess; }
+inline hipError_t timing_end(dsh_ctx* ctx) { return ctx->timing ? hipEventRecord(ctx->ev_stop, ctx->stream) : hipSuccess; }
+inline hipError_t timing_collect(dsh_ctx* ctx) {
+  if (!ctx->timing) return hipSuccess;
+  hipError_t e = hipEventSynchronize(ctx->ev_stop);
+  if (e != hipSuccess) return e;
+  float ms = 0.f;
+  e = hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop);
+  if (e != hipSuccess) return e;
+  ctx->timed_ms += (double)ms;
+  ctx->timed_launches += 1;
+  return hipSuccess;
+}
+
 inline dim3 grid_for(int64_t work, int block) { return dim3((unsigned)((work + block - 1) / block)); }
 
 }  // namespace dsh

@@ -74,6 +74,7 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   const bool ba = atol_nb == 1 && nb != 1;
   const bool wave = T.r.o.group == 64;
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
+  DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
     const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (wave ? "true" : "false") + ", " + (method == 1 ? "3" : "4") + ">";
     rc = jit_launch(ctx, model, "dsh_sdirk_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
@@ -94,9 +95,11 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
     }
   });
   DSH_HIP_CHECK(hipGetLastError());
+  DSH_HIP_CHECK(timing_end(ctx));
   unsigned long long totals[8] = {0};
   DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  DSH_HIP_CHECK(timing_collect(ctx));
   dsh_free(ctx, t_eval_dev);
   dsh_free(ctx, totals_dev);
   dsh_free(ctx, consts_dev);

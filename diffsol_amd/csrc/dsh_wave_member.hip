@@ -92,6 +92,7 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
 #define DSH_WM_LAUNCH(NPV)                                                                                                                              \
   hipLaunchKernelGGL((k_bdf_wave_member<NPV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
                      (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+  DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
     const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
     rc = jit_launch(ctx, model, "dsh_jit_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64), (unsigned)lds_bytes, nb, p, atol, ab,
@@ -103,9 +104,11 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   else DSH_WM_LAUNCH(64);
 #undef DSH_WM_LAUNCH
   DSH_HIP_CHECK(hipGetLastError());
+  DSH_HIP_CHECK(timing_end(ctx));
   unsigned long long totals[8] = {0};
   DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  DSH_HIP_CHECK(timing_collect(ctx));
   dsh_free(ctx, t_eval_dev);
   dsh_free(ctx, totals_dev);
   dsh_free(ctx, consts_dev);

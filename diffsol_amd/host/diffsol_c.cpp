@@ -51,7 +51,7 @@ struct diffsol_ode_wrapper {
   int64_t n = 0, np = 0, nroots = 0, nout = 0;
   bool has_mass = false, no_inputs = false;
   std::vector<double> defaults;
-  int32_t linear_solver = DIFFSOL_LINEAR_SOLVER_DEFAULT, ode_solver = DIFFSOL_ODE_SOLVER_BDF, ensemble_mode = DIFFSOL_ENSEMBLE_LOCKSTEP;
+  int32_t linear_solver = DIFFSOL_LINEAR_SOLVER_DEFAULT, ode_solver = DIFFSOL_ODE_SOLVER_BDF, ensemble_mode = DIFFSOL_ENSEMBLE_AUTO;
   double rtol = 1e-6, t0 = 0.0, h0 = 1.0;
   std::vector<double> atol{1e-6};
   std::shared_ptr<Settings> settings;
@@ -325,7 +325,7 @@ int32_t diffsol_ode_rhs_jac_mul(OdeWrapper* ode, const double* params_ptr, size_
 
 int32_t diffsol_ode_solve(OdeWrapper* ode, const double* params_ptr, size_t params_len, double final_time, SolutionWrapper** out_solution) {
   if (!ode || !out_solution || (!params_ptr && params_len)) return C_INVALID_ARG("invalid arguments to diffsol_ode_solve");
-  if (ode->ensemble_mode != DIFFSOL_ENSEMBLE_LOCKSTEP)
+  if (ode->ensemble_mode != DIFFSOL_ENSEMBLE_LOCKSTEP && ode->ensemble_mode != DIFFSOL_ENSEMBLE_AUTO)
     return C_ERROR("solve() returns every internal step, which only exists for the lock-step ensemble; use solve_dense with the per-member / wavefront modes");
   SolverGuard g;
   int64_t nb = 0;
@@ -367,8 +367,12 @@ int32_t diffsol_ode_solve_dense(OdeWrapper* ode, const double* params_ptr, size_
   sol->root_index.assign((size_t)nb, -1);
   sol->member_cols.assign((size_t)nb, (int32_t)nt);
   int64_t ncols = nt;
-  if (ode->ensemble_mode == DIFFSOL_ENSEMBLE_LOCKSTEP) {
+  // DIFFSOL_ENSEMBLE_AUTO: what dshs_solve_dense would pick (device-resident whenever the model has such a kernel, include/diffsol_hip_solver.h)
+  int mode = ode->ensemble_mode;
+  if (mode == DIFFSOL_ENSEMBLE_AUTO) { int requested = 0; dshs_get_ensemble_mode(g.s, &requested, &mode); }
+  if (mode == DIFFSOL_ENSEMBLE_LOCKSTEP) {
     int reason = 0;
+    if (dshs_set_ensemble_mode(g.s, DSHS_ENSEMBLE_LOCKSTEP) != 0) return C_ERROR(std::string(dshs_last_error()));
     if (dshs_solve_dense(g.s, t_eval_ptr, nt, sol->ys.data(), nullptr, &reason) != 0) return C_ERROR(std::string(dshs_last_error()));
     if (reason == DSHS_STOP_ROOT_FOUND) {  // solve_dense stops at the root: the column after the last t_eval <= t_root holds the state at the root (method.rs:498-516)
       double t_root = 0.0; int idx = -1;
@@ -385,7 +389,7 @@ int32_t diffsol_ode_solve_dense(OdeWrapper* ode, const double* params_ptr, size_
     }
   } else {
     int64_t totals[6];
-    if (dshs_solve_dense_adaptive(g.s, t_eval_ptr, nt, ode->ensemble_mode, 1, sol->ys.data(), nullptr, nullptr, sol->status.data(), sol->t_root.data(), sol->root_index.data(),
+    if (dshs_solve_dense_adaptive(g.s, t_eval_ptr, nt, mode, 1, sol->ys.data(), nullptr, nullptr, sol->status.data(), sol->t_root.data(), sol->root_index.data(),
                                   sol->member_cols.data(), totals) != 0)
       return C_ERROR(std::string(dshs_last_error()));
     sol->ts.assign(t_eval_ptr, t_eval_ptr + nt);
@@ -433,7 +437,8 @@ DIFFSOL_SCALAR_ACCESSORS(h0, ode->h0, ode->h0 = value)
 int32_t diffsol_ode_get_ensemble_mode(const OdeWrapper* ode) { if (!ode) { C_INVALID_ARG("ode is null"); return -1; } return ode->ensemble_mode; }
 int32_t diffsol_ode_set_ensemble_mode(OdeWrapper* ode, int32_t mode) {
   if (!ode) return C_INVALID_ARG("ode is null");
-  if (mode != DIFFSOL_ENSEMBLE_LOCKSTEP && mode != DIFFSOL_ENSEMBLE_PER_MEMBER && mode != DIFFSOL_ENSEMBLE_WAVEFRONT) return C_INVALID_ARG("invalid ensemble mode");
+  if (mode != DIFFSOL_ENSEMBLE_AUTO && mode != DIFFSOL_ENSEMBLE_LOCKSTEP && mode != DIFFSOL_ENSEMBLE_PER_MEMBER && mode != DIFFSOL_ENSEMBLE_WAVEFRONT)
+    return C_INVALID_ARG("invalid ensemble mode");
   ode->ensemble_mode = mode;
   return DIFFSOL_OK;
 }

@@ -7,6 +7,7 @@
 #include <functional>
 #include <limits>
 
+#include "../../include/diffsol_detpow.h"
 #include "hip_la.hpp"
 
 namespace diffsol_hip {
@@ -28,6 +29,12 @@ inline double powi(double a, int b) {  // f64::powi (compiler-rt __powidf2), use
   return recip ? 1.0 / r : r;
 }
 
+// pow() of the step-size controller, the convergence-rate estimate and the initial-step heuristic: libm (the reference's arithmetic) by default;
+// dshs_set_deterministic_pow(1) switches the host-driven integrators to include/diffsol_detpow.h — the pow the device-resident integrators use —
+// so that both execution modes produce the same bits.  Constants (20^1.25, eps^(2/3)) are libm's in either mode, as in the device kernels' tables.
+inline bool& det_pow_flag() { static bool f = false; return f; }
+inline double hpow(double x, double y) { return det_pow_flag() ? dsh_det_pow(x, y) : std::pow(x, y); }
+
 class Convergence {  // convergence.rs:7-140
  public:
   double rtol;
@@ -44,14 +51,14 @@ class Convergence {  // convergence.rs:7-140
   ConvergenceStatus check_norm(double norm) {
     niter_ += 1;
     if (has_old_norm_) {
-      double rate = std::pow(norm / old_norm_, 1.0 / (double)(niter_ - 1));
+      double rate = hpow(norm / old_norm_, 1.0 / (double)(niter_ - 1));
       if (rate > 0.9) return ConvergenceStatus::Diverged;
       if (powi(rate, max_iter_ - niter_) / (1.0 - rate) * norm > tol_) return ConvergenceStatus::Diverged;
       eta_ = rate / (1.0 - rate);
     } else {
       double min_eta = 1e4 * std::numeric_limits<double>::epsilon();
       if (eta_ < min_eta) eta_ = min_eta;
-      eta_ = std::pow(eta_, 0.8);
+      eta_ = hpow(eta_, 0.8);
     }
     if (eta_ * norm < tol_) return ConvergenceStatus::Converged;
     return ConvergenceStatus::Continue;

@@ -236,12 +236,12 @@ class JacobianUpdate {
 // runge_kutta.rs:1313-1336
 inline double pi_controller_raw(double error_norm, std::optional<double> prev_error_norm, double pi_integral, double pi_proportional, int eff_order) {
   double order_f = (double)eff_order, ki = pi_integral / order_f;
-  if (pi_proportional == 0.0) return std::pow(error_norm, -ki);
+  if (pi_proportional == 0.0) return hpow(error_norm, -ki);
   if (prev_error_norm) {
     double kp = pi_proportional / order_f;
-    return std::pow(error_norm, -(ki + kp)) * std::pow(*prev_error_norm, kp);
+    return hpow(error_norm, -(ki + kp)) * hpow(*prev_error_norm, kp);
   }
-  return std::pow(error_norm, -ki);
+  return hpow(error_norm, -ki);
 }
 
 // StateCommon (ode_solver/state.rs) restricted to the main equations
@@ -369,7 +369,7 @@ inline void set_step_size(StateCommon& s, double h0_in, const HipVec& atol, doub
   if (max_d < d1) max_d = d1;
   double h1;
   if (max_d < 1e-15) { h1 = h0 * 1e-3; if (h1 < 1e-6) h1 = 1e-6; }
-  else h1 = std::pow(0.01 / max_d, 1.0 / (1.0 + (double)solver_order));
+  else h1 = hpow(0.01 / max_d, 1.0 / (1.0 + (double)solver_order));
   s.h = 100.0 * h0;
   if (s.h > h1) s.h = h1;
   if (is_neg_h) s.h = -s.h;

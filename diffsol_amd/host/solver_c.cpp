@@ -3,8 +3,10 @@
 #include <cmath>
 #include "../../include/diffsol_hip_solver.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "bdf.hpp"
 #include "diffsl.hpp"
@@ -40,6 +42,10 @@ struct dshs_solver {
   }
   HipMat traj_y;
   std::vector<double> traj_t;
+  // Which integrator solve_dense runs (include/diffsol_hip_solver.h DSHS_ENSEMBLE_*); -1 = auto.
+  int ensemble_mode = -1;
+  int last_mode = 0;              // mode the last solve_dense actually ran in
+  int64_t last_totals[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -63,6 +69,132 @@ int guarded(F&& f) {
 void download(const HipVec& v, double* host) {
   std::vector<double> tmp = v.clone_as_vec();
   std::memcpy(host, tmp.data(), tmp.size() * sizeof(double));
+}
+
+// Which device-resident kernel (if any) integrates this problem (model x method) in the given control granularity.
+struct ResidentPick {
+  bool ok = false;
+  bool wave_member = false;  // one wavefront per member (run-time-sized models, BDF, identity mass, n <= 64)
+  int model = 0;
+  int64_t size = 0;
+  int method = 0;
+};
+ResidentPick pick_resident(const dshs_solver* s, int group) {
+  ResidentPick r;
+  r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
+  if (group != 1 && group != 64) return r;
+  int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it
+  const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
+  const bool lane_ok = !(lane_env && lane_env[0] == '0');
+  int model = 0;
+  int64_t size = 0;
+  if (lane_ok && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(r.method, twin, 0)) {
+    r.ok = true; r.model = twin; r.size = 0;
+  } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
+    r.ok = true; r.model = model; r.size = size;
+  } else if (group == 1 && r.method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size) && !s->problem.eqn->has_mass()) {
+    r.ok = true; r.wave_member = true; r.model = model; r.size = size;
+  }
+  return r;
+}
+// DSHS_ENSEMBLE_AUTO: the device-resident integrators whenever the model has one — wavefront-sized lock-step groups (the reference's batched
+// semantics, nbatch = 64 per group; for nbatch <= 64 that IS the lock-step ensemble, bit for bit) for models without root functions, one
+// history per member (every member stops at its own event) for models with them — else the host-driven lock-step path over the trait operations.
+int resolve_mode(const dshs_solver* s) {
+  int mode = s->ensemble_mode;
+  if (mode == DSHS_ENSEMBLE_AUTO) {
+    static const int env_mode = [] {
+      const char* e = std::getenv("DSH_ENSEMBLE_MODE");
+      if (!e) return DSHS_ENSEMBLE_AUTO;
+      const std::string v(e);
+      if (v == "lockstep" || v == "0") return DSHS_ENSEMBLE_LOCKSTEP;
+      if (v == "member" || v == "1") return DSHS_ENSEMBLE_PER_MEMBER;
+      if (v == "wave" || v == "64") return DSHS_ENSEMBLE_WAVEFRONT;
+      return DSHS_ENSEMBLE_AUTO;
+    }();
+    mode = env_mode;
+  }
+  if (mode == DSHS_ENSEMBLE_AUTO) {
+    // the device-resident integrators start from the problem's (t0, y0): a solver that was stepped by hand continues on the host path
+    if (s->solver->get_statistics().number_of_steps != 0 || s->solver->t() != s->problem.t0) return DSHS_ENSEMBLE_LOCKSTEP;
+    const bool roots = s->problem.eqn->nroots() > 0;
+    if (!roots && pick_resident(s, 64).ok) return DSHS_ENSEMBLE_WAVEFRONT;
+    if (pick_resident(s, 1).ok) return DSHS_ENSEMBLE_PER_MEMBER;
+    return DSHS_ENSEMBLE_LOCKSTEP;
+  }
+  if (mode != DSHS_ENSEMBLE_LOCKSTEP && !pick_resident(s, mode).ok) return DSHS_ENSEMBLE_LOCKSTEP;
+  return mode;
+}
+
+void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
+                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
+  const ResidentPick pk = pick_resident(s, group);
+  if (!pk.ok)
+    throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
+                                     "run-time-sized ODE models with n <= 64: BDF)");
+  const int model = pk.model;
+  const int64_t size = pk.size;
+  const int method = pk.method;
+  const bool wave_member = pk.wave_member;
+  const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
+  const OdeSolverOptions& oo = s->problem.ode_options;
+  const InitialConditionSolverOptions& ic = s->problem.ic_options;
+  dsh_adaptive_options o;
+  dsh_adaptive_default_options(&o);
+  o.max_nonlinear_solver_iterations = oo.max_nonlinear_solver_iterations;
+  o.max_error_test_failures = oo.max_error_test_failures;
+  o.max_nonlinear_solver_failures = oo.max_nonlinear_solver_failures;
+  o.nonlinear_solver_tolerance = oo.nonlinear_solver_tolerance;
+  o.min_timestep = oo.min_timestep;
+  // BdfConfig / SdirkConfig defaults (config.rs:53-109) are identical
+  o.max_timestep_growth = oo.max_timestep_growth.value_or(2.0);
+  o.min_timestep_growth = oo.min_timestep_growth.value_or(2.0);
+  o.max_timestep_shrink = oo.max_timestep_shrink.value_or(0.9);
+  o.min_timestep_shrink = oo.min_timestep_shrink.value_or(0.5);
+  o.update_jacobian_after_steps = oo.update_jacobian_after_steps;
+  o.update_rhs_jacobian_after_steps = oo.update_rhs_jacobian_after_steps;
+  o.threshold_to_update_jacobian = oo.threshold_to_update_jacobian;
+  o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
+  o.pi_control_proportional = oo.pi_control_proportional;
+  o.pi_control_integral = oo.pi_control_integral;
+  o.ic_use_linesearch = ic.use_linesearch ? 1 : 0;
+  o.ic_max_linesearch_iterations = ic.max_linesearch_iterations;
+  o.ic_max_linear_solver_setups = ic.max_linear_solver_setups;
+  o.ic_max_newton_iterations = ic.max_newton_iterations;
+  o.ic_step_reduction_factor = ic.step_reduction_factor;
+  o.ic_armijo_constant = ic.armijo_constant;
+  o.group = group;
+  o.deterministic_pow = deterministic_pow;
+  dsh_ctx* c = s->ctx.raw();
+  double* out = y_dev;
+  void* tmp_out = nullptr;
+  if (!out) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &tmp_out), "adaptive out"); out = (double*)tmp_out; }
+  void *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
+  if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
+  if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
+  if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "adaptive t_root");
+  if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
+  if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
+  int rc;
+  if (wave_member)
+    rc = dsh_bdf_solve_wave_member(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                   t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
+  else if (method == 0)
+    rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
+  else
+    rc = dsh_sdirk_solve_resident(c, method, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0,
+                                  s->problem.h0, &o, t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
+                                  (int32_t*)ncols_dev, totals);
+  if (rc == DSH_OK && y_host)
+    for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
+  if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
+  if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
+  if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
+  if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
+  if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
+  for (void* q : {tmp_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
+  check(rc, "solve_dense_adaptive");
 }
 }  // namespace
 
@@ -268,6 +400,29 @@ int dshs_trajectory(dshs_solver* s, double* t_host, double* y_host) {
 
 int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int* stop_reason) {
   return guarded([&]() {
+    const int mode = resolve_mode(s);
+    s->last_mode = mode;
+    if (mode != DSHS_ENSEMBLE_LOCKSTEP) {
+      // OdeSolverMethod::solve_dense (method.rs:467-520) of the whole ensemble in one launch: the state never leaves the chip.
+      const int64_t nb = s->ctx.nbatch();
+      std::vector<int32_t> status((size_t)nb), ridx((size_t)nb);
+      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), nullptr, ridx.data(), nullptr, s->last_totals);
+      int64_t failed = 0, rooted = 0;
+      int first_bad = 0;
+      for (int64_t b = 0; b < nb; ++b) {
+        if (status[(size_t)b] != 0) { if (!failed) first_bad = status[(size_t)b]; ++failed; }
+        if (ridx[(size_t)b] >= 0) ++rooted;
+      }
+      if (failed) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "solve_dense: %lld of %lld ensemble members failed (first status %d); dshs_solve_dense_adaptive returns the per-member status",
+                      (long long)failed, (long long)nb, first_bad);
+        if (first_bad >= 1 && first_bad <= (int)OdeSolverError::LinearSolveFailed) throw DiffsolError((OdeSolverError)first_bad, buf);
+        throw LaError(first_bad == 20 ? DSH_E_BATCH_MISMATCH : DSH_E_INVALID, buf);
+      }
+      if (stop_reason) *stop_reason = rooted == nb ? DSHS_STOP_ROOT_FOUND : DSHS_STOP_TSTOP_REACHED;
+      return 0;
+    }
     std::vector<double> te(t_eval, t_eval + nt);
     HipMat ret;
     OdeSolverStopReason r = s->solver->solve_dense(te, ret);
@@ -277,8 +432,37 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       for (int64_t c = 0; c < ret.ncols(); ++c) check(dsh_vec_download(s->ctx.raw(), n, nb, ret.column(c).p, y_host + (size_t)(c * n * nb)), "solve_dense download");
     s->ctx.sync();
     if (stop_reason) *stop_reason = (int)r;
+    const OdeSolverStatistics& st = s->solver->get_statistics();
+    s->last_totals[0] = st.number_of_steps * nb; s->last_totals[1] = st.number_of_nonlinear_solver_iterations * nb;
+    s->last_totals[2] = st.number_of_linear_solver_setups * nb; s->last_totals[3] = st.number_of_error_test_failures * nb;
+    s->last_totals[4] = st.number_of_nonlinear_solver_fails * nb; s->last_totals[5] = 0;
     return 0;
   });
+}
+
+int dshs_set_deterministic_pow(int on) {
+  det_pow_flag() = on != 0;
+  return 0;
+}
+int dshs_set_ensemble_mode(dshs_solver* s, int mode) {
+  return guarded([&]() {
+    if (mode != DSHS_ENSEMBLE_AUTO && mode != DSHS_ENSEMBLE_LOCKSTEP && mode != DSHS_ENSEMBLE_PER_MEMBER && mode != DSHS_ENSEMBLE_WAVEFRONT)
+      throw LaError(DSH_E_INVALID, "dshs_set_ensemble_mode: mode must be DSHS_ENSEMBLE_AUTO, _LOCKSTEP, _PER_MEMBER or _WAVEFRONT");
+    if ((mode == DSHS_ENSEMBLE_PER_MEMBER || mode == DSHS_ENSEMBLE_WAVEFRONT) && !pick_resident(s, mode).ok)
+      throw LaError(DSH_E_UNSUPPORTED, "dshs_set_ensemble_mode: no device-resident kernel for this model/method in that mode");
+    s->ensemble_mode = mode;
+    return 0;
+  });
+}
+int dshs_get_ensemble_mode(const dshs_solver* s, int* requested, int* resolved) {
+  if (requested) *requested = s->ensemble_mode;
+  if (resolved) *resolved = resolve_mode(s);
+  return 0;
+}
+int dshs_last_solve_info(const dshs_solver* s, int* mode, int64_t* totals) {
+  if (mode) *mode = s->last_mode;
+  if (totals) for (int k = 0; k < 6; ++k) totals[k] = s->last_totals[k];
+  return 0;
 }
 
 // Device-resident integration, whole ensemble solve in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident); the problem (model,
@@ -286,83 +470,10 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
 int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
   return guarded([&]() {
-    int model = 0;
-    int64_t size = 0;
-    const int method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
-    bool wave_member = false;
-    int twin = -1;  // a run-time-compiled model may carry its banded lane-per-member form: per-member BDF solves use it
-    const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
-    const bool lane_ok = !(lane_env && lane_env[0] == '0');
-    if (lane_ok && (group == 1 || group == 64) && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(method, twin, 0)) {
-      model = twin; size = 0;
-    } else if (!s->problem.eqn->fused_model(&model, &size) || !dsh_model_has_resident(method, model, size)) {
-      // run-time-sized models: one wavefront per member (BDF, identity mass, n <= 64)
-      wave_member = method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size) && !s->problem.eqn->has_mass();
-      if (!wave_member)
-        throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
-                                         "run-time-sized ODE models with n <= 64: BDF)");
-    }
-    const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
-    const OdeSolverOptions& oo = s->problem.ode_options;
-    const InitialConditionSolverOptions& ic = s->problem.ic_options;
-    dsh_adaptive_options o;
-    dsh_adaptive_default_options(&o);
-    o.max_nonlinear_solver_iterations = oo.max_nonlinear_solver_iterations;
-    o.max_error_test_failures = oo.max_error_test_failures;
-    o.max_nonlinear_solver_failures = oo.max_nonlinear_solver_failures;
-    o.nonlinear_solver_tolerance = oo.nonlinear_solver_tolerance;
-    o.min_timestep = oo.min_timestep;
-    // BdfConfig / SdirkConfig defaults (config.rs:53-109) are identical
-    o.max_timestep_growth = oo.max_timestep_growth.value_or(2.0);
-    o.min_timestep_growth = oo.min_timestep_growth.value_or(2.0);
-    o.max_timestep_shrink = oo.max_timestep_shrink.value_or(0.9);
-    o.min_timestep_shrink = oo.min_timestep_shrink.value_or(0.5);
-    o.update_jacobian_after_steps = oo.update_jacobian_after_steps;
-    o.update_rhs_jacobian_after_steps = oo.update_rhs_jacobian_after_steps;
-    o.threshold_to_update_jacobian = oo.threshold_to_update_jacobian;
-    o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
-    o.pi_control_proportional = oo.pi_control_proportional;
-    o.pi_control_integral = oo.pi_control_integral;
-    o.ic_use_linesearch = ic.use_linesearch ? 1 : 0;
-    o.ic_max_linesearch_iterations = ic.max_linesearch_iterations;
-    o.ic_max_linear_solver_setups = ic.max_linear_solver_setups;
-    o.ic_max_newton_iterations = ic.max_newton_iterations;
-    o.ic_step_reduction_factor = ic.step_reduction_factor;
-    o.ic_armijo_constant = ic.armijo_constant;
-    o.group = group;
-    o.deterministic_pow = deterministic_pow;
-    dsh_ctx* c = s->ctx.raw();
-    double* out = y_dev;
-    void* tmp_out = nullptr;
-    if (!out) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &tmp_out), "adaptive out"); out = (double*)tmp_out; }
-    void *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
-    if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
-    if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
-    {
-      if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "adaptive t_root");
-      if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
-      if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
-    }
-    int rc;
-    if (wave_member)
-      rc = dsh_bdf_solve_wave_member(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
-                                     t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
-    else if (method == 0)
-      rc = dsh_bdf_solve_adaptive(c, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
-                                  t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
-    else
-      rc = dsh_sdirk_solve_resident(c, method, model, size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0,
-                                    s->problem.h0, &o, t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
-                                    (int32_t*)ncols_dev, totals);
-    if (rc == DSH_OK && y_host)
-      for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
-    if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
-    if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
-    if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
-    if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
-    if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
-    for (void* q : {tmp_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
-    check(rc, "solve_dense_adaptive");
+    int64_t tot[6];
+    run_resident(s, t_eval, nt, group, deterministic_pow, y_host, y_dev, stats_host, status_host, t_root_host, root_idx_host, ncols_host, tot);
+    for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
+    s->last_mode = group;
     return 0;
   });
 }

@@ -24,13 +24,20 @@ STAT_NAMES = [
 ]
 
 STOP_INTERNAL_TIMESTEP, STOP_ROOT_FOUND, STOP_TSTOP_REACHED = 0, 1, 2
+# dshs_set_ensemble_mode (include/diffsol_hip_solver.h): which integrator solve_dense runs for an ensemble
+ENSEMBLE_AUTO, ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT = -1, 0, 1, 64
+
+
+def set_deterministic_pow(on):
+    """dshs_set_deterministic_pow: pow() of the host-driven integrators = include/diffsol_detpow.h (the device-resident integrators' pow) instead of libm."""
+    check(_ffi.load_host_lib().dshs_set_deterministic_pow(1 if on else 0), host=True)
 
 
 class Solver:
-    """One (batched, lock-step) solver instance on one GPU."""
+    """One ensemble solver instance on one GPU."""
 
     def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, device=0, stream=None,
-                 fused=True, block_threads=0, options=None):
+                 fused=True, block_threads=0, options=None, ensemble_mode=None):
         L = _ffi.load_host_lib()
         self._L = L
         if isinstance(model, str):
@@ -56,6 +63,24 @@ class Solver:
         self.n = int(L.dshs_nstates(h))
         self.nbatch = int(L.dshs_nbatch(h))
         self.fused = bool(L.dshs_is_fused(h))
+        if ensemble_mode is not None:
+            self.set_ensemble_mode(ensemble_mode)
+
+    def set_ensemble_mode(self, mode):
+        """ENSEMBLE_AUTO (default): solve_dense runs device-resident whenever the model has such a kernel; ENSEMBLE_LOCKSTEP: host-driven trait path."""
+        check(self._L.dshs_set_ensemble_mode(self._h, int(mode)), host=True)
+
+    def ensemble_mode(self):
+        """(requested, resolved) ensemble mode of solve_dense."""
+        a, b = C.c_int(), C.c_int()
+        check(self._L.dshs_get_ensemble_mode(self._h, C.byref(a), C.byref(b)), host=True)
+        return a.value, b.value
+
+    def last_solve_info(self):
+        """(mode the last solve_dense ran in, counters summed over the ensemble members)."""
+        m, tot = C.c_int(), (C.c_int64 * 6)()
+        check(self._L.dshs_last_solve_info(self._h, C.byref(m), tot), host=True)
+        return m.value, dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in tot]))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -24,7 +24,9 @@
  *                            ndim 3 for nbatch > 1: (nrows, ncols, nbatch), the batch axis fastest (strides in bytes: 8 nbatch, 8 nbatch nrows, 8)
  *   ts                       1-D, ncols
  * nrows = number of out_i components if the model defines out_i, else the number of states (DiffSl::out; ode_solver/method.rs write_state_out).
- * Ensemble mode (diffsol_ode_set_ensemble_mode): DIFFSOL_ENSEMBLE_LOCKSTEP (default) integrates all members with one (t, h, order) sequence — the
+ * Ensemble mode (diffsol_ode_set_ensemble_mode): DIFFSOL_ENSEMBLE_AUTO (default) runs solve_dense on the device-resident integrators whenever the
+ * model has such a kernel (wavefront groups of 64 without root functions — for nbatch <= 64 that is the lock-step ensemble, bit for bit —, per member
+ * with them), else lock-step; `solve` is always lock-step.  DIFFSOL_ENSEMBLE_LOCKSTEP integrates all members with one (t, h, order) sequence — the
  * reference's batched-vector semantics, and `solve` returns every accepted step; DIFFSOL_ENSEMBLE_PER_MEMBER / _WAVEFRONT run solve_dense
  * entirely on the device (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident: every member its own steps and event time / 64-member groups);
  * columns after a member's own root stop are NaN and diffsol_solution_wrapper_get_member_info returns per-member status, root time and column count.
@@ -65,6 +67,7 @@ extern "C" {
 #define DIFFSOL_JIT_LLVM 1
 #define DIFFSOL_JIT_HIPRTC 2
 
+#define DIFFSOL_ENSEMBLE_AUTO (-1)
 #define DIFFSOL_ENSEMBLE_LOCKSTEP 0
 #define DIFFSOL_ENSEMBLE_PER_MEMBER 1
 #define DIFFSOL_ENSEMBLE_WAVEFRONT 64

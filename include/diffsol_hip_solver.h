@@ -90,6 +90,32 @@ int dshs_trajectory(dshs_solver* s, double* t_host, double* y_host /* [col][b][s
 /* OdeSolverMethod::solve_dense (method.rs:467-520): interpolated output at t_eval.  y_host ([nt][b][state]) and/or y_dev (DEVICE pointer,
  * [nt][state][b] batch-fastest — the buffer the multi-GPU gather concatenates along the batch axis) may be NULL. */
 int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y_host, double* y_dev, int* stop_reason);
+/* Which integrator dshs_solve_dense runs for an ensemble (nbatch members):
+ *   DSHS_ENSEMBLE_AUTO (default; environment DSH_ENSEMBLE_MODE=lockstep|member|wave overrides it): the device-resident integrators whenever the
+ *     model/method has one (dsh_model_has_resident / dsh_model_has_wave_member) — the whole solve_dense in ONE launch, solver state in registers:
+ *     wavefront-sized lock-step groups for models without root functions (the reference's batched semantics with nbatch = 64 per group; an
+ *     ensemble of <= 64 members is one group, i.e. exactly the lock-step ensemble, bit for bit), one step-size/order history per member for
+ *     models with root functions (every member stops at its own event); otherwise DSHS_ENSEMBLE_LOCKSTEP.
+ *   DSHS_ENSEMBLE_LOCKSTEP: host-driven, one (t, h, order) sequence for the whole ensemble over the Vector/Matrix/LinearSolver operations of
+ *     diffsol_hip.h — what the reference's generic Bdf/Sdirk do on a batched context (method.rs:467-520 over bdf.rs:1277-1589).
+ *   DSHS_ENSEMBLE_PER_MEMBER / DSHS_ENSEMBLE_WAVEFRONT: force one of the device-resident granularities (error if the model has no such kernel).
+ * In the device-resident modes the host-side solver state (dshs_get_state, dshs_stats) is not advanced — the problem is integrated from
+ * (t0, y0) on every call; dshs_last_solve_info returns the counters.  A member that fails makes dshs_solve_dense fail like the reference's
+ * solve_dense does (-100 - OdeSolverError ordinal of the first failing member); dshs_solve_dense_adaptive returns per-member status instead.
+ * stop_reason: DSHS_STOP_ROOT_FOUND if every member stopped at a root, else DSHS_STOP_TSTOP_REACHED. */
+#define DSHS_ENSEMBLE_AUTO (-1)
+#define DSHS_ENSEMBLE_LOCKSTEP 0
+#define DSHS_ENSEMBLE_PER_MEMBER 1
+#define DSHS_ENSEMBLE_WAVEFRONT 64
+int dshs_set_ensemble_mode(dshs_solver* s, int mode);
+/* Process-wide: pow() of the HOST-driven integrators (step-size controller, convergence rate, initial step).  0 (default) = libm, the reference's
+ * arithmetic; 1 = include/diffsol_detpow.h, the pow of the device-resident integrators — then DSHS_ENSEMBLE_LOCKSTEP and the device-resident
+ * wavefront mode give the same bits for ensembles of <= 64 members (one group). */
+int dshs_set_deterministic_pow(int on);
+int dshs_get_ensemble_mode(const dshs_solver* s, int* requested, int* resolved);
+/* mode the last solve_dense ran in and its counters summed over members: totals[6] = steps, Newton iterations, LU setups, error-test failures,
+ * Newton failures, failed members (lock-step: the solver's counters x nbatch). */
+int dshs_last_solve_info(const dshs_solver* s, int* mode, int64_t* totals);
 /* solve_dense entirely on the device, the whole ensemble in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident).
  * group = 1: every member is integrated as the independent IVP it is on diffsol's CPU path, with its own step sizes, orders and EVENT TIMES;
  * group = 64: wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64).  Static models with n <= 4 and banded run-time-sized models with n <= 64 (BDF, TR-BDF2,

@@ -1,0 +1,49 @@
+"""bench.py's launcher / argument / aggregation path on a CPU-only box: `python bench.py --gpus 2` must start two ranks itself,
+and a rank count that disagrees with --gpus must fail instead of silently reporting n_gpus = 1.  Uses bench.py's --cpu-stub test hook (gloo, stub solver)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_launches_two_ranks_and_aggregates():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--nb", "1000", "--cpu-stub"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["config"]["members_total"] == 2000 and rec["config"]["backend"] == "gloo" and rec["scaling"] == "weak"
+    assert rec["data"].startswith("cpu-stub")
+    # whole-job aggregate: units of both ranks / max time over ranks
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 * 2 - 2 * 300 * 2000) < 1e-3 * 2 * 300 * 2000
+    assert rec["config"]["mean_steps_per_member"] == 300
+
+
+def test_single_rank_stub_line_has_contract_keys():
+    r = _run(["--steps", "1", "--warmup", "0", "--nb", "64", "--cpu-stub"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec
+    assert rec["n_gpus"] == 1 and rec["dtype"] == "f64" and rec["vs_baseline"] is None and "workload" in rec["config"]
+
+
+def test_rank_count_must_match_gpus_flag():
+    """A launcher that started 1 rank for --gpus 2 (round 1's silent n_gpus = 1) is an error now."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--nb", "64", "--cpu-stub"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

@@ -227,14 +227,65 @@ def test_launch_structure_knobs_do_not_change_a_single_bit(H, O, monkeypatch, en
 
 
 # ------------------------------------------------------------------ BASELINE.json config 2 at full size: size-independent properties
-@pytest.fixture(scope="module")
-def full_size_run(H):
+@pytest.fixture(scope="module", params=["default", "host_lockstep"])
+def full_size_run(H, request):
+    """`default`: dshs_solve_dense as a user gets it (DSHS_ENSEMBLE_AUTO -> the device-resident integrator, wavefront groups of 64 — bench.py's
+    `value` path); `host_lockstep`: the trait-boundary path, one (t, h, order) for all 100 000 members."""
     nb = 100_000
     p = robertson_params(nb)
-    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **ROB)
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, ensemble_mode=0 if request.param == "host_lockstep" else None, **ROB)
+    assert s.ensemble_mode() == ((0, 0) if request.param == "host_lockstep" else (-1, 64))
     t_eval = [0.4, 4.0, 40.0, 400.0, 4e3, 4e4, 4e5]
     y, reason = s.solve_dense(t_eval)
-    return p, t_eval, y, s.stats(), reason
+    mode, tot = s.last_solve_info()
+    assert mode == (0 if request.param == "host_lockstep" else 64) and tot["failed_members"] == 0
+    st = {k: v // nb for k, v in tot.items()}  # mean per member
+    if request.param == "host_lockstep":
+        assert st["number_of_steps"] == s.stats()["number_of_steps"]
+    return p, t_eval, y, st, reason
+
+
+def test_default_solve_dense_is_the_device_resident_integrator_and_equals_the_oracle_group_by_group(H, O, request):
+    """The drop-in default: dshs_solve_dense routes to dsh_bdf_solve_adaptive in wavefront lock-step groups of 64, i.e. the
+    reference's batched semantics with nbatch = 64 per group: every member equals the oracle's lock-step batched run of its own group bit for bit
+    (ragged last group included); an ensemble of <= 64 members is ONE group = the host-driven lock-step ensemble, bit for bit."""
+    nb = 64 * 5 + 23
+    p = robertson_params(nb, seed=4242)
+    t_eval = [0.4, 4.0, 40.0, 400.0, 4e3]
+    O.set_det_pow(True)           # the device-resident integrators' pow is include/diffsol_detpow.h: same switch on the oracle ...
+    H.set_deterministic_pow(True)  # ... and on the host-driven integrators (libm by default = the reference's arithmetic)
+    request.addfinalizer(lambda: (O.set_det_pow(False), H.set_deterministic_pow(False)))
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **ROB)
+    assert s.ensemble_mode() == (-1, 64)
+    y, reason = s.solve_dense(t_eval)
+    mode, tot = s.last_solve_info()
+    assert reason == 2 and mode == 64 and tot["failed_members"] == 0
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL["robertson_ode"], p, t_eval, model_size=1, group=64, **ROB)
+    assert failed == 0 and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    assert tot["number_of_steps"] == int(so[:, 0].sum()) and tot["number_of_nonlinear_solver_iterations"] == int(so[:, 1].sum())
+    # the solver object was not advanced: calling again gives the same bits; the host-driven mode continues to work on the same object
+    y2, _ = s.solve_dense(t_eval)
+    assert np.array_equal(y2, y)
+    small = H.Solver("robertson_ode", p[:40], nbatch=40, model_size=1, **ROB)
+    ya, _ = small.solve_dense(t_eval)
+    host = H.Solver("robertson_ode", p[:40], nbatch=40, model_size=1, ensemble_mode=0, **ROB)
+    yh, _ = host.solve_dense(t_eval)
+    assert small.last_solve_info()[0] == 64 and host.last_solve_info()[0] == 0 and np.array_equal(ya, yh)
+    assert small.last_solve_info()[1]["number_of_steps"] == host.last_solve_info()[1]["number_of_steps"] == 40 * host.stats()["number_of_steps"]
+    # a solver that was stepped by hand continues on the host path (the device-resident integrators start from t0)
+    host2 = H.Solver("robertson_ode", p[:40], nbatch=40, model_size=1, **ROB)
+    host2.step()
+    assert host2.ensemble_mode() == (-1, 0)
+
+
+def test_default_solve_dense_fails_like_the_reference_when_a_member_fails(H):
+    """solve_dense returns Err when the integration fails; the ensemble default does the same when ANY member fails (per-member status is what
+    dshs_solve_dense_adaptive is for)."""
+    p = robertson_params(70, seed=3)
+    s = H.Solver("robertson_ode", p, nbatch=70, model_size=1, options=dict(max_error_test_failures=1, max_nonlinear_solver_failures=1), **ROB)
+    with pytest.raises(H.DiffsolHipError) as e:
+        s.solve_dense([0.4, 4e5])
+    assert "ensemble members failed" in str(e.value) and e.value.code <= -100
 
 
 def test_full_size_ensemble_invariants(full_size_run):
