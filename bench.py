@@ -195,7 +195,7 @@ def main():
         def solve_once():
             solver.solve_dense(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
             mode, tot = solver.last_solve_info()
-            assert mode == resolved
+            assert mode == solver.ensemble_mode()[1], (mode, solver.ensemble_mode())
             return tot
 
     def one_step():

@@ -60,6 +60,12 @@ DSH_UNROLL_N
   __shared__ double sDt[kNC * LN][64];
   __shared__ double sJ[LN * LN][64];
   const int ln = threadIdx.x;
+  // Bdf::_new tables in LDS: every lookup is indexed by the current order and sits in the serial chain of the step (h alpha_order, the error
+  // constants, the R U rescaling) — an LDS read instead of a global load there.
+  __shared__ double sAlpha[6], sGamma[6], sEc2[6], sU[kMaxOrder * 36];
+  if (ln < 6) { sAlpha[ln] = C.alpha[ln]; sGamma[ln] = C.gamma[ln]; sEc2[ln] = C.ec2[ln]; }
+  for (int k = ln; k < kMaxOrder * 36; k += 64) sU[k] = C.u[k / 36][k % 36];
+  __syncthreads();
   double Dt_p[BANDED ? kNC : 1][BANDED ? N : 1];
   double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
   auto dt_get = [&](int j, int i) __attribute__((always_inline)) -> double { if constexpr (BANDED) return Dt_p[j][i]; else return sDt[j * N + i][ln]; };
@@ -71,7 +77,7 @@ DSH_UNROLL_N
     for (int i = 0; i < N; ++i) { D[j][i] = 0.0; dt_set(j, i, 0.0); }
 DSH_UNROLL_N
   for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
-  double opc = h * C.alpha[1];  // BdfCallable::c
+  double opc = h * sAlpha[1];  // BdfCallable::c
   double A[BANDED ? 1 : N * N];
   int P[N];
   bool jac_stale = true;
@@ -136,7 +142,7 @@ DSH_UNROLL_N
 #pragma unroll
       for (int i = 1; i < 6; ++i) R[j][i] = (j == 0) ? 0.0 : R[j][i - 1] * ((double)i - 1.0 - factor * (double)j) / (double)i;
     }
-    const double* U = C.u[order - 1];  // element (row k, col j) at U[j*6 + k]
+    const double* U = sU + (order - 1) * 36;  // element (row k, col j) at U[j*6 + k]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       if (j <= order) {
@@ -162,7 +168,7 @@ DSH_UNROLL_N
     for (int j = 0; j < kNC; ++j)
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = dt_get(j, i); dt_set(j, i, tmp); }
-    opc = new_h * C.alpha[order];
+    opc = new_h * sAlpha[order];
     h = new_h;
     eta = C.r.eta_reset_ts;  // reset_eta_timestep_change
     new_h_out = new_h;
@@ -176,10 +182,10 @@ DSH_UNROLL_N
       double s = 0.0;
 #pragma unroll
       for (int j = 0; j < 6; ++j) if (j <= order) s = s + D[j][i];
-      double q = C.gamma[1] * D[1][i];
+      double q = sGamma[1] * D[1][i];
 #pragma unroll
-      for (int j = 2; j < 6; ++j) if (j <= order) q = C.gamma[j] * D[j][i] + 1.0 * q;
-      q = q * C.alpha[order];
+      for (int j = 2; j < 6; ++j) if (j <= order) q = sGamma[j] * D[j][i] + 1.0 * q;
+      q = q * sAlpha[order];
       q = q - s;
       yp[i] = s;
       psi[i] = q;
@@ -231,6 +237,7 @@ DSH_UNROLL_N
   };
 
   int col = 0;
+  double te_next = t_eval[0];  // t_eval[col], kept in a register: it is compared after every step
   // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
   {
     const int r = handle_tstop();
@@ -318,10 +325,10 @@ DSH_UNROLL_N
         if (convergence_fail) {
           double new_h;
           if (update_step_size(0.3, new_h)) { status = kRsStepSizeTooSmall; break; }
-          jacobian_updates(new_h * C.alpha[order], JState::SecondConvergenceFail);
+          jacobian_updates(new_h * sAlpha[order], JState::SecondConvergenceFail);
           predict_forward();
         } else {
-          jacobian_updates(h * C.alpha[order], JState::FirstConvergenceFail);
+          jacobian_updates(h * sAlpha[order], JState::FirstConvergenceFail);
           convergence_fail = true;
         }
         continue;
@@ -330,7 +337,7 @@ DSH_UNROLL_N
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
       // error_control (bdf.rs:812-843): norm against the CURRENT state y
-      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * C.ec2[order - 1]);
+      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * sEc2[order - 1]);
       const double maxiter = (double)o.max_nonlinear_solver_iterations;
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
@@ -356,7 +363,7 @@ DSH_UNROLL_N
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
       double new_h;
       if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
-      jacobian_updates(new_h * C.alpha[order], JState::ErrorTestFail);
+      jacobian_updates(new_h * sAlpha[order], JState::ErrorTestFail);
       predict_forward();
       n_err_fails += 1;
       if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kRsTooManyErrorTestFailures; break; }
@@ -377,8 +384,8 @@ DSH_UNROLL_N
         col_m[i] = vm; col_p[i] = vp;
       }
       const double inf = __builtin_huge_val();
-      const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * C.ec2[order - 1] : inf;
-      const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * C.ec2[order + 1] : inf;
+      const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * sEc2[order - 1] : inf;
+      const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * sEc2[order + 1] : inf;
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
       const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
       const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
@@ -395,7 +402,7 @@ DSH_UNROLL_N
       if (factor >= o.min_timestep_growth || factor <= o.max_timestep_shrink || max_index == 0 || max_index == 2) {
         double new_h;
         if (update_step_size(factor, new_h)) { status = kRsStepSizeTooSmall; break; }
-        jacobian_updates(new_h * C.alpha[new_order], JState::StepSuccess);
+        jacobian_updates(new_h * sAlpha[new_order], JState::StepSuccess);
       }
     }
     // interpolate_from_diff (bdf.rs:767-782)
@@ -423,12 +430,13 @@ DSH_UNROLL_N
     if (reason == 2) reason = 0;  // the reference unwraps / ignores this inside step()
     // ================================================================ solve_dense (method.rs:467-520): interpolated output
     const double upto = reason == 3 ? t_root : t;
-    while (col < C.r.n_eval && t_eval[col] <= upto) {
+    while (col < C.r.n_eval && te_next <= upto) {
       double yv[N];
-      interpolate(t_eval[col], yv);
+      interpolate(te_next, yv);
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
       col++;
+      if (col < C.r.n_eval) te_next = t_eval[col];
     }
     if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
       if (col < C.r.n_eval) {

@@ -3,6 +3,7 @@
 #include <cmath>
 #include "../../include/diffsol_hip_solver.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,7 @@ struct dshs_solver {
   int ensemble_mode = -1;
   int last_mode = 0;              // mode the last solve_dense actually ran in
   int64_t last_totals[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> scratch_status, scratch_ridx;
 };
 
 namespace {
@@ -126,8 +128,10 @@ int resolve_mode(const dshs_solver* s) {
   return mode;
 }
 
+// lazy: status_host is fetched only when a member failed (totals[5] != 0; it is all zero otherwise) and root_idx_host only for models with root
+// functions (all -1 otherwise): the common case of dshs_solve_dense then moves no per-member bookkeeping over PCIe at all.
 void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
-                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
+                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals, bool lazy = false) {
   const ResidentPick pk = pick_resident(s, group);
   if (!pk.ok)
     throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
@@ -189,9 +193,10 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   if (rc == DSH_OK && y_host)
     for (int64_t k = 0; k < nt && rc == DSH_OK; ++k) rc = dsh_vec_download(c, n, nb, out + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb));
   if (rc == DSH_OK && stats_host) rc = dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb);
-  if (rc == DSH_OK && status_host) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb);
+  const bool want_status = !lazy || totals[5] != 0, want_ridx = !lazy || s->problem.eqn->nroots() > 0;
+  if (rc == DSH_OK && status_host) { if (want_status) rc = dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb); else std::fill(status_host, status_host + nb, 0); }
   if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
-  if (rc == DSH_OK && root_idx_host) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb);
+  if (rc == DSH_OK && root_idx_host) { if (want_ridx) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb); else std::fill(root_idx_host, root_idx_host + nb, -1); }
   if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
   for (void* q : {tmp_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
   check(rc, "solve_dense_adaptive");
@@ -405,8 +410,9 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
     if (mode != DSHS_ENSEMBLE_LOCKSTEP) {
       // OdeSolverMethod::solve_dense (method.rs:467-520) of the whole ensemble in one launch: the state never leaves the chip.
       const int64_t nb = s->ctx.nbatch();
-      std::vector<int32_t> status((size_t)nb), ridx((size_t)nb);
-      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), nullptr, ridx.data(), nullptr, s->last_totals);
+      std::vector<int32_t>&status = s->scratch_status, &ridx = s->scratch_ridx;
+      status.resize((size_t)nb); ridx.resize((size_t)nb);
+      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), nullptr, ridx.data(), nullptr, s->last_totals, /*lazy=*/true);
       int64_t failed = 0, rooted = 0;
       int first_bad = 0;
       for (int64_t b = 0; b < nb; ++b) {

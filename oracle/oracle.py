@@ -217,6 +217,30 @@ def solve_ensemble_independent(model, p, *, model_size=0, rtol=1e-6, atol=(1e-6,
                 failed=int(counters[3]), y=y)
 
 
+def solve_ensemble_independent_fast(model, p, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, t_final=1.0, nthreads=1, want_y=True,
+                                    want_stats=False):
+    """solve_ensemble_independent on the stack-array build of the BDF (oracle_fast.hpp: same arithmetic, no per-operation allocation) — ODE
+    models with identity mass, no roots, n in (3, 4).  `stats` [nsys, 5] per member when want_stats."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    nsys, np_ = p.shape
+    a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
+    s = OracleSolver(model, p[0], model_size=model_size, rtol=rtol, atol=atol, t0=t0, h0=h0)
+    n = s.n
+    del s
+    y = np.empty((nsys, n)) if want_y else None
+    stats = np.zeros((nsys, 5), dtype=np.int64) if want_stats else None
+    counters = (C.c_long * 4)()
+    f = lib().orc_solve_ensemble_independent_fast
+    f.restype = C.c_double
+    secs = f(C.c_int(model), C.c_int(model_size), C.c_int(nsys), p.ctypes.data_as(_dp), C.c_int(np_), C.c_double(rtol), a_ptr, C.c_int(a_arr.size),
+             C.c_double(t0), C.c_double(h0), C.c_double(t_final), C.c_int(nthreads), y.ctypes.data_as(_dp) if want_y else None,
+             stats.ctypes.data_as(C.POINTER(C.c_long)) if want_stats else None, counters)
+    if secs < 0:
+        raise ValueError("oracle_fast: model does not qualify (identity mass, no roots, n in (3, 4))")
+    return dict(seconds=secs, steps=int(counters[0]), newton_iterations=int(counters[1]), lu_setups=int(counters[2]), failed=int(counters[3]), y=y,
+                stats=stats)
+
+
 def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1, group=1):
     """solve_dense per member (each its own IVP; group > 1: consecutive groups of `group` members as one lock-step batched problem each); a member
     that finds a root stops there (its next column is the state at the root, later columns NaN; see solve_dense_independent.last_roots).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""

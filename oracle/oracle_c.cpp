@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include "oracle_ode.hpp"
 #include "oracle_sdirk.hpp"
+#include "oracle_fast.hpp"
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -196,6 +197,46 @@ double orc_solve_ensemble_independent(int model_id, int model_size, int nsys, co
   for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
   for (auto& t : th) t.join();
   double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (counters_out) { counters_out[0] = steps; counters_out[1] = iters; counters_out[2] = setups; counters_out[3] = failed; }
+  return secs;
+}
+
+// The same job as orc_solve_ensemble_independent on the stack-array build of the BDF (oracle_fast.hpp): ODE models with identity mass, no
+// root function and n = 3 or 4 states (what bench.py's cpu_baseline times).  Also returns every member's own counters when stats_out
+// ([nsys][5]: steps, Newton iterations, LU setups, error-test failures, Newton failures) is given, so that the fidelity build can be compared
+// member by member.  Returns wall seconds, negative if the model does not qualify.
+double orc_solve_ensemble_independent_fast(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol,
+                                           double t0, double h0, double t_final, int nthreads, double* y_out, long* stats_out, long* counters_out) {
+  auto probe = make_model(model_id, model_size);
+  const int n = probe->n;
+  if (probe->has_mass || probe->nroots > 0 || (n != 3 && n != 4) || probe->np != np) return -1.0;
+  std::atomic<long> steps{0}, iters{0}, setups{0};
+  std::atomic<int> failed{0};
+  auto t_start = std::chrono::steady_clock::now();
+  auto work = [&](int tid) {
+    auto model = make_model(model_id, model_size);
+    const OdeSolverOptions opts;
+    long ls = 0, li = 0, lu = 0;
+    for (int s = tid; s < nsys; s += nthreads) {
+      Stats st;
+      double* yo = y_out ? y_out + (size_t)s * n : nullptr;
+      const double* ps = p + (size_t)s * np;
+      const OdeErr e = n == 3 ? fast_solve<3>(*model, ps, rtol, atol, natol, t0, h0, opts, t_final, yo, &st)
+                              : fast_solve<4>(*model, ps, rtol, atol, natol, t0, h0, opts, t_final, yo, &st);
+      if (e != OdeErr::Ok) { failed++; continue; }
+      ls += st.number_of_steps; li += st.number_of_nonlinear_solver_iterations; lu += st.number_of_linear_solver_setups;
+      if (stats_out) {
+        long* so = stats_out + (size_t)s * 5;
+        so[0] = st.number_of_steps; so[1] = st.number_of_nonlinear_solver_iterations; so[2] = st.number_of_linear_solver_setups;
+        so[3] = st.number_of_error_test_failures; so[4] = st.number_of_nonlinear_solver_fails;
+      }
+    }
+    steps += ls; iters += li; setups += lu;
+  };
+  std::vector<std::thread> th;
+  for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
+  for (auto& t : th) t.join();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (counters_out) { counters_out[0] = steps; counters_out[1] = iters; counters_out[2] = setups; counters_out[3] = failed; }
   return secs;
 }

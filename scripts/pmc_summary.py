@@ -25,7 +25,7 @@ def counters(db):
 
 def trace(db):
     con = sqlite3.connect(db)
-    return [dict(name=r[0], calls=r[1], total_us=r[2] / 1e3, avg_us=r[3] / 1e3, pct=r[4]) for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels")]
+    return [dict(name=r[0], calls=r[1], total_us=r[2], avg_us=r[3], pct=r[4]) for r in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels")]
 
 
 def main():
