@@ -3,7 +3,7 @@ integer work counters of the insta snapshots, SUNDIALS solution tables, analytic
 import numpy as np
 import pytest
 
-from helpers import METHOD, ORACLE_MODEL, times_of, weighted_error_norm
+from helpers import METHOD, ORACLE_MODEL, robertson_params, times_of, weighted_error_norm
 
 BDF_CASES = ["bdf_test_nalgebra_exponential_decay", "test_bdf_nalgebra_exponential_decay_algebraic", "test_bdf_nalgebra_robertson",
              "test_bdf_nalgebra_robertson_ode", "test_bdf_nalgebra_dydt_y2", "test_bdf_nalgebra_gaussian_decay"]
@@ -283,3 +283,30 @@ def test_deterministic_elementary_functions_are_within_a_few_ulp_of_libm(O):
     x = rng.uniform(-2000.0, 2000.0, 20000)
     assert np.max(np.abs(O.det_fn("sin", x) - np.sin(x))) <= 2.3e-16  # absolute: sin has zeros
     assert O.det_fn("sin", [0.0])[0] == 0.0 and O.det_fn("tanh", [0.0, 30.0, -30.0]).tolist() == [0.0, 1.0, -1.0] and O.det_fn("asinh", [0.0])[0] == 0.0
+
+
+@pytest.mark.parametrize("det", [False, True])
+def test_stack_array_build_of_the_oracle_bdf_is_bit_identical_to_the_fidelity_build(O, det):
+    """oracle/oracle_fast.hpp (what bench.py's cpu_baseline times) restates oracle_ode.hpp's Bdf on fixed-size stack arrays: same arithmetic in the same
+    order, so the final state and every counter of every member equal the fidelity build's, with libm's pow and with include/diffsol_detpow.h."""
+    p = robertson_params(96, seed=31)
+    kw = dict(model_size=1, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    O.set_det_pow(det)
+    try:
+        fast = O.solve_ensemble_independent_fast(O.MODEL_ROBERTSON_ODE, p, t_final=4e5, nthreads=2, want_stats=True, **kw)
+        slow = O.solve_ensemble_independent(O.MODEL_ROBERTSON_ODE, p, t_final=4e5, nthreads=2, **kw)
+        assert fast["failed"] == 0 and slow["failed"] == 0 and np.array_equal(fast["y"], slow["y"])
+        assert (fast["steps"], fast["newton_iterations"], fast["lu_setups"]) == (slow["steps"], slow["newton_iterations"], slow["lu_setups"])
+        # member by member against solve_dense of the fidelity build: all five counters (its output column is the interpolant at t_final, whereas solve()
+        # returns state.y, which bdf.rs:1473 sets to y_predict — the two differ by the last Newton correction in the reference too)
+        _, so, failed = O.solve_dense_independent(O.MODEL_ROBERTSON_ODE, p[:24], [4e5], **kw)
+        assert failed == 0 and np.array_equal(so, fast["stats"][:24])
+        # tight tolerance, long horizon: many order changes and step-size rescalings
+        kw2 = dict(model_size=1, rtol=1e-8, atol=[1e-10, 1e-16, 1e-8])
+        f2 = O.solve_ensemble_independent_fast(O.MODEL_ROBERTSON_ODE, p[:8], t_final=4e10, **kw2)
+        s2 = O.solve_ensemble_independent(O.MODEL_ROBERTSON_ODE, p[:8], t_final=4e10, **kw2)
+        assert np.array_equal(f2["y"], s2["y"]) and f2["steps"] == s2["steps"] and f2["newton_iterations"] == s2["newton_iterations"]
+    finally:
+        O.set_det_pow(False)
+    with pytest.raises(ValueError):
+        O.solve_ensemble_independent_fast(O.MODEL_ROBERTSON_DAE, p[:2], t_final=1.0, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
