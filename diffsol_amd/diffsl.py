@@ -23,8 +23,11 @@ def generate(code, target):
     L = _ffi.load_host_lib()
     out = vp()
     dims = (C.c_int64 * 10)()
-    defaults = (C.c_double * 256)()
-    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, defaults, 256), host=True)
+    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, None, 0), host=True)  # dimensions first: one default per declared input
+    L.dshs_free_string(out)
+    ndef = max(int(dims[1]), 1)
+    defaults = (C.c_double * ndef)()
+    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, defaults, ndef), host=True)
     try:
         src = C.string_at(out).decode()
     finally:

@@ -272,7 +272,9 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   // dimensions first (any target), then the form that fits them
   char* src = nullptr;
   int64_t dims[10];
-  std::vector<double> defaults(256, 0.0);
+  if (dshs_diffsl_generate(code, DSHS_DIFFSL_HOST_C, &src, dims, nullptr, 0) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
+  dshs_free_string(src);
+  std::vector<double> defaults((size_t)std::max<int64_t>(dims[1], 1), 0.0);  // one default per declared input, however many there are
   if (dshs_diffsl_generate(code, DSHS_DIFFSL_HOST_C, &src, dims, defaults.data(), (int64_t)defaults.size()) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
   dshs_free_string(src);
   const bool is_static = dims[0] <= 8 && dims[2] <= 1;

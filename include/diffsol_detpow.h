@@ -212,14 +212,67 @@ DSH_DETPOW_FN double dsh_det_asinh(double x) {
   }
   return x < 0.0 ? -r : r;
 }
-/* sin(x + shift pi/2) for |x| up to ~1e6: Cody-Waite reduction by pi/2 in three parts, Taylor kernels on [-pi/4, pi/4] */
-DSH_DETPOW_FN double dsh_detpow_sincos(double ax, int shift) {
-  const double t = ax * 0.63661977236758138 + 0.5;
-  const double kf = (double)(long long)t; /* ax >= 0: truncation is floor */
-  const long long k = (long long)kf + shift;
-  /* pi/2 = c1 + c2 + c3, c1 and c2 with trailing zero bits so that k*c1, k*c2 are exact for k < 2^20 */
-  const double c1 = 1.5707963267341256, c2 = 6.07710050630396597660e-11, c3 = 2.02226624879595063154e-21;
-  const double r = ((ax - kf * c1) - kf * c2) - kf * c3;
+/* 64 x 64 -> 128 bit product from 32-bit pieces (the same integer instructions under gcc, hipcc and hiprtc) */
+DSH_DETPOW_FN void dsh_detpow_mul64(unsigned long long a, unsigned long long b, unsigned long long* hi, unsigned long long* lo) {
+  const unsigned long long a0 = a & 0xffffffffull, a1 = a >> 32, b0 = b & 0xffffffffull, b1 = b >> 32;
+  const unsigned long long p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const unsigned long long mid = (p00 >> 32) + (p01 & 0xffffffffull) + (p10 & 0xffffffffull);
+  *lo = (p00 & 0xffffffffull) | (mid << 32);
+  *hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+/* Payne-Hanek reduction for finite ax >= 2^20 (beyond the three-part Cody-Waite range): ax = M 2^E with a 53-bit integer M; the 192 bits of 2/pi
+ * that decide (ax 2/pi) mod 4 and its first 128 fraction bits are multiplied by M in integer arithmetic.  Returns r in [-pi/4, pi/4] with
+ * ax = (k + 4j) pi/2 + r, *kq = k.  Integer work plus a handful of IEEE operations in a fixed order: the same bits on host and device. */
+DSH_DETPOW_FN double dsh_detpow_reduce_large(double ax, int* kq) {
+  /* fraction bits of 2/pi, most significant first (1280 bits) */
+  const unsigned long long T[20] = {0xa2f9836e4e441529ull, 0xfc2757d1f534ddc0ull, 0xdb6295993c439041ull, 0xfe5163abdebbc561ull, 0xb7246e3a424dd2e0ull,
+                                    0x06492eea09d1921cull, 0xfe1deb1cb129a73eull, 0xe88235f52ebb4484ull, 0xe99c7026b45f7e41ull, 0x3991d639835339f4ull,
+                                    0x9c845f8bbdf9283bull, 0x1ff897ffde05980full, 0xef2f118b5a0a6d1full, 0x6d367ecf27cb09b7ull, 0x4f463f669e5fea2dull,
+                                    0x7527bac7ebe5f17bull, 0x3d0739f78a5292eaull, 0x6bfb5fb11f8d5d08ull, 0x56033046fc7b6babull, 0xf0cfbc209af4361dull};
+  const unsigned long long bits = dsh_detpow_bits(ax);
+  const int E = (int)((bits >> 52) & 0x7ff) - 1075;
+  const unsigned long long M = (bits & 0xfffffffffffffull) | 0x10000000000000ull;
+  /* window: bits s+1 .. s+192 of the fraction of 2/pi, s = E - 2 (bits above contribute multiples of 4 to M 2^E 2/pi) */
+  const int s = E - 2;
+  unsigned long long w0, w1, w2;
+  if (s >= 0) {
+    const int q = s >> 6, sh = s & 63;
+    if (sh == 0) { w0 = T[q]; w1 = T[q + 1]; w2 = T[q + 2]; }
+    else { w0 = (T[q] << sh) | (T[q + 1] >> (64 - sh)); w1 = (T[q + 1] << sh) | (T[q + 2] >> (64 - sh)); w2 = (T[q + 2] << sh) | (T[q + 3] >> (64 - sh)); }
+  } else {
+    const int n = -s; /* 1 .. 35 leading zero bits */
+    w0 = T[0] >> n; w1 = (T[0] << (64 - n)) | (T[1] >> n); w2 = (T[1] << (64 - n)) | (T[2] >> n);
+  }
+  /* P = M (w0 2^128 + w1 2^64 + w2) mod 2^192; integer part mod 4 = bits 190..191, fraction = bits 0..189 */
+  unsigned long long h2, l2, h1, l1, h0, l0;
+  dsh_detpow_mul64(M, w2, &h2, &l2);
+  dsh_detpow_mul64(M, w1, &h1, &l1);
+  dsh_detpow_mul64(M, w0, &h0, &l0);
+  (void)h0;
+  const unsigned long long p0 = l2;
+  const unsigned long long p1 = h2 + l1;
+  const unsigned long long c1 = p1 < h2 ? 1ull : 0ull;
+  const unsigned long long p2 = h1 + l0 + c1;
+  int k = (int)(p2 >> 62);
+  unsigned long long fh = (p2 << 2) | (p1 >> 62), fl = (p1 << 2) | (p0 >> 62); /* 128 fraction bits */
+  int neg = 0;
+  if (fh >> 63) { /* fraction >= 1/2: next quadrant, negative remainder */
+    k += 1;
+    neg = 1;
+    fl = ~fl + 1ull;
+    fh = ~fh + (fl == 0ull ? 1ull : 0ull);
+  }
+  /* fraction = a 2^-53 + b 2^-106 + c 2^-128, every piece exact in a double */
+  const double a = (double)(long long)(fh >> 11);
+  const double b = (double)(long long)(((fh & 0x7ffull) << 42) | (fl >> 22));
+  const double c = (double)(long long)(fl & 0x3fffffull);
+  const double fa = a * 1.1102230246251565e-16, fb = b * 1.2325951644078309e-32, fc = c * 2.9387358770557188e-39; /* 2^-53, 2^-106, 2^-128 */
+  const double ph = 1.5707963267948966, pl = 6.123233995736766e-17; /* pi/2 = ph + pl */
+  const double r = fa * ph + ((fa * pl + fb * ph) + fc * ph);
+  *kq = k & 3;
+  return neg ? -r : r;
+}
+DSH_DETPOW_FN double dsh_detpow_sincos_kernel(double r, long long k) {
   const double r2 = r * r;
   double sn = -1.0 / 355687428096000.0; /* r^17/17! */
   sn = sn * r2 + 1.0 / 1307674368000.0;
@@ -245,17 +298,33 @@ DSH_DETPOW_FN double dsh_detpow_sincos(double ax, int shift) {
     default: return -c_r;
   }
 }
+/* sin(ax + shift pi/2), ax >= 0 finite: Cody-Waite reduction by pi/2 in three parts up to 1e6 (k c1, k c2 exact for k < 2^20), Payne-Hanek above;
+ * Taylor kernels on [-pi/4, pi/4] */
+DSH_DETPOW_FN double dsh_detpow_sincos(double ax, int shift) {
+  if (ax > 1.0e6) {
+    int kq;
+    const double rl = dsh_detpow_reduce_large(ax, &kq);
+    return dsh_detpow_sincos_kernel(rl, (long long)(kq + shift));
+  }
+  const double t = ax * 0.63661977236758138 + 0.5;
+  const double kf = (double)(long long)t; /* ax >= 0: truncation is floor */
+  const long long k = (long long)kf + shift;
+  /* pi/2 = c1 + c2 + c3, c1 and c2 with trailing zero bits so that k*c1, k*c2 are exact for k < 2^20 */
+  const double c1 = 1.5707963267341256, c2 = 6.07710050630396597660e-11, c3 = 2.02226624879595063154e-21;
+  const double r = ((ax - kf * c1) - kf * c2) - kf * c3;
+  return dsh_detpow_sincos_kernel(r, k);
+}
 DSH_DETPOW_FN double dsh_det_sin(double x) {
-  if (x != x) return x;
+  if (x != x || x == 0.0) return x; /* NaN; sin(+-0) = +-0 */
   const double ax = x < 0.0 ? -x : x;
-  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull); /* outside the supported range */
+  if (ax > 1.7976931348623157e308) return dsh_detpow_from_bits(0x7ff8000000000000ull); /* sin(inf) */
   const double v = dsh_detpow_sincos(ax, 0);
   return x < 0.0 ? -v : v;
 }
 DSH_DETPOW_FN double dsh_det_cos(double x) {
   if (x != x) return x;
   const double ax = x < 0.0 ? -x : x;
-  if (ax > 1.0e6) return dsh_detpow_from_bits(0x7ff8000000000000ull);
+  if (ax > 1.7976931348623157e308) return dsh_detpow_from_bits(0x7ff8000000000000ull);
   return dsh_detpow_sincos(ax, 1);
 }
 DSH_DETPOW_FN double dsh_det_tan(double x) { return dsh_det_sin(x) / dsh_det_cos(x); }

@@ -338,7 +338,7 @@ def model_root(model, x, p, t=0.0, model_size=0, max_roots=4):
     return g[:k]
 
 
-DET_FN = {"exp": 0, "log": 1, "tanh": 2, "asinh": 3, "sin": 4}
+DET_FN = {"exp": 0, "log": 1, "tanh": 2, "asinh": 3, "sin": 4, "cos": 5}
 
 
 def det_fn(name, x):

@@ -407,13 +407,14 @@ int orc_model_root(int model_id, int model_size, const double* x, const double* 
   m->root(x, p, t, g);
   return m->nroots;
 }
-// the deterministic elementary functions of include/diffsol_detpow.h the registry models are written with: 0 exp, 1 log, 2 tanh, 3 asinh, 4 sin
+// the deterministic elementary functions of include/diffsol_detpow.h the registry models are written with: 0 exp, 1 log, 2 tanh, 3 asinh, 4 sin, 5 cos
 double orc_det_fn(int which, double x) {
   switch (which) {
     case 0: return dsh_det_exp(x);
     case 1: return dsh_det_log(x);
     case 2: return dsh_det_tanh(x);
     case 3: return dsh_det_asinh(x);
+    case 5: return dsh_det_cos(x);
     default: return dsh_det_sin(x);
   }
 }

@@ -98,12 +98,30 @@ def test_oracle_solves_the_diffsl_robertson_like_the_built_in_one(O, fe, kats):
     ("u_i { x = 1 } F_i { x ", "expected"),
     ("A_ij { (0,0): 1, (1,1): 2 } b_i { 1, 2 } u_i { x = 1, y = 1 } F_i { A_ij * u_j + b_i }", "does not appear in every term"),
     ("A_ij { (0,0): 1, (1,1): 2 } u_i { x = 1, y = 1 } F_i { A_i * u_i }", "has rank 2"),
+    # hybrid models must be refused, not silently integrated to the first root (crates/diffsol-c/tests/hybrid_logistic_jit.rs,
+    # examples/bouncing-ball-declarative use reset_i; the model index N)
+    ("in_i { r = 1 } u_i { y = 0.1 } dudt_i { dydt = 0 } F_i { (r * y) * (1 - y) } stop_i { y - 0.9 } reset_i { 0.1 } out_i { y }", "reset_i / hybrid models are not supported"),
+    ("u_i { x = 1 } F_i { x * N }", "model index N is not supported"),
+    ("N { 1 } u_i { x = 1 } F_i { x }", "model index N is reserved"),
+    # M_i has to be LINEAR in dudt (the mass matrix is assembled from unit vectors)
+    ("u_i { x = 1, y = 2 } dudt_i { dxdt = 0, dydt = 0 } M_i { dxdt * dxdt, 0 } F_i { x, y }", "must be linear in dudt"),
+    ("u_i { x = 1, y = 2 } dudt_i { dxdt = 0, dydt = 0 } M_i { dxdt + 1, dydt } F_i { x, y }", "must be linear in dudt"),
+    ("u_i { x = 1, y = 2 } dudt_i { dxdt = 0, dydt = 0 } M_i { sin(dxdt), dydt } F_i { x, y }", "must be linear in dudt"),
+    ("u_i { x = 1 } F_i { " + "-" * 300 + "x }", "nested too deeply"),
+    ("u_i { x = 1 } F_i { " + "(" * 300 + "x" + ")" * 300 + " }", "nested too deeply"),
 ])
 def test_front_end_rejects_malformed_models_with_a_located_message(fe, code, msg):
     from diffsol_amd import DiffsolHipError
     with pytest.raises(DiffsolHipError) as e:
         fe.generate(code, fe.TARGET_HOST_C)
     assert msg in str(e.value) and "diffsl:" in str(e.value)
+
+
+def test_linear_mass_matrices_with_parameter_coefficients_are_accepted(fe):
+    """the linearity check must not reject what the reference's models use: sums of dudt terms with constant / parameter / time coefficients, zero rows"""
+    code = "in = [c] c { 2.0 } u_i { x = 1, y = 2, z = 0 } dudt_i { dxdt = 0, dydt = 0, dzdt = 0 } M_i { c * dxdt + dydt / 3 - (t + 1) * dxdt, -dydt, 0 } F_i { x, y, x + y + z }"
+    src, dims, _ = fe.generate(code, fe.TARGET_HOST_C)
+    assert dims["has_mass"] and dims["n"] == 3
 
 
 def test_language_rules_ranges_labels_broadcast_contraction_and_defaults(O, fe):

@@ -311,3 +311,31 @@ def test_a_model_that_does_not_compile_is_rejected_with_the_compiler_log(H, fe):
     good = fe.generate(D.LOGISTIC, fe.TARGET_HIP_STATIC)[0]
     rc = L.dsh_model_compile(good.encode(), 0, 3, 2, 1, 0, 0, C.byref(mid))  # wrong n for this source
     assert rc < 0 and b"dimensions do not match" in L.dsh_last_error()
+
+
+def test_fast_forcing_terms_sin_cos_of_huge_arguments_are_the_same_bits_on_device_and_host_and_close_to_libm(H, O, fe):
+    """a forcing term sin(w t) with w t > 1e6 (a 1 MHz source integrated for 1 s) used to return NaN.  The deterministic sin / cos now
+    reduce large arguments with an integer Payne-Hanek step: device == host twin bit for bit, within 2 ulp of libm, over the whole double range."""
+    code = """
+    in = [w]
+    w { 1.0 }
+    u_i { x = 1.0, y = 0.0, z = 0.0 }
+    F_i { sin(w * t) - x, cos(w * t) - y, tan(w * t) * 0.0 + sin(-w * t) - z }
+    """
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    m = fe.DiffslModel(code)
+    mid = D.host_model(O, code)
+    rng = np.random.default_rng(8)
+    w = np.concatenate([10.0 ** rng.uniform(6, 300, 120), [1e9, 1e22, 2.0 ** 1023, 1e6 + 0.5]])
+    nb, t = len(w), 1.0
+    c = H.HipContext(nbatch=nb)
+    x = np.zeros((nb, 3))
+    X, P, Y = H.HipVec.from_vec(x, c), H.HipVec.from_vec(w[:, None], c), H.HipVec.zeros(3, c)
+    assert L.dsh_model_rhs(c._h, m.model_id, 0, nb, t, X.ptr, P.ptr, Y.ptr) == 0
+    dev = Y.clone_as_vec()
+    host = np.stack([O.model_rhs(mid, x[b], w[b:b + 1], t) for b in range(nb)])
+    assert np.isfinite(dev).all() and np.array_equal(dev, host)
+    assert np.max(np.abs(dev[:, 0] - np.sin(w)) / np.spacing(np.abs(np.sin(w)))) <= 3.0
+    assert np.max(np.abs(dev[:, 1] - np.cos(w)) / np.spacing(np.abs(np.cos(w)))) <= 3.0
+    assert np.array_equal(dev[:, 2], -dev[:, 0])  # odd symmetry (the tan term only checks that tan of a huge argument is finite)

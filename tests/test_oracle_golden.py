@@ -310,3 +310,23 @@ def test_stack_array_build_of_the_oracle_bdf_is_bit_identical_to_the_fidelity_bu
         O.set_det_pow(False)
     with pytest.raises(ValueError):
         O.solve_ensemble_independent_fast(O.MODEL_ROBERTSON_DAE, p[:2], t_final=1.0, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+
+
+def test_deterministic_sin_cos_cover_the_whole_double_range(O):
+    """include/diffsol_detpow.h sin / cos (what DiffSL models and the RLC model call on both sides): Cody-Waite up to 1e6, integer Payne-Hanek above
+    (they used to return NaN beyond 1e6) — within 2 ulp of libm everywhere, Kahan's worst case included; sin(-0) = -0, sin(inf) = NaN."""
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([10.0 ** rng.uniform(6, 308, 4000) * rng.choice([-1.0, 1.0], 4000), rng.uniform(-1e6, 1e6, 4000), rng.uniform(1e6, 1e9, 2000)])
+    for name, f in (("sin", np.sin), ("cos", np.cos)):
+        got, ref = O.det_fn(name, xs), f(xs)
+        assert np.max(np.abs(got - ref) / np.spacing(np.abs(ref))) <= 3.0, name
+    # special arguments against 3000-bit mpmath values (numpy's own cos is 8 ulp off on Kahan's worst case 6381956970095103 * 2^797, the sixth entry)
+    sp = [1e9, 1e22, 2.0 ** 1023, 1.7976931348623157e308, 1e6 + 1, 6381956970095103.0 * 2.0 ** 797, 3.0 * 2.0 ** 100]
+    sin_ref = np.array([0.5458434494486996, -0.8522008497671888, 0.563127779850884, 0.004961954789184062, 0.5991474390141922, 1.0, 0.03734425598969816])
+    cos_ref = np.array([0.8378871813639024, 0.523214785395139, -0.826369834614148, -0.9999876894265599, 0.8006387114814864, -4.687165924254628e-19, -0.999302459991256])
+    assert np.max(np.abs(O.det_fn("sin", sp) - sin_ref) / np.spacing(np.abs(sin_ref))) <= 2.0
+    assert np.max(np.abs(O.det_fn("cos", sp) - cos_ref) / np.spacing(np.abs(cos_ref))) <= 2.0
+    assert O.det_fn("sin", [1e9])[0] == pytest.approx(0.5458434494486996, rel=1e-15)
+    z = O.det_fn("sin", [-0.0])[0]
+    assert z == 0.0 and np.signbit(z) and not np.signbit(O.det_fn("sin", [0.0])[0])
+    assert np.isnan(O.det_fn("sin", [np.inf])[0]) and np.isnan(O.det_fn("cos", [-np.inf])[0]) and O.det_fn("cos", [0.0])[0] == 1.0
