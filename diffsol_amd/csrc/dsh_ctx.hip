@@ -2,6 +2,7 @@
 // Replaces CudaContext (diffsol-la/src/context/cuda.rs:41-144) and the cudarc driver calls listed in SURVEY §2a.
 #include "dsh_internal.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 #include <cstring>
@@ -79,10 +80,10 @@ int ensure_f64_scratch(dsh_ctx* ctx, int64_t len) {
 using namespace dsh;
 
 // [b][i] (host order) <-> [i][b] (device order) through a padded LDS tile so both sides stay coalesced
-__global__ void k_transpose(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int64_t cols) {
+__global__ void k_transpose(const double* __restrict__ src, double* __restrict__ dst, int64_t rows, int64_t cols, int64_t row_block0) {
   // src is rows x cols row-major; dst is cols x rows row-major
   __shared__ double tile[32][33];
-  int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (row_block0 + (int64_t)blockIdx.y) * 32;
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
   for (int k = ty; k < 32; k += 8) {
     int64_t r = r0 + k, c = c0 + tx;
@@ -97,8 +98,13 @@ __global__ void k_transpose(const double* __restrict__ src, double* __restrict__
 
 static int launch_transpose(dsh_ctx* ctx, const double* src, double* dst, int64_t rows, int64_t cols) {
   if (rows == 0 || cols == 0) return DSH_OK;
-  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, src, dst, rows, cols);
+  // grid.y holds at most 65535 row tiles: ensembles beyond 2.09M members (rows = nbatch on upload) go in several launches
+  const int64_t row_tiles = (rows + 31) / 32, col_tiles = (cols + 31) / 32;
+  DSH_REQUIRE(col_tiles <= 2147483647LL, "transpose: too many columns");
+  for (int64_t rb = 0; rb < row_tiles; rb += 65535) {
+    dim3 grid((unsigned)col_tiles, (unsigned)std::min<int64_t>(65535, row_tiles - rb));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, ctx->stream, src, dst, rows, cols, rb);
+  }
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
@@ -113,6 +119,18 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   int count = 0;
   DSH_HIP_CHECK(hipGetDeviceCount(&count));
   DSH_REQUIRE(device >= 0 && device < count, "no such HIP device (a gfx950 GPU is required; there is no CPU fallback)");
+  {
+    // One process per GPU: launches do not switch devices, and run-time-compiled modules / function attributes are loaded once per
+    // process.  A second context on ANOTHER device in the same process would launch on the wrong device: refuse it instead.
+    static std::mutex mu;
+    static int first_device = -1;
+    std::lock_guard<std::mutex> lk(mu);
+    if (first_device < 0) first_device = device;
+    if (device != first_device) {
+      set_error("dsh_ctx_create: this process already uses HIP device " + std::to_string(first_device) + "; the backend runs one process per GPU (use one rank per device)");
+      return DSH_E_UNSUPPORTED;
+    }
+  }
   DSH_HIP_CHECK(hipSetDevice(device));
   dsh_ctx* ctx = new dsh_ctx();
   ctx->device = device;

@@ -88,8 +88,30 @@ uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
 uint64_t headers_fingerprint() {
   static const uint64_t fp = [] {
     uint64_t h = 1469598103934665603ull;
-    const std::string d = lib_dir();
-    for (const std::string& pat : {d + "/../csrc/*.hpp", d + "/../../include/*.h"}) {
+    // the toolchain that generates the code: a ROCm upgrade must not load code objects of the previous compiler
+    int rtc_major = 0, rtc_minor = 0, hip_rt = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    (void)hipRuntimeGetVersion(&hip_rt);
+    const int ver[3] = {rtc_major, rtc_minor, hip_rt};
+    h = fnv1a((const char*)ver, sizeof ver, h);
+    // every resolved include option (ROCM_PATH, clang resource directory, DSH_JIT_INCLUDE) ...
+    std::vector<std::string> pats;
+    // (not the two package-relative directories: their CONTENTS are hashed below, and the in-tree cache must stay valid when the tree is copied)
+    const std::string own = "-I" + lib_dir();
+    for (const std::string& o : include_options()) if (o.rfind(own, 0) != 0) h = fnv1a(o.data(), o.size() + 1, h);
+    // ... and the contents of the library's own headers in the directories the compilation will read them from
+    const char* over = std::getenv("DSH_JIT_INCLUDE");
+    if (over && *over) {
+      for (const std::string& o : include_options()) {
+        if (o.rfind("-I", 0) != 0 || o.find("/lib/llvm/") != std::string::npos || o == std::string("-I") + (std::getenv("ROCM_PATH") && *std::getenv("ROCM_PATH") ? std::getenv("ROCM_PATH") : "/opt/rocm") + "/include") continue;
+        pats.push_back(o.substr(2) + "/dsh_*.hpp");
+        pats.push_back(o.substr(2) + "/diffsol_*.h");
+      }
+    } else {
+      const std::string d = lib_dir();
+      pats = {d + "/../csrc/*.hpp", d + "/../../include/*.h"};
+    }
+    for (const std::string& pat : pats) {
       glob_t g;
       if (glob(pat.c_str(), 0, nullptr, &g) != 0) continue;
       for (size_t i = 0; i < g.gl_pathc; ++i) {
@@ -248,10 +270,13 @@ const std::vector<std::string>& jit_static_op_names() {
 }
 
 const JitInfo* jit_info(int model) {
+  // a copy taken under the registry lock, per calling thread: the pointer stays valid if another thread releases the model meanwhile
+  thread_local JitInfo copy;
   std::lock_guard<std::mutex> lk(g_mu);
   JitModelRec* rec = find_model(model);
   if (!rec) { set_error("unknown run-time-compiled model id " + std::to_string(model)); return nullptr; }
-  return &rec->info;
+  copy = rec->info;
+  return &copy;
 }
 
 int jit_get_function(int model, const char* header, const std::string& group_key, const std::vector<std::string>& group, const std::string& name,

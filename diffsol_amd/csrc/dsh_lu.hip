@@ -186,6 +186,7 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
         }
       }
       // system-major copy of the operand, then factor in place
+      DSH_REQUIRE((n * n + 31) / 32 <= 65535, "dsh_lu_factor: n > 1448 exceeds the launch geometry of the operand transpose (grid.y)");
       dim3 tg((unsigned)((nb + 31) / 32), (unsigned)((n * n + 31) / 32));
       hipLaunchKernelGGL(k_soa_to_aos, tg, dim3(256), 0, ctx->stream, n * n, nb, a, lu->factors);
       if (n <= 64) {  // one system per (part of a) wavefront, rows in registers
@@ -199,7 +200,8 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
 #undef DSH_LU_WAVE
       } else {  // one workgroup per system
         const size_t budget = 140 * 1024;
-        static bool attr_set = false;
+        static bool attr_set_dev[64] = {false};  // hipFuncSetAttribute applies per device
+        bool& attr_set = attr_set_dev[ctx->device & 63];
         static const int wg_threads = [] { const char* e = getenv("DSH_LU_BLOCKED_THREADS"); return e ? atoi(e) : 0; }();  // tuning knob: 256 | 512
         // measured (profiles/r01_lu_bench.md): 512 threads win for n around 512 (58 vs 71 ms at 512 x 4096), lose below 384 and at 1024
         const int threads = wg_threads == 256 || wg_threads == 512 ? wg_threads : (n >= 384 && n < 900 ? 512 : 256);
