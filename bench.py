@@ -59,7 +59,10 @@ def cpu_baseline(params, sample):
     the line-by-line restatement oracle_ode.hpp by tests/test_oracle_golden.py — on a bounded sample of the same sweep."""
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))  # the CPUs this process may run on (a container is often confined to fewer than os.cpu_count())
+    except AttributeError:
+        cores = os.cpu_count() or 1
     p = params[:sample]
     kw = dict(model_size=1, rtol=RTOL, atol=ATOL, t_final=T_EVAL[-1], want_y=False)
     fast = hasattr(O, "solve_ensemble_independent_fast")
@@ -68,7 +71,7 @@ def cpu_baseline(params, sample):
     n1 = max(1, min(sample, 2000 if fast else 200))
     r1 = run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
     rec = {
-        "value": r["steps"] / r["seconds"], "unit": "ODE steps/s", "cores": cores, "kind": "port",
+        "value": r["steps"] / r["seconds"], "unit": "ODE steps/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
         "newton_solves_per_sec": r["newton_iterations"] / r["seconds"], "seconds": r["seconds"],
         "sample": f"first {sample} members of the same Robertson sweep, one independent BDF solve per member to t={T_EVAL[-1]:g} "
                   f"({'oracle_fast.hpp: stack-array build of the' if fast else ''} C++ restatement of diffsol Bdf+NalgebraLU), {cores} std::threads, static partition",
