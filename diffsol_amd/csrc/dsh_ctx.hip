@@ -308,5 +308,19 @@ int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_
   DSH_REQUIRE(b >= 0 && b < nbatch && i >= 0, "index out of range");
   return dsh_h2d(ctx, v + i * nbatch + b, &value, sizeof(double));
 }
+// One member of a batched vector as a contiguous vector with nbatch = 1 and back (Vector::get_batch / get_batch_mut, vector/mod.rs:227-231): with the
+// batch-fastest layout member b is the stride-nbatch slice v[i * nbatch + b]; a stream-ordered strided copy, no kernel.
+int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t b, double* dst) {
+  DSH_REQUIRE(ctx != nullptr && b >= 0 && b < nbatch && n >= 0, "batch index out of range");
+  if (n == 0) return DSH_OK;
+  DSH_HIP_CHECK(hipMemcpy2DAsync(dst, sizeof(double), v + b, sizeof(double) * (size_t)nbatch, sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  return DSH_OK;
+}
+int dsh_vec_insert_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, int64_t b, const double* src) {
+  DSH_REQUIRE(ctx != nullptr && b >= 0 && b < nbatch && n >= 0, "batch index out of range");
+  if (n == 0) return DSH_OK;
+  DSH_HIP_CHECK(hipMemcpy2DAsync(v + b, sizeof(double) * (size_t)nbatch, src, sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  return DSH_OK;
+}
 
 }  // extern "C"

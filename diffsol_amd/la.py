@@ -215,6 +215,18 @@ class HipVec:
         check(self.ctx._L.dsh_vec_get_index(self.ctx._h, 1, self.ptr, i, 0, C.byref(out)))
         return out.value
 
+    def get_batch(self, b):
+        """Vector::get_batch (vector/mod.rs:227): member b as an owned vector with nbatch = 1 (dsh_vec_extract_batch)."""
+        out = HipVec(self.ctx.clone_with_nbatch(1), self.n)
+        check(self.ctx._L.dsh_vec_extract_batch(self.ctx._h, self.n, self.nb, self.ptr, b, out.ptr))
+        return out
+
+    def set_batch(self, b, v):
+        """write-back of a get_batch_mut view: member b <- v (nbatch 1)"""
+        if v.n != self.n or v.nb != 1:
+            raise DiffsolHipError(-1, "set_batch needs a vector of the same length with nbatch == 1")
+        check(self.ctx._L.dsh_vec_insert_batch(self.ctx._h, self.n, self.nb, self.ptr, b, v.ptr))
+
     def set_index(self, i, v):
         if not 0 <= i < self.n:
             raise DiffsolHipError(-1, "index out of bounds")

@@ -85,6 +85,10 @@ int dsh_vec_download(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* dev,
 /* Vector::get_index / set_index (vector/cuda.rs:762-779): one element of one batch member */
 int dsh_vec_get_index(dsh_ctx* ctx, int64_t nbatch, const double* v, int64_t i, int64_t b, double* out);
 int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_t b, double value);
+/* Vector::get_batch / get_batch_mut (vector/mod.rs:227-231): member b of a batched vector as a contiguous vector with nbatch = 1, and back
+ * (stream-ordered strided copies; with the batch-fastest layout member b is v[i * nbatch + b]). */
+int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t b, double* dst);
+int dsh_vec_insert_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, int64_t b, const double* src);
 /* set element i of EVERY batch member to `value` (the reference does nbatch H2D copies for this, vector/cuda.rs:762-774) */
 int dsh_vec_set_index_all(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, double value);
 

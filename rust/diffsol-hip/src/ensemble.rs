@@ -1,0 +1,139 @@
+//! `solve_dense` of a whole ensemble in ONE launch: the device-resident integrators of libdiffsol_hip.so
+//! (`dsh_bdf_solve_adaptive`, `dsh_sdirk_solve_resident`, `dsh_bdf_solve_wave_member`).  diffsol's generic `Bdf` / `Sdirk` on `HipVec` / `HipMat` /
+//! `HipLU` advance the ensemble in lock-step with one host round trip per reduction; here `Bdf::step` / `Sdirk::step`, `NewtonNonlinearSolver`,
+//! `Convergence`, `JacobianUpdate`, `RootFinder` and `OdeSolverMethod::solve_dense` (method.rs:467-520) run per member — or per 64-member wavefront
+//! group, the reference's batched semantics at nbatch = 64 — with the solver state in registers.  Results are bit-identical to the CPU restatement
+//! of the reference algorithm (oracle/, tests/test_gpu_adaptive.py).
+use crate::equations::HipModelEquations;
+use crate::error::{check, last_error};
+use crate::ffi;
+use crate::matrix::HipMat;
+use diffsol::OdeSolverProblem;
+use diffsol_la::error::LaError;
+use diffsol_la::matrix::Matrix;
+use diffsol_la::{Context, Vector};
+use std::os::raw::c_void;
+use std::ptr;
+
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Method {
+    Bdf = 0,
+    TrBdf2 = 1,
+    Esdirk34 = 2,
+}
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum EnsembleMode {
+    /// every member its own step-size / order history and its own event time: diffsol's CPU semantics for a sweep of independent IVPs
+    PerMember = 1,
+    /// the 64 members of a wavefront in lock-step (max-norms over the group): the reference's batched semantics with nbatch = 64
+    Wavefront = 64,
+}
+
+/// Interpolated solution at `t_eval` plus per-member bookkeeping.
+pub struct EnsembleSolution {
+    /// `nstates x t_eval.len()` batched matrix: column k = the states at `t_eval[k]` (NaN after a member's own stop)
+    pub ys: HipMat,
+    /// 0 = ok, else the `OdeSolverError` ordinal of the member's failure (20: members of a lock-step group disagree on a root, 99: step guard)
+    pub status: Vec<i32>,
+    /// root time (NaN if none), root index (-1 if none) and number of valid columns per member
+    pub t_root: Vec<f64>,
+    pub root_index: Vec<i32>,
+    pub ncols: Vec<i32>,
+    /// [steps, Newton iterations, LU setups, error-test failures, Newton failures] per member
+    pub stats: Vec<[i32; 5]>,
+    /// the same counters summed over members + number of failed members
+    pub totals: [i64; 6],
+}
+
+/// `problem.bdf()/tr_bdf2()/esdirk34()` + `solve_dense(t_eval)` for every member, on the device.  Uses the problem's tolerances, options, t0 and h0.
+pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, method: Method, t_eval: &[f64], mode: EnsembleMode) -> Result<EnsembleSolution, LaError> {
+    let eqn = &problem.eqn;
+    let ctx = eqn.ctx.clone();
+    let (nb, n, nt) = (ctx.nbatch(), eqn.nstates, t_eval.len());
+    let mut o = std::mem::MaybeUninit::<ffi::dsh_adaptive_options>::uninit();
+    unsafe { ffi::dsh_adaptive_default_options(o.as_mut_ptr()) };
+    let mut o = unsafe { o.assume_init() };
+    let oo = &problem.ode_options;
+    o.max_nonlinear_solver_iterations = oo.max_nonlinear_solver_iterations as i32;
+    o.max_error_test_failures = oo.max_error_test_failures as i32;
+    o.max_nonlinear_solver_failures = oo.max_nonlinear_solver_failures as i32;
+    o.nonlinear_solver_tolerance = oo.nonlinear_solver_tolerance;
+    o.min_timestep = oo.min_timestep;
+    o.update_jacobian_after_steps = oo.update_jacobian_after_steps as i32;
+    o.update_rhs_jacobian_after_steps = oo.update_rhs_jacobian_after_steps as i32;
+    o.threshold_to_update_jacobian = oo.threshold_to_update_jacobian;
+    o.threshold_to_update_rhs_jacobian = oo.threshold_to_update_rhs_jacobian;
+    let ic = &problem.ic_options;
+    o.ic_use_linesearch = ic.use_linesearch as i32;
+    o.ic_max_linesearch_iterations = ic.max_linesearch_iterations as i32;
+    o.ic_max_linear_solver_setups = ic.max_linear_solver_setups as i32;
+    o.ic_max_newton_iterations = ic.max_newton_iterations as i32;
+    o.ic_step_reduction_factor = ic.step_reduction_factor;
+    o.ic_armijo_constant = ic.armijo_constant;
+    o.group = mode as i32;
+    let ys = HipMat::zeros(n, nt, ctx.clone());
+    let c = ctx.ptr();
+    let alloc = |bytes: usize| -> *mut c_void {
+        let mut p = ptr::null_mut();
+        check(unsafe { ffi::dsh_malloc(c, bytes as i64, 0, &mut p) }, "dsh_malloc");
+        p
+    };
+    let (stats_d, status_d, troot_d, ridx_d, ncols_d) = (alloc(20 * nb), alloc(4 * nb), alloc(8 * nb), alloc(4 * nb), alloc(4 * nb));
+    let mut totals = [0i64; 6];
+    let atol = &problem.atol;
+    // which kernel: the banded lane-per-member twin of a run-time-sized model, the register-resident kernels (n <= 4), or one wavefront per member (n <= 64, BDF)
+    let twin = unsafe { ffi::dsh_model_lane_twin(eqn.model, eqn.size) };
+    let (model, size) = if twin >= 0 && unsafe { ffi::dsh_model_has_resident(method as i32, twin, 0) } != 0 { (twin, 0) } else { (eqn.model, eqn.size) };
+    let rc = if unsafe { ffi::dsh_model_has_resident(method as i32, model, size) } != 0 {
+        if method == Method::Bdf {
+            unsafe {
+                ffi::dsh_bdf_solve_adaptive(
+                    c, model, size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64, ys.ptr(),
+                    stats_d as *mut i32, status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+                )
+            }
+        } else {
+            unsafe {
+                ffi::dsh_sdirk_solve_resident(
+                    c, method as i32, model, size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64,
+                    ys.ptr(), stats_d as *mut i32, status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+                )
+            }
+        }
+    } else if method == Method::Bdf && mode == EnsembleMode::PerMember && unsafe { ffi::dsh_model_has_wave_member(eqn.model, eqn.size) } != 0 && !eqn.has_mass {
+        unsafe {
+            ffi::dsh_bdf_solve_wave_member(
+                c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64, ys.ptr(),
+                stats_d as *mut i32, status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else {
+        ffi::DSH_E_UNSUPPORTED
+    };
+    let fetch = |dev: *mut c_void, host: *mut c_void, bytes: usize| check(unsafe { ffi::dsh_d2h(c, host, dev, bytes as i64) }, "dsh_d2h");
+    let mut out = EnsembleSolution { ys, status: vec![0; nb], t_root: vec![0.0; nb], root_index: vec![0; nb], ncols: vec![0; nb], stats: vec![[0; 5]; nb], totals };
+    if rc >= 0 {
+        let mut flat = vec![0i32; 5 * nb];
+        fetch(stats_d, flat.as_mut_ptr() as *mut c_void, 20 * nb);
+        for b in 0..nb {
+            for k in 0..5 {
+                out.stats[b][k] = flat[k * nb + b];
+            }
+        }
+        fetch(status_d, out.status.as_mut_ptr() as *mut c_void, 4 * nb);
+        fetch(troot_d, out.t_root.as_mut_ptr() as *mut c_void, 8 * nb);
+        fetch(ridx_d, out.root_index.as_mut_ptr() as *mut c_void, 4 * nb);
+        fetch(ncols_d, out.ncols.as_mut_ptr() as *mut c_void, 4 * nb);
+    }
+    for p in [stats_d, status_d, troot_d, ridx_d, ncols_d] {
+        unsafe { ffi::dsh_free(c, p) };
+    }
+    if rc < 0 {
+        return Err(LaError::Other(if rc == ffi::DSH_E_UNSUPPORTED && last_error().is_empty() {
+            "no device-resident kernel for this model / method (static models with n <= 4: BDF, TR-BDF2, ESDIRK34; run-time-sized ODE models with n <= 64: BDF)".into()
+        } else {
+            last_error()
+        }));
+    }
+    Ok(out)
+}

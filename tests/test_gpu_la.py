@@ -102,6 +102,21 @@ def test_ref_batched_incompatible_nbatch_is_an_error(H, ctx1):  # :1102-1135 (#[
         a.axpy(1.0, H.HipVec.zeros(3, c2), 1.0)
 
 
+def test_get_batch_and_write_back(H, ctx1):  # Vector::get_batch / get_batch_mut (vector/mod.rs:227-231; cuda.rs:1285-1308)
+    c = ctx1.clone_with_nbatch(5)
+    x = np.arange(35, dtype=float).reshape(5, 7)
+    v = H.HipVec.from_vec(x, c)
+    for b in (0, 3, 4):
+        g = v.get_batch(b)
+        assert g.nb == 1 and np.array_equal(g.clone_as_vec().reshape(-1), x[b]) and g.get_index(2) == x[b, 2]
+    w = H.HipVec.from_vec(-np.arange(7, dtype=float)[None, :], ctx1)
+    v.set_batch(2, w)
+    x[2] = -np.arange(7)
+    assert np.array_equal(v.clone_as_vec(), x)
+    with pytest.raises(H.DiffsolHipError):
+        v.get_batch(5)
+
+
 def test_ref_batched_norms(H, ctx1):  # :756-789
     c2 = ctx1.clone_with_nbatch(2)
     assert abs(V(H, [1.0, 0.0, 0.0, 3.0], c2).norm(2) - 3.0) < 1e-12
