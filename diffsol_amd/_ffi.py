@@ -100,6 +100,9 @@ DEVICE_ABI = {
     "dsh_lu_set_structure": (cint, [vp, cint]),
     "dsh_lu_band_width": (cint, [vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_has_sens": (cint, [cint, i64]),
+    "dsh_model_rhs_sens": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_init_sens": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_out": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_compile": (cint, [C.c_char_p, cint, i64, i64, i64, i64, cint, c_ip]),
     "dsh_model_release": (cint, [cint]),
@@ -148,7 +151,10 @@ HOST_ABI = {
     "dshs_last_error": (C.c_char_p, []),
     "dshs_default_options": (None, [C.POINTER(DshsOptions)]),
     "dshs_create": (cint, [cint, vp, cint, i64, i64, c_dp, i64, dbl, c_dp, i64, dbl, dbl, cint, C.POINTER(DshsOptions), C.POINTER(vp)]),
+    "dshs_create_sens": (cint, [cint, vp, cint, i64, i64, c_dp, i64, dbl, c_dp, i64, dbl, dbl, cint, C.POINTER(DshsOptions), cint, dbl, c_dp, i64, C.POINTER(vp)]),
     "dshs_destroy": (None, [vp]),
+    "dshs_nparams": (i64, [vp]),
+    "dshs_interpolate_sens": (cint, [vp, dbl, c_dp]),
     "dshs_reset": (cint, [vp]),
     "dshs_set_kernel_timing": (cint, [vp, cint]),
     "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),

@@ -7,7 +7,7 @@
 
 namespace dsh {
 
-enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root, Out };
+enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root, Out, RhsSens, InitSens };
 
 template <class Mdl, Op OP>
 __global__ void k_static_model(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
@@ -55,6 +55,23 @@ __global__ void k_static_model(int64_t nb, double t, const double* __restrict__ 
       Mdl::root(t, xr, pp, g);
 #pragma unroll
       for (int k = 0; k < Mdl::NROOTS; ++k) y[(int64_t)k * nb + b] = g[k];
+    }
+  } else if constexpr (OP == Op::RhsSens || OP == Op::InitSens) {
+    // df/dp (n x np) resp. dy0/dp (n x np), column by column from sens_mul / init_sens_mul with unit vectors: NonLinearOpSens::_default_sens_inplace
+    // (op/nonlinear_op.rs:72-81) and SensInit (ode_equations/sens_equations.rs:62-70) for every parameter at once; column j at (j*N + i)*nb + b
+    if constexpr (model_has_sens<Mdl>::value) {
+      double xr[N];
+      if constexpr (OP == Op::RhsSens) load_vec<N>(x, nb, b, xr);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        double e[NP], col[N];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) e[k] = (k == j) ? 1.0 : 0.0;
+        if constexpr (OP == Op::RhsSens) Mdl::sens_mul(t, xr, pp, e, col);
+        else Mdl::init_sens_mul(t, pp, e, col);
+#pragma unroll
+        for (int i = 0; i < N; ++i) y[((int64_t)j * N + i) * nb + b] = col[i];
+      }
     }
   } else if constexpr (OP == Op::Out) {  // out_i of a DiffSL model (calc_out): nout x nb, batch-fastest
     constexpr int NO = model_nout<Mdl>::value;

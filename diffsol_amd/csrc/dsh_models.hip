@@ -188,6 +188,23 @@ int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
+// forward sensitivities: df/dp and dy0/dp as n x np batched matrices, one launch each
+int dsh_model_has_sens(int model, int64_t size) {
+  if (is_jit_model(model)) return 0;  // the DiffSL front end does not emit parameter derivatives yet
+  bool ok = false;
+  dispatch_static_model(model, size, [&](auto mdl) { ok = model_has_sens<decltype(mdl)>::value; });
+  return ok ? 1 : 0;
+}
+int dsh_model_rhs_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* sens) {
+  if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_rhs_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
+  bool handled = false;
+  return launch_static<Op::RhsSens>(ctx, model, size, nb, t, x, p, nullptr, 0.0, sens, &handled);
+}
+int dsh_model_init_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* sens0) {
+  if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_init_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
+  bool handled = false;
+  return launch_static<Op::InitSens>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, sens0, &handled);
+}
 int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double beta, double* y) {
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::MassGemv, nb, t, x, p, nullptr, beta, y);
   bool handled = false;

@@ -40,6 +40,12 @@ struct ExponentialDecayT {
     for (int i = 0; i < N; ++i) y[i] = p[1];
   }
   __device__ static void root(double, const double (&x)[N], const double (&)[NP], double (&g)[1]) { g[0] = x[0] - 0.6; }
+  // forward sensitivities: (df/dp) v = -x v_k  (exponential_decay.rs:33-36), (dy0/dp) v = (v_y0, v_y0)  (:90-93)
+  __device__ static void sens_mul(double, const double (&x)[N], const double (&)[NP], const double (&v)[NP], double (&y)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] * (-v[0]);
+  }
+  __device__ static void init_sens_mul(double, const double (&)[NP], const double (&v)[NP], double (&y)[N]) { y[0] = v[1]; y[1] = v[1]; }
 };
 
 // test_models/exponential_decay_with_algebraic.rs:18-23 (rhs), :64-75 (jac), :94-105 (mass), :122-126 / :267-276 (init)
@@ -87,6 +93,13 @@ struct RobertsonOde1 {
   }
   __device__ static void init(double, const double (&)[NP], double (&y)[N]) { y[0] = 1.0; y[1] = 0.0; y[2] = 0.0; }
   __device__ static void root(double, const double (&)[N], const double (&)[NP], double (&)[1]) {}
+  // forward sensitivities: test_models/robertson_ode_with_sens.rs:38-42 (df/dp v), :50 (dy0/dp v = 0)
+  __device__ static void sens_mul(double, const double (&x)[N], const double (&)[NP], const double (&v)[NP], double (&y)[N]) {
+    y[0] = -v[0] * x[0] + v[1] * x[1] * x[2];
+    y[1] = v[0] * x[0] - v[1] * x[1] * x[2] - v[2] * x[1] * x[1];
+    y[2] = v[2] * x[1] * x[1];
+  }
+  __device__ static void init_sens_mul(double, const double (&)[NP], const double (&)[NP], double (&y)[N]) { y[0] = 0.0; y[1] = 0.0; y[2] = 0.0; }
 };
 
 // test_models/robertson.rs:60-94
@@ -144,6 +157,10 @@ struct RlcT {
 template <class...> using model_void_t = void;
 template <class M, class = void> struct model_nout { static constexpr int value = 0; };
 template <class M> struct model_nout<M, model_void_t<decltype(M::NOUT)>> { static constexpr int value = M::NOUT; };
+
+// a model with parameter sensitivities provides sens_mul ((df/dp) v) and init_sens_mul ((dy0/dp) v), v of length NP (NonLinearOpSens / ConstantOpSens)
+template <class M, class = void> struct model_has_sens { static constexpr bool value = false; };
+template <class M> struct model_has_sens<M, model_void_t<decltype(&M::sens_mul)>> { static constexpr bool value = true; };
 
 // a model may declare that its Jacobian is banded (BAND_K = max(kl, ku) <= 4) and provide the band directly (jac_band): the device-resident BDF then keeps
 // the state in per-lane memory and factors the band only, which lifts its size limit from the register budget (n <= 4) to n <= 64

@@ -116,17 +116,37 @@ class Bdf : public OdeSolverMethod {
     minimum_timestep_growth_ = o.min_timestep_growth.value_or(2.0);
     maximum_timestep_shrink_ = o.max_timestep_shrink.value_or(0.9);
     minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
-    fused_ = problem.use_fused_kernels && problem.eqn->fused_model(&model_, &model_size_);
+    // forward sensitivities run on the trait operations (the fused step kernels integrate the state equations only)
+    fused_ = problem.use_fused_kernels && !problem.sens && problem.eqn->fused_model(&model_, &model_size_);
     // Run-time-sized models have no fused Newton kernel, but the difference-array kernels (rescale, predict, accept + order-selection norms) are model
     // independent: with enough members to fill the chip with one lane per system they replace ~20 vector launches per step (same bits, tested against
     // the trait composition).  DSH_FUSE_LA=0 keeps the 1:1 trait operations.
     {
       const char* e = std::getenv("DSH_FUSE_LA");
-      fused_la_ = problem.use_fused_kernels && !fused_ && problem.context().nbatch() >= 8192 && !(e && e[0] == '0');
+      fused_la_ = problem.use_fused_kernels && !problem.sens && !fused_ && problem.context().nbatch() >= 8192 && !(e && e[0] == '0');
     }
 
     StateCommon sc = new_and_consistent(problem, 1);
     y_ = sc.y; dy_ = sc.dy; t_ = sc.t; h_ = sc.h;
+    if (problem.sens) {
+      // bdf_state_sens -> new_with_sensitivities_and_consistent (state.rs:1032-1083): s_j = SensInit(t0) (:1157-1175), ds_j = SensRhs(s_j) about (y0, t0)
+      // (set_consistent_augmented :167-186).  DAEs would need InitOp on the augmented equations (:188-240): not provided.
+      if (problem.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "forward sensitivities of DAEs (mass matrix) are not supported by the HIP backend");
+      const int64_t n0 = problem.eqn->nstates(), npar = problem.eqn->nparams();
+      const HipContext& c0 = problem.context();
+      sens_mat_ = HipMat::zeros(n0, npar, c0);
+      sens_y_ = HipVec::zeros(n0, c0);
+      HipMat s0 = HipMat::zeros(n0, npar, c0);
+      problem.eqn->init_sens_inplace(t_, s0);
+      sens_update_state(y_, t_);
+      for (int64_t j = 0; j < npar; ++j) {
+        HipVec sj = HipVec::zeros(n0, c0), dsj = HipVec::zeros(n0, c0);
+        sj.copy_from_view(s0.column(j));
+        sens_rhs_call((int)j, sj, t_, dsj);
+        s_.push_back(std::move(sj));
+        ds_.push_back(std::move(dsj));
+      }
+    }
 
     // kappa table and derived constants (bdf.rs:253-276)
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
@@ -161,7 +181,86 @@ class Bdf : public OdeSolverMethod {
     u_ = compute_r(order_, 1.0);
     statistics_.number_of_linear_solver_setups = 1;
     statistics_.number_of_linear_solver_setups_from_checkpoint = 1;
+    if (problem.sens) {  // new_augmented (bdf.rs:384-432): initialise_sdiff_to_first_order (bdf_state.rs:80-91); s_op = BdfCallable::new_no_jacobian (c = 0!)
+      for (size_t j = 0; j < s_.size(); ++j) {
+        HipMat sd = HipMat::zeros(n, MAX_ORDER + 3, ctx);
+        sd.column_mut(0).copy_from(s_[j]);
+        sd.column_mut(1).copy_from(ds_[j]);
+        sd.column_mut(1).mul_assign(scale(h_));
+        sdiff_.push_back(std::move(sd));
+        s_deltas_.push_back(HipVec::zeros(n, ctx));
+      }
+      s_predict_ = HipVec::zeros(n, ctx);
+      s_psi_neg_y0_ = HipVec::zeros(n, ctx);
+      s_tmp_ = HipVec::zeros(n, ctx);
+    }
   }
+
+  // ---- forward sensitivities (bdf.rs:934-989 sensitivity_solve; SensRhs ode_equations/sens_equations.rs:72-180)
+  // SensRhs::update_state: df/dp and the linearisation point
+  void sens_update_state(const HipVec& y, double t) {
+    pr_.eqn->rhs_sens_inplace(y, t, sens_mat_);
+    sens_y_.copy_from(y);
+  }
+  // SensRhs::call_inplace: J(sens_y) x + (df/dp)[:, index]
+  void sens_rhs_call(int index, const HipVec& x, double t, HipVec& y) const {
+    pr_.eqn->rhs_jac_mul_inplace(sens_y_, t, x, y);
+    y.add_assign(sens_mat_.column(index));  // Matrix::add_column_to_vector
+  }
+  // the BdfCallable of the sensitivity equations (op/bdf.rs:240-256, identity mass) for parameter `index`: F(s) = (s - s0 + psi) - c SensRhs(s).
+  // Its c is set by _update_step_size only (bdf.rs:551-553): new_augmented never calls set_c on it, so it is 0 until the first step-size change —
+  // the reference's behaviour, kept because the reference's step counts only reproduce with it (tests/test_oracle_golden.py).
+  struct SensOp : NonLinearOpRef {
+    Bdf& b; int index;
+    SensOp(Bdf& b_, int i) : b(b_), index(i) {}
+    int64_t nstates() const override { return b.n(); }
+    const HipContext& context() const override { return b.ctx(); }
+    void call_inplace(const HipVec& x, double t, HipVec& y) override {
+      b.sens_rhs_call(index, x, t, y);
+      b.s_tmp_.copy_from(x);
+      b.s_tmp_.add_assign(b.s_psi_neg_y0_);
+      y.axpy(1.0, b.s_tmp_, -b.s_c_);
+    }
+    void jacobian_inplace(const HipVec&, double, HipMat&) override { throw LaError(DSH_E_UNSUPPORTED, "the sensitivity operator shares the state equations' factors"); }
+  };
+  // one Newton solve per parameter with the factors of the state equations; false = SensitivitySolveFailed
+  bool sensitivity_solve(double t_new) {
+    const int order = order_;
+    sens_update_state(y_predict_, t_new);  // `y_new = &self.y_predict` (bdf.rs:941)
+    for (size_t j = 0; j < sdiff_.size(); ++j) {
+      s_predict_.fill(0.0);  // _predict_using_diff
+      for (int i = 0; i <= order; ++i) s_predict_.add_assign(sdiff_[j].column(i));
+      s_psi_neg_y0_.axpy_v(gamma_[1], sdiff_[j].column(1), 0.0);  // set_psi_and_y0
+      for (int i = 2; i <= order; ++i) s_psi_neg_y0_.axpy_v(gamma_[(size_t)i], sdiff_[j].column(i), 1.0);
+      s_psi_neg_y0_.mul_assign(scale(alpha_[(size_t)order]));
+      s_psi_neg_y0_.sub_assign(s_predict_);
+      s_[j].copy_from(s_predict_);
+      SensOp sop(*this, (int)j);
+      if (nonlinear_solver_.solve_in_place(sop, s_[j], t_new, s_predict_, convergence_, line_search_) != NlError::Ok) return false;  // `?` before the count
+      statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
+      s_deltas_[j].copy_from(s_[j]);
+      s_deltas_[j].sub_assign(s_predict_);
+    }
+    return true;
+  }
+  // OdeSolverMethod::interpolate_sens (bdf.rs:1162-1215)
+  void interpolate_sens_inplace(double t, std::vector<HipVec>& out) const {
+    const bool is_forward = h_ > 0.0;
+    if ((is_forward && t > t_) || (!is_forward && t < t_)) throw DSH_ODE_ERR(InterpolationTimeAfterCurrentTime);
+    out.clear();
+    for (size_t j = 0; j < sdiff_.size(); ++j) {
+      HipVec v = HipVec::zeros(n(), ctx());
+      double time_factor = 1.0;
+      v.copy_from_view(sdiff_[j].column(0));
+      for (int i = 0; i < order_; ++i) {
+        double i_t = (double)i;
+        time_factor *= (t - (t_ - h_ * i_t)) / (h_ * (1.0 + i_t));
+        v.axpy_v(time_factor, sdiff_[j].column(i + 1), 1.0);
+      }
+      out.push_back(std::move(v));
+    }
+  }
+  const std::vector<HipVec>& sens() const { return s_; }
 
   // _compute_r (bdf.rs:433-463), column-major (order+1)^2, kept on the host (the reference keeps it in an nbatch = 1 context)
   static std::vector<double> compute_r(int order, double factor) {
@@ -215,6 +314,7 @@ class Bdf : public OdeSolverMethod {
       statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
       if (solve_result == NlError::Ok && fused_la_) { d_tmp_.copy_from(y_delta_); d_tmp_.sub_assign(y_predict_); }  // y_delta_ keeps y_new for the accept kernel
       else if (solve_result == NlError::Ok && !fused_) y_delta_.sub_assign(y_predict_);  // fused mode keeps y_new; d is formed in-kernel
+      if (solve_result == NlError::Ok && pr_.sens && !sensitivity_solve(t_predict_)) solve_result = NlError::NewtonDiverged;  // SensitivitySolveFailed (bdf.rs:1355-1360)
       if (solve_result != NlError::Ok) {
         statistics_.number_of_nonlinear_solver_fails += 1;
         if (statistics_.number_of_nonlinear_solver_fails > maximum_newton_fails_) throw DSH_ODE_ERR(TooManyNonlinearSolverFailures);
@@ -233,6 +333,9 @@ class Bdf : public OdeSolverMethod {
       // error_control (bdf.rs:826-835): squared norm of d weighted by the OLD state, times error_const2[order-1]
       double err_sq = fused_ ? fused_err_sq : (fused_la_ ? d_tmp_.squared_norm(y_, pr_.atol, pr_.rtol) : y_delta_.squared_norm(y_, pr_.atol, pr_.rtol));
       error_norm = std::fmax(0.0, err_sq * error_const2_[(size_t)order_ - 1]);
+      if (pr_.sens && pr_.sens_error_control)  // bdf.rs:844-858 — error_const2[order], not [order - 1]
+        for (size_t j = 0; j < sdiff_.size(); ++j)
+          error_norm = std::fmax(error_norm, s_deltas_[j].squared_norm(s_[j], pr_.sens_atol, pr_.sens_rtol) * error_const2_[(size_t)order_]);
       double maxiter = (double)convergence_.max_iter(), niter = (double)convergence_.niter();
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       if (error_norm <= 1.0) break;
@@ -300,6 +403,7 @@ class Bdf : public OdeSolverMethod {
       }
     } else {
       update_diff(order_, y_delta_);
+      for (size_t j = 0; j < sdiff_.size(); ++j) update_diff_of(sdiff_[j], order_, s_deltas_[j]);  // update_differences_and_integrate_out (bdf.rs:628-643)
       y_.copy_from(y_predict_);
       t_ = t_predict_;
       dy_.copy_from_view(diff_.column(1));
@@ -316,6 +420,12 @@ class Bdf : public OdeSolverMethod {
       double error_m_norm = inf, error_p_norm = inf;
       if (order > 1) error_m_norm = std::fmax(0.0, ((fused_ || fused_la_) ? sel_norms[0] : diff_.column(order).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order - 1]);
       if (order < MAX_ORDER) error_p_norm = std::fmax(0.0, ((fused_ || fused_la_) ? sel_norms[1] : diff_.column(order + 2).squared_norm(y_, pr_.atol, pr_.rtol)) * error_const2_[(size_t)order + 1]);
+      if (pr_.sens && pr_.sens_error_control) {  // predict_error_control with the augmented system (bdf.rs:908-919)
+        for (size_t j = 0; j < sdiff_.size(); ++j) {
+          if (order > 1) error_m_norm = std::fmax(error_m_norm, sdiff_[j].column(order).squared_norm(s_[j], pr_.sens_atol, pr_.sens_rtol) * error_const2_[(size_t)order - 1]);
+          if (order < MAX_ORDER) error_p_norm = std::fmax(error_p_norm, sdiff_[j].column(order + 2).squared_norm(s_[j], pr_.sens_atol, pr_.sens_rtol) * error_const2_[(size_t)order + 1]);
+        }
+      }
       const double pi_i = pr_.ode_options.pi_control_integral, pi_p = pr_.ode_options.pi_control_proportional;
       const double factors[3] = {pi_controller_raw(error_m_norm, prev_error_norm_, pi_i, pi_p, order), pi_controller_raw(error_norm, prev_error_norm_, pi_i, pi_p, order + 1),
                                  pi_controller_raw(error_p_norm, prev_error_norm_, pi_i, pi_p, order + 2)};
@@ -380,6 +490,7 @@ class Bdf : public OdeSolverMethod {
   }
   // state_mut_back (bdf.rs:1232-1262): move the state to an interpolated time inside the last step
   void state_mut_back(double t) override {
+    if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "state_mut_back with forward sensitivities is not supported by the HIP backend");
     if (is_state_modified_) { if (t != t_) throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep); return; }
     const bool is_forward = h_ > 0.0;
     if ((is_forward && t > t_) || (!is_forward && t < t_)) throw DSH_ODE_ERR(InterpolationTimeAfterCurrentTime);
@@ -465,6 +576,14 @@ class Bdf : public OdeSolverMethod {
       diff_tmp_.columns_mut(0, order + 1).gemm_vo(1.0, diff_.columns(0, order + 1), ru_dev, 0.0);
     }
     diff_.swap(diff_tmp_);
+    if (pr_.sens) {  // bdf.rs:546-553: every sdiff through the SAME scratch matrix, then set_c on the sensitivity operator
+      HipMat ru_dev = HipMat::from_vec(order + 1, order + 1, ru, ctx().clone_with_nbatch(1));
+      for (HipMat& sd : sdiff_) {
+        diff_tmp_.columns_mut(0, order + 1).gemm_vo(1.0, sd.columns(0, order + 1), ru_dev, 0.0);
+        sd.swap(diff_tmp_);
+      }
+      s_c_ = new_h * alpha_[(size_t)order];
+    }
     op_.set_c(new_h, alpha_[(size_t)order]);
     h_ = new_h;
     convergence_.reset_eta_timestep_change();
@@ -472,6 +591,13 @@ class Bdf : public OdeSolverMethod {
     return new_h;
   }
 
+  void update_diff_of(HipMat& diff, int order, const HipVec& d) {  // _update_diff on a sensitivity difference array
+    d_tmp_.copy_from(d);
+    d_tmp_.sub_assign(diff.column(order + 1));
+    diff.column_mut(order + 2).copy_from(d_tmp_);
+    diff.column_mut(order + 1).copy_from(d);
+    for (int i = order; i >= 0; --i) diff.column_axpy(1.0, i + 1, i);
+  }
   void update_diff(int order, const HipVec& d) {  // bdf.rs:646-664 (trait mode)
     d_tmp_.copy_from(d);
     d_tmp_.sub_assign(diff_.column(order + 1));
@@ -599,6 +725,12 @@ class Bdf : public OdeSolverMethod {
   double minimum_timestep_, maximum_timestep_growth_, minimum_timestep_growth_, maximum_timestep_shrink_, minimum_timestep_shrink_;
   int maximum_error_test_failures_, maximum_newton_fails_;
   std::optional<double> prev_error_norm_;
+  // forward sensitivities
+  std::vector<HipVec> s_, ds_, s_deltas_;
+  std::vector<HipMat> sdiff_;
+  HipVec s_predict_, s_psi_neg_y0_, s_tmp_, sens_y_;
+  HipMat sens_mat_;
+  double s_c_ = 0.0;
   bool fused_ = false;
   bool fused_la_ = false;  // model-independent difference-array kernels for run-time-sized models (large ensembles)
   bool prediction_valid_ = false;

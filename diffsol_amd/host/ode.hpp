@@ -68,6 +68,11 @@ class OdeEquations {
   virtual void mass_matrix_inplace(double t, HipMat& y) const = 0;
   virtual void init_call_inplace(double t, HipVec& y) const = 0;
   virtual void root_call_inplace(const HipVec& x, double t, HipVec& g) const = 0;
+  // forward sensitivities (OdeEquationsImplicitSens): df/dp at (x, t) and dy0/dp as n x nparams matrices (NonLinearOpSens::sens_inplace,
+  // op/nonlinear_op.rs:67-81; SensInit, ode_equations/sens_equations.rs:62-70)
+  virtual bool has_sens() const { return false; }
+  virtual void rhs_sens_inplace(const HipVec&, double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
+  virtual void init_sens_inplace(double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
   virtual bool fused_model(int* model, int64_t* size) const { (void)model; (void)size; return false; }
   // registry id of the model when it is one of libdiffsol_hip's built-in device models (fused or not)
   virtual bool registry_model(int*, int64_t*) const { return false; }
@@ -120,6 +125,13 @@ class HipKernelEquations : public OdeEquations {
   void root_call_inplace(const HipVec& x, double t, HipVec& g) const override {
     check(dsh_model_root(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), g.ptr()), "root");
   }
+  bool has_sens() const override { return dsh_model_has_sens(model_, size_) != 0; }
+  void rhs_sens_inplace(const HipVec& x, double t, HipMat& S) const override {
+    check(dsh_model_rhs_sens(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), S.ptr()), "rhs_sens");
+  }
+  void init_sens_inplace(double t, HipMat& S0) const override {
+    check(dsh_model_init_sens(ctx_.raw(), model_, size_, ctx_.nbatch(), t, p_.ptr(), S0.ptr()), "init_sens");
+  }
   bool fused_model(int* model, int64_t* size) const override { if (!fused_) return false; *model = model_; *size = size_; return true; }
   bool registry_model(int* model, int64_t* size) const override { *model = model_; *size = size_; return true; }
   const HipVec& params() const override { return p_; }
@@ -159,6 +171,12 @@ struct OdeSolverProblem {
   InitialConditionSolverOptions ic_options;
   OdeSolverOptions ode_options;
   bool use_fused_kernels = true;  // build-time choice of this backend: fused device kernels where the model provides them
+  // forward sensitivities (problem.bdf_sens(), problem.rs:819-832): s_j = dy/dp_j integrated alongside the states; with sens_rtol / sens_atol they take
+  // part in the error control (sens_equations.rs:283-285), without (builder.rs:1501-1505) they do not
+  bool sens = false;
+  bool sens_error_control = false;
+  double sens_rtol = 0.0;
+  HipVec sens_atol;  // nstates entries, nbatch 1; the same for every parameter (builder.rs build_atols with unit parameter scales)
   const HipContext& context() const { return eqn->context(); }
 };
 
@@ -173,6 +191,9 @@ class OdeBuilder {
   OdeBuilder& use_fused_kernels(bool v) { fused_ = v; return *this; }
   OdeBuilder& ode_options(const OdeSolverOptions& o) { ode_options_ = o; return *this; }
   OdeBuilder& ic_options(const InitialConditionSolverOptions& o) { ic_options_ = o; return *this; }
+  // sensitivities(true) = bdf_sens(); sens_tolerances(rtol, atol) = .sens_rtol().sens_atol() (builder.rs:1453-1477), none = turn_off_sensitivities_error_control
+  OdeBuilder& sensitivities(bool v) { sens_ = v; return *this; }
+  OdeBuilder& sens_tolerances(double rtol, const std::vector<double>& atol) { sens_rtol_ = rtol; sens_atol_ = atol; return *this; }
   // build_from_eqn (builder.rs:1933-1981): atol of length 1 is broadcast to all states
   OdeSolverProblem build_from_eqn(std::shared_ptr<OdeEquations> eqn) const {
     OdeSolverProblem p;
@@ -186,6 +207,17 @@ class OdeBuilder {
     p.rtol = rtol_; p.t0 = t0_; p.h0 = h0_;
     p.ode_options = ode_options_; p.ic_options = ic_options_;
     p.use_fused_kernels = fused_;
+    if (sens_) {
+      if (!p.eqn->has_sens()) throw LaError(DSH_E_UNSUPPORTED, "forward sensitivities: the model has no parameter derivatives (dsh_model_has_sens)");
+      p.sens = true;
+      p.sens_error_control = !sens_atol_.empty();
+      p.sens_rtol = sens_rtol_;
+      std::vector<double> sa((size_t)n, 0.0);
+      if (sens_atol_.size() == 1) sa.assign((size_t)n, sens_atol_[0]);
+      else if ((int64_t)sens_atol_.size() == n) sa = sens_atol_;
+      else if (!sens_atol_.empty()) throw LaError(DSH_E_INVALID, "sens_atol must have length 1 or nstates");
+      p.sens_atol = HipVec::from_vec(sa, p.eqn->context().clone_with_nbatch(1));
+    }
     return p;
   }
   OdeSolverProblem build_model(int model, int64_t size, const std::vector<double>& params) const {
@@ -197,6 +229,9 @@ class OdeBuilder {
   std::vector<double> atol_{1e-6};
   HipContext ctx_;
   bool fused_ = true;
+  bool sens_ = false;
+  double sens_rtol_ = 0.0;
+  std::vector<double> sens_atol_;
   OdeSolverOptions ode_options_;
   InitialConditionSolverOptions ic_options_;
 };

@@ -247,6 +247,12 @@ void dshs_default_options(dshs_options* o) {
 
 int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
                 const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, dshs_solver** out) {
+  return dshs_create_sens(device, stream, model, model_size, nbatch, params, nparams_total, rtol, atol, natol, t0, h0, method, opts, /*sens=*/0, 0.0, nullptr, 0, out);
+}
+
+int dshs_create_sens(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
+                     const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, int sens, double sens_rtol,
+                     const double* sens_atol, int64_t nsens_atol, dshs_solver** out) {
   return guarded([&]() {
     if (!out) throw LaError(DSH_E_INVALID, "out is null");
     dshs_options o;
@@ -273,8 +279,14 @@ int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t
     ic.step_reduction_factor = o.ic_step_reduction_factor;
     ic.armijo_constant = o.ic_armijo_constant;
     std::vector<double> p(params, params + nparams_total), a(atol, atol + natol);
-    s->problem = OdeBuilder().t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic)
-                     .build_model(model, model_size, p);
+    OdeBuilder builder;
+    builder.t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic);
+    if (sens) {
+      if (method != DSHS_METHOD_BDF) throw LaError(DSH_E_UNSUPPORTED, "forward sensitivities are provided for BDF (problem.bdf_sens())");
+      builder.sensitivities(true);
+      if (nsens_atol > 0) builder.sens_tolerances(sens_rtol, std::vector<double>(sens_atol, sens_atol + nsens_atol));
+    }
+    s->problem = builder.build_model(model, model_size, p);
     s->method = method;
     s->make_solver();
     *out = s.release();
@@ -322,6 +334,21 @@ int dshs_get_state(dshs_solver* s, double* t, double* h, int* order, double* y_h
     if (order) *order = s->solver->order();
     if (y_host) download(s->solver->y(), y_host);
     if (dy_host) download(s->solver->dy(), dy_host);
+    return 0;
+  });
+}
+int64_t dshs_nparams(const dshs_solver* s) { return s->problem.eqn->nparams(); }
+int dshs_interpolate_sens(dshs_solver* s, double t, double* s_host) {
+  return guarded([&]() {
+    if (!s->bdf || !s->problem.sens) throw LaError(DSH_E_INVALID, "the solver was not created with forward sensitivities (dshs_create_sens)");
+    const size_t len = (size_t)(s->problem.eqn->nstates() * s->ctx.nbatch());
+    if (t != t) {  // NaN: state.s, the sensitivities at the current time
+      for (size_t j = 0; j < s->bdf->sens().size(); ++j) download(s->bdf->sens()[j], s_host + j * len);
+      return 0;
+    }
+    std::vector<HipVec> out;
+    s->bdf->interpolate_sens_inplace(t, out);
+    for (size_t j = 0; j < out.size(); ++j) download(out[j], s_host + j * len);
     return 0;
   });
 }

@@ -37,7 +37,7 @@ class Solver:
     """One ensemble solver instance on one GPU."""
 
     def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, device=0, stream=None,
-                 fused=True, block_threads=0, options=None, ensemble_mode=None):
+                 fused=True, block_threads=0, options=None, ensemble_mode=None, sens=False, sens_rtol=None, sens_atol=None):
         L = _ffi.load_host_lib()
         self._L = L
         if isinstance(model, str):
@@ -56,8 +56,14 @@ class Solver:
         for k, v in (options or {}).items():
             setattr(o, k, v)
         h = vp()
-        rc = L.dshs_create(device, stream, model, model_size, nbatch, p.ctypes.data_as(_ffi.c_dp), p.size, rtol, a.ctypes.data_as(_ffi.c_dp), a.size,
-                           t0, h0, method, C.byref(o), C.byref(h))
+        if sens:  # problem.bdf_sens(): forward sensitivities integrated alongside (sens_atol None: not part of the error control)
+            sa = np.zeros(0) if sens_atol is None else np.ascontiguousarray(np.asarray(sens_atol, dtype=np.float64).reshape(-1))
+            sa_buf = sa if sa.size else np.zeros(1)
+            rc = L.dshs_create_sens(device, stream, model, model_size, nbatch, p.ctypes.data_as(_ffi.c_dp), p.size, rtol, a.ctypes.data_as(_ffi.c_dp), a.size,
+                                    t0, h0, method, C.byref(o), 1, 0.0 if sens_rtol is None else float(sens_rtol), sa_buf.ctypes.data_as(_ffi.c_dp), sa.size, C.byref(h))
+        else:
+            rc = L.dshs_create(device, stream, model, model_size, nbatch, p.ctypes.data_as(_ffi.c_dp), p.size, rtol, a.ctypes.data_as(_ffi.c_dp), a.size,
+                               t0, h0, method, C.byref(o), C.byref(h))
         check(rc, host=True)
         self._h = h
         self.n = int(L.dshs_nstates(h))
@@ -133,6 +139,13 @@ class Solver:
         y = np.empty((self.nbatch, self.n))
         check(self._L.dshs_interpolate(self._h, t, y.ctypes.data_as(_ffi.c_dp)), host=True)
         return y
+
+    def interpolate_sens(self, t=None):
+        """OdeSolverMethod::interpolate_sens: [nparams, nbatch, n]; t=None: state.s at the current time."""
+        npar = int(self._L.dshs_nparams(self._h))
+        out = np.empty((npar, self.nbatch, self.n))
+        check(self._L.dshs_interpolate_sens(self._h, float("nan") if t is None else float(t), out.ctypes.data_as(_ffi.c_dp)), host=True)
+        return out
 
     def root_info(self):
         t, i = C.c_double(), C.c_int()

@@ -244,6 +244,13 @@ int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, d
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* mass);
 int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* y);
 int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* g);
+/* Forward sensitivities (OdeEquationsImplicitSens): df/dp at (x, t) and dy0/dp as n x nparams batched matrices (column j =
+ * NonLinearOpSens::sens_mul / ConstantOpSens::sens_mul with the unit vector e_j: op/nonlinear_op.rs:51-81, ode_equations/sens_equations.rs:62-70),
+ * one launch each.  Built-in models with parameter derivatives: exponential decay (test_models/exponential_decay.rs:33-36, :90-93) and the Robertson
+ * ODE (test_models/robertson_ode_with_sens.rs:38-50); dsh_model_has_sens tells. */
+int dsh_model_has_sens(int model, int64_t size);
+int dsh_model_rhs_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* sens);
+int dsh_model_init_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* sens0);
 
 /* ---- Fused fast paths (optional; results are bit-identical to composing the 1:1 ops above) ---- */
 /* One Newton iteration of the BDF residual F(y) = M(y + (psi - y0)) - c f(y)  (NoLineSearch::take_optimal_step

@@ -55,6 +55,14 @@ void dshs_default_options(dshs_options* opts);
  * params: batch-major, nparams per batch member.  atol: 1 or nstates entries.  stream: NULL or a hipStream_t to run on. */
 int dshs_create(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
                 const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, dshs_solver** out);
+/* problem.bdf_sens() (problem.rs:819-832): the same solver with the forward sensitivities s_j = dy/dp_j of every parameter integrated
+ * alongside the states — Bdf::sensitivity_solve (bdf.rs:934-989: one Newton solve per parameter and step with the LU factors of the state equations),
+ * SensEquations (ode_equations/sens_equations.rs), sensitivity difference arrays rescaled / updated with the states'.  nsens_atol > 0: the
+ * sensitivities take part in the error control with sens_rtol / sens_atol (length 1 or nstates, the same for every parameter); nsens_atol = 0:
+ * turn_off_sensitivities_error_control.  BDF, ODE models with parameter derivatives (dsh_model_has_sens); host-driven lock-step over the ensemble. */
+int dshs_create_sens(int device, void* stream, int model, int64_t model_size, int64_t nbatch, const double* params, int64_t nparams_total, double rtol,
+                     const double* atol, int64_t natol, double t0, double h0, int method, const dshs_options* opts, int sens, double sens_rtol,
+                     const double* sens_atol, int64_t nsens_atol, dshs_solver** out);
 void dshs_destroy(dshs_solver* s);
 
 /* Re-create the solver state from the problem (parameters stay resident on the device): OdeSolverProblem::bdf()/... again —
@@ -75,6 +83,9 @@ int dshs_set_stop_time(dshs_solver* s, double tstop);
 int dshs_interpolate(dshs_solver* s, double t, double* y_host);
 int dshs_get_state(dshs_solver* s, double* t, double* h, int* order, double* y_host, double* dy_host);
 int dshs_root_info(dshs_solver* s, double* t_root, int* root_index);
+/* OdeSolverMethod::interpolate_sens (bdf.rs:1162-1215): s_host [nparams][b][state]; t = NaN returns state.s (the sensitivities at the current time) */
+int64_t dshs_nparams(const dshs_solver* s);
+int dshs_interpolate_sens(dshs_solver* s, double t, double* s_host);
 /* BDF only: difference array D as [b][col(8)][row] */
 int dshs_bdf_get_diff(dshs_solver* s, double* diff_host);
 /* out[0..10) OdeSolverStatistics in declaration order (ode_solver/mod.rs:28-69); out[10..13) rhs OpStatistics calls / jac_muls / matrix_evals */

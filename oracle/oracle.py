@@ -114,15 +114,37 @@ class OracleError(RuntimeError):
 class OracleSolver:
     """One (possibly batched, lock-step) solver instance of the CPU restatement."""
 
-    def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF):
+    def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, sens=False, sens_rtol=None,
+                 sens_atol=None):
+        """sens=True: problem.bdf_sens() — forward sensitivities integrated alongside; sens_rtol / sens_atol put them into the error control
+        (None: turn_off_sensitivities_error_control)."""
         L = lib()
         p_arr, p_ptr = _d(np.asarray(p, dtype=np.float64).reshape(-1))
         a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
-        self._h = L.orc_solver_create(model, model_size, nbatch, p_ptr, p_arr.size, rtol, a_ptr, a_arr.size, t0, h0, method)
+        if sens:
+            sa = np.zeros(0) if sens_atol is None else np.asarray(sens_atol, dtype=np.float64).reshape(-1)
+            sa_arr, sa_ptr = _d(sa if sa.size else np.zeros(1))
+            L.orc_solver_create_sens.restype = C.c_void_p
+            self._h = L.orc_solver_create_sens(C.c_int(model), C.c_int(model_size), C.c_int(nbatch), p_ptr, C.c_int(p_arr.size), C.c_double(rtol), a_ptr,
+                                               C.c_int(a_arr.size), C.c_double(t0), C.c_double(h0), C.c_int(method),
+                                               C.c_double(0.0 if sens_rtol is None else sens_rtol), sa_ptr, C.c_int(sa.size))
+        else:
+            self._h = L.orc_solver_create(model, model_size, nbatch, p_ptr, p_arr.size, rtol, a_ptr, a_arr.size, t0, h0, method)
         if not self._h:
             raise OracleError(L.orc_last_error().decode())
         self.n = L.orc_nstates(self._h)
         self.nbatch = L.orc_nbatch(self._h)
+        self.sens = bool(sens)
+
+    def interpolate_sens(self, t=None):
+        """OdeSolverMethod::interpolate_sens: [nparams, nbatch, n]; t=None: state.s at the current time."""
+        L = lib()
+        npar = L.orc_nparams(C.c_void_p(self._h))
+        out = np.empty((npar, self.nbatch, self.n))
+        r = L.orc_interpolate_sens(C.c_void_p(self._h), C.c_double(np.nan if t is None else t), out.ctypes.data_as(_dp))
+        if r < 0:
+            raise OracleError(f"oracle interpolate_sens failed with {r}")
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -20,6 +20,9 @@ struct Handle {
   int init_error = 0;
 };
 thread_local std::string g_last_error;
+// forward-sensitivity request for the next make_handle call (orc_solver_create_sens)
+struct SensRequest { bool on = false; bool error_control = false; double rtol = 0.0; std::vector<double> atol; };
+thread_local SensRequest g_sens_request;
 
 enum Method : int { METHOD_BDF = 0, METHOD_TR_BDF2 = 1, METHOD_ESDIRK34 = 2 };
 
@@ -37,6 +40,21 @@ std::unique_ptr<Handle> make_handle(int model_id, int model_size, int nbatch, co
   else throw std::runtime_error("oracle: atol must have length 1 or nstates");
   h->problem.t0 = t0;
   h->problem.h0 = h0;
+  if (g_sens_request.on) {
+    const SensRequest rq = g_sens_request;
+    g_sens_request = SensRequest();
+    if (method != METHOD_BDF) throw std::runtime_error("oracle: forward sensitivities are restated for BDF only");
+    if (!h->problem.eqn->model->has_sens) throw std::runtime_error("oracle: model has no parameter sensitivities");
+    h->problem.sens = true;
+    h->problem.sens_error_control = rq.error_control;
+    h->problem.sens_rtol = rq.rtol;
+    h->problem.sens_atol = V(n, 1);
+    if (rq.error_control) {
+      if ((int)rq.atol.size() == 1) for (int i = 0; i < n; ++i) h->problem.sens_atol.d[i] = rq.atol[0];
+      else if ((int)rq.atol.size() == n) for (int i = 0; i < n; ++i) h->problem.sens_atol.d[i] = rq.atol[(size_t)i];
+      else throw std::runtime_error("oracle: sens_atol must have length 1 or nstates");
+    }
+  }
   if (method == METHOD_BDF) {
     auto s = std::make_unique<Bdf>(&h->problem);
     h->init_error = (int)s->init_error;
@@ -62,6 +80,31 @@ void* orc_solver_create(int model_id, int model_size, int nbatch, const double* 
     if (h->init_error != 0) { g_last_error = "oracle: initialisation failed with OdeErr " + std::to_string(h->init_error); return nullptr; }
     return h.release();
   } catch (const std::exception& e) { g_last_error = e.what(); return nullptr; }
+}
+// problem.bdf_sens() (problem.rs:819-832): the same solver with the forward sensitivities s_j = dy/dp_j integrated alongside; nsens_atol = 0 turns the
+// sensitivities' part in the error control off (builder.rs:1501-1505), else sens_rtol / sens_atol (length 1 or nstates) are used for every parameter
+void* orc_solver_create_sens(int model_id, int model_size, int nbatch, const double* p, int np_total, double rtol, const double* atol, int natol,
+                             double t0, double h0, int method, double sens_rtol, const double* sens_atol, int nsens_atol) {
+  g_sens_request.on = true;
+  g_sens_request.error_control = nsens_atol > 0;
+  g_sens_request.rtol = sens_rtol;
+  g_sens_request.atol.assign(sens_atol, sens_atol + (nsens_atol > 0 ? nsens_atol : 0));
+  void* r = orc_solver_create(model_id, model_size, nbatch, p, np_total, rtol, atol, natol, t0, h0, method);
+  g_sens_request = SensRequest();
+  return r;
+}
+int orc_nparams(void* hv) { return ((Handle*)hv)->problem.eqn->model->np; }
+// OdeSolverMethod::interpolate_sens (bdf.rs:1162-1215): out [np][nb][n]; state.s (the sensitivities at the current time) with t = NaN
+int orc_interpolate_sens(void* hv, double t, double* out) {
+  Handle* h = (Handle*)hv;
+  Bdf* b = dynamic_cast<Bdf*>(h->solver.get());
+  if (!b || !h->problem.sens) return -100;
+  std::vector<V> s;
+  if (t != t) s = b->s_;
+  else { OdeErr e = b->interpolate_sens(t, s); if (e != OdeErr::Ok) return -(int)e; }
+  const size_t len = (size_t)h->problem.n() * h->problem.nb();
+  for (size_t j = 0; j < s.size(); ++j) std::memcpy(out + j * len, s[j].d.data(), len * sizeof(double));
+  return 0;
 }
 void orc_solver_destroy(void* hv) { delete (Handle*)hv; }
 

@@ -42,11 +42,19 @@ struct Model {
   virtual void mass(const double*, const double*, double, double, double*) const {}
   virtual void init(const double* p, double t, double* y) const = 0;
   virtual void root(const double*, const double*, double, double*) const {}
+  // forward sensitivities (OdeEquationsImplicitSens): y = (df/dp)(x, p, t) v  and  y = (dy0/dp)(p, t) v, v of length np
+  // (NonLinearOpSens::sens_mul_inplace op/nonlinear_op.rs:51-53, ConstantOpSens::sens_mul_inplace)
+  bool has_sens = false;
+  virtual void sens_mul(const double*, const double*, double, const double*, double*) const { throw std::runtime_error("oracle: model has no parameter sensitivities"); }
+  virtual void init_sens_mul(const double*, double, const double*, double*) const { throw std::runtime_error("oracle: model has no parameter sensitivities"); }
 };
 
 // crates/diffsol/src/ode_equations/test_models/exponential_decay.rs:14-21 (rhs), :54-61 (jac), :72-81 (init), :98-100 (root)
 struct ExponentialDecay : Model {
-  explicit ExponentialDecay(bool with_root = false) { n = 2; np = 2; nroots = with_root ? 1 : 0; }
+  explicit ExponentialDecay(bool with_root = false) { n = 2; np = 2; nroots = with_root ? 1 : 0; has_sens = true; }
+  // exponential_decay.rs:33-36 (df/dp v = -x v_k) and :90-93 (dy0/dp v = (v_y0, v_y0))
+  void sens_mul(const double* x, const double*, double, const double* v, double* y) const override { for (int i = 0; i < n; ++i) y[i] = x[i] * (-v[0]); }
+  void init_sens_mul(const double*, double, const double* v, double* y) const override { y[0] = v[1]; y[1] = v[1]; }
   void rhs(const double* x, const double* p, double, double* y) const override { for (int i = 0; i < n; ++i) y[i] = x[i] * (-p[0]); }
   void jac_mul(const double*, const double* p, double, const double* v, double* y) const override { for (int i = 0; i < n; ++i) y[i] = v[i] * (-p[0]); }
   void init(const double* p, double, double* y) const override { for (int i = 0; i < n; ++i) y[i] = p[1]; }
@@ -77,7 +85,17 @@ struct ExponentialDecayAlgebraic : Model {
 // crates/diffsol/src/ode_equations/test_models/robertson_ode.rs:71-90 (rhs, jac_mul), :92-101 (init)
 struct RobertsonOde : Model {
   int ngroups;
-  explicit RobertsonOde(int ngroups_) : ngroups(ngroups_) { n = 3 * ngroups_; np = 3; }
+  explicit RobertsonOde(int ngroups_) : ngroups(ngroups_) { n = 3 * ngroups_; np = 3; has_sens = true; }
+  // robertson_ode_with_sens.rs:38-42 (df/dp v) and :50 (dy0/dp v = 0)
+  void sens_mul(const double* x, const double*, double, const double* v, double* y) const override {
+    for (int ig = 0; ig < ngroups; ++ig) {
+      int i = ig * 3;
+      y[i] = -v[0] * x[i] + v[1] * x[i + 1] * x[i + 2];
+      y[i + 1] = v[0] * x[i] - v[1] * x[i + 1] * x[i + 2] - v[2] * x[i + 1] * x[i + 1];
+      y[i + 2] = v[2] * x[i + 1] * x[i + 1];
+    }
+  }
+  void init_sens_mul(const double*, double, const double*, double* y) const override { for (int i = 0; i < n; ++i) y[i] = 0.0; }
   void rhs(const double* x, const double* p, double, double* y) const override {
     for (int ig = 0; ig < ngroups; ++ig) {
       int i = ig * 3;
@@ -363,6 +381,25 @@ struct Eqn {
   }
   void init(double t, V& y) const {
     for (int b = 0; b < nb; ++b) model->init(pb(b), t, &y.d[(size_t)b * y.n]);
+  }
+  // df/dp as an n x np matrix, column by column from sens_mul with unit vectors (NonLinearOpSens::_default_sens_inplace, op/nonlinear_op.rs:72-81;
+  // closure_with_sens.rs does not count these calls in OpStatistics)
+  void rhs_sens(const V& x, double t, M& S) const {
+    const int n_ = n(), np_ = model->np;
+    std::vector<double> v((size_t)np_, 0.0);
+    V col(n_, nb);
+    for (int j = 0; j < np_; ++j) {
+      v[(size_t)j] = 1.0;
+      for (int b = 0; b < nb; ++b) model->sens_mul(&x.d[(size_t)b * x.n], pb(b), t, v.data(), &col.d[(size_t)b * n_]);
+      S.set_column(j, col);
+      v[(size_t)j] = 0.0;
+    }
+  }
+  // SensInit::call (ode_equations/sens_equations.rs:62-70): s_j(t0) = (dy0/dp) e_j
+  void init_sens(double t, int j, V& s) const {
+    std::vector<double> v((size_t)model->np, 0.0);
+    v[(size_t)j] = 1.0;
+    for (int b = 0; b < nb; ++b) model->init_sens_mul(pb(b), t, v.data(), &s.d[(size_t)b * s.n]);
   }
   void root(const V& x, double t, V& g) const {
     for (int b = 0; b < nb; ++b) model->root(&x.d[(size_t)b * x.n], pb(b), t, &g.d[(size_t)b * g.n]);

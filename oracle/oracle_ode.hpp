@@ -56,6 +56,13 @@ struct Problem {
   double t0 = 0.0, h0 = 1.0;
   OdeSolverOptions ode_options;
   InitialConditionSolverOptions ic_options;
+  // forward sensitivities (problem.bdf_sens(), problem.rs:819-832): integrate s_j = dy/dp_j alongside the states; with sens_rtol / sens_atol they
+  // take part in the error control (SensEquations::include_in_error_control, sens_equations.rs:283-285), without
+  // (turn_off_sensitivities_error_control, builder.rs:1501-1505) they do not
+  bool sens = false;
+  bool sens_error_control = false;
+  double sens_rtol = 0.0;
+  V sens_atol;  // n x 1, the same for every parameter (builder.rs build_atols)
   int n() const { return eqn->n(); }
   int nb() const { return eqn->nb; }
 };
@@ -445,6 +452,16 @@ struct Bdf : SolverBase {
   int maximum_error_test_failures, maximum_newton_fails;
   std::optional<double> prev_error_norm;
   OdeErr init_error = OdeErr::Ok;
+  // forward sensitivities (bdf.rs:370-432 new_augmented, :934-989 sensitivity_solve; SensRhs / SensEquations ode_equations/sens_equations.rs:72-180)
+  std::vector<V> s_, ds_, s_deltas;
+  std::vector<M> sdiff;
+  V s_predict, s_psi_neg_y0, s_tmp, sens_y;  // sens_y: the state SensRhs linearises about (update_rhs_out_state)
+  M sens_mat;                                // df/dp at sens_y, n x np
+  // BdfCallable::c of the sensitivity operator.  new_augmented builds it with BdfCallable::new_no_jacobian (bdf.rs:403) and never calls set_c on it
+  // (c = 0, op/bdf.rs:61): until the first _update_step_size (:551-553) the sensitivity residual is F(s) = s - s0 + psi.  Restated as it is — the
+  // reference's counters (14 setups / 56 steps / 1 error-test failure on exponential decay) only reproduce with it.
+  double s_c = 0.0;
+  int naug() const { return pr->sens ? pr->eqn->model->np : 0; }
 
   static M compute_r(int order, double factor) {  // :433-463
     int nrows = order + 1, ncols = order + 1;
@@ -473,6 +490,19 @@ struct Bdf : SolverBase {
     init_error = new_and_consistent(*p, 1, sc);
     y_ = sc.y; dy_ = sc.dy; t_ = sc.t; h_ = sc.h;
     if (init_error != OdeErr::Ok) return;
+    if (p->sens) {
+      // bdf_state_sens -> new_with_sensitivities_and_consistent (state.rs:1032-1083): initialise_augmented_state (:1157-1205: s_j = SensInit(t0), ds_j = 0),
+      // [set_consistent — done above, before set_step_size in both orders the result is the same: it only touches y, dy],
+      // set_consistent_augmented (:167-240: ds_j = SensRhs(s_j) about (y0, t0); DAEs would need InitOp on the augmented equations: not restated)
+      if (p->eqn->has_mass()) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
+      const int n0 = p->n(), nb0 = p->nb(), npar = p->eqn->model->np;
+      sens_mat = M(n0, npar, nb0);
+      sens_y = V(n0, nb0);
+      s_.assign((size_t)npar, V(n0, nb0)); ds_.assign((size_t)npar, V(n0, nb0));
+      for (int j = 0; j < npar; ++j) p->eqn->init_sens(t_, j, s_[(size_t)j]);
+      sens_update_state(y_, t_);
+      for (int j = 0; j < npar; ++j) sens_rhs_call(j, s_[(size_t)j], t_, ds_[(size_t)j]);
+    }
     // _new :244-368
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
     alpha = {0.0}; gamma = {0.0}; error_const2 = {1.0};
@@ -499,6 +529,60 @@ struct Bdf : SolverBase {
     u = compute_r(order_, 1.0);
     statistics.number_of_linear_solver_setups = 1;
     statistics.setups_from_checkpoint = 1;
+    if (p->sens) {  // new_augmented (bdf.rs:384-432): set_augmented_problem -> initialise_sdiff_to_first_order (bdf_state.rs:80-91); s_op = BdfCallable::new_no_jacobian
+      const int npar = naug();
+      sdiff.assign((size_t)npar, M(n, MAX_ORDER + 3, nb));
+      for (int j = 0; j < npar; ++j) {
+        sdiff[(size_t)j].set_column(0, s_[(size_t)j]);
+        V c1 = ds_[(size_t)j];
+        mul_assign(c1, h_);
+        sdiff[(size_t)j].set_column(1, c1);
+      }
+      s_deltas.assign((size_t)npar, V(n, nb));
+      s_predict = V(n, nb);
+      s_psi_neg_y0 = V(n, nb);
+      s_tmp = V(n, nb);
+    }
+  }
+
+  // SensRhs::update_state (sens_equations.rs:119-125): df/dp and the linearisation point
+  void sens_update_state(const V& y, double t) {
+    pr->eqn->rhs_sens(y, t, sens_mat);
+    copy_from(sens_y, y);
+  }
+  // SensRhs::call_inplace (:155-161): J(sens_y) x + (df/dp)[:, index]
+  void sens_rhs_call(int index, const V& x, double t, V& y) const {
+    pr->eqn->jac_mul(sens_y, t, x, y);
+    add_assign(y, sens_mat.column(index));
+  }
+  // BdfCallable::call_inplace of the sensitivity operator (op/bdf.rs:240-256, identity mass): F(s) = (s - s0 + psi) - c SensRhs(s)
+  void s_op_call(int index, const V& x, double t, V& y) {
+    sens_rhs_call(index, x, t, y);
+    copy_from(s_tmp, x);
+    add_assign(s_tmp, s_psi_neg_y0);
+    axpy(y, 1.0, s_tmp, -s_c);
+  }
+  // sensitivity_solve (bdf.rs:934-989): one Newton solve per parameter with the factors of the state equations
+  bool sensitivity_solve(double t_new) {
+    const int order = order_;
+    sens_update_state(y_predict, t_new);  // `y_new = &self.y_predict` (:941)
+    for (int j = 0; j < naug(); ++j) {
+      predict_using_diff(s_predict, sdiff[(size_t)j], order);
+      axpy(s_psi_neg_y0, gamma[1], sdiff[(size_t)j].column(1), 0.0);  // set_psi_and_y0 (op/bdf.rs:182-210)
+      for (int i = 2; i <= order; ++i) axpy(s_psi_neg_y0, gamma[(size_t)i], sdiff[(size_t)j].column(i), 1.0);
+      mul_assign(s_psi_neg_y0, alpha[(size_t)order]);
+      sub_assign(s_psi_neg_y0, s_predict);
+      V& s_new = s_[(size_t)j];
+      copy_from(s_new, s_predict);
+      FunT fun = [&](const V& x, V& y) { s_op_call(j, x, t_new, y); };
+      LinSolveT solve = [&](V& x) { return nonlinear_solver.lu.solve(x); };
+      NlErr e = newton_iteration(s_new, nonlinear_solver.tmp, s_predict, fun, solve, convergence, line_search);
+      if (e != NlErr::Ok) return false;  // `?` before the iteration count is added
+      statistics.number_of_nonlinear_solver_iterations += convergence.niter;
+      copy_from(s_deltas[(size_t)j], s_new);
+      sub_assign(s_deltas[(size_t)j], s_predict);
+    }
+    return true;
   }
 
   void initialise_diff_to_first_order() {  // bdf_state.rs:72-78
@@ -536,7 +620,12 @@ struct Bdf : SolverBase {
     // _update_diff_for_step_size :568-577 : diff_tmp[:,0..order+1] = diff[:,0..order+1]*RU ; swap(diff, diff_tmp)
     gemm_cols(diff_tmp, diff, order + 1, ru);
     std::swap(diff, diff_tmp);
+    for (M& sd : sdiff) {  // :546-548: every sdiff through the SAME scratch matrix (the swap chain hands the previous matrix's columns on)
+      gemm_cols(diff_tmp, sd, order + 1, ru);
+      std::swap(sd, diff_tmp);
+    }
     op.set_c(new_h, alpha[order]);
+    if (pr->sens) s_c = new_h * alpha[order];
     h_ = new_h;
     convergence.reset_eta_timestep_change();
     if (new_h_out) *new_h_out = new_h;
@@ -601,10 +690,19 @@ struct Bdf : SolverBase {
 
   double error_control() const {  // :812-843 (main equations only)
     double err = squared_norm(y_delta, y_, pr->atol, pr->rtol) * error_const2[order_ - 1];
-    return std::fmax(0.0, err);  // `error_norm.max(err)` starting from zero (f64::max drops NaN like fmax)
+    double error_norm = std::fmax(0.0, err);  // `error_norm.max(err)` starting from zero (f64::max drops NaN like fmax)
+    if (pr->sens && pr->sens_error_control)  // :844-858 — note error_const2[order], not [order - 1]
+      for (size_t j = 0; j < sdiff.size(); ++j)
+        error_norm = std::fmax(error_norm, squared_norm(s_deltas[j], s_[j], pr->sens_atol, pr->sens_rtol) * error_const2[order_]);
+    return error_norm;
   }
-  double predict_error_control(int order) const {  // :871-900
-    return squared_norm(diff.column(order + 1), y_, pr->atol, pr->rtol) * error_const2[order];
+  double predict_error_control(int order) const {  // :871-932
+    double error_norm = squared_norm(diff.column(order + 1), y_, pr->atol, pr->rtol) * error_const2[order];
+    if (pr->sens) error_norm = std::fmax(0.0, error_norm);  // with an augmented system the reference's `error_norm.max(err)` chain is visible (NaN handling)
+    if (pr->sens && pr->sens_error_control)
+      for (size_t j = 0; j < sdiff.size(); ++j)
+        error_norm = std::fmax(error_norm, squared_norm(sdiff[j].column(order + 1), s_[j], pr->sens_atol, pr->sens_rtol) * error_const2[order]);
+    return error_norm;
   }
 
   OdeErr step(StopReason& reason) override {  // :1277-1589
@@ -618,6 +716,7 @@ struct Bdf : SolverBase {
       NlErr solve_result = nonlinear_solver.solve_in_place(op, y_delta, t_predict, y_predict, convergence, line_search);
       statistics.number_of_nonlinear_solver_iterations += convergence.niter;
       if (solve_result == NlErr::Ok) sub_assign(y_delta, y_predict);
+      if (solve_result == NlErr::Ok && pr->sens && !sensitivity_solve(t_predict)) solve_result = NlErr::NewtonDiverged;  // SensitivitySolveFailed (:1355-1360)
       if (solve_result != NlErr::Ok) {
         statistics.number_of_nonlinear_solver_fails += 1;
         if (statistics.number_of_nonlinear_solver_fails > maximum_newton_fails) return OdeErr::TooManyNonlinearSolverFailures;
@@ -653,6 +752,7 @@ struct Bdf : SolverBase {
     }
     // take the accepted step
     update_diff(order_, y_delta, diff);
+    for (size_t j = 0; j < sdiff.size(); ++j) update_diff(order_, s_deltas[j], sdiff[j]);  // update_differences_and_integrate_out (:628-643)
     copy_from(y_, y_predict);
     t_ = t_predict;
     dy_ = diff.column(1);
@@ -720,6 +820,14 @@ struct Bdf : SolverBase {
     bool is_forward = h_ > 0.0;
     if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
     interpolate_derivative_from_diff(t, diff, t_, h_, order_, dy);
+    return OdeErr::Ok;
+  }
+  // interpolate_sens_inplace (bdf.rs:1162-1215)
+  OdeErr interpolate_sens(double t, std::vector<V>& out) const {
+    bool is_forward = h_ > 0.0;
+    if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
+    out.assign(sdiff.size(), V(pr->n(), pr->nb()));
+    for (size_t j = 0; j < sdiff.size(); ++j) interpolate_from_diff(t, sdiff[j], t_, h_, order_, out[j]);
     return OdeErr::Ok;
   }
   const V& y() const override { return y_; }

@@ -77,6 +77,18 @@ impl HipModelEquations {
     fn nb(&self) -> i64 {
         self.ctx.nbatch() as i64
     }
+    /// Does the model provide parameter derivatives (forward sensitivities, `OdeEquationsImplicitSens`)?
+    pub fn has_sens(&self) -> bool {
+        unsafe { ffi::dsh_model_has_sens(self.model, self.size) != 0 }
+    }
+    /// `df/dp` at `(x, t)` as an `nstates x nparams` batched matrix in one launch (`NonLinearOpSens::sens_inplace`, op/nonlinear_op.rs:67-81).
+    pub fn rhs_sens_inplace(&self, x: &HipVec, t: f64, sens: &mut HipMat) {
+        check(unsafe { ffi::dsh_model_rhs_sens(self.ctx.ptr(), self.model, self.size, self.nb(), t, x.ptr(), self.p.ptr(), sens.ptr()) }, "dsh_model_rhs_sens");
+    }
+    /// `dy0/dp` as an `nstates x nparams` batched matrix (`SensInit`, ode_equations/sens_equations.rs:62-70).
+    pub fn init_sens_inplace(&self, t: f64, sens0: &mut HipMat) {
+        check(unsafe { ffi::dsh_model_init_sens(self.ctx.ptr(), self.model, self.size, self.nb(), t, self.p.ptr(), sens0.ptr()) }, "dsh_model_init_sens");
+    }
 }
 impl Drop for HipModelEquations {
     fn drop(&mut self) {

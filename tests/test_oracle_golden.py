@@ -330,3 +330,80 @@ def test_deterministic_sin_cos_cover_the_whole_double_range(O):
     z = O.det_fn("sin", [-0.0])[0]
     assert z == 0.0 and np.signbit(z) and not np.signbit(O.det_fn("sin", [0.0])[0])
     assert np.isnan(O.det_fn("sin", [np.inf])[0]) and np.isnan(O.det_fn("cos", [-np.inf])[0]) and O.det_fn("cos", [0.0])[0] == 1.0
+
+
+
+# ------------------------------------------------------------------ forward sensitivities (bdf.rs:934-989, sens_equations.rs)
+def _run_points(o, pts, sens=True):
+    ys, ss = [], []
+    for t in pts:
+        while abs(o.state()["t"]) < abs(t):
+            o.step()
+        ys.append(o.interpolate(t))
+        if sens:
+            ss.append(o.interpolate_sens(t))
+    return np.array(ys), np.array(ss)
+
+
+def test_oracle_bdf_sens_reproduces_the_reference_snapshot_on_exponential_decay(O):
+    """bdf_test_nalgebra_exponential_decay_sens (bdf.rs:1811-1835): problem exponential_decay_problem_sens (exponential_decay.rs:703-742: p = (k, y0) =
+    (0.1, 1), default rtol = atol = 1e-6, sens_rtol = 1e-6, sens_atol = 1e-6), harness test_ode_solver(.., sens = true) (ode_solver/mod.rs:104-194).
+    ALL 13 counters of the two insta snapshots — which only come out with the reference's quirk that the sensitivity operator's c stays 0 until the
+    first step-size change — and the harness' own acceptance norms for states (< 20) and sensitivities (< 29) against the closed forms."""
+    o = O.OracleSolver(O.MODEL_EXPONENTIAL_DECAY, [0.1, 1.0], rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6])
+    pts = [float(i) for i in range(10)]
+    ys, ss = _run_points(o, pts)
+    st = o.stats()
+    assert [st[k] for k in st] == [14, 56, 1, 175, 0, 1, 0, 0, 1, 12, 60, 123, 2]
+    for i, t in enumerate(pts):
+        y_ref = np.full(2, np.exp(-0.1 * t))
+        assert weighted_error_norm(ys[i, 0], y_ref, [1e-6], 1e-6) < 20.0
+        assert weighted_error_norm(ss[i, 0, 0], -t * y_ref, [1e-6], 1e-6) < 29.0   # dy/dk = -t y0 exp(-k t)
+        assert weighted_error_norm(ss[i, 1, 0], y_ref, [1e-6], 1e-6) < 29.0        # dy/dy0 = exp(-k t)
+    # without error control on the sensitivities (turn_off_sensitivities_error_control) the state steps are those of the plain solver
+    o2 = O.OracleSolver(O.MODEL_EXPONENTIAL_DECAY, [0.1, 1.0], rtol=1e-6, atol=[1e-6], sens=True)
+    o3 = O.OracleSolver(O.MODEL_EXPONENTIAL_DECAY, [0.1, 1.0], rtol=1e-6, atol=[1e-6])
+    y2, s2 = _run_points(o2, pts)
+    y3, _ = _run_points(o3, pts, sens=False)
+    assert np.array_equal(y2, y3) and o2.stats()["number_of_steps"] == o3.stats()["number_of_steps"]
+    assert np.abs(s2[-1, 1, 0] - np.exp(-0.9)).max() < 1e-4
+
+
+def test_oracle_bdf_sens_on_the_robertson_ode(O):
+    """test_bdf_nalgebra_robertson_ode_sens (bdf.rs:2323-2347; problem test_models/robertson_ode_with_sens.rs:8-85).  States against the problem's own
+    SUNDIALS table under the harness norm; sensitivities against central finite differences of the plain solver.  The counters of this snapshot
+    (364 setups, 840 steps, 226 error-test failures, 5099 Newton iterations) are NOT reproduced bit for bit (370 / 851 / 234 / 5166 here): the run rejects
+    every fourth step and is chaotic in the last bit of pow() — switching this oracle to the other pow() of this repository moves it to 942 steps — so the
+    pin on the reference's step sequence for the sensitivity path is the exponential-decay snapshot above; here the counters are held to 5 %."""
+    table = [([1.0, 0.0, 0.0], 0.0), ([9.851641e-01, 3.386242e-05, 1.480205e-02], 0.4), ([9.055097e-01, 2.240338e-05, 9.446793e-02], 4.0),
+             ([7.158017e-01, 9.185037e-06, 2.841892e-01], 40.0), ([4.505360e-01, 3.223271e-06, 5.494608e-01], 400.0),
+             ([1.832299e-01, 8.944378e-07, 8.167692e-01], 4000.0), ([3.898902e-02, 1.622006e-07, 9.610108e-01], 40000.0),
+             ([4.936383e-03, 1.984224e-08, 9.950636e-01], 400000.0), ([5.168093e-04, 2.068293e-09, 9.994832e-01], 4000000.0),
+             ([5.202440e-05, 2.081083e-10, 9.999480e-01], 4.0e7), ([5.201061e-06, 2.080435e-11, 9.999948e-01], 4.0e8),
+             ([5.258603e-07, 2.103442e-12, 9.999995e-01], 4.0e9), ([6.934511e-08, 2.773804e-13, 9.999999e-01], 4.0e10)]
+    p0 = np.array([0.04, 1.0e4, 3.0e7])
+    kw = dict(model_size=1, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+    o = O.OracleSolver(O.MODEL_ROBERTSON_ODE, p0, sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6, 1e-6], **kw)
+    pts = [t for _, t in table]
+    ys, ss = _run_points(o, pts)
+    for (ref, _), y in zip(table, ys):
+        assert weighted_error_norm(y[0], ref, kw["atol"], kw["rtol"]) < 20.0
+    st = o.stats()
+    for key, snap in (("number_of_steps", 840), ("number_of_linear_solver_setups", 364), ("number_of_error_test_failures", 226), ("number_of_nonlinear_solver_iterations", 5099)):
+        assert abs(st[key] - snap) <= 0.05 * snap, (key, st[key], snap)
+    # dy/dp_j against central differences at t = 0.4 ... 400 (tight tolerances for the difference quotient)
+    tight = dict(model_size=1, rtol=1e-10, atol=[1e-14, 1e-16, 1e-14])
+    os_ = O.OracleSolver(O.MODEL_ROBERTSON_ODE, p0, sens=True, sens_rtol=1e-10, sens_atol=[1e-12], **tight)
+    tp = [0.4, 4.0, 40.0, 400.0]
+    _, s_tight = _run_points(os_, tp)
+    for j in range(3):
+        dp = 1e-5 * p0[j]
+        pp, pm = p0.copy(), p0.copy()
+        pp[j] += dp
+        pm[j] -= dp
+        yp, _ = _run_points(O.OracleSolver(O.MODEL_ROBERTSON_ODE, pp, **tight), tp, sens=False)
+        ym, _ = _run_points(O.OracleSolver(O.MODEL_ROBERTSON_ODE, pm, **tight), tp, sens=False)
+        fd = (yp - ym)[:, 0] / (2 * dp)
+        assert np.abs(s_tight[:, j, 0] - fd).max() <= 2e-4 * np.abs(fd).max(), j
+    with pytest.raises(O.OracleError):
+        O.OracleSolver(O.MODEL_ROBERTSON_DAE, p0, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], sens=True)   # DAE sensitivities are not restated
