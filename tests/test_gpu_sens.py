@@ -72,7 +72,8 @@ def test_exponential_decay_sensitivities_equal_the_oracle_bitwise_and_reproduce_
         st = s.stats()
         assert [st[k] for k in st] == [14, 56, 1, 175, 0, 1, 0, 0, 1, 12, 60, 123, 2]
     t = np.array(pts)[:, None]
-    assert np.abs(ss[:, 1, 0, :] - np.exp(-0.1 * t)).max() < 2e-5 and np.abs(ss[:, 0, 0, :] + t * np.exp(-0.1 * t)).max() < 2e-5
+    tol = 2e-5 if error_control else 5e-3  # outside the error control nothing bounds the effect of the reference's c = 0 start on the sensitivities
+    assert np.abs(ss[:, 1, 0, :] - np.exp(-0.1 * t)).max() < tol and np.abs(ss[:, 0, 0, :] + t * np.exp(-0.1 * t)).max() < tol
     nb = 5
     p = np.stack([0.1 * (np.arange(nb) + 1), 1.0 + np.arange(nb)], axis=1)
     sb = H.Solver("exponential_decay", p, nbatch=nb, rtol=1e-6, atol=[1e-6], **skw)
