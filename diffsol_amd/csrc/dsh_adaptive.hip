@@ -32,6 +32,7 @@
 #include "dsh_resident.hpp"
 
 #include "dsh_adaptive_kernel.hpp"
+#include "dsh_member_sched_kernel.hpp"
 #include "dsh_jit.hpp"
 
 using namespace dsh;
@@ -133,9 +134,15 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   bool launched = false;
   DSH_HIP_CHECK(timing_begin(ctx));
+  // per-member control of the register-resident models can run on the phase-scheduled kernel (dsh_member_sched_kernel.hpp; same bits) with
+  // DSH_MEMBER_SCHED=1: opt-in (measured slower than the nested-loop kernel on C2: 10.75 vs 9.23 ms); read per call: tests run both kernels
+  const bool sched_env = [] { const char* e = std::getenv("DSH_MEMBER_SCHED"); return e && e[0] == '1'; }();
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
-    const std::string name = std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
-    rc = jit_launch(ctx, model, "dsh_adaptive_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
+    const JitInfo* ji = jit_info(model);
+    const bool sched = sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
+    const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
+                                   : std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
+    rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : "dsh_adaptive_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
                     stats, status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     launched = true;
@@ -146,6 +153,10 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
 #define DSH_ADAPTIVE_LAUNCH(BA, WAVE) \
   hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
       if (C.r.o.group == 64) { if (ba) DSH_ADAPTIVE_LAUNCH(true, true); else DSH_ADAPTIVE_LAUNCH(false, true); }
+      else if (sched_env) {
+        if (ba) hipLaunchKernelGGL((k_bdf_member_sched<Mdl, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+        else hipLaunchKernelGGL((k_bdf_member_sched<Mdl, false>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+      }
       else { if (ba) DSH_ADAPTIVE_LAUNCH(true, false); else DSH_ADAPTIVE_LAUNCH(false, false); }
 #undef DSH_ADAPTIVE_LAUNCH
     }

@@ -383,3 +383,46 @@ def test_deterministic_pow_is_the_same_function_on_host_and_device_and_close_to_
     ref = np.power(x, y)
     assert np.max(np.abs(got - ref) / np.spacing(ref)) <= 1.0
     assert O.det_pow(0.0, -0.5) == np.inf and O.det_pow(4.0, 0.5) == 2.0 and O.det_pow(7.0, 0.0) == 1.0 and np.isnan(O.det_pow(np.nan, 0.5))
+
+
+@pytest.mark.parametrize("model,method", [("robertson_ode", 0), ("robertson", 0), ("exponential_decay_with_root", 0), ("exponential_decay_with_algebraic", 0)])
+def test_phase_scheduled_per_member_kernel_gives_the_bits_of_the_nested_loop_kernel_and_of_the_oracle(H, O, det_pow, monkeypatch, model, method):
+    """Per-member control runs on the nested-loop kernel by default; DSH_MEMBER_SCHED=1 selects the phase-scheduled kernel (k_bdf_member_sched: one
+    phase per wavefront pass, chosen by ballot).  Both must give every member's states, counters, event times, column counts and failure codes
+    bit for bit — and equal the oracle's independent solves.  Ensembles are sized and parameterised so that lanes of a wavefront sit in different phases
+    (different iteration counts, rejected steps, refactorisations, early event stops, a member that fails)."""
+    rng = np.random.default_rng(12)
+    nb = 333
+    if model in ("robertson_ode", "robertson"):
+        p = np.exp(rng.uniform(np.log([0.004, 1e3, 3e6]), np.log([0.4, 1e5, 3e8]), (nb, 3)))
+        kw = dict(model_size=1 if model == "robertson_ode" else 0, rtol=1e-5, atol=[1e-9, 1e-13, 1e-8])
+        t_eval = [0.4, 4.0, 40.0, 400.0, 4e3, 4e4]
+    elif model == "exponential_decay_with_root":
+        p = np.stack([rng.uniform(0.01, 5.0, nb), rng.uniform(0.7, 3.0, nb)], axis=1)
+        kw = dict(model_size=0, rtol=1e-7, atol=[1e-8, 1e-8])
+        t_eval = [0.1, 0.5, 2.0, 8.0, 30.0]
+    else:
+        p = rng.uniform(0.05, 5.0, (nb, 1))
+        kw = dict(model_size=0, rtol=1e-6, atol=[1e-7] * 3)
+        t_eval = [0.5, 3.0, 20.0]
+    out = {}
+    for sched in ("1", "0"):
+        monkeypatch.setenv("DSH_MEMBER_SCHED", sched)
+        s = H.Solver(model, p, nbatch=nb, method=method, **kw)
+        out[sched] = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    (y1, tot1, m1), (y0, tot0, m0) = out["1"], out["0"]
+    assert np.array_equal(y1, y0, equal_nan=True) and tot1 == tot0
+    for k in ("stats", "status", "root_idx", "ncols"):
+        assert np.array_equal(m1[k], m0[k]), k
+    assert np.array_equal(m1["t_root"], m0["t_root"], equal_nan=True)
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL[model], p, t_eval, nthreads=8, method=method, **kw)
+    ok = m1["status"] == 0
+    assert int((~ok).sum()) == failed
+    assert np.array_equal(y1[:, ok], np.transpose(yo, (1, 0, 2))[:, ok], equal_nan=True) and np.array_equal(m1["stats"].T[ok], so[ok])
+    # a run in which members fail (error-test limit): the same failure codes from both kernels
+    for sched in ("1", "0"):
+        monkeypatch.setenv("DSH_MEMBER_SCHED", sched)
+        s = H.Solver(model, p, nbatch=nb, method=method, options=dict(max_error_test_failures=1, max_nonlinear_solver_failures=2), **kw)
+        out[sched] = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    assert np.array_equal(out["1"][2]["status"], out["0"][2]["status"]) and np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
+    assert np.array_equal(out["1"][2]["stats"], out["0"][2]["stats"])
