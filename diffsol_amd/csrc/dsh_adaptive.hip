@@ -140,9 +140,12 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
     const JitInfo* ji = jit_info(model);
     const bool sched = sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
+    // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
+    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }();
+    const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
-                                   : std::string("dsh::k_bdf_adaptive<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
-    rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : "dsh_adaptive_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
+                             : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;
+    rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : (lane_v2 ? "dsh_lane_banded_kernel.hpp" : "dsh_adaptive_kernel.hpp"), name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
                     stats, status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     launched = true;

@@ -187,6 +187,8 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
     // and integrates 262 144 members in 0.245 s instead of 0.308 s.  DSH_BANDED_NOUNROLL=0 unrolls them like the register-resident kernels.
     const char* nu = std::getenv("DSH_BANDED_NOUNROLL");
     if (!(nu && nu[0] == '0')) tu += "#define DSH_NOUNROLL_N 1\n";
+    tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";
+    if (const char* un = std::getenv("DSH_LANE_BANDED_UNROLL")) if (*un) tu += std::string("#define DSH_LANE_BANDED_UNROLL ") + un + "\n";  // tuning knob
     tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }
   tu += rec.source;
@@ -414,7 +416,7 @@ int dsh_model_precompile(int model_id, int family) {
     if (family != 2 && family != 3) { set_error("dsh_model_precompile: the banded lane-per-member form only has the device-resident integrators (families 2, 3)"); return DSH_E_UNSUPPORTED; }
     // the variants with shared tolerances and per-member control (what the host-side problem uses) are enough to pay the cost up front
     std::vector<std::pair<const char*, std::string>> units;
-    if (family == 2) units.push_back({"dsh_adaptive_kernel.hpp", "dsh::k_bdf_adaptive<dsh::JitModel, true, false>"});
+    if (family == 2) units.push_back({"dsh_lane_banded_kernel.hpp", "dsh::k_bdf_lane_banded<dsh::JitModel, true, false>"});
     else for (int s = 3; s <= 4; ++s) units.push_back({"dsh_sdirk_kernel.hpp", "dsh::k_sdirk_resident<dsh::JitModel, true, false, " + std::to_string(s) + ">"});
     for (const auto& u : units) {
       const std::string key = std::string(u.first) + "|" + u.second;

@@ -12,11 +12,14 @@ template <int MODEL, int SIZE_N, int NPAR, int NROOT, int K>
 struct DynLane {
   static constexpr int N = SIZE_N, NP = NPAR, NROOTS = NROOT, NOUT = 0, BAND_K = K;
   static constexpr bool HAS_MASS = false;
-  __device__ static void rhs(double t, const double (&x)[N], const double (&p)[NP], double (&y)[N]) {
+  // f is evaluated in every Newton iteration of the lane-per-member integrators, whose vectors live in per-lane memory: inlined (scratch addressing
+  // instead of generic pointers) and fully unrolled (the component index is a constant: the model's case distinctions fold away and all loads of x can be
+  // in flight together — rolled, every component waits for its own loads, ~n serialised memory round trips per call)
+  __device__ __forceinline__ static void rhs(double t, const double (&x)[N], const double (&p)[NP], double (&y)[N]) {
     auto X = [&](int64_t k) { return x[k]; };
     auto V = [&](int64_t) { return 0.0; };
     auto P = [&](int64_t k) { return p[k]; };
-DSH_UNROLL_N
+#pragma unroll
     for (int i = 0; i < N; ++i) y[i] = dyn_component(MODEL, (int64_t)N, t, (int64_t)i, X, V, P, false);
   }
   __device__ static void jac_mul(double t, const double (&x)[N], const double (&p)[NP], const double (&v)[N], double (&y)[N]) {

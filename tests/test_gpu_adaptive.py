@@ -426,3 +426,28 @@ def test_phase_scheduled_per_member_kernel_gives_the_bits_of_the_nested_loop_ker
         out[sched] = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
     assert np.array_equal(out["1"][2]["status"], out["0"][2]["status"]) and np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
     assert np.array_equal(out["1"][2]["stats"], out["0"][2]["stats"])
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_streaming_lane_per_member_kernel_gives_the_bits_of_the_register_array_form(H, monkeypatch, group):
+    """Banded run-time-sized models run k_bdf_lane_banded (dsh_lane_banded_kernel.hpp: fused passes over per-lane memory, chunked loads, buffer-index swap
+    of diff / diff_tmp, next prediction made by the accept pass); DSH_LANE_BANDED_V1=1 selects k_bdf_adaptive's banded branch (one loop per vector
+    operation).  Same arithmetic in the same order: states, counters, event data bit for bit — for sizes that are / are not multiples of the load chunks
+    (13 is prime), bandwidth 1 and 2, per-member control and wavefront lock-step groups, with steps that fail and orders that change."""
+    rng = np.random.default_rng(8)
+    cases = [("heat1d", rng.uniform(0.5, 2.0, (130, 1)), [0.01, 0.1, 0.3], 13, dict(rtol=1e-6, atol=[1e-7])),
+             ("robertson_ode", robertson_params(70), [0.4, 4.0, 40.0, 400.0], 4, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 4)),
+             ("spm", np.linspace(0.6, 1.4, 70)[:, None], [600.0, 1800.0, 3600.0], 20, dict(rtol=1e-6, atol=[1e-6]))]
+    for model, p, t_eval, size, tol in cases:
+        if group == 64 and model == "spm":
+            t_eval = [60.0, 600.0, 1200.0]  # before any cut-off: lock-step groups have no per-member events
+        out = {}
+        for v1 in ("0", "1"):
+            monkeypatch.setenv("DSH_LANE_BANDED_V1", v1)
+            s = H.Solver(model, p, nbatch=len(p), model_size=size, **tol)
+            out[v1] = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+        (ya, ta, ma), (yb, tb, mb) = out["0"], out["1"]
+        assert ta == tb and ta["number_of_steps"] > 20 * len(p), model
+        assert np.array_equal(ya, yb, equal_nan=True), model
+        for k in ma:
+            assert np.array_equal(ma[k], mb[k], equal_nan=True), (model, k)
