@@ -257,9 +257,21 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
   if (n > 8 && lu->band_k > 0) {  // banded factors: one lane per system
-    g = grid_for(nb, 64);
+    // small ensembles: 8 systems per wavefront with the operands prefetched by all 64 lanes (k_lu_band_solve_wide: same bits, the memory latency off the
+    // sequential chain); large ones fill the machine with one lane per system.  DSH_LU_BAND_WIDE=0 / 1 forces either.
+    static const int wide_env = [] { const char* e = std::getenv("DSH_LU_BAND_WIDE"); return e && *e ? std::atoi(e) : -1; }();
+    const bool wide = wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384);  // long chains, few wavefronts (n = 42 x 32 768: 43 us one lane per system, 171 us wide)
+    g = wide ? grid_for(nb, 8) : grid_for(nb, 64);
     int rc = begin_records(ctx, g.x, &rec, &seq);
     if (rc != DSH_OK) return rc;
+    if (wide) {
+      switch (lu->band_k) {
+        case 1: hipLaunchKernelGGL((k_lu_band_solve_wide<1, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+        case 2: hipLaunchKernelGGL((k_lu_band_solve_wide<2, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+        case 3: hipLaunchKernelGGL((k_lu_band_solve_wide<3, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+        default: hipLaunchKernelGGL((k_lu_band_solve_wide<4, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
+      }
+    } else
     switch (lu->band_k) {
       case 1: hipLaunchKernelGGL((k_lu_band_solve<1>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
       case 2: hipLaunchKernelGGL((k_lu_band_solve<2>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;

@@ -13,6 +13,7 @@
 // eliminated matrix), compile-time indices only.  Layouts (batch-fastest, coalesced across lanes): input = the dense matrix (j*n + i)*nb + b;
 // U(r, r+d) at ((d)*n + r)*nb + b for d = 0..2K; multiplier of row j+r at step j at ((2K+1 + r-1)*n + j)*nb + b; pivots k*nb + b.
 #pragma once
+#include <type_traits>
 #include "dsh_device.hpp"
 
 namespace dsh {
@@ -208,6 +209,194 @@ __global__ __launch_bounds__(64) void k_lu_band_solve(int64_t n, int64_t nb, con
     }
   }
   block_publish(0ull, 0ull, bad, rec, seq);
+}
+
+
+// Banded solve for SMALL ensembles (a few thousand systems): same factors, same arithmetic in the same order as k_lu_band_solve — bit-identical
+// solutions — with the memory latency taken off the sequential chain.
+// One lane per system gives nb / 64 wavefronts; at BASELINE config 3's shape (n = 512, 4096 systems) that is 64 wavefronts, each walking a 2 x 512-step
+// dependent chain whose operands arrive 32 steps at a time: 64 memory round trips of ~3 us per solve, 204 us, 0.53 TB/s (profiles/r01_lu_bench.md).
+// Here a wavefront owns S = 8 systems.  Its 64 lanes are 8 row groups x 8 systems: every load instruction fetches one operand of 8 consecutive
+// steps (64-byte segments of 8 neighbouring systems), several chunks of 16 steps ahead of the chain (up to ~40 loads, ~100 steps, in flight per
+// wavefront; 8x as many wavefronts), lands in registers, and is handed through LDS to the 8 lanes that run the chain.  Results go back through LDS
+// and are stored by all 64 lanes.  No data is shared between systems and no operation is reordered.
+template <int K, int S>
+__global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb, const double* __restrict__ fac, const int32_t* __restrict__ piv, double* __restrict__ rhs,
+                                                           unsigned long long* rec, unsigned int seq) {
+  constexpr int G = 64 / S, R = K + 1, C = 2 * K + 1;
+  constexpr int CHK = 16;           // steps per chunk
+  constexpr int Q = CHK / G;        // load instructions per operand and chunk
+  constexpr int FO = K + 2;         // forward operands per step: K multipliers, pivot offset, the entry that enters the window
+  constexpr int BO = C + 1;         // backward: C entries of U, the entry that enters the window
+  constexpr int MO = BO > FO ? BO : FO;
+  constexpr int DF = (40 / (FO * Q)) < 2 ? 2 : (40 / (FO * Q));  // chunks in flight
+  constexpr int DB = (40 / (BO * Q)) < 2 ? 2 : (40 / (BO * Q));
+  static_assert(CHK % G == 0, "chunk must be a multiple of the row groups");
+  __shared__ double sOp[MO][CHK][S];
+  __shared__ double sOut[CHK][S];
+  const int lane = threadIdx.x, s = lane % S, g = lane / S;
+  const int64_t b0 = (int64_t)blockIdx.x * S + s;
+  const bool valid = b0 < nb;
+  const int64_t b = valid ? b0 : nb - 1;  // lanes past the ensemble shadow the last system (no stores)
+  const bool chain = g == 0;
+  const int64_t nch = (n + CHK - 1) / CHK;
+  unsigned long long bad = 0ull;
+
+  // ---------------------------------------------------------------- forward: interchanges interleaved with the unit-lower-triangular solve
+  {
+    double pf[DF][FO][Q];
+    int pp[DF][Q];  // the pivot rows stay integers until they land (a conversion at issue would wait for the load)
+    auto issue = [&](int64_t c, double (&pd)[FO][Q], int (&pi)[Q]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int64_t j = min(c * CHK + q * G + g, n - 1);  // clamped, unconditional loads; steps beyond n are skipped by the chain
+#pragma unroll
+        for (int r = 0; r < K; ++r) pd[r][q] = fac[((int64_t)(C + r) * n + j) * nb + b];
+        pi[q] = piv[j * nb + b];
+        pd[K + 1][q] = rhs[min(j + 1 + K, n - 1) * nb + b];
+      }
+    };
+    double v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const double t = rhs[min((int64_t)r, n - 1) * nb + b]; v[r] = r < n ? t : 0.0; }
+    // the window is loop-carried state: its loads complete here, before the prefetch starts — otherwise every first use inside the loop is given a wait
+    // that drains the prefetch queue
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(v[r]));
+#pragma unroll
+    for (int d = 0; d < DF; ++d) issue(d, pf[d], pp[d]);
+    // every trip runs all DF stages and every stage issues its loads (clamped rows past the end): with a fixed number of younger loads behind each
+    // landing the compiler's s_waitcnt leaves the prefetch in flight; a conditional issue would make it wait for everything
+    for (int64_t c0 = 0; c0 < nch; c0 += DF) {
+#pragma unroll
+      for (int d = 0; d < DF; ++d) {
+        const int64_t c = c0 + d;
+        {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int o = 0; o < FO; ++o) if (o != K) sOp[o][q * G + g][s] = pf[d][o][q];
+            sOp[K][q * G + g][s] = (double)(pp[d][q] - (int)min(c * CHK + q * G + g, n - 1));  // pivot row - step
+          }
+          issue(c + DF, pf[d], pp[d]);
+          __builtin_amdgcn_wave_barrier();
+          if (chain) {
+            double l[CHK][K], pvd[CHK], nxt[CHK];
+#pragma unroll
+            for (int t = 0; t < CHK; ++t) {
+#pragma unroll
+              for (int r = 0; r < K; ++r) l[t][r] = sOp[r][t][s];
+              pvd[t] = sOp[K][t][s];
+              nxt[t] = sOp[K + 1][t][s];
+            }
+            // full chunks run without a branch per step (a scalar branch on a vector compare costs more than the step's arithmetic)
+            auto steps = [&](auto full) __attribute__((always_inline)) {
+              const int jb = (int)c * CHK, ni = (int)n;
+#pragma unroll
+              for (int t = 0; t < CHK; ++t) {
+                const int j = jb + t;
+                if (decltype(full)::value || j < ni) {
+                  const int pv = (int)pvd[t];
+                  const double top = v[0];
+                  double x = top;
+#pragma unroll
+                  for (int r = 1; r < R; ++r) {
+                    const bool sel = (r == pv);
+                    const double cur = v[r];
+                    x = sel ? cur : x;
+                    v[r] = sel ? top : cur;
+                  }
+                  sOut[t][s] = x;
+#pragma unroll
+                  for (int r = 1; r < R; ++r) v[r] = (-x) * l[t][r - 1] + v[r];
+#pragma unroll
+                  for (int r = 0; r + 1 < R; ++r) v[r] = v[r + 1];
+                  v[R - 1] = j + 1 + K < ni ? nxt[t] : 0.0;
+                }
+              }
+            };
+            if ((c + 1) * CHK <= n) steps(std::true_type{}); else steps(std::false_type{});
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const int64_t j = c * CHK + q * G + g;
+            if (valid && j < n) rhs[j * nb + b0] = sOut[q * G + g][s];
+          }
+        }
+      }
+    }
+  }
+  __threadfence();  // the backward sweep reads, from other lanes, what the forward sweep stored
+  // ---------------------------------------------------------------- backward with U (bandwidth 2K): chunk c covers rows n-1 - (c*CHK + t)
+  {
+    double pb[DB][BO][Q];
+    auto issue = [&](int64_t c, double (&pd)[BO][Q]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int64_t i = max(n - 1 - (c * CHK + q * G + g), (int64_t)0);
+#pragma unroll
+        for (int d = 0; d < C; ++d) pd[d][q] = fac[((int64_t)d * n + max(i - d, (int64_t)0)) * nb + b];  // U(i-d, i)
+        pd[C][q] = rhs[max(i - C, (int64_t)0) * nb + b];
+      }
+    };
+    double w[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) { const int64_t r = n - 1 - (C - 1) + q; const double t = rhs[max(r, (int64_t)0) * nb + b]; w[q] = r >= 0 ? t : 0.0; }
+#pragma unroll
+    for (int q = 0; q < C; ++q) asm volatile("" : "+v"(w[q]));
+#pragma unroll
+    for (int d = 0; d < DB; ++d) issue(d, pb[d]);
+    for (int64_t c0 = 0; c0 < nch; c0 += DB) {
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const int64_t c = c0 + d;
+        {
+#pragma unroll
+          for (int o = 0; o < BO; ++o)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) sOp[o][q * G + g][s] = pb[d][o][q];
+          issue(c + DB, pb[d]);
+          __builtin_amdgcn_wave_barrier();
+          if (chain) {
+            double u[CHK][C], nxt[CHK];
+#pragma unroll
+            for (int t = 0; t < CHK; ++t) {
+#pragma unroll
+              for (int d2 = 0; d2 < C; ++d2) u[t][d2] = sOp[d2][t][s];
+              nxt[t] = sOp[C][t][s];
+            }
+            auto steps = [&](auto full) __attribute__((always_inline)) {
+              const int ib = (int)n - 1 - (int)c * CHK;
+#pragma unroll
+              for (int t = 0; t < CHK; ++t) {
+                const int i = ib - t;
+                if (decltype(full)::value || i >= 0) {
+                  const double diag = u[t][0];
+                  if (diag == 0.0) bad = 1ull;
+                  const double x = w[C - 1] / diag;
+                  sOut[t][s] = x;
+#pragma unroll
+                  for (int d2 = 1; d2 < C; ++d2) { const double uu = i - d2 >= 0 ? u[t][d2] : 0.0; w[C - 1 - d2] = (-x) * uu + w[C - 1 - d2]; }  // as k_lu_band_solve: entries above row 0 are zeros
+#pragma unroll
+                  for (int q = C - 1; q > 0; --q) w[q] = w[q - 1];
+                  w[0] = i - C >= 0 ? nxt[t] : 0.0;
+                }
+              }
+            };
+            if ((c + 1) * CHK <= n) steps(std::true_type{}); else steps(std::false_type{});
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const int64_t i = n - 1 - (c * CHK + q * G + g);
+            if (valid && i >= 0) rhs[i * nb + b0] = sOut[q * G + g][s];
+          }
+        }
+      }
+    }
+  }
+  block_publish(0ull, 0ull, (chain && valid) ? bad : 0ull, rec, seq);
 }
 
 }  // namespace dsh
