@@ -212,6 +212,8 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
           DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<16, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
           DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
           DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<8, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
+          DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_blocked<32, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 141 * 1024));
           attr_set = true;
         }
         static const bool phase_profile = [] { const char* e = getenv("DSH_LU_PHASE_PROFILE"); return e && atoi(e) != 0; }();
@@ -226,6 +228,16 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
       hipLaunchKernelGGL((k_lu_factor_blocked<NBK, 256>), dim3((unsigned)nb), dim3(256), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
                          lu->pivots, lu->singular, lu->singular_epoch, phase_clocks);                                                                   \
   } while (0)
+        // opt-in: trailing update on the FP64 matrix cores (not bit-identical: tested to a tolerance).  Read per call so that tests can compare both.
+        const bool mfma = [] { const char* e = getenv("DSH_LU_MFMA"); return e && e[0] == '1'; }() && n % 16 == 0 && blocked_lds_bytes(n, 32) <= budget;
+        if (mfma) {
+          if (threads == 512)
+            hipLaunchKernelGGL((k_lu_factor_blocked<32, 512, true>), dim3((unsigned)nb), dim3(512), blocked_lds_bytes(n, 32), ctx->stream, (int)n, nb, lu->factors, lu->pivots,
+                               lu->singular, lu->singular_epoch, phase_clocks);
+          else
+            hipLaunchKernelGGL((k_lu_factor_blocked<32, 256, true>), dim3((unsigned)nb), dim3(256), blocked_lds_bytes(n, 32), ctx->stream, (int)n, nb, lu->factors, lu->pivots,
+                               lu->singular, lu->singular_epoch, phase_clocks);
+        } else
         if (blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
         else if (blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
         else if (blocked_lds_bytes(n, 8) <= budget) DSH_LU_BLOCKED(8);

@@ -124,7 +124,14 @@ __global__ void k_lu_solve_global_coop(int n, int64_t nb, const double* __restri
 // Every element still receives exactly the updates a_rc = (-u_kc) * l_rk + a_rc for k ascending, each as a separate multiply and add, so
 // the factors are bit-identical to the unblocked kernels and the oracle; only the number of passes over the trailing matrix changes
 // (n/NB instead of n): HBM/L2 traffic per system ~ 16 n^3 / (3 NB) bytes instead of 16 n^3 / 3.
-template <int NB, int THREADS>
+// MFMA = true (opt-in, DSH_LU_MFMA=1, n a multiple of 16): the trailing update runs on the FP64 matrix cores, v_mfma_f64_16x16x4_f64, one 16 x 16 tile of
+// A22 per wavefront and step, A22 -= L21 U12 as eight chained 16x16x4 products.  Operand layout found by experiment (scripts/ubench/mfma_f64_layout.hip):
+// a(l) = A[l % 16][l / 16], b(l) = B[l / 16][l % 16], d(l, r) = D[4 r + l / 16][l % 16].  The product is formed TRANSPOSED — MFMA row index = column of
+// A22, MFMA column index = row of A22 — so that every register of the accumulator holds 16 consecutive rows of one column (128-byte segments of the
+// column-major factor storage) and the L21 operand of a row tile is loaded once for all its column tiles.  The matrix cores fuse each multiply-add and
+// sum the four products of an instruction in their own order: results differ from the bit-exact path in the last bits (and a near-tie between pivot
+// candidates may then resolve differently), which is why this is opt-in and tested to a tolerance (tests/test_gpu_lu_models.py), not bitwise.
+template <int NB, int THREADS, bool MFMA = false>
 __global__ __launch_bounds__(THREADS) void k_lu_factor_blocked(int n, int64_t nb, double* __restrict__ f_aos, int32_t* __restrict__ piv_aos,
                                                                    unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
   // optional phase profile (DSH_LU_PHASE_PROFILE=1): workgroup 0 accumulates the 100 MHz wall clock per phase
@@ -231,6 +238,37 @@ __global__ __launch_bounds__(THREADS) void k_lu_factor_blocked(int n, int64_t nb
     }
     __syncthreads();
     mark(4);
+    if constexpr (MFMA) {
+      // ---- 6 (matrix cores). mc is a multiple of 16 here (n % 16 == 0, NB % 16 == 0)
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+      const int ntile = mc / 16;
+      for (int tr = wave; tr < ntile; tr += THREADS / 64) {
+        const int r0 = jb + w + tr * 16;
+        double bl[NB / 4];  // L21^T operand of this row tile: L21[r0 + lr][4 kb + lg]
+#pragma unroll
+        for (int kb = 0; kb < NB / 4; ++kb) bl[kb] = A[(size_t)(jb + kb * 4 + lg) * n + r0 + lr];
+        double* ctile = A + (size_t)(jb + w + lg) * n + r0 + lr;  // element (row r0 + lr, column jb + w + c0 + 4 reg + lg) at ctile[(c0 + 4 reg) * n]
+        d4 acc, nxt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = ctile[(size_t)(4 * q) * n];
+        for (int tc = 0; tc < ntile; ++tc) {
+          const int c0 = tc * 16;
+          acc = nxt;
+          if (tc + 1 < ntile) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nxt[q] = ctile[(size_t)(c0 + 16 + 4 * q) * n];
+          }
+#pragma unroll
+          for (int kb = 0; kb < NB / 4; ++kb) {
+            const double au = -sh[(c0 + lr) * LDU + kb * 4 + lg];  // (-U12)^T operand: -U12[4 kb + lg][c0 + lr]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bl[kb], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ctile[(size_t)(c0 + 4 * q) * n] = acc[q];
+        }
+      }
+    } else
     // ---- 6. trailing update: thread = row, NB multipliers in registers, 4 columns in flight
     for (int r = jb + w + tid; r < n; r += THREADS) {
       double l[NB];

@@ -374,3 +374,33 @@ def test_lu_solve_with_several_right_hand_sides_equals_separate_solves_bitwise(H
     got = B.to_array()
     for r in range(nrhs):
         assert np.array_equal(got[:, :, r], O.lu_solve(a, rhs[:, :, r])[0])
+
+
+@pytest.mark.parametrize("n,nb", [(144, 5), (256, 3), (512, 4)])
+def test_opt_in_matrix_core_trailing_update_agrees_with_the_bit_exact_factorisation_to_tolerance(H, ctx1, monkeypatch, n, nb):
+    """DSH_LU_MFMA=1: the trailing update of the blocked dense LU (n > 137, n a multiple of 16) on v_mfma_f64_16x16x4_f64 (dsh_lu_coop.hpp).  The matrix
+    cores fuse the multiply-adds, so this path is NOT bit-identical — north_star's bar for floating point is 1e-6 relative.  Held here far tighter on
+    well-conditioned systems: same pivot rows, factors to 1e-11 of the largest entry, solutions to 1e-9 relative, residual at rounding level; and the
+    default path (no environment variable) is untouched — bitwise equal to what it was before the call."""
+    rng = np.random.default_rng(n)
+    c = ctx1.clone_with_nbatch(nb)
+    a = rng.standard_normal((nb, n, n)) + np.eye(n) * 3.0
+    a[:, 0, 0] *= 1e-6  # force at least one interchange
+    b = rng.standard_normal((nb, n))
+    out = {}
+    for flag in ("0", "1", "0"):
+        monkeypatch.setenv("DSH_LU_MFMA", flag)
+        lu = H.HipLU(c, n)
+        lu.factor(H.HipMat.from_array(a, c))
+        x = H.HipVec.from_vec(b, c)
+        lu.solve_in_place(x)
+        f, p = lu.factors()
+        out.setdefault(flag, []).append((f, p, x.clone_as_vec()))
+    (f0, p0, x0), (f0b, p0b, x0b) = out["0"]
+    f1, p1, x1 = out["1"][0]
+    assert np.array_equal(f0, f0b) and np.array_equal(p0, p0b) and np.array_equal(x0, x0b)
+    assert not np.array_equal(f0, f1), "the matrix-core path did not run (factors are bitwise those of the vector path)"
+    assert np.array_equal(p0, p1)
+    assert np.max(np.abs(f1 - f0)) <= 1e-11 * np.max(np.abs(f0))
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * np.max(np.abs(x0))
+    assert np.max(np.abs(np.einsum("bij,bj->bi", a, x1) - b)) <= 1e-10 * n
