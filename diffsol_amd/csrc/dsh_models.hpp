@@ -71,6 +71,13 @@ struct ExponentialDecayAlgebraicT {
   }
   __device__ static void init(double, const double (&)[NP], double (&y)[N]) { y[0] = 1.0; y[1] = 1.0; y[2] = BATCHED_INIT ? 1.0 : 0.0; }
   __device__ static void root(double, const double (&)[N], const double (&)[NP], double (&)[1]) {}
+  // exponential_decay_with_algebraic.rs:33-44 (sens: y = x * (-v[0]), last = 0), :128-135 (init_sens: zeros)
+  __device__ static void sens_mul(double, const double (&x)[N], const double (&)[NP], const double (&v)[NP], double (&y)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = x[i] * (-v[0]);
+    y[N - 1] = 0.0;
+  }
+  __device__ static void init_sens_mul(double, const double (&)[NP], const double (&)[NP], double (&y)[N]) { y[0] = 0.0; y[1] = 0.0; y[2] = 0.0; }
 };
 
 // test_models/robertson_ode.rs:71-90 (rhs, jac_mul), :92-101 (init); one group per system (ensembles vary p, not ngroups)
@@ -123,6 +130,13 @@ struct RobertsonDae {
   }
   __device__ static void init(double, const double (&)[NP], double (&y)[N]) { y[0] = 1.0; y[1] = 0.0; y[2] = 0.0; }
   __device__ static void root(double, const double (&)[N], const double (&)[NP], double (&)[1]) {}
+  // robertson.rs:73-77 (sens_mul), :91-93 (init_sens: zeros)
+  __device__ static void sens_mul(double, const double (&x)[N], const double (&)[NP], const double (&v)[NP], double (&y)[N]) {
+    y[0] = -v[0] * x[0] + v[1] * x[1] * x[2];
+    y[1] = v[0] * x[0] - v[1] * x[1] * x[2] - v[2] * x[1] * x[1];
+    y[2] = 0.0;
+  }
+  __device__ static void init_sens_mul(double, const double (&)[NP], const double (&)[NP], double (&y)[N]) { y[0] = 0.0; y[1] = 0.0; y[2] = 0.0; }
 };
 
 // examples/electrical-circuits/src/main.rs:10-41 — u=(iR,iL,iC,V), M=diag(0,1,0,1), p=[R,L,C,V0,omega,ithresh]

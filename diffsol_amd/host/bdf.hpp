@@ -130,8 +130,7 @@ class Bdf : public OdeSolverMethod {
     y_ = sc.y; dy_ = sc.dy; t_ = sc.t; h_ = sc.h;
     if (problem.sens) {
       // bdf_state_sens -> new_with_sensitivities_and_consistent (state.rs:1032-1083): s_j = SensInit(t0) (:1157-1175), ds_j = SensRhs(s_j) about (y0, t0)
-      // (set_consistent_augmented :167-186).  DAEs would need InitOp on the augmented equations (:188-240): not provided.
-      if (problem.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "forward sensitivities of DAEs (mass matrix) are not supported by the HIP backend");
+      // (set_consistent_augmented :167-186); with a singular mass matrix InitOp on the sensitivity equations (:187-238), below
       const int64_t n0 = problem.eqn->nstates(), npar = problem.eqn->nparams();
       const HipContext& c0 = problem.context();
       sens_mat_ = HipMat::zeros(n0, npar, c0);
@@ -146,6 +145,7 @@ class Bdf : public OdeSolverMethod {
         s_.push_back(std::move(sj));
         ds_.push_back(std::move(dsj));
       }
+      if (problem.eqn->has_mass()) sens_set_consistent();
     }
 
     // kappa table and derived constants (bdf.rs:253-276)
@@ -202,12 +202,51 @@ class Bdf : public OdeSolverMethod {
     pr_.eqn->rhs_sens_inplace(y, t, sens_mat_);
     sens_y_.copy_from(y);
   }
+  // the DAE half of set_consistent_augmented (state.rs:187-238): per parameter one Newton solve on InitOp over the sensitivity equations for (ds_j on the
+  // differential, s_j on the algebraic components), with the tolerances of the STATE equations and the consistent-initialisation options
+  void sens_set_consistent() {
+    const OdeEquations& eqn = *pr_.eqn;
+    const int64_t n0 = eqn.nstates();
+    HipMat mass = HipMat::zeros(n0, n0, pr_.context());
+    eqn.mass_matrix_inplace(pr_.t0, mass);
+    std::vector<double> diag = mass.diagonal().clone_as_vec();
+    std::vector<int> alg;
+    for (int64_t i = 0; i < n0; ++i) if (diag[(size_t)i] == 0.0) alg.push_back((int)i);
+    if (alg.empty()) return;
+    Convergence conv(pr_.rtol, &pr_.atol, pr_.ode_options.nonlinear_solver_tolerance);
+    conv.set_max_iter(pr_.ic_options.max_newton_iterations);
+    std::unique_ptr<LineSearch> ls;
+    if (pr_.ic_options.use_linesearch) {
+      auto b = std::make_unique<BacktrackingLineSearch>();
+      b->c = pr_.ic_options.armijo_constant; b->max_iter = pr_.ic_options.max_linesearch_iterations; b->tau = pr_.ic_options.step_reduction_factor;
+      ls = std::move(b);
+    } else ls = std::make_unique<NoLineSearch>();
+    for (size_t j = 0; j < s_.size(); ++j) {
+      InitOp f(eqn, t_, s_[j], alg, [this, j](const HipVec& x, double t, HipVec& y) { sens_rhs_call((int)j, x, t, y); },
+               [this, &eqn](double t, HipMat& out) { eqn.rhs_jacobian_inplace(sens_y_, t, out); });
+      NewtonNonlinearSolver root_solver;
+      root_solver.set_problem(f);
+      HipVec y_tmp = ds_[j].clone();
+      y_tmp.copy_from_indices(s_[j], f.algebraic_indices());
+      HipVec yerr = y_tmp.clone();
+      NlError result = NlError::Ok;
+      for (int k = 0; k < pr_.ic_options.max_linear_solver_setups; ++k) {
+        root_solver.reset_jacobian(f, y_tmp, t_);
+        result = root_solver.solve_in_place(f, y_tmp, t_, yerr, conv, *ls);
+        if (result == NlError::Ok) break;
+        if (result != NlError::NewtonMaxIterations) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
+        yerr.copy_from(y_tmp);
+      }
+      if (result != NlError::Ok) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
+      f.scatter_soln(y_tmp, s_[j], ds_[j]);
+    }
+  }
   // SensRhs::call_inplace: J(sens_y) x + (df/dp)[:, index]
   void sens_rhs_call(int index, const HipVec& x, double t, HipVec& y) const {
     pr_.eqn->rhs_jac_mul_inplace(sens_y_, t, x, y);
     y.add_assign(sens_mat_.column(index));  // Matrix::add_column_to_vector
   }
-  // the BdfCallable of the sensitivity equations (op/bdf.rs:240-256, identity mass) for parameter `index`: F(s) = (s - s0 + psi) - c SensRhs(s).
+  // the BdfCallable of the sensitivity equations (op/bdf.rs:240-256) for parameter `index`: F(s) = M (s - s0 + psi) - c SensRhs(s).
   // Its c is set by _update_step_size only (bdf.rs:551-553): new_augmented never calls set_c on it, so it is 0 until the first step-size change —
   // the reference's behaviour, kept because the reference's step counts only reproduce with it (tests/test_oracle_golden.py).
   struct SensOp : NonLinearOpRef {
@@ -219,7 +258,8 @@ class Bdf : public OdeSolverMethod {
       b.sens_rhs_call(index, x, t, y);
       b.s_tmp_.copy_from(x);
       b.s_tmp_.add_assign(b.s_psi_neg_y0_);
-      y.axpy(1.0, b.s_tmp_, -b.s_c_);
+      if (b.pr_.eqn->has_mass()) b.pr_.eqn->mass_gemv_inplace(b.s_tmp_, t, -b.s_c_, y);  // SensEquations::mass is the state equations' mass (sens_equations.rs:305-307)
+      else y.axpy(1.0, b.s_tmp_, -b.s_c_);
     }
     void jacobian_inplace(const HipVec&, double, HipMat&) override { throw LaError(DSH_E_UNSUPPORTED, "the sensitivity operator shares the state equations' factors"); }
   };

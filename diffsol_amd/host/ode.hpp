@@ -7,6 +7,7 @@
 //   ode_solver/state.rs:84-162,969-997,1086-1124,1209-1277                 nonlinear_solver/root.rs:12-222
 //   ode_solver/method.rs:42-198,227-258,467-520,721-1040
 #pragma once
+#include <functional>
 #include <array>
 #include <cmath>
 #include <optional>
@@ -285,11 +286,16 @@ struct StateCommon { HipVec y, dy; double t = 0.0, h = 0.0; };
 // op/init.rs:14-135
 class InitOp : public NonLinearOpRef {
  public:
-  InitOp(const OdeEquations& eqn, double t0, const HipVec& y0, const std::vector<int>& alg) : eqn_(eqn), y0_(y0.clone()), alg_host_(alg), alg_(alg, eqn.context()) {
+  // rhs_fn / jac_fn: the right-hand side and its Jacobian when the equations are built ON `eqn` rather than being it — InitOp::new(augmented_eqn, ..)
+  // in set_consistent_augmented (state.rs:209-214): SensRhs, whose Jacobian is the state equations' at the linearisation point (sens_equations.rs:185-187)
+  InitOp(const OdeEquations& eqn, double t0, const HipVec& y0, const std::vector<int>& alg, std::function<void(const HipVec&, double, HipVec&)> rhs_fn = nullptr,
+         std::function<void(double, HipMat&)> jac_fn = nullptr)
+      : eqn_(eqn), y0_(y0.clone()), alg_host_(alg), alg_(alg, eqn.context()), rhs_fn_(std::move(rhs_fn)) {
     const int64_t n = eqn.nstates();
     const HipContext& ctx = eqn.context();
     HipMat rhs_jac = HipMat::zeros(n, n, ctx), mass = HipMat::zeros(n, n, ctx);
-    eqn.rhs_jacobian_inplace(y0, t0, rhs_jac);
+    if (jac_fn) jac_fn(t0, rhs_jac);
+    else eqn.rhs_jacobian_inplace(y0, t0, rhs_jac);
     eqn.mass_matrix_inplace(t0, mass);
     // jac = (-M_u, df/dv; 0, dg/dv), neg_mass = (-M_u, 0; 0, 0) in the original ordering (Matrix::split / combine, matrix/mod.rs:261-303)
     jac_ = HipMat::zeros(n, n, ctx);
@@ -314,7 +320,8 @@ class InitOp : public NonLinearOpRef {
   const HipContext& context() const override { return eqn_.context(); }
   void call_inplace(const HipVec& x, double t, HipVec& y) override {  // :103-115
     y0_.copy_from_indices(x, alg_);
-    eqn_.rhs_call_inplace(y0_, t, y);
+    if (rhs_fn_) rhs_fn_(y0_, t, y);
+    else eqn_.rhs_call_inplace(y0_, t, y);
     neg_mass_.gemv(1.0, x, 1.0, y);
   }
   void jacobian_inplace(const HipVec&, double, HipMat& y) override { y.copy_from(jac_); }  // :125-127
@@ -332,6 +339,7 @@ class InitOp : public NonLinearOpRef {
   HipVec y0_;
   std::vector<int> alg_host_;
   HipIndex alg_;
+  std::function<void(const HipVec&, double, HipVec&)> rhs_fn_;
 };
 
 // state.rs:1086-1124

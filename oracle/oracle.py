@@ -115,12 +115,14 @@ class OracleSolver:
     """One (possibly batched, lock-step) solver instance of the CPU restatement."""
 
     def __init__(self, model, p, *, nbatch=1, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, sens=False, sens_rtol=None,
-                 sens_atol=None):
+                 sens_atol=None, options=None):
         """sens=True: problem.bdf_sens() — forward sensitivities integrated alongside; sens_rtol / sens_atol put them into the error control
         (None: turn_off_sensitivities_error_control)."""
         L = lib()
         p_arr, p_ptr = _d(np.asarray(p, dtype=np.float64).reshape(-1))
         a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
+        for k, v in (options or {}).items():  # problem.ode_options.<k> = v (max_nonlinear_solver_failures, max_error_test_failures)
+            L.orc_next_solver_option(k.encode(), C.c_double(float(v)))
         if sens:
             sa = np.zeros(0) if sens_atol is None else np.asarray(sens_atol, dtype=np.float64).reshape(-1)
             sa_arr, sa_ptr = _d(sa if sa.size else np.zeros(1))

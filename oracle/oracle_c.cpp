@@ -23,6 +23,8 @@ thread_local std::string g_last_error;
 // forward-sensitivity request for the next make_handle call (orc_solver_create_sens)
 struct SensRequest { bool on = false; bool error_control = false; double rtol = 0.0; std::vector<double> atol; };
 thread_local SensRequest g_sens_request;
+// ode_options overrides for the next make_handle call (the reference's tests set problem.ode_options.* before building the solver)
+thread_local std::vector<std::pair<std::string, double>> g_option_request;
 
 enum Method : int { METHOD_BDF = 0, METHOD_TR_BDF2 = 1, METHOD_ESDIRK34 = 2 };
 
@@ -40,6 +42,12 @@ std::unique_ptr<Handle> make_handle(int model_id, int model_size, int nbatch, co
   else throw std::runtime_error("oracle: atol must have length 1 or nstates");
   h->problem.t0 = t0;
   h->problem.h0 = h0;
+  for (const auto& kv : g_option_request) {
+    if (kv.first == "max_nonlinear_solver_failures") h->problem.ode_options.max_nonlinear_solver_failures = (int)kv.second;
+    else if (kv.first == "max_error_test_failures") h->problem.ode_options.max_error_test_failures = (int)kv.second;
+    else { g_option_request.clear(); throw std::runtime_error("oracle: unknown option " + kv.first); }
+  }
+  g_option_request.clear();
   if (g_sens_request.on) {
     const SensRequest rq = g_sens_request;
     g_sens_request = SensRequest();
@@ -93,6 +101,8 @@ void* orc_solver_create_sens(int model_id, int model_size, int nbatch, const dou
   g_sens_request = SensRequest();
   return r;
 }
+// problem.ode_options.<name> = value for the NEXT solver created on this thread
+void orc_next_solver_option(const char* name, double value) { g_option_request.emplace_back(name, value); }
 int orc_nparams(void* hv) { return ((Handle*)hv)->problem.eqn->model->np; }
 // OdeSolverMethod::interpolate_sens (bdf.rs:1162-1215): out [np][nb][n]; state.s (the sensitivities at the current time) with t = NaN
 int orc_interpolate_sens(void* hv, double t, double* out) {

@@ -65,7 +65,13 @@ struct ExponentialDecay : Model {
 // :94-105 (mass), :122-126 (init), :267-276 (batched init)
 struct ExponentialDecayAlgebraic : Model {
   bool batched_init;
-  explicit ExponentialDecayAlgebraic(bool batched_init_) : batched_init(batched_init_) { n = 3; np = 1; has_mass = true; }
+  explicit ExponentialDecayAlgebraic(bool batched_init_) : batched_init(batched_init_) { n = 3; np = 1; has_mass = true; has_sens = true; }
+  // :33-44 (sens: y = x * (-v[0]), last = 0), :128-135 (init_sens: zeros)
+  void sens_mul(const double* x, const double*, double, const double* v, double* y) const override {
+    for (int i = 0; i < n; ++i) y[i] = x[i] * (-v[0]);
+    y[n - 1] = 0.0;
+  }
+  void init_sens_mul(const double*, double, const double*, double* y) const override { for (int i = 0; i < n; ++i) y[i] = 0.0; }
   void rhs(const double* x, const double* p, double, double* y) const override {
     for (int i = 0; i < n; ++i) y[i] = x[i] * (-p[0]);
     y[n - 1] = x[n - 1] - x[n - 2];
@@ -119,7 +125,14 @@ struct RobertsonOde : Model {
 
 // crates/diffsol/src/ode_equations/test_models/robertson.rs:60-94
 struct RobertsonDae : Model {
-  RobertsonDae() { n = 3; np = 3; has_mass = true; }
+  RobertsonDae() { n = 3; np = 3; has_mass = true; has_sens = true; }
+  // robertson.rs:73-77 (sens_mul), :91-93 (init_sens: zeros)
+  void sens_mul(const double* x, const double*, double, const double* v, double* y) const override {
+    y[0] = -v[0] * x[0] + v[1] * x[1] * x[2];
+    y[1] = v[0] * x[0] - v[1] * x[1] * x[2] - v[2] * x[1] * x[1];
+    y[2] = 0.0;
+  }
+  void init_sens_mul(const double*, double, const double*, double* y) const override { for (int i = 0; i < n; ++i) y[i] = 0.0; }
   void rhs(const double* x, const double* p, double, double* y) const override {
     y[0] = -p[0] * x[0] + p[1] * x[1] * x[2];
     y[1] = p[0] * x[0] - p[1] * x[1] * x[2] - p[2] * x[1] * x[1];

@@ -194,10 +194,16 @@ struct InitOp {
   M jac, neg_mass;
   V y0;
   std::vector<int> algebraic_indices;
-  InitOp(const Eqn* e, double t0, const V& y0_, const std::vector<int>& alg) : eqn(e), y0(y0_), algebraic_indices(alg) {
+  // the right-hand side and its Jacobian when the equations are not `eqn` itself but equations built on it (InitOp::new(augmented_eqn, ..) in
+  // set_consistent_augmented, state.rs:209-214: SensRhs, whose Jacobian is the state equations' at the linearisation point, sens_equations.rs:185-187)
+  std::function<void(const V&, double, V&)> rhs_override;
+  InitOp(const Eqn* e, double t0, const V& y0_, const std::vector<int>& alg, std::function<void(const V&, double, V&)> rhs_fn = nullptr,
+         std::function<void(double, M&)> jac_fn = nullptr)
+      : eqn(e), y0(y0_), algebraic_indices(alg), rhs_override(std::move(rhs_fn)) {
     int n = e->n(), nb = e->nb;
     M rhs_jac(n, n, nb), mass(n, n, nb);
-    e->jacobian(y0_, t0, rhs_jac);
+    if (jac_fn) jac_fn(t0, rhs_jac);
+    else e->jacobian(y0_, t0, rhs_jac);
     e->mass_matrix(t0, mass);
     std::vector<char> is_alg(n, 0);
     for (int i : alg) is_alg[i] = 1;
@@ -231,7 +237,8 @@ struct InitOp {
   }
   void call_inplace(const V& x, double t, V& y) {  // :103-115
     copy_from_indices(y0, x, algebraic_indices);
-    eqn->rhs(y0, t, y);
+    if (rhs_override) rhs_override(y0, t, y);
+    else eqn->rhs(y0, t, y);
     gemv(neg_mass, 1.0, x, 1.0, y);
   }
   void jacobian_inplace(const V&, double, M& y) const { y = jac; }  // :125-127
@@ -493,8 +500,7 @@ struct Bdf : SolverBase {
     if (p->sens) {
       // bdf_state_sens -> new_with_sensitivities_and_consistent (state.rs:1032-1083): initialise_augmented_state (:1157-1205: s_j = SensInit(t0), ds_j = 0),
       // [set_consistent — done above, before set_step_size in both orders the result is the same: it only touches y, dy],
-      // set_consistent_augmented (:167-240: ds_j = SensRhs(s_j) about (y0, t0); DAEs would need InitOp on the augmented equations: not restated)
-      if (p->eqn->has_mass()) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
+      // set_consistent_augmented (:167-240: ds_j = SensRhs(s_j) about (y0, t0); with a singular mass matrix InitOp on the sensitivity equations, below)
       const int n0 = p->n(), nb0 = p->nb(), npar = p->eqn->model->np;
       sens_mat = M(n0, npar, nb0);
       sens_y = V(n0, nb0);
@@ -502,6 +508,44 @@ struct Bdf : SolverBase {
       for (int j = 0; j < npar; ++j) p->eqn->init_sens(t_, j, s_[(size_t)j]);
       sens_update_state(y_, t_);
       for (int j = 0; j < npar; ++j) sens_rhs_call(j, s_[(size_t)j], t_, ds_[(size_t)j]);
+      if (p->eqn->has_mass()) {
+        // the DAE half of set_consistent_augmented (state.rs:187-238): per parameter one Newton solve on InitOp over the sensitivity equations for
+        // (ds_j on the differential, s_j on the algebraic components); tolerances of the STATE equations, the consistent-initialisation options
+        const Eqn& eqn = *p->eqn;
+        M mass(n0, n0, nb0);
+        eqn.mass_matrix(p->t0, mass);
+        std::vector<int> alg;
+        for (int i = 0; i < n0; ++i) if (mass.at(0, i, i) == 0.0) alg.push_back(i);
+        if (!alg.empty()) {
+          Convergence conv(p->rtol, &p->atol, p->ode_options.nonlinear_solver_tolerance);
+          conv.max_iter = p->ic_options.max_newton_iterations;
+          std::unique_ptr<LineSearch> ls;
+          if (p->ic_options.use_linesearch) {
+            auto b = std::make_unique<BacktrackingLineSearch>();
+            b->c = p->ic_options.armijo_constant; b->max_iter = p->ic_options.max_linesearch_iterations; b->tau = p->ic_options.step_reduction_factor;
+            ls = std::move(b);
+          } else ls = std::make_unique<NoLineSearch>();
+          NewtonSolver root_solver;
+          for (int j = 0; j < npar; ++j) {
+            InitOp f(&eqn, t_, s_[(size_t)j], alg, [this, j](const V& x, double t, V& y) { sens_rhs_call(j, x, t, y); },
+                     [this, &eqn](double t, M& out) { eqn.jacobian(sens_y, t, out); });
+            root_solver.set_problem(n0, nb0);
+            V y_tmp = ds_[(size_t)j];
+            InitOp::copy_from_indices(y_tmp, s_[(size_t)j], alg);
+            V yerr = y_tmp;
+            NlErr result = NlErr::Ok;
+            for (int k = 0; k < p->ic_options.max_linear_solver_setups; ++k) {
+              root_solver.reset_jacobian(f, y_tmp, t_);
+              result = root_solver.solve_in_place(f, y_tmp, t_, yerr, conv, *ls);
+              if (result == NlErr::Ok) break;
+              if (result != NlErr::NewtonMaxIterations) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
+              copy_from(yerr, y_tmp);
+            }
+            if (result != NlErr::Ok) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
+            f.scatter_soln(y_tmp, s_[(size_t)j], ds_[(size_t)j]);
+          }
+        }
+      }
     }
     // _new :244-368
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
@@ -555,12 +599,13 @@ struct Bdf : SolverBase {
     pr->eqn->jac_mul(sens_y, t, x, y);
     add_assign(y, sens_mat.column(index));
   }
-  // BdfCallable::call_inplace of the sensitivity operator (op/bdf.rs:240-256, identity mass): F(s) = (s - s0 + psi) - c SensRhs(s)
+  // BdfCallable::call_inplace of the sensitivity operator (op/bdf.rs:240-256): F(s) = M (s - s0 + psi) - c SensRhs(s)
   void s_op_call(int index, const V& x, double t, V& y) {
     sens_rhs_call(index, x, t, y);
     copy_from(s_tmp, x);
     add_assign(s_tmp, s_psi_neg_y0);
-    axpy(y, 1.0, s_tmp, -s_c);
+    if (pr->eqn->has_mass()) pr->eqn->mass_gemv(s_tmp, t, -s_c, y);  // SensEquations::mass is the state equations' mass (sens_equations.rs:305-307)
+    else axpy(y, 1.0, s_tmp, -s_c);
   }
   // sensitivity_solve (bdf.rs:934-989): one Newton solve per parameter with the factors of the state equations
   bool sensitivity_solve(double t_new) {

@@ -32,7 +32,8 @@ def test_device_sensitivity_operators_match_the_oracle_models(H, O):
     import ctypes as C
     L = _ffi.load_device_lib()
     assert L.dsh_model_has_sens(H.MODELS["robertson_ode"], 1) == 1 and L.dsh_model_has_sens(H.MODELS["exponential_decay"], 0) == 1
-    assert L.dsh_model_has_sens(H.MODELS["robertson"], 0) == 0 and L.dsh_model_has_sens(H.MODELS["heat1d"], 16) == 0
+    assert L.dsh_model_has_sens(H.MODELS["robertson"], 0) == 1 and L.dsh_model_has_sens(H.MODELS["exponential_decay_with_algebraic"], 0) == 1
+    assert L.dsh_model_has_sens(H.MODELS["rlc"], 0) == 0 and L.dsh_model_has_sens(H.MODELS["heat1d"], 16) == 0
     nb = 37
     c = H.HipContext(nbatch=nb)
     rng = np.random.default_rng(2)
@@ -53,8 +54,8 @@ def test_device_sensitivity_operators_match_the_oracle_models(H, O):
         if name == "exponential_decay":
             ref0[:, :, 1] = 1.0
         assert np.array_equal(S.to_array(), ref0)
-    S = H.HipMat.zeros(3, 3, c)
-    assert L.dsh_model_rhs_sens(c._h, H.MODELS["robertson"], 0, nb, 0.0, X.ptr, P.ptr, S.ptr) < 0  # loud: the DAE model has no parameter derivatives
+    S = H.HipMat.zeros(4, 6, c)
+    assert L.dsh_model_rhs_sens(c._h, H.MODELS["rlc"], 0, nb, 0.0, X.ptr, P.ptr, S.ptr) < 0  # loud: this model has no parameter derivatives
 
 
 @pytest.mark.parametrize("error_control", [True, False])
@@ -112,9 +113,44 @@ def test_robertson_ensemble_sensitivities_equal_the_oracle_bitwise_and_finite_di
         assert np.abs(s_t[:, j] - fd).max() <= 5e-4 * np.abs(fd).max(), j
 
 
+def test_dae_sensitivities_reproduce_the_reference_snapshots_and_equal_the_oracle_bitwise(H, O):
+    """Singular mass matrix: set_consistent_augmented's InitOp over the sensitivity equations (state.rs:187-238) and the mass matrix in the sensitivity
+    residual, on the device.  The HIP path gives all 13 counters of test_bdf_nalgebra_exponential_decay_algebraic_sens (bdf.rs:2118-2141) and of
+    test_bdf_nalgebra_robertson_sens (bdf.rs:2248-2271: 319 steps, 28 failed nonlinear solves) and the oracle's states and sensitivities bit for bit;
+    then a Robertson DAE ensemble in lock-step against the oracle."""
+    kw = dict(rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6, 1e-6])
+    s = H.Solver("exponential_decay_with_algebraic", [[0.1]], nbatch=1, **kw)
+    o = O.OracleSolver(ORACLE_MODEL["exponential_decay_with_algebraic"], [0.1], **kw)
+    pts = [i / 10.0 for i in range(10)]
+    ys, ss = _points(s, pts)
+    yo, so = _points(o, pts)
+    st = s.stats()
+    assert [st[k] for k in st] == [24, 45, 8, 115, 0, 1, 0, 0, 8, 15, 66, 64, 3]
+    assert np.array_equal(ys, yo) and np.array_equal(ss, so) and st == o.stats()
+    t = np.array(pts)[:, None]
+    assert np.abs(ss[:, 0, 0, :] + t * np.exp(-0.1 * t)).max() < 2e-5
+    kw = dict(rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], sens=True)
+    pts = [0.4, 4.0, 40.0, 400.0, 4000.0, 4e4, 4e5, 4e6, 4e7, 4e8, 4e9, 4e10]
+    s = H.Solver("robertson", [[0.04, 1.0e4, 3.0e7]], nbatch=1, options=dict(max_nonlinear_solver_failures=70), **kw)
+    o = O.OracleSolver(ORACLE_MODEL["robertson"], [0.04, 1.0e4, 3.0e7], options=dict(max_nonlinear_solver_failures=70), **kw)
+    ys, ss = _points(s, pts)
+    yo, so = _points(o, pts)
+    st = s.stats()
+    assert [st[k] for k in st] == [92, 319, 4, 1941, 28, 1, 26, 2, 4, 59, 575, 1522, 31]
+    assert np.array_equal(ys, yo) and np.array_equal(ss, so) and st == o.stats()
+    nb = 5
+    p = robertson_params(nb, seed=3)
+    sb = H.Solver("robertson", p, nbatch=nb, sens_rtol=1e-4, sens_atol=[1e-8, 1e-6, 1e-6], **kw)
+    ob = O.OracleSolver(ORACLE_MODEL["robertson"], p, nbatch=nb, sens_rtol=1e-4, sens_atol=[1e-8, 1e-6, 1e-6], **kw)
+    yb, sv = _points(sb, pts[:4])
+    yob, sov = _points(ob, pts[:4])
+    assert np.array_equal(yb, yob) and np.array_equal(sv, sov) and sb.stats() == ob.stats()
+    assert np.abs(sv.sum(axis=-1)).max() < 1e-6 * np.abs(sv).max()  # x + y + z = 1: every sensitivity sums to zero
+
+
 def test_sensitivity_requests_that_the_backend_cannot_serve_fail_loudly(H):
     with pytest.raises(H.DiffsolHipError):
-        H.Solver("robertson", robertson_params(2), nbatch=2, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], sens=True)            # DAE model: no parameter derivatives
+        H.Solver("rlc", [[100.0, 1.0, 1e-3, 10.0, 100.0, 1e3]] * 2, nbatch=2, rtol=1e-4, atol=[1e-6], sens=True)        # a model without parameter derivatives
     with pytest.raises(H.DiffsolHipError):
         H.Solver("robertson_ode", robertson_params(2), nbatch=2, model_size=1, method=H.METHOD_TR_BDF2, sens=True)     # BDF only
     s = H.Solver("robertson_ode", robertson_params(2), nbatch=2, model_size=1)

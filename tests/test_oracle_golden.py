@@ -406,4 +406,32 @@ def test_oracle_bdf_sens_on_the_robertson_ode(O):
         fd = (yp - ym)[:, 0] / (2 * dp)
         assert np.abs(s_tight[:, j, 0] - fd).max() <= 2e-4 * np.abs(fd).max(), j
     with pytest.raises(O.OracleError):
-        O.OracleSolver(O.MODEL_ROBERTSON_DAE, p0, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], sens=True)   # DAE sensitivities are not restated
+        O.OracleSolver(O.MODEL_HEAT1D, [1.0], model_size=8, sens=True)   # a model without sens_mul
+
+
+def test_oracle_bdf_sens_reproduces_the_reference_snapshots_on_the_daes(O):
+    """Forward sensitivities of DAEs (singular mass matrix): set_consistent_augmented's InitOp over the sensitivity equations (state.rs:187-238), the mass
+    matrix in the sensitivity operator's residual.  ALL 13 counters of both insta snapshot pairs:
+    test_bdf_nalgebra_exponential_decay_algebraic_sens (bdf.rs:2118-2141; exponential_decay_with_algebraic_problem_sens, sens_rtol = sens_atol = 1e-6) and
+    test_bdf_nalgebra_robertson_sens (bdf.rs:2248-2271; robertson_sens with turn_off_sensitivities_error_control and max_nonlinear_solver_failures = 70:
+    319 steps, 28 failed nonlinear solves, 1941 iterations) — plus the harness' acceptance norms against the closed forms / the problem's table."""
+    o = O.OracleSolver(O.MODEL_EXPONENTIAL_DECAY_ALGEBRAIC, [0.1], rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6, 1e-6])
+    pts = [i / 10.0 for i in range(10)]
+    ys, ss = _run_points(o, pts)
+    st = o.stats()
+    assert [st[k] for k in st] == [24, 45, 8, 115, 0, 1, 0, 0, 8, 15, 66, 64, 3]
+    for i, t in enumerate(pts):
+        y_ref = np.full(3, np.exp(-0.1 * t))
+        assert weighted_error_norm(ys[i, 0], y_ref, [1e-6], 1e-6) < 20.0
+        assert weighted_error_norm(ss[i, 0, 0], -t * y_ref, [1e-6], 1e-6) < 29.0
+    table = [([1.0, 0.0, 0.0], 0.0), ([9.8517e-01, 3.3864e-05, 1.4794e-02], 0.4), ([9.0553e-01, 2.2406e-05, 9.4452e-02], 4.0), ([7.1579e-01, 9.1838e-06, 2.8420e-01], 40.0),
+             ([4.5044e-01, 3.2218e-06, 5.4956e-01], 400.0), ([1.8320e-01, 8.9444e-07, 8.1680e-01], 4000.0), ([3.8992e-02, 1.6221e-07, 9.6101e-01], 40000.0),
+             ([4.9369e-03, 1.9842e-08, 9.9506e-01], 400000.0), ([5.1674e-04, 2.0684e-09, 9.9948e-01], 4000000.0), ([5.2009e-05, 2.0805e-10, 9.9995e-01], 4.0e7),
+             ([5.2012e-06, 2.0805e-11, 9.9999e-01], 4.0e8), ([5.1850e-07, 2.0740e-12, 1.0], 4.0e9), ([4.8641e-08, 1.9456e-13, 1.0], 4.0e10)]
+    o = O.OracleSolver(O.MODEL_ROBERTSON_DAE, [0.04, 1.0e4, 3.0e7], rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], sens=True, options=dict(max_nonlinear_solver_failures=70))
+    ys, ss = _run_points(o, [t for _, t in table])
+    st = o.stats()
+    assert [st[k] for k in st] == [92, 319, 4, 1941, 28, 1, 26, 2, 4, 59, 575, 1522, 31]
+    for (y_ref, _), y in zip(table, ys):
+        assert weighted_error_norm(y[0], np.array(y_ref), [1e-8, 1e-6, 1e-6], 1e-4) < 15.0
+    assert np.isfinite(ss).all() and abs(ss[-1, 0, 0].sum()) < 1e-8  # the constraint x + y + z = 1 holds for every sensitivity too
