@@ -5,6 +5,7 @@
 // SURVEY §2a).  A broadcast operand (nbatch 1) is indexed by the state index idx / nbatch.
 // Arithmetic is written exactly as in the CPU reference path (no FMA contraction: built with -ffp-contract=off) so the
 // results are bit-identical to the oracle.
+#include <cstdlib>
 #include "dsh_internal.hpp"
 
 using namespace dsh;
@@ -169,6 +170,65 @@ __global__ __launch_bounds__(256) void k_squared_norm(int64_t n, int64_t nb, con
     }
     double nrm = acc / (double)n;
     if (per_batch) per_batch[b] = nrm;
+    bits = d2u(nrm);
+  }
+  block_publish(bits, 0ull, 0ull, rec, seq);
+}
+
+// The same norm for SMALL ensembles of LONG vectors (config 3: n = 512, 4096 members): one lane per member is 64 wavefronts walking 512 dependent
+// loads-divisions-additions each (60 us, 0.56 TB/s).  Here a wavefront owns 8 members; its lanes are 8 row groups x 8 members, so the loads and the
+// divisions of 32 components per member run in parallel on all 64 lanes, and only the additions — in index order, as Vector::squared_norm sums —
+// are a chain, on the 8 lanes of row group 0, fed through LDS.  Same terms, same order of additions: the same bits.
+template <bool BY, bool BA>
+__global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
+                                                          double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch) {
+  constexpr int S = 8, G = 8, QL = 4, CH = G * QL, LD = CH + 8;  // LD: row stride of the staging array (bank spread)
+  __shared__ double sT[S][LD];
+  const int lane = threadIdx.x, s = lane % S, g = lane / S;
+  const int64_t b0 = (int64_t)blockIdx.x * S + s;
+  const bool valid = b0 < nb;
+  const int64_t b = valid ? b0 : nb - 1;
+  double acc = 0.0;
+  double xa[QL], ya[QL], aa[QL];
+  auto fetch = [&](int64_t base, double (&xs)[QL], double (&ys)[QL], double (&as)[QL]) {
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const int64_t r = min(base + q * G + g, n - 1);  // clamped: components past the end are not added
+      xs[q] = x[r * nb + b];
+      ys[q] = BY ? y[r] : y[r * nb + b];
+      as[q] = BA ? atol[r] : atol[r * nb + b];
+    }
+  };
+  fetch(0, xa, ya, aa);
+  for (int64_t i0 = 0; i0 < n; i0 += CH) {
+    double xn[QL], yn[QL], an[QL];
+    const bool more = i0 + CH < n;
+    if (more) fetch(i0 + CH, xn, yn, an);
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const double term = xa[q] / (fabs(ya[q]) * rtol + aa[q]);
+      sT[s][q * G + g] = term * term;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (g == 0) {
+      const int cnt = (int)min((int64_t)CH, n - i0);
+      if (cnt == CH) {
+#pragma unroll
+        for (int t = 0; t < CH; ++t) acc += sT[s][t];
+      } else {
+        for (int t = 0; t < cnt; ++t) acc += sT[s][t];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) { xa[q] = xn[q]; ya[q] = yn[q]; aa[q] = an[q]; }
+    }
+  }
+  unsigned long long bits = 0ull;
+  if (g == 0 && valid) {
+    const double nrm = acc / (double)n;
+    if (per_batch) per_batch[b0] = nrm;
     bits = d2u(nrm);
   }
   block_publish(bits, 0ull, 0ull, rec, seq);
@@ -344,10 +404,19 @@ int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, c
   if (n == 0) { *out_max = 0.0; return DSH_OK; }  // vector/cuda.rs:1365-1367
   unsigned long long* rec; unsigned int seq;
   const int threads = ctx->block < 256 ? ctx->block : 256;  // the kernel is compiled for at most 256 threads (register budget of its pipelined loop)
-  dim3 g = grid_for(nb, threads), b(threads);
+  // long vectors, few members: 8 members per wavefront, terms on all lanes (k_squared_norm_wide: same bits).  DSH_NORM_WIDE=0 / 1 forces either.
+  static const int wide_env = [] { const char* e = std::getenv("DSH_NORM_WIDE"); return e && *e ? std::atoi(e) : -1; }();
+  const bool wide = wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384);
+  dim3 g = wide ? grid_for(nb, 8) : grid_for(nb, threads), b(threads);
   int rc = begin_records(ctx, g.x, &rec, &seq);
   if (rc != DSH_OK) return rc;
   bool by = ynb == 1 && nb != 1, ba = anb == 1 && nb != 1;
+  if (wide) {
+    if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<false, false>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+    else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<true, false>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+    else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_wide<false, true>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+    else hipLaunchKernelGGL((k_squared_norm_wide<true, true>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+  } else
   if (!by && !ba) hipLaunchKernelGGL((k_squared_norm<false, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
   else if (by && !ba) hipLaunchKernelGGL((k_squared_norm<true, false>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
   else if (!by && ba) hipLaunchKernelGGL((k_squared_norm<false, true>), g, b, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);

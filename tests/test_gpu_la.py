@@ -274,3 +274,36 @@ def test_matrix_ops_match_numpy(H, ctx1, nb):
         ref[:, :, j] = acc
     assert np.array_equal(Cm.to_array(), ref)
     assert np.allclose(ref, x @ ru[0], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,nb", [(128, 8), (130, 3), (512, 37), (1000, 9), (161, 64)])
+def test_norm_of_long_vectors_in_small_ensembles_keeps_the_sequential_summation_bits(H, ctx1, n, nb):
+    """n >= 128 and at most 16 384 members run k_squared_norm_wide (8 members per wavefront, the terms of 32 components computed on all 64 lanes, the additions in
+    index order on one row group): every member's value bit for bit the sequential sum, for member counts and lengths that are not multiples of the tile; all four
+    broadcast combinations of y and atol; per-member atol; NaN propagation."""
+    rng = np.random.default_rng(n + nb)
+    c = ctx1.clone_with_nbatch(nb)
+    x, y = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
+    atol1, atolb = np.abs(rng.standard_normal(n)) + 1e-3, np.abs(rng.standard_normal((nb, n))) + 1e-3
+    rtol = 1e-3
+
+    def ref(yy, aa):
+        out = np.empty(nb)
+        for b in range(nb):
+            yb = yy[b] if yy.shape[0] > 1 else yy[0]
+            ab = aa[b] if aa.ndim > 1 else aa
+            acc = 0.0
+            for i in range(n):
+                term = x[b, i] / (abs(yb[i]) * rtol + ab[i])
+                acc += term * term
+            out[b] = acc / n
+        return out
+
+    for yy, yc in ((y, c), (y[:1], ctx1)):
+        for aa, ac in ((atol1, ctx1), (atolb, c)):
+            got, per = V(H, x, c).squared_norm(V(H, yy, yc), V(H, aa, ac), rtol, per_batch=True)
+            want = ref(yy, aa)
+            assert np.array_equal(per, want) and got == want.max()
+    xn = x.copy()
+    xn[nb // 2, n - 1] = np.nan
+    assert np.isnan(V(H, xn, c).squared_norm(V(H, y, c), V(H, atol1, ctx1), rtol))
