@@ -93,6 +93,8 @@ DEVICE_ABI = {
     "dsh_model_rhs": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_jac_mul": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp, vp]),
     "dsh_model_jacobian": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_has_band_jacobian": (cint, [cint, i64]),
+    "dsh_model_jacobian_band": (cint, [vp, cint, i64, i64, dbl, vp, vp, cint, cint, vp]),
     "dsh_model_mass_gemv": (cint, [vp, cint, i64, i64, dbl, vp, vp, dbl, vp]),
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),

@@ -57,6 +57,20 @@ __global__ void k_dyn_jacobian(int model, int64_t n, int64_t nb, double t, const
     jac[idx] = dyn_component(model, n, t, i, X, V, P, true);
   }
 }
+// the same entries on the declared band only (row i, columns i-kl .. i+ku); everything else of the container is left as it is (zero, by the caller's promise)
+__global__ void k_dyn_jacobian_band(int model, int64_t n, int64_t nb, int kl, int ku, double t, const double* __restrict__ x, const double* __restrict__ p,
+                                    double* __restrict__ jac) {
+  const int64_t w = kl + ku + 1, total = n * w * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, b = idx % nb;
+    const int64_t i = e % n, j = i + e / n - kl;
+    if (j < 0 || j >= n) continue;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    jac[(j * n + i) * nb + b] = dyn_component(model, n, t, i, X, V, P, true);
+  }
+}
 __global__ void k_dyn_init(int model, int64_t n, int64_t nb, double* __restrict__ y) {
   int64_t total = n * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -185,6 +199,22 @@ int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double
   DSH_REQUIRE(is_dynamic_model(model, size), "unknown model id");
   int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
   hipLaunchKernelGGL(k_dyn_jacobian, ew_grid(n * n * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, t, x, p, jac);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+// The Jacobian of a run-time-sized registry model with a declared band (dsh_model_band), written on the band only: for a dense container whose entries
+// outside the band are already zero (a freshly zeroed matrix that only this function has written).  n (kl + ku + 1) entries instead of n^2 per member —
+// config 3: 50 MB instead of 8.6 GB per evaluation.  Same arithmetic per entry as dsh_model_jacobian.  Other models: DSH_E_UNSUPPORTED.
+int dsh_model_has_band_jacobian(int model, int64_t size) {
+  int jl = -1, ju = -1, ml = -1, mu = -1;
+  return !is_jit_model(model) && is_dynamic_model(model, size) && dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 ? 1 : 0;
+}
+int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, int kl, int ku, double* jac) {
+  DSH_REQUIRE(!is_jit_model(model) && is_dynamic_model(model, size), "dsh_model_jacobian_band: run-time-sized registry models only");
+  int jl = -1, ju = -1, ml = -1, mu = -1;
+  DSH_REQUIRE(dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 && kl >= jl && ku >= ju, "dsh_model_jacobian_band: the band must cover the declared one");
+  int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_dyn_jacobian_band, ew_grid(n * (kl + ku + 1) * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, kl, ku, t, x, p, jac);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }

@@ -93,6 +93,8 @@ class HipKernelEquations : public OdeEquations {
     p_ = np_ > 0 ? HipVec::from_vec(p, ctx) : HipVec::zeros(0, ctx);
     fused_ = dsh_model_has_fused(model, size) != 0;
     check(dsh_model_band(model, size, &jac_kl_, &jac_ku_, &mass_kl_, &mass_ku_), "HipKernelEquations (band)");
+    const char* e = std::getenv("DSH_JAC_BAND");  // =0: always evaluate the whole dense container
+    band_eval_ = dsh_model_has_band_jacobian(model, size) != 0 && !(e && e[0] == '0');
   }
   int64_t nstates() const override { return n_; }
   int64_t nparams() const override { return np_; }
@@ -112,7 +114,11 @@ class HipKernelEquations : public OdeEquations {
   void rhs_jacobian_inplace(const HipVec& x, double t, HipMat& y) const override {
     rhs_statistics.number_of_matrix_evals++;
     rhs_statistics.number_of_jac_muls += n_;
-    check(dsh_model_jacobian(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), y.ptr()), "jacobian");
+    // a container that is known to be zero outside the declared band (freshly zeroed, or last written by this very function) is evaluated on the band only
+    const bool on_band = band_eval_ && jac_kl_ >= 0 && jac_ku_ >= 0 && y.has_band() && y.band_kl() <= jac_kl_ && y.band_ku() <= jac_ku_ && n_ >= 16 &&
+                         (int64_t)(jac_kl_ + jac_ku_ + 1) * 2 <= n_;
+    if (on_band) check(dsh_model_jacobian_band(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), jac_kl_, jac_ku_, y.ptr()), "jacobian (band)");
+    else check(dsh_model_jacobian(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), y.ptr()), "jacobian");
     if (jac_kl_ >= 0 && jac_ku_ >= 0) y.set_band(jac_kl_, jac_ku_);  // the model declares the structure of f_y (dsh_model_band)
   }
   void mass_gemv_inplace(const HipVec& x, double t, double beta, HipVec& y) const override {
@@ -143,6 +149,7 @@ class HipKernelEquations : public OdeEquations {
   int64_t size_, n_ = 0, np_ = 0, nroots_ = 0;
   bool has_mass_ = false, fused_ = false;
   int jac_kl_ = -1, jac_ku_ = -1, mass_kl_ = -1, mass_ku_ = -1;
+  bool band_eval_ = false;
   HipContext ctx_;
   HipVec p_;
 };

@@ -240,6 +240,10 @@ int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, 
 int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* y);
 int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, const double* v, double* y);
 int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* jac);
+/* the same entries on the band (kl, ku) only, for a container whose entries outside the band are already zero; run-time-sized registry models with a
+   declared band (dsh_model_band) covered by (kl, ku).  What a banded matrix type would evaluate (book/src/benchmarks/sundials.md:27-28 notes its absence). */
+int dsh_model_has_band_jacobian(int model, int64_t size); /* 1 if dsh_model_jacobian_band serves this model */
+int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, int kl, int ku, double* jac);
 int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double beta, double* y);
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* mass);
 int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* y);

@@ -404,3 +404,31 @@ def test_opt_in_matrix_core_trailing_update_agrees_with_the_bit_exact_factorisat
     assert np.max(np.abs(f1 - f0)) <= 1e-11 * np.max(np.abs(f0))
     assert np.max(np.abs(x1 - x0)) <= 1e-9 * np.max(np.abs(x0))
     assert np.max(np.abs(np.einsum("bij,bj->bi", a, x1) - b)) <= 1e-10 * n
+
+
+@pytest.mark.parametrize("name,size,n,npar", [("heat1d", 64, 64, 1), ("spm", 20, 42, 1), ("robertson_ode", 8, 24, 3)])
+def test_band_only_jacobian_evaluation_writes_the_bits_of_the_dense_one(H, ctx1, name, size, n, npar):
+    """dsh_model_jacobian_band: the Jacobian of a run-time-sized registry model on its declared band only, into a zeroed container = dsh_model_jacobian's dense
+    result bit for bit (what the host-driven integrators now do for such models: config 3 writes 50 MB per evaluation instead of 8.6 GB); models without a
+    declared band or with a static form are refused."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb = 37
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(n)
+    x, p = rng.uniform(0.1, 0.9, (nb, n)), rng.uniform(0.5, 1.5, (nb, npar))
+    X, P = H.HipVec.from_vec(x, c), H.HipVec.from_vec(p, c)
+    import ctypes as C
+    kl, ku, ml, mu = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert L.dsh_model_band(H.MODELS[name], size, C.byref(kl), C.byref(ku), C.byref(ml), C.byref(mu)) == 0 and kl.value >= 0
+    assert L.dsh_model_has_band_jacobian(H.MODELS[name], size) == 1
+    Jd, Jb = H.HipMat.zeros(n, n, c), H.HipMat.zeros(n, n, c)
+    assert L.dsh_model_jacobian(c._h, H.MODELS[name], size, nb, 0.3, X.ptr, P.ptr, Jd.ptr) == 0
+    assert L.dsh_model_jacobian_band(c._h, H.MODELS[name], size, nb, 0.3, X.ptr, P.ptr, kl.value, ku.value, Jb.ptr) == 0
+    d, b = Jd.to_array(), Jb.to_array()
+    assert np.array_equal(d, b) and np.abs(d).max() > 0
+    i, j = np.indices((n, n))
+    assert not d[:, (j - i > ku.value) | (i - j > kl.value)].any()
+    assert L.dsh_model_has_band_jacobian(H.MODELS["robertson_ode"], 1) == 0 and L.dsh_model_has_band_jacobian(H.MODELS["rlc"], 0) == 0  # register-resident forms
+    assert L.dsh_model_jacobian_band(c._h, H.MODELS["robertson_ode"], 1, nb, 0.0, X.ptr, P.ptr, 2, 2, Jb.ptr) < 0
+    assert L.dsh_model_jacobian_band(c._h, H.MODELS[name], size, nb, 0.0, X.ptr, P.ptr, kl.value - 1, ku.value, Jb.ptr) < 0  # narrower than the declared band
