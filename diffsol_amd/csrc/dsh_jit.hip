@@ -187,7 +187,7 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
     // and integrates 262 144 members in 0.245 s instead of 0.308 s.  DSH_BANDED_NOUNROLL=0 unrolls them like the register-resident kernels.
     const char* nu = std::getenv("DSH_BANDED_NOUNROLL");
     if (!(nu && nu[0] == '0')) tu += "#define DSH_NOUNROLL_N 1\n";
-    tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";
+    tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : "3") + "\n";  // k_bdf_lane_banded, same workload: 0.192 / 0.137 / 0.141 / 0.158 / 0.160 s at 2 / 3 / 4 / 6 / 8
     if (const char* un = std::getenv("DSH_LANE_BANDED_UNROLL")) if (*un) tu += std::string("#define DSH_LANE_BANDED_UNROLL ") + un + "\n";  // tuning knob
     tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }

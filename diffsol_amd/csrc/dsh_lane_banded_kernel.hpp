@@ -26,7 +26,7 @@
 namespace dsh {
 
 #ifndef DSH_LANE_BANDED_WAVES_PER_EU
-#define DSH_LANE_BANDED_WAVES_PER_EU 4
+#define DSH_LANE_BANDED_WAVES_PER_EU 3
 #endif
 #ifndef DSH_LANE_BANDED_UNROLL
 #define DSH_LANE_BANDED_UNROLL 4
