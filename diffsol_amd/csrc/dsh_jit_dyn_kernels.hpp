@@ -59,6 +59,19 @@ extern "C" __global__ void k_jit_dyn_mass_matrix(int64_t nb, double t, const dou
     mass[idx] = jit_mass_component(t, (long)i, X, P);
   }
 }
+// df/dp (init = 0) or du0/dp (init = 1) as an n x np matrix, column j at (j * n + i) * nb + b: component i of sens_mul / init_sens_mul with the unit vector e_j
+// (NonLinearOpSens::_default_sens_inplace, op/nonlinear_op.rs:72-81), like k_static_model<.., Op::RhsSens> of the register-resident forms
+extern "C" __global__ void k_jit_dyn_sens(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, int init, double* __restrict__ s) {
+  const int64_t total = (int64_t)kJitN * kJitNP * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, b = idx % nb;
+    const int64_t i = e % kJitN, j = e / kJitN;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    s[idx] = jit_sens_component(t, (long)i, X, V, P, init != 0);
+  }
+}
 // which = 0: stop_i (roots), 1: out_i; g is count x nb, batch-fastest
 extern "C" __global__ void k_jit_dyn_root_out(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, int which, double* __restrict__ g) {
   const int64_t count = which == 0 ? kJitNRoots : kJitNOut, total = count * nb;

@@ -105,6 +105,8 @@ const char* static_op_name(Op op) {
     case Op::MassMatrix: return "dsh::k_static_model<dsh::JitModel, dsh::Op::MassMatrix>";
     case Op::Init: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Init>";
     case Op::Root: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Root>";
+    case Op::RhsSens: return "dsh::k_static_model<dsh::JitModel, dsh::Op::RhsSens>";
+    case Op::InitSens: return "dsh::k_static_model<dsh::JitModel, dsh::Op::InitSens>";
     default: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Out>";
   }
 }
@@ -127,6 +129,8 @@ int jit_model_op(dsh_ctx* ctx, int model, Op op, int64_t nb, double t, const dou
     case Op::MassMatrix: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_mass_matrix", ew_grid(n * n * nb), dim3(kBlock), 0, nb, t, p, y);
     case Op::Init: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_init", ew_grid(n * nb), dim3(kBlock), 0, nb, t, p, y);
     case Op::Root: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nroots * nb), dim3(kBlock), 0, nb, t, x, p, (int)0, y);
+    case Op::RhsSens: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_sens", ew_grid(n * ji->np * nb), dim3(kBlock), 0, nb, t, x, p, (int)0, y);
+    case Op::InitSens: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_sens", ew_grid(n * ji->np * nb), dim3(kBlock), 0, nb, t, x, p, (int)1, y);
     default: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nout * nb), dim3(kBlock), 0, nb, t, x, p, (int)1, y);
   }
 }
@@ -220,18 +224,20 @@ int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, d
 }
 // forward sensitivities: df/dp and dy0/dp as n x np batched matrices, one launch each
 int dsh_model_has_sens(int model, int64_t size) {
-  if (is_jit_model(model)) return 0;  // the DiffSL front end does not emit parameter derivatives yet
+  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && ji->has_sens && ji->form != DSH_JIT_FORM_STATIC_BANDED ? 1 : 0; }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) { ok = model_has_sens<decltype(mdl)>::value; });
   return ok ? 1 : 0;
 }
 int dsh_model_rhs_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* sens) {
   if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_rhs_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::RhsSens, nb, t, x, p, nullptr, 0.0, sens);
   bool handled = false;
   return launch_static<Op::RhsSens>(ctx, model, size, nb, t, x, p, nullptr, 0.0, sens, &handled);
 }
 int dsh_model_init_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* sens0) {
   if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_init_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
+  if (is_jit_model(model)) return jit_model_op(ctx, model, Op::InitSens, nb, t, p, p, nullptr, 0.0, sens0);  // x is not read by du0/dp
   bool handled = false;
   return launch_static<Op::InitSens>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, sens0, &handled);
 }

@@ -354,6 +354,25 @@ def model_jac_mul(model, x, p, v, t=0.0, model_size=0):
     return y
 
 
+def model_sens_mul(model, x, p, v, t=0.0, model_size=0):
+    """(dF/dp) v, v in parameter space; None for a model without parameter sensitivities."""
+    x_a, x_p = _d(np.asarray(x, dtype=np.float64))
+    p_a, p_p = _d(np.asarray(p, dtype=np.float64))
+    v_a, v_p = _d(np.asarray(v, dtype=np.float64))
+    y = np.empty(x_a.size)
+    r = lib().orc_model_sens_mul(C.c_int(model), C.c_int(model_size), x_p, p_p, C.c_double(t), v_p, y.ctypes.data_as(_dp))
+    return y if r == 0 else None
+
+
+def model_init_sens_mul(model, p, v, n, t=0.0, model_size=0):
+    """(du0/dp) v, v in parameter space (n = number of states); None for a model without parameter sensitivities."""
+    p_a, p_p = _d(np.asarray(p, dtype=np.float64))
+    v_a, v_p = _d(np.asarray(v, dtype=np.float64))
+    y = np.empty(int(n))
+    r = lib().orc_model_init_sens_mul(C.c_int(model), C.c_int(model_size), p_p, C.c_double(t), v_p, y.ctypes.data_as(_dp))
+    return y if r == 0 else None
+
+
 def model_root(model, x, p, t=0.0, model_size=0, max_roots=4):
     xa, xp = _d(x)
     pa, pp = _d(p)

@@ -419,6 +419,19 @@ void orc_model_jac_mul(int model_id, int model_size, const double* x, const doub
   auto m = make_model(model_id, model_size);
   m->jac_mul(x, p, t, v, y);
 }
+// (dF/dp) v and (du0/dp) v of a model with parameter sensitivities; returns -1 for a model without
+int orc_model_sens_mul(int model_id, int model_size, const double* x, const double* p, double t, const double* v, double* y) {
+  auto m = make_model(model_id, model_size);
+  if (!m->has_sens) return -1;
+  m->sens_mul(x, p, t, v, y);
+  return 0;
+}
+int orc_model_init_sens_mul(int model_id, int model_size, const double* p, double t, const double* v, double* y) {
+  auto m = make_model(model_id, model_size);
+  if (!m->has_sens) return -1;
+  m->init_sens_mul(p, t, v, y);
+  return 0;
+}
 // load a model library generated from DiffSL (diffsol_amd/host/diffsl.hpp, Target::HostC) and register it; returns its model id (>= 1000) or -1
 int orc_load_external_model(const char* path) {
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -431,6 +444,8 @@ int orc_load_external_model(const char* path) {
   f.init = (decltype(f.init))dlsym(h, "dsl_init");
   f.root = (decltype(f.root))dlsym(h, "dsl_root");
   f.out = (decltype(f.out))dlsym(h, "dsl_out");
+  f.sens_mul = (decltype(f.sens_mul))dlsym(h, "dsl_sens_mul");
+  f.init_sens_mul = (decltype(f.init_sens_mul))dlsym(h, "dsl_init_sens_mul");
   if (!f.dims || !f.rhs || !f.jac_mul || !f.mass_gemv || !f.init || !f.root || !f.out) { std::fprintf(stderr, "oracle: %s lacks a dsl_* symbol\n", path); return -1; }
   external_models().push_back(f);
   return MODEL_EXTERNAL_BASE + (int)external_models().size() - 1;

@@ -304,6 +304,9 @@ struct ExternalFns {
   void (*init)(double, const double*, double*) = nullptr;
   void (*root)(double, const double*, const double*, double*) = nullptr;
   void (*out)(double, const double*, const double*, double*) = nullptr;
+  // optional (models with inputs): (dF/dp) v and (du0/dp) v — rhs_sgrad / set_u0_sgrad of the reference's compiled DiffSL module
+  void (*sens_mul)(double, const double*, const double*, const double*, double*) = nullptr;
+  void (*init_sens_mul)(double, const double*, const double*, double*) = nullptr;
 };
 constexpr int MODEL_EXTERNAL_BASE = 1000;
 inline std::vector<ExternalFns>& external_models() {
@@ -317,7 +320,10 @@ struct ExternalModel : Model {
     int hm = 0;
     f.dims(&n, &np, &nroots, &nout, &hm);
     has_mass = hm != 0;
+    has_sens = f.sens_mul != nullptr && f.init_sens_mul != nullptr;
   }
+  void sens_mul(const double* x, const double* p, double t, const double* v, double* y) const override { f.sens_mul(t, x, p, v, y); }
+  void init_sens_mul(const double* p, double t, const double* v, double* y) const override { f.init_sens_mul(t, p, v, y); }
   void rhs(const double* x, const double* p, double t, double* y) const override { f.rhs(t, x, p, y); }
   void jac_mul(const double* x, const double* p, double t, const double* v, double* y) const override { f.jac_mul(t, x, p, v, y); }
   void mass(const double* x, const double* p, double t, double beta, double* y) const override { f.mass_gemv(t, x, p, beta, y); }

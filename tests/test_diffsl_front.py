@@ -267,3 +267,38 @@ def test_random_models_evaluate_like_numpy_and_differentiate_like_finite_differe
         jv = O.model_jac_mul(mid, xv, pv, v, t)
         smooth = np.abs(fd - jv) <= 1e-5 * (1.0 + np.abs(fd))  # min / max / abs kinks may sit within eps of the evaluation point: allow one component to miss
         assert smooth.sum() >= 2, (k, code, jv, fd)
+
+
+def test_parameter_sensitivities_of_diffsl_models_reference_snapshot_and_finite_differences(O, fe):
+    """Models with inputs also get (dF/dp) v and (du0/dp) v (the compiled module's rhs_sgrad / set_u0_sgrad in the reference, ode_equations/diffsl.rs) by
+    forward-mode differentiation along a direction in parameter space.  (1) The reference's own DiffSL sensitivity problem, text verbatim from
+    exponential_decay_problem_diffsl (exponential_decay.rs:225-236), integrated by the oracle with the generated host model: ALL 13 counters of
+    bdf_test_nalgebra_exponential_decay_diffsl_sens (bdf.rs:1845-1862).  (2) 20 random models and the function zoo: sens_mul against central differences
+    in the parameters; initial values that depend on the inputs; (3) a model without inputs has no sensitivities."""
+    code = "in_i { k = 0.1, y0 = 1.0 }\nu_i { x = y0, y = y0 }\nF_i { -k * u_i }\nout_i { u_i }\n"
+    mid = D.host_model(O, code)
+    o = O.OracleSolver(mid, [0.1, 1.0], rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6])
+    for t in [float(i) for i in range(10)]:
+        while abs(o.state()["t"]) < abs(t):
+            o.step()
+    st = o.stats()
+    assert [st[k] for k in st] == [14, 56, 1, 175, 0, 1, 0, 0, 1, 12, 60, 123, 2]
+    s9 = o.interpolate_sens(9.0)
+    assert np.allclose(s9[0, 0], -9.0 * np.exp(-0.9), rtol=1e-5) and np.allclose(s9[1, 0], np.exp(-0.9), rtol=1e-5)
+    assert np.array_equal(O.model_init_sens_mul(mid, [0.1, 1.0], [0.3, 2.0], 2), [2.0, 2.0])
+    rng = np.random.default_rng(77)
+    names = ["x", "y", "z", "a", "b", "t"]
+    mids = [D.host_model(O, D.ZOO)]
+    for k in range(20):
+        exprs = [D.random_expr(rng, 4, names) for _ in range(3)]
+        mids.append(D.host_model(O, "in = [a, b]\na { 1 } b { 1 }\nu_i { x = 0.4 * a, y = 0.9 + b * b, z = 1.7 }\nF_i {\n" + ",\n".join(e[0] for e in exprs) + "\n}\n", opt="-O1"))
+    for k, m in enumerate(mids):
+        xv, pv, t = rng.uniform(0.3, 2.0, 3), rng.uniform(0.5, 1.5, 2), float(rng.uniform(0.0, 1.0))
+        v = rng.standard_normal(2)
+        eps = 1e-6
+        fd = (O.model_rhs(m, xv, pv + eps * v, t) - O.model_rhs(m, xv, pv - eps * v, t)) / (2 * eps)
+        sv = O.model_sens_mul(m, xv, pv, v, t)
+        assert (np.abs(fd - sv) <= 1e-5 * (1.0 + np.abs(fd))).sum() >= 2, (k, sv, fd)  # kinks of min / max / abs may sit within eps: one component may miss
+        if k > 0:
+            assert np.allclose(O.model_init_sens_mul(m, pv, v, 3), [0.4 * v[0], 2 * pv[1] * v[1], 0.0], rtol=1e-14, atol=0)
+    assert O.model_sens_mul(D.host_model(O, "u_i { x = 1 }\nF_i { -x }\n"), [1.0], [0.0], [1.0]) is None

@@ -156,3 +156,51 @@ def test_sensitivity_requests_that_the_backend_cannot_serve_fail_loudly(H):
     s = H.Solver("robertson_ode", robertson_params(2), nbatch=2, model_size=1)
     with pytest.raises(H.DiffsolHipError):
         s.interpolate_sens(0.0)                                                                                         # not created with sensitivities
+
+
+def test_diffsl_models_integrate_their_parameter_sensitivities_on_the_device(H, O):
+    """DiffSL models with inputs carry sens_mul / init_sens_mul (forward-mode differentiation in parameter space by the front end, host/diffsl.hpp) in both
+    device forms.  Register-resident form: the reference's own DiffSL sensitivity problem (text of exponential_decay_problem_diffsl) on the HIP path gives all
+    13 counters of bdf_test_nalgebra_exponential_decay_diffsl_sens (bdf.rs:1845-1862) and the bits of the oracle integrating the generated host twin.
+    Run-time-sized form (n = 12, one thread per component): a decay chain with parameter-dependent initial values, a batched lock-step ensemble, bit for bit
+    against the oracle; sensitivities against central differences of plain solves."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl as fe
+    code = "in_i { k = 0.1, y0 = 1.0 }\nu_i { x = y0, y = y0 }\nF_i { -k * u_i }\nout_i { u_i }\n"
+    m, mid = fe.DiffslModel(code), D.host_model(O, code)
+    assert m.form == fe.FORM_STATIC
+    kw = dict(rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6])
+    s = H.Solver(m, [[0.1, 1.0]], nbatch=1, **kw)
+    o = O.OracleSolver(mid, [0.1, 1.0], **kw)
+    pts = [float(i) for i in range(10)]
+    ys, ss = _points(s, pts)
+    yo, so = _points(o, pts)
+    st = s.stats()
+    assert [st[k] for k in st] == [14, 56, 1, 175, 0, 1, 0, 0, 1, 12, 60, 123, 2]
+    assert np.array_equal(ys, yo) and np.array_equal(ss, so) and st == o.stats()
+    chain = ("in = [k, c]\nk { 0.5 } c { 1.0 }\nu_i { (0): a = c * c, (1:12): b = 0.1 * c }\n"
+             "A_ij { (0..12, 0..12): -1.0, (1..12, 0..11): 1.0 }\nF_i { k * A_ij * u_j }\n")
+    m, mid = fe.DiffslModel(chain), D.host_model(O, chain)
+    assert m.form == fe.FORM_DYNAMIC
+    nb = 4
+    p = np.stack([0.3 + 0.2 * np.arange(nb), 1.0 + 0.5 * np.arange(nb)], axis=1)
+    kw = dict(rtol=1e-7, atol=[1e-9], sens=True, sens_rtol=1e-7, sens_atol=[1e-9])
+    sb = H.Solver(m, p, nbatch=nb, **kw)
+    ob = O.OracleSolver(mid, p, nbatch=nb, **kw)
+    pts = [0.5, 2.0, 6.0]
+    yb, sv = _points(sb, pts)
+    yob, sov = _points(ob, pts)
+    assert np.array_equal(yb, yob) and np.array_equal(sv, sov) and sb.stats() == ob.stats()
+    tight = dict(rtol=1e-11, atol=[1e-13])
+    for j in range(2):
+        dp = 1e-6 * p[:, j]
+        pp, pm = p.copy(), p.copy()
+        pp[:, j] += dp
+        pm[:, j] -= dp
+        yp, _ = H.Solver(m, pp, nbatch=nb, **tight).solve_to_points(pts)
+        ym, _ = H.Solver(m, pm, nbatch=nb, **tight).solve_to_points(pts)
+        fd = (yp - ym) / (2 * dp)[None, :, None]
+        assert np.abs(sv[:, j] - fd).max() <= 2e-5 * np.abs(fd).max(), j
+    noin = fe.DiffslModel("u_i { x = 1 }\nF_i { -x }\n")
+    with pytest.raises(H.DiffsolHipError):
+        H.Solver(noin, [[0.0]], nbatch=1, sens=True)  # no inputs: nothing to differentiate with respect to
