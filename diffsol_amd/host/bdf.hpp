@@ -202,44 +202,8 @@ class Bdf : public OdeSolverMethod {
     pr_.eqn->rhs_sens_inplace(y, t, sens_mat_);
     sens_y_.copy_from(y);
   }
-  // the DAE half of set_consistent_augmented (state.rs:187-238): per parameter one Newton solve on InitOp over the sensitivity equations for (ds_j on the
-  // differential, s_j on the algebraic components), with the tolerances of the STATE equations and the consistent-initialisation options
   void sens_set_consistent() {
-    const OdeEquations& eqn = *pr_.eqn;
-    const int64_t n0 = eqn.nstates();
-    HipMat mass = HipMat::zeros(n0, n0, pr_.context());
-    eqn.mass_matrix_inplace(pr_.t0, mass);
-    std::vector<double> diag = mass.diagonal().clone_as_vec();
-    std::vector<int> alg;
-    for (int64_t i = 0; i < n0; ++i) if (diag[(size_t)i] == 0.0) alg.push_back((int)i);
-    if (alg.empty()) return;
-    Convergence conv(pr_.rtol, &pr_.atol, pr_.ode_options.nonlinear_solver_tolerance);
-    conv.set_max_iter(pr_.ic_options.max_newton_iterations);
-    std::unique_ptr<LineSearch> ls;
-    if (pr_.ic_options.use_linesearch) {
-      auto b = std::make_unique<BacktrackingLineSearch>();
-      b->c = pr_.ic_options.armijo_constant; b->max_iter = pr_.ic_options.max_linesearch_iterations; b->tau = pr_.ic_options.step_reduction_factor;
-      ls = std::move(b);
-    } else ls = std::make_unique<NoLineSearch>();
-    for (size_t j = 0; j < s_.size(); ++j) {
-      InitOp f(eqn, t_, s_[j], alg, [this, j](const HipVec& x, double t, HipVec& y) { sens_rhs_call((int)j, x, t, y); },
-               [this, &eqn](double t, HipMat& out) { eqn.rhs_jacobian_inplace(sens_y_, t, out); });
-      NewtonNonlinearSolver root_solver;
-      root_solver.set_problem(f);
-      HipVec y_tmp = ds_[j].clone();
-      y_tmp.copy_from_indices(s_[j], f.algebraic_indices());
-      HipVec yerr = y_tmp.clone();
-      NlError result = NlError::Ok;
-      for (int k = 0; k < pr_.ic_options.max_linear_solver_setups; ++k) {
-        root_solver.reset_jacobian(f, y_tmp, t_);
-        result = root_solver.solve_in_place(f, y_tmp, t_, yerr, conv, *ls);
-        if (result == NlError::Ok) break;
-        if (result != NlError::NewtonMaxIterations) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
-        yerr.copy_from(y_tmp);
-      }
-      if (result != NlError::Ok) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
-      f.scatter_soln(y_tmp, s_[j], ds_[j]);
-    }
+    sens_set_consistent_augmented(pr_, t_, sens_y_, s_, ds_, [this](int j, const HipVec& x, double t, HipVec& y) { sens_rhs_call(j, x, t, y); });
   }
   // SensRhs::call_inplace: J(sens_y) x + (df/dp)[:, index]
   void sens_rhs_call(int index, const HipVec& x, double t, HipVec& y) const {

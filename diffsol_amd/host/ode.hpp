@@ -399,6 +399,49 @@ inline void set_consistent(StateCommon& s, const OdeSolverProblem& pr) {
   s.dy.assign_at_indices(f.algebraic_indices(), 0.0);
 }
 
+// The DAE half of set_consistent_augmented (state.rs:187-238), shared by Bdf and Sdirk: per parameter one Newton solve on InitOp over the sensitivity
+// equations for (ds_j on the differential, s_j on the algebraic components), with the tolerances of the STATE equations and the consistent-initialisation
+// options.  sens_rhs(j, x, t, y) = SensRhs::call_inplace for parameter j about the linearisation point sens_y.
+template <class SensRhsFn>
+inline void sens_set_consistent_augmented(const OdeSolverProblem& pr, double t0, const HipVec& sens_y, std::vector<HipVec>& s, std::vector<HipVec>& ds, SensRhsFn sens_rhs) {
+  const OdeEquations& eqn = *pr.eqn;
+  if (!eqn.has_mass()) return;
+  const int64_t n0 = eqn.nstates();
+  HipMat mass = HipMat::zeros(n0, n0, pr.context());
+  eqn.mass_matrix_inplace(pr.t0, mass);
+  std::vector<double> diag = mass.diagonal().clone_as_vec();
+  std::vector<int> alg;
+  for (int64_t i = 0; i < n0; ++i) if (diag[(size_t)i] == 0.0) alg.push_back((int)i);
+  if (alg.empty()) return;
+  Convergence conv(pr.rtol, &pr.atol, pr.ode_options.nonlinear_solver_tolerance);
+  conv.set_max_iter(pr.ic_options.max_newton_iterations);
+  std::unique_ptr<LineSearch> ls;
+  if (pr.ic_options.use_linesearch) {
+    auto b = std::make_unique<BacktrackingLineSearch>();
+    b->c = pr.ic_options.armijo_constant; b->max_iter = pr.ic_options.max_linesearch_iterations; b->tau = pr.ic_options.step_reduction_factor;
+    ls = std::move(b);
+  } else ls = std::make_unique<NoLineSearch>();
+  for (size_t j = 0; j < s.size(); ++j) {
+    InitOp f(eqn, t0, s[j], alg, [&sens_rhs, j](const HipVec& x, double t, HipVec& y) { sens_rhs((int)j, x, t, y); },
+             [&eqn, &sens_y](double t, HipMat& out) { eqn.rhs_jacobian_inplace(sens_y, t, out); });
+    NewtonNonlinearSolver root_solver;
+    root_solver.set_problem(f);
+    HipVec y_tmp = ds[j].clone();
+    y_tmp.copy_from_indices(s[j], f.algebraic_indices());
+    HipVec yerr = y_tmp.clone();
+    NlError result = NlError::Ok;
+    for (int k = 0; k < pr.ic_options.max_linear_solver_setups; ++k) {
+      root_solver.reset_jacobian(f, y_tmp, t0);
+      result = root_solver.solve_in_place(f, y_tmp, t0, yerr, conv, *ls);
+      if (result == NlError::Ok) break;
+      if (result != NlError::NewtonMaxIterations) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
+      yerr.copy_from(y_tmp);
+    }
+    if (result != NlError::Ok) throw DSH_ODE_ERR(InitialConditionDidNotConverge);
+    f.scatter_soln(y_tmp, s[j], ds[j]);
+  }
+}
+
 // state.rs:1209-1277
 inline void set_step_size(StateCommon& s, double h0_in, const HipVec& atol, double rtol, const OdeEquations& eqn, int solver_order) {
   const bool is_neg_h = h0_in < 0.0;

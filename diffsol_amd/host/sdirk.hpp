@@ -5,6 +5,8 @@
 //   tableau.rs:41-160   op/sdirk.rs:18-300   runge_kutta.rs:110-190, :466-495, :505-516, :610-689, :752-800, :841-960, :962-1127
 //   sdirk.rs:172-215 _new, :260-303 jacobian_updates, :409-543 step
 #pragma once
+#include <functional>
+#include <memory>
 #include "ode.hpp"
 
 namespace diffsol_hip {
@@ -70,9 +72,12 @@ class SdirkCallable : public NonLinearOpRef {
   void set_jacobian_is_stale() { jacobian_is_stale_ = true; }
   bool jacobian_is_stale() const { return jacobian_is_stale_; }
   void clear_jacobian_is_stale() { jacobian_is_stale_ = false; }
+  // SdirkCallable over the sensitivity equations (s_op): the right-hand side is SensRhs for the current parameter
+  std::function<void(const HipVec&, double, HipVec&)> rhs_override;
   void call_inplace(const HipVec& x, double t, HipVec& y) override {  // :229-244
     set_tmp(x);
-    eqn_.rhs_call_inplace(tmp_, t, y);
+    if (rhs_override) rhs_override(tmp_, t, y);
+    else eqn_.rhs_call_inplace(tmp_, t, y);
     const double beta = -h_;
     if (eqn_.has_mass()) eqn_.mass_gemv_inplace(x, t, beta, y);
     else y.axpy(1.0, x, beta);
@@ -116,7 +121,8 @@ class Sdirk : public OdeSolverMethod {
     minimum_timestep_growth_ = o.min_timestep_growth.value_or(2.0);
     maximum_timestep_shrink_ = o.max_timestep_shrink.value_or(0.9);
     minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
-    fused_ = problem.use_fused_kernels && problem.eqn->fused_model(&model_, &model_size_);
+    // forward sensitivities run on the trait operations (the fused stage kernels integrate the state equations only)
+    fused_ = problem.use_fused_kernels && !problem.sens && problem.eqn->fused_model(&model_, &model_size_);
     state_ = new_and_consistent(problem, tab_.order());
     const int64_t n = problem.eqn->nstates();
     const HipContext& ctx = problem.context();
@@ -129,6 +135,31 @@ class Sdirk : public OdeSolverMethod {
     d_vec_ = HipVec::from_vec(tab_.d, ctx1);
     if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, state_.y, state_.t); }
     diff_ = HipMat::zeros(n, tab_.s, ctx);
+    if (problem.sens) {
+      // RkState::new_with_sensitivities_and_consistent (state.rs:1032-1083): s_j = SensInit(t0), ds_j = SensRhs(s_j) about (y0, t0), DAEs through InitOp
+      const int64_t npar = problem.eqn->nparams();
+      sens_mat_ = HipMat::zeros(n, npar, ctx);
+      sens_y_ = HipVec::zeros(n, ctx);
+      HipMat s0 = HipMat::zeros(n, npar, ctx);
+      problem.eqn->init_sens_inplace(state_.t, s0);
+      sens_update_state(state_.y, state_.t);
+      for (int64_t j = 0; j < npar; ++j) {
+        HipVec sj = HipVec::zeros(n, ctx), dsj = HipVec::zeros(n, ctx);
+        sj.copy_from_view(s0.column(j));
+        sens_rhs_call((int)j, sj, state_.t, dsj);
+        s_.push_back(std::move(sj));
+        ds_.push_back(std::move(dsj));
+      }
+      sens_set_consistent_augmented(problem, state_.t, sens_y_, s_, ds_, [this](int j, const HipVec& x, double t, HipVec& y) { sens_rhs_call(j, x, t, y); });
+      for (int64_t j = 0; j < npar; ++j) {
+        old_s_.push_back(s_[(size_t)j].clone());
+        old_ds_.push_back(ds_[(size_t)j].clone());
+        sdiff_.push_back(HipMat::zeros(n, tab_.s, ctx));
+      }
+      sens_error_ = HipVec::zeros(n, ctx);
+      s_op_ = std::make_unique<SdirkCallable>(*problem.eqn, tab_.A(1, 1));
+      s_op_->rhs_override = [this](const HipVec& x, double t, HipVec& y) { sens_rhs_call(sens_index_, x, t, y); };
+    }
     old_state_.y = state_.y.clone(); old_state_.dy = state_.dy.clone(); old_state_.t = state_.t; old_state_.h = state_.h;
     error_ = HipVec::zeros(n, ctx);
     error_tmp_ = HipVec::zeros(n, ctx);
@@ -136,9 +167,48 @@ class Sdirk : public OdeSolverMethod {
     jacobian_update_.update_jacobian(state_.h);
     jacobian_update_.update_rhs_jacobian(state_.h);
     convergence_.set_max_iter(o.max_nonlinear_solver_iterations);
-    op_.set_h(state_.h);
+    set_op_h(state_.h);
     nonlinear_solver_.set_problem(op_);
+    // Sdirk::new_augmented ends with jacobian_updates(h, Checkpoint) (sdirk.rs:251): with sensitivities the first linearisation is made here, at t0 and —
+    // op.phi still being zero — about gamma * y0, not lazily inside the first stage (the reference's behaviour; its step counts only reproduce with it)
+    if (s_op_) jacobian_updates(state_.h, SolverState::Checkpoint);
   }
+  // OdeSolverMethod::interpolate_sens (runge_kutta.rs:1237-1330): the state's interpolant applied to (old_state.s, state.s, sdiff)
+  void interpolate_sens_inplace(double t, std::vector<HipVec>& out) const {
+    if (!pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "the solver was created without forward sensitivities");
+    const bool is_forward = state_.h > 0.0;
+    if ((is_forward && (t > state_.t || t < old_state_.t)) || (!is_forward && (t < state_.t || t > old_state_.t))) throw DSH_ODE_ERR(InterpolationTimeOutsideCurrentStep);
+    const double dt = state_.t - old_state_.t;
+    const double theta = dt == 0.0 ? 1.0 : (t - old_state_.t) / dt;
+    out.clear();
+    for (size_t j = 0; j < s_.size(); ++j) out.push_back(HipVec::zeros(n(), ctx()));
+    if (tab_.has_beta) {
+      std::vector<double> thetav{theta};
+      for (int i = 1; i < tab_.beta_cols; ++i) thetav.push_back(theta * thetav[(size_t)i - 1]);
+      std::vector<double> beta_f((size_t)tab_.beta_rows);
+      for (int i = 0; i < tab_.beta_rows; ++i) {
+        double acc = 1.0 * tab_.beta[(size_t)i] * thetav[0];
+        for (int j = 1; j < tab_.beta_cols; ++j) acc = 1.0 * tab_.beta[(size_t)(j * tab_.beta_rows + i)] * thetav[(size_t)j] + acc;
+        beta_f[(size_t)i] = acc;
+      }
+      HipVec bf = HipVec::from_vec(beta_f, pr_.context().clone_with_nbatch(1));
+      for (size_t j = 0; j < s_.size(); ++j) {
+        out[j].copy_from(old_s_[j]);
+        sdiff_[j].gemv(1.0, bf, 1.0, out[j]);
+      }
+    } else {
+      for (size_t j = 0; j < s_.size(); ++j) {
+        HipVec& ret = out[j];
+        ret.copy_from(s_[j]);
+        ret.sub_assign(old_s_[j]);
+        ret.axpy_v(1.0 * (theta - 1.0), sdiff_[j].column(0), 1.0 - 2.0 * theta);
+        ret.axpy_v(1.0 * theta, sdiff_[j].column(tab_.s - 1), 1.0);
+        ret.axpy(1.0 - theta, old_s_[j], theta * (theta - 1.0));
+        ret.axpy(theta, s_[j], 1.0);
+      }
+    }
+  }
+  const std::vector<HipVec>& sens() const { return s_; }
 
   OdeSolverStopReason step() override {  // sdirk.rs:409-543
     if (is_state_mutated_) {  // Rk::start_step (runge_kutta.rs:444-464)
@@ -148,13 +218,16 @@ class Sdirk : public OdeSolverMethod {
     }
     double h = state_.h;
     if (std::fabs(h) < minimum_timestep_) throw DSH_ODE_ERR(StepSizeTooSmall);
-    op_.set_h(h);
+    set_op_h(h);
     int nattempts = 0;
     bool updated_jacobian = false;
     const int start = skip_first_stage() ? 1 : 0;
     double fac = 1.0, error_norm = 0.0;
     while (true) {
-      if (skip_first_stage()) diff_.column_mut(0).axpy(h, state_.dy, 0.0);  // start_step_attempt (runge_kutta.rs:505-516)
+      if (skip_first_stage()) {  // start_step_attempt (runge_kutta.rs:505-534), "sensitivities too"
+        diff_.column_mut(0).axpy(h, state_.dy, 0.0);
+        for (size_t j = 0; j < sdiff_.size(); ++j) sdiff_[j].column_mut(0).axpy(h, ds_[j], 0.0);
+      }
       bool failed = false;
       for (int i = start; i < tab_.s; ++i) {
         if (do_stage_sdirk(i, h) != NlError::Ok) {
@@ -164,7 +237,7 @@ class Sdirk : public OdeSolverMethod {
           } else {
             h *= 0.3;
             convergence_.reset_eta_timestep_change();
-            op_.set_h(h);
+            set_op_h(h);
             jacobian_updates(h, SolverState::SecondConvergenceFail);
           }
           prev_error_norm_.reset();
@@ -184,13 +257,18 @@ class Sdirk : public OdeSolverMethod {
       }
       if (!nonlinear_solver_.solve_linearised_in_place(error_)) throw DSH_ODE_ERR(LinearSolveFailed);
       error_norm = std::fmax(0.0, error_.squared_norm(state_.y, pr_.atol, pr_.rtol));
+      if (pr_.sens && pr_.sens_error_control)  // runge_kutta.rs:812-822 — no linear solve on the sensitivity error estimates
+        for (size_t j = 0; j < sdiff_.size(); ++j) {
+          sdiff_[j].gemv(1.0, d_vec_, 0.0, sens_error_);
+          error_norm = std::fmax(error_norm, sens_error_.squared_norm(s_[j], pr_.sens_atol, pr_.sens_rtol));
+        }
       const double maxiter = (double)convergence_.max_iter(), niter = (double)convergence_.niter();
       const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       fac = factor(error_norm, safety_factor);
       if (error_norm < 1.0) break;
       h *= fac;
       convergence_.reset_eta_timestep_change();
-      op_.set_h(h);
+      set_op_h(h);
       jacobian_updates(h, SolverState::ErrorTestFail);
       nattempts += 1;
       prev_error_norm_.reset();
@@ -200,7 +278,7 @@ class Sdirk : public OdeSolverMethod {
     }
     const double new_h = h * fac;
     if (fac != 1.0) convergence_.reset_eta_timestep_change();
-    op_.set_h(new_h);
+    set_op_h(new_h);
     jacobian_updates(new_h, SolverState::StepSuccess);
     jacobian_update_.step();
     prev_error_norm_ = error_norm;
@@ -208,7 +286,10 @@ class Sdirk : public OdeSolverMethod {
     old_state_.t = state_.t + h;
     old_state_.h = new_h;
     old_state_.dy.mul_assign(scale(1.0 / h));
+    for (HipVec& d : old_ds_) d.mul_assign(scale(1.0 / h));
     std::swap(old_state_, state_);
+    std::swap(old_s_, s_);
+    std::swap(old_ds_, ds_);
     statistics_.number_of_steps += 1;
     if (root_finder_) {
       auto interp = [&](double tt, HipVec& yy) { interpolate_inplace(tt, yy); };
@@ -302,6 +383,7 @@ class Sdirk : public OdeSolverMethod {
     }
   }
   void state_mut_back(double t) override {  // runge_kutta.rs:396-434: y and dy from the step's interpolants
+    if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "state_mut_back with forward sensitivities is not supported by the HIP backend");
     HipVec ynew = HipVec::zeros(state_.y.len(), pr_.context()), dynew = HipVec::zeros(state_.y.len(), pr_.context());
     interpolate_inplace(t, ynew);
     interpolate_dy_inplace(t, dynew);
@@ -370,13 +452,14 @@ class Sdirk : public OdeSolverMethod {
     return false;
   }
 
-  void predict_stage_sdirk(int i, double h, const HipVec& dy0, HipVec& hdy) const {  // runge_kutta.rs:610-629
+  void predict_stage_sdirk(int i, double h, const HipVec& dy0, HipVec& hdy) const { predict_stage_sdirk(i, h, dy0, diff_, hdy); }
+  void predict_stage_sdirk(int i, double h, const HipVec& dy0, const HipMat& df, HipVec& hdy) const {  // runge_kutta.rs:610-629
     if (i == 0) hdy.axpy(h, dy0, 0.0);
-    else if (i == 1) hdy.copy_from_view(diff_.column(0));
+    else if (i == 1) hdy.copy_from_view(df.column(0));
     else {
       const double c = (tab_.c[(size_t)i] - tab_.c[(size_t)i - 2]) / (tab_.c[(size_t)i - 1] - tab_.c[(size_t)i - 2]);
-      hdy.copy_from_view(diff_.column(i - 1));
-      hdy.axpy_v(-c, diff_.column(i - 2), 1.0 + c);
+      hdy.copy_from_view(df.column(i - 1));
+      hdy.axpy_v(-c, df.column(i - 2), 1.0 + c);
     }
   }
 
@@ -393,7 +476,30 @@ class Sdirk : public OdeSolverMethod {
     if (r != NlError::Ok) return r;
     op_.get_f_eval(old_state_.dy, old_state_.y);
     diff_.column_mut(i).copy_from(old_state_.dy);
+    if (s_op_) {  // the sensitivity half of do_stage_sdirk (runge_kutta.rs:691-748)
+      sens_update_state(old_state_.y, t);  // update_rhs_out_state(old_state.y, old_state.dy, t)
+      for (size_t j = 0; j < sdiff_.size(); ++j) {
+        s_op_->set_phi(sdiff_[j].columns(0, i), s_[j], a_rows_[(size_t)i]);
+        sens_index_ = (int)j;
+        predict_stage_sdirk(i, h, ds_[j], sdiff_[j], old_ds_[j]);
+        NlError rs = nonlinear_solver_.solve_in_place(*s_op_, old_ds_[j], t, s_[j], convergence_, line_search_);
+        statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();  // counted before the `?` here
+        if (rs != NlError::Ok) return rs;
+        s_op_->get_f_eval(old_ds_[j], old_s_[j]);
+        sdiff_[j].column_mut(i).copy_from(old_ds_[j]);
+      }
+    }
     return NlError::Ok;
+  }
+  void set_op_h(double h) { op_.set_h(h); if (s_op_) s_op_->set_h(h); }  // update_op_step_size (sdirk.rs:305-313)
+  // SensRhs (ode_equations/sens_equations.rs:87-190): df/dp and the linearisation point; J(sens_y) x + (df/dp)[:, index]
+  void sens_update_state(const HipVec& y, double t) {
+    pr_.eqn->rhs_sens_inplace(y, t, sens_mat_);
+    sens_y_.copy_from(y);
+  }
+  void sens_rhs_call(int index, const HipVec& x, double t, HipVec& y) const {
+    pr_.eqn->rhs_jac_mul_inplace(sens_y_, t, x, y);
+    y.add_assign(sens_mat_.column(index));
   }
 
   NlError newton_fused(double t) {
@@ -443,6 +549,13 @@ class Sdirk : public OdeSolverMethod {
   bool fused_ = false;
   int model_ = -1;
   int64_t model_size_ = 0;
+  // forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens())
+  std::vector<HipVec> s_, ds_, old_s_, old_ds_;
+  std::vector<HipMat> sdiff_;
+  std::unique_ptr<SdirkCallable> s_op_;
+  HipMat sens_mat_;
+  HipVec sens_y_, sens_error_;
+  int sens_index_ = 0;
 };
 
 }  // namespace diffsol_hip

@@ -20,12 +20,14 @@ struct dshs_solver {
   OdeSolverProblem problem;
   std::unique_ptr<OdeSolverMethod> solver;
   Bdf* bdf = nullptr;
+  Sdirk* sdirk = nullptr;
   bool fused = false;
   bool kernel_timing = false;
   int method = 0;
   void make_solver() {
     solver.reset();
     bdf = nullptr;
+    sdirk = nullptr;
     problem.eqn->rhs_statistics = OpStatistics();
     if (method == DSHS_METHOD_BDF) {
       auto b = std::make_unique<Bdf>(problem);
@@ -36,6 +38,7 @@ struct dshs_solver {
     } else if (method == DSHS_METHOD_TR_BDF2 || method == DSHS_METHOD_ESDIRK34) {
       auto k = std::make_unique<Sdirk>(problem, method == DSHS_METHOD_TR_BDF2 ? Tableau::tr_bdf2() : Tableau::esdirk34());
       fused = k->is_fused();
+      sdirk = k.get();
       solver = std::move(k);
     } else {
       throw LaError(DSH_E_INVALID, "unknown method");
@@ -85,6 +88,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group) {
   ResidentPick r;
   r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
   if (group != 1 && group != 64) return r;
+  if (s->problem.sens) return r;  // the device-resident kernels integrate the state equations only: sensitivities run host-driven
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it
   const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
   const bool lane_ok = !(lane_env && lane_env[0] == '0');
@@ -282,7 +286,6 @@ int dshs_create_sens(int device, void* stream, int model, int64_t model_size, in
     OdeBuilder builder;
     builder.t0(t0).h0(h0).rtol(rtol).atol(a).context(s->ctx).use_fused_kernels(o.use_fused_kernels != 0).ode_options(oo).ic_options(ic);
     if (sens) {
-      if (method != DSHS_METHOD_BDF) throw LaError(DSH_E_UNSUPPORTED, "forward sensitivities are provided for BDF (problem.bdf_sens())");
       builder.sensitivities(true);
       if (nsens_atol > 0) builder.sens_tolerances(sens_rtol, std::vector<double>(sens_atol, sens_atol + nsens_atol));
     }
@@ -340,14 +343,16 @@ int dshs_get_state(dshs_solver* s, double* t, double* h, int* order, double* y_h
 int64_t dshs_nparams(const dshs_solver* s) { return s->problem.eqn->nparams(); }
 int dshs_interpolate_sens(dshs_solver* s, double t, double* s_host) {
   return guarded([&]() {
-    if (!s->bdf || !s->problem.sens) throw LaError(DSH_E_INVALID, "the solver was not created with forward sensitivities (dshs_create_sens)");
+    if ((!s->bdf && !s->sdirk) || !s->problem.sens) throw LaError(DSH_E_INVALID, "the solver was not created with forward sensitivities (dshs_create_sens)");
     const size_t len = (size_t)(s->problem.eqn->nstates() * s->ctx.nbatch());
+    const std::vector<HipVec>& cur = s->bdf ? s->bdf->sens() : s->sdirk->sens();
     if (t != t) {  // NaN: state.s, the sensitivities at the current time
-      for (size_t j = 0; j < s->bdf->sens().size(); ++j) download(s->bdf->sens()[j], s_host + j * len);
+      for (size_t j = 0; j < cur.size(); ++j) download(cur[j], s_host + j * len);
       return 0;
     }
     std::vector<HipVec> out;
-    s->bdf->interpolate_sens_inplace(t, out);
+    if (s->bdf) s->bdf->interpolate_sens_inplace(t, out);
+    else s->sdirk->interpolate_sens_inplace(t, out);
     for (size_t j = 0; j < out.size(); ++j) download(out[j], s_host + j * len);
     return 0;
   });

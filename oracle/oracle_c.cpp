@@ -45,13 +45,13 @@ std::unique_ptr<Handle> make_handle(int model_id, int model_size, int nbatch, co
   for (const auto& kv : g_option_request) {
     if (kv.first == "max_nonlinear_solver_failures") h->problem.ode_options.max_nonlinear_solver_failures = (int)kv.second;
     else if (kv.first == "max_error_test_failures") h->problem.ode_options.max_error_test_failures = (int)kv.second;
+    else if (kv.first == "max_nonlinear_solver_iterations") h->problem.ode_options.max_nonlinear_solver_iterations = (int)kv.second;
     else { g_option_request.clear(); throw std::runtime_error("oracle: unknown option " + kv.first); }
   }
   g_option_request.clear();
   if (g_sens_request.on) {
     const SensRequest rq = g_sens_request;
     g_sens_request = SensRequest();
-    if (method != METHOD_BDF) throw std::runtime_error("oracle: forward sensitivities are restated for BDF only");
     if (!h->problem.eqn->model->has_sens) throw std::runtime_error("oracle: model has no parameter sensitivities");
     h->problem.sens = true;
     h->problem.sens_error_control = rq.error_control;
@@ -108,10 +108,11 @@ int orc_nparams(void* hv) { return ((Handle*)hv)->problem.eqn->model->np; }
 int orc_interpolate_sens(void* hv, double t, double* out) {
   Handle* h = (Handle*)hv;
   Bdf* b = dynamic_cast<Bdf*>(h->solver.get());
-  if (!b || !h->problem.sens) return -100;
+  Sdirk* k = dynamic_cast<Sdirk*>(h->solver.get());
+  if ((!b && !k) || !h->problem.sens) return -100;
   std::vector<V> s;
-  if (t != t) s = b->s_;
-  else { OdeErr e = b->interpolate_sens(t, s); if (e != OdeErr::Ok) return -(int)e; }
+  if (t != t) s = b ? b->s_ : k->s_;
+  else { OdeErr e = b ? b->interpolate_sens(t, s) : k->interpolate_sens(t, s); if (e != OdeErr::Ok) return -(int)e; }
   const size_t len = (size_t)h->problem.n() * h->problem.nb();
   for (size_t j = 0; j < s.size(); ++j) std::memcpy(out + j * len, s[j].d.data(), len * sizeof(double));
   return 0;

@@ -338,6 +338,49 @@ inline OdeErr new_and_consistent(const Problem& pr, int solver_order, StateCommo
   return OdeErr::Ok;
 }
 
+// The DAE half of set_consistent_augmented (state.rs:187-238), shared by the BDF and SDIRK restatements: per parameter one Newton solve on InitOp over the
+// sensitivity equations for (ds_j on the differential, s_j on the algebraic components); tolerances of the STATE equations, the consistent-initialisation
+// options.  `sens_rhs(j, x, t, y)` = SensRhs::call_inplace for parameter j about the linearisation point sens_y.
+template <class SensRhsFn>
+inline OdeErr sens_set_consistent(const Problem& pr, double t0, const V& sens_y, std::vector<V>& s, std::vector<V>& ds, SensRhsFn&& sens_rhs) {
+  const Eqn& eqn = *pr.eqn;
+  if (!eqn.has_mass()) return OdeErr::Ok;
+  const int n0 = pr.n(), nb0 = pr.nb();
+  M mass(n0, n0, nb0);
+  eqn.mass_matrix(pr.t0, mass);
+  std::vector<int> alg;
+  for (int i = 0; i < n0; ++i) if (mass.at(0, i, i) == 0.0) alg.push_back(i);
+  if (alg.empty()) return OdeErr::Ok;
+  Convergence conv(pr.rtol, &pr.atol, pr.ode_options.nonlinear_solver_tolerance);
+  conv.max_iter = pr.ic_options.max_newton_iterations;
+  std::unique_ptr<LineSearch> ls;
+  if (pr.ic_options.use_linesearch) {
+    auto b = std::make_unique<BacktrackingLineSearch>();
+    b->c = pr.ic_options.armijo_constant; b->max_iter = pr.ic_options.max_linesearch_iterations; b->tau = pr.ic_options.step_reduction_factor;
+    ls = std::move(b);
+  } else ls = std::make_unique<NoLineSearch>();
+  NewtonSolver root_solver;
+  for (size_t j = 0; j < s.size(); ++j) {
+    InitOp f(&eqn, t0, s[j], alg, [&sens_rhs, j](const V& x, double t, V& y) { sens_rhs((int)j, x, t, y); },
+             [&eqn, &sens_y](double t, M& out) { eqn.jacobian(sens_y, t, out); });
+    root_solver.set_problem(n0, nb0);
+    V y_tmp = ds[j];
+    InitOp::copy_from_indices(y_tmp, s[j], alg);
+    V yerr = y_tmp;
+    NlErr result = NlErr::Ok;
+    for (int k = 0; k < pr.ic_options.max_linear_solver_setups; ++k) {
+      root_solver.reset_jacobian(f, y_tmp, t0);
+      result = root_solver.solve_in_place(f, y_tmp, t0, yerr, conv, *ls);
+      if (result == NlErr::Ok) break;
+      if (result != NlErr::NewtonMaxIterations) return OdeErr::InitialConditionDidNotConverge;
+      copy_from(yerr, y_tmp);
+    }
+    if (result != NlErr::Ok) return OdeErr::InitialConditionDidNotConverge;
+    f.scatter_soln(y_tmp, s[j], ds[j]);
+  }
+  return OdeErr::Ok;
+}
+
 // vector root_finding, batch semantics of crates/diffsol-la/src/vector/cuda.rs:1153-1177 (all batches must agree)
 struct RootFindingResult { bool found; double frac; int idx; bool mismatch; };
 inline RootFindingResult root_finding(const V& g0, const V& g1) {
@@ -508,44 +551,8 @@ struct Bdf : SolverBase {
       for (int j = 0; j < npar; ++j) p->eqn->init_sens(t_, j, s_[(size_t)j]);
       sens_update_state(y_, t_);
       for (int j = 0; j < npar; ++j) sens_rhs_call(j, s_[(size_t)j], t_, ds_[(size_t)j]);
-      if (p->eqn->has_mass()) {
-        // the DAE half of set_consistent_augmented (state.rs:187-238): per parameter one Newton solve on InitOp over the sensitivity equations for
-        // (ds_j on the differential, s_j on the algebraic components); tolerances of the STATE equations, the consistent-initialisation options
-        const Eqn& eqn = *p->eqn;
-        M mass(n0, n0, nb0);
-        eqn.mass_matrix(p->t0, mass);
-        std::vector<int> alg;
-        for (int i = 0; i < n0; ++i) if (mass.at(0, i, i) == 0.0) alg.push_back(i);
-        if (!alg.empty()) {
-          Convergence conv(p->rtol, &p->atol, p->ode_options.nonlinear_solver_tolerance);
-          conv.max_iter = p->ic_options.max_newton_iterations;
-          std::unique_ptr<LineSearch> ls;
-          if (p->ic_options.use_linesearch) {
-            auto b = std::make_unique<BacktrackingLineSearch>();
-            b->c = p->ic_options.armijo_constant; b->max_iter = p->ic_options.max_linesearch_iterations; b->tau = p->ic_options.step_reduction_factor;
-            ls = std::move(b);
-          } else ls = std::make_unique<NoLineSearch>();
-          NewtonSolver root_solver;
-          for (int j = 0; j < npar; ++j) {
-            InitOp f(&eqn, t_, s_[(size_t)j], alg, [this, j](const V& x, double t, V& y) { sens_rhs_call(j, x, t, y); },
-                     [this, &eqn](double t, M& out) { eqn.jacobian(sens_y, t, out); });
-            root_solver.set_problem(n0, nb0);
-            V y_tmp = ds_[(size_t)j];
-            InitOp::copy_from_indices(y_tmp, s_[(size_t)j], alg);
-            V yerr = y_tmp;
-            NlErr result = NlErr::Ok;
-            for (int k = 0; k < p->ic_options.max_linear_solver_setups; ++k) {
-              root_solver.reset_jacobian(f, y_tmp, t_);
-              result = root_solver.solve_in_place(f, y_tmp, t_, yerr, conv, *ls);
-              if (result == NlErr::Ok) break;
-              if (result != NlErr::NewtonMaxIterations) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
-              copy_from(yerr, y_tmp);
-            }
-            if (result != NlErr::Ok) { init_error = OdeErr::InitialConditionDidNotConverge; return; }
-            f.scatter_soln(y_tmp, s_[(size_t)j], ds_[(size_t)j]);
-          }
-        }
-      }
+      init_error = sens_set_consistent(*p, t_, sens_y, s_, ds_, [this](int j, const V& x, double t, V& y) { sens_rhs_call(j, x, t, y); });
+      if (init_error != OdeErr::Ok) return;
     }
     // _new :244-368
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};

@@ -10,6 +10,8 @@
 //                            :841-892     error_test_fail / solve_fail;  :894-960 step_accepted;  :962-990, :1016-1035 interpolation
 //   ode_solver/sdirk.rs:172-215 _new, :260-303 jacobian_updates, :409-543 step
 #pragma once
+#include <functional>
+#include <memory>
 #include "oracle_ode.hpp"
 
 namespace orc {
@@ -87,9 +89,12 @@ struct SdirkCallable {
   void set_tmp(const V& x) { copy_from(tmp, phi); axpy(tmp, c, x, 1.0); }           // :186-195
   void get_f_eval(const V& x, V& f_eval) const { copy_from(f_eval, phi); axpy(f_eval, c, x, 1.0); }  // :197-203
   void set_jacobian_is_stale() { jacobian_is_stale = true; }
+  // SdirkCallable over the sensitivity equations (s_op): the right-hand side is SensRhs for the current parameter index
+  std::function<void(const V&, double, V&)> rhs_override;
   void call_inplace(const V& x, double t, V& y) {  // :229-244
     set_tmp(x);
-    eqn->rhs(tmp, t, y);
+    if (rhs_override) rhs_override(tmp, t, y);
+    else eqn->rhs(tmp, t, y);
     double beta = -h;
     if (eqn->has_mass()) eqn->mass_gemv(x, t, beta, y);
     else axpy(y, 1.0, x, beta);
@@ -124,6 +129,17 @@ struct Sdirk : SolverBase {
   std::optional<double> tstop;
   std::optional<RootFinder> root_finder;
   std::optional<double> prev_error_norm;
+  // forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:196-232 new_augmented, :691-748 the sensitivity half of do_stage_sdirk,
+  // :812-822 sensitivities in the error norm, :1237-1300 interpolate_sens_inplace; SensRhs ode_equations/sens_equations.rs:87-190)
+  std::vector<V> s_, ds_, old_s_, old_ds_;  // state.s / state.ds and their old_state partners
+  std::vector<M> sdiff;
+  std::unique_ptr<SdirkCallable> s_op;
+  M sens_mat;
+  V sens_y, sens_error;
+  int sens_index = 0;
+  int naug() const { return pr->sens ? pr->eqn->model->np : 0; }
+  void sens_update_state(const V& y, double t) { pr->eqn->rhs_sens(y, t, sens_mat); copy_from(sens_y, y); }
+  void sens_rhs_call(int index, const V& x, double t, V& y) const { pr->eqn->jac_mul(sens_y, t, x, y); add_assign(y, sens_mat.column(index)); }
   // config.rs:76-109
   double minimum_timestep, maximum_timestep_growth, minimum_timestep_growth, maximum_timestep_shrink, minimum_timestep_shrink;
   int maximum_error_test_failures, maximum_newton_fails;
@@ -147,6 +163,23 @@ struct Sdirk : SolverBase {
     for (int i = 0; i < tab.s; ++i) { std::vector<double> row; for (int j = 0; j < i; ++j) row.push_back(tab.A(i, j)); a_rows.push_back(row); }
     if (p->eqn->model->nroots > 0) { root_finder.emplace(p->eqn->model->nroots, n, nb); root_finder->init(*p->eqn, state.y, state.t); }
     diff = M(n, tab.s, nb);
+    if (p->sens) {
+      // RkState::new_with_sensitivities_and_consistent (state.rs:1032-1083): s_j = SensInit(t0), ds_j = SensRhs(s_j) about (y0, t0), DAEs through InitOp
+      const int npar = naug();
+      sens_mat = M(n, npar, nb);
+      sens_y = V(n, nb);
+      s_.assign((size_t)npar, V(n, nb)); ds_.assign((size_t)npar, V(n, nb));
+      for (int j = 0; j < npar; ++j) p->eqn->init_sens(state.t, j, s_[(size_t)j]);
+      sens_update_state(state.y, state.t);
+      for (int j = 0; j < npar; ++j) sens_rhs_call(j, s_[(size_t)j], state.t, ds_[(size_t)j]);
+      init_error = sens_set_consistent(*p, state.t, sens_y, s_, ds_, [this](int j, const V& x, double t, V& y) { sens_rhs_call(j, x, t, y); });
+      if (init_error != OdeErr::Ok) return;
+      old_s_ = s_; old_ds_ = ds_;
+      sdiff.assign((size_t)npar, M(n, tab.s, nb));
+      sens_error = V(n, nb);
+      s_op = std::make_unique<SdirkCallable>(p->eqn.get(), tab.A(1, 1));
+      s_op->rhs_override = [this](const V& x, double t, V& y) { sens_rhs_call(sens_index, x, t, y); };
+    }
     old_state = state;
     error = V(n, nb);
     // Sdirk::_new
@@ -154,8 +187,13 @@ struct Sdirk : SolverBase {
     jacobian_update.update_rhs_jacobian(state.h);
     convergence.max_iter = o.max_nonlinear_solver_iterations;
     op.set_h(state.h);
+    if (s_op) s_op->set_h(state.h);
     nonlinear_solver.set_problem(n, nb);
+    // Sdirk::new_augmented ends with jacobian_updates(h, Checkpoint) (sdirk.rs:251): the first linearisation of a solver WITH sensitivities is made here, at
+    // t0 and — op.phi still being zero — about gamma * y0 (SdirkCallable::jacobian_inplace evaluates at phi + c x), not lazily inside the first stage
+    if (s_op) jacobian_updates(state.h, SolverState::Checkpoint);
   }
+  void set_op_h(double h) { op.set_h(h); if (s_op) s_op->set_h(h); }  // update_op_step_size (sdirk.rs)
 
   bool skip_first_stage() const { return tab.A(0, 0) == 0.0; }
 
@@ -198,13 +236,14 @@ struct Sdirk : SolverBase {
     return OdeErr::Ok;
   }
 
-  void predict_stage_sdirk(int i, double h, const V& dy0, V& hdy) const {  // runge_kutta.rs:610-629
+  void predict_stage_sdirk(int i, double h, const V& dy0, V& hdy) const { predict_stage_sdirk(i, h, dy0, diff, hdy); }
+  void predict_stage_sdirk(int i, double h, const V& dy0, const M& df, V& hdy) const {  // runge_kutta.rs:610-629
     if (i == 0) axpy(hdy, h, dy0, 0.0);
-    else if (i == 1) hdy = diff.column(0);
+    else if (i == 1) hdy = df.column(0);
     else {
       double c = (tab.c[i] - tab.c[i - 2]) / (tab.c[i - 1] - tab.c[i - 2]);
-      hdy = diff.column(i - 1);
-      axpy(hdy, -c, diff.column(i - 2), 1.0 + c);
+      hdy = df.column(i - 1);
+      axpy(hdy, -c, df.column(i - 2), 1.0 + c);
     }
   }
 
@@ -221,6 +260,19 @@ struct Sdirk : SolverBase {
     if (r != NlErr::Ok) return r;
     op.get_f_eval(old_state.dy, old_state.y);
     diff.set_column(i, old_state.dy);
+    if (s_op) {  // :691-748
+      sens_update_state(old_state.y, t);  // update_rhs_out_state(old_state.y, old_state.dy, t)
+      for (int j = 0; j < naug(); ++j) {
+        s_op->set_phi(sdiff[(size_t)j], i, s_[(size_t)j], a_rows[i]);
+        sens_index = j;
+        predict_stage_sdirk(i, h, ds_[(size_t)j], sdiff[(size_t)j], old_ds_[(size_t)j]);
+        NlErr rs = nonlinear_solver.solve_in_place(*s_op, old_ds_[(size_t)j], t, s_[(size_t)j], convergence, line_search);
+        statistics.number_of_nonlinear_solver_iterations += convergence.niter;  // here the count is added before the `?`
+        if (rs != NlErr::Ok) return rs;
+        s_op->get_f_eval(old_ds_[(size_t)j], old_s_[(size_t)j]);
+        sdiff[(size_t)j].set_column(i, old_ds_[(size_t)j]);
+      }
+    }
     return NlErr::Ok;
   }
 
@@ -237,14 +289,17 @@ struct Sdirk : SolverBase {
   OdeErr step(StopReason& reason) override {  // sdirk.rs:409-543
     double h = state.h;  // rk.start_step()
     if (std::fabs(h) < minimum_timestep) return OdeErr::StepSizeTooSmall;
-    op.set_h(h);
+    set_op_h(h);
     int nattempts = 0;
     bool updated_jacobian = false;
     int start = skip_first_stage() ? 1 : 0;
     double fac = 1.0, error_norm = 0.0;
     while (true) {
       // start_step_attempt (runge_kutta.rs:505-516)
-      if (skip_first_stage()) { V c0(state.dy.n, state.dy.nb); axpy(c0, h, state.dy, 0.0); diff.set_column(0, c0); }
+      if (skip_first_stage()) {
+        V c0(state.dy.n, state.dy.nb); axpy(c0, h, state.dy, 0.0); diff.set_column(0, c0);
+        for (int j = 0; j < naug(); ++j) { axpy(c0, h, ds_[(size_t)j], 0.0); sdiff[(size_t)j].set_column(0, c0); }  // "sensitivities too" (:518-523)
+      }
       bool failed = false;
       for (int i = start; i < tab.s; ++i) {
         if (do_stage_sdirk(i, h) != NlErr::Ok) {
@@ -254,7 +309,7 @@ struct Sdirk : SolverBase {
           } else {
             h *= 0.3;
             convergence.reset_eta_timestep_change();
-            op.set_h(h);
+            set_op_h(h);
             jacobian_updates(h, SolverState::SecondConvergenceFail);
           }
           prev_error_norm.reset();
@@ -281,13 +336,18 @@ struct Sdirk : SolverBase {
       }
       if (!nonlinear_solver.solve_linearised_in_place(error)) return OdeErr::TooManyNonlinearSolverFailures;  // `?` on LuSolveFailed
       error_norm = std::fmax(0.0, squared_norm(error, state.y, pr->atol, pr->rtol));
+      if (pr->sens && pr->sens_error_control)  // :812-822 — no linear solve on the sensitivity error estimates
+        for (int j = 0; j < naug(); ++j) {
+          gemv_cols(sdiff[(size_t)j], tab.s, 1.0, tab.d.data(), 0.0, sens_error);
+          error_norm = std::fmax(error_norm, squared_norm(sens_error, s_[(size_t)j], pr->sens_atol, pr->sens_rtol));
+        }
       double maxiter = (double)convergence.max_iter, niter = (double)convergence.niter;
       double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       fac = factor(error_norm, safety_factor);
       if (error_norm < 1.0) break;
       h *= fac;
       convergence.reset_eta_timestep_change();
-      op.set_h(h);
+      set_op_h(h);
       jacobian_updates(h, SolverState::ErrorTestFail);
       nattempts += 1;
       prev_error_norm.reset();
@@ -298,7 +358,7 @@ struct Sdirk : SolverBase {
     }
     double new_h = h * fac;
     if (fac != 1.0) convergence.reset_eta_timestep_change();
-    op.set_h(new_h);
+    set_op_h(new_h);
     jacobian_updates(new_h, SolverState::StepSuccess);
     jacobian_update.step();
     prev_error_norm = error_norm;
@@ -306,7 +366,10 @@ struct Sdirk : SolverBase {
     old_state.t = state.t + h;
     old_state.h = new_h;
     mul_assign(old_state.dy, 1.0 / h);
+    for (V& d : old_ds_) mul_assign(d, 1.0 / h);
     std::swap(old_state, state);
+    std::swap(old_s_, s_);
+    std::swap(old_ds_, ds_);
     statistics.number_of_steps += 1;
     if (root_finder) {
       auto interp = [&](double tt, V& yy) { (void)interpolate_inplace(tt, yy); };
@@ -346,6 +409,38 @@ struct Sdirk : SolverBase {
       axpy(ret, 1.0 * theta, f1, 1.0);
       axpy(ret, 1.0 - theta, old_state.y, theta * (theta - 1.0));
       axpy(ret, theta, state.y, 1.0);
+    }
+    return OdeErr::Ok;
+  }
+  // interpolate_sens_inplace (runge_kutta.rs:1237-1330): the state's interpolant applied to (old_state.s, state.s, sdiff)
+  OdeErr interpolate_sens(double t, std::vector<V>& out) const {
+    bool is_forward = state.h > 0.0;
+    if ((is_forward && (t > state.t || t < old_state.t)) || (!is_forward && (t < state.t || t > old_state.t)))
+      return OdeErr::InterpolationTimeOutsideCurrentStep;
+    double dt = state.t - old_state.t;
+    double theta = dt == 0.0 ? 1.0 : (t - old_state.t) / dt;
+    out.assign(s_.size(), V(state.y.n, state.y.nb));
+    if (tab.has_beta) {
+      int poly_order = tab.beta.nc, s_star = tab.beta.nr;
+      std::vector<double> thetav{theta};
+      for (int i = 1; i < poly_order; ++i) thetav.push_back(theta * thetav[i - 1]);
+      V beta_f(s_star, 1);
+      gemv_cols(tab.beta, poly_order, 1.0, thetav.data(), 0.0, beta_f);
+      for (size_t j = 0; j < s_.size(); ++j) {
+        copy_from(out[j], old_s_[j]);
+        gemv_cols(sdiff[j], s_star, 1.0, beta_f.d.data(), 1.0, out[j]);
+      }
+    } else {
+      for (size_t j = 0; j < s_.size(); ++j) {
+        V f0 = sdiff[j].column(0), f1 = sdiff[j].column(sdiff[j].nc - 1);
+        V& ret = out[j];
+        copy_from(ret, s_[j]);
+        sub_assign(ret, old_s_[j]);
+        axpy(ret, 1.0 * (theta - 1.0), f0, 1.0 - 2.0 * theta);
+        axpy(ret, 1.0 * theta, f1, 1.0);
+        axpy(ret, 1.0 - theta, old_s_[j], theta * (theta - 1.0));
+        axpy(ret, theta, s_[j], 1.0);
+      }
     }
     return OdeErr::Ok;
   }

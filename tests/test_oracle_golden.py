@@ -435,3 +435,34 @@ def test_oracle_bdf_sens_reproduces_the_reference_snapshots_on_the_daes(O):
     for (y_ref, _), y in zip(table, ys):
         assert weighted_error_norm(y[0], np.array(y_ref), [1e-8, 1e-6, 1e-6], 1e-4) < 15.0
     assert np.isfinite(ss).all() and abs(ss[-1, 0, 0].sum()) < 1e-8  # the constraint x + y + z = 1 holds for every sensitivity too
+
+
+_ROBERTSON_TABLE_T = [0.0, 0.4, 4.0, 40.0, 400.0, 4000.0, 4e4, 4e5, 4e6, 4e7, 4e8, 4e9, 4e10]
+
+
+@pytest.mark.parametrize("method,model,snap", [
+    ("tr_bdf2", "exp", [10, 90, 0, 620, 0, 1, 0, 0, 0, 9, 207, 421, 2]),
+    ("esdirk34", "exp", [6, 33, 0, 347, 0, 1, 0, 0, 0, 5, 107, 246, 1]),
+    ("tr_bdf2", "robertson", [77, 286, 0, 4146, 30, 1, 29, 1, 0, 46, 1303, 2954, 34]),
+    ("esdirk34", "robertson", [68, 333, 0, 6856, 10, 1, 8, 2, 0, 57, 2272, 4644, 17])])
+def test_oracle_sdirk_sens_reproduces_the_reference_snapshots(O, method, model, snap):
+    """Forward sensitivities in the SDIRK integrators (the sensitivity half of do_stage_sdirk, runge_kutta.rs:691-748; sensitivities in the error norm :812-822;
+    Sdirk::new_augmented's jacobian_updates(h, Checkpoint), sdirk.rs:251, which makes the FIRST linearisation at t0 about gamma * y0).  ALL 13 counters of the four
+    insta snapshot pairs: test_tr_bdf2_nalgebra_exponential_decay_sens (sdirk.rs:707-730), test_esdirk34_nalgebra_exponential_decay_sens (:782-805),
+    test_tr_bdf2_nalgebra_robertson_sens (:894-918, the DAE, max_nonlinear_solver_iterations = 10) and test_esdirk34_nalgebra_robertson_sens (:945-968)."""
+    m = O.METHOD_TR_BDF2 if method == "tr_bdf2" else O.METHOD_ESDIRK34
+    if model == "exp":
+        o = O.OracleSolver(O.MODEL_EXPONENTIAL_DECAY, [0.1, 1.0], rtol=1e-6, atol=[1e-6], method=m, sens=True, sens_rtol=1e-6, sens_atol=[1e-6, 1e-6])
+        pts = [float(i) for i in range(10)]
+    else:
+        opts = dict(max_nonlinear_solver_iterations=10) if method == "tr_bdf2" else None
+        o = O.OracleSolver(O.MODEL_ROBERTSON_DAE, [0.04, 1.0e4, 3.0e7], rtol=1e-4, atol=[1e-8, 1e-6, 1e-6], method=m, sens=True, options=opts)
+        pts = _ROBERTSON_TABLE_T
+    ys, ss = _run_points(o, pts)
+    st = o.stats()
+    assert [st[k] for k in st] == snap
+    if model == "exp":
+        t = np.array(pts)
+        assert np.abs(ss[:, 0, 0, 0] + t * np.exp(-0.1 * t)).max() < 1e-4 and np.abs(ss[:, 1, 0, 0] - np.exp(-0.1 * t)).max() < 1e-4
+    else:
+        assert np.isfinite(ss).all() and np.abs(ss.sum(axis=-1)).max() < 1e-6 * np.abs(ss).max()
