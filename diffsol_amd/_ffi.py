@@ -51,6 +51,7 @@ DEVICE_ABI = {
     "dsh_vec_get_index": (cint, [vp, i64, vp, i64, i64, c_dp]),
     "dsh_vec_set_index": (cint, [vp, i64, vp, i64, i64, dbl]),
     "dsh_vec_extract_batch": (cint, [vp, i64, i64, vp, i64, vp]),
+    "dsh_permute_members": (cint, [vp, i64, i64, cint, vp, vp, vp]),
     "dsh_vec_insert_batch": (cint, [vp, i64, i64, vp, i64, vp]),
     "dsh_vec_set_index_all": (cint, [vp, i64, vp, i64, dbl]),
     "dsh_vec_add": (cint, [vp, i64, i64, vp, i64, vp, i64, vp]),

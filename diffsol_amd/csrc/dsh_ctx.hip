@@ -109,6 +109,17 @@ static int launch_transpose(dsh_ctx* ctx, const double* src, double* dst, int64_
   return DSH_OK;
 }
 
+namespace {
+template <class T>
+__global__ void k_permute_members(int64_t rows, int64_t nb, const T* __restrict__ src, const int32_t* __restrict__ idx, T* __restrict__ dst) {
+  const int64_t total = rows * nb;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / nb, b = e % nb;
+    dst[e] = src[r * nb + idx[b]];
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char* dsh_last_error(void) { return g_err.c_str(); }
@@ -314,6 +325,19 @@ int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double*
   DSH_REQUIRE(ctx != nullptr && b >= 0 && b < nbatch && n >= 0, "batch index out of range");
   if (n == 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpy2DAsync(dst, sizeof(double), v + b, sizeof(double) * (size_t)nbatch, sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+  return DSH_OK;
+}
+// Members of a batched array re-ordered: dst[r * nbatch + b] = src[r * nbatch + idx[b]] for every row r (rows of elem_bytes = 4 or 8).  The per-member
+// device-resident solves run the ensemble sorted by parameters (members with similar parameters take similar paths: a wavefront of neighbours diverges
+// less) and hand results back in the caller's order with the inverse permutation.
+int dsh_permute_members(dsh_ctx* ctx, int64_t rows, int64_t nbatch, int elem_bytes, const void* src, const int32_t* idx_dev, void* dst) {
+  DSH_REQUIRE(ctx != nullptr && rows >= 0 && nbatch >= 1 && (elem_bytes == 4 || elem_bytes == 8) && src != dst, "dsh_permute_members: bad argument");
+  if (rows == 0) return DSH_OK;
+  const int64_t total = rows * nbatch;
+  const dim3 g((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20)), blk(256);
+  if (elem_bytes == 8) hipLaunchKernelGGL((k_permute_members<unsigned long long>), g, blk, 0, ctx->stream, rows, nbatch, (const unsigned long long*)src, idx_dev, (unsigned long long*)dst);
+  else hipLaunchKernelGGL((k_permute_members<unsigned int>), g, blk, 0, ctx->stream, rows, nbatch, (const unsigned int*)src, idx_dev, (unsigned int*)dst);
+  DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
 int dsh_vec_insert_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, int64_t b, const double* src) {

@@ -88,6 +88,9 @@ int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_
 /* Vector::get_batch / get_batch_mut (vector/mod.rs:227-231): member b of a batched vector as a contiguous vector with nbatch = 1, and back
  * (stream-ordered strided copies; with the batch-fastest layout member b is v[i * nbatch + b]). */
 int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t b, double* dst);
+/* members of a batched array re-ordered: dst[r * nbatch + b] = src[r * nbatch + idx[b]], rows of 4- or 8-byte elements, idx on the device.  (No reference
+   counterpart: diffsol solves a sweep member by member; here a per-member ensemble is sorted by parameters so that wavefronts hold similar members.) */
+int dsh_permute_members(dsh_ctx* ctx, int64_t rows, int64_t nbatch, int elem_bytes, const void* src, const int32_t* idx_dev, void* dst);
 int dsh_vec_insert_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, int64_t b, const double* src);
 /* set element i of EVERY batch member to `value` (the reference does nbatch H2D copies for this, vector/cuda.rs:762-774) */
 int dsh_vec_set_index_all(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, double value);

@@ -451,3 +451,31 @@ def test_streaming_lane_per_member_kernel_gives_the_bits_of_the_register_array_f
         assert np.array_equal(ya, yb, equal_nan=True), model
         for k in ma:
             assert np.array_equal(ma[k], mb[k], equal_nan=True), (model, k)
+
+
+@pytest.mark.parametrize("model", ["robertson_ode", "spm", "rlc"])
+def test_per_member_ensembles_run_sorted_by_parameters_and_return_every_result_in_the_callers_order(H, monkeypatch, model):
+    """Per-member device-resident solves of >= 1024 members run the ensemble along a Z-order curve through parameter space (host/solver_c.cpp
+    prepare_member_order: neighbours in a wavefront have similar parameters, hence similar step counts and paths) and un-permute every output.  A member's
+    result does not depend on its position: states, per-member counters, status, event times / indices / column counts and the totals are bit for bit those
+    of the unsorted run (DSH_MEMBER_SORT=0) — BDF on registers, BDF on per-lane memory with events, ESDIRK34 on a DAE with events."""
+    rng = np.random.default_rng(21)
+    nb = 2500
+    if model == "robertson_ode":
+        p, kw, t_eval = robertson_params(nb, seed=4), dict(model_size=1, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6]), [0.4, 4.0, 40.0, 400.0]
+    elif model == "spm":
+        p, kw, t_eval = rng.uniform(0.6, 1.4, (nb, 1)), dict(model_size=20, rtol=1e-6, atol=[1e-6]), [600.0, 1800.0, 3600.0]
+    else:
+        R, Cc = rng.uniform(50.0, 200.0, nb), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+        p = np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, 0.03)], axis=1)
+        kw, t_eval = dict(method=2, rtol=1e-6, atol=[1e-6] * 4), [0.002, 0.005, 0.01, 0.02, 0.05]
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DSH_MEMBER_SORT", flag)
+        s = H.Solver(model, p, nbatch=nb, **kw)
+        out[flag] = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    (ya, ta, ma), (yb, tb, mb) = out["1"], out["0"]
+    assert ta == tb and np.array_equal(ya, yb, equal_nan=True)
+    for k in ma:
+        assert np.array_equal(ma[k], mb[k], equal_nan=True), k
+    assert len(np.unique(ma["stats"][0])) > 3  # members really differ
