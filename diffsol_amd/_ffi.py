@@ -103,6 +103,8 @@ DEVICE_ABI = {
     "dsh_lu_set_structure": (cint, [vp, cint]),
     "dsh_lu_band_width": (cint, [vp]),
     "dsh_model_root": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
+    "dsh_model_has_reset": (cint, [cint, i64]),
+    "dsh_model_reset": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_has_sens": (cint, [cint, i64]),
     "dsh_model_rhs_sens": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_init_sens": (cint, [vp, cint, i64, i64, dbl, vp, vp]),

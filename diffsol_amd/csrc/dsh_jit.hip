@@ -268,7 +268,8 @@ const std::vector<std::string>& jit_static_op_names() {
                                              "dsh::k_static_model<dsh::JitModel, dsh::Op::Jacobian>",   "dsh::k_static_model<dsh::JitModel, dsh::Op::MassGemv>",
                                              "dsh::k_static_model<dsh::JitModel, dsh::Op::MassMatrix>", "dsh::k_static_model<dsh::JitModel, dsh::Op::Init>",
                                              "dsh::k_static_model<dsh::JitModel, dsh::Op::Root>",       "dsh::k_static_model<dsh::JitModel, dsh::Op::Out>",
-                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::RhsSens>",    "dsh::k_static_model<dsh::JitModel, dsh::Op::InitSens>"};
+                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::RhsSens>",    "dsh::k_static_model<dsh::JitModel, dsh::Op::InitSens>",
+                                             "dsh::k_static_model<dsh::JitModel, dsh::Op::Reset>"};
   return v;
 }
 
@@ -326,6 +327,7 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   rec->info.form = form; rec->info.n = n; rec->info.np = nparams; rec->info.nroots = nroots; rec->info.nout = nout; rec->info.has_mass = has_mass ? 1 : 0;
   rec->source = source;
   rec->info.has_sens = rec->source.find("DSH_JIT_HAS_SENS") != std::string::npos ? 1 : 0;
+  rec->info.has_reset = rec->source.find("DSH_JIT_HAS_RESET") != std::string::npos ? 1 : 0;
   // the stated dimensions must be the ones the source was generated with
   if (form != DSH_JIT_FORM_DYNAMIC)
     rec->source += "\nstatic_assert(dsh::JitModel::N == " + std::to_string(n) + " && dsh::JitModel::NP == " + std::to_string(nparams) + " && dsh::JitModel::NROOTS == " +

@@ -72,6 +72,16 @@ extern "C" __global__ void k_jit_dyn_sens(int64_t nb, double t, const double* __
     s[idx] = jit_sens_component(t, (long)i, X, V, P, init != 0);
   }
 }
+// y = reset(x): the state after an event of a hybrid model
+extern "C" __global__ void k_jit_dyn_reset(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, double* __restrict__ y) {
+  const int64_t total = (int64_t)kJitN * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto X = [&](int64_t k) { return x[k * nb + b]; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    y[idx] = jit_reset_component(t, (long)i, X, P);
+  }
+}
 // which = 0: stop_i (roots), 1: out_i; g is count x nb, batch-fastest
 extern "C" __global__ void k_jit_dyn_root_out(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, int which, double* __restrict__ g) {
   const int64_t count = which == 0 ? kJitNRoots : kJitNOut, total = count * nb;

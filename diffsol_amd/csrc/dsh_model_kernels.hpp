@@ -7,7 +7,7 @@
 
 namespace dsh {
 
-enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root, Out, RhsSens, InitSens };
+enum class Op { Rhs, JacMul, Jacobian, MassGemv, MassMatrix, Init, Root, Out, RhsSens, InitSens, Reset };
 
 template <class Mdl, Op OP>
 __global__ void k_static_model(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
@@ -72,6 +72,13 @@ __global__ void k_static_model(int64_t nb, double t, const double* __restrict__ 
 #pragma unroll
         for (int i = 0; i < N; ++i) y[((int64_t)j * N + i) * nb + b] = col[i];
       }
+    }
+  } else if constexpr (OP == Op::Reset) {  // reset_i of a hybrid model: the state after an event
+    if constexpr (model_has_reset<Mdl>::value) {
+      double xr[N], yr[N];
+      load_vec<N>(x, nb, b, xr);
+      Mdl::reset(t, xr, pp, yr);
+      store_vec<N>(y, nb, b, yr);
     }
   } else if constexpr (OP == Op::Out) {  // out_i of a DiffSL model (calc_out): nout x nb, batch-fastest
     constexpr int NO = model_nout<Mdl>::value;

@@ -107,6 +107,7 @@ const char* static_op_name(Op op) {
     case Op::Root: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Root>";
     case Op::RhsSens: return "dsh::k_static_model<dsh::JitModel, dsh::Op::RhsSens>";
     case Op::InitSens: return "dsh::k_static_model<dsh::JitModel, dsh::Op::InitSens>";
+    case Op::Reset: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Reset>";
     default: return "dsh::k_static_model<dsh::JitModel, dsh::Op::Out>";
   }
 }
@@ -129,6 +130,7 @@ int jit_model_op(dsh_ctx* ctx, int model, Op op, int64_t nb, double t, const dou
     case Op::MassMatrix: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_mass_matrix", ew_grid(n * n * nb), dim3(kBlock), 0, nb, t, p, y);
     case Op::Init: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_init", ew_grid(n * nb), dim3(kBlock), 0, nb, t, p, y);
     case Op::Root: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nroots * nb), dim3(kBlock), 0, nb, t, x, p, (int)0, y);
+    case Op::Reset: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_reset", ew_grid(n * nb), dim3(kBlock), 0, nb, t, x, p, y);
     case Op::RhsSens: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_sens", ew_grid(n * ji->np * nb), dim3(kBlock), 0, nb, t, x, p, (int)0, y);
     case Op::InitSens: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_sens", ew_grid(n * ji->np * nb), dim3(kBlock), 0, nb, t, x, p, (int)1, y);
     default: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_root_out", ew_grid(ji->nout * nb), dim3(kBlock), 0, nb, t, x, p, (int)1, y);
@@ -221,6 +223,18 @@ int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, d
   hipLaunchKernelGGL(k_dyn_jacobian_band, ew_grid(n * (kl + ku + 1) * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, kl, ku, t, x, p, jac);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
+}
+// Reset operator of hybrid models (OdeEquations::reset, ode_equations/mod.rs; DiffSL reset_i): y = reset(x, t), the state after an event.  Models
+// compiled from DiffSL text with a reset_i tensor have one; the built-in registry models do not.
+int dsh_model_has_reset(int model, int64_t size) {
+  (void)size;
+  if (!is_jit_model(model)) return 0;
+  const JitInfo* ji = jit_info(model);
+  return ji && ji->has_reset && ji->form != DSH_JIT_FORM_STATIC_BANDED ? 1 : 0;
+}
+int dsh_model_reset(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* y) {
+  if (!dsh_model_has_reset(model, size)) { set_error("dsh_model_reset: model has no reset operator"); return DSH_E_UNSUPPORTED; }
+  return jit_model_op(ctx, model, Op::Reset, nb, t, x, p, nullptr, 0.0, y);
 }
 // forward sensitivities: df/dp and dy0/dp as n x np batched matrices, one launch each
 int dsh_model_has_sens(int model, int64_t size) {

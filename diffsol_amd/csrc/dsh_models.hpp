@@ -175,6 +175,9 @@ template <class M> struct model_nout<M, model_void_t<decltype(M::NOUT)>> { stati
 // a model with parameter sensitivities provides sens_mul ((df/dp) v) and init_sens_mul ((dy0/dp) v), v of length NP (NonLinearOpSens / ConstantOpSens)
 template <class M, class = void> struct model_has_sens { static constexpr bool value = false; };
 template <class M> struct model_has_sens<M, model_void_t<decltype(&M::sens_mul)>> { static constexpr bool value = true; };
+// a hybrid model provides reset (the state after an event; OdeEquations::reset, DiffSL reset_i)
+template <class M, class = void> struct model_has_reset { static constexpr bool value = false; };
+template <class M> struct model_has_reset<M, model_void_t<decltype(&M::reset)>> { static constexpr bool value = true; };
 
 // a model may declare that its Jacobian is banded (BAND_K = max(kl, ku) <= 4) and provide the band directly (jac_band): the device-resident BDF then keeps
 // the state in per-lane memory and factors the band only, which lifts its size limit from the register budget (n <= 4) to n <= 64

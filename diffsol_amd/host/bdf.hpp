@@ -492,6 +492,16 @@ class Bdf : public OdeSolverMethod {
       dy.axpy_v(d_pi, diff_.column(i + 1), 1.0);
     }
   }
+  void apply_reset() override {
+    if (pr_.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with a mass matrix (apply_reset_with_mass) is not supported by the HIP backend");
+    if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with forward sensitivities is not supported by the HIP backend");
+    HipVec y_out = HipVec::zeros(n(), ctx());
+    pr_.eqn->reset_call_inplace(y_, t_, y_out);
+    y_.copy_from(y_out);
+    pr_.eqn->rhs_call_inplace(y_, t_, y_out);
+    dy_.copy_from(y_out);
+    is_state_modified_ = true;  // state_mut()
+  }
   // state_mut_back (bdf.rs:1232-1262): move the state to an interpolated time inside the last step
   void state_mut_back(double t) override {
     if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "state_mut_back with forward sensitivities is not supported by the HIP backend");

@@ -72,6 +72,9 @@ class OdeEquations {
   // forward sensitivities (OdeEquationsImplicitSens): df/dp at (x, t) and dy0/dp as n x nparams matrices (NonLinearOpSens::sens_inplace,
   // op/nonlinear_op.rs:67-81; SensInit, ode_equations/sens_equations.rs:62-70)
   virtual bool has_sens() const { return false; }
+  // OdeEquations::reset (ode_equations/mod.rs): the state after an event, y = reset(x, t); hybrid models only
+  virtual bool has_reset() const { return false; }
+  virtual void reset_call_inplace(const HipVec&, double, HipVec&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no reset operator"); }
   virtual void rhs_sens_inplace(const HipVec&, double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
   virtual void init_sens_inplace(double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
   virtual bool fused_model(int* model, int64_t* size) const { (void)model; (void)size; return false; }
@@ -133,6 +136,10 @@ class HipKernelEquations : public OdeEquations {
     check(dsh_model_root(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), g.ptr()), "root");
   }
   bool has_sens() const override { return dsh_model_has_sens(model_, size_) != 0; }
+  bool has_reset() const override { return dsh_model_has_reset(model_, size_) != 0; }
+  void reset_call_inplace(const HipVec& x, double t, HipVec& y) const override {
+    check(dsh_model_reset(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), y.ptr()), "reset");
+  }
   void rhs_sens_inplace(const HipVec& x, double t, HipMat& S) const override {
     check(dsh_model_rhs_sens(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), S.ptr()), "rhs_sens");
   }
@@ -560,6 +567,8 @@ class OdeSolverMethod {
   virtual const OdeSolverStatistics& get_statistics() const = 0;
   virtual const OdeSolverProblem& problem() const = 0;
   virtual void state_mut_back(double t) = 0;
+  // OdeSolverMethod::apply_reset (method.rs:175-181) over StateRefMut::apply_reset (state.rs:246-268): y <- reset(y, t), dy <- f(y, t), state marked as modified
+  virtual void apply_reset() = 0;
   double root_time = 0.0;
   int root_index = -1;
 
@@ -588,6 +597,13 @@ class OdeSolverMethod {
       if (reason == OdeSolverStopReason::InternalTimestep) { write_out(); continue; }
       if (reason == OdeSolverStopReason::TstopReached) { write_out(); break; }
       state_mut_back(root_time);
+      if (problem().eqn->has_reset()) {  // method.rs:926-944: the reset state is written out at the root time, then the solve continues
+        apply_reset();
+        write_out();
+        if (t() < final_time) { set_stop_time(final_time); continue; }
+        reason = OdeSolverStopReason::TstopReached;
+        break;
+      }
       write_out();
       break;
     }
@@ -619,6 +635,12 @@ class OdeSolverMethod {
       if (reason == OdeSolverStopReason::TstopReached) { drain(t()); break; }
       drain(root_time);
       state_mut_back(root_time);
+      if (problem().eqn->has_reset()) {  // a reset operator is configured (method.rs:774-797): apply it at the root and continue to the last evaluation time
+        apply_reset();
+        if (t() < t_eval.back()) { set_stop_time(t_eval.back()); continue; }
+        reason = OdeSolverStopReason::TstopReached;
+        break;
+      }
       if (col < t_eval.size()) {
         ret.column_mut((int64_t)col).copy_from(y());
         if ((int64_t)col + 1 < ret.ncols()) ret.resize_cols((int64_t)col + 1);

@@ -382,6 +382,16 @@ class Sdirk : public OdeSolverMethod {
       dy.axpy(theta * (theta - 1.0) / dt, q, 1.0);
     }
   }
+  void apply_reset() override {
+    if (pr_.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with a mass matrix (apply_reset_with_mass) is not supported by the HIP backend");
+    if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with forward sensitivities is not supported by the HIP backend");
+    HipVec y_out = HipVec::zeros(state_.y.len(), pr_.context());
+    pr_.eqn->reset_call_inplace(state_.y, state_.t, y_out);
+    state_.y.copy_from(y_out);
+    pr_.eqn->rhs_call_inplace(state_.y, state_.t, y_out);
+    state_.dy.copy_from(y_out);
+    is_state_mutated_ = true;  // state_mut()
+  }
   void state_mut_back(double t) override {  // runge_kutta.rs:396-434: y and dy from the step's interpolants
     if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "state_mut_back with forward sensitivities is not supported by the HIP backend");
     HipVec ynew = HipVec::zeros(state_.y.len(), pr_.context()), dynew = HipVec::zeros(state_.y.len(), pr_.context());

@@ -97,6 +97,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group) {
   r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
   if (group != 1 && group != 64) return r;
   if (s->problem.sens) return r;  // the device-resident kernels integrate the state equations only: sensitivities run host-driven
+  if (s->problem.eqn->has_reset()) return r;  // hybrid models: the resident kernels stop at an event; the host-driven solve_dense applies the reset and continues
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it
   const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
   const bool lane_ok = !(lane_env && lane_env[0] == '0');

@@ -255,6 +255,10 @@ int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double
  * NonLinearOpSens::sens_mul / ConstantOpSens::sens_mul with the unit vector e_j: op/nonlinear_op.rs:51-81, ode_equations/sens_equations.rs:62-70),
  * one launch each.  Built-in models with parameter derivatives: exponential decay (test_models/exponential_decay.rs:33-36, :90-93) and the Robertson
  * ODE (test_models/robertson_ode_with_sens.rs:38-50); dsh_model_has_sens tells. */
+/* reset operator of hybrid models (OdeEquations::reset, crates/diffsol/src/ode_equations/mod.rs; DiffSL reset_i, ode_equations/diffsl.rs:872): y = reset(x, t),
+   the state after an event; the solver applies it at every root and continues (ode_solver/method.rs:774-797) */
+int dsh_model_has_reset(int model, int64_t size);
+int dsh_model_reset(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* y);
 int dsh_model_has_sens(int model, int64_t size);
 int dsh_model_rhs_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double* sens);
 int dsh_model_init_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* sens0);

@@ -337,6 +337,13 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
                 for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
               col++;
             }
+            if (h->problem.eqn->model->has_reset) {
+              // a reset operator is configured (method.rs:774-797): move back to the root, apply the reset, continue to the last evaluation time
+              if (sv.state_mut_back(rt) != OdeErr::Ok || sv.apply_reset() != OdeErr::Ok) { ok = false; break; }
+              for (int b = 0; b < cnt; ++b) { if (root_t_out) root_t_out[s0 + b] = rt; if (root_idx_out) root_idx_out[s0 + b] = sv.root_index; }
+              if (sv.t() < t_eval[nt - 1]) { if (sv.set_stop_time(t_eval[nt - 1]) != OdeErr::Ok) { ok = false; break; } continue; }
+              break;  // TstopReached
+            }
             if (col < nt) {
               (void)sv.interpolate_inplace(rt, tmp);
               if (y_out)
@@ -447,6 +454,7 @@ int orc_load_external_model(const char* path) {
   f.out = (decltype(f.out))dlsym(h, "dsl_out");
   f.sens_mul = (decltype(f.sens_mul))dlsym(h, "dsl_sens_mul");
   f.init_sens_mul = (decltype(f.init_sens_mul))dlsym(h, "dsl_init_sens_mul");
+  f.reset = (decltype(f.reset))dlsym(h, "dsl_reset");
   if (!f.dims || !f.rhs || !f.jac_mul || !f.mass_gemv || !f.init || !f.root || !f.out) { std::fprintf(stderr, "oracle: %s lacks a dsl_* symbol\n", path); return -1; }
   external_models().push_back(f);
   return MODEL_EXTERNAL_BASE + (int)external_models().size() - 1;

@@ -42,6 +42,9 @@ struct Model {
   virtual void mass(const double*, const double*, double, double, double*) const {}
   virtual void init(const double* p, double t, double* y) const = 0;
   virtual void root(const double*, const double*, double, double*) const {}
+  // Reset operator of hybrid models (OdeEquations::reset, DiffSL reset_i): the state after an event, y_new = reset(y, t)
+  bool has_reset = false;
+  virtual void reset(const double*, const double*, double, double*) const { throw std::runtime_error("oracle: model has no reset operator"); }
   // forward sensitivities (OdeEquationsImplicitSens): y = (df/dp)(x, p, t) v  and  y = (dy0/dp)(p, t) v, v of length np
   // (NonLinearOpSens::sens_mul_inplace op/nonlinear_op.rs:51-53, ConstantOpSens::sens_mul_inplace)
   bool has_sens = false;
@@ -307,6 +310,7 @@ struct ExternalFns {
   // optional (models with inputs): (dF/dp) v and (du0/dp) v — rhs_sgrad / set_u0_sgrad of the reference's compiled DiffSL module
   void (*sens_mul)(double, const double*, const double*, const double*, double*) = nullptr;
   void (*init_sens_mul)(double, const double*, const double*, double*) = nullptr;
+  void (*reset)(double, const double*, const double*, double*) = nullptr;  // optional: reset_i
 };
 constexpr int MODEL_EXTERNAL_BASE = 1000;
 inline std::vector<ExternalFns>& external_models() {
@@ -321,7 +325,9 @@ struct ExternalModel : Model {
     f.dims(&n, &np, &nroots, &nout, &hm);
     has_mass = hm != 0;
     has_sens = f.sens_mul != nullptr && f.init_sens_mul != nullptr;
+    has_reset = f.reset != nullptr;
   }
+  void reset(const double* x, const double* p, double t, double* y) const override { f.reset(t, x, p, y); }
   void sens_mul(const double* x, const double* p, double t, const double* v, double* y) const override { f.sens_mul(t, x, p, v, y); }
   void init_sens_mul(const double* p, double t, const double* v, double* y) const override { f.init_sens_mul(t, p, v, y); }
   void rhs(const double* x, const double* p, double t, double* y) const override { f.rhs(t, x, p, y); }
@@ -422,6 +428,9 @@ struct Eqn {
   }
   void root(const V& x, double t, V& g) const {
     for (int b = 0; b < nb; ++b) model->root(&x.d[(size_t)b * x.n], pb(b), t, &g.d[(size_t)b * g.n]);
+  }
+  void reset(const V& x, double t, V& y) const {
+    for (int b = 0; b < nb; ++b) model->reset(&x.d[(size_t)b * x.n], pb(b), t, &y.d[(size_t)b * y.n]);
   }
 };
 

@@ -472,6 +472,10 @@ struct SolverBase {
   virtual int order() const = 0;
   virtual const Stats& stats() const = 0;
   virtual const Problem& problem() const = 0;
+  // state_mut_back (bdf.rs:1232-1262, runge_kutta.rs:396-434): move the state to an interpolated time inside the last step; the next step restarts from it
+  virtual OdeErr state_mut_back(double t) = 0;
+  // OdeSolverMethod::apply_reset (method.rs:175-181) over StateRefMut::apply_reset (state.rs:246-268): y <- reset(y, t), dy <- f(y, t); no mass matrices
+  virtual OdeErr apply_reset() = 0;
   double root_time = 0.0;
   int root_index = -1;
 };
@@ -757,10 +761,47 @@ struct Bdf : SolverBase {
     return error_norm;
   }
 
+  bool is_state_modified = false;
+  OdeErr state_mut_back(double t) override {  // :1232-1262
+    if (pr->sens) return OdeErr::InterpolationTimeOutsideCurrentStep;  // not restated with sensitivities
+    if (is_state_modified) return t == t_ ? OdeErr::Ok : OdeErr::InterpolationTimeOutsideCurrentStep;
+    V ynew(pr->n(), pr->nb()), dynew(pr->n(), pr->nb());
+    OdeErr e = interpolate_inplace(t, ynew);
+    if (e != OdeErr::Ok) return e;
+    e = interpolate_dy_inplace(t, dynew);
+    if (e != OdeErr::Ok) return e;
+    copy_from(y_, ynew);
+    copy_from(dy_, dynew);
+    t_ = t;
+    is_state_modified = true;
+    return OdeErr::Ok;
+  }
+  OdeErr apply_reset() override {
+    if (!pr->eqn->model->has_reset || pr->eqn->has_mass()) return OdeErr::InterpolationTimeOutsideCurrentStep;
+    V y_out(pr->n(), pr->nb());
+    pr->eqn->reset(y_, t_, y_out);
+    copy_from(y_, y_out);
+    pr->eqn->rhs(y_, t_, y_out);
+    copy_from(dy_, y_out);
+    is_state_modified = true;  // state_mut()
+    return OdeErr::Ok;
+  }
   OdeErr step(StopReason& reason) override {  // :1277-1589
     double safety = 0.0, error_norm = 0.0;
     long old_num_error_test_failures = statistics.number_of_error_test_failures;
     bool convergence_fail = false;
+    if (is_state_modified) {  // :1290-1318: restart from first order at the modified state
+      if (root_finder) root_finder->init(*pr->eqn, y_, t_);
+      n_equal_steps = 0;
+      initialise_diff_to_first_order();
+      u = compute_r(1, 1.0);
+      is_state_modified = false;
+      const double c = h_ * alpha[(size_t)order_];
+      op.set_c(h_, alpha[(size_t)order_]);
+      jacobian_updates(c, SolverState::StepSuccess);
+      prev_error_norm.reset();
+      if (tstop) { OdeErr e = set_stop_time(*tstop); if (e != OdeErr::Ok) return e; }
+    }
     predict_forward();
     while (true) {
       int order = order_;
@@ -863,12 +904,14 @@ struct Bdf : SolverBase {
   }
 
   OdeErr interpolate_inplace(double t, V& y) const override {  // :1081-1108
+    if (is_state_modified) { if (t != t_) return OdeErr::InterpolationTimeOutsideCurrentStep; copy_from(y, y_); return OdeErr::Ok; }
     bool is_forward = h_ > 0.0;
     if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
     interpolate_from_diff(t, diff, t_, h_, order_, y);
     return OdeErr::Ok;
   }
   OdeErr interpolate_dy_inplace(double t, V& dy) const override {  // :1108-1132
+    if (is_state_modified) { if (t != t_) return OdeErr::InterpolationTimeOutsideCurrentStep; copy_from(dy, dy_); return OdeErr::Ok; }
     bool is_forward = h_ > 0.0;
     if ((is_forward && t > t_) || (!is_forward && t < t_)) return OdeErr::InterpolationTimeAfterCurrentTime;
     interpolate_derivative_from_diff(t, diff, t_, h_, order_, dy);

@@ -286,7 +286,36 @@ struct Sdirk : SolverBase {
     return f;
   }
 
+  bool is_state_mutated = false;
+  OdeErr state_mut_back(double t) override {  // runge_kutta.rs:396-434
+    if (pr->sens) return OdeErr::InterpolationTimeOutsideCurrentStep;  // not restated with sensitivities
+    V ynew(state.y.n, state.y.nb), dynew(state.y.n, state.y.nb);
+    OdeErr e = interpolate_inplace(t, ynew);
+    if (e != OdeErr::Ok) return e;
+    e = interpolate_dy_inplace(t, dynew);
+    if (e != OdeErr::Ok) return e;
+    copy_from(state.y, ynew);
+    copy_from(state.dy, dynew);
+    state.t = t;
+    is_state_mutated = true;
+    return OdeErr::Ok;
+  }
+  OdeErr apply_reset() override {  // state.rs:246-268 through state_mut()
+    if (!pr->eqn->model->has_reset || pr->eqn->has_mass()) return OdeErr::InterpolationTimeOutsideCurrentStep;
+    V y_out(state.y.n, state.y.nb);
+    pr->eqn->reset(state.y, state.t, y_out);
+    copy_from(state.y, y_out);
+    pr->eqn->rhs(state.y, state.t, y_out);
+    copy_from(state.dy, y_out);
+    is_state_mutated = true;
+    return OdeErr::Ok;
+  }
   OdeErr step(StopReason& reason) override {  // sdirk.rs:409-543
+    if (is_state_mutated) {  // Rk::start_step (runge_kutta.rs:444-464)
+      if (root_finder) root_finder->init(*pr->eqn, state.y, state.t);
+      if (tstop) { OdeErr e = set_stop_time(*tstop); if (e != OdeErr::Ok) return e; }
+      is_state_mutated = false;
+    }
     double h = state.h;  // rk.start_step()
     if (std::fabs(h) < minimum_timestep) return OdeErr::StepSizeTooSmall;
     set_op_h(h);
@@ -388,6 +417,7 @@ struct Sdirk : SolverBase {
   }
 
   OdeErr interpolate_inplace(double t, V& ret) const override {  // runge_kutta.rs:1080-1127
+    if (is_state_mutated) { if (t != state.t) return OdeErr::InterpolationTimeOutsideCurrentStep; copy_from(ret, state.y); return OdeErr::Ok; }
     bool is_forward = state.h > 0.0;
     if ((is_forward && (t > state.t || t < old_state.t)) || (!is_forward && (t < state.t || t > old_state.t)))
       return OdeErr::InterpolationTimeOutsideCurrentStep;
@@ -445,6 +475,7 @@ struct Sdirk : SolverBase {
     return OdeErr::Ok;
   }
   OdeErr interpolate_dy_inplace(double t, V& dy) const override {  // runge_kutta.rs:1129-1181
+    if (is_state_mutated) { if (t != state.t) return OdeErr::InterpolationTimeOutsideCurrentStep; copy_from(dy, state.dy); return OdeErr::Ok; }
     bool is_forward = state.h > 0.0;
     if ((is_forward && (t > state.t || t < old_state.t)) || (!is_forward && (t < state.t || t > old_state.t)))
       return OdeErr::InterpolationTimeOutsideCurrentStep;

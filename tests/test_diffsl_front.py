@@ -98,9 +98,9 @@ def test_oracle_solves_the_diffsl_robertson_like_the_built_in_one(O, fe, kats):
     ("u_i { x = 1 } F_i { x ", "expected"),
     ("A_ij { (0,0): 1, (1,1): 2 } b_i { 1, 2 } u_i { x = 1, y = 1 } F_i { A_ij * u_j + b_i }", "does not appear in every term"),
     ("A_ij { (0,0): 1, (1,1): 2 } u_i { x = 1, y = 1 } F_i { A_i * u_i }", "has rank 2"),
-    # hybrid models must be refused, not silently integrated to the first root (crates/diffsol-c/tests/hybrid_logistic_jit.rs,
-    # examples/bouncing-ball-declarative use reset_i; the model index N)
-    ("in_i { r = 1 } u_i { y = 0.1 } dudt_i { dydt = 0 } F_i { (r * y) * (1 - y) } stop_i { y - 0.9 } reset_i { 0.1 } out_i { y }", "reset_i / hybrid models are not supported"),
+    # the model index N must be refused; reset_i (hybrid models) is compiled since round 2 — but has to match u_i
+    ("u_i { x = 1, y = 2 } F_i { x, y } stop_i { x - 2 } reset_i { 0.1 }", "reset_i has 1 components but u_i has 2"),
+    ("u_i { x = 1 } dudt_i { dxdt = 0 } F_i { x } stop_i { x - 2 } reset_i { dxdt }", "reset_i"),
     ("u_i { x = 1 } F_i { x * N }", "model index N is not supported"),
     ("N { 1 } u_i { x = 1 } F_i { x }", "model index N is reserved"),
     # M_i has to be LINEAR in dudt (the mass matrix is assembled from unit vectors)
@@ -302,3 +302,40 @@ def test_parameter_sensitivities_of_diffsl_models_reference_snapshot_and_finite_
         if k > 0:
             assert np.allclose(O.model_init_sens_mul(m, pv, v, 3), [0.4 * v[0], 2 * pv[1] * v[1], 0.0], rtol=1e-14, atol=0)
     assert O.model_sens_mul(D.host_model(O, "u_i { x = 1 }\nF_i { -x }\n"), [1.0], [0.0], [1.0]) is None
+
+
+def test_hybrid_models_reset_at_every_event_and_continue(O, fe):
+    """reset_i (the reference's hybrid models: crates/diffsol-c/tests/hybrid_logistic_jit.rs, examples/bouncing-ball-declarative): the state after an event of
+    stop_i.  solve_dense applies it at every root and keeps integrating to the last evaluation time (ode_solver/method.rs:774-797, state.rs:246-268), which
+    needs state_mut_back and the restart of the integrator from a modified state (bdf.rs:1290-1318, runge_kutta.rs:444-464) in the oracle.  The reference's
+    own reset problem (exponential_decay_with_reset_problem, exponential_decay.rs:827-861: dy/dt = -0.1 y, roots at y = 0.6 and y = 0.3, reset to 0.4) as
+    DiffSL text, checked the way test_solve_dense_with_reset (ode_solver/mod.rs:1302-1375) checks it — the evaluation time AT the event holds the pre-reset
+    state, the one 1e-6 later the reset state — and against the closed-form sawtooth over several periods, for BDF, TR-BDF2 and ESDIRK34."""
+    base = "in = [k]\nk { 0.1 }\nu_i { x = 1, y = 1 }\nF_i { -k * x, -k * y }\nstop_i { x - 0.6, x - 0.3 }\n"
+    hybrid = D.host_model(O, base + "reset_i { 0.4, 0.4 }\n")
+    plain = D.host_model(O, base)
+    src, dims, _ = fe.generate(base + "reset_i { 0.4, 0.4 }\n", fe.TARGET_HIP_STATIC)
+    assert "DSH_JIT_HAS_RESET" in src and "static void reset(" in src
+    assert "DSH_JIT_HAS_RESET" in fe.generate(base + "reset_i { 0.4, 0.4 }\n", fe.TARGET_HIP_DYNAMIC)[0]
+    assert "DSH_JIT_HAS_RESET" not in fe.generate(base, fe.TARGET_HIP_STATIC)[0]
+    p = np.array([[0.1]])
+    t0, per = -np.log(0.6) / 0.1, np.log(4.0 / 3.0) / 0.1
+
+    def saw(t):
+        return np.exp(-0.1 * t) if t <= t0 else 0.4 * np.exp(-0.1 * ((t - t0) % per))
+
+    for method in (O.METHOD_BDF, O.METHOD_TR_BDF2, O.METHOD_ESDIRK34):
+        kw = dict(rtol=1e-6, atol=[1e-6], method=method)
+        # without a reset operator the solve stops at the first root: its time is where the hybrid model resets first (same steps up to there)
+        _, _, failed = O.solve_dense_independent(plain, p, [0.0, 20.0], **kw)
+        t_event = float(O.solve_dense_independent.last_roots["t_root"][0])
+        assert failed == 0 and abs(t_event - t0) < 1e-4 and O.solve_dense_independent.last_roots["root_idx"][0] == 0
+        final = 2.0 * (t0 + per)
+        t_eval = [0.0, 2.0, t_event, t_event + 1e-6, 7.9, 8.0, 12.0, final]
+        y, st, failed = O.solve_dense_independent(hybrid, p, t_eval, **kw)
+        assert failed == 0 and O.solve_dense_independent.last_roots["ncols"][0] == len(t_eval)  # every evaluation time is filled: TstopReached
+        assert abs(y[0, 2, 0] - 0.6) < 2e-5 and abs(y[0, 3, 0] - 0.4 * np.exp(-1e-7)) < 2e-5  # pre-reset AT the event, reset state just after
+        ref = np.array([saw(t) for t in t_eval])
+        ref[2], ref[3] = 0.6, 0.4 * np.exp(-1e-7)  # the solver's event time is within 1e-4 of the analytic one: pin the two columns around it
+        assert np.abs(y[0, :, 0] - ref).max() < 5e-5 and np.array_equal(y[0, :, 0], y[0, :, 1])
+        assert st[0, 0] > 25  # steps of all segments are counted

@@ -339,3 +339,28 @@ def test_fast_forcing_terms_sin_cos_of_huge_arguments_are_the_same_bits_on_devic
     assert np.max(np.abs(dev[:, 0] - np.sin(w)) / np.spacing(np.abs(np.sin(w)))) <= 3.0
     assert np.max(np.abs(dev[:, 1] - np.cos(w)) / np.spacing(np.abs(np.cos(w)))) <= 3.0
     assert np.array_equal(dev[:, 2], -dev[:, 0])  # odd symmetry (the tan term only checks that tan of a huge argument is finite)
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_hybrid_diffsl_models_reset_at_every_event_on_the_device_like_the_oracle(H, O, fe, method):
+    """reset_i on the HIP backend: the model's reset operator is compiled into both device forms (dsh_model_reset), solve_dense of a hybrid model runs host-driven
+    (the device-resident kernels stop at an event), moves the state back to every root, applies the reset, restarts the integrator from the modified state and
+    continues to the last evaluation time — bit for bit the oracle integrating the generated host twin (the reference's reset test problem as DiffSL text;
+    single IVP and a lock-step batch of identical members, which must agree on every event), and the same again for a run-time-sized hybrid model."""
+    base = "in = [k]\nk { 0.1 }\nu_i { x = 1, y = 1 }\nF_i { -k * x, -k * y }\nstop_i { x - 0.6, x - 0.3 }\nreset_i { 0.4, 0.4 }\n"
+    big = ("in = [k]\nk { 0.1 }\nu_i { (0:10): x = 1 }\nF_i { -k * x_i }\nstop_i { x_i[0:1] - 0.6, x_i[0:1] - 0.3 }\nreset_i { (0:10): 0.4 }\n")
+    t_eval = [0.0, 2.0, 5.2, 7.9, 8.0, 12.0, 16.0]
+    hm, om = METHOD[method], {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    for code, n in ((base, 2), (big, 10)):
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        for nb in (1, 3):
+            p = np.full((nb, 1), 0.1)
+            s = H.Solver(m, p, nbatch=nb, method=hm, rtol=1e-6, atol=[1e-6])
+            assert s.ensemble_mode()[1] == 0  # hybrid models resolve to the host-driven path
+            y, reason = s.solve_dense(t_eval)  # [nt, nbatch, n]
+            yo, so, failed = O.solve_dense_independent(mid, p, t_eval, group=nb, method=om, rtol=1e-6, atol=[1e-6])
+            assert failed == 0 and reason == 2  # TstopReached: every evaluation time is filled
+            assert np.array_equal(np.transpose(y, (1, 0, 2)), yo)
+            t0, per = -np.log(0.6) / 0.1, np.log(4.0 / 3.0) / 0.1  # closed-form sawtooth: decay to 0.6, then 0.4 -> 0.3 periods
+            assert abs(yo[0, -1, 0] - 0.4 * np.exp(-0.1 * ((t_eval[-1] - t0) % per))) < 1e-4 and yo.shape[2] == n
+            assert s.stats()["number_of_steps"] == so[0, 0]
