@@ -31,6 +31,10 @@ C_ABI = {
     "diffsol_ode_y0": (_i32, [_vp, _dp, _sz, C.POINTER(_vp)]), "diffsol_ode_rhs": (_i32, [_vp, _dp, _sz, _dbl, _dp, _sz, C.POINTER(_vp)]),
     "diffsol_ode_rhs_jac_mul": (_i32, [_vp, _dp, _sz, _dbl, _dp, _sz, _dp, _sz, C.POINTER(_vp)]),
     "diffsol_ode_solve": (_i32, [_vp, _dp, _sz, _dbl, C.POINTER(_vp)]), "diffsol_ode_solve_dense": (_i32, [_vp, _dp, _sz, _dp, _sz, C.POINTER(_vp)]),
+    "diffsol_ode_solve_fwd_sens": (_i32, [_vp, _dp, _sz, _dp, _sz, C.POINTER(_vp)]),
+    "diffsol_ode_get_sens_rtol": (_i32, [_vp, C.POINTER(_i32), _dp]), "diffsol_ode_set_sens_rtol": (_i32, [_vp, _i32, _dbl]),
+    "diffsol_ode_get_sens_atol": (_i32, [_vp, C.POINTER(_i32), _dp]), "diffsol_ode_set_sens_atol": (_i32, [_vp, _i32, _dbl]),
+    "diffsol_solution_wrapper_get_sens": (_i32, [_vp, C.POINTER(C.POINTER(_vp)), C.POINTER(_sz)]), "diffsol_host_array_list_free": (None, [C.POINTER(_vp), _sz]),
     "diffsol_ode_get_matrix_type": (_i32, [_vp]), "diffsol_ode_get_ode_solver": (_i32, [_vp]), "diffsol_ode_set_ode_solver": (_i32, [_vp, _i32]),
     "diffsol_ode_get_linear_solver": (_i32, [_vp]), "diffsol_ode_set_linear_solver": (_i32, [_vp, _i32]),
     "diffsol_ode_get_ensemble_mode": (_i32, [_vp]), "diffsol_ode_set_ensemble_mode": (_i32, [_vp, _i32]),
@@ -130,6 +134,17 @@ class Solution:
     def ts(self):
         return self._array(lib().diffsol_solution_wrapper_get_ts)
 
+    @property
+    def sens(self):
+        """diffsol_solution_wrapper_get_sens: one array per parameter, shaped like ys (empty list unless the solution comes from solve_fwd_sens)."""
+        L = lib()
+        lst, n = C.POINTER(_vp)(), _sz()
+        _check(L.diffsol_solution_wrapper_get_sens(self._h, C.byref(lst), C.byref(n)))
+        out = [_to_numpy(_vp(lst[j])) for j in range(n.value)]
+        if n.value:
+            L.diffsol_host_array_list_free(lst, n.value)
+        return out
+
     def member_info(self):
         L = lib()
         nb = L.diffsol_solution_wrapper_get_member_info(self._h, None, None, None, None)
@@ -201,6 +216,24 @@ class Ode:
         out = _vp()
         _check(lib().diffsol_ode_solve_dense(self._h, pp, n, tp, tn, C.byref(out)))
         return Solution(out)
+
+    def solve_fwd_sens(self, params, t_eval):
+        """diffsol_ode_solve_fwd_sens: states and forward sensitivities at t_eval (Solution.ys, Solution.sens)."""
+        p, pp, n = self._p(params)
+        te, tp, tn = self._p(t_eval)
+        out = _vp()
+        _check(lib().diffsol_ode_solve_fwd_sens(self._h, pp, n, tp, tn, C.byref(out)))
+        return Solution(out)
+
+    def _opt_get(self, fn):
+        some, val = _i32(), _dbl()
+        _check(fn(self._h, C.byref(some), C.byref(val)))
+        return val.value if some.value else None
+
+    sens_rtol = property(lambda self: self._opt_get(lib().diffsol_ode_get_sens_rtol),
+                         lambda self, v: _check(lib().diffsol_ode_set_sens_rtol(self._h, 0 if v is None else 1, 0.0 if v is None else float(v))))
+    sens_atol = property(lambda self: self._opt_get(lib().diffsol_ode_get_sens_atol),
+                         lambda self, v: _check(lib().diffsol_ode_set_sens_atol(self._h, 0 if v is None else 1, 0.0 if v is None else float(v))))
 
     def set_atol_vector(self, atol):
         a, ap, n = self._p(atol)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -14,6 +15,8 @@
 #include "../../include/diffsol_hip.h"
 #include "../../include/diffsol_hip_solver.h"
 #include "hip_la.hpp"
+#include "diffsl.hpp"
+#include <optional>
 
 using namespace diffsol_hip;
 
@@ -54,6 +57,8 @@ struct diffsol_ode_wrapper {
   int32_t linear_solver = DIFFSOL_LINEAR_SOLVER_DEFAULT, ode_solver = DIFFSOL_ODE_SOLVER_BDF, ensemble_mode = DIFFSOL_ENSEMBLE_AUTO;
   double rtol = 1e-6, t0 = 0.0, h0 = 1.0;
   std::vector<double> atol{1e-6};
+  std::optional<double> sens_rtol, sens_atol;  // None: the sensitivities stay out of the error control (ode.rs get/set_sens_rtol / _atol)
+  bool out_is_state = false;                   // out_i { u_i }: the outputs are the states
   std::shared_ptr<Settings> settings;
   ~diffsol_ode_wrapper() {
     if (model >= 0) dsh_model_release(model);
@@ -62,6 +67,7 @@ struct diffsol_ode_wrapper {
 };
 struct diffsol_solution_wrapper {
   int64_t nrows = 0, ncols = 0, nb = 1;
+  std::vector<std::vector<double>> sens;  // per parameter: [col][row][b] like ys (solve_fwd_sens only)
   std::vector<double> ys;  // [col][row][b]
   std::vector<double> ts;
   std::vector<int32_t> status, root_index, member_cols;
@@ -288,6 +294,14 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
   ode->model = id;
   dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
+  try {  // out_i { u_i } (the outputs are the states, component by component): solve_fwd_sens then needs no output derivatives
+    const diffsl::Compiled c = diffsl::compile(code);
+    ode->out_is_state = (int64_t)c.out.size() == ode->n;
+    for (size_t i = 0; i < c.out.size() && ode->out_is_state; ++i) {
+      const diffsl::Node& nd = c.g.at(c.out[i]);
+      ode->out_is_state = nd.k == diffsl::NK::State && nd.i == (int)i;
+    }
+  } catch (...) { ode->out_is_state = false; }
   // banded run-time-sized model: the same text once more in the lane-per-member form, which per-member / wavefront device-resident solves run on
   if (!is_static && ode->n <= 64 && !ode->has_mass && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4 &&
       dshs_diffsl_generate(code, DSHS_DIFFSL_HIP_STATIC, &src, nullptr, nullptr, 0) == 0) {
@@ -404,6 +418,92 @@ int32_t diffsol_ode_solve_dense(OdeWrapper* ode, const double* params_ptr, size_
   return DIFFSOL_OK;
 }
 
+// ode_c.rs:586-617 over ode.rs:514-528 over OdeSolverMethod::solve_dense_sensitivities (ode_solver/sensitivities.rs:114-261): the states (outputs) and the
+// forward sensitivities d(out)/dp_j at t_eval, one parameter set or a lock-step batch of them.  BDF / TR-BDF2 / ESDIRK34, ODEs and DAEs; host-driven over the
+// device operators (the resident kernels integrate the state equations only).  Limits of this backend: out_i other than the states themselves, stop
+// conditions that fire, and reset_i are refused here.
+int32_t diffsol_ode_solve_fwd_sens(OdeWrapper* ode, const double* params_ptr, size_t params_len, const double* t_eval_ptr, size_t t_eval_len,
+                                   SolutionWrapper** out_solution) {
+  if (!ode || !out_solution || (!params_ptr && params_len) || (!t_eval_ptr && t_eval_len)) return C_INVALID_ARG("invalid arguments to diffsol_ode_solve_fwd_sens");
+  if (t_eval_len == 0) return C_ERROR("t_eval must not be empty");
+  if (ode->no_inputs) return C_ERROR("the model has no inputs: nothing to differentiate with respect to");
+  if (ode->nout != 0 && !ode->out_is_state) return C_ERROR("solve_fwd_sens with an out_i other than the states is not supported by the HIP backend (omit out_i or use out_i { u_i })");
+  for (size_t k = 0; k + 1 < t_eval_len; ++k) if (t_eval_ptr[k] > t_eval_ptr[k + 1]) return C_ERROR("t_eval must be increasing");
+  if (t_eval_ptr[0] < ode->t0) return C_ERROR("t_eval must not start before t0");
+  const int64_t nb = batch_of(ode, params_len);
+  if (nb < 1) return C_ERROR("expected " + std::to_string(ode->np) + " parameters per member, got " + std::to_string(params_len));
+  const int method = method_of(ode->ode_solver);
+  if (method < 0) return C_ERROR("ode solver type is not available in the HIP backend");
+  SolverGuard g;
+  const double sa = ode->sens_atol.value_or(0.0);
+  // with either tolerance missing the sensitivities stay out of the error control (builder.rs:1501-1505 / sens_equations.rs:283-285)
+  const bool ec = ode->sens_rtol.has_value() && ode->sens_atol.has_value();
+  if (dshs_create_sens(0, nullptr, ode->model, 0, nb, params_ptr, (int64_t)params_len, ode->rtol, ode->atol.data(), (int64_t)ode->atol.size(), ode->t0, ode->h0, method,
+                       &ode->settings->o, 1, ode->sens_rtol.value_or(0.0), &sa, ec ? 1 : 0, &g.s) != 0)
+    return C_ERROR(std::string(dshs_last_error()));
+  auto sol = std::make_unique<diffsol_solution_wrapper>();
+  const int64_t nt = (int64_t)t_eval_len, n = ode->n, np = ode->np;
+  sol->nb = nb; sol->nrows = n; sol->ncols = nt;
+  sol->ys.resize((size_t)(nt * nb * n));
+  sol->sens.assign((size_t)np, std::vector<double>((size_t)(nt * nb * n)));
+  sol->ts.assign(t_eval_ptr, t_eval_ptr + nt);
+  sol->status.assign((size_t)nb, 0);
+  sol->t_root.assign((size_t)nb, std::numeric_limits<double>::quiet_NaN());
+  sol->root_index.assign((size_t)nb, -1);
+  sol->member_cols.assign((size_t)nb, (int32_t)nt);
+  std::vector<double> ybuf((size_t)(nb * n)), sbuf((size_t)(np * nb * n));
+  int64_t col = 0;
+  auto drain = [&](double upto) -> bool {
+    while (col < nt && t_eval_ptr[col] <= upto) {
+      if (dshs_interpolate(g.s, t_eval_ptr[col], ybuf.data()) != 0 || dshs_interpolate_sens(g.s, t_eval_ptr[col], sbuf.data()) != 0) return false;
+      // host buffers are [b][i]; the wrapper stores [col][i][b]
+      for (int64_t b = 0; b < nb; ++b)
+        for (int64_t i = 0; i < n; ++i) {
+          sol->ys[(size_t)((col * n + i) * nb + b)] = ybuf[(size_t)(b * n + i)];
+          for (int64_t j = 0; j < np; ++j) sol->sens[(size_t)j][(size_t)((col * n + i) * nb + b)] = sbuf[(size_t)((j * nb + b) * n + i)];
+        }
+      ++col;
+    }
+    return true;
+  };
+  double t_now = ode->t0, h_now = 0.0;
+  int order_now = 0;
+  if (!drain(t_now)) return C_ERROR(std::string(dshs_last_error()));
+  if (col < nt) {
+    if (dshs_set_stop_time(g.s, t_eval_ptr[nt - 1]) != 0) return C_ERROR(std::string(dshs_last_error()));
+    while (true) {
+      int reason = 0;
+      if (dshs_step(g.s, &reason) != 0) return C_ERROR(std::string(dshs_last_error()));
+      if (reason == DSHS_STOP_ROOT_FOUND) return C_ERROR("solve_fwd_sens: a stop condition fired; events with forward sensitivities are not supported by the HIP backend");
+      dshs_get_state(g.s, &t_now, &h_now, &order_now, nullptr, nullptr);
+      if (!drain(t_now)) return C_ERROR(std::string(dshs_last_error()));
+      if (reason == DSHS_STOP_TSTOP_REACHED) break;
+    }
+  }
+  *out_solution = sol.release();
+  return DIFFSOL_OK;
+}
+int32_t diffsol_ode_get_sens_rtol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value) {
+  if (!ode || !out_is_some || !out_value) return C_INVALID_ARG("invalid arguments to diffsol_ode_get_sens_rtol");
+  *out_is_some = ode->sens_rtol.has_value() ? 1 : 0; *out_value = ode->sens_rtol.value_or(0.0);
+  return DIFFSOL_OK;
+}
+int32_t diffsol_ode_set_sens_rtol(OdeWrapper* ode, int32_t value_is_some, double value) {
+  if (!ode) return C_INVALID_ARG("ode is null");
+  if (value_is_some) ode->sens_rtol = value; else ode->sens_rtol.reset();
+  return DIFFSOL_OK;
+}
+int32_t diffsol_ode_get_sens_atol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value) {
+  if (!ode || !out_is_some || !out_value) return C_INVALID_ARG("invalid arguments to diffsol_ode_get_sens_atol");
+  *out_is_some = ode->sens_atol.has_value() ? 1 : 0; *out_value = ode->sens_atol.value_or(0.0);
+  return DIFFSOL_OK;
+}
+int32_t diffsol_ode_set_sens_atol(OdeWrapper* ode, int32_t value_is_some, double value) {
+  if (!ode) return C_INVALID_ARG("ode is null");
+  if (value_is_some) ode->sens_atol = value; else ode->sens_atol.reset();
+  return DIFFSOL_OK;
+}
+
 int32_t diffsol_ode_get_matrix_type(const OdeWrapper* ode) { if (!ode) { C_INVALID_ARG("ode is null"); return -1; } return DIFFSOL_MATRIX_HIP_DENSE; }
 int32_t diffsol_ode_get_ode_solver(const OdeWrapper* ode) { if (!ode) { C_INVALID_ARG("ode is null"); return -1; } return ode->ode_solver; }
 int32_t diffsol_ode_set_ode_solver(OdeWrapper* ode, int32_t value) {
@@ -504,6 +604,28 @@ int32_t diffsol_solution_wrapper_get_ts(const SolutionWrapper* solution, HostArr
   if (!solution || !out_array) return C_INVALID_ARG("invalid arguments to diffsol_solution_wrapper_get_ts");
   *out_array = vector_array(std::vector<double>(solution->ts));
   return DIFFSOL_OK;
+}
+// solution_wrapper_c.rs:101-125: one array per parameter, shaped like ys; the list (not the arrays) is released with diffsol_host_array_list_free (ode_c.rs:163-171)
+int32_t diffsol_solution_wrapper_get_sens(const SolutionWrapper* solution, HostArray*** out_sens, size_t* out_sens_len) {
+  if (!solution || !out_sens || !out_sens_len) return C_INVALID_ARG("invalid arguments to diffsol_solution_wrapper_get_sens");
+  const size_t np = solution->sens.size();
+  HostArray** list = np ? (HostArray**)std::malloc(np * sizeof(HostArray*)) : nullptr;
+  const size_t nb = (size_t)solution->nb, nr = (size_t)solution->nrows, nc = (size_t)solution->ncols, e = sizeof(double);
+  for (size_t j = 0; j < np; ++j) {
+    auto* a = new diffsol_host_array();
+    a->data = solution->sens[j];
+    if (nb == 1) { a->shape = {nr, nc}; a->strides = {e, e * nr}; }
+    else { a->shape = {nr, nc, nb}; a->strides = {e * nb, e * nb * nr, e}; }
+    list[j] = a;
+  }
+  *out_sens = list;
+  *out_sens_len = np;
+  return DIFFSOL_OK;
+}
+void diffsol_host_array_list_free(HostArray** list, size_t len) {  // ode_c.rs:163-171: the list only — its arrays are freed one by one
+  (void)len;
+  if (!list) { C_INVALID_ARG("host array list is null"); return; }
+  std::free(list);
 }
 int64_t diffsol_solution_wrapper_get_member_info(const SolutionWrapper* solution, int32_t* status, double* t_root, int32_t* root_index, int32_t* ncols) {
   if (!solution) { C_INVALID_ARG("solution wrapper is null"); return -1; }

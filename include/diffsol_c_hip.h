@@ -125,6 +125,14 @@ int32_t diffsol_ode_rhs_jac_mul(OdeWrapper* ode, const double* params_ptr, size_
 int32_t diffsol_ode_solve(OdeWrapper* ode, const double* params_ptr, size_t params_len, double final_time, SolutionWrapper** out_solution);
 int32_t diffsol_ode_solve_dense(OdeWrapper* ode, const double* params_ptr, size_t params_len, const double* t_eval_ptr, size_t t_eval_len,
                                 SolutionWrapper** out_solution);
+/* ode_c.rs:586-617: states and forward sensitivities at t_eval (OdeSolverMethod::solve_dense_sensitivities); the sensitivities come back through
+ * diffsol_solution_wrapper_get_sens.  sens_rtol / sens_atol (ode_c.rs:949-1040) put them into the error control when both are set. */
+int32_t diffsol_ode_solve_fwd_sens(OdeWrapper* ode, const double* params_ptr, size_t params_len, const double* t_eval_ptr, size_t t_eval_len,
+                                   SolutionWrapper** out_solution);
+int32_t diffsol_ode_get_sens_rtol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_sens_rtol(OdeWrapper* ode, int32_t value_is_some, double value);
+int32_t diffsol_ode_get_sens_atol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_sens_atol(OdeWrapper* ode, int32_t value_is_some, double value);
 int32_t diffsol_ode_get_matrix_type(const OdeWrapper* ode);
 int32_t diffsol_ode_get_ode_solver(const OdeWrapper* ode);
 int32_t diffsol_ode_set_ode_solver(OdeWrapper* ode, int32_t value);
@@ -169,6 +177,10 @@ DIFFSOL_DECLARE_OPTION(diffsol_ic_options, InitialConditionSolverOptions, double
 void diffsol_solution_wrapper_free(SolutionWrapper* solution);
 int32_t diffsol_solution_wrapper_get_ys(const SolutionWrapper* solution, HostArray** out_array);
 int32_t diffsol_solution_wrapper_get_ts(const SolutionWrapper* solution, HostArray** out_array);
+/* solution_wrapper_c.rs:101-125: one HostArray per parameter, shaped like ys; free every array with diffsol_host_array_free and the list with
+ * diffsol_host_array_list_free (ode_c.rs:163-171) */
+int32_t diffsol_solution_wrapper_get_sens(const SolutionWrapper* solution, HostArray*** out_sens, size_t* out_sens_len);
+void diffsol_host_array_list_free(HostArray** list, size_t len);
 /* addition of this backend: per-member outcome of an ensemble solve.  status (0 ok, else OdeSolverError ordinal), t_root (NaN if the member hit no
  * stop condition), root_index (-1), ncols (valid output columns); each array has nbatch entries and may be NULL.  Returns nbatch. */
 int64_t diffsol_solution_wrapper_get_member_info(const SolutionWrapper* solution, int32_t* status, double* t_root, int32_t* root_index, int32_t* ncols);

@@ -152,3 +152,42 @@ def test_banded_diffsl_models_run_their_lane_per_member_form_through_the_c_api(c
     b = int(np.argmax(info["root_index"] >= 0))
     c = info["ncols"][b] - 1  # the column holding the state at the member's own cut-off: the voltage there is the cut-off voltage
     assert abs(ys[0, c, b] - (3.105 if info["root_index"][b] == 0 else 4.1)) < 1e-6 and np.isnan(ys[0, c + 1:, b]).all()
+
+
+def test_forward_sensitivities_through_the_c_api(capi, O):
+    """diffsol_ode_solve_fwd_sens / diffsol_ode_[gs]et_sens_[ra]tol / diffsol_solution_wrapper_get_sens (ode_c.rs:586-617, :949-1040, solution_wrapper_c.rs:101-125):
+    the reference's DiffSL sensitivity problem through the C API — states and d(state)/dp at t_eval for one parameter set (2-D arrays as in the reference) and for
+    an ensemble (batch axis last), BDF and TR-BDF2, equal to the oracle integrating the generated host twin bit for bit and to the closed forms; optional
+    tolerances round-trip; the limits of this backend are refused with a message."""
+    code = "in_i { k = 0.1, y0 = 1.0 }\nu_i { x = y0, y = y0 }\nF_i { -k * u_i }\nout_i { u_i }\n"
+    ode = capi.Ode(code)
+    mid = D.host_model(O, code)
+    assert ode.sens_rtol is None and ode.sens_atol is None
+    ode.sens_rtol, ode.sens_atol = 1e-6, 1e-6
+    assert ode.sens_rtol == 1e-6 and ode.sens_atol == 1e-6
+    t_eval = [0.0, 1.0, 2.5, 9.0]
+    sol = ode.solve_fwd_sens([0.1, 1.0], t_eval)
+    ys, sens = sol.ys, sol.sens
+    assert ys.shape == (2, 4) and len(sens) == 2 and sens[0].shape == (2, 4) and np.array_equal(sol.ts, t_eval)
+    t = np.array(t_eval)
+    assert np.abs(ys[0] - np.exp(-0.1 * t)).max() < 1e-5 and np.abs(sens[0][0] + t * np.exp(-0.1 * t)).max() < 1e-4 and np.abs(sens[1][1] - np.exp(-0.1 * t)).max() < 1e-5
+    o = O.OracleSolver(mid, [0.1, 1.0], rtol=1e-6, atol=[1e-6], sens=True, sens_rtol=1e-6, sens_atol=[1e-6])
+    o.set_stop_time(t_eval[-1])  # solve_dense_sensitivities sets the stop time first (sensitivities.rs:221)
+    for k, te in enumerate(t_eval):
+        while o.state()["t"] < te:
+            o.step()
+        assert np.array_equal(o.interpolate(te)[0], ys[:, k]) and np.array_equal(o.interpolate_sens(te)[:, 0, :], np.stack([sens[0][:, k], sens[1][:, k]]))
+    # ensemble + another method, sensitivities out of the error control
+    ode.sens_rtol = None
+    ode.ode_solver = capi.ODE_SOLVER_TR_BDF2
+    p = np.array([[0.1, 1.0], [0.3, 2.0], [0.05, 0.5]])
+    sol = ode.solve_fwd_sens(p.reshape(-1), t_eval)
+    ys, sens = sol.ys, sol.sens
+    assert ys.shape == (2, 4, 3) and sens[1].shape == (2, 4, 3)
+    for b in range(3):
+        assert np.abs(ys[0, :, b] - p[b, 1] * np.exp(-p[b, 0] * t)).max() < 1e-4
+        assert np.abs(sens[0][0, :, b] + p[b, 1] * t * np.exp(-p[b, 0] * t)).max() < 2e-3 and np.abs(sens[1][0, :, b] - np.exp(-p[b, 0] * t)).max() < 1e-3
+    with pytest.raises(capi.DiffsolCError, match="out_i"):
+        capi.Ode("in = [k]\nu_i { x = 1 }\nF_i { -k * x }\nout_i { 2 * x }\n").solve_fwd_sens([0.1], [1.0])
+    with pytest.raises(capi.DiffsolCError, match="no inputs"):
+        capi.Ode("u_i { x = 1 }\nF_i { -x }\n").solve_fwd_sens([], [1.0])
