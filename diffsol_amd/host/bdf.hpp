@@ -493,14 +493,19 @@ class Bdf : public OdeSolverMethod {
     }
   }
   void apply_reset() override {
-    if (pr_.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with a mass matrix (apply_reset_with_mass) is not supported by the HIP backend");
     if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with forward sensitivities is not supported by the HIP backend");
     HipVec y_out = HipVec::zeros(n(), ctx());
     pr_.eqn->reset_call_inplace(y_, t_, y_out);
     y_.copy_from(y_out);
+    is_state_modified_ = true;  // already set by state_mut_back (bdf.rs:1260)
+    if (pr_.eqn->has_mass()) {  // state.rs:297-300
+      StateCommon sc; sc.y = std::move(y_); sc.dy = std::move(dy_); sc.t = t_; sc.h = h_;
+      try { set_consistent(sc, pr_, true); } catch (...) { y_ = std::move(sc.y); dy_ = std::move(sc.dy); throw; }
+      y_ = std::move(sc.y); dy_ = std::move(sc.dy);
+      return;
+    }
     pr_.eqn->rhs_call_inplace(y_, t_, y_out);
     dy_.copy_from(y_out);
-    is_state_modified_ = true;  // state_mut()
   }
   // state_mut_back (bdf.rs:1232-1262): move the state to an interpolated time inside the last step
   void state_mut_back(double t) override {

@@ -367,8 +367,8 @@ inline StateCommon new_without_initialise(const OdeSolverProblem& pr) {
   return s;
 }
 
-// state.rs:84-162
-inline void set_consistent(StateCommon& s, const OdeSolverProblem& pr) {
+// state.rs:84-162.  no_linesearch: the root solver apply_reset_with_mass builds (state.rs:299: NewtonNonlinearSolver::new(LS::default(), NoLineSearch))
+inline void set_consistent(StateCommon& s, const OdeSolverProblem& pr, bool no_linesearch = false) {
   const OdeEquations& eqn = *pr.eqn;
   if (!eqn.has_mass()) return;
   const int64_t n = eqn.nstates();
@@ -388,7 +388,7 @@ inline void set_consistent(StateCommon& s, const OdeSolverProblem& pr) {
   Convergence conv(pr.rtol, &pr.atol, pr.ode_options.nonlinear_solver_tolerance);
   conv.set_max_iter(pr.ic_options.max_newton_iterations);
   std::unique_ptr<LineSearch> ls;
-  if (pr.ic_options.use_linesearch) {
+  if (pr.ic_options.use_linesearch && !no_linesearch) {
     auto b = std::make_unique<BacktrackingLineSearch>();
     b->c = pr.ic_options.armijo_constant; b->max_iter = pr.ic_options.max_linesearch_iterations; b->tau = pr.ic_options.step_reduction_factor;
     ls = std::move(b);
@@ -567,7 +567,8 @@ class OdeSolverMethod {
   virtual const OdeSolverStatistics& get_statistics() const = 0;
   virtual const OdeSolverProblem& problem() const = 0;
   virtual void state_mut_back(double t) = 0;
-  // OdeSolverMethod::apply_reset (method.rs:175-181) over StateRefMut::apply_reset (state.rs:246-268): y <- reset(y, t), dy <- f(y, t), state marked as modified
+  // Bdf / Sdirk::apply_reset (bdf.rs:1017-1020, sdirk.rs:368-374) over StateRefMut::apply_reset_with_mass (state.rs:279-306): y <- reset(y, t), then dy <- f(y, t)
+  // or, with a mass matrix, set_consistent with a Newton solver without line search; state marked as modified
   virtual void apply_reset() = 0;
   double root_time = 0.0;
   int root_index = -1;

@@ -383,11 +383,12 @@ class Sdirk : public OdeSolverMethod {
     }
   }
   void apply_reset() override {
-    if (pr_.eqn->has_mass()) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with a mass matrix (apply_reset_with_mass) is not supported by the HIP backend");
     if (pr_.sens) throw LaError(DSH_E_UNSUPPORTED, "apply_reset with forward sensitivities is not supported by the HIP backend");
     HipVec y_out = HipVec::zeros(state_.y.len(), pr_.context());
     pr_.eqn->reset_call_inplace(state_.y, state_.t, y_out);
     state_.y.copy_from(y_out);
+    is_state_mutated_ = true;  // state_mut()
+    if (pr_.eqn->has_mass()) { set_consistent(state_, pr_, true); return; }  // state.rs:297-300
     pr_.eqn->rhs_call_inplace(state_.y, state_.t, y_out);
     state_.dy.copy_from(y_out);
     is_state_mutated_ = true;  // state_mut()

@@ -268,7 +268,8 @@ inline StateCommon new_without_initialise(const Problem& pr) {
 }
 
 // state.rs:84-162
-inline OdeErr set_consistent(StateCommon& s, const Problem& pr, Stats* /*unused*/ = nullptr) {
+// no_linesearch: the root solver apply_reset_with_mass builds (state.rs:299: NewtonNonlinearSolver::new(LS::default(), NoLineSearch)), whatever ic_options say
+inline OdeErr set_consistent(StateCommon& s, const Problem& pr, bool no_linesearch = false) {
   const Eqn& eqn = *pr.eqn;
   if (!eqn.has_mass()) return OdeErr::Ok;
   int n = pr.n(), nb = pr.nb();
@@ -286,7 +287,7 @@ inline OdeErr set_consistent(StateCommon& s, const Problem& pr, Stats* /*unused*
   Convergence conv(pr.rtol, &pr.atol, pr.ode_options.nonlinear_solver_tolerance);
   conv.max_iter = pr.ic_options.max_newton_iterations;
   std::unique_ptr<LineSearch> ls;
-  if (pr.ic_options.use_linesearch) {
+  if (pr.ic_options.use_linesearch && !no_linesearch) {
     auto b = std::make_unique<BacktrackingLineSearch>();
     b->c = pr.ic_options.armijo_constant; b->max_iter = pr.ic_options.max_linesearch_iterations; b->tau = pr.ic_options.step_reduction_factor;
     ls = std::move(b);
@@ -474,7 +475,8 @@ struct SolverBase {
   virtual const Problem& problem() const = 0;
   // state_mut_back (bdf.rs:1232-1262, runge_kutta.rs:396-434): move the state to an interpolated time inside the last step; the next step restarts from it
   virtual OdeErr state_mut_back(double t) = 0;
-  // OdeSolverMethod::apply_reset (method.rs:175-181) over StateRefMut::apply_reset (state.rs:246-268): y <- reset(y, t), dy <- f(y, t); no mass matrices
+  // Bdf / Sdirk::apply_reset (bdf.rs:1017-1020, sdirk.rs:368-374) over StateRefMut::apply_reset_with_mass (state.rs:279-306): y <- reset(y, t), then
+  // dy <- f(y, t), or set_consistent when there is a mass matrix
   virtual OdeErr apply_reset() = 0;
   double root_time = 0.0;
   int root_index = -1;
@@ -777,13 +779,19 @@ struct Bdf : SolverBase {
     return OdeErr::Ok;
   }
   OdeErr apply_reset() override {
-    if (!pr->eqn->model->has_reset || pr->eqn->has_mass()) return OdeErr::InterpolationTimeOutsideCurrentStep;
+    if (!pr->eqn->model->has_reset) return OdeErr::InterpolationTimeOutsideCurrentStep;
     V y_out(pr->n(), pr->nb());
     pr->eqn->reset(y_, t_, y_out);
     copy_from(y_, y_out);
+    is_state_modified = true;  // already set by state_mut_back (bdf.rs:1260)
+    if (pr->eqn->has_mass()) {  // apply_reset_with_mass (state.rs:279-306, bdf.rs:1017-1020): consistent (y, dy) by a Newton solve on InitOp, no line search
+      StateCommon sc; sc.y = std::move(y_); sc.dy = std::move(dy_); sc.t = t_; sc.h = h_;
+      OdeErr e = set_consistent(sc, *pr, true);
+      y_ = std::move(sc.y); dy_ = std::move(sc.dy);
+      return e;
+    }
     pr->eqn->rhs(y_, t_, y_out);
     copy_from(dy_, y_out);
-    is_state_modified = true;  // state_mut()
     return OdeErr::Ok;
   }
   OdeErr step(StopReason& reason) override {  // :1277-1589

@@ -300,11 +300,13 @@ struct Sdirk : SolverBase {
     is_state_mutated = true;
     return OdeErr::Ok;
   }
-  OdeErr apply_reset() override {  // state.rs:246-268 through state_mut()
-    if (!pr->eqn->model->has_reset || pr->eqn->has_mass()) return OdeErr::InterpolationTimeOutsideCurrentStep;
+  OdeErr apply_reset() override {  // sdirk.rs:368-374 over state.rs:279-306, through state_mut()
+    if (!pr->eqn->model->has_reset) return OdeErr::InterpolationTimeOutsideCurrentStep;
     V y_out(state.y.n, state.y.nb);
     pr->eqn->reset(state.y, state.t, y_out);
     copy_from(state.y, y_out);
+    is_state_mutated = true;
+    if (pr->eqn->has_mass()) return set_consistent(state, *pr, true);  // apply_reset_with_mass (state.rs:297-300)
     pr->eqn->rhs(state.y, state.t, y_out);
     copy_from(state.dy, y_out);
     is_state_mutated = true;

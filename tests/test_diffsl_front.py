@@ -339,3 +339,28 @@ def test_hybrid_models_reset_at_every_event_and_continue(O, fe):
         ref[2], ref[3] = 0.6, 0.4 * np.exp(-1e-7)  # the solver's event time is within 1e-4 of the analytic one: pin the two columns around it
         assert np.abs(y[0, :, 0] - ref).max() < 5e-5 and np.array_equal(y[0, :, 0], y[0, :, 1])
         assert st[0, 0] > 25  # steps of all segments are counted
+
+
+def test_hybrid_dae_models_are_made_consistent_after_every_reset(O, fe):
+    """apply_reset_with_mass (ode_solver/state.rs:279-306, called by Bdf / Sdirk::apply_reset, bdf.rs:1017-1020, sdirk.rs:368-374): with a mass matrix the reset
+    state is made consistent by the same Newton solve on InitOp as at t0 — but without line search — instead of dy <- f(y).  The reference's reset problem with
+    an algebraic companion z^2 = 4 x^2 that reset_i puts NEAR the constraint (0.81 for 0.8: InitOp's Jacobian is frozen at the reset state, and the
+    convergence test's predicted-rate check refuses a slow chord iteration — reset_i { 0.4, z }, a jump from 1.2, fails with InitialConditionDidNotConverge,
+    as it does in the reference): after every event z must be back on the constraint, and the differential component must follow the ODE's sawtooth."""
+    code = ("in = [k]\nk { 0.1 }\nu_i { x = 1, z = 2 }\ndudt_i { dxdt = 0, dzdt = 0 }\nM_i { dxdt, 0 }\nF_i { -k * x, z * z - 4 * x * x }\n"
+            "stop_i { x - 0.6, x - 0.3 }\nreset_i { 0.4, 0.81 }\n")
+    m = D.host_model(O, code)
+    p = np.array([[0.1]])
+    t0, per = -np.log(0.6) / 0.1, np.log(4.0 / 3.0) / 0.1
+    for method in (O.METHOD_BDF, O.METHOD_TR_BDF2, O.METHOD_ESDIRK34):
+        t_eval = [0.0, 2.0, t0 + 0.01, 7.9, 8.0, 12.0, 16.0]
+        y, st, failed = O.solve_dense_independent(m, p, t_eval, rtol=1e-6, atol=[1e-6], method=method)
+        assert failed == 0 and O.solve_dense_independent.last_roots["ncols"][0] == len(t_eval)
+        ref = np.array([np.exp(-0.1 * t) if t <= t0 else 0.4 * np.exp(-0.1 * ((t - t0) % per)) for t in t_eval])
+        assert np.abs(y[0, :, 0] - ref).max() < 5e-5
+        # z = 2 x: 1.2 at the first event, 0.8 right after it (not the 0.81 of reset_i).  The Hermite interpolant of ESDIRK34 in the first step after a reset
+        # is built on dz/dt = 0, which set_consistent leaves on the algebraic components (state.rs:158-160): 5e-4 off at 0.01 after the event
+        assert np.abs(y[0, :, 1] - 2.0 * ref).max() < 1e-3 and np.abs(y[0, [1, 3, 5, 6], 1] - 2.0 * ref[[1, 3, 5, 6]]).max() < 5e-5
+    far = D.host_model(O, code.replace("0.81", "z"))
+    assert O.solve_dense_independent(far, p, [0.0, 2.0, 8.0], rtol=1e-6, atol=[1e-6], method=O.METHOD_BDF)[2] == 1
+

@@ -364,3 +364,14 @@ def test_hybrid_diffsl_models_reset_at_every_event_on_the_device_like_the_oracle
             t0, per = -np.log(0.6) / 0.1, np.log(4.0 / 3.0) / 0.1  # closed-form sawtooth: decay to 0.6, then 0.4 -> 0.3 periods
             assert abs(yo[0, -1, 0] - 0.4 * np.exp(-0.1 * ((t_eval[-1] - t0) % per))) < 1e-4 and yo.shape[2] == n
             assert s.stats()["number_of_steps"] == so[0, 0]
+    # hybrid DAE: apply_reset_with_mass (state.rs:279-306) makes the reset state consistent with a Newton solve on InitOp, without line search
+    dae = ("in = [k]\nk { 0.1 }\nu_i { x = 1, z = 2 }\ndudt_i { dxdt = 0, dzdt = 0 }\nM_i { dxdt, 0 }\nF_i { -k * x, z * z - 4 * x * x }\n"
+           "stop_i { x - 0.6, x - 0.3 }\nreset_i { 0.4, 0.81 }\n")
+    m, mid = fe.DiffslModel(dae), D.host_model(O, dae)
+    for nb in (1, 3):
+        p = np.full((nb, 1), 0.1)
+        s = H.Solver(m, p, nbatch=nb, method=hm, rtol=1e-6, atol=[1e-6])
+        y, reason = s.solve_dense(t_eval)
+        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, group=nb, method=om, rtol=1e-6, atol=[1e-6])
+        assert failed == 0 and reason == 2 and np.array_equal(np.transpose(y, (1, 0, 2)), yo)
+        assert abs(yo[0, -1, 1] - 2.0 * yo[0, -1, 0]) < 1e-5 and s.stats()["number_of_steps"] == so[0, 0]
