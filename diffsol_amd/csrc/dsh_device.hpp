@@ -22,6 +22,40 @@ constexpr int kRecRegions = 8;
 __device__ __forceinline__ unsigned long long d2u(double x) { return (unsigned long long)__double_as_longlong(x); }
 
 // NaN-propagating maximum in the bit-pattern domain (inputs are squares / counts: never negative zero or negative)
+// ---- An IEEE FP64 division split into its denominator half and its numerator half.
+// hipcc expands x / y for gfx950 into v_div_scale(y), v_rcp, four FMAs that refine the reciprocal, v_div_scale(x), a multiply, an FMA, v_div_fmas and
+// v_div_fixup: ~11 dependent instructions.  When neither operand needs scaling (v_div_scale returns its operand, VCC is clear, v_div_fmas is a plain FMA
+// and v_div_fixup passes its first operand through — true whenever both magnitudes are within [2^-300, 2^300]) the first six depend on y alone.
+// div_refined_rcp(y) is that half — computed once per denominator, off any dependent chain — and div_by_refined(x, y, r) the other: three dependent
+// instructions that return the bits of x / y (scripts/ubench/div_split.hip: 2.6e11 pairs incl. extreme mantissas and exact / halfway quotients, no
+// mismatch).  Two ways to know that a quotient made this way is the quotient:
+//   * div_split_ok(x, y): both operands in range; a numerator of +0 also is (the three instructions give the right signed zero), -0 is not (they
+//     return +0 for a positive denominator);
+//   * after the fact, with no instruction on the chain: div_den_ok(y) (|y| within [2^-49, 2^49]) and div_quot_ok(q) (|q| within [2^-250, 2^250])
+//     together imply |x| within [2^-300, 2^300] — a numerator outside of it (zero, denormal, huge, Inf, NaN) cannot produce a quotient inside.
+// Whoever finds the test false divides the ordinary way.
+constexpr double kDivSplitLo = 0x1p-300, kDivSplitHi = 0x1p300, kDivDenLo = 0x1p-49, kDivDenHi = 0x1p49, kDivQuotLo = 0x1p-250, kDivQuotHi = 0x1p250;
+__device__ __forceinline__ double div_refined_rcp(double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  double e = __builtin_fma(-y, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-y, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_by_refined(double x, double y, double r) {
+  const double q = x * r;
+  const double e = __builtin_fma(-y, q, x);
+  return __builtin_fma(e, r, q);
+}
+// bitwise, not short-circuit, operators: compares and scalar mask logic, no branches
+__device__ __forceinline__ bool div_split_ok(double x, double y) {
+  const double a = __builtin_fabs(x), d = __builtin_fabs(y);
+  return (((a >= kDivSplitLo) & (a <= kDivSplitHi)) | __builtin_amdgcn_class(x, 1 << 6)) & (d >= kDivSplitLo) & (d <= kDivSplitHi);  // class bit 6: +0
+}
+__device__ __forceinline__ bool div_den_ok(double y) { const double d = __builtin_fabs(y); return (d >= kDivDenLo) & (d <= kDivDenHi); }
+__device__ __forceinline__ bool div_quot_ok(double q) { const double a = __builtin_fabs(q); return (a >= kDivQuotLo) & (a <= kDivQuotHi); }
+
 __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 
 // Wavefront reductions without the LDS crossbar: four DPP butterfly stages inside each row of 16 lanes (quad_perm [1,0,3,2], quad_perm [2,3,0,1],

@@ -272,7 +272,7 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
     // small ensembles: 8 systems per wavefront with the operands prefetched by all 64 lanes (k_lu_band_solve_wide: same bits, the memory latency off the
     // sequential chain); large ones fill the machine with one lane per system.  DSH_LU_BAND_WIDE=0 / 1 forces either.
     static const int wide_env = [] { const char* e = std::getenv("DSH_LU_BAND_WIDE"); return e && *e ? std::atoi(e) : -1; }();
-    const bool wide = wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384);  // long chains, few wavefronts (n = 42 x 32 768: 43 us one lane per system, 171 us wide)
+    const bool wide = (wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384)) && n * nb < (1ll << 28);  // the wide kernel addresses rows with 32-bit byte offsets  // long chains, few wavefronts (n = 42 x 32 768: 43 us one lane per system, 171 us wide)
     g = wide ? grid_for(nb, 8) : grid_for(nb, 64);
     int rc = begin_records(ctx, g.x, &rec, &seq);
     if (rc != DSH_OK) return rc;

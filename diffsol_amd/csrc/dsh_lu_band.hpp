@@ -220,11 +220,14 @@ __global__ __launch_bounds__(64) void k_lu_band_solve(int64_t n, int64_t nb, con
 // steps (64-byte segments of 8 neighbouring systems), several chunks of 16 steps ahead of the chain (up to ~40 loads, ~100 steps, in flight per
 // wavefront; 8x as many wavefronts), lands in registers, and is handed through LDS to the 8 lanes that run the chain.  Results go back through LDS
 // and are stored by all 64 lanes.  No data is shared between systems and no operation is reordered.
+// Measured at n = 512 x 4096 (scripts/ubench/band_wide_bench.hip, HIP events): one lane per system 212 us; this kernel 126 us as first written; 86 us with
+// the stripped interior chunks (no end-of-matrix / interchange selects, the division's denominator half off the chain); 76 us with 32-bit row offsets
+// on wavefront-uniform bases.  512 systems (one wavefront per CU) take 61 us: that is the chain itself, ~2 x (7 dependent FP64 instructions per row).
 template <int K, int S>
 __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb, const double* __restrict__ fac, const int32_t* __restrict__ piv, double* __restrict__ rhs,
                                                            unsigned long long* rec, unsigned int seq) {
   constexpr int G = 64 / S, R = K + 1, C = 2 * K + 1;
-  constexpr int CHK = 16;           // steps per chunk
+  constexpr int CHK = 16;           // steps per chunk (8 and 32 measure the same: the cost is per row)
   constexpr int Q = CHK / G;        // load instructions per operand and chunk
   constexpr int FO = K + 2;         // forward operands per step: K multipliers, pivot offset, the entry that enters the window
   constexpr int BO = C + 1;         // backward: C entries of U, the entry that enters the window
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
   static_assert(CHK % G == 0, "chunk must be a multiple of the row groups");
   __shared__ double sOp[MO][CHK][S];
   __shared__ double sOut[CHK][S];
+  __shared__ double sInv[CHK][S];  // backward sweep: the denominator half of the division by U's diagonal (div_refined_rcp), made by the staging lanes
   const int lane = threadIdx.x, s = lane % S, g = lane / S;
   const int64_t b0 = (int64_t)blockIdx.x * S + s;
   const bool valid = b0 < nb;
@@ -241,19 +245,38 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
   const bool chain = g == 0;
   const int64_t nch = (n + CHK - 1) / CHK;
   unsigned long long bad = 0ull;
+  const uint32_t nb8 = (uint32_t)nb * 8u, b8 = (uint32_t)b * 8u, last8 = (uint32_t)(n - 1) * nb8 + b8;  // byte offsets: row stride, this system, its last row
+  auto ld_f64 = [](const double* base, uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off); };
+  auto ld_i32 = [](const int32_t* base, uint32_t off) __attribute__((always_inline)) { return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(base) + off); };
+  auto st_f64 = [](double* base, uint32_t off, double v) __attribute__((always_inline)) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) = v; };
+
+  // The wavefront is alone on its SIMD and runs one instruction stream: what a row costs is the number of instructions the chain lanes spend on it
+  // (~5 cycles each, ~10 when dependent).  So every chunk that can — all of them but the ends of the matrix — runs a stripped variant of the step:
+  // no end-of-matrix selects; forward, no interchange selects when no system of the wavefront interchanges in the chunk (diagonally dominant
+  // matrices never do); backward, the division by the diagonal reduced to its three-instruction numerator half (dsh_device.hpp).  Same operations on
+  // the same operands in the same order as the general variant, which the remaining chunks use.
 
   // ---------------------------------------------------------------- forward: interchanges interleaved with the unit-lower-triangular solve
   {
     double pf[DF][FO][Q];
     int pp[DF][Q];  // the pivot rows stay integers until they land (a conversion at issue would wait for the load)
-    auto issue = [&](int64_t c, double (&pd)[FO][Q], int (&pi)[Q]) __attribute__((always_inline)) {
+    // Addresses: a wavefront-uniform base per operand plus ONE 32-bit byte offset per row (global_load saddr + voffset), advanced by a constant per
+    // chunk — a 64-bit index product per load cost more instructions than the chunk's arithmetic.  The caller guarantees n * nb < 2^28.
+    const double* lbase[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) lbase[r] = fac + (int64_t)(C + r) * n * nb;
+    uint32_t offq[Q];  // byte offset of row c*CHK + q*G + g of this lane's system, for the chunk issued next
+#pragma unroll
+    for (int q = 0; q < Q; ++q) offq[q] = (uint32_t)(q * G + g) * nb8 + b8;
+    auto issue = [&](double (&pd)[FO][Q], int (&pi)[Q]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const int64_t j = min(c * CHK + q * G + g, n - 1);  // clamped, unconditional loads; steps beyond n are skipped by the chain
+        const uint32_t o = min(offq[q], last8);  // clamped, unconditional loads; steps beyond n are skipped by the chain
 #pragma unroll
-        for (int r = 0; r < K; ++r) pd[r][q] = fac[((int64_t)(C + r) * n + j) * nb + b];
-        pi[q] = piv[j * nb + b];
-        pd[K + 1][q] = rhs[min(j + 1 + K, n - 1) * nb + b];
+        for (int r = 0; r < K; ++r) pd[r][q] = ld_f64(lbase[r], o);
+        pi[q] = ld_i32(piv, o >> 1);
+        pd[K + 1][q] = ld_f64(rhs, min(offq[q] + (uint32_t)(1 + K) * nb8, last8));
+        offq[q] += (uint32_t)CHK * nb8;
       }
     };
     double v[R];
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
 #pragma unroll
     for (int r = 0; r < R; ++r) asm volatile("" : "+v"(v[r]));
 #pragma unroll
-    for (int d = 0; d < DF; ++d) issue(d, pf[d], pp[d]);
+    for (int d = 0; d < DF; ++d) issue(pf[d], pp[d]);
     // every trip runs all DF stages and every stage issues its loads (clamped rows past the end): with a fixed number of younger loads behind each
     // landing the compiler's s_waitcnt leaves the prefetch in flight; a conditional issue would make it wait for everything
     for (int64_t c0 = 0; c0 < nch; c0 += DF) {
@@ -272,31 +295,44 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
       for (int d = 0; d < DF; ++d) {
         const int64_t c = c0 + d;
         {
+          bool moved = false;
 #pragma unroll
           for (int q = 0; q < Q; ++q) {
 #pragma unroll
             for (int o = 0; o < FO; ++o) if (o != K) sOp[o][q * G + g][s] = pf[d][o][q];
-            sOp[K][q * G + g][s] = (double)(pp[d][q] - (int)min(c * CHK + q * G + g, n - 1));  // pivot row - step
+            const int off = pp[d][q] - min((int)c * CHK + q * G + g, (int)n - 1);  // pivot row - step
+            sOp[K][q * G + g][s] = (double)off;
+            moved = moved | (off != 0);
           }
-          issue(c + DF, pf[d], pp[d]);
+          const bool stripped = (c + 1) * CHK + K < n && __builtin_amdgcn_ballot_w64(moved) == 0ull;  // wavefront-uniform
+          issue(pf[d], pp[d]);
           __builtin_amdgcn_wave_barrier();
           if (chain) {
-            double l[CHK][K], pvd[CHK], nxt[CHK];
+            double l[CHK][K], nxt[CHK];
 #pragma unroll
             for (int t = 0; t < CHK; ++t) {
 #pragma unroll
               for (int r = 0; r < K; ++r) l[t][r] = sOp[r][t][s];
-              pvd[t] = sOp[K][t][s];
               nxt[t] = sOp[K + 1][t][s];
             }
-            // full chunks run without a branch per step (a scalar branch on a vector compare costs more than the step's arithmetic)
-            auto steps = [&](auto full) __attribute__((always_inline)) {
+            if (stripped) {
+#pragma unroll
+              for (int t = 0; t < CHK; ++t) {
+                const double x = v[0];
+                sOut[t][s] = x;
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[r] = (-x) * l[t][r - 1] + v[r];
+#pragma unroll
+                for (int r = 0; r + 1 < R; ++r) v[r] = v[r + 1];
+                v[R - 1] = nxt[t];
+              }
+            } else {
               const int jb = (int)c * CHK, ni = (int)n;
 #pragma unroll
               for (int t = 0; t < CHK; ++t) {
                 const int j = jb + t;
-                if (decltype(full)::value || j < ni) {
-                  const int pv = (int)pvd[t];
+                if (j < ni) {
+                  const int pv = (int)sOp[K][t][s];
                   const double top = v[0];
                   double x = top;
 #pragma unroll
@@ -314,14 +350,13 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
                   v[R - 1] = j + 1 + K < ni ? nxt[t] : 0.0;
                 }
               }
-            };
-            if ((c + 1) * CHK <= n) steps(std::true_type{}); else steps(std::false_type{});
+            }
           }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int q = 0; q < Q; ++q) {
-            const int64_t j = c * CHK + q * G + g;
-            if (valid && j < n) rhs[j * nb + b0] = sOut[q * G + g][s];
+            const int j = (int)c * CHK + q * G + g;
+            if (valid && j < (int)n) st_f64(rhs, (uint32_t)j * nb8 + b8, sOut[q * G + g][s]);
           }
         }
       }
@@ -331,13 +366,22 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
   // ---------------------------------------------------------------- backward with U (bandwidth 2K): chunk c covers rows n-1 - (c*CHK + t)
   {
     double pb[DB][BO][Q];
-    auto issue = [&](int64_t c, double (&pd)[BO][Q]) __attribute__((always_inline)) {
+    // U(i-d, i) lives at fac[(d*n + i-d)*nb + b] = (fac + (d*n - d)*nb)[i*nb + b]: one offset per row serves every diagonal; a row above the matrix
+    // (i - d < 0, its value is never used) is clamped to row 0 of its diagonal by a single max
+    const double* ubase[C];
+    int ulo[C];
+#pragma unroll
+    for (int d = 0; d < C; ++d) { ubase[d] = fac + ((int64_t)d * n - d) * nb; ulo[d] = (int)((uint32_t)d * nb8 + b8); }
+    int offi[Q];  // byte offset of row i = n-1 - (c*CHK + q*G + g), for the chunk issued next; negative past the top of the matrix
+#pragma unroll
+    for (int q = 0; q < Q; ++q) offi[q] = ((int)n - 1 - (q * G + g)) * (int)nb8 + (int)b8;
+    auto issue = [&](double (&pd)[BO][Q]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        const int64_t i = max(n - 1 - (c * CHK + q * G + g), (int64_t)0);
 #pragma unroll
-        for (int d = 0; d < C; ++d) pd[d][q] = fac[((int64_t)d * n + max(i - d, (int64_t)0)) * nb + b];  // U(i-d, i)
-        pd[C][q] = rhs[max(i - C, (int64_t)0) * nb + b];
+        for (int d = 0; d < C; ++d) pd[d][q] = ld_f64(ubase[d], (uint32_t)max(offi[q], ulo[d]));
+        pd[C][q] = ld_f64(rhs, (uint32_t)max(offi[q] - C * (int)nb8, (int)b8));
+        offi[q] -= CHK * (int)nb8;
       }
     };
     double w[C];
@@ -346,51 +390,96 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
 #pragma unroll
     for (int q = 0; q < C; ++q) asm volatile("" : "+v"(w[q]));
 #pragma unroll
-    for (int d = 0; d < DB; ++d) issue(d, pb[d]);
+    for (int d = 0; d < DB; ++d) issue(pb[d]);
     for (int64_t c0 = 0; c0 < nch; c0 += DB) {
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
         const int64_t c = c0 + d;
         {
+          bool den_ok = true;
 #pragma unroll
           for (int o = 0; o < BO; ++o)
 #pragma unroll
             for (int q = 0; q < Q; ++q) sOp[o][q * G + g][s] = pb[d][o][q];
-          issue(c + DB, pb[d]);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) { sInv[q * G + g][s] = div_refined_rcp(pb[d][0][q]); den_ok = den_ok & div_den_ok(pb[d][0][q]); }
+          const bool stripped = n - 1 - (c * CHK + CHK - 1) - C >= 0;  // every row of the chunk has its whole band and a successor entering the window
+          issue(pb[d]);
           __builtin_amdgcn_wave_barrier();
-          if (chain) {
-            double u[CHK][C], nxt[CHK];
+          double w0[C];
+          // the general step; also the second run of a stripped chunk whose quotients could not be vouched for
+          auto general = [&]() __attribute__((always_inline)) {
+            const int ib = (int)n - 1 - (int)c * CHK;
 #pragma unroll
             for (int t = 0; t < CHK; ++t) {
+              const int i = ib - t;
+              if (i >= 0) {
+                const double diag = sOp[0][t][s];
+                if (diag == 0.0) bad = 1ull;
+                const double x = w[C - 1] / diag;
+                sOut[t][s] = x;
 #pragma unroll
-              for (int d2 = 0; d2 < C; ++d2) u[t][d2] = sOp[d2][t][s];
-              nxt[t] = sOp[C][t][s];
+                for (int d2 = 1; d2 < C; ++d2) { const double uu = i - d2 >= 0 ? sOp[d2][t][s] : 0.0; w[C - 1 - d2] = (-x) * uu + w[C - 1 - d2]; }  // as k_lu_band_solve: entries above row 0 are zeros
+#pragma unroll
+                for (int q = C - 1; q > 0; --q) w[q] = w[q - 1];
+                w[0] = i - C >= 0 ? sOp[C][t][s] : 0.0;
+              }
             }
-            auto steps = [&](auto full) __attribute__((always_inline)) {
-              const int ib = (int)n - 1 - (int)c * CHK;
+          };
+          if (chain) {
+            if (stripped) {
+              double u[CHK][C], nxt[CHK], iv[CHK];
 #pragma unroll
               for (int t = 0; t < CHK; ++t) {
-                const int i = ib - t;
-                if (decltype(full)::value || i >= 0) {
-                  const double diag = u[t][0];
-                  if (diag == 0.0) bad = 1ull;
-                  const double x = w[C - 1] / diag;
-                  sOut[t][s] = x;
 #pragma unroll
-                  for (int d2 = 1; d2 < C; ++d2) { const double uu = i - d2 >= 0 ? u[t][d2] : 0.0; w[C - 1 - d2] = (-x) * uu + w[C - 1 - d2]; }  // as k_lu_band_solve: entries above row 0 are zeros
-#pragma unroll
-                  for (int q = C - 1; q > 0; --q) w[q] = w[q - 1];
-                  w[0] = i - C >= 0 ? nxt[t] : 0.0;
-                }
+                for (int d2 = 0; d2 < C; ++d2) u[t][d2] = sOp[d2][t][s];
+                nxt[t] = sOp[C][t][s];
+                iv[t] = sInv[t][s];
               }
-            };
-            if ((c + 1) * CHK <= n) steps(std::true_type{}); else steps(std::false_type{});
+#pragma unroll
+              for (int q = 0; q < C; ++q) w0[q] = w[q];
+#pragma unroll
+              for (int t = 0; t < CHK; ++t) {
+                const double x = div_by_refined(w[C - 1], u[t][0], iv[t]);
+                sOut[t][s] = x;
+#pragma unroll
+                for (int d2 = 1; d2 < C; ++d2) w[C - 1 - d2] = (-x) * u[t][d2] + w[C - 1 - d2];
+#pragma unroll
+                for (int q = C - 1; q > 0; --q) w[q] = w[q - 1];
+                w[0] = nxt[t];
+              }
+            } else {
+              general();
+            }
           }
           __builtin_amdgcn_wave_barrier();
+          double xq[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) xq[q] = sOut[q * G + g][s];
+          if (stripped) {
+            // were the quotients quotients?  Checked here by the lanes that store them, off the chain: diagonal and quotient in the ranges that imply
+            // a numerator in range.  Otherwise (zero / tiny / huge entries: rare) the system's chain lane runs the chunk again from its saved window
+            bool ok = den_ok;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) ok = ok & div_quot_ok(xq[q]);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(!ok);
+            if (m != 0ull) {
+              m |= m >> 32; m |= m >> 16; m |= m >> 8;  // bit s: some row of system s failed (lane = g*S + s, S = 8)
+              static_assert(S == 8, "the fold above assumes 8 systems per wavefront");
+              if (chain && ((m >> s) & 1ull)) {
+#pragma unroll
+                for (int q = 0; q < C; ++q) w[q] = w0[q];
+                general();
+              }
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int q = 0; q < Q; ++q) xq[q] = sOut[q * G + g][s];
+            }
+          }
 #pragma unroll
           for (int q = 0; q < Q; ++q) {
-            const int64_t i = n - 1 - (c * CHK + q * G + g);
-            if (valid && i >= 0) rhs[i * nb + b0] = sOut[q * G + g][s];
+            const int i = (int)n - 1 - ((int)c * CHK + q * G + g);
+            if (valid && i >= 0) st_f64(rhs, (uint32_t)i * nb8 + b8, xq[q]);
           }
         }
       }

@@ -1,6 +1,7 @@
 """GPU parity tests: batched LU (row a5), model registry (row a16) and the fused kernels (rows a7, a9-a11) against the CPU oracle and
 against compositions of the 1:1 trait ops.  Integer/bit-level equality wherever the arithmetic order is identical."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -304,6 +305,68 @@ def test_banded_operands_in_dense_containers_are_solved_by_the_banded_kernels_wi
     x3 = H.HipVec.from_vec(b, c)
     lu.solve_in_place(x3)
     assert np.array_equal(x3.clone_as_vec(), O.lu_solve(wide, b)[0])
+
+
+_SPECIAL_BAND_SOLVE = """
+import sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import diffsol_amd as H
+from test_gpu_lu_models import _special_band_case
+n, k, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+a, b = _special_band_case(n, k)
+c = H.HipContext(nbatch=a.shape[0])
+lu = H.HipLU(c, n)
+lu.factor(H.HipMat.from_array(a, c))
+assert lu.band_width() == k
+x = H.HipVec.from_vec(b, c)
+lu.solve_in_place(x)
+np.save(out, np.asarray(x.clone_as_vec()).reshape(a.shape[0], n))
+"""
+
+
+def _special_band_case(n, k):
+    nb = 37
+    rng = np.random.default_rng(77 * n + k)
+    a = _banded(rng, nb, n, k, k, True)
+    a[3] *= 1e-150   # diagonal below 2^-300: every chunk of these systems takes the ordinary division
+    a[11] *= 1e180
+    a[20, 100:140] *= 1e-120  # a stretch of one system only
+    b = rng.standard_normal((nb, n))
+    b[0] = 0.0
+    b[1, ::2] = -0.0
+    b[2, 5:60] = 0.0
+    b[4, ::7] = 1e-310
+    b[5] *= 1e-200
+    b[6] *= 1e250
+    b[7, 300 % n] = -0.0
+    b[8] = 0.0; b[8, n // 2] = 1.0   # a unit vector: zeros above it stay +0 through the backward sweep
+    b[9] = -0.0; b[9, n - 1] = -1.0
+    return a, b
+
+
+@pytest.mark.parametrize("n,k", [(512, 1), (200, 2), (131, 4)])
+def test_wide_banded_solve_splits_its_divisions_only_where_that_keeps_the_bits(O, tmp_path, n, k):
+    """k_lu_band_solve_wide runs the division by U's diagonal as `refined reciprocal of the diagonal (off the chain) x numerator` (dsh_device.hpp:
+    div_refined_rcp / div_by_refined — the instruction sequence of the compiler's own x / y when no operand needs scaling) and re-runs a chunk with
+    ordinary divisions when an operand is outside that range.  Right-hand sides with +0, -0, denormal, tiny and huge entries, and systems scaled far out
+    of range (mixed with ordinary ones in the same wavefront): the bit patterns — signs of zeros included — must be those of the one-lane-per-system
+    kernel, which divides the ordinary way (DSH_LU_BAND_WIDE=0; the choice is read once per process, hence two child processes), and the values those of
+    the oracle's dense LU (whose eliminations with structurally zero multipliers may turn a -0 into +0, so signs of zeros are not compared there)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _SPECIAL_BAND_SOLVE.format(root=root, tests=os.path.join(root, "tests"))
+    res = {}
+    for wide in ("0", "1"):
+        out = str(tmp_path / f"x{wide}.npy")
+        subprocess.run([sys.executable, "-c", code, str(n), str(k), out], check=True, env=dict(os.environ, DSH_LU_BAND_WIDE=wide), timeout=300)
+        res[wide] = np.load(out)
+    assert np.array_equal(res["0"].view(np.int64), res["1"].view(np.int64))
+    a, b = _special_band_case(n, k)
+    xo, _, _, rc = O.lu_solve(a, b)
+    assert rc == 0 and np.array_equal(res["1"], np.asarray(xo).reshape(res["1"].shape))
+    assert (res["1"] == 0.0).any() and (np.abs(res["1"]) > 1e100).any() and (np.abs(res["1"][res["1"] != 0.0]) < 1e-100).any()  # the case does reach the edges
 
 
 def test_banded_lu_reports_singular_systems_like_the_dense_one(H, O):
