@@ -82,6 +82,7 @@ def lib():
                                                      C.c_int, C.c_double, C.c_int, _dp, _lp]
         L.orc_compute_r.argtypes = [C.c_int, C.c_double, _dp]
         L.orc_lu_solve.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+        L.orc_lu_solve_fullpiv.argtypes = [C.c_int, C.c_int, _dp, _dp]
         L.orc_squared_norm.restype = C.c_double
         L.orc_squared_norm.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double]
         L.orc_convergence_trace.argtypes = [C.c_double, C.c_double, C.c_int, _dp, C.c_int, _ip, _dp]
@@ -318,6 +319,16 @@ def lu_solve(a, b):
     piv = np.empty((nb, n), dtype=np.int32)
     rc = lib().orc_lu_solve(n, nb, a_cm.ctypes.data_as(_dp), x.ctypes.data_as(_dp), lu.ctypes.data_as(_dp), piv.ctypes.data_as(_ip))
     return x, np.transpose(lu, (0, 2, 1)).copy(), piv, rc
+
+
+def lu_solve_fullpiv(a, b):
+    """Complete-pivoting LU (the algorithm of the reference's FaerLU). a: [nbatch, n, n] (row, col), b: [nbatch, n]. Returns x, singular flag."""
+    a = np.asarray(a, dtype=np.float64)
+    nb, n, _ = a.shape
+    a_cm = np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+    x = np.ascontiguousarray(b, dtype=np.float64).copy()
+    rc = lib().orc_lu_solve_fullpiv(n, nb, a_cm.ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return x, rc
 
 
 def squared_norm(x, y, atol, rtol):

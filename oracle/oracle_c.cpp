@@ -399,6 +399,17 @@ int orc_lu_solve(int n, int nbatch, const double* a, double* b_inout, double* lu
   if (piv_out) std::memcpy(piv_out, lu.piv.data(), lu.piv.size() * sizeof(int));
   return ok ? 0 : 1;
 }
+// the same systems through the complete-pivoting LU (FaerLU's algorithm); returns 0 / 1 if singular
+int orc_lu_solve_fullpiv(int n, int nbatch, const double* a, double* b_inout) {
+  M m(n, n, nbatch);
+  std::memcpy(m.d.data(), a, m.d.size() * sizeof(double));
+  FullPivLU lu; lu.factor(m);
+  V v(n, nbatch);
+  std::memcpy(v.d.data(), b_inout, v.d.size() * sizeof(double));
+  bool ok = lu.solve(v);
+  std::memcpy(b_inout, v.d.data(), v.d.size() * sizeof(double));
+  return ok ? 0 : 1;
+}
 double orc_squared_norm(int n, int nbatch, const double* x, const double* y, const double* atol, double rtol) {
   V xv(n, nbatch), yv(n, nbatch), av(n, 1);
   std::memcpy(xv.d.data(), x, xv.d.size() * sizeof(double));

@@ -180,6 +180,54 @@ struct DenseLU {
   }
 };
 
+// The reference's other CPU solver, FaerLU (diffsol-la/src/linear_solver/faer/lu.rs:12-56), wraps faer's `FullPivLu` (faer is a Cargo dependency, absent
+// from /root/reference; faer 0.24 per the workspace Cargo.toml:29): Gaussian elimination with COMPLETE pivoting, P A Q = L U, the pivot of step k being the
+// entry of largest magnitude of the trailing block.  This is that published algorithm, unblocked.  faer's own evaluation order (blocked rank updates, SIMD
+// reductions inside its kernels) is not restated — **parity unpinned** for this variant beyond the reference's own known answer (lu.rs:60-73, a diagonal
+// operator) and agreement to rounding with the partial-pivoting restatement above; nothing on the HIP path depends on it (CudaLU pivots by column).
+struct FullPivLU {
+  int n = 0, nb = 0;
+  std::vector<double> lu;        // [b][col-major n*n]
+  std::vector<int> rperm, cperm; // [b][n]: row / column swapped with k at step k
+  void factor(const M& a) {
+    n = a.nr; nb = a.nb;
+    lu = a.d;
+    rperm.assign((size_t)n * nb, 0); cperm.assign((size_t)n * nb, 0);
+    for (int b = 0; b < nb; ++b) {
+      double* A = lu.data() + (size_t)b * n * n;
+      int* RP = rperm.data() + (size_t)b * n; int* CP = cperm.data() + (size_t)b * n;
+      for (int k = 0; k < n; ++k) {
+        int pr = k, pc = k; double best = -1.0;
+        for (int c = k; c < n; ++c) for (int r = k; r < n; ++r) { const double v = std::fabs(A[c * n + r]); if (v > best) { best = v; pr = r; pc = c; } }
+        RP[k] = pr; CP[k] = pc;
+        if (best == 0.0) continue;  // the trailing block is zero: rank-deficient, U gets zero diagonals from here on
+        if (pr != k) for (int c = 0; c < n; ++c) std::swap(A[c * n + k], A[c * n + pr]);
+        if (pc != k) for (int r = 0; r < n; ++r) std::swap(A[k * n + r], A[pc * n + r]);
+        const double inv = 1.0 / A[k * n + k];
+        for (int r = k + 1; r < n; ++r) A[k * n + r] *= inv;
+        for (int c = k + 1; c < n; ++c) { const double u = A[c * n + k]; for (int r = k + 1; r < n; ++r) A[c * n + r] -= A[k * n + r] * u; }
+      }
+    }
+  }
+  bool solve(V& x) const {
+    bool ok = true;
+    for (int b = 0; b < nb; ++b) {
+      const double* A = lu.data() + (size_t)b * n * n;
+      const int* RP = rperm.data() + (size_t)b * n; const int* CP = cperm.data() + (size_t)b * n;
+      double* v = x.d.data() + (size_t)b * n;
+      for (int k = 0; k < n; ++k) if (RP[k] != k) std::swap(v[k], v[RP[k]]);
+      for (int k = 0; k + 1 < n; ++k) for (int r = k + 1; r < n; ++r) v[r] -= A[k * n + r] * v[k];
+      for (int k = n - 1; k >= 0; --k) {
+        if (A[k * n + k] == 0.0) { ok = false; break; }
+        v[k] /= A[k * n + k];
+        for (int r = 0; r < k; ++r) v[r] -= A[k * n + r] * v[k];
+      }
+      for (int k = n - 1; k >= 0; --k) if (CP[k] != k) std::swap(v[k], v[CP[k]]);  // x = Q y: undo the column interchanges, last first
+    }
+    return ok;
+  }
+};
+
 // pow as the integrators use it: libm's (what Rust's f64::powf calls), or — for bit-for-bit comparison with the device-resident kernels, which
 // cannot call libm — the deterministic pow of include/diffsol_detpow.h on both sides (orc_set_det_pow).  Constants (20^1.25, eps^(2/3), ...) always
 // come from libm: the device receives them from the host.

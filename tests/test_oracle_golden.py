@@ -466,3 +466,25 @@ def test_oracle_sdirk_sens_reproduces_the_reference_snapshots(O, method, model, 
         assert np.abs(ss[:, 0, 0, 0] + t * np.exp(-0.1 * t)).max() < 1e-4 and np.abs(ss[:, 1, 0, 0] - np.exp(-0.1 * t)).max() < 1e-4
     else:
         assert np.isfinite(ss).all() and np.abs(ss.sum(axis=-1)).max() < 1e-6 * np.abs(ss).max()
+
+
+def test_complete_pivoting_lu_of_the_faer_solver_variant(O):
+    """FaerLU (diffsol-la/src/linear_solver/faer/lu.rs:12-56) is faer's FullPivLu: the oracle's complete-pivoting restatement solves the reference's own
+    known answer (lu.rs:60-73: diag(2) x = [2, 4] -> [1, 2]) exactly, agrees with the partial-pivoting LU (NalgebraLU / CudaLU's algorithm) and with LAPACK
+    to rounding on random and on badly row-scaled systems, and reports rank deficiency like the other one does."""
+    x, rc = O.lu_solve_fullpiv(np.diag([2.0, 2.0])[None], np.array([[2.0, 4.0]]))
+    assert rc == 0 and np.array_equal(x, [[1.0, 2.0]])
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 7, 20, 64):
+        a = rng.standard_normal((5, n, n))
+        a[1] *= np.logspace(-8, 8, n)[:, None]  # rows of very different scale: complete pivoting picks different pivots than partial
+        b = rng.standard_normal((5, n))
+        xf, rc = O.lu_solve_fullpiv(a, b)
+        xp, _, _, rcp = O.lu_solve(a, b)
+        ref = np.linalg.solve(a, b[..., None])[..., 0]
+        scale = np.abs(ref).max(axis=1, keepdims=True) * np.linalg.cond(a)[:, None]
+        assert rc == 0 and rcp == 0
+        assert (np.abs(xf - ref) <= 1e-14 * scale).all() and (np.abs(xf - xp) <= 1e-14 * scale).all()
+    sing = np.array([[[1.0, 2.0, 3.0], [2.0, 4.0, 6.0], [1.0, 0.0, 1.0]]])
+    assert O.lu_solve_fullpiv(sing, np.ones((1, 3)))[1] == 1
+
