@@ -7,14 +7,25 @@
 
 namespace dsh {
 
+// The accessors the generated functions read their operands through.  Concrete types shared by every kernel (not one closure type per kernel): an
+// outlined model (one __noinline__ function per component, diffsl.hpp emit_switch) is then instantiated once, not once per kernel.
+struct JitVec {  // element k of this thread's system
+  const double* p; int64_t nb, b;
+  __device__ __forceinline__ double operator()(int64_t k) const { return p[k * nb + b]; }
+};
+struct JitDir {  // a direction: a vector of the batch, or the unit vector e_unit (Jacobian / mass-matrix columns)
+  const double* p; int64_t nb, b, unit;
+  __device__ __forceinline__ double operator()(int64_t k) const { return unit >= 0 ? (k == unit ? 1.0 : 0.0) : p[k * nb + b]; }
+};
+
 extern "C" __global__ void k_jit_dyn_rhs(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, const double* __restrict__ v,
                                          double* __restrict__ y) {
   const int64_t total = (int64_t)kJitN * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / nb, b = idx % nb;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto V = [&](int64_t k) { return v[k * nb + b]; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitDir V{v, nb, b, -1};
+    const JitVec P{p, nb, b};
     y[idx] = jit_component(t, (long)i, X, V, P, v != nullptr);
   }
 }
@@ -24,9 +35,9 @@ extern "C" __global__ void k_jit_dyn_jacobian(int64_t nb, double t, const double
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = idx / nb, b = idx % nb;
     const int64_t i = e % kJitN, j = e / kJitN;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitDir V{nullptr, nb, b, j};
+    const JitVec P{p, nb, b};
     jac[idx] = jit_component(t, (long)i, X, V, P, true);
   }
 }
@@ -34,7 +45,7 @@ extern "C" __global__ void k_jit_dyn_init(int64_t nb, double t, const double* __
   const int64_t total = (int64_t)kJitN * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / nb, b = idx % nb;
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec P{p, nb, b};
     y[idx] = jit_init_component(t, (long)i, P);
   }
 }
@@ -43,8 +54,8 @@ extern "C" __global__ void k_jit_dyn_mass_gemv(int64_t nb, double t, const doubl
   const int64_t total = (int64_t)kJitN * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / nb, b = idx % nb;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitVec P{p, nb, b};
     y[idx] = jit_mass_component(t, (long)i, X, P) + beta * y[idx];
   }
 }
@@ -54,8 +65,8 @@ extern "C" __global__ void k_jit_dyn_mass_matrix(int64_t nb, double t, const dou
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = idx / nb, b = idx % nb;
     const int64_t i = e % kJitN, j = e / kJitN;
-    auto X = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitDir X{nullptr, nb, b, j};
+    const JitVec P{p, nb, b};
     mass[idx] = jit_mass_component(t, (long)i, X, P);
   }
 }
@@ -66,9 +77,9 @@ extern "C" __global__ void k_jit_dyn_sens(int64_t nb, double t, const double* __
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = idx / nb, b = idx % nb;
     const int64_t i = e % kJitN, j = e / kJitN;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitDir V{nullptr, nb, b, j};
+    const JitVec P{p, nb, b};
     s[idx] = jit_sens_component(t, (long)i, X, V, P, init != 0);
   }
 }
@@ -77,8 +88,8 @@ extern "C" __global__ void k_jit_dyn_reset(int64_t nb, double t, const double* _
   const int64_t total = (int64_t)kJitN * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / nb, b = idx % nb;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitVec P{p, nb, b};
     y[idx] = jit_reset_component(t, (long)i, X, P);
   }
 }
@@ -87,8 +98,8 @@ extern "C" __global__ void k_jit_dyn_root_out(int64_t nb, double t, const double
   const int64_t count = which == 0 ? kJitNRoots : kJitNOut, total = count * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = idx / nb, b = idx % nb;
-    auto X = [&](int64_t k) { return x[k * nb + b]; };
-    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const JitVec X{x, nb, b};
+    const JitVec P{p, nb, b};
     g[idx] = which == 0 ? jit_root_component(t, (long)i, X, P) : jit_out_component(t, (long)i, X, P);
   }
 }

@@ -266,16 +266,18 @@ def solve_ensemble_independent_fast(model, p, *, model_size=0, rtol=1e-6, atol=(
                 stats=stats)
 
 
-def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1, group=1):
+def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, nthreads=1, group=1, options=None):
     """solve_dense per member (each its own IVP; group > 1: consecutive groups of `group` members as one lock-step batched problem each); a member
     that finds a root stops there (its next column is the state at the root, later columns NaN; see solve_dense_independent.last_roots).  Returns y [nsys, nt, n], stats [nsys, 5] (steps, newton its, LU setups, error fails, newton fails), nfailed."""
     p = np.ascontiguousarray(p, dtype=np.float64)
     nsys, np_ = p.shape
     a_arr, a_ptr = _d(np.asarray(atol, dtype=np.float64).reshape(-1))
     te, te_ptr = _d(t_eval)
-    s = OracleSolver(model, p[0], model_size=model_size, rtol=rtol, atol=atol, t0=t0, h0=h0, method=method)
+    s = OracleSolver(model, p[0], model_size=model_size, rtol=rtol, atol=atol, t0=t0, h0=h0, method=method, options=options)
     n = s.n
     del s
+    for k, v in (options or {}).items():  # problem.<ode / ic>_options.<k> = v for every problem of this call
+        lib().orc_next_solver_option(k.encode(), C.c_double(v))
     y = np.empty((nsys, te.size, n))
     stats = np.zeros((nsys, 5), dtype=np.int64)
     root_t = np.full(nsys, np.nan)

@@ -46,6 +46,8 @@ std::unique_ptr<Handle> make_handle(int model_id, int model_size, int nbatch, co
     if (kv.first == "max_nonlinear_solver_failures") h->problem.ode_options.max_nonlinear_solver_failures = (int)kv.second;
     else if (kv.first == "max_error_test_failures") h->problem.ode_options.max_error_test_failures = (int)kv.second;
     else if (kv.first == "max_nonlinear_solver_iterations") h->problem.ode_options.max_nonlinear_solver_iterations = (int)kv.second;
+    else if (kv.first == "ic_armijo_constant") h->problem.ic_options.armijo_constant = kv.second;
+    else if (kv.first == "ic_use_linesearch") h->problem.ic_options.use_linesearch = kv.second != 0.0;
     else { g_option_request.clear(); throw std::runtime_error("oracle: unknown option " + kv.first); }
   }
   g_option_request.clear();
@@ -306,10 +308,13 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
   std::atomic<int> failed{0};
   if (group < 1) group = 1;
   const int ngroups = (nsys + group - 1) / group;
+  const auto options = g_option_request;  // orc_next_solver_option requests of the calling thread apply to every problem built here
+  g_option_request.clear();
   auto work = [&](int tid) {
     for (int g = tid; g < ngroups; g += nthreads) {
       const int s0 = g * group, cnt = std::min(group, nsys - s0);
       try {
+        g_option_request = options;
         auto h = make_handle(model_id, model_size, cnt, p + (size_t)s0 * np, np * cnt, rtol, atol, natol, t0, h0, method);
         if (h->init_error != 0) { failed += cnt; continue; }
         const int n = h->problem.n();

@@ -232,6 +232,11 @@ def test_the_references_dfn_benchmark_model_parses_and_differentiates(O, fe):
     code = open(REF_DFN).read()
     src, dims, _ = fe.generate(code, fe.TARGET_HOST_C)
     assert dims["n"] == 962 and dims["has_mass"] and dims["nroots"] == 2 and dims["no_inputs"]
+    # the device form of a model this size is outlined: one __noinline__ function per component (3 x 962 of them for f, J v and M alone) behind a
+    # dispatching switch — the inline form (12 MB in one function) does not get through the device compiler; small models stay inline
+    dev = fe.generate(code, fe.TARGET_HIP_DYNAMIC)[0]
+    assert "DSH_JIT_OUTLINED" in dev and dev.count("__attribute__((noinline))") >= 3 * 962 and "case 961: return jit_jac_c_961(t, X, V, P);" in dev
+    assert "DSH_JIT_OUTLINED" not in fe.generate(D.heat1d(512), fe.TARGET_HIP_DYNAMIC)[0]
     mid = D.host_model(O, code, opt="-O0")
     y0 = O.model_init(mid, [0.0])
     f0 = O.model_rhs(mid, y0, [0.0])

@@ -48,6 +48,25 @@ def _sample(name, dims, rng, nb):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_every_operator_of_a_compiled_model_matches_the_cpu_model_bitwise(H, O, fe, name):
+    _check_every_operator(H, O, fe, name)
+
+
+@pytest.mark.parametrize("name", ["heat16", "spm", "heat_dae"])
+def test_outlined_form_of_large_models_gives_the_same_bits(H, O, fe, name, monkeypatch):
+    """Models whose inline device source would exceed 4 MB (the reference's pybamm_dfn.diffsl: 962 states, 12 MB) are emitted OUTLINED — one __noinline__
+    function per component behind a dispatching switch, instantiated once for all kernels through the concrete accessor types of dsh_jit_dyn_kernels.hpp —
+    because one function of that size does not get through the device compiler.  Forced here on the run-time-sized test models: every operator (right-hand
+    side, J v, dense Jacobian, initial state, mass product and matrix, roots, outputs) must still equal the host model bit for bit."""
+    monkeypatch.setenv("DSH_DIFFSL_OUTLINE", "1")
+    src = fe.generate(CASES[name], fe.TARGET_HIP_DYNAMIC)[0]
+    assert "DSH_JIT_OUTLINED" in src and src.count("__attribute__((noinline))") >= 3 * O.model_dims(D.host_model(O, CASES[name]))["n"]
+    monkeypatch.setenv("DSH_DIFFSL_OUTLINE", "0")
+    assert "DSH_JIT_OUTLINED" not in fe.generate(CASES[name], fe.TARGET_HIP_DYNAMIC)[0]
+    monkeypatch.setenv("DSH_DIFFSL_OUTLINE", "1")
+    _check_every_operator(H, O, fe, name)
+
+
+def _check_every_operator(H, O, fe, name):
     from diffsol_amd import _ffi
     L = _ffi.load_device_lib()
     m = fe.DiffslModel(CASES[name])
