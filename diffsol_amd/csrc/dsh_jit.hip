@@ -318,7 +318,7 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   DSH_REQUIRE(source != nullptr && model_id != nullptr, "null argument");
   DSH_REQUIRE(form == DSH_JIT_FORM_STATIC || form == DSH_JIT_FORM_DYNAMIC || form == DSH_JIT_FORM_STATIC_BANDED, "unknown model form");
   DSH_REQUIRE(n >= 1 && nparams >= 1 && nroots >= 0 && nout >= 0, "bad model dimensions");
-  if (form == DSH_JIT_FORM_STATIC_BANDED) DSH_REQUIRE(n <= 64 && !has_mass && nroots <= 8, "the lane-per-member banded form needs n <= 64, an identity mass matrix and at most 8 stop conditions");
+  if (form == DSH_JIT_FORM_STATIC_BANDED) DSH_REQUIRE(n <= 512 && !has_mass && nroots <= 8, "the lane-per-member banded form needs n <= 512, an identity mass matrix and at most 8 stop conditions");
   if (form == DSH_JIT_FORM_STATIC) {
     DSH_REQUIRE(n <= 8, "the register-resident form needs n <= 8");
     DSH_REQUIRE(nroots <= 1, "the register-resident form supports at most one root function; use the dynamic form");
@@ -362,6 +362,14 @@ int dsh_model_set_band(int model_id, int jac_kl, int jac_ku, int mass_kl, int ma
 
 // The banded lane-per-member form of a built-in run-time-sized model (dsh_models_lane.hpp), created on first request and kept for the life of the process.
 // -1 if the model has none (not a registry model with n <= 64, identity mass, declared bandwidth <= 4, at most 2 stop conditions and parameters that fit).
+// largest built-in banded model that gets a lane-per-member twin: 512 (the kernels keep their arrays in per-lane scratch, ~230 bytes per state for BDF, and
+// the hardware's scratch wave size allows 128 KB per lane); DSH_LANE_TWIN_MAX_N lowers it (64: the round-1 limit).  hiprtc needs ~3 minutes for the
+// BDF kernel at n = 512 (seconds at n = 100), once per size: the code object is cached.
+static int64_t lane_twin_max_n() {
+  const char* e = std::getenv("DSH_LANE_TWIN_MAX_N");
+  const int64_t v = e && *e ? std::atoll(e) : 512;
+  return v < 8 ? 8 : (v > 512 ? 512 : v);
+}
 int dsh_model_lane_twin(int model, int64_t size) {
   if (is_jit_model(model)) return dsh_model_twin(model);
   static std::map<std::pair<int, int64_t>, int> twins;
@@ -373,7 +381,7 @@ int dsh_model_lane_twin(int model, int64_t size) {
   int64_t n = 0, np = 0, nroots = 0;
   int has_mass = 0, jl = -1, ju = -1, ml = -1, mu2 = -1;
   if (dsh_model_info(model, size, &n, &np, &has_mass, &nroots) == DSH_OK && dsh_model_band(model, size, &jl, &ju, &ml, &mu2) == DSH_OK && !dsh_model_has_fused(model, size) &&
-      n > 8 && n <= 64 && !has_mass && jl >= 0 && ju >= 0 && std::max(jl, ju) <= 4 && nroots <= 2 && np >= 1 && np <= 8) {
+      n > 8 && n <= lane_twin_max_n() && !has_mass && jl >= 0 && ju >= 0 && std::max(jl, ju) <= 4 && nroots <= 2 && np >= 1 && np <= 8) {
     const int k = std::max(1, std::max(jl, ju));
     const std::string src = "#include \"dsh_models_lane.hpp\"\nnamespace dsh { using JitModel = DynLane<" + std::to_string(model) + ", " + std::to_string(n) + ", " + std::to_string(np) +
                             ", " + std::to_string(nroots) + ", " + std::to_string(k) + ">; }\n";

@@ -92,7 +92,11 @@ struct ResidentPick {
   int64_t size = 0;
   int method = 0;
 };
-ResidentPick pick_resident(const dshs_solver* s, int group) {
+// for_auto: the choice DSHS_ENSEMBLE_AUTO makes.  A built-in banded model with 64 < n <= 512 has a lane-per-member twin too (one lane walks the whole
+// state: ~1 s for TR-BDF2 at n = 512 whatever the ensemble size up to ~65 000 members, 0.17 s for BDF), which only pays against the host-driven
+// lock-step path (config 3: 0.154 s per 4096 members, growing with the ensemble) for large ensembles: AUTO takes it from 32 768 members on; an
+// explicit per-member / wavefront-group request always gets it (it is the only per-member device path for such a model).
+ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = false) {
   ResidentPick r;
   r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
   if (group != 1 && group != 64) return r;
@@ -103,7 +107,8 @@ ResidentPick pick_resident(const dshs_solver* s, int group) {
   const bool lane_ok = !(lane_env && lane_env[0] == '0');
   int model = 0;
   int64_t size = 0;
-  if (lane_ok && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(r.method, twin, 0)) {
+  const bool big_twin_pays = !for_auto || s->problem.eqn->nstates() <= 64 || s->ctx.nbatch() >= 32768;
+  if (lane_ok && big_twin_pays && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(r.method, twin, 0)) {
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
     r.ok = true; r.model = model; r.size = size;
@@ -133,8 +138,8 @@ int resolve_mode(const dshs_solver* s) {
     // the device-resident integrators start from the problem's (t0, y0): a solver that was stepped by hand continues on the host path
     if (s->solver->get_statistics().number_of_steps != 0 || s->solver->t() != s->problem.t0) return DSHS_ENSEMBLE_LOCKSTEP;
     const bool roots = s->problem.eqn->nroots() > 0;
-    if (!roots && pick_resident(s, 64).ok) return DSHS_ENSEMBLE_WAVEFRONT;
-    if (pick_resident(s, 1).ok) return DSHS_ENSEMBLE_PER_MEMBER;
+    if (!roots && pick_resident(s, 64, true).ok) return DSHS_ENSEMBLE_WAVEFRONT;
+    if (pick_resident(s, 1, true).ok) return DSHS_ENSEMBLE_PER_MEMBER;
     return DSHS_ENSEMBLE_LOCKSTEP;
   }
   if (mode != DSHS_ENSEMBLE_LOCKSTEP && !pick_resident(s, mode).ok) return DSHS_ENSEMBLE_LOCKSTEP;

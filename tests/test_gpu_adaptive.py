@@ -359,6 +359,23 @@ def test_with_a_shared_deterministic_pow_the_wavefront_per_member_bdf_is_bit_ide
     _bitwise_pair(H, O, "robertson_ode", robertson_params(12), [0.4, 4.0, 40.0], 3, 1, 0, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
 
 
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("group", [1, 64])
+def test_banded_models_up_to_512_states_have_a_device_resident_lane_per_member_form(H, O, det_pow, method, group):
+    """a device-resident path for 64 < n <= 512 (BASELINE config 3 per member).  The lane-per-member kernels keep the whole solver state
+    in per-lane scratch, so the built-in banded models get their static form for any size up to 512 (~230 bytes of scratch per state for BDF; the hardware's
+    scratch wave size allows 128 KB per lane).  heat1d at n = 100 (not a multiple of any chunk size), BDF / TR-BDF2 / ESDIRK34, every member its own history
+    and wavefront lock-step groups: the oracle's bits.  AUTO keeps ensembles below 32 768 members on the host-driven path, where such a model is faster
+    (scripts/heat_resident.py: n = 512 x 4096, TR-BDF2: 1.0 s device-resident whatever the ensemble size, 0.154 s host-driven per 4096 members)."""
+    from diffsol_amd import _ffi
+    assert _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["heat1d"], 100) >= 1000 and _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["heat1d"], 513) == -1
+    rng = np.random.default_rng(100)
+    D = rng.uniform(0.5, 2.0, (70, 1))
+    _bitwise_pair(H, O, "heat1d", D, [0.01, 0.1, 0.3], 100, group, method, rtol=1e-6, atol=[1e-6])
+    s = H.Solver("heat1d", D, nbatch=70, model_size=100, rtol=1e-6, atol=[1e-6], method=[H.METHOD_BDF, H.METHOD_TR_BDF2, H.METHOD_ESDIRK34][method])
+    assert s.ensemble_mode()[1] == 0  # AUTO: host-driven lock-step for a small ensemble of a large model
+
+
 @pytest.mark.parametrize("group", [1, 64])
 def test_rlc_config5_esdirk34_with_threshold_events_is_bit_identical_to_the_oracle(H, O, det_pow, group):
     """BASELINE config 5 at reduced size: RLC DAE (singular mass, sin source term), ESDIRK34, root iR - i_thresh.  States, counters, root times,
