@@ -92,10 +92,11 @@ struct ResidentPick {
   int64_t size = 0;
   int method = 0;
 };
-// for_auto: the choice DSHS_ENSEMBLE_AUTO makes.  A built-in banded model with 64 < n <= 512 has a lane-per-member twin too (one lane walks the whole
-// state: ~1 s for TR-BDF2 at n = 512 whatever the ensemble size up to ~65 000 members, 0.17 s for BDF), which only pays against the host-driven
-// lock-step path (config 3: 0.154 s per 4096 members, growing with the ensemble) for large ensembles: AUTO takes it from 32 768 members on; an
-// explicit per-member / wavefront-group request always gets it (it is the only per-member device path for such a model).
+// for_auto: the choice DSHS_ENSEMBLE_AUTO makes.  A built-in banded model with 64 < n <= 512 has a lane-per-member twin too: one lane walks the whole
+// state, so the time is one member's chain whatever the ensemble size up to ~65 000 members (n = 512: BDF 0.16 - 0.24 s, TR-BDF2 1.0 - 1.6 s), while the
+// host-driven lock-step path grows with the ensemble (BDF 0.30 s, TR-BDF2 0.49 s at 16 384 members; profiles/r02_heat_resident.jsonl).  AUTO takes the
+// twin where it pays: BDF from 16 384 members on, the SDIRK methods from 65 536 on; an explicit per-member / wavefront-group request always gets it (it
+// is the only per-member device path for such a model).
 ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = false) {
   ResidentPick r;
   r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
@@ -107,7 +108,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
   const bool lane_ok = !(lane_env && lane_env[0] == '0');
   int model = 0;
   int64_t size = 0;
-  const bool big_twin_pays = !for_auto || s->problem.eqn->nstates() <= 64 || s->ctx.nbatch() >= 32768;
+  const bool big_twin_pays = !for_auto || s->problem.eqn->nstates() <= 64 || s->ctx.nbatch() >= (r.method == 0 ? 16384 : 65536);
   if (lane_ok && big_twin_pays && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_lane_twin(model, size)) >= 0 && dsh_model_has_resident(r.method, twin, 0)) {
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {

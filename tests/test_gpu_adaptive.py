@@ -365,8 +365,8 @@ def test_banded_models_up_to_512_states_have_a_device_resident_lane_per_member_f
     """a device-resident path for 64 < n <= 512 (BASELINE config 3 per member).  The lane-per-member kernels keep the whole solver state
     in per-lane scratch, so the built-in banded models get their static form for any size up to 512 (~230 bytes of scratch per state for BDF; the hardware's
     scratch wave size allows 128 KB per lane).  heat1d at n = 100 (not a multiple of any chunk size), BDF / TR-BDF2 / ESDIRK34, every member its own history
-    and wavefront lock-step groups: the oracle's bits.  AUTO keeps ensembles below 32 768 members on the host-driven path, where such a model is faster
-    (scripts/heat_resident.py: n = 512 x 4096, TR-BDF2: 1.0 s device-resident whatever the ensemble size, 0.154 s host-driven per 4096 members)."""
+    and wavefront lock-step groups: the oracle's bits.  AUTO keeps small ensembles of such a model on the host-driven path, where they are faster (scripts/heat_resident.py,
+    profiles/r02_heat_resident.jsonl: BDF pays from 16 384 members on, TR-BDF2 does not at any size that fits)."""
     from diffsol_amd import _ffi
     assert _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["heat1d"], 100) >= 1000 and _ffi.load_device_lib().dsh_model_lane_twin(H.MODELS["heat1d"], 513) == -1
     rng = np.random.default_rng(100)
