@@ -162,6 +162,7 @@ int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, dou
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* x, const double* p, int recompute, double* rhs_jac,
                    double* mass_jac, dsh_lu* lu) {
   DSH_REQUIRE(lu != nullptr && rhs_jac != nullptr, "null argument");
+  { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
   lu->singular_epoch += 1;  // the kernel adds (epoch << 32 | 1) per singular system: no reset launch needed between factorisations
   bool ok = false;
   if (jit_static(model)) {

@@ -107,6 +107,9 @@ struct dsh_lu {
   int band_k = 0;
   int* band_probe = nullptr;
 };
+// allocates the factor / pivot storage of an LU handle on first use (dsh_lu.hip): every entry point that WRITES factors calls it
+extern "C" __attribute__((visibility("hidden"))) int lu_ensure_storage(dsh_lu* lu);
+
 
 namespace dsh {
 

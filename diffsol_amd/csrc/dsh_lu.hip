@@ -87,14 +87,21 @@ int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
   dsh_lu* lu = new dsh_lu();
   lu->ctx = ctx; lu->n = n; lu->nbatch = nbatch;
   lu->system_major = n > 8;
-  DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
-  DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
+  // the factor storage (n^2 doubles per system) is allocated by the first factorisation: a solver whose ensemble is integrated by the device-resident
+  // kernels never factors through this handle, and at n = 512 x 32 768 members the storage alone would be 69 GB
   DSH_HIP_CHECK(hipMalloc((void**)&lu->singular, sizeof(unsigned long long)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->band_probe, 2 * sizeof(int)));
   static const int default_structure = [] { const char* e = getenv("DSH_LU_STRUCTURE"); return e && std::string(e) == "dense" ? 1 : 0; }();
   lu->structure = default_structure;
   DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
   *out = lu;
+  return DSH_OK;
+}
+__attribute__((visibility("hidden"))) int lu_ensure_storage(dsh_lu* lu) {
+  if (lu->factors) return DSH_OK;
+  const int64_t n = lu->n, nbatch = lu->nbatch;
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
+  DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
   return DSH_OK;
 }
 void dsh_lu_destroy(dsh_lu* lu) {
@@ -106,8 +113,8 @@ void dsh_lu_destroy(dsh_lu* lu) {
   (void)hipFree(lu->band_probe);
   delete lu;
 }
-double* dsh_lu_factors(dsh_lu* lu) { return lu->factors; }
-int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu->pivots; }
+double* dsh_lu_factors(dsh_lu* lu) { return lu_ensure_storage(lu) == DSH_OK ? lu->factors : nullptr; }
+int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu_ensure_storage(lu) == DSH_OK ? lu->pivots : nullptr; }
 int dsh_lu_system_major(const dsh_lu* lu) { return lu->system_major ? 1 : 0; }
 int dsh_lu_set_structure(dsh_lu* lu, int structure) {
   DSH_REQUIRE(lu != nullptr && (structure == DSH_LU_STRUCTURE_AUTO || structure == DSH_LU_STRUCTURE_DENSE), "bad arguments");
@@ -120,6 +127,7 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) return DSH_OK;
+  { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
   if (lu->band_k > 0) { set_error("dsh_lu_download: the current factors are banded (dsh_lu_band_width); factor with DSH_LU_STRUCTURE_DENSE to download dense factors"); return DSH_E_UNSUPPORTED; }
   if (lu->system_major) {  // already [b][col][row] / [b][k]
     if (factors_host) { int rc = dsh_d2h(ctx, factors_host, lu->factors, sizeof(double) * n * n * nb); if (rc != DSH_OK) return rc; }
@@ -147,6 +155,7 @@ int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku) {
 static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
+  { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
   lu->singular_epoch += 1;
   lu->factored = true;
   if (n == 0) return DSH_OK;

@@ -164,7 +164,10 @@ class Bdf : public OdeSolverMethod {
     const HipContext& ctx = problem.context();
     op_.set_c(h_, alpha_[(size_t)order_]);
     nonlinear_solver_.set_problem(op_);
-    reset_jacobian();  // first Jacobian + LU (bdf.rs:289-293)
+    // first Jacobian + LU (bdf.rs:289-293).  State and time cannot change between here and the first step, so the work is done at the top of that step
+    // (ensure_linearised) with the same operands: an ensemble that is handed to the device-resident kernels never touches the n x n containers of this
+    // path (lazily allocated, hip_la.hpp) — at n = 512 they would not fit the device from ~30 000 members on.
+    first_linearisation_pending_ = true;
     diff_ = HipMat::zeros(n, MAX_ORDER + 3, ctx);
     initialise_diff_to_first_order();
     if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, y_, t_); }
@@ -290,7 +293,9 @@ class Bdf : public OdeSolverMethod {
     return out;
   }
 
+  void ensure_linearised() { if (first_linearisation_pending_) { first_linearisation_pending_ = false; reset_jacobian(); } }
   OdeSolverStopReason step() override {  // bdf.rs:1277-1589
+    ensure_linearised();
     double safety = 0.0, error_norm = 0.0;
     const long old_num_error_test_failures = statistics_.number_of_error_test_failures;
     bool convergence_fail = false;
@@ -731,6 +736,7 @@ class Bdf : public OdeSolverMethod {
   int64_t prelaunch_ticket_ = 0;
   double t_predict_ = 0.0;
   HipMat diff_, diff_tmp_;
+  bool first_linearisation_pending_ = false;
   std::vector<double> u_, alpha_, gamma_, error_const2_;
   OdeSolverStatistics statistics_;
   // BdfState (bdf_state.rs:13-37)

@@ -293,8 +293,8 @@ class HipMat {
   bool has_band() const { return band_kl_ >= 0 && band_ku_ >= 0; }
   int band_kl() const { return band_kl_; }
   int band_ku() const { return band_ku_; }
-  double* ptr() { clear_band(); return data_.get(); }  // write access from outside: the content is no longer known to be banded
-  const double* ptr() const { return data_.get(); }
+  double* ptr() { clear_band(); return buf(); }  // write access from outside: the content is no longer known to be banded
+  const double* ptr() const { return buf(); }
   int64_t col_stride() const { return nrows_ * nb(); }
 
   HipVecView column(int64_t j) const { bounds(j); return HipVecView{ptr() + j * col_stride(), nrows_, nb(), ctx_}; }
@@ -312,9 +312,9 @@ class HipMat {
     const int kl = tagged ? std::max(x.band_kl(), y.band_kl()) : -1, ku = tagged ? std::max(x.band_ku(), y.band_ku()) : -1;
     // banded assembly: the result's band must cover what this container holds now (else stale entries outside it would survive)
     if (tagged && has_band() && band_kl_ <= kl && band_ku_ <= ku && nrows_ >= 16 && (int64_t)(kl + ku + 1) * 2 <= nrows_) {
-      check(dsh_mat_scale_add_assign_banded(ctx_.raw(), nrows_, nb(), kl, ku, data_.get(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign (banded)");
+      check(dsh_mat_scale_add_assign_banded(ctx_.raw(), nrows_, nb(), kl, ku, buf(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign (banded)");
     } else {
-      check(dsh_mat_scale_add_assign(ctx_.raw(), nrows_ * ncols_, nb(), data_.get(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign");
+      check(dsh_mat_scale_add_assign(ctx_.raw(), nrows_ * ncols_, nb(), buf(), x.ptr(), x.nb(), beta, y.ptr(), y.nb()), "scale_add_and_assign");
     }
     band_kl_ = kl; band_ku_ = ku;
   }
@@ -339,16 +339,26 @@ class HipMat {
 
  private:
   int band_kl_ = -1, band_ku_ = -1;
+  // The storage of a LARGE zero matrix (>= 256 MB) is allocated when it is first touched: a solver object owns the n x n containers of the host-driven path
+  // (Jacobian, mass, M - cJ: 2 MB per member each at n = 512) whether or not a solve ever uses them, and an ensemble integrated by the device-resident
+  // kernels never does — 32 768 members of a 512-state model would not fit the device otherwise.  Copies share the buffer, allocated or not.
+  struct Buf {
+    HipContext ctx; int64_t bytes; double* p = nullptr;
+    Buf(const HipContext& c, int64_t b) : ctx(c), bytes(b) {}
+    ~Buf() { if (p) dsh_free(ctx.raw(), p); }
+    double* get(bool zero) { if (!p) { void* d = nullptr; check(dsh_malloc(ctx.raw(), bytes, zero ? 1 : 0, &d), "HipMat alloc"); p = (double*)d; } return p; }
+  };
   HipMat(int64_t nrows, int64_t ncols, const HipContext& ctx, bool zero) : nrows_(nrows), ncols_(ncols), ctx_(ctx) {
-    void* d = nullptr;
-    check(dsh_malloc(ctx.raw(), (int64_t)sizeof(double) * nrows * ncols * ctx.nbatch(), zero ? 1 : 0, &d), "HipMat alloc");
-    data_ = std::shared_ptr<double>((double*)d, [ctx](double* p) { dsh_free(ctx.raw(), p); });
+    const int64_t bytes = (int64_t)sizeof(double) * nrows * ncols * ctx.nbatch();
+    data_ = std::make_shared<Buf>(ctx, bytes);
+    if (!(zero && bytes >= ((int64_t)256 << 20))) (void)data_->get(zero);
   }
+  double* buf() const { return data_ ? data_->get(true) : nullptr; }
   void bounds(int64_t j) const { if (j < 0 || j >= ncols_) throw LaError(DSH_E_INVALID, "Column index out of bounds"); }
   void same_shape(const HipMat& o) const { if (o.nrows_ != nrows_ || o.ncols_ != ncols_) throw LaError(DSH_E_INVALID, "Matrix shape mismatch"); }
   int64_t nrows_ = 0, ncols_ = 0;
   HipContext ctx_;
-  std::shared_ptr<double> data_;
+  std::shared_ptr<Buf> data_;
 };
 
 inline void HipMatViewMut::gemm_vo(double alpha, const HipMatView& a, const HipMat& b, double beta) {
