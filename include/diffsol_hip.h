@@ -222,7 +222,7 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 #define DSH_MODEL_JIT_BASE 1000
 #define DSH_JIT_FORM_STATIC 0
 #define DSH_JIT_FORM_DYNAMIC 1
-#define DSH_JIT_FORM_STATIC_BANDED 2 /* `struct dsh::JitModel` with BAND_K and jac_band (n <= 64, identity mass, Jacobian bandwidth <= 4): only the lane-per-member
+#define DSH_JIT_FORM_STATIC_BANDED 2 /* `struct dsh::JitModel` with BAND_K and jac_band (n <= 512 — DiffSL-emitted forms n <= 64 —, identity mass, Jacobian bandwidth <= 4): only the lane-per-member
                                       * device-resident BDF is instantiated for it (state in per-lane memory, banded LU in registers); attach it to the
                                       * run-time-sized form of the same model with dsh_model_set_twin and per-member solve_dense uses it */
 int dsh_model_compile(const char* source, int form, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id);
@@ -335,7 +335,7 @@ int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
  * step-size / order history — the semantics of diffsol's CPU path for a parameter sweep (one independent IVP per member), i.e. of
  * Bdf::step (ode_solver/bdf.rs:1277-1589) + NewtonNonlinearSolver (diffsol-nl/src/newton.rs) + solve_dense (method.rs:467-520) per member.
  * Static models with n <= 4 (dsh_model_has_adaptive), mass matrices (consistent initialisation on the device) and root functions included; and run-time-compiled
- * models in the banded lane-per-member form (DSH_JIT_FORM_STATIC_BANDED, dsh_model_lane_twin: n <= 64, identity mass, Jacobian bandwidth <= 4), whose state lives in
+ * models in the banded lane-per-member form (DSH_JIT_FORM_STATIC_BANDED, dsh_model_lane_twin: built-in models n <= 512, DiffSL models n <= 64; identity mass, Jacobian bandwidth <= 4), whose state lives in
  * per-lane memory and whose LU is banded. */
 typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) + BdfConfig (config.rs:53-74) */
   int max_nonlinear_solver_iterations, max_error_test_failures, max_nonlinear_solver_failures;

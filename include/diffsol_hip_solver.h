@@ -129,7 +129,7 @@ int dshs_get_ensemble_mode(const dshs_solver* s, int* requested, int* resolved);
 int dshs_last_solve_info(const dshs_solver* s, int* mode, int64_t* totals);
 /* solve_dense entirely on the device, the whole ensemble in one launch (dsh_bdf_solve_adaptive / dsh_sdirk_solve_resident).
  * group = 1: every member is integrated as the independent IVP it is on diffsol's CPU path, with its own step sizes, orders and EVENT TIMES;
- * group = 64: wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64).  Static models with n <= 4 and banded run-time-sized models with n <= 64 (BDF, TR-BDF2,
+ * group = 64: wavefront-sized lock-step groups (the reference's batched semantics with nbatch = 64).  Static models with n <= 4 and banded run-time-sized models (built-in: n <= 512, from DiffSL: n <= 64; BDF, TR-BDF2,
  * ESDIRK34), mass matrices and root functions included.
  * stats_host: [5][b] int32 (steps, Newton iterations, LU setups, error-test failures, Newton failures); status_host: [b] (0 ok, else OdeSolverError
  * ordinal, 20 root batch mismatch, 99 runaway guard); t_root_host / root_idx_host / ncols_host: [b] root time (NaN if none), root index (-1),
