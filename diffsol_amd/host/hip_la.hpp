@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -271,8 +272,13 @@ class HipMat {
     return m;
   }
   static HipMat from_diagonal(const HipVec& v) {
-    HipMat m(v.len(), v.len(), v.context(), false);
-    check(dsh_mat_from_diagonal(v.context().raw(), v.len(), v.nb(), v.ptr(), v.nb(), m.ptr()), "from_diagonal");
+    HipMat m(v.len(), v.len(), v.context(), true);  // large: storage deferred (see Buf)
+    if (m.data_->p) {
+      check(dsh_mat_from_diagonal(v.context().raw(), v.len(), v.nb(), v.ptr(), v.nb(), m.data_->p), "from_diagonal");
+    } else {
+      const HipVec keep = v.clone();  // the diagonal (n per member) is kept until the n x n storage is first touched
+      m.data_->init = [keep](double* p) { check(dsh_mat_from_diagonal(keep.context().raw(), keep.len(), keep.nb(), keep.ptr(), keep.nb(), p), "from_diagonal"); };
+    }
     m.set_band(0, 0);
     return m;
   }
@@ -346,7 +352,16 @@ class HipMat {
     HipContext ctx; int64_t bytes; double* p = nullptr;
     Buf(const HipContext& c, int64_t b) : ctx(c), bytes(b) {}
     ~Buf() { if (p) dsh_free(ctx.raw(), p); }
-    double* get(bool zero) { if (!p) { void* d = nullptr; check(dsh_malloc(ctx.raw(), bytes, zero ? 1 : 0, &d), "HipMat alloc"); p = (double*)d; } return p; }
+    std::function<void(double*)> init;  // content of a deferred matrix that is not all zeros (from_diagonal): written when the storage is made
+    double* get(bool zero) {
+      if (!p) {
+        void* d = nullptr;
+        check(dsh_malloc(ctx.raw(), bytes, (zero && !init) ? 1 : 0, &d), "HipMat alloc");
+        p = (double*)d;
+        if (init) { init(p); init = nullptr; }
+      }
+      return p;
+    }
   };
   HipMat(int64_t nrows, int64_t ncols, const HipContext& ctx, bool zero) : nrows_(nrows), ncols_(ncols), ctx_(ctx) {
     const int64_t bytes = (int64_t)sizeof(double) * nrows * ncols * ctx.nbatch();
