@@ -237,6 +237,8 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
       hipLaunchKernelGGL((k_lu_factor_blocked<NBK, 256>), dim3((unsigned)nb), dim3(256), blocked_lds_bytes(n, NBK), ctx->stream, (int)n, nb, lu->factors, \
                          lu->pivots, lu->singular, lu->singular_epoch, phase_clocks);                                                                   \
   } while (0)
+        // DSH_LU_BLOCKED_NB = 16 | 8: narrower panels than would fit (less LDS per workgroup, more workgroups per CU); same bits for every width
+        static const int nb_cap = [] { const char* e = getenv("DSH_LU_BLOCKED_NB"); const int v = e ? atoi(e) : 32; return v == 8 || v == 16 ? v : 32; }();
         // opt-in: trailing update on the FP64 matrix cores (not bit-identical: tested to a tolerance).  Read per call so that tests can compare both.
         const bool mfma = [] { const char* e = getenv("DSH_LU_MFMA"); return e && e[0] == '1'; }() && n % 16 == 0 && blocked_lds_bytes(n, 32) <= budget;
         if (mfma) {
@@ -247,8 +249,8 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
             hipLaunchKernelGGL((k_lu_factor_blocked<32, 256, true>), dim3((unsigned)nb), dim3(256), blocked_lds_bytes(n, 32), ctx->stream, (int)n, nb, lu->factors, lu->pivots,
                                lu->singular, lu->singular_epoch, phase_clocks);
         } else
-        if (blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
-        else if (blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
+        if (nb_cap >= 32 && blocked_lds_bytes(n, 32) <= budget) DSH_LU_BLOCKED(32);
+        else if (nb_cap >= 16 && blocked_lds_bytes(n, 16) <= budget) DSH_LU_BLOCKED(16);
         else if (blocked_lds_bytes(n, 8) <= budget) DSH_LU_BLOCKED(8);
         else
           hipLaunchKernelGGL(k_lu_factor_global_coop, dim3((unsigned)nb), dim3(kCoopThreads), 0, ctx->stream, (int)n, nb, lu->factors, lu->pivots, lu->singular,
