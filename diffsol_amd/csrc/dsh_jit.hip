@@ -442,7 +442,7 @@ int dsh_model_precompile(int model_id, int family) {
   }
   auto tf = [](bool b) { return b ? "true" : "false"; };
   if (family == 0) units.push_back({ops_header(rec->info.form), "ops", st ? jit_static_op_names() : std::vector<std::string>()});
-  else if (!st && family == 2 && rec->info.n <= 64 && !rec->info.has_mass && rec->info.nroots <= 2) {  // wavefront-per-member BDF
+  else if (!st && family == 2 && rec->info.n <= (rec->info.has_mass ? 48 : 64) && rec->info.nroots <= 2) {  // wavefront-per-member BDF
     const int64_t n = rec->info.n;
     const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
     units.push_back({"dsh_jit_wave_member.hpp", name, {name}});

@@ -26,7 +26,8 @@ extern "C" {
 int dsh_model_has_wave_member(int model, int64_t size) {
   if (is_jit_model(model)) {  // run-time-sized DiffSL model: identity mass, at most two stop conditions, one lane per component
     const JitInfo* ji = jit_info(model);
-    return ji && ji->form == DSH_JIT_FORM_DYNAMIC && ji->n <= 64 && !ji->has_mass && ji->nroots <= 2 && ji->np <= 64 ? 1 : 0;
+    // with a mass matrix (DAEs: consistent initialisation and M in the residual and in M - cJ) the kernel keeps M's rows in LDS next to J's: n <= 48
+    return ji && ji->form == DSH_JIT_FORM_DYNAMIC && ji->n <= (ji->has_mass ? 48 : 64) && ji->nroots <= 2 && ji->np <= 64 ? 1 : 0;
   }
   if (!(model == DSH_MODEL_DYDT_Y2 || model == DSH_MODEL_GAUSSIAN_DECAY || model == DSH_MODEL_HEAT1D || model == DSH_MODEL_SPM ||
         (model == DSH_MODEL_ROBERTSON_ODE && size > 1)))
@@ -44,7 +45,7 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  if (!dsh_model_has_wave_member(model, size)) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64, identity mass and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  if (!dsh_model_has_wave_member(model, size)) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveMemberConsts C;
   int64_t n = 0, np = 0, nroots = 0;
@@ -87,7 +88,9 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   rc = dsh_malloc(ctx, (int64_t)(sizeof(unsigned long long) * 8), 1, (void**)&totals_dev);
   if (rc != DSH_OK) return rc;
   DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
-  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64);
+  int has_mass = 0;
+  (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
   const int ab = atol_nb == 1 ? 1 : 0;
 #define DSH_WM_LAUNCH(NPV)                                                                                                                              \
   hipLaunchKernelGGL((k_bdf_wave_member<NPV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \

@@ -22,7 +22,14 @@ __device__ __forceinline__ int wm_root_values(int, int64_t, double t, XF X, PF P
   if (kJitNRoots > 1) g[1] = jit_root_component(t, 1, X, P);
   return kJitNRoots < 2 ? kJitNRoots : 2;
 }
+// component i of M(t) x: DiffSL models may carry a (singular) mass matrix — DAEs; the built-in run-time-sized models do not
+constexpr bool kWmHasMass = kJitHasMass;
+template <class XF, class PF>
+__device__ __forceinline__ double wm_mass_component(double t, int64_t i, XF X, PF P) { return jit_mass_component(t, (long)i, X, P); }
 #else
+constexpr bool kWmHasMass = false;
+template <class XF, class PF>
+__device__ __forceinline__ double wm_mass_component(double, int64_t i, XF X, PF) { return X(i); }
 template <class XF, class VF, class PF>
 __device__ __forceinline__ double wm_component(int model, int64_t n, double t, int64_t i, XF X, VF V, PF P, bool jac) { return dyn_component(model, n, t, i, X, V, P, jac); }
 template <class PF>
@@ -56,10 +63,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ y_out,
                                                        int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
                                                        int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
-  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64]
+  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64] | with a mass matrix: sM[n][64] | xs2[64]
   double* xs = lds;
   double* ps = lds + 64;
   double* sJ = lds + 128;
+  double* sM = sJ + (size_t)Cp->n * 64;    // rows of M (only touched when kWmHasMass)
+  double* xs2 = sM + (size_t)Cp->n * 64;   // a second published vector (InitOp: x next to y0; Newton: y - y0 + psi)
   const WaveMemberConsts& C = *Cp;
   const dsh_adaptive_options& o = C.r.o;
   const bool det = o.deterministic_pow != 0;
@@ -92,6 +101,129 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double t = C.r.t0, h;
   double y = rowlive ? wm_init_value(model, (int64_t)n, (int64_t)ln, t, Pf) : 0.0;
   double f0 = rhs_of(y, t);
+  double a[NP];  // my row of the LU factors (of the InitOp Jacobian during the consistent initialisation, of M - c J afterwards)
+  int pos = ln, myinv = ln;
+  // factor the rows in `a`; afterwards lane i needs the unknown number i of a solve: remember which lane holds position i
+  auto factor_rows = [&]() __attribute__((always_inline)) {
+    bool sing = false;
+    int mypiv;
+    wave_lu_factor_rows<NP, 64>(a, n, true, rowlive, ln, 0, pos, mypiv, sing);
+    for (int k = 0; k < n; ++k) {
+      const int holder = __ffsll((unsigned long long)__ballot(rowlive && pos == k)) - 1;
+      if (ln == k) myinv = holder;
+    }
+  };
+  if constexpr (kWmHasMass) {
+    // StateRefMut::set_consistent (state.rs:84-162) over InitOp (op/init.rs:14-135), Newton with the backtracking line search (line_search.rs:84-201):
+    // the per-lane restatement of dsh_resident.hpp (set_consistent<Mdl, WAVE>) with one row per lane.  sJ holds the InitOp Jacobian, sM its neg_mass
+    // block (both are recomputed for the integrator afterwards: jac_stale starts true).
+    __syncthreads();
+    xs[ln] = y;
+    __syncthreads();
+    double mdiag = 1.0;
+    for (int j = 0; j < n; ++j) {
+      auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+      const double mij = rowlive ? wm_mass_component(t, (int64_t)ln, Ej, Pf) : 0.0;
+      const double rij = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+      sM[j * 64 + ln] = mij;
+      sJ[j * 64 + ln] = rij;
+      if (j == ln) mdiag = mij;
+    }
+    const bool is_alg = rowlive && mdiag == 0.0;  // partition_indices_by_zero_diagonal
+    const unsigned long long alg_mask = __ballot(is_alg);
+    if (alg_mask != 0ull) {
+      // InitOp::new: jac = (-M_u, df/dv; 0, dg/dv), neg_mass = (-M_u, 0; 0, 0) in the original ordering
+      for (int j = 0; j < n; ++j) {
+        const bool alg_j = (alg_mask >> j) & 1ull;
+        if (!alg_j) {
+          const double v = is_alg ? 0.0 : sM[j * 64 + ln] * (-1.0);
+          sJ[j * 64 + ln] = v;
+          sM[j * 64 + ln] = v;
+        } else {
+          sM[j * 64 + ln] = 0.0;  // sJ keeps df/dv, dg/dv
+        }
+      }
+      const double y_orig = y;
+      double x = is_alg ? y : f0, yerr = x, delta = 0.0;
+      // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out  (nalgebra gemv order)
+      auto init_fun = [&](double x_mine) __attribute__((always_inline)) -> double {
+        __syncthreads();
+        xs[ln] = is_alg ? x_mine : y_orig;
+        xs2[ln] = x_mine;
+        __syncthreads();
+        const double out = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, V0, Pf, false) : 0.0;
+        double acc = 1.0 * sM[0 * 64 + ln] * xs2[0] + 1.0 * out;
+        for (int j = 1; j < n; ++j) acc = 1.0 * sM[j * 64 + ln] * xs2[j] + acc;
+        return rowlive ? acc : 0.0;
+      };
+      auto init_solve = [&](double& v) __attribute__((always_inline)) -> bool {
+        const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
+        v = __shfl(v, myinv, 64);
+        return ok;
+      };
+      ConvState conv;
+      conv.eta = C.r.eta_reset;
+      conv.tol = o.nonlinear_solver_tolerance;
+      conv.max_iter = o.ic_max_newton_iterations;
+      conv.det = det;
+      bool ok = false, fatal_all = false;
+      for (int k = 0; k < o.ic_max_linear_solver_setups && !ok && !fatal_all; ++k) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] : 0.0;  // reset_jacobian: the InitOp Jacobian is constant
+        factor_rows();
+        conv.reset();
+        double ls_norm = 1.0;
+        int result = 2;  // 0 ok, 1 fatal (diverged / LU / line search), 2 NewtonMaxIterations
+        for (int it = 0; it < conv.max_iter; ++it) {
+          ConvStatus st = ConvStatus::Continue;
+          bool fatal = false;
+          if (!o.ic_use_linesearch) {  // NoLineSearch::take_optimal_step
+            delta = init_fun(x);
+            if (!init_solve(delta)) fatal = true;
+            else { x = x - delta; st = conv.check_new_iteration(sqrt(wms_wave(delta, yerr))); }
+          } else {  // BacktrackingLineSearch::take_optimal_step
+            bool returned = false;
+            if (conv.niter == 0) {
+              delta = init_fun(x);
+              if (!init_solve(delta)) { fatal = true; returned = true; }
+              else {
+                ls_norm = sqrt(wms_wave(delta, yerr));
+                if (conv.check_norm(ls_norm) == ConvStatus::Converged) { x = x - delta; st = ConvStatus::Converged; returned = true; }
+              }
+            }
+            if (!returned) {
+              const double x0 = x, delta0 = delta;
+              const double nrm = ls_norm;
+              const double phi0 = nrm * nrm * 0.5, two_phi0 = nrm * nrm, min_alpha = C.r.ls_steptol / nrm;
+              double alpha = 1.0;
+              bool found = false;
+              for (int i = 0; i < o.ic_max_linesearch_iterations; ++i) {
+                x = (-alpha) * delta0 + 1.0 * x;
+                delta = init_fun(x);
+                if (!init_solve(delta)) { fatal = true; break; }
+                const double new_norm = sqrt(wms_wave(delta, yerr));
+                const double phi1 = new_norm * new_norm * 0.5;
+                if (phi1 <= phi0 - o.ic_armijo_constant * alpha * two_phi0) { ls_norm = new_norm; st = conv.check_norm(new_norm); found = true; break; }
+                if (alpha < min_alpha) { fatal = true; break; }  // LinesearchFailedMinStep
+                alpha *= o.ic_step_reduction_factor;
+                x = x0;
+              }
+              if (!found) fatal = true;  // incl. LinesearchFailedMaxIterations
+            }
+          }
+          if (fatal) { result = 1; break; }
+          if (st == ConvStatus::Converged) { result = 0; break; }
+          if (st == ConvStatus::Diverged) { result = 1; break; }
+        }
+        if (result == 0) ok = true;
+        else if (result != 2) fatal_all = true;  // anything but NewtonMaxIterations is fatal (state.rs:131-140)
+        else yerr = x;
+      }
+      if (!ok) status = kRsInitialConditionDidNotConverge;
+      else if (is_alg) { y = x; f0 = 0.0; }  // scatter_soln (:76-81) + zero the algebraic derivatives (state.rs:155-158)
+      else f0 = x;
+    }
+  }
   {
     const bool is_neg_h = C.r.h0 < 0.0;
     const double d0 = sqrt(wms_wave(y, y)), d1 = sqrt(wms_wave(f0, y));
@@ -118,8 +250,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int j = 0; j < kNC; ++j) { D[j] = 0.0; Dt[j] = 0.0; }
   D[0] = y; D[1] = f0 * h;
   double opc = h * C.alpha[1];
-  double a[NP];  // my row of the LU factors of M - c J
-  int pos = ln, myinv = ln;
   bool jac_stale = true;
   // The factorisation is by far the largest piece of code of this kernel: every request for a new linearisation only records what the reference
   // would have used (the value of c at that moment; state and time do not change before the next Newton solve) and the one inlined copy of
@@ -136,19 +266,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int j = 0; j < n; ++j) {
         auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
         sJ[j * 64 + ln] = rowlive ? wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+        if constexpr (kWmHasMass) sM[j * 64 + ln] = rowlive ? wm_mass_component(tt, (int64_t)ln, Ej, Pf) : 0.0;  // the mass matrix is evaluated with the Jacobian (op/bdf.rs:138-160)
       }
       jac_stale = false;
     }
 #pragma unroll
-    for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0) : 0.0;
-    bool sing = false;
-    int mypiv;
-    wave_lu_factor_rows<NP, 64>(a, n, true, rowlive, ln, 0, pos, mypiv, sing);
-    // lane i will need the unknown number i after a solve: remember which lane holds position i
-    for (int k = 0; k < n; ++k) {
-      const int holder = __ffsll((unsigned long long)__ballot(rowlive && pos == k)) - 1;
-      if (ln == k) myinv = holder;
+    for (int j = 0; j < NP; ++j) {
+      double m = j == ln ? 1.0 : 0.0;
+      if constexpr (kWmHasMass) m = (rowlive && j < n) ? sM[j * 64 + ln] : 0.0;
+      a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * (-c_reset) + m : 0.0;
     }
+    factor_rows();
   };
   n_setups = 1;
   // RootFinder::init
@@ -303,7 +431,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
         const double f = rhs_of(x, t_predict);
         const double tmpv = x + psi;
-        double delta = 1.0 * tmpv + (-opc) * f;  // F(y) = (y - y0 + psi) - c f(y)
+        double delta;
+        if constexpr (kWmHasMass) {  // F(y) = M (y - y0 + psi) - c f(y): M's row times the published vector, then + (-c) f (mass_gemv with beta = -c)
+          xs2[ln] = tmpv;
+          __syncthreads();
+          auto X2f = [&](int64_t k) { return xs2[k]; };
+          delta = rowlive ? wm_mass_component(t_predict, (int64_t)ln, X2f, Pf) + (-opc) * f : 0.0;
+          __syncthreads();
+        } else {
+          delta = 1.0 * tmpv + (-opc) * f;  // F(y) = (y - y0 + psi) - c f(y)
+        }
         const bool lu_ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, delta);
         if (!lu_ok) break;
         delta = __shfl(delta, myinv, 64);  // unknown i to lane i

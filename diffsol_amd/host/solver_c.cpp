@@ -87,7 +87,7 @@ void download(const HipVec& v, double* host) {
 // Which device-resident kernel (if any) integrates this problem (model x method) in the given control granularity.
 struct ResidentPick {
   bool ok = false;
-  bool wave_member = false;  // one wavefront per member (run-time-sized models, BDF, identity mass, n <= 64)
+  bool wave_member = false;  // one wavefront per member (run-time-sized models, BDF, n <= 64; DiffSL models with a mass matrix: n <= 48)
   int model = 0;
   int64_t size = 0;
   int method = 0;
@@ -113,7 +113,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
     r.ok = true; r.model = model; r.size = size;
-  } else if (group == 1 && r.method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size) && !s->problem.eqn->has_mass()) {
+  } else if (group == 1 && r.method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size)) {
     r.ok = true; r.wave_member = true; r.model = model; r.size = size;
   }
   return r;

@@ -367,7 +367,7 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
  * n <= 4, mass matrices and root functions included, and the banded lane-per-member form as above (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds
  * the state at the root (solve_dense's return), ncols[b] counts its valid columns, later columns are NaN.  t_root / root_idx / ncols (nb each) may be NULL.
  * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
-/* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
+/* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; DiffSL models with a mass matrix — DAEs, made consistent on the device — n <= 48; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
  * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).  Identity mass only.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
 int dsh_model_has_wave_member(int model, int64_t size);

@@ -237,8 +237,35 @@ def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_membe
     y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=1)
     yo, so, failed = O.solve_dense_independent(mid, p, [0.01, 0.1], nthreads=4, group=1, method=0, **tol)
     assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
-    with pytest.raises(H.DiffsolHipError):  # a DAE of that size has no device-resident kernel yet
-        H.Solver(fe.DiffslModel(D.HEAT_DAE), np.ones((2, 1)), nbatch=2, **tol).solve_dense_adaptive([0.01])
+
+
+DAE10 = """
+in = [k]
+k { 1.0 }
+u_i { (0:8): x = 1, p = 0.7, q = 0.2 }
+dudt_i { (0:8): dxdt = 0, dpdt = 0, dqdt = 0 }
+M_i { dxdt_i, 0, 0 }
+F_i { (-k * x_i) * (1.0 + p) + q, p * p + p - x_i[0:1], q - 0.1 * p * x_i[7:8] }
+"""
+
+
+def test_wavefront_per_member_bdf_integrates_daes_with_a_consistent_initialisation_on_the_device(H, O, fe, det_pow):
+    """mass matrices in the wavefront-per-member kernel (run-time-sized DiffSL models, n <= 48).  The kernel makes the initial state
+    consistent itself — InitOp's Newton iteration with the backtracking line search, one row per lane (state.rs:84-162, op/init.rs, line_search.rs:84-201) —
+    and carries M in the residual M (y - y0 + psi) - c f and in M - cJ.  A heat equation with algebraic boundary unknowns, and a ten-state DAE whose two
+    algebraic unknowns start OFF their nonlinear constraints (p^2 + p = x_0, q = 0.1 p x_7): states and counters of every member bit-identical to
+    independent CPU solves of the host twin."""
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    for code, p, t_eval in ((D.HEAT_DAE, np.random.default_rng(3).uniform(0.5, 2.0, (9, 1)), [0.005, 0.02, 0.1]),
+                            (DAE10, np.linspace(0.5, 3.0, 11)[:, None], [0.1, 0.5, 2.0])):
+        m, mid = fe.DiffslModel(code, lane_resident=False), D.host_model(O, code)
+        assert m.has_mass and m.form == fe.FORM_DYNAMIC
+        s = H.Solver(m, p, nbatch=len(p), **tol)
+        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=4, group=1, method=0, **tol)
+        assert failed == 0 and (mem["status"] == 0).all()
+        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    assert abs(yo[0, 0, 8] ** 2 + yo[0, 0, 8] - yo[0, 0, 0]) < 1e-5  # on the constraint
 
 
 def test_banded_models_get_the_lane_per_member_bdf_with_state_in_memory_and_a_banded_lu(H, O, fe, det_pow):
