@@ -130,6 +130,8 @@ DEVICE_ABI = {
     "dsh_adaptive_default_options": (None, [vp]),
     "dsh_model_has_wave_member": (cint, [cint, i64]),
     "dsh_bdf_solve_wave_member": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
+    "dsh_model_has_wave_member_sdirk": (cint, [cint, i64]),
+    "dsh_sdirk_solve_wave_member": (cint, [vp, cint, i64, cint, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_model_has_resident": (cint, [cint, cint, i64]),
     "dsh_sdirk_solve_resident": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),

@@ -447,7 +447,14 @@ int dsh_model_precompile(int model_id, int family) {
     const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
     units.push_back({"dsh_jit_wave_member.hpp", name, {name}});
   }
-  else if (!st) { set_error("dsh_model_precompile: run-time-sized models have the operator kernels and (n <= 64, identity mass) the wavefront-per-member BDF"); return DSH_E_UNSUPPORTED; }
+  else if (!st && family == 3 && rec->info.n <= 64 && !rec->info.has_mass && rec->info.nroots <= 2) {  // wavefront-per-member TR-BDF2 / ESDIRK34
+    const int64_t n = rec->info.n;
+    for (int S = 3; S <= 4; ++S) {
+      const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + ">";
+      units.push_back({"dsh_jit_sdirk_wave_member.hpp", name, {name}});
+    }
+  }
+  else if (!st) { set_error("dsh_model_precompile: run-time-sized models have the operator kernels and (n <= 64) the wavefront-per-member integrators"); return DSH_E_UNSUPPORTED; }
   else if (family == 1) {
     units.push_back({"dsh_fused_kernels.hpp", "jac_factor", {"dsh::k_jac_factor<dsh::JitModel>"}});
     for (int sd = 0; sd < 2; ++sd)

@@ -16,6 +16,7 @@
 #include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
 #include "dsh_wave_member_kernel.hpp"
+#include "dsh_sdirk_wave_member_kernel.hpp"
 #include "dsh_jit.hpp"
 
 using namespace dsh;
@@ -106,6 +107,80 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   else if (n <= 48) DSH_WM_LAUNCH(48);
   else DSH_WM_LAUNCH(64);
 #undef DSH_WM_LAUNCH
+  DSH_HIP_CHECK(hipGetLastError());
+  DSH_HIP_CHECK(timing_end(ctx));
+  unsigned long long totals[8] = {0};
+  DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
+  DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  DSH_HIP_CHECK(timing_collect(ctx));
+  dsh_free(ctx, t_eval_dev);
+  dsh_free(ctx, totals_dev);
+  dsh_free(ctx, consts_dev);
+  if (totals_host) for (int q = 0; q < 6; ++q) totals_host[q] = (int64_t)totals[q];
+  return DSH_OK;
+}
+
+// has_wave_member for the SDIRK methods: as for BDF, but identity mass only
+int dsh_model_has_wave_member_sdirk(int model, int64_t size) {
+  if (!dsh_model_has_wave_member(model, size)) return 0;
+  int has_mass = 0;
+  if (dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr) != DSH_OK) return 0;
+  return has_mass ? 0 : 1;
+}
+
+int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_REQUIRE(ctx != nullptr, "ctx is null");
+  DSH_REQUIRE(method == 1 || method == 2, "method: 1 TR-BDF2, 2 ESDIRK34");
+  DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
+  DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
+  for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
+  DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
+  if (!dsh_model_has_wave_member_sdirk(model, size)) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64, identity mass and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  if (nb == 0) return DSH_OK;
+  WaveSdirkConsts C;
+  int64_t n = 0, np = 0, nroots = 0;
+  int rc = dsh_model_info(model, size, &n, &np, nullptr, &nroots);
+  if (rc != DSH_OK) return rc;
+  C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
+  fill_tableau(method, C.T);
+  C.T.r.rtol = rtol; C.T.r.t0 = t0; C.T.r.h0 = h0; C.T.r.n_eval = (int)n_eval;
+  C.T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+  C.T.r.eta_reset = std::pow(20.0, 1.25);
+  C.T.r.eta_reset_ts = std::pow(100.0, 1.25);
+  if (opts) C.T.r.o = *opts; else dsh_adaptive_default_options(&C.T.r.o);
+  if (C.T.r.o.max_steps <= 0) C.T.r.o.max_steps = 10000000;
+  double* t_eval_dev = nullptr;
+  unsigned long long* totals_dev = nullptr;
+  WaveSdirkConsts* consts_dev = nullptr;
+  rc = dsh_malloc(ctx, (int64_t)sizeof(WaveSdirkConsts), 0, (void**)&consts_dev);
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipMemcpyAsync(consts_dev, &C, sizeof(WaveSdirkConsts), hipMemcpyHostToDevice, ctx->stream));
+  rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * n_eval), 0, (void**)&t_eval_dev);
+  if (rc != DSH_OK) return rc;
+  rc = dsh_malloc(ctx, (int64_t)(sizeof(unsigned long long) * 8), 1, (void**)&totals_dev);
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64);
+  const int ab = atol_nb == 1 ? 1 : 0;
+  const int S = C.T.s;
+#define DSH_WS_LAUNCH(NPV, SV)                                                                                                                                  \
+  hipLaunchKernelGGL((k_sdirk_wave_member<NPV, SV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveSdirkConsts*)consts_dev, \
+                     (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+#define DSH_WS_LAUNCH_S(NPV) do { if (S == 3) DSH_WS_LAUNCH(NPV, 3); else DSH_WS_LAUNCH(NPV, 4); } while (0)
+  DSH_HIP_CHECK(timing_begin(ctx));
+  if (is_jit_model(model)) {
+    const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + ">";
+    rc = jit_launch(ctx, model, "dsh_jit_sdirk_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64), (unsigned)lds_bytes, nb, p, atol, ab,
+                    (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+    if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+  } else if (n <= 16) DSH_WS_LAUNCH_S(16);
+  else if (n <= 32) DSH_WS_LAUNCH_S(32);
+  else if (n <= 48) DSH_WS_LAUNCH_S(48);
+  else DSH_WS_LAUNCH_S(64);
+#undef DSH_WS_LAUNCH_S
+#undef DSH_WS_LAUNCH
   DSH_HIP_CHECK(hipGetLastError());
   DSH_HIP_CHECK(timing_end(ctx));
   unsigned long long totals[8] = {0};

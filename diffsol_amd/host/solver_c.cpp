@@ -87,7 +87,7 @@ void download(const HipVec& v, double* host) {
 // Which device-resident kernel (if any) integrates this problem (model x method) in the given control granularity.
 struct ResidentPick {
   bool ok = false;
-  bool wave_member = false;  // one wavefront per member (run-time-sized models, BDF, n <= 64; DiffSL models with a mass matrix: n <= 48)
+  bool wave_member = false;  // one wavefront per member (run-time-sized models, n <= 64; BDF also DiffSL models with a mass matrix, n <= 48; SDIRK identity mass)
   int model = 0;
   int64_t size = 0;
   int method = 0;
@@ -113,7 +113,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
     r.ok = true; r.model = model; r.size = size;
-  } else if (group == 1 && r.method == 0 && s->problem.eqn->registry_model(&model, &size) && dsh_model_has_wave_member(model, size)) {
+  } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) : dsh_model_has_wave_member_sdirk(model, size))) {
     r.ok = true; r.wave_member = true; r.model = model; r.size = size;
   }
   return r;
@@ -261,7 +261,10 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
   if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
   int rc;
-  if (wave_member)
+  if (wave_member && method != 0)
+    rc = dsh_sdirk_solve_wave_member(c, model, size, method, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                     t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
+  else if (wave_member)
     rc = dsh_bdf_solve_wave_member(c, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
                                    t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
   else if (method == 0)

@@ -368,12 +368,18 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
  * the state at the root (solve_dense's return), ncols[b] counts its valid columns, later columns are NaN.  t_root / root_idx / ncols (nb each) may be NULL.
  * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
 /* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; DiffSL models with a mass matrix — DAEs, made consistent on the device — n <= 48; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
- * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).  Identity mass only.
+ * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).
+ * dsh_sdirk_solve_wave_member: the same for TR-BDF2 (method 1) / ESDIRK34 (method 2) — Sdirk::step (sdirk.rs:409-543) over Rk (runge_kutta.rs:466-960),
+ * identity mass only (dsh_model_has_wave_member_sdirk).
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
 int dsh_model_has_wave_member(int model, int64_t size);
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
+int dsh_model_has_wave_member_sdirk(int model, int64_t size);
+int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 int dsh_model_has_resident(int method, int model, int64_t size);
 int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                              double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,

@@ -100,7 +100,7 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s3 = H.Solver("gaussian_decay", [[1.0] * 12], nbatch=1, model_size=12, method=1)  # run-time sized, 12 parameters: no lane-per-member form, and the wavefront-per-member kernel is BDF only
+    s3 = H.Solver("gaussian_decay", [[1.0] * 70], nbatch=1, model_size=70, method=1)  # run-time sized, dense Jacobian, n = 70: no lane-per-member form and too large for the wavefront-per-member kernels
     with pytest.raises(H.DiffsolHipError) as e:
         s3.solve_dense_adaptive([0.1])
     assert e.value.code == -6
@@ -357,6 +357,23 @@ def test_with_a_shared_deterministic_pow_the_wavefront_per_member_bdf_is_bit_ide
     rng = np.random.default_rng(1)
     _bitwise_pair(H, O, "heat1d", rng.uniform(0.5, 2.0, (12, 1)), [0.01, 0.1], 64, 1, 0, rtol=1e-6, atol=[1e-6])
     _bitwise_pair(H, O, "robertson_ode", robertson_params(12), [0.4, 4.0, 40.0], 3, 1, 0, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_with_a_shared_deterministic_pow_the_wavefront_per_member_sdirk_is_bit_identical_to_the_oracle(H, O, det_pow, monkeypatch, method):
+    """VERDICT r1 item 10: TR-BDF2 / ESDIRK34 in the wavefront-per-member form (k_sdirk_wave_member: Sdirk::step over Rk with one state component per lane,
+    the LU rows in registers, the linearisation requested where the reference resets its Jacobian and carried out before the next Newton solve).  Run-time-
+    sized built-in models without a banded twin, and — with DSH_RESIDENT_LANE=0 — the banded ones too, the battery model through its voltage cut-off events:
+    states, counters, event times, indices and column counts of every member are the oracle's."""
+    _bitwise_pair(H, O, "gaussian_decay", np.random.default_rng(1).uniform(0.5, 2.0, (9, 12)), [0.5, 2.0], 12, 1, method, rtol=1e-6, atol=[1e-6])
+    _bitwise_pair(H, O, "robertson_ode", robertson_params(12), [0.4, 4.0, 40.0], 3, 1, method, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 3)
+    monkeypatch.setenv("DSH_RESIDENT_LANE", "0")
+    rng = np.random.default_rng(1)
+    _bitwise_pair(H, O, "heat1d", rng.uniform(0.5, 2.0, (12, 1)), [0.01, 0.1], 64, 1, method, rtol=1e-6, atol=[1e-6])
+    cur = np.linspace(0.6, 1.4, 24)[:, None]
+    m, ref = _bitwise_pair(H, O, "spm", cur, [600.0, 1800.0, 3600.0], 20, 1, method, rtol=1e-6, atol=[1e-6])
+    assert (m["root_idx"] >= 0).sum() > 10 and np.array_equal(m["root_idx"], ref["root_idx"]) and np.array_equal(m["ncols"], ref["ncols"])
+    assert np.array_equal(m["t_root"], ref["t_root"], equal_nan=True)
 
 
 @pytest.mark.parametrize("method", [0, 1, 2])

@@ -237,6 +237,17 @@ def test_wavefront_per_member_bdf_on_run_time_sized_diffsl_models_with_per_membe
     y, tot, mem = s.solve_dense_adaptive([0.01, 0.1], want_member_stats=True, group=1)
     yo, so, failed = O.solve_dense_independent(mid, p, [0.01, 0.1], nthreads=4, group=1, method=0, **tol)
     assert failed == 0 and np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    # the SDIRK methods in the same form (k_sdirk_wave_member, instantiated by hiprtc for the model): the battery model through its events, TR-BDF2 and ESDIRK34
+    code = D.spm(20)
+    m, mid = fe.DiffslModel(code, lane_resident=False), D.host_model(O, code)
+    for hm, om in ((H.METHOD_TR_BDF2, 1), (H.METHOD_ESDIRK34, 2)):
+        s = H.Solver(m, cur, nbatch=24, method=hm, **tol)
+        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+        yo, so, failed = O.solve_dense_independent(mid, cur, t_eval, nthreads=8, group=1, method=om, **tol)
+        ref = O.solve_dense_independent.last_roots
+        assert failed == 0 and (mem["status"] == 0).all() and (mem["root_idx"] >= 0).sum() > 3
+        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+        assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
 
 
 DAE10 = """
