@@ -447,7 +447,7 @@ int dsh_model_precompile(int model_id, int family) {
     const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
     units.push_back({"dsh_jit_wave_member.hpp", name, {name}});
   }
-  else if (!st && family == 3 && rec->info.n <= 64 && !rec->info.has_mass && rec->info.nroots <= 2) {  // wavefront-per-member TR-BDF2 / ESDIRK34
+  else if (!st && family == 3 && rec->info.n <= (rec->info.has_mass ? 48 : 64) && rec->info.nroots <= 2) {  // wavefront-per-member TR-BDF2 / ESDIRK34
     const int64_t n = rec->info.n;
     for (int S = 3; S <= 4; ++S) {
       const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + ">";

@@ -1,4 +1,4 @@
-// One wavefront per ensemble member: the SDIRK integrators (TR-BDF2, ESDIRK34) for run-time-sized models with n <= 64 and an identity mass matrix — the
+// One wavefront per ensemble member: the SDIRK integrators (TR-BDF2, ESDIRK34) for run-time-sized models with n <= 64 (n <= 48 with a mass matrix) — the
 // wavefront-distributed form of k_sdirk_resident (dsh_sdirk_kernel.hpp: Sdirk::step sdirk.rs:409-543 over Rk runge_kutta.rs:466-960), built from the
 // pieces of k_bdf_wave_member (dsh_wave_member_kernel.hpp): lane i holds component i of the state, of every stage increment and its row of the LU
 // factors; the state is published through LDS for the model's component functions; norms are summed in index order.  Launch code: dsh_wave_member.hip.
@@ -18,10 +18,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                                          const WaveSdirkConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ y_out,
                                                          int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
                                                          int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
-  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64]
+  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64] | with a mass matrix: sM[n][64] | xs2[64]
   double* xs = lds;
   double* ps = lds + 64;
   double* sJ = lds + 128;
+  double* sM = sJ + (size_t)Cp->n * 64;
+  double* xs2 = sM + (size_t)Cp->n * 64;
   const SdirkConsts& T = Cp->T;
   const ResidentConsts& C = T.r;
   const dsh_adaptive_options& o = C.o;
@@ -53,6 +55,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double t = C.t0, h;
   double y = rowlive ? wm_init_value(model, (int64_t)n, (int64_t)ln, t, Pf) : 0.0;
   double dy = rhs_of(y, t);
+  double a[NP];  // my row of the LU factors (InitOp's during the consistent initialisation, of M - (c h) f' afterwards)
+  int pos = ln, myinv = ln;
+  auto lu_solve = [&](double& v) __attribute__((always_inline)) -> bool {
+    const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
+    v = __shfl(v, myinv, 64);
+    return ok;
+  };
+  if constexpr (kWmHasMass) {  // DAEs: consistent initial state (shared with k_bdf_wave_member)
+    auto factor_init = [&]() __attribute__((always_inline)) {
+      bool sing = false;
+      int mypiv;
+      wave_lu_factor_rows<NP, 64>(a, n, true, rowlive, ln, 0, pos, mypiv, sing);
+      for (int k = 0; k < n; ++k) {
+        const int holder = __ffsll((unsigned long long)__ballot(rowlive && pos == k)) - 1;
+        if (ln == k) myinv = holder;
+      }
+    };
+    auto comp_of = [&]() __attribute__((always_inline)) { return rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, V0, Pf, false) : 0.0; };
+    auto mass_e = [&](int j) __attribute__((always_inline)) { auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; }; return rowlive ? wm_mass_component(t, (int64_t)ln, Ej, Pf) : 0.0; };
+    auto jac_e = [&](int j) __attribute__((always_inline)) { auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; }; return rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0; };
+    if (!wm_set_consistent<NP>(n, ln, rowlive, xs, xs2, sJ, sM, a, C, comp_of, mass_e, jac_e, factor_init, lu_solve, wms_wave, y, dy)) status = kRsInitialConditionDidNotConverge;
+  }
   {
     const bool is_neg_h = C.h0 < 0.0;
     const double d0 = sqrt(wms_wave(y, y)), d1 = sqrt(wms_wave(dy, y));
@@ -102,8 +126,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double op_h = h;
   const double op_c = T.gamma;
   double phi = 0.0;  // V::zeros until the first set_phi
-  double a[NP];      // my row of the LU factors of I - (c h) f'
-  int pos = ln, myinv = ln;
   bool is_jacobian_set = false;
   bool has_prev_err = false;
   double prev_err = 0.0;
@@ -128,12 +150,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int j = 0; j < n; ++j) {
         auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
         sJ[j * 64 + ln] = rowlive ? wm_component(model, (int64_t)n, lin_t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+        if constexpr (kWmHasMass) sM[j * 64 + ln] = rowlive ? wm_mass_component(lin_t, (int64_t)ln, Ej, Pf) : 0.0;  // the mass matrix is evaluated with the Jacobian (op/sdirk.rs:266-296)
       }
       eval_pending = false;
     }
     const double beta = -(op_c * factor_h);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * beta + (j == ln ? 1.0 : 0.0) : 0.0;
+    for (int j = 0; j < NP; ++j) {
+      double m = j == ln ? 1.0 : 0.0;
+      if constexpr (kWmHasMass) m = (rowlive && j < n) ? sM[j * 64 + ln] : 0.0;
+      a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] * beta + m : 0.0;
+    }
     bool sing = false;
     int mypiv;
     wave_lu_factor_rows<NP, 64>(a, n, true, rowlive, ln, 0, pos, mypiv, sing);
@@ -142,11 +169,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (ln == k) myinv = holder;
     }
     factor_pending = false;
-  };
-  auto lu_solve = [&](double& v) __attribute__((always_inline)) -> bool {
-    const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
-    v = __shfl(v, myinv, 64);
-    return ok;
   };
   // Sdirk::_jacobian_updates (sdirk.rs:260-303)
   auto jacobian_updates = [&](double hh, JState st) __attribute__((always_inline)) {
@@ -262,7 +284,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           const double tmp = op_c * k + 1.0 * phi;
           const double f = rhs_of(tmp, ts);
           const double beta = -op_h;
-          double delta = 1.0 * k + beta * f;
+          double delta;
+          if constexpr (kWmHasMass) {  // F(k) = M k - h f(phi + c k): the model's mass product of the published increment, plus beta f (mass_gemv)
+            xs2[ln] = k;
+            __syncthreads();
+            auto X2f = [&](int64_t q) { return xs2[q]; };
+            delta = rowlive ? wm_mass_component(ts, (int64_t)ln, X2f, Pf) + beta * f : 0.0;
+            __syncthreads();
+          } else {
+            delta = 1.0 * k + beta * f;
+          }
           if (!lu_solve(delta)) break;  // LuSolveFailed
           k = k - delta;
           const ConvStatus st = conv.check_new_iteration(sqrt(wms_wave(delta, y)));
@@ -296,6 +327,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       double err = 1.0 * diff[0] * T.d[0];
 #pragma unroll
       for (int j = 1; j < S; ++j) err = 1.0 * diff[j] * T.d[j] + err;
+      if constexpr (kWmHasMass) {  // through the mass matrix as it was last evaluated (current_mass().gemv, nalgebra order)
+        __syncthreads();
+        xs2[ln] = err;
+        __syncthreads();
+        double acc = 1.0 * sM[0 * 64 + ln] * xs2[0];
+        for (int j = 1; j < n; ++j) acc = 1.0 * sM[j * 64 + ln] * xs2[j] + acc;
+        err = rowlive ? acc : 0.0;
+      }
       if (!lu_solve(err)) { status = kRsTooManyNonlinearSolverFailures; break; }
       error_norm = fmax(0.0, wms_wave(err, y));
       const double maxiter = (double)conv.max_iter, niter = (double)conv.niter;

@@ -120,13 +120,8 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   return DSH_OK;
 }
 
-// has_wave_member for the SDIRK methods: as for BDF, but identity mass only
-int dsh_model_has_wave_member_sdirk(int model, int64_t size) {
-  if (!dsh_model_has_wave_member(model, size)) return 0;
-  int has_mass = 0;
-  if (dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr) != DSH_OK) return 0;
-  return has_mass ? 0 : 1;
-}
+// has_wave_member for the SDIRK methods: the same models as for BDF
+int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size); }
 
 int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                 double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
@@ -137,7 +132,7 @@ int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int metho
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  if (!dsh_model_has_wave_member_sdirk(model, size)) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64, identity mass and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  if (!dsh_model_has_wave_member_sdirk(model, size)) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveSdirkConsts C;
   int64_t n = 0, np = 0, nroots = 0;
@@ -162,7 +157,9 @@ int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int metho
   rc = dsh_malloc(ctx, (int64_t)(sizeof(unsigned long long) * 8), 1, (void**)&totals_dev);
   if (rc != DSH_OK) return rc;
   DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
-  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64);
+  int has_mass = 0;
+  (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
   const int ab = atol_nb == 1 ? 1 : 0;
   const int S = C.T.s;
 #define DSH_WS_LAUNCH(NPV, SV)                                                                                                                                  \

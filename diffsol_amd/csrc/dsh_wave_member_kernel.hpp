@@ -58,6 +58,124 @@ __device__ __forceinline__ double seq_sum(double term, int n) {
   return acc;
 }
 
+// StateRefMut::set_consistent (state.rs:84-162) over InitOp (op/init.rs:14-135), Newton with the backtracking line search (line_search.rs:84-201): the
+// per-lane restatement of dsh_resident.hpp (set_consistent<Mdl, WAVE>) with one row per lane, shared by the wavefront-per-member BDF and SDIRK kernels.
+// On entry xs need not hold anything; sJ / sM receive the InitOp Jacobian and its neg_mass block (the integrators recompute both afterwards).
+// comp_of(): component ln of f at the vector published in xs; mass_e(j) / jac_e(j): entry (ln, j) of M / of f' at the published vector;
+// factor_rows(): factor the rows in `a`; solve_rows(v): solve with them, unknown i to lane i; wms(v, w): weighted mean square.  False = did not converge.
+template <int NP, class CompF, class MassF, class JacF, class FactorF, class SolveF, class WmsF>
+__device__ __forceinline__ bool wm_set_consistent(int n, int ln, bool rowlive, double* xs, double* xs2, double* sJ, double* sM, double (&a)[NP], const ResidentConsts& R,
+                                                  CompF comp_of, MassF mass_e, JacF jac_e, FactorF factor_rows, SolveF solve_rows, WmsF wms, double& y, double& f0) {
+  const dsh_adaptive_options& o = R.o;
+  const bool det = o.deterministic_pow != 0;
+  {
+    // StateRefMut::set_consistent (state.rs:84-162) over InitOp (op/init.rs:14-135), Newton with the backtracking line search (line_search.rs:84-201):
+    // the per-lane restatement of dsh_resident.hpp (set_consistent<Mdl, WAVE>) with one row per lane.  sJ holds the InitOp Jacobian, sM its neg_mass
+    // block (both are recomputed for the integrator afterwards: jac_stale starts true).
+    __syncthreads();
+    xs[ln] = y;
+    __syncthreads();
+    double mdiag = 1.0;
+    for (int j = 0; j < n; ++j) {
+      const double mij = mass_e(j);
+      const double rij = jac_e(j);
+      sM[j * 64 + ln] = mij;
+      sJ[j * 64 + ln] = rij;
+      if (j == ln) mdiag = mij;
+    }
+    const bool is_alg = rowlive && mdiag == 0.0;  // partition_indices_by_zero_diagonal
+    const unsigned long long alg_mask = __ballot(is_alg);
+    if (alg_mask != 0ull) {
+      // InitOp::new: jac = (-M_u, df/dv; 0, dg/dv), neg_mass = (-M_u, 0; 0, 0) in the original ordering
+      for (int j = 0; j < n; ++j) {
+        const bool alg_j = (alg_mask >> j) & 1ull;
+        if (!alg_j) {
+          const double v = is_alg ? 0.0 : sM[j * 64 + ln] * (-1.0);
+          sJ[j * 64 + ln] = v;
+          sM[j * 64 + ln] = v;
+        } else {
+          sM[j * 64 + ln] = 0.0;  // sJ keeps df/dv, dg/dv
+        }
+      }
+      const double y_orig = y;
+      double x = is_alg ? y : f0, yerr = x, delta = 0.0;
+      // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out  (nalgebra gemv order)
+      auto init_fun = [&](double x_mine) __attribute__((always_inline)) -> double {
+        __syncthreads();
+        xs[ln] = is_alg ? x_mine : y_orig;
+        xs2[ln] = x_mine;
+        __syncthreads();
+        const double out = comp_of();
+        double acc = 1.0 * sM[0 * 64 + ln] * xs2[0] + 1.0 * out;
+        for (int j = 1; j < n; ++j) acc = 1.0 * sM[j * 64 + ln] * xs2[j] + acc;
+        return rowlive ? acc : 0.0;
+      };
+      ConvState conv;
+      conv.eta = R.eta_reset;
+      conv.tol = o.nonlinear_solver_tolerance;
+      conv.max_iter = o.ic_max_newton_iterations;
+      conv.det = det;
+      bool ok = false, fatal_all = false;
+      for (int k = 0; k < o.ic_max_linear_solver_setups && !ok && !fatal_all; ++k) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] : 0.0;  // reset_jacobian: the InitOp Jacobian is constant
+        factor_rows();
+        conv.reset();
+        double ls_norm = 1.0;
+        int result = 2;  // 0 ok, 1 fatal (diverged / LU / line search), 2 NewtonMaxIterations
+        for (int it = 0; it < conv.max_iter; ++it) {
+          ConvStatus st = ConvStatus::Continue;
+          bool fatal = false;
+          if (!o.ic_use_linesearch) {  // NoLineSearch::take_optimal_step
+            delta = init_fun(x);
+            if (!solve_rows(delta)) fatal = true;
+            else { x = x - delta; st = conv.check_new_iteration(sqrt(wms(delta, yerr))); }
+          } else {  // BacktrackingLineSearch::take_optimal_step
+            bool returned = false;
+            if (conv.niter == 0) {
+              delta = init_fun(x);
+              if (!solve_rows(delta)) { fatal = true; returned = true; }
+              else {
+                ls_norm = sqrt(wms(delta, yerr));
+                if (conv.check_norm(ls_norm) == ConvStatus::Converged) { x = x - delta; st = ConvStatus::Converged; returned = true; }
+              }
+            }
+            if (!returned) {
+              const double x0 = x, delta0 = delta;
+              const double nrm = ls_norm;
+              const double phi0 = nrm * nrm * 0.5, two_phi0 = nrm * nrm, min_alpha = R.ls_steptol / nrm;
+              double alpha = 1.0;
+              bool found = false;
+              for (int i = 0; i < o.ic_max_linesearch_iterations; ++i) {
+                x = (-alpha) * delta0 + 1.0 * x;
+                delta = init_fun(x);
+                if (!solve_rows(delta)) { fatal = true; break; }
+                const double new_norm = sqrt(wms(delta, yerr));
+                const double phi1 = new_norm * new_norm * 0.5;
+                if (phi1 <= phi0 - o.ic_armijo_constant * alpha * two_phi0) { ls_norm = new_norm; st = conv.check_norm(new_norm); found = true; break; }
+                if (alpha < min_alpha) { fatal = true; break; }  // LinesearchFailedMinStep
+                alpha *= o.ic_step_reduction_factor;
+                x = x0;
+              }
+              if (!found) fatal = true;  // incl. LinesearchFailedMaxIterations
+            }
+          }
+          if (fatal) { result = 1; break; }
+          if (st == ConvStatus::Converged) { result = 0; break; }
+          if (st == ConvStatus::Diverged) { result = 1; break; }
+        }
+        if (result == 0) ok = true;
+        else if (result != 2) fatal_all = true;  // anything but NewtonMaxIterations is fatal (state.rs:131-140)
+        else yerr = x;
+      }
+      if (!ok) return false;
+      if (is_alg) { y = x; f0 = 0.0; }  // scatter_soln (:76-81) + zero the algebraic derivatives (state.rs:155-158)
+      else f0 = x;
+    }
+    }
+  return true;
+}
+
 template <int NP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bdf_wave_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ y_out,
@@ -114,115 +232,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   };
   if constexpr (kWmHasMass) {
-    // StateRefMut::set_consistent (state.rs:84-162) over InitOp (op/init.rs:14-135), Newton with the backtracking line search (line_search.rs:84-201):
-    // the per-lane restatement of dsh_resident.hpp (set_consistent<Mdl, WAVE>) with one row per lane.  sJ holds the InitOp Jacobian, sM its neg_mass
-    // block (both are recomputed for the integrator afterwards: jac_stale starts true).
-    __syncthreads();
-    xs[ln] = y;
-    __syncthreads();
-    double mdiag = 1.0;
-    for (int j = 0; j < n; ++j) {
-      auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-      const double mij = rowlive ? wm_mass_component(t, (int64_t)ln, Ej, Pf) : 0.0;
-      const double rij = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
-      sM[j * 64 + ln] = mij;
-      sJ[j * 64 + ln] = rij;
-      if (j == ln) mdiag = mij;
-    }
-    const bool is_alg = rowlive && mdiag == 0.0;  // partition_indices_by_zero_diagonal
-    const unsigned long long alg_mask = __ballot(is_alg);
-    if (alg_mask != 0ull) {
-      // InitOp::new: jac = (-M_u, df/dv; 0, dg/dv), neg_mass = (-M_u, 0; 0, 0) in the original ordering
-      for (int j = 0; j < n; ++j) {
-        const bool alg_j = (alg_mask >> j) & 1ull;
-        if (!alg_j) {
-          const double v = is_alg ? 0.0 : sM[j * 64 + ln] * (-1.0);
-          sJ[j * 64 + ln] = v;
-          sM[j * 64 + ln] = v;
-        } else {
-          sM[j * 64 + ln] = 0.0;  // sJ keeps df/dv, dg/dv
-        }
-      }
-      const double y_orig = y;
-      double x = is_alg ? y : f0, yerr = x, delta = 0.0;
-      // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out  (nalgebra gemv order)
-      auto init_fun = [&](double x_mine) __attribute__((always_inline)) -> double {
-        __syncthreads();
-        xs[ln] = is_alg ? x_mine : y_orig;
-        xs2[ln] = x_mine;
-        __syncthreads();
-        const double out = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, V0, Pf, false) : 0.0;
-        double acc = 1.0 * sM[0 * 64 + ln] * xs2[0] + 1.0 * out;
-        for (int j = 1; j < n; ++j) acc = 1.0 * sM[j * 64 + ln] * xs2[j] + acc;
-        return rowlive ? acc : 0.0;
-      };
-      auto init_solve = [&](double& v) __attribute__((always_inline)) -> bool {
-        const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
-        v = __shfl(v, myinv, 64);
-        return ok;
-      };
-      ConvState conv;
-      conv.eta = C.r.eta_reset;
-      conv.tol = o.nonlinear_solver_tolerance;
-      conv.max_iter = o.ic_max_newton_iterations;
-      conv.det = det;
-      bool ok = false, fatal_all = false;
-      for (int k = 0; k < o.ic_max_linear_solver_setups && !ok && !fatal_all; ++k) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) a[j] = (rowlive && j < n) ? sJ[j * 64 + ln] : 0.0;  // reset_jacobian: the InitOp Jacobian is constant
-        factor_rows();
-        conv.reset();
-        double ls_norm = 1.0;
-        int result = 2;  // 0 ok, 1 fatal (diverged / LU / line search), 2 NewtonMaxIterations
-        for (int it = 0; it < conv.max_iter; ++it) {
-          ConvStatus st = ConvStatus::Continue;
-          bool fatal = false;
-          if (!o.ic_use_linesearch) {  // NoLineSearch::take_optimal_step
-            delta = init_fun(x);
-            if (!init_solve(delta)) fatal = true;
-            else { x = x - delta; st = conv.check_new_iteration(sqrt(wms_wave(delta, yerr))); }
-          } else {  // BacktrackingLineSearch::take_optimal_step
-            bool returned = false;
-            if (conv.niter == 0) {
-              delta = init_fun(x);
-              if (!init_solve(delta)) { fatal = true; returned = true; }
-              else {
-                ls_norm = sqrt(wms_wave(delta, yerr));
-                if (conv.check_norm(ls_norm) == ConvStatus::Converged) { x = x - delta; st = ConvStatus::Converged; returned = true; }
-              }
-            }
-            if (!returned) {
-              const double x0 = x, delta0 = delta;
-              const double nrm = ls_norm;
-              const double phi0 = nrm * nrm * 0.5, two_phi0 = nrm * nrm, min_alpha = C.r.ls_steptol / nrm;
-              double alpha = 1.0;
-              bool found = false;
-              for (int i = 0; i < o.ic_max_linesearch_iterations; ++i) {
-                x = (-alpha) * delta0 + 1.0 * x;
-                delta = init_fun(x);
-                if (!init_solve(delta)) { fatal = true; break; }
-                const double new_norm = sqrt(wms_wave(delta, yerr));
-                const double phi1 = new_norm * new_norm * 0.5;
-                if (phi1 <= phi0 - o.ic_armijo_constant * alpha * two_phi0) { ls_norm = new_norm; st = conv.check_norm(new_norm); found = true; break; }
-                if (alpha < min_alpha) { fatal = true; break; }  // LinesearchFailedMinStep
-                alpha *= o.ic_step_reduction_factor;
-                x = x0;
-              }
-              if (!found) fatal = true;  // incl. LinesearchFailedMaxIterations
-            }
-          }
-          if (fatal) { result = 1; break; }
-          if (st == ConvStatus::Converged) { result = 0; break; }
-          if (st == ConvStatus::Diverged) { result = 1; break; }
-        }
-        if (result == 0) ok = true;
-        else if (result != 2) fatal_all = true;  // anything but NewtonMaxIterations is fatal (state.rs:131-140)
-        else yerr = x;
-      }
-      if (!ok) status = kRsInitialConditionDidNotConverge;
-      else if (is_alg) { y = x; f0 = 0.0; }  // scatter_soln (:76-81) + zero the algebraic derivatives (state.rs:155-158)
-      else f0 = x;
-    }
+    auto comp_of = [&]() __attribute__((always_inline)) { return rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, V0, Pf, false) : 0.0; };
+    auto mass_e = [&](int j) __attribute__((always_inline)) { auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; }; return rowlive ? wm_mass_component(t, (int64_t)ln, Ej, Pf) : 0.0; };
+    auto jac_e = [&](int j) __attribute__((always_inline)) { auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; }; return rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0; };
+    auto solve_rows = [&](double& v) __attribute__((always_inline)) -> bool { const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v); v = __shfl(v, myinv, 64); return ok; };
+    if (!wm_set_consistent<NP>(n, ln, rowlive, xs, xs2, sJ, sM, a, C.r, comp_of, mass_e, jac_e, factor_rows, solve_rows, wms_wave, y, f0)) status = kRsInitialConditionDidNotConverge;
   }
   {
     const bool is_neg_h = C.r.h0 < 0.0;

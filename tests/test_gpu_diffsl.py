@@ -260,7 +260,7 @@ F_i { (-k * x_i) * (1.0 + p) + q, p * p + p - x_i[0:1], q - 0.1 * p * x_i[7:8] }
 """
 
 
-def test_wavefront_per_member_bdf_integrates_daes_with_a_consistent_initialisation_on_the_device(H, O, fe, det_pow):
+def test_wavefront_per_member_integrators_take_daes_with_a_consistent_initialisation_on_the_device(H, O, fe, det_pow):
     """mass matrices in the wavefront-per-member kernel (run-time-sized DiffSL models, n <= 48).  The kernel makes the initial state
     consistent itself — InitOp's Newton iteration with the backtracking line search, one row per lane (state.rs:84-162, op/init.rs, line_search.rs:84-201) —
     and carries M in the residual M (y - y0 + psi) - c f and in M - cJ.  A heat equation with algebraic boundary unknowns, and a ten-state DAE whose two
@@ -271,11 +271,12 @@ def test_wavefront_per_member_bdf_integrates_daes_with_a_consistent_initialisati
                             (DAE10, np.linspace(0.5, 3.0, 11)[:, None], [0.1, 0.5, 2.0])):
         m, mid = fe.DiffslModel(code, lane_resident=False), D.host_model(O, code)
         assert m.has_mass and m.form == fe.FORM_DYNAMIC
-        s = H.Solver(m, p, nbatch=len(p), **tol)
-        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
-        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=4, group=1, method=0, **tol)
-        assert failed == 0 and (mem["status"] == 0).all()
-        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+        for hm, om in ((H.METHOD_BDF, 0), (H.METHOD_TR_BDF2, 1), (H.METHOD_ESDIRK34, 2)):  # k_bdf_wave_member, k_sdirk_wave_member<., 3>, <., 4>
+            s = H.Solver(m, p, nbatch=len(p), method=hm, **tol)
+            y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+            yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=4, group=1, method=om, **tol)
+            assert failed == 0 and (mem["status"] == 0).all(), (hm, mem["status"])
+            assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2))), hm
     assert abs(yo[0, 0, 8] ** 2 + yo[0, 0, 8] - yo[0, 0, 0]) < 1e-5  # on the constraint
 
 
