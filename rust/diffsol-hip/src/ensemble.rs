@@ -1,5 +1,5 @@
 //! `solve_dense` of a whole ensemble in ONE launch: the device-resident integrators of libdiffsol_hip.so
-//! (`dsh_bdf_solve_adaptive`, `dsh_sdirk_solve_resident`, `dsh_bdf_solve_wave_member`).  diffsol's generic `Bdf` / `Sdirk` on `HipVec` / `HipMat` /
+//! (`dsh_bdf_solve_adaptive`, `dsh_sdirk_solve_resident`, `dsh_bdf_solve_wave_member`, `dsh_sdirk_solve_wave_member`).  diffsol's generic `Bdf` / `Sdirk` on `HipVec` / `HipMat` /
 //! `HipLU` advance the ensemble in lock-step with one host round trip per reduction; here `Bdf::step` / `Sdirk::step`, `NewtonNonlinearSolver`,
 //! `Convergence`, `JacobianUpdate`, `RootFinder` and `OdeSolverMethod::solve_dense` (method.rs:467-520) run per member — or per 64-member wavefront
 //! group, the reference's batched semantics at nbatch = 64 — with the solver state in registers.  Results are bit-identical to the CPU restatement
@@ -81,7 +81,7 @@ pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, metho
     let (stats_d, status_d, troot_d, ridx_d, ncols_d) = (alloc(20 * nb), alloc(4 * nb), alloc(8 * nb), alloc(4 * nb), alloc(4 * nb));
     let mut totals = [0i64; 6];
     let atol = &problem.atol;
-    // which kernel: the banded lane-per-member twin of a run-time-sized model, the register-resident kernels (n <= 4), or one wavefront per member (n <= 64, BDF)
+    // which kernel: the banded lane-per-member twin of a run-time-sized model, the register-resident kernels (n <= 4), or one wavefront per member (n <= 64)
     let twin = unsafe { ffi::dsh_model_lane_twin(eqn.model, eqn.size) };
     let (model, size) = if twin >= 0 && unsafe { ffi::dsh_model_has_resident(method as i32, twin, 0) } != 0 { (twin, 0) } else { (eqn.model, eqn.size) };
     let rc = if unsafe { ffi::dsh_model_has_resident(method as i32, model, size) } != 0 {
@@ -100,11 +100,20 @@ pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, metho
                 )
             }
         }
-    } else if method == Method::Bdf && mode == EnsembleMode::PerMember && unsafe { ffi::dsh_model_has_wave_member(eqn.model, eqn.size) } != 0 && !eqn.has_mass {
+    } else if method == Method::Bdf && mode == EnsembleMode::PerMember && unsafe { ffi::dsh_model_has_wave_member(eqn.model, eqn.size) } != 0 {
+        // one wavefront per member: dense run-time-sized models with n <= 64, DiffSL DAEs (n <= 48) included — made consistent on the device
         unsafe {
             ffi::dsh_bdf_solve_wave_member(
                 c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64, ys.ptr(),
                 stats_d as *mut i32, status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else if method != Method::Bdf && mode == EnsembleMode::PerMember && unsafe { ffi::dsh_model_has_wave_member_sdirk(eqn.model, eqn.size) } != 0 {
+        // the same for TR-BDF2 / ESDIRK34
+        unsafe {
+            ffi::dsh_sdirk_solve_wave_member(
+                c, eqn.model, eqn.size, method as i32, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64,
+                ys.ptr(), stats_d as *mut i32, status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
             )
         }
     } else {
