@@ -171,6 +171,12 @@ def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
         h.precompile(fe.FAMILY_FUSED)
     assert "run-time-sized" in str(e.value)
     h.precompile(fe.FAMILY_RESIDENT_BDF)  # the wavefront-per-member BDF, instantiated for the DiffSL model
+    h.precompile(fe.FAMILY_RESIDENT_SDIRK)  # ... and TR-BDF2 / ESDIRK34 (k_sdirk_wave_member<32, 3>, <32, 4>)
+    dae = fe.DiffslModel(D.HEAT_DAE, lane_resident=False)  # a DAE: the wavefront-per-member kernels with the mass-matrix path (consistent initialisation, M in the residuals)
+    assert dae.form == fe.FORM_DYNAMIC and dae.has_mass
+    dae.precompile(fe.FAMILY_RESIDENT_BDF)
+    dae.precompile(fe.FAMILY_RESIDENT_SDIRK)
+    dae.release()
     # tridiagonal Jacobian, identity mass: the model is also compiled in the lane-per-member banded form (BAND_K, jac_band)
     assert h.lane_model_id is not None and "BAND_K = 1" in fe.generate(D.heat1d(24), fe.TARGET_HIP_STATIC)[0]
     from diffsol_amd import _ffi
