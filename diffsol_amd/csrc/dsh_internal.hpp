@@ -92,6 +92,7 @@ struct dsh_lu {
   // n  > 8 (cooperative kernels): system-major, factors b*n*n + j*n + i, pivots b*n + k.   pivots[k] = row swapped with row k at step k.
   double* factors = nullptr;
   int32_t* pivots = nullptr;
+  double* work = nullptr;  // row-major working copies of the systems for the matrix-core kernel (dsh_lu_tiled.hpp), allocated by its first use
   bool system_major = false;
   // device word: (epoch << 32) | number of systems with a zero pivot found by the factorisation launch of that epoch.  A launch of a
   // newer epoch replaces an older word (CAS loop, only executed by waves that actually found a singular system), so no reset

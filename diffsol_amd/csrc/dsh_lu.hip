@@ -14,6 +14,7 @@
 #include "dsh_lu_coop.hpp"
 #include "dsh_lu_wave.hpp"
 #include "dsh_lu_band.hpp"
+#include "dsh_lu_tiled.hpp"
 
 using namespace dsh;
 
@@ -98,10 +99,16 @@ int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
   return DSH_OK;
 }
 __attribute__((visibility("hidden"))) int lu_ensure_storage(dsh_lu* lu) {
-  if (lu->factors) return DSH_OK;
+  if (lu->factors && lu->pivots) return DSH_OK;
   const int64_t n = lu->n, nbatch = lu->nbatch;
-  DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
-  DSH_HIP_CHECK(hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)));
+  if (!lu->factors) DSH_HIP_CHECK(hipMalloc((void**)&lu->factors, sizeof(double) * (size_t)(n * n * nbatch > 0 ? n * n * nbatch : 1)));
+  if (hipMalloc((void**)&lu->pivots, sizeof(int32_t) * (size_t)(n * nbatch > 0 ? n * nbatch : 1)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(lu->factors);  // all or nothing: a later call must not find half of the storage and report success
+    lu->factors = nullptr; lu->pivots = nullptr;
+    set_error("lu_ensure_storage: out of device memory for the pivots");
+    return DSH_E_HIP;
+  }
   return DSH_OK;
 }
 void dsh_lu_destroy(dsh_lu* lu) {
@@ -109,6 +116,7 @@ void dsh_lu_destroy(dsh_lu* lu) {
   (void)hipStreamSynchronize(lu->ctx->stream);
   (void)hipFree(lu->factors);
   (void)hipFree(lu->pivots);
+  (void)hipFree(lu->work);
   (void)hipFree(lu->singular);
   (void)hipFree(lu->band_probe);
   delete lu;
@@ -192,6 +200,48 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
             default: hipLaunchKernelGGL((k_lu_band_factor<4>), bg, bblk, 0, ctx->stream, n, nb, a, lu->factors, lu->pivots, lu->singular, lu->singular_epoch); break;
           }
           break;
+        }
+      }
+      // Default for 288 <= n <= 1024: the matrix-core kernel on a row-major working copy (dsh_lu_tiled.hpp): same pivots, factors within rounding of the
+      // exact kernels' (fused multiply-adds, the matrix cores' summation order).  DSH_LU_EXACT=1 keeps the kernels below, bit-identical to the CPU path;
+      // DSH_LU_TILED_MIN moves the lower end (measured crossover with the exact blocked kernel: 13.3 vs 16.8 ms at 256 x 4096, 33.4 vs 19.0 ms at 320 x 4096).  Both read per call so that tests can compare.
+      {
+        const char* ex = getenv("DSH_LU_EXACT");
+        const char* tm = getenv("DSH_LU_TILED_MIN");
+        const int64_t tiled_min = tm && *tm ? atoll(tm) : 288;
+        if (!(ex && ex[0] == '1') && n >= std::max<int64_t>(tiled_min, 65) && n <= kTlMaxN) {
+          const int ldw = tiled_ldw(n);
+          if (!lu->work) {
+            if (hipMalloc((void**)&lu->work, sizeof(double) * (size_t)n * ldw * nb) != hipSuccess) { (void)hipGetLastError(); lu->work = nullptr; }
+          }
+          if (lu->work) {  // no room for the working copy: the in-place exact kernels below
+            static bool tl_attr_dev[64] = {false};
+            bool& tl_attr = tl_attr_dev[ctx->device & 63];
+            if (!tl_attr) {
+              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_lds_bytes()));
+              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_tiled<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_lds_bytes()));
+              tl_attr = true;
+            }
+            static const bool tl_prof = [] { const char* e = getenv("DSH_LU_PHASE_PROFILE"); return e && atoi(e) != 0; }();
+            unsigned long long* clk = nullptr;
+            if (tl_prof) { DSH_HIP_CHECK(hipMalloc(&clk, 8 * sizeof(unsigned long long))); DSH_HIP_CHECK(hipMemset(clk, 0, 8 * sizeof(unsigned long long))); }
+            const dim3 sg((unsigned)((nb + 31) / 32), (unsigned)((ldw + 31) / 32), (unsigned)n);
+            hipLaunchKernelGGL(k_lu_stage_rowmajor, sg, dim3(256), 0, ctx->stream, (int)n, ldw, nb, a, lu->work);
+            if (n <= kTlThreads)
+              hipLaunchKernelGGL((k_lu_factor_tiled<1>), dim3((unsigned)nb), dim3(kTlThreads), tiled_lds_bytes(), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+                                 lu->pivots, lu->singular, lu->singular_epoch, clk);
+            else
+              hipLaunchKernelGGL((k_lu_factor_tiled<2>), dim3((unsigned)nb), dim3(kTlThreads), tiled_lds_bytes(), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+                                 lu->pivots, lu->singular, lu->singular_epoch, clk);
+            if (tl_prof) {
+              unsigned long long h[8];
+              DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+              DSH_HIP_CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+              DSH_HIP_CHECK(hipFree(clk));
+              fprintf(stderr, "[dsh_lu tiled phase us, workgroup 0] panel %.1f  finish %.1f  u12 %.1f  update %.1f\n", h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0);
+            }
+            break;
+          }
         }
       }
       // system-major copy of the operand, then factor in place

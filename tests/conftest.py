@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The parity tests compare bit patterns with the CPU oracle: they run the dense LU for n >= 288 in its exact mode (DSH_LU_EXACT=1, read per call by
+# dsh_lu_factor).  The default mode — the matrix-core kernel of dsh_lu_tiled.hpp, tested to a tolerance — is exercised by the tests that delete the
+# variable again (test_gpu_lu_models.py, test_gpu_configs.py).
+os.environ.setdefault("DSH_LU_EXACT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 

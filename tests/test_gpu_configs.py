@@ -58,6 +58,24 @@ def test_config3_heat1d_n512_tr_bdf2_members_equal_the_oracle_bitwise(H, O, monk
     assert np.abs(y[1] - heat_fourier(512, D, 0.5)).max() < 2e-5
 
 
+def test_config3_dense_mode_on_the_default_matrix_core_lu_stays_within_rounding_of_the_oracle(H, O, monkeypatch):
+    """BASELINE configs[2] says "banded-as-dense LU": with DSH_LU_STRUCTURE=dense and the library's DEFAULT dense LU for n = 512 (the matrix-core kernel of
+    dsh_lu_tiled.hpp; every other test of this file pins the exact mode) the integrator must take the oracle's step sequence — all counters equal — and
+    return its states to 1e-9 relative (north_star: 1e-6): the factors differ from the exact ones in the last bits only."""
+    monkeypatch.delenv("DSH_LU_EXACT", raising=False)
+    monkeypatch.setenv("DSH_LU_STRUCTURE", "dense")
+    D = heat_params(4096)[:8]
+    kw = dict(nbatch=8, model_size=512, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)
+    s = H.Solver("heat1d", D[:, None], **kw)
+    times = [0.01, 0.5]
+    y, _ = s.solve_to_points(times)
+    o = O.OracleSolver(ORACLE_MODEL["heat1d"], D[:, None], **kw)
+    yo, _ = o.solve_to_points(times)
+    assert s.stats() == o.stats()
+    assert np.max(np.abs(y - yo)) <= 1e-9 * np.max(np.abs(yo))
+    assert np.abs(y[1] - heat_fourier(512, D, 0.5)).max() < 2e-5
+
+
 @pytest.fixture(scope="module")
 def config3_full(H):
     out = {}
