@@ -10,9 +10,8 @@
 //     factor storage F — and simply leaves the list of active rows.  No interchange costs memory traffic.  Every thread keeps, for the rows it owns,
 //     the position the reference's interchanges would have put them at (`pos`), so that ties are broken and pivots are recorded exactly as the
 //     sequential algorithm does (pivots[k] = position swapped with k at step k).
-//   * panels of 64 columns (8 round trips at n = 512), factored as two sub-panels of 32 columns in REGISTERS, one thread per row (two rows for n > 512):
-//     per pivot ONE workgroup barrier — every wavefront reduces its candidates with DPP, the lane that owns the wavefront's best row publishes that row
-//     to LDS, and after the barrier all threads pick the same winner among the eight published rows and eliminate with it.
+//   * panels of 64 columns (8 round trips at n = 512), factored as two sub-panels of 32 columns in REGISTERS with the columns dealt to the wavefronts
+//     (tl_panel below): per pivot ONE workgroup barrier and one exchange through LDS — the column of multipliers.
 //   * U12 = L11^-1 A12 and the trailing update A22 -= L21 U12 run on v_mfma_f64_16x16x4_f64.  U12 is a blocked substitution with 16 x 16 blocks (the
 //     inverses of the four unit-triangular diagonal blocks and the six blocks below them are the A operands; an accumulator register of one product is,
 //     as it stands, the B operand of the next: d(l, r) = D[4 r + l/16][l%16] = b(l) of k-block r), kept in LDS for a chunk of 208 columns; the update
@@ -119,8 +118,20 @@ __device__ __forceinline__ void tl_update_tiles(tl_gdouble* __restrict__ W, cons
   }
 }
 
-// (value, position) arg-max over the wavefront, smallest position on ties, without branches: four DPP stages inside each row of 16 lanes, then the
-// four row results through v_readlane.  Every lane returns the wavefront's result.
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The panel.  A sub-panel of 32 columns lives in registers with the COLUMNS dealt to the wavefronts — wavefront w holds columns w, w + 8, w + 16, w + 24
+// of it, all rows (lane l: rows l, l + 64, ...; RS of them) — because then a pivot step needs ONE exchange: the wavefront that owns column k finds the
+// pivot by itself (DPP reduction, no LDS), forms the multipliers of all rows and publishes them (a column of the LDS buffer Lbuf, which is also where the
+// flush to W reads them from) together with {lane, slot} of the pivot row; behind ONE barrier every wavefront reads its rows' multipliers, takes the pivot
+// row's entry of each of its own columns out of its own registers (v_readlane at the published lane; the slot selects the register through a uniform
+// switch) and eliminates.  Measured before this form (one thread per row, the pivot row broadcast through LDS): 2.1-2.5 us per pivot step in three
+// variants — two exchanges per step, the second one a 1 KB broadcast read per wavefront.
+// Rows never move; where the interchanges of the reference would have put them is kept in LDS: pos[row] (rows with pos < the current step are finished)
+// and its inverse rowat[pos]; only the owner of a step reads them, one lane updates them.
+// Layout of the dynamic LDS during the panel (doubles): [0, 16384) T / Lbuf — [32][512] (RS = 8) or [16][1024] (RS = 16): first the transposing stage
+// (thread per row in, column per wavefront out), then the multipliers, column kk at kk * P — and before the stage of the second sub-panel the operands of
+// its matrix-core update (L11A, the inverses of its diagonal blocks, U'); [16384, 17440) Ubuf [32][33]: the pivot rows' entries of the sub-panel's own
+// columns (U11), written by the column owners step by step.
 template <int CTRL>
 __device__ __forceinline__ void tl_argmax_stage(double& v, int& p) {
   const double ov = __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(v)));
@@ -133,234 +144,368 @@ template <int CTRL>
 __device__ __forceinline__ double tl_dpp_max(double v) {
   return __builtin_fmax(v, __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(v))));
 }
-// The common case first: the maximum alone (one v_max per stage), then a ballot of the lanes that hold it; only a tie (several lanes with the same
-// magnitude) takes the reduction that carries the positions along.  No NaN reaches this (mapped to -1 before).
-__device__ __forceinline__ void tl_wave_argmax(double& v, int& p) {
+__device__ __forceinline__ double tl_readlane_f64(double x, int lane) {
+  return __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(x), lane));
+}
+// Lane of the wavefront's best candidate (largest v, smallest position p on ties).  The common case first: the maximum alone (one v_max per DPP stage),
+// then a ballot of the lanes that hold it; only a tie takes the reduction that carries the positions along.  No NaN reaches this (mapped to -1 before).
+__device__ __forceinline__ int tl_wave_argmax_lane(double v, int p) {
   double m = tl_dpp_max<kDppQuadXor1>(v);
   m = tl_dpp_max<kDppQuadXor2>(m);
   m = tl_dpp_max<kDppRowHalfMirror>(m);
   m = tl_dpp_max<kDppRowMirror>(m);
-  const double m0 = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(m), 0));
-  const double m1 = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(m), 16));
-  const double m2 = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(m), 32));
-  const double m3 = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(m), 48));
-  const double wm = __builtin_fmax(__builtin_fmax(m0, m1), __builtin_fmax(m2, m3));
-  const unsigned long long holders = __ballot(v == wm);
-  if (__popcll(holders) == 1) {
-    p = __builtin_amdgcn_readlane(p, __ffsll((long long)holders) - 1);
-    v = wm;
-    return;
-  }
-  tl_argmax_stage<kDppQuadXor1>(v, p);
-  tl_argmax_stage<kDppQuadXor2>(v, p);
-  tl_argmax_stage<kDppRowHalfMirror>(v, p);
-  tl_argmax_stage<kDppRowMirror>(v, p);
-  double bv = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), 0));
-  int bp = __builtin_amdgcn_readlane(p, 0);
+  const double wm = __builtin_fmax(__builtin_fmax(tl_readlane_f64(m, 0), tl_readlane_f64(m, 16)), __builtin_fmax(tl_readlane_f64(m, 32), tl_readlane_f64(m, 48)));
+  unsigned long long holders = __ballot(v == wm);
+  if (__popcll(holders) != 1) {  // several lanes hold the largest magnitude: the smallest position among them
+    int q = (v == wm) ? p : 0x7fffffff;
+    double dummy = 0.0;
+    tl_argmax_stage<kDppQuadXor1>(dummy, q);
+    tl_argmax_stage<kDppQuadXor2>(dummy, q);
+    tl_argmax_stage<kDppRowHalfMirror>(dummy, q);
+    tl_argmax_stage<kDppRowMirror>(dummy, q);
+    int bq = __builtin_amdgcn_readlane(q, 0);
 #pragma unroll
-  for (int r = 1; r < 4; ++r) {
-    const double ov = __longlong_as_double((long long)readlane_u64((unsigned long long)__double_as_longlong(v), 16 * r));
-    const int op = __builtin_amdgcn_readlane(p, 16 * r);
-    const bool better = (ov > bv) | ((ov == bv) & (op < bp));
-    bv = better ? ov : bv;
-    bp = better ? op : bp;
+    for (int r = 1; r < 4; ++r) { const int oq = __builtin_amdgcn_readlane(q, 16 * r); bq = oq < bq ? oq : bq; }
+    holders = __ballot((v == wm) & (p == bq));
   }
-  v = bv;
-  p = bp;
+  return __ffsll((long long)holders) - 1;
 }
 
-// The pivot steps of a sub-panel held in registers, as ONE rolled loop (a loop body per step, unrolled so that the register arrays get static indices, was
-// 100 KB of code).  The array ROTATES instead: a[i][0] is always the pivot column, every step writes a[i][c-1] = a[i][c] - u[c] l and shifts a zero in at
-// the right, so register indices are static while the step index is not.  What leaves the array goes to W at once: the multiplier of every active row (one
-// 8-byte store per row and step), and the winner's row — its U entries from the pivot column on — copied from LDS by one wavefront.  Rows that are
-// finished keep rotating garbage nobody reads.
-// Per step two exchanges through LDS, each closed by a barrier that waits for LDS only (never for the global stores): (1) every wavefront reduces its
-// candidates with DPP and publishes {|value|, position}; everybody picks the same winner; (2) the one thread that owns the winning row publishes the row
-// (its 32 - k live columns), its reciprocal pivot and its row index.  (Publishing all eight wavefronts' candidate rows before a single barrier was
-// measured: 2.4 us per step, the LDS port busy with 136 one-lane 16-byte writes.)
-// s_slot[0][w] = header of wavefront w; s_slot[1][0] = {-, inverse pivot, row index} + the row at [4..36).
+template <int RS> struct tl_colvec;
+template <> struct tl_colvec<8> { typedef double type __attribute__((ext_vector_type(8))); };
+template <> struct tl_colvec<16> { typedef double type __attribute__((ext_vector_type(16))); };
+// a register column of the panel: RS rows of one lane.  A VECTOR, so that a wavefront-uniform run-time slot becomes relative register addressing
+// (v_movrels) instead of a switch over the slots — whose joins cost ~60 register moves per step.
+template <int RS> using tl_col = typename tl_colvec<RS>::type;
+
+constexpr int kTlUs = 2048, kTlUsP = 48, kTlUbuf = 16384;  // offsets (doubles) into the dynamic LDS and the pitch of Us (conflict-free operand reads)
+
 #ifdef TL_X_STEPPROF
-__device__ unsigned long long tl_stepprof[5];
+__device__ unsigned long long tl_stepprof[8];
 #endif
-template <int R>
-__device__ __forceinline__ void tl_subpanel_steps(double (&a)[R][kTlSW], bool (&act)[R], int (&pos)[R], bool& singular, double (*s_slot)[kTlWaves][36], int* s_prow,
-                                                  int* s_ipiv, tl_gdouble* __restrict__ W, int ldw, int ws, int cb, int pbase, int tid, int wave, int lane) {
-  double* const rowbuf = &s_slot[1][0][0];
+// Pivot search of step k by the wavefront that owns its column (register column JC), and everything that has to be published for it: the multipliers
+// (column kk of Lbuf), {lane, slot} of the pivot row, the interchange bookkeeping.  `done`: bit s set = row slot s of this lane is finished (every
+// wavefront keeps these bits from the published {lane, slot} pairs); finished rows are no candidates and get zero multipliers, so nothing ever
+// changes them again.  The search is a maximum of magnitudes — v_max ignores NaNs, as the sequential scan does.
+// Positions (LDS) are looked at only when they decide: several rows of the largest magnitude, or a column without a positive entry.
+template <int RS, int JC>
+__device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned done, int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
+                                             int* s_ipiv, int* s_hdr, int* s_flags, int lane) {
+  constexpr int P = 64 * RS;
+  const int g = cb + k;
+  const int kk = RS == 8 ? k : (k & 15);
+  double* const lcol = dyn + kk * P + lane;
 #ifdef TL_X_STEPPROF
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0};
-#define TL_T(ix) { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[ix] += now_ - t0_; t0_ = now_; }
+  const unsigned long long ts0_ = __builtin_readcyclecounter();
+#endif
+  const int rg = s_rowat[g];  // the row at the diagonal position (used at the end: its latency hides behind the search)
+  double m = -1.0;
+#pragma unroll
+  for (int s = 0; s < RS; ++s) m = __builtin_fmax(m, (done >> s) & 1u ? -1.0 : __builtin_fabs(a[JC][s]));
+  m = tl_dpp_max<kDppQuadXor1>(m);
+  m = tl_dpp_max<kDppQuadXor2>(m);
+  m = tl_dpp_max<kDppRowHalfMirror>(m);
+  m = tl_dpp_max<kDppRowMirror>(m);
+  const double wm = __builtin_fmax(__builtin_fmax(tl_readlane_f64(m, 0), tl_readlane_f64(m, 16)), __builtin_fmax(tl_readlane_f64(m, 32), tl_readlane_f64(m, 48)));
+  unsigned long long M[RS];
+  int cnt = 0;
+#pragma unroll
+  for (int s = 0; s < RS; ++s) { M[s] = __ballot(!((done >> s) & 1u) & (__builtin_fabs(a[JC][s]) == wm)); cnt += __popcll(M[s]); }
+  int ls = 0, ss = 0;
+  double piv = 0.0;
+  if (cnt == 1 && wm > 0.0) {  // the common case: one row holds the largest magnitude
+#pragma unroll
+    for (int s = 0; s < RS; ++s)
+      if (M[s] != 0ull) { ss = s; ls = __ffsll((long long)M[s]) - 1; piv = tl_readlane_f64(a[JC][s], ls); }
+  } else {
+    // the smallest position among the candidates: the rows of the largest magnitude, or — no number in the column (all NaN) — every row not finished
+    int bp = 0x7fffffff, bs = 0;
+#pragma unroll
+    for (int s = 0; s < RS; ++s) {
+      const int ps = s_pos[lane + 64 * s];
+      const bool c = (ps >= g) & (wm >= 0.0 ? __builtin_fabs(a[JC][s]) == wm : true);
+      const bool take = c & (ps < bp);
+      bp = take ? ps : bp;
+      bs = take ? s : bs;
+    }
+    int q = bp;
+    double dummy = 0.0;
+    tl_argmax_stage<kDppQuadXor1>(dummy, q);
+    tl_argmax_stage<kDppQuadXor2>(dummy, q);
+    tl_argmax_stage<kDppRowHalfMirror>(dummy, q);
+    tl_argmax_stage<kDppRowMirror>(dummy, q);
+    int bq = __builtin_amdgcn_readlane(q, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { const int oq = __builtin_amdgcn_readlane(q, 16 * r); bq = oq < bq ? oq : bq; }
+    ls = __ffsll((long long)__ballot(bp == bq)) - 1;
+    ss = __builtin_amdgcn_readlane(bs, ls);
+    piv = tl_readlane_f64(a[JC][ss], ls);
+  }
+  const bool zero = piv == 0.0;
+  const double inv = zero ? 0.0 : div_refined_rcp(piv);  // a zero pivot eliminates nothing (its column is all zeros)
+#pragma unroll
+  for (int s = 0; s < RS; ++s) lcol[64 * s] = (done >> s) & 1u ? 0.0 : a[JC][s] * inv;
+  if (lane == ls) lcol[64 * ss] = 0.0;  // the pivot row itself
+  const int rstar = ls + 64 * ss;
+  const int ps = s_pos[rstar];
+  if (lane == 0) {
+    s_hdr[2 * (k & 1)] = ls;
+    s_hdr[2 * (k & 1) + 1] = ss;
+    dyn[kTlUbuf + k * 33 + k] = piv;
+    if (zero) s_flags[0] = 1;
+    s_pos[rstar] = (short)g;  // the row at the diagonal position trades places with the winner
+    if (rg != rstar) { s_pos[rg] = (short)ps; s_rowat[ps] = (short)rg; }
+    s_rowat[g] = (short)rstar;
+    s_prow[pbase + k] = rstar;
+    s_ipiv[pbase + k] = ps;
+  }
+#ifdef TL_X_STEPPROF
+  if (threadIdx.x == 0 && blockIdx.x == 0) { tl_stepprof[4] += __builtin_readcyclecounter() - ts0_; tl_stepprof[5] += 1; }
+#endif
+}
+
+template <int RS, int J>
+__device__ __forceinline__ void tl_co_update_col(tl_col<RS> (&a)[4], const double (&l)[RS], const double (&u)[4], double* __restrict__ dyn, int k, int wave, int lane) {
+  if (lane == 0) dyn[kTlUbuf + k * 33 + wave + 8 * J] = u[J];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) a[J][s] = __builtin_fma(-u[J], l[s], a[J][s]);
+}
+
+// Pivot step k = 8 JO + wo of the sub-panel at column cb, behind the barrier that published it (JO static: register column of its owner): every
+// wavefront eliminates in its columns behind k.  The wavefront that owns column k + 1 updates that column first and runs the search of step k + 1
+// before it touches its other columns (pipe == true), so the next step's exchange is ready when the others arrive at the barrier.
+template <int RS, int JO>
+__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], unsigned& done, int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
+                                           int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
+  constexpr int P = 64 * RS;
+  const int k = 8 * JO + wo;
+  const int kk = RS == 8 ? k : (k & 15);
+  const double* const lcol = dyn + kk * P + lane;
+#ifdef TL_X_STEPPROF
+  unsigned long long t0_ = __builtin_readcyclecounter();
+#define TL_T(ix) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x == 0) tl_stepprof[ix] += now_ - t0_; t0_ = now_; }
 #else
 #define TL_T(ix)
 #endif
-#pragma nounroll
-  for (int k = 0; k < ws; ++k) {
-#ifdef TL_X_STEPPROF
-    unsigned long long t0_ = __builtin_readcyclecounter();
-#endif
-    const int g = cb + k;
-    const int nact = kTlSW - k;  // live columns of the rotating arrays
-    double wv = -2.0;
-    int wp = 0x7fffffff;
-    double rinv[R];  // the step's division, for every row before anybody knows the winner: off the chain of dependent exchanges
+  const int ls = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 1)]), ss = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 1) + 1]);
+  double l[RS];
 #pragma unroll
-    for (int i = 0; i < R; ++i) rinv[i] = 1.0 / a[i][0];
+  for (int s = 0; s < RS; ++s) l[s] = lcol[64 * s];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  TL_T(0)
+  // the pivot row's entries in this wavefront's columns, out of its own registers (relative register addressing by the uniform slot); the row is finished
+  double u[4];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      double v = __builtin_fabs(a[i][0]);
-      v = (v == v) ? v : -1.0;  // a NaN never beats a number; if nothing else is left the row at the diagonal position wins, like the sequential scan
-      v = act[i] ? v : -2.0;
-      const int pi = act[i] ? pos[i] : 0x7fffffff;
-      const bool better = (v > wv) | ((v == wv) & (pi < wp));
-      wv = better ? v : wv;
-      wp = better ? pi : wp;
-    }
-    tl_wave_argmax(wv, wp);
-    TL_T(0)
-    if (lane == 0) { tl_d2 h; h[0] = wv; h[1] = __hiloint2double(0, wp); *reinterpret_cast<tl_d2*>(&s_slot[0][wave][0]) = h; }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    TL_T(1)
-    // the same winner in every thread: lane l reads the header of wavefront l % 8 (ONE LDS round trip; eight reads in a row came out as four), three DPP
-    // stages reduce every group of eight lanes
-    int bpos;
-    {
-      const tl_d2 h = *reinterpret_cast<const tl_d2*>(&s_slot[0][lane & (kTlWaves - 1)][0]);
-      double hv = h[0];
-      int hp = __double2loint(h[1]);
-      tl_argmax_stage<kDppQuadXor1>(hv, hp);
-      tl_argmax_stage<kDppQuadXor2>(hv, hp);
-      tl_argmax_stage<kDppRowHalfMirror>(hv, hp);
-      bpos = __builtin_amdgcn_readfirstlane(hp);
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-      if (act[i] && pos[i] == bpos) {  // one thread of the workgroup
-        rowbuf[1] = rinv[i];
-        rowbuf[2] = __hiloint2double(0, tid + kTlThreads * i);
-#pragma unroll
-        for (int c = 0; c < kTlSW; c += 2)
-          if (c < nact) { tl_d2 v; v[0] = a[i][c]; v[1] = a[i][c + 1]; *reinterpret_cast<tl_d2*>(rowbuf + 4 + c) = v; }
+  for (int j = 0; j < 4; ++j) u[j] = tl_readlane_f64(a[j][ss], ls);
+  done |= lane == ls ? 1u << ss : 0u;
+  TL_T(1)
+  const bool next_owner = pipe && wave == ((wo + 1) & 7) && k + 1 < ws;
+  if (next_owner) {
+    if (wo == 7) {  // wavefront 0, its next register column
+      if constexpr (JO < 3) {
+        tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
+        tl_co_search<RS, JO + 1>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+        if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
+        if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
       }
-    TL_T(2)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    TL_T(3)
-    const double inv = rowbuf[1];
-    const int brow = __builtin_amdgcn_readfirstlane(__double2loint(rowbuf[2]));
-    double u[kTlSW];
-#pragma unroll
-    for (int c = 0; c < kTlSW; c += 2) {
-      if (c < nact) { const tl_d2 v = *reinterpret_cast<const tl_d2*>(rowbuf + 4 + c); u[c] = v[0]; u[c + 1] = v[1]; }
-      else { u[c] = 0.0; u[c + 1] = 0.0; }
+    } else {
+      tl_co_update_col<RS, JO>(a, l, u, dyn, k, wave, lane);
+      tl_co_search<RS, JO>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+      if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
+      if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
+      if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
     }
-    const double diag = u[0];
-    const bool zero = diag == 0.0;
-    if (zero) singular = true;
-    if (tid == 0) { s_ipiv[pbase + k] = bpos; s_prow[pbase + k] = brow; }
-    if (wave == (k & (kTlWaves - 1)) && lane < nact) W[(size_t)brow * ldw + g + lane] = rowbuf[4 + lane];  // the winner's row from its diagonal entry on
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const bool winner = act[i] & (pos[i] == bpos);
-      const double l = zero ? a[i][0] : a[i][0] * inv;  // a zero pivot leaves its column (all zeros) as it is
-      if (act[i] & !winner) W[(size_t)(tid + kTlThreads * i) * ldw + g] = l;
-      if (act[i]) {
-        if (winner) { act[i] = false; pos[i] = g; }
-        else if (pos[i] == g) pos[i] = bpos;
-      }
-      const double le = zero ? 0.0 : l;
-#pragma unroll
-      for (int c = 1; c < kTlSW; ++c) a[i][c - 1] = __builtin_fma(-u[c], le, a[i][c]);
-      a[i][kTlSW - 1] = 0.0;
-    }
-    // the row buffer is rewritten only behind the first barrier of the next step, the headers behind the second of this one: single buffers are enough
-    TL_T(4)
+  } else {
+    if (wave > wo) tl_co_update_col<RS, JO>(a, l, u, dyn, k, wave, lane);
+    if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
+    if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
+    if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
   }
-#ifdef TL_X_STEPPROF
-  if (tid == 0 && blockIdx.x == 0) for (int e = 0; e < 5; ++e) atomicAdd(&tl_stepprof[e], tacc[e]);
-#endif
+  TL_T(2)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: never wait for global stores here
+  TL_T(3)
 }
 
-// The panel of 64 columns at jb.  Not inlined: its registers (the rows' 32 columns, the pivot row) are allocated apart from the rest of the kernel —
-// a spill reload inside the step loop would wait for the global stores of the previous steps (one counter for loads and stores: ~10 us per step).
-// st: positions, activity flags of this thread's R rows, the singular flag (in / out).
-template <int R>
-__device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, int n, int jb, double* dyn, double (*s_slot)[kTlWaves][36], int* s_prow, int* s_ipiv, int* st) {
-  tl_gdouble* const W = (tl_gdouble*)W_generic;
-  double* const u12s = dyn;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  bool act[R];
-  int pos[R];
+// Multipliers (and, for the rows chosen in this sub-panel, their U entries from their step on) of the steps [k0, k0 + cnt) from LDS to the rows of W.
+template <int RS>
+__device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, int n, int cb, int k0, int cnt, const double* __restrict__ dyn, const short* s_pos, int tid) {
+  constexpr int P = 64 * RS;
 #pragma unroll
-  for (int i = 0; i < R; ++i) { pos[i] = st[i]; act[i] = st[R + i] != 0; }
-  bool singular = st[2 * R] != 0;
-    double a[R][kTlSW];
-#pragma nounroll
-    for (int s = 0; s < 2; ++s) {
-      const int cb = jb + kTlSW * s;
-      const int ws = (n - cb) < kTlSW ? (n - cb) : kTlSW;
-      if (ws <= 0) break;
-      if (s == 0) {
+  for (int i = 0; i < RS / 8; ++i) {
+    const int row = tid + kTlThreads * i;
+    const int pr = row < n ? (int)s_pos[row] : -1;
+    if (pr >= cb) {  // the row entered this sub-panel
+      const int kr = pr - cb;  // its own step, if it was chosen here (else >= 32 or beyond the steps done)
+      tl_gd2* dst = reinterpret_cast<tl_gd2*>(W + (size_t)row * ldw + cb + k0);
+      for (int c = 0; c < cnt; c += 2) {
+        tl_d2 v;
 #pragma unroll
-        for (int i = 0; i < R; ++i)
-          if (act[i]) {
-            const tl_gd2* src = reinterpret_cast<const tl_gd2*>(W + (size_t)(tid + kTlThreads * i) * ldw + cb);
-#pragma unroll
-            for (int c = 0; c < kTlSW; c += 2) { const tl_d2 v = src[c >> 1]; a[i][c] = v[0]; a[i][c + 1] = v[1]; }
-          }
-      } else {
-        // ---- columns cb..cb+31 take the 32 eliminations of the first sub-panel: U' = L11A^-1 (pivot rows' entries), then row -= L_row U'
-        double* const Bp = u12s;
-        double* const Us = u12s + 1024;
-        double* const L11A = u12s + 2048;
-        {
-          const int k = tid >> 4, c2 = (tid & 15) * 2;  // 32 pivot rows x 16 pairs of columns
-          const tl_gdouble* const prw = W + (size_t)s_prow[k] * ldw + jb;
-          *reinterpret_cast<tl_d2*>(Bp + k * 32 + c2) = *reinterpret_cast<const tl_gd2*>(prw + kTlSW + c2);
-          *reinterpret_cast<tl_d2*>(L11A + k * 32 + c2) = *reinterpret_cast<const tl_gd2*>(prw + c2);
+        for (int e = 0; e < 2; ++e) {
+          const int k = k0 + c + e;
+          v[e] = k < kr ? dyn[(RS == 8 ? k : (k & 15)) * P + row] : dyn[kTlUbuf + (kr < 32 ? kr : 0) * 33 + k];
         }
-        __syncthreads();
-        if (wave == 0 && lane < 32) {
-          double x[32];
-#pragma unroll
-          for (int k = 0; k < 32; ++k) x[k] = Bp[k * 32 + lane];
-#pragma unroll
-          for (int i = 0; i < 31; ++i)
-#pragma unroll
-            for (int k = i + 1; k < 32; ++k) x[k] = __builtin_fma(-L11A[k * 32 + i], x[i], x[k]);
-#pragma unroll
-          for (int k = 0; k < 32; ++k) {
-            Us[k * 32 + lane] = x[k];
-            W[(size_t)s_prow[k] * ldw + cb + lane] = x[k];
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < R; ++i)
-          if (act[i]) {
-            double b[kTlSW], l[kTlSW];
-            const tl_gd2* src = reinterpret_cast<const tl_gd2*>(W + (size_t)(tid + kTlThreads * i) * ldw + jb);
-#pragma unroll
-            for (int c = 0; c < kTlSW; c += 2) { const tl_d2 v = src[c >> 1]; l[c] = v[0]; l[c + 1] = v[1]; }
-#pragma unroll
-            for (int c = 0; c < kTlSW; c += 2) { const tl_d2 v = src[(kTlSW + c) >> 1]; b[c] = v[0]; b[c + 1] = v[1]; }
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-#pragma unroll
-              for (int c = 0; c < kTlSW; c += 2) {
-                const tl_d2 u = *reinterpret_cast<const tl_d2*>(Us + k * 32 + c);
-                b[c] = __builtin_fma(-l[k], u[0], b[c]);
-                b[c + 1] = __builtin_fma(-l[k], u[1], b[c + 1]);
-              }
-            }
-#pragma unroll
-            for (int c = 0; c < kTlSW; ++c) a[i][c] = b[c];
-          }
+        dst[c >> 1] = v;
       }
-      const int pbase = kTlSW * s;
-      tl_subpanel_steps<R>(a, act, pos, singular, s_slot, s_prow, s_ipiv, W, ldw, ws, cb, pbase, tid, wave, lane);
+    }
+  }
+}
+
+// The panel of 64 columns at jb (two sub-panels).  Not inlined: its registers are allocated apart from the rest of the kernel.
+template <int RS>
+__device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, int n, int jb, double* dyn, short* s_pos, short* s_rowat, int* s_prow, int* s_ipiv,
+                                      int* s_hdr, int* s_flags, const unsigned short* s_rowlist, int m_in, unsigned long long* phase_clocks) {
+  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long tprev = prof ? wall_clock64() : 0ull;
+  auto mark = [&](int phase) {
+    if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
+  };
+  constexpr int R = RS / 8;        // rows per thread in the staging layout (thread t: rows t, t + 512)
+  constexpr int P = 64 * RS;       // rows of a column in LDS
+  constexpr int NH = RS / 8;       // the 32 columns pass through LDS in NH halves of 32 / NH
+  constexpr int HC = kTlSW / NH;
+  tl_gdouble* const W = (tl_gdouble*)W_generic;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double* const Us = dyn + kTlUs;  // [32][kTlUsP]: dead before the stage writes T over it
+#pragma nounroll
+  for (int sp = 0; sp < 2; ++sp) {
+    const int cb = jb + kTlSW * sp;
+    const int ws = (n - cb) < kTlSW ? (n - cb) : kTlSW;
+    if (ws <= 0) break;
+    if (sp == 1) {
+      // ---- the columns cb..cb+31 take the 32 eliminations of the first sub-panel, on the matrix cores (LDS broadcast reads made the vector form of
+      // this 50 us per panel): L11A and the inverses of its two diagonal blocks to LDS, U' = L11A^-1 B for the pivot rows (blocked substitution, two
+      // column tiles), then B -= L_A U' for the rows that entered the panel (the row list of the previous panel; rows finished since are not stored).
+      double* const la = dyn;         // [32][33]
+      double* const ia = dyn + 1056;  // [2][16][17]
+      const int q = lane >> 4, j = lane & 15;
+      for (int idx = tid; idx < 1024; idx += kTlThreads) {
+        const int k = idx >> 5, i = idx & 31;
+        la[k * 33 + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      if (wave == 0 && lane < 32) {
+        const int blk = lane >> 4;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = r == j ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 15; ++i)
+#pragma unroll
+          for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-la[(16 * blk + r) * 33 + 16 * blk + i], x[i], x[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ia[(blk * 16 + r) * 17 + j] = x[r];
+      }
+      __syncthreads();
+      if (wave < 2) {
+        const int c0 = 16 * wave;
+        tl_d4 B0, B1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          B0[r] = W[(size_t)s_prow[4 * r + q] * ldw + cb + c0 + j];
+          B1[r] = W[(size_t)s_prow[16 + 4 * r + q] * ldw + cb + c0 + j];
+        }
+        tl_d4 X0 = {0.0, 0.0, 0.0, 0.0}, X1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[j * 17 + 4 * kb + q], B0[kb], X0, 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) B1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 + j) * 33 + 4 * kb + q], X0[kb], B1, 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[(16 + j) * 17 + 4 * kb + q], B1[kb], X1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Us[(4 * r + q) * kTlUsP + c0 + j] = X0[r];
+          Us[(16 + 4 * r + q) * kTlUsP + c0 + j] = X1[r];
+          W[(size_t)s_prow[4 * r + q] * ldw + cb + c0 + j] = X0[r];
+          W[(size_t)s_prow[16 + 4 * r + q] * ldw + cb + c0 + j] = X1[r];
+        }
+      }
+      __syncthreads();
+      const int nrt = (m_in + 15) / 16;
+      for (int tile = wave; tile < nrt; tile += kTlWaves) {
+        double aneg[8];
+        const size_t arow = (size_t)s_rowlist[16 * tile + j] * ldw;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) aneg[kb] = -W[arow + jb + 4 * kb + q];
+        size_t ro[4];
+        bool ok[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = s_rowlist[16 * tile + 4 * r + q];
+          ro[r] = (size_t)row * ldw + cb + j;
+          ok[r] = 16 * tile + 4 * r + q < m_in && s_pos[row] >= cb;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          tl_d4 acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = W[ro[r] + 16 * ct];
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aneg[kb], Us[(4 * kb + q) * kTlUsP + 16 * ct + j], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (ok[r]) W[ro[r] + 16 * ct] = acc[r];
+        }
+      }
       __syncthreads();
     }
+    mark(4);
+    // ---- stage: thread per row in (the second sub-panel's rows take the 32 eliminations of the first on the way: row -= L_row U'), column per wavefront out
+    tl_col<RS> a[4];
+    unsigned done = 0u;
+    {
 #pragma unroll
-  for (int i = 0; i < R; ++i) { st[i] = pos[i]; st[R + i] = act[i] ? 1 : 0; }
-  st[2 * R] = singular ? 1 : 0;
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {  // HC columns of one row at a time (registers); finished rows and rows beyond n enter as zeros
+          const int row = tid + kTlThreads * i;
+          const bool live = row < n && s_pos[row] >= cb;
+          double b[HC];
+          if (live) {
+            const tl_gd2* src = reinterpret_cast<const tl_gd2*>(W + (size_t)row * ldw + cb + HC * h);
+#pragma unroll
+            for (int c = 0; c < HC; c += 2) { const tl_d2 v = src[c >> 1]; b[c] = v[0]; b[c + 1] = v[1]; }
+          }
+#pragma unroll
+          for (int c = 0; c < HC; ++c) dyn[c * P + row] = live ? b[c] : 0.0;
+        }
+        __syncthreads();
+        mark(9);
+#pragma unroll
+        for (int jj = 0; jj < 4 / NH; ++jj)
+#pragma unroll
+          for (int s = 0; s < RS; ++s) a[(4 / NH) * h + jj][s] = dyn[(wave + 8 * jj) * P + lane + 64 * s];
+        __syncthreads();
+        mark(10);
+      }
+    }
+    mark(5);
+    // ---- the pivot steps
+    const int pbase = kTlSW * sp;
+#define TL_STEPS(JO)                                                                                                                        \
+  _Pragma("nounroll") for (int wo = 0; wo < 8; ++wo) {                                                                                      \
+    if (8 * JO + wo >= ws) break;                                                                                                           \
+    const bool pipe = !(RS == 16 && JO == 1 && wo == 7); /* the next column of Lbuf is free only behind the flush */                        \
+    tl_co_step<RS, JO>(a, done, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                        \
+  }                                                                                                                                         \
+  if (RS == 16 && JO == 1 && ws > 16) {                                                                                                     \
+    __syncthreads();                                                                                                                        \
+    tl_flush<RS>(W, ldw, n, cb, 0, 16, dyn, s_pos, tid);                                                                                    \
+    __syncthreads();                                                                                                                        \
+    if (wave == 0) tl_co_search<RS, 2>(a, done, 16, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);                        \
+    __syncthreads();                                                                                                                        \
+  }
+#pragma unroll
+    for (int s2 = 0; s2 < RS; ++s2) { const int row = lane + 64 * s2; done |= (row < n && s_pos[row] >= cb) ? 0u : 1u << s2; }
+    if (wave == 0) tl_co_search<RS, 0>(a, done, 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+    __syncthreads();
+    TL_STEPS(0) TL_STEPS(1) TL_STEPS(2) TL_STEPS(3)
+#undef TL_STEPS
+    __syncthreads();
+    mark(6);
+    if (RS == 8 || ws <= 16) tl_flush<RS>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
+    else tl_flush<RS>(W, ldw, n, cb, 16, ((ws + 1) & ~1) - 16, dyn, s_pos, tid);
+    __syncthreads();
+    mark(7);
+  }
 }
 
 // Everything behind a finished 64-column panel: U12 and the update of the active rows, a chunk of <= 208 trailing columns at a time.  A function of its own
@@ -470,54 +615,50 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic, double*
     }
   }
 
-template <int R>
+// RS = rows per lane of the panel's register layout: 8 for n <= 512, 16 for n <= 1024
+template <int RS>
 __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
                                                                  unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
+  constexpr int R = RS / 8;
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-  extern __shared__ double dyn[];
-  double* const u12s = dyn;                      // [64][LDP]; during the panel: Bp [32][32], Us [32][32], L11A [32][32]
-  double* const l11 = dyn + 64 * kTlLDP;         // [64][65]
-  double* const invd = l11 + 64 * kTlL11P;       // [4][16][17]
-  __shared__ double s_slot[2][kTlWaves][36];     // per wavefront: {value, (row, pos)} + the candidate row's 32 columns at [4..36)
-  __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];
+  extern __shared__ double dyn[];                // trailing phase: u12s [64][LDP], l11 [64][65], invd [4][16][17]; panel: see tl_panel
+  double* const l11 = dyn + 64 * kTlLDP;
+  double* const invd = l11 + 64 * kTlL11P;
+  __shared__ short s_pos[kTlMaxN], s_rowat[kTlMaxN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
+  __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];        // the panel's pivot rows (row indices) and recorded pivots (positions)
   __shared__ unsigned short s_rowlist[kTlMaxN + 16];
   __shared__ int s_wcnt[R][kTlWaves];
+  __shared__ int s_hdr[4], s_flags[1];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* const W = w_all + (size_t)blockIdx.x * n * ldw;
   double* const F = f_all + (size_t)blockIdx.x * n * n;
   int32_t* const PIV = piv_all + (size_t)blockIdx.x * n;
-  bool act[R];
-  int pos[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) { const int row = tid + kTlThreads * i; act[i] = row < n; pos[i] = row; }
-  bool singular = false;
+  for (int r = tid; r < kTlMaxN; r += kTlThreads) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
+  for (int r = tid; r < n + 16; r += kTlThreads) s_rowlist[r] = (unsigned short)(r < n ? r : n - 1);  // rows entering the first panel (padded: whole tiles)
+  int m_act = n;
+  if (tid == 0) s_flags[0] = 0;
+  __syncthreads();
   const int nct = (n + 15) / 16 * 16;  // columns processed by the tile phases (the padding up to it stays isolated in its own columns)
 
   for (int jb = 0; jb < n; jb += kTlPW) {
     const int pw = (n - jb) < kTlPW ? (n - jb) : kTlPW;
     // =========================================================== panel: two sub-panels of 32 columns in registers
-    {
-      int st[2 * R + 1];  // the rows' bookkeeping travels through memory: the panel is a function of its own (registers)
-#pragma unroll
-      for (int i = 0; i < R; ++i) { st[i] = pos[i]; st[R + i] = act[i] ? 1 : 0; }
-      st[2 * R] = singular ? 1 : 0;
-      tl_panel<R>(W, ldw, n, jb, dyn, &s_slot[0], s_prow, s_ipiv, st);
-#pragma unroll
-      for (int i = 0; i < R; ++i) { pos[i] = st[i]; act[i] = st[R + i] != 0; }
-      singular = st[2 * R] != 0;
-    }
+    tl_panel<RS>(W, ldw, n, jb, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, s_rowlist, m_act, phase_clocks);
     mark(0);
     // =========================================================== the 64 finished rows -> F; list of the rows still active; L11 and its diagonal-block inverses
     int m2 = 0;
     {
+      bool act[R];
       unsigned long long bal[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) {
+        const int row = tid + kTlThreads * i;
+        act[i] = row < n && s_pos[row] >= jb + pw;
         bal[i] = __ballot(act[i]);
         if (lane == 0) s_wcnt[i][wave] = __popcll(bal[i]);
       }
@@ -533,6 +674,7 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
       }
       m2 = base;
     }
+    m_act = m2;
     const int mc = nct - jb - kTlPW;  // trailing columns (exist only behind a full panel)
     const bool trailing = pw == kTlPW && mc > 0 && m2 > 0;
     if (trailing) {
@@ -553,8 +695,8 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
     }
     if (tid < pw) PIV[jb + tid] = s_ipiv[tid];
     __syncthreads();
+    if (m2 > 0 && tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
     if (!trailing) { mark(1); continue; }
-    if (tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
     if (wave == 1) {  // inverse of the four 16 x 16 unit lower triangular diagonal blocks: lane = (block, column)
       const int blk = lane >> 4, jc = lane & 15;
       double x[16];
@@ -572,7 +714,7 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
     tl_trailing(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
     if (prof) tprev = wall_clock64();
   }
-  if (singular && tid == 0) publish_singular(singular_word, 1ull, epoch);
+  if (tid == 0 && s_flags[0] != 0) publish_singular(singular_word, 1ull, epoch);
 }
 
 }  // namespace dsh

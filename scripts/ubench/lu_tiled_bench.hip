@@ -59,13 +59,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_w, sizeof(double) * (size_t)n * ldw * nb));
   CK(hipMalloc(&d_f, sizeof(double) * (size_t)n * n * nb));
   CK(hipMalloc(&d_p, sizeof(int32_t) * (size_t)n * nb));
-  CK(hipMalloc(&d_sing, 8)); CK(hipMalloc(&d_clk, 64));
-  CK(hipMemset(d_sing, 0, 8)); CK(hipMemset(d_clk, 0, 64));
+  CK(hipMalloc(&d_sing, 8)); CK(hipMalloc(&d_clk, 128));
+  CK(hipMemset(d_sing, 0, 8)); CK(hipMemset(d_clk, 0, 128));
   CK(hipMemset(d_f, 0xff, sizeof(double) * (size_t)n * n * nb));
   CK(hipMemcpy(d_a, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice));
   const size_t lds = dsh::tiled_lds_bytes();
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   float best_stage = 1e30f, best_factor = 1e30f;
@@ -75,8 +75,8 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(dsh::k_lu_stage_rowmajor, sg, dim3(256), 0, 0, n, ldw, nb, (const double*)d_a, d_w);
     CK(hipEventRecord(e1));
-    if (n <= 512) hipLaunchKernelGGL((dsh::k_lu_factor_tiled<1>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
-    else hipLaunchKernelGGL((dsh::k_lu_factor_tiled<2>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    if (n <= 512) hipLaunchKernelGGL((dsh::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    else hipLaunchKernelGGL((dsh::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
     CK(hipEventRecord(e2));
     CK(hipGetLastError());
     CK(hipEventSynchronize(e2));
@@ -107,17 +107,19 @@ int main(int argc, char** argv) {
     pivbad += bad;
     if (!(dev / big <= worst)) worst = dev / big;
   }
-  unsigned long long sing = 0, clk[8];
+  unsigned long long sing = 0, clk[16];
   CK(hipMemcpy(&sing, d_sing, 8, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(clk, d_clk, 64, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(clk, d_clk, 128, hipMemcpyDeviceToHost));
   const double flop = 2.0 / 3.0 * n * (double)n * n * nb;
   printf("n=%d nb=%lld %s: stage %.3f ms  factor %.3f ms  %.2f TFLOP/s (kernel)  %.2f TFLOP/s (with staging)   pivots wrong %d  max dev %.3e  singular %llu\n", n,
          (long long)nb, kind, best_stage, best_factor, flop / best_factor / 1e9, flop / (best_factor + best_stage) / 1e9, pivbad, worst,
          (unsigned long long)(sing & 0xffffffffull));
   printf("  phases of workgroup 0 (us): panel %.1f  finish+lists %.1f  u12 %.1f  update %.1f\n", clk[0] / 100.0, clk[1] / 100.0, clk[2] / 100.0, clk[3] / 100.0);
+  printf("  inside the panel (us): U' solve %.1f  stage %.1f  pivot steps %.1f  flush %.1f\n", clk[4] / 100.0, clk[5] / 100.0, clk[6] / 100.0, clk[7] / 100.0);
+  printf("  inside stage (us): loads+B-update %.1f  T writes %.1f  CO reads %.1f\n", clk[8] / 100.0, clk[9] / 100.0, clk[10] / 100.0);
 #ifdef TL_X_STEPPROF
-  { unsigned long long sp[5]; CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(dsh::tl_stepprof), sizeof sp));
-    printf("  step profile (shader cycles summed over %d launches, thread 0 of wg 0): argmax %llu  barrierA %llu  select+publish %llu  barrierB %llu  read+eliminate %llu\n", reps + 1, sp[0], sp[1], sp[2], sp[3], sp[4]); }
+  { unsigned long long sp[8]; CK(hipMemcpyFromSymbol(sp, HIP_SYMBOL(dsh::tl_stepprof), sizeof sp));
+    printf("  step profile (shader cycles over %d launches, thread 0 of workgroup 0): reads %llu  pivot-row entries %llu  update/search %llu  barrier %llu; searches by thread 0: %llu cycles in %llu calls\n", reps + 1, sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]); }
 #endif
   return (pivbad == 0 && worst < 1e-10) ? 0 : 1;
 }
