@@ -56,6 +56,7 @@ class BdfCallable : public NonLinearOpRef {
   int64_t nstates() const override { return eqn_.nstates(); }
   const HipContext& context() const override { return eqn_.context(); }
   void set_c(double h, double alpha) { c_ = h * alpha; }
+  void set_c_value(double c) { c_ = c; }
   double c() const { return c_; }
   void set_psi(const HipMat& diff, const std::vector<double>& gamma, const std::vector<double>& alpha, int order, HipVec& psi) const {  // :182-196
     psi.axpy_v(gamma[1], diff.column(1), 0.0);
@@ -165,9 +166,12 @@ class Bdf : public OdeSolverMethod {
     op_.set_c(h_, alpha_[(size_t)order_]);
     nonlinear_solver_.set_problem(op_);
     // first Jacobian + LU (bdf.rs:289-293).  State and time cannot change between here and the first step, so the work is done at the top of that step
-    // (ensure_linearised) with the same operands: an ensemble that is handed to the device-resident kernels never touches the n x n containers of this
-    // path (lazily allocated, hip_la.hpp) — at n = 512 they would not fit the device from ~30 000 members on.
+    // (ensure_linearised) with the same operands — INCLUDING the c of this moment: set_stop_time may shorten the first step before it is taken
+    // (handle_tstop -> update_step_size changes op.c), and the reference then keeps the factors of M - c0 J it made here unless its update rule asks
+    // for new ones.  An ensemble that is handed to the device-resident kernels never touches the n x n containers of this path (lazily allocated,
+    // hip_la.hpp) — at n = 512 they would not fit the device from ~30 000 members on.
     first_linearisation_pending_ = true;
+    first_linearisation_c_ = op_.c();
     diff_ = HipMat::zeros(n, MAX_ORDER + 3, ctx);
     initialise_diff_to_first_order();
     if (problem.eqn->nroots() > 0) { root_finder_.emplace(problem.eqn->nroots(), n, ctx); root_finder_->init(*problem.eqn, y_, t_); }
@@ -293,7 +297,13 @@ class Bdf : public OdeSolverMethod {
     return out;
   }
 
-  void ensure_linearised() { if (first_linearisation_pending_) { first_linearisation_pending_ = false; reset_jacobian(); } }
+  void ensure_linearised() {
+    if (!first_linearisation_pending_) return;
+    const double c_now = op_.c();
+    op_.set_c_value(first_linearisation_c_);  // the constructor's factorisation, made late
+    reset_jacobian();
+    op_.set_c_value(c_now);
+  }
   OdeSolverStopReason step() override {  // bdf.rs:1277-1589
     ensure_linearised();
     double safety = 0.0, error_norm = 0.0;
@@ -552,6 +562,7 @@ class Bdf : public OdeSolverMethod {
 
   // NewtonNonlinearSolver::reset_jacobian(op, state.y, state.t): assemble M - cJ and factor
   void reset_jacobian() {
+    first_linearisation_pending_ = false;  // any factorisation supersedes the constructor's (its Jacobian is still marked stale, so it is evaluated here)
     prelaunch_valid_ = false;  // a pre-launched Newton iteration used the old factors
     if (fused_) {
       const bool recompute = op_.jacobian_is_stale();
@@ -737,6 +748,7 @@ class Bdf : public OdeSolverMethod {
   double t_predict_ = 0.0;
   HipMat diff_, diff_tmp_;
   bool first_linearisation_pending_ = false;
+  double first_linearisation_c_ = 0.0;
   std::vector<double> u_, alpha_, gamma_, error_const2_;
   OdeSolverStatistics statistics_;
   // BdfState (bdf_state.rs:13-37)

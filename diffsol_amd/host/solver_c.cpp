@@ -51,6 +51,8 @@ struct dshs_solver {
   int last_mode = 0;              // mode the last solve_dense actually ran in
   int64_t last_totals[6] = {0, 0, 0, 0, 0, 0};
   std::vector<int32_t> scratch_status, scratch_ridx;
+  std::vector<double> member_troot;  // root time of every member after a device-resident solve_dense (NaN: none)
+  bool resident_roots_valid = false; // dshs_root_info reports the earliest of them instead of the (unstepped) host solver's
   // per-member device-resident solves run the ensemble sorted by parameters (member_order below); cached: the parameters are fixed at creation
   bool order_ready = false;
   void* perm_dev = nullptr;  // sorted position -> member
@@ -139,6 +141,9 @@ int resolve_mode(const dshs_solver* s) {
     // the device-resident integrators start from the problem's (t0, y0): a solver that was stepped by hand continues on the host path
     if (s->solver->get_statistics().number_of_steps != 0 || s->solver->t() != s->problem.t0) return DSHS_ENSEMBLE_LOCKSTEP;
     const bool roots = s->problem.eqn->nroots() > 0;
+    // a single IVP with a root function keeps the reference's solve_dense contract to the letter (output truncated at the root, solver state moved
+    // to it): host-driven.  Ensembles with root functions are integrated per member — every member stops at ITS event (see dshs_root_info).
+    if (roots && s->ctx.nbatch() == 1) return DSHS_ENSEMBLE_LOCKSTEP;
     if (!roots && pick_resident(s, 64, true).ok) return DSHS_ENSEMBLE_WAVEFRONT;
     if (pick_resident(s, 1, true).ok) return DSHS_ENSEMBLE_PER_MEMBER;
     return DSHS_ENSEMBLE_LOCKSTEP;
@@ -451,6 +456,17 @@ int dshs_interpolate_sens(dshs_solver* s, double t, double* s_host) {
   });
 }
 int dshs_root_info(dshs_solver* s, double* t_root, int* root_index) {
+  if (s->resident_roots_valid) {  // the last solve_dense ran device-resident: the host solver was not stepped; report the EARLIEST member event
+    double best = 0.0;
+    int idx = -1;
+    for (size_t b = 0; b < s->member_troot.size(); ++b) {
+      const double tr = s->member_troot[b];
+      if (s->scratch_ridx[b] >= 0 && (idx < 0 || std::fabs(tr) < std::fabs(best))) { best = tr; idx = s->scratch_ridx[b]; }
+    }
+    *t_root = best;
+    *root_index = idx;
+    return 0;
+  }
   *t_root = s->solver->root_time;
   *root_index = s->solver->root_index;
   return 0;
@@ -537,7 +553,10 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       const int64_t nb = s->ctx.nbatch();
       std::vector<int32_t>&status = s->scratch_status, &ridx = s->scratch_ridx;
       status.resize((size_t)nb); ridx.resize((size_t)nb);
-      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), nullptr, ridx.data(), nullptr, s->last_totals, /*lazy=*/true);
+      s->member_troot.assign((size_t)nb, std::nan(""));
+      s->resident_roots_valid = false;
+      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), s->member_troot.data(), ridx.data(), nullptr, s->last_totals, /*lazy=*/true);
+      s->resident_roots_valid = true;
       int64_t failed = 0, rooted = 0;
       int first_bad = 0;
       for (int64_t b = 0; b < nb; ++b) {
@@ -554,6 +573,7 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       if (stop_reason) *stop_reason = rooted == nb ? DSHS_STOP_ROOT_FOUND : DSHS_STOP_TSTOP_REACHED;
       return 0;
     }
+    s->resident_roots_valid = false;
     std::vector<double> te(t_eval, t_eval + nt);
     HipMat ret;
     OdeSolverStopReason r = s->solver->solve_dense(te, ret);

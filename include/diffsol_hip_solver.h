@@ -106,7 +106,10 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
  *     model/method has one (dsh_model_has_resident / dsh_model_has_wave_member) — the whole solve_dense in ONE launch, solver state in registers:
  *     wavefront-sized lock-step groups for models without root functions (the reference's batched semantics with nbatch = 64 per group; an
  *     ensemble of <= 64 members is one group, i.e. exactly the lock-step ensemble, bit for bit), one step-size/order history per member for
- *     models with root functions (every member stops at its own event); otherwise DSHS_ENSEMBLE_LOCKSTEP.
+ *     ENSEMBLES (nbatch > 1) of models with root functions (every member stops at its own event: its output columns behind the event are NaN,
+ *     dshs_root_info reports the earliest member event, dshs_solve_dense_adaptive returns every member's); a single IVP (nbatch == 1) with root
+ *     functions keeps the reference's contract to the letter — output truncated at the root, solver state moved to it — on the host-driven path;
+ *     otherwise DSHS_ENSEMBLE_LOCKSTEP.
  *   DSHS_ENSEMBLE_LOCKSTEP: host-driven, one (t, h, order) sequence for the whole ensemble over the Vector/Matrix/LinearSolver operations of
  *     diffsol_hip.h — what the reference's generic Bdf/Sdirk do on a batched context (method.rs:467-520 over bdf.rs:1277-1589).
  *   DSHS_ENSEMBLE_PER_MEMBER / DSHS_ENSEMBLE_WAVEFRONT: force one of the device-resident granularities (error if the model has no such kernel).

@@ -31,13 +31,18 @@ struct Convergence {
   ConvergenceStatus check_norm(double norm) {                         // :68-131
     niter += 1;
     if (has_old_norm) {
+      if (niter > 2) event_counts().pow_rate++;
       double rate = rpow(norm / old_norm, 1.0 / (double)(niter - 1));
       if (rate > 0.9) return ConvergenceStatus::Diverged;
+      event_counts().powi_calls++;
       if (powi(rate, max_iter - niter) / (1.0 - rate) * norm > tol) return ConvergenceStatus::Diverged;
       eta = rate / (1.0 - rate);
     } else {
       double min_eta = 1e4 * std::numeric_limits<double>::epsilon();
       if (eta < min_eta) eta = min_eta;
+      event_counts().pow_first_iter++;
+      if (eta == std::pow(20.0, 1.25)) event_counts().pow_first_iter_eta_reset++;
+      if (eta == std::pow(100.0, 1.25)) event_counts().pow_first_iter_eta_reset_ts++;
       eta = rpow(eta, 0.8);
     }
     if (eta * norm < tol) return ConvergenceStatus::Converged;

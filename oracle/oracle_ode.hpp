@@ -670,6 +670,7 @@ struct Bdf : SolverBase {
   }
 
   OdeErr update_step_size(double factor, double* new_h_out = nullptr) {  // :508-566
+    event_counts().step_size_updates++;
     double new_h = factor * h_;
     n_equal_steps = 0;
     int order = order_;
@@ -863,6 +864,7 @@ struct Bdf : SolverBase {
     prev_error_norm = error_norm;
     n_equal_steps += 1;
     if (n_equal_steps > order_) {
+      event_counts().order_selections++;
       int order = order_;
       const double inf = std::numeric_limits<double>::infinity();
       double error_m_norm = order > 1 ? predict_error_control(order - 1) : inf;

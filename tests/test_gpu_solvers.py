@@ -46,6 +46,23 @@ def test_gpu_reproduces_reference_snapshot_counters_and_oracle_states(H, O, kats
     assert s.fused == (fused and has_fused)
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2"])
+def test_stop_time_inside_the_first_step_keeps_the_factors_of_the_initial_step_size(H, O, method, fused):
+    """A final time closer than the initial step: set_stop_time shortens h (and the operator's c) BEFORE the first step is taken.  The reference made
+    its first factorisation of M - c0 J in the constructor (bdf.rs:289-293) and keeps it; the host integrator here defers that factorisation to
+    its first step (the containers are allocated lazily) and must make it with the constructor's c0 all the same — Newton iterates, counters and bits
+    against the oracle, which does not defer."""
+    p = robertson_params(5)
+    kw = dict(nbatch=5, model_size=1, method=METHOD[method], h0=1e-2, **ROB)
+    for t_end in (1e-5, 3e-3):  # both inside [t0, t0 + h0]
+        s = H.Solver("robertson_ode", p, fused=fused, **kw)
+        o = O.OracleSolver(ORACLE_MODEL["robertson_ode"], p, **kw)
+        y, ncols, _ = s.solve(t_end)  # OdeSolverMethod::solve: set_stop_time(final_time) first (method.rs:227-258)
+        yo, ncols_o = o.solve(t_end)
+        assert np.array_equal(y, yo) and ncols == ncols_o and s.stats() == o.stats()
+
+
 @pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("nb", [2, 67, 1000])
