@@ -46,6 +46,21 @@ PUBLISHED_SINGLE_SOLVE_S = 3.115e-05  # /root/reference book/src/benchmarks/pyth
 NEWTON_READ_BYTES, NEWTON_WRITE_BYTES_PER_ITER = 204, 24
 
 
+KERNEL_SOURCES = ["diffsol_amd/csrc/dsh_adaptive_kernel.hpp", "diffsol_amd/csrc/dsh_resident.hpp", "diffsol_amd/csrc/dsh_device.hpp", "diffsol_amd/csrc/dsh_lu_dev.hpp",
+                  "diffsol_amd/csrc/dsh_models.hpp", "include/diffsol_detpow.h"]
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources that define the headline kernel: the committed instruction counters (profiles/*_pmc_resident.json) carry
+    the hash they were measured with, and the roofline refuses counters of another kernel (a stale fraction after a kernel edit)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def robertson_params(nb, seed=12345):
     """k1~logU[0.02,0.08], k2~logU[0.5e4,2e4], k3~logU[1.5e7,6e7], numpy default_rng(12345)."""
     rng = np.random.default_rng(seed)
@@ -316,16 +331,18 @@ def main():
         if launches > 0:
             avg_s = kernel_ms * 1e-3 / launches
             pmc = {}
-            for name in ("r02_pmc_resident.json", "pmc_resident.json"):
-                path = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(path):
-                    try:
-                        pmc = json.load(open(path)).get("bench_kernel", {}) or {}
-                    except Exception:
+            stale = None
+            path = os.path.join(ROOT, "profiles", "r03_pmc_resident.json")
+            if os.path.exists(path):
+                try:
+                    pmc = json.load(open(path)).get("bench_kernel", {}) or {}
+                except Exception:
+                    pmc = {}
+                if pmc:
+                    pmc["file"] = "profiles/r03_pmc_resident.json"
+                    if pmc.get("kernel_source_sha16") != kernel_source_hash():  # counters of another kernel: no fraction rather than a stale one
+                        stale = f"profiles/r03_pmc_resident.json was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r03.sh"
                         pmc = {}
-                    if pmc:
-                        pmc["file"] = "profiles/" + name
-                        break
             algo_hbm = 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * (hi - lo)
             roof = {"bound": "valu", "kernel": "dsh::k_bdf_adaptive<RobertsonOde1, BA=true, WAVE=true> (the whole ensemble solve, one launch)",
                     "avg_launch_us": avg_s * 1e6, "launches_timed": launches, "empty_bracket_us": bracket_ms * 1e3,
@@ -348,7 +365,7 @@ def main():
                 roof["traffic"] = pmc.get("hbm_bytes_per_launch")
                 roof["counters_from"] = pmc.get("file")
             else:
-                roof.update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC summary for this ensemble size under profiles/"})
+                roof.update({"achieved": None, "frac": None, "traffic": None, "note": stale or "no PMC summary for this ensemble size under profiles/"})
             rec["roofline"] = roof
         else:
             rec["roofline"] = None

@@ -12,7 +12,20 @@ struct AdaptiveConsts {
   ResidentConsts r;
   double alpha[6], gamma[6], ec2[6];  // Bdf::_new tables (bdf.rs:286-306), computed on the host
   double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
+  double eta_reset_p08, eta_reset_ts_p08;  // dsh_det_pow(eta_reset, 0.8), dsh_det_pow(eta_reset_ts, 0.8): the first Newton iteration after a reset (appended: older code objects ignore them)
 };
+
+// `if (c) body` that STAYS a branch.  In wavefront lock-step groups the BDF order is wavefront-uniform (a scalar register), and the loops over the
+// difference columns test it per column: the compiler turns such tiny guarded blocks into selects (v_cndmask on every 32-bit half: 56 % of the
+// kernel's VALU instructions were not FP64, profiles/r02) although a scalar branch would skip them for nothing.  An empty volatile asm inside the block
+// keeps it a block.  The arithmetic and its order per component are untouched.  Per-member control (order differs by lane) keeps the select form.
+template <bool WAVE, class F>
+__device__ __forceinline__ void guarded(bool c, F&& f) {
+  if (c) {
+    if constexpr (WAVE) asm volatile("" ::);
+    f();
+  }
+}
 
 // wavefronts per SIMD the kernel is compiled for: 2 for the register-resident models (256 VGPRs hold the whole BDF state); the run-time-compiled banded
 // form, whose state lives in per-lane memory anyway, overrides it (dsh_jit.hip) to trade registers for latency hiding
@@ -24,6 +37,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
                                                     int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
+  // @phase set-up (init, consistent state, first factorisation)
   constexpr int N = Mdl::N, NP = Mdl::NP;
   constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
   const AdaptiveConsts& C = *Cp;
@@ -63,6 +77,7 @@ DSH_UNROLL_N
   // Bdf::_new tables in LDS: every lookup is indexed by the current order and sits in the serial chain of the step (h alpha_order, the error
   // constants, the R U rescaling) — an LDS read instead of a global load there.
   __shared__ double sAlpha[6], sGamma[6], sEc2[6], sU[kMaxOrder * 36];
+  __shared__ double sRw[48], sRUw[48];  // R and R U of a step-size change in wavefront lock-step groups (a workgroup is one wavefront)
   if (ln < 6) { sAlpha[ln] = C.alpha[ln]; sGamma[ln] = C.gamma[ln]; sEc2[ln] = C.ec2[ln]; }
   for (int k = ln; k < kMaxOrder * 36; k += 64) sU[k] = C.u[k / 36][k % 36];
   __syncthreads();
@@ -131,10 +146,52 @@ DSH_UNROLL_N
   double yp[N], psi[N];
   double t_predict = t;
 
+  // @phase update_step_size (R, R U, D <- D R U)
   // _update_step_size (bdf.rs:508-566) with _update_diff_for_step_size (:568-577): diff_tmp[:, 0..=order] = diff[:, 0..=order] * (R U); swap
   auto update_step_size = [&](double factor, double& new_h_out) __attribute__((always_inline)) -> bool {
     const double new_h = factor * h;
     n_equal_steps = 0;
+    if constexpr (WAVE) {
+      // R and R U are wavefront-uniform 6 x 6 matrices: every lane used to compute all of both (25 recurrences with 10 true divisions, 216 multiply-add
+      // pairs).  Here lane m computes column m of R (its recurrence down the rows), lane k + 8 j the entry (k, j) of R U, both through LDS — each
+      // entry by the operations, in the order, of the sequential code, so the bits are the same; then every lane applies R U to its own differences.
+      const int ou = __builtin_amdgcn_readfirstlane(order);
+      {
+        const int m = ln & 7;  // lanes 0..5: column m
+        double r = 1.0;
+        sRw[m * 6 + 0] = r;
+#pragma unroll
+        for (int i = 1; i < 6; ++i) { r = (m == 0) ? 0.0 : r * ((double)i - 1.0 - factor * (double)m) / (double)i; if (m < 6) sRw[m * 6 + i] = r; }
+      }
+      {
+        const int k = ln & 7, j = ln >> 3;
+        const bool mine = (k < 6) & (j < 6);
+        const double* U = sU + (ou - 1) * 36 + (mine ? j : 0) * 6;
+        const int kk = mine ? k : 0;
+        double acc = sRw[0 * 6 + kk] * U[0];
+#pragma unroll
+        for (int m = 1; m < 6; ++m)
+          guarded<WAVE>(m <= ou, [&]() __attribute__((always_inline)) { acc = sRw[m * 6 + kk] * U[m] + acc; });
+        if (mine) sRUw[j * 6 + k] = acc;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        guarded<WAVE>(j <= ou, [&]() __attribute__((always_inline)) {
+          double acc[N];
+          const double ru0 = sRUw[j * 6 + 0];
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) acc[i] = D[0][i] * ru0;
+#pragma unroll
+          for (int k = 1; k < 6; ++k)
+            guarded<WAVE>(k <= ou, [&]() __attribute__((always_inline)) {
+              const double ruk = sRUw[j * 6 + k];
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) acc[i] = D[k][i] * ruk + acc[i];
+            });
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) dt_set(j, i, acc[i]);
+        });
+    } else {
     double R[6][6];  // R[j][i] = element (row i, col j) of compute_r(order, factor)   (bdf.rs:433-463)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -164,6 +221,7 @@ DSH_UNROLL_N
         }
       }
     }
+    }
 #pragma unroll
     for (int j = 0; j < kNC; ++j)
 DSH_UNROLL_N
@@ -175,8 +233,33 @@ DSH_UNROLL_N
     return fabs(h) < o.min_timestep;  // true = StepSizeTooSmall
   };
 
+  // @phase predict_forward
   // _predict_forward (bdf.rs:674-692): y_predict = sum_{j<=order} D_j ; psi_neg_y0 = alpha_order * sum_{1<=j<=order} gamma_j D_j - y_predict
   auto predict_forward = [&]() __attribute__((always_inline)) {
+    if constexpr (WAVE) {
+      const int ou = __builtin_amdgcn_readfirstlane(order);
+      double s[N], q[N];
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) { s[i] = 0.0; q[i] = sGamma[1] * D[1][i]; }
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        guarded<WAVE>(j <= ou, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) s[i] = s[i] + D[j][i];
+          if (j >= 2) {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) q[i] = sGamma[j] * D[j][i] + 1.0 * q[i];
+          }
+        });
+      const double al = sAlpha[ou];
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) {
+        double qq = q[i] * al;
+        qq = qq - s[i];
+        yp[i] = s[i];
+        psi[i] = qq;
+      }
+    } else {
 DSH_UNROLL_N
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
@@ -190,9 +273,11 @@ DSH_UNROLL_N
       yp[i] = s;
       psi[i] = q;
     }
+    }
     t_predict = t + h;
   };
 
+  // @phase jacobian_updates (re-evaluation, M - cJ, LU factor)
   // _jacobian_updates (bdf.rs:465-506) over JacobianUpdate::check_* (jacobian_update.rs:38-79)
   auto jacobian_updates = [&](double c, JState st) __attribute__((always_inline)) {
     bool check_rhs = false, check_jac = true;
@@ -220,6 +305,7 @@ DSH_UNROLL_N
     }
   };
 
+  // @phase handle_tstop / loop head
   // handle_tstop (bdf.rs:694-731): 0 = nothing, 1 = TstopReached, 2 = StopTimeBeforeCurrentTime
   bool has_tstop = true;
   const double tstop = t_eval[C.r.n_eval - 1];
@@ -255,6 +341,7 @@ DSH_UNROLL_N
     bool convergence_fail = false;
     double x[N];
     int niter = 0;
+    // @phase Newton iteration (residual, update, norm, convergence test)
     predict_forward();
     while (true) {
       // ---- NewtonNonlinearSolver::solve_in_place over NoLineSearch (newton.rs:13-36, line_search.rs:46-72)
@@ -310,13 +397,17 @@ DSH_UNROLL_N
         } else {
           const double min_eta = 1e4 * 2.220446049250313e-16;
           if (eta < min_eta) eta = min_eta;
-          eta = rpow(eta, 0.8, det);
+          // after a reset eta is one of two constants (convergence.rs:36-42): their 0.8th powers come from the host (the same deterministic pow)
+          if (det && eta == C.r.eta_reset) eta = C.eta_reset_p08;
+          else if (det && eta == C.r.eta_reset_ts) eta = C.eta_reset_ts_p08;
+          else eta = rpow(eta, 0.8, det);
         }
         const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
         if (niter == 1) { has_old = true; old_norm = norm; }
         if (diverged) break;
         if (converged) { solved = true; break; }
       }
+      // @phase Newton failure handling
       n_newton += niter;
       if (!solved) {
         n_nl_fails += 1;
@@ -333,6 +424,7 @@ DSH_UNROLL_N
         }
         continue;
       }
+      // @phase error norm
       double ydelta[N];
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
@@ -341,7 +433,41 @@ DSH_UNROLL_N
       const double maxiter = (double)o.max_nonlinear_solver_iterations;
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
+        // @phase accept: update of the differences
         // ---- accepted: _update_diff (bdf.rs:646-664), state update
+        if constexpr (WAVE) {
+          const int ou = __builtin_amdgcn_readfirstlane(order);
+          double dk1[N], upper[N];
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) dk1[i] = 0.0;
+#pragma unroll
+          for (int j = 2; j < 7; ++j)
+            guarded<WAVE>(j == ou + 1, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) dk1[i] = D[j][i];
+            });
+#pragma unroll
+          for (int j = 2; j < kNC; ++j) {
+            guarded<WAVE>(j == ou + 2, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) D[j][i] = ydelta[i] - dk1[i];
+            });
+            guarded<WAVE>(j == ou + 1, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) D[j][i] = ydelta[i];
+            });
+          }
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) upper[i] = ydelta[i];
+#pragma unroll
+          for (int j = 5; j >= 0; --j)
+            guarded<WAVE>(j <= ou, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) { const double v = D[j][i] + 1.0 * upper[i]; D[j][i] = v; upper[i] = v; }
+            });
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) y[i] = yp[i];
+        } else {
 DSH_UNROLL_N
         for (int i = 0; i < N; ++i) {
           double dk1 = 0.0;
@@ -355,9 +481,11 @@ DSH_UNROLL_N
           for (int j = 5; j >= 0; --j) if (j <= order) { const double v = D[j][i] + 1.0 * upper; D[j][i] = v; upper = v; }
           y[i] = yp[i];
         }
+        }
         t = t_predict;
         break;
       }
+      // @phase error-test failure
       double factor = safety * pi_controller_raw(error_norm, has_prev_err, prev_err, o.pi_control_integral, o.pi_control_proportional, order + 1, det);
       has_prev_err = false;
       if (factor < o.min_timestep_shrink) factor = o.min_timestep_shrink;
@@ -368,6 +496,7 @@ DSH_UNROLL_N
       n_err_fails += 1;
       if (n_err_fails - old_err_fails >= o.max_error_test_failures) { status = kRsTooManyErrorTestFailures; break; }
     }
+    // @phase order selection
     if (status != kRsOk) break;
     n_steps += 1;
     steps_since_jac += 1; steps_since_rhs_jac += 1;  // JacobianUpdate::step
@@ -376,6 +505,22 @@ DSH_UNROLL_N
     if (n_equal_steps > order) {
       // order selection (bdf.rs:1494-1560): predict_error_control(order-1) / (order+1) on the updated differences
       double col_m[N], col_p[N];
+      if constexpr (WAVE) {
+        const int ou = __builtin_amdgcn_readfirstlane(order);
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) { col_m[i] = 0.0; col_p[i] = 0.0; }
+#pragma unroll
+        for (int j = 1; j < kNC; ++j) {
+          guarded<WAVE>(j == ou, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) col_m[i] = D[j][i];
+          });
+          guarded<WAVE>(j == ou + 2, [&]() __attribute__((always_inline)) {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) col_p[i] = D[j][i];
+          });
+        }
+      } else {
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) {
         double vm = 0.0, vp = 0.0;
@@ -383,13 +528,35 @@ DSH_UNROLL_N
         for (int j = 1; j < kNC; ++j) { if (j == order) vm = D[j][i]; if (j == order + 2) vp = D[j][i]; }
         col_m[i] = vm; col_p[i] = vp;
       }
+      }
       const double inf = __builtin_huge_val();
       const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * sEc2[order - 1] : inf;
       const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * sEc2[order + 1] : inf;
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
-      const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
-      const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
-      const double f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2, det);
+      double f0c, f1c, f2c;
+      if constexpr (WAVE) {
+        // the three controller values (runge_kutta.rs:1313-1336) are wavefront-uniform, and each is one pow or a product of two: lanes 0..5 take one
+        // (base, exponent) pair each and ONE call of pow serves all of them — the same function on the same arguments, so the same bits, for a sixth
+        // (or a third) of the instructions; v_readlane brings the results back
+        const bool two = (pi_p != 0.0) & has_prev_err;
+        const int l6 = ln & 7, which = l6 >> 1;
+        const double eo = (double)(order + which);
+        const double ki = pi_i / eo, kp = pi_p / eo;
+        const double errs = which == 0 ? error_m_norm : (which == 1 ? error_norm : error_p_norm);
+        const double base = (l6 & 1) ? prev_err : errs;
+        const double expo = (l6 & 1) ? kp : (two ? -(ki + kp) : -ki);
+        const double r = rpow(l6 < 6 ? base : 1.0, expo, det);
+        auto rl = [&](int lane) __attribute__((always_inline)) -> double {
+          return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r), lane), __builtin_amdgcn_readlane(__double2loint(r), lane));
+        };
+        f0c = two ? rl(0) * rl(1) : rl(0);
+        f1c = two ? rl(2) * rl(3) : rl(2);
+        f2c = two ? rl(4) * rl(5) : rl(4);
+      } else {
+        f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
+        f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
+        f2c = pi_controller_raw(error_p_norm, has_prev_err, prev_err, pi_i, pi_p, order + 2, det);
+      }
       int max_index = 0;  // Iterator::max_by keeps the LAST maximum
       double fmaxv = f0c;
       if (f1c >= fmaxv) { max_index = 1; fmaxv = f1c; }
@@ -405,6 +572,7 @@ DSH_UNROLL_N
         jacobian_updates(new_h * sAlpha[new_order], JState::StepSuccess);
       }
     }
+    // @phase interpolation / output / stop tests
     // interpolate_from_diff (bdf.rs:767-782)
     auto interpolate = [&](double te, double (&yv)[N]) __attribute__((always_inline)) {
       double time_factor = 1.0;
@@ -450,6 +618,7 @@ DSH_UNROLL_N
     }
     if (reason == 1) done = true;
   }
+  // @phase epilogue
   if (active) {
     if (ncols_out != nullptr) ncols_out[b] = col;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");

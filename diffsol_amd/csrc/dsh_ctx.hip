@@ -153,8 +153,12 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   ctx->pool = new std::multimap<size_t, void*>();
   ctx->live = new std::map<void*, size_t>();
   {
-    const char* env = std::getenv("DSH_SYNC_MODE");  // "poll" (default) or "sync"
-    ctx->poll = !(env && std::string(env) == "sync");
+    // "poll" or "sync".  Default: poll for a single process (a spinning host core buys ~10 us per reduction), sync when the process is one of several
+    // ranks (WORLD_SIZE > 1: one process per GPU — eight spinning cores on a node help nobody)
+    const char* env = std::getenv("DSH_SYNC_MODE");
+    const char* ws = std::getenv("WORLD_SIZE");
+    const bool multi = ws && std::atoi(ws) > 1;
+    ctx->poll = env ? std::string(env) != "sync" : !multi;
   }
   *out = ctx;
   return DSH_OK;

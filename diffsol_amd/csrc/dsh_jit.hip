@@ -18,6 +18,10 @@
 #include <memory>
 #include <mutex>
 
+#include <atomic>
+#include <fcntl.h>
+#include <sys/file.h>
+
 #include "dsh_jit.hpp"
 
 using namespace dsh;
@@ -128,6 +132,7 @@ uint64_t headers_fingerprint() {
   }();
   return fp;
 }
+std::atomic<long> g_jit_compiles{0};  // modules this process compiled itself (not loaded from the cache): dsh_jit_compile_count
 std::string cache_dir() {
   const char* e = std::getenv("DSH_JIT_CACHE");
   if (e && std::string(e) == "off") return "";
@@ -208,8 +213,21 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
     if (cache_load(path, group, out)) return DSH_OK;
   }
   for (const std::string& o : include_options()) opts.push_back(o);
+  // One process per GPU: eight ranks that meet the same model on a cold cache would each spend the minutes hiprtc takes on it.  An exclusive lock on
+  // <entry>.lock around "look again, compile, store" lets the first one compile and the others load what it stored (the store itself was already
+  // atomic: temporary file + rename).  A cache directory that cannot be locked (read-only tree) just compiles.
+  int lock_fd = -1;
+  if (!path.empty()) {
+    std::error_code ec;
+    std::filesystem::create_directories(dir, ec);
+    lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
+    if (lock_fd >= 0 && flock(lock_fd, LOCK_EX) != 0) { close(lock_fd); lock_fd = -1; }
+    if (lock_fd >= 0 && cache_load(path, group, out)) { flock(lock_fd, LOCK_UN); close(lock_fd); return DSH_OK; }
+  }
   int rc = compile_module_uncached(rec, tu, header, group, opts, out);
+  if (rc == DSH_OK) g_jit_compiles.fetch_add(1);
   if (rc == DSH_OK && !path.empty()) cache_store(dir, path, group, *out);
+  if (lock_fd >= 0) { flock(lock_fd, LOCK_UN); close(lock_fd); (void)unlink((path + ".lock").c_str()); }
   return rc;
 }
 
@@ -417,6 +435,8 @@ int dsh_model_release(int model_id) {
 
 // compile (not load) one kernel family of a run-time-compiled model: 0 operators, 1 fused Newton kernels, 2 resident BDF, 3 resident SDIRK.
 // Needs no GPU; used by the build check and by callers that want to pay the compilation before the first solve.
+int64_t dsh_jit_compile_count(void) { return (int64_t)g_jit_compiles.load(); }
+
 int dsh_model_precompile(int model_id, int family) {
   std::lock_guard<std::mutex> lk(g_mu);
   JitModelRec* rec = find_model(model_id);

@@ -555,7 +555,8 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       status.resize((size_t)nb); ridx.resize((size_t)nb);
       s->member_troot.assign((size_t)nb, std::nan(""));
       s->resident_roots_valid = false;
-      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), s->member_troot.data(), ridx.data(), nullptr, s->last_totals, /*lazy=*/true);
+      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), s->problem.eqn->nroots() > 0 ? s->member_troot.data() : nullptr, ridx.data(), nullptr,
+                   s->last_totals, /*lazy=*/true);  // no root functions: no per-member bookkeeping crosses PCIe at all
       s->resident_roots_valid = true;
       int64_t failed = 0, rooted = 0;
       int first_bad = 0;

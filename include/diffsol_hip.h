@@ -228,6 +228,9 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 int dsh_model_compile(const char* source, int form, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout, int has_mass, int* model_id);
 int dsh_model_release(int model_id);
 int dsh_model_precompile(int model_id, int family);
+/* code objects this process compiled itself with hiprtc (not loaded from the on-disk cache, DSH_JIT_CACHE): one process per GPU shares the cache, and an
+ * exclusive lock per entry makes the first rank that meets a model compile it while the others wait and load (tests/test_dist_cpu.py) */
+int64_t dsh_jit_compile_count(void);
 int dsh_model_set_twin(int model_id, int twin_id);
 int dsh_model_twin(int model_id); /* -1: none */
 /* the same for any model id: a run-time-compiled model's twin, or — created on first request — the banded lane-per-member form of a built-in

@@ -299,6 +299,15 @@ def set_det_pow(on):
     lib().orc_set_det_pow(C.c_int(1 if on else 0))
 
 
+def event_counts(reset=True):
+    """Diagnostic counters of the BDF restatement since the last reset: how often a run takes each path (pow calls by site, step-size updates, order
+    selections): what scripts/phase_frequencies.py weights the per-phase instruction counts of the device kernel with."""
+    out = (C.c_long * 8)()
+    lib().orc_event_counts(out, C.c_int(1 if reset else 0))
+    names = ["pow_calls", "pow_first_iter", "pow_first_iter_eta_reset", "pow_first_iter_eta_reset_ts", "pow_rate", "step_size_updates", "order_selections", "powi_calls"]
+    return dict(zip(names, list(out)))
+
+
 def det_pow(x, y):
     f = lib().orc_det_pow
     f.restype = C.c_double

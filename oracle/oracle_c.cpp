@@ -384,6 +384,13 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
 
 // libm pow (default, the reference's arithmetic) or the deterministic pow shared with the device kernels (verification of the resident kernels)
 void orc_set_det_pow(int on) { det_pow_flag() = on != 0; }
+// diagnostic event counters (oracle_la.hpp EventCounts), in declaration order; reset != 0 clears them after reading
+void orc_event_counts(long* out8, int reset) {
+  EventCounts& c = event_counts();
+  const long v[8] = {c.pow_calls, c.pow_first_iter, c.pow_first_iter_eta_reset, c.pow_first_iter_eta_reset_ts, c.pow_rate, c.step_size_updates, c.order_selections, c.powi_calls};
+  for (int k = 0; k < 8; ++k) out8[k] = v[k];
+  if (reset) c = EventCounts();
+}
 double orc_det_pow(double x, double y) { return dsh_det_pow(x, y); }
 
 // --- small KAT entry points for the LA / NL restatement ---

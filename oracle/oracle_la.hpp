@@ -234,7 +234,7 @@ struct FullPivLU {
 inline bool& det_pow_flag() { static bool f = false; return f; }
 // event counters (diagnostic: how often a BDF run takes each of its paths; scripts/phase_frequencies.py reads them through orc_event_counts)
 struct EventCounts { long pow_calls = 0, pow_first_iter = 0, pow_first_iter_eta_reset = 0, pow_first_iter_eta_reset_ts = 0, pow_rate = 0, step_size_updates = 0, order_selections = 0, powi_calls = 0; };
-inline EventCounts& event_counts() { static EventCounts c; return c; }
+inline EventCounts& event_counts() { static thread_local EventCounts c; return c; }  // per thread: the multi-threaded baseline must not share a cache line
 inline double rpow(double x, double y) { event_counts().pow_calls++; return det_pow_flag() ? dsh_det_pow(x, y) : std::pow(x, y); }
 
 // compiler-rt __powidf2 (what Rust's f64::powi lowers to) — convergence.rs:85 uses `rate.pow(i32)`.

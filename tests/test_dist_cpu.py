@@ -101,3 +101,31 @@ def test_sharded_solve_and_gather_over_gloo(world, n_total):
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == list(range(world))
     assert all(r[1] for r in results), results
+
+
+def _compile_rank(rank, cache_dir, q):
+    os.environ["DSH_JIT_CACHE"] = cache_dir
+    os.environ["WORLD_SIZE"] = "4"
+    from diffsol_amd import _ffi, diffsl as fe
+    import diffsl_models as D
+    m = fe.DiffslModel(D.heat1d(24))
+    m.precompile(fe.FAMILY_RESIDENT_BDF)
+    q.put((rank, int(_ffi.load_device_lib().dsh_jit_compile_count())))
+    m.release()
+
+
+def test_ranks_that_meet_the_same_model_on_a_cold_cache_compile_it_once(tmp_path):
+    """One process per GPU: four ranks start together, each builds the same DiffSL model against one cold on-disk cache (DSH_JIT_CACHE).  The
+    entry lock of dsh_jit.hip makes ONE of them run hiprtc (seconds to minutes per kernel family) while the others wait and load its code object:
+    dsh_jit_compile_count sums to the number of distinct modules, not to four times that; every rank ends with the module loaded."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_compile_rank, args=(r, str(tmp_path), q)) for r in range(4)]
+    for p in procs: p.start()
+    for p in procs: p.join(600)
+    assert all(p.exitcode == 0 for p in procs)
+    counts = dict(q.get(timeout=10) for _ in range(4))
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) >= 1 and not [f for f in os.listdir(tmp_path) if ".tmp" in f or f.endswith(".lock")]
+    assert sum(counts.values()) == len(files), (counts, files)
