@@ -35,6 +35,10 @@ C_ABI = {
     "diffsol_ode_get_sens_rtol": (_i32, [_vp, C.POINTER(_i32), _dp]), "diffsol_ode_set_sens_rtol": (_i32, [_vp, _i32, _dbl]),
     "diffsol_ode_get_sens_atol": (_i32, [_vp, C.POINTER(_i32), _dp]), "diffsol_ode_set_sens_atol": (_i32, [_vp, _i32, _dbl]),
     "diffsol_solution_wrapper_get_sens": (_i32, [_vp, C.POINTER(C.POINTER(_vp)), C.POINTER(_sz)]), "diffsol_host_array_list_free": (None, [C.POINTER(_vp), _sz]),
+    "diffsol_ode_new_external": (_vp, [_i32, _i32, _i32, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "diffsol_ode_new_external_dynamic": (_vp, [C.c_char_p, _i32, _i32, _i32, _vp, _sz, _vp, _sz, _vp, _sz]),
+    "diffsol_ode_get_integrate_out": (_i32, [_vp, C.POINTER(_i32)]), "diffsol_ode_set_integrate_out": (_i32, [_vp, _i32]),
+    "diffsol_alloc_string": (_vp, [_sz]), "diffsol_free_string": (None, [_vp, _sz]), "diffsol_alloc": (_vp, [_sz, _sz]), "diffsol_free": (None, [_vp, _sz, _sz]),
     "diffsol_ode_get_matrix_type": (_i32, [_vp]), "diffsol_ode_get_ode_solver": (_i32, [_vp]), "diffsol_ode_set_ode_solver": (_i32, [_vp, _i32]),
     "diffsol_ode_get_linear_solver": (_i32, [_vp]), "diffsol_ode_set_linear_solver": (_i32, [_vp, _i32]),
     "diffsol_ode_get_ensemble_mode": (_i32, [_vp]), "diffsol_ode_set_ensemble_mode": (_i32, [_vp, _i32]),
@@ -49,6 +53,9 @@ for _kind in ("matrix", "linear_solver", "ode_solver", "scalar", "jit_backend"):
     C_ABI[f"diffsol_{_kind}_type_count"] = (_sz, [])
     C_ABI[f"diffsol_{_kind}_type_is_valid"] = (_i32, [_i32])
     C_ABI[f"diffsol_{_kind}_type_name"] = (C.c_char_p, [_i32])
+for _f in ("out_rtol", "out_atol", "param_rtol", "param_atol"):
+    C_ABI[f"diffsol_ode_get_{_f}"] = (_i32, [_vp, C.POINTER(_i32), _dp])
+    C_ABI[f"diffsol_ode_set_{_f}"] = (_i32, [_vp, _i32, _dbl])
 for _f in ("rtol", "atol", "t0", "h0"):
     C_ABI[f"diffsol_ode_get_{_f}"] = (_i32, [_vp, _dp])
     C_ABI[f"diffsol_ode_set_{_f}"] = (_i32, [_vp, _dbl])
@@ -167,6 +174,16 @@ class Ode:
         if not h:
             _check(ERR)
         self._h = h
+
+    @classmethod
+    def external_dynamic(cls, path, matrix_type=MATRIX_HIP_DENSE, linear_solver=LINEAR_SOLVER_DEFAULT, ode_solver=ODE_SOLVER_BDF):
+        """diffsol_ode_new_external_dynamic: a HIP source file with the reference's external model functions as device functions (include/diffsol_c_hip.h)."""
+        h = lib().diffsol_ode_new_external_dynamic(str(path).encode(), matrix_type, linear_solver, ode_solver, None, 0, None, 0, None, 0)
+        if not h:
+            _check(ERR)
+        self = cls.__new__(cls)
+        self._h = h
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -58,6 +58,10 @@ struct diffsol_ode_wrapper {
   double rtol = 1e-6, t0 = 0.0, h0 = 1.0;
   std::vector<double> atol{1e-6};
   std::optional<double> sens_rtol, sens_atol;  // None: the sensitivities stay out of the error control (ode.rs get/set_sens_rtol / _atol)
+  // ode.rs:319-388: stored and returned like the reference's; integrating the outputs and the adjoint tolerances are not implemented by this backend,
+  // so a solve of a wrapper with integrate_out set fails with an explicit error instead of silently ignoring it
+  bool integrate_out = false;
+  std::optional<double> out_rtol, out_atol, param_rtol, param_atol;
   bool out_is_state = false;                   // out_i { u_i }: the outputs are the states
   std::shared_ptr<Settings> settings;
   ~diffsol_ode_wrapper() {
@@ -311,6 +315,108 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   }
   return ode.release();
 }
+
+namespace {
+// `#define NAME <unsigned>` in a user's external HIP source
+bool macro_value(const std::string& text, const char* name, int64_t* out) {
+  const std::string key = std::string("#define ") + name;
+  size_t p = text.find(key);
+  while (p != std::string::npos) {
+    size_t q = p + key.size();
+    if (q < text.size() && (text[q] == ' ' || text[q] == '\t')) {
+      while (q < text.size() && (text[q] == ' ' || text[q] == '\t')) ++q;
+      char* end = nullptr;
+      const long long v = std::strtoll(text.c_str() + q, &end, 10);
+      if (end != text.c_str() + q && v >= 0) { *out = v; return true; }
+    }
+    p = text.find(key, p + 1);
+  }
+  return false;
+}
+}  // namespace
+
+// diffsol_ode_new_external (ode_c.rs:181-230): a model whose functions are LINKED INTO the library.  Nothing is linked into this one — device code is
+// compiled at run time — so the constructor exists for binding compatibility and reports that; diffsol_ode_new_external_dynamic takes the model as a file.
+OdeWrapper* diffsol_ode_new_external(int32_t matrix_type, int32_t linear_solver, int32_t ode_solver, const DiffsolDepPair* rhs_state_deps_ptr, size_t rhs_state_deps_len,
+                                     const DiffsolDepPair* rhs_input_deps_ptr, size_t rhs_input_deps_len, const DiffsolDepPair* mass_state_deps_ptr,
+                                     size_t mass_state_deps_len) {
+  (void)matrix_type; (void)linear_solver; (void)ode_solver; (void)rhs_state_deps_ptr; (void)rhs_state_deps_len; (void)rhs_input_deps_ptr; (void)rhs_input_deps_len;
+  (void)mass_state_deps_ptr; (void)mass_state_deps_len;
+  C_ERROR("diffsol_ode_new_external: no model is statically linked into the HIP backend (device code is compiled at run time); "
+          "use diffsol_ode_new_external_dynamic with the path of a HIP source that defines the external functions");
+  return nullptr;
+}
+
+// diffsol_ode_new_external_dynamic (ode_c.rs:232-281).  The reference loads a shared library that exports the external model ABI (set_u0, rhs, rhs_grad,
+// mass, calc_out, calc_stop, set_inputs, get_dims, ...: crates/diffsol-c/tests/external-dynamic-logistic/src/lib.rs).  A device backend cannot call host
+// code, so `path` names a HIP SOURCE file instead that defines the same functions, same names and argument orders, as device functions
+// (`DIFFSOL_DEVICE void rhs(double time, const double* u, double* data, double* rr, uint32_t thread_id, uint32_t thread_dim)` ...), and states what
+// get_dims would return as macros: DIFFSOL_EXTERNAL_STATES, _INPUTS, _OUTPUTS, _DATA, _STOP, _HAS_MASS.  Required: set_inputs(const double* inputs,
+// double* data), set_u0(u, data, tid, tdim), rhs, rhs_grad(time, u, du, data, ddata, rr, drr, tid, tdim); with _HAS_MASS: mass(time, v, data, mv, tid, tdim);
+// with _STOP > 0: calc_stop(time, u, data, root, tid, tdim); with _OUTPUTS > 0: calc_out(time, u, data, out, tid, tdim) (else the outputs are the states).
+// thread_id = 0, thread_dim = 1: one ensemble member per lane.  Register-resident form: at most 8 states and one stop condition.  The dependency
+// lists (sparsity) are accepted and not needed: Jacobians are assembled dense from rhs_grad.
+OdeWrapper* diffsol_ode_new_external_dynamic(const char* path, int32_t matrix_type, int32_t linear_solver, int32_t ode_solver, const DiffsolDepPair* rhs_state_deps_ptr,
+                                             size_t rhs_state_deps_len, const DiffsolDepPair* rhs_input_deps_ptr, size_t rhs_input_deps_len,
+                                             const DiffsolDepPair* mass_state_deps_ptr, size_t mass_state_deps_len) {
+  if (!path) { C_INVALID_ARG("path is null"); return nullptr; }
+  if ((!rhs_state_deps_ptr && rhs_state_deps_len) || (!rhs_input_deps_ptr && rhs_input_deps_len) || (!mass_state_deps_ptr && mass_state_deps_len)) {
+    C_INVALID_ARG("dependency pointer is null with a non-zero length"); return nullptr;
+  }
+  if (!enum_valid(kMatrix, matrix_type)) { C_INVALID_ARG("invalid matrix_type (this library provides hip_dense)"); return nullptr; }
+  if (!enum_valid(kLinear, linear_solver)) { C_INVALID_ARG("invalid linear_solver_type"); return nullptr; }
+  if (!enum_valid(kOdeSolver, ode_solver)) { C_INVALID_ARG("invalid ode_solver_type"); return nullptr; }
+  std::string text;
+  {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { C_ERROR(std::string("diffsol_ode_new_external_dynamic: cannot open ") + path); return nullptr; }
+    char buf[4096];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+    std::fclose(f);
+  }
+  int64_t ns = -1, ni = -1, no = 0, nd = 0, nstop = 0, hm = 0;
+  if (!macro_value(text, "DIFFSOL_EXTERNAL_STATES", &ns) || !macro_value(text, "DIFFSOL_EXTERNAL_INPUTS", &ni)) {
+    C_ERROR("diffsol_ode_new_external_dynamic: the source must #define DIFFSOL_EXTERNAL_STATES and DIFFSOL_EXTERNAL_INPUTS (what get_dims returns)"); return nullptr;
+  }
+  (void)macro_value(text, "DIFFSOL_EXTERNAL_OUTPUTS", &no); (void)macro_value(text, "DIFFSOL_EXTERNAL_DATA", &nd);
+  (void)macro_value(text, "DIFFSOL_EXTERNAL_STOP", &nstop); (void)macro_value(text, "DIFFSOL_EXTERNAL_HAS_MASS", &hm);
+  if (ns < 1 || ns > 8 || nstop > 1) { C_ERROR("diffsol_ode_new_external_dynamic: external models run in the register-resident form: 1..8 states, at most one stop condition"); return nullptr; }
+  const bool no_inputs = ni == 0;
+  const int64_t np = no_inputs ? 1 : ni, nout = no > 0 ? no : ns;
+  std::string src = "// adapter generated by diffsol_ode_new_external_dynamic around a user's external model (the reference's external ABI as device functions)\n"
+                    "#include <stdint.h>\n#define DIFFSOL_DEVICE __device__ static inline\nnamespace dsh_ext {\n" + text + "\n}  // namespace dsh_ext\nnamespace dsh {\nstruct JitModel {\n";
+  src += "  static constexpr int N = " + std::to_string(ns) + ", NP = " + std::to_string(np) + ", NROOTS = " + std::to_string(nstop) + ", NOUT = " + std::to_string(nout) + ";\n";
+  src += std::string("  static constexpr bool HAS_MASS = ") + (hm ? "true" : "false") + ";\n  static constexpr int ND = " + std::to_string(nd > 0 ? nd : 1) + ";\n";
+  src += "  __device__ static void load(const double (&p)[NP], double (&data)[ND]) {\n    for (int k = 0; k < ND; ++k) data[k] = 0.0;\n";
+  src += no_inputs ? "    (void)p;\n  }\n" : "    dsh_ext::set_inputs(p, data);\n  }\n";
+  src += "  __device__ static void rhs(double t, const double (&x)[N], const double (&p)[NP], double (&y)[N]) { double data[ND]; load(p, data); dsh_ext::rhs(t, x, data, y, 0u, 1u); }\n";
+  src += "  __device__ static void jac_mul(double t, const double (&x)[N], const double (&p)[NP], const double (&v)[N], double (&y)[N]) {\n"
+         "    double data[ND], ddata[ND], rr[N];\n    load(p, data);\n    for (int k = 0; k < ND; ++k) ddata[k] = 0.0;\n"
+         "    dsh_ext::rhs(t, x, data, rr, 0u, 1u);\n    dsh_ext::rhs_grad(t, x, v, data, ddata, rr, y, 0u, 1u);\n  }\n";
+  src += "  __device__ static void mass_gemv(double t, const double (&x)[N], const double (&p)[NP], double beta, double (&y)[N]) {\n";
+  src += hm ? "    double data[ND], mv[N];\n    load(p, data);\n    dsh_ext::mass(t, x, data, mv, 0u, 1u);\n    for (int i = 0; i < N; ++i) y[i] = mv[i] + beta * y[i];\n  }\n"
+            : "    (void)t; (void)p;\n    for (int i = 0; i < N; ++i) y[i] = x[i] + beta * y[i];\n  }\n";
+  src += "  __device__ static void init(double t, const double (&p)[NP], double (&y)[N]) { (void)t; double data[ND]; load(p, data); dsh_ext::set_u0(y, data, 0u, 1u); }\n";
+  src += std::string("  __device__ static void root(double t, const double (&x)[N], const double (&p)[NP], double (&g)[") + std::to_string(nstop > 0 ? nstop : 1) + "]) {\n";
+  src += nstop > 0 ? "    double data[ND]; load(p, data); dsh_ext::calc_stop(t, x, data, g, 0u, 1u);\n  }\n" : "    (void)t; (void)x; (void)p; g[0] = 1.0;\n  }\n";
+  src += "  __device__ static void out(double t, const double (&x)[N], const double (&p)[NP], double (&g)[NOUT]) {\n";
+  src += no > 0 ? "    double data[ND]; load(p, data); dsh_ext::calc_out(t, x, data, g, 0u, 1u);\n  }\n" : "    (void)t; (void)p;\n    for (int i = 0; i < N; ++i) g[i] = x[i];\n  }\n";
+  src += "};\n}  // namespace dsh\n";
+  auto ode = std::make_unique<diffsol_ode_wrapper>();
+  ode->code = src;
+  ode->linear_solver = linear_solver;
+  ode->ode_solver = ode_solver;
+  ode->settings = std::make_shared<Settings>();
+  dshs_default_options(&ode->settings->o);
+  ode->n = ns; ode->np = np; ode->nroots = nstop; ode->nout = nout; ode->has_mass = hm != 0; ode->no_inputs = no_inputs;
+  ode->defaults.assign((size_t)np, 0.0);
+  ode->out_is_state = no == 0;
+  int id = -1;
+  if (dsh_model_compile(src.c_str(), DSH_JIT_FORM_STATIC, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &id) != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
+  ode->model = id;
+  return ode.release();
+}
 void diffsol_ode_free(OdeWrapper* ode) {
   if (!ode) { C_INVALID_ARG("ode is null"); return; }
   delete ode;
@@ -341,6 +447,7 @@ int32_t diffsol_ode_rhs_jac_mul(OdeWrapper* ode, const double* params_ptr, size_
 
 int32_t diffsol_ode_solve(OdeWrapper* ode, const double* params_ptr, size_t params_len, double final_time, SolutionWrapper** out_solution) {
   if (!ode || !out_solution || (!params_ptr && params_len)) return C_INVALID_ARG("invalid arguments to diffsol_ode_solve");
+  if (ode->integrate_out) return C_ERROR("integrate_out is set: integrating the output equations alongside the states is not implemented by the HIP backend (clear it with diffsol_ode_set_integrate_out)");
   if (ode->ensemble_mode != DIFFSOL_ENSEMBLE_LOCKSTEP && ode->ensemble_mode != DIFFSOL_ENSEMBLE_AUTO)
     return C_ERROR("solve() returns every internal step, which only exists for the lock-step ensemble; use solve_dense with the per-member / wavefront modes");
   SolverGuard g;
@@ -370,6 +477,7 @@ int32_t diffsol_ode_solve(OdeWrapper* ode, const double* params_ptr, size_t para
 int32_t diffsol_ode_solve_dense(OdeWrapper* ode, const double* params_ptr, size_t params_len, const double* t_eval_ptr, size_t t_eval_len,
                                 SolutionWrapper** out_solution) {
   if (!ode || !out_solution || (!params_ptr && params_len) || !t_eval_ptr || t_eval_len == 0) return C_INVALID_ARG("invalid arguments to diffsol_ode_solve_dense");
+  if (ode->integrate_out) return C_ERROR("integrate_out is set: integrating the output equations alongside the states is not implemented by the HIP backend (clear it with diffsol_ode_set_integrate_out)");
   SolverGuard g;
   int64_t nb = 0;
   int32_t rc = make_solver(ode, params_ptr, params_len, &g, &nb);
@@ -426,6 +534,7 @@ int32_t diffsol_ode_solve_fwd_sens(OdeWrapper* ode, const double* params_ptr, si
                                    SolutionWrapper** out_solution) {
   if (!ode || !out_solution || (!params_ptr && params_len) || (!t_eval_ptr && t_eval_len)) return C_INVALID_ARG("invalid arguments to diffsol_ode_solve_fwd_sens");
   if (t_eval_len == 0) return C_ERROR("t_eval must not be empty");
+  if (ode->integrate_out) return C_ERROR("integrate_out is set: integrating the output equations alongside the states is not implemented by the HIP backend (clear it with diffsol_ode_set_integrate_out)");
   if (ode->no_inputs) return C_ERROR("the model has no inputs: nothing to differentiate with respect to");
   if (ode->nout != 0 && !ode->out_is_state) return C_ERROR("solve_fwd_sens with an out_i other than the states is not supported by the HIP backend (omit out_i or use out_i { u_i })");
   for (size_t k = 0; k + 1 < t_eval_len; ++k) if (t_eval_ptr[k] > t_eval_ptr[k + 1]) return C_ERROR("t_eval must be increasing");
@@ -503,6 +612,49 @@ int32_t diffsol_ode_set_sens_atol(OdeWrapper* ode, int32_t value_is_some, double
   if (value_is_some) ode->sens_atol = value; else ode->sens_atol.reset();
   return DIFFSOL_OK;
 }
+
+
+// ode_c.rs:893-1190: integrate_out and the output / parameter tolerances of the adjoint equations — kept and returned; see diffsol_ode_wrapper
+int32_t diffsol_ode_get_integrate_out(const OdeWrapper* ode, int32_t* out_value) {
+  if (!ode || !out_value) return C_INVALID_ARG("invalid arguments to diffsol_ode_get_integrate_out");
+  *out_value = ode->integrate_out ? 1 : 0;
+  return DIFFSOL_OK;
+}
+int32_t diffsol_ode_set_integrate_out(OdeWrapper* ode, int32_t value) {
+  if (!ode) return C_INVALID_ARG("ode is null");
+  ode->integrate_out = value != 0;
+  return DIFFSOL_OK;
+}
+#define DIFFSOL_OPTIONAL_F64(field)                                                                                         \
+  int32_t diffsol_ode_get_##field(const OdeWrapper* ode, int32_t* out_is_some, double* out_value) {                          \
+    if (!ode || !out_is_some || !out_value) return C_INVALID_ARG("invalid arguments to diffsol_ode_get_" #field);            \
+    *out_is_some = ode->field.has_value() ? 1 : 0; *out_value = ode->field.value_or(0.0);                                   \
+    return DIFFSOL_OK;                                                                                                      \
+  }                                                                                                                         \
+  int32_t diffsol_ode_set_##field(OdeWrapper* ode, int32_t value_is_some, double value) {                                    \
+    if (!ode) return C_INVALID_ARG("ode is null");                                                                           \
+    if (value_is_some) ode->field = value; else ode->field.reset();                                                         \
+    return DIFFSOL_OK;                                                                                                      \
+  }
+DIFFSOL_OPTIONAL_F64(out_rtol)
+DIFFSOL_OPTIONAL_F64(out_atol)
+DIFFSOL_OPTIONAL_F64(param_rtol)
+DIFFSOL_OPTIONAL_F64(param_atol)
+#undef DIFFSOL_OPTIONAL_F64
+
+// string_c.rs:11-78: memory the caller fills and hands to the library (bindings build their strings in it)
+char* diffsol_alloc_string(size_t size) { return size == 0 ? nullptr : (char*)std::calloc(size, 1); }
+void diffsol_free_string(char* ptr, size_t size) { if (ptr && size) std::free(ptr); }
+uint8_t* diffsol_alloc(size_t size, size_t align) {
+  if (size == 0) return nullptr;
+  if (align == 0) align = 1;
+  if (align & (align - 1)) return nullptr;  // Layout::from_size_align refuses alignments that are not powers of two
+  void* p = nullptr;
+  if (align <= alignof(max_align_t)) return (uint8_t*)std::malloc(size);
+  if (posix_memalign(&p, align < sizeof(void*) ? sizeof(void*) : align, size) != 0) return nullptr;
+  return (uint8_t*)p;
+}
+void diffsol_free(uint8_t* ptr, size_t size, size_t align) { (void)align; if (ptr && size) std::free(ptr); }
 
 int32_t diffsol_ode_get_matrix_type(const OdeWrapper* ode) { if (!ode) { C_INVALID_ARG("ode is null"); return -1; } return DIFFSOL_MATRIX_HIP_DENSE; }
 int32_t diffsol_ode_get_ode_solver(const OdeWrapper* ode) { if (!ode) { C_INVALID_ARG("ode is null"); return -1; } return ode->ode_solver; }

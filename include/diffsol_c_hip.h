@@ -115,6 +115,20 @@ const char* diffsol_jit_backend_type_name(int32_t value);
 /* ---- ode_c.rs */
 /* diffsol_ode_new_jit (ode_c.rs:263-317): DiffSL text -> model (front end + hiprtc).  NULL on error. */
 OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t matrix_type, int32_t linear_solver, int32_t ode_solver);
+/* ode_c.rs:46-49 */
+typedef struct DiffsolDepPair { size_t row, col; } DiffsolDepPair;
+/* diffsol_ode_new_external (ode_c.rs:181-230): models linked into the library.  Nothing is linked into this one (device code is compiled at run time):
+ * always NULL with an error message that points to diffsol_ode_new_external_dynamic. */
+OdeWrapper* diffsol_ode_new_external(int32_t matrix_type, int32_t linear_solver, int32_t ode_solver, const DiffsolDepPair* rhs_state_deps_ptr, size_t rhs_state_deps_len,
+                                     const DiffsolDepPair* rhs_input_deps_ptr, size_t rhs_input_deps_len, const DiffsolDepPair* mass_state_deps_ptr,
+                                     size_t mass_state_deps_len);
+/* diffsol_ode_new_external_dynamic (ode_c.rs:232-281).  `path`: a HIP SOURCE file that defines the reference's external model functions (same names and
+ * argument orders as crates/diffsol-c/tests/external-dynamic-logistic/src/lib.rs) as `DIFFSOL_DEVICE void name(...)` device functions — set_inputs,
+ * set_u0, rhs, rhs_grad; mass / calc_stop / calc_out when declared — and what get_dims returns as macros DIFFSOL_EXTERNAL_STATES, _INPUTS, _OUTPUTS, _DATA,
+ * _STOP, _HAS_MASS.  At most 8 states and one stop condition (register-resident form).  The dependency lists are accepted and not needed. */
+OdeWrapper* diffsol_ode_new_external_dynamic(const char* path, int32_t matrix_type, int32_t linear_solver, int32_t ode_solver, const DiffsolDepPair* rhs_state_deps_ptr,
+                                             size_t rhs_state_deps_len, const DiffsolDepPair* rhs_input_deps_ptr, size_t rhs_input_deps_len,
+                                             const DiffsolDepPair* mass_state_deps_ptr, size_t mass_state_deps_len);
 void diffsol_ode_free(OdeWrapper* ode);
 int32_t diffsol_ode_get_options(const OdeWrapper* ode, OdeSolverOptions** out_options);           /* shares state with the ode; free with _options_free */
 int32_t diffsol_ode_get_ic_options(const OdeWrapper* ode, InitialConditionSolverOptions** out_options);
@@ -133,6 +147,22 @@ int32_t diffsol_ode_get_sens_rtol(const OdeWrapper* ode, int32_t* out_is_some, d
 int32_t diffsol_ode_set_sens_rtol(OdeWrapper* ode, int32_t value_is_some, double value);
 int32_t diffsol_ode_get_sens_atol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
 int32_t diffsol_ode_set_sens_atol(OdeWrapper* ode, int32_t value_is_some, double value);
+/* ode_c.rs:893-1190: stored and returned; a solve with integrate_out set fails (not implemented by this backend) */
+int32_t diffsol_ode_get_integrate_out(const OdeWrapper* ode, int32_t* out_value);
+int32_t diffsol_ode_set_integrate_out(OdeWrapper* ode, int32_t value);
+int32_t diffsol_ode_get_out_rtol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_out_rtol(OdeWrapper* ode, int32_t value_is_some, double value);
+int32_t diffsol_ode_get_out_atol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_out_atol(OdeWrapper* ode, int32_t value_is_some, double value);
+int32_t diffsol_ode_get_param_rtol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_param_rtol(OdeWrapper* ode, int32_t value_is_some, double value);
+int32_t diffsol_ode_get_param_atol(const OdeWrapper* ode, int32_t* out_is_some, double* out_value);
+int32_t diffsol_ode_set_param_atol(OdeWrapper* ode, int32_t value_is_some, double value);
+/* string_c.rs:11-78 */
+char* diffsol_alloc_string(size_t size);
+void diffsol_free_string(char* ptr, size_t size);
+uint8_t* diffsol_alloc(size_t size, size_t align);
+void diffsol_free(uint8_t* ptr, size_t size, size_t align);
 int32_t diffsol_ode_get_matrix_type(const OdeWrapper* ode);
 int32_t diffsol_ode_get_ode_solver(const OdeWrapper* ode);
 int32_t diffsol_ode_set_ode_solver(OdeWrapper* ode, int32_t value);
