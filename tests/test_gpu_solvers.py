@@ -315,6 +315,20 @@ def test_full_size_ensemble_invariants(full_size_run):
     assert st["number_of_steps"] > 100 and st["number_of_nonlinear_solver_iterations"] >= st["number_of_steps"]
 
 
+def test_first_and_last_wavefront_group_of_the_full_size_run_equal_the_oracle_bitwise(O, full_size_run, request):
+    """BASELINE config 2 at its full 100 000 members, bit for bit where it costs nothing: the first wavefront group (members 0..63) and the
+    last, ragged one (members 99 968..99 999: 32 live lanes next to 32 shadow lanes) of the default run against the oracle's lock-step batched run of
+    exactly those members — the device-resident integrator's result for a member does not depend on how many other groups the launch has."""
+    p, t_eval, y, _, _ = full_size_run
+    if request.node.callspec.params.get("full_size_run") == "host_lockstep":
+        pytest.skip("the host-driven lock-step ensemble has ONE step sequence for all 100 000 members: its groups are not independent problems")
+    O.set_det_pow(True)
+    request.addfinalizer(lambda: O.set_det_pow(False))
+    for lo, hi in ((0, 64), (99_968, 100_000)):
+        yo, _, failed = O.solve_dense_independent(ORACLE_MODEL["robertson_ode"], p[lo:hi], t_eval, model_size=1, group=64, **ROB)
+        assert failed == 0 and np.array_equal(y[:, lo:hi], np.transpose(yo, (1, 0, 2)))
+
+
 def test_full_size_ensemble_members_agree_with_independent_cpu_solves(O, full_size_run):
     """'step counts may differ, solution error must not': a random sample of members, each re-solved on the CPU as an independent IVP
     with its own adaptive step sequence (the reference's CPU usage pattern), agrees within the reference's acceptance norm."""
