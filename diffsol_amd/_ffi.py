@@ -127,6 +127,7 @@ DEVICE_ABI = {
     "dsh_sdirk_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_jac_factor": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, cint, vp, vp, vp]),
     "dsh_model_has_fused": (cint, [cint, i64]),
+    "dsh_model_has_staged_newton": (cint, [cint, i64]),
     "dsh_model_has_adaptive": (cint, [cint, i64]),
     "dsh_adaptive_default_options": (None, [vp]),
     "dsh_model_has_wave_member": (cint, [cint, i64]),

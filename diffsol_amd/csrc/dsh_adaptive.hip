@@ -181,7 +181,7 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
     const JitInfo* ji = jit_info(model);
     const bool sched = sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
     // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
-    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }();
+    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }());  // models with a mass matrix: k_bdf_lane_banded only
     const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
                              : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;

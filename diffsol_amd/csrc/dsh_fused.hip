@@ -150,9 +150,40 @@ int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
                                 int64_t* ticket) {
   return newton_launch(ctx, true, model, size, nb, t, c, h, nit, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, ticket);
 }
+// Run-time-sized registry models without a mass matrix (heat1d, spm, ...: no register-resident specialisation): the same iteration as three launches
+// instead of seven — residual (tmp, rhs and the axpy in one pass), the LU solve, Newton update + norm in one pass — and ONE wait for both result records
+// (zero-pivot count of the solve, norm).  Entry by entry the arithmetic of SdirkCallable::call_inplace + NoLineSearch::take_optimal_step through the vector
+// kernels: bit-identical iterates.
+int dsh_model_has_staged_newton(int model, int64_t size) { return model_has_staged_newton(model, size) ? 1 : 0; }
+static int sdirk_newton_staged(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, const double* k_in, double* k_out, const double* phi,
+                               const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol, double* out) {
+  DSH_REQUIRE(lu != nullptr && out != nullptr, "null argument");
+  if (!lu->factored) { set_error("newton iteration: LU not initialised"); return DSH_E_NOT_SETUP; }
+  int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+  int rc = ensure_f64_scratch(ctx, n * nb);
+  if (rc != DSH_OK) return rc;
+  double* delta = ctx->f64_scratch;
+  if (!model_dyn_sdirk_residual(ctx, model, size, nb, t, c, h, phi, k_in, p, delta)) { set_error("newton iteration: model has no staged form"); return DSH_E_UNSUPPORTED; }
+  unsigned int gs = 0, ss = 0, gn = 0, sn = 0;
+  rc = lu_solve_launch(lu, delta, &gs, &ss);
+  if (rc != DSH_OK) return rc;
+  rc = vec_sub_squared_norm_launch(ctx, n, nb, delta, k_in, k_out, error_y, nb, atol, anb, rtol, &gn, &sn);
+  if (rc != DSH_OK) return rc;
+  DSH_HIP_CHECK(hipGetLastError());
+  rc = fetch_records(ctx, gn, sn);  // the later launch first: when its records are there the solve's are too
+  if (rc != DSH_OK) return rc;
+  out[0] = bits_to_double(ctx->res_m0);
+  out[1] = 0.0;
+  rc = fetch_records(ctx, gs, ss);
+  if (rc != DSH_OK) return rc;
+  out[2] = (double)ctx->res_cnt;
+  return DSH_OK;
+}
+
 int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, const double* k_in, double* k_out,
                           const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
                           double* out) {
+  if (dsh_model_has_staged_newton(model, size)) return sdirk_newton_staged(ctx, model, size, nb, t, h, c, k_in, k_out, phi, p, lu, error_y, atol, anb, rtol, out);
   int64_t ticket = 0;
   int rc = newton_launch(ctx, true, model, size, nb, t, c, h, 1, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, &ticket);
   if (rc != DSH_OK) return rc;

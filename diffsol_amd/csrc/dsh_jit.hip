@@ -336,7 +336,7 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   DSH_REQUIRE(source != nullptr && model_id != nullptr, "null argument");
   DSH_REQUIRE(form == DSH_JIT_FORM_STATIC || form == DSH_JIT_FORM_DYNAMIC || form == DSH_JIT_FORM_STATIC_BANDED, "unknown model form");
   DSH_REQUIRE(n >= 1 && nparams >= 1 && nroots >= 0 && nout >= 0, "bad model dimensions");
-  if (form == DSH_JIT_FORM_STATIC_BANDED) DSH_REQUIRE(n <= 512 && !has_mass && nroots <= 8, "the lane-per-member banded form needs n <= 512, an identity mass matrix and at most 8 stop conditions");
+  if (form == DSH_JIT_FORM_STATIC_BANDED) DSH_REQUIRE(n <= 512 && nroots <= 8, "the lane-per-member banded form needs n <= 512 and at most 8 stop conditions (a mass matrix must be diagonal)");
   if (form == DSH_JIT_FORM_STATIC) {
     DSH_REQUIRE(n <= 8, "the register-resident form needs n <= 8");
     DSH_REQUIRE(nroots <= 1, "the register-resident form supports at most one root function; use the dynamic form");

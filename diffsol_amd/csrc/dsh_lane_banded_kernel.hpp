@@ -46,6 +46,118 @@ constexpr int lb_chunk(int n, int want) {
 #define DSH_LANE_BANDED_CHUNK_SCALE 1
 #endif
 
+
+// StateRefMut::set_consistent (state.rs:84-162) over InitOp (op/init.rs:14-135) for a banded model with a DIAGONAL mass matrix, every array in per-lane
+// memory: the restatement of dsh_resident.hpp's set_consistent (Newton on (du for the differential, v for the algebraic unknowns), backtracking line
+// search, line_search.rs:84-201) with the banded LU in place of the dense one — the same eliminations in the same order on a banded matrix, so the same
+// bits as the oracle's dense solve.  md: the diagonal of M (0 = algebraic row).  y / dy in-out; Jb, Lf, Uf, P: the kernel's band / factor storage, free at
+// this point.  Returns false for InitialConditionDidNotConverge.
+template <class Mdl, bool WAVE, bool BA>
+__device__ __forceinline__ bool set_consistent_banded(double t0, const double (&p)[Mdl::NP], double* y, double* dy, const double* md, const double* atol_g, int64_t nb,
+                                                      int64_t b, double rtol, const ResidentConsts& C, double* Jb, double* Lf, double* Uf, int* P) {
+  constexpr int N = Mdl::N, K = model_band_k<Mdl>::value;
+  const dsh_adaptive_options& o = C.o;
+  auto AT = [&](int i) __attribute__((always_inline)) -> double { return BA ? atol_g[i] : atol_g[(int64_t)i * nb + b]; };
+  bool any_alg = false;
+  for (int i = 0; i < N; ++i) any_alg = any_alg || md[i] == 0.0;  // partition_indices_by_zero_diagonal
+  if (!any_alg) return true;
+  // InitOp::new: jac = (-M_u, df/dv; 0, dg/dv): column j of f_y for an algebraic unknown j, -M's column for a differential one
+  Mdl::jac_band(t0, *reinterpret_cast<const double (*)[N]>(y), p, *reinterpret_cast<double (*)[(2 * K + 1) * N]>(Jb));
+  alignas(16) double y0[N], x[N], yerr[N], delta[N], x0[N], delta0[N];
+  for (int i = 0; i < N; ++i) { y0[i] = y[i]; x[i] = md[i] == 0.0 ? y[i] : dy[i]; yerr[i] = x[i]; delta[i] = 0.0; }
+  // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out — with a diagonal neg_mass the gemv leaves (-m_i) x_i + out_i
+  auto fun = [&](const double* xx, double* out) __attribute__((always_inline)) {
+    for (int i = 0; i < N; ++i) if (md[i] == 0.0) y0[i] = xx[i];
+    Mdl::rhs(t0, *reinterpret_cast<const double (*)[N]>(y0), p, *reinterpret_cast<double (*)[N]>(out));
+    for (int i = 0; i < N; ++i) if (md[i] != 0.0) out[i] = (md[i] * (-1.0)) * xx[i] + out[i];
+  };
+  auto norm_of = [&](const double* v) __attribute__((always_inline)) -> double {  // Convergence::norm against yerr
+    double acc = 0.0;
+    for (int i = 0; i < N; ++i) { const double term = v[i] / (fabs(yerr[i]) * rtol + AT(i)); acc += term * term; }
+    return sqrt(group_norm<WAVE>(acc / (double)N));
+  };
+  ConvState conv;
+  conv.eta = C.eta_reset;
+  conv.tol = o.nonlinear_solver_tolerance;
+  conv.max_iter = o.ic_max_newton_iterations;
+  conv.det = o.deterministic_pow != 0;
+  bool ok = false;
+  for (int k = 0; k < o.ic_max_linear_solver_setups; ++k) {
+    // reset_jacobian: the InitOp Jacobian is constant
+    bool sing = false;
+    band_factor_lane_fn<N, K>([&](int i, int col) -> double {
+      if (md[col] == 0.0) return Jb[(col - i + K) * N + i];
+      return i == col ? md[col] * (-1.0) : 0.0;
+    }, Lf, Uf, P, sing);
+    conv.reset();
+    double ls_norm = 1.0;
+    int result = 2;  // 0 ok, 1 fatal (diverged / LU / line search), 2 NewtonMaxIterations
+    for (int it = 0; it < conv.max_iter; ++it) {
+      ConvStatus st = ConvStatus::Continue;
+      bool fatal = false;
+      if (!o.ic_use_linesearch) {  // NoLineSearch::take_optimal_step
+        fun(x, delta);
+        if (!group_all<WAVE>(band_solve_lane<N, K>(Lf, Uf, P, delta))) fatal = true;
+        else {
+          for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+          st = conv.check_new_iteration(norm_of(delta));
+        }
+      } else {  // BacktrackingLineSearch::take_optimal_step
+        bool returned = false;
+        if (conv.niter == 0) {
+          fun(x, delta);
+          if (!group_all<WAVE>(band_solve_lane<N, K>(Lf, Uf, P, delta))) { fatal = true; returned = true; }
+          else {
+            ls_norm = norm_of(delta);
+            if (conv.check_norm(ls_norm) == ConvStatus::Converged) {
+              for (int i = 0; i < N; ++i) x[i] = x[i] - delta[i];
+              st = ConvStatus::Converged;
+              returned = true;
+            }
+          }
+        }
+        if (!returned) {
+          for (int i = 0; i < N; ++i) { x0[i] = x[i]; delta0[i] = delta[i]; }
+          const double nrm = ls_norm;
+          const double phi0 = nrm * nrm * 0.5, two_phi0 = nrm * nrm, min_alpha = C.ls_steptol / nrm;
+          double alpha = 1.0;
+          bool found = false;
+          for (int i = 0; i < o.ic_max_linesearch_iterations; ++i) {
+            for (int q = 0; q < N; ++q) x[q] = (-alpha) * delta0[q] + 1.0 * x[q];
+            fun(x, delta);
+            if (!group_all<WAVE>(band_solve_lane<N, K>(Lf, Uf, P, delta))) { fatal = true; break; }
+            const double new_norm = norm_of(delta);
+            const double phi1 = new_norm * new_norm * 0.5;
+            if (phi1 <= phi0 - o.ic_armijo_constant * alpha * two_phi0) {
+              ls_norm = new_norm;
+              st = conv.check_norm(new_norm);
+              found = true;
+              break;
+            }
+            if (alpha < min_alpha) { fatal = true; break; }  // LinesearchFailedMinStep
+            alpha *= o.ic_step_reduction_factor;
+            for (int q = 0; q < N; ++q) x[q] = x0[q];
+          }
+          if (!found) fatal = true;  // incl. LinesearchFailedMaxIterations
+        }
+      }
+      if (fatal) { result = 1; break; }
+      if (st == ConvStatus::Converged) { result = 0; break; }
+      if (st == ConvStatus::Diverged) { result = 1; break; }
+    }
+    if (result == 0) { ok = true; break; }
+    if (result != 2) return false;  // anything but NewtonMaxIterations is fatal (state.rs:131-140)
+    for (int i = 0; i < N; ++i) yerr[i] = x[i];
+  }
+  if (!ok) return false;
+  // scatter_soln (:76-81) + zero the algebraic derivatives (state.rs:155-158)
+  for (int i = 0; i < N; ++i) {
+    if (md[i] == 0.0) { y[i] = x[i]; dy[i] = 0.0; }
+    else dy[i] = x[i];
+  }
+  return true;
+}
+
 template <class Mdl, bool BA, bool WAVE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BANDED_WAVES_PER_EU, DSH_LANE_BANDED_WAVES_PER_EU))) void k_bdf_lane_banded(
     int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp, const double* __restrict__ t_eval,
@@ -54,7 +166,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BAN
   constexpr int N = Mdl::N, NP = Mdl::NP;
   constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
   constexpr int K = model_band_k<Mdl>::value, RW = K + 1, CW = 2 * K + 1;
-  static_assert(K > 0 && !Mdl::HAS_MASS, "k_bdf_lane_banded: banded models with an identity mass matrix");
+  static_assert(K > 0, "k_bdf_lane_banded: banded models");  // a mass matrix must be DIAGONAL (checked where the model is made: mass bandwidths 0, 0)
   const AdaptiveConsts& C = *Cp;
   const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
@@ -77,6 +189,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BAN
   alignas(16) double Jb[CW * N], Lf[K * N], Uf[CW * N];     // band of f_y, banded LU factors of I - c f_y
   int P[N];
   alignas(16) double y[N], xy[2 * N], psi[N], w[N];         // state, (y_predict | Newton iterate), psi_neg_y0, work vector (f, then the solve in place)
+  constexpr bool MASS = Mdl::HAS_MASS;
+  // M x == diag(md) x bit for bit (model_mass_rows_scaled): the residual entry is formed where the sweep consumes it, (md_i == 0 ? 0 : md_i (x_i + psi_i)) + (-c) f_i —
+  // the arithmetic of the generated mass_gemv row (literal 0 / x_i / coefficient * x_i, then + beta y_i) without the two extra passes over per-lane memory
+  constexpr bool MSCALED = MASS && model_mass_rows_scaled<Mdl>::value;
+  alignas(16) double md[MASS ? N : 1];  // models with a (diagonal) mass matrix: its diagonal
   double* const yp = xy;
   double* const X = xy + N;
   int cur = 0;
@@ -91,6 +208,13 @@ DSH_UNROLL_N
     for (int i = 0; i < N; ++i) atol_arr[i] = AT(i);
     Mdl::init(t, p, y);
     Mdl::rhs(t, y, p, w);
+    if constexpr (MASS) {
+      // the diagonal of M: M applied to a vector of ones (a diagonal matrix's row sums are its diagonal)
+      alignas(16) double tmpv[N];
+      for (int i = 0; i < N; ++i) { tmpv[i] = 1.0; md[i] = 0.0; }
+      Mdl::mass_gemv(t, *reinterpret_cast<const double (*)[N]>(tmpv), p, 0.0, *reinterpret_cast<double (*)[N]>(md));
+      if (!group_all<WAVE>(set_consistent_banded<Mdl, WAVE, BA>(t, p, y, w, md, atol_g, nb, b, rtol, C.r, Jb, Lf, Uf, P))) status = kRsInitialConditionDidNotConverge;
+    }
     h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, w, p, atol_arr, rtol, 1, det);
   }
 
@@ -108,6 +232,9 @@ DSH_LB_STREAM
   auto reset_jacobian = [&](double tt) __attribute__((always_inline)) {
     if (jac_stale) { Mdl::jac_band(tt, y, p, Jb); jac_stale = false; }
     bool sing = false;
+    if constexpr (MASS)  // J (-c) + M (op/bdf.rs:273-300), M diagonal
+      band_factor_lane_fn<N, K>([&](int i, int col) -> double { return Jb[(col - i + K) * N + i] * (-opc) + (i == col ? md[i] : 0.0); }, Lf, Uf, P, sing);
+    else
     band_factor_lane<N, K>(Jb, opc, Lf, Uf, P, sing);
   };
   reset_jacobian(t);
@@ -323,6 +450,12 @@ DSH_LB_STREAM
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
         const double* xin = it == 0 ? yp : X;  // the iterate: y_predict itself in the first iteration
         Mdl::rhs(t_predict, *reinterpret_cast<const double (*)[N]>(xin), p, *reinterpret_cast<double (*)[N]>(w));
+        if constexpr (MASS && !MSCALED) {  // F(y) = M (y - y0 + psi) - c f(y) as one more pass: w <- M (x + psi) + (-c) w   (op/bdf.rs:240-256)
+          alignas(16) double tmpv[N];
+DSH_LB_STREAM
+          for (int i = 0; i < N; ++i) tmpv[i] = xin[i] + psi[i];
+          Mdl::mass_gemv(t_predict, *reinterpret_cast<const double (*)[N]>(tmpv), p, -opc, *reinterpret_cast<double (*)[N]>(w));
+        }
         // F(y) = M (y - y0 + psi) - c f(y) (op/bdf.rs:240-256), element by element as it enters the window of the forward sweep:
         // interchanges interleaved with the unit-lower-triangular solve; win[0..K] = entries j..j+K
         {
@@ -330,12 +463,15 @@ DSH_LB_STREAM
           constexpr bool EXACT = N % CH == 0;
           double win[RW];
 #pragma unroll
-          for (int r = 0; r < RW; ++r) win[r] = r < N ? 1.0 * (xin[r] + psi[r]) + (-opc) * w[r] : 0.0;
+          for (int r = 0; r < RW; ++r) {
+            if constexpr (MSCALED) win[r] = r < N ? (md[r] == 0.0 ? 0.0 : md[r] * (xin[r] + psi[r])) + (-opc) * w[r] : 0.0;
+            else win[r] = r < N ? (MASS ? w[r] : 1.0 * (xin[r] + psi[r]) + (-opc) * w[r]) : 0.0;
+          }
 #pragma unroll 1
           for (int j0 = 0; j0 < N; j0 += CH) {
             // operands of the CH steps j0.. : pivot offset and multipliers of step j, and x, psi, f of the entry that enters the window after it
             int pv[CH];
-            double lf[CH][K], xn[CH], pn[CH], fn[CH];
+            double lf[CH][K], xn[CH], pn[CH], fn[CH], mn[MSCALED ? CH : 1];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
               const int j = EXACT ? j0 + c : (j0 + c < N ? j0 + c : N - 1);
@@ -344,6 +480,7 @@ DSH_LB_STREAM
 #pragma unroll
               for (int r = 0; r < K; ++r) lf[c][r] = Lf[r * N + j];
               xn[c] = xin[jn]; pn[c] = psi[jn]; fn[c] = w[jn];
+              if constexpr (MSCALED) mn[c] = md[jn];
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
@@ -363,7 +500,8 @@ DSH_LB_STREAM
                 for (int r = 1; r < RW; ++r) win[r] = (-xv) * lf[c][r - 1] + win[r];
 #pragma unroll
                 for (int r = 0; r + 1 < RW; ++r) win[r] = win[r + 1];
-                win[RW - 1] = j + 1 + K < N ? 1.0 * (xn[c] + pn[c]) + (-opc) * fn[c] : 0.0;
+                if constexpr (MSCALED) win[RW - 1] = j + 1 + K < N ? (mn[c] == 0.0 ? 0.0 : mn[c] * (xn[c] + pn[c])) + (-opc) * fn[c] : 0.0;
+                else win[RW - 1] = j + 1 + K < N ? (MASS ? fn[c] : 1.0 * (xn[c] + pn[c]) + (-opc) * fn[c]) : 0.0;
               }
             }
           }

@@ -14,6 +14,7 @@
 #include "dsh_lu_coop.hpp"
 #include "dsh_lu_wave.hpp"
 #include "dsh_lu_band.hpp"
+#include "dsh_lu_band_team.hpp"
 #include "dsh_lu_tiled.hpp"
 
 using namespace dsh;
@@ -92,8 +93,8 @@ int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
   // kernels never factors through this handle, and at n = 512 x 32 768 members the storage alone would be 69 GB
   DSH_HIP_CHECK(hipMalloc((void**)&lu->singular, sizeof(unsigned long long)));
   DSH_HIP_CHECK(hipMalloc((void**)&lu->band_probe, 2 * sizeof(int)));
-  static const int default_structure = [] { const char* e = getenv("DSH_LU_STRUCTURE"); return e && std::string(e) == "dense" ? 1 : 0; }();
-  lu->structure = default_structure;
+  const char* structure_env = getenv("DSH_LU_STRUCTURE");  // read per handle: a process may make solvers of both kinds (tests/test_gpu_configs.py does)
+  lu->structure = structure_env && std::string(structure_env) == "dense" ? 1 : 0;
   DSH_HIP_CHECK(hipMemsetAsync(lu->singular, 0, sizeof(unsigned long long), ctx->stream));
   *out = lu;
   return DSH_OK;
@@ -322,7 +323,16 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
   return DSH_OK;
 }
 
-int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
+static int lu_solve_launch_impl(const dsh_lu* lu, double* rhs, bool wait, unsigned int* gx_out, unsigned int* seq_out);
+int dsh_lu_solve(const dsh_lu* lu, double* rhs) { return lu_solve_launch_impl(lu, rhs, true, nullptr, nullptr); }
+}  // extern "C"
+namespace dsh {
+// the solve enqueued only: the zero-pivot count arrives in the launch's records (fetch_records(ctx, *gx, *seq): res_cnt) — for callers that redeem it
+// together with a later reduction (the staged SDIRK Newton iteration, dsh_fused.hip)
+int lu_solve_launch(const dsh_lu* lu, double* rhs, unsigned int* gx, unsigned int* seq) { return lu_solve_launch_impl(lu, rhs, false, gx, seq); }
+}  // namespace dsh
+extern "C" {
+static int lu_solve_launch_impl(const dsh_lu* lu, double* rhs, bool wait, unsigned int* gx_out, unsigned int* seq_out) {
   dsh_ctx* ctx = lu->ctx;
   if (!lu->factored) { set_error("dsh_lu_solve: LU not initialised"); return DSH_E_NOT_SETUP; }
   const int64_t n = lu->n, nb = lu->nbatch;
@@ -330,14 +340,28 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
   if (n > 8 && lu->band_k > 0) {  // banded factors: one lane per system
-    // small ensembles: 8 systems per wavefront with the operands prefetched by all 64 lanes (k_lu_band_solve_wide: same bits, the memory latency off the
-    // sequential chain); large ones fill the machine with one lane per system.  DSH_LU_BAND_WIDE=0 / 1 forces either.
+    // small ensembles, long chains: one workgroup per 16-64 systems, a chain wavefront fed through LDS by four loader wavefronts (k_lu_band_solve_team: same
+    // bits, the memory traffic off the chain wavefront's instruction stream); DSH_LU_BAND_WIDE=2 selects the round-2 kernel instead (8 systems per wavefront,
+    // k_lu_band_solve_wide); large ensembles fill the machine with one lane per system.  DSH_LU_BAND_WIDE=0 / 1 / 2 forces one of them.
     static const int wide_env = [] { const char* e = std::getenv("DSH_LU_BAND_WIDE"); return e && *e ? std::atoi(e) : -1; }();
-    const bool wide = (wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384)) && n * nb < (1ll << 28);  // the wide kernel addresses rows with 32-bit byte offsets  // long chains, few wavefronts (n = 42 x 32 768: 43 us one lane per system, 171 us wide)
-    g = wide ? grid_for(nb, 8) : grid_for(nb, 64);
+    const bool wide = (wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384)) && n * nb < (1ll << 28);  // 32-bit byte offsets; n = 42 x 32 768: 43 us one lane per system, 171 us wide
+    const bool team = wide && wide_env != 2;
+    const int sys = nb <= 4096 ? 16 : (nb <= 8192 ? 32 : 64);
+    g = team ? grid_for(nb, sys) : (wide ? grid_for(nb, 8) : grid_for(nb, 64));
     int rc = begin_records(ctx, g.x, &rec, &seq);
     if (rc != DSH_OK) return rc;
-    if (wide) {
+    if (team) {
+#define DSH_TEAM_CASE(KK, SS) hipLaunchKernelGGL((k_lu_band_solve_team<KK, SS>), g, dim3(kTeamThreads), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
+#define DSH_TEAM_K(KK) do { if (sys == 16) DSH_TEAM_CASE(KK, 16); else if (sys == 32) DSH_TEAM_CASE(KK, 32); else DSH_TEAM_CASE(KK, 64); } while (0)
+      switch (lu->band_k) {
+        case 1: DSH_TEAM_K(1); break;
+        case 2: DSH_TEAM_K(2); break;
+        case 3: DSH_TEAM_K(3); break;
+        default: DSH_TEAM_K(4); break;
+      }
+#undef DSH_TEAM_K
+#undef DSH_TEAM_CASE
+    } else if (wide) {
       switch (lu->band_k) {
         case 1: hipLaunchKernelGGL((k_lu_band_solve_wide<1, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
         case 2: hipLaunchKernelGGL((k_lu_band_solve_wide<2, 8>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
@@ -352,6 +376,7 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
       default: hipLaunchKernelGGL((k_lu_band_solve<4>), g, dim3(64), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq); break;
     }
     DSH_HIP_CHECK(hipGetLastError());
+    if (!wait) { *gx_out = g.x; *seq_out = seq; return DSH_OK; }
     rc = fetch_records(ctx, g.x, seq);
     if (rc != DSH_OK) return rc;
     if (ctx->res_cnt != 0ull) {
@@ -396,6 +421,7 @@ int dsh_lu_solve(const dsh_lu* lu, double* rhs) {
 #undef DSH_LU_SOLVE_CASE
   DSH_HIP_CHECK(hipGetLastError());
   // LinearSolver::solve_in_place returns Result<(), LaError>: the zero-pivot flag has to come back (blocking, like the reference's getrs loop)
+  if (!wait) { *gx_out = g.x; *seq_out = seq; return DSH_OK; }
   rc = fetch_records(ctx, g.x, seq);
   if (rc != DSH_OK) return rc;
   if (ctx->res_cnt != 0ull) {

@@ -362,7 +362,10 @@ __global__ __launch_bounds__(64) void k_lu_band_solve_wide(int64_t n, int64_t nb
       }
     }
   }
-  __threadfence();  // the backward sweep reads, from other lanes, what the forward sweep stored
+  // the backward sweep reads, from other lanes of this wavefront, what the forward sweep stored: a WORKGROUP-scope fence (stores acknowledged, same L1).
+  // __threadfence() is an agent-scope fence — on this multi-XCD part an L2 write-back and invalidate per wavefront, 20 us of the kernel at 512 x 4096
+  // (scripts/ubench/band_wide_bench.hip timeline, profiles/r03_band_solve.md)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // ---------------------------------------------------------------- backward with U (bandwidth 2K): chunk c covers rows n-1 - (c*CHK + t)
   {
     double pb[DB][BO][Q];

@@ -128,13 +128,14 @@ __device__ __forceinline__ void store_vec(double* __restrict__ p, int64_t nb, in
 // ---- banded LU on per-lane arrays (device-resident integrators for banded models): the algorithm of dsh_lu_band.hpp — LAPACK dgbtrf-style partial
 // pivoting with a (K+1) x (2K+1) register window, the non-trivial operations of the dense elimination in the same order — on the matrix
 // A = Jb * (-c) + I, where Jb holds the band of the Jacobian: entry (i, col) at Jb[(col - i + K) * N + i].  Factors: U(r, r+d) at Uf[d*N + r] (d <= 2K),
-// multiplier of row j+r at step j at Lf[(r-1)*N + j].
-template <int N, int K>
-__device__ __forceinline__ void band_factor_lane(const double* Jb, double c, double* Lf, double* Uf, int* P, bool& singular) {
+// multiplier of row j+r at step j at Lf[(r-1)*N + j].  band_factor_lane_fn takes the entries of the matrix from a function instead (models with a mass
+// matrix: J (-c) + M; the InitOp Jacobian of the consistent initialisation).
+template <int N, int K, class ENTRY>
+__device__ __forceinline__ void band_factor_lane_fn(ENTRY&& in_band, double* Lf, double* Uf, int* P, bool& singular) {
   constexpr int R = K + 1, C = 2 * K + 1;
-  auto in = [&](int i, int col) -> double {
+  auto in = [&](int i, int col) -> double {  // in_band(i, col): entry (i, col) of the matrix, asked for |i - col| <= K inside the matrix only
     if (i >= N || col >= N) return 0.0;
-    return Jb[(col - i + K) * N + i] * (-c) + (i == col ? 1.0 : 0.0);  // J * (-c) + M with M = from_diagonal(ones) (op/bdf.rs:138-141, :273-300)
+    return in_band(i, col);
   };
   double W[R][C];
 #pragma unroll
@@ -194,6 +195,12 @@ __device__ __forceinline__ void band_factor_lane(const double* Jb, double c, dou
 #pragma unroll
     for (int q = 0; q < C; ++q) W[R - 1][q] = in(i, i - K + q);
   }
+}
+
+template <int N, int K>
+__device__ __forceinline__ void band_factor_lane(const double* Jb, double c, double* Lf, double* Uf, int* P, bool& singular) {
+  // J * (-c) + M with M = from_diagonal(ones) (op/bdf.rs:138-141, :273-300)
+  band_factor_lane_fn<N, K>([&](int i, int col) -> double { return Jb[(col - i + K) * N + i] * (-c) + (i == col ? 1.0 : 0.0); }, Lf, Uf, P, singular);
 }
 
 // returns false if a zero diagonal of U was met (LuSolveFailed)

@@ -45,6 +45,21 @@ __global__ void k_dyn_rhs(int model, int64_t n, int64_t nb, double t, const doub
     y[idx] = dyn_component(model, n, t, i, X, V, P, v != nullptr);
   }
 }
+// SdirkCallable::call_inplace (op/sdirk.rs:229-244) of an identity-mass model as ONE pass: tmp = phi + c k (copy, then axpy: c * k + 1.0 * phi), f = rhs(tmp, t),
+// out = k - h f (axpy: 1.0 * k + (-h) * f) — the arithmetic of the three vector kernels and k_dyn_rhs, entry by entry; the stencil's neighbours of tmp are
+// formed again from phi and k instead of being read back
+__global__ void k_dyn_sdirk_residual(int model, int64_t n, int64_t nb, double t, double c, double h, const double* __restrict__ phi, const double* __restrict__ kk,
+                                     const double* __restrict__ p, double* __restrict__ out) {
+  int64_t total = n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t i = idx / nb, b = idx % nb;
+    auto X = [&](int64_t k) { return c * kk[k * nb + b] + 1.0 * phi[k * nb + b]; };
+    auto V = [&](int64_t) { return 0.0; };
+    auto P = [&](int64_t k) { return p[k * nb + b]; };
+    const double f = dyn_component(model, n, t, i, X, V, P, false);
+    out[idx] = 1.0 * kk[idx] + (-h) * f;
+  }
+}
 // dense Jacobian entry (i,j) = component i of J e_j (same arithmetic as jac_mul with a unit vector)
 __global__ void k_dyn_jacobian(int model, int64_t n, int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, double* __restrict__ jac) {
   int64_t total = n * n * nb;
@@ -186,6 +201,23 @@ int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, c
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
+}  // extern "C"
+namespace dsh {
+bool model_has_staged_newton(int model, int64_t size) {
+  if (is_jit_model(model) || !is_dynamic_model(model, size)) return false;
+  int64_t n; int hm = 0;
+  return dsh_model_info(model, size, &n, nullptr, &hm, nullptr) == DSH_OK && hm == 0;
+}
+// out = k - h f(phi + c k, t) for a run-time-sized registry model without a mass matrix, one launch; false when the model is of another kind
+bool model_dyn_sdirk_residual(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, double h, const double* phi, const double* k, const double* p,
+                              double* out) {
+  if (!model_has_staged_newton(model, size)) return false;
+  int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_dyn_sdirk_residual, ew_grid(n * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, t, c, h, phi, k, p, out);
+  return true;
+}
+}  // namespace dsh
+extern "C" {
 int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, const double* v, double* y) {
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::JacMul, nb, t, x, p, v, 0.0, y);
   bool handled = false;

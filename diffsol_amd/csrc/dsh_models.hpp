@@ -183,6 +183,9 @@ template <class M> struct model_has_reset<M, model_void_t<decltype(&M::reset)>> 
 // the state in per-lane memory and factors the band only, which lifts its size limit from the register budget (n <= 4) to n <= 64
 template <class M, class = void> struct model_band_k { static constexpr int value = 0; };
 template <class M> struct model_band_k<M, model_void_t<decltype(M::BAND_K)>> { static constexpr int value = M::BAND_K; };
+// a banded model with a DIAGONAL mass matrix may state that M x == diag(M 1) x bit for bit (rows: 0, x_i, or coefficient * x_i; the DiffSL front end checks it)
+template <class M, class = void> struct model_mass_rows_scaled { static constexpr bool value = false; };
+template <class M> struct model_mass_rows_scaled<M, model_void_t<decltype(M::MASS_ROWS_SCALED)>> { static constexpr bool value = M::MASS_ROWS_SCALED; };
 
 // Column-by-column dense assembly from jac_mul / mass_gemv with unit vectors (see header comment).  Column-major A[j*N+i].
 template <class Mdl>

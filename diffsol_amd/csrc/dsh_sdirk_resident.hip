@@ -30,7 +30,8 @@ int dsh_model_has_resident(int method, int model, int64_t size) {
   if (is_jit_model(model)) {
     const JitInfo* ji = jit_info(model);
     if (!ji) return 0;
-    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || (ji->form == DSH_JIT_FORM_STATIC_BANDED && ji->n <= 512) ? 1 : 0;
+    // banded lane-per-member form with a mass matrix: BDF only so far (k_bdf_lane_banded); TR-BDF2 / ESDIRK34 of such a model run wavefront per member
+    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || (ji->form == DSH_JIT_FORM_STATIC_BANDED && ji->n <= 512 && !ji->has_mass) ? 1 : 0;
   }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {

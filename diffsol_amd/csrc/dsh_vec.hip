@@ -179,9 +179,12 @@ __global__ __launch_bounds__(256) void k_squared_norm(int64_t n, int64_t nb, con
 // loads-divisions-additions each (60 us, 0.56 TB/s).  Here a wavefront owns 8 members; its lanes are 8 row groups x 8 members, so the loads and the
 // divisions of 32 components per member run in parallel on all 64 lanes, and only the additions — in index order, as Vector::squared_norm sums —
 // are a chain, on the 8 lanes of row group 0, fed through LDS.  Same terms, same order of additions: the same bits.
-template <bool BY, bool BA>
+// SUB: the lanes that fetch the terms also apply the Newton update the norm belongs to, xout = xin - x (x = the Newton step delta; xout may be xin) —
+// NoLineSearch::take_optimal_step's `xn -= delta` and Convergence::norm(delta) in one pass over delta (line_search.rs:43-72)
+template <bool BY, bool BA, bool SUB = false>
 __global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
-                                                          double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch) {
+                                                          double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch,
+                                                          const double* xin = nullptr, double* xout = nullptr) {
   constexpr int S = 8, G = 8, QL = 4, CH = G * QL, LD = CH + 8;  // LD: row stride of the staging array (bank spread)
   __shared__ double sT[S][LD];
   const int lane = threadIdx.x, s = lane % S, g = lane / S;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb,
     for (int q = 0; q < QL; ++q) {
       const int64_t r = min(base + q * G + g, n - 1);  // clamped: components past the end are not added
       xs[q] = x[r * nb + b];
+      if constexpr (SUB) { if (valid && base + q * G + g < n) xout[r * nb + b] = xin[r * nb + b] - xs[q]; }
       ys[q] = BY ? y[r] : y[r * nb + b];
       as[q] = BA ? atol[r] : atol[r * nb + b];
     }
@@ -396,6 +400,43 @@ int dsh_vec_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, int k, do
   *out_max = bits_to_double(ctx->res_m0);
   return DSH_OK;
 }
+
+}  // extern "C"
+namespace dsh {
+// xout = xin - delta and the squared norm of delta in one launch where the wide kernel applies (long vectors, few members), two launches otherwise; the
+// caller redeems the norm's records (fetch_records(ctx, *gx, *seq): res_m0).  Used by the staged SDIRK Newton iteration (dsh_fused.hip).
+int vec_sub_squared_norm_launch(dsh_ctx* ctx, int64_t n, int64_t nb, const double* delta, const double* xin, double* xout, const double* y, int64_t ynb,
+                                const double* atol, int64_t anb, double rtol, unsigned int* gx, unsigned int* seq_out) {
+  DSH_CHECK_NB(ynb, nb); DSH_CHECK_NB(anb, nb);
+  unsigned long long* rec; unsigned int seq;
+  const int threads = ctx->block < 256 ? ctx->block : 256;
+  static const int wide_env = [] { const char* e = std::getenv("DSH_NORM_WIDE"); return e && *e ? std::atoi(e) : -1; }();
+  const bool wide = wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384);
+  const bool by = ynb == 1 && nb != 1, ba = anb == 1 && nb != 1;
+  if (!wide) {
+    int rc = launch_ternary(ctx, n, nb, xin, nb, delta, nb, xout, FSub{});
+    if (rc != DSH_OK) return rc;
+  }
+  dim3 g = wide ? grid_for(nb, 8) : grid_for(nb, threads), b(threads);
+  int rc = begin_records(ctx, g.x, &rec, &seq);
+  if (rc != DSH_OK) return rc;
+  double* none = nullptr;
+  if (wide) {
+    if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<false, false, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+    else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<true, false, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+    else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_wide<false, true, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+    else hipLaunchKernelGGL((k_squared_norm_wide<true, true, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+  } else
+  if (!by && !ba) hipLaunchKernelGGL((k_squared_norm<false, false>), g, b, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none);
+  else if (by && !ba) hipLaunchKernelGGL((k_squared_norm<true, false>), g, b, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none);
+  else if (!by && ba) hipLaunchKernelGGL((k_squared_norm<false, true>), g, b, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none);
+  else hipLaunchKernelGGL((k_squared_norm<true, true>), g, b, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none);
+  DSH_HIP_CHECK(hipGetLastError());
+  *gx = g.x; *seq_out = seq;
+  return DSH_OK;
+}
+}  // namespace dsh
+extern "C" {
 
 int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, const double* y, int64_t ynb, const double* atol, int64_t anb,
                          double rtol, double* out_max, double* per_batch_dev) {

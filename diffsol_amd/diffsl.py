@@ -52,11 +52,12 @@ class DiffslModel:
         self.model_id = mid.value
         self.lane_model_id = None
         jkl, jku = d["band"][0], d["band"][1]
-        if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and not self.has_mass and max(jkl, jku) <= 4 and self.nroots <= 8:
+        diag_mass = (not self.has_mass) or (d["band"][2] == 0 and d["band"][3] == 0)  # the lane-per-member banded kernels take a diagonal mass matrix
+        if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and diag_mass and max(jkl, jku) <= 4 and self.nroots <= 8:
             # banded Jacobian: the same model once more in the lane-per-member form; per-member device-resident BDF solves run on it (compiled on first use)
             lane_src = generate(code, TARGET_HIP_STATIC)[0]
             lid = C.c_int()
-            check(self._L.dsh_model_compile(lane_src.encode(), FORM_STATIC_BANDED, self.n, self.nparams, self.nroots, self.nout, 0, C.byref(lid)))
+            check(self._L.dsh_model_compile(lane_src.encode(), FORM_STATIC_BANDED, self.n, self.nparams, self.nroots, self.nout, 1 if self.has_mass else 0, C.byref(lid)))
             self.lane_model_id = lid.value
             check(self._L.dsh_model_set_twin(self.model_id, self.lane_model_id))
         self.band = d["band"]  # (jac_kl, jac_ku, mass_kl, mass_ku): structural bandwidths, declared so that banded models are assembled / factored on the band

@@ -307,10 +307,10 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
     }
   } catch (...) { ode->out_is_state = false; }
   // banded run-time-sized model: the same text once more in the lane-per-member form, which per-member / wavefront device-resident solves run on
-  if (!is_static && ode->n <= 64 && !ode->has_mass && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4 &&
+  if (!is_static && ode->n <= 64 && (!ode->has_mass || (dims[8] == 0 && dims[9] == 0)) && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4 &&
       dshs_diffsl_generate(code, DSHS_DIFFSL_HIP_STATIC, &src, nullptr, nullptr, 0) == 0) {
     int lane = -1;
-    if (dsh_model_compile(src, DSH_JIT_FORM_STATIC_BANDED, ode->n, ode->np, ode->nroots, ode->nout, 0, &lane) == 0 && dsh_model_set_twin(id, lane) == 0) ode->lane_model = lane;
+    if (dsh_model_compile(src, DSH_JIT_FORM_STATIC_BANDED, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &lane) == 0 && dsh_model_set_twin(id, lane) == 0) ode->lane_model = lane;
     dshs_free_string(src);
   }
   return ode.release();

@@ -123,6 +123,8 @@ class Sdirk : public OdeSolverMethod {
     minimum_timestep_shrink_ = o.min_timestep_shrink.value_or(0.5);
     // forward sensitivities run on the trait operations (the fused stage kernels integrate the state equations only)
     fused_ = problem.use_fused_kernels && !problem.sens && problem.eqn->fused_model(&model_, &model_size_);
+    // run-time-sized registry models: the Newton iteration in its staged form (three launches, one wait: dsh_sdirk_newton_iter); everything else stays generic
+    staged_ = !fused_ && problem.use_fused_kernels && !problem.sens && problem.eqn->registry_model(&model_, &model_size_) && dsh_model_has_staged_newton(model_, model_size_) != 0;
     state_ = new_and_consistent(problem, tab_.order());
     const int64_t n = problem.eqn->nstates();
     const HipContext& ctx = problem.context();
@@ -482,7 +484,7 @@ class Sdirk : public OdeSolverMethod {
       reset_jacobian(t);
       record_linear_solver_setup(statistics_, SolverState::Checkpoint);
     }
-    NlError r = fused_ ? newton_fused(t) : nonlinear_solver_.solve_in_place(op_, old_state_.dy, t, state_.y, convergence_, line_search_);
+    NlError r = (fused_ || staged_) ? newton_fused(t) : nonlinear_solver_.solve_in_place(op_, old_state_.dy, t, state_.y, convergence_, line_search_);
     statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
     if (r != NlError::Ok) return r;
     op_.get_f_eval(old_state_.dy, old_state_.y);
@@ -557,7 +559,7 @@ class Sdirk : public OdeSolverMethod {
   bool is_state_mutated_ = false;
   double minimum_timestep_, maximum_timestep_growth_, minimum_timestep_growth_, maximum_timestep_shrink_, minimum_timestep_shrink_;
   int maximum_error_test_failures_, maximum_newton_fails_;
-  bool fused_ = false;
+  bool fused_ = false, staged_ = false;
   int model_ = -1;
   int64_t model_size_ = 0;
   // forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens())

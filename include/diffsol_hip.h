@@ -302,6 +302,10 @@ int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, const double* x, const double* p,
                    int recompute_rhs_jac, double* rhs_jac, double* mass_jac, dsh_lu* lu);
 int dsh_model_has_fused(int model, int64_t size);
+/* 1 when dsh_sdirk_newton_iter runs the model's SDIRK Newton iteration in its staged form: run-time-sized registry models without a mass matrix (heat1d, spm:
+ * no register-resident kernels) — residual / LU solve / update + norm as three launches and one wait instead of the seven launches and two waits of the
+ * host-driven vector operations, bit-identical iterates (op/sdirk.rs:229-244, diffsol-nl line_search.rs:43-72) */
+int dsh_model_has_staged_newton(int model, int64_t size);
 /* BDF step preparation, one launch (Bdf::_update_diff_for_step_size ode_solver/bdf.rs:568-577, _predict_using_diff :667-672,
  * BdfCallable::set_psi_and_y0 op/bdf.rs:182-210):
  *   if ru_host != NULL: diff_tmp[:,0..=order] = diff[:,0..=order] * RU  (RU is (order+1)^2 column-major on the HOST; caller swaps

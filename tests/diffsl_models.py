@@ -187,6 +187,98 @@ F_i {{
 {stops}"""
 
 
+def spm_dae(m=20):
+    """BASELINE configs[3] as it is worded — "physics-based battery SPM DAE (singular mass matrix)": the single-particle model of the battery primer with the
+    TERMINAL VOLTAGE as an algebraic state (the way benches/pybamm_dfn.diffsl carries its voltage): n = 2 + 2m + 1, M = diag(1, ..., 1, 0, 1, ..., 1),
+    0 = volt(c_neg surface, c_pos surface, I) - V, stop when V leaves [3.105, 4.1].  State order: the two charge counters, the negative particle's shells
+    (centre to surface), V, the positive particle's shells SURFACE TO CENTRE — so that V sits between the four shell values it depends on and the
+    Jacobian keeps a bandwidth of 2 (the lane-per-member banded kernels).  Same constants and formulas as spm(m, voltage=True); V starts at a guess and is
+    made consistent by the solver (StateRefMut::set_consistent)."""
+    def lap_rows(scale, reverse):
+        rows = []
+        dr = 1.0 / m
+        for k in range(m):
+            i0, i1 = float(k), float(k + 1)
+            vol = i1 * i1 * i1 - i0 * i0 * i0
+            lower = 3.0 * i0 * i0 / vol / (dr * dr) * scale
+            upper = 3.0 * i1 * i1 / vol / (dr * dr) * scale if k + 1 < m else 0.0
+            ix = (lambda a: m - 1 - a) if reverse else (lambda a: a)
+            if k > 0:
+                rows.append(f"  ({ix(k)},{ix(k - 1)}): {lower!r}")
+            rows.append(f"  ({ix(k)},{ix(k)}): {-(lower + upper)!r}")
+            if k + 1 < m:
+                rows.append(f"  ({ix(k)},{ix(k + 1)}): {upper!r}")
+        return ",\n".join(rows)
+    a = 2 + m
+    clamp = lambda v, lo, hi: f"max(min({v}, {hi!r}), {lo!r})"
+    ocp_p = ("2.16216 + 0.07645 * tanh(30.834 - 57.858397200000006 * stp) + 2.1581 * tanh(52.294 - 53.412228 * stp) - 0.14169 * tanh(11.0923 - 21.0852666 * stp) + "
+             "0.2051 * tanh(1.4684 - 5.829105600000001 * stp) + 0.2531 * tanh(4.291641337386018 - 8.069908814589667 * stp) - 0.02167 * tanh(-87.5 + 177.0 * stp)"
+             " + 0.000001 * (1.0 / stp + 1.0 / (-1.0 + stp))")
+    ocp_n = ("0.194 + 1.5 * exp(-120.0 * stn) + 0.0351 * tanh(-3.44578313253012 + 12.048192771084336 * stn) - 0.0045 * tanh(-7.1344537815126055 + 8.403361344537815 * stn) - "
+             "0.035 * tanh(-18.466 + 20.0 * stn) - 0.0147 * tanh(-14.705882352941176 + 29.41176470588235 * stn) - 0.102 * tanh(-1.3661971830985917 + 7.042253521126761 * stn) - "
+             "0.022 * tanh(-54.8780487804878 + 60.975609756097555 * stn) - 0.011 * tanh(-5.486725663716814 + 44.24778761061947 * stn) + "
+             "0.0155 * tanh(-3.6206896551724133 + 34.48275862068965 * stn) + 0.000001 * (1.0 / stn + 1.0 / (-1.0 + stn))")
+    return f"""
+in = [current]
+current {{ 1.0 }}
+Aneg_ij {{
+{lap_rows(0.39e-3, False)}
+}}
+Aposr_ij {{
+{lap_rows(1.0e-3, True)}
+}}
+eneg_i {{ (0:{m - 1}): 0.0, ({m - 1}): {3.2835305549534856e-12 * -520607810.21082705!r} }}
+eposr_i {{ (0): {4.106800547504748e-12 * 243644455.17866704!r}, (1:{m}): 0.0 }}
+SP_ij {{ (0,0): 1.4999999999999982, (0,1): -0.4999999999999983 }}
+SN_ij {{ (0,{m - 2}): -0.4999999999999983, (0,{m - 1}): 1.4999999999999984 }}
+CP_ij {{ (0,0): 76826.88859639116, (0,1): -25608.96286546366 }}
+CN_ij {{ (0,{m - 2}): -12491.630996921805, (0,{m - 1}): 37474.892990765504 }}
+u_i {{
+  q = 0.0,
+  thr = 0.0,
+  (2:{a}): cn = 0.8000000000000016,
+  V = 4.0,
+  ({a + 1}:{a + 1 + m}): cpr = 0.6000000000000001,
+}}
+dudt_i {{
+  dq = 0.0,
+  dthr = 0.0,
+  (2:{a}): dcn = 0.0,
+  dV = 0.0,
+  ({a + 1}:{a + 1 + m}): dcpr = 0.0,
+}}
+ln_i {{ Aneg_ij * cn_j }}
+lp_i {{ Aposr_ij * cpr_j }}
+spr_i {{ SP_ij * cpr_j[0:2] }}
+snr_i {{ SN_ij * cn_j }}
+cpr2_i {{ CP_ij * cpr_j[0:2] }}
+cnr_i {{ CN_ij * cn_j }}
+stp {{ {clamp("spr_i", 1e-10, 0.9999999999)} }}
+stn {{ {clamp("snr_i", 1e-10, 0.9999999999)} }}
+cps {{ {clamp("cpr2_i", 0.000512179257309275, 51217.92521874824)} }}
+cns {{ {clamp("cnr_i", 0.000249832619938437, 24983.261744011077)} }}
+etap {{ 0.05138515824298745 * arcsinh((-2.3508116177110145 * current) / (2.0 * ((1.8973665961010275e-05 * sqrt(cps)) * sqrt(51217.9257309275 - cps)))) }}
+etan {{ 0.05138515824298745 * arcsinh((1.9590096814258458 * current) / (2.0 * ((0.0006324555320336759 * sqrt(cns)) * sqrt(24983.2619938437 - cns)))) }}
+volt {{ (etap + ({ocp_p})) - (etan + ({ocp_n})) }}
+M_i {{
+  dq,
+  dthr,
+  dcn_i,
+  0,
+  dcpr_i,
+}}
+F_i {{
+  0.0002777777777777778 * current,
+  0.0002777777777777778 * abs(current),
+  ln_i + eneg_i * current,
+  volt - V,
+  lp_i + eposr_i * current,
+}}
+stop_i {{ V - 3.105, 4.1 - V }}
+out_i {{ V }}
+"""
+
+
 def random_expr(rng, depth, names):
     """(DiffSL text, python callable on a dict of values) of a random expression that stays smooth and finite for positive inputs."""
     if depth == 0 or rng.random() < 0.25:

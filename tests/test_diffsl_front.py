@@ -183,8 +183,10 @@ def test_generated_device_models_compile_for_gfx950_without_a_gpu(fe):
     assert _ffi.load_device_lib().dsh_model_precompile(h.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0
     h.release()
     with pytest.raises(Exception) as e:
-        fe.generate(D.HEAT_DAE, fe.TARGET_HIP_STATIC)  # n = 12 with a mass matrix: no lane-per-member form
-    assert "identity mass" in str(e.value)
+        fe.generate(D.HEAT_DAE, fe.TARGET_HIP_STATIC)  # n = 12 with a dense Jacobian: no lane-per-member form
+    assert "lane-per-member form needs" in str(e.value)  # its Jacobian is wide (bandwidth 10); the DIAGONAL mass matrix alone would be fine
+    v = fe.generate(D.spm_dae(6), fe.TARGET_HIP_STATIC)  # the battery model with the algebraic terminal voltage: diagonal mass, bandwidth 2
+    assert "HAS_MASS = true" in v[0] and "BAND_K = 2" in v[0] and v[1]["band"] == (2, 2, 0, 0) and v[1]["n"] == 15
     s = fe.DiffslModel(D.spm(20))
     assert s.form == fe.FORM_DYNAMIC and s.n == 42 and s.nroots == 2
     s.release()
@@ -205,6 +207,11 @@ def test_the_device_resident_kernel_families_of_the_diffsl_test_models_compile_w
         m = fe.DiffslModel(code)
         assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is not None
         assert L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0 and L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_SDIRK) == 0, L.dsh_last_error()
+    for code in (D.spm_dae(5), D.spm_dae(20)):  # diagonal SINGULAR mass matrix: the lane-per-member banded BDF with the consistent initialisation per lane
+        m = fe.DiffslModel(code)
+        assert m.form == fe.FORM_DYNAMIC and m.has_mass and m.lane_model_id is not None
+        assert L.dsh_model_precompile(m.lane_model_id, fe.FAMILY_RESIDENT_BDF) == 0, L.dsh_last_error()
+        m.precompile(fe.FAMILY_RESIDENT_SDIRK)  # TR-BDF2 / ESDIRK34 of a DAE stay on the wavefront-per-member kernels
 
 
 REF_SPM = "/root/reference/book/src/primer/src/spm.ds"

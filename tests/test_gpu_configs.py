@@ -144,6 +144,46 @@ def test_config4_spm_32768_members_with_voltage_cutoffs(H, O, det_pow):
     assert np.array_equal(m["root_idx"][pick], ref["root_idx"]) and np.array_equal(m["ncols"][pick], ref["ncols"])
 
 
+def test_config4_as_worded_singular_mass_spm_dae_32768_members(H, O, det_pow):
+    """BASELINE configs[3] in its own words — "SPM DAE (singular mass matrix)": the battery model with the terminal voltage as an ALGEBRAIC state
+    (tests/diffsl_models.py spm_dae(20): n = 43, M = diag(1.., 0, ..1), bandwidth 2), one GPU's shard of 32 768 members on the lane-per-member banded BDF
+    (k_bdf_lane_banded with the diagonal mass matrix and the consistent initialisation per lane).  Same properties as the identity-mass run
+    above — capacity = I t, cut-off time decreasing in the current, NaN after the stop — plus: V at the first save point sits on its constraint, and the
+    cut-off times agree with the identity-mass formulation's (same physics, the voltage an expression there) to the integration tolerance.  24 sampled
+    members bit for bit (states, counters, stop times) against their own oracle solves of the DiffSL host twin."""
+    import diffsl_models as DM
+    from diffsol_amd import diffsl as fe
+    nb = 32768
+    cur = spm_currents(nb)
+    code = DM.spm_dae(20)
+    model = fe.DiffslModel(code)
+    assert model.n == 43 and model.has_mass and model.lane_model_id is not None
+    s = H.Solver(model, cur[:, None], nbatch=nb, rtol=1e-6, atol=[1e-6])
+    t_eval = np.linspace(360.0, 3600.0, 10)
+    y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all()
+    hit = m["root_idx"] >= 0
+    assert 0.8 * nb < hit.sum() < nb and np.all(m["root_idx"][hit] == 0)        # stop 0: V - 3.105
+    assert np.all(m["t_root"][hit] > 1500.0) and np.all(m["t_root"][hit] <= 3600.0)
+    o = np.argsort(cur[hit])
+    assert np.all(np.diff(m["t_root"][hit][o]) <= 0.0)
+    for k, t in enumerate(t_eval):
+        live = (~hit) | (m["t_root"] >= t)
+        assert np.allclose(y[k, live, 0], cur[live] * t / 3600.0, rtol=1e-5)
+        assert np.all(y[k, live, 22] > 3.105 - 1e-6) and np.all(y[k, live, 22] < 4.1)  # the algebraic state between its two stops
+        assert np.isnan(y[k, hit & (m["ncols"] <= k)]).all()
+    ident = H.Solver("spm", cur[:, None], nbatch=nb, model_size=20, rtol=1e-6, atol=[1e-6])
+    _, _, mi = ident.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    both = hit & (mi["root_idx"] >= 0)
+    assert both.sum() > 0.8 * nb and np.abs(m["t_root"][both] / mi["t_root"][both] - 1.0).max() < 2e-4
+    pick = np.sort(np.random.default_rng(3).choice(nb, 24, replace=False))
+    yo, so, failed = O.solve_dense_independent(DM.host_model(O, code), cur[pick, None], t_eval, nthreads=8, rtol=1e-6, atol=[1e-6])
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and np.array_equal(y[:, pick], np.transpose(yo, (1, 0, 2)), equal_nan=True)
+    assert np.array_equal(m["stats"].T[pick], so) and np.array_equal(m["t_root"][pick], ref["t_root"], equal_nan=True)
+    assert np.array_equal(m["root_idx"][pick], ref["root_idx"]) and np.array_equal(m["ncols"][pick], ref["ncols"])
+
+
 def rlc_params(nb, thresh):
     rng = np.random.default_rng(12345)  # SURVEY 8(d) C5: R ~ U[50, 200], L = 1, C ~ logU[5e-4, 2e-3], V0 = 10, omega = 100
     R = rng.uniform(50.0, 200.0, nb)

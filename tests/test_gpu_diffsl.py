@@ -308,6 +308,33 @@ def test_banded_models_get_the_lane_per_member_bdf_with_state_in_memory_and_a_ba
     assert saw_events  # the battery members reach a cut-off voltage, each at its own time
 
 
+def test_singular_mass_battery_dae_runs_on_the_lane_per_member_banded_bdf_with_the_initialisation_on_the_device(H, O, fe, det_pow):
+    """a DIAGONAL mass matrix in k_bdf_lane_banded.  The battery model with the terminal voltage as an algebraic state (n = 13 and 43,
+    M = diag(1.., 0, ..1), bandwidth 2; BASELINE configs[3] as worded): every lane makes its own member consistent (InitOp's Newton iteration with the line
+    search on the banded LU, state.rs:84-162), then integrates with M in the residual M (y - y0 + psi) - c f and in M - cJ (op/bdf.rs:240-300).  States,
+    counters and stop times (the voltage cut-off, now a condition on a STATE) of every member equal independent CPU solves bit for bit — per member and in
+    lock-step groups of 64."""
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    saw_events = False
+    for m_shells, nb, group in ((5, 70, 1), (20, 70, 1), (20, 150, 64)):
+        code = D.spm_dae(m_shells)
+        p = np.linspace(0.6, 1.4, nb)[:, None]
+        # a lock-step group stops only where ALL its members see the root (the reference's batched root finding, kRsRootBatchMismatch otherwise): it ends before the first cut-off
+        t_eval = [600.0, 3000.0, 9000.0, 20000.0] if group == 1 else [600.0, 1500.0]
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        assert m.has_mass and m.lane_model_id is not None
+        s = H.Solver(m, p, nbatch=nb, **tol)
+        y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+        yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=group, method=0, **tol)
+        ref = O.solve_dense_independent.last_roots
+        assert failed == 0 and (mem["status"] == 0).all(), mem["status"]
+        assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True)
+        assert np.array_equal(mem["root_idx"], ref["root_idx"]) and np.array_equal(mem["ncols"], ref["ncols"]) and np.array_equal(mem["t_root"], ref["t_root"], equal_nan=True)
+        saw_events = saw_events or mem["root_idx"].max() >= 0
+        assert np.isfinite(y[0]).all() and (y[0][:, 2 + m_shells] > 3.105 - 1e-6).all() and (y[0][:, 2 + m_shells] < 4.1).all()  # the algebraic state: a voltage between its two stops (a member stopped before the first save point holds its event state there)
+    assert saw_events
+
+
 @pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
 def test_banded_models_also_get_the_lane_per_member_sdirk_integrators(H, O, fe, det_pow, method):
     """TR-BDF2 / ESDIRK34 per member on the device for a banded run-time-sized model (k_sdirk_resident in its banded form), with stop conditions."""
