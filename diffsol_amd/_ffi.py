@@ -63,6 +63,7 @@ DEVICE_ABI = {
     "dsh_vec_mul_assign_scalar": (cint, [vp, i64, i64, vp, dbl]),
     "dsh_vec_mul_scalar": (cint, [vp, i64, i64, vp, dbl, vp]),
     "dsh_vec_axpy": (cint, [vp, i64, i64, dbl, vp, i64, dbl, vp]),
+    "dsh_vec_axpby_to": (cint, [vp, i64, i64, dbl, vp, dbl, vp, vp, vp]),
     "dsh_vec_batched_axpy": (cint, [vp, i64, i64, c_dp, vp, i64, dbl, vp]),
     "dsh_vec_copy": (cint, [vp, i64, i64, vp, i64, vp]),
     "dsh_vec_fill": (cint, [vp, i64, i64, vp, dbl]),
@@ -74,12 +75,15 @@ DEVICE_ABI = {
     "dsh_vec_squared_norm": (cint, [vp, i64, i64, vp, vp, i64, vp, i64, dbl, c_dp, vp]),
     "dsh_vec_root_finding": (cint, [vp, i64, i64, vp, vp, c_ip, c_dp, c_ip]),
     "dsh_mat_from_diagonal": (cint, [vp, i64, i64, vp, i64, vp]),
+    "dsh_mat_band_from_diagonal": (cint, [vp, i64, i64, cint, cint, vp, i64, vp]),
+    "dsh_mat_band_gemv": (cint, [vp, i64, i64, cint, cint, dbl, vp, vp, i64, dbl, vp]),
     "dsh_mat_get_diagonal": (cint, [vp, i64, i64, vp, vp]),
     "dsh_mat_set_column": (cint, [vp, i64, i64, i64, vp, i64, vp, i64]),
     "dsh_mat_scale_add_assign": (cint, [vp, i64, i64, vp, vp, i64, dbl, vp, i64]),
     "dsh_mat_set_data_with_indices": (cint, [vp, i64, i64, i64, vp, vp, vp, i64, vp]),
     "dsh_mat_column_axpy": (cint, [vp, i64, i64, vp, dbl, i64, i64]),
     "dsh_mat_gemv": (cint, [vp, i64, i64, i64, dbl, vp, i64, vp, i64, dbl, vp]),
+    "dsh_mat_gemv_from": (cint, [vp, i64, i64, i64, dbl, vp, i64, vp, i64, dbl, vp, vp]),
     "dsh_mat_gemm": (cint, [vp, i64, i64, i64, i64, dbl, vp, i64, vp, i64, dbl, vp]),
     "dsh_lu_create": (cint, [vp, i64, i64, C.POINTER(vp)]),
     "dsh_lu_destroy": (None, [vp]),
@@ -96,6 +100,7 @@ DEVICE_ABI = {
     "dsh_model_jacobian": (cint, [vp, cint, i64, i64, dbl, vp, vp, vp]),
     "dsh_model_has_band_jacobian": (cint, [cint, i64]),
     "dsh_model_jacobian_band": (cint, [vp, cint, i64, i64, dbl, vp, vp, cint, cint, vp]),
+    "dsh_model_jacobian_band_packed": (cint, [vp, cint, i64, i64, dbl, vp, vp, cint, cint, vp]),
     "dsh_model_mass_gemv": (cint, [vp, cint, i64, i64, dbl, vp, vp, dbl, vp]),
     "dsh_model_mass_matrix": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
     "dsh_model_init": (cint, [vp, cint, i64, i64, dbl, vp, vp]),
@@ -119,6 +124,8 @@ DEVICE_ABI = {
     "dsh_model_set_band": (cint, [cint, cint, cint, cint, cint]),
     "dsh_model_band": (cint, [cint, i64, c_ip, c_ip, c_ip, c_ip]),
     "dsh_lu_factor_banded": (cint, [vp, vp, cint, cint]),
+    "dsh_lu_create_banded": (cint, [vp, i64, i64, cint, C.POINTER(vp)]),
+    "dsh_lu_factor_packed": (cint, [vp, vp, cint, cint]),
     "dsh_mat_scale_add_assign_banded": (cint, [vp, i64, i64, cint, cint, vp, vp, i64, dbl, vp, i64]),
     "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_bdf_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),

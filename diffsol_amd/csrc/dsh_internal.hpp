@@ -106,6 +106,7 @@ struct dsh_lu {
   // pivots batch-fastest.
   int structure = 0;
   int band_k = 0;
+  int packed_k = 0;  // > 0: a handle made by dsh_lu_create_banded — `factors` holds (3 packed_k + 1) n doubles per system and takes banded factorisations with K <= packed_k only
   int* band_probe = nullptr;
 };
 // allocates the factor / pivot storage of an LU handle on first use (dsh_lu.hip): every entry point that WRITES factors calls it

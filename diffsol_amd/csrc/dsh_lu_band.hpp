@@ -38,9 +38,11 @@ __global__ void k_band_probe(int64_t n, int64_t nb, const double* __restrict__ a
   }
 }
 
-template <int K>
+// PACKED: the operand is a band container (diffsol_hip.h dsh_mat_band_*: entry (i, j), -kl <= j - i <= ku, at ((j - i + kl) * n + i) * nb + b) instead of a
+// dense one — same entries, same eliminations
+template <int K, bool PACKED = false>
 __global__ __launch_bounds__(64) void k_lu_band_factor(int64_t n, int64_t nb, const double* __restrict__ a, double* __restrict__ fac, int32_t* __restrict__ piv,
-                                                       unsigned long long* singular_count, unsigned int epoch) {
+                                                       unsigned long long* singular_count, unsigned int epoch, int pkl = 0, int pku = 0) {
   constexpr int R = K + 1, C = 2 * K + 1;
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long sing = 0ull;
@@ -49,8 +51,14 @@ __global__ __launch_bounds__(64) void k_lu_band_factor(int64_t n, int64_t nb, co
     // loads are unconditional (clamped address, value selected afterwards): a conditional load becomes a branch and the compiler then waits for
     // every load separately instead of keeping a whole chunk in flight
     auto in = [&](int64_t i, int64_t c) -> double {
-      const double v = a[(min(c, n - 1) * n + min(i, n - 1)) * nb + b];
-      return (i < n && c < n) ? v : 0.0;
+      if constexpr (PACKED) {
+        const int64_t d = c - i, dc = min(max(d, (int64_t)-pkl), (int64_t)pku);
+        const double v = a[((dc + pkl) * n + min(i, n - 1)) * nb + b];
+        return (i < n && c < n && d == dc) ? v : 0.0;
+      } else {
+        const double v = a[(min(c, n - 1) * n + min(i, n - 1)) * nb + b];
+        return (i < n && c < n) ? v : 0.0;
+      }
     };
 #pragma unroll
     for (int r = 0; r < R; ++r)

@@ -56,6 +56,30 @@ __global__ void k_scale_add_assign_banded(int64_t n, int64_t nb, int kl, int ku,
     self[e * nb + b] = yv * beta + xv;
   }
 }
+// ---- band containers: entry (i, j), -kl <= j - i <= ku, at ((j - i + kl) * n + i) * nb + b; the corners that fall outside the matrix are kept at zero
+template <bool BV>
+__global__ void k_band_from_diagonal(int64_t n, int64_t nb, int kl, int ku, const double* __restrict__ v, double* __restrict__ band) {
+  const int64_t total = (int64_t)(kl + ku + 1) * n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = idx % nb, r = idx / nb, i = r % n, pl = r / n;
+    band[idx] = pl == kl ? (BV ? v[i] : v[i * nb + b]) : 0.0;
+  }
+}
+// y = alpha * A x + beta * y over the band, columns ascending: Matrix::gemv's order (the first term carries beta * y, dense_nalgebra_serial gemv) restricted to
+// the entries the container holds — the skipped terms of a dense gemv are alpha * 0 * x_j + acc
+__global__ void k_band_gemv(int64_t n, int64_t nb, int kl, int ku, double alpha, const double* __restrict__ band, const double* __restrict__ x, int64_t xnb, double beta,
+                            double* __restrict__ y) {
+  const int64_t total = n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb, b = idx % nb;
+    auto A = [&](int64_t j) { const int64_t d = j - i; return (d >= -kl && d <= ku) ? band[((d + kl) * n + i) * nb + b] : 0.0; };
+    auto X = [&](int64_t j) { return xnb == 1 && nb != 1 ? x[j] : x[j * nb + b]; };
+    double acc = beta == 0.0 ? alpha * A(0) * X(0) : alpha * A(0) * X(0) + beta * y[idx];
+    const int64_t lo = i - kl > 1 ? i - kl : 1, hi = i + ku < n - 1 ? i + ku : n - 1;
+    for (int64_t j = lo; j <= hi; ++j) acc = alpha * A(j) * X(j) + acc;
+    y[idx] = acc;
+  }
+}
 __global__ void k_set_data_with_indices(int64_t nidx, int64_t nb, double* __restrict__ self, const int32_t* __restrict__ dst_idx,
                                         const int32_t* __restrict__ src_idx, const double* __restrict__ data) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nidx * nb; t += (int64_t)gridDim.x * blockDim.x) {
@@ -71,16 +95,18 @@ __global__ void k_column_axpy(int64_t total, double* __restrict__ ci, const doub
 
 // y = alpha*A*x + beta*y with nalgebra's accumulation order: first column carries beta (beta==0 never reads y),
 // remaining columns accumulate  acc = alpha*A[i,j]*x[j] + acc.  One thread per (row, system).
+// y0 != nullptr: y = alpha*A*x + beta*y0 — `y.copy_from(y0); A.gemv(alpha, x, beta, y)` in one pass (the same first term alpha*A(0)*X(0) + beta*y0_i)
 template <bool BA, bool BX>
 __global__ void k_gemv(int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* __restrict__ a, const double* __restrict__ x, double beta,
-                       double* __restrict__ y) {
+                       double* y, const double* y0 = nullptr) {
   int64_t total = nrows * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t i = idx / nb, b = idx % nb;
-    if (ncols == 0) { y[idx] = beta == 0.0 ? 0.0 : y[idx] * beta; continue; }
+    const double yin = beta == 0.0 ? 0.0 : (y0 ? y0[idx] : y[idx]);
+    if (ncols == 0) { y[idx] = beta == 0.0 ? 0.0 : yin * beta; continue; }
     auto A = [&](int64_t j) { return BA ? a[j * nrows + i] : a[(j * nrows + i) * nb + b]; };
     auto X = [&](int64_t j) { return BX ? x[j] : x[j * nb + b]; };
-    double acc = beta == 0.0 ? alpha * A(0) * X(0) : alpha * A(0) * X(0) + beta * y[idx];
+    double acc = beta == 0.0 ? alpha * A(0) * X(0) : alpha * A(0) * X(0) + beta * yin;
     for (int64_t j = 1; j < ncols; ++j) acc = alpha * A(j) * X(j) + acc;
     y[idx] = acc;
   }
@@ -111,6 +137,24 @@ int dsh_mat_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, const double* v, 
   if (total == 0) return DSH_OK;
   if (vnb == 1 && nb != 1) hipLaunchKernelGGL((k_from_diagonal<true>), ew_grid(total), dim3(kBlock), 0, ctx->stream, n, nb, v, mat);
   else hipLaunchKernelGGL((k_from_diagonal<false>), ew_grid(total), dim3(kBlock), 0, ctx->stream, n, nb, v, mat);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+int dsh_mat_band_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, const double* v, int64_t vnb, double* band) {
+  DSH_CHECK_NB(vnb, nb);
+  DSH_REQUIRE(kl >= 0 && ku >= 0 && band != nullptr, "bad arguments");
+  const int64_t total = (int64_t)(kl + ku + 1) * n * nb;
+  if (total == 0) return DSH_OK;
+  if (vnb == 1 && nb != 1) hipLaunchKernelGGL((k_band_from_diagonal<true>), ew_grid(total), dim3(kBlock), 0, ctx->stream, n, nb, kl, ku, v, band);
+  else hipLaunchKernelGGL((k_band_from_diagonal<false>), ew_grid(total), dim3(kBlock), 0, ctx->stream, n, nb, kl, ku, v, band);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+int dsh_mat_band_gemv(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, double alpha, const double* band, const double* x, int64_t xnb, double beta, double* y) {
+  DSH_CHECK_NB(xnb, nb);
+  DSH_REQUIRE(kl >= 0 && ku >= 0 && band && x && y, "bad arguments");
+  if (n * nb == 0) return DSH_OK;
+  hipLaunchKernelGGL(k_band_gemv, ew_grid(n * nb), dim3(kBlock), 0, ctx->stream, n, nb, kl, ku, alpha, band, x, xnb, beta, y);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
@@ -170,19 +214,23 @@ int dsh_mat_column_axpy(dsh_ctx* ctx, int64_t nrows, int64_t nb, double* mat, do
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
-int dsh_mat_gemv(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* a, int64_t anb, const double* x, int64_t xnb,
-                 double beta, double* y) {
+int dsh_mat_gemv_from(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* a, int64_t anb, const double* x, int64_t xnb,
+                      double beta, const double* y0, double* y) {
   DSH_CHECK_NB(anb, nb); DSH_CHECK_NB(xnb, nb);
   int64_t total = nrows * nb;
   if (total == 0) return DSH_OK;
   bool ba = anb == 1 && nb != 1, bx = xnb == 1 && nb != 1;
   dim3 g = ew_grid(total), b(kBlock);
-  if (!ba && !bx) hipLaunchKernelGGL((k_gemv<false, false>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y);
-  else if (ba && !bx) hipLaunchKernelGGL((k_gemv<true, false>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y);
-  else if (!ba && bx) hipLaunchKernelGGL((k_gemv<false, true>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y);
-  else hipLaunchKernelGGL((k_gemv<true, true>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y);
+  if (!ba && !bx) hipLaunchKernelGGL((k_gemv<false, false>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y, y0);
+  else if (ba && !bx) hipLaunchKernelGGL((k_gemv<true, false>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y, y0);
+  else if (!ba && bx) hipLaunchKernelGGL((k_gemv<false, true>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y, y0);
+  else hipLaunchKernelGGL((k_gemv<true, true>), g, b, 0, ctx->stream, nrows, ncols, nb, alpha, a, x, beta, y, y0);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
+}
+int dsh_mat_gemv(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* a, int64_t anb, const double* x, int64_t xnb,
+                 double beta, double* y) {
+  return dsh_mat_gemv_from(ctx, nrows, ncols, nb, alpha, a, anb, x, xnb, beta, nullptr, y);
 }
 int dsh_mat_gemm(dsh_ctx* ctx, int64_t m, int64_t n, int64_t k, int64_t nb, double alpha, const double* a, int64_t anb, const double* bm, int64_t bnb,
                  double beta, double* c) {

@@ -73,17 +73,19 @@ __global__ void k_dyn_jacobian(int model, int64_t n, int64_t nb, double t, const
   }
 }
 // the same entries on the declared band only (row i, columns i-kl .. i+ku); everything else of the container is left as it is (zero, by the caller's promise)
+// PACKED: into a band container (entry (i, j) at ((j - i + kl) * n + i) * nb + b — the loop index itself; the corners outside the matrix are written as zeros)
+template <bool PACKED>
 __global__ void k_dyn_jacobian_band(int model, int64_t n, int64_t nb, int kl, int ku, double t, const double* __restrict__ x, const double* __restrict__ p,
                                     double* __restrict__ jac) {
   const int64_t w = kl + ku + 1, total = n * w * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = idx / nb, b = idx % nb;
     const int64_t i = e % n, j = i + e / n - kl;
-    if (j < 0 || j >= n) continue;
+    if (j < 0 || j >= n) { if (PACKED) jac[idx] = 0.0; continue; }
     auto X = [&](int64_t k) { return x[k * nb + b]; };
     auto V = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
     auto P = [&](int64_t k) { return p[k * nb + b]; };
-    jac[(j * n + i) * nb + b] = dyn_component(model, n, t, i, X, V, P, true);
+    jac[PACKED ? idx : (j * n + i) * nb + b] = dyn_component(model, n, t, i, X, V, P, true);
   }
 }
 __global__ void k_dyn_init(int model, int64_t n, int64_t nb, double* __restrict__ y) {
@@ -252,7 +254,17 @@ int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, d
   int jl = -1, ju = -1, ml = -1, mu = -1;
   DSH_REQUIRE(dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 && kl >= jl && ku >= ju, "dsh_model_jacobian_band: the band must cover the declared one");
   int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
-  hipLaunchKernelGGL(k_dyn_jacobian_band, ew_grid(n * (kl + ku + 1) * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, kl, ku, t, x, p, jac);
+  hipLaunchKernelGGL(k_dyn_jacobian_band<false>, ew_grid(n * (kl + ku + 1) * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, kl, ku, t, x, p, jac);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+// the same entries into a band container of bandwidths (kl, ku): (kl + ku + 1) n doubles per member, every one of them written
+int dsh_model_jacobian_band_packed(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, int kl, int ku, double* band) {
+  DSH_REQUIRE(!is_jit_model(model) && is_dynamic_model(model, size), "dsh_model_jacobian_band_packed: run-time-sized registry models only");
+  int jl = -1, ju = -1, ml = -1, mu = -1;
+  DSH_REQUIRE(dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 && kl >= jl && ku >= ju, "dsh_model_jacobian_band_packed: the band must cover the declared one");
+  int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_dyn_jacobian_band<true>, ew_grid(n * (kl + ku + 1) * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, kl, ku, t, x, p, band);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }

@@ -192,22 +192,26 @@ __global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb,
   const bool valid = b0 < nb;
   const int64_t b = valid ? b0 : nb - 1;
   double acc = 0.0;
-  double xa[QL], ya[QL], aa[QL];
-  auto fetch = [&](int64_t base, double (&xs)[QL], double (&ys)[QL], double (&as)[QL]) {
+  double xa[QL], ya[QL], aa[QL], ia[SUB ? QL : 1];
+  auto fetch = [&](int64_t base, double (&xs)[QL], double (&ys)[QL], double (&as)[QL], double (&is)[SUB ? QL : 1]) {
 #pragma unroll
     for (int q = 0; q < QL; ++q) {
       const int64_t r = min(base + q * G + g, n - 1);  // clamped: components past the end are not added
       xs[q] = x[r * nb + b];
-      if constexpr (SUB) { if (valid && base + q * G + g < n) xout[r * nb + b] = xin[r * nb + b] - xs[q]; }
+      if constexpr (SUB) is[q] = xin[r * nb + b];  // the update is stored when the chunk is consumed: a store here would wait for the loads just issued
       ys[q] = BY ? y[r] : y[r * nb + b];
       as[q] = BA ? atol[r] : atol[r * nb + b];
     }
   };
-  fetch(0, xa, ya, aa);
+  fetch(0, xa, ya, aa, ia);
   for (int64_t i0 = 0; i0 < n; i0 += CH) {
-    double xn[QL], yn[QL], an[QL];
+    double xn[QL], yn[QL], an[QL], in[SUB ? QL : 1];
     const bool more = i0 + CH < n;
-    if (more) fetch(i0 + CH, xn, yn, an);
+    if (more) fetch(i0 + CH, xn, yn, an, in);
+    if constexpr (SUB) {
+#pragma unroll
+      for (int q = 0; q < QL; ++q) { const int64_t r = i0 + q * G + g; if (valid && r < n) xout[r * nb + b] = ia[q] - xa[q]; }
+    }
 #pragma unroll
     for (int q = 0; q < QL; ++q) {
       const double term = xa[q] / (fabs(ya[q]) * rtol + aa[q]);
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb,
     __builtin_amdgcn_wave_barrier();
     if (more) {
 #pragma unroll
-      for (int q = 0; q < QL; ++q) { xa[q] = xn[q]; ya[q] = yn[q]; aa[q] = an[q]; }
+      for (int q = 0; q < QL; ++q) { xa[q] = xn[q]; ya[q] = yn[q]; aa[q] = an[q]; if constexpr (SUB) ia[q] = in[q]; }
     }
   }
   unsigned long long bits = 0ull;
@@ -326,6 +330,24 @@ int dsh_vec_axpy(dsh_ctx* ctx, int64_t n, int64_t nb, double alpha, const double
   DSH_CHECK_NB(xnb, nb);
   if (beta == 0.0) return launch_binary(ctx, n, nb, y, x, xnb, FAxpy0{alpha});
   return launch_binary(ctx, n, nb, y, x, xnb, FAxpy{alpha, beta});
+}
+// out = alpha*x + beta*y0 (`out.copy_from(y0); out.axpy(alpha, x, beta)` in one pass); copy_x_to (optional) additionally receives x
+__global__ void k_axpby_to(int64_t total, double alpha, const double* __restrict__ x, double beta, const double* __restrict__ y0, double* __restrict__ out,
+                           double* __restrict__ copy_x_to) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const double xv = x[idx];
+    out[idx] = alpha * xv + beta * y0[idx];
+    if (copy_x_to) copy_x_to[idx] = xv;
+  }
+}
+int dsh_vec_axpby_to(dsh_ctx* ctx, int64_t n, int64_t nb, double alpha, const double* x, double beta, const double* y0, double* out, double* copy_x_to) {
+  DSH_REQUIRE(x && y0 && out, "null argument");
+  DSH_REQUIRE(out != x && out != copy_x_to, "dsh_vec_axpby_to: out must not alias x or the copy");
+  const int64_t total = n * nb;
+  if (total == 0) return DSH_OK;
+  hipLaunchKernelGGL(k_axpby_to, ew_grid(total), dim3(kEwBlock), 0, ctx->stream, total, alpha, x, beta, y0, out, copy_x_to);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
 }
 int dsh_vec_batched_axpy(dsh_ctx* ctx, int64_t n, int64_t nb, const double* alpha_host, const double* x, int64_t xnb, double beta, double* y) {
   DSH_CHECK_NB(xnb, nb);

@@ -50,11 +50,18 @@ class BdfCallable : public NonLinearOpRef {
       : eqn_(eqn), psi_neg_y0_(HipVec::zeros(eqn.nstates(), eqn.context())), tmp_(HipVec::zeros(eqn.nstates(), eqn.context())),
         rhs_jac_(HipMat::zeros(eqn.nstates(), eqn.nstates(), eqn.context())) {
     const int64_t n = eqn.nstates();
+    int pkl = 0, pku = 0;
+    if (eqn.packed_band(&pkl, &pku)) {  // declared narrow band, identity mass: band containers for f_y, M and (through packed_band below) M - cJ and its factors
+      packed_ = true; pkl_ = pkl; pku_ = pku;
+      rhs_jac_ = HipMat::zeros_banded(n, pkl, pku, eqn.context());
+      mass_jac_ = HipMat::from_diagonal_banded(HipVec::from_element(n, 1.0, eqn.context()), pkl, pku);
+    } else
     if (!eqn.has_mass()) mass_jac_ = HipMat::from_diagonal(HipVec::from_element(n, 1.0, eqn.context()));  // :138-141
     else mass_jac_ = HipMat::zeros(n, n, eqn.context());
   }
   int64_t nstates() const override { return eqn_.nstates(); }
   const HipContext& context() const override { return eqn_.context(); }
+  bool packed_band(int* kl, int* ku) const override { if (!packed_) return false; *kl = pkl_; *ku = pku_; return true; }
   void set_c(double h, double alpha) { c_ = h * alpha; }
   void set_c_value(double c) { c_ = c; }
   double c() const { return c_; }
@@ -98,6 +105,8 @@ class BdfCallable : public NonLinearOpRef {
   HipVec psi_neg_y0_, tmp_;
   double c_ = 0.0;
   HipMat rhs_jac_, mass_jac_;
+  bool packed_ = false;
+  int pkl_ = 0, pku_ = 0;
   bool jacobian_is_stale_ = true;
 };
 

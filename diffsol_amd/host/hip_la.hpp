@@ -155,6 +155,10 @@ class HipVec {
   void copy_from(const HipVec& x) { same_len(x.n_); HipContext::check_compatible(nb(), x.nb()); check(dsh_vec_copy(ctx_.raw(), n_, nb(), x.ptr(), x.nb(), ptr()), "copy_from"); }
   void copy_from_view(const HipVecView& x) { same_len(x.n); HipContext::check_compatible(nb(), x.nb); check(dsh_vec_copy(ctx_.raw(), n_, nb(), x.p, x.nb, ptr()), "copy_from_view"); }
   // y = alpha*x + beta*y (vector/cuda.rs:937-966)
+  // self = alpha*x + beta*y0 (copy_from(y0) + axpy in one pass); copy_x_to (optional, same shape) also receives x
+  void assign_axpby(double alpha, const double* x, double beta, const double* y0, double* copy_x_to = nullptr) {
+    check(dsh_vec_axpby_to(ctx_.raw(), n_, nb(), alpha, x, beta, y0, ptr(), copy_x_to), "assign_axpby");
+  }
   void axpy(double alpha, const HipVec& x, double beta) { same_len(x.n_); HipContext::check_compatible(nb(), x.nb()); check(dsh_vec_axpy(ctx_.raw(), n_, nb(), alpha, x.ptr(), x.nb(), beta, ptr()), "axpy"); }
   void axpy_v(double alpha, const HipVecView& x, double beta) { same_len(x.n); HipContext::check_compatible(nb(), x.nb); check(dsh_vec_axpy(ctx_.raw(), n_, nb(), alpha, x.p, x.nb, beta, ptr()), "axpy_v"); }
   void batched_axpy(const std::vector<double>& alpha, const HipVec& x, double beta) {
@@ -250,6 +254,11 @@ struct HipMatView {
     if (x.len() != ncols || y.len() != nrows) throw LaError(DSH_E_INVALID, "gemv: shape mismatch");
     check(dsh_mat_gemv(ctx.raw(), nrows, ncols, nb, alpha, p, nb, x.ptr(), x.nb(), beta, y.ptr()), "gemv_o");
   }
+  // y = alpha*self*x + beta*y0: y.copy_from(y0) + gemv_o in one pass
+  void gemv_from(double alpha, const HipVec& x, double beta, const HipVec& y0, HipVec& y) const {
+    if (x.len() != ncols || y.len() != nrows || y0.len() != nrows || y0.nb() != y.nb()) throw LaError(DSH_E_INVALID, "gemv_from: shape mismatch");
+    check(dsh_mat_gemv_from(ctx.raw(), nrows, ncols, nb, alpha, p, nb, x.ptr(), x.nb(), beta, y0.ptr(), y.ptr()), "gemv_from");
+  }
 };
 struct HipMatViewMut {
   double* p = nullptr;
@@ -264,6 +273,23 @@ class HipMat {
  public:
   HipMat() = default;
   static HipMat zeros(int64_t nrows, int64_t ncols, const HipContext& ctx) { HipMat m(nrows, ncols, ctx, true); m.set_band(0, 0); return m; }
+  // BAND CONTAINER of a square matrix whose structure is declared (diffsol_hip.h dsh_mat_band_*): (kl + ku + 1) n entries per member instead of n^2, entry (i, j)
+  // at ((j - i + kl) n + i) nbatch + b.  It takes what the Jacobian / mass / M - cJ containers of the implicit integrators need — scale_add_and_assign with
+  // containers of the same bands, gemv, copy_from, the model's banded Jacobian evaluation, the LU factorisation — and refuses every other matrix operation.
+  static HipMat zeros_banded(int64_t n, int kl, int ku, const HipContext& ctx) {
+    if (kl < 0 || ku < 0 || kl + ku + 1 > n) throw LaError(DSH_E_INVALID, "zeros_banded: bad bandwidths");
+    HipMat m(n, n, ctx, true, (int64_t)(kl + ku + 1) * n);
+    m.packed_ = true; m.band_kl_ = kl; m.band_ku_ = ku;
+    return m;
+  }
+  static HipMat from_diagonal_banded(const HipVec& v, int kl, int ku) {
+    HipMat m = zeros_banded(v.len(), kl, ku, v.context());
+    check(dsh_mat_band_from_diagonal(v.context().raw(), v.len(), v.nb(), kl, ku, v.ptr(), v.nb(), m.buf()), "from_diagonal_banded");
+    return m;
+  }
+  bool packed() const { return packed_; }
+  double* band_ptr() { if (!packed_) throw LaError(DSH_E_INVALID, "band_ptr: not a band container"); return buf(); }
+  int64_t storage_entries() const { return packed_ ? (int64_t)(band_kl_ + band_ku_ + 1) * nrows_ : nrows_ * ncols_; }
   // data: batch-major, column-major per batch member ([b][col][row], matrix/cuda.rs:20-31)
   static HipMat from_vec(int64_t nrows, int64_t ncols, const std::vector<double>& data, const HipContext& ctx) {
     if ((int64_t)data.size() != nrows * ncols * ctx.nbatch()) throw LaError(DSH_E_INVALID, "from_vec: wrong data length");
@@ -283,6 +309,7 @@ class HipMat {
     return m;
   }
   std::vector<double> clone_as_vec() const {
+    dense_only("clone_as_vec");
     std::vector<double> out((size_t)(nrows_ * ncols_ * nb()));
     check(dsh_vec_download(ctx_.raw(), nrows_ * ncols_, nb(), ptr(), out.data()), "HipMat::clone_as_vec");
     return out;
@@ -294,26 +321,40 @@ class HipMat {
   // Structure tag of the CONTENT: every entry outside |i - j| <= (kl below, ku above) is exactly zero.  Set by writers that know it (zeros, from_diagonal,
   // a model that declares the bandwidth of its Jacobian / mass matrix, the banded scale_add_and_assign); any other write access clears it.  It lets
   // M - cJ be assembled and factored on the band only (dsh_mat_scale_add_assign_banded, dsh_lu_factor_banded) — same arithmetic per entry.
-  void set_band(int kl, int ku) { band_kl_ = kl; band_ku_ = ku; }
-  void clear_band() { band_kl_ = band_ku_ = -1; }
+  void set_band(int kl, int ku) { if (packed_) { if (kl > band_kl_ || ku > band_ku_) throw LaError(DSH_E_INVALID, "set_band: wider than the band container"); return; } band_kl_ = kl; band_ku_ = ku; }
+  void clear_band() { if (!packed_) band_kl_ = band_ku_ = -1; }
   bool has_band() const { return band_kl_ >= 0 && band_ku_ >= 0; }
   int band_kl() const { return band_kl_; }
   int band_ku() const { return band_ku_; }
-  double* ptr() { clear_band(); return buf(); }  // write access from outside: the content is no longer known to be banded
+  double* ptr() { dense_only("ptr"); clear_band(); return buf(); }  // write access from outside: the content is no longer known to be banded
   const double* ptr() const { return buf(); }
   int64_t col_stride() const { return nrows_ * nb(); }
 
-  HipVecView column(int64_t j) const { bounds(j); return HipVecView{ptr() + j * col_stride(), nrows_, nb(), ctx_}; }
-  HipVecViewMut column_mut(int64_t j) { bounds(j); return HipVecViewMut{ptr() + j * col_stride(), nrows_, nb(), ctx_}; }
-  HipMatView columns(int64_t start, int64_t end) const { if (start < 0 || end > ncols_ || start > end) throw LaError(DSH_E_INVALID, "columns: out of bounds"); return HipMatView{ptr() + start * col_stride(), nrows_, end - start, nb(), ctx_}; }
-  HipMatViewMut columns_mut(int64_t start, int64_t end) { if (start < 0 || end > ncols_ || start > end) throw LaError(DSH_E_INVALID, "columns_mut: out of bounds"); return HipMatViewMut{ptr() + start * col_stride(), nrows_, end - start, nb(), ctx_}; }
-  HipVec diagonal() const { HipVec v = HipVec::zeros(nrows_, ctx_); check(dsh_mat_get_diagonal(ctx_.raw(), nrows_, nb(), ptr(), v.ptr()), "diagonal"); return v; }
+  HipVecView column(int64_t j) const { dense_only("column"); bounds(j); return HipVecView{ptr() + j * col_stride(), nrows_, nb(), ctx_}; }
+  HipVecViewMut column_mut(int64_t j) { dense_only("column_mut"); bounds(j); return HipVecViewMut{ptr() + j * col_stride(), nrows_, nb(), ctx_}; }
+  HipMatView columns(int64_t start, int64_t end) const { dense_only("columns"); if (start < 0 || end > ncols_ || start > end) throw LaError(DSH_E_INVALID, "columns: out of bounds"); return HipMatView{ptr() + start * col_stride(), nrows_, end - start, nb(), ctx_}; }
+  HipMatViewMut columns_mut(int64_t start, int64_t end) { dense_only("columns_mut"); if (start < 0 || end > ncols_ || start > end) throw LaError(DSH_E_INVALID, "columns_mut: out of bounds"); return HipMatViewMut{ptr() + start * col_stride(), nrows_, end - start, nb(), ctx_}; }
+  HipVec diagonal() const { dense_only("diagonal"); HipVec v = HipVec::zeros(nrows_, ctx_); check(dsh_mat_get_diagonal(ctx_.raw(), nrows_, nb(), ptr(), v.ptr()), "diagonal"); return v; }
 
-  void copy_from(const HipMat& o) { same_shape(o); check(dsh_vec_copy(ctx_.raw(), nrows_ * ncols_, nb(), o.ptr(), o.nb(), ptr()), "HipMat::copy_from"); }
-  void set_column(int64_t j, const HipVec& v) { if (v.len() != nrows_) throw LaError(DSH_E_INVALID, "set_column: length mismatch"); check(dsh_mat_set_column(ctx_.raw(), nrows_, ncols_, nb(), ptr(), j, v.ptr(), v.nb()), "set_column"); }
+  void copy_from(const HipMat& o) {
+    same_shape(o);
+    if (packed_ || o.packed_) {
+      if (!(packed_ && o.packed_ && band_kl_ == o.band_kl_ && band_ku_ == o.band_ku_)) throw LaError(DSH_E_UNSUPPORTED, "copy_from: band containers of different structure");
+      check(dsh_vec_copy(ctx_.raw(), storage_entries(), nb(), o.buf(), o.nb(), buf()), "HipMat::copy_from (band)");
+      return;
+    }
+    check(dsh_vec_copy(ctx_.raw(), nrows_ * ncols_, nb(), o.ptr(), o.nb(), ptr()), "HipMat::copy_from");
+  }
+  void set_column(int64_t j, const HipVec& v) { dense_only("set_column"); if (v.len() != nrows_) throw LaError(DSH_E_INVALID, "set_column: length mismatch"); check(dsh_mat_set_column(ctx_.raw(), nrows_, ncols_, nb(), ptr(), j, v.ptr(), v.nb()), "set_column"); }
   // self = x + beta*y  (matrix/cuda.rs:1424-1458)
   void scale_add_and_assign(const HipMat& x, double beta, const HipMat& y) {
     same_shape(x); same_shape(y);
+    if (packed_ || x.packed_ || y.packed_) {  // band containers of one structure: the same entry-wise x + beta*y over (kl + ku + 1) n entries
+      if (!(packed_ && x.packed_ && y.packed_ && band_kl_ == x.band_kl_ && band_ku_ == x.band_ku_ && band_kl_ == y.band_kl_ && band_ku_ == y.band_ku_))
+        throw LaError(DSH_E_UNSUPPORTED, "scale_add_and_assign: band containers of different structure");
+      check(dsh_mat_scale_add_assign(ctx_.raw(), storage_entries(), nb(), buf(), x.buf(), x.nb(), beta, y.buf(), y.nb()), "scale_add_and_assign (band container)");
+      return;
+    }
     const bool tagged = x.has_band() && y.has_band() && nrows_ == ncols_;
     const int kl = tagged ? std::max(x.band_kl(), y.band_kl()) : -1, ku = tagged ? std::max(x.band_ku(), y.band_ku()) : -1;
     // banded assembly: the result's band must cover what this container holds now (else stale entries outside it would survive)
@@ -325,15 +366,24 @@ class HipMat {
     band_kl_ = kl; band_ku_ = ku;
   }
   // column i += alpha * column j  (matrix/cuda.rs:1048-1088)
-  void column_axpy(double alpha, int64_t j, int64_t i) { bounds(i); bounds(j); check(dsh_mat_column_axpy(ctx_.raw(), nrows_, nb(), ptr(), alpha, j, i), "column_axpy"); }
-  void gemv(double alpha, const HipVec& x, double beta, HipVec& y) const { columns(0, ncols_).gemv_o(alpha, x, beta, y); }
+  void column_axpy(double alpha, int64_t j, int64_t i) { dense_only("column_axpy"); bounds(i); bounds(j); check(dsh_mat_column_axpy(ctx_.raw(), nrows_, nb(), ptr(), alpha, j, i), "column_axpy"); }
+  void gemv(double alpha, const HipVec& x, double beta, HipVec& y) const {
+    if (packed_) {
+      if (x.len() != ncols_ || y.len() != nrows_) throw LaError(DSH_E_INVALID, "gemv: shape mismatch");
+      check(dsh_mat_band_gemv(ctx_.raw(), nrows_, nb(), band_kl_, band_ku_, alpha, buf(), x.ptr(), x.nb(), beta, y.ptr()), "gemv (band container)");
+      return;
+    }
+    columns(0, ncols_).gemv_o(alpha, x, beta, y);
+  }
   void gemm(double alpha, const HipMat& a, const HipMat& b, double beta) {
+    dense_only("gemm"); a.dense_only("gemm"); b.dense_only("gemm");
     if (a.nrows_ != nrows_ || b.ncols_ != ncols_ || a.ncols_ != b.nrows_) throw LaError(DSH_E_INVALID, "gemm: shape mismatch");
     check(dsh_mat_gemm(ctx_.raw(), nrows_, ncols_, a.ncols_, nb(), alpha, a.ptr(), a.nb(), b.ptr(), b.nb(), beta, ptr()), "gemm");
   }
   HipMat mat_mul(const HipMat& b) const { HipMat r = HipMat::zeros(nrows_, b.ncols_, ctx_); r.gemm(1.0, *this, b, 0.0); return r; }
   // resize_cols preserving data (matrix/cuda.rs resize_cols; used by OdeSolverMethod::solve, method.rs:1000-1003)
   void resize_cols(int64_t ncols) {
+    dense_only("resize_cols");
     if (ncols == ncols_) return;
     HipMat m(nrows_, ncols, ctx_, true);
     int64_t keep = ncols < ncols_ ? ncols : ncols_;
@@ -345,6 +395,8 @@ class HipMat {
 
  private:
   int band_kl_ = -1, band_ku_ = -1;
+  bool packed_ = false;
+  void dense_only(const char* what) const { if (packed_) throw LaError(DSH_E_UNSUPPORTED, std::string(what) + ": not available on a band container"); }
   // The storage of a LARGE zero matrix (>= 256 MB) is allocated when it is first touched: a solver object owns the n x n containers of the host-driven path
   // (Jacobian, mass, M - cJ: 2 MB per member each at n = 512) whether or not a solve ever uses them, and an ensemble integrated by the device-resident
   // kernels never does — 32 768 members of a 512-state model would not fit the device otherwise.  Copies share the buffer, allocated or not.
@@ -363,8 +415,8 @@ class HipMat {
       return p;
     }
   };
-  HipMat(int64_t nrows, int64_t ncols, const HipContext& ctx, bool zero) : nrows_(nrows), ncols_(ncols), ctx_(ctx) {
-    const int64_t bytes = (int64_t)sizeof(double) * nrows * ncols * ctx.nbatch();
+  HipMat(int64_t nrows, int64_t ncols, const HipContext& ctx, bool zero, int64_t packed_entries = 0) : nrows_(nrows), ncols_(ncols), ctx_(ctx) {
+    const int64_t bytes = (int64_t)sizeof(double) * (packed_entries > 0 ? packed_entries : nrows * ncols) * ctx.nbatch();
     data_ = std::make_shared<Buf>(ctx, bytes);
     if (!(zero && bytes >= ((int64_t)256 << 20))) (void)data_->get(zero);
   }
@@ -388,6 +440,8 @@ struct LinearOpRef {
   virtual int64_t ncols() const = 0;
   virtual const HipContext& context() const = 0;
   virtual void matrix_inplace(HipMat& y) const = 0;
+  // the operator's matrices live in band containers of these bandwidths (HipMat::zeros_banded): the solver then keeps its own matrix and its factors banded too
+  virtual bool packed_band(int* kl, int* ku) const { (void)kl; (void)ku; return false; }
 };
 
 // HipLU: LinearSolver<HipMat> (CudaLU, linear_solver/cuda/lu.rs:15-191)
@@ -397,9 +451,15 @@ class HipLU {
   void set_sparsity(const LinearOpRef& op) {  // lu.rs:148-190
     if (op.nrows() != op.ncols()) throw LaError(DSH_E_INVALID, "LinearSolverMatrixNotSquare");
     ctx_ = op.context();
-    matrix_ = HipMat::zeros(op.nrows(), op.ncols(), ctx_);
+    int kl = 0, ku = 0;
     dsh_lu* lu = nullptr;
-    check(dsh_lu_create(ctx_.raw(), op.nrows(), ctx_.nbatch(), &lu), "HipLU::set_sparsity");
+    if (op.packed_band(&kl, &ku)) {
+      matrix_ = HipMat::zeros_banded(op.nrows(), kl, ku, ctx_);
+      check(dsh_lu_create_banded(ctx_.raw(), op.nrows(), ctx_.nbatch(), std::max(1, std::max(kl, ku)), &lu), "HipLU::set_sparsity (band)");
+    } else {
+      matrix_ = HipMat::zeros(op.nrows(), op.ncols(), ctx_);
+      check(dsh_lu_create(ctx_.raw(), op.nrows(), ctx_.nbatch(), &lu), "HipLU::set_sparsity");
+    }
     HipContext keep = ctx_;
     lu_ = std::shared_ptr<dsh_lu>(lu, [keep](dsh_lu* p) { dsh_lu_destroy(p); });
     factored_ = false;
@@ -408,7 +468,8 @@ class HipLU {
     if (!lu_) throw LaError(DSH_E_NOT_SETUP, "LinearSolverNotSetup");
     op.matrix_inplace(matrix_);
     const HipMat& m = matrix_;  // const access keeps the structure tag
-    if (m.has_band()) check(dsh_lu_factor_banded(lu_.get(), m.ptr(), m.band_kl(), m.band_ku()), "HipLU::set_linearisation (declared band)");
+    if (m.packed()) check(dsh_lu_factor_packed(lu_.get(), m.ptr(), m.band_kl(), m.band_ku()), "HipLU::set_linearisation (band container)");
+    else if (m.has_band()) check(dsh_lu_factor_banded(lu_.get(), m.ptr(), m.band_kl(), m.band_ku()), "HipLU::set_linearisation (declared band)");
     else check(dsh_lu_factor(lu_.get(), m.ptr()), "HipLU::set_linearisation");
     factored_ = true;
   }

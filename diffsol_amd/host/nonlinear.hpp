@@ -168,6 +168,7 @@ struct NonLinearOpRef {
   virtual const HipContext& context() const = 0;
   virtual void call_inplace(const HipVec& x, double t, HipVec& y) = 0;
   virtual void jacobian_inplace(const HipVec& x, double t, HipMat& y) = 0;
+  virtual bool packed_band(int* kl, int* ku) const { (void)kl; (void)ku; return false; }  // the operator's matrices are band containers (LinearOpRef::packed_band)
 };
 
 // NewtonNonlinearSolver<M, LS, Lsearch> (newton.rs:88-180) with LS = HipLU
@@ -183,6 +184,7 @@ class NewtonNonlinearSolver {
       int64_t ncols() const override { return op.nstates(); }
       const HipContext& context() const override { return op.context(); }
       void matrix_inplace(HipMat&) const override {}
+      bool packed_band(int* kl, int* ku) const override { return op.packed_band(kl, ku); }
     } sp(op);
     linear_solver_.set_sparsity(sp);
     is_jacobian_set_ = false;

@@ -7,6 +7,8 @@
 //   ode_solver/state.rs:84-162,969-997,1086-1124,1209-1277                 nonlinear_solver/root.rs:12-222
 //   ode_solver/method.rs:42-198,227-258,467-520,721-1040
 #pragma once
+#include <cstdlib>
+#include <string>
 #include <functional>
 #include <array>
 #include <cmath>
@@ -78,6 +80,9 @@ class OdeEquations {
   virtual void rhs_sens_inplace(const HipVec&, double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
   virtual void init_sens_inplace(double, HipMat&) const { throw LaError(DSH_E_UNSUPPORTED, "the equations have no parameter sensitivities"); }
   virtual bool fused_model(int* model, int64_t* size) const { (void)model; (void)size; return false; }
+  // the equations declare a narrow band for f_y and have no mass matrix: the integrators keep Jacobian, mass and M - cJ in band containers
+  // (HipMat::zeros_banded: (kl + ku + 1) n entries per member instead of n^2) and the LU keeps banded factors
+  virtual bool packed_band(int* kl, int* ku) const { (void)kl; (void)ku; return false; }
   // registry id of the model when it is one of libdiffsol_hip's built-in device models (fused or not)
   virtual bool registry_model(int*, int64_t*) const { return false; }
   virtual const HipVec& params() const = 0;
@@ -117,6 +122,10 @@ class HipKernelEquations : public OdeEquations {
   void rhs_jacobian_inplace(const HipVec& x, double t, HipMat& y) const override {
     rhs_statistics.number_of_matrix_evals++;
     rhs_statistics.number_of_jac_muls += n_;
+    if (y.packed()) {  // band container: the same entries, (kl + ku + 1) n of them
+      check(dsh_model_jacobian_band_packed(ctx_.raw(), model_, size_, ctx_.nbatch(), t, x.ptr(), p_.ptr(), y.band_kl(), y.band_ku(), y.band_ptr()), "jacobian (band container)");
+      return;
+    }
     // a container that is known to be zero outside the declared band (freshly zeroed, or last written by this very function) is evaluated on the band only
     const bool on_band = band_eval_ && jac_kl_ >= 0 && jac_ku_ >= 0 && y.has_band() && y.band_kl() <= jac_kl_ && y.band_ku() <= jac_ku_ && n_ >= 16 &&
                          (int64_t)(jac_kl_ + jac_ku_ + 1) * 2 <= n_;
@@ -147,6 +156,15 @@ class HipKernelEquations : public OdeEquations {
     check(dsh_model_init_sens(ctx_.raw(), model_, size_, ctx_.nbatch(), t, p_.ptr(), S0.ptr()), "init_sens");
   }
   bool fused_model(int* model, int64_t* size) const override { if (!fused_) return false; *model = model_; *size = size_; return true; }
+  bool packed_band(int* kl, int* ku) const override {
+    // DSH_BAND_CONTAINER=0 keeps the dense containers with a structure tag (round 2); DSH_LU_STRUCTURE=dense asks for dense factorisations, which need them
+    const char* e = std::getenv("DSH_BAND_CONTAINER");
+    const char* st = std::getenv("DSH_LU_STRUCTURE");
+    if ((e && e[0] == '0') || (st && std::string(st) == "dense")) return false;
+    if (!band_eval_ || has_mass_ || jac_kl_ < 0 || jac_ku_ < 0 || n_ < 16 || std::max(jac_kl_, jac_ku_) > 4 || (int64_t)(jac_kl_ + jac_ku_ + 1) * 2 > n_) return false;
+    *kl = jac_kl_; *ku = jac_ku_;
+    return true;
+  }
   bool registry_model(int* model, int64_t* size) const override { *model = model_; *size = size_; return true; }
   const HipVec& params() const override { return p_; }
   void count_fused_rhs_call() const { rhs_statistics.number_of_calls++; }

@@ -54,21 +54,31 @@ class SdirkCallable : public NonLinearOpRef {
       : eqn_(eqn), c_(c), phi_(HipVec::zeros(eqn.nstates(), eqn.context())), tmp_(HipVec::zeros(eqn.nstates(), eqn.context())),
         rhs_jac_(HipMat::zeros(eqn.nstates(), eqn.nstates(), eqn.context())) {
     const int64_t n = eqn.nstates();
+    int pkl = 0, pku = 0;
+    if (eqn.packed_band(&pkl, &pku)) {  // declared narrow band, identity mass: band containers for f_y, M and (through packed_band below) M - cJ and its factors
+      packed_ = true; pkl_ = pkl; pku_ = pku;
+      rhs_jac_ = HipMat::zeros_banded(n, pkl, pku, eqn.context());
+      mass_jac_ = HipMat::from_diagonal_banded(HipVec::from_element(n, 1.0, eqn.context()), pkl, pku);
+    } else
     if (!eqn.has_mass()) mass_jac_ = HipMat::from_diagonal(HipVec::from_element(n, 1.0, eqn.context()));
     else mass_jac_ = HipMat::zeros(n, n, eqn.context());
   }
   int64_t nstates() const override { return eqn_.nstates(); }
   const HipContext& context() const override { return eqn_.context(); }
+  bool packed_band(int* kl, int* ku) const override { if (!packed_) return false; *kl = pkl_; *ku = pku_; return true; }
   void set_h(double h) { h_ = h; }
   double h() const { return h_; }
   double c() const { return c_; }
   // phi = y0 + diff[:,0..ncols) * a   (set_phi with h = 1, :174-184)
   void set_phi(const HipMatView& diff, const HipVec& y0, const HipVec& a) {
+    if (y0.nb() == phi_.nb()) { diff.gemv_from(1.0, a, 1.0, y0, phi_); return; }  // the copy and the gemv in one pass (dsh_mat_gemv_from)
     phi_.copy_from(y0);
     diff.gemv_o(1.0, a, 1.0, phi_);
   }
   void set_tmp(const HipVec& x) { tmp_.copy_from(phi_); tmp_.axpy(c_, x, 1.0); }                               // :186-195
   void get_f_eval(const HipVec& x, HipVec& f_eval) const { f_eval.copy_from(phi_); f_eval.axpy(c_, x, 1.0); }  // :197-203
+  // get_f_eval and the copy of the stage increment into its column of diff (runge_kutta.rs:672-676) in one pass
+  void get_f_eval_and_store(const HipVec& x, HipVec& f_eval, double* column) const { f_eval.assign_axpby(c_, x.ptr(), 1.0, phi_.ptr(), column); }
   void set_jacobian_is_stale() { jacobian_is_stale_ = true; }
   bool jacobian_is_stale() const { return jacobian_is_stale_; }
   void clear_jacobian_is_stale() { jacobian_is_stale_ = false; }
@@ -104,6 +114,8 @@ class SdirkCallable : public NonLinearOpRef {
   double c_, h_ = 0.0;
   HipVec phi_, tmp_;
   HipMat rhs_jac_, mass_jac_;
+  bool packed_ = false;
+  int pkl_ = 0, pku_ = 0;
   bool jacobian_is_stale_ = true;
 };
 
@@ -471,6 +483,7 @@ class Sdirk : public OdeSolverMethod {
     else if (i == 1) hdy.copy_from_view(df.column(0));
     else {
       const double c = (tab_.c[(size_t)i] - tab_.c[(size_t)i - 2]) / (tab_.c[(size_t)i - 1] - tab_.c[(size_t)i - 2]);
+      if (df.nb() == hdy.nb()) { hdy.assign_axpby(-c, df.column(i - 2).p, 1.0 + c, df.column(i - 1).p); return; }  // the copy and the axpy in one pass
       hdy.copy_from_view(df.column(i - 1));
       hdy.axpy_v(-c, df.column(i - 2), 1.0 + c);
     }
@@ -487,8 +500,11 @@ class Sdirk : public OdeSolverMethod {
     NlError r = (fused_ || staged_) ? newton_fused(t) : nonlinear_solver_.solve_in_place(op_, old_state_.dy, t, state_.y, convergence_, line_search_);
     statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
     if (r != NlError::Ok) return r;
-    op_.get_f_eval(old_state_.dy, old_state_.y);
-    diff_.column_mut(i).copy_from(old_state_.dy);
+    if (old_state_.dy.nb() == nb() && old_state_.y.nb() == nb()) op_.get_f_eval_and_store(old_state_.dy, old_state_.y, diff_.column_mut(i).p);
+    else {
+      op_.get_f_eval(old_state_.dy, old_state_.y);
+      diff_.column_mut(i).copy_from(old_state_.dy);
+    }
     if (s_op_) {  // the sensitivity half of do_stage_sdirk (runge_kutta.rs:691-748)
       sens_update_state(old_state_.y, t);  // update_rhs_out_state(old_state.y, old_state.dy, t)
       for (size_t j = 0; j < sdiff_.size(); ++j) {

@@ -110,6 +110,10 @@ int dsh_vec_mul_assign_scalar(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v
 int dsh_vec_mul_scalar(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, double s, double* res);
 /* y = alpha*x + beta*y                              (vec_axpy.cu:1; vector/cuda.rs:937-966, :1459-1489) */
 int dsh_vec_axpy(dsh_ctx* ctx, int64_t n, int64_t nbatch, double alpha, const double* x, int64_t x_nb, double beta, double* y);
+/* out = alpha*x + beta*y0: `out.copy_from(y0); out.axpy(alpha, x, beta)` in one pass (same arithmetic per entry); copy_x_to, when not NULL, also receives x.
+ * out must not alias x or copy_x_to (it may be y0).  What the SDIRK stages use for get_f_eval + the stage's column of diff and for predict_stage
+ * (op/sdirk.rs:197-203, runge_kutta.rs:610-689). */
+int dsh_vec_axpby_to(dsh_ctx* ctx, int64_t n, int64_t nbatch, double alpha, const double* x, double beta, const double* y0, double* out, double* copy_x_to);
 /* y_b = alpha[b]*x_b + beta*y_b, alpha is a HOST array of nbatch values (vec_batched_axpy.cu:4; vector/cuda.rs:967-1012) */
 int dsh_vec_batched_axpy(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* alpha_host, const double* x, int64_t x_nb, double beta, double* y);
 /* dst = src (broadcast if src_nb==1) ; v = value    (vec_copy.cu:1, vec_fill.cu:1; vector/cuda.rs:208-236, :867-886) */
@@ -140,6 +144,13 @@ int dsh_vec_root_finding(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* 
 /* ---- Matrix / DenseMatrix ops (matrix/cuda.rs:848-1468) ---- */
 /* mat = diag(v) (n x n) ; v = diag(mat)             (mat_from_diagonal.cu:2, mat_get_diagonal.cu:2; matrix/cuda.rs:129-160, :1333-1365) */
 int dsh_mat_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t v_nb, double* mat);
+/* ---- band containers (the storage of a matrix whose structure is declared: SUNDIALS' band matrix in book/src/benchmarks/sundials.md:27-28; the reference's
+ * own containers are dense or CSC, matrix/cuda.rs:848-1089).  Layout as dsh_model_jacobian_band_packed.  self = x + beta*y on band containers of the same
+ * (kl, ku) is dsh_mat_scale_add_assign over (kl + ku + 1) * n entries; the factorisation is dsh_lu_factor_packed. */
+int dsh_mat_band_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, int kl, int ku, const double* v, int64_t v_nb, double* band);
+/* y = alpha*A*x + beta*y, columns ascending (Matrix::gemv's order on the entries the container holds) */
+int dsh_mat_band_gemv(dsh_ctx* ctx, int64_t n, int64_t nbatch, int kl, int ku, double alpha, const double* band, const double* x, int64_t x_nb, double beta,
+                      double* y);
 int dsh_mat_get_diagonal(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* mat, double* v);
 /* column j of mat (nrows x ncols) = v               (mat_set_column.cu:2; matrix/cuda.rs:1389-1421) */
 int dsh_mat_set_column(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double* mat, int64_t j, const double* v, int64_t v_nb);
@@ -158,6 +169,9 @@ int dsh_mat_column_axpy(dsh_ctx* ctx, int64_t nrows, int64_t nbatch, double* mat
 /* y = alpha*A*x + beta*y, A nrows x ncols            (cublasDgemv host loop over batches; matrix/cuda.rs:620-677, :1267-1293) */
 int dsh_mat_gemv(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double alpha, const double* a, int64_t a_nb, const double* x,
                  int64_t x_nb, double beta, double* y);
+/* y = alpha*A*x + beta*y0: `y.copy_from(y0); gemv(alpha, x, beta, y)` in one pass (y0 NULL: plain gemv on y).  SdirkCallable::set_phi (op/sdirk.rs:174-184). */
+int dsh_mat_gemv_from(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nbatch, double alpha, const double* a, int64_t a_nb, const double* x, int64_t x_nb,
+                      double beta, const double* y0, double* y);
 /* C = alpha*A*B + beta*C, A m x k, B k x n, C m x n  (cublasDgemmStridedBatched, stride 0 = broadcast; matrix/cuda.rs:757-822, :960) */
 int dsh_mat_gemm(dsh_ctx* ctx, int64_t m, int64_t n, int64_t k, int64_t nbatch, double alpha, const double* a, int64_t a_nb, const double* b,
                  int64_t b_nb, double beta, double* c);
@@ -192,6 +206,11 @@ int dsh_lu_set_structure(dsh_lu* lu, int structure);
 /* the same with the band DECLARED by the caller (a model that knows the structure of its Jacobian, dsh_model_band): no probe pass.  Entries with
  * |i - j| > max(kl, ku) are not read.  DSH_CHECK_BAND=1 (debug) probes anyway and fails if the declaration is wrong. */
 int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku);
+/* An LU handle for banded systems only: (3k + 1) n doubles of factor storage per system instead of n^2; takes dsh_lu_factor_packed with max(kl, ku) <= k
+ * (1 <= k <= 4, n >= 16); dsh_lu_solve as for any handle; dense operands are refused. */
+int dsh_lu_create_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int k, dsh_lu** out);
+/* Factor a band container: the eliminations of dsh_lu_factor_banded on the same entries (bit-identical factors and solutions).  Works on any handle. */
+int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku);
 int dsh_lu_band_width(const dsh_lu* lu);
 /* packed LU factors as [b][col][row] and pivot rows as [b][k] on the host, whatever the device layout; blocking */
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
@@ -250,6 +269,10 @@ int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, do
    declared band (dsh_model_band) covered by (kl, ku).  What a banded matrix type would evaluate (book/src/benchmarks/sundials.md:27-28 notes its absence). */
 int dsh_model_has_band_jacobian(int model, int64_t size); /* 1 if dsh_model_jacobian_band serves this model */
 int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, int kl, int ku, double* jac);
+/* ... into a BAND CONTAINER: entry (i, j), -kl <= j - i <= ku, at ((j - i + kl) * n + i) * nbatch + b — (kl + ku + 1) n doubles per member instead of n^2
+ * (config 3: 12 KB instead of 2 MB per matrix and member).  Every entry of the container is written (the corners outside the matrix as zeros). */
+int dsh_model_jacobian_band_packed(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, int kl, int ku,
+                                   double* band);
 int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* x, const double* p, double beta, double* y);
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* mass);
 int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, const double* p, double* y);

@@ -109,6 +109,23 @@ def test_config3_full_size_heat1d_512x4096_against_the_fourier_series(config3_fu
     assert np.array_equal(y, yd) and st == std
 
 
+def test_config3_model_at_65536_members_runs_host_driven_because_its_matrices_are_band_containers(H):
+    """heat1d n = 512 x 65 536 members, host-driven TR-BDF2.  Jacobian, mass, M - cJ and the LU factors of this declared-band model live in
+    band containers (3 n, resp. 4 n doubles per member): 0.8 - 1.1 GB each at this size, where the dense containers would take 137 GB each — the run would not
+    fit the device.  Checks: it runs, the device memory in use stays below 24 GB, the solution is the Fourier series' to the integration tolerance."""
+    import torch
+    nb, n = 65536, 512
+    D = np.random.default_rng(12345).uniform(0.5, 2.0, nb)
+    free0, _ = torch.cuda.mem_get_info()
+    s = H.Solver("heat1d", D[:, None], nbatch=nb, model_size=n, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)
+    y, _ = s.solve_to_points([0.05])
+    free1, _ = torch.cuda.mem_get_info()
+    assert (free0 - free1) < 24 * 2**30, (free0 - free1) / 2**30
+    assert np.isfinite(y).all() and s.stats()["number_of_steps"] > 20
+    pick = np.arange(0, nb, 1024)
+    assert np.abs(y[0, pick] - heat_fourier(n, D[pick], 0.05)).max() < 2e-4  # the semi-discretisation error at this early time dominates
+
+
 def spm_currents(nb):
     return np.random.default_rng(12345).uniform(0.6, 1.4, nb)  # SURVEY 8(d) C4: I_b ~ U[0.6, 1.4] A
 

@@ -420,6 +420,84 @@ def test_declared_band_assembly_and_factorisation_touch_only_the_band_and_give_t
         assert L.dsh_model_band(H.MODELS[model], size, *[C.byref(o) for o in out]) == 0 and tuple(o.value for o in out) == expect
 
 
+def _pack_band(a, kl, ku):
+    """[nb, n, n] dense -> [nb, (kl + ku + 1) * n] band container: entry (i, j) at plane j - i + kl, row i; the corners outside the matrix are zeros"""
+    nb, n, _ = a.shape
+    out = np.zeros((nb, kl + ku + 1, n))
+    for d in range(-kl, ku + 1):
+        i = np.arange(max(0, -d), min(n, n - d))
+        out[:, d + kl, i] = a[:, i, i + d]
+    return out.reshape(nb, -1)
+
+
+@pytest.mark.parametrize("n,kl,ku", [(16, 1, 1), (42, 1, 1), (100, 2, 1), (64, 0, 3), (77, 3, 3), (512, 1, 1), (130, 4, 2)])
+@pytest.mark.parametrize("dominant", [True, False])
+def test_band_containers_factor_solve_and_multiply_with_the_bits_of_the_dense_route(H, O, ctx1, n, kl, ku, dominant):
+    """the band container ((kl + ku + 1) n entries per member instead of n^2; diffsol_hip.h dsh_mat_band_*, dsh_lu_create_banded,
+    dsh_lu_factor_packed).  Factorisation + solve on a banded LU handle (factor storage (3k + 1) n per member) give the oracle's dense LU solution bit for
+    bit, with and without real row interchanges; x + beta*y of containers is the entry-wise scale_add_and_assign; gemv and from_diagonal agree with the
+    dense kernels; a dense operand is refused by the banded handle."""
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb = 70 if n < 500 else 9
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(7000 * n + 10 * kl + ku)
+    jac, mass = _banded(rng, nb, n, kl, ku, False), _banded(rng, nb, n, 0, 0, True)
+    if dominant:
+        mass[:, np.arange(n), np.arange(n)] += 4.0 * (kl + ku + 1)
+    w = (kl + ku + 1) * n
+    Jb, Mb = H.HipVec.from_vec(_pack_band(jac, kl, ku), c), H.HipVec.from_vec(_pack_band(mass, kl, ku), c)
+    Ab = H.HipVec.from_vec(np.full((nb, w), 7.0), c)
+    assert L.dsh_mat_scale_add_assign(c._h, w, nb, Ab.ptr, Mb.ptr, nb, -0.3, Jb.ptr, nb) == 0
+    exact = jac * -0.3 + mass
+    assert np.array_equal(Ab.clone_as_vec(), _pack_band(exact, kl, ku))
+    h = C.c_void_p()
+    k = max(1, kl, ku)
+    assert L.dsh_lu_create_banded(c._h, n, nb, k, C.byref(h)) == 0
+    try:
+        assert L.dsh_lu_factor_packed(h, Ab.ptr, kl, ku) == 0 and L.dsh_lu_band_width(h) == k
+        b = rng.standard_normal((nb, n))
+        x = H.HipVec.from_vec(b, c)
+        assert L.dsh_lu_solve(h, x.ptr) == 0
+        xo, _, _, rc = O.lu_solve(exact, b)
+        assert rc == 0 and np.array_equal(x.clone_as_vec(), xo)
+        assert L.dsh_lu_factor(h, H.HipMat.from_array(exact, c).ptr) != 0  # no room for dense factors in this handle
+    finally:
+        L.dsh_lu_destroy(h)
+    # the same container through an ordinary handle
+    lu = H.HipLU(c, n)
+    assert L.dsh_lu_factor_packed(lu._h, Ab.ptr, kl, ku) == 0
+    x2 = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x2)
+    assert np.array_equal(x2.clone_as_vec(), xo)
+    # gemv: y = alpha A x + beta y, and from_diagonal
+    xv, yv = rng.standard_normal((nb, n)), rng.standard_normal((nb, n))
+    X, Y, Yd = H.HipVec.from_vec(xv, c), H.HipVec.from_vec(yv, c), H.HipVec.from_vec(yv, c)
+    assert L.dsh_mat_band_gemv(c._h, n, nb, kl, ku, 1.7, Ab.ptr, X.ptr, nb, -0.4, Y.ptr) == 0
+    assert L.dsh_mat_gemv(c._h, n, n, nb, 1.7, H.HipMat.from_array(exact, c).ptr, nb, X.ptr, nb, -0.4, Yd.ptr) == 0
+    assert np.array_equal(Y.clone_as_vec(), Yd.clone_as_vec())
+    D = H.HipVec.from_vec(np.full((nb, w), 3.0), c)
+    assert L.dsh_mat_band_from_diagonal(c._h, n, nb, kl, ku, X.ptr, nb, D.ptr) == 0
+    dd = np.zeros((nb, n, n)); dd[:, np.arange(n), np.arange(n)] = xv
+    assert np.array_equal(D.clone_as_vec(), _pack_band(dd, kl, ku))
+
+
+def test_band_container_jacobian_of_a_declared_model_holds_the_entries_of_the_dense_one(H, ctx1):
+    from diffsol_amd import _ffi
+    L = _ffi.load_device_lib()
+    nb, n = 9, 64
+    c = ctx1.clone_with_nbatch(nb)
+    rng = np.random.default_rng(5)
+    x, p = H.HipVec.from_vec(rng.uniform(0.1, 1.0, (nb, n)), c), H.HipVec.from_vec(rng.uniform(0.5, 2.0, (nb, 1)), c)
+    dense = H.HipMat.from_array(np.zeros((nb, n, n)), c)
+    assert L.dsh_model_jacobian(c._h, H.MODELS["heat1d"], n, nb, 0.0, x.ptr, p.ptr, dense.ptr) == 0
+    for kl, ku in ((1, 1), (2, 3)):
+        band = H.HipVec.from_vec(np.full((nb, (kl + ku + 1) * n), 7.0), c)
+        assert L.dsh_model_jacobian_band_packed(c._h, H.MODELS["heat1d"], n, nb, 0.0, x.ptr, p.ptr, kl, ku, band.ptr) == 0
+        assert np.array_equal(band.clone_as_vec(), _pack_band(dense.to_array(), kl, ku))
+    assert L.dsh_model_jacobian_band_packed(c._h, H.MODELS["heat1d"], n, nb, 0.0, x.ptr, p.ptr, 0, 1, band.ptr) != 0  # narrower than the declared band
+
+
 @pytest.mark.parametrize("n,nrhs", [(3, 5), (8, 3), (42, 4), (100, 2)])
 def test_lu_solve_with_several_right_hand_sides_equals_separate_solves_bitwise(H, O, ctx1, n, nrhs):
     """dsh_lu_solve_multi: the factors serve nrhs columns per system (forward-sensitivity solves); same bits as one dsh_lu_solve per column and as the oracle."""
