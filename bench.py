@@ -266,6 +266,21 @@ def main():
                     "mean_steps_per_member": st / k_x / n_total, "failed_members": int(fl)}
 
         extras["per_member"] = dict(mode_pass(ENSEMBLE_PER_MEMBER, False), note="every member its own step-size/order history (diffsol's CPU semantics for a sweep)")
+        try:  # its roofline entry, from the committed counters of the same kernel (MODE=member scripts/profile_r03.sh); refused when the kernel sources changed since
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_per_member.json"))).get("bench_kernel", {})
+            if pm.get("kernel_source_sha16") == kernel_source_hash() and pm.get("members") == nb and world == 1:
+                t_s = extras["per_member"]["ms_per_step"] * 1e-3
+                extras["per_member"]["roofline"] = {
+                    "bound": "valu", "kernel": pm.get("kernel"), "avg_launch_us": t_s * 1e6, "measured": "wall clock of the per-member solves of this pass (one launch each)",
+                    "achieved": pm["valu_insts_per_launch"] * 64 / t_s / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                    "frac": pm["valu_insts_per_launch"] * 64 / t_s / 1e12 / VALU_PEAK_TLANEOPS, "valu_wave_instructions_per_launch": pm["valu_insts_per_launch"],
+                    "fp64_wave_instructions_per_launch": pm.get("f64_insts_per_launch"), "traffic": pm.get("hbm_bytes_per_launch"), "counters_from": "profiles/r03_pmc_per_member.json",
+                    "note": "lane-operations ISSUED, most of them masked off: 3.3x the wave-instructions of the lock-step kernel for fewer member-steps is divergence inside "
+                            "wavefronts (profiles/r03_per_member.md: 8.3 ms against 3.2 ms for the same ensemble size with no divergence inside any wavefront)"}
+            else:
+                extras["per_member"]["roofline"] = None
+        except Exception:
+            extras["per_member"]["roofline"] = None
         hl = mode_pass(ENSEMBLE_LOCKSTEP, True)
         hl["note"] = ("DSHS_ENSEMBLE_LOCKSTEP: host-driven, one (t, h, order) for all members over the trait-boundary operations (fused Newton / accept kernels); "
                       "round 1's `value` path")

@@ -89,6 +89,7 @@ DEVICE_ABI = {
     "dsh_lu_destroy": (None, [vp]),
     "dsh_lu_factor": (cint, [vp, vp]),
     "dsh_lu_solve": (cint, [vp, vp]),
+    "dsh_lu_solve_squared_norm": (cint, [vp, vp, vp, i64, vp, i64, dbl, vp]),
     "dsh_lu_info": (cint, [vp, c_i64p]),
     "dsh_lu_factors": (vp, [vp]),
     "dsh_lu_pivots": (vp, [vp]),

@@ -36,6 +36,7 @@
 #include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
 
+#include <hipcub/hipcub.hpp>
 #include "dsh_adaptive_kernel.hpp"
 #include "dsh_member_sched_kernel.hpp"
 #include "dsh_jit.hpp"
@@ -174,6 +175,83 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   bool launched = false;
   DSH_HIP_CHECK(timing_begin(ctx));
+  // ---- per-member control in SEGMENTS with re-binning between them (DSH_REBIN=k: a segment ends when a member has produced k more save points; 0 / unset:
+  // one launch).  Members drift apart inside a wavefront — different orders, step sizes, distances to the next order selection — and a wavefront pays for the
+  // union of its lanes' paths (profiles/r03_per_member.md: 61 % of the per-member time).  Between segments every member's integrator state is in memory and
+  // the members are dealt to lanes again, sorted by (order, steps since the last change, step size).  The state is read back exactly, so results do not
+  // depend on where the segments end: bit-identical to the single launch.  Register-resident static models only.
+  const int rebin = [] { const char* e = std::getenv("DSH_REBIN"); return e && *e ? std::atoi(e) : 0; }();
+  // DSH_REBIN_STEPS=k: a segment ends for a member after k trips of its step loop instead (all wavefronts of a segment then do the same number of trips: no
+  // waiting for the slowest member of a segment); the host launches segments until no member is left, then one launch that only writes the results.
+  const int rebin_steps = [] { const char* e = std::getenv("DSH_REBIN_STEPS"); return e && *e ? std::atoi(e) : 0; }();
+  if ((rebin_steps > 0 || (rebin > 0 && n_eval > rebin)) && !is_jit_model(model) && C.r.o.group == 1 && nb >= 128) {
+    double* seg_dbl = nullptr; int* seg_int = nullptr; unsigned long long *keys = nullptr, *keys_out = nullptr; int *idx_iota = nullptr, *lane_member = nullptr; void* cub_tmp = nullptr;
+    AdaptiveConsts* seg_consts = nullptr; unsigned int* remaining = nullptr;
+    size_t cub_bytes = 0;
+    auto release = [&]() { (void)hipFree(seg_dbl); (void)hipFree(seg_int); (void)hipFree(keys); (void)hipFree(keys_out); (void)hipFree(idx_iota); (void)hipFree(lane_member); (void)hipFree(cub_tmp); (void)hipFree(seg_consts); (void)hipFree(remaining); };
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, keys, keys_out, idx_iota, lane_member, (int)nb, 0, 64, ctx->stream);
+    const bool by_steps = rebin_steps > 0;
+    const int nseg = by_steps ? 3 : (int)((n_eval + rebin - 1) / rebin);  // by steps: first / resumed / results-only
+    bool okm = hipMalloc((void**)&seg_dbl, sizeof(double) * (size_t)kSegDbl * nb) == hipSuccess && hipMalloc((void**)&seg_int, sizeof(int) * (size_t)kSegInt * nb) == hipSuccess &&
+               hipMalloc((void**)&keys, 8 * (size_t)nb) == hipSuccess && hipMalloc((void**)&keys_out, 8 * (size_t)nb) == hipSuccess && hipMalloc((void**)&idx_iota, 4 * (size_t)nb) == hipSuccess &&
+               hipMalloc((void**)&lane_member, 4 * (size_t)nb) == hipSuccess && hipMalloc(&cub_tmp, cub_bytes ? cub_bytes : 8) == hipSuccess &&
+               hipMalloc((void**)&seg_consts, sizeof(AdaptiveConsts) * (size_t)nseg) == hipSuccess && hipMalloc((void**)&remaining, 4) == hipSuccess;
+    if (!okm) { (void)hipGetLastError(); release(); set_error("dsh_bdf_solve_adaptive (DSH_REBIN): out of device memory for the segment state"); dsh_free(ctx, totals_dev); if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } return DSH_E_HIP; }
+    {
+      std::vector<int> iota((size_t)nb);
+      for (int64_t k = 0; k < nb; ++k) iota[(size_t)k] = (int)k;
+      DSH_HIP_CHECK(hipMemcpyAsync(idx_iota, iota.data(), 4 * (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+      DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<AdaptiveConsts> segc((size_t)nseg, C);
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      AdaptiveConsts& S = segc[(size_t)sgi];
+      S.seg_dbl = seg_dbl; S.seg_int = seg_int; S.seg_key = keys; S.seg_lane_member = sgi == 0 ? nullptr : lane_member;
+      S.seg_fresh = sgi == 0; S.seg_last = sgi == nseg - 1; S.seg_remaining = nullptr; S.seg_step_budget = 0;
+      S.seg_col_end = (int)std::min<int64_t>(n_eval, (int64_t)(sgi + 1) * rebin);
+      if (by_steps) { S.seg_col_end = (int)n_eval + 1; S.seg_step_budget = rebin_steps; S.seg_remaining = remaining; if (S.seg_last) S.seg_lane_member = nullptr; }
+    }
+    DSH_HIP_CHECK(hipMemcpyAsync(seg_consts, segc.data(), sizeof(AdaptiveConsts) * (size_t)nseg, hipMemcpyHostToDevice, ctx->stream));
+    auto launch_seg = [&](const AdaptiveConsts* cd) {
+      return dispatch_static_model(model, size, [&](auto mdl) {
+        using Mdl = decltype(mdl);
+        if constexpr (Mdl::N <= 4) {
+          if (ba) hipLaunchKernelGGL((k_bdf_adaptive<Mdl, true, false, true>), grid, blk, 0, ctx->stream, nb, p, atol, cd, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+          else hipLaunchKernelGGL((k_bdf_adaptive<Mdl, false, false, true>), grid, blk, 0, ctx->stream, nb, p, atol, cd, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+        }
+      });
+    };
+    bool seg_ok = true;
+    if (by_steps) {
+      for (long sgi = 0; seg_ok; ++sgi) {
+        DSH_HIP_CHECK(hipMemsetAsync(remaining, 0, 4, ctx->stream));
+        seg_ok = launch_seg(seg_consts + (sgi == 0 ? 0 : 1));
+        unsigned int left = 0;
+        DSH_HIP_CHECK(hipMemcpyAsync(&left, remaining, 4, hipMemcpyDeviceToHost, ctx->stream));
+        (void)hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys, keys_out, idx_iota, lane_member, (int)nb, 0, 64, ctx->stream);
+        DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (left == 0) break;
+      }
+      if (seg_ok) seg_ok = launch_seg(seg_consts + 2);
+    } else {
+      for (int sgi = 0; sgi < nseg && seg_ok; ++sgi) {
+        seg_ok = launch_seg(seg_consts + sgi);
+        if (sgi + 1 < nseg)
+          (void)hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, keys, keys_out, idx_iota, lane_member, (int)nb, 0, 64, ctx->stream);
+      }
+    }
+    DSH_HIP_CHECK(hipGetLastError());
+    DSH_HIP_CHECK(timing_end(ctx));
+    unsigned long long totals_s[8] = {0};
+    DSH_HIP_CHECK(hipMemcpyAsync(totals_s, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
+    DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    DSH_HIP_CHECK(timing_collect(ctx));
+    release();
+    if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); }
+    dsh_free(ctx, totals_dev);
+    if (totals_host) for (int k = 0; k < 6; ++k) totals_host[k] = (int64_t)totals_s[k];
+    return DSH_OK;
+  }
   // per-member control of the register-resident models can run on the phase-scheduled kernel (dsh_member_sched_kernel.hpp; same bits) with
   // DSH_MEMBER_SCHED=1: opt-in (measured slower than the nested-loop kernel on C2: 10.75 vs 9.23 ms); read per call: tests run both kernels
   const bool sched_env = [] { const char* e = std::getenv("DSH_MEMBER_SCHED"); return e && e[0] == '1'; }();

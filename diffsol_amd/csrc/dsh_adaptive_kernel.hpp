@@ -13,7 +13,17 @@ struct AdaptiveConsts {
   double alpha[6], gamma[6], ec2[6];  // Bdf::_new tables (bdf.rs:286-306), computed on the host
   double u[kMaxOrder][36];            // compute_r(order, 1.0), 6x6 column-major (unused entries 0)
   double eta_reset_p08, eta_reset_ts_p08;  // dsh_det_pow(eta_reset, 0.8), dsh_det_pow(eta_reset_ts, 0.8): the first Newton iteration after a reset (appended: older code objects ignore them)
+  // Segmented per-member runs (k_bdf_adaptive<.., SEG = true>, dsh_adaptive.hip): the launch integrates every member until it has produced seg_col_end
+  // save points, writes the member's whole integrator state to seg_dbl / seg_int ([slot][member]) and a sort key to seg_key; the next launch resumes from
+  // it with the members dealt to lanes in a new order (seg_lane_member).  Nothing of the arithmetic depends on where a launch ends.
+  double* seg_dbl;
+  int* seg_int;
+  unsigned long long* seg_key;
+  const int* seg_lane_member;
+  int seg_fresh, seg_last, seg_col_end, seg_step_budget;  // seg_step_budget > 0: the launch also ends for a member after that many trips of its step loop
+  unsigned int* seg_remaining;                             // number of members that are not finished when the launch ends (one atomic per wavefront)
 };
+constexpr int kSegDbl = 128, kSegInt = 32;  // slots per member (upper bounds for n <= 4)
 
 // `if (c) body` that STAYS a branch.  In wavefront lock-step groups the BDF order is wavefront-uniform (a scalar register), and the loops over the
 // difference columns test it per column: the compiler turns such tiny guarded blocks into selects (v_cndmask on every 32-bit half: 56 % of the
@@ -32,7 +42,7 @@ __device__ __forceinline__ void guarded(bool c, F&& f) {
 #ifndef DSH_ADAPTIVE_WAVES_PER_EU
 #define DSH_ADAPTIVE_WAVES_PER_EU 2
 #endif
-template <class Mdl, bool BA, bool WAVE>
+template <class Mdl, bool BA, bool WAVE, bool SEG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE_WAVES_PER_EU, DSH_ADAPTIVE_WAVES_PER_EU))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
@@ -43,7 +53,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
   const AdaptiveConsts& C = *Cp;
   const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
-  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
+  int64_t b_ = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
+  if constexpr (SEG) { if (C.seg_lane_member != nullptr) b_ = C.seg_lane_member[b_]; }  // segmented runs: the member this lane works for in this launch
+  const int64_t b = b_;
+  const bool fresh = !SEG || C.seg_fresh != 0;  // not a resumed launch
   const dsh_adaptive_options& o = C.r.o;
   const bool det = o.deterministic_pow != 0;
   const double rtol = C.r.rtol;
@@ -53,13 +66,18 @@ DSH_UNROLL_N
   for (int i = 0; i < N; ++i) atol[i] = BA ? atol_g[i] : atol_g[(int64_t)i * nb + b];
 
   // ------------------------------------------------------------ OdeSolverState::new_and_consistent (state.rs:969-997, :1086-1124)
-  double t = C.r.t0, h;
+  double t = C.r.t0, h = 0.0;
   double y[N], f0[N];
-  Mdl::init(t, p, y);
-  Mdl::rhs(t, y, p, f0);
   int32_t status = kRsOk;
-  if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, f0, atol, rtol, C.r))) status = kRsInitialConditionDidNotConverge;
-  h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1, det);
+  if (fresh) {
+    Mdl::init(t, p, y);
+    Mdl::rhs(t, y, p, f0);
+    if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, f0, atol, rtol, C.r))) status = kRsInitialConditionDidNotConverge;
+    h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, f0, p, atol, rtol, 1, det);
+  } else {
+DSH_UNROLL_N
+    for (int i = 0; i < N; ++i) { y[i] = 0.0; f0[i] = 0.0; }
+  }
 
   // ------------------------------------------------------------ Bdf::_new (bdf.rs:244-368) + BdfState::initialise_diff_to_first_order
   int order = 1;
@@ -127,12 +145,14 @@ DSH_UNROLL_N
     lu_factor_reg<N>(A, P, sing);
     }
   };
-  reset_jacobian(y, t);
-  n_setups = 1;
+  if (fresh) {
+    reset_jacobian(y, t);
+    n_setups = 1;
+  }
   // RootFinder::init (root.rs:44-49)
   double g0[NR] = {0.0};
   double rf_t0 = t;
-  if constexpr (Mdl::NROOTS > 0) Mdl::root(t, y, p, g0);
+  if constexpr (Mdl::NROOTS > 0) { if (fresh) Mdl::root(t, y, p, g0); }
   double t_root = 0.0;
   int root_idx = -1;
   // JacobianUpdate (jacobian_update.rs:12-36)
@@ -325,7 +345,7 @@ DSH_UNROLL_N
   int col = 0;
   double te_next = t_eval[0];  // t_eval[col], kept in a register: it is compared after every step
   // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
-  {
+  if (fresh) {
     const int r = handle_tstop();
     if (r == 1) status = kRsStopTimeAtCurrentTime;
     else if (r == 2) status = kRsStopTimeBeforeCurrentTime;
@@ -333,6 +353,38 @@ DSH_UNROLL_N
 
   long guard = 0;
   bool done = status != kRsOk || (!WAVE && !active);  // wavefront lock-step: shadow lanes run along (their reductions must not be masked off)
+  // ---- segmented runs: the whole per-member state, enumerated ONCE for both directions
+  auto seg_xfer = [&](auto&& fd, auto&& fi) __attribute__((always_inline)) {
+    int kd = 0, ki = 0;
+    auto d_ = [&](double& v) __attribute__((always_inline)) { fd(kd++, v); };
+    auto i_ = [&](int& v) __attribute__((always_inline)) { fi(ki++, v); };
+    d_(t); d_(h); d_(opc); d_(h_at_last_jac); d_(eta); d_(prev_err); d_(te_next); d_(rf_t0); d_(t_root); d_(t_predict);
+#pragma unroll
+    for (int j = 0; j < kNC; ++j)
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) { d_(D[j][i]); double v = dt_get(j, i); d_(v); dt_set(j, i, v); }
+    if constexpr (!BANDED) {
+#pragma unroll
+      for (int e = 0; e < N * N; ++e) { double v = sJ[e][ln]; d_(v); sJ[e][ln] = v; d_(A[e]); }
+    }
+DSH_UNROLL_N
+    for (int i = 0; i < N; ++i) { d_(y[i]); i_(P[i]); }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) d_(g0[r]);
+    int js = jac_stale ? 1 : 0, hp = has_prev_err ? 1 : 0, ht = has_tstop ? 1 : 0, dn = done ? 1 : 0, glo = (int)(guard & 0x7fffffff), ghi = (int)(guard >> 31), st = (int)status;
+    i_(order); i_(js); i_(n_setups); i_(n_steps); i_(n_err_fails); i_(n_newton); i_(n_nl_fails); i_(steps_since_jac); i_(steps_since_rhs_jac); i_(n_equal_steps);
+    i_(hp); i_(col); i_(root_idx); i_(st); i_(ht); i_(dn); i_(glo); i_(ghi);
+    jac_stale = js != 0; has_prev_err = hp != 0; has_tstop = ht != 0; done = dn != 0; guard = ((long)ghi << 31) | (long)glo; status = (int32_t)st;
+  };
+  if constexpr (SEG) {
+    static_assert(!WAVE && !BANDED, "segmented runs: per-member control of the register-resident models");
+    static_assert(10 + 2 * kNC * N + 2 * N * N + N + NR <= kSegDbl && N + 18 <= kSegInt, "segment state does not fit its slots");
+    if (!fresh && active) {
+      seg_xfer([&](int k, double& v) __attribute__((always_inline)) { v = C.seg_dbl[(int64_t)k * nb + b]; },
+               [&](int k, int& v) __attribute__((always_inline)) { v = C.seg_int[(int64_t)k * nb + b]; });
+    }
+  }
+  int seg_trips = 0;
   while (!done) {
     if (++guard > o.max_steps) { status = kRsMaxStepsExceeded; break; }
     // ================================================================ Bdf::step (bdf.rs:1277-1589)
@@ -617,6 +669,26 @@ DSH_UNROLL_N
       done = true;
     }
     if (reason == 1) done = true;
+    if constexpr (SEG) {  // this launch's share of the save points (or of the steps) is out: the next launch goes on from here
+      if (!C.seg_last && (col >= C.seg_col_end || (C.seg_step_budget > 0 && ++seg_trips >= C.seg_step_budget))) break;
+    }
+  }
+  if constexpr (SEG) {
+    if (status != kRsOk) done = true;
+    if (active) {
+      seg_xfer([&](int k, double& v) __attribute__((always_inline)) { C.seg_dbl[(int64_t)k * nb + b] = v; },
+               [&](int k, int& v) __attribute__((always_inline)) { C.seg_int[(int64_t)k * nb + b] = v; });
+      // members that go on together should look alike: same order, same distance to the next order selection, neighbouring step sizes
+      const int ne = n_equal_steps < 15 ? n_equal_steps : 15;
+      C.seg_key[b] = done ? ~0ull : (((unsigned long long)order << 60) | ((unsigned long long)ne << 56) | ((unsigned long long)__double_as_longlong(fabs(h)) >> 8));
+    }
+    if (!C.seg_last) {
+      if (C.seg_remaining != nullptr) {
+        const int left = __popcll(__ballot(active && !done));
+        if ((threadIdx.x & 63) == 0 && left) atomicAdd(C.seg_remaining, (unsigned int)left);
+      }
+      return;
+    }
   }
   // @phase epilogue
   if (active) {

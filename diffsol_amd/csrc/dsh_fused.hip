@@ -180,6 +180,28 @@ static int sdirk_newton_staged(dsh_ctx* ctx, int model, int64_t size, int64_t nb
   return DSH_OK;
 }
 
+// x <- A^-1 x with the factors of `lu`, then max_b mean_i (x_i / (|y_i| rtol + atol_i))^2: the error estimate of the SDIRK step (sdirk.rs:474-495 filtered
+// through the Newton matrix, runge_kutta.rs:783-800) as two launches and ONE wait for both results.  DSH_E_SINGULAR like dsh_lu_solve.
+int dsh_lu_solve_squared_norm(const dsh_lu* lu, double* x, const double* y, int64_t ynb, const double* atol, int64_t anb, double rtol, double* out_norm) {
+  DSH_REQUIRE(lu != nullptr && x != nullptr && out_norm != nullptr, "null argument");
+  dsh_ctx* ctx = lu->ctx;
+  if (!lu->factored) { set_error("dsh_lu_solve_squared_norm: LU not initialised"); return DSH_E_NOT_SETUP; }
+  const int64_t n = lu->n, nb = lu->nbatch;
+  if (n == 0) { *out_norm = 0.0; return DSH_OK; }
+  unsigned int gs = 0, ss = 0;
+  int rc = lu_solve_launch(lu, x, &gs, &ss);
+  if (rc != DSH_OK) return rc;
+  rc = dsh_vec_squared_norm(ctx, n, nb, x, y, ynb, atol, anb, rtol, out_norm, nullptr);  // waits for its own records: the solve's are there by then
+  if (rc != DSH_OK) return rc;
+  rc = fetch_records(ctx, gs, ss);
+  if (rc != DSH_OK) return rc;
+  if (ctx->res_cnt != 0ull) {
+    set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+    return DSH_E_SINGULAR;
+  }
+  return DSH_OK;
+}
+
 int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, const double* k_in, double* k_out,
                           const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
                           double* out) {

@@ -482,6 +482,15 @@ class HipLU {
     check(rc, "HipLU::solve_in_place");
     return true;
   }
+  // solve_in_place(x) and x.squared_norm(y, atol, rtol) with one wait for both results; false on LuSolveFailed
+  bool solve_in_place_and_norm(HipVec& x, const HipVec& y, const HipVec& atol, double rtol, double* norm) const {
+    if (!lu_ || !factored_) throw LaError(DSH_E_NOT_SETUP, "LuNotInitialized");
+    if (x.len() != matrix_.nrows()) throw LaError(DSH_E_INVALID, "LinearSolverMatrixVectorNotCompatible");
+    int rc = dsh_lu_solve_squared_norm(lu_.get(), x.ptr(), y.ptr(), y.nb(), atol.ptr(), atol.nb(), rtol, norm);
+    if (rc == DSH_E_SINGULAR) return false;
+    check(rc, "HipLU::solve_in_place_and_norm");
+    return true;
+  }
   dsh_lu* raw() const { return lu_.get(); }
   bool is_setup() const { return (bool)lu_; }
   void mark_factored() { factored_ = true; }

@@ -269,8 +269,11 @@ class Sdirk : public OdeSolverMethod {
         error_tmp_.copy_from(error_);
         op_.current_mass().gemv(1.0, error_tmp_, 0.0, error_);
       }
-      if (!nonlinear_solver_.solve_linearised_in_place(error_)) throw DSH_ODE_ERR(LinearSolveFailed);
-      error_norm = std::fmax(0.0, error_.squared_norm(state_.y, pr_.atol, pr_.rtol));
+      {
+        double en = 0.0;  // the solve and the norm with one wait (dsh_lu_solve_squared_norm)
+        if (!nonlinear_solver_.linear_solver().solve_in_place_and_norm(error_, state_.y, pr_.atol, pr_.rtol, &en)) throw DSH_ODE_ERR(LinearSolveFailed);
+        error_norm = std::fmax(0.0, en);
+      }
       if (pr_.sens && pr_.sens_error_control)  // runge_kutta.rs:812-822 — no linear solve on the sensitivity error estimates
         for (size_t j = 0; j < sdiff_.size(); ++j) {
           sdiff_[j].gemv(1.0, d_vec_, 0.0, sens_error_);

@@ -185,6 +185,9 @@ void dsh_lu_destroy(dsh_lu* lu);
 int dsh_lu_factor(dsh_lu* lu, const double* a);
 /* solve_in_place, nrhs = 1, all systems in ONE launch (replaces the getrs host loop, lu.rs:127-145) */
 int dsh_lu_solve(const dsh_lu* lu, double* b);
+/* dsh_lu_solve(lu, x) followed by dsh_vec_squared_norm(x, y, atol, rtol) with ONE wait for both results (the zero-pivot count and the norm): the error
+ * estimate of an SDIRK step (sdirk.rs:474-495, runge_kutta.rs:783-800).  Same kernels, same bits; DSH_E_SINGULAR like dsh_lu_solve. */
+int dsh_lu_solve_squared_norm(const dsh_lu* lu, double* x, const double* y, int64_t y_nb, const double* atol, int64_t atol_nb, double rtol, double* out_norm);
 /* nrhs right-hand sides per system with the same factors (the linear algebra of forward sensitivities: Bdf::sensitivity_solve, bdf.rs:934-989, solves one
  * system per parameter with the LU of the state equations): b is an n x nrhs matrix in the library's layout, column r at b + r*n*nbatch.  For n <= 8 one launch
  * loads the factors once for all columns; every column's solution equals dsh_lu_solve's bit for bit. */

@@ -10,10 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+member = len(sys.argv) > 3 and sys.argv[3] == "member"  # the per-member kernel (MODE=member bash scripts/profile_r03.sh <tag>) -> profiles/<round>_pmc_per_member.json
 sys.path.insert(0, ROOT)
 from bench import kernel_source_hash
 d = json.load(open(os.path.join(ROOT, "gpurun_out", rnd, f"pmc_resident_{tag}.json")))
-name, k = next((n, v) for n, v in d["kernels"].items() if "k_bdf_adaptive" in n and "true, true" in n)
+name, k = next((n, v) for n, v in d["kernels"].items() if "k_bdf_adaptive" in n and ("true, false" if member else "true, true") in n)
 tr = [r for r in d.get("kernel_trace", []) if "k_bdf_adaptive" in r["name"]]
 out = {
     "_note": "rocprofv3 --kernel-trace --pmc <counters> -- python scripts/bench_kernel_once.py 100000 3  (scripts/profile_r03.sh; one MI355X; separate passes: "
@@ -33,6 +34,12 @@ out = {
     },
     "raw": k,
 }
+if member:
+    out["_note"] = out["_note"].replace("bench_kernel_once.py 100000 3 ", "bench_kernel_once.py 100000 3 member ").replace(
+        "wavefront lock-step groups of 64", "PER-MEMBER control (every member its own step sizes and orders; members in the library's launch-time Morton order) — bench.py's `per_member` extra")
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_per_member.json"), "w"), indent=1)
+    print(json.dumps(out["bench_kernel"], indent=1))
+    sys.exit(0)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_resident.json"), "w"), indent=1)
 with open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 2   (1 x MI355X)\n\n"

@@ -178,5 +178,15 @@ if __name__ == "__main__":
         out.append(run_spm(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "heat"):
         out.append(run_heat(a.heat_nb, a.heat_n)); print(json.dumps(out[-1]), flush=True)
+    if a.only in ("", "heat", "heat_dense"):
+        # BASELINE configs[2] says "banded-as-dense LU": the same run with the structure detection off — dense containers, the library's default dense LU for
+        # n = 512 (the matrix-core kernel of dsh_lu_tiled.hpp; DSH_LU_EXACT=1 selects the bit-exact blocked kernel instead)
+        os.environ["DSH_LU_STRUCTURE"] = "dense"
+        try:
+            r = run_heat(a.heat_nb, a.heat_n)
+            r["config"] = "C3 heat1d, DSH_LU_STRUCTURE=dense (%s dense LU)" % ("bit-exact blocked" if os.environ.get("DSH_LU_EXACT") == "1" else "matrix-core")
+            out.append(r); print(json.dumps(out[-1]), flush=True)
+        finally:
+            os.environ.pop("DSH_LU_STRUCTURE", None)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
