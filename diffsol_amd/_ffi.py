@@ -144,6 +144,8 @@ DEVICE_ABI = {
     "dsh_sdirk_solve_wave_member": (cint, [vp, cint, i64, cint, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_model_has_resident": (cint, [cint, cint, i64]),
     "dsh_sdirk_solve_resident": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
+    "dsh_model_has_adaptive_sens": (cint, [cint, i64]),
+    "dsh_bdf_solve_adaptive_sens": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
     "dsh_bdf_accept_newton_async": (cint, [vp, cint, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, dbl, dbl, cint, vp, vp, vp, c_i64p, c_i64p]),
@@ -196,6 +198,7 @@ HOST_ABI = {
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
     "dshs_diffsl_generate": (cint, [C.c_char_p, cint, C.POINTER(vp), c_i64p, c_dp, i64]),
     "dshs_free_string": (None, [vp]),
+    "dshs_solve_dense_adaptive_sens": (cint, [vp, c_dp, i64, cint, cint, c_dp, c_dp, c_i32p, c_i32p, c_i64p]),
     "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
 }
 

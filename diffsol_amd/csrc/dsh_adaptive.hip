@@ -89,9 +89,47 @@ int dsh_model_has_adaptive(int model, int64_t size) {
   return ok ? 1 : 0;
 }
 
+}  // extern "C"
+namespace {
+struct SensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };  // forward sensitivities of dsh_bdf_solve_adaptive_sens
+// does the static model have a device-resident BDF with forward sensitivities?  (sens_mul / init_sens_mul, identity mass, no root functions, n <= 4)
+template <class Mdl> constexpr bool adaptive_sens_ok() {
+  if constexpr (model_has_sens<Mdl>::value) return Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS == 0 && model_band_k<Mdl>::value == 0;
+  else return false;
+}
+int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
+                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens);
+}  // namespace
+extern "C" {
+int dsh_model_has_adaptive_sens(int model, int64_t size) {
+  if (is_jit_model(model)) return 0;
+  bool ok = false;
+  dispatch_static_model(model, size, [&](auto mdl) { ok = adaptive_sens_ok<decltype(mdl)>(); });
+  return ok ? 1 : 0;
+}
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  return bdf_solve_adaptive_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
+}
+int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
+                                int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
+  DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
+  if (!dsh_model_has_adaptive_sens(model, size)) {
+    set_error("dsh_bdf_solve_adaptive_sens: the model has no device-resident BDF with forward sensitivities (static ODE model with parameter derivatives, n <= 4, no root functions)");
+    return DSH_E_UNSUPPORTED;
+  }
+  const SensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
+  return bdf_solve_adaptive_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, nullptr, nullptr, nullptr, totals_host, &sp);
+}
+}  // extern "C"
+namespace {
+int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
+                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
@@ -100,11 +138,19 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   if (!dsh_model_has_adaptive(model, size)) { set_error("dsh_bdf_solve_adaptive: model has no device-resident kernel (needs a static model, n <= 4)"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   AdaptiveConsts C;
+  std::memset((void*)&C, 0, sizeof C);  // the block is compared byte-wise with the cached copy below
   C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
   if (C.r.o.max_steps <= 0) C.r.o.max_steps = 10000000;
   DSH_REQUIRE(C.r.o.group == 1 || C.r.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
+  if (sens) {
+    C.sens_out = sens->out; C.sens_rtol = sens->rtol; C.sens_error_control = sens->natol > 0 ? 1 : 0;
+    int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;
+    if (dsh_model_info(model, size, &ns, &npar_, &hm_, &nroots_) != DSH_OK) return DSH_E_INVALID;
+    DSH_REQUIRE(sens->natol == 0 || sens->natol == 1 || sens->natol == ns, "sens_atol must have length 1 or nstates");
+    for (int64_t i = 0; i < 4 && i < ns; ++i) C.sens_atol[i] = sens->natol == 0 ? 0.0 : (sens->natol == 1 ? sens->atol_host[0] : sens->atol_host[i]);
+  }
   {  // Bdf::_new tables (bdf.rs:286-306)
     const double kappa[6] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0};
     C.alpha[0] = 0.0; C.gamma[0] = 0.0; C.ec2[0] = 1.0;
@@ -184,7 +230,7 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   // DSH_REBIN_STEPS=k: a segment ends for a member after k trips of its step loop instead (all wavefronts of a segment then do the same number of trips: no
   // waiting for the slowest member of a segment); the host launches segments until no member is left, then one launch that only writes the results.
   const int rebin_steps = [] { const char* e = std::getenv("DSH_REBIN_STEPS"); return e && *e ? std::atoi(e) : 0; }();
-  if ((rebin_steps > 0 || (rebin > 0 && n_eval > rebin)) && !is_jit_model(model) && C.r.o.group == 1 && nb >= 128) {
+  if (!sens && (rebin_steps > 0 || (rebin > 0 && n_eval > rebin)) && !is_jit_model(model) && C.r.o.group == 1 && nb >= 128) {
     double* seg_dbl = nullptr; int* seg_int = nullptr; unsigned long long *keys = nullptr, *keys_out = nullptr; int *idx_iota = nullptr, *lane_member = nullptr; void* cub_tmp = nullptr;
     AdaptiveConsts* seg_consts = nullptr; unsigned int* remaining = nullptr;
     size_t cub_bytes = 0;
@@ -268,6 +314,18 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
     if (rc != DSH_OK) { if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } dsh_free(ctx, totals_dev); return rc; }
     launched = true;
   } else
+  if (sens) {
+    launched = dispatch_static_model(model, size, [&](auto mdl) {
+      using Mdl = decltype(mdl);
+      if constexpr (adaptive_sens_ok<Mdl>()) {
+#define DSH_ADAPTIVE_SENS_LAUNCH(BA, WAVE) \
+  hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE, false, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+        if (C.r.o.group == 64) { if (ba) DSH_ADAPTIVE_SENS_LAUNCH(true, true); else DSH_ADAPTIVE_SENS_LAUNCH(false, true); }
+        else { if (ba) DSH_ADAPTIVE_SENS_LAUNCH(true, false); else DSH_ADAPTIVE_SENS_LAUNCH(false, false); }
+#undef DSH_ADAPTIVE_SENS_LAUNCH
+      }
+    });
+  } else
   launched = dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
     if constexpr (Mdl::N <= 4) {
@@ -294,5 +352,4 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
   if (totals_host) for (int k = 0; k < 6; ++k) totals_host[k] = (int64_t)totals[k];
   return DSH_OK;
 }
-
-}  // extern "C"
+}  // namespace

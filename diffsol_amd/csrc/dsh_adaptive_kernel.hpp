@@ -22,6 +22,12 @@ struct AdaptiveConsts {
   const int* seg_lane_member;
   int seg_fresh, seg_last, seg_col_end, seg_step_budget;  // seg_step_budget > 0: the launch also ends for a member after that many trips of its step loop
   unsigned int* seg_remaining;                             // number of members that are not finished when the launch ends (one atomic per wavefront)
+  // Forward sensitivities (k_bdf_adaptive<.., SENS = true>; problem.bdf_sens(), bdf.rs:370-432, :934-989): s_j = dy/dp_j of every parameter integrated
+  // alongside.  sens_out: n_eval x NP x N x nb (device, batch-fastest); sens_error_control != 0: the sensitivities take part in the error test and in the
+  // order selection with sens_rtol / sens_atol (the same for every parameter and member; builder.rs build_atols), else turn_off_sensitivities_error_control.
+  double* sens_out;
+  double sens_rtol, sens_atol[4];
+  int sens_error_control, sens_pad;
 };
 constexpr int kSegDbl = 128, kSegInt = 32;  // slots per member (upper bounds for n <= 4)
 
@@ -42,7 +48,7 @@ __device__ __forceinline__ void guarded(bool c, F&& f) {
 #ifndef DSH_ADAPTIVE_WAVES_PER_EU
 #define DSH_ADAPTIVE_WAVES_PER_EU 2
 #endif
-template <class Mdl, bool BA, bool WAVE, bool SEG = false>
+template <class Mdl, bool BA, bool WAVE, bool SEG = false, bool SENS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE_WAVES_PER_EU, DSH_ADAPTIVE_WAVES_PER_EU))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
@@ -111,6 +117,39 @@ DSH_UNROLL_N
 DSH_UNROLL_N
   for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = f0[i] * h; }
   double opc = h * sAlpha[1];  // BdfCallable::c
+  // ---- forward sensitivities: new_with_sensitivities_and_consistent (state.rs:1032-1083: s_j = SensInit(t0) e_j, ds_j = SensRhs(s_j) about (y0, t0)),
+  // new_augmented (bdf.rs:384-432): sdiff_j[:, 0] = s_j, sdiff_j[:, 1] = h ds_j.  Per-lane arrays in scratch memory (indexed by the parameter at run time).
+  constexpr int NPS = SENS ? NP : 1, NCS = SENS ? kNC : 1, NS = SENS ? N : 1;
+  static_assert(!SENS || (!Mdl::HAS_MASS && model_band_k<Mdl>::value == 0 && Mdl::NROOTS == 0 && !SEG),
+                "device-resident forward sensitivities: register-resident ODE models without root functions");
+  double S[NPS][NCS][NS];    // sdiff
+  double s_cur[NPS][NS];     // state.s: the latest solution of the sensitivity equations (the scale of the sensitivity error norms)
+  double s_delta[NPS][NS];   // s - s_predict of the last sensitivity_solve
+  double s_c = 0.0;          // BdfCallable::c of the sensitivity operator: 0 until the first _update_step_size (new_no_jacobian, bdf.rs:403; op/bdf.rs:61)
+  double s_atol[NS];
+  if constexpr (SENS) {
+DSH_UNROLL_N
+    for (int i = 0; i < N; ++i) s_atol[i] = C.sens_atol[i];
+    for (int j = 0; j < NP; ++j) {
+      double ev[NP], s0[N], jm[N], dfdp[N];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) ev[k] = k == j ? 1.0 : 0.0;
+      Mdl::init_sens_mul(t, p, ev, s0);
+      Mdl::sens_mul(t, y, p, ev, dfdp);   // SensRhs::update_state(y0, t0): column j of df/dp
+      Mdl::jac_mul(t, y, p, s0, jm);      // SensRhs::call_inplace: J(y0) s_j + (df/dp)_j
+      for (int k = 0; k < kNC; ++k)
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) S[j][k][i] = 0.0;
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) {
+        const double ds = jm[i] + dfdp[i];
+        S[j][0][i] = s0[i];
+        S[j][1][i] = ds * h;
+        s_cur[j][i] = s0[i];
+        s_delta[j][i] = 0.0;
+      }
+    }
+  }
   double A[BANDED ? 1 : N * N];
   int P[N];
   bool jac_stale = true;
@@ -246,6 +285,48 @@ DSH_UNROLL_N
     for (int j = 0; j < kNC; ++j)
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) { const double tmp = D[j][i]; D[j][i] = dt_get(j, i); dt_set(j, i, tmp); }
+    if constexpr (SENS) {
+      // bdf.rs:546-548: every sdiff goes through the SAME scratch matrix as the states' differences — diff_tmp[:, 0..=order] = sdiff_j[:, 0..=order] (R U),
+      // swap(sdiff_j, diff_tmp) — so the columns behind `order` are handed down the chain (states -> s_0 -> s_1 -> ... -> the states at the next change)
+      double RU[6][6];  // RU[j][k] = element (row k, col j); the operations of the code above
+      {
+        double R[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          R[j][0] = 1.0;
+#pragma unroll
+          for (int i = 1; i < 6; ++i) R[j][i] = (j == 0) ? 0.0 : R[j][i - 1] * ((double)i - 1.0 - factor * (double)j) / (double)i;
+        }
+        const double* U = sU + (order - 1) * 36;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            double acc = R[0][k] * U[j * 6 + 0];
+#pragma unroll
+            for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
+            RU[j][k] = acc;
+          }
+      }
+      for (int q = 0; q < NP; ++q) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j <= order) {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              double acc = S[q][0][i] * RU[j][0];
+#pragma unroll
+              for (int k = 1; k < 6; ++k) if (k <= order) acc = S[q][k][i] * RU[j][k] + acc;
+              dt_set(j, i, acc);
+            }
+          }
+#pragma unroll
+        for (int j = 0; j < kNC; ++j)
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) { const double tmp = S[q][j][i]; S[q][j][i] = dt_get(j, i); dt_set(j, i, tmp); }
+      }
+      s_c = new_h * sAlpha[order];  // s_op.set_c (bdf.rs:551-553)
+    }
     opc = new_h * sAlpha[order];
     h = new_h;
     eta = C.r.eta_reset_ts;  // reset_eta_timestep_change
@@ -461,6 +542,77 @@ DSH_UNROLL_N
       }
       // @phase Newton failure handling
       n_newton += niter;
+      if constexpr (SENS) {
+        // sensitivity_solve (bdf.rs:934-989): SensRhs linearised about (y_predict, t_new); per parameter the predictor / psi of its difference array and a
+        // Newton solve of F(s) = (s - s0 + psi) - c_s (J s + (df/dp)_j) with the factors of the state equations and the SHARED Convergence (eta carries over,
+        // state tolerances); a failure is a failure of the step's nonlinear solve (SensitivitySolveFailed, :1355-1360)
+        if (solved) {
+          for (int j = 0; j < NP && solved; ++j) {
+            double ev[NP], dfdp[N], sp[N], spsi[N], xs[N];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) ev[k] = k == j ? 1.0 : 0.0;
+            Mdl::sens_mul(t_predict, yp, p, ev, dfdp);
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              double sacc = 0.0;
+#pragma unroll
+              for (int k = 0; k < 6; ++k) if (k <= order) sacc = sacc + S[j][k][i];
+              double q = sGamma[1] * S[j][1][i];
+#pragma unroll
+              for (int k = 2; k < 6; ++k) if (k <= order) q = sGamma[k] * S[j][k][i] + 1.0 * q;
+              q = q * sAlpha[order];
+              q = q - sacc;
+              sp[i] = sacc; spsi[i] = q; xs[i] = sacc;
+            }
+            int sn = 0;
+            bool s_has_old = false, s_solved = false;
+            double s_old_norm = 0.0;
+            for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
+              double jm[N], delta[N];
+              Mdl::jac_mul(t_predict, yp, p, xs, jm);
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) {
+                const double fr = jm[i] + dfdp[i];
+                delta[i] = 1.0 * (xs[i] + spsi[i]) + (-s_c) * fr;
+              }
+              const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
+              if (!lu_ok) break;
+              double acc = 0.0;
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) {
+                const double d = delta[i];
+                xs[i] = xs[i] - d;
+                const double term = d / (fabs(sp[i]) * rtol + atol[i]);
+                acc += term * term;
+              }
+              const double norm = sqrt(group_norm<WAVE>(acc / (double)N));
+              sn += 1;
+              bool diverged = false;
+              if (s_has_old) {
+                const double rate = sn == 2 ? norm / s_old_norm : rpow(norm / s_old_norm, 1.0 / (double)(sn - 1), det);
+                if (rate > 0.9) diverged = true;
+                else if (powi_rt(rate, o.max_nonlinear_solver_iterations - sn) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
+                else eta = rate / (1.0 - rate);
+              } else {
+                const double min_eta = 1e4 * 2.220446049250313e-16;
+                if (eta < min_eta) eta = min_eta;
+                if (det && eta == C.r.eta_reset) eta = C.eta_reset_p08;
+                else if (det && eta == C.r.eta_reset_ts) eta = C.eta_reset_ts_p08;
+                else eta = rpow(eta, 0.8, det);
+              }
+              const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
+              if (sn == 1) { s_has_old = true; s_old_norm = norm; }
+              if (diverged) break;
+              if (converged) { s_solved = true; break; }
+            }
+            niter = sn;  // Convergence::niter is the last solve's: the safety factor below reads it
+            if (!s_solved) { solved = false; break; }  // `?` before the iteration count is added
+            n_newton += sn;
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) { s_cur[j][i] = xs[i]; s_delta[j][i] = xs[i] - sp[i]; }
+          }
+        }
+      }
       if (!solved) {
         n_nl_fails += 1;
         if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kRsTooManyNonlinearSolverFailures; break; }
@@ -482,6 +634,10 @@ DSH_UNROLL_N
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
       // error_control (bdf.rs:812-843): norm against the CURRENT state y
       error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * sEc2[order - 1]);
+      if constexpr (SENS) {
+        if (C.sens_error_control)  // bdf.rs:844-858 — error_const2[order], not [order - 1]
+          for (int j = 0; j < NP; ++j) error_norm = fmax(error_norm, group_norm<WAVE>(wms<N>(s_delta[j], s_cur[j], s_atol, C.sens_rtol)) * sEc2[order]);
+      }
       const double maxiter = (double)o.max_nonlinear_solver_iterations;
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
@@ -534,6 +690,22 @@ DSH_UNROLL_N
           y[i] = yp[i];
         }
         }
+        if constexpr (SENS) {  // update_differences_and_integrate_out (bdf.rs:628-643): _update_diff on every sensitivity difference array
+          for (int q = 0; q < NP; ++q)
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              const double sd = s_delta[q][i];
+              double dk1 = 0.0;
+#pragma unroll
+              for (int j = 2; j < 7; ++j) if (j == order + 1) dk1 = S[q][j][i];
+              const double dk2 = sd - dk1;
+#pragma unroll
+              for (int j = 2; j < kNC; ++j) { if (j == order + 2) S[q][j][i] = dk2; if (j == order + 1) S[q][j][i] = sd; }
+              double upper = sd;
+#pragma unroll
+              for (int j = 5; j >= 0; --j) if (j <= order) { const double v = S[q][j][i] + 1.0 * upper; S[q][j][i] = v; upper = v; }
+            }
+        }
         t = t_predict;
         break;
       }
@@ -582,8 +754,25 @@ DSH_UNROLL_N
       }
       }
       const double inf = __builtin_huge_val();
-      const double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * sEc2[order - 1] : inf;
-      const double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * sEc2[order + 1] : inf;
+      double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * sEc2[order - 1] : inf;
+      double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * sEc2[order + 1] : inf;
+      if constexpr (SENS) {  // predict_error_control with the augmented system (bdf.rs:871-932): the `error_norm.max(err)` chain from zero, then the sensitivities' terms
+        if (order > 1) error_m_norm = fmax(0.0, error_m_norm);
+        if (order < kMaxOrder) error_p_norm = fmax(0.0, error_p_norm);
+        if (C.sens_error_control)
+          for (int q = 0; q < NP; ++q) {
+            double cm[N], cp[N];
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              double vm = 0.0, vp = 0.0;
+#pragma unroll
+              for (int j = 1; j < kNC; ++j) { if (j == order) vm = S[q][j][i]; if (j == order + 2) vp = S[q][j][i]; }
+              cm[i] = vm; cp[i] = vp;
+            }
+            if (order > 1) error_m_norm = fmax(error_m_norm, group_norm<WAVE>(wms<N>(cm, s_cur[q], s_atol, C.sens_rtol)) * sEc2[order - 1]);
+            if (order < kMaxOrder) error_p_norm = fmax(error_p_norm, group_norm<WAVE>(wms<N>(cp, s_cur[q], s_atol, C.sens_rtol)) * sEc2[order + 1]);
+          }
+      }
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
       double f0c, f1c, f2c;
       if constexpr (WAVE) {
@@ -655,6 +844,25 @@ DSH_UNROLL_N
       interpolate(te_next, yv);
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+      if constexpr (SENS) {  // interpolate_sens (bdf.rs:1162-1215): the same polynomial on every sensitivity difference array
+        for (int q = 0; q < NP; ++q) {
+          double sv[N];
+          double time_factor = 1.0;
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) sv[i] = S[q][0][i];
+#pragma unroll
+          for (int j = 0; j < kMaxOrder; ++j) {
+            if (j < order) {
+              const double jt = (double)j;
+              time_factor *= (te_next - (t - h * jt)) / (h * (1.0 + jt));
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) sv[i] = time_factor * S[q][j + 1][i] + 1.0 * sv[i];
+            }
+          }
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) if (active) C.sens_out[(((int64_t)col * NP + q) * N + i) * nb + b] = sv[i];
+        }
+      }
       col++;
       if (col < C.r.n_eval) te_next = t_eval[col];
     }
@@ -696,9 +904,14 @@ DSH_UNROLL_N
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
     // columns that were never reached (root stop or error exit): NaN
-    for (; col < C.r.n_eval; ++col)
+    for (; col < C.r.n_eval; ++col) {
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
+      if constexpr (SENS)
+        for (int q = 0; q < NP; ++q)
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) C.sens_out[(((int64_t)col * NP + q) * N + i) * nb + b] = __builtin_nan("");
+    }
     if (status_out != nullptr) status_out[b] = status;
     if (stats_out != nullptr) {
       stats_out[0 * nb + b] = n_steps;

@@ -103,7 +103,14 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
   ResidentPick r;
   r.method = s->method == DSHS_METHOD_BDF ? 0 : (s->method == DSHS_METHOD_TR_BDF2 ? 1 : 2);
   if (group != 1 && group != 64) return r;
-  if (s->problem.sens) return r;  // the device-resident kernels integrate the state equations only: sensitivities run host-driven
+  if (s->problem.sens) {
+    // forward sensitivities: the register-resident BDF integrates them alongside (k_bdf_adaptive<.., SENS>; static ODE models, n <= 4, no root functions) on an
+    // explicit request (dshs_solve_dense_adaptive_sens); dshs_solve_dense keeps the host-driven path, whose solver state dshs_interpolate_sens reads
+    int m = 0; int64_t sz = 0;
+    if (for_auto || r.method != 0 || s->problem.eqn->has_reset() || !s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_sens(m, sz)) return r;
+    r.ok = true; r.model = m; r.size = sz;
+    return r;
+  }
   if (s->problem.eqn->has_reset()) return r;  // hybrid models: the resident kernels stop at an event; the host-driven solve_dense applies the reset and continues
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it
   const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
@@ -212,8 +219,11 @@ bool prepare_member_order(dshs_solver* s) {
 // lazy: status_host is fetched only when a member failed (totals[5] != 0; it is all zero otherwise) and root_idx_host only for models with root
 // functions (all -1 otherwise): the common case of dshs_solve_dense then moves no per-member bookkeeping over PCIe at all.
 void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
-                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals, bool lazy = false) {
+                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals, bool lazy = false, double* sens_host = nullptr) {
   const ResidentPick pk = pick_resident(s, group);
+  if (s->problem.sens && (!pk.ok || !sens_host))
+    throw LaError(DSH_E_UNSUPPORTED, "device-resident integration with forward sensitivities: dshs_solve_dense_adaptive_sens, BDF, static ODE models with parameter "
+                                     "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
   if (!pk.ok)
     throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
                                      "run-time-sized ODE models with n <= 64: BDF)");
@@ -266,6 +276,21 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
   if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
   int rc;
+  void *sens_dev = nullptr, *sens_sorted = nullptr;
+  const int64_t npar = s->problem.eqn->nparams();
+  if (s->problem.sens) {
+    check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_dev), "adaptive sens out");
+    if (sorted) check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_sorted), "adaptive sens out (sorted)");
+    const std::vector<double> sa = s->problem.sens_error_control ? s->problem.sens_atol.clone_as_vec() : std::vector<double>();
+    rc = dsh_bdf_solve_adaptive_sens(c, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
+                                     s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
+                                     (int32_t*)status_dev, totals);
+    if (rc == DSH_OK && sorted) rc = dsh_permute_members(c, nt * npar * n, nb, 8, sens_sorted, (const int32_t*)s->inv_dev, sens_dev);
+    // [col][parameter][state][b] on the device -> [parameter][col][b][state] on the host (one y-shaped array per parameter: solve_dense_sensitivities' Vec<M>)
+    for (int64_t k = 0; k < nt && rc == DSH_OK; ++k)
+      for (int64_t q = 0; q < npar && rc == DSH_OK; ++q)
+        rc = dsh_vec_download(c, n, nb, (const double*)sens_dev + (size_t)((k * npar + q) * n * nb), sens_host + (size_t)((q * nt + k) * n * nb));
+  } else
   if (wave_member && method != 0)
     rc = dsh_sdirk_solve_wave_member(c, model, size, method, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
                                      t_eval, nt, out, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev, (int32_t*)ncols_dev, totals);
@@ -300,7 +325,7 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
   if (rc == DSH_OK && root_idx_host) { if (want_ridx) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb); else std::fill(root_idx_host, root_idx_host + nb, -1); }
   if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
-  for (void* q : {tmp_out, sorted_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev}) if (q) dsh_free(c, q);
+  for (void* q : {tmp_out, sorted_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev, sens_dev, sens_sorted}) if (q) dsh_free(c, q);
   check(rc, "solve_dense_adaptive");
 }
 }  // namespace
@@ -624,6 +649,19 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
   return guarded([&]() {
     int64_t tot[6];
     run_resident(s, t_eval, nt, group, deterministic_pow, y_host, y_dev, stats_host, status_host, t_root_host, root_idx_host, ncols_host, tot);
+    for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
+    s->last_mode = group;
+    return 0;
+  });
+}
+
+int dshs_solve_dense_adaptive_sens(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* sens_host,
+                                   int32_t* stats_host, int32_t* status_host, int64_t* totals) {
+  return guarded([&]() {
+    if (!s->problem.sens) throw LaError(DSH_E_INVALID, "the solver was not created with forward sensitivities (dshs_create_sens)");
+    if (!sens_host) throw LaError(DSH_E_INVALID, "dshs_solve_dense_adaptive_sens: sens_host is null");
+    int64_t tot[6];
+    run_resident(s, t_eval, nt, group, deterministic_pow, y_host, nullptr, stats_host, status_host, nullptr, nullptr, nullptr, tot, false, sens_host);
     for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
     s->last_mode = group;
     return 0;

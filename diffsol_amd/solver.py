@@ -207,6 +207,23 @@ class Solver:
         tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))
         return (out, tot, m) if want_member_stats else (out, tot)
 
+    def solve_dense_adaptive_sens(self, t_eval, group=1, deterministic_pow=True, want_member_stats=False):
+        """solve_dense_sensitivities (sensitivities.rs:114-260) on the device-resident BDF with forward sensitivities (dshs_solve_dense_adaptive_sens): states AND
+        the sensitivities of every parameter at t_eval from one launch; the solver must have been created with sens=True.
+        Returns (y [nt, nbatch, n], sens [nparams, nt, nbatch, n], totals dict[, member dict(stats [5, nbatch], status)])."""
+        te = np.ascontiguousarray(t_eval, dtype=np.float64)
+        npar = int(self._L.dshs_nparams(self._h))
+        out = np.empty((te.size, self.nbatch, self.n))
+        sens = np.empty((npar, te.size, self.nbatch, self.n))
+        totals = (C.c_int64 * 6)()
+        m = dict(stats=np.empty((5, self.nbatch), dtype=np.int32), status=np.empty(self.nbatch, dtype=np.int32)) if want_member_stats else None
+        i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
+        check(self._L.dshs_solve_dense_adaptive_sens(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), 1 if deterministic_pow else 0,
+                                                     out.ctypes.data_as(_ffi.c_dp), sens.ctypes.data_as(_ffi.c_dp), i32(m["stats"]) if m else None,
+                                                     i32(m["status"]) if m else None, totals), host=True)
+        tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))
+        return (out, sens, tot, m) if want_member_stats else (out, sens, tot)
+
 
 class OdeBuilder:
     """OdeBuilder (crates/diffsol/src/ode_solver/builder.rs:22-146): fluent problem description; `.bdf()` etc. create the solver."""

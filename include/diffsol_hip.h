@@ -395,6 +395,19 @@ int dsh_model_has_adaptive(int model, int64_t size);
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                            int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
+/* The same with FORWARD SENSITIVITIES (problem.bdf_sens(), problem.rs:819-832; Bdf::new_augmented bdf.rs:370-432, sensitivity_solve :934-989, the sensitivity
+ * terms of error_control :844-858 and predict_error_control :871-932, interpolate_sens :1162-1215, solve_dense_sensitivities sensitivities.rs:114-260):
+ * s_j = dy/dp_j of every parameter integrated alongside, in the same launch — per step and parameter one Newton solve with the factors of the state equations
+ * and the shared Convergence, the sensitivity difference arrays rescaled and updated with the states'.  Static ODE models with parameter derivatives, n <= 4,
+ * identity mass, no root functions (dsh_model_has_adaptive_sens).  nsens_atol = 0: turn_off_sensitivities_error_control; else sens_rtol / sens_atol_host
+ * (length 1 or n, the same for every parameter and member) put the sensitivities into the error test and the order selection.
+ * sens_out: n_eval x np x n x nb (device, batch-fastest per save point and parameter).  Results are bit-identical to the oracle's per-member
+ * (group = 1) resp. 64-member lock-step (group = 64) solves with sensitivities in the deterministic-pow mode. */
+int dsh_model_has_adaptive_sens(int model, int64_t size);
+int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
+                                const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status,
+                                int64_t* totals_host);
 /* Device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): Sdirk::step (ode_solver/sdirk.rs:409-543) + Rk core (runge_kutta.rs) + consistent DAE initialisation
  * (state.rs:84-162) + RootFinder (nonlinear_solver/root.rs) + solve_dense (method.rs:467-520) per member, one launch per ensemble solve.  Static models with
  * n <= 4, mass matrices and root functions included, and the banded lane-per-member form as above (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds

@@ -141,6 +141,13 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
                               double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals);
 
+/* dshs_solve_dense_adaptive for a solver created with forward sensitivities (dshs_create_sens): states and sensitivities at t_eval from ONE launch
+ * (dsh_bdf_solve_adaptive_sens; BDF, static ODE models with parameter derivatives, n <= 4, no root functions — DSH_E_UNSUPPORTED otherwise: such problems
+ * integrate their sensitivities host-driven, dshs_solve_dense + dshs_interpolate_sens).  The reference's solve_dense_sensitivities (sensitivities.rs:114-260)
+ * per member (group = 1) or per 64-member lock-step group (group = 64).  y_host: [nt][b][state] or NULL; sens_host: [nparams][nt][b][state]. */
+int dshs_solve_dense_adaptive_sens(dshs_solver* s, const double* t_eval, int64_t nt, int group /* 1 | 64 */, int deterministic_pow, double* y_host,
+                                   double* sens_host, int32_t* stats_host, int32_t* status_host, int64_t* totals);
+
 /* ---- DiffSL front end: what OdeBuilder::build_from_diffsl does with the external `diffsl` compiler
  * (crates/diffsol/src/ode_solver/builder.rs, crates/diffsol/src/ode_equations/diffsl.rs): DiffSL text -> source code of the model.
  * target DSHS_DIFFSL_HIP_STATIC: `struct dsh::JitModel` (n <= 8, register-resident; feeds dsh_model_compile);

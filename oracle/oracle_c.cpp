@@ -300,9 +300,9 @@ double orc_solve_ensemble_independent_fast(int model_id, int model_size, int nsy
 // OdeSolverMethod::solve_dense (method.rs:467-520) for every member as its own IVP (nbatch = 1): interpolated output at t_eval, the last
 // t_eval is the stop time.  y_out: [nsys][nt][n]; stats_out: [nsys][5] = steps, Newton iterations, LU setups, error-test failures, Newton
 // failures (all may be null).  Returns the number of members that failed.
-int orc_solve_dense_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
-                                double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out,
-                                double* root_t_out, int* root_idx_out, int* ncols_out) {
+static int solve_dense_independent_impl(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
+                                       double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out,
+                                       double* root_t_out, int* root_idx_out, int* ncols_out, const SensRequest* sens_rq, double* sens_out) {
   // group = 1: every member its own IVP.  group = G > 1: consecutive groups of G members (the last one may be smaller) solved as one
   // lock-step batched problem each (the reference's batched semantics with nbatch = G); stats are the group's, repeated per member.
   std::atomic<int> failed{0};
@@ -315,6 +315,7 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
       const int s0 = g * group, cnt = std::min(group, nsys - s0);
       try {
         g_option_request = options;
+        if (sens_rq) g_sens_request = *sens_rq;  // consumed by make_handle
         auto h = make_handle(model_id, model_size, cnt, p + (size_t)s0 * np, np * cnt, rtol, atol, natol, t0, h0, method);
         if (h->init_error != 0) { failed += cnt; continue; }
         const int n = h->problem.n();
@@ -330,8 +331,17 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
             (void)sv.interpolate_inplace(t_eval[col], tmp);
             if (y_out)
               for (int b = 0; b < cnt; ++b) std::memcpy(y_out + ((size_t)(s0 + b) * nt + col) * n, tmp.d.data() + (size_t)b * n, sizeof(double) * n);
+            if (sens_rq && sens_out) {  // dense_write_out_sensitivities (sensitivities.rs): interpolate_sens at the save point; sens_out [np][nsys][nt][n]
+              std::vector<V> sv_s;
+              Bdf* bb = dynamic_cast<Bdf*>(&sv);
+              if (!bb || bb->interpolate_sens(t_eval[col], sv_s) != OdeErr::Ok) { ok = false; break; }
+              for (size_t q = 0; q < sv_s.size(); ++q)
+                for (int b = 0; b < cnt; ++b)
+                  std::memcpy(sens_out + (((size_t)q * nsys + (size_t)(s0 + b)) * nt + col) * n, sv_s[q].d.data() + (size_t)b * n, sizeof(double) * n);
+            }
             col++;
           }
+          if (!ok) break;
           if (r == StopReason::TstopReached) break;
           if (r == StopReason::RootFound) {
             // solve_dense (method.rs:498-516): drain up to the root, then the column after holds the state moved back to the root time
@@ -380,6 +390,24 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
   for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
   for (auto& t : th) t.join();
   return failed;
+}
+
+int orc_solve_dense_independent(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
+                                double h0, int method, const double* t_eval, int nt, int nthreads, int group, double* y_out, long* stats_out,
+                                double* root_t_out, int* root_idx_out, int* ncols_out) {
+  return solve_dense_independent_impl(model_id, model_size, nsys, p, np, rtol, atol, natol, t0, h0, method, t_eval, nt, nthreads, group, y_out, stats_out, root_t_out,
+                                      root_idx_out, ncols_out, nullptr, nullptr);
+}
+// solve_dense_sensitivities (sensitivities.rs:114-260) per member / per lock-step group: problem.bdf_sens() for every group, the states and
+// interpolate_sens at every save point.  sens_out [np][nsys][nt][n].  nsens_atol = 0: turn_off_sensitivities_error_control.  BDF, models without root functions.
+int orc_solve_dense_independent_sens(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
+                                     double h0, const double* t_eval, int nt, int nthreads, int group, double sens_rtol, const double* sens_atol, int nsens_atol,
+                                     double* y_out, double* sens_out, long* stats_out) {
+  SensRequest rq;
+  rq.on = true; rq.error_control = nsens_atol > 0; rq.rtol = sens_rtol;
+  rq.atol.assign(sens_atol, sens_atol + (nsens_atol > 0 ? nsens_atol : 0));
+  return solve_dense_independent_impl(model_id, model_size, nsys, p, np, rtol, atol, natol, t0, h0, METHOD_BDF, t_eval, nt, nthreads, group, y_out, stats_out, nullptr,
+                                      nullptr, nullptr, &rq, sens_out);
 }
 
 // libm pow (default, the reference's arithmetic) or the deterministic pow shared with the device kernels (verification of the resident kernels)

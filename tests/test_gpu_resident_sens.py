@@ -1,0 +1,97 @@
+"""Forward sensitivities INSIDE the device-resident BDF (dsh_bdf_solve_adaptive_sens, k_bdf_adaptive<.., SENS>): states and dy/dp_j of every
+parameter at t_eval from one launch, against the oracle's solve_dense_sensitivities per member (group = 1) and per 64-member lock-step group (group = 64).
+
+What is restated on the device: new_with_sensitivities_and_consistent (state.rs:1032-1083), Bdf::new_augmented (bdf.rs:370-432, the sensitivity operator's c = 0
+until the first step-size change), sensitivity_solve (:934-989: one Newton solve per parameter with the factors of the state equations and the SHARED
+Convergence), the sensitivity terms of error_control (:844-858) and predict_error_control (:871-932), _update_step_size's chain of every sensitivity difference
+array through the one scratch matrix (:546-548), interpolate_sens (:1162-1215).  With the deterministic pow on both sides every counter and every output bit agrees."""
+import numpy as np
+import pytest
+
+from helpers import ORACLE_MODEL
+from bench import robertson_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import diffsol_amd
+    return diffsol_amd
+
+
+@pytest.fixture
+def det_pow(O):
+    O.set_det_pow(True)
+    yield
+    O.set_det_pow(False)
+
+
+T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]
+ROB = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+
+
+def _pair(H, O, model, p, t_eval, size, group, sens_tol, expect_failed_at_most=0, **tol):
+    nb = len(p)
+    kw = dict(sens_rtol=sens_tol[0], sens_atol=sens_tol[1]) if sens_tol else {}
+    s = H.Solver(model, p, nbatch=nb, model_size=size, sens=True, **kw, **tol)
+    y, sens, tot, m = s.solve_dense_adaptive_sens(t_eval, group=group, want_member_stats=True)
+    yo, so, sto, failed = O.solve_dense_independent_sens(ORACLE_MODEL[model], np.asarray(p, dtype=float), t_eval, model_size=size, nthreads=8, group=group, **kw, **tol)
+    # a member (group) that fails — too many error-test failures under tight sensitivity tolerances — fails in both, at the same step: the counters, the columns
+    # written up to there and the NaN columns behind are compared like everything else
+    assert failed == tot["failed_members"] == int((m["status"] != 0).sum()) and failed <= expect_failed_at_most
+    assert np.array_equal(m["stats"].T, sto), "counters differ"
+    assert np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True), "states differ"
+    assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3)), equal_nan=True), "sensitivities differ"
+    assert tot["number_of_steps"] == int(sto[:, 0].sum()) and tot["number_of_nonlinear_solver_iterations"] == int(sto[:, 1].sum())
+    _pair.failed = failed
+    return y, sens, sto
+
+
+@pytest.mark.parametrize("group", [1, 64])
+@pytest.mark.parametrize("error_control", [None, "mild", "tight"])
+def test_resident_bdf_with_sensitivities_is_bit_identical_to_the_oracle_on_robertson(H, O, det_pow, group, error_control):
+    """Robertson ODE with its 3 rate constants as parameters (test_models/robertson_ode_with_sens.rs): 300 members (4 full wavefronts + a partial one).
+    "tight": the states' absolute tolerances on sensitivities that are 1e4 times larger — some members exhaust their error-test failures, in the oracle too."""
+    p = robertson_params(300, seed=11)
+    tol = {None: None, "mild": (1e-4, [1e-6]), "tight": (1e-4, [1e-8, 1e-14, 1e-6])}[error_control]
+    y, sens, st = _pair(H, O, "robertson_ode", p, T_EVAL, 1, group, tol, expect_failed_at_most=0 if error_control != "tight" else 128, **ROB)
+    # (that the oracle's sensitivities are the derivatives of its states: tests/test_oracle_sens_independent.py)
+    if error_control != "tight":
+        assert np.isfinite(sens).all() and np.abs(sens[0]).max() > 1.0
+    if error_control == "mild":  # the sensitivities take part in the error test: more work than without
+        _, _, st0 = _pair(H, O, "robertson_ode", p[:64], T_EVAL, 1, group, None, **ROB)
+        assert st[:64, 0].sum() > st0[:, 0].sum()
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_resident_bdf_with_sensitivities_on_the_exponential_decay_snapshot_problem(H, O, det_pow, group):
+    """exponential_decay_problem_sens (test_models/exponential_decay.rs:224-262): y' = -k y, y(0) = y0, parameters (k, y0); rtol = atol = 1e-6, sensitivities in
+    the error control.  Analytic: y = y0 e^{-kt}, dy/dk = -t y0 e^{-kt}, dy/dy0 = e^{-kt}."""
+    k = 0.1 * (1 + np.arange(130) % 7)
+    y0 = 1.0 + 0.25 * (np.arange(130) % 5)
+    p = np.stack([k, y0], axis=1)
+    te = [float(i) for i in range(0, 11)]
+    y, sens, st = _pair(H, O, "exponential_decay", p, te, 0, group, (1e-6, [1e-6]), rtol=1e-6, atol=[1e-6, 1e-6])
+    t = np.asarray(te)[:, None]
+    e = np.exp(-k[None, :] * t)
+    assert np.allclose(y[:, :, 0], y0[None, :] * e, rtol=2e-4, atol=1e-6) and np.allclose(y[:, :, 1], y[:, :, 0])
+    assert np.allclose(sens[0, :, :, 0], -t * y0[None, :] * e, rtol=1e-3, atol=3e-5)
+    assert np.allclose(sens[1, :, :, 0], e, rtol=1e-3, atol=3e-5)
+    # the reference's snapshot member (k = 0.1, y0 = 1): the device-resident run of that one problem repeats the counters of the oracle's stepping solver
+    _pair(H, O, "exponential_decay", [[0.1, 1.0]], te, 0, 1, (1e-6, [1e-6]), rtol=1e-6, atol=[1e-6, 1e-6])
+
+
+def test_resident_sensitivities_refuse_what_they_do_not_cover(H):
+    import diffsol_amd
+    dev = diffsol_amd._ffi.load_device_lib()
+    assert dev.dsh_model_has_adaptive_sens(diffsol_amd.MODELS["robertson_ode"], 1) == 1
+    assert dev.dsh_model_has_adaptive_sens(diffsol_amd.MODELS["exponential_decay"], 0) == 1
+    assert dev.dsh_model_has_adaptive_sens(diffsol_amd.MODELS["robertson"], 0) == 0  # DAE (mass matrix): host-driven
+    assert dev.dsh_model_has_adaptive_sens(diffsol_amd.MODELS["heat1d"], 20) == 0
+    s = H.Solver("robertson", [[0.04, 1e4, 3e7]] * 4, nbatch=4, sens=True, rtol=1e-4, atol=[1e-8, 1e-6, 1e-6])
+    with pytest.raises(Exception, match="forward sensitivities"):
+        s.solve_dense_adaptive_sens([1.0])
+    s2 = H.Solver("robertson_ode", [[0.04, 1e4, 3e7]] * 4, nbatch=4, model_size=1, **ROB)  # no sens requested
+    with pytest.raises(Exception, match="dshs_create_sens"):
+        s2.solve_dense_adaptive_sens([1.0])

@@ -71,7 +71,11 @@ def test_every_ffi_call_in_the_shim_matches_a_declaration():
             used.add(fn)
     # the trait surface of SURVEY §8(b) is wired up: every vec_* / mat_* / lu_* entry point the traits need has a caller in the shim
     # (not needed by the traits: inspection helpers of the factors and the declared-band variants used by the C++ host integrators)
-    optional = {"dsh_lu_download", "dsh_lu_system_major", "dsh_lu_band_width", "dsh_lu_factor_banded", "dsh_lu_factors", "dsh_lu_pivots", "dsh_mat_scale_add_assign_banded"}
+    optional = {"dsh_lu_download", "dsh_lu_system_major", "dsh_lu_band_width", "dsh_lu_factor_banded", "dsh_lu_factors", "dsh_lu_pivots", "dsh_mat_scale_add_assign_banded",
+                # round 3: band containers and the single-pass stage operations of the C++ host integrators (every one equals a sequence of trait operations, bit for bit)
+                "dsh_lu_create_banded", "dsh_lu_factor_packed", "dsh_lu_solve_squared_norm", "dsh_mat_band_from_diagonal", "dsh_mat_band_gemv", "dsh_mat_gemv_from",
+                "dsh_vec_axpby_to"}
+    optional |= {n for n in decl if n.startswith("dsh_mat_band_")}
     needed = {n for n in decl if re.match(r"dsh_(vec|mat|lu)_", n)} - optional
     assert needed <= used, sorted(needed - used)
 
