@@ -281,6 +281,23 @@ def main():
                 extras["per_member"]["roofline"] = None
         except Exception:
             extras["per_member"]["roofline"] = None
+        # the opt-in fast-arithmetic variant of the same kernel (dsh_adaptive_fast.hip: fused multiply-adds, reciprocal-math division, ocml pow; NOT bit-comparable
+        # with the oracle, held to 1e-6 relative by tests/test_gpu_adaptive.py) — an extra key, never `value`
+        def fast_step():
+            _, tot = solver.solve_dense_adaptive(T_EVAL, want_host=False, dev_ptr=out.data_ptr(), group=64, deterministic_pow=2)
+            return tot, (gather_batch_axis(out, n_total, rank, world) if world > 1 else out)
+        try:
+            y_exact = y.clone()
+            fast_step()
+            el, a, yf = timed(k_x, fast_step)
+            el, st, nw, fl = allreduce([el, a["number_of_steps"], a["number_of_nonlinear_solver_iterations"], a["failed_members"]])
+            big = y_exact.abs() > 1e-9
+            extras["fast_variant"] = {"ms_per_step": 1e3 * el / k_x, "ode_steps_per_sec": st / el, "newton_solves_per_sec": nw / el, "failed_members": int(fl),
+                                      "max_rel_diff_vs_exact_states": float(((yf - y_exact).abs() / y_exact.abs().clamp_min(1e-300))[big].max().item()),
+                                      "note": "opt-in (deterministic_pow = 2): -ffp-contract=fast, reciprocal-math division, ocml pow, reciprocal Newton weights; "
+                                              "wavefront lock-step groups like `value`, not bit-comparable with the oracle"}
+        except Exception as e:  # noqa: BLE001 — an extra must not take the bench line down
+            extras["fast_variant"] = {"error": str(e)[:200]}
         hl = mode_pass(ENSEMBLE_LOCKSTEP, True)
         hl["note"] = ("DSHS_ENSEMBLE_LOCKSTEP: host-driven, one (t, h, order) for all members over the trait-boundary operations (fused Newton / accept kernels); "
                       "round 1's `value` path")

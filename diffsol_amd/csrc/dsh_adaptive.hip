@@ -90,6 +90,11 @@ int dsh_model_has_adaptive(int model, int64_t size) {
 }
 
 }  // extern "C"
+namespace dsh {
+bool adaptive_fast_launch(int model, int64_t size, bool ba, bool wave, dim3 grid, hipStream_t stream, int64_t nb, const double* p, const double* atol,
+                          const AdaptiveConsts* consts, const double* t_eval, double* y_out, int32_t* stats, int32_t* status, double* t_root, int32_t* root_idx,
+                          int32_t* ncols, unsigned long long* totals);  // dsh_adaptive_fast.hip
+}
 namespace {
 struct SensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };  // forward sensitivities of dsh_bdf_solve_adaptive_sens
 // does the static model have a device-resident BDF with forward sensitivities?  (sens_mul / init_sens_mul, identity mass, no root functions, n <= 4)
@@ -314,7 +319,11 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     if (rc != DSH_OK) { if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } dsh_free(ctx, totals_dev); return rc; }
     launched = true;
   } else
-  if (sens) {
+  if (!sens && C.r.o.deterministic_pow == 2) {
+    // the opt-in fast-arithmetic variant (dsh_adaptive_fast.hip): static models; everything else about the call is the same
+    launched = adaptive_fast_launch(model, size, ba, C.r.o.group == 64, grid, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
+                                    status, t_root, root_idx, ncols, totals_dev);
+  } else if (sens) {
     launched = dispatch_static_model(model, size, [&](auto mdl) {
       using Mdl = decltype(mdl);
       if constexpr (adaptive_sens_ok<Mdl>()) {

@@ -48,7 +48,10 @@ __device__ __forceinline__ void guarded(bool c, F&& f) {
 #ifndef DSH_ADAPTIVE_WAVES_PER_EU
 #define DSH_ADAPTIVE_WAVES_PER_EU 2
 #endif
-template <class Mdl, bool BA, bool WAVE, bool SEG = false, bool SENS = false>
+// FAST (opt-in, dsh_adaptive_options::deterministic_pow == 2; instantiated only in dsh_adaptive_fast.hip, which is compiled with -ffp-contract=fast and
+// reciprocal-math division): ocml's pow, fused multiply-adds, the Newton norm's weights as reciprocals computed once per solve.  NOT bit-comparable with the
+// oracle: held to 1e-6 relative on the states at tight tolerances (tests/test_gpu_adaptive.py).
+template <class Mdl, bool BA, bool WAVE, bool SEG = false, bool SENS = false, bool FAST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE_WAVES_PER_EU, DSH_ADAPTIVE_WAVES_PER_EU))) void k_bdf_adaptive(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const AdaptiveConsts* __restrict__ Cp,
                                                     const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                     int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
   const int64_t b = b_;
   const bool fresh = !SEG || C.seg_fresh != 0;  // not a resumed launch
   const dsh_adaptive_options& o = C.r.o;
-  const bool det = o.deterministic_pow != 0;
+  const bool det = !FAST && o.deterministic_pow != 0;
   const double rtol = C.r.rtol;
   double p[NP], atol[N];
   load_vec<NP>(p_g, nb, b, p);
@@ -151,6 +154,8 @@ DSH_UNROLL_N
     }
   }
   double A[BANDED ? 1 : N * N];
+  double Adinv[(FAST && !BANDED) ? N : 1];  // fast variant: reciprocals of U's diagonal, once per factorisation
+  double wyinv[FAST ? N : 1];               // fast variant: 1 / (|y_i| rtol + atol_i) for the current state (error test, order selection)
   int P[N];
   bool jac_stale = true;
   // statistics (ode_solver/mod.rs:28-69)
@@ -182,6 +187,10 @@ DSH_UNROLL_N
     for (int e = 0; e < N * N; ++e) A[e] = J[e] * (-opc) + Mm[e];
     bool sing = false;
     lu_factor_reg<N>(A, P, sing);
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) Adinv[i] = 1.0 / A[i * N + i];
+    }
     }
   };
   if (fresh) {
@@ -204,6 +213,23 @@ DSH_UNROLL_N
   double prev_err = 0.0;
   double yp[N], psi[N];
   double t_predict = t;
+
+  // fast variant: the weighted mean square against the current state with the cached reciprocal weights
+  auto wms_y = [&](const double (&v)[N]) __attribute__((always_inline)) -> double {
+    if constexpr (FAST) {
+      double acc = 0.0;
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) { const double term = v[i] * wyinv[i]; acc += term * term; }
+      return acc / (double)N;
+    } else return wms<N>(v, y, atol, rtol);
+  };
+  auto refresh_wyinv = [&]() __attribute__((always_inline)) {
+    if constexpr (FAST) {
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) wyinv[i] = 1.0 / (fabs(y[i]) * rtol + atol[i]);
+    }
+  };
+  refresh_wyinv();
 
   // @phase update_step_size (R, R U, D <- D R U)
   // _update_step_size (bdf.rs:508-566) with _update_diff_for_step_size (:568-577): diff_tmp[:, 0..=order] = diff[:, 0..=order] * (R U); swap
@@ -480,6 +506,11 @@ DSH_UNROLL_N
       // ---- NewtonNonlinearSolver::solve_in_place over NoLineSearch (newton.rs:13-36, line_search.rs:46-72)
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) x[i] = yp[i];
+      double winv[FAST ? N : 1];
+      if constexpr (FAST) {
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) winv[i] = 1.0 / (fabs(yp[i]) * rtol + atol[i]);
+      }
       niter = 0;
       bool has_old = false;
       double old_norm = 0.0;
@@ -502,6 +533,7 @@ DSH_UNROLL_N
         }
         bool solved_ok;
         if constexpr (BANDED) solved_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
+        else if constexpr (FAST) solved_ok = lu_solve_reg_inv<N>(A, Adinv, P, delta);
         else solved_ok = lu_solve_reg<N>(A, P, delta);
         const bool lu_ok = group_all<WAVE>(solved_ok);
         if (!lu_ok) break;  // LuSolveFailed
@@ -512,7 +544,8 @@ DSH_UNROLL_N
           for (int i = 0; i < N; ++i) {
             const double d = delta[i];
             x[i] = x[i] - d;
-            const double term = d / (fabs(yp[i]) * rtol + atol[i]);
+            double term;
+            if constexpr (FAST) term = d * winv[i]; else term = d / (fabs(yp[i]) * rtol + atol[i]);
             acc += term * term;
           }
           delta_ms = acc / (double)N;
@@ -531,8 +564,8 @@ DSH_UNROLL_N
           const double min_eta = 1e4 * 2.220446049250313e-16;
           if (eta < min_eta) eta = min_eta;
           // after a reset eta is one of two constants (convergence.rs:36-42): their 0.8th powers come from the host (the same deterministic pow)
-          if (det && eta == C.r.eta_reset) eta = C.eta_reset_p08;
-          else if (det && eta == C.r.eta_reset_ts) eta = C.eta_reset_ts_p08;
+          if ((det || FAST) && eta == C.r.eta_reset) eta = C.eta_reset_p08;
+          else if ((det || FAST) && eta == C.r.eta_reset_ts) eta = C.eta_reset_ts_p08;
           else eta = rpow(eta, 0.8, det);
         }
         const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
@@ -633,7 +666,7 @@ DSH_UNROLL_N
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) ydelta[i] = x[i] - yp[i];
       // error_control (bdf.rs:812-843): norm against the CURRENT state y
-      error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(ydelta, y, atol, rtol)) * sEc2[order - 1]);
+      error_norm = fmax(0.0, group_norm<WAVE>(wms_y(ydelta)) * sEc2[order - 1]);
       if constexpr (SENS) {
         if (C.sens_error_control)  // bdf.rs:844-858 — error_const2[order], not [order - 1]
           for (int j = 0; j < NP; ++j) error_norm = fmax(error_norm, group_norm<WAVE>(wms<N>(s_delta[j], s_cur[j], s_atol, C.sens_rtol)) * sEc2[order]);
@@ -706,6 +739,7 @@ DSH_UNROLL_N
               for (int j = 5; j >= 0; --j) if (j <= order) { const double v = S[q][j][i] + 1.0 * upper; S[q][j][i] = v; upper = v; }
             }
         }
+        refresh_wyinv();
         t = t_predict;
         break;
       }
@@ -754,8 +788,8 @@ DSH_UNROLL_N
       }
       }
       const double inf = __builtin_huge_val();
-      double error_m_norm = order > 1 ? group_norm<WAVE>(wms<N>(col_m, y, atol, rtol)) * sEc2[order - 1] : inf;
-      double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms<N>(col_p, y, atol, rtol)) * sEc2[order + 1] : inf;
+      double error_m_norm = order > 1 ? group_norm<WAVE>(wms_y(col_m)) * sEc2[order - 1] : inf;
+      double error_p_norm = order < kMaxOrder ? group_norm<WAVE>(wms_y(col_p)) * sEc2[order + 1] : inf;
       if constexpr (SENS) {  // predict_error_control with the augmented system (bdf.rs:871-932): the `error_norm.max(err)` chain from zero, then the sensitivities' terms
         if (order > 1) error_m_norm = fmax(0.0, error_m_norm);
         if (order < kMaxOrder) error_p_norm = fmax(0.0, error_p_norm);

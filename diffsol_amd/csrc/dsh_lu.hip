@@ -445,7 +445,24 @@ static int lu_solve_launch_impl(const dsh_lu* lu, double* rhs, bool wait, unsign
 #undef DSH_LU_WAVE
       } else {
         static const bool blocked_solve = [] { const char* e = getenv("DSH_LU_BLOCKED_SOLVE"); return !e || atoi(e) != 0; }();
-        if (blocked_solve)
+        // factor panels prefetched through a register ring (same bits) when there is at most one system per compute unit — with several workgroups per
+        // CU the plain kernel's occupancy hides the latency better (512 x 4096: 1.8 ms against 4.4 ms; 962 x 256: 1.06 ms against 0.67 ms,
+        // gpurun_out/r03_solve_check.txt).  DSH_LU_STREAM_SOLVE=0 keeps k_lu_solve_blocked, =2/4/6 forces the ring depth for any ensemble size.
+        static const int stream_env = [] { const char* e = getenv("DSH_LU_STREAM_SOLVE"); return e ? atoi(e) : -1; }();
+        const int stream_depth = stream_env >= 0 ? stream_env : (nb <= (int64_t)ctx->num_cu ? 2 : 0);
+        if (blocked_solve && stream_depth > 0 && n <= 2 * kStreamThreads) {
+          const size_t lds = stream_solve_lds_bytes(n);
+#define DSH_STREAM(RPT, D, BB) hipLaunchKernelGGL((k_lu_solve_stream<RPT, D, BB>), g, dim3(kStreamThreads), lds, ctx->stream, (int)n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
+          static const int stream_b = [] { const char* e = getenv("DSH_LU_STREAM_B"); return e ? atoi(e) : 8; }();
+          if (n <= kStreamThreads) {
+            if (stream_b >= 32) DSH_STREAM(1, 2, 32); else if (stream_b >= 16) { if (stream_depth >= 4) DSH_STREAM(1, 4, 16); else DSH_STREAM(1, 2, 16); }
+            else if (stream_depth >= 6) DSH_STREAM(1, 6, 8); else if (stream_depth >= 4) DSH_STREAM(1, 4, 8); else DSH_STREAM(1, 2, 8);
+          } else {
+            if (stream_b >= 32) DSH_STREAM(2, 2, 32); else if (stream_b >= 16) { if (stream_depth >= 3) DSH_STREAM(2, 3, 16); else DSH_STREAM(2, 2, 16); }
+            else if (stream_depth >= 6) DSH_STREAM(2, 6, 8); else if (stream_depth >= 4) DSH_STREAM(2, 4, 8); else DSH_STREAM(2, 2, 8);
+          }
+#undef DSH_STREAM
+        } else if (blocked_solve)
           hipLaunchKernelGGL(k_lu_solve_blocked, g, dim3(kCoopThreads), sizeof(double) * n, ctx->stream, (int)n, nb, (const double*)lu->factors,
                              (const int32_t*)lu->pivots, rhs, rec, seq);
         else

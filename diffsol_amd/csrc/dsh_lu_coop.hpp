@@ -406,4 +406,166 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_solve_blocked(int n, int64_
   block_publish(0ull, 0ull, (tid == 0 && !ok) ? 1ull : 0ull, rec, seq);
 }
 
+// The same triangular solves with the factor panels PREFETCHED.  k_lu_solve_blocked is a chain of 2 n / B steps, each of which issues its loads, waits for HBM,
+// computes and meets a barrier — twice (diagonal block, then the panel): at n = 962 x 256 systems 1.02 ms per solve for 1.9 GB of factors (1.9 TB/s), 45 % of
+// the DFN model's kernel time (profiles/r03_dfn_kernel_stats_256.md).  Nothing a step loads depends on the right-hand side, so here every thread keeps a ring
+// of D panels in registers: the loads of step s + D are issued as soon as the registers of step s are free, and D - 1 panels (~60 KB per workgroup) are
+// in flight while a step computes.  Rows are owned by threads (row r = tid + q * kStreamThreads), the 8 x 8 diagonal block by eight lanes of the first
+// wavefront; the interchanges are read into LDS and only the rows that really move are visited.  Every element receives the updates of the
+// column-by-column algorithm in its order (v_r = (-v_k) * a_rk + v_r, k ascending for L, descending for U): bit-identical to k_lu_solve_blocked.
+constexpr int kStreamThreads = 512;
+template <int RPT, int D, int B = kSolveBlock>
+__global__ __launch_bounds__(kStreamThreads) void k_lu_solve_stream(int n, int64_t nb, const double* __restrict__ f_aos, const int32_t* __restrict__ piv_aos,
+                                                                  double* __restrict__ rhs, unsigned long long* rec, unsigned int seq) {
+  extern __shared__ double v[];  // n values, then n pivot rows (int), then the bit mask of the rows that move
+  constexpr int T = kStreamThreads;  // B columns per block step: the fixed cost of a step (two barriers, the diagonal block's chain) is paid n / B times per sweep
+  const int64_t b = blockIdx.x;
+  const double* A = f_aos + (size_t)b * n * n;
+  const int tid = threadIdx.x;
+  int* P = reinterpret_cast<int*>(v + n);
+  unsigned long long* moved = reinterpret_cast<unsigned long long*>(P + ((n + 1) & ~1));
+  const int nwords = (n + 63) / 64;
+  const int ns = (n + B - 1) / B;  // block steps of each sweep
+  double ring[D][RPT][B];
+  double dring[D][B];
+  // panel of the L sweep, step s: columns kb .. kb + B - 1, rows below the block; diagonal block: row kb + j, columns left of it
+  auto load_L = [&](int s, double (&buf)[RPT][B], double (&dg)[B]) __attribute__((always_inline)) {
+    const int kb = s * B;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + q * T;
+#pragma unroll
+      for (int i = 0; i < B; ++i) buf[q][i] = (s < ns && r >= kb + B && r < n) ? A[(size_t)(kb + i) * n + r] : 0.0;
+    }
+    if (tid < 64) {
+      const int j = tid;
+#pragma unroll
+      for (int i = 0; i < B; ++i) dg[i] = (s < ns && j < B && i < j && kb + j < n) ? A[(size_t)(kb + i) * n + kb + j] : 0.0;
+    }
+  };
+  // panel of the U sweep, step s (counted from the last block upwards): columns kb .. kb + w - 1, rows above the block
+  auto load_U = [&](int s, double (&buf)[RPT][B], double (&dg)[B]) __attribute__((always_inline)) {
+    const int kb = (ns - 1 - s) * B;
+    const int w = (n - kb) < B ? (n - kb) : B;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + q * T;
+#pragma unroll
+      for (int i = 0; i < B; ++i) buf[q][i] = (s < ns && r < kb && i < w) ? A[(size_t)(kb + i) * n + r] : 0.0;
+    }
+    if (tid < 64) {
+      const int j = tid;
+#pragma unroll
+      for (int i = 0; i < B; ++i) dg[i] = (s < ns && j < w && i < w && i >= j) ? A[(size_t)(kb + i) * n + kb + j] : 1.0;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < D; ++u) load_L(u, ring[u], dring[u]);  // in flight while the right-hand side is permuted
+  for (int r = tid; r < n; r += T) { v[r] = rhs[(int64_t)r * nb + b]; P[r] = piv_aos[(size_t)b * n + r]; }
+  __syncthreads();
+  for (int wd = tid >> 6; wd < nwords; wd += T / 64) {
+    const int i = wd * 64 + (tid & 63);
+    const unsigned long long m = __ballot(i < n && P[i] != i);
+    if ((tid & 63) == 0) moved[wd] = m;
+  }
+  __syncthreads();
+  if (tid == 0) {  // the recorded interchanges, in order, visiting only the rows that move
+    for (int wd = 0; wd < nwords; ++wd) {
+      unsigned long long m = moved[wd];
+      while (m) {
+        const int i = wd * 64 + __builtin_ctzll(m);
+        m &= m - 1;
+        const int p = P[i];
+        const double tmp = v[i]; v[i] = v[p]; v[p] = tmp;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- L y = P b (unit lower triangle)
+  for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int s = s0 + u;
+      if (s < ns) {  // uniform
+        const int kb = s * B;
+        const int w = (n - kb) < B ? (n - kb) : B;
+        if (tid < 64) {
+          const int j = tid;
+          double vj = j < w ? v[kb + j] : 0.0;
+#pragma unroll
+          for (int i = 0; i < B; ++i) {
+            const double vi = __shfl(vj, i, 64);
+            if (i < j && j < w) vj = (-vi) * dring[u][i] + vj;
+          }
+          if (j < w) v[kb + j] = vj;
+        }
+        __syncthreads();
+        double vk[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) vk[i] = i < w ? v[kb + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          const int r = tid + q * T;
+          if (r >= kb + w && r < n) {
+            double vr = v[r];
+#pragma unroll
+            for (int i = 0; i < B; ++i) if (i < w) vr = (-vk[i]) * ring[u][q][i] + vr;
+            v[r] = vr;
+          }
+        }
+        __syncthreads();
+        load_L(s + D, ring[u], dring[u]);
+      }
+    }
+  }
+  // ---- U x = y
+#pragma unroll
+  for (int u = 0; u < D; ++u) load_U(u, ring[u], dring[u]);
+  bool ok = true;
+  for (int s0 = 0; s0 < ns; s0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int s = s0 + u;
+      if (s < ns) {
+        const int kb = (ns - 1 - s) * B;
+        const int w = (n - kb) < B ? (n - kb) : B;
+        if (tid < 64) {
+          const int j = tid;
+          double vj = j < w ? v[kb + j] : 0.0;
+#pragma unroll
+          for (int i = B - 1; i >= 0; --i) {
+            if (i < w) {
+              const double diag = __shfl(dring[u][i], i, 64);  // U(kb+i, kb+i), held by lane i
+              if (diag == 0.0) ok = false;
+              const double coeff = __shfl(vj, i, 64) / diag;
+              if (j == i) vj = coeff;
+              else if (j < i) vj = (-coeff) * dring[u][i] + vj;
+            }
+          }
+          if (j < w) v[kb + j] = vj;
+        }
+        __syncthreads();
+        double vk[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) vk[i] = i < w ? v[kb + i] : 0.0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+          const int r = tid + q * T;
+          if (r < kb) {
+            double vr = v[r];
+#pragma unroll
+            for (int i = B - 1; i >= 0; --i) if (i < w) vr = (-vk[i]) * ring[u][q][i] + vr;
+            v[r] = vr;
+          }
+        }
+        __syncthreads();
+        load_U(s + D, ring[u], dring[u]);
+      }
+    }
+  }
+  for (int r = tid; r < n; r += T) rhs[(int64_t)r * nb + b] = v[r];
+  block_publish(0ull, 0ull, (tid == 0 && !ok) ? 1ull : 0ull, rec, seq);
+}
+inline size_t stream_solve_lds_bytes(int64_t n) { return sizeof(double) * (size_t)n + sizeof(int) * (size_t)((n + 1) & ~1) + 8 * (size_t)((n + 63) / 64); }
+
 }  // namespace dsh

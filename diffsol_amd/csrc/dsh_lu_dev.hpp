@@ -58,6 +58,41 @@ __device__ __forceinline__ void lu_factor_reg(double (&A)[N * N], int (&P)[N], b
 }
 
 // returns false if a zero diagonal of U was met (LuSolveFailed)
+// lu_solve_reg with the reciprocals of U's diagonal supplied (dinv[i] = 1 / A[i * N + i], computed once per factorisation): the back substitution multiplies instead
+// of dividing.  NOT the arithmetic of the reference's solve — used by the opt-in fast variant of the device-resident BDF only (dsh_adaptive_fast.hip).
+template <int N>
+__device__ __forceinline__ bool lu_solve_reg_inv(const double (&A)[N * N], const double (&dinv)[N], const int (&P)[N], double (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double vi = v[i];
+    double picked = vi;
+#pragma unroll
+    for (int r = i + 1; r < N; ++r) {
+      const bool s = (r == P[i]);
+      const double vr = v[r];
+      picked = s ? vr : picked;
+      v[r] = s ? vi : vr;
+    }
+    v[i] = picked;
+  }
+#pragma unroll
+  for (int i = 0; i + 1 < N; ++i) {
+    double coeff = v[i];
+#pragma unroll
+    for (int r = i + 1; r < N; ++r) v[r] = (-coeff) * A[i * N + r] + v[r];
+  }
+  bool ok = true;
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    if (A[i * N + i] == 0.0) ok = false;
+    double coeff = v[i] * dinv[i];
+    v[i] = coeff;
+#pragma unroll
+    for (int r = 0; r < i; ++r) v[r] = (-coeff) * A[i * N + r] + v[r];
+  }
+  return ok;
+}
+
 template <int N>
 __device__ __forceinline__ bool lu_solve_reg(const double (&A)[N * N], const int (&P)[N], double (&v)[N]) {
 #pragma unroll

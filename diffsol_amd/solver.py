@@ -199,7 +199,7 @@ class Solver:
             m = dict(stats=np.empty((5, self.nbatch), dtype=np.int32), status=np.empty(self.nbatch, dtype=np.int32), t_root=np.empty(self.nbatch),
                      root_idx=np.empty(self.nbatch, dtype=np.int32), ncols=np.empty(self.nbatch, dtype=np.int32))
         i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
-        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), 1 if deterministic_pow else 0,
+        check(self._L.dshs_solve_dense_adaptive(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), int(deterministic_pow),
                                                 out.ctypes.data_as(_ffi.c_dp) if want_host else None,
                                                 vp(dev_ptr) if dev_ptr else None, i32(m["stats"]) if m else None, i32(m["status"]) if m else None,
                                                 m["t_root"].ctypes.data_as(_ffi.c_dp) if m else None, i32(m["root_idx"]) if m else None,
@@ -218,7 +218,7 @@ class Solver:
         totals = (C.c_int64 * 6)()
         m = dict(stats=np.empty((5, self.nbatch), dtype=np.int32), status=np.empty(self.nbatch, dtype=np.int32)) if want_member_stats else None
         i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
-        check(self._L.dshs_solve_dense_adaptive_sens(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), 1 if deterministic_pow else 0,
+        check(self._L.dshs_solve_dense_adaptive_sens(self._h, te.ctypes.data_as(_ffi.c_dp), te.size, int(group), int(deterministic_pow),
                                                      out.ctypes.data_as(_ffi.c_dp), sens.ctypes.data_as(_ffi.c_dp), i32(m["stats"]) if m else None,
                                                      i32(m["status"]) if m else None, totals), host=True)
         tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))

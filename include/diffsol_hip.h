@@ -381,7 +381,11 @@ typedef struct dsh_adaptive_options { /* OdeSolverOptions (problem.rs:132-152) +
   int ic_use_linesearch, ic_max_linesearch_iterations, ic_max_linear_solver_setups, ic_max_newton_iterations;
   double ic_step_reduction_factor, ic_armijo_constant;
   int64_t max_steps; /* per-member guard against a runaway loop (status 99) */
-  int deterministic_pow; /* 1 (default): pow() of diffsol_detpow.h — the results are bit-identical to the oracle's in the same mode; 0: ocml's pow() (~3 % faster) */
+  int deterministic_pow; /* arithmetic mode.  1 (default): pow() of diffsol_detpow.h — the results are bit-identical to the oracle's in the same mode;
+                            0: ocml's pow(), everything else exact;
+                            2: the opt-in FAST variant of dsh_bdf_solve_adaptive for static models (dsh_adaptive_fast.hip, compiled with -ffp-contract=fast
+                               and reciprocal-math division; ocml pow; reciprocal Newton weights): ~1.2x, NOT bit-comparable with the oracle, states within
+                               1e-6 relative at tight tolerances; every other kernel treats 2 like 1 */
   int group;         /* control granularity: 1 = every member its own step/order history; 64 = the 64 members of a wavefront in lock-step
                         (the reference's batched semantics with nbatch = 64 per group, max-norms over the wavefront) */
 } dsh_adaptive_options;

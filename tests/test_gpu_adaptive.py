@@ -409,6 +409,30 @@ def test_rlc_config5_esdirk34_with_threshold_events_is_bit_identical_to_the_orac
         assert 0 < (m["root_idx"] >= 0).sum() < nb
 
 
+@pytest.mark.parametrize("group", [1, 64])
+def test_the_opt_in_fast_arithmetic_variant_stays_within_1e6_relative_of_the_cpu_result(H, O, group):
+    """deterministic_pow = 2 (dsh_adaptive_fast.hip: -ffp-contract=fast, reciprocal-math division, ocml pow, reciprocal Newton weights) is the one kernel of the
+    library that is not bit-comparable with the oracle.  north_star's bar for it: states within 1e-6 relative of the CPU result — checked at tight tolerances,
+    where the integration error itself is below that, against the oracle with libm's pow; at the bench's tolerances the members must still all succeed,
+    conserve mass and stay within the solver tolerance of the exact kernel."""
+    p = robertson_params(640, seed=3)
+    tight = dict(rtol=1e-9, atol=[1e-13, 1e-17, 1e-11])
+    s = H.Solver("robertson_ode", p, nbatch=len(p), model_size=1, **tight)
+    y, tot = s.solve_dense_adaptive(T_EVAL[:5], group=group, deterministic_pow=2)
+    yo, so, failed = O.solve_dense_independent(ORACLE_MODEL["robertson_ode"], np.asarray(p, dtype=float), T_EVAL[:5], model_size=1, nthreads=8, group=group, **tight)
+    yo = np.transpose(yo, (1, 0, 2))
+    assert failed == 0 and tot["failed_members"] == 0
+    big = np.abs(yo) > 1e-7
+    assert (np.abs(y - yo)[big] / np.abs(yo)[big]).max() < 1e-6
+    assert np.allclose(y, yo, rtol=1e-6, atol=1e-13)
+    s2 = H.Solver("robertson_ode", p, nbatch=len(p), model_size=1, **ROB)
+    yf, totf = s2.solve_dense_adaptive(T_EVAL, group=group, deterministic_pow=2)
+    ye, tote = s2.solve_dense_adaptive(T_EVAL, group=group, deterministic_pow=1)
+    assert totf["failed_members"] == 0 and np.abs(yf.sum(axis=2) - 1.0).max() < 1e-9
+    assert np.allclose(yf, ye, rtol=5e-3, atol=1e-9) and not np.array_equal(yf, ye)
+    assert abs(totf["number_of_steps"] - tote["number_of_steps"]) < 0.02 * tote["number_of_steps"]
+
+
 def test_deterministic_pow_is_the_same_function_on_host_and_device_and_close_to_libm(H, O):
     """diffsol_detpow.h against libm on the host (the device-side identity is what the bitwise tests above establish)."""
     rng = np.random.default_rng(0)
