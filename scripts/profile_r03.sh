@@ -17,4 +17,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc3_$TAG -o pmc -- $P > $OUT/
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc4_$TAG -o pmc -- $P > $OUT/pmc4_$TAG.log 2>&1 < /dev/null
 TR=$(ls $OUT/trace_$TAG/*/*_results.db $OUT/trace_$TAG/*_results.db 2>/dev/null | head -1)
 python scripts/pmc_summary.py --match k_bdf_adaptive --match k_bdf_member --trace "$TR" --out $OUT/pmc_resident_$TAG.json "$OUT/pmc1_$TAG/*.db" "$OUT/pmc1_$TAG/*/*.db" "$OUT/pmc2_$TAG/*.db" "$OUT/pmc2_$TAG/*/*.db" "$OUT/pmc3_$TAG/*.db" "$OUT/pmc3_$TAG/*/*.db" "$OUT/pmc4_$TAG/*.db" "$OUT/pmc4_$TAG/*/*.db" > $OUT/summary_$TAG.log 2>&1 < /dev/null
+# the merge back from the GPU box is capped at 64 MiB: keep the summaries, drop the raw databases unless asked (KEEP_RAW=1)
+python scripts/top_kernels.py "$TR" 6 > $OUT/kernel_stats_$TAG.md 2>/dev/null
+if [ "${KEEP_RAW:-0}" != 1 ]; then rm -rf $OUT/trace_$TAG $OUT/pmc1_$TAG $OUT/pmc2_$TAG $OUT/pmc3_$TAG $OUT/pmc4_$TAG; fi
 tail -5 $OUT/trace_$TAG.log
