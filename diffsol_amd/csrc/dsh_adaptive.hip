@@ -108,7 +108,10 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
 }  // namespace
 extern "C" {
 int dsh_model_has_adaptive_sens(int model, int64_t size) {
-  if (is_jit_model(model)) return 0;
+  if (is_jit_model(model)) {  // DiffSL / external models in the register-resident form with parameter derivatives (DSH_JIT_HAS_SENS)
+    const JitInfo* ji = jit_info(model);
+    return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 && ji->has_sens && !ji->has_mass && ji->nroots == 0 ? 1 : 0;
+  }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) { ok = adaptive_sens_ok<decltype(mdl)>(); });
   return ok ? 1 : 0;
@@ -308,10 +311,10 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   const bool sched_env = [] { const char* e = std::getenv("DSH_MEMBER_SCHED"); return e && e[0] == '1'; }();
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
     const JitInfo* ji = jit_info(model);
-    const bool sched = sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
+    const bool sched = !sens && sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
     // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
     const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }());  // models with a mass matrix: k_bdf_lane_banded only
-    const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + ">";
+    const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + (sens ? ", false, true>" : ">");  // SENS: <.., SEG = false, SENS = true>
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
                              : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;
     rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : (lane_v2 ? "dsh_lane_banded_kernel.hpp" : "dsh_adaptive_kernel.hpp"), name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,

@@ -279,40 +279,37 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   ode->ode_solver = ode_solver;
   ode->settings = std::make_shared<Settings>();
   dshs_default_options(&ode->settings->o);
-  // dimensions first (any target), then the form that fits them
-  char* src = nullptr;
-  int64_t dims[10];
-  if (dshs_diffsl_generate(code, DSHS_DIFFSL_HOST_C, &src, dims, nullptr, 0) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
-  dshs_free_string(src);
-  std::vector<double> defaults((size_t)std::max<int64_t>(dims[1], 1), 0.0);  // one default per declared input, however many there are
-  if (dshs_diffsl_generate(code, DSHS_DIFFSL_HOST_C, &src, dims, defaults.data(), (int64_t)defaults.size()) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
-  dshs_free_string(src);
-  const bool is_static = dims[0] <= 8 && dims[2] <= 1;
-  if (dshs_diffsl_generate(code, is_static ? DSHS_DIFFSL_HIP_STATIC : DSHS_DIFFSL_HIP_DYNAMIC, &src, dims, nullptr, 0) != 0) { C_ERROR(std::string(dshs_last_error())); return nullptr; }
-  ode->n = dims[0]; ode->np = dims[1]; ode->nroots = dims[2]; ode->nout = dims[3]; ode->has_mass = dims[4] != 0; ode->no_inputs = dims[5] != 0;
-  defaults.resize((size_t)ode->np);
-  ode->defaults = defaults;
+  // ONE parse / differentiation of the text (it takes seconds for the 290 000-line DFN model): dimensions, input defaults, the out_i shape and every device form
+  // are read off the same diffsl::Compiled
   int id = -1;
-  int rc = dsh_model_compile(src, is_static ? DSH_JIT_FORM_STATIC : DSH_JIT_FORM_DYNAMIC, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &id);
-  dshs_free_string(src);
-  if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
-  ode->model = id;
-  dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
-  try {  // out_i { u_i } (the outputs are the states, component by component): solve_fwd_sens then needs no output derivatives
+  try {
     const diffsl::Compiled c = diffsl::compile(code);
+    const int64_t dims[10] = {c.n, c.np, c.nroots, c.nout, c.has_mass ? 1 : 0, c.dummy_param ? 1 : 0, c.jac_kl, c.jac_ku, c.mass_kl, c.mass_ku};
+    const bool is_static = dims[0] <= 8 && dims[2] <= 1;
+    ode->n = dims[0]; ode->np = dims[1]; ode->nroots = dims[2]; ode->nout = dims[3]; ode->has_mass = dims[4] != 0; ode->no_inputs = dims[5] != 0;
+    ode->defaults.assign((size_t)ode->np, 0.0);
+    for (size_t k = 0; k < ode->defaults.size() && k < c.input_defaults.size(); ++k) ode->defaults[k] = c.input_defaults[k];
+    const std::string src = diffsl::generate(c, is_static ? diffsl::Target::HipStatic : diffsl::Target::HipDynamic);
+    const int rc = dsh_model_compile(src.c_str(), is_static ? DSH_JIT_FORM_STATIC : DSH_JIT_FORM_DYNAMIC, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &id);
+    if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
+    ode->model = id;
+    dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
+    // out_i { u_i } (the outputs are the states, component by component): solve_fwd_sens then needs no output derivatives
     ode->out_is_state = (int64_t)c.out.size() == ode->n;
     for (size_t i = 0; i < c.out.size() && ode->out_is_state; ++i) {
       const diffsl::Node& nd = c.g.at(c.out[i]);
       ode->out_is_state = nd.k == diffsl::NK::State && nd.i == (int)i;
     }
-  } catch (...) { ode->out_is_state = false; }
-  // banded run-time-sized model: the same text once more in the lane-per-member form, which per-member / wavefront device-resident solves run on
-  if (!is_static && ode->n <= 64 && (!ode->has_mass || (dims[8] == 0 && dims[9] == 0)) && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4 &&
-      dshs_diffsl_generate(code, DSHS_DIFFSL_HIP_STATIC, &src, nullptr, nullptr, 0) == 0) {
-    int lane = -1;
-    if (dsh_model_compile(src, DSH_JIT_FORM_STATIC_BANDED, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &lane) == 0 && dsh_model_set_twin(id, lane) == 0) ode->lane_model = lane;
-    dshs_free_string(src);
-  }
+    // banded run-time-sized model: the same text once more in the lane-per-member form, which per-member / wavefront device-resident solves run on
+    if (!is_static && ode->n <= 64 && (!ode->has_mass || (dims[8] == 0 && dims[9] == 0)) && ode->nroots <= 8 && std::max(dims[6], dims[7]) <= 4) {
+      int lane = -1;
+      std::string lane_src;
+      bool have = true;
+      try { lane_src = diffsl::generate(c, diffsl::Target::HipStatic); } catch (...) { have = false; }
+      if (have && dsh_model_compile(lane_src.c_str(), DSH_JIT_FORM_STATIC_BANDED, ode->n, ode->np, ode->nroots, ode->nout, ode->has_mass ? 1 : 0, &lane) == 0 && dsh_model_set_twin(id, lane) == 0)
+        ode->lane_model = lane;
+    }
+  } catch (const std::exception& e) { C_ERROR(std::string(e.what())); return nullptr; }
   return ode.release();
 }
 

@@ -264,19 +264,23 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   const bool sorted = group == 1 && prepare_member_order(s);
   const double* params_dev = sorted ? (const double*)s->p_sorted_dev : s->problem.eqn->params().ptr();
   double* out = y_dev;
-  void* tmp_out = nullptr;
+  // every device buffer of this call is released when the function leaves, also by the exceptions check() throws between the allocations (an out-of-memory on
+  // the second output buffer is exactly when leaking the first one would hurt)
+  void *tmp_out = nullptr, *sorted_out = nullptr, *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr, *sens_dev = nullptr,
+       *sens_sorted = nullptr;
+  struct Release {
+    dsh_ctx* c; std::vector<void**> bufs;
+    ~Release() { for (void** q : bufs) if (*q) dsh_free(c, *q); }
+  } release{c, {&tmp_out, &sorted_out, &stats_dev, &status_dev, &troot_dev, &ridx_dev, &ncols_dev, &sens_dev, &sens_sorted}};
   if (!out) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &tmp_out), "adaptive out"); out = (double*)tmp_out; }
   double* user_out = out;
-  void* sorted_out = nullptr;
   if (sorted) { check(dsh_malloc(c, (int64_t)sizeof(double) * nt * n * nb, 0, &sorted_out), "adaptive out (sorted)"); out = (double*)sorted_out; }
-  void *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
   if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "adaptive stats");
   if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "adaptive status");
   if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "adaptive t_root");
   if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "adaptive root_idx");
   if (ncols_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "adaptive ncols");
   int rc;
-  void *sens_dev = nullptr, *sens_sorted = nullptr;
   const int64_t npar = s->problem.eqn->nparams();
   if (s->problem.sens) {
     check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_dev), "adaptive sens out");
@@ -325,7 +329,6 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   if (rc == DSH_OK && t_root_host) rc = dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb);
   if (rc == DSH_OK && root_idx_host) { if (want_ridx) rc = dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb); else std::fill(root_idx_host, root_idx_host + nb, -1); }
   if (rc == DSH_OK && ncols_host) rc = dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb);
-  for (void* q : {tmp_out, sorted_out, stats_dev, status_dev, troot_dev, ridx_dev, ncols_dev, sens_dev, sens_sorted}) if (q) dsh_free(c, q);
   check(rc, "solve_dense_adaptive");
 }
 }  // namespace

@@ -402,8 +402,8 @@ int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, co
 /* The same with FORWARD SENSITIVITIES (problem.bdf_sens(), problem.rs:819-832; Bdf::new_augmented bdf.rs:370-432, sensitivity_solve :934-989, the sensitivity
  * terms of error_control :844-858 and predict_error_control :871-932, interpolate_sens :1162-1215, solve_dense_sensitivities sensitivities.rs:114-260):
  * s_j = dy/dp_j of every parameter integrated alongside, in the same launch — per step and parameter one Newton solve with the factors of the state equations
- * and the shared Convergence, the sensitivity difference arrays rescaled and updated with the states'.  Static ODE models with parameter derivatives, n <= 4,
- * identity mass, no root functions (dsh_model_has_adaptive_sens).  nsens_atol = 0: turn_off_sensitivities_error_control; else sens_rtol / sens_atol_host
+ * and the shared Convergence, the sensitivity difference arrays rescaled and updated with the states'.  ODE models in the register-resident form with parameter
+ * derivatives (built-in, or DiffSL / external models compiled at run time), n <= 4, identity mass, no root functions (dsh_model_has_adaptive_sens).  nsens_atol = 0: turn_off_sensitivities_error_control; else sens_rtol / sens_atol_host
  * (length 1 or n, the same for every parameter and member) put the sensitivities into the error test and the order selection.
  * sens_out: n_eval x np x n x nb (device, batch-fastest per save point and parameter).  Results are bit-identical to the oracle's per-member
  * (group = 1) resp. 64-member lock-step (group = 64) solves with sensitivities in the deterministic-pow mode. */

@@ -1,5 +1,5 @@
 //! `Context` (crates/diffsol-la/src/context/mod.rs:20-68): device + stream + `nbatch`, with the broadcast compatibility rule of the trait's
-//! default `assert_compatible_nbatch`.  One `dsh_ctx` is shared (Arc) by every clone: all users issue work on its one in-order stream, which is
+//! default `assert_compatible_nbatch`.  One `dsh_ctx` is shared (Rc) by every clone: all users issue work on its one in-order stream, which is
 //! what makes the stream-ordered allocation cache of the library safe.
 use crate::error::{check, last_error};
 use crate::ffi;
@@ -7,13 +7,14 @@ use diffsol_la::error::LaError;
 use diffsol_la::Context;
 use std::os::raw::c_void;
 use std::ptr;
-use std::sync::Arc;
+use std::rc::Rc;
 
 #[derive(Debug)]
 pub(crate) struct CtxHandle(pub(crate) *mut ffi::dsh_ctx);
-// the C library serialises work on the context's stream; the handle itself is only freed once (Arc)
-unsafe impl Send for CtxHandle {}
-unsafe impl Sync for CtxHandle {}
+// ONE THREAD PER CONTEXT.  The C context is not thread-safe (record ring and sequence numbers, scratch buffers, the stream-ordered allocation cache, the
+// last-error string): the handle is deliberately neither `Send` nor `Sync` (a raw pointer), so `HipContext`, and every `HipVec` / `HipMat` / `HipLU` that
+// holds a clone of it, stay on the thread that created them.  diffsol's Context / Vector / Matrix / LinearSolver traits do not ask for `Send`.  Ensembles on
+// several GPUs use one process (or one thread with its own context) per device — DESIGN.md 6.
 impl Drop for CtxHandle {
     fn drop(&mut self) {
         unsafe { ffi::dsh_ctx_destroy(self.0) }
@@ -22,7 +23,7 @@ impl Drop for CtxHandle {
 
 #[derive(Clone, Debug)]
 pub struct HipContext {
-    pub(crate) raw: Arc<CtxHandle>,
+    pub(crate) raw: Rc<CtxHandle>,
     pub(crate) nbatch: usize,
 }
 
@@ -38,7 +39,7 @@ impl HipContext {
         if rc < 0 {
             return Err(LaError::Other(format!("dsh_ctx_create: {}", last_error())));
         }
-        Ok(Self { raw: Arc::new(CtxHandle(h)), nbatch: 1 })
+        Ok(Self { raw: Rc::new(CtxHandle(h)), nbatch: 1 })
     }
     pub(crate) fn ptr(&self) -> *mut ffi::dsh_ctx {
         self.raw.0
@@ -49,7 +50,7 @@ impl HipContext {
     }
     /// Two contexts are the same device context if they share the handle (the `nbatch` may differ: broadcast operands).
     pub(crate) fn same_device_context(&self, other: &Self) -> bool {
-        Arc::ptr_eq(&self.raw, &other.raw)
+        Rc::ptr_eq(&self.raw, &other.raw)
     }
 }
 

@@ -20,7 +20,7 @@ pub struct HipLU {
     structure: i32,
 }
 // one host thread per solver (like the reference); the factors live on the context's stream
-unsafe impl Send for HipLU {}
+// (no `Send`: one thread per context, see context.rs)
 
 impl Default for HipLU {
     fn default() -> Self {

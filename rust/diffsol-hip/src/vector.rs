@@ -26,7 +26,7 @@ pub struct DeviceBuf {
     pub(crate) nbytes: usize,
     pub(crate) ctx: HipContext,
 }
-unsafe impl Send for DeviceBuf {}
+// (no `Send`: one thread per context, see context.rs)
 impl DeviceBuf {
     pub(crate) fn new(nbytes: usize, zero: bool, ctx: &HipContext) -> Self {
         let mut p: *mut c_void = ptr::null_mut();

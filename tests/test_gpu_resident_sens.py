@@ -82,6 +82,27 @@ def test_resident_bdf_with_sensitivities_on_the_exponential_decay_snapshot_probl
     _pair(H, O, "exponential_decay", [[0.1, 1.0]], te, 0, 1, (1e-6, [1e-6]), rtol=1e-6, atol=[1e-6, 1e-6])
 
 
+@pytest.mark.parametrize("group", [1, 64])
+def test_resident_bdf_with_sensitivities_of_a_diffsl_model(H, O, det_pow, group):
+    """A DiffSL model with inputs in its register-resident form carries sens_mul / init_sens_mul (forward-mode differentiation by the front end): the same kernel
+    template, instantiated by hiprtc for the user's model with SENS = true.  Robertson's kinetics written in DiffSL with the three rate constants as inputs, and
+    the reference's exponential_decay_problem_diffsl text (parameter-dependent initial state); the checker is the oracle integrating the generated host twin."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl as fe
+    for code, p, te, tol, stol in (
+            (D.ROBERTSON_ODE, robertson_params(150, seed=4), T_EVAL[:6], ROB, (1e-4, [1e-6])),
+            ("in_i { k = 0.1, y0 = 1.0 }\nu_i { x = y0, y = y0 }\nF_i { -k * u_i }\nout_i { u_i }\n",
+             np.stack([0.1 * (1 + np.arange(70) % 7), 1.0 + 0.25 * (np.arange(70) % 5)], axis=1), [float(i) for i in range(0, 10)], dict(rtol=1e-6, atol=[1e-6, 1e-6]), (1e-6, [1e-6]))):
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        assert m.form == fe.FORM_STATIC
+        nb = len(p)
+        s = H.Solver(m, p, nbatch=nb, sens=True, sens_rtol=stol[0], sens_atol=stol[1], **tol)
+        y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=group, want_member_stats=True)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=group, sens_rtol=stol[0], sens_atol=stol[1], **tol)
+        assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
+        assert np.array_equal(mm["stats"].T, sto) and np.array_equal(y, np.transpose(yo, (1, 0, 2))) and np.array_equal(sens, np.transpose(so, (0, 2, 1, 3)))
+
+
 def test_resident_sensitivities_refuse_what_they_do_not_cover(H):
     import diffsol_amd
     dev = diffsol_amd._ffi.load_device_lib()
