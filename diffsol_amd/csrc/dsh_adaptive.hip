@@ -107,6 +107,20 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
                             double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens);
 }  // namespace
 extern "C" {
+// hybrid models whose events are handled INSIDE dsh_bdf_solve_adaptive (move back to the root, apply the reset, restart at first order, go on to the last save
+// point): register-resident form, n <= 4, identity mass, with root functions
+int dsh_model_has_adaptive_reset(int model, int64_t size) {
+  if (is_jit_model(model)) {
+    const JitInfo* ji = jit_info(model);
+    return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? 1 : 0;
+  }
+  bool ok = false;
+  dispatch_static_model(model, size, [&](auto mdl) {
+    using Mdl = decltype(mdl);
+    ok = model_has_reset<Mdl>::value && Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS > 0 && model_band_k<Mdl>::value == 0;
+  });
+  return ok ? 1 : 0;
+}
 int dsh_model_has_adaptive_sens(int model, int64_t size) {
   if (is_jit_model(model)) {  // DiffSL / external models in the register-resident form with parameter derivatives (DSH_JIT_HAS_SENS)
     const JitInfo* ji = jit_info(model);
@@ -311,7 +325,7 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   const bool sched_env = [] { const char* e = std::getenv("DSH_MEMBER_SCHED"); return e && e[0] == '1'; }();
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
     const JitInfo* ji = jit_info(model);
-    const bool sched = !sens && sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC;
+    const bool sched = !sens && sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC && !ji->has_reset;  // the phase-scheduled kernel stops at events
     // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
     const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }());  // models with a mass matrix: k_bdf_lane_banded only
     const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + (sens ? ", false, true>" : ">");  // SENS: <.., SEG = false, SENS = true>

@@ -97,6 +97,8 @@ DSH_UNROLL_N
   constexpr int BK = model_band_k<Mdl>::value;
   constexpr bool BANDED = BK > 0;
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
+  // hybrid models (a reset operator: OdeEquations::reset, DiffSL reset_i) apply the reset at every event and go on, as the reference's solve_dense does
+  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && !BANDED && Mdl::NROOTS > 0;
   constexpr int LN = BANDED ? 1 : N;
   __shared__ double sDt[kNC * LN][64];
   __shared__ double sJ[LN * LN][64];
@@ -899,6 +901,40 @@ DSH_UNROLL_N
       }
       col++;
       if (col < C.r.n_eval) te_next = t_eval[col];
+    }
+    if constexpr (kResets) {
+      if (reason == 3) {
+        // A reset operator is configured (solve_dense, method.rs:774-797): move the state back to the root (state_mut_back, bdf.rs:1232-1262), apply the reset
+        // (apply_reset, bdf.rs:1017-1020 over state.rs:279-306: y <- reset(y, t), dy <- f(y, t)), arm the stop time again and go on — the next step restarts
+        // from the modified state at first order (bdf.rs:1290-1318).  The save points up to the root were written from the step's polynomial above.
+        double yb[N], yr[N], dyr[N];
+        interpolate(t_root, yb);
+        t = t_root;
+        Mdl::reset(t, yb, p, yr);
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) y[i] = yr[i];
+        Mdl::rhs(t, y, p, dyr);
+        if (t < tstop) {
+          has_tstop = true;  // set_stop_time (bdf.rs:1591-1600): on the OLD differences and order, like the reference (the step size may change here)
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          // ---- the `is_state_modified` branch of the next Bdf::step
+          Mdl::root(t, y, p, g0);  // RootFinder::init
+          rf_t0 = t;
+          n_equal_steps = 0;
+          order = 1;               // initialise_diff_to_first_order: columns 0 and 1 only, the others keep what they hold
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) { D[0][i] = y[i]; D[1][i] = dyr[i] * h; }
+          opc = h * sAlpha[1];
+          jacobian_updates(h * sAlpha[1], JState::StepSuccess);
+          has_prev_err = false;
+          if (has_tstop) { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          refresh_wyinv();
+          reason = 0;
+        } else {
+          done = true;  // the event sits on the last save point: TstopReached
+          reason = 0;
+        }
+      }
     }
     if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
       if (col < C.r.n_eval) {

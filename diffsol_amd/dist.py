@@ -20,17 +20,18 @@ def max_shard(n_total, world):
     return (int(n_total) + int(world) - 1) // int(world)
 
 
-def gather_batch_axis(local, n_total, rank, world, group=None):
+def gather_batch_axis(local, n_total, rank, world, group=None, force_collective=False):
     """All-gather `local` ([..., nb_local], batch-fastest like the device layout) along its last axis into [..., n_total] on every rank.
 
     Shards may differ in size by one: each rank pads to the maximum shard size, one all_gather_into_tensor moves the data, the padding is
-    dropped on the way out.  `local` may be a CUDA tensor (RCCL) or a CPU tensor (gloo)."""
+    dropped on the way out.  `local` may be a CUDA tensor (RCCL) or a CPU tensor (gloo).  force_collective: issue the collective also for world == 1 (the
+    GPU tier runs the RCCL call that way on the one GPU it has)."""
     import torch
     import torch.distributed as dist
 
     lo, hi = shard_bounds(n_total, rank, world)
     assert local.shape[-1] == hi - lo, (local.shape, lo, hi)
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     m = max_shard(n_total, world)
     lead = tuple(local.shape[:-1])

@@ -111,7 +111,14 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = m; r.size = sz;
     return r;
   }
-  if (s->problem.eqn->has_reset()) return r;  // hybrid models: the resident kernels stop at an event; the host-driven solve_dense applies the reset and continues
+  if (s->problem.eqn->has_reset()) {
+    // hybrid models: the register-resident BDF applies the reset at every event inside the launch (dsh_model_has_adaptive_reset); every other form stops at an
+    // event, so those models stay on the host-driven solve_dense, which applies the reset and continues
+    int m = 0; int64_t sz = 0;
+    if (r.method != 0 || !s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_reset(m, sz)) return r;
+    r.ok = true; r.model = m; r.size = sz;
+    return r;
+  }
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it
   const char* lane_env = std::getenv("DSH_RESIDENT_LANE");  // "0": keep banded models on the wavefront-per-member kernel (testing / comparison)
   const bool lane_ok = !(lane_env && lane_env[0] == '0');
@@ -605,7 +612,8 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
         if (first_bad >= 1 && first_bad <= (int)OdeSolverError::LinearSolveFailed) throw DiffsolError((OdeSolverError)first_bad, buf);
         throw LaError(first_bad == 20 ? DSH_E_BATCH_MISMATCH : DSH_E_INVALID, buf);
       }
-      if (stop_reason) *stop_reason = (has_roots && rooted == nb) ? DSHS_STOP_ROOT_FOUND : DSHS_STOP_TSTOP_REACHED;
+      // hybrid models go on after their events: the solve ends at the last save point
+      if (stop_reason) *stop_reason = (has_roots && rooted == nb && !s->problem.eqn->has_reset()) ? DSHS_STOP_ROOT_FOUND : DSHS_STOP_TSTOP_REACHED;
       return 0;
     }
     s->resident_roots_valid = false;
