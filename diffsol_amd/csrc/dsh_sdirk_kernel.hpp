@@ -17,6 +17,10 @@ struct SdirkConsts {
   double b[kMaxStages], c[kMaxStages], d[kMaxStages];
   double beta[kMaxStages * kMaxPoly];  // column-major s x poly_order
   double gamma;                        // a(1,1)
+  // forward sensitivities (k_sdirk_resident<.., SENS = true>; problem.tr_bdf2_sens() / esdirk34_sens()): as in AdaptiveConsts (dsh_adaptive_kernel.hpp)
+  double* sens_out;                    // n_eval x NP x N x nb
+  double sens_rtol, sens_atol[4];
+  int sens_error_control, sens_pad;
 };
 
 // the run-time-compiled banded form (state in per-lane memory) is built for a fixed occupancy like the BDF kernel (dsh_jit.hip defines the macro)
@@ -25,7 +29,7 @@ struct SdirkConsts {
 #else
 #define DSH_SDIRK_OCCUPANCY
 #endif
-template <class Mdl, bool BA, bool WAVE, int S>
+template <class Mdl, bool BA, bool WAVE, int S, bool SENS = false>
 __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const SdirkConsts* __restrict__ Cp,
                                                        const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                        int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,
@@ -92,6 +96,33 @@ DSH_UNROLL_N
   bool has_prev_err = false;
   double prev_err = 0.0;
   int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
+  // ---- forward sensitivities (runge_kutta.rs:196-232 new_augmented, :691-748 the sensitivity half of do_stage_sdirk, :812-822 error norm, :1237-1330
+  // interpolate_sens; RkState::new_with_sensitivities_and_consistent state.rs:1032-1083).  Per-lane arrays in scratch memory, indexed by the parameter at run time.
+  constexpr int NPS = SENS ? NP : 1, NS = SENS ? N : 1, SS = SENS ? S : 1;
+  static_assert(!SENS || (!Mdl::HAS_MASS && model_band_k<Mdl>::value == 0 && Mdl::NROOTS == 0),
+                "device-resident forward sensitivities: register-resident ODE models without root functions");
+  double sv[NPS][NS], dsv[NPS][NS], old_sv[NPS][NS], old_dsv[NPS][NS], sdiff[NPS][SS][NS];
+  double s_atol[NS];
+  if constexpr (SENS) {
+DSH_UNROLL_N
+    for (int i = 0; i < N; ++i) s_atol[i] = T.sens_atol[i];
+    for (int j = 0; j < NP; ++j) {
+      double ev[NP], s0[N], jm[N], dfdp[N];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) ev[q] = q == j ? 1.0 : 0.0;
+      Mdl::init_sens_mul(t, p, ev, s0);
+      Mdl::sens_mul(t, y, p, ev, dfdp);  // SensRhs::update_state(y0, t0)
+      Mdl::jac_mul(t, y, p, s0, jm);     // SensRhs::call_inplace: J(y0) s_j + (df/dp)_j
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) {
+        const double d0 = jm[i] + dfdp[i];
+        sv[j][i] = s0[i]; dsv[j][i] = d0; old_sv[j][i] = s0[i]; old_dsv[j][i] = d0;
+      }
+      for (int m = 0; m < S; ++m)
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) sdiff[j][m][i] = 0.0;
+    }
+  }
 
   // SdirkCallable::jacobian_inplace (op/sdirk.rs:266-296) + LU: M - (c h) f'(phi + c x)
   auto reset_jacobian = [&](const double (&xx)[N], double tt) __attribute__((always_inline)) {
@@ -149,6 +180,18 @@ DSH_UNROLL_N
       n_setups++;
     }
   };
+  if constexpr (SENS) {
+    // Sdirk::new_augmented ends with jacobian_updates(h, Checkpoint) (sdirk.rs:251): with sensitivities the first linearisation is made at construction, at t0 and
+    // — phi still being zero — about gamma y0; Checkpoint always refreshes the right-hand side's Jacobian (jacobian_update.rs)
+    if (status == kRsOk) {
+      jac_stale = true;
+      reset_jacobian(y, t);
+      ju.update_rhs_jacobian(h);
+      ju.update_jacobian(h);
+      conv.eta = C.eta_reset;
+      n_setups++;
+    }
+  }
   // handle_tstop (runge_kutta.rs:752-781): 0 nothing, 1 reached, 2 StopTimeBeforeCurrentTime
   bool has_tstop = true;
   const double tstop = t_eval[C.n_eval - 1];
@@ -225,6 +268,11 @@ DSH_UNROLL_N
       if (skip_first) {
 DSH_UNROLL_N
         for (int i = 0; i < N; ++i) diff[0][i] = hh * dy[i];  // start_step_attempt (runge_kutta.rs:505-516)
+        if constexpr (SENS) {  // "sensitivities too" (:518-523)
+          for (int j = 0; j < NP; ++j)
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) sdiff[j][0][i] = hh * dsv[j][i];
+        }
       }
       bool failed = false;
 #pragma unroll
@@ -287,7 +335,66 @@ DSH_UNROLL_N
         if (solved) {
 DSH_UNROLL_N
           for (int r = 0; r < N; ++r) { old_y[r] = op_c * k[r] + 1.0 * phi[r]; diff[i][r] = k[r]; }  // get_f_eval; diff.column_mut(i)
-        } else {
+        }
+        if constexpr (SENS) {
+          if (solved) {
+            // the sensitivity half of do_stage_sdirk (:691-748): SensRhs linearised about this stage's state (old_state.y = f_eval, ts); per parameter phi and
+            // the stage predictor from ITS difference array, a Newton solve of F(k) = k - h (J (phi + c k) + (df/dp)_j) with the factors of the state
+            // equations and the shared Convergence (the norm against s_j with the states' tolerances); the iteration count is added before the failure test
+            for (int j = 0; j < NP && solved; ++j) {
+              double ev[NP], dfdp[N], sphi[N], ks[N];
+#pragma unroll
+              for (int q = 0; q < NP; ++q) ev[q] = q == j ? 1.0 : 0.0;
+              Mdl::sens_mul(ts, old_y, p, ev, dfdp);
+DSH_UNROLL_N
+              for (int r = 0; r < N; ++r) {
+                if (i == 0) sphi[r] = sv[j][r] * 1.0;
+                else {
+                  double acc = 1.0 * sdiff[j][0][r] * T.a[0 * S + i] + 1.0 * sv[j][r];
+#pragma unroll
+                  for (int m = 1; m < i; ++m) acc = 1.0 * sdiff[j][m][r] * T.a[m * S + i] + acc;
+                  sphi[r] = acc;
+                }
+              }
+              if (i == 0) {
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) ks[r] = hh * dsv[j][r];
+              } else if (i == 1) {
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) ks[r] = sdiff[j][0][r];
+              } else {
+                const double cc = (T.c[i] - T.c[i - 2]) / (T.c[i - 1] - T.c[i - 2]);
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) ks[r] = (-cc) * sdiff[j][i - 2][r] + (1.0 + cc) * sdiff[j][i - 1][r];
+              }
+              conv.reset();
+              bool s_solved = false;
+              for (int it = 0; it < conv.max_iter; ++it) {
+                double tmp[N], jm[N], delta[N];
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) tmp[r] = op_c * ks[r] + 1.0 * sphi[r];
+                Mdl::jac_mul(ts, old_y, p, tmp, jm);
+                const double beta = -op_h;
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) {
+                  const double fr = jm[r] + dfdp[r];
+                  delta[r] = 1.0 * ks[r] + beta * fr;
+                }
+                if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) break;
+DSH_UNROLL_N
+                for (int r = 0; r < N; ++r) ks[r] = ks[r] - delta[r];
+                const ConvStatus st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, sv[j], atol, rtol))));
+                if (st == ConvStatus::Converged) { s_solved = true; break; }
+                if (st == ConvStatus::Diverged) break;
+              }
+              n_newton += conv.niter;
+              if (!s_solved) { solved = false; break; }
+DSH_UNROLL_N
+              for (int r = 0; r < N; ++r) { old_sv[j][r] = op_c * ks[r] + 1.0 * sphi[r]; old_dsv[j][r] = ks[r]; sdiff[j][i][r] = ks[r]; }
+            }
+          }
+        }
+        if (!solved) {
           if (!updated_jacobian) {
             updated_jacobian = true;
             jacobian_updates(hh, JState::FirstConvergenceFail);
@@ -333,6 +440,20 @@ DSH_UNROLL_N
       else err_ok = lu_solve_reg<N>(A, P, err);
       if (!group_all<WAVE>(err_ok)) { status = kRsTooManyNonlinearSolverFailures; break; }
       error_norm = fmax(0.0, group_norm<WAVE>(wms<N>(err, y, atol, rtol)));
+      if constexpr (SENS) {
+        if (T.sens_error_control)  // runge_kutta.rs:812-822 — no linear solve on the sensitivity error estimates
+          for (int j = 0; j < NP; ++j) {
+            double se[N];
+DSH_UNROLL_N
+            for (int r = 0; r < N; ++r) {
+              double acc = 1.0 * sdiff[j][0][r] * T.d[0];
+#pragma unroll
+              for (int m = 1; m < S; ++m) acc = 1.0 * sdiff[j][m][r] * T.d[m] + acc;
+              se[r] = acc;
+            }
+            error_norm = fmax(error_norm, group_norm<WAVE>(wms<N>(se, sv[j], s_atol, T.sens_rtol)));
+          }
+      }
       const double maxiter = (double)conv.max_iter, niter = (double)conv.niter;
       const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       {  // Rk::factor (runge_kutta.rs:466-495)
@@ -370,6 +491,15 @@ DSH_UNROLL_N
         old_y[r] = y[r]; old_dy[r] = dy[r];
         y[r] = ny; dy[r] = ndy;
       }
+      if constexpr (SENS) {  // old_ds_j *= 1/h; swap(old_s, s); swap(old_ds, ds)
+        for (int j = 0; j < NP; ++j)
+DSH_UNROLL_N
+          for (int r = 0; r < N; ++r) {
+            const double ns = old_sv[j][r], nds = old_dsv[j][r] * inv_h;
+            old_sv[j][r] = sv[j][r]; old_dsv[j][r] = dsv[j][r];
+            sv[j][r] = ns; dsv[j][r] = nds;
+          }
+      }
       const double nt = t + hh;
       old_t = t;
       t = nt;
@@ -394,6 +524,49 @@ DSH_UNROLL_N
       interpolate(t_eval[col], yv);
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) if (active) y_out[((int64_t)col * N + i) * nb + b] = yv[i];
+      if constexpr (SENS) {  // interpolate_sens_inplace (runge_kutta.rs:1237-1330): the state's interpolant on (old_s, s, sdiff_j)
+        const double tt = t_eval[col];
+        const double dt = t - old_t;
+        const double theta = dt == 0.0 ? 1.0 : (tt - old_t) / dt;
+        double bf[S];
+        if (T.has_beta) {
+          double thetav[kMaxPoly];
+          thetav[0] = theta;
+#pragma unroll
+          for (int q = 1; q < kMaxPoly; ++q) thetav[q] = theta * thetav[q - 1];
+#pragma unroll
+          for (int i = 0; i < S; ++i) {
+            double acc = 1.0 * T.beta[0 * S + i] * thetav[0];
+#pragma unroll
+            for (int q = 1; q < kMaxPoly; ++q) if (q < T.poly_order) acc = 1.0 * T.beta[q * S + i] * thetav[q] + acc;
+            bf[i] = acc;
+          }
+        }
+        for (int j = 0; j < NP; ++j) {
+          double ret[N];
+          if (T.has_beta) {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              double acc = 1.0 * sdiff[j][0][i] * bf[0] + 1.0 * old_sv[j][i];
+#pragma unroll
+              for (int m = 1; m < S; ++m) acc = 1.0 * sdiff[j][m][i] * bf[m] + acc;
+              ret[i] = acc;
+            }
+          } else {
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) {
+              double r = sv[j][i] - old_sv[j][i];
+              r = (1.0 * (theta - 1.0)) * sdiff[j][0][i] + (1.0 - 2.0 * theta) * r;
+              r = (1.0 * theta) * sdiff[j][S - 1][i] + 1.0 * r;
+              r = (1.0 - theta) * old_sv[j][i] + (theta * (theta - 1.0)) * r;
+              r = theta * sv[j][i] + 1.0 * r;
+              ret[i] = r;
+            }
+          }
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) if (active) T.sens_out[(((int64_t)col * NP + j) * N + i) * nb + b] = ret[i];
+        }
+      }
       col++;
     }
     if (reason == 3) {  // state_mut_back(root_time); the column after the drained ones holds the state at the root
@@ -410,9 +583,14 @@ DSH_UNROLL_N
   }
   if (active) {
     if (ncols_out != nullptr) ncols_out[b] = col;
-    for (; col < C.n_eval; ++col)  // columns that were never reached (root stop or error exit): NaN
+    for (; col < C.n_eval; ++col) {  // columns that were never reached (root stop or error exit): NaN
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");
+      if constexpr (SENS)
+        for (int j = 0; j < NP; ++j)
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) T.sens_out[(((int64_t)col * NP + j) * N + i) * nb + b] = __builtin_nan("");
+    }
     if (status_out != nullptr) status_out[b] = status;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;

@@ -11,6 +11,7 @@
 // State per lane (n = 4, s = 4): stage derivatives diff (n x s), state/old state (y, dy), φ, LU factors in registers; cached Jacobian in LDS.
 // Arithmetic is the oracle's operation for operation (oracle/oracle_sdirk.hpp); pow()/sin() are ocml's.
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "dsh_internal.hpp"
@@ -41,9 +42,43 @@ int dsh_model_has_resident(int method, int model, int64_t size) {
   return ok ? 1 : 0;
 }
 
+}  // extern "C"
+namespace {
+struct SdirkSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
+template <class Mdl> constexpr bool sdirk_sens_ok() {
+  if constexpr (model_has_sens<Mdl>::value) return Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS == 0 && model_band_k<Mdl>::value == 0;
+  else return false;
+}
+int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                              double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens);
+}  // namespace
+extern "C" {
 int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                              double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  return sdirk_solve_resident_impl(ctx, method, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols,
+                                   totals_host, nullptr);
+}
+// TR-BDF2 / ESDIRK34 with forward sensitivities in the same launch (dsh_bdf_solve_adaptive_sens is the BDF): the same models (dsh_model_has_adaptive_sens)
+int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                  double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
+                                  const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
+  DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
+  if (!dsh_model_has_adaptive_sens(model, size)) {
+    set_error("dsh_sdirk_solve_resident_sens: the model has no device-resident integrator with forward sensitivities (register-resident ODE model with parameter derivatives, n <= 4, no root functions)");
+    return DSH_E_UNSUPPORTED;
+  }
+  const SdirkSensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
+  return sdirk_solve_resident_impl(ctx, method, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, nullptr, nullptr, nullptr,
+                                   totals_host, &sp);
+}
+}  // extern "C"
+namespace {
+int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                              double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(method == 1 || method == 2, "method must be 1 (TR-BDF2) or 2 (ESDIRK34)");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
@@ -53,6 +88,7 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   if (!dsh_model_has_resident(method, model, size)) { set_error("dsh_sdirk_solve_resident: model has no device-resident kernel (needs a static model, n <= 4)"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   SdirkConsts T;
+  std::memset((void*)&T, 0, sizeof T);
   T.r.rtol = rtol; T.r.t0 = t0; T.r.h0 = h0; T.r.n_eval = (int)n_eval;
   if (opts) T.r.o = *opts; else dsh_adaptive_default_options(&T.r.o);
   if (T.r.o.max_steps <= 0) T.r.o.max_steps = 10000000;
@@ -61,6 +97,13 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   T.r.eta_reset_ts = std::pow(100.0, 1.25);
   T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   fill_tableau(method, T);
+  if (sens) {
+    T.sens_out = sens->out; T.sens_rtol = sens->rtol; T.sens_error_control = sens->natol > 0 ? 1 : 0;
+    int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;
+    if (dsh_model_info(model, size, &ns, &npar_, &hm_, &nroots_) != DSH_OK) return DSH_E_INVALID;
+    DSH_REQUIRE(sens->natol == 0 || sens->natol == 1 || sens->natol == ns, "sens_atol must have length 1 or nstates");
+    for (int64_t i = 0; i < 4 && i < ns; ++i) T.sens_atol[i] = sens->natol == 0 ? 0.0 : (sens->natol == 1 ? sens->atol_host[0] : sens->atol_host[i]);
+  }
   double* t_eval_dev = nullptr;
   unsigned long long* totals_dev = nullptr;
   SdirkConsts* consts_dev = nullptr;
@@ -77,10 +120,24 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
-    const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (wave ? "true" : "false") + ", " + (method == 1 ? "3" : "4") + ">";
+    const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (wave ? "true" : "false") + ", " + (method == 1 ? "3" : "4") + (sens ? ", true>" : ">");
     rc = jit_launch(ctx, model, "dsh_sdirk_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
                     status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) return rc;
+  } else if (sens) {
+    dispatch_static_model(model, size, [&](auto mdl) {
+      using Mdl = decltype(mdl);
+      if constexpr (sdirk_sens_ok<Mdl>()) {
+#define DSH_SDIRK_SENS_LAUNCH(BA, WAVE, S)                                                                                                                              \
+  hipLaunchKernelGGL((k_sdirk_resident<Mdl, BA, WAVE, S, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, \
+                     y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+#define DSH_SDIRK_SENS_LAUNCH_S(BA, WAVE) do { if (method == 1) DSH_SDIRK_SENS_LAUNCH(BA, WAVE, 3); else DSH_SDIRK_SENS_LAUNCH(BA, WAVE, 4); } while (0)
+        if (ba) { if (wave) DSH_SDIRK_SENS_LAUNCH_S(true, true); else DSH_SDIRK_SENS_LAUNCH_S(true, false); }
+        else { if (wave) DSH_SDIRK_SENS_LAUNCH_S(false, true); else DSH_SDIRK_SENS_LAUNCH_S(false, false); }
+#undef DSH_SDIRK_SENS_LAUNCH_S
+#undef DSH_SDIRK_SENS_LAUNCH
+      }
+    });
   } else
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
@@ -107,5 +164,4 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
   if (totals_host) for (int q = 0; q < 6; ++q) totals_host[q] = (int64_t)totals[q];
   return DSH_OK;
 }
-
-}  // extern "C"
+}  // namespace

@@ -107,7 +107,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     // forward sensitivities: the register-resident BDF integrates them alongside (k_bdf_adaptive<.., SENS>; static ODE models, n <= 4, no root functions) on an
     // explicit request (dshs_solve_dense_adaptive_sens); dshs_solve_dense keeps the host-driven path, whose solver state dshs_interpolate_sens reads
     int m = 0; int64_t sz = 0;
-    if (for_auto || r.method != 0 || s->problem.eqn->has_reset() || !s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_sens(m, sz)) return r;
+    if (for_auto || s->problem.eqn->has_reset() || !s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_sens(m, sz)) return r;
     r.ok = true; r.model = m; r.size = sz;
     return r;
   }
@@ -293,9 +293,14 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
     check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_dev), "adaptive sens out");
     if (sorted) check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_sorted), "adaptive sens out (sorted)");
     const std::vector<double> sa = s->problem.sens_error_control ? s->problem.sens_atol.clone_as_vec() : std::vector<double>();
-    rc = dsh_bdf_solve_adaptive_sens(c, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
-                                     s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
-                                     (int32_t*)status_dev, totals);
+    if (method == 0)
+      rc = dsh_bdf_solve_adaptive_sens(c, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
+                                       s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
+                                       (int32_t*)status_dev, totals);
+    else
+      rc = dsh_sdirk_solve_resident_sens(c, method, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
+                                         s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
+                                         (int32_t*)status_dev, totals);
     if (rc == DSH_OK && sorted) rc = dsh_permute_members(c, nt * npar * n, nb, 8, sens_sorted, (const int32_t*)s->inv_dev, sens_dev);
     // [col][parameter][state][b] on the device -> [parameter][col][b][state] on the host (one y-shaped array per parameter: solve_dense_sensitivities' Vec<M>)
     for (int64_t k = 0; k < nt && rc == DSH_OK; ++k)

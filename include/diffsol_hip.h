@@ -418,6 +418,13 @@ int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t n
                                 double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
                                 const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status,
                                 int64_t* totals_host);
+/* dsh_sdirk_solve_resident with FORWARD SENSITIVITIES (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:196-232 new_augmented, :691-748 the sensitivity half
+ * of do_stage_sdirk, :812-822 sensitivities in the error norm, :1237-1330 interpolate_sens; sdirk.rs:251 the linearisation at construction): arguments and scope as
+ * dsh_bdf_solve_adaptive_sens, method = 1 (TR-BDF2) or 2 (ESDIRK34). */
+int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                  double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
+                                  const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status,
+                                  int64_t* totals_host);
 /* Device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): Sdirk::step (ode_solver/sdirk.rs:409-543) + Rk core (runge_kutta.rs) + consistent DAE initialisation
  * (state.rs:84-162) + RootFinder (nonlinear_solver/root.rs) + solve_dense (method.rs:467-520) per member, one launch per ensemble solve.  Static models with
  * n <= 4, mass matrices and root functions included, and the banded lane-per-member form as above (dsh_model_has_resident).  A member that finds a root stops there: its column after the drained save points holds

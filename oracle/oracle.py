@@ -293,9 +293,9 @@ def solve_dense_independent(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(
     return y, stats, int(failed)
 
 
-def solve_dense_independent_sens(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, sens_rtol=None, sens_atol=None, nthreads=1, group=1,
-                                 options=None):
-    """solve_dense_sensitivities per member (group > 1: per lock-step group of `group` members): BDF with forward sensitivities (problem.bdf_sens());
+def solve_dense_independent_sens(model, p, t_eval, *, model_size=0, rtol=1e-6, atol=(1e-6,), t0=0.0, h0=1.0, method=METHOD_BDF, sens_rtol=None, sens_atol=None,
+                                 nthreads=1, group=1, options=None):
+    """solve_dense_sensitivities per member (group > 1: per lock-step group of `group` members): BDF / TR-BDF2 / ESDIRK34 with forward sensitivities (problem.bdf_sens(), .tr_bdf2_sens(), .esdirk34_sens());
     sens_atol None: turn_off_sensitivities_error_control.  Returns y [nsys, nt, n], sens [np, nsys, nt, n], stats [nsys, 5], nfailed."""
     p = np.ascontiguousarray(p, dtype=np.float64)
     nsys, np_ = p.shape
@@ -311,10 +311,10 @@ def solve_dense_independent_sens(model, p, t_eval, *, model_size=0, rtol=1e-6, a
     y = np.empty((nsys, te.size, n))
     sens = np.full((np_, nsys, te.size, n), np.nan)
     stats = np.zeros((nsys, 5), dtype=np.int64)
-    f = lib().orc_solve_dense_independent_sens
+    f = lib().orc_solve_dense_independent_sens_method
     f.restype = C.c_int
     failed = f(C.c_int(model), C.c_int(model_size), C.c_int(nsys), p.ctypes.data_as(_dp), C.c_int(np_), C.c_double(rtol), a_ptr, C.c_int(a_arr.size), C.c_double(t0),
-               C.c_double(h0), te_ptr, C.c_int(te.size), C.c_int(nthreads), C.c_int(group), C.c_double(0.0 if sens_rtol is None else sens_rtol), sa_ptr, C.c_int(sa.size),
+               C.c_double(h0), C.c_int(method), te_ptr, C.c_int(te.size), C.c_int(nthreads), C.c_int(group), C.c_double(0.0 if sens_rtol is None else sens_rtol), sa_ptr, C.c_int(sa.size),
                y.ctypes.data_as(_dp), sens.ctypes.data_as(_dp), stats.ctypes.data_as(C.POINTER(C.c_long)))
     return y, sens, stats, int(failed)
 

@@ -334,7 +334,8 @@ static int solve_dense_independent_impl(int model_id, int model_size, int nsys, 
             if (sens_rq && sens_out) {  // dense_write_out_sensitivities (sensitivities.rs): interpolate_sens at the save point; sens_out [np][nsys][nt][n]
               std::vector<V> sv_s;
               Bdf* bb = dynamic_cast<Bdf*>(&sv);
-              if (!bb || bb->interpolate_sens(t_eval[col], sv_s) != OdeErr::Ok) { ok = false; break; }
+              Sdirk* kk = dynamic_cast<Sdirk*>(&sv);
+              if ((!bb && !kk) || (bb ? bb->interpolate_sens(t_eval[col], sv_s) : kk->interpolate_sens(t_eval[col], sv_s)) != OdeErr::Ok) { ok = false; break; }
               for (size_t q = 0; q < sv_s.size(); ++q)
                 for (int b = 0; b < cnt; ++b)
                   std::memcpy(sens_out + (((size_t)q * nsys + (size_t)(s0 + b)) * nt + col) * n, sv_s[q].d.data() + (size_t)b * n, sizeof(double) * n);
@@ -400,6 +401,15 @@ int orc_solve_dense_independent(int model_id, int model_size, int nsys, const do
 }
 // solve_dense_sensitivities (sensitivities.rs:114-260) per member / per lock-step group: problem.bdf_sens() for every group, the states and
 // interpolate_sens at every save point.  sens_out [np][nsys][nt][n].  nsens_atol = 0: turn_off_sensitivities_error_control.  BDF, models without root functions.
+int orc_solve_dense_independent_sens_method(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
+                                            double h0, int method, const double* t_eval, int nt, int nthreads, int group, double sens_rtol, const double* sens_atol,
+                                            int nsens_atol, double* y_out, double* sens_out, long* stats_out) {
+  SensRequest rq;
+  rq.on = true; rq.error_control = nsens_atol > 0; rq.rtol = sens_rtol;
+  rq.atol.assign(sens_atol, sens_atol + (nsens_atol > 0 ? nsens_atol : 0));
+  return solve_dense_independent_impl(model_id, model_size, nsys, p, np, rtol, atol, natol, t0, h0, method, t_eval, nt, nthreads, group, y_out, stats_out, nullptr,
+                                      nullptr, nullptr, &rq, sens_out);
+}
 int orc_solve_dense_independent_sens(int model_id, int model_size, int nsys, const double* p, int np, double rtol, const double* atol, int natol, double t0,
                                      double h0, const double* t_eval, int nt, int nthreads, int group, double sens_rtol, const double* sens_atol, int nsens_atol,
                                      double* y_out, double* sens_out, long* stats_out) {

@@ -83,6 +83,34 @@ def test_resident_bdf_with_sensitivities_on_the_exponential_decay_snapshot_probl
 
 
 @pytest.mark.parametrize("group", [1, 64])
+@pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
+@pytest.mark.parametrize("error_control", [False, True])
+def test_resident_sdirk_with_sensitivities_is_bit_identical_to_the_oracle(H, O, det_pow, method, group, error_control):
+    """TR-BDF2 and ESDIRK34 (k_sdirk_resident<.., SENS>, dsh_sdirk_solve_resident_sens): the sensitivity half of do_stage_sdirk (runge_kutta.rs:691-748: per stage and
+    parameter a Newton solve with the factors of the state equations and the shared Convergence, SensRhs linearised about the stage's state), the linearisation made
+    at construction (sdirk.rs:251), the sensitivity terms of the error norm (:812-822), interpolate_sens (:1237-1330: TR-BDF2's Hermite interpolant, ESDIRK34's beta
+    polynomial), against the oracle's solve_dense_sensitivities per member / per 64-member group."""
+    hm = {"tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    kw = dict(sens_rtol=1e-4, sens_atol=[1e-6]) if error_control else {}
+    for model, size, p, te, tol in (("robertson_ode", 1, robertson_params(200, seed=7), T_EVAL[:6], ROB),
+                                    ("exponential_decay", 0, np.stack([0.1 * (1 + np.arange(70) % 7), 1.0 + 0.25 * (np.arange(70) % 5)], axis=1), [float(i) for i in range(0, 10)],
+                                     dict(rtol=1e-6, atol=[1e-6, 1e-6]))):
+        nb = len(p)
+        s = H.Solver(model, p, nbatch=nb, model_size=size, method=hm, sens=True, **kw, **tol)
+        y, sens, tot, m = s.solve_dense_adaptive_sens(te, group=group, want_member_stats=True)
+        yo, so, sto, failed = O.solve_dense_independent_sens(ORACLE_MODEL[model], np.asarray(p, dtype=float), te, model_size=size, nthreads=8, group=group, method=om, **kw, **tol)
+        assert failed == tot["failed_members"] == int((m["status"] != 0).sum()) == 0
+        assert np.array_equal(m["stats"].T, sto), "counters differ"
+        assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
+        assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3))), "sensitivities differ"
+    k, y0 = p[:, 0], p[:, 1]  # exponential decay: analytic derivatives
+    t = np.asarray(te)[:, None]
+    e = np.exp(-k[None, :] * t)
+    assert np.allclose(sens[0, :, :, 0], -t * y0[None, :] * e, rtol=2e-3, atol=2e-4) and np.allclose(sens[1, :, :, 0], e, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("group", [1, 64])
 def test_resident_bdf_with_sensitivities_of_a_diffsl_model(H, O, det_pow, group):
     """A DiffSL model with inputs in its register-resident form carries sens_mul / init_sens_mul (forward-mode differentiation by the front end): the same kernel
     template, instantiated by hiprtc for the user's model with SENS = true.  Robertson's kinetics written in DiffSL with the three rate constants as inputs, and
