@@ -51,6 +51,7 @@ DSH_UNROLL_N
   constexpr int BK = model_band_k<Mdl>::value;
   constexpr bool BANDED = BK > 0;
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
+  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && !BANDED && Mdl::NROOTS > 0;  // hybrid models: events handled in the launch
   constexpr int LN = BANDED ? 1 : N;
   __shared__ double sJ[LN * LN][64];
   double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
@@ -568,6 +569,28 @@ DSH_UNROLL_N
         }
       }
       col++;
+    }
+    if constexpr (kResets) {
+      if (reason == 3) {
+        // A reset operator is configured (solve_dense, method.rs:774-797): state_mut_back(t_root) (runge_kutta.rs:396-434), apply_reset (sdirk.rs:368-374 over
+        // state.rs:279-306: y <- reset(y, t), dy <- f(y, t)), the stop time armed again, then Rk::start_step's branch for a mutated state (:444-464: root finder
+        // re-initialised, stop time checked once more) — a one-step method restarts from (t, y, dy, h) as they are
+        double yb[N], yr[N];
+        interpolate(t_root, yb);
+        t = t_root;
+        Mdl::reset(t, yb, p, yr);
+DSH_UNROLL_N
+        for (int i = 0; i < N; ++i) y[i] = yr[i];
+        Mdl::rhs(t, y, p, dy);
+        if (t < tstop) {
+          has_tstop = true;
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          Mdl::root(t, y, p, g0);
+          rf_t0 = t;
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+        } else done = true;
+        reason = 0;
+      }
     }
     if (reason == 3) {  // state_mut_back(root_time); the column after the drained ones holds the state at the root
       if (col < C.n_eval) {

@@ -112,10 +112,10 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     return r;
   }
   if (s->problem.eqn->has_reset()) {
-    // hybrid models: the register-resident BDF applies the reset at every event inside the launch (dsh_model_has_adaptive_reset); every other form stops at an
+    // hybrid models: the register-resident integrators apply the reset at every event inside the launch (dsh_model_has_adaptive_reset); every other form stops at an
     // event, so those models stay on the host-driven solve_dense, which applies the reset and continues
     int m = 0; int64_t sz = 0;
-    if (r.method != 0 || !s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_reset(m, sz)) return r;
+    if (!s->problem.eqn->fused_model(&m, &sz) || !dsh_model_has_adaptive_reset(m, sz)) return r;  // BDF, TR-BDF2 and ESDIRK34 alike
     r.ok = true; r.model = m; r.size = sz;
     return r;
   }

@@ -399,8 +399,8 @@ int dsh_model_has_adaptive(int model, int64_t size);
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                            int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
-/* HYBRID models (a reset operator: OdeEquations::reset, DiffSL reset_i) in the register-resident form (n <= 4, identity mass): dsh_bdf_solve_adaptive handles every
- * event inside the launch the way the reference's solve_dense does when a reset is configured (method.rs:774-797): the save points up to the root from the step's
+/* HYBRID models (a reset operator: OdeEquations::reset, DiffSL reset_i) in the register-resident form (n <= 4, identity mass): dsh_bdf_solve_adaptive and
+ * dsh_sdirk_solve_resident (runge_kutta.rs:396-464, sdirk.rs:368-374) handle every event inside the launch the way the reference's solve_dense does when a reset is configured (method.rs:774-797): the save points up to the root from the step's
  * polynomial, state moved back to the root (bdf.rs:1232-1262), y <- reset(y, t), dy <- f(y, t) (bdf.rs:1017-1020), stop time armed again, restart from the modified
  * state at first order (bdf.rs:1290-1318), on to the last save point.  Per member with group = 1 (every member its own event times); t_root / root_idx report the
  * member's LAST event.  Bit-identical to the oracle's per-member solve_dense with resets. */

@@ -28,8 +28,11 @@ def det_pow(O):
 SAWTOOTH = "in = [k]\nk { 0.1 }\nu_i { x = 1, y = 1 }\nF_i { -k * x, -0.5 * k * y }\nstop_i { x - 0.6 }\nreset_i { 1.0, 0.9 * y + 0.05 }\n"
 
 
-def test_per_member_events_with_resets_inside_the_resident_bdf_are_bit_identical_to_the_oracle(H, O, det_pow):
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_per_member_events_with_resets_inside_the_resident_integrators_are_bit_identical_to_the_oracle(H, O, det_pow, method):
     from diffsol_amd import diffsl as fe
+    hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
     import diffsol_amd
     m, mid = fe.DiffslModel(SAWTOOTH), D.host_model(O, SAWTOOTH)
     assert m.form == fe.FORM_STATIC
@@ -40,10 +43,10 @@ def test_per_member_events_with_resets_inside_the_resident_bdf_are_bit_identical
     p = k[:, None]
     t_eval = [0.0, 0.7, 3.0, 5.2, 9.9, 10.0, 14.5, 20.0]
     tol = dict(rtol=1e-6, atol=[1e-8])
-    s = H.Solver(m, p, nbatch=nb, **tol)
+    s = H.Solver(m, p, nbatch=nb, method=hm, **tol)
     assert s.ensemble_mode()[1] == 1  # AUTO: an ensemble of a model with root functions runs per member on the device — now also when it has a reset operator
     y, tot, mm = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
-    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, **tol)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, method=om, **tol)
     lr = O.solve_dense_independent.last_roots
     assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
     assert np.array_equal(mm["stats"].T, so), "counters differ"
@@ -55,14 +58,16 @@ def test_per_member_events_with_resets_inside_the_resident_bdf_are_bit_identical
     # closed form of the sawtooth
     per = -np.log(0.6) / k
     for c, t in enumerate(t_eval):
-        ok = ~np.isnan(y[c, :, 0])
-        assert np.allclose(y[c, ok, 0], np.exp(-k[ok] * (t % per[ok])), rtol=2e-4, atol=1e-6)
+        ph = (t % per) / per
+        ok = ~np.isnan(y[c, :, 0]) & (ph > 0.02) & (ph < 0.98)  # away from the jumps (an event located 1e-4 early or late is on the other branch there)
+        assert np.allclose(y[c, ok, 0], np.exp(-k[ok] * (t % per[ok])), rtol=2e-4 if method == "bdf" else 3e-3, atol=1e-6)  # up to ~80 located events add up
     # the same through dshs_solve_dense (AUTO): every save point filled, the solve ends at the last one
     y2, reason = s.solve_dense(t_eval)
     assert reason == 2 and np.array_equal(y2, y, equal_nan=True)
 
 
-def test_a_lockstep_group_of_identical_hybrid_members_resets_together(H, O, det_pow):
+@pytest.mark.parametrize("method", ["bdf", "esdirk34"])
+def test_a_lockstep_group_of_identical_hybrid_members_resets_together(H, O, det_pow, method):
     """group = 64: the reference's batched semantics — the members of a group must agree on every event (identical members do)."""
     from diffsol_amd import diffsl as fe
     m, mid = fe.DiffslModel(SAWTOOTH), D.host_model(O, SAWTOOTH)
@@ -70,8 +75,10 @@ def test_a_lockstep_group_of_identical_hybrid_members_resets_together(H, O, det_
     p = np.full((nb, 1), 0.3)
     t_eval = [0.0, 1.0, 2.0, 5.0, 9.0]
     tol = dict(rtol=1e-6, atol=[1e-8])
-    s = H.Solver(m, p, nbatch=nb, **tol)
+    hm = {"bdf": H.METHOD_BDF, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"bdf": O.METHOD_BDF, "esdirk34": O.METHOD_ESDIRK34}[method]
+    s = H.Solver(m, p, nbatch=nb, method=hm, **tol)
     y, tot, mm = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=64)
-    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=2, group=64, **tol)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=2, group=64, method=om, **tol)
     assert failed == 0 and (mm["status"] == 0).all()
     assert np.array_equal(mm["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
