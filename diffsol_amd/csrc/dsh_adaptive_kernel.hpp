@@ -294,9 +294,12 @@ DSH_UNROLL_N
         double ru[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
+          // U = compute_r(order, 1) is stored zero-padded to 6 x 6: the terms m > order add R * (+0) = +-0 to a sum that starts at +0 or 1 and is therefore
+          // never -0 — the sum is unchanged bit for bit, and the per-lane test `m <= order` (two selects per term: a third of this function's instructions
+          // when every lane has its own order) is not needed
           double acc = R[0][k] * U[j * 6 + 0];
 #pragma unroll
-          for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
+          for (int m = 1; m < 6; ++m) acc = R[m][k] * U[j * 6 + m] + acc;
           ru[k] = acc;
         }
 DSH_UNROLL_N
