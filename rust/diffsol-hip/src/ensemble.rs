@@ -45,11 +45,8 @@ pub struct EnsembleSolution {
     pub totals: [i64; 6],
 }
 
-/// `problem.bdf()/tr_bdf2()/esdirk34()` + `solve_dense(t_eval)` for every member, on the device.  Uses the problem's tolerances, options, t0 and h0.
-pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, method: Method, t_eval: &[f64], mode: EnsembleMode) -> Result<EnsembleSolution, LaError> {
-    let eqn = &problem.eqn;
-    let ctx = eqn.ctx.clone();
-    let (nb, n, nt) = (ctx.nbatch(), eqn.nstates, t_eval.len());
+/// `OdeSolverOptions` / `InitialConditionSolverOptions` of the problem as the kernels' option block
+fn adaptive_options(problem: &OdeSolverProblem<HipModelEquations>, mode: EnsembleMode) -> ffi::dsh_adaptive_options {
     let mut o = std::mem::MaybeUninit::<ffi::dsh_adaptive_options>::uninit();
     unsafe { ffi::dsh_adaptive_default_options(o.as_mut_ptr()) };
     let mut o = unsafe { o.assume_init() };
@@ -71,6 +68,15 @@ pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, metho
     o.ic_step_reduction_factor = ic.step_reduction_factor;
     o.ic_armijo_constant = ic.armijo_constant;
     o.group = mode as i32;
+    o
+}
+
+/// `problem.bdf()/tr_bdf2()/esdirk34()` + `solve_dense(t_eval)` for every member, on the device.  Uses the problem's tolerances, options, t0 and h0.
+pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, method: Method, t_eval: &[f64], mode: EnsembleMode) -> Result<EnsembleSolution, LaError> {
+    let eqn = &problem.eqn;
+    let ctx = eqn.ctx.clone();
+    let (nb, n, nt) = (ctx.nbatch(), eqn.nstates, t_eval.len());
+    let o = adaptive_options(problem, mode);
     let ys = HipMat::zeros(n, nt, ctx.clone());
     let c = ctx.ptr();
     let alloc = |bytes: usize| -> *mut c_void {
@@ -143,6 +149,94 @@ pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, metho
         } else {
             last_error()
         }));
+    }
+    Ok(out)
+}
+
+/// States and forward sensitivities of a whole ensemble at `t_eval` from one launch.
+pub struct EnsembleSensSolution {
+    /// `nstates x t_eval.len()` batched matrix of the states
+    pub ys: HipMat,
+    /// one `nstates x t_eval.len()` batched matrix per parameter: `dy/dp_j` at `t_eval[k]` in column k (the `Vec<M>` of `solve_dense_sensitivities`)
+    pub sens: Vec<HipMat>,
+    pub status: Vec<i32>,
+    pub stats: Vec<[i32; 5]>,
+    pub totals: [i64; 6],
+}
+
+/// `problem.bdf_sens()/tr_bdf2_sens()/esdirk34_sens()` + `SensitivitiesOdeSolverMethod::solve_dense_sensitivities(t_eval)` (sensitivities.rs:114-260) for every member,
+/// on the device: `dsh_bdf_solve_adaptive_sens` / `dsh_sdirk_solve_resident_sens` integrate `s_j = dy/dp_j` of every parameter alongside the states in the same launch
+/// (`Bdf::sensitivity_solve` bdf.rs:934-989, the sensitivity half of `do_stage_sdirk` runge_kutta.rs:691-748).  Models in the register-resident form with parameter
+/// derivatives, n <= 4, no mass matrix, no root functions (`dsh_model_has_adaptive_sens`); everything else integrates its sensitivities through the trait seam.
+/// `sens_tol = None` is `turn_off_sensitivities_error_control`.
+pub fn solve_dense_sensitivities_ensemble(
+    problem: &OdeSolverProblem<HipModelEquations>, method: Method, t_eval: &[f64], mode: EnsembleMode, sens_tol: Option<(f64, &[f64])>,
+) -> Result<EnsembleSensSolution, LaError> {
+    let eqn = &problem.eqn;
+    let ctx = eqn.ctx.clone();
+    let (nb, n, np, nt) = (ctx.nbatch(), eqn.nstates, eqn.nparams, t_eval.len());
+    if unsafe { ffi::dsh_model_has_adaptive_sens(eqn.model, eqn.size) } == 0 {
+        return Err(LaError::Other("no device-resident integrator with forward sensitivities for this model (register-resident ODE model with parameter derivatives, n <= 4)".into()));
+    }
+    let o = adaptive_options(problem, mode);
+    let ys = HipMat::zeros(n, nt, ctx.clone());
+    let c = ctx.ptr();
+    let alloc = |bytes: usize| -> *mut c_void {
+        let mut p = ptr::null_mut();
+        check(unsafe { ffi::dsh_malloc(c, bytes as i64, 0, &mut p) }, "dsh_malloc");
+        p
+    };
+    // the kernels write [save point][parameter][state][member]; one n x nt matrix per parameter is gathered from it below
+    let sens_d = alloc(8 * nt * np * n * nb);
+    let (stats_d, status_d) = (alloc(20 * nb), alloc(4 * nb));
+    let mut totals = [0i64; 6];
+    let atol = &problem.atol;
+    let (srtol, satol): (f64, &[f64]) = sens_tol.unwrap_or((0.0, &[]));
+    let rc = if method == Method::Bdf {
+        unsafe {
+            ffi::dsh_bdf_solve_adaptive_sens(
+                c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64, srtol,
+                satol.as_ptr(), satol.len() as i64, ys.ptr(), sens_d as *mut f64, stats_d as *mut i32, status_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else {
+        unsafe {
+            ffi::dsh_sdirk_solve_resident_sens(
+                c, method as i32, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(),
+                nt as i64, srtol, satol.as_ptr(), satol.len() as i64, ys.ptr(), sens_d as *mut f64, stats_d as *mut i32, status_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    };
+    let mut sens = Vec::with_capacity(np);
+    if rc >= 0 {
+        for j in 0..np {
+            let m = HipMat::zeros(n, nt, ctx.clone());
+            for k in 0..nt {
+                // column k of parameter j: n x nb doubles, contiguous in both layouts
+                let src = unsafe { (sens_d as *const f64).add((k * np + j) * n * nb) };
+                let dst = unsafe { m.ptr().add(k * n * nb) };
+                check(unsafe { ffi::dsh_d2d(c, dst as *mut c_void, src as *const c_void, (8 * n * nb) as i64) }, "dsh_d2d");
+            }
+            sens.push(m);
+        }
+    }
+    let fetch = |dev: *mut c_void, host: *mut c_void, bytes: usize| check(unsafe { ffi::dsh_d2h(c, host, dev, bytes as i64) }, "dsh_d2h");
+    let mut out = EnsembleSensSolution { ys, sens, status: vec![0; nb], stats: vec![[0; 5]; nb], totals };
+    if rc >= 0 {
+        let mut flat = vec![0i32; 5 * nb];
+        fetch(stats_d, flat.as_mut_ptr() as *mut c_void, 20 * nb);
+        for b in 0..nb {
+            for k in 0..5 {
+                out.stats[b][k] = flat[k * nb + b];
+            }
+        }
+        fetch(status_d, out.status.as_mut_ptr() as *mut c_void, 4 * nb);
+    }
+    for p in [sens_d, stats_d, status_d] {
+        unsafe { ffi::dsh_free(c, p) };
+    }
+    if rc < 0 {
+        return Err(LaError::Other(last_error()));
     }
     Ok(out)
 }

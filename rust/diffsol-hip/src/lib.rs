@@ -38,7 +38,7 @@ pub mod matrix;
 pub mod vector;
 
 pub use context::HipContext;
-pub use ensemble::{solve_dense_ensemble, EnsembleMode, EnsembleSolution, Method};
+pub use ensemble::{solve_dense_ensemble, solve_dense_sensitivities_ensemble, EnsembleMode, EnsembleSensSolution, EnsembleSolution, Method};
 pub use equations::{HipModelEquations, Model};
 pub use lu::HipLU;
 pub use matrix::{HipMat, HipMatMut, HipMatRef};
