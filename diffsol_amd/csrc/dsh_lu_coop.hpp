@@ -414,11 +414,11 @@ __global__ __launch_bounds__(kCoopThreads) void k_lu_solve_blocked(int n, int64_
 // wavefront; the interchanges are read into LDS and only the rows that really move are visited.  Every element receives the updates of the
 // column-by-column algorithm in its order (v_r = (-v_k) * a_rk + v_r, k ascending for L, descending for U): bit-identical to k_lu_solve_blocked.
 constexpr int kStreamThreads = 512;
-template <int RPT, int D, int B = kSolveBlock>
-__global__ __launch_bounds__(kStreamThreads) void k_lu_solve_stream(int n, int64_t nb, const double* __restrict__ f_aos, const int32_t* __restrict__ piv_aos,
+template <int RPT, int D, int B = kSolveBlock, int T = kStreamThreads>
+__global__ __launch_bounds__(T) void k_lu_solve_stream(int n, int64_t nb, const double* __restrict__ f_aos, const int32_t* __restrict__ piv_aos,
                                                                   double* __restrict__ rhs, unsigned long long* rec, unsigned int seq) {
   extern __shared__ double v[];  // n values, then n pivot rows (int), then the bit mask of the rows that move
-  constexpr int T = kStreamThreads;  // B columns per block step: the fixed cost of a step (two barriers, the diagonal block's chain) is paid n / B times per sweep
+  // B columns per block step: the fixed cost of a step (two barriers, the diagonal block's chain) is paid n / B times per sweep
   const int64_t b = blockIdx.x;
   const double* A = f_aos + (size_t)b * n * n;
   const int tid = threadIdx.x;
