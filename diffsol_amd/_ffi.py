@@ -200,6 +200,7 @@ HOST_ABI = {
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
     "dshs_diffsl_generate": (cint, [C.c_char_p, cint, C.POINTER(vp), c_i64p, c_dp, i64]),
     "dshs_free_string": (None, [vp]),
+    "dshs_diffsl_set_model_index": (cint, [cint]),
     "dshs_solve_dense_adaptive_sens": (cint, [vp, c_dp, i64, cint, cint, c_dp, c_dp, c_i32p, c_i32p, c_i64p]),
     "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
 }

@@ -18,9 +18,11 @@ FORM_STATIC, FORM_DYNAMIC, FORM_STATIC_BANDED = 0, 1, 2
 FAMILY_OPERATORS, FAMILY_FUSED, FAMILY_RESIDENT_BDF, FAMILY_RESIDENT_SDIRK = 0, 1, 2, 3
 
 
-def generate(code, target):
-    """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate."""
+def generate(code, target, model_index=0):
+    """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate.  model_index: the value of the scalar `N` in the text (the reference's
+    DiffSlContext::model_index, 0 by default), a compile-time constant of the generated model."""
     L = _ffi.load_host_lib()
+    check(L.dshs_diffsl_set_model_index(int(model_index)), host=True)
     out = vp()
     dims = (C.c_int64 * 10)()
     check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, None, 0), host=True)  # dimensions first: one default per declared input
@@ -38,13 +40,14 @@ def generate(code, target):
 
 
 class DiffslModel:
-    def __init__(self, code, form=None, lane_resident=True):
+    def __init__(self, code, form=None, lane_resident=True, model_index=0):
         self.code = code
-        _, d, self.defaults = generate(code, TARGET_HOST_C)
+        self.model_index = int(model_index)
+        _, d, self.defaults = generate(code, TARGET_HOST_C, model_index)
         if form is None:
             form = FORM_STATIC if d["n"] <= 8 and d["nroots"] <= 1 else FORM_DYNAMIC
         self.form = form
-        self.source, d, _ = generate(code, TARGET_HIP_STATIC if form == FORM_STATIC else TARGET_HIP_DYNAMIC)
+        self.source, d, _ = generate(code, TARGET_HIP_STATIC if form == FORM_STATIC else TARGET_HIP_DYNAMIC, model_index)
         self.n, self.nparams, self.nroots, self.nout, self.has_mass, self.no_inputs = (d[k] for k in ("n", "nparams", "nroots", "nout", "has_mass", "no_inputs"))
         self._L = _ffi.load_device_lib()
         mid = C.c_int()
@@ -55,7 +58,7 @@ class DiffslModel:
         diag_mass = (not self.has_mass) or (d["band"][2] == 0 and d["band"][3] == 0)  # the lane-per-member banded kernels take a diagonal mass matrix
         if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and diag_mass and max(jkl, jku) <= 4 and self.nroots <= 8:
             # banded Jacobian: the same model once more in the lane-per-member form; per-member device-resident BDF solves run on it (compiled on first use)
-            lane_src = generate(code, TARGET_HIP_STATIC)[0]
+            lane_src = generate(code, TARGET_HIP_STATIC, model_index)[0]
             lid = C.c_int()
             check(self._L.dsh_model_compile(lane_src.encode(), FORM_STATIC_BANDED, self.n, self.nparams, self.nroots, self.nout, 1 if self.has_mass else 0, C.byref(lid)))
             self.lane_model_id = lid.value

@@ -366,6 +366,11 @@ int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_
   });
 }
 void dshs_free_string(char* s) { std::free(s); }
+int dshs_diffsl_set_model_index(int model_index) {
+  if (model_index < 0) { g_err = "dshs_diffsl_set_model_index: the model index is unsigned"; return DSH_E_INVALID; }
+  diffsl::set_model_index(model_index);
+  return 0;
+}
 
 void dshs_default_options(dshs_options* o) {
   o->max_nonlinear_solver_iterations = 10;

@@ -162,6 +162,10 @@ int dshs_solve_dense_adaptive_sens(dshs_solver* s, const double* t_eval, int64_t
 #define DSHS_DIFFSL_HOST_C 2
 int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap);
 void dshs_free_string(char* s);
+/* The reference's DiffSL model index (DiffSlContext::model_index, ode_equations/diffsl.rs:52,115,406-411; the scalar `N` of a DiffSL text, 0 unless
+ * set_params_and_model changes it) for the texts this thread compiles from now on (dshs_diffsl_generate, diffsol_ode_new_jit).  It is a compile-time constant of the
+ * generated model: another index is another compiled model. */
+int dshs_diffsl_set_model_index(int model_index);
 
 #ifdef __cplusplus
 }

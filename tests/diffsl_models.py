@@ -311,13 +311,13 @@ def random_expr(rng, depth, names):
 _cache = {}
 
 
-def host_model(O, code, opt="-O2"):
+def host_model(O, code, opt="-O2", model_index=0):
     """DiffSL text -> CPU model library (product front end, Target::HostC) -> compiled with g++ -> registered with the oracle.  Returns the oracle id."""
-    key = hashlib.sha1(code.encode()).hexdigest()
+    key = hashlib.sha1((code + "#N=%d" % model_index).encode()).hexdigest()
     if key in _cache:
         return _cache[key]
     from diffsol_amd import diffsl
-    src, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C)
+    src, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C, model_index)
     d = tempfile.mkdtemp(prefix="dsl_host_")
     cpp, so = os.path.join(d, "model.cpp"), os.path.join(d, "libmodel.so")
     with open(cpp, "w") as f:

@@ -101,7 +101,7 @@ def test_oracle_solves_the_diffsl_robertson_like_the_built_in_one(O, fe, kats):
     # the model index N must be refused; reset_i (hybrid models) is compiled since round 2 — but has to match u_i
     ("u_i { x = 1, y = 2 } F_i { x, y } stop_i { x - 2 } reset_i { 0.1 }", "reset_i has 1 components but u_i has 2"),
     ("u_i { x = 1 } dudt_i { dxdt = 0 } F_i { x } stop_i { x - 2 } reset_i { dxdt }", "reset_i"),
-    ("u_i { x = 1 } F_i { x * N }", "model index N is not supported"),
+    ("u_i { x = 1 } F_i { x * N_i }", "model index N is a scalar"),
     ("N { 1 } u_i { x = 1 } F_i { x }", "model index N is reserved"),
     # M_i has to be LINEAR in dudt (the mass matrix is assembled from unit vectors)
     ("u_i { x = 1, y = 2 } dudt_i { dxdt = 0, dydt = 0 } M_i { dxdt * dxdt, 0 } F_i { x, y }", "must be linear in dudt"),
@@ -115,6 +115,26 @@ def test_front_end_rejects_malformed_models_with_a_located_message(fe, code, msg
     with pytest.raises(DiffsolHipError) as e:
         fe.generate(code, fe.TARGET_HOST_C)
     assert msg in str(e.value) and "diffsl:" in str(e.value)
+
+
+def test_the_model_index_is_a_constant_of_the_compiled_model(O, fe):
+    """`N` in a DiffSL text is the reference's model index (DiffSlContext::model_index, ode_equations/diffsl.rs:52,115,406-411; 0 unless set_params_and_model changes it).
+    The front end takes it as a compile-time constant (dshs_diffsl_set_model_index): index 0 by default, another index = another compiled model."""
+    code = "in = [k]\nk { 0.5 }\nu_i { x = 1, y = 2 }\nF_i { -(N + 1) * k * x, -k * y + N }\n"
+    p, x = np.array([0.5]), np.array([1.0, 2.0])
+    for idx in (0, 2, 7):
+        mid = D.host_model(O, code, model_index=idx)
+        assert np.array_equal(O.model_rhs(mid, x, p), [-(idx + 1) * 0.5 * 1.0, -0.5 * 2.0 + idx])
+        assert np.array_equal(O.model_jac_mul(mid, x, p, np.array([1.0, 0.0])), [-(idx + 1) * 0.5, 0.0])  # N is a constant: it does not differentiate
+        src, dims, _ = fe.generate(code, fe.TARGET_HIP_STATIC, idx)
+        assert dims["n"] == 2 and dims["nparams"] == 1
+    assert fe.generate(code, fe.TARGET_HIP_STATIC, 0)[0] != fe.generate(code, fe.TARGET_HIP_STATIC, 2)[0]
+    # an integrated check: x(t) = exp(-(N + 1) k t)
+    mid = D.host_model(O, code, model_index=2)
+    o = O.OracleSolver(mid, p, rtol=1e-8, atol=[1e-10])
+    yf, _ = o.solve(1.0)
+    assert abs(yf[0, 0] - np.exp(-3 * 0.5 * 1.0)) < 1e-6
+    fe.generate(code, fe.TARGET_HOST_C, 0)  # back to the default for the texts compiled after this test
 
 
 def test_linear_mass_matrices_with_parameter_coefficients_are_accepted(fe):

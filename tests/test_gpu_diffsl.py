@@ -460,3 +460,25 @@ def test_hybrid_diffsl_models_reset_at_every_event_on_the_device_like_the_oracle
         yo, so, failed = O.solve_dense_independent(mid, p, t_eval, group=nb, method=om, rtol=1e-6, atol=[1e-6])
         assert failed == 0 and reason == 2 and np.array_equal(np.transpose(y, (1, 0, 2)), yo)
         assert abs(yo[0, -1, 1] - 2.0 * yo[0, -1, 0]) < 1e-5 and s.stats()["number_of_steps"] == so[0, 0]
+
+
+def test_the_model_index_of_a_diffsl_text_reaches_the_device_model(H, O, fe):
+    """`N` (the reference's DiffSlContext::model_index) is a compile-time constant of the generated model: the device model compiled for index 2 integrates like the
+    host twin compiled for index 2, bit for bit, and unlike the one for index 0."""
+    code = "in = [k]\nk { 0.5 }\nu_i { x = 1, y = 2 }\nF_i { -(N + 1) * k * x, -k * y + N }\n"
+    p = 0.25 + 0.05 * np.arange(70)[:, None]
+    te = [0.5, 1.0, 2.0]
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    ys = {}
+    for idx in (0, 2):
+        m, mid = fe.DiffslModel(code, model_index=idx), D.host_model(O, code, model_index=idx)
+        O.set_det_pow(True)
+        try:
+            y, tot = H.Solver(m, p, nbatch=len(p), **tol).solve_dense_adaptive(te, group=1)
+            yo, so, failed = O.solve_dense_independent(mid, p, te, nthreads=4, **tol)
+        finally:
+            O.set_det_pow(False)
+        assert failed == 0 and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+        assert np.allclose(y[:, :, 0], np.exp(-(idx + 1) * p[None, :, 0] * np.asarray(te)[:, None]), rtol=1e-4, atol=1e-7)
+        ys[idx] = y
+    assert not np.array_equal(ys[0], ys[2])
