@@ -186,7 +186,7 @@ if __name__ == "__main__":
         out.append(run_spm(a.spm_nb)); print(json.dumps(out[-1]), flush=True)
     if a.only in ("", "heat"):
         out.append(run_heat(a.heat_nb, a.heat_n)); print(json.dumps(out[-1]), flush=True)
-    if a.only in ("", "heat", "heat_dense"):
+    if a.only in ("", "heat_dense"):
         # BASELINE configs[2] says "banded-as-dense LU": the same run with the structure detection off — dense containers, the library's default dense LU for
         # n = 512 (the matrix-core kernel of dsh_lu_tiled.hpp; DSH_LU_EXACT=1 selects the bit-exact blocked kernel instead)
         os.environ["DSH_LU_STRUCTURE"] = "dense"
