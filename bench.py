@@ -239,7 +239,7 @@ def main():
     if not stub and args.spinup_seconds > 0:  # not steps of the measurement: the job is timed at its steady clocks, like any long-running ensemble service
         t_end = time.perf_counter() + args.spinup_seconds
         while time.perf_counter() < t_end:
-            one_step()
+            solve_once()  # the rank's own solves only — no collective: ranks may leave this loop after different numbers of solves
             spun += 1
     for _ in range(args.warmup):
         one_step()
