@@ -143,6 +143,9 @@ def main():
                          "~0.5 s after idle run 3 %% slower in the kernel and with 0.1 ms more host time per solve); 0 disables")
     ap.add_argument("--nb", type=int, default=NB_PER_GPU, help="ensemble members per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-gather", action="store_true",
+                    help="N > 1: wait for every step's trajectory all-gather before the next solve starts (default: the gather of step k runs on RCCL's stream while "
+                         "step k + 1 integrates, two output buffers in turn)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (host-driven lock-step, per-member control, 1.6M members)")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--large-nb", type=int, default=1_600_000)
@@ -171,7 +174,7 @@ def main():
         dist.init_process_group("gloo" if stub else "nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    from diffsol_amd.dist import gather_batch_axis, shard_bounds
+    from diffsol_amd.dist import gather_batch_axis, gather_batch_axis_async, shard_bounds
 
     nb = args.nb
     n_total = nb * world
@@ -203,8 +206,8 @@ def main():
         solver = _CpuStub(params[lo:hi])
         resolved = 64
 
-        def solve_once():
-            return solver.solve_dense_into(out)
+        def solve_once(buf=None):
+            return solver.solve_dense_into(out if buf is None else buf)
     else:
         import diffsol_amd
         from diffsol_amd.solver import ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT, ENSEMBLE_AUTO
@@ -213,25 +216,54 @@ def main():
         _, resolved = solver.ensemble_mode()
         assert resolved == ENSEMBLE_WAVEFRONT, f"solve_dense did not resolve to the device-resident integrator (mode {resolved})"
 
-        def solve_once():
-            solver.solve_dense(T_EVAL, want_host=False, dev_ptr=out.data_ptr())
+        def solve_once(buf=None):
+            solver.solve_dense(T_EVAL, want_host=False, dev_ptr=(out if buf is None else buf).data_ptr())
             mode, tot = solver.last_solve_info()
             assert mode == solver.ensemble_mode()[1], (mode, solver.ensemble_mode())
             return tot
 
+    # N > 1: the all-gather of step k's trajectories overlaps the integration of step k + 1 (RCCL runs on its own stream; the solver's launch is on the solver's
+    # stream): two output buffers in turn, a buffer is handed to the solver again only after the gather that read it has finished.  The timed region ends when the
+    # last gather has finished too (drain).  --no-overlap-gather: gather and wait inside every step.
+    overlap = world > 1 and not args.no_overlap_gather
+    bufs = [out, torch.empty_like(out)] if overlap else [out]
+    pend = [None, None]
+    turn = [0]
+
     def one_step():
-        tot = solve_once()
-        y = gather_batch_axis(out, n_total, rank, world) if world > 1 else out
-        return tot, y
+        if not overlap:
+            tot = solve_once()
+            return tot, (gather_batch_axis(out, n_total, rank, world) if world > 1 else out)
+        i = turn[0] % 2
+        turn[0] += 1
+        if pend[i] is not None:
+            pend[i].finish()
+        tot = solve_once(bufs[i])
+        pend[i] = gather_batch_axis_async(bufs[i], n_total, rank, world)
+        return tot, None
+
+    def drain():
+        """wait for the gathers still in flight; returns the newest gathered trajectory (None if there is none)"""
+        newest = pend[(turn[0] - 1) % 2] if turn[0] > 0 else None
+        y_last = None
+        for q in (pend[turn[0] % 2], newest):  # older first
+            if q is not None:
+                y_last = q.finish()
+        pend[0] = pend[1] = None
+        return y_last
 
     def timed(k, step):
         barrier()
         t0 = time.perf_counter()
         acc = {}
+        y = None
         for _ in range(k):
             tot, y = step()
             for key, v in tot.items():
                 acc[key] = acc.get(key, 0) + v
+        if overlap:
+            yd = drain()
+            y = yd if yd is not None else y
         barrier()
         return time.perf_counter() - t0, acc, y
 
@@ -243,6 +275,8 @@ def main():
             spun += 1
     for _ in range(args.warmup):
         one_step()
+    if overlap:
+        drain()
     if not stub:
         solver.set_kernel_timing(True)  # HIP events around the one launch of every solve (the launch is synchronous anyway: the counters come back)
     elapsed, acc, y = timed(args.steps, one_step)
@@ -316,6 +350,8 @@ def main():
         solver.set_ensemble_mode(ENSEMBLE_LOCKSTEP)
         solver.set_kernel_timing(True)
         solver.reset(); one_step()
+        if overlap:
+            drain()
         nl, nms = solver.kernel_timing()
         solver.set_kernel_timing(False)
         solver.set_ensemble_mode(ENSEMBLE_AUTO)
@@ -367,7 +403,7 @@ def main():
                         "(the reference's batched semantics with nbatch = 64 per group)",
                 "ensemble_mode": resolved, "untimed_spinup_solves": spun, "mean_steps_per_member": member_steps / args.steps / n_total,
                 "mean_newton_iterations_per_member": member_newton / args.steps / n_total, "parallelism": f"ensemble-shard x{world}",
-                "backend": "gloo" if stub else ("nccl" if world > 1 else "none"),
+                "backend": "gloo" if stub else ("nccl" if world > 1 else "none"), "gather": ("overlapped with the next solve" if overlap else ("per step" if world > 1 else "none")),
             },
             "checks": {"finite": finite, "max_mass_conservation_error": mass_err, "failed_members": int(failed)},
         }

@@ -48,6 +48,54 @@ def gather_batch_axis(local, n_total, rank, world, group=None, force_collective=
     return torch.cat(pieces, dim=-1)
 
 
+class PendingGather:
+    """An all-gather of a shard's trajectories that has been issued but not waited for (gather_batch_axis_async).  `finish()` waits — for device tensors it makes
+    the host wait too, because the solver that will overwrite the shard's buffer launches on its OWN stream, which no stream-level wait of torch orders — and
+    returns the gathered [..., n_total] tensor (every rank the same), dropping the padding of uneven shards."""
+
+    def __init__(self, work, flat_in, flat_out, lead, m, n_total, world):
+        self._work, self._flat_in, self._flat_out = work, flat_in, flat_out
+        self._lead, self._m, self._n_total, self._world = lead, m, n_total, world
+        self._result = None
+
+    def finish(self):
+        import torch
+
+        if self._result is None:
+            self._work.wait()
+            if self._flat_out.is_cuda:
+                torch.cuda.current_stream(self._flat_out.device).synchronize()
+            out = self._flat_out.view((self._world,) + self._lead + (self._m,))
+            pieces = []
+            for r in range(self._world):
+                l, h = shard_bounds(self._n_total, r, self._world)
+                pieces.append(out[r][..., : h - l])
+            self._result = torch.cat(pieces, dim=-1)
+            self._flat_in = None
+        return self._result
+
+
+def gather_batch_axis_async(local, n_total, rank, world, group=None):
+    """gather_batch_axis without the wait: the collective is issued (async_op) and a PendingGather comes back, so that the next ensemble solve of this rank runs while
+    the links move the last one's trajectories (bench.py: two output buffers in turn; a buffer is reused only after the gather that read it has finished).  `local` must
+    not be written until `finish()` has returned."""
+    import torch.distributed as dist
+
+    lo, hi = shard_bounds(n_total, rank, world)
+    assert local.shape[-1] == hi - lo, (local.shape, lo, hi)
+    m = max_shard(n_total, world)
+    lead = tuple(local.shape[:-1])
+    if hi - lo == m and local.is_contiguous():
+        flat_in = local.view(-1)  # even shards: the collective reads the solver's buffer itself
+    else:
+        padded = local.new_zeros(lead + (m,))
+        padded[..., : hi - lo] = local
+        flat_in = padded.contiguous().view(-1)
+    flat_out = local.new_empty(world * flat_in.numel())
+    work = dist.all_gather_into_tensor(flat_out, flat_in, group=group, async_op=True)
+    return PendingGather(work, flat_in, flat_out, lead, m, n_total, world)
+
+
 def solve_ensemble_sharded(model, params, t_eval, *, rank, world, device, method=0, model_size=0, gather=True, group=None, solver_factory=None,
                            resident=None, **solver_kw):
     """Integrate this rank's shard of the ensemble and (optionally) gather the interpolated trajectories.

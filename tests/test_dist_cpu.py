@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from diffsol_amd.dist import gather_batch_axis, shard_bounds, solve_ensemble_sharded  # noqa: E402
+from diffsol_amd.dist import gather_batch_axis, gather_batch_axis_async, shard_bounds, solve_ensemble_sharded  # noqa: E402
 
 
 def test_shard_bounds_partition_exactly():
@@ -74,6 +74,21 @@ def _worker(rank, world, port, n_total, q):
         local = torch.arange(lo, hi, dtype=torch.float64).repeat(4, 1)
         g = gather_batch_axis(local, n_total, rank, world)
         ok = ok and torch.equal(g, torch.arange(n_total, dtype=torch.float64).repeat(4, 1))
+        # the overlapped form (bench.py, N > 1): several gathers in flight over two buffers, a buffer reused only after its gather has finished
+        bufs = [torch.empty((3, 2, hi - lo), dtype=torch.float64) for _ in range(2)]
+        pend = [None, None]
+        got = []
+        for k in range(5):
+            i = k % 2
+            if pend[i] is not None:
+                got.append(pend[i].finish())
+            bufs[i].copy_(torch.arange(lo, hi, dtype=torch.float64).repeat(3, 2, 1) + 1000.0 * k)  # "the solve of step k"
+            pend[i] = gather_batch_axis_async(bufs[i], n_total, rank, world)
+        for i in (5 % 2, 4 % 2):  # older first
+            got.append(pend[i].finish())
+        for k, gk in enumerate(got):
+            ok = ok and tuple(gk.shape) == (3, 2, n_total) and torch.equal(gk, torch.arange(n_total, dtype=torch.float64).repeat(3, 2, 1) + 1000.0 * k)
+        ok = ok and len(got) == 5 and got[4] is pend[0].finish()  # finish() is idempotent
         q.put((rank, bool(ok), stats["number_of_steps"]))
     finally:
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ def test_the_trajectory_gather_runs_on_rccl_with_device_tensors():
 
     import diffsol_amd
     from bench import robertson_params, T_EVAL, RTOL, ATOL
-    from diffsol_amd.dist import gather_batch_axis
+    from diffsol_amd.dist import gather_batch_axis, gather_batch_axis_async
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
@@ -31,5 +31,17 @@ def test_the_trajectory_gather_runs_on_rccl_with_device_tensors():
         assert g.shape == out.shape and torch.equal(g, out)
         y_host, _ = s.solve_dense(T_EVAL)
         assert np.array_equal(np.transpose(g.cpu().numpy(), (0, 2, 1)), np.asarray(y_host))
+        # the overlapped form of bench.py (N > 1): the gather of solve k is in flight on RCCL's stream while solve k + 1 runs on the solver's stream; two buffers in turn
+        bufs = [out, torch.empty_like(out)]
+        pend = [None, None]
+        got = []
+        for k in range(6):
+            i = k % 2
+            if pend[i] is not None:
+                got.append(pend[i].finish())
+            s.solve_dense(T_EVAL, want_host=False, dev_ptr=bufs[i].data_ptr())
+            pend[i] = gather_batch_axis_async(bufs[i], nb, 0, 1)
+        got += [pend[0].finish(), pend[1].finish()]
+        assert len(got) == 6 and all(torch.equal(gk, g) for gk in got)
     finally:
         dist.destroy_process_group()
