@@ -409,6 +409,22 @@ def test_rlc_config5_esdirk34_with_threshold_events_is_bit_identical_to_the_orac
         assert 0 < (m["root_idx"] >= 0).sum() < nb
 
 
+@pytest.mark.parametrize("var,k", [("DSH_REBIN", "1"), ("DSH_REBIN", "3"), ("DSH_REBIN_STEPS", "16"), ("DSH_REBIN_STEPS", "100")])
+def test_segmented_per_member_runs_with_rebinning_between_launches_give_the_bits_of_the_single_launch(H, monkeypatch, var, k):
+    """k_bdf_adaptive<.., SEG>: the launch ends for a member after k save points (or k trips of its step loop), the whole per-member integrator state goes to memory,
+    the members are dealt to lanes again in another order (device radix sort on (order, steps since the last change, |h|)) and the next launch resumes.  Nothing of the
+    arithmetic depends on where a launch ends: every output bit, every counter equals the single launch.  (Measured slower than the single launch in every setting —
+    profiles/r03_per_member.md — so it stays an opt-in.)"""
+    p = robertson_params(700, seed=9)
+    s = H.Solver("robertson_ode", p, nbatch=len(p), model_size=1, **ROB)
+    y0, t0, m0 = s.solve_dense_adaptive(T_EVAL, want_member_stats=True, group=1)
+    monkeypatch.setenv(var, k)
+    y1, t1, m1 = s.solve_dense_adaptive(T_EVAL, want_member_stats=True, group=1)
+    monkeypatch.delenv(var)
+    assert np.array_equal(y1, y0) and t1 == t0 and all(np.array_equal(m1[q], m0[q], equal_nan=True) for q in m0)
+    assert t0["failed_members"] == 0 and m0["stats"][0].min() < m0["stats"][0].max()
+
+
 @pytest.mark.parametrize("group", [1, 64])
 def test_the_opt_in_fast_arithmetic_variant_stays_within_1e6_relative_of_the_cpu_result(H, O, group):
     """deterministic_pow = 2 (dsh_adaptive_fast.hip: -ffp-contract=fast, reciprocal-math division, ocml pow, reciprocal Newton weights) is the one kernel of the
