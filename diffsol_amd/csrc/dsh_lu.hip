@@ -448,7 +448,7 @@ static int lu_solve_launch_impl(const dsh_lu* lu, double* rhs, bool wait, unsign
         // factor panels prefetched through a register ring (same bits) when there is at most one system per compute unit — with several workgroups per
         // CU the plain kernel's occupancy hides the latency better (512 x 4096: 1.8 ms against 4.4 ms; 962 x 256: 1.06 ms against 0.67 ms,
         // gpurun_out/r03_solve_check.txt).  DSH_LU_STREAM_SOLVE=0 keeps k_lu_solve_blocked, =2/4/6 forces the ring depth for any ensemble size.
-        static const int stream_env = [] { const char* e = getenv("DSH_LU_STREAM_SOLVE"); return e ? atoi(e) : -1; }();
+        const int stream_env = [] { const char* e = getenv("DSH_LU_STREAM_SOLVE"); return e ? atoi(e) : -1; }();  // read per call: the GPU tier runs both kernels in one process
         const int stream_depth = stream_env >= 0 ? stream_env : (nb <= (int64_t)ctx->num_cu ? 2 : 0);
         if (blocked_solve && stream_depth > 0 && n <= 2 * kStreamThreads) {
           const size_t lds = stream_solve_lds_bytes(n);

@@ -42,6 +42,32 @@ def test_lu_factor_and_solve_match_oracle_bitwise(H, O, ctx1, n, nb):
     assert np.allclose(np.einsum("bij,bj->bi", a, x_ref), b, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,nb", [(65, 7), (100, 9), (300, 3), (512, 4), (700, 2), (962, 3), (1024, 2)])
+def test_streaming_dense_solve_with_prefetched_factor_panels_gives_the_bits_of_the_blocked_solve(H, ctx1, monkeypatch, n, nb):
+    """k_lu_solve_stream (a register ring of factor panels in flight, the interchanges applied from LDS visiting only the rows that move) performs per element the
+    operations of k_lu_solve_blocked in their order: same bits for every ring depth; also with a matrix that needs no interchange at all."""
+    rng = np.random.default_rng(n + nb)
+    c = ctx1.clone_with_nbatch(nb)
+    for dominant in (False, True):
+        a = rng.standard_normal((nb, n, n))
+        if dominant:
+            a += 2.0 * n * np.eye(n)[None]  # no row moves
+        else:
+            a[:, 0, 0] *= 1e-6
+        b = rng.standard_normal((nb, n))
+        lu = H.HipLU(c, n)
+        lu.factor(H.HipMat.from_array(a, c))
+        sols = []
+        for depth in ("0", "2", "4", "6"):
+            monkeypatch.setenv("DSH_LU_STREAM_SOLVE", depth)
+            x = H.HipVec.from_vec(b, c)
+            lu.solve_in_place(x)
+            sols.append(x.clone_as_vec())
+        monkeypatch.delenv("DSH_LU_STREAM_SOLVE")
+        assert all(np.array_equal(sols[0], q) for q in sols[1:])
+        assert np.allclose(np.einsum("bij,bj->bi", a, np.asarray(sols[0]).reshape(nb, n)), b, atol=1e-6 * n)
+
+
 def test_lu_reference_diagonal_kat_and_singular_reporting(H, ctx1):
     """2x2 diagonal solve incl. the batched variant (diffsol/src/linear_solver/mod.rs:283-321); zero pivot -> LuSolveFailed."""
     c2 = ctx1.clone_with_nbatch(2)
