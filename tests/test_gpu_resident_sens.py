@@ -111,7 +111,8 @@ def test_resident_sdirk_with_sensitivities_is_bit_identical_to_the_oracle(H, O, 
 
 
 @pytest.mark.parametrize("group", [1, 64])
-def test_resident_bdf_with_sensitivities_of_a_diffsl_model(H, O, det_pow, group):
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_resident_integrators_with_sensitivities_of_a_diffsl_model(H, O, det_pow, group, method):
     """A DiffSL model with inputs in its register-resident form carries sens_mul / init_sens_mul (forward-mode differentiation by the front end): the same kernel
     template, instantiated by hiprtc for the user's model with SENS = true.  Robertson's kinetics written in DiffSL with the three rate constants as inputs, and
     the reference's exponential_decay_problem_diffsl text (parameter-dependent initial state); the checker is the oracle integrating the generated host twin."""
@@ -124,9 +125,11 @@ def test_resident_bdf_with_sensitivities_of_a_diffsl_model(H, O, det_pow, group)
         m, mid = fe.DiffslModel(code), D.host_model(O, code)
         assert m.form == fe.FORM_STATIC
         nb = len(p)
-        s = H.Solver(m, p, nbatch=nb, sens=True, sens_rtol=stol[0], sens_atol=stol[1], **tol)
+        hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+        om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+        s = H.Solver(m, p, nbatch=nb, method=hm, sens=True, sens_rtol=stol[0], sens_atol=stol[1], **tol)
         y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=group, want_member_stats=True)
-        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=group, sens_rtol=stol[0], sens_atol=stol[1], **tol)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=group, method=om, sens_rtol=stol[0], sens_atol=stol[1], **tol)
         assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
         assert np.array_equal(mm["stats"].T, sto) and np.array_equal(y, np.transpose(yo, (1, 0, 2))) and np.array_equal(sens, np.transpose(so, (0, 2, 1, 3)))
 
