@@ -68,29 +68,94 @@ def robertson_params(nb, seed=12345):
                      np.exp(rng.uniform(np.log(1.5e7), np.log(6e7), nb))], axis=1)
 
 
+def cpu_limits():
+    """CPUs this process may use: affinity mask, and the cgroup-v2 quota (cpu.max "quota period": quota/period CPUs) when the container has one."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    raw = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            raw = open(path).read().strip()
+        except OSError:
+            continue
+        try:
+            if path.endswith("cpu.max"):
+                q, per = raw.split()
+                quota = None if q == "max" else float(q) / float(per)
+            else:
+                q = float(raw)
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = None if q < 0 else q / per
+        except (ValueError, OSError):
+            quota = None
+        break
+    return {"affinity_cpus": aff, "os_cpu_count": os.cpu_count(), "cgroup_cpu_max": raw, "cgroup_quota_cpus": quota}
+
+
+def thread_counts(lim):
+    """Thread counts of the sweep: with a cgroup CPU quota q (the GPU boxes of this pool: 16 of 256 CPUs) q, 2q, 4q — more threads than that only time-slice;
+    without one 16, 32, 64, ... up to the CPUs of the affinity mask (the sweep VERDICT r3 asked for)."""
+    aff, q = lim["affinity_cpus"], lim["cgroup_quota_cpus"]
+    if q and q < aff:
+        q = max(1, int(round(q)))
+        return sorted({min(aff, q), min(aff, 2 * q), min(aff, 4 * q)})
+    c, out = 16, []
+    while c < aff:
+        out.append(c)
+        c *= 2
+    out.append(aff)
+    return out if aff >= 16 else [aff]
+
+
+def usable_cpus(lim):
+    q = lim["cgroup_quota_cpus"]
+    return min(lim["affinity_cpus"], q) if q else lim["affinity_cpus"]
+
+
+def cpu_sweep(run, single, counts, lim):
+    """run(nthreads) -> (units, newton, seconds) for the whole sample; single = units/s measured on one thread.  Returns the best thread count; parallel efficiency =
+    rate / (min(threads, usable CPUs) x single-thread rate), usable CPUs = min(affinity mask, cgroup quota)."""
+    rows = []
+    for c in counts:
+        u, nw, sec = run(c)
+        rows.append({"threads": c, "value": u / sec, "newton_solves_per_sec": nw / sec, "seconds": sec, "parallel_efficiency": (u / sec) / (min(c, usable_cpus(lim)) * single)})
+    best = max(rows, key=lambda r: r["value"])
+    return best, rows
+
+
 def cpu_baseline(params, sample):
     """Reference algorithm on the host cores, one independent IVP per member (how diffsol's CPU path runs a sweep).  The timed code is
     oracle/oracle_fast.hpp — the oracle's BDF with fixed-size stack arrays (no per-operation allocation, -O3), verified bit for bit against
-    the line-by-line restatement oracle_ode.hpp by tests/test_oracle_golden.py — on a bounded sample of the same sweep."""
+    the line-by-line restatement oracle_ode.hpp by tests/test_oracle_golden.py — on a bounded sample of the same sweep.  The thread count is SWEPT
+    (16 ... all CPUs) and the best is reported with its parallel efficiency against the single-core rate; cgroup CPU quota stated."""
     from oracle import oracle as O
     O.build()
-    try:
-        cores = len(os.sched_getaffinity(0))  # the CPUs this process may run on (a container is often confined to fewer than os.cpu_count())
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    lim = cpu_limits()
+    cores = lim["affinity_cpus"]
     p = params[:sample]
     kw = dict(model_size=1, rtol=RTOL, atol=ATOL, t_final=T_EVAL[-1], want_y=False)
     fast = hasattr(O, "solve_ensemble_independent_fast")
     run = O.solve_ensemble_independent_fast if fast else O.solve_ensemble_independent
-    r = run(O.MODEL_ROBERTSON_ODE, p, nthreads=cores, **kw)
     n1 = max(1, min(sample, 2000 if fast else 200))
     r1 = run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
+    single = r1["steps"] / r1["seconds"]
+
+    def go(c):
+        r = run(O.MODEL_ROBERTSON_ODE, p, nthreads=c, **kw)
+        return r["steps"], r["newton_iterations"], r["seconds"]
+    go(min(cores, 16))  # page in, spin the cores up
+    best, rows = cpu_sweep(go, single, thread_counts(lim), lim)
     rec = {
-        "value": r["steps"] / r["seconds"], "unit": "ODE steps/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
-        "newton_solves_per_sec": r["newton_iterations"] / r["seconds"], "seconds": r["seconds"],
+        "value": best["value"], "unit": "ODE steps/s", "cores": best["threads"], "usable_cpus": usable_cpus(lim), "kind": "port",
+        "newton_solves_per_sec": best["newton_solves_per_sec"], "seconds": best["seconds"],
+        "parallel_efficiency": best["parallel_efficiency"], "thread_sweep": rows, "cpu_limits": lim,
         "sample": f"first {sample} members of the same Robertson sweep, one independent BDF solve per member to t={T_EVAL[-1]:g} "
-                  f"({'oracle_fast.hpp: stack-array build of the' if fast else ''} C++ restatement of diffsol Bdf+NalgebraLU), {cores} std::threads, static partition",
-        "single_core": {"value": r1["steps"] / r1["seconds"], "unit": "ODE steps/s", "cores": 1, "seconds_per_solve": r1["seconds"] / n1,
+                  f"({'oracle_fast.hpp: stack-array build of the' if fast else ''} C++ restatement of diffsol Bdf+NalgebraLU), std::threads with a static partition; "
+                  f"thread count swept, best reported",
+        "single_core": {"value": single, "unit": "ODE steps/s", "cores": 1, "seconds_per_solve": r1["seconds"] / n1,
                         "newton_solves_per_sec": r1["newton_iterations"] / r1["seconds"], "sample": f"first {n1} members, one thread"},
         "reference_published": {"seconds_per_solve": PUBLISHED_SINGLE_SOLVE_S,
                                 "what": "diffsol BDF+nalgebra LU via pydiffsol, robertson_ode n=3, rtol=atol=1e-4, one EPYC 7343 core "
@@ -101,6 +166,291 @@ def cpu_baseline(params, sample):
         rs = O.solve_ensemble_independent(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
         rec["fidelity_build_single_core_seconds_per_solve"] = rs["seconds"] / n1
     return rec
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2..4] (extra keys of the line; `value` stays configs[1])
+# Workloads as SURVEY §8(d) defines them (seed 12345): C3 heat1d n = 512 x 4096, D ~ U[0.5, 2], rtol = atol = 1e-6, TR-BDF2, t in [0, 0.5];
+# C4 single-particle battery model n = 42 (ODE form) / 43 (singular mass: terminal voltage algebraic), I ~ U[0.6, 1.4] A, BDF, t in [0, 3600 s], voltage
+# cut-offs armed, 32 768 (one GPU's shard of the 8-GPU job) and 262 144 members; C5 series RLC DAE n = 4 x 65 536, R ~ U[50, 200], C ~ logU[5e-4, 2e-3],
+# ESDIRK34, t in [0, 1], root i_R = i_thresh.
+TIMING_RESIDENT, TIMING_LU_SOLVE, TIMING_LU_FACTOR = 0, 1, 2
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 matrix (= vector) peak
+CFG_SOURCES = {
+    "c3_banded": ["diffsol_amd/csrc/dsh_lu_band_team.hpp", "diffsol_amd/csrc/dsh_lu_band.hpp"],
+    "c3_dense": ["diffsol_amd/csrc/dsh_lu_tiled.hpp", "diffsol_amd/csrc/dsh_lu_coop.hpp"],
+    "c4": ["diffsol_amd/csrc/dsh_lane_banded_kernel.hpp", "diffsol_amd/csrc/dsh_lu_band.hpp", "diffsol_amd/csrc/dsh_resident.hpp"],
+    "c5": ["diffsol_amd/csrc/dsh_sdirk_kernel.hpp", "diffsol_amd/csrc/dsh_resident.hpp", "diffsol_amd/csrc/dsh_models.hpp", "include/diffsol_detpow.h"],
+}
+
+
+def source_hash(files):
+    import hashlib
+    h = hashlib.sha256()
+    for rel in files:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def heat_params(nb):
+    return np.random.default_rng(12345).uniform(0.5, 2.0, nb)[:, None]
+
+
+def spm_params(nb):
+    return np.random.default_rng(12345).uniform(0.6, 1.4, nb)[:, None]
+
+
+def rlc_params(nb, i_thresh):
+    rng = np.random.default_rng(12345)
+    R = rng.uniform(50.0, 200.0, nb)
+    Cc = np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), nb))
+    return np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, i_thresh)], axis=1)
+
+
+def _counters(name, key, sources):
+    """committed PMC summary of a config's kernel (profiles/r04_pmc_configs.json), refused when the kernel's sources changed since it was taken"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
+    except Exception:
+        return None
+    if not d or d.get("kernel_source_sha16") != source_hash(sources):
+        return None
+    return d
+
+
+def cfg_cpu(model, p, t_eval, method, what, single_n, **kw):
+    """CPU leg of a config: the oracle's solve_dense per member (independent IVPs, the reference's CPU usage) on a bounded sample; thread count swept."""
+    from oracle import oracle as O
+    lim = cpu_limits()
+    cores = lim["affinity_cpus"]
+
+    def run(pp, c):
+        t0 = time.perf_counter()
+        _, st, failed = O.solve_dense_independent(model, pp, t_eval, method=method, nthreads=c, **kw)
+        return int(st[:, 0].sum()), int(st[:, 1].sum()), time.perf_counter() - t0, failed
+    u1, n1, s1, _ = run(p[:single_n], 1)
+    single = u1 / s1
+    counts = [c for c in thread_counts(lim) if c <= p.shape[0]] or [min(cores, p.shape[0])]
+    if len(counts) > 3:
+        counts = counts[-3:]  # bounded: the three largest thread counts
+    best, rows = cpu_sweep(lambda c: run(p, c)[:3], single, counts, lim)
+    return {"value": best["value"], "unit": "ODE steps/s", "cores": best["threads"], "usable_cpus": usable_cpus(lim), "kind": "port", "newton_solves_per_sec": best["newton_solves_per_sec"],
+            "seconds": best["seconds"], "seconds_per_solve_single_core": s1 / single_n, "parallel_efficiency": best["parallel_efficiency"],
+            "thread_sweep": rows, "sample": f"{what}: first {p.shape[0]} members, one independent solve_dense per member (oracle restatement), best of the thread sweep"}
+
+
+def bench_configs(device, want_cpu, quick=False):
+    """BASELINE configs[2..4] on one GPU, each with its own roofline entry (dominant kernel, live launch durations from HIP-event brackets on the solver's stream)
+    and CPU leg.  Every entry is guarded: a failing config reports {"error": ...} and the line still prints."""
+    import diffsol_amd as H
+    from diffsol_amd import diffsl
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    out = {}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        out[name]["bench_seconds"] = time.perf_counter() - t0
+
+    O = None
+    cpu_memo = {}
+    if want_cpu:
+        from oracle import oracle as O
+        O.build()
+
+    # ---------------------------------------------------------------- C3
+    def c3(dense):
+        nb, n, tf = (512 if quick else 4096), 512, 0.5
+        D = heat_params(nb)
+        if dense:
+            os.environ["DSH_LU_STRUCTURE"] = "dense"
+        try:
+            s = H.Solver("heat1d", D, nbatch=nb, model_size=n, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2, device=device)
+            t0 = time.perf_counter(); y, _ = s.solve_to_points([tf]); first = time.perf_counter() - t0
+            st = s.stats()
+            walls = []
+            for _ in range(2 if dense else 3):  # from a fresh .tr_bdf2() state on the same problem (dshs_reset): the context keeps its device blocks
+                s.reset()
+                t0 = time.perf_counter(); y2, _ = s.solve_to_points([tf]); walls.append(time.perf_counter() - t0)
+            wall = min(walls)
+            assert np.array_equal(y2, y)
+            timed = {}
+            for tgt, nm in ((TIMING_LU_SOLVE, "solve"), (TIMING_LU_FACTOR, "factor")):
+                s.reset()
+                s.set_kernel_timing(True); s.set_kernel_timing_target(tgt)
+                s.solve_to_points([tf])
+                timed[nm] = s.kernel_timing()
+                s.set_kernel_timing(False)
+            del s
+        finally:
+            os.environ.pop("DSH_LU_STRUCTURE", None)
+        h = 1.0 / (n + 1)
+        x = (np.arange(n) + 1) * h
+        m = np.arange(1, 200)[:, None, None]
+        ref = (np.sin((2 * m - 1) * np.pi * x[None, None, :]) * np.exp(-(2 * m - 1) ** 2 * np.pi ** 2 * D[None, :64, 0, None] * tf) / (2 * m - 1) ** 2).sum(0) * 8 / np.pi ** 2
+        steps, newton = st["number_of_steps"] * nb, st["number_of_nonlinear_solver_iterations"] * nb
+        rec = {"workload": f"BASELINE configs[2]: heat1d n={n} x {nb}, TR-BDF2, rtol=atol=1e-6, t in [0, {tf}]; host-driven lock-step over the trait operations, "
+                           + ("dense containers and the default dense LU (DSH_LU_STRUCTURE=dense: the literal 'banded-as-dense')" if dense else "band containers + banded LU (bit-identical to the dense route)"),
+               "ms_per_solve": 1e3 * wall, "first_solve_ms": 1e3 * first, "ode_steps_per_sec": steps / wall, "newton_solves_per_sec": newton / wall,
+               "lockstep_steps": st["number_of_steps"], "newton_iterations": st["number_of_nonlinear_solver_iterations"], "lu_setups": st["number_of_linear_solver_setups"],
+               "max_abs_err_vs_fourier_first64": float(np.abs(y[0, :64] - ref).max()), "finite": bool(np.isfinite(y).all())}
+        ns, ms_s = timed["solve"]
+        nf, ms_f = timed["factor"]
+        if dense:
+            by = nb * (8 * n * n + 20 * n)
+            fl = nb * 2.0 / 3.0 * n ** 3
+            rec["roofline"] = {"bound": "hbm", "kernel": "dsh_lu_solve (k_lu_solve_blocked: forward + backward substitution on the dense factors)", "launches_timed": ns,
+                               "avg_launch_us": 1e3 * ms_s / max(ns, 1), "algorithmic_bytes_per_launch": by, "achieved": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9 / HBM_PEAK_GBS, "share_of_solve_wall": ms_s * 1e-3 / wall,
+                               "measured": "HIP events on the solver stream around every dsh_lu_solve launch of one whole solve", "kernel_source_sha16": source_hash(CFG_SOURCES["c3_dense"])}
+            rec["roofline_factor"] = {"bound": "mfma", "kernel": "dsh_lu_factor (staging copy + dense LU factor kernel, FP64 matrix cores)", "launches_timed": nf,
+                                      "avg_launch_us": 1e3 * ms_f / max(nf, 1), "algorithmic_flop_per_launch": fl, "achieved": fl / (ms_f * 1e-3 / max(nf, 1)) / 1e12,
+                                      "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / (ms_f * 1e-3 / max(nf, 1)) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                                      "share_of_solve_wall": ms_f * 1e-3 / wall}
+        else:
+            K = 1
+            by = nb * (8 * n * (3 * K + 1) + 4 * n + 16 * n)
+            rec["roofline"] = {"bound": "hbm", "kernel": "dsh_lu_solve (k_lu_band_solve_team<1,16>: banded forward + backward substitution)", "launches_timed": ns,
+                               "avg_launch_us": 1e3 * ms_s / max(ns, 1), "algorithmic_bytes_per_launch": by, "achieved": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9 / HBM_PEAK_GBS, "share_of_solve_wall": ms_s * 1e-3 / wall,
+                               "measured": "HIP events on the solver stream around every dsh_lu_solve launch of one whole solve", "kernel_source_sha16": source_hash(CFG_SOURCES["c3_banded"]),
+                               "note": "the chain of one wavefront's dependent FP64 operations bounds this kernel (profiles/r03_band_solve.md), not HBM"}
+        if want_cpu:
+            if "c3" not in cpu_memo:  # the reference's CPU path has one route for this config (NalgebraLU on the dense matrix): one measurement serves both GPU routes
+                ns_cpu = max(1, min(nb, 4 * int(usable_cpus(cpu_limits()))))
+                cpu_memo["c3"] = cfg_cpu(O.MODEL_HEAT1D, D[:ns_cpu], [tf], O.METHOD_TR_BDF2, "heat1d n=512 TR-BDF2 with the dense LU (the reference's CPU path: NalgebraLU on a dense matrix)",
+                                         1, model_size=n, rtol=1e-6, atol=[1e-6])
+            rec["cpu_baseline"] = cpu_memo["c3"]
+        return rec
+
+    guarded("c3_banded", lambda: c3(False))
+    guarded("c3_dense", lambda: c3(True))
+
+    # ---------------------------------------------------------------- C4
+    # algorithmic bytes (SURVEY §8(d) with the banded factors): per accepted step read + write the difference array 2 x 8 n (q + 3) at the mean order q = 4, write
+    # y, dy (16 n), read atol (8 n); per Newton iteration read the banded factors 8 n (3K + 1) + pivots 4 n, and 8 (5 n + np) of vectors
+    def c4_bytes(n, steps, newton, K=1, q=4, npar=1):
+        return steps * (16 * n * (q + 3) + 24 * n) + newton * (8 * n * (3 * K + 1) + 4 * n + 8 * (5 * n + npar))
+
+    def c4(nb, dae):
+        import diffsl_models as DM
+        cur = spm_params(nb)
+        t_eval = np.linspace(360.0, 3600.0, 10)
+        if dae:
+            model = diffsl.DiffslModel(DM.spm_dae(20))
+            s = H.Solver(model, cur, nbatch=nb, rtol=1e-6, atol=[1e-6], device=device)
+        else:
+            s = H.Solver("spm", cur, nbatch=nb, model_size=20, rtol=1e-6, atol=[1e-6], device=device)
+        import torch
+        outb = torch.empty((len(t_eval), s.n, nb), dtype=torch.float64, device=f"cuda:{device}")
+        t0 = time.perf_counter(); s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr()); first = time.perf_counter() - t0
+        walls = []
+        for _ in range(3):
+            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr()); walls.append(time.perf_counter() - t0)
+        wall = min(walls)
+        s.set_kernel_timing(True); s.set_kernel_timing_target(TIMING_RESIDENT)
+        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True)
+        nl, ms = s.kernel_timing()
+        s.set_kernel_timing(False)
+        steps, newton = tot["number_of_steps"], tot["number_of_nonlinear_solver_iterations"]
+        by = c4_bytes(s.n, steps, newton)
+        rec = {"workload": f"BASELINE configs[3]: single-particle battery model, {'singular mass (terminal voltage algebraic), n=43, DiffSL' if dae else 'identity-mass form, n=42'}, {nb} members"
+                           f"{' (one GPU shard of the 8-GPU job)' if nb == 32768 else ' (the whole 8-GPU ensemble on one GPU)'}, BDF, rtol=atol=1e-6, t in [0, 3600 s], voltage cut-offs armed; "
+                           "device-resident, one lane per member, banded LU, output left in HBM",
+               "ms_per_solve": 1e3 * wall, "first_solve_ms_incl_compilation": 1e3 * first, "ode_steps_per_sec": steps / wall, "newton_solves_per_sec": newton / wall,
+               "mean_steps_per_member": steps / nb, "failed_members": tot["failed_members"], "members_stopped_by_event": int((mm["root_idx"] >= 0).sum()),
+               "finite": bool(torch.isfinite(outb[:1]).all().item()),
+               "roofline": {"bound": "hbm", "kernel": "dsh::k_bdf_lane_banded (the whole ensemble solve, one launch; state, difference arrays, band and factors in per-lane HBM)",
+                            "launches_timed": nl, "avg_launch_us": 1e3 * ms / max(nl, 1), "algorithmic_bytes_per_launch": by, "achieved": by / (ms * 1e-3 / max(nl, 1)) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms * 1e-3 / max(nl, 1)) / 1e9 / HBM_PEAK_GBS,
+                            "bytes_model": "steps x (16 n (q+3) + 24 n) + newton x (8 n (3K+1) + 4 n + 8 (5 n + np)), q = 4, K = 1",
+                            "measured": "HIP events on the solver stream around the launch", "kernel_source_sha16": source_hash(CFG_SOURCES["c4"])}}
+        pm = _counters("r04_pmc_configs.json", "c4_dae" if dae else "c4_ode", CFG_SOURCES["c4"])
+        if pm and pm.get("members") == nb:
+            rec["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
+            rec["roofline"]["counters_from"] = "profiles/r04_pmc_configs.json"
+        if want_cpu and nb == 32768:
+            mid = DM.host_model(O, DM.spm_dae(20)) if dae else O.MODEL_SPM
+            ns_cpu = 8192 if dae else 32768
+            rec["cpu_baseline"] = cfg_cpu(mid, cur[:ns_cpu], t_eval, O.METHOD_BDF, "SPM BDF, dense LU n=%d" % s.n, 64, **({} if dae else {"model_size": 20}), rtol=1e-6, atol=[1e-6])
+        del s, outb
+        return rec
+
+    for nb in ((4096,) if quick else (32768, 262144)):
+        guarded(f"c4_ode_{nb}", lambda nb=nb: c4(nb, False))
+        guarded(f"c4_dae_{nb}", lambda nb=nb: c4(nb, True))
+
+    # ---------------------------------------------------------------- C5
+    def c5(group):
+        nb = 4096 if quick else 65536
+        i_thresh = 0.03 if group == 1 else 1e3  # lock-step groups must agree on every event (the reference's batched root finding): threshold out of reach there
+        p = rlc_params(nb, i_thresh)
+        t_eval = np.linspace(0.1, 1.0, 10)
+        s = H.Solver("rlc", p, nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34, device=device)
+        import torch
+        outb = torch.empty((len(t_eval), s.n, nb), dtype=torch.float64, device=f"cuda:{device}")
+        s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group)
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group); walls.append(time.perf_counter() - t0)
+        wall = min(walls)
+        s.set_kernel_timing(True); s.set_kernel_timing_target(TIMING_RESIDENT)
+        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True, group=group)
+        nl, ms = s.kernel_timing()
+        s.set_kernel_timing(False)
+        steps, newton = tot["number_of_steps"], tot["number_of_nonlinear_solver_iterations"]
+        rec = {"workload": f"BASELINE configs[4]: series RLC DAE n=4 x {nb}, ESDIRK34, rtol=atol=1e-6, t in [0, 1], root i_R = {i_thresh:g}; device-resident, "
+                           + ("every member its own steps and its own event" if group == 1 else "wavefront lock-step groups of 64 (threshold out of reach)"),
+               "ms_per_solve": 1e3 * wall, "ode_steps_per_sec": steps / wall, "newton_solves_per_sec": (newton + steps) / wall, "newton_iterations_per_sec": newton / wall,
+               "mean_steps_per_member": steps / nb, "failed_members": tot["failed_members"], "members_stopped_by_event": int((mm["root_idx"] >= 0).sum()),
+               "roofline": {"bound": "valu", "kernel": f"dsh::k_sdirk_resident<RlcModel, ESDIRK34, group {group}> (the whole ensemble solve, one launch; state in registers)", "launches_timed": nl,
+                            "avg_launch_us": 1e3 * ms / max(nl, 1), "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "measured": "HIP events on the solver stream around the launch",
+                            "kernel_source_sha16": source_hash(CFG_SOURCES["c5"]),
+                            "hbm": {"algorithmic_bytes_per_launch": 8 * (p.shape[1] + s.n * len(t_eval)) * nb,
+                                    "note": "parameters in + save points out; the solver state never leaves registers, HBM does not bound this kernel"}}}
+        pm = _counters("r04_pmc_configs.json", "c5_per_member" if group == 1 else "c5_group64", CFG_SOURCES["c5"])
+        avg_s = ms * 1e-3 / max(nl, 1)
+        if pm and pm.get("members") == nb:
+            valu, f64 = pm["valu_insts_per_launch"], pm.get("f64_insts_per_launch") or 0
+            rec["roofline"].update({"achieved": valu * 64 / avg_s / 1e12, "frac": valu * 64 / avg_s / 1e12 / VALU_PEAK_TLANEOPS, "valu_wave_instructions_per_launch": valu,
+                                    "issue_slot_frac": (4 * f64 + 2 * (valu - f64)) / (SIMD_CYCLES_PER_S * avg_s), "traffic": pm.get("hbm_bytes_per_launch"),
+                                    "counters_from": "profiles/r04_pmc_configs.json"})
+        else:
+            rec["roofline"].update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC summary of this kernel build under profiles/ (scripts/profile_configs.sh)"})
+        if want_cpu:
+            ns_cpu = 16384
+            rec["cpu_baseline"] = cfg_cpu(O.MODEL_RLC, p[:ns_cpu], t_eval, O.METHOD_ESDIRK34, "RLC ESDIRK34 with the root function armed", 256, model_size=1, rtol=1e-6, atol=[1e-6])
+            rec["cpu_baseline"]["note"] = "independent solves = the per-member semantics; the group-of-64 GPU entry runs the batched (lock-step) semantics" if group != 1 else "same semantics as this entry"
+        del s, outb
+        return rec
+
+    guarded("c5_per_member", lambda: c5(1))
+    guarded("c5_group64", lambda: c5(64))
+    return out
+
+
+def bench_trait_path(params, device, k):
+    """BASELINE configs[1] through the pure 1:1 trait composition: fused=False (every algorithm step one Vector/Matrix/LinearSolver call, one launch each — what an unchanged
+    OdeBuilder....bdf::<HipLU>() of the Rust shim executes), host-driven lock-step over the whole ensemble."""
+    import diffsol_amd as H
+    from diffsol_amd.solver import ENSEMBLE_LOCKSTEP
+    nb = params.shape[0]
+    s = H.Solver("robertson_ode", params, nbatch=nb, model_size=1, rtol=RTOL, atol=ATOL, device=device, fused=False, ensemble_mode=ENSEMBLE_LOCKSTEP)
+    assert not s.fused
+    s.solve_dense(T_EVAL, want_host=False)
+    walls = []
+    for _ in range(k):
+        s.reset()
+        t0 = time.perf_counter(); s.solve_dense(T_EVAL, want_host=False); walls.append(time.perf_counter() - t0)
+    st = s.stats()
+    wall = min(walls)
+    return {"ms_per_step": 1e3 * wall, "ode_steps_per_sec": st["number_of_steps"] * nb / wall, "newton_solves_per_sec": st["number_of_nonlinear_solver_iterations"] * nb / wall,
+            "lockstep_steps": st["number_of_steps"], "failed_members": 0,
+            "note": "use_fused_kernels = 0 + DSHS_ENSEMBLE_LOCKSTEP: the literal drop-in composition (HipVec/HipMat/HipLU operations only, one launch each, the reference's own "
+                    "sequence of trait calls); the Rust shim's OdeBuilder/.bdf() executes exactly these dsh_* calls"}
 
 
 class _CpuStub:
@@ -147,7 +497,9 @@ def main():
                     help="N > 1: wait for every step's trajectory all-gather before the next solve starts (default: the gather of step k runs on RCCL's stream while "
                          "step k + 1 integrates, two output buffers in turn)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (host-driven lock-step, per-member control, 1.6M members)")
-    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[2..4] (the `configs` object) and the pure trait-path pass")
+    ap.add_argument("--quick-configs", action="store_true", help="configs at reduced ensemble sizes (smoke test of the bench itself; never a measurement)")
+    ap.add_argument("--cpu-sample", type=int, default=400_000)
     ap.add_argument("--large-nb", type=int, default=1_600_000)
     ap.add_argument("--cpu-stub", action="store_true", help="TEST HOOK: no GPU, gloo backend, stub solver (exercises launcher + aggregation only)")
     args = ap.parse_args()
@@ -450,7 +802,15 @@ def main():
             rec["roofline"] = None
         rec.update(extras)
         if world == 1 and not args.no_cpu_baseline and not stub:
-            rec["cpu_baseline"] = cpu_baseline(params, min(args.cpu_sample, n_total))
+            big_sample = robertson_params(max(args.cpu_sample, n_total))  # same distribution, same seed, a longer draw
+            rec["cpu_baseline"] = cpu_baseline(big_sample, args.cpu_sample)
+        if world == 1 and not stub and not args.no_configs:
+            del solver
+            try:
+                rec["trait_path"] = bench_trait_path(params[lo:hi], local_rank, 3)
+            except Exception as e:  # noqa: BLE001
+                rec["trait_path"] = {"error": str(e)[:300]}
+            rec["configs"] = bench_configs(local_rank, not args.no_cpu_baseline, quick=args.quick_configs)
         print(json.dumps(rec))
         sys.stdout.flush()
     if world > 1:

@@ -37,6 +37,7 @@ DEVICE_ABI = {
     "dsh_ctx_device": (cint, [vp]),
     "dsh_ctx_set_block": (cint, [vp, cint]),
     "dsh_ctx_set_timing": (cint, [vp, cint]),
+    "dsh_ctx_set_timing_target": (cint, [vp, cint]),
     "dsh_ctx_set_poll": (cint, [vp, cint]),
     "dsh_ctx_get_timing": (cint, [vp, c_i64p, c_dp]),
     "dsh_ctx_get_timing_overhead": (cint, [vp, c_dp, c_dp]),
@@ -178,6 +179,7 @@ HOST_ABI = {
     "dshs_interpolate_sens": (cint, [vp, dbl, c_dp]),
     "dshs_reset": (cint, [vp]),
     "dshs_set_kernel_timing": (cint, [vp, cint]),
+    "dshs_set_kernel_timing_target": (cint, [vp, cint]),
     "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),
     "dshs_get_kernel_timing_overhead": (cint, [vp, c_dp, c_dp]),
     "dshs_nstates": (i64, [vp]),
@@ -199,6 +201,7 @@ HOST_ABI = {
     "dshs_trajectory": (cint, [vp, c_dp, c_dp]),
     "dshs_solve_dense": (cint, [vp, c_dp, i64, c_dp, vp, c_ip]),
     "dshs_diffsl_generate": (cint, [C.c_char_p, cint, C.POINTER(vp), c_i64p, c_dp, i64]),
+    "dshs_diffsl_generate_indexed": (cint, [C.c_char_p, cint, cint, C.POINTER(vp), c_i64p, c_dp, i64]),
     "dshs_free_string": (None, [vp]),
     "dshs_diffsl_set_model_index": (cint, [cint]),
     "dshs_solve_dense_adaptive_sens": (cint, [vp, c_dp, i64, cint, cint, c_dp, c_dp, c_i32p, c_i32p, c_i64p]),

@@ -201,31 +201,24 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   int rc = DSH_OK;
   // Repeated solves of one problem (a parameter study, the benchmark loop) pass the same constants and save points every time: they stay on the device
   // and are compared on the host instead of being uploaded again (two pageable host-to-device copies, ~15 us each on a 2.5 ms solve).  One small block per
-  // context, kept until the process ends.
-  struct ConstCache { std::vector<unsigned char> host; unsigned char* dev = nullptr; int device = -1; };
-  static std::mutex cache_mutex;
-  static std::map<dsh_ctx*, ConstCache> cache;
+  // context, released with it.
   const size_t cbytes = sizeof(AdaptiveConsts), tbytes = sizeof(double) * (size_t)n_eval, need = cbytes + tbytes;
   bool cached = false;
-  if (tbytes <= 4096) {
-    std::lock_guard<std::mutex> g(cache_mutex);
-    ConstCache& cc = cache[ctx];
-    if (cc.dev && cc.device != ctx->device) { (void)hipFree(cc.dev); cc.dev = nullptr; cc.host.clear(); }  // a new context at an old address, on another device
-    if (!cc.dev) {
-      cc.device = ctx->device;
-      if (hipMalloc((void**)&cc.dev, cbytes + 4096) != hipSuccess) { (void)hipGetLastError(); cc.dev = nullptr; }
-    }
-    if (cc.dev) {
+  if (tbytes <= 4096) {  // the block belongs to the context (one thread per context) and goes with it (dsh_ctx_destroy)
+    if (!ctx->const_cache_dev && hipMalloc((void**)&ctx->const_cache_dev, cbytes + 4096) != hipSuccess) { (void)hipGetLastError(); ctx->const_cache_dev = nullptr; }
+    if (ctx->const_cache_dev) {
+      if (!ctx->const_cache_host) ctx->const_cache_host = new std::vector<unsigned char>();
+      std::vector<unsigned char>& held = *ctx->const_cache_host;
       std::vector<unsigned char> now(need);
       std::memcpy(now.data(), &C, cbytes);
       std::memcpy(now.data() + cbytes, t_eval_host, tbytes);
-      if (now != cc.host) {
-        cc.host.swap(now);  // the staging vector must outlive the asynchronous copy: it is the cache itself
-        DSH_HIP_CHECK(hipMemcpyAsync(cc.dev, cc.host.data(), need, hipMemcpyHostToDevice, ctx->stream));
+      if (now != held) {
+        held.swap(now);  // the staging vector must outlive the asynchronous copy: it is the cache itself
+        DSH_HIP_CHECK(hipMemcpyAsync(ctx->const_cache_dev, held.data(), need, hipMemcpyHostToDevice, ctx->stream));
         DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
       }
-      consts_dev = (AdaptiveConsts*)cc.dev;
-      t_eval_dev = (double*)(cc.dev + cbytes);
+      consts_dev = (AdaptiveConsts*)ctx->const_cache_dev;
+      t_eval_dev = (double*)(ctx->const_cache_dev + cbytes);
       cached = true;
     }
   }

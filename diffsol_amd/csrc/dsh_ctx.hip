@@ -16,10 +16,19 @@ int begin_records(dsh_ctx* ctx, int64_t nblocks, unsigned long long** rec_dev, u
   if (nblocks > ctx->rec_capacity) {
     int64_t cap = ctx->rec_capacity > 0 ? ctx->rec_capacity : 1024;
     while (cap < nblocks) cap *= 2;
+    // Launches already enqueued may still owe their records (the staged Newton iteration enqueues the solve, then the norm, and redeems both afterwards): after
+    // the synchronize they are all in the old ring, so the ring grows by COPYING every region to the same region of the new one — a later fetch_records of an
+    // older sequence number finds its records where it expects them (same region, same record index).
     DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->rec_host) DSH_HIP_CHECK(hipHostFree(ctx->rec_host));
-    DSH_HIP_CHECK(hipHostMalloc((void**)&ctx->rec_host, sizeof(unsigned long long) * kRecWords * cap * kRecRegions, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(ctx->rec_host, 0, sizeof(unsigned long long) * kRecWords * cap * kRecRegions);
+    unsigned long long* grown = nullptr;
+    DSH_HIP_CHECK(hipHostMalloc((void**)&grown, sizeof(unsigned long long) * kRecWords * cap * kRecRegions, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(grown, 0, sizeof(unsigned long long) * kRecWords * cap * kRecRegions);
+    if (ctx->rec_host) {
+      for (int64_t r = 0; r < (int64_t)kRecRegions; ++r)
+        std::memcpy(grown + (size_t)r * cap * kRecWords, ctx->rec_host + (size_t)r * ctx->rec_capacity * kRecWords, sizeof(unsigned long long) * kRecWords * ctx->rec_capacity);
+      DSH_HIP_CHECK(hipHostFree(ctx->rec_host));
+    }
+    ctx->rec_host = grown;
     DSH_HIP_CHECK(hipHostGetDevicePointer((void**)&ctx->rec_dev, ctx->rec_host, 0));
     ctx->rec_capacity = cap;
   }
@@ -173,6 +182,8 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   if (ctx->rec_host) (void)hipHostFree(ctx->rec_host);
   if (ctx->i32_scratch) (void)hipFree(ctx->i32_scratch);
   if (ctx->f64_scratch) (void)hipFree(ctx->f64_scratch);
+  if (ctx->const_cache_dev) (void)hipFree(ctx->const_cache_dev);
+  delete ctx->const_cache_host;
   if (ctx->ev_start) { (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop); }
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -215,6 +226,14 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
     }
     ctx->bracket_overhead_ms = acc / reps;
   }
+  return DSH_OK;
+}
+int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target) {
+  DSH_REQUIRE(target >= DSH_TIMING_RESIDENT && target <= DSH_TIMING_LU_FACTOR, "dsh_ctx_set_timing_target: unknown target");
+  ctx->timing_target = target;
+  ctx->timed_ms = 0.0;
+  ctx->timed_clock_ms = 0.0;
+  ctx->timed_launches = 0;
   return DSH_OK;
 }
 int dsh_ctx_get_timing_overhead(dsh_ctx* ctx, double* empty_bracket_ms, double* device_clock_total_ms) {

@@ -62,7 +62,7 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   const bool ba = anb == 1 && nb != 1;
   const bool with_err = y_old != nullptr;
   unsigned long long* clk = nullptr;
-  if (ctx->timing) {
+  if (timing_on(ctx)) {
     rc = ensure_i32_scratch(ctx, 4 * (int64_t)g.x);  // 2 x u64 per workgroup
     if (rc != DSH_OK) return rc;
     clk = reinterpret_cast<unsigned long long*>(ctx->i32_scratch);
@@ -97,7 +97,7 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
   });
   if (!ok) { set_error("newton iteration: model has no fused (register-resident) specialisation"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipGetLastError());
-  if (ctx->timing) {  // event timing needs completed events: timed launches are synchronous
+  if (timing_on(ctx)) {  // event timing needs completed events: timed launches are synchronous
     DSH_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
     DSH_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
     float ms = 0.f;

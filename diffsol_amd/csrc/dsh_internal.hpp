@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <vector>
 #include <string>
 
 #include "../../include/diffsol_hip.h"
@@ -77,12 +78,16 @@ struct dsh_ctx {
   size_t pool_bytes = 0;
   // optional HIP-event timing of the dominant (fused Newton iteration) kernel on this context's stream
   bool timing = false;
+  int timing_target = 0;  // which launches the brackets go around (DSH_TIMING_*): 0 = the device-resident integrators / the fused Newton launch, 1 = dsh_lu_solve, 2 = dsh_lu_factor
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool ev_pending = false;
   double timed_ms = 0.0;
   double timed_clock_ms = 0.0;       // same launches measured with the in-kernel 100 MHz device clock (max block end - min block start)
   double bracket_overhead_ms = 0.0;  // elapsed time of an empty event bracket (calibrated when timing is enabled)
   int64_t timed_launches = 0;
+  // constants + save points of the last device-resident solve, kept on the device between solves (dsh_adaptive.hip); freed by dsh_ctx_destroy
+  unsigned char* const_cache_dev = nullptr;
+  std::vector<unsigned char>* const_cache_host = nullptr;
 };
 
 struct dsh_lu {
@@ -137,10 +142,11 @@ inline double bits_to_double(unsigned long long b) {
 
 // HIP-event bracket around ONE launch on the context's stream (dsh_ctx_set_timing): record before / after the launch, collect after the stream
 // has been synchronised.  Used by the device-resident integrators, whose single launch per ensemble solve is the whole timed region.
-inline hipError_t timing_begin(dsh_ctx* ctx) { return ctx->timing ? hipEventRecord(ctx->ev_start, ctx->stream) : hipSuccess; }
-inline hipError_t timing_end(dsh_ctx* ctx) { return ctx->timing ? hipEventRecord(ctx->ev_stop, ctx->stream) : hipSuccess; }
-inline hipError_t timing_collect(dsh_ctx* ctx) {
-  if (!ctx->timing) return hipSuccess;
+inline bool timing_on(const dsh_ctx* ctx, int target = 0) { return ctx->timing && ctx->timing_target == target; }
+inline hipError_t timing_begin(dsh_ctx* ctx, int target = 0) { return timing_on(ctx, target) ? hipEventRecord(ctx->ev_start, ctx->stream) : hipSuccess; }
+inline hipError_t timing_end(dsh_ctx* ctx, int target = 0) { return timing_on(ctx, target) ? hipEventRecord(ctx->ev_stop, ctx->stream) : hipSuccess; }
+inline hipError_t timing_collect(dsh_ctx* ctx, int target = 0) {
+  if (!timing_on(ctx, target)) return hipSuccess;
   hipError_t e = hipEventSynchronize(ctx->ev_stop);
   if (e != hipSuccess) return e;
   float ms = 0.f;
@@ -149,6 +155,16 @@ inline hipError_t timing_collect(dsh_ctx* ctx) {
   ctx->timed_ms += (double)ms;
   ctx->timed_launches += 1;
   return hipSuccess;
+}
+// bracket around everything `f` enqueues (one kernel for the solves; staging + factor kernel for the tiled dense factorisation); timed calls are synchronous
+template <class F>
+inline int timed_call(dsh_ctx* ctx, int target, F&& f) {
+  if (!timing_on(ctx, target)) return f();
+  if (hipEventRecord(ctx->ev_start, ctx->stream) != hipSuccess) { set_error("timing: hipEventRecord failed"); return DSH_E_HIP; }
+  const int rc = f();
+  if (rc != DSH_OK) return rc;
+  if (timing_end(ctx, target) != hipSuccess || timing_collect(ctx, target) != hipSuccess) { set_error("timing: event collection failed"); return DSH_E_HIP; }
+  return rc;
 }
 
 inline dim3 grid_for(int64_t work, int block) { return dim3((unsigned)((work + block - 1) / block)); }

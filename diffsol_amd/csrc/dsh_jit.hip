@@ -21,6 +21,7 @@
 #include <atomic>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 
 #include "dsh_jit.hpp"
 
@@ -220,14 +221,23 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
   if (!path.empty()) {
     std::error_code ec;
     std::filesystem::create_directories(dir, ec);
-    lock_fd = open((path + ".lock").c_str(), O_CREAT | O_RDWR, 0644);
-    if (lock_fd >= 0 && flock(lock_fd, LOCK_EX) != 0) { close(lock_fd); lock_fd = -1; }
-    if (lock_fd >= 0 && cache_load(path, group, out)) { flock(lock_fd, LOCK_UN); close(lock_fd); return DSH_OK; }
+    // The lock file is removed by its holder WHILE it holds the lock, so whoever acquires a lock checks that the file it locked is still the one on disk
+    // (same inode) and otherwise starts over: a waiter that wakes up on an unlinked inode never shares the critical section with a newcomer on a fresh file.
+    const std::string lock_path = path + ".lock";
+    for (int attempt = 0; attempt < 64; ++attempt) {
+      lock_fd = open(lock_path.c_str(), O_CREAT | O_RDWR, 0644);
+      if (lock_fd < 0) break;
+      if (flock(lock_fd, LOCK_EX) != 0) { close(lock_fd); lock_fd = -1; break; }
+      struct stat held, disk;
+      if (fstat(lock_fd, &held) == 0 && stat(lock_path.c_str(), &disk) == 0 && held.st_ino == disk.st_ino && held.st_dev == disk.st_dev) break;
+      flock(lock_fd, LOCK_UN); close(lock_fd); lock_fd = -1;  // the previous holder removed this file: lock the current one
+    }
+    if (lock_fd >= 0 && cache_load(path, group, out)) { (void)unlink(lock_path.c_str()); flock(lock_fd, LOCK_UN); close(lock_fd); return DSH_OK; }
   }
   int rc = compile_module_uncached(rec, tu, header, group, opts, out);
   if (rc == DSH_OK) g_jit_compiles.fetch_add(1);
   if (rc == DSH_OK && !path.empty()) cache_store(dir, path, group, *out);
-  if (lock_fd >= 0) { flock(lock_fd, LOCK_UN); close(lock_fd); (void)unlink((path + ".lock").c_str()); }
+  if (lock_fd >= 0) { (void)unlink((path + ".lock").c_str()); flock(lock_fd, LOCK_UN); close(lock_fd); }
   return rc;
 }
 

@@ -19,17 +19,17 @@ FAMILY_OPERATORS, FAMILY_FUSED, FAMILY_RESIDENT_BDF, FAMILY_RESIDENT_SDIRK = 0, 
 
 
 def generate(code, target, model_index=0):
-    """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate.  model_index: the value of the scalar `N` in the text (the reference's
+    """DiffSL text -> (source code, dims dict, input defaults): dshs_diffsl_generate_indexed.  model_index: the value of the scalar `N` in the text (the reference's
     DiffSlContext::model_index, 0 by default), a compile-time constant of the generated model."""
     L = _ffi.load_host_lib()
-    check(L.dshs_diffsl_set_model_index(int(model_index)), host=True)
+    k = int(model_index)
     out = vp()
     dims = (C.c_int64 * 10)()
-    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, None, 0), host=True)  # dimensions first: one default per declared input
+    check(L.dshs_diffsl_generate_indexed(code.encode(), target, k, C.byref(out), dims, None, 0), host=True)  # dimensions first: one default per declared input
     L.dshs_free_string(out)
     ndef = max(int(dims[1]), 1)
     defaults = (C.c_double * ndef)()
-    check(L.dshs_diffsl_generate(code.encode(), target, C.byref(out), dims, defaults, ndef), host=True)
+    check(L.dshs_diffsl_generate_indexed(code.encode(), target, k, C.byref(out), dims, defaults, ndef), host=True)
     try:
         src = C.string_at(out).decode()
     finally:

@@ -283,7 +283,7 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
   // are read off the same diffsl::Compiled
   int id = -1;
   try {
-    const diffsl::Compiled c = diffsl::compile(code);
+    const diffsl::Compiled c = diffsl::compile(code, diffsl::take_pending_model_index());  // the index armed for THIS call, 0 otherwise
     const int64_t dims[10] = {c.n, c.np, c.nroots, c.nout, c.has_mass ? 1 : 0, c.dummy_param ? 1 : 0, c.jac_kl, c.jac_ku, c.mass_kl, c.mass_ku};
     const bool is_static = dims[0] <= 8 && dims[2] <= 1;
     ode->n = dims[0]; ode->np = dims[1]; ode->nroots = dims[2]; ode->nout = dims[3]; ode->has_mass = dims[4] != 0; ode->no_inputs = dims[5] != 0;

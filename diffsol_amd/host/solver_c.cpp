@@ -349,11 +349,12 @@ extern "C" {
 
 const char* dshs_last_error(void) { return g_err.c_str(); }
 
-int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap) {
+static int diffsl_generate_impl(const char* code, int target, int model_index, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap) {
   return guarded([&] {
     if (!code || !source_out) throw LaError(DSH_E_INVALID, "dshs_diffsl_generate: null argument");
     if (target < 0 || target > 2) throw LaError(DSH_E_INVALID, "dshs_diffsl_generate: unknown target");
-    diffsl::Compiled c = diffsl::compile(code);
+    if (model_index < 0) throw LaError(DSH_E_INVALID, "dshs_diffsl_generate: the model index is unsigned");
+    diffsl::Compiled c = diffsl::compile(code, model_index);
     const diffsl::Target t = target == DSHS_DIFFSL_HIP_STATIC ? diffsl::Target::HipStatic : target == DSHS_DIFFSL_HIP_DYNAMIC ? diffsl::Target::HipDynamic : diffsl::Target::HostC;
     std::string src = diffsl::generate(c, t);
     char* out = (char*)std::malloc(src.size() + 1);
@@ -364,6 +365,13 @@ int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_
     if (defaults_out) for (int64_t k = 0; k < defaults_cap && k < (int64_t)c.input_defaults.size(); ++k) defaults_out[k] = c.input_defaults[k];
     return 0;
   });
+}
+int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap) {
+  // consumes the one-shot index armed by dshs_diffsl_set_model_index (0 when none was armed): a later call never inherits it
+  return diffsl_generate_impl(code, target, diffsl::take_pending_model_index(), source_out, dims, defaults_out, defaults_cap);
+}
+int dshs_diffsl_generate_indexed(const char* code, int target, int model_index, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap) {
+  return diffsl_generate_impl(code, target, model_index, source_out, dims, defaults_out, defaults_cap);
 }
 void dshs_free_string(char* s) { std::free(s); }
 int dshs_diffsl_set_model_index(int model_index) {
@@ -443,7 +451,7 @@ int dshs_create_sens(int device, void* stream, int model, int64_t model_size, in
 void dshs_destroy(dshs_solver* s) { delete s; }
 
 int dshs_reset(dshs_solver* s) {
-  return guarded([&]() { s->make_solver(); return 0; });
+  return guarded([&]() { s->resident_roots_valid = false; s->make_solver(); return 0; });
 }
 int dshs_set_kernel_timing(dshs_solver* s, int enable) {
   // timed launches bracket the stand-alone Newton kernel: keep the accept launch separate while timing is on
@@ -451,6 +459,7 @@ int dshs_set_kernel_timing(dshs_solver* s, int enable) {
   if (s->bdf && s->kernel_timing) s->bdf->set_fuse_accept(false);
   return dsh_ctx_set_timing(s->ctx.raw(), enable);
 }
+int dshs_set_kernel_timing_target(dshs_solver* s, int target) { return dsh_ctx_set_timing_target(s->ctx.raw(), target); }
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms) { return dsh_ctx_get_timing(s->ctx.raw(), launches, total_ms); }
 int dshs_get_kernel_timing_overhead(dshs_solver* s, double* empty_bracket_ms, double* device_clock_total_ms) {
   return dsh_ctx_get_timing_overhead(s->ctx.raw(), empty_bracket_ms, device_clock_total_ms);
@@ -462,13 +471,14 @@ int dshs_is_fused(const dshs_solver* s) { return s->fused ? 1 : 0; }
 
 int dshs_step(dshs_solver* s, int* stop_reason) {
   return guarded([&]() {
+    s->resident_roots_valid = false;  // the host solver moves again: dshs_root_info reports ITS events from here on
     OdeSolverStopReason r = s->solver->step();
     if (stop_reason) *stop_reason = (int)r;
     return 0;
   });
 }
 int dshs_set_stop_time(dshs_solver* s, double tstop) {
-  return guarded([&]() { s->solver->set_stop_time(tstop); return 0; });
+  return guarded([&]() { s->resident_roots_valid = false; s->solver->set_stop_time(tstop); return 0; });
 }
 int dshs_interpolate(dshs_solver* s, double t, double* y_host) {
   return guarded([&]() { HipVec y = s->solver->interpolate(t); download(y, y_host); return 0; });
@@ -502,11 +512,13 @@ int dshs_interpolate_sens(dshs_solver* s, double t, double* s_host) {
 }
 int dshs_root_info(dshs_solver* s, double* t_root, int* root_index) {
   if (s->resident_roots_valid) {  // the last solve_dense ran device-resident: the host solver was not stepped; report the EARLIEST member event
+    // earliest = smallest distance from t0 along the direction of integration (sign of h0), not smallest |t|: t0 may be non-zero and times negative
+    const double t0 = s->problem.t0, dir = s->problem.h0 < 0.0 ? -1.0 : 1.0;
     double best = 0.0;
     int idx = -1;
     for (size_t b = 0; b < s->member_troot.size(); ++b) {
       const double tr = s->member_troot[b];
-      if (s->scratch_ridx[b] >= 0 && (idx < 0 || std::fabs(tr) < std::fabs(best))) { best = tr; idx = s->scratch_ridx[b]; }
+      if (s->scratch_ridx[b] >= 0 && (idx < 0 || dir * (tr - t0) < dir * (best - t0))) { best = tr; idx = s->scratch_ridx[b]; }
     }
     *t_root = best;
     *root_index = idx;
@@ -538,6 +550,7 @@ int dshs_stats(dshs_solver* s, int64_t* out) {
 
 int dshs_solve_to_points(dshs_solver* s, const double* t_points, int64_t npoints, double* y_host) {
   return guarded([&]() {
+    s->resident_roots_valid = false;
     const size_t len = (size_t)(s->problem.eqn->nstates() * s->ctx.nbatch());
     for (int64_t k = 0; k < npoints; ++k) {
       while (std::fabs(s->solver->t()) < std::fabs(t_points[k])) {
@@ -556,6 +569,7 @@ int dshs_solve_to_points(dshs_solver* s, const double* t_points, int64_t npoints
 
 int dshs_solve(dshs_solver* s, double final_time, int keep_trajectory, double* y_final_host, int64_t* ncols, int* stop_reason) {
   return guarded([&]() {
+    s->resident_roots_valid = false;
     OdeSolverStopReason r;
     int64_t cols = 1;
     if (keep_trajectory) {
@@ -675,6 +689,7 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals) {
   return guarded([&]() {
     int64_t tot[6];
+    s->resident_roots_valid = false;  // this call hands the per-member events to the caller's arrays; dshs_root_info falls back to the host solver's
     run_resident(s, t_eval, nt, group, deterministic_pow, y_host, y_dev, stats_host, status_host, t_root_host, root_idx_host, ncols_host, tot);
     for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
     s->last_mode = group;
@@ -688,6 +703,7 @@ int dshs_solve_dense_adaptive_sens(dshs_solver* s, const double* t_eval, int64_t
     if (!s->problem.sens) throw LaError(DSH_E_INVALID, "the solver was not created with forward sensitivities (dshs_create_sens)");
     if (!sens_host) throw LaError(DSH_E_INVALID, "dshs_solve_dense_adaptive_sens: sens_host is null");
     int64_t tot[6];
+    s->resident_roots_valid = false;
     run_resident(s, t_eval, nt, group, deterministic_pow, y_host, nullptr, stats_host, status_host, nullptr, nullptr, nullptr, tot, false, sens_host);
     for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
     s->last_mode = group;

@@ -100,6 +100,10 @@ class Solver:
     def set_kernel_timing(self, enable=True):
         check(self._L.dshs_set_kernel_timing(self._h, 1 if enable else 0), host=True)
 
+    def set_kernel_timing_target(self, target):
+        """which launches the event brackets go around: TIMING_RESIDENT (default), TIMING_LU_SOLVE, TIMING_LU_FACTOR (include/diffsol_hip.h DSH_TIMING_*)"""
+        check(self._L.dshs_set_kernel_timing_target(self._h, int(target)), host=True)
+
     def kernel_timing(self):
         n, ms = C.c_int64(), C.c_double()
         check(self._L.dshs_get_kernel_timing(self._h, C.byref(n), C.byref(ms)), host=True)

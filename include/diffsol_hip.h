@@ -63,6 +63,12 @@ int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
  * dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch is bracketed by two events; get_timing returns the number of launches and
  * the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figure. */
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
+/* Which launches the event brackets go around while timing is enabled (resets the accumulated time): the device-resident integrators and the fused Newton launch
+ * (default), every dsh_lu_solve launch, or every dsh_lu_factor call (staging copy + factor kernel for the matrix-core kernel).  bench.py's per-config rooflines. */
+#define DSH_TIMING_RESIDENT 0
+#define DSH_TIMING_LU_SOLVE 1
+#define DSH_TIMING_LU_FACTOR 2
+int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target);
 /* How blocking reductions wait for the device: poll != 0 (default; env DSH_SYNC_MODE=sync flips it) spins on the sequence tags of the
  * per-workgroup result records the kernels write into pinned host memory; poll == 0 uses hipStreamSynchronize. */
 int dsh_ctx_set_poll(dsh_ctx* ctx, int poll);

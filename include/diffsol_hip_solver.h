@@ -70,6 +70,7 @@ void dshs_destroy(dshs_solver* s);
 int dshs_reset(dshs_solver* s);
 /* forwarders to dsh_ctx_set_timing / dsh_ctx_get_timing of the solver's context */
 int dshs_set_kernel_timing(dshs_solver* s, int enable);
+int dshs_set_kernel_timing_target(dshs_solver* s, int target); /* DSH_TIMING_* of diffsol_hip.h */
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms);
 int dshs_get_kernel_timing_overhead(dshs_solver* s, double* empty_bracket_ms, double* device_clock_total_ms);
 
@@ -163,8 +164,10 @@ int dshs_solve_dense_adaptive_sens(dshs_solver* s, const double* t_eval, int64_t
 int dshs_diffsl_generate(const char* code, int target, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap);
 void dshs_free_string(char* s);
 /* The reference's DiffSL model index (DiffSlContext::model_index, ode_equations/diffsl.rs:52,115,406-411; the scalar `N` of a DiffSL text, 0 unless
- * set_params_and_model changes it) for the texts this thread compiles from now on (dshs_diffsl_generate, diffsol_ode_new_jit).  It is a compile-time constant of the
- * generated model: another index is another compiled model. */
+ * set_params_and_model changes it).  It is a compile-time constant of the generated model: another index is another compiled model.
+ * dshs_diffsl_generate_indexed passes it explicitly.  dshs_diffsl_set_model_index arms it ONE-SHOT for the next text this thread compiles through an entry
+ * that has no index argument (dshs_diffsl_generate, diffsol_ode_new_jit): that call consumes it, every later call compiles with index 0 again. */
+int dshs_diffsl_generate_indexed(const char* code, int target, int model_index, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap);
 int dshs_diffsl_set_model_index(int model_index);
 
 #ifdef __cplusplus
