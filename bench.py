@@ -501,6 +501,13 @@ def main():
     ap.add_argument("--quick-configs", action="store_true", help="configs at reduced ensemble sizes (smoke test of the bench itself; never a measurement)")
     ap.add_argument("--cpu-sample", type=int, default=400_000)
     ap.add_argument("--large-nb", type=int, default=1_600_000)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2 (default): BASELINE configs[1], weak scaling (100 000 members per GPU).  c4: BASELINE configs[3] as worded — 262 144 battery-model members SPLIT over "
+                         "the N GPUs (strong scaling), one gather of the trajectories at the end of every solve")
+    ap.add_argument("--members-total", type=int, default=262_144, help="--config c4: ensemble size (split over the ranks)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "cabi"],
+                    help="--config c4: torch = torch.distributed all_gather_into_tensor (RCCL); cabi = the library's own dsh_gather_batch_axis (csrc/dsh_dist.hip: librccl bound "
+                         "by libdiffsol_hip.so, what a Rust / C caller uses), the 128-byte id broadcast through torch's store")
     ap.add_argument("--cpu-stub", action="store_true", help="TEST HOOK: no GPU, gloo backend, stub solver (exercises launcher + aggregation only)")
     args = ap.parse_args()
     assert args.gpus >= 1 and args.steps >= 1 and args.warmup >= 0
@@ -528,6 +535,8 @@ def main():
 
     from diffsol_amd.dist import gather_batch_axis, gather_batch_axis_async, shard_bounds
 
+    if args.config == "c4":
+        return main_c4(args, rank, local_rank, world, stub)
     nb = args.nb
     n_total = nb * world
     params = robertson_params(n_total)
@@ -813,6 +822,96 @@ def main():
             rec["configs"] = bench_configs(local_rank, not args.no_cpu_baseline, quick=args.quick_configs)
         print(json.dumps(rec))
         sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_c4(args, rank, local_rank, world, stub):
+    """BASELINE configs[3] as worded: the 262 144-member battery ensemble SPLIT over the N ranks (strong scaling), device-resident BDF per rank on its shard
+    (no collective inside the integration), ONE gather of the [save points x states x members] trajectories per solve.  One JSON line, `scaling: "strong"`."""
+    import torch
+    import torch.distributed as dist
+
+    from diffsol_amd.dist import CabiCommunicator, gather_batch_axis, shard_bounds
+    n_total = args.members_total
+    lo, hi = shard_bounds(n_total, rank, world)
+    cur = spm_params(n_total)
+    t_eval = np.linspace(360.0, 3600.0, 10)
+    dev = "cpu" if stub else f"cuda:{local_rank}"
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+    comm = None
+    if stub:
+        n = 42
+
+        def solve(buf):
+            buf.copy_(torch.from_numpy(np.broadcast_to(cur[lo:hi, 0], (len(t_eval), n, hi - lo)).copy()))
+            return {"number_of_steps": 90 * (hi - lo), "number_of_nonlinear_solver_iterations": 100 * (hi - lo), "failed_members": 0}
+    else:
+        import diffsol_amd as H
+        s = H.Solver("spm", cur[lo:hi], nbatch=hi - lo, model_size=20, rtol=1e-6, atol=[1e-6], device=local_rank)
+        n = s.n
+
+        def solve(buf):
+            return s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=buf.data_ptr())[1]
+        if args.gather == "cabi":
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(CabiCommunicator.unique_id()), dtype=torch.uint8).to(dev)
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            comm = CabiCommunicator(s.context_handle(), rank, world, bytes(idt.cpu().numpy().tobytes()))
+    out = torch.empty((len(t_eval), n, hi - lo), dtype=torch.float64, device=dev)
+    full = torch.empty((len(t_eval), n, n_total), dtype=torch.float64, device=dev) if comm is not None else None
+
+    def step():
+        tot = solve(out)
+        if comm is not None:
+            return tot, comm.gather(out, n_total, out=full)
+        return tot, (gather_batch_axis(out, n_total, rank, world) if world > 1 else out)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        tot, y = step()
+        for k, v in tot.items():
+            acc[k] = acc.get(k, 0) + v
+    barrier()
+    el = time.perf_counter() - t0
+    a = torch.tensor([el, acc["number_of_steps"], acc["number_of_nonlinear_solver_iterations"], acc["failed_members"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = a[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        a[0] = tmax[0]
+    el, steps, newton, failed = [float(v) for v in a.tolist()]
+    ok = bool(torch.isfinite(y[0]).all().item()) and y.shape[-1] == n_total
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ODE steps/sec (and Newton solves/sec) per ensemble", "value": steps / el, "unit": "accepted ODE steps/s summed over ensemble members",
+            "newton_solves_per_sec": newton / el, "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "cpu-stub (test hook: launcher/aggregation path only, not a measurement)" if stub else "synthetic",
+            "config": {"workload": f"BASELINE.json configs[3]: single-particle battery model (n = {n}), {n_total} members SPLIT over {world} GPU(s), BDF, rtol=atol=1e-6, t in [0, 3600 s], "
+                                   "voltage cut-offs armed, device-resident per-member control, one trajectory gather per solve",
+                       "members_total": n_total, "members_per_gpu": hi - lo, "parallelism": f"ensemble-shard x{world}",
+                       "gather": "none" if world == 1 and comm is None else ("dsh_gather_batch_axis (library-bound RCCL)" if comm is not None else "torch.distributed all_gather_into_tensor (RCCL)"),
+                       "gathered_bytes_per_solve": 8 * len(t_eval) * n * n_total},
+            "checks": {"finite_and_complete": ok, "failed_members": int(failed)}}))
+        sys.stdout.flush()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

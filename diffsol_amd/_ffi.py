@@ -36,6 +36,18 @@ DEVICE_ABI = {
     "dsh_ctx_stream": (vp, [vp]),
     "dsh_ctx_device": (cint, [vp]),
     "dsh_ctx_set_block": (cint, [vp, cint]),
+    "dsh_experiments_enabled": (cint, []),
+    "dsh_dist_shard_bounds": (cint, [i64, cint, cint, c_i64p, c_i64p]),
+    "dsh_dist_unique_id": (cint, [C.c_char_p]),
+    "dsh_dist_init": (cint, [vp, cint, cint, C.c_char_p, C.POINTER(vp)]),
+    "dsh_dist_destroy": (None, [vp]),
+    "dsh_dist_rank": (cint, [vp]),
+    "dsh_dist_world": (cint, [vp]),
+    "dsh_gather_batch_axis": (cint, [vp, vp, i64, i64, vp]),
+    "dsh_gather_batch_axis_async": (cint, [vp, vp, i64, i64, vp]),
+    "dsh_gather_wait": (cint, [vp]),
+    "dsh_dist_pack_shard": (cint, [vp, vp, vp, i64, i64, i64, vp]),
+    "dsh_dist_unpack_gathered": (cint, [vp, vp, vp, i64, i64, cint, vp]),
     "dsh_ctx_set_timing": (cint, [vp, cint]),
     "dsh_ctx_set_timing_target": (cint, [vp, cint]),
     "dsh_ctx_set_poll": (cint, [vp, cint]),
@@ -178,6 +190,7 @@ HOST_ABI = {
     "dshs_nparams": (i64, [vp]),
     "dshs_interpolate_sens": (cint, [vp, dbl, c_dp]),
     "dshs_reset": (cint, [vp]),
+    "dshs_context": (vp, [vp]),
     "dshs_set_kernel_timing": (cint, [vp, cint]),
     "dshs_set_kernel_timing_target": (cint, [vp, cint]),
     "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),

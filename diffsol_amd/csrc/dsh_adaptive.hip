@@ -36,15 +36,31 @@
 #include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
 
+// DSH_EXPERIMENTS (compile time, `make EXPERIMENTS=1`; off in the shipped library): the variants that were built, verified bit-identical and MEASURED SLOWER than
+// what ships — re-binning between segments of a per-member run (DSH_REBIN / DSH_REBIN_STEPS: 10.3 - 19 ms against 8.4 ms, profiles/r03_rebin.txt) and the
+// phase-scheduled per-member kernel (DSH_MEMBER_SCHED: 10.75 against 9.23 ms).  Kept in the tree for the record and for whoever wants to take them further;
+// dsh_experiments_enabled() tells a caller (the tests) whether this build has them.
+#ifdef DSH_EXPERIMENTS
 #include <hipcub/hipcub.hpp>
+#endif
 #include "dsh_adaptive_kernel.hpp"
+#ifdef DSH_EXPERIMENTS
 #include "dsh_member_sched_kernel.hpp"
+#endif
 #include "dsh_jit.hpp"
 
 using namespace dsh;
 
 
 extern "C" {
+
+int dsh_experiments_enabled(void) {
+#ifdef DSH_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 void dsh_adaptive_default_options(dsh_adaptive_options* o) {
   if (!o) return;
@@ -236,6 +252,7 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
   bool launched = false;
   DSH_HIP_CHECK(timing_begin(ctx));
+#ifdef DSH_EXPERIMENTS
   // ---- per-member control in SEGMENTS with re-binning between them (DSH_REBIN=k: a segment ends when a member has produced k more save points; 0 / unset:
   // one launch).  Members drift apart inside a wavefront — different orders, step sizes, distances to the next order selection — and a wavefront pays for the
   // union of its lanes' paths (profiles/r03_per_member.md: 61 % of the per-member time).  Between segments every member's integrator state is in memory and
@@ -313,14 +330,20 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     if (totals_host) for (int k = 0; k < 6; ++k) totals_host[k] = (int64_t)totals_s[k];
     return DSH_OK;
   }
+#endif  // DSH_EXPERIMENTS
   // per-member control of the register-resident models can run on the phase-scheduled kernel (dsh_member_sched_kernel.hpp; same bits) with
   // DSH_MEMBER_SCHED=1: opt-in (measured slower than the nested-loop kernel on C2: 10.75 vs 9.23 ms); read per call: tests run both kernels
+#ifdef DSH_EXPERIMENTS
   const bool sched_env = [] { const char* e = std::getenv("DSH_MEMBER_SCHED"); return e && e[0] == '1'; }();
+  const bool lane_v1_env = [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return e && e[0] == '1'; }();  // the round-1 banded branch of k_bdf_adaptive (slower, same bits)
+#else
+  constexpr bool sched_env = false, lane_v1_env = false;
+#endif
   if (is_jit_model(model)) {  // run-time-compiled model: the same kernel template, instantiated by hiprtc for the user's model
     const JitInfo* ji = jit_info(model);
     const bool sched = !sens && sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC && !ji->has_reset;  // the phase-scheduled kernel stops at events
     // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
-    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || [] { const char* e = std::getenv("DSH_LANE_BANDED_V1"); return !(e && e[0] == '1'); }());  // models with a mass matrix: k_bdf_lane_banded only
+    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || !lane_v1_env);  // models with a mass matrix: k_bdf_lane_banded only
     const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + (sens ? ", false, true>" : ">");  // SENS: <.., SEG = false, SENS = true>
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
                              : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;
@@ -351,10 +374,12 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
 #define DSH_ADAPTIVE_LAUNCH(BA, WAVE) \
   hipLaunchKernelGGL((k_bdf_adaptive<Mdl, BA, WAVE>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
       if (C.r.o.group == 64) { if (ba) DSH_ADAPTIVE_LAUNCH(true, true); else DSH_ADAPTIVE_LAUNCH(false, true); }
+#ifdef DSH_EXPERIMENTS
       else if (sched_env) {
         if (ba) hipLaunchKernelGGL((k_bdf_member_sched<Mdl, true>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
         else hipLaunchKernelGGL((k_bdf_member_sched<Mdl, false>), grid, blk, 0, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
       }
+#endif
       else { if (ba) DSH_ADAPTIVE_LAUNCH(true, false); else DSH_ADAPTIVE_LAUNCH(false, false); }
 #undef DSH_ADAPTIVE_LAUNCH
     }

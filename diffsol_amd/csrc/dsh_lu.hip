@@ -464,12 +464,14 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
           const size_t lds = stream_solve_lds_bytes(n);
 #define DSH_STREAM(RPT, D, BB) hipLaunchKernelGGL((k_lu_solve_stream<RPT, D, BB>), g, dim3(kStreamThreads), lds, ctx->stream, (int)n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
           static const int stream_b = [] { const char* e = getenv("DSH_LU_STREAM_B"); return e ? atoi(e) : 8; }();
+#ifdef DSH_EXPERIMENTS
           static const int stream_t = [] { const char* e = getenv("DSH_LU_STREAM_THREADS"); return e ? atoi(e) : 512; }();
-          if (stream_t >= 1024 && n <= 1024) {  // 16 wavefronts, one row per thread: more loads in flight per CU
+          if (stream_t >= 1024 && n <= 1024) {  // 16 wavefronts, one row per thread: more loads in flight per CU (measured slower: profiles/r03_dense_solve.txt)
 #define DSH_STREAM_T(D) hipLaunchKernelGGL((k_lu_solve_stream<1, D, 8, 1024>), g, dim3(1024), lds, ctx->stream, (int)n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
             if (stream_depth >= 4) DSH_STREAM_T(4); else if (stream_depth >= 3) DSH_STREAM_T(3); else DSH_STREAM_T(2);
 #undef DSH_STREAM_T
           } else
+#endif
           if (n <= kStreamThreads) {
             if (stream_b >= 32) DSH_STREAM(1, 2, 32); else if (stream_b >= 16) { if (stream_depth >= 4) DSH_STREAM(1, 4, 16); else DSH_STREAM(1, 2, 16); }
             else if (stream_depth >= 6) DSH_STREAM(1, 6, 8); else if (stream_depth >= 4) DSH_STREAM(1, 4, 8); else DSH_STREAM(1, 2, 8);

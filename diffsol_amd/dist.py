@@ -96,6 +96,57 @@ def gather_batch_axis_async(local, n_total, rank, world, group=None):
     return PendingGather(work, flat_in, flat_out, lead, m, n_total, world)
 
 
+class CabiCommunicator:
+    """The gather at the C ABI (include/diffsol_hip.h dsh_dist_*: librccl bound by the library itself, no torch.distributed in the data path): what a Rust / C caller
+    of libdiffsol_hip.so uses.  `unique_id` (128 bytes) comes from rank 0's CabiCommunicator.unique_id() and reaches the other ranks by any side channel (here: the
+    launcher's store, a file, an environment variable)."""
+
+    def __init__(self, ctx_handle, rank, world, unique_id):
+        import ctypes as C
+
+        from . import _ffi
+        self._L = _ffi.load_device_lib()
+        self._h = _ffi.vp()
+        assert len(unique_id) == 128
+        _ffi.check(self._L.dsh_dist_init(ctx_handle, int(rank), int(world), bytes(unique_id), C.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        from . import _ffi
+        buf = C.create_string_buffer(128)
+        _ffi.check(_ffi.load_device_lib().dsh_dist_unique_id(buf))
+        return buf.raw
+
+    def gather(self, local, n_total, out=None, wait=True):
+        """local: CUDA tensor [..., nb_local] (batch-fastest, contiguous) -> out [..., n_total] on every rank; wait=False leaves the gather in flight (call wait())"""
+        import torch
+
+        from . import _ffi
+        assert local.is_cuda and local.is_contiguous() and local.dtype == torch.float64
+        lead = int(np.prod(local.shape[:-1])) if local.dim() > 1 else 1
+        if out is None:
+            out = torch.empty(tuple(local.shape[:-1]) + (int(n_total),), dtype=torch.float64, device=local.device)
+        f = self._L.dsh_gather_batch_axis if wait else self._L.dsh_gather_batch_axis_async
+        _ffi.check(f(self._h, _ffi.vp(local.data_ptr()), lead, int(n_total), _ffi.vp(out.data_ptr())))
+        self._keep = (local, out)
+        return out
+
+    def wait(self):
+        from . import _ffi
+        _ffi.check(self._L.dsh_gather_wait(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dsh_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 def solve_ensemble_sharded(model, params, t_eval, *, rank, world, device, method=0, model_size=0, gather=True, group=None, solver_factory=None,
                            resident=None, **solver_kw):
     """Integrate this rank's shard of the ensemble and (optionally) gather the interpolated trajectories.

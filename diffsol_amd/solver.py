@@ -97,6 +97,10 @@ class Solver:
         """Re-create the solver state from the (device-resident) problem: a fresh `.bdf()` / `.tr_bdf2()` / `.esdirk34()`."""
         check(self._L.dshs_reset(self._h), host=True)
 
+    def context_handle(self):
+        """raw dsh_ctx* of this solver (dshs_context): what dist.CabiCommunicator takes"""
+        return vp(self._L.dshs_context(self._h))
+
     def set_kernel_timing(self, enable=True):
         check(self._L.dshs_set_kernel_timing(self._h, 1 if enable else 0), host=True)
 

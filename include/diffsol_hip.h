@@ -62,6 +62,9 @@ int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
 /* HIP-event timing of the fused Newton-iteration kernel (the dominant kernel) on the context's own stream: when enabled every
  * dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch is bracketed by two events; get_timing returns the number of launches and
  * the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figure. */
+/* 1 when the library was built with -DDSH_EXPERIMENTS (make EXPERIMENTS=1): the measured-slower kernel variants and their DSH_REBIN / DSH_REBIN_STEPS /
+ * DSH_MEMBER_SCHED / DSH_LANE_BANDED_V1 / DSH_LU_STREAM_THREADS knobs exist; 0 in the shipped library (the knobs are then ignored). */
+int dsh_experiments_enabled(void);
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
 /* Which launches the event brackets go around while timing is enabled (resets the accumulated time): the device-resident integrators and the fused Newton launch
  * (default), every dsh_lu_solve launch, or every dsh_lu_factor call (staging copy + factor kernel for the matrix-core kernel).  bench.py's per-config rooflines. */
@@ -454,6 +457,33 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
                              double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 
+
+/* ------------------------------------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU trajectory collection (BASELINE configs[3]: "sharded over 8 MI355X with RCCL gather").  One process per GPU; rank r integrates the
+ * members [lo, hi) = dsh_dist_shard_bounds(n_total, r, world) with no collective inside the integration; the solve_dense output ([lead][nb_local] on the device,
+ * batch-fastest, lead = save points x states) is gathered along the batch axis with ONE ncclAllGather (RCCL over xGMI) into [lead][n_total] on every rank.
+ * The reference has no distributed layer; a Rust caller would hold a dsh_dist next to its HipContext.  librccl is bound at run time (dlopen; an
+ * RCCL already in the process, e.g. PyTorch's, is reused; DSH_RCCL_LIB names one explicitly): DSH_E_UNSUPPORTED when there is none.
+ *   dsh_dist_unique_id   rank 0 makes the 128-byte id and ships it to the other ranks by whatever the launcher offers (file, environment, MPI, a TCP store)
+ *   dsh_dist_init        collective over all ranks (ncclCommInitRank); the communicator runs on its own stream of ctx's device
+ *   dsh_gather_batch_axis[_async] / dsh_gather_wait   the gather; the async form returns at once — the transfer waits for what the solver's stream holds at the time
+ *                        of the call and overlaps whatever is enqueued there afterwards (the next solve, into another buffer) — `local` and `out` belong to the
+ *                        gather until dsh_gather_wait returns; one gather in flight per communicator
+ *   dsh_dist_pack_shard / dsh_dist_unpack_gathered    the two layout copies on their own: [lead][nb_local] -> [lead][m] zero-padded (m = ceil(n_total / world));
+ *                        [world][lead][m] -> [lead][n_total] */
+#define DSH_DIST_ID_BYTES 128
+typedef struct dsh_dist dsh_dist;
+int dsh_dist_shard_bounds(int64_t n_total, int rank, int world, int64_t* lo, int64_t* hi);
+int dsh_dist_unique_id(unsigned char* id128);
+int dsh_dist_init(dsh_ctx* ctx, int rank, int world, const unsigned char* id128, dsh_dist** out);
+void dsh_dist_destroy(dsh_dist* d);
+int dsh_dist_rank(const dsh_dist* d);
+int dsh_dist_world(const dsh_dist* d);
+int dsh_gather_batch_axis(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out);
+int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out);
+int dsh_gather_wait(dsh_dist* d);
+int dsh_dist_pack_shard(dsh_ctx* ctx, void* stream, const double* local, int64_t lead, int64_t nb_local, int64_t m, double* send);
+int dsh_dist_unpack_gathered(dsh_ctx* ctx, void* stream, const double* recv, int64_t lead, int64_t n_total, int world, double* out);
 
 #ifdef __cplusplus
 }

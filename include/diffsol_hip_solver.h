@@ -18,6 +18,7 @@ extern "C" {
 #endif
 
 typedef struct dshs_solver dshs_solver;
+typedef struct dsh_ctx dsh_ctx; /* include/diffsol_hip.h */
 
 #define DSHS_METHOD_BDF 0      /* OdeSolverProblem::bdf       crates/diffsol/src/ode_solver/problem.rs:649-655 */
 #define DSHS_METHOD_TR_BDF2 1  /* OdeSolverProblem::tr_bdf2   problem.rs:839-861 (sdirk_solver_from_tableau!) */
@@ -69,6 +70,8 @@ void dshs_destroy(dshs_solver* s);
  * initial state, consistent initialisation, initial step size, first Jacobian + LU.  Lets a benchmark time whole solves back to back. */
 int dshs_reset(dshs_solver* s);
 /* forwarders to dsh_ctx_set_timing / dsh_ctx_get_timing of the solver's context */
+/* the solver's device context (its stream is where every launch of this solver goes): e.g. for dsh_dist_init — a gather issued on it waits for the solver's work */
+dsh_ctx* dshs_context(dshs_solver* s);
 int dshs_set_kernel_timing(dshs_solver* s, int enable);
 int dshs_set_kernel_timing_target(dshs_solver* s, int target); /* DSH_TIMING_* of diffsol_hip.h */
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms);

@@ -47,3 +47,13 @@ def test_rank_count_must_match_gpus_flag():
     """A launcher that started 1 rank for --gpus 2 (round 1's silent n_gpus = 1) is an error now."""
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--nb", "64", "--cpu-stub"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_strong_scaling_mode_splits_one_ensemble_over_the_ranks():
+    """--config c4 = BASELINE configs[3] as worded: ONE ensemble split over the ranks (strong scaling), one trajectory gather per solve; prints ranks and scaling."""
+    r = _run(["--gpus", "2", "--config", "c4", "--members-total", "1001", "--steps", "2", "--warmup", "1", "--cpu-stub"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json_line(r.stdout)
+    assert rec["scaling"] == "strong" and rec["ranks"] == 2 and rec["n_gpus"] == 2
+    assert rec["config"]["members_total"] == 1001 and rec["config"]["members_per_gpu"] == 501 and rec["checks"]["finite_and_complete"]
+    assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 * 2 - 2 * 90 * 1001) < 1e-3 * 2 * 90 * 1001

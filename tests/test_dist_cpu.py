@@ -144,3 +144,27 @@ def test_ranks_that_meet_the_same_model_on_a_cold_cache_compile_it_once(tmp_path
     files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
     assert len(files) >= 1 and not [f for f in os.listdir(tmp_path) if ".tmp" in f or f.endswith(".lock")]
     assert sum(counts.values()) == len(files), (counts, files)
+
+
+def test_c_abi_shard_bounds_equal_the_python_partition():
+    """dsh_dist_shard_bounds (include/diffsol_hip.h; what a Rust / C caller shards with) is the partition of diffsol_amd.dist.shard_bounds: contiguous, sizes differ
+    by at most one, covers [0, n_total) — no GPU needed for the index arithmetic."""
+    import ctypes as C
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from diffsol_amd import _ffi
+    from diffsol_amd.dist import shard_bounds
+    L = _ffi.load_device_lib()
+    for n_total in (0, 1, 2, 7, 8, 9, 100_000, 262_144, 262_145):
+        for world in (1, 2, 3, 4, 7, 8):
+            prev = 0
+            for rank in range(world):
+                lo, hi = C.c_int64(), C.c_int64()
+                assert L.dsh_dist_shard_bounds(n_total, rank, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(n_total, rank, world)
+                assert lo.value == prev
+                prev = hi.value
+            assert prev == n_total
+    lo, hi = C.c_int64(), C.c_int64()
+    assert L.dsh_dist_shard_bounds(10, 3, 3, C.byref(lo), C.byref(hi)) < 0  # rank out of range

@@ -409,12 +409,20 @@ def test_rlc_config5_esdirk34_with_threshold_events_is_bit_identical_to_the_orac
         assert 0 < (m["root_idx"] >= 0).sum() < nb
 
 
+def _needs_experiments():
+    """the measured-slower variants are compiled only with `make EXPERIMENTS=1` (csrc/Makefile, -DDSH_EXPERIMENTS); the shipped library ignores their knobs"""
+    from diffsol_amd import _ffi
+    if not _ffi.load_device_lib().dsh_experiments_enabled():
+        pytest.skip("library built without DSH_EXPERIMENTS (make -C diffsol_amd/csrc EXPERIMENTS=1)")
+
+
 @pytest.mark.parametrize("var,k", [("DSH_REBIN", "1"), ("DSH_REBIN", "3"), ("DSH_REBIN_STEPS", "16"), ("DSH_REBIN_STEPS", "100")])
 def test_segmented_per_member_runs_with_rebinning_between_launches_give_the_bits_of_the_single_launch(H, monkeypatch, var, k):
     """k_bdf_adaptive<.., SEG>: the launch ends for a member after k save points (or k trips of its step loop), the whole per-member integrator state goes to memory,
     the members are dealt to lanes again in another order (device radix sort on (order, steps since the last change, |h|)) and the next launch resumes.  Nothing of the
     arithmetic depends on where a launch ends: every output bit, every counter equals the single launch.  (Measured slower than the single launch in every setting —
     profiles/r03_per_member.md — so it stays an opt-in.)"""
+    _needs_experiments()
     p = robertson_params(700, seed=9)
     s = H.Solver("robertson_ode", p, nbatch=len(p), model_size=1, **ROB)
     y0, t0, m0 = s.solve_dense_adaptive(T_EVAL, want_member_stats=True, group=1)
@@ -465,6 +473,7 @@ def test_phase_scheduled_per_member_kernel_gives_the_bits_of_the_nested_loop_ker
     phase per wavefront pass, chosen by ballot).  Both must give every member's states, counters, event times, column counts and failure codes
     bit for bit — and equal the oracle's independent solves.  Ensembles are sized and parameterised so that lanes of a wavefront sit in different phases
     (different iteration counts, rejected steps, refactorisations, early event stops, a member that fails)."""
+    _needs_experiments()
     rng = np.random.default_rng(12)
     nb = 333
     if model in ("robertson_ode", "robertson"):
@@ -508,6 +517,7 @@ def test_streaming_lane_per_member_kernel_gives_the_bits_of_the_register_array_f
     of diff / diff_tmp, next prediction made by the accept pass); DSH_LANE_BANDED_V1=1 selects k_bdf_adaptive's banded branch (one loop per vector
     operation).  Same arithmetic in the same order: states, counters, event data bit for bit — for sizes that are / are not multiples of the load chunks
     (13 is prime), bandwidth 1 and 2, per-member control and wavefront lock-step groups, with steps that fail and orders that change."""
+    _needs_experiments()
     rng = np.random.default_rng(8)
     cases = [("heat1d", rng.uniform(0.5, 2.0, (130, 1)), [0.01, 0.1, 0.3], 13, dict(rtol=1e-6, atol=[1e-7])),
              ("robertson_ode", robertson_params(70), [0.4, 4.0, 40.0, 400.0], 4, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 4)),
