@@ -153,7 +153,7 @@ int dsh_dist_world(const dsh_dist* d) { return d ? d->world : -1; }
 
 // the two copies on their own (also what the GPU tier drives with synthetic buffers for world sizes the box does not have)
 int dsh_dist_pack_shard(dsh_ctx* ctx, void* stream, const double* local, int64_t lead, int64_t nb_local, int64_t m, double* send) {
-  DSH_REQUIRE(ctx && local && send && lead >= 0 && nb_local >= 0 && m >= nb_local, "dsh_dist_pack_shard: bad arguments");
+  DSH_REQUIRE(ctx && (local || nb_local == 0) && send && lead >= 0 && nb_local >= 0 && m >= nb_local, "dsh_dist_pack_shard: bad arguments");  // an empty shard (more ranks than members) has no buffer
   if (lead == 0 || m == 0) return DSH_OK;
   DSH_REQUIRE(lead <= 65535, "dsh_dist_pack_shard: more than 65535 rows (save points x states) per call");
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((m + 255) / 256), (unsigned)lead), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream, local, send, lead, nb_local, m);
@@ -173,13 +173,14 @@ int dsh_dist_unpack_gathered(dsh_ctx* ctx, void* stream, const double* recv, int
 // All-gather of this rank's [lead][hi - lo] along the batch axis into out [lead][n_total] (every rank gets all of it), issued behind everything the solver's
 // stream holds at the time of the call and run on the communicator's stream: returns at once.  `local` and `out` must stay untouched until dsh_gather_wait.
 int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out) {
-  if (!d || !local || !out || lead < 0 || n_total < 0) { set_error("dsh_gather_batch_axis: bad arguments"); return DSH_E_INVALID; }
+  if (!d || !out || lead < 0 || n_total < 0) { set_error("dsh_gather_batch_axis: bad arguments"); return DSH_E_INVALID; }
   if (d->pending) { set_error("dsh_gather_batch_axis_async: the previous gather of this communicator has not been waited for (dsh_gather_wait)"); return DSH_E_INVALID; }
   int64_t lo = 0, hi = 0;
   int rc = dsh_dist_shard_bounds(n_total, d->rank, d->world, &lo, &hi);
   if (rc != DSH_OK) return rc;
   DSH_HIP_CHECK(hipSetDevice(d->ctx->device));
   const int64_t m = (n_total + d->world - 1) / d->world, nl = hi - lo;
+  if (!local && nl > 0) { set_error("dsh_gather_batch_axis: null shard buffer"); return DSH_E_INVALID; }
   const size_t send_len = (size_t)(lead * m), recv_len = send_len * (size_t)d->world;
   DSH_HIP_CHECK(hipEventRecord(d->ready, d->ctx->stream));
   DSH_HIP_CHECK(hipStreamWaitEvent(d->stream, d->ready, 0));

@@ -33,6 +33,7 @@ int jit_launch(dsh_ctx* ctx, int model, const char* header, const std::string& g
   int rc = jit_get_function(model, header, group_key, group, name, &f);
   if (rc != DSH_OK) return rc;
   void* argv[] = {(void*)&args...};
+  if (shmem > 64u * 1024u) { (void)hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); (void)hipGetLastError(); }  // up to the 160 KB of a CU
   DSH_HIP_CHECK(hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem, ctx->stream, argv, nullptr));
   return DSH_OK;
 }

@@ -16,6 +16,7 @@
 #include "dsh_internal.hpp"
 #include "dsh_resident.hpp"
 #include "dsh_wave_member_kernel.hpp"
+#include "dsh_team_member_kernel.hpp"
 #include "dsh_sdirk_wave_member_kernel.hpp"
 #include "dsh_jit.hpp"
 
@@ -24,18 +25,21 @@ using namespace dsh;
 
 extern "C" {
 
+// 1: one wavefront per member (n <= 64; BDF and the SDIRK methods); 2: one workgroup per member (64 < n <= 140, identity mass; BDF — dsh_team_member_kernel.hpp); 0: neither
 int dsh_model_has_wave_member(int model, int64_t size) {
-  if (is_jit_model(model)) {  // run-time-sized DiffSL model: identity mass, at most two stop conditions, one lane per component
+  if (is_jit_model(model)) {  // run-time-sized DiffSL model: at most two stop conditions, one lane per component
     const JitInfo* ji = jit_info(model);
+    if (!(ji && ji->form == DSH_JIT_FORM_DYNAMIC && ji->nroots <= 2 && ji->np <= 64)) return 0;  // (the workgroup form would take up to 128 / 192 parameters)
     // with a mass matrix (DAEs: consistent initialisation and M in the residual and in M - cJ) the kernel keeps M's rows in LDS next to J's: n <= 48
-    return ji && ji->form == DSH_JIT_FORM_DYNAMIC && ji->n <= (ji->has_mass ? 48 : 64) && ji->nroots <= 2 && ji->np <= 64 ? 1 : 0;
+    if (ji->n <= (ji->has_mass ? 48 : 64)) return 1;
+    return !ji->has_mass && ji->n <= kTeamMaxN ? 2 : 0;
   }
   if (!(model == DSH_MODEL_DYDT_Y2 || model == DSH_MODEL_GAUSSIAN_DECAY || model == DSH_MODEL_HEAT1D || model == DSH_MODEL_SPM ||
         (model == DSH_MODEL_ROBERTSON_ODE && size > 1)))
     return 0;
   int64_t n = 0;
   if (dsh_model_info(model, size, &n, nullptr, nullptr, nullptr) != DSH_OK) return 0;
-  return n >= 1 && n <= 64 ? 1 : 0;
+  return n >= 1 && n <= 64 ? 1 : (n <= kTeamMaxN ? 2 : 0);
 }
 
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
@@ -46,13 +50,14 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  if (!dsh_model_has_wave_member(model, size)) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  const int wm_kind = dsh_model_has_wave_member(model, size);
+  if (!wm_kind) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; identity mass: n <= 140, one workgroup per member) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveMemberConsts C;
   int64_t n = 0, np = 0, nroots = 0;
   int rc = dsh_model_info(model, size, &n, &np, nullptr, &nroots);
   if (rc != DSH_OK) return rc;
-  DSH_REQUIRE(np <= 64 && nroots <= 2, "wave-member kernel: at most 64 parameters and 2 root functions");
+  DSH_REQUIRE(np <= (wm_kind == 2 ? (n <= 128 ? 128 : 192) : 64) && nroots <= 2, "wave-member kernel: at most 64 parameters (workgroup form: one per thread) and 2 root functions");
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
@@ -91,8 +96,39 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
   int has_mass = 0;
   (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
-  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
   const int ab = atol_nb == 1 ? 1 : 0;
+  double* jac_scratch = nullptr;
+  if (wm_kind == 2) {
+    // one workgroup per member (64 < n <= 140): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
+    const int waves = n <= 128 ? 2 : 3;
+    const size_t lds_team = sizeof(double) * team_lds_doubles((int)n, waves);
+    rc = dsh_malloc(ctx, (int64_t)sizeof(double) * n * n * nb, 0, (void**)&jac_scratch);
+    if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+    DSH_HIP_CHECK(timing_begin(ctx));
+    if (is_jit_model(model)) {
+      const std::string name = std::string("dsh::k_bdf_team_member<") + (waves == 2 ? "2" : "3") + ">";
+      rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
+                      (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+      if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+    } else {
+      static bool attr_dev[64] = {false};
+      bool& attr = attr_dev[ctx->device & 63];
+      if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+      }
+      if (waves == 2)
+        hipLaunchKernelGGL((k_bdf_team_member<2>), dim3((unsigned)nb), dim3(128), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev,
+                           (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+      else
+        hipLaunchKernelGGL((k_bdf_team_member<3>), dim3((unsigned)nb), dim3(192), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev,
+                           (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+    }
+  } else {
+  int has_mass = 0;
+  (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
 #define DSH_WM_LAUNCH(NPV)                                                                                                                              \
   hipLaunchKernelGGL((k_bdf_wave_member<NPV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
                      (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
@@ -106,6 +142,7 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   else if (n <= 32) DSH_WM_LAUNCH(32);
   else if (n <= 48) DSH_WM_LAUNCH(48);
   else DSH_WM_LAUNCH(64);
+  }
 #undef DSH_WM_LAUNCH
   DSH_HIP_CHECK(hipGetLastError());
   DSH_HIP_CHECK(timing_end(ctx));
@@ -113,6 +150,7 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   DSH_HIP_CHECK(timing_collect(ctx));
+  if (jac_scratch) dsh_free(ctx, jac_scratch);
   dsh_free(ctx, t_eval_dev);
   dsh_free(ctx, totals_dev);
   dsh_free(ctx, consts_dev);
@@ -120,8 +158,8 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   return DSH_OK;
 }
 
-// has_wave_member for the SDIRK methods: the same models as for BDF
-int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size); }
+// has_wave_member for the SDIRK methods: the wavefront-per-member models (n <= 64); the workgroup-per-member form is BDF only
+int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size) == 1 ? 1 : 0; }
 
 int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                 double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,

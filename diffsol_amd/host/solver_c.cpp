@@ -89,7 +89,7 @@ void download(const HipVec& v, double* host) {
 // Which device-resident kernel (if any) integrates this problem (model x method) in the given control granularity.
 struct ResidentPick {
   bool ok = false;
-  bool wave_member = false;  // one wavefront per member (run-time-sized models, n <= 64; BDF also DiffSL models with a mass matrix, n <= 48; SDIRK identity mass)
+  bool wave_member = false;  // one wavefront per member (run-time-sized models, n <= 64; BDF also DiffSL models with a mass matrix, n <= 48; SDIRK identity mass) or, BDF with 64 < n <= 140, one workgroup per member
   int model = 0;
   int64_t size = 0;
   int method = 0;
@@ -129,7 +129,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
     r.ok = true; r.model = model; r.size = size;
-  } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) : dsh_model_has_wave_member_sdirk(model, size))) {
+  } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) != 0 : dsh_model_has_wave_member_sdirk(model, size) != 0)) {
     r.ok = true; r.wave_member = true; r.model = model; r.size = size;
   }
   return r;
@@ -233,7 +233,7 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
                                      "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
   if (!pk.ok)
     throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
-                                     "run-time-sized ODE models with n <= 64: BDF)");
+                                     "run-time-sized ODE models with n <= 140: BDF)");
   const int model = pk.model;
   const int64_t size = pk.size;
   const int method = pk.method;

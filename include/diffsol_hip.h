@@ -441,6 +441,9 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
  * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
 /* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; DiffSL models with a mass matrix — DAEs, made consistent on the device — n <= 48; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
  * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).
+ * Identity-mass models with 64 < n <= 140 (dense Jacobians: the sizes between the wavefront form and the host-driven path) run ONE WORKGROUP per member instead
+ * (dsh_team_member_kernel.hpp: thread = state component, the LU of M - cJ in the CU's 160 KB LDS): dsh_model_has_wave_member returns 1 for the wavefront form,
+ * 2 for the workgroup form, 0 for neither; dsh_bdf_solve_wave_member takes both.
  * dsh_sdirk_solve_wave_member: the same for TR-BDF2 (method 1) / ESDIRK34 (method 2) — Sdirk::step (sdirk.rs:409-543) over Rk (runge_kutta.rs:466-960),
  * the same models (dsh_model_has_wave_member_sdirk), DAEs included.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */

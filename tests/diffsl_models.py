@@ -343,3 +343,19 @@ M_i { 0, dydt_i, 0 }
 F_i { a, D * (lap_i + eleft_i * a + eright_i * b) * 121.0, b }
 out_i { y_i * y_i }
 """
+
+
+def oscillators(m):
+    """n = 2 m states: m damped oscillator pairs (x_k, z_k) with frequency w >> damping a, every x coupled to every other through a DENSE m x m block.  The Jacobian has
+    no band structure, and w c > 1 + a c makes the partial pivoting of M - c J interchange rows (the off-diagonal w beats the diagonal): what the workgroup-per-member
+    integrator (64 < n <= 140) is tested on."""
+    return f"""
+in = [w, a, eps]
+w {{ 50.0 }}
+a {{ 1.0 }}
+eps {{ 0.01 }}
+S_ij {{ (0:{m}, 0:{m}): 1.0 }}
+u_i {{ (0:{m}): x = 1.0, ({m}:{2 * m}): z = 0.0 }}
+sx_i {{ S_ij * x_j }}
+F_i {{ (0:{m}): -w * z_i - a * x_i - eps * sx_i, ({m}:{2 * m}): w * x_i - a * z_i }}
+"""
