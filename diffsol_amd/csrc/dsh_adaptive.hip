@@ -140,7 +140,9 @@ int dsh_model_has_adaptive_reset(int model, int64_t size) {
 int dsh_model_has_adaptive_sens(int model, int64_t size) {
   if (is_jit_model(model)) {  // DiffSL / external models in the register-resident form with parameter derivatives (DSH_JIT_HAS_SENS)
     const JitInfo* ji = jit_info(model);
-    return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 && ji->has_sens && !ji->has_mass && ji->nroots == 0 ? 1 : 0;
+    if (!(ji && ji->has_sens && !ji->has_mass && ji->nroots == 0)) return 0;
+    // register-resident form (n <= 4) or the banded lane-per-member form (the state and the sensitivity arrays in per-lane memory; k_bdf_adaptive's banded branch)
+    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || ji->form == DSH_JIT_FORM_STATIC_BANDED ? 1 : 0;
   }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) { ok = adaptive_sens_ok<decltype(mdl)>(); });
@@ -157,7 +159,7 @@ int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t n
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_adaptive_sens(model, size)) {
-    set_error("dsh_bdf_solve_adaptive_sens: the model has no device-resident BDF with forward sensitivities (static ODE model with parameter derivatives, n <= 4, no root functions)");
+    set_error("dsh_bdf_solve_adaptive_sens: the model has no device-resident BDF with forward sensitivities (identity-mass ODE model with parameter derivatives and no root functions: register-resident n <= 4, or the banded lane-per-member form)");
     return DSH_E_UNSUPPORTED;
   }
   const SensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
@@ -187,6 +189,10 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;
     if (dsh_model_info(model, size, &ns, &npar_, &hm_, &nroots_) != DSH_OK) return DSH_E_INVALID;
     DSH_REQUIRE(sens->natol == 0 || sens->natol == 1 || sens->natol == ns, "sens_atol must have length 1 or nstates");
+    bool uniform = true;
+    for (int64_t i = 1; i < sens->natol; ++i) uniform = uniform && sens->atol_host[i] == sens->atol_host[0];
+    DSH_REQUIRE(ns <= 4 || uniform, "device-resident sensitivities of models with more than 4 states take one sens_atol for every state");
+    C.sens_pad = (ns > 4 || sens->natol <= 1) ? 1 : 0;  // 1: sens_atol[0] for every state
     for (int64_t i = 0; i < 4 && i < ns; ++i) C.sens_atol[i] = sens->natol == 0 ? 0.0 : (sens->natol == 1 ? sens->atol_host[0] : sens->atol_host[i]);
   }
   {  // Bdf::_new tables (bdf.rs:286-306)
@@ -343,7 +349,7 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     const JitInfo* ji = jit_info(model);
     const bool sched = !sens && sched_env && C.r.o.group == 1 && ji && ji->form == DSH_JIT_FORM_STATIC && !ji->has_reset;  // the phase-scheduled kernel stops at events
     // banded lane-per-member form: the memory-streaming kernel (dsh_lane_banded_kernel.hpp; same bits); DSH_LANE_BANDED_V1=1 keeps k_bdf_adaptive's banded branch
-    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || !lane_v1_env);  // models with a mass matrix: k_bdf_lane_banded only
+    const bool lane_v2 = ji && ji->form == DSH_JIT_FORM_STATIC_BANDED && (ji->has_mass || !lane_v1_env) && !sens;  // forward sensitivities: k_bdf_adaptive's banded branch (the streaming kernel does not carry them)  // models with a mass matrix: k_bdf_lane_banded only
     const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + (sens ? ", false, true>" : ">");  // SENS: <.., SEG = false, SENS = true>
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
                              : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;

@@ -125,8 +125,10 @@ DSH_UNROLL_N
   // ---- forward sensitivities: new_with_sensitivities_and_consistent (state.rs:1032-1083: s_j = SensInit(t0) e_j, ds_j = SensRhs(s_j) about (y0, t0)),
   // new_augmented (bdf.rs:384-432): sdiff_j[:, 0] = s_j, sdiff_j[:, 1] = h ds_j.  Per-lane arrays in scratch memory (indexed by the parameter at run time).
   constexpr int NPS = SENS ? NP : 1, NCS = SENS ? kNC : 1, NS = SENS ? N : 1;
-  static_assert(!SENS || (!Mdl::HAS_MASS && model_band_k<Mdl>::value == 0 && Mdl::NROOTS == 0 && !SEG),
-                "device-resident forward sensitivities: register-resident ODE models without root functions");
+  // banded lane-per-member models (model_band_k > 0: the state in per-lane memory) take the same code: the sensitivity arrays are per-lane memory too, the
+  // sensitivity solves run on the banded factors (bdf.rs:934-989 for the battery / PDE models)
+  static_assert(!SENS || (!Mdl::HAS_MASS && Mdl::NROOTS == 0 && !SEG),
+                "device-resident forward sensitivities: identity-mass ODE models without root functions");
   double S[NPS][NCS][NS];    // sdiff
   double s_cur[NPS][NS];     // state.s: the latest solution of the sensitivity equations (the scale of the sensitivity error norms)
   double s_delta[NPS][NS];   // s - s_predict of the last sensitivity_solve
@@ -134,7 +136,7 @@ DSH_UNROLL_N
   double s_atol[NS];
   if constexpr (SENS) {
 DSH_UNROLL_N
-    for (int i = 0; i < N; ++i) s_atol[i] = C.sens_atol[i];
+    for (int i = 0; i < N; ++i) s_atol[i] = C.sens_atol[C.sens_pad != 0 ? 0 : (i < 4 ? i : 0)];  // sens_pad = 1: one value for every state (the only form for n > 4)
     for (int j = 0; j < NP; ++j) {
       double ev[NP], s0[N], jm[N], dfdp[N];
 #pragma unroll
@@ -613,7 +615,10 @@ DSH_UNROLL_N
                 const double fr = jm[i] + dfdp[i];
                 delta[i] = 1.0 * (xs[i] + spsi[i]) + (-s_c) * fr;
               }
-              const bool lu_ok = group_all<WAVE>(lu_solve_reg<N>(A, P, delta));
+              bool s_lu_ok;
+              if constexpr (BANDED) s_lu_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
+              else s_lu_ok = lu_solve_reg<N>(A, P, delta);
+              const bool lu_ok = group_all<WAVE>(s_lu_ok);
               if (!lu_ok) break;
               double acc = 0.0;
 DSH_UNROLL_N

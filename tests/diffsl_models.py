@@ -100,8 +100,9 @@ F_i {{ D * heat_i / (h * h) }}
 """
 
 
-def spm(m=20, voltage=False):
-    """voltage=True: the stop conditions of the battery primer (terminal voltage leaves [3.105, 4.1] V) instead of the cheap surface-concentration limits.
+def spm(m=20, voltage=False, no_stops=False):
+    """no_stops=True: the same equations without stop conditions (forward sensitivities in the device-resident kernels need a model without root functions).
+    voltage=True: the stop conditions of the battery primer (terminal voltage leaves [3.105, 4.1] V) instead of the cheap surface-concentration limits.
     The single-particle model of the battery primer (n = 2 + 2m) written as DiffSL from its formulas: spherical finite-volume Laplacians as sparse
     matrices, flux terms on the outer shells, terminal-voltage stop conditions.  Constants as in the built-in model (oracle_models.hpp Spm)."""
     def lap(scale):
@@ -156,6 +157,8 @@ stop_i {{
 }}
 out_i {{ sn_i, sp_i, {ocp_p.replace("sp", "sp_i")} }}
 """
+    if no_stops:
+        stops = ""
     return f"""
 in = [current]
 current {{ 1.0 }}

@@ -147,3 +147,31 @@ def test_resident_sensitivities_refuse_what_they_do_not_cover(H):
     s2 = H.Solver("robertson_ode", [[0.04, 1e4, 3e7]] * 4, nbatch=4, model_size=1, **ROB)  # no sens requested
     with pytest.raises(Exception, match="dshs_create_sens"):
         s2.solve_dense_adaptive_sens([1.0])
+
+
+@pytest.mark.parametrize("group", [1, 64])
+@pytest.mark.parametrize("error_control", [None, (1e-6, [1e-6])])
+def test_banded_lane_per_member_bdf_with_sensitivities_heat_and_battery(H, O, det_pow, group, error_control):
+    """forward sensitivities in the banded lane-per-member form (bdf.rs:934-989 for the PDE / battery models).  The state, the difference arrays
+    of the state AND of every sensitivity live in per-lane memory (k_bdf_adaptive's banded branch with SENS; the sensitivity solves run on the banded factors):
+    heat1d with du/dD (n = 20 and 33: bandwidth 1) and the single-particle battery model with d(state)/dI (n = 42), 70 members (one full wavefront + a partial
+    one), per member and in lock-step groups, with and without sensitivity error control — every counter and every bit of states and sensitivities against the
+    oracle's solve_dense_sensitivities on the host twin."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl as fe
+    rng = np.random.default_rng(5)
+    cases = [(D.heat1d(20), rng.uniform(0.5, 2.0, (70, 1)), [0.01, 0.05, 0.2], dict(rtol=1e-6, atol=[1e-7])),
+             (D.heat1d(33), rng.uniform(0.5, 2.0, (70, 1)), [0.01, 0.1], dict(rtol=1e-5, atol=[1e-7])),
+             (D.spm(20, no_stops=True), rng.uniform(0.6, 1.4, (70, 1)), [360.0, 1200.0, 3000.0], dict(rtol=1e-6, atol=[1e-6]))]
+    for code, p, te, tol in cases:
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        assert m.form == fe.FORM_DYNAMIC and m.nroots == 0
+        kw = dict(sens_rtol=error_control[0], sens_atol=error_control[1]) if error_control else {}
+        s = H.Solver(m, p, nbatch=len(p), sens=True, **kw, **tol)
+        y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=group, want_member_stats=True)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=group, **kw, **tol)
+        assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
+        assert np.array_equal(mm["stats"].T, sto), "counters differ"
+        assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
+        assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3))), "sensitivities differ"
+        assert np.abs(sens).max() > 0
