@@ -50,6 +50,8 @@ DEVICE_ABI = {
     "dsh_dist_unpack_gathered": (cint, [vp, vp, vp, i64, i64, cint, vp]),
     "dsh_ctx_set_timing": (cint, [vp, cint]),
     "dsh_ctx_set_timing_target": (cint, [vp, cint]),
+    "dsh_ctx_set_solve_mode": (cint, [vp, cint]),
+    "dsh_ctx_get_solve_mode": (cint, [vp]),
     "dsh_ctx_set_poll": (cint, [vp, cint]),
     "dsh_ctx_get_timing": (cint, [vp, c_i64p, c_dp]),
     "dsh_ctx_get_timing_overhead": (cint, [vp, c_dp, c_dp]),
@@ -191,6 +193,7 @@ HOST_ABI = {
     "dshs_interpolate_sens": (cint, [vp, dbl, c_dp]),
     "dshs_reset": (cint, [vp]),
     "dshs_context": (vp, [vp]),
+    "dshs_set_linear_solve_mode": (cint, [vp, cint]),
     "dshs_set_kernel_timing": (cint, [vp, cint]),
     "dshs_set_kernel_timing_target": (cint, [vp, cint]),
     "dshs_get_kernel_timing": (cint, [vp, c_i64p, c_dp]),

@@ -228,6 +228,12 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
   }
   return DSH_OK;
 }
+int dsh_ctx_set_solve_mode(dsh_ctx* ctx, int mode) {
+  DSH_REQUIRE(ctx != nullptr && (mode == DSH_SOLVE_EXACT || mode == DSH_SOLVE_REORDERED), "dsh_ctx_set_solve_mode: unknown mode");
+  ctx->solve_mode = mode;
+  return DSH_OK;
+}
+int dsh_ctx_get_solve_mode(const dsh_ctx* ctx) { return ctx ? ctx->solve_mode : -1; }
 int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target) {
   DSH_REQUIRE(target >= DSH_TIMING_RESIDENT && target <= DSH_TIMING_LU_FACTOR, "dsh_ctx_set_timing_target: unknown target");
   ctx->timing_target = target;

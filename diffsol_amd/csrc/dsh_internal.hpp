@@ -85,6 +85,7 @@ struct dsh_ctx {
   double timed_clock_ms = 0.0;       // same launches measured with the in-kernel 100 MHz device clock (max block end - min block start)
   double bracket_overhead_ms = 0.0;  // elapsed time of an empty event bracket (calibrated when timing is enabled)
   int64_t timed_launches = 0;
+  int solve_mode = 0;  // DSH_SOLVE_EXACT (default: every solve in the reference's order of operations) | DSH_SOLVE_REORDERED (opt-in: dsh_lu_band_affine.hpp where it applies)
   // constants + save points of the last device-resident solve, kept on the device between solves (dsh_adaptive.hip); freed by dsh_ctx_destroy
   unsigned char* const_cache_dev = nullptr;
   std::vector<unsigned char>* const_cache_host = nullptr;

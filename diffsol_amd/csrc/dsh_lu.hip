@@ -15,6 +15,7 @@
 #include "dsh_lu_wave.hpp"
 #include "dsh_lu_band.hpp"
 #include "dsh_lu_band_team.hpp"
+#include "dsh_lu_band_affine.hpp"
 #include "dsh_lu_tiled.hpp"
 
 using namespace dsh;
@@ -391,6 +392,24 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
     // k_lu_band_solve_wide); large ensembles fill the machine with one lane per system.  DSH_LU_BAND_WIDE=0 / 1 / 2 forces one of them.
     static const int wide_env = [] { const char* e = std::getenv("DSH_LU_BAND_WIDE"); return e && *e ? std::atoi(e) : -1; }();
     const bool wide = (wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384)) && n * nb < (1ll << 28);  // 32-bit byte offsets; n = 42 x 32 768: 43 us one lane per system, 171 us wide
+    // opt-in (dsh_ctx_set_solve_mode): chunked affine maps, another order of the same sums — tridiagonal systems, n <= 1024
+    if (ctx->solve_mode == DSH_SOLVE_REORDERED && lu->band_k == 1 && n >= 32 && n <= 1024 && nb <= 16384) {
+      g = grid_for(nb, kAffSys);
+      int rc = begin_records(ctx, g.x, &rec, &seq);
+      if (rc != DSH_OK) return rc;
+#define DSH_AFF(CLV) hipLaunchKernelGGL((k_lu_band_solve_affine<CLV>), g, dim3(kAffThreads), 0, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
+      if (n <= 128) DSH_AFF(8); else if (n <= 256) DSH_AFF(16); else if (n <= 512) DSH_AFF(32); else DSH_AFF(64);
+#undef DSH_AFF
+      DSH_HIP_CHECK(hipGetLastError());
+      if (!wait) { *gx_out = g.x; *seq_out = seq; return DSH_OK; }
+      rc = fetch_records(ctx, g.x, seq);
+      if (rc != DSH_OK) return rc;
+      if (ctx->res_cnt != 0ull) {
+        set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+        return DSH_E_SINGULAR;
+      }
+      return DSH_OK;
+    }
     const bool team = wide && wide_env != 2;
     const int sys = nb <= 4096 ? 16 : (nb <= 8192 ? 32 : 64);
     g = team ? grid_for(nb, sys) : (wide ? grid_for(nb, 8) : grid_for(nb, 64));

@@ -457,6 +457,7 @@ int dshs_reset(dshs_solver* s) {
   return guarded([&]() { s->resident_roots_valid = false; s->make_solver(); return 0; });
 }
 dsh_ctx* dshs_context(dshs_solver* s) { return s ? s->ctx.raw() : nullptr; }
+int dshs_set_linear_solve_mode(dshs_solver* s, int mode) { return dsh_ctx_set_solve_mode(s->ctx.raw(), mode); }
 int dshs_set_kernel_timing(dshs_solver* s, int enable) {
   // timed launches bracket the stand-alone Newton kernel: keep the accept launch separate while timing is on
   s->kernel_timing = enable != 0;

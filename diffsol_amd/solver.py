@@ -101,6 +101,10 @@ class Solver:
         """raw dsh_ctx* of this solver (dshs_context): what dist.CabiCommunicator takes"""
         return vp(self._L.dshs_context(self._h))
 
+    def set_linear_solve_mode(self, mode):
+        """0 = exact (default: the reference's order of operations, bit-identical to the CPU path); 1 = reordered (opt-in: the chunked-affine banded solve, ~1e-13 relative)"""
+        check(self._L.dshs_set_linear_solve_mode(self._h, int(mode)), host=True)
+
     def set_kernel_timing(self, enable=True):
         check(self._L.dshs_set_kernel_timing(self._h, 1 if enable else 0), host=True)
 

@@ -68,6 +68,14 @@ int dsh_experiments_enabled(void);
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
 /* Which launches the event brackets go around while timing is enabled (resets the accumulated time): the device-resident integrators and the fused Newton launch
  * (default), every dsh_lu_solve launch, or every dsh_lu_factor call (staging copy + factor kernel for the matrix-core kernel).  bench.py's per-config rooflines. */
+/* Order of operations of the linear solves issued on this context.  DSH_SOLVE_EXACT (default): the reference's getrs order — solutions bit-identical to the CPU
+ * path.  DSH_SOLVE_REORDERED (opt-in, like dsh_adaptive_options.deterministic_pow = 2): banded solves of small ensembles (K = 1, n <= 1024, <= 16384 systems) run as
+ * chunked affine maps (csrc/dsh_lu_band_affine.hpp: 1/8 of the dependent chain, another association of the same sums, reciprocal instead of division) — equal to
+ * the exact solve to ~1e-13 relative on the library's models, NOT bit-comparable; everything else keeps the exact kernels. */
+#define DSH_SOLVE_EXACT 0
+#define DSH_SOLVE_REORDERED 1
+int dsh_ctx_set_solve_mode(dsh_ctx* ctx, int mode);
+int dsh_ctx_get_solve_mode(const dsh_ctx* ctx);
 #define DSH_TIMING_RESIDENT 0
 #define DSH_TIMING_LU_SOLVE 1
 #define DSH_TIMING_LU_FACTOR 2

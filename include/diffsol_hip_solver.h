@@ -72,6 +72,8 @@ int dshs_reset(dshs_solver* s);
 /* forwarders to dsh_ctx_set_timing / dsh_ctx_get_timing of the solver's context */
 /* the solver's device context (its stream is where every launch of this solver goes): e.g. for dsh_dist_init — a gather issued on it waits for the solver's work */
 dsh_ctx* dshs_context(dshs_solver* s);
+/* dsh_ctx_set_solve_mode of the solver's context: DSH_SOLVE_EXACT (default, bit-identical to the CPU path) | DSH_SOLVE_REORDERED (opt-in, tolerance-level differences) */
+int dshs_set_linear_solve_mode(dshs_solver* s, int mode);
 int dshs_set_kernel_timing(dshs_solver* s, int enable);
 int dshs_set_kernel_timing_target(dshs_solver* s, int target); /* DSH_TIMING_* of diffsol_hip.h */
 int dshs_get_kernel_timing(dshs_solver* s, int64_t* launches, double* total_ms);
