@@ -673,14 +673,15 @@ def main():
 
         extras["per_member"] = dict(mode_pass(ENSEMBLE_PER_MEMBER, False), note="every member its own step-size/order history (diffsol's CPU semantics for a sweep)")
         try:  # its roofline entry, from the committed counters of the same kernel (MODE=member scripts/profile_r03.sh); refused when the kernel sources changed since
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_per_member.json"))).get("bench_kernel", {})
+            pm_name = next((f for f in ("r04_pmc_per_member.json", "r03_pmc_per_member.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_per_member.json")
+            pm = json.load(open(os.path.join(ROOT, "profiles", pm_name))).get("bench_kernel", {})
             if pm.get("kernel_source_sha16") == kernel_source_hash() and pm.get("members") == nb and world == 1:
                 t_s = extras["per_member"]["ms_per_step"] * 1e-3
                 extras["per_member"]["roofline"] = {
                     "bound": "valu", "kernel": pm.get("kernel"), "avg_launch_us": t_s * 1e6, "measured": "wall clock of the per-member solves of this pass (one launch each)",
                     "achieved": pm["valu_insts_per_launch"] * 64 / t_s / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s",
                     "frac": pm["valu_insts_per_launch"] * 64 / t_s / 1e12 / VALU_PEAK_TLANEOPS, "valu_wave_instructions_per_launch": pm["valu_insts_per_launch"],
-                    "fp64_wave_instructions_per_launch": pm.get("f64_insts_per_launch"), "traffic": pm.get("hbm_bytes_per_launch"), "counters_from": "profiles/r03_pmc_per_member.json",
+                    "fp64_wave_instructions_per_launch": pm.get("f64_insts_per_launch"), "traffic": pm.get("hbm_bytes_per_launch"), "counters_from": "profiles/" + pm_name,
                     "note": "lane-operations ISSUED, most of them masked off: 3.3x the wave-instructions of the lock-step kernel for fewer member-steps is divergence inside "
                             "wavefronts (profiles/r03_per_member.md: 8.3 ms against 3.2 ms for the same ensemble size with no divergence inside any wavefront)"}
             else:
@@ -772,16 +773,17 @@ def main():
             avg_s = kernel_ms * 1e-3 / launches
             pmc = {}
             stale = None
-            path = os.path.join(ROOT, "profiles", "r03_pmc_resident.json")
+            pmc_name = next((f for f in ("r04_pmc_resident.json", "r03_pmc_resident.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_resident.json")
+            path = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(path):
                 try:
                     pmc = json.load(open(path)).get("bench_kernel", {}) or {}
                 except Exception:
                     pmc = {}
                 if pmc:
-                    pmc["file"] = "profiles/r03_pmc_resident.json"
+                    pmc["file"] = "profiles/" + pmc_name
                     if pmc.get("kernel_source_sha16") != kernel_source_hash():  # counters of another kernel: no fraction rather than a stale one
-                        stale = f"profiles/r03_pmc_resident.json was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r03.sh"
+                        stale = f"profiles/{pmc_name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r04.sh"
                         pmc = {}
             algo_hbm = 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * (hi - lo)
             roof = {"bound": "valu", "kernel": "dsh::k_bdf_adaptive<RobertsonOde1, BA=true, WAVE=true> (the whole ensemble solve, one launch)",
