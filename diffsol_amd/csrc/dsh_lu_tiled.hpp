@@ -31,12 +31,39 @@ constexpr int kTlThreads = 512;
 constexpr int kTlWaves = kTlThreads / 64;
 constexpr int kTlPW = 64;     // panel width
 constexpr int kTlSW = 32;     // sub-panel width (columns of a row held in registers)
-constexpr int kTlLDP = 208;   // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
-constexpr int kTlCH = 208;    // columns per chunk (13 tiles of 16)
-constexpr int kTlL11P = 65;   // pitch of the staged L11
+constexpr int kTlLC = 16;     // columns of multipliers kept in LDS at a time (a sub-panel is flushed to W in two halves)
+constexpr int kTlL11P = 49;   // pitch of the staged L11 (rows 16..63, columns 0..47: the blocks below the diagonal blocks)
 constexpr int kTlMaxN = 1024;
+// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024).  kWavesPerEu = 4 lays a configuration out for TWO workgroups per CU
+// (at most 80 KB of LDS and 128 registers per lane: kLDP = kCH = 80, kRT = 2) so that one system's pivot-step chain runs under another system's trailing
+// update.  Measured for n = 512 x 4096 (profiles/r04_lu_bench.md): 40.4 ms against 33.6 ms with one workgroup per CU — under 128 registers the pivot-step
+// loop spills and the update keeps only two row tiles per wavefront — so both sizes run one workgroup per CU.
+#ifndef DSH_TL_TWO_PER_CU
+#define DSH_TL_TWO_PER_CU 0
+#endif
+template <int RS> struct tl_cfg;
+template <> struct tl_cfg<8> {
+  static constexpr int kMaxN = 512;                            // rows
+  static constexpr int kLDP = DSH_TL_TWO_PER_CU ? 80 : 208;    // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
+  static constexpr int kCH = DSH_TL_TWO_PER_CU ? 80 : 208;     // columns per chunk (tiles of 16)
+  static constexpr int kRT = DSH_TL_TWO_PER_CU ? 2 : 4;        // row tiles per wavefront whose L21 operand stays in registers
+  static constexpr int kWavesPerEu = DSH_TL_TWO_PER_CU ? 4 : 2;
+};
+template <> struct tl_cfg<16> {
+  static constexpr int kMaxN = 1024;
+  static constexpr int kLDP = 208;
+  static constexpr int kCH = 208;      // 13 tiles of 16
+  static constexpr int kRT = 4;
+  static constexpr int kWavesPerEu = 2;
+};
 inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }
-inline size_t tiled_lds_bytes() { return sizeof(double) * (size_t)(64 * kTlLDP + 64 * kTlL11P + 4 * 16 * 17); }
+// dynamic LDS (doubles): the panel needs kTlLC columns of 64 RS rows + Ubuf [32][33]; the trailing phase u12s [64][LDP] + l11 [48][49] + invd [4][16][17]
+template <int RS> constexpr size_t tiled_lds_doubles() {
+  constexpr size_t panel = (size_t)kTlLC * 64 * RS + 32 * 33;
+  constexpr size_t trail = (size_t)64 * tl_cfg<RS>::kLDP + 48 * kTlL11P + 4 * 16 * 17;
+  return panel > trail ? panel : trail;
+}
+inline size_t tiled_lds_bytes(int64_t n) { return sizeof(double) * (n <= 512 ? tiled_lds_doubles<8>() : tiled_lds_doubles<16>()); }
 
 typedef double tl_d4 __attribute__((ext_vector_type(4)));
 typedef double tl_d2 __attribute__((ext_vector_type(2)));
@@ -45,6 +72,15 @@ typedef double tl_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) double tl_gdouble;
 typedef __attribute__((address_space(1))) tl_d2 tl_gd2;
 typedef __attribute__((address_space(1))) char tl_gchar;
+
+// Arguments of a function that is not inlined arrive in vector registers, and the function cannot know that they are the same in every lane: these make
+// them scalars again (in the two-workgroups-per-CU layout the ~25 registers they would occupy per lane are a fifth of the budget).
+__device__ __forceinline__ int tl_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <class T> __device__ __forceinline__ T* tl_uni(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
 
 // batch-fastest operand a[(j*n + i)*nb + b] -> row-major working copies w[b][i][j], pitch ldw, columns n..ldw-1 zero.  One 32 x 32 (column x system)
 // tile per workgroup and row: reads are coalesced along b, writes along j.
@@ -68,41 +104,52 @@ __global__ void k_lu_stage_rowmajor(int n, int ldw, int64_t nb, const double* __
 }
 
 // trailing update of one group of RT row tiles over the column tiles tc0, tc0 + tcs, ... of the current chunk.  roffb: byte offsets of the lane's four
-// rows of every tile (32-bit: the loads and stores take the system's base from scalar registers)
-template <int RT>
-__device__ __forceinline__ void tl_update_tiles(tl_gdouble* __restrict__ W, const double* __restrict__ u12s, const double (&aneg)[4][16], const unsigned (&roffb)[4][4],
+// rows of every tile (32-bit: the loads and stores take the system's base from scalar registers).  LDP: pitch of the U12 chunk in LDS.  PF: the C tiles
+// of the next column tile are loaded while this one is multiplied (one workgroup per CU; with two workgroups per CU the other one hides the loads and the
+// registers are not there).
+template <int RT, int RTMAX, int LDP, bool PF>
+__device__ __forceinline__ void tl_update_tiles(tl_gdouble* __restrict__ W, const double* __restrict__ u12s, const double (&aneg)[RTMAX][16], const unsigned (&roffb)[RTMAX][4],
                                                 unsigned valid, int c_lo, int ntc, int tc0, int tcs, int lane) {
   const int q = lane >> 4, j = lane & 15;
   tl_gchar* const Wb = reinterpret_cast<tl_gchar*>(W);
-  tl_d4 acc[RT], nxt[RT];
+  tl_d4 acc[RT], nxt[PF ? RT : 1];
   const unsigned colb0 = (unsigned)(c_lo + j) * 8u;
-  if (tc0 < ntc) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb0 + 128u * (unsigned)tc0));
-  }
-  for (int tc = tc0; tc < ntc; tc += tcs) {
-    const unsigned colb = colb0 + 128u * (unsigned)tc;
-#pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = nxt[t];
-    if (tc + tcs < ntc) {
+  if constexpr (PF) {
+    if (tc0 < ntc) {
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb + 128u * (unsigned)tcs));
+        for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb0 + 128u * (unsigned)tc0));
     }
-    const double* ub = u12s + q * kTlLDP + 16 * tc + j;
+  }
+  for (int tc = tc0; tc < ntc; tc += tcs) {
+    const unsigned colb = colb0 + 128u * (unsigned)tc;
+    if constexpr (PF) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = nxt[t];
+      if (tc + tcs < ntc) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb + 128u * (unsigned)tcs));
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb));
+    }
+    const double* ub = u12s + q * LDP + 16 * tc + j;
     double bv[4], bn[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bn[e] = ub[4 * e * kTlLDP];
+    for (int e = 0; e < 4; ++e) bn[e] = ub[4 * e * LDP];
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {  // four k-blocks at a time, the next four U12 operands in flight behind them (and no more: registers)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = bn[e];
       if (kg < 3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bn[e] = ub[4 * (4 * kg + 4 + e) * kTlLDP];
+        for (int e = 0; e < 4; ++e) bn[e] = ub[4 * (4 * kg + 4 + e) * LDP];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -128,10 +175,10 @@ __device__ __forceinline__ void tl_update_tiles(tl_gdouble* __restrict__ W, cons
 // variants — two exchanges per step, the second one a 1 KB broadcast read per wavefront.
 // Rows never move; where the interchanges of the reference would have put them is kept in LDS: pos[row] (rows with pos < the current step are finished)
 // and its inverse rowat[pos]; only the owner of a step reads them, one lane updates them.
-// Layout of the dynamic LDS during the panel (doubles): [0, 16384) T / Lbuf — [32][512] (RS = 8) or [16][1024] (RS = 16): first the transposing stage
-// (thread per row in, column per wavefront out), then the multipliers, column kk at kk * P — and before the stage of the second sub-panel the operands of
-// its matrix-core update (L11A, the inverses of its diagonal blocks, U'); [16384, 17440) Ubuf [32][33]: the pivot rows' entries of the sub-panel's own
-// columns (U11), written by the column owners step by step.
+// Layout of the dynamic LDS during the panel (doubles), P = 64 RS rows: [0, 16 P) T / Lbuf — [16][P]: first the transposing stage (thread per row in,
+// column per wavefront out, 16 columns at a time), then the multipliers of 16 steps, column k & 15 at (k & 15) P, flushed to W after step 15 and after
+// step 31 — and before the stage of the second sub-panel the operands of its matrix-core update (L11A, the inverses of its diagonal blocks, U');
+// [16 P, 16 P + 1056) Ubuf [32][33]: the pivot rows' entries of the sub-panel's own columns (U11), written by the column owners step by step.
 template <int CTRL>
 __device__ __forceinline__ void tl_argmax_stage(double& v, int& p) {
   const double ov = __longlong_as_double((long long)dpp_move_u64<CTRL>((unsigned long long)__double_as_longlong(v)));
@@ -177,8 +224,23 @@ template <> struct tl_colvec<16> { typedef double type __attribute__((ext_vector
 // a register column of the panel: RS rows of one lane.  A VECTOR, so that a wavefront-uniform run-time slot becomes relative register addressing
 // (v_movrels) instead of a switch over the slots — whose joins cost ~60 register moves per step.
 template <int RS> using tl_col = typename tl_colvec<RS>::type;
+// entry `ss` (the same in every lane) of a register column: relative register addressing; in the 128-registers-per-lane layout a tree of three
+// selects on the bits of ss instead — a column that is never indexed at run time is eight independent registers to the allocator, not an aligned block
+// of sixteen, and the blocks are what made the pivot-step loop spill.
+template <int RS>
+__device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) {
+  if constexpr (RS == 8 && tl_cfg<RS>::kWavesPerEu == 4) {
+    const bool b0 = ss & 1, b1 = ss & 2, b2 = ss & 4;
+    const double x0 = b0 ? c[1] : c[0], x1 = b0 ? c[3] : c[2], x2 = b0 ? c[5] : c[4], x3 = b0 ? c[7] : c[6];
+    const double y0 = b1 ? x1 : x0, y1 = b1 ? x3 : x2;
+    return b2 ? y1 : y0;
+  } else {
+    return c[ss];
+  }
+}
 
-constexpr int kTlUs = 2048, kTlUsP = 48, kTlUbuf = 16384;  // offsets (doubles) into the dynamic LDS and the pitch of Us (conflict-free operand reads)
+constexpr int kTlUs = 2048, kTlUsP = 48;  // offset (doubles) of Us in the dynamic LDS and its pitch (conflict-free operand reads)
+template <int RS> constexpr int tl_ubuf() { return kTlLC * 64 * RS; }  // offset of Ubuf
 
 #ifdef TL_X_STEPPROF
 __device__ unsigned long long tl_stepprof[8];
@@ -193,7 +255,7 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
                                              int* s_ipiv, int* s_hdr, int* s_flags, int lane) {
   constexpr int P = 64 * RS;
   const int g = cb + k;
-  const int kk = RS == 8 ? k : (k & 15);
+  const int kk = k & (kTlLC - 1);
   double* const lcol = dyn + kk * P + lane;
 #ifdef TL_X_STEPPROF
   const unsigned long long ts0_ = __builtin_readcyclecounter();
@@ -239,7 +301,7 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
     for (int r = 1; r < 4; ++r) { const int oq = __builtin_amdgcn_readlane(q, 16 * r); bq = oq < bq ? oq : bq; }
     ls = __ffsll((long long)__ballot(bp == bq)) - 1;
     ss = __builtin_amdgcn_readlane(bs, ls);
-    piv = tl_readlane_f64(a[JC][ss], ls);
+    piv = tl_readlane_f64(tl_slot<RS>(a[JC], ss), ls);
   }
   const bool zero = piv == 0.0;
   const double inv = zero ? 0.0 : div_refined_rcp(piv);  // a zero pivot eliminates nothing (its column is all zeros)
@@ -249,9 +311,9 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
   const int rstar = ls + 64 * ss;
   const int ps = s_pos[rstar];
   if (lane == 0) {
-    s_hdr[2 * (k & 1)] = ls;
-    s_hdr[2 * (k & 1) + 1] = ss;
-    dyn[kTlUbuf + k * 33 + k] = piv;
+    s_hdr[2 * (k & 3)] = ls;
+    s_hdr[2 * (k & 3) + 1] = ss;
+    dyn[tl_ubuf<RS>() + k * 33 + k] = piv;
     if (zero) s_flags[0] = 1;
     s_pos[rstar] = (short)g;  // the row at the diagonal position trades places with the winner
     if (rg != rstar) { s_pos[rg] = (short)ps; s_rowat[ps] = (short)rg; }
@@ -264,22 +326,24 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
 #endif
 }
 
+// a[J] -= u l (the elimination of one step in one register column)
 template <int RS, int J>
-__device__ __forceinline__ void tl_co_update_col(tl_col<RS> (&a)[4], const double (&l)[RS], const double (&u)[4], double* __restrict__ dyn, int k, int wave, int lane) {
-  if (lane == 0) dyn[kTlUbuf + k * 33 + wave + 8 * J] = u[J];
+__device__ __forceinline__ void tl_co_update_col(tl_col<RS> (&a)[4], const double (&l)[RS], const double (&u)[4]) {
 #pragma unroll
   for (int s = 0; s < RS; ++s) a[J][s] = __builtin_fma(-u[J], l[s], a[J][s]);
 }
-
 // Pivot step k = 8 JO + wo of the sub-panel at column cb, behind the barrier that published it (JO static: register column of its owner): every
-// wavefront eliminates in its columns behind k.  The wavefront that owns column k + 1 updates that column first and runs the search of step k + 1
-// before it touches its other columns (pipe == true), so the next step's exchange is ready when the others arrive at the barrier.
+// wavefront eliminates in its columns behind k.  The chain that bounds the panel is barrier -> multipliers -> column k + 1 -> search of step k + 1 ->
+// publish -> barrier, so the wavefront that owns column k + 1 (pipe == true) does exactly that and PUTS OFF the elimination of step k in its other
+// columns: it makes up for it behind the next barrier, before step k + 1's (the same multiply-adds in the same order, so every entry sees the
+// operations it would see without the delay).  What it needs then is still there: the multipliers in Lbuf (a column is reused 16 steps later),
+// {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's entries in its own registers (a finished row never changes).
 template <int RS, int JO>
 __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], unsigned& done, int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
                                            int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
   constexpr int P = 64 * RS;
   const int k = 8 * JO + wo;
-  const int kk = RS == 8 ? k : (k & 15);
+  const int kk = k & (kTlLC - 1);
   const double* const lcol = dyn + kk * P + lane;
 #ifdef TL_X_STEPPROF
   unsigned long long t0_ = __builtin_readcyclecounter();
@@ -287,39 +351,55 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], unsigned& done, i
 #else
 #define TL_T(ix)
 #endif
-  const int ls = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 1)]), ss = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 1) + 1]);
+  const int ls = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 3)]), ss = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 3) + 1]);
   double l[RS];
 #pragma unroll
   for (int s = 0; s < RS; ++s) l[s] = lcol[64 * s];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   TL_T(0)
-  // the pivot row's entries in this wavefront's columns, out of its own registers (relative register addressing by the uniform slot); the row is finished
+  // this wavefront owned step k and ran its search at once (see above): step k - 1 is still to be eliminated in its columns behind k
+  if constexpr (JO < 3) {
+    if (wave == wo && kk != 0) {
+      const int k1 = k - 1;
+      const int ls1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3)]), ss1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3) + 1]);
+      const double* const l1col = dyn + (k1 & (kTlLC - 1)) * P + lane;
+      double l1[RS], u1[4];
+#pragma unroll
+      for (int s = 0; s < RS; ++s) l1[s] = l1col[64 * s];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u1[j] = j > JO ? tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1) : 0.0;
+      if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l1, u1);
+      if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l1, u1);
+      if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l1, u1);
+    }
+  }
+  // the pivot row's entries in this wavefront's columns, out of its own registers; the row is finished
   double u[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) u[j] = tl_readlane_f64(a[j][ss], ls);
+  for (int j = 0; j < 4; ++j) u[j] = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
+  if (lane == 0) {  // U11: the entries behind the diagonal
+    if (wave > wo) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
+#pragma unroll
+    for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * j] = u[j];
+  }
   done |= lane == ls ? 1u << ss : 0u;
   TL_T(1)
   const bool next_owner = pipe && wave == ((wo + 1) & 7) && k + 1 < ws;
   if (next_owner) {
     if (wo == 7) {  // wavefront 0, its next register column
       if constexpr (JO < 3) {
-        tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
+        tl_co_update_col<RS, JO + 1>(a, l, u);
         tl_co_search<RS, JO + 1>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
-        if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
-        if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
       }
     } else {
-      tl_co_update_col<RS, JO>(a, l, u, dyn, k, wave, lane);
+      tl_co_update_col<RS, JO>(a, l, u);
       tl_co_search<RS, JO>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
-      if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
-      if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
-      if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
     }
   } else {
-    if (wave > wo) tl_co_update_col<RS, JO>(a, l, u, dyn, k, wave, lane);
-    if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u, dyn, k, wave, lane);
-    if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u, dyn, k, wave, lane);
-    if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u, dyn, k, wave, lane);
+    if (wave > wo) tl_co_update_col<RS, JO>(a, l, u);
+    if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u);
+    if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u);
+    if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u);
   }
   TL_T(2)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: never wait for global stores here
@@ -342,7 +422,7 @@ __device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, in
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int k = k0 + c + e;
-          v[e] = k < kr ? dyn[(RS == 8 ? k : (k & 15)) * P + row] : dyn[kTlUbuf + (kr < 32 ? kr : 0) * 33 + k];
+          v[e] = k < kr ? dyn[(k & (kTlLC - 1)) * P + row] : dyn[tl_ubuf<RS>() + (kr < 32 ? kr : 0) * 33 + k];
         }
         dst[c >> 1] = v;
       }
@@ -352,8 +432,19 @@ __device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, in
 
 // The panel of 64 columns at jb (two sub-panels).  Not inlined: its registers are allocated apart from the rest of the kernel.
 template <int RS>
-__device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, int n, int jb, double* dyn, short* s_pos, short* s_rowat, int* s_prow, int* s_ipiv,
-                                      int* s_hdr, int* s_flags, const unsigned short* s_rowlist, int m_in, unsigned long long* phase_clocks) {
+__device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_, int n_, int jb_, double* dyn_, short* s_pos_, short* s_rowat_, int* s_prow_, int* s_ipiv_,
+                                      int* s_hdr_, int* s_flags_, const unsigned short* s_rowlist_, int m_in_, unsigned long long* phase_clocks_) {
+  double* const W_generic = tl_uni(W_generic_);
+  const int ldw = tl_uni(ldw_), n = tl_uni(n_), jb = tl_uni(jb_), m_in = tl_uni(m_in_);
+  double* const dyn = tl_uni(dyn_);
+  short* const s_pos = tl_uni(s_pos_);
+  short* const s_rowat = tl_uni(s_rowat_);
+  int* const s_prow = tl_uni(s_prow_);
+  int* const s_ipiv = tl_uni(s_ipiv_);
+  int* const s_hdr = tl_uni(s_hdr_);
+  int* const s_flags = tl_uni(s_flags_);
+  const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
+  unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
   auto mark = [&](int phase) {
@@ -361,8 +452,8 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, i
   };
   constexpr int R = RS / 8;        // rows per thread in the staging layout (thread t: rows t, t + 512)
   constexpr int P = 64 * RS;       // rows of a column in LDS
-  constexpr int NH = RS / 8;       // the 32 columns pass through LDS in NH halves of 32 / NH
-  constexpr int HC = kTlSW / NH;
+  constexpr int NH = kTlSW / kTlLC;  // the 32 columns pass through LDS in NH = 2 halves of 16
+  constexpr int HC = kTlLC;
   tl_gdouble* const W = (tl_gdouble*)W_generic;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* const Us = dyn + kTlUs;  // [32][kTlUsP]: dead before the stage writes T over it
@@ -483,10 +574,10 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, i
 #define TL_STEPS(JO)                                                                                                                        \
   _Pragma("nounroll") for (int wo = 0; wo < 8; ++wo) {                                                                                      \
     if (8 * JO + wo >= ws) break;                                                                                                           \
-    const bool pipe = !(RS == 16 && JO == 1 && wo == 7); /* the next column of Lbuf is free only behind the flush */                        \
+    const bool pipe = !(JO == 1 && wo == 7); /* the next column of Lbuf is free only behind the flush */                                    \
     tl_co_step<RS, JO>(a, done, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                        \
   }                                                                                                                                         \
-  if (RS == 16 && JO == 1 && ws > 16) {                                                                                                     \
+  if (JO == 1 && ws > 16) {                                                                                                                 \
     __syncthreads();                                                                                                                        \
     tl_flush<RS>(W, ldw, n, cb, 0, 16, dyn, s_pos, tid);                                                                                    \
     __syncthreads();                                                                                                                        \
@@ -501,144 +592,162 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic, int ldw, i
 #undef TL_STEPS
     __syncthreads();
     mark(6);
-    if (RS == 8 || ws <= 16) tl_flush<RS>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
+    if (ws <= 16) tl_flush<RS>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
     else tl_flush<RS>(W, ldw, n, cb, 16, ((ws + 1) & ~1) - 16, dyn, s_pos, tid);
     __syncthreads();
     mark(7);
   }
 }
 
-// Everything behind a finished 64-column panel: U12 and the update of the active rows, a chunk of <= 208 trailing columns at a time.  A function of its own
-// (not inlined) so that its registers — the L21 operand of four row tiles stays in them across the chunks — are allocated apart from the panel's.
-__device__ __noinline__ void tl_trailing(double* __restrict__ W_generic, double* __restrict__ F_generic, double* dyn, const int* s_prow, const unsigned short* s_rowlist,
-                                         unsigned long long* phase_clocks, int n, int ldw, int jb, int nct, int m2) {
+// Everything behind a finished 64-column panel: U12 and the update of the active rows, a chunk of <= kCH trailing columns at a time.  A function of its own
+// (not inlined) so that its registers — the L21 operand of kRT row tiles stays in them across the chunks — are allocated apart from the panel's.
+template <int RS>
+__device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double* __restrict__ F_generic_, double* dyn_, const int* s_prow_, const unsigned short* s_rowlist_,
+                                         unsigned long long* phase_clocks_, int n_, int ldw_, int jb_, int nct_, int m2_) {
+  using C = tl_cfg<RS>;
+  double* const W_generic = tl_uni(W_generic_);
+  double* const F_generic = tl_uni(F_generic_);
+  double* const dyn = tl_uni(dyn_);
+  const int* const s_prow = tl_uni(s_prow_);
+  const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
+  unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
+  const int n = tl_uni(n_), ldw = tl_uni(ldw_), jb = tl_uni(jb_), nct = tl_uni(nct_), m2 = tl_uni(m2_);
+  constexpr int LDP = C::kLDP, CH = C::kCH, RTM = C::kRT;
+  constexpr bool PF = C::kWavesPerEu <= 2;
   tl_gdouble* const W = (tl_gdouble*)W_generic;
   tl_gdouble* const F = (tl_gdouble*)F_generic;
   double* const u12s = dyn;
-  const double* const l11 = dyn + 64 * kTlLDP;
-  const double* const invd = l11 + 64 * kTlL11P;
+  const double* const l11 = dyn + 64 * LDP;        // rows 16..63, columns 0..47 of L11, pitch kTlL11P
+  const double* const invd = l11 + 48 * kTlL11P;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-    const int q = lane >> 4, j = lane & 15;
-    // decomposition of the update: groups of RTw row tiles; with fewer groups than wavefronts the column tiles are split as well
-    const int nrt = (m2 + 15) / 16;
-    const int rtw = (nrt + kTlWaves - 1) / kTlWaves < 4 ? (nrt + kTlWaves - 1) / kTlWaves : 4;
-    const int groups = (nrt + rtw - 1) / rtw;
-    const int csplit = groups >= kTlWaves ? 1 : kTlWaves / groups;
-    const bool fixed_group = groups <= kTlWaves;
-    double aneg[4][16];
-    unsigned roffb[4][4];
-    unsigned valid = 0;
-    int loaded_group = -1;
-    for (int c_lo = jb + kTlPW; c_lo < nct; c_lo += kTlCH) {
-      const int cw = (nct - c_lo) < kTlCH ? (nct - c_lo) : kTlCH;
-      const int ntc = cw / 16;
-      // ---- U12 of the chunk: blocked substitution on the matrix cores, one column tile per wavefront at a time
-      {
-        // the A operands (inverses of the diagonal blocks, negated blocks below them) come from LDS as they are needed: holding all 40 of them next
-        // to the L21 operand of the update, which stays in registers across the chunks, does not fit in 256 registers
-        const double* const dinv_l = invd + j * 17 + q;            // block b, k-block kb: + b * 272 + 4 kb
-        const double* const l11_l = l11 + j * kTlL11P + q;         // block (rb, cbk), k-block kb: + 16 rb * pitch + 16 cbk + 4 kb
-        for (int tc = wave; tc < ntc; tc += kTlWaves) {
-          const int c0 = c_lo + 16 * tc;
-          tl_d4 B[4], X[4];
+  const int q = lane >> 4, j = lane & 15;
+  // decomposition of the update: groups of rtw row tiles; with fewer groups than wavefronts the column tiles are split as well
+  const int nrt = (m2 + 15) / 16;
+  const int rtw = (nrt + kTlWaves - 1) / kTlWaves < RTM ? (nrt + kTlWaves - 1) / kTlWaves : RTM;
+  const int groups = (nrt + rtw - 1) / rtw;
+  const int csplit = groups >= kTlWaves ? 1 : kTlWaves / groups;
+  const bool fixed_group = groups <= kTlWaves;
+  double aneg[RTM][16];
+  unsigned roffb[RTM][4];
+  unsigned valid = 0;
+  int loaded_group = -1;
+  for (int c_lo = jb + kTlPW; c_lo < nct; c_lo += CH) {
+    const int cw = (nct - c_lo) < CH ? (nct - c_lo) : CH;
+    const int ntc = cw / 16;
+    // ---- U12 of the chunk: blocked substitution on the matrix cores, one column tile per wavefront at a time
+    {
+      // the A operands (inverses of the diagonal blocks, negated blocks below them) come from LDS as they are needed: holding all 40 of them next
+      // to the L21 operand of the update, which stays in registers across the chunks, does not fit in the registers
+      const double* const dinv_l = invd + j * 17 + q;            // block b, k-block kb: + b * 272 + 4 kb
+      const double* const l11_l = l11 + j * kTlL11P + q;         // block (rb, cbk), rb >= 1, k-block kb: + 16 (rb - 1) * pitch + 16 cbk + 4 kb
+      for (int tc = wave; tc < ntc; tc += kTlWaves) {
+        const int c0 = c_lo + 16 * tc;
+        tl_d4 B[4], X[4];
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)(s_prow[16 * rb + 4 * r + q] * ldw) + c0 + j];
+          for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)(s_prow[16 * rb + 4 * r + q] * ldw) + c0 + j];
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb) {
+        for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-            for (int cbk = 0; cbk < rb; ++cbk) {
-              double lo[4];
+          for (int cbk = 0; cbk < rb; ++cbk) {
+            double lo[4];
 #pragma unroll
-              for (int kb = 0; kb < 4; ++kb) lo[kb] = -l11_l[16 * rb * kTlL11P + 16 * cbk + 4 * kb];
+            for (int kb = 0; kb < 4; ++kb) lo[kb] = -l11_l[16 * (rb - 1) * kTlL11P + 16 * cbk + 4 * kb];
 #pragma unroll
-              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[kb], X[cbk][kb], B[rb], 0, 0, 0);
-            }
-            double di[4];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) di[kb] = dinv_l[rb * 272 + 4 * kb];
-            tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(di[kb], B[rb][kb], acc, 0, 0, 0);
-            X[rb] = acc;
+            for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[kb], X[cbk][kb], B[rb], 0, 0, 0);
           }
-          const bool incol = c0 + j < n;
+          double di[4];
 #pragma unroll
-          for (int rb = 0; rb < 4; ++rb)
+          for (int kb = 0; kb < 4; ++kb) di[kb] = dinv_l[rb * 272 + 4 * kb];
+          tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              u12s[(16 * rb + 4 * r + q) * kTlLDP + 16 * tc + j] = X[rb][r];
-              if (incol) F[(size_t)(c0 + j) * n + jb + 16 * rb + 4 * r + q] = X[rb][r];
-            }
+          for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(di[kb], B[rb][kb], acc, 0, 0, 0);
+          X[rb] = acc;
         }
-      }
-      __syncthreads();
-      mark(2);
-      // ---- A22 -= L21 U12 for the chunk's columns
-      for (int grp = fixed_group ? wave % groups : wave; grp < groups; grp += kTlWaves) {
-        const int csub = fixed_group ? wave / groups : 0;
-        if (csub >= csplit) break;
-        if (grp != loaded_group) {
-          loaded_group = grp;
-          valid = 0;
+        const bool incol = c0 + j < n;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int tile = grp * rtw + t;
-            const bool tv = t < rtw && tile < nrt;
-            const int arow = tv ? (int)s_rowlist[16 * tile + j] * ldw : 0;
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int kb = 0; kb < 16; ++kb) aneg[t][kb] = tv ? -W[(size_t)arow + jb + 4 * kb + q] : 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              roffb[t][r] = tv ? (unsigned)s_rowlist[16 * tile + 4 * r + q] * (unsigned)ldw * 8u : 0u;
-              if (tv && 16 * tile + 4 * r + q < m2) valid |= 1u << (4 * t + r);
-            }
+          for (int r = 0; r < 4; ++r) {
+            u12s[(16 * rb + 4 * r + q) * LDP + 16 * tc + j] = X[rb][r];
+            if (incol) F[(size_t)(c0 + j) * n + jb + 16 * rb + 4 * r + q] = X[rb][r];
           }
-        }
-        const int ngt = (nrt - grp * rtw) < rtw ? (nrt - grp * rtw) : rtw;  // row tiles of this group
-        switch (ngt) {
-          case 1: tl_update_tiles<1>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          case 2: tl_update_tiles<2>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          case 3: tl_update_tiles<3>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          default: tl_update_tiles<4>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-        }
-        if (fixed_group) break;
       }
-      __syncthreads();
-      mark(3);
     }
+    __syncthreads();
+    mark(2);
+    // ---- A22 -= L21 U12 for the chunk's columns
+    for (int grp = fixed_group ? wave % groups : wave; grp < groups; grp += kTlWaves) {
+      const int csub = fixed_group ? wave / groups : 0;
+      if (csub >= csplit) break;
+      if (grp != loaded_group) {
+        loaded_group = grp;
+        valid = 0;
+#pragma unroll
+        for (int t = 0; t < RTM; ++t) {
+          const int tile = grp * rtw + t;
+          const bool tv = t < rtw && tile < nrt;
+          const int arow = tv ? (int)s_rowlist[16 * tile + j] * ldw : 0;
+#pragma unroll
+          for (int kb = 0; kb < 16; ++kb) aneg[t][kb] = tv ? -W[(size_t)arow + jb + 4 * kb + q] : 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            roffb[t][r] = tv ? (unsigned)s_rowlist[16 * tile + 4 * r + q] * (unsigned)ldw * 8u : 0u;
+            if (tv && 16 * tile + 4 * r + q < m2) valid |= 1u << (4 * t + r);
+          }
+        }
+      }
+      const int ngt = (nrt - grp * rtw) < rtw ? (nrt - grp * rtw) : rtw;  // row tiles of this group
+      if constexpr (RTM == 4) {
+        switch (ngt) {
+          case 1: tl_update_tiles<1, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
+          case 2: tl_update_tiles<2, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
+          case 3: tl_update_tiles<3, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
+          default: tl_update_tiles<4, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
+        }
+      } else {
+        if (ngt == 1) tl_update_tiles<1, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane);
+        else tl_update_tiles<2, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane);
+      }
+      if (fixed_group) break;
+    }
+    __syncthreads();
+    mark(3);
   }
+}
 
-// RS = rows per lane of the panel's register layout: 8 for n <= 512, 16 for n <= 1024
+// RS = rows per lane of the panel's register layout: 8 for n <= 512 (two workgroups per CU), 16 for n <= 1024
 template <int RS>
-__global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
+__global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
                                                                  unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
+  using C = tl_cfg<RS>;
   constexpr int R = RS / 8;
+  constexpr int MAXN = C::kMaxN;
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-  extern __shared__ double dyn[];                // trailing phase: u12s [64][LDP], l11 [64][65], invd [4][16][17]; panel: see tl_panel
-  double* const l11 = dyn + 64 * kTlLDP;
-  double* const invd = l11 + 64 * kTlL11P;
-  __shared__ short s_pos[kTlMaxN], s_rowat[kTlMaxN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
+  extern __shared__ double dyn[];                // trailing phase: u12s [64][LDP], l11 [48][49], invd [4][16][17]; panel: see tl_panel
+  double* const l11 = dyn + 64 * C::kLDP;
+  double* const invd = l11 + 48 * kTlL11P;
+  __shared__ short s_pos[MAXN], s_rowat[MAXN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
   __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];        // the panel's pivot rows (row indices) and recorded pivots (positions)
-  __shared__ unsigned short s_rowlist[kTlMaxN + 16];
+  __shared__ unsigned short s_rowlist[MAXN + 16];
   __shared__ int s_wcnt[R][kTlWaves];
-  __shared__ int s_hdr[4], s_flags[1];
+  __shared__ int s_hdr[8], s_flags[1];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* const W = w_all + (size_t)blockIdx.x * n * ldw;
   double* const F = f_all + (size_t)blockIdx.x * n * n;
   int32_t* const PIV = piv_all + (size_t)blockIdx.x * n;
-  for (int r = tid; r < kTlMaxN; r += kTlThreads) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
+  for (int r = tid; r < MAXN; r += kTlThreads) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
   for (int r = tid; r < n + 16; r += kTlThreads) s_rowlist[r] = (unsigned short)(r < n ? r : n - 1);  // rows entering the first panel (padded: whole tiles)
   int m_act = n;
   if (tid == 0) s_flags[0] = 0;
@@ -678,9 +787,14 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
     const int mc = nct - jb - kTlPW;  // trailing columns (exist only behind a full panel)
     const bool trailing = pw == kTlPW && mc > 0 && m2 > 0;
     if (trailing) {
-      for (int idx = tid; idx < 64 * 64; idx += kTlThreads) {
-        const int k = idx >> 6, i = idx & 63;
-        l11[k * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
+      // the blocks of L11 below its diagonal blocks (rows 16..63, columns 0..47) and, where their inverses will be, the four diagonal blocks themselves
+      for (int idx = tid; idx < 48 * 48; idx += kTlThreads) {
+        const int k = 16 + idx / 48, i = idx % 48;
+        l11[(k - 16) * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
+      }
+      for (int idx = tid; idx < 4 * 256; idx += kTlThreads) {
+        const int blk = idx >> 8, r = (idx >> 4) & 15, i = idx & 15;
+        invd[(blk * 16 + r) * 17 + i] = i < r ? W[(size_t)s_prow[16 * blk + r] * ldw + jb + 16 * blk + i] : (i == r ? 1.0 : 0.0);
       }
     }
     for (int c = tid; c < jb + pw; c += kTlThreads) {
@@ -697,7 +811,7 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
     __syncthreads();
     if (m2 > 0 && tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
     if (!trailing) { mark(1); continue; }
-    if (wave == 1) {  // inverse of the four 16 x 16 unit lower triangular diagonal blocks: lane = (block, column)
+    if (wave == 1) {  // inverse of the four 16 x 16 unit lower triangular diagonal blocks, in place: lane = (block, column); the 16 lanes of a block are in step
       const int blk = lane >> 4, jc = lane & 15;
       double x[16];
 #pragma unroll
@@ -705,13 +819,14 @@ __global__ __launch_bounds__(kTlThreads) void k_lu_factor_tiled(int n, int ldw, 
 #pragma unroll
       for (int i = 0; i < 15; ++i)
 #pragma unroll
-        for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-l11[(16 * blk + r) * kTlL11P + 16 * blk + i], x[i], x[r]);
+        for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-invd[(16 * blk + r) * 17 + i], x[i], x[r]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read the block before any lane overwrites it
 #pragma unroll
       for (int r = 0; r < 16; ++r) invd[(blk * 16 + r) * 17 + jc] = x[r];
     }
     __syncthreads();
     mark(1);
-    tl_trailing(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
+    tl_trailing<RS>(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
     if (prof) tprev = wall_clock64();
   }
   if (tid == 0 && s_flags[0] != 0) publish_singular(singular_word, 1ull, epoch);

@@ -63,9 +63,13 @@ int main(int argc, char** argv) {
   CK(hipMemset(d_sing, 0, 8)); CK(hipMemset(d_clk, 0, 128));
   CK(hipMemset(d_f, 0xff, sizeof(double) * (size_t)n * n * nb));
   CK(hipMemcpy(d_a, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice));
-  const size_t lds = dsh::tiled_lds_bytes();
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = dsh::tiled_lds_bytes(n);
+  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(512)));
+  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(1024)));
+  { int occ8 = 0, occ16 = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, (const void*)dsh::k_lu_factor_tiled<8>, 512, dsh::tiled_lds_bytes(512)));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, (const void*)dsh::k_lu_factor_tiled<16>, 512, dsh::tiled_lds_bytes(1024)));
+    printf("workgroups per CU: %d (n <= 512, %zu B of dynamic LDS), %d (n <= 1024, %zu B)\n", occ8, dsh::tiled_lds_bytes(512), occ16, dsh::tiled_lds_bytes(1024)); }
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   float best_stage = 1e30f, best_factor = 1e30f;

@@ -65,11 +65,13 @@ def test_pack_and_unpack_reassemble_uneven_shards_for_worlds_the_box_does_not_ha
     for r in range(world):  # what ncclAllGather delivers: every rank's padded shard, rank-major
         lo, hi = shard_bounds(n_total, r, world)
         local = torch.from_numpy(np.ascontiguousarray(full[:, lo:hi])).cuda()
+        torch.cuda.synchronize()
         _ffi.check(L.dsh_dist_pack_shard(ctx._h, None, _ffi.vp(local.data_ptr()), lead, hi - lo, m, _ffi.vp(recv[r].data_ptr())))
         ctx.sync()
         packed = recv[r].cpu().numpy()
         assert np.array_equal(packed[:, : hi - lo], full[:, lo:hi]) and not packed[:, hi - lo:].any()
     out = torch.full((lead, n_total), np.nan, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()  # torch fills on ITS stream; the library's stream does not wait for it
     _ffi.check(L.dsh_dist_unpack_gathered(ctx._h, None, _ffi.vp(recv.data_ptr()), lead, n_total, world, _ffi.vp(out.data_ptr())))
     ctx.sync()
     assert np.array_equal(out.cpu().numpy(), full)
