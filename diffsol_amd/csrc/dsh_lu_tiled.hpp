@@ -246,12 +246,13 @@ template <int RS> constexpr int tl_ubuf() { return kTlLC * 64 * RS; }  // offset
 __device__ unsigned long long tl_stepprof[8];
 #endif
 // Pivot search of step k by the wavefront that owns its column (register column JC), and everything that has to be published for it: the multipliers
-// (column kk of Lbuf), {lane, slot} of the pivot row, the interchange bookkeeping.  `done`: bit s set = row slot s of this lane is finished (every
-// wavefront keeps these bits from the published {lane, slot} pairs); finished rows are no candidates and get zero multipliers, so nothing ever
-// changes them again.  The search is a maximum of magnitudes — v_max ignores NaNs, as the sequential scan does.
+// (column kk of Lbuf), {lane, slot} of the pivot row, the interchange bookkeeping.  Finished rows need no mask: the pivot row's own "multiplier" is
+// published as 1, so the elimination of its step leaves an exact 0 (u - u * 1) in every column behind it, rows finished in earlier sub-panels and rows
+// beyond n enter the stage as zeros, and a zero is no candidate unless the whole column is zero (the position scan below).
+// Their multipliers in later steps are 0 * (1 / pivot) = 0, so nothing ever changes them again.  The search is a maximum of magnitudes — v_max ignores NaNs, as the sequential scan does.
 // Positions (LDS) are looked at only when they decide: several rows of the largest magnitude, or a column without a positive entry.
 template <int RS, int JC>
-__device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned done, int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
+__device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
                                              int* s_ipiv, int* s_hdr, int* s_flags, int lane) {
   constexpr int P = 64 * RS;
   const int g = cb + k;
@@ -261,9 +262,14 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
   const unsigned long long ts0_ = __builtin_readcyclecounter();
 #endif
   const int rg = s_rowat[g];  // the row at the diagonal position (used at the end: its latency hides behind the search)
-  double m = -1.0;
+  double mt[RS];
 #pragma unroll
-  for (int s = 0; s < RS; ++s) m = __builtin_fmax(m, (done >> s) & 1u ? -1.0 : __builtin_fabs(a[JC][s]));
+  for (int s = 0; s < RS; ++s) mt[s] = __builtin_fabs(a[JC][s]);
+#pragma unroll
+  for (int w = RS / 2; w >= 1; w >>= 1)
+#pragma unroll
+    for (int s = 0; s < w; ++s) mt[s] = __builtin_fmax(mt[s], mt[s + w]);
+  double m = __builtin_fmax(mt[0], -1.0);  // -1: no number in the column
   m = tl_dpp_max<kDppQuadXor1>(m);
   m = tl_dpp_max<kDppQuadXor2>(m);
   m = tl_dpp_max<kDppRowHalfMirror>(m);
@@ -272,7 +278,7 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
   unsigned long long M[RS];
   int cnt = 0;
 #pragma unroll
-  for (int s = 0; s < RS; ++s) { M[s] = __ballot(!((done >> s) & 1u) & (__builtin_fabs(a[JC][s]) == wm)); cnt += __popcll(M[s]); }
+  for (int s = 0; s < RS; ++s) { M[s] = __builtin_amdgcn_ballot_w64(__builtin_fabs(a[JC][s]) == wm); cnt += __popcll(M[s]); }
   int ls = 0, ss = 0;
   double piv = 0.0;
   if (cnt == 1 && wm > 0.0) {  // the common case: one row holds the largest magnitude
@@ -306,8 +312,8 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], unsigned 
   const bool zero = piv == 0.0;
   const double inv = zero ? 0.0 : div_refined_rcp(piv);  // a zero pivot eliminates nothing (its column is all zeros)
 #pragma unroll
-  for (int s = 0; s < RS; ++s) lcol[64 * s] = (done >> s) & 1u ? 0.0 : a[JC][s] * inv;
-  if (lane == ls) lcol[64 * ss] = 0.0;  // the pivot row itself
+  for (int s = 0; s < RS; ++s) lcol[64 * s] = a[JC][s] * inv;
+  if (lane == ls) lcol[64 * ss] = 1.0;  // the pivot row itself: its entries behind this column become exact zeros
   const int rstar = ls + 64 * ss;
   const int ps = s_pos[rstar];
   if (lane == 0) {
@@ -339,7 +345,7 @@ __device__ __forceinline__ void tl_co_update_col(tl_col<RS> (&a)[4], const doubl
 // operations it would see without the delay).  What it needs then is still there: the multipliers in Lbuf (a column is reused 16 steps later),
 // {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's entries in its own registers (a finished row never changes).
 template <int RS, int JO>
-__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], unsigned& done, int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
+__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
                                            int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
   constexpr int P = 64 * RS;
   const int k = 8 * JO + wo;
@@ -368,34 +374,41 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], unsigned& done, i
       for (int s = 0; s < RS; ++s) l1[s] = l1col[64 * s];
 #pragma unroll
       for (int j = 0; j < 4; ++j) u1[j] = j > JO ? tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1) : 0.0;
+      if (lane == 0) {  // U11 of step k - 1 in these columns
+#pragma unroll
+        for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k1 * 33 + wave + 8 * j] = u1[j];
+      }
       if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l1, u1);
       if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l1, u1);
       if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l1, u1);
     }
   }
-  // the pivot row's entries in this wavefront's columns, out of its own registers; the row is finished
-  double u[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) u[j] = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
-  if (lane == 0) {  // U11: the entries behind the diagonal
-    if (wave > wo) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
-#pragma unroll
-    for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * j] = u[j];
-  }
-  done |= lane == ls ? 1u << ss : 0u;
   TL_T(1)
   const bool next_owner = pipe && wave == ((wo + 1) & 7) && k + 1 < ws;
-  if (next_owner) {
+  double u[4];
+  if (next_owner) {  // the pivot row's entry in column k + 1 only (the row is finished: out of this wavefront's own registers), that column, the search
     if (wo == 7) {  // wavefront 0, its next register column
       if constexpr (JO < 3) {
+        u[JO + 1] = tl_readlane_f64(tl_slot<RS>(a[JO + 1], ss), ls);
+        if (lane == 0) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * (JO + 1)] = u[JO + 1];
         tl_co_update_col<RS, JO + 1>(a, l, u);
-        tl_co_search<RS, JO + 1>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+        tl_co_search<RS, JO + 1>(a, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
       }
     } else {
+      u[JO] = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
+      if (lane == 0) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
       tl_co_update_col<RS, JO>(a, l, u);
-      tl_co_search<RS, JO>(a, done, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+      tl_co_search<RS, JO>(a, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
     }
   } else {
+    // the pivot row's entries in this wavefront's columns behind k
+#pragma unroll
+    for (int j = JO; j < 4; ++j) u[j] = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
+    if (lane == 0) {  // U11
+      if (wave > wo) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
+#pragma unroll
+      for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * j] = u[j];
+    }
     if (wave > wo) tl_co_update_col<RS, JO>(a, l, u);
     if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u);
     if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u);
@@ -541,7 +554,6 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
     mark(4);
     // ---- stage: thread per row in (the second sub-panel's rows take the 32 eliminations of the first on the way: row -= L_row U'), column per wavefront out
     tl_col<RS> a[4];
-    unsigned done = 0u;
     {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -575,18 +587,16 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
   _Pragma("nounroll") for (int wo = 0; wo < 8; ++wo) {                                                                                      \
     if (8 * JO + wo >= ws) break;                                                                                                           \
     const bool pipe = !(JO == 1 && wo == 7); /* the next column of Lbuf is free only behind the flush */                                    \
-    tl_co_step<RS, JO>(a, done, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                        \
+    tl_co_step<RS, JO>(a, wo, ws,       pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                        \
   }                                                                                                                                         \
   if (JO == 1 && ws > 16) {                                                                                                                 \
     __syncthreads();                                                                                                                        \
     tl_flush<RS>(W, ldw, n, cb, 0, 16, dyn, s_pos, tid);                                                                                    \
     __syncthreads();                                                                                                                        \
-    if (wave == 0) tl_co_search<RS, 2>(a, done, 16, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);                        \
+    if (wave == 0) tl_co_search<RS, 2>(a, 16,       cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);                        \
     __syncthreads();                                                                                                                        \
   }
-#pragma unroll
-    for (int s2 = 0; s2 < RS; ++s2) { const int row = lane + 64 * s2; done |= (row < n && s_pos[row] >= cb) ? 0u : 1u << s2; }
-    if (wave == 0) tl_co_search<RS, 0>(a, done, 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+    if (wave == 0) tl_co_search<RS, 0>(a, 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
     __syncthreads();
     TL_STEPS(0) TL_STEPS(1) TL_STEPS(2) TL_STEPS(3)
 #undef TL_STEPS
