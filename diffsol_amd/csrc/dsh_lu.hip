@@ -272,11 +272,11 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
             if (tl_prof) { DSH_HIP_CHECK(hipMalloc(&clk, 8 * sizeof(unsigned long long))); DSH_HIP_CHECK(hipMemset(clk, 0, 8 * sizeof(unsigned long long))); }
             const dim3 sg((unsigned)((nb + 31) / 32), (unsigned)((ldw + 31) / 32), (unsigned)n);
             hipLaunchKernelGGL(k_lu_stage_rowmajor, sg, dim3(256), 0, ctx->stream, (int)n, ldw, nb, a, lu->work);
-            if (n <= kTlThreads)
-              hipLaunchKernelGGL((k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(kTlThreads), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+            if (n <= 512)
+              hipLaunchKernelGGL((k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
                                  lu->pivots, lu->singular, lu->singular_epoch, clk);
             else
-              hipLaunchKernelGGL((k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(kTlThreads), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+              hipLaunchKernelGGL((k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
                                  lu->pivots, lu->singular, lu->singular_epoch, clk);
             if (tl_prof) {
               unsigned long long h[8];

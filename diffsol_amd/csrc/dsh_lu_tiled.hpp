@@ -27,35 +27,37 @@
 
 namespace dsh {
 
-constexpr int kTlThreads = 512;
-constexpr int kTlWaves = kTlThreads / 64;
+constexpr int kTlMaxThreads = 512;
 constexpr int kTlPW = 64;     // panel width
 constexpr int kTlSW = 32;     // sub-panel width (columns of a row held in registers)
 constexpr int kTlLC = 16;     // columns of multipliers kept in LDS at a time (a sub-panel is flushed to W in two halves)
 constexpr int kTlL11P = 49;   // pitch of the staged L11 (rows 16..63, columns 0..47: the blocks below the diagonal blocks)
 constexpr int kTlMaxN = 1024;
-// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024).  kWavesPerEu = 4 lays a configuration out for TWO workgroups per CU
-// (at most 80 KB of LDS and 128 registers per lane: kLDP = kCH = 80, kRT = 2) so that one system's pivot-step chain runs under another system's trailing
-// update.  Measured for n = 512 x 4096 (profiles/r04_lu_bench.md): 40.4 ms against 33.6 ms with one workgroup per CU — under 128 registers the pivot-step
-// loop spills and the update keeps only two row tiles per wavefront — so both sizes run one workgroup per CU.
-#ifndef DSH_TL_TWO_PER_CU
-#define DSH_TL_TWO_PER_CU 0
+// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024); kWaves = wavefronts per workgroup (a workgroup per system; wavefront w
+// holds the columns w, w + kWaves, ... of a 32-column sub-panel in registers).  One workgroup of eight wavefronts per CU for both sizes.
+// TWO workgroups per CU — one system's pivot steps, a latency chain of ~1 us per step with the matrix cores idle, under the other system's trailing
+// update — were built in both possible shapes for n <= 512 and measured at 512 x 4096 (profiles/r04_lu_bench.md): eight wavefronts of 128 registers
+// (40.4 ms) and four wavefronts of 256 registers holding eight columns each (-DDSH_TL_WAVES8=4: 51.0 ms) against 27.4 ms with one workgroup: in both
+// the register columns of a sub-panel leave the pivot-step loop no room and it spills; it would take 16-column sub-panels to make the second fit.
+#ifndef DSH_TL_WAVES8
+#define DSH_TL_WAVES8 8
 #endif
 template <int RS> struct tl_cfg;
 template <> struct tl_cfg<8> {
-  static constexpr int kMaxN = 512;                            // rows
-  static constexpr int kLDP = DSH_TL_TWO_PER_CU ? 80 : 208;    // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
-  static constexpr int kCH = DSH_TL_TWO_PER_CU ? 80 : 208;     // columns per chunk (tiles of 16)
-  static constexpr int kRT = DSH_TL_TWO_PER_CU ? 2 : 4;        // row tiles per wavefront whose L21 operand stays in registers
-  static constexpr int kWavesPerEu = DSH_TL_TWO_PER_CU ? 4 : 2;
+  static constexpr int kWaves = DSH_TL_WAVES8;
+  static constexpr int kMaxN = 512;                               // rows
+  static constexpr int kLDP = DSH_TL_WAVES8 == 4 ? 80 : 208;      // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
+  static constexpr int kCH = DSH_TL_WAVES8 == 4 ? 64 : 208;       // columns per chunk (tiles of 16; a multiple of the wavefronts: U12 is one tile per wavefront at a time)
+  static constexpr int kRT = 4;                                   // row tiles per wavefront whose L21 operand stays in registers
 };
 template <> struct tl_cfg<16> {
+  static constexpr int kWaves = 8;
   static constexpr int kMaxN = 1024;
   static constexpr int kLDP = 208;
   static constexpr int kCH = 208;      // 13 tiles of 16
   static constexpr int kRT = 4;
-  static constexpr int kWavesPerEu = 2;
 };
+inline int tiled_threads(int64_t n) { return 64 * (n <= 512 ? tl_cfg<8>::kWaves : tl_cfg<16>::kWaves); }
 inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }
 // dynamic LDS (doubles): the panel needs kTlLC columns of 64 RS rows + Ubuf [32][33]; the trailing phase u12s [64][LDP] + l11 [48][49] + invd [4][16][17]
 template <int RS> constexpr size_t tiled_lds_doubles() {
@@ -229,7 +231,7 @@ template <int RS> using tl_col = typename tl_colvec<RS>::type;
 // of sixteen, and the blocks are what made the pivot-step loop spill.
 template <int RS>
 __device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) {
-  if constexpr (RS == 8 && tl_cfg<RS>::kWavesPerEu == 4) {
+  if constexpr (RS == 8 && tl_cfg<RS>::kWaves == 4) {
     const bool b0 = ss & 1, b1 = ss & 2, b2 = ss & 4;
     const double x0 = b0 ? c[1] : c[0], x1 = b0 ? c[3] : c[2], x2 = b0 ? c[5] : c[4], x3 = b0 ? c[7] : c[6];
     const double y0 = b1 ? x1 : x0, y1 = b1 ? x3 : x2;
@@ -251,8 +253,8 @@ __device__ unsigned long long tl_stepprof[8];
 // beyond n enter the stage as zeros, and a zero is no candidate unless the whole column is zero (the position scan below).
 // Their multipliers in later steps are 0 * (1 / pivot) = 0, so nothing ever changes them again.  The search is a maximum of magnitudes — v_max ignores NaNs, as the sequential scan does.
 // Positions (LDS) are looked at only when they decide: several rows of the largest magnitude, or a column without a positive entry.
-template <int RS, int JC>
-__device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
+template <int RS>
+__device__ __forceinline__ void tl_co_search(const tl_col<RS>& col, int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
                                              int* s_ipiv, int* s_hdr, int* s_flags, int lane) {
   constexpr int P = 64 * RS;
   const int g = cb + k;
@@ -264,7 +266,7 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, in
   const int rg = s_rowat[g];  // the row at the diagonal position (used at the end: its latency hides behind the search)
   double mt[RS];
 #pragma unroll
-  for (int s = 0; s < RS; ++s) mt[s] = __builtin_fabs(a[JC][s]);
+  for (int s = 0; s < RS; ++s) mt[s] = __builtin_fabs(col[s]);
 #pragma unroll
   for (int w = RS / 2; w >= 1; w >>= 1)
 #pragma unroll
@@ -278,20 +280,20 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, in
   unsigned long long M[RS];
   int cnt = 0;
 #pragma unroll
-  for (int s = 0; s < RS; ++s) { M[s] = __builtin_amdgcn_ballot_w64(__builtin_fabs(a[JC][s]) == wm); cnt += __popcll(M[s]); }
+  for (int s = 0; s < RS; ++s) { M[s] = __builtin_amdgcn_ballot_w64(__builtin_fabs(col[s]) == wm); cnt += __popcll(M[s]); }
   int ls = 0, ss = 0;
   double piv = 0.0;
   if (cnt == 1 && wm > 0.0) {  // the common case: one row holds the largest magnitude
 #pragma unroll
     for (int s = 0; s < RS; ++s)
-      if (M[s] != 0ull) { ss = s; ls = __ffsll((long long)M[s]) - 1; piv = tl_readlane_f64(a[JC][s], ls); }
+      if (M[s] != 0ull) { ss = s; ls = __ffsll((long long)M[s]) - 1; piv = tl_readlane_f64(col[s], ls); }
   } else {
     // the smallest position among the candidates: the rows of the largest magnitude, or — no number in the column (all NaN) — every row not finished
     int bp = 0x7fffffff, bs = 0;
 #pragma unroll
     for (int s = 0; s < RS; ++s) {
       const int ps = s_pos[lane + 64 * s];
-      const bool c = (ps >= g) & (wm >= 0.0 ? __builtin_fabs(a[JC][s]) == wm : true);
+      const bool c = (ps >= g) & (wm >= 0.0 ? __builtin_fabs(col[s]) == wm : true);
       const bool take = c & (ps < bp);
       bp = take ? ps : bp;
       bs = take ? s : bs;
@@ -307,12 +309,12 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, in
     for (int r = 1; r < 4; ++r) { const int oq = __builtin_amdgcn_readlane(q, 16 * r); bq = oq < bq ? oq : bq; }
     ls = __ffsll((long long)__ballot(bp == bq)) - 1;
     ss = __builtin_amdgcn_readlane(bs, ls);
-    piv = tl_readlane_f64(tl_slot<RS>(a[JC], ss), ls);
+    piv = tl_readlane_f64(tl_slot<RS>(col, ss), ls);
   }
   const bool zero = piv == 0.0;
   const double inv = zero ? 0.0 : div_refined_rcp(piv);  // a zero pivot eliminates nothing (its column is all zeros)
 #pragma unroll
-  for (int s = 0; s < RS; ++s) lcol[64 * s] = a[JC][s] * inv;
+  for (int s = 0; s < RS; ++s) lcol[64 * s] = col[s] * inv;
   if (lane == ls) lcol[64 * ss] = 1.0;  // the pivot row itself: its entries behind this column become exact zeros
   const int rstar = ls + 64 * ss;
   const int ps = s_pos[rstar];
@@ -332,25 +334,27 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS> (&a)[4], int k, in
 #endif
 }
 
-// a[J] -= u l (the elimination of one step in one register column)
-template <int RS, int J>
-__device__ __forceinline__ void tl_co_update_col(tl_col<RS> (&a)[4], const double (&l)[RS], const double (&u)[4]) {
+// c -= u l (the elimination of one step in one register column)
+template <int RS>
+__device__ __forceinline__ void tl_co_elim(tl_col<RS>& c, const double (&l)[RS], double u) {
 #pragma unroll
-  for (int s = 0; s < RS; ++s) a[J][s] = __builtin_fma(-u[J], l[s], a[J][s]);
+  for (int s = 0; s < RS; ++s) c[s] = __builtin_fma(-u, l[s], c[s]);
 }
-// Pivot step k = 8 JO + wo of the sub-panel at column cb, behind the barrier that published it (JO static: register column of its owner): every
-// wavefront eliminates in its columns behind k.  The chain that bounds the panel is barrier -> multipliers -> column k + 1 -> search of step k + 1 ->
-// publish -> barrier, so the wavefront that owns column k + 1 (pipe == true) does exactly that and PUTS OFF the elimination of step k in its other
-// columns: it makes up for it behind the next barrier, before step k + 1's (the same multiply-adds in the same order, so every entry sees the
-// operations it would see without the delay).  What it needs then is still there: the multipliers in Lbuf (a column is reused 16 steps later),
-// {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's entries in its own registers (a finished row never changes).
-template <int RS, int JO>
-__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
+// Pivot step k = NW JO + wo of the sub-panel at column cb, behind the barrier that published it (NW wavefronts; JO static: register column of its
+// owner; wavefront w holds the sub-panel's columns w, w + NW, ...): every wavefront eliminates in its columns behind k.  The chain that bounds the panel
+// is barrier -> multipliers -> column k + 1 -> search of step k + 1 -> publish -> barrier, so the wavefront that owns column k + 1 (pipe == true) does
+// exactly that and PUTS OFF the elimination of step k in its other columns: it makes up for it behind the next barrier, before step k + 1's (the same
+// multiply-adds in the same order, so every entry sees the operations it would see without the delay).  What it needs then is still there: the
+// multipliers in Lbuf (a column is reused 16 steps later), {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's
+// entries in its own registers (a finished row changes only through its own step's elimination).
+template <int RS, int NW, int JO>
+__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
                                            int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
-  constexpr int P = 64 * RS;
-  const int k = 8 * JO + wo;
+  constexpr int P = 64 * RS, CPW = 32 / NW;
+  const int k = NW * JO + wo;
   const int kk = k & (kTlLC - 1);
   const double* const lcol = dyn + kk * P + lane;
+  double* const ubuf = dyn + tl_ubuf<RS>() + wave;
 #ifdef TL_X_STEPPROF
   unsigned long long t0_ = __builtin_readcyclecounter();
 #define TL_T(ix) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x == 0) tl_stepprof[ix] += now_ - t0_; t0_ = now_; }
@@ -364,55 +368,51 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], int wo, int ws, b
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   TL_T(0)
   // this wavefront owned step k and ran its search at once (see above): step k - 1 is still to be eliminated in its columns behind k
-  if constexpr (JO < 3) {
+  if constexpr (JO < CPW - 1) {
     if (wave == wo && kk != 0) {
       const int k1 = k - 1;
       const int ls1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3)]), ss1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3) + 1]);
       const double* const l1col = dyn + (k1 & (kTlLC - 1)) * P + lane;
-      double l1[RS], u1[4];
+      double l1[RS];
 #pragma unroll
       for (int s = 0; s < RS; ++s) l1[s] = l1col[64 * s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) u1[j] = j > JO ? tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1) : 0.0;
-      if (lane == 0) {  // U11 of step k - 1 in these columns
-#pragma unroll
-        for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k1 * 33 + wave + 8 * j] = u1[j];
+      for (int j = JO + 1; j < CPW; ++j) {
+        const double u1 = tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1);
+        if (lane == 0) ubuf[k1 * 33 + NW * j] = u1;  // U11 of step k - 1 in this column
+        tl_co_elim<RS>(a[j], l1, u1);
       }
-      if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l1, u1);
-      if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l1, u1);
-      if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l1, u1);
     }
   }
   TL_T(1)
-  const bool next_owner = pipe && wave == ((wo + 1) & 7) && k + 1 < ws;
-  double u[4];
+  const bool next_owner = pipe && wave == (wo + 1) % NW && k + 1 < ws;
   if (next_owner) {  // the pivot row's entry in column k + 1 only (the row is finished: out of this wavefront's own registers), that column, the search
-    if (wo == 7) {  // wavefront 0, its next register column
-      if constexpr (JO < 3) {
-        u[JO + 1] = tl_readlane_f64(tl_slot<RS>(a[JO + 1], ss), ls);
-        if (lane == 0) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * (JO + 1)] = u[JO + 1];
-        tl_co_update_col<RS, JO + 1>(a, l, u);
-        tl_co_search<RS, JO + 1>(a, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+    if (wo == NW - 1) {  // wavefront 0, its next register column
+      if constexpr (JO < CPW - 1) {
+        const double u = tl_readlane_f64(tl_slot<RS>(a[JO + 1], ss), ls);
+        if (lane == 0) ubuf[k * 33 + NW * (JO + 1)] = u;
+        tl_co_elim<RS>(a[JO + 1], l, u);
+        tl_co_search<RS>(a[JO + 1], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
       }
     } else {
-      u[JO] = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
-      if (lane == 0) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
-      tl_co_update_col<RS, JO>(a, l, u);
-      tl_co_search<RS, JO>(a, k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+      const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
+      if (lane == 0) ubuf[k * 33 + NW * JO] = u;
+      tl_co_elim<RS>(a[JO], l, u);
+      tl_co_search<RS>(a[JO], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
     }
   } else {
-    // the pivot row's entries in this wavefront's columns behind k
-#pragma unroll
-    for (int j = JO; j < 4; ++j) u[j] = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
-    if (lane == 0) {  // U11
-      if (wave > wo) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * JO] = u[JO];
-#pragma unroll
-      for (int j = JO + 1; j < 4; ++j) dyn[tl_ubuf<RS>() + k * 33 + wave + 8 * j] = u[j];
+    // the pivot row's entries in this wavefront's columns behind k (U11), and the elimination there
+    if (wave > wo) {
+      const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
+      if (lane == 0) ubuf[k * 33 + NW * JO] = u;
+      tl_co_elim<RS>(a[JO], l, u);
     }
-    if (wave > wo) tl_co_update_col<RS, JO>(a, l, u);
-    if constexpr (JO + 1 < 4) tl_co_update_col<RS, JO + 1>(a, l, u);
-    if constexpr (JO + 2 < 4) tl_co_update_col<RS, JO + 2>(a, l, u);
-    if constexpr (JO + 3 < 4) tl_co_update_col<RS, JO + 3>(a, l, u);
+#pragma unroll
+    for (int j = JO + 1; j < CPW; ++j) {
+      const double u = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
+      if (lane == 0) ubuf[k * 33 + NW * j] = u;
+      tl_co_elim<RS>(a[j], l, u);
+    }
   }
   TL_T(2)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: never wait for global stores here
@@ -420,12 +420,12 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[4], int wo, int ws, b
 }
 
 // Multipliers (and, for the rows chosen in this sub-panel, their U entries from their step on) of the steps [k0, k0 + cnt) from LDS to the rows of W.
-template <int RS>
+template <int RS, int NW>
 __device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, int n, int cb, int k0, int cnt, const double* __restrict__ dyn, const short* s_pos, int tid) {
   constexpr int P = 64 * RS;
 #pragma unroll
-  for (int i = 0; i < RS / 8; ++i) {
-    const int row = tid + kTlThreads * i;
+  for (int i = 0; i < RS / NW; ++i) {
+    const int row = tid + 64 * NW * i;
     const int pr = row < n ? (int)s_pos[row] : -1;
     if (pr >= cb) {  // the row entered this sub-panel
       const int kr = pr - cb;  // its own step, if it was chosen here (else >= 32 or beyond the steps done)
@@ -463,7 +463,8 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-  constexpr int R = RS / 8;        // rows per thread in the staging layout (thread t: rows t, t + 512)
+  constexpr int NW = tl_cfg<RS>::kWaves, NT = 64 * NW, CPW = kTlSW / NW;
+  constexpr int R = RS / NW;       // rows per thread in the staging layout (thread t: rows t, t + NT, ...)
   constexpr int P = 64 * RS;       // rows of a column in LDS
   constexpr int NH = kTlSW / kTlLC;  // the 32 columns pass through LDS in NH = 2 halves of 16
   constexpr int HC = kTlLC;
@@ -482,7 +483,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
       double* const la = dyn;         // [32][33]
       double* const ia = dyn + 1056;  // [2][16][17]
       const int q = lane >> 4, j = lane & 15;
-      for (int idx = tid; idx < 1024; idx += kTlThreads) {
+      for (int idx = tid; idx < 1024; idx += NT) {
         const int k = idx >> 5, i = idx & 31;
         la[k * 33 + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
       }
@@ -525,7 +526,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
       }
       __syncthreads();
       const int nrt = (m_in + 15) / 16;
-      for (int tile = wave; tile < nrt; tile += kTlWaves) {
+      for (int tile = wave; tile < nrt; tile += NW) {
         double aneg[8];
         const size_t arow = (size_t)s_rowlist[16 * tile + j] * ldw;
 #pragma unroll
@@ -553,13 +554,13 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
     }
     mark(4);
     // ---- stage: thread per row in (the second sub-panel's rows take the 32 eliminations of the first on the way: row -= L_row U'), column per wavefront out
-    tl_col<RS> a[4];
+    tl_col<RS> a[CPW];
     {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {  // HC columns of one row at a time (registers); finished rows and rows beyond n enter as zeros
-          const int row = tid + kTlThreads * i;
+          const int row = tid + NT * i;
           const bool live = row < n && s_pos[row] >= cb;
           double b[HC];
           if (live) {
@@ -573,9 +574,9 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
         __syncthreads();
         mark(9);
 #pragma unroll
-        for (int jj = 0; jj < 4 / NH; ++jj)
+        for (int jj = 0; jj < CPW / NH; ++jj)
 #pragma unroll
-          for (int s = 0; s < RS; ++s) a[(4 / NH) * h + jj][s] = dyn[(wave + 8 * jj) * P + lane + 64 * s];
+          for (int s = 0; s < RS; ++s) a[(CPW / NH) * h + jj][s] = dyn[(wave + NW * jj) * P + lane + 64 * s];
         __syncthreads();
         mark(10);
       }
@@ -584,26 +585,28 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
     // ---- the pivot steps
     const int pbase = kTlSW * sp;
 #define TL_STEPS(JO)                                                                                                                        \
-  _Pragma("nounroll") for (int wo = 0; wo < 8; ++wo) {                                                                                      \
-    if (8 * JO + wo >= ws) break;                                                                                                           \
-    const bool pipe = !(JO == 1 && wo == 7); /* the next column of Lbuf is free only behind the flush */                                    \
-    tl_co_step<RS, JO>(a, wo, ws,       pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                        \
-  }                                                                                                                                         \
-  if (JO == 1 && ws > 16) {                                                                                                                 \
-    __syncthreads();                                                                                                                        \
-    tl_flush<RS>(W, ldw, n, cb, 0, 16, dyn, s_pos, tid);                                                                                    \
-    __syncthreads();                                                                                                                        \
-    if (wave == 0) tl_co_search<RS, 2>(a, 16,       cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);                        \
-    __syncthreads();                                                                                                                        \
+  if constexpr (JO < CPW) {                                                                                                                 \
+    _Pragma("nounroll") for (int wo = 0; wo < NW; ++wo) {                                                                                   \
+      if (NW * JO + wo >= ws) break;                                                                                                        \
+      const bool pipe = NW * JO + wo != kTlLC - 1; /* the next column of Lbuf is free only behind the flush */                              \
+      tl_co_step<RS, NW, JO>(a, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                  \
+    }                                                                                                                                       \
+    if (JO == kTlLC / NW - 1 && ws > kTlLC) {                                                                                               \
+      __syncthreads();                                                                                                                      \
+      tl_flush<RS, NW>(W, ldw, n, cb, 0, kTlLC, dyn, s_pos, tid);                                                                           \
+      __syncthreads();                                                                                                                      \
+      if (wave == 0) tl_co_search<RS>(a[kTlLC / NW], kTlLC, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);          \
+      __syncthreads();                                                                                                                      \
+    }                                                                                                                                       \
   }
-    if (wave == 0) tl_co_search<RS, 0>(a, 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
+    if (wave == 0) tl_co_search<RS>(a[0], 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
     __syncthreads();
-    TL_STEPS(0) TL_STEPS(1) TL_STEPS(2) TL_STEPS(3)
+    TL_STEPS(0) TL_STEPS(1) TL_STEPS(2) TL_STEPS(3) TL_STEPS(4) TL_STEPS(5) TL_STEPS(6) TL_STEPS(7)
 #undef TL_STEPS
     __syncthreads();
     mark(6);
-    if (ws <= 16) tl_flush<RS>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
-    else tl_flush<RS>(W, ldw, n, cb, 16, ((ws + 1) & ~1) - 16, dyn, s_pos, tid);
+    if (ws <= 16) tl_flush<RS, NW>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
+    else tl_flush<RS, NW>(W, ldw, n, cb, 16, ((ws + 1) & ~1) - 16, dyn, s_pos, tid);
     __syncthreads();
     mark(7);
   }
@@ -622,8 +625,8 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
   const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
   unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
   const int n = tl_uni(n_), ldw = tl_uni(ldw_), jb = tl_uni(jb_), nct = tl_uni(nct_), m2 = tl_uni(m2_);
-  constexpr int LDP = C::kLDP, CH = C::kCH, RTM = C::kRT;
-  constexpr bool PF = C::kWavesPerEu <= 2;
+  constexpr int LDP = C::kLDP, CH = C::kCH, RTM = C::kRT, NW = C::kWaves;
+  constexpr bool PF = true;
   tl_gdouble* const W = (tl_gdouble*)W_generic;
   tl_gdouble* const F = (tl_gdouble*)F_generic;
   double* const u12s = dyn;
@@ -638,10 +641,10 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
   const int q = lane >> 4, j = lane & 15;
   // decomposition of the update: groups of rtw row tiles; with fewer groups than wavefronts the column tiles are split as well
   const int nrt = (m2 + 15) / 16;
-  const int rtw = (nrt + kTlWaves - 1) / kTlWaves < RTM ? (nrt + kTlWaves - 1) / kTlWaves : RTM;
+  const int rtw = (nrt + NW - 1) / NW < RTM ? (nrt + NW - 1) / NW : RTM;
   const int groups = (nrt + rtw - 1) / rtw;
-  const int csplit = groups >= kTlWaves ? 1 : kTlWaves / groups;
-  const bool fixed_group = groups <= kTlWaves;
+  const int csplit = groups >= NW ? 1 : NW / groups;
+  const bool fixed_group = groups <= NW;
   double aneg[RTM][16];
   unsigned roffb[RTM][4];
   unsigned valid = 0;
@@ -655,7 +658,7 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
       // to the L21 operand of the update, which stays in registers across the chunks, does not fit in the registers
       const double* const dinv_l = invd + j * 17 + q;            // block b, k-block kb: + b * 272 + 4 kb
       const double* const l11_l = l11 + j * kTlL11P + q;         // block (rb, cbk), rb >= 1, k-block kb: + 16 (rb - 1) * pitch + 16 cbk + 4 kb
-      for (int tc = wave; tc < ntc; tc += kTlWaves) {
+      for (int tc = wave; tc < ntc; tc += NW) {
         const int c0 = c_lo + 16 * tc;
         tl_d4 B[4], X[4];
 #pragma unroll
@@ -693,7 +696,7 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
     __syncthreads();
     mark(2);
     // ---- A22 -= L21 U12 for the chunk's columns
-    for (int grp = fixed_group ? wave % groups : wave; grp < groups; grp += kTlWaves) {
+    for (int grp = fixed_group ? wave % groups : wave; grp < groups; grp += NW) {
       const int csub = fixed_group ? wave / groups : 0;
       if (csub >= csplit) break;
       if (grp != loaded_group) {
@@ -734,10 +737,11 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
 
 // RS = rows per lane of the panel's register layout: 8 for n <= 512 (two workgroups per CU), 16 for n <= 1024
 template <int RS>
-__global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
+__global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
                                                                  unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
   using C = tl_cfg<RS>;
-  constexpr int R = RS / 8;
+  constexpr int NW = C::kWaves, NT = 64 * NW;
+  constexpr int R = RS / NW;
   constexpr int MAXN = C::kMaxN;
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
@@ -750,15 +754,15 @@ __global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_fact
   __shared__ short s_pos[MAXN], s_rowat[MAXN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
   __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];        // the panel's pivot rows (row indices) and recorded pivots (positions)
   __shared__ unsigned short s_rowlist[MAXN + 16];
-  __shared__ int s_wcnt[R][kTlWaves];
+  __shared__ int s_wcnt[R][NW];
   __shared__ int s_hdr[8], s_flags[1];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   double* const W = w_all + (size_t)blockIdx.x * n * ldw;
   double* const F = f_all + (size_t)blockIdx.x * n * n;
   int32_t* const PIV = piv_all + (size_t)blockIdx.x * n;
-  for (int r = tid; r < MAXN; r += kTlThreads) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
-  for (int r = tid; r < n + 16; r += kTlThreads) s_rowlist[r] = (unsigned short)(r < n ? r : n - 1);  // rows entering the first panel (padded: whole tiles)
+  for (int r = tid; r < MAXN; r += NT) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
+  for (int r = tid; r < n + 16; r += NT) s_rowlist[r] = (unsigned short)(r < n ? r : n - 1);  // rows entering the first panel (padded: whole tiles)
   int m_act = n;
   if (tid == 0) s_flags[0] = 0;
   __syncthreads();
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_fact
       unsigned long long bal[R];
 #pragma unroll
       for (int i = 0; i < R; ++i) {
-        const int row = tid + kTlThreads * i;
+        const int row = tid + NT * i;
         act[i] = row < n && s_pos[row] >= jb + pw;
         bal[i] = __ballot(act[i]);
         if (lane == 0) s_wcnt[i][wave] = __popcll(bal[i]);
@@ -787,8 +791,8 @@ __global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_fact
       for (int i = 0; i < R; ++i) {
         int before = 0, total = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < kTlWaves; ++w2) { const int cnt = s_wcnt[i][w2]; total += cnt; if (w2 < wave) before += cnt; }
-        if (act[i]) s_rowlist[base + before + __popcll(bal[i] & ((1ull << lane) - 1ull))] = (unsigned short)(tid + kTlThreads * i);
+        for (int w2 = 0; w2 < NW; ++w2) { const int cnt = s_wcnt[i][w2]; total += cnt; if (w2 < wave) before += cnt; }
+        if (act[i]) s_rowlist[base + before + __popcll(bal[i] & ((1ull << lane) - 1ull))] = (unsigned short)(tid + NT * i);
         base += total;
       }
       m2 = base;
@@ -798,16 +802,16 @@ __global__ __launch_bounds__(kTlThreads, tl_cfg<RS>::kWavesPerEu) void k_lu_fact
     const bool trailing = pw == kTlPW && mc > 0 && m2 > 0;
     if (trailing) {
       // the blocks of L11 below its diagonal blocks (rows 16..63, columns 0..47) and, where their inverses will be, the four diagonal blocks themselves
-      for (int idx = tid; idx < 48 * 48; idx += kTlThreads) {
+      for (int idx = tid; idx < 48 * 48; idx += NT) {
         const int k = 16 + idx / 48, i = idx % 48;
         l11[(k - 16) * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
       }
-      for (int idx = tid; idx < 4 * 256; idx += kTlThreads) {
+      for (int idx = tid; idx < 4 * 256; idx += NT) {
         const int blk = idx >> 8, r = (idx >> 4) & 15, i = idx & 15;
         invd[(blk * 16 + r) * 17 + i] = i < r ? W[(size_t)s_prow[16 * blk + r] * ldw + jb + 16 * blk + i] : (i == r ? 1.0 : 0.0);
       }
     }
-    for (int c = tid; c < jb + pw; c += kTlThreads) {
+    for (int c = tid; c < jb + pw; c += NT) {
       double* const dst = F + (size_t)c * n + jb;
       for (int k0 = 0; k0 < pw; k0 += 16) {
         double v[16];

@@ -1,4 +1,4 @@
-# round 3: tests of the dense LU paths + library-level timing of the matrix-core kernel against the exact one (needs a GPU)
+# round 4: tests of the dense LU paths + library-level timing of the matrix-core kernel against the exact one (needs a GPU)
 cd /root/repo
 python -m pytest tests/test_gpu_lu_models.py -q -x -m gpu -k "matrix_core or bitwise or singular" 2>&1 | tail -3
 python -m pytest tests/test_gpu_configs.py -q -x -m gpu -k "config3" 2>&1 | tail -3

@@ -67,8 +67,8 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(512)));
   CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(1024)));
   { int occ8 = 0, occ16 = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, (const void*)dsh::k_lu_factor_tiled<8>, 512, dsh::tiled_lds_bytes(512)));
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, (const void*)dsh::k_lu_factor_tiled<16>, 512, dsh::tiled_lds_bytes(1024)));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, (const void*)dsh::k_lu_factor_tiled<8>, dsh::tiled_threads(512), dsh::tiled_lds_bytes(512)));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, (const void*)dsh::k_lu_factor_tiled<16>, dsh::tiled_threads(1024), dsh::tiled_lds_bytes(1024)));
     printf("workgroups per CU: %d (n <= 512, %zu B of dynamic LDS), %d (n <= 1024, %zu B)\n", occ8, dsh::tiled_lds_bytes(512), occ16, dsh::tiled_lds_bytes(1024)); }
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
@@ -79,8 +79,8 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(dsh::k_lu_stage_rowmajor, sg, dim3(256), 0, 0, n, ldw, nb, (const double*)d_a, d_w);
     CK(hipEventRecord(e1));
-    if (n <= 512) hipLaunchKernelGGL((dsh::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
-    else hipLaunchKernelGGL((dsh::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(512), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    if (n <= 512) hipLaunchKernelGGL((dsh::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    else hipLaunchKernelGGL((dsh::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
     CK(hipEventRecord(e2));
     CK(hipGetLastError());
     CK(hipEventSynchronize(e2));
