@@ -29,29 +29,34 @@ namespace dsh {
 
 constexpr int kTlMaxThreads = 512;
 constexpr int kTlPW = 64;     // panel width
-constexpr int kTlSW = 32;     // sub-panel width (columns of a row held in registers)
 constexpr int kTlLC = 16;     // columns of multipliers kept in LDS at a time (a sub-panel is flushed to W in two halves)
 constexpr int kTlL11P = 49;   // pitch of the staged L11 (rows 16..63, columns 0..47: the blocks below the diagonal blocks)
 constexpr int kTlMaxN = 1024;
-// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024); kWaves = wavefronts per workgroup (a workgroup per system; wavefront w
-// holds the columns w, w + kWaves, ... of a 32-column sub-panel in registers).  One workgroup of eight wavefronts per CU for both sizes.
-// TWO workgroups per CU — one system's pivot steps, a latency chain of ~1 us per step with the matrix cores idle, under the other system's trailing
-// update — were built in both possible shapes for n <= 512 and measured at 512 x 4096 (profiles/r04_lu_bench.md): eight wavefronts of 128 registers
-// (40.4 ms) and four wavefronts of 256 registers holding eight columns each (-DDSH_TL_WAVES8=4: 51.0 ms) against 27.4 ms with one workgroup: in both
-// the register columns of a sub-panel leave the pivot-step loop no room and it spills; it would take 16-column sub-panels to make the second fit.
-#ifndef DSH_TL_WAVES8
-#define DSH_TL_WAVES8 8
+// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024); kWaves = wavefronts per workgroup (a workgroup per system); kSW = width
+// of a sub-panel, the columns that live in registers during the pivot steps: wavefront w holds its columns w, w + kWaves, ... — four columns each in
+// both layouts.
+//   n <= 1024: one workgroup of eight wavefronts per CU, sub-panels of 32 columns.
+//   n <= 512:  TWO workgroups of four wavefronts per CU (256 registers per lane and at most 80 KB of LDS each), sub-panels of 16 columns: one system's
+//              pivot steps — a latency chain of ~1 us per step with the matrix cores idle — run under the other system's trailing update, and two such
+//              chains interleave on a SIMD at almost no cost.
+// Two workgroups per CU with 32-column sub-panels were measured first (profiles/r04_lu_bench.md, 512 x 4096): eight wavefronts of 128 registers 40.4 ms,
+// four wavefronts holding eight columns each 51.0 ms, against 27.4 ms with one workgroup per CU — the register columns leave the pivot-step loop no room
+// and it spills.  -DDSH_TL_LAYOUT8=0 keeps the one-workgroup layout for n <= 512 as well.
+#ifndef DSH_TL_LAYOUT8
+#define DSH_TL_LAYOUT8 1
 #endif
 template <int RS> struct tl_cfg;
 template <> struct tl_cfg<8> {
-  static constexpr int kWaves = DSH_TL_WAVES8;
-  static constexpr int kMaxN = 512;                               // rows
-  static constexpr int kLDP = DSH_TL_WAVES8 == 4 ? 80 : 208;      // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
-  static constexpr int kCH = DSH_TL_WAVES8 == 4 ? 64 : 208;       // columns per chunk (tiles of 16; a multiple of the wavefronts: U12 is one tile per wavefront at a time)
-  static constexpr int kRT = 4;                                   // row tiles per wavefront whose L21 operand stays in registers
+  static constexpr int kWaves = DSH_TL_LAYOUT8 ? 4 : 8;
+  static constexpr int kSW = DSH_TL_LAYOUT8 ? 16 : 32;
+  static constexpr int kMaxN = 512;                          // rows
+  static constexpr int kLDP = DSH_TL_LAYOUT8 ? 80 : 208;     // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
+  static constexpr int kCH = DSH_TL_LAYOUT8 ? 64 : 208;      // columns per chunk (tiles of 16; U12 is one tile per wavefront at a time)
+  static constexpr int kRT = 4;                              // row tiles per wavefront whose L21 operand stays in registers
 };
 template <> struct tl_cfg<16> {
   static constexpr int kWaves = 8;
+  static constexpr int kSW = 32;
   static constexpr int kMaxN = 1024;
   static constexpr int kLDP = 208;
   static constexpr int kCH = 208;      // 13 tiles of 16
@@ -59,11 +64,14 @@ template <> struct tl_cfg<16> {
 };
 inline int tiled_threads(int64_t n) { return 64 * (n <= 512 ? tl_cfg<8>::kWaves : tl_cfg<16>::kWaves); }
 inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }
-// dynamic LDS (doubles): the panel needs kTlLC columns of 64 RS rows + Ubuf [32][33]; the trailing phase u12s [64][LDP] + l11 [48][49] + invd [4][16][17]
+// dynamic LDS (doubles): [0, 16 P) Lbuf during the pivot steps (P = 64 RS rows) / the operands of the matrix-core phases otherwise (panel: L11A, U'; trailing:
+// u12s [64][LDP], l11 [48][49]); then Ubuf [SW][SW + 1]; then invd [4][16][17], the inverses of the panel's diagonal blocks, which live from the
+// sub-panel that produces them to the end of the trailing phase
+template <int RS> constexpr int tl_ubuf() { return kTlLC * 64 * RS; }  // offset of Ubuf
+template <int RS> constexpr int tl_invd() { return tl_ubuf<RS>() + tl_cfg<RS>::kSW * (tl_cfg<RS>::kSW + 1); }
 template <int RS> constexpr size_t tiled_lds_doubles() {
-  constexpr size_t panel = (size_t)kTlLC * 64 * RS + 32 * 33;
-  constexpr size_t trail = (size_t)64 * tl_cfg<RS>::kLDP + 48 * kTlL11P + 4 * 16 * 17;
-  return panel > trail ? panel : trail;
+  static_assert(64 * tl_cfg<RS>::kLDP + 48 * kTlL11P <= tl_ubuf<RS>(), "the trailing phase's operands must end before Ubuf / invd");
+  return (size_t)tl_invd<RS>() + 4 * 16 * 17;
 }
 inline size_t tiled_lds_bytes(int64_t n) { return sizeof(double) * (n <= 512 ? tiled_lds_doubles<8>() : tiled_lds_doubles<16>()); }
 
@@ -241,8 +249,8 @@ __device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) {
   }
 }
 
-constexpr int kTlUs = 2048, kTlUsP = 48;  // offset (doubles) of Us in the dynamic LDS and its pitch (conflict-free operand reads)
-template <int RS> constexpr int tl_ubuf() { return kTlLC * 64 * RS; }  // offset of Ubuf
+constexpr int kTlLaP = 49;                // pitch of L11A in LDS
+constexpr int kTlUs = 2400, kTlUsP = 48;  // offset (doubles) of Us in the dynamic LDS (behind L11A [48][49]) and its pitch (conflict-free operand reads)
 
 #ifdef TL_X_STEPPROF
 __device__ unsigned long long tl_stepprof[8];
@@ -321,7 +329,7 @@ __device__ __forceinline__ void tl_co_search(const tl_col<RS>& col, int k, int c
   if (lane == 0) {
     s_hdr[2 * (k & 3)] = ls;
     s_hdr[2 * (k & 3) + 1] = ss;
-    dyn[tl_ubuf<RS>() + k * 33 + k] = piv;
+    dyn[tl_ubuf<RS>() + k * (tl_cfg<RS>::kSW + 1) + k] = piv;
     if (zero) s_flags[0] = 1;
     s_pos[rstar] = (short)g;  // the row at the diagonal position trades places with the winner
     if (rg != rstar) { s_pos[rg] = (short)ps; s_rowat[ps] = (short)rg; }
@@ -348,9 +356,9 @@ __device__ __forceinline__ void tl_co_elim(tl_col<RS>& c, const double (&l)[RS],
 // multipliers in Lbuf (a column is reused 16 steps later), {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's
 // entries in its own registers (a finished row changes only through its own step's elimination).
 template <int RS, int NW, int JO>
-__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
+__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[tl_cfg<RS>::kSW / NW], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
                                            int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
-  constexpr int P = 64 * RS, CPW = 32 / NW;
+  constexpr int P = 64 * RS, CPW = tl_cfg<RS>::kSW / NW, UP = tl_cfg<RS>::kSW + 1;
   const int k = NW * JO + wo;
   const int kk = k & (kTlLC - 1);
   const double* const lcol = dyn + kk * P + lane;
@@ -379,7 +387,7 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int
 #pragma unroll
       for (int j = JO + 1; j < CPW; ++j) {
         const double u1 = tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1);
-        if (lane == 0) ubuf[k1 * 33 + NW * j] = u1;  // U11 of step k - 1 in this column
+        if (lane == 0) ubuf[k1 * UP + NW * j] = u1;  // U11 of step k - 1 in this column
         tl_co_elim<RS>(a[j], l1, u1);
       }
     }
@@ -390,13 +398,13 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int
     if (wo == NW - 1) {  // wavefront 0, its next register column
       if constexpr (JO < CPW - 1) {
         const double u = tl_readlane_f64(tl_slot<RS>(a[JO + 1], ss), ls);
-        if (lane == 0) ubuf[k * 33 + NW * (JO + 1)] = u;
+        if (lane == 0) ubuf[k * UP + NW * (JO + 1)] = u;
         tl_co_elim<RS>(a[JO + 1], l, u);
         tl_co_search<RS>(a[JO + 1], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
       }
     } else {
       const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
-      if (lane == 0) ubuf[k * 33 + NW * JO] = u;
+      if (lane == 0) ubuf[k * UP + NW * JO] = u;
       tl_co_elim<RS>(a[JO], l, u);
       tl_co_search<RS>(a[JO], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
     }
@@ -404,13 +412,13 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int
     // the pivot row's entries in this wavefront's columns behind k (U11), and the elimination there
     if (wave > wo) {
       const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
-      if (lane == 0) ubuf[k * 33 + NW * JO] = u;
+      if (lane == 0) ubuf[k * UP + NW * JO] = u;
       tl_co_elim<RS>(a[JO], l, u);
     }
 #pragma unroll
     for (int j = JO + 1; j < CPW; ++j) {
       const double u = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
-      if (lane == 0) ubuf[k * 33 + NW * j] = u;
+      if (lane == 0) ubuf[k * UP + NW * j] = u;
       tl_co_elim<RS>(a[j], l, u);
     }
   }
@@ -422,20 +430,20 @@ __device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[32 / NW], int wo, int
 // Multipliers (and, for the rows chosen in this sub-panel, their U entries from their step on) of the steps [k0, k0 + cnt) from LDS to the rows of W.
 template <int RS, int NW>
 __device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, int n, int cb, int k0, int cnt, const double* __restrict__ dyn, const short* s_pos, int tid) {
-  constexpr int P = 64 * RS;
+  constexpr int P = 64 * RS, SW = tl_cfg<RS>::kSW;
 #pragma unroll
   for (int i = 0; i < RS / NW; ++i) {
     const int row = tid + 64 * NW * i;
     const int pr = row < n ? (int)s_pos[row] : -1;
     if (pr >= cb) {  // the row entered this sub-panel
-      const int kr = pr - cb;  // its own step, if it was chosen here (else >= 32 or beyond the steps done)
+      const int kr = pr - cb;  // its own step, if it was chosen here (else >= SW or beyond the steps done)
       tl_gd2* dst = reinterpret_cast<tl_gd2*>(W + (size_t)row * ldw + cb + k0);
       for (int c = 0; c < cnt; c += 2) {
         tl_d2 v;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int k = k0 + c + e;
-          v[e] = k < kr ? dyn[(k & (kTlLC - 1)) * P + row] : dyn[tl_ubuf<RS>() + (kr < 32 ? kr : 0) * 33 + k];
+          v[e] = k < kr ? dyn[(k & (kTlLC - 1)) * P + row] : dyn[tl_ubuf<RS>() + (kr < SW ? kr : 0) * (SW + 1) + k];
         }
         dst[c >> 1] = v;
       }
@@ -443,7 +451,30 @@ __device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, in
   }
 }
 
-// The panel of 64 columns at jb (two sub-panels).  Not inlined: its registers are allocated apart from the rest of the kernel.
+// Inverse of the unit lower triangular 16 x 16 diagonal block of the 16 steps whose multipliers Lbuf holds (panel steps pb .. pb + 15, diagonal block `blk` of the
+// panel), by the first 16 lanes of one wavefront: lane = column.  The inverses are the A operands of every blocked substitution that follows (the later
+// sub-panels' U', the trailing phase's U12).
+template <int RS>
+__device__ __forceinline__ void tl_invert_diag(double* __restrict__ dyn, const int* s_prow, int pb, int blk, int lane) {
+  constexpr int P = 64 * RS;
+  if (lane < 16) {
+    int rows[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[r] = s_prow[pb + r];
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = r == lane ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 15; ++i)
+#pragma unroll
+      for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-dyn[i * P + rows[r]], x[i], x[r]);
+    double* const invd = dyn + tl_invd<RS>() + blk * 272;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) invd[r * 17 + lane] = x[r];
+  }
+}
+
+// The panel of 64 columns at jb (sub-panels of kSW columns).  Not inlined: its registers are allocated apart from the rest of the kernel.
 template <int RS>
 __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_, int n_, int jb_, double* dyn_, short* s_pos_, short* s_rowat_, int* s_prow_, int* s_ipiv_,
                                       int* s_hdr_, int* s_flags_, const unsigned short* s_rowlist_, int m_in_, unsigned long long* phase_clocks_) {
@@ -463,74 +494,69 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-  constexpr int NW = tl_cfg<RS>::kWaves, NT = 64 * NW, CPW = kTlSW / NW;
+  constexpr int NW = tl_cfg<RS>::kWaves, NT = 64 * NW, SW = tl_cfg<RS>::kSW, CPW = SW / NW;
   constexpr int R = RS / NW;       // rows per thread in the staging layout (thread t: rows t, t + NT, ...)
   constexpr int P = 64 * RS;       // rows of a column in LDS
-  constexpr int NH = kTlSW / kTlLC;  // the 32 columns pass through LDS in NH = 2 halves of 16
+  constexpr int NH = SW / kTlLC;   // the sub-panel's columns pass through LDS 16 at a time
   constexpr int HC = kTlLC;
+  constexpr int NCT = SW / 16;     // column tiles of a sub-panel
+  constexpr int MAXD = (kTlPW - SW) / 16;  // diagonal blocks in front of the last sub-panel
   tl_gdouble* const W = (tl_gdouble*)W_generic;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* const Us = dyn + kTlUs;  // [32][kTlUsP]: dead before the stage writes T over it
+  double* const Us = dyn + kTlUs;  // [<= 48][kTlUsP]: dead before the stage writes T over it
+  const double* const invd = dyn + tl_invd<RS>();
 #pragma nounroll
-  for (int sp = 0; sp < 2; ++sp) {
-    const int cb = jb + kTlSW * sp;
-    const int ws = (n - cb) < kTlSW ? (n - cb) : kTlSW;
+  for (int sp = 0; sp < kTlPW / SW; ++sp) {
+    const int cb = jb + SW * sp;
+    const int ws = (n - cb) < SW ? (n - cb) : SW;
     if (ws <= 0) break;
-    if (sp == 1) {
-      // ---- the columns cb..cb+31 take the 32 eliminations of the first sub-panel, on the matrix cores (LDS broadcast reads made the vector form of
-      // this 50 us per panel): L11A and the inverses of its two diagonal blocks to LDS, U' = L11A^-1 B for the pivot rows (blocked substitution, two
-      // column tiles), then B -= L_A U' for the rows that entered the panel (the row list of the previous panel; rows finished since are not stored).
-      double* const la = dyn;         // [32][33]
-      double* const ia = dyn + 1056;  // [2][16][17]
+    if (sp > 0) {
+      // ---- the columns cb..cb+SW-1 take the D = SW sp eliminations of the panel's earlier sub-panels, on the matrix cores (LDS broadcast reads made the
+      // vector form of this 50 us per panel): the blocks of L11A below its diagonal blocks to LDS (the inverses of the diagonal blocks are there since
+      // their sub-panels finished), U' = L11A^-1 B for the pivot rows (blocked substitution, one column tile per wavefront), then B -= L_A U' for the
+      // rows that entered the panel (the row list of the previous panel; rows finished since are not stored).
+      const int D = SW * sp, nd = D / 16;
+      double* const la = dyn;         // [D][kTlLaP]
       const int q = lane >> 4, j = lane & 15;
-      for (int idx = tid; idx < 1024; idx += NT) {
-        const int k = idx >> 5, i = idx & 31;
-        la[k * 33 + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
+      for (int idx = tid; idx < D * D; idx += NT) {
+        const int k = idx / D, i = idx - k * D;
+        if (i < (k & ~15)) la[k * kTlLaP + i] = W[(size_t)s_prow[k] * ldw + jb + i];
       }
       __syncthreads();
-      if (wave == 0 && lane < 32) {
-        const int blk = lane >> 4;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = r == j ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < 15; ++i)
-#pragma unroll
-          for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-la[(16 * blk + r) * 33 + 16 * blk + i], x[i], x[r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ia[(blk * 16 + r) * 17 + j] = x[r];
-      }
-      __syncthreads();
-      if (wave < 2) {
+      if (wave < NCT) {
         const int c0 = 16 * wave;
-        tl_d4 B0, B1;
+        tl_d4 B[MAXD], X[MAXD];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          B0[r] = W[(size_t)s_prow[4 * r + q] * ldw + cb + c0 + j];
-          B1[r] = W[(size_t)s_prow[16 + 4 * r + q] * ldw + cb + c0 + j];
-        }
-        tl_d4 X0 = {0.0, 0.0, 0.0, 0.0}, X1 = {0.0, 0.0, 0.0, 0.0};
+        for (int rb = 0; rb < MAXD; ++rb)
+          if (rb < nd) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) X0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[j * 17 + 4 * kb + q], B0[kb], X0, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j];
+          }
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) B1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 + j) * 33 + 4 * kb + q], X0[kb], B1, 0, 0, 0);
+        for (int rb = 0; rb < MAXD; ++rb)
+          if (rb < nd) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ia[(16 + j) * 17 + 4 * kb + q], B1[kb], X1, 0, 0, 0);
+            for (int cbk = 0; cbk < rb; ++cbk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          Us[(4 * r + q) * kTlUsP + c0 + j] = X0[r];
-          Us[(16 + 4 * r + q) * kTlUsP + c0 + j] = X1[r];
-          W[(size_t)s_prow[4 * r + q] * ldw + cb + c0 + j] = X0[r];
-          W[(size_t)s_prow[16 + 4 * r + q] * ldw + cb + c0 + j] = X1[r];
-        }
+              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 * rb + j) * kTlLaP + 16 * cbk + 4 * kb + q], X[cbk][kb], B[rb], 0, 0, 0);
+            tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(invd[rb * 272 + j * 17 + 4 * kb + q], B[rb][kb], acc, 0, 0, 0);
+            X[rb] = acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              Us[(16 * rb + 4 * r + q) * kTlUsP + c0 + j] = acc[r];
+              W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j] = acc[r];
+            }
+          }
       }
       __syncthreads();
       const int nrt = (m_in + 15) / 16;
       for (int tile = wave; tile < nrt; tile += NW) {
-        double aneg[8];
+        double aneg[4 * MAXD];
         const size_t arow = (size_t)s_rowlist[16 * tile + j] * ldw;
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) aneg[kb] = -W[arow + jb + 4 * kb + q];
+        for (int kb = 0; kb < 4 * MAXD; ++kb) aneg[kb] = kb < 4 * nd ? -W[arow + jb + 4 * kb + q] : 0.0;
         size_t ro[4];
         bool ok[4];
 #pragma unroll
@@ -540,12 +566,13 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
           ok[r] = 16 * tile + 4 * r + q < m_in && s_pos[row] >= cb;
         }
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct) {
           tl_d4 acc;
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = W[ro[r] + 16 * ct];
 #pragma unroll
-          for (int kb = 0; kb < 8; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aneg[kb], Us[(4 * kb + q) * kTlUsP + 16 * ct + j], acc, 0, 0, 0);
+          for (int kb = 0; kb < 4 * MAXD; ++kb)
+            if (kb < 4 * nd) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aneg[kb], Us[(4 * kb + q) * kTlUsP + 16 * ct + j], acc, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (ok[r]) W[ro[r] + 16 * ct] = acc[r];
         }
@@ -583,7 +610,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
     }
     mark(5);
     // ---- the pivot steps
-    const int pbase = kTlSW * sp;
+    const int pbase = SW * sp;
 #define TL_STEPS(JO)                                                                                                                        \
   if constexpr (JO < CPW) {                                                                                                                 \
     _Pragma("nounroll") for (int wo = 0; wo < NW; ++wo) {                                                                                   \
@@ -591,11 +618,12 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
       const bool pipe = NW * JO + wo != kTlLC - 1; /* the next column of Lbuf is free only behind the flush */                              \
       tl_co_step<RS, NW, JO>(a, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                  \
     }                                                                                                                                       \
-    if (JO == kTlLC / NW - 1 && ws > kTlLC) {                                                                                               \
+    if (SW > kTlLC && JO == kTlLC / NW - 1 && ws > kTlLC) {                                                                                 \
       __syncthreads();                                                                                                                      \
       tl_flush<RS, NW>(W, ldw, n, cb, 0, kTlLC, dyn, s_pos, tid);                                                                           \
+      if (wave == 1) tl_invert_diag<RS>(dyn, s_prow, pbase, pbase / 16, lane);                                                              \
       __syncthreads();                                                                                                                      \
-      if (wave == 0) tl_co_search<RS>(a[kTlLC / NW], kTlLC, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);          \
+      if (wave == 0) tl_co_search<RS>(a[kTlLC / NW < CPW ? kTlLC / NW : 0], kTlLC, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane); \
       __syncthreads();                                                                                                                      \
     }                                                                                                                                       \
   }
@@ -605,8 +633,9 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
 #undef TL_STEPS
     __syncthreads();
     mark(6);
-    if (ws <= 16) tl_flush<RS, NW>(W, ldw, n, cb, 0, (ws + 1) & ~1, dyn, s_pos, tid);
-    else tl_flush<RS, NW>(W, ldw, n, cb, 16, ((ws + 1) & ~1) - 16, dyn, s_pos, tid);
+    const int f0 = ws <= kTlLC ? 0 : kTlLC;  // the steps whose multipliers Lbuf holds now
+    tl_flush<RS, NW>(W, ldw, n, cb, f0, ((ws + 1) & ~1) - f0, dyn, s_pos, tid);
+    if (wave == 1 && ws - f0 == 16) tl_invert_diag<RS>(dyn, s_prow, pbase + f0, (pbase + f0) / 16, lane);
     __syncthreads();
     mark(7);
   }
@@ -631,7 +660,7 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
   tl_gdouble* const F = (tl_gdouble*)F_generic;
   double* const u12s = dyn;
   const double* const l11 = dyn + 64 * LDP;        // rows 16..63, columns 0..47 of L11, pitch kTlL11P
-  const double* const invd = l11 + 48 * kTlL11P;
+  const double* const invd = dyn + tl_invd<RS>();  // the inverses of the panel's four diagonal blocks (tl_invert_diag)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
@@ -748,9 +777,8 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
   auto mark = [&](int phase) {
     if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
   };
-  extern __shared__ double dyn[];                // trailing phase: u12s [64][LDP], l11 [48][49], invd [4][16][17]; panel: see tl_panel
+  extern __shared__ double dyn[];                // see tiled_lds_doubles
   double* const l11 = dyn + 64 * C::kLDP;
-  double* const invd = l11 + 48 * kTlL11P;
   __shared__ short s_pos[MAXN], s_rowat[MAXN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
   __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];        // the panel's pivot rows (row indices) and recorded pivots (positions)
   __shared__ unsigned short s_rowlist[MAXN + 16];
@@ -770,10 +798,10 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
 
   for (int jb = 0; jb < n; jb += kTlPW) {
     const int pw = (n - jb) < kTlPW ? (n - jb) : kTlPW;
-    // =========================================================== panel: two sub-panels of 32 columns in registers
+    // =========================================================== panel: sub-panels of kSW columns in registers
     tl_panel<RS>(W, ldw, n, jb, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, s_rowlist, m_act, phase_clocks);
     mark(0);
-    // =========================================================== the 64 finished rows -> F; list of the rows still active; L11 and its diagonal-block inverses
+    // =========================================================== the 64 finished rows -> F; list of the rows still active; L11
     int m2 = 0;
     {
       bool act[R];
@@ -801,14 +829,10 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
     const int mc = nct - jb - kTlPW;  // trailing columns (exist only behind a full panel)
     const bool trailing = pw == kTlPW && mc > 0 && m2 > 0;
     if (trailing) {
-      // the blocks of L11 below its diagonal blocks (rows 16..63, columns 0..47) and, where their inverses will be, the four diagonal blocks themselves
+      // the blocks of L11 below its diagonal blocks (rows 16..63, columns 0..47); the inverses of the diagonal blocks are in LDS already (tl_invert_diag)
       for (int idx = tid; idx < 48 * 48; idx += NT) {
         const int k = 16 + idx / 48, i = idx % 48;
         l11[(k - 16) * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
-      }
-      for (int idx = tid; idx < 4 * 256; idx += NT) {
-        const int blk = idx >> 8, r = (idx >> 4) & 15, i = idx & 15;
-        invd[(blk * 16 + r) * 17 + i] = i < r ? W[(size_t)s_prow[16 * blk + r] * ldw + jb + 16 * blk + i] : (i == r ? 1.0 : 0.0);
       }
     }
     for (int c = tid; c < jb + pw; c += NT) {
@@ -825,19 +849,6 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
     __syncthreads();
     if (m2 > 0 && tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
     if (!trailing) { mark(1); continue; }
-    if (wave == 1) {  // inverse of the four 16 x 16 unit lower triangular diagonal blocks, in place: lane = (block, column); the 16 lanes of a block are in step
-      const int blk = lane >> 4, jc = lane & 15;
-      double x[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = r == jc ? 1.0 : 0.0;
-#pragma unroll
-      for (int i = 0; i < 15; ++i)
-#pragma unroll
-        for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-invd[(16 * blk + r) * 17 + i], x[i], x[r]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every lane has read the block before any lane overwrites it
-#pragma unroll
-      for (int r = 0; r < 16; ++r) invd[(blk * 16 + r) * 17 + jc] = x[r];
-    }
     __syncthreads();
     mark(1);
     tl_trailing<RS>(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
