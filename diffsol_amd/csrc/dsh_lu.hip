@@ -263,8 +263,9 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
             static bool tl_attr_dev[64] = {false};
             bool& tl_attr = tl_attr_dev[ctx->device & 63];
             if (!tl_attr) {
-              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_lds_bytes(512)));
-              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiled_lds_bytes(1024)));
+              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)tl_one::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_one::tiled_lds_bytes(512)));
+              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)tl_one::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_one::tiled_lds_bytes(1024)));
+              DSH_HIP_CHECK(hipFuncSetAttribute((const void*)tl_two::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl_two::tiled_lds_bytes(512)));
               tl_attr = true;
             }
             static const bool tl_prof = [] { const char* e = getenv("DSH_LU_PHASE_PROFILE"); return e && atoi(e) != 0; }();
@@ -272,11 +273,14 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
             if (tl_prof) { DSH_HIP_CHECK(hipMalloc(&clk, 8 * sizeof(unsigned long long))); DSH_HIP_CHECK(hipMemset(clk, 0, 8 * sizeof(unsigned long long))); }
             const dim3 sg((unsigned)((nb + 31) / 32), (unsigned)((ldw + 31) / 32), (unsigned)n);
             hipLaunchKernelGGL(k_lu_stage_rowmajor, sg, dim3(256), 0, ctx->stream, (int)n, ldw, nb, a, lu->work);
-            if (n <= 512)
-              hipLaunchKernelGGL((k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+            if (n > 512)
+              hipLaunchKernelGGL((tl_one::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+                                 lu->pivots, lu->singular, lu->singular_epoch, clk);
+            else if (tiled_layout(n) == 2)  // two workgroups of four wavefronts per CU
+              hipLaunchKernelGGL((tl_two::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
                                  lu->pivots, lu->singular, lu->singular_epoch, clk);
             else
-              hipLaunchKernelGGL((k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
+              hipLaunchKernelGGL((tl_one::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(tiled_threads(n)), tiled_lds_bytes(n), ctx->stream, (int)n, ldw, lu->work, lu->factors,
                                  lu->pivots, lu->singular, lu->singular_epoch, clk);
             if (tl_prof) {
               unsigned long long h[8];

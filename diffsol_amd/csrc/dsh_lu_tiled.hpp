@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 
 #include "dsh_device.hpp"
 
@@ -32,49 +33,7 @@ constexpr int kTlPW = 64;     // panel width
 constexpr int kTlLC = 16;     // columns of multipliers kept in LDS at a time (a sub-panel is flushed to W in two halves)
 constexpr int kTlL11P = 49;   // pitch of the staged L11 (rows 16..63, columns 0..47: the blocks below the diagonal blocks)
 constexpr int kTlMaxN = 1024;
-// RS = rows per lane of the panel's register layout (8: n <= 512, 16: n <= 1024); kWaves = wavefronts per workgroup (a workgroup per system); kSW = width
-// of a sub-panel, the columns that live in registers during the pivot steps: wavefront w holds its columns w, w + kWaves, ... — four columns each in
-// both layouts.
-//   n <= 1024: one workgroup of eight wavefronts per CU, sub-panels of 32 columns.
-//   n <= 512:  TWO workgroups of four wavefronts per CU (256 registers per lane and at most 80 KB of LDS each), sub-panels of 16 columns: one system's
-//              pivot steps — a latency chain of ~1 us per step with the matrix cores idle — run under the other system's trailing update, and two such
-//              chains interleave on a SIMD at almost no cost.
-// Two workgroups per CU with 32-column sub-panels were measured first (profiles/r04_lu_bench.md, 512 x 4096): eight wavefronts of 128 registers 40.4 ms,
-// four wavefronts holding eight columns each 51.0 ms, against 27.4 ms with one workgroup per CU — the register columns leave the pivot-step loop no room
-// and it spills.  -DDSH_TL_LAYOUT8=0 keeps the one-workgroup layout for n <= 512 as well.
-#ifndef DSH_TL_LAYOUT8
-#define DSH_TL_LAYOUT8 1
-#endif
-template <int RS> struct tl_cfg;
-template <> struct tl_cfg<8> {
-  static constexpr int kWaves = DSH_TL_LAYOUT8 ? 4 : 8;
-  static constexpr int kSW = DSH_TL_LAYOUT8 ? 16 : 32;
-  static constexpr int kMaxN = 512;                          // rows
-  static constexpr int kLDP = DSH_TL_LAYOUT8 ? 80 : 208;     // pitch of the U12 chunk in LDS (doubles); LDP % 32 == 16 keeps the operand reads conflict-free
-  static constexpr int kCH = DSH_TL_LAYOUT8 ? 64 : 208;      // columns per chunk (tiles of 16; U12 is one tile per wavefront at a time)
-  static constexpr int kRT = 4;                              // row tiles per wavefront whose L21 operand stays in registers
-};
-template <> struct tl_cfg<16> {
-  static constexpr int kWaves = 8;
-  static constexpr int kSW = 32;
-  static constexpr int kMaxN = 1024;
-  static constexpr int kLDP = 208;
-  static constexpr int kCH = 208;      // 13 tiles of 16
-  static constexpr int kRT = 4;
-};
-inline int tiled_threads(int64_t n) { return 64 * (n <= 512 ? tl_cfg<8>::kWaves : tl_cfg<16>::kWaves); }
-inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }
-// dynamic LDS (doubles): [0, 16 P) Lbuf during the pivot steps (P = 64 RS rows) / the operands of the matrix-core phases otherwise (panel: L11A, U'; trailing:
-// u12s [64][LDP], l11 [48][49]); then Ubuf [SW][SW + 1]; then invd [4][16][17], the inverses of the panel's diagonal blocks, which live from the
-// sub-panel that produces them to the end of the trailing phase
-template <int RS> constexpr int tl_ubuf() { return kTlLC * 64 * RS; }  // offset of Ubuf
-template <int RS> constexpr int tl_invd() { return tl_ubuf<RS>() + tl_cfg<RS>::kSW * (tl_cfg<RS>::kSW + 1); }
-template <int RS> constexpr size_t tiled_lds_doubles() {
-  static_assert(64 * tl_cfg<RS>::kLDP + 48 * kTlL11P <= tl_ubuf<RS>(), "the trailing phase's operands must end before Ubuf / invd");
-  return (size_t)tl_invd<RS>() + 4 * 16 * 17;
-}
-inline size_t tiled_lds_bytes(int64_t n) { return sizeof(double) * (n <= 512 ? tiled_lds_doubles<8>() : tiled_lds_doubles<16>()); }
-
+inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }  // pitch of the row-major working copy
 typedef double tl_d4 __attribute__((ext_vector_type(4)));
 typedef double tl_d2 __attribute__((ext_vector_type(2)));
 // The panel and the trailing phase are functions of their own (register allocation); their pointer arguments would be generic, and a FLAT store counts
@@ -114,40 +73,35 @@ __global__ void k_lu_stage_rowmajor(int n, int ldw, int64_t nb, const double* __
 }
 
 // trailing update of one group of RT row tiles over the column tiles tc0, tc0 + tcs, ... of the current chunk.  roffb: byte offsets of the lane's four
-// rows of every tile (32-bit: the loads and stores take the system's base from scalar registers).  LDP: pitch of the U12 chunk in LDS.  PF: the C tiles
-// of the next column tile are loaded while this one is multiplied (one workgroup per CU; with two workgroups per CU the other one hides the loads and the
-// registers are not there).
-template <int RT, int RTMAX, int LDP, bool PF>
+// rows of every tile (32-bit: the loads and stores take the system's base from scalar registers).  LDP: pitch of the U12 chunk in LDS.  PF: how many
+// column tiles ahead the C tiles are loaded while one is multiplied.
+template <int RT, int RTMAX, int LDP, int PF>
 __device__ __forceinline__ void tl_update_tiles(tl_gdouble* __restrict__ W, const double* __restrict__ u12s, const double (&aneg)[RTMAX][16], const unsigned (&roffb)[RTMAX][4],
                                                 unsigned valid, int c_lo, int ntc, int tc0, int tcs, int lane) {
   const int q = lane >> 4, j = lane & 15;
   tl_gchar* const Wb = reinterpret_cast<tl_gchar*>(W);
-  tl_d4 acc[RT], nxt[PF ? RT : 1];
+  tl_d4 acc[RT], nxt[PF >= 1 ? RT : 1], nx2[PF >= 2 ? RT : 1];
   const unsigned colb0 = (unsigned)(c_lo + j) * 8u;
-  if constexpr (PF) {
-    if (tc0 < ntc) {
+  auto load_tiles = [&](tl_d4 (&dst)[RT], int tc) {
 #pragma unroll
-      for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb0 + 128u * (unsigned)tc0));
-    }
-  }
+      for (int r = 0; r < 4; ++r) dst[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb0 + 128u * (unsigned)tc));
+  };
+  if constexpr (PF >= 1) { if (tc0 < ntc) load_tiles(nxt, tc0); }
+  if constexpr (PF >= 2) { if (tc0 + tcs < ntc) load_tiles(nx2, tc0 + tcs); }
   for (int tc = tc0; tc < ntc; tc += tcs) {
     const unsigned colb = colb0 + 128u * (unsigned)tc;
-    if constexpr (PF) {
+    if constexpr (PF >= 2) {  // the C tiles of the next two column tiles are in flight while this one is multiplied
+#pragma unroll
+      for (int t = 0; t < RT; ++t) { acc[t] = nxt[t]; nxt[t] = nx2[t]; }
+      if (tc + 2 * tcs < ntc) load_tiles(nx2, tc + 2 * tcs);
+    } else if constexpr (PF == 1) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = nxt[t];
-      if (tc + tcs < ntc) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) nxt[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb + 128u * (unsigned)tcs));
-      }
+      if (tc + tcs < ntc) load_tiles(nxt, tc + tcs);
     } else {
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (roffb[t][r] + colb));
+      load_tiles(acc, tc);
     }
     const double* ub = u12s + q * LDP + 16 * tc + j;
     double bv[4], bn[4];
@@ -234,20 +188,9 @@ template <> struct tl_colvec<16> { typedef double type __attribute__((ext_vector
 // a register column of the panel: RS rows of one lane.  A VECTOR, so that a wavefront-uniform run-time slot becomes relative register addressing
 // (v_movrels) instead of a switch over the slots — whose joins cost ~60 register moves per step.
 template <int RS> using tl_col = typename tl_colvec<RS>::type;
-// entry `ss` (the same in every lane) of a register column: relative register addressing; in the 128-registers-per-lane layout a tree of three
-// selects on the bits of ss instead — a column that is never indexed at run time is eight independent registers to the allocator, not an aligned block
-// of sixteen, and the blocks are what made the pivot-step loop spill.
+// entry `ss` (the same in every lane) of a register column: relative register addressing
 template <int RS>
-__device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) {
-  if constexpr (RS == 8 && tl_cfg<RS>::kWaves == 4) {
-    const bool b0 = ss & 1, b1 = ss & 2, b2 = ss & 4;
-    const double x0 = b0 ? c[1] : c[0], x1 = b0 ? c[3] : c[2], x2 = b0 ? c[5] : c[4], x3 = b0 ? c[7] : c[6];
-    const double y0 = b1 ? x1 : x0, y1 = b1 ? x3 : x2;
-    return b2 ? y1 : y0;
-  } else {
-    return c[ss];
-  }
-}
+__device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) { return c[ss]; }
 
 constexpr int kTlLaP = 49;                // pitch of L11A in LDS
 constexpr int kTlUs = 2400, kTlUsP = 48;  // offset (doubles) of Us in the dynamic LDS (behind L11A [48][49]) and its pitch (conflict-free operand reads)
@@ -255,606 +198,30 @@ constexpr int kTlUs = 2400, kTlUsP = 48;  // offset (doubles) of Us in the dynam
 #ifdef TL_X_STEPPROF
 __device__ unsigned long long tl_stepprof[8];
 #endif
-// Pivot search of step k by the wavefront that owns its column (register column JC), and everything that has to be published for it: the multipliers
-// (column kk of Lbuf), {lane, slot} of the pivot row, the interchange bookkeeping.  Finished rows need no mask: the pivot row's own "multiplier" is
-// published as 1, so the elimination of its step leaves an exact 0 (u - u * 1) in every column behind it, rows finished in earlier sub-panels and rows
-// beyond n enter the stage as zeros, and a zero is no candidate unless the whole column is zero (the position scan below).
-// Their multipliers in later steps are 0 * (1 / pivot) = 0, so nothing ever changes them again.  The search is a maximum of magnitudes — v_max ignores NaNs, as the sequential scan does.
-// Positions (LDS) are looked at only when they decide: several rows of the largest magnitude, or a column without a positive entry.
-template <int RS>
-__device__ __forceinline__ void tl_co_search(const tl_col<RS>& col, int k, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat, int* s_prow,
-                                             int* s_ipiv, int* s_hdr, int* s_flags, int lane) {
-  constexpr int P = 64 * RS;
-  const int g = cb + k;
-  const int kk = k & (kTlLC - 1);
-  double* const lcol = dyn + kk * P + lane;
-#ifdef TL_X_STEPPROF
-  const unsigned long long ts0_ = __builtin_readcyclecounter();
-#endif
-  const int rg = s_rowat[g];  // the row at the diagonal position (used at the end: its latency hides behind the search)
-  double mt[RS];
-#pragma unroll
-  for (int s = 0; s < RS; ++s) mt[s] = __builtin_fabs(col[s]);
-#pragma unroll
-  for (int w = RS / 2; w >= 1; w >>= 1)
-#pragma unroll
-    for (int s = 0; s < w; ++s) mt[s] = __builtin_fmax(mt[s], mt[s + w]);
-  double m = __builtin_fmax(mt[0], -1.0);  // -1: no number in the column
-  m = tl_dpp_max<kDppQuadXor1>(m);
-  m = tl_dpp_max<kDppQuadXor2>(m);
-  m = tl_dpp_max<kDppRowHalfMirror>(m);
-  m = tl_dpp_max<kDppRowMirror>(m);
-  const double wm = __builtin_fmax(__builtin_fmax(tl_readlane_f64(m, 0), tl_readlane_f64(m, 16)), __builtin_fmax(tl_readlane_f64(m, 32), tl_readlane_f64(m, 48)));
-  unsigned long long M[RS];
-  int cnt = 0;
-#pragma unroll
-  for (int s = 0; s < RS; ++s) { M[s] = __builtin_amdgcn_ballot_w64(__builtin_fabs(col[s]) == wm); cnt += __popcll(M[s]); }
-  int ls = 0, ss = 0;
-  double piv = 0.0;
-  if (cnt == 1 && wm > 0.0) {  // the common case: one row holds the largest magnitude
-#pragma unroll
-    for (int s = 0; s < RS; ++s)
-      if (M[s] != 0ull) { ss = s; ls = __ffsll((long long)M[s]) - 1; piv = tl_readlane_f64(col[s], ls); }
-  } else {
-    // the smallest position among the candidates: the rows of the largest magnitude, or — no number in the column (all NaN) — every row not finished
-    int bp = 0x7fffffff, bs = 0;
-#pragma unroll
-    for (int s = 0; s < RS; ++s) {
-      const int ps = s_pos[lane + 64 * s];
-      const bool c = (ps >= g) & (wm >= 0.0 ? __builtin_fabs(col[s]) == wm : true);
-      const bool take = c & (ps < bp);
-      bp = take ? ps : bp;
-      bs = take ? s : bs;
-    }
-    int q = bp;
-    double dummy = 0.0;
-    tl_argmax_stage<kDppQuadXor1>(dummy, q);
-    tl_argmax_stage<kDppQuadXor2>(dummy, q);
-    tl_argmax_stage<kDppRowHalfMirror>(dummy, q);
-    tl_argmax_stage<kDppRowMirror>(dummy, q);
-    int bq = __builtin_amdgcn_readlane(q, 0);
-#pragma unroll
-    for (int r = 1; r < 4; ++r) { const int oq = __builtin_amdgcn_readlane(q, 16 * r); bq = oq < bq ? oq : bq; }
-    ls = __ffsll((long long)__ballot(bp == bq)) - 1;
-    ss = __builtin_amdgcn_readlane(bs, ls);
-    piv = tl_readlane_f64(tl_slot<RS>(col, ss), ls);
-  }
-  const bool zero = piv == 0.0;
-  const double inv = zero ? 0.0 : div_refined_rcp(piv);  // a zero pivot eliminates nothing (its column is all zeros)
-#pragma unroll
-  for (int s = 0; s < RS; ++s) lcol[64 * s] = col[s] * inv;
-  if (lane == ls) lcol[64 * ss] = 1.0;  // the pivot row itself: its entries behind this column become exact zeros
-  const int rstar = ls + 64 * ss;
-  const int ps = s_pos[rstar];
-  if (lane == 0) {
-    s_hdr[2 * (k & 3)] = ls;
-    s_hdr[2 * (k & 3) + 1] = ss;
-    dyn[tl_ubuf<RS>() + k * (tl_cfg<RS>::kSW + 1) + k] = piv;
-    if (zero) s_flags[0] = 1;
-    s_pos[rstar] = (short)g;  // the row at the diagonal position trades places with the winner
-    if (rg != rstar) { s_pos[rg] = (short)ps; s_rowat[ps] = (short)rg; }
-    s_rowat[g] = (short)rstar;
-    s_prow[pbase + k] = rstar;
-    s_ipiv[pbase + k] = ps;
-  }
-#ifdef TL_X_STEPPROF
-  if (threadIdx.x == 0 && blockIdx.x == 0) { tl_stepprof[4] += __builtin_readcyclecounter() - ts0_; tl_stepprof[5] += 1; }
-#endif
+}  // namespace dsh
+
+// one workgroup of eight wavefronts per CU (n <= 1024)
+#define DSH_TL_LAYOUT8 0
+namespace dsh { namespace tl_one {
+#include "dsh_lu_tiled_impl.hpp"
+} }
+#undef DSH_TL_LAYOUT8
+// two workgroups of four wavefronts per CU, 16-column sub-panels (n <= 512)
+#define DSH_TL_LAYOUT8 1
+namespace dsh { namespace tl_two {
+#include "dsh_lu_tiled_impl.hpp"
+} }
+#undef DSH_TL_LAYOUT8
+
+namespace dsh {
+// Which layout factors a system of n rows: two workgroups per CU pay while the trailing update is the smaller part of the work (measured on 4096 systems,
+// profiles/r04_lu_bench.md: n = 320 9.9 against 11.7 ms, n = 384 14.9 against 15.8, n = 448 20.9 against 20.1, n = 512 29.8 against 27.1).  DSH_LU_TILED_LAYOUT=1|2 forces one.
+inline int tiled_layout(int64_t n) {
+  if (n > 512) return 1;
+  static const int forced = [] { const char* e = getenv("DSH_LU_TILED_LAYOUT"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2) return forced;
+  return n <= 416 ? 2 : 1;
 }
-
-// c -= u l (the elimination of one step in one register column)
-template <int RS>
-__device__ __forceinline__ void tl_co_elim(tl_col<RS>& c, const double (&l)[RS], double u) {
-#pragma unroll
-  for (int s = 0; s < RS; ++s) c[s] = __builtin_fma(-u, l[s], c[s]);
-}
-// Pivot step k = NW JO + wo of the sub-panel at column cb, behind the barrier that published it (NW wavefronts; JO static: register column of its
-// owner; wavefront w holds the sub-panel's columns w, w + NW, ...): every wavefront eliminates in its columns behind k.  The chain that bounds the panel
-// is barrier -> multipliers -> column k + 1 -> search of step k + 1 -> publish -> barrier, so the wavefront that owns column k + 1 (pipe == true) does
-// exactly that and PUTS OFF the elimination of step k in its other columns: it makes up for it behind the next barrier, before step k + 1's (the same
-// multiply-adds in the same order, so every entry sees the operations it would see without the delay).  What it needs then is still there: the
-// multipliers in Lbuf (a column is reused 16 steps later), {lane, slot} of step k's pivot row in s_hdr (four entries deep), and the pivot row's
-// entries in its own registers (a finished row changes only through its own step's elimination).
-template <int RS, int NW, int JO>
-__device__ __forceinline__ void tl_co_step(tl_col<RS> (&a)[tl_cfg<RS>::kSW / NW], int wo, int ws, bool pipe, int cb, int pbase, double* __restrict__ dyn, short* s_pos, short* s_rowat,
-                                           int* s_prow, int* s_ipiv, int* s_hdr, int* s_flags, int wave, int lane) {
-  constexpr int P = 64 * RS, CPW = tl_cfg<RS>::kSW / NW, UP = tl_cfg<RS>::kSW + 1;
-  const int k = NW * JO + wo;
-  const int kk = k & (kTlLC - 1);
-  const double* const lcol = dyn + kk * P + lane;
-  double* const ubuf = dyn + tl_ubuf<RS>() + wave;
-#ifdef TL_X_STEPPROF
-  unsigned long long t0_ = __builtin_readcyclecounter();
-#define TL_T(ix) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x == 0) tl_stepprof[ix] += now_ - t0_; t0_ = now_; }
-#else
-#define TL_T(ix)
-#endif
-  const int ls = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 3)]), ss = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k & 3) + 1]);
-  double l[RS];
-#pragma unroll
-  for (int s = 0; s < RS; ++s) l[s] = lcol[64 * s];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  TL_T(0)
-  // this wavefront owned step k and ran its search at once (see above): step k - 1 is still to be eliminated in its columns behind k
-  if constexpr (JO < CPW - 1) {
-    if (wave == wo && kk != 0) {
-      const int k1 = k - 1;
-      const int ls1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3)]), ss1 = __builtin_amdgcn_readfirstlane(s_hdr[2 * (k1 & 3) + 1]);
-      const double* const l1col = dyn + (k1 & (kTlLC - 1)) * P + lane;
-      double l1[RS];
-#pragma unroll
-      for (int s = 0; s < RS; ++s) l1[s] = l1col[64 * s];
-#pragma unroll
-      for (int j = JO + 1; j < CPW; ++j) {
-        const double u1 = tl_readlane_f64(tl_slot<RS>(a[j], ss1), ls1);
-        if (lane == 0) ubuf[k1 * UP + NW * j] = u1;  // U11 of step k - 1 in this column
-        tl_co_elim<RS>(a[j], l1, u1);
-      }
-    }
-  }
-  TL_T(1)
-  const bool next_owner = pipe && wave == (wo + 1) % NW && k + 1 < ws;
-  if (next_owner) {  // the pivot row's entry in column k + 1 only (the row is finished: out of this wavefront's own registers), that column, the search
-    if (wo == NW - 1) {  // wavefront 0, its next register column
-      if constexpr (JO < CPW - 1) {
-        const double u = tl_readlane_f64(tl_slot<RS>(a[JO + 1], ss), ls);
-        if (lane == 0) ubuf[k * UP + NW * (JO + 1)] = u;
-        tl_co_elim<RS>(a[JO + 1], l, u);
-        tl_co_search<RS>(a[JO + 1], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
-      }
-    } else {
-      const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
-      if (lane == 0) ubuf[k * UP + NW * JO] = u;
-      tl_co_elim<RS>(a[JO], l, u);
-      tl_co_search<RS>(a[JO], k + 1, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
-    }
-  } else {
-    // the pivot row's entries in this wavefront's columns behind k (U11), and the elimination there
-    if (wave > wo) {
-      const double u = tl_readlane_f64(tl_slot<RS>(a[JO], ss), ls);
-      if (lane == 0) ubuf[k * UP + NW * JO] = u;
-      tl_co_elim<RS>(a[JO], l, u);
-    }
-#pragma unroll
-    for (int j = JO + 1; j < CPW; ++j) {
-      const double u = tl_readlane_f64(tl_slot<RS>(a[j], ss), ls);
-      if (lane == 0) ubuf[k * UP + NW * j] = u;
-      tl_co_elim<RS>(a[j], l, u);
-    }
-  }
-  TL_T(2)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // LDS only: never wait for global stores here
-  TL_T(3)
-}
-
-// Multipliers (and, for the rows chosen in this sub-panel, their U entries from their step on) of the steps [k0, k0 + cnt) from LDS to the rows of W.
-template <int RS, int NW>
-__device__ __forceinline__ void tl_flush(tl_gdouble* __restrict__ W, int ldw, int n, int cb, int k0, int cnt, const double* __restrict__ dyn, const short* s_pos, int tid) {
-  constexpr int P = 64 * RS, SW = tl_cfg<RS>::kSW;
-#pragma unroll
-  for (int i = 0; i < RS / NW; ++i) {
-    const int row = tid + 64 * NW * i;
-    const int pr = row < n ? (int)s_pos[row] : -1;
-    if (pr >= cb) {  // the row entered this sub-panel
-      const int kr = pr - cb;  // its own step, if it was chosen here (else >= SW or beyond the steps done)
-      tl_gd2* dst = reinterpret_cast<tl_gd2*>(W + (size_t)row * ldw + cb + k0);
-      for (int c = 0; c < cnt; c += 2) {
-        tl_d2 v;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int k = k0 + c + e;
-          v[e] = k < kr ? dyn[(k & (kTlLC - 1)) * P + row] : dyn[tl_ubuf<RS>() + (kr < SW ? kr : 0) * (SW + 1) + k];
-        }
-        dst[c >> 1] = v;
-      }
-    }
-  }
-}
-
-// Inverse of the unit lower triangular 16 x 16 diagonal block of the 16 steps whose multipliers Lbuf holds (panel steps pb .. pb + 15, diagonal block `blk` of the
-// panel), by the first 16 lanes of one wavefront: lane = column.  The inverses are the A operands of every blocked substitution that follows (the later
-// sub-panels' U', the trailing phase's U12).
-template <int RS>
-__device__ __forceinline__ void tl_invert_diag(double* __restrict__ dyn, const int* s_prow, int pb, int blk, int lane) {
-  constexpr int P = 64 * RS;
-  if (lane < 16) {
-    int rows[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rows[r] = s_prow[pb + r];
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = r == lane ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = 0; i < 15; ++i)
-#pragma unroll
-      for (int r = i + 1; r < 16; ++r) x[r] = __builtin_fma(-dyn[i * P + rows[r]], x[i], x[r]);
-    double* const invd = dyn + tl_invd<RS>() + blk * 272;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) invd[r * 17 + lane] = x[r];
-  }
-}
-
-// The panel of 64 columns at jb (sub-panels of kSW columns).  Not inlined: its registers are allocated apart from the rest of the kernel.
-template <int RS>
-__device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_, int n_, int jb_, double* dyn_, short* s_pos_, short* s_rowat_, int* s_prow_, int* s_ipiv_,
-                                      int* s_hdr_, int* s_flags_, const unsigned short* s_rowlist_, int m_in_, unsigned long long* phase_clocks_) {
-  double* const W_generic = tl_uni(W_generic_);
-  const int ldw = tl_uni(ldw_), n = tl_uni(n_), jb = tl_uni(jb_), m_in = tl_uni(m_in_);
-  double* const dyn = tl_uni(dyn_);
-  short* const s_pos = tl_uni(s_pos_);
-  short* const s_rowat = tl_uni(s_rowat_);
-  int* const s_prow = tl_uni(s_prow_);
-  int* const s_ipiv = tl_uni(s_ipiv_);
-  int* const s_hdr = tl_uni(s_hdr_);
-  int* const s_flags = tl_uni(s_flags_);
-  const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
-  unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
-  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long tprev = prof ? wall_clock64() : 0ull;
-  auto mark = [&](int phase) {
-    if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
-  };
-  constexpr int NW = tl_cfg<RS>::kWaves, NT = 64 * NW, SW = tl_cfg<RS>::kSW, CPW = SW / NW;
-  constexpr int R = RS / NW;       // rows per thread in the staging layout (thread t: rows t, t + NT, ...)
-  constexpr int P = 64 * RS;       // rows of a column in LDS
-  constexpr int NH = SW / kTlLC;   // the sub-panel's columns pass through LDS 16 at a time
-  constexpr int HC = kTlLC;
-  constexpr int NCT = SW / 16;     // column tiles of a sub-panel
-  constexpr int MAXD = (kTlPW - SW) / 16;  // diagonal blocks in front of the last sub-panel
-  tl_gdouble* const W = (tl_gdouble*)W_generic;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* const Us = dyn + kTlUs;  // [<= 48][kTlUsP]: dead before the stage writes T over it
-  const double* const invd = dyn + tl_invd<RS>();
-#pragma nounroll
-  for (int sp = 0; sp < kTlPW / SW; ++sp) {
-    const int cb = jb + SW * sp;
-    const int ws = (n - cb) < SW ? (n - cb) : SW;
-    if (ws <= 0) break;
-    if (sp > 0) {
-      // ---- the columns cb..cb+SW-1 take the D = SW sp eliminations of the panel's earlier sub-panels, on the matrix cores (LDS broadcast reads made the
-      // vector form of this 50 us per panel): the blocks of L11A below its diagonal blocks to LDS (the inverses of the diagonal blocks are there since
-      // their sub-panels finished), U' = L11A^-1 B for the pivot rows (blocked substitution, one column tile per wavefront), then B -= L_A U' for the
-      // rows that entered the panel (the row list of the previous panel; rows finished since are not stored).
-      const int D = SW * sp, nd = D / 16;
-      double* const la = dyn;         // [D][kTlLaP]
-      const int q = lane >> 4, j = lane & 15;
-      for (int idx = tid; idx < D * D; idx += NT) {
-        const int k = idx / D, i = idx - k * D;
-        if (i < (k & ~15)) la[k * kTlLaP + i] = W[(size_t)s_prow[k] * ldw + jb + i];
-      }
-      __syncthreads();
-      if (wave < NCT) {
-        const int c0 = 16 * wave;
-        tl_d4 B[MAXD], X[MAXD];
-#pragma unroll
-        for (int rb = 0; rb < MAXD; ++rb)
-          if (rb < nd) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j];
-          }
-#pragma unroll
-        for (int rb = 0; rb < MAXD; ++rb)
-          if (rb < nd) {
-#pragma unroll
-            for (int cbk = 0; cbk < rb; ++cbk)
-#pragma unroll
-              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 * rb + j) * kTlLaP + 16 * cbk + 4 * kb + q], X[cbk][kb], B[rb], 0, 0, 0);
-            tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(invd[rb * 272 + j * 17 + 4 * kb + q], B[rb][kb], acc, 0, 0, 0);
-            X[rb] = acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              Us[(16 * rb + 4 * r + q) * kTlUsP + c0 + j] = acc[r];
-              W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j] = acc[r];
-            }
-          }
-      }
-      __syncthreads();
-      const int nrt = (m_in + 15) / 16;
-      for (int tile = wave; tile < nrt; tile += NW) {
-        double aneg[4 * MAXD];
-        const size_t arow = (size_t)s_rowlist[16 * tile + j] * ldw;
-#pragma unroll
-        for (int kb = 0; kb < 4 * MAXD; ++kb) aneg[kb] = kb < 4 * nd ? -W[arow + jb + 4 * kb + q] : 0.0;
-        size_t ro[4];
-        bool ok[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = s_rowlist[16 * tile + 4 * r + q];
-          ro[r] = (size_t)row * ldw + cb + j;
-          ok[r] = 16 * tile + 4 * r + q < m_in && s_pos[row] >= cb;
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          tl_d4 acc;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = W[ro[r] + 16 * ct];
-#pragma unroll
-          for (int kb = 0; kb < 4 * MAXD; ++kb)
-            if (kb < 4 * nd) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aneg[kb], Us[(4 * kb + q) * kTlUsP + 16 * ct + j], acc, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (ok[r]) W[ro[r] + 16 * ct] = acc[r];
-        }
-      }
-      __syncthreads();
-    }
-    mark(4);
-    // ---- stage: thread per row in (the second sub-panel's rows take the 32 eliminations of the first on the way: row -= L_row U'), column per wavefront out
-    tl_col<RS> a[CPW];
-    {
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {  // HC columns of one row at a time (registers); finished rows and rows beyond n enter as zeros
-          const int row = tid + NT * i;
-          const bool live = row < n && s_pos[row] >= cb;
-          double b[HC];
-          if (live) {
-            const tl_gd2* src = reinterpret_cast<const tl_gd2*>(W + (size_t)row * ldw + cb + HC * h);
-#pragma unroll
-            for (int c = 0; c < HC; c += 2) { const tl_d2 v = src[c >> 1]; b[c] = v[0]; b[c + 1] = v[1]; }
-          }
-#pragma unroll
-          for (int c = 0; c < HC; ++c) dyn[c * P + row] = live ? b[c] : 0.0;
-        }
-        __syncthreads();
-        mark(9);
-#pragma unroll
-        for (int jj = 0; jj < CPW / NH; ++jj)
-#pragma unroll
-          for (int s = 0; s < RS; ++s) a[(CPW / NH) * h + jj][s] = dyn[(wave + NW * jj) * P + lane + 64 * s];
-        __syncthreads();
-        mark(10);
-      }
-    }
-    mark(5);
-    // ---- the pivot steps
-    const int pbase = SW * sp;
-#define TL_STEPS(JO)                                                                                                                        \
-  if constexpr (JO < CPW) {                                                                                                                 \
-    _Pragma("nounroll") for (int wo = 0; wo < NW; ++wo) {                                                                                   \
-      if (NW * JO + wo >= ws) break;                                                                                                        \
-      const bool pipe = NW * JO + wo != kTlLC - 1; /* the next column of Lbuf is free only behind the flush */                              \
-      tl_co_step<RS, NW, JO>(a, wo, ws, pipe, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, wave, lane);                  \
-    }                                                                                                                                       \
-    if (SW > kTlLC && JO == kTlLC / NW - 1 && ws > kTlLC) {                                                                                 \
-      __syncthreads();                                                                                                                      \
-      tl_flush<RS, NW>(W, ldw, n, cb, 0, kTlLC, dyn, s_pos, tid);                                                                           \
-      if (wave == 1) tl_invert_diag<RS>(dyn, s_prow, pbase, pbase / 16, lane);                                                              \
-      __syncthreads();                                                                                                                      \
-      if (wave == 0) tl_co_search<RS>(a[kTlLC / NW < CPW ? kTlLC / NW : 0], kTlLC, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane); \
-      __syncthreads();                                                                                                                      \
-    }                                                                                                                                       \
-  }
-    if (wave == 0) tl_co_search<RS>(a[0], 0, cb, pbase, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, lane);
-    __syncthreads();
-    TL_STEPS(0) TL_STEPS(1) TL_STEPS(2) TL_STEPS(3) TL_STEPS(4) TL_STEPS(5) TL_STEPS(6) TL_STEPS(7)
-#undef TL_STEPS
-    __syncthreads();
-    mark(6);
-    const int f0 = ws <= kTlLC ? 0 : kTlLC;  // the steps whose multipliers Lbuf holds now
-    tl_flush<RS, NW>(W, ldw, n, cb, f0, ((ws + 1) & ~1) - f0, dyn, s_pos, tid);
-    if (wave == 1 && ws - f0 == 16) tl_invert_diag<RS>(dyn, s_prow, pbase + f0, (pbase + f0) / 16, lane);
-    __syncthreads();
-    mark(7);
-  }
-}
-
-// Everything behind a finished 64-column panel: U12 and the update of the active rows, a chunk of <= kCH trailing columns at a time.  A function of its own
-// (not inlined) so that its registers — the L21 operand of kRT row tiles stays in them across the chunks — are allocated apart from the panel's.
-template <int RS>
-__device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double* __restrict__ F_generic_, double* dyn_, const int* s_prow_, const unsigned short* s_rowlist_,
-                                         unsigned long long* phase_clocks_, int n_, int ldw_, int jb_, int nct_, int m2_) {
-  using C = tl_cfg<RS>;
-  double* const W_generic = tl_uni(W_generic_);
-  double* const F_generic = tl_uni(F_generic_);
-  double* const dyn = tl_uni(dyn_);
-  const int* const s_prow = tl_uni(s_prow_);
-  const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
-  unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
-  const int n = tl_uni(n_), ldw = tl_uni(ldw_), jb = tl_uni(jb_), nct = tl_uni(nct_), m2 = tl_uni(m2_);
-  constexpr int LDP = C::kLDP, CH = C::kCH, RTM = C::kRT, NW = C::kWaves;
-  constexpr bool PF = true;
-  tl_gdouble* const W = (tl_gdouble*)W_generic;
-  tl_gdouble* const F = (tl_gdouble*)F_generic;
-  double* const u12s = dyn;
-  const double* const l11 = dyn + 64 * LDP;        // rows 16..63, columns 0..47 of L11, pitch kTlL11P
-  const double* const invd = dyn + tl_invd<RS>();  // the inverses of the panel's four diagonal blocks (tl_invert_diag)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long tprev = prof ? wall_clock64() : 0ull;
-  auto mark = [&](int phase) {
-    if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
-  };
-  const int q = lane >> 4, j = lane & 15;
-  // decomposition of the update: groups of rtw row tiles; with fewer groups than wavefronts the column tiles are split as well
-  const int nrt = (m2 + 15) / 16;
-  const int rtw = (nrt + NW - 1) / NW < RTM ? (nrt + NW - 1) / NW : RTM;
-  const int groups = (nrt + rtw - 1) / rtw;
-  const int csplit = groups >= NW ? 1 : NW / groups;
-  const bool fixed_group = groups <= NW;
-  double aneg[RTM][16];
-  unsigned roffb[RTM][4];
-  unsigned valid = 0;
-  int loaded_group = -1;
-  for (int c_lo = jb + kTlPW; c_lo < nct; c_lo += CH) {
-    const int cw = (nct - c_lo) < CH ? (nct - c_lo) : CH;
-    const int ntc = cw / 16;
-    // ---- U12 of the chunk: blocked substitution on the matrix cores, one column tile per wavefront at a time
-    {
-      // the A operands (inverses of the diagonal blocks, negated blocks below them) come from LDS as they are needed: holding all 40 of them next
-      // to the L21 operand of the update, which stays in registers across the chunks, does not fit in the registers
-      const double* const dinv_l = invd + j * 17 + q;            // block b, k-block kb: + b * 272 + 4 kb
-      const double* const l11_l = l11 + j * kTlL11P + q;         // block (rb, cbk), rb >= 1, k-block kb: + 16 (rb - 1) * pitch + 16 cbk + 4 kb
-      for (int tc = wave; tc < ntc; tc += NW) {
-        const int c0 = c_lo + 16 * tc;
-        tl_d4 B[4], X[4];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)(s_prow[16 * rb + 4 * r + q] * ldw) + c0 + j];
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-          for (int cbk = 0; cbk < rb; ++cbk) {
-            double lo[4];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) lo[kb] = -l11_l[16 * (rb - 1) * kTlL11P + 16 * cbk + 4 * kb];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[kb], X[cbk][kb], B[rb], 0, 0, 0);
-          }
-          double di[4];
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) di[kb] = dinv_l[rb * 272 + 4 * kb];
-          tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(di[kb], B[rb][kb], acc, 0, 0, 0);
-          X[rb] = acc;
-        }
-        const bool incol = c0 + j < n;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            u12s[(16 * rb + 4 * r + q) * LDP + 16 * tc + j] = X[rb][r];
-            if (incol) F[(size_t)(c0 + j) * n + jb + 16 * rb + 4 * r + q] = X[rb][r];
-          }
-      }
-    }
-    __syncthreads();
-    mark(2);
-    // ---- A22 -= L21 U12 for the chunk's columns
-    for (int grp = fixed_group ? wave % groups : wave; grp < groups; grp += NW) {
-      const int csub = fixed_group ? wave / groups : 0;
-      if (csub >= csplit) break;
-      if (grp != loaded_group) {
-        loaded_group = grp;
-        valid = 0;
-#pragma unroll
-        for (int t = 0; t < RTM; ++t) {
-          const int tile = grp * rtw + t;
-          const bool tv = t < rtw && tile < nrt;
-          const int arow = tv ? (int)s_rowlist[16 * tile + j] * ldw : 0;
-#pragma unroll
-          for (int kb = 0; kb < 16; ++kb) aneg[t][kb] = tv ? -W[(size_t)arow + jb + 4 * kb + q] : 0.0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            roffb[t][r] = tv ? (unsigned)s_rowlist[16 * tile + 4 * r + q] * (unsigned)ldw * 8u : 0u;
-            if (tv && 16 * tile + 4 * r + q < m2) valid |= 1u << (4 * t + r);
-          }
-        }
-      }
-      const int ngt = (nrt - grp * rtw) < rtw ? (nrt - grp * rtw) : rtw;  // row tiles of this group
-      if constexpr (RTM == 4) {
-        switch (ngt) {
-          case 1: tl_update_tiles<1, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          case 2: tl_update_tiles<2, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          case 3: tl_update_tiles<3, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-          default: tl_update_tiles<4, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane); break;
-        }
-      } else {
-        if (ngt == 1) tl_update_tiles<1, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane);
-        else tl_update_tiles<2, RTM, LDP, PF>(W, u12s, aneg, roffb, valid, c_lo, ntc, csub, csplit, lane);
-      }
-      if (fixed_group) break;
-    }
-    __syncthreads();
-    mark(3);
-  }
-}
-
-// RS = rows per lane of the panel's register layout: 8 for n <= 512 (two workgroups per CU), 16 for n <= 1024
-template <int RS>
-__global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
-                                                                 unsigned long long* singular_word, unsigned int epoch, unsigned long long* phase_clocks) {
-  using C = tl_cfg<RS>;
-  constexpr int NW = C::kWaves, NT = 64 * NW;
-  constexpr int R = RS / NW;
-  constexpr int MAXN = C::kMaxN;
-  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-  unsigned long long tprev = prof ? wall_clock64() : 0ull;
-  auto mark = [&](int phase) {
-    if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[phase] += now - tprev; tprev = now; }
-  };
-  extern __shared__ double dyn[];                // see tiled_lds_doubles
-  double* const l11 = dyn + 64 * C::kLDP;
-  __shared__ short s_pos[MAXN], s_rowat[MAXN];  // position of every row under the reference's interchanges (-1: no such row) and its inverse
-  __shared__ int s_prow[kTlPW], s_ipiv[kTlPW];        // the panel's pivot rows (row indices) and recorded pivots (positions)
-  __shared__ unsigned short s_rowlist[MAXN + 16];
-  __shared__ int s_wcnt[R][NW];
-  __shared__ int s_hdr[8], s_flags[1];
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* const W = w_all + (size_t)blockIdx.x * n * ldw;
-  double* const F = f_all + (size_t)blockIdx.x * n * n;
-  int32_t* const PIV = piv_all + (size_t)blockIdx.x * n;
-  for (int r = tid; r < MAXN; r += NT) { s_pos[r] = (short)(r < n ? r : -1); s_rowat[r] = (short)r; }
-  for (int r = tid; r < n + 16; r += NT) s_rowlist[r] = (unsigned short)(r < n ? r : n - 1);  // rows entering the first panel (padded: whole tiles)
-  int m_act = n;
-  if (tid == 0) s_flags[0] = 0;
-  __syncthreads();
-  const int nct = (n + 15) / 16 * 16;  // columns processed by the tile phases (the padding up to it stays isolated in its own columns)
-
-  for (int jb = 0; jb < n; jb += kTlPW) {
-    const int pw = (n - jb) < kTlPW ? (n - jb) : kTlPW;
-    // =========================================================== panel: sub-panels of kSW columns in registers
-    tl_panel<RS>(W, ldw, n, jb, dyn, s_pos, s_rowat, s_prow, s_ipiv, s_hdr, s_flags, s_rowlist, m_act, phase_clocks);
-    mark(0);
-    // =========================================================== the 64 finished rows -> F; list of the rows still active; L11
-    int m2 = 0;
-    {
-      bool act[R];
-      unsigned long long bal[R];
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const int row = tid + NT * i;
-        act[i] = row < n && s_pos[row] >= jb + pw;
-        bal[i] = __ballot(act[i]);
-        if (lane == 0) s_wcnt[i][wave] = __popcll(bal[i]);
-      }
-      __syncthreads();
-      int base = 0;
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) { const int cnt = s_wcnt[i][w2]; total += cnt; if (w2 < wave) before += cnt; }
-        if (act[i]) s_rowlist[base + before + __popcll(bal[i] & ((1ull << lane) - 1ull))] = (unsigned short)(tid + NT * i);
-        base += total;
-      }
-      m2 = base;
-    }
-    m_act = m2;
-    const int mc = nct - jb - kTlPW;  // trailing columns (exist only behind a full panel)
-    const bool trailing = pw == kTlPW && mc > 0 && m2 > 0;
-    if (trailing) {
-      // the blocks of L11 below its diagonal blocks (rows 16..63, columns 0..47); the inverses of the diagonal blocks are in LDS already (tl_invert_diag)
-      for (int idx = tid; idx < 48 * 48; idx += NT) {
-        const int k = 16 + idx / 48, i = idx % 48;
-        l11[(k - 16) * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
-      }
-    }
-    for (int c = tid; c < jb + pw; c += NT) {
-      double* const dst = F + (size_t)c * n + jb;
-      for (int k0 = 0; k0 < pw; k0 += 16) {
-        double v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = (k0 + k < pw) ? W[(size_t)s_prow[k0 + k] * ldw + c] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) if (k0 + k < pw) dst[k0 + k] = v[k];
-      }
-    }
-    if (tid < pw) PIV[jb + tid] = s_ipiv[tid];
-    __syncthreads();
-    if (m2 > 0 && tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
-    if (!trailing) { mark(1); continue; }
-    __syncthreads();
-    mark(1);
-    tl_trailing<RS>(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
-    if (prof) tprev = wall_clock64();
-  }
-  if (tid == 0 && s_flags[0] != 0) publish_singular(singular_word, 1ull, epoch);
-}
-
+inline int tiled_threads(int64_t n) { return n > 512 ? tl_one::tiled_threads(n) : (tiled_layout(n) == 2 ? tl_two::tiled_threads(n) : tl_one::tiled_threads(n)); }
+inline size_t tiled_lds_bytes(int64_t n) { return n > 512 ? tl_one::tiled_lds_bytes(n) : (tiled_layout(n) == 2 ? tl_two::tiled_lds_bytes(n) : tl_one::tiled_lds_bytes(n)); }
 }  // namespace dsh

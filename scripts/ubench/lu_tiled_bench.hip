@@ -64,12 +64,13 @@ int main(int argc, char** argv) {
   CK(hipMemset(d_f, 0xff, sizeof(double) * (size_t)n * n * nb));
   CK(hipMemcpy(d_a, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice));
   const size_t lds = dsh::tiled_lds_bytes(n);
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(512)));
-  CK(hipFuncSetAttribute((const void*)dsh::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tiled_lds_bytes(1024)));
-  { int occ8 = 0, occ16 = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, (const void*)dsh::k_lu_factor_tiled<8>, dsh::tiled_threads(512), dsh::tiled_lds_bytes(512)));
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, (const void*)dsh::k_lu_factor_tiled<16>, dsh::tiled_threads(1024), dsh::tiled_lds_bytes(1024)));
-    printf("workgroups per CU: %d (n <= 512, %zu B of dynamic LDS), %d (n <= 1024, %zu B)\n", occ8, dsh::tiled_lds_bytes(512), occ16, dsh::tiled_lds_bytes(1024)); }
+  CK(hipFuncSetAttribute((const void*)dsh::tl_one::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tl_one::tiled_lds_bytes(512)));
+  CK(hipFuncSetAttribute((const void*)dsh::tl_one::k_lu_factor_tiled<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tl_one::tiled_lds_bytes(1024)));
+  CK(hipFuncSetAttribute((const void*)dsh::tl_two::k_lu_factor_tiled<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsh::tl_two::tiled_lds_bytes(512)));
+  { int occ = 0;
+    const void* kf = n > 512 ? (const void*)dsh::tl_one::k_lu_factor_tiled<16> : (dsh::tiled_layout(n) == 2 ? (const void*)dsh::tl_two::k_lu_factor_tiled<8> : (const void*)dsh::tl_one::k_lu_factor_tiled<8>);
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, dsh::tiled_threads(n), lds));
+    printf("layout %d: %d threads, %zu B of dynamic LDS, %d workgroups per CU\n", dsh::tiled_layout(n), dsh::tiled_threads(n), lds, occ); }
   hipEvent_t e0, e1, e2;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   float best_stage = 1e30f, best_factor = 1e30f;
@@ -79,8 +80,9 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL(dsh::k_lu_stage_rowmajor, sg, dim3(256), 0, 0, n, ldw, nb, (const double*)d_a, d_w);
     CK(hipEventRecord(e1));
-    if (n <= 512) hipLaunchKernelGGL((dsh::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
-    else hipLaunchKernelGGL((dsh::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    if (n > 512) hipLaunchKernelGGL((dsh::tl_one::k_lu_factor_tiled<16>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    else if (dsh::tiled_layout(n) == 2) hipLaunchKernelGGL((dsh::tl_two::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
+    else hipLaunchKernelGGL((dsh::tl_one::k_lu_factor_tiled<8>), dim3((unsigned)nb), dim3(dsh::tiled_threads(n)), lds, 0, n, ldw, d_w, d_f, d_p, d_sing, 1u, clk);
     CK(hipEventRecord(e2));
     CK(hipGetLastError());
     CK(hipEventSynchronize(e2));
