@@ -801,6 +801,12 @@ def main():
                 if f64:  # issue-slot utilisation: an FP64 VALU instruction occupies the SIMD for 4 cycles, any other for 2
                     roof["fp64_wave_instructions_per_launch"] = f64
                     roof["issue_slot_frac"] = (4 * f64 + 2 * (valu - f64)) / (SIMD_CYCLES_PER_S * avg_s)
+                    # the headline fraction is the issue-slot one (the honest one for a kernel whose VALU stream is mixed FP64 / other); the lane-operation
+                    # rate against the FP64 VALU peak stays next to it
+                    roof["lane_ops"] = {"achieved": roof["achieved"], "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": roof["frac"]}
+                    roof.update({"bound": "valu-issue", "achieved": (4 * f64 + 2 * (valu - f64)) / avg_s / 1e12, "peak": SIMD_CYCLES_PER_S / 1e12, "unit": "T issue-cycles/s (all SIMDs)",
+                                 "frac": roof["issue_slot_frac"],
+                                 "frac_definition": "VALU issue cycles of the launch (4 per FP64 wave-instruction, 2 per other VALU wave-instruction, from the committed counters) / (1024 SIMDs x clock x launch time)"})
                     roof["fp64_flop_per_launch"] = pmc.get("f64_flop_per_launch")
                     if pmc.get("f64_flop_per_launch"):
                         roof["fp64_tflops"] = pmc["f64_flop_per_launch"] / avg_s / 1e12

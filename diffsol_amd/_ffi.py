@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_DIR = os.path.join(_HERE, "lib")
+_LIB_DIR = os.environ.get("DSH_LIB_DIR") or os.path.join(_HERE, "lib")  # DSH_LIB_DIR: another build of both libraries (occupancy experiments, scripts/occupancy_experiment.sh)
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)

@@ -48,6 +48,11 @@ __device__ __forceinline__ void guarded(bool c, F&& f) {
 #ifndef DSH_ADAPTIVE_WAVES_PER_EU
 #define DSH_ADAPTIVE_WAVES_PER_EU 2
 #endif
+// occupancy experiment (profiles/r04_headline_occupancy.md): D's swap partner in per-lane memory instead of LDS (12 of the 19 KB a wavefront of the Robertson
+// kernel holds), so that LDS allows more than two wavefronts per SIMD when DSH_ADAPTIVE_WAVES_PER_EU asks for them
+#ifndef DSH_ADAPTIVE_DT_PRIVATE
+#define DSH_ADAPTIVE_DT_PRIVATE 0
+#endif
 // FAST (opt-in, dsh_adaptive_options::deterministic_pow == 2; instantiated only in dsh_adaptive_fast.hip, which is compiled with -ffp-contract=fast and
 // reciprocal-math division): ocml's pow, fused multiply-adds, the Newton norm's weights as reciprocals computed once per solve.  NOT bit-comparable with the
 // oracle: held to 1e-6 relative on the states at tight tolerances (tests/test_gpu_adaptive.py).
@@ -99,8 +104,9 @@ DSH_UNROLL_N
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
   // hybrid models (a reset operator: OdeEquations::reset, DiffSL reset_i) apply the reset at every event and go on, as the reference's solve_dense does
   constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && !BANDED && Mdl::NROOTS > 0;
+  constexpr bool DTP = BANDED || DSH_ADAPTIVE_DT_PRIVATE != 0;  // the swap partner of D in per-lane memory
   constexpr int LN = BANDED ? 1 : N;
-  __shared__ double sDt[kNC * LN][64];
+  __shared__ double sDt[DTP ? 1 : kNC * LN][64];
   __shared__ double sJ[LN * LN][64];
   const int ln = threadIdx.x;
   // Bdf::_new tables in LDS: every lookup is indexed by the current order and sits in the serial chain of the step (h alpha_order, the error
@@ -110,10 +116,10 @@ DSH_UNROLL_N
   if (ln < 6) { sAlpha[ln] = C.alpha[ln]; sGamma[ln] = C.gamma[ln]; sEc2[ln] = C.ec2[ln]; }
   for (int k = ln; k < kMaxOrder * 36; k += 64) sU[k] = C.u[k / 36][k % 36];
   __syncthreads();
-  double Dt_p[BANDED ? kNC : 1][BANDED ? N : 1];
+  double Dt_p[DTP ? kNC : 1][DTP ? N : 1];
   double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
-  auto dt_get = [&](int j, int i) __attribute__((always_inline)) -> double { if constexpr (BANDED) return Dt_p[j][i]; else return sDt[j * N + i][ln]; };
-  auto dt_set = [&](int j, int i, double v) __attribute__((always_inline)) { if constexpr (BANDED) Dt_p[j][i] = v; else sDt[j * N + i][ln] = v; };
+  auto dt_get = [&](int j, int i) __attribute__((always_inline)) -> double { if constexpr (DTP) return Dt_p[j][i]; else return sDt[j * N + i][ln]; };
+  auto dt_set = [&](int j, int i, double v) __attribute__((always_inline)) { if constexpr (DTP) Dt_p[j][i] = v; else sDt[j * N + i][ln] = v; };
   double D[kNC][N];
 #pragma unroll
   for (int j = 0; j < kNC; ++j)
