@@ -163,6 +163,8 @@ DEVICE_ABI = {
     "dsh_model_has_adaptive_reset": (cint, [cint, i64]),
     "dsh_sdirk_solve_resident_sens": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive_sens": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
+    "dsh_model_has_adaptive_steps": (cint, [cint, i64]),
+    "dsh_bdf_solve_adaptive_steps": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, dbl, i64, vp, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
     "dsh_bdf_accept_newton_async": (cint, [vp, cint, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, dbl, dbl, cint, vp, vp, vp, c_i64p, c_i64p]),
@@ -222,6 +224,7 @@ HOST_ABI = {
     "dshs_diffsl_set_model_index": (cint, [cint]),
     "dshs_solve_dense_adaptive_sens": (cint, [vp, c_dp, i64, cint, cint, c_dp, c_dp, c_i32p, c_i32p, c_i64p]),
     "dshs_solve_dense_adaptive": (cint, [vp, c_dp, i64, cint, cint, c_dp, vp, c_i32p, c_i32p, c_dp, c_i32p, c_i32p, c_i64p]),
+    "dshs_solve_adaptive": (cint, [vp, dbl, i64, cint, cint, c_dp, c_dp, c_i32p, c_i32p, c_i32p, c_dp, c_i32p, c_i64p]),
 }
 
 _dev = None

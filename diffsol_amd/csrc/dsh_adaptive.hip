@@ -118,9 +118,10 @@ template <class Mdl> constexpr bool adaptive_sens_ok() {
   if constexpr (model_has_sens<Mdl>::value) return Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS == 0 && model_band_k<Mdl>::value == 0;
   else return false;
 }
+struct StepsSpec { double* t_out; int64_t cap; };  // OdeSolverMethod::solve: every accepted step out (AdaptiveConsts::steps_cap)
 int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                             double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
-                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens);
+                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens, const StepsSpec* steps = nullptr);
 }  // namespace
 extern "C" {
 // hybrid models whose events are handled INSIDE dsh_bdf_solve_adaptive (move back to the root, apply the reset, restart at first order, go on to the last save
@@ -165,11 +166,28 @@ int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t n
   const SensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
   return bdf_solve_adaptive_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, nullptr, nullptr, nullptr, totals_host, &sp);
 }
+// OdeSolverMethod::solve (method.rs:227-258 over :881-961) inside the launch: the register-resident kernels only (static models, built-in or run-time-compiled)
+int dsh_model_has_adaptive_steps(int model, int64_t size) {
+  if (!dsh_model_has_adaptive(model, size)) return 0;
+  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && ji->form == DSH_JIT_FORM_STATIC ? 1 : 0; }
+  return 1;
+}
+int dsh_bdf_solve_adaptive_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                 double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                 int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_bdf_solve_adaptive_steps: max_cols >= 2, y_out, t_out and ncols are needed");
+  if (!dsh_model_has_adaptive_steps(model, size)) {
+    set_error("dsh_bdf_solve_adaptive_steps: the model has no register-resident BDF (static model, n <= 4; the lane-per-member banded form and the wavefront / workgroup forms write save points only)");
+    return DSH_E_UNSUPPORTED;
+  }
+  const StepsSpec st{t_out, max_cols};
+  return bdf_solve_adaptive_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
+}
 }  // extern "C"
 namespace {
 int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                             double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
-                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens) {
+                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SensSpec* sens, const StepsSpec* steps) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
@@ -184,6 +202,7 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
   if (C.r.o.max_steps <= 0) C.r.o.max_steps = 10000000;
   DSH_REQUIRE(C.r.o.group == 1 || C.r.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
+  if (steps) { C.steps_t_out = steps->t_out; C.steps_cap = (int)steps->cap; }
   if (sens) {
     C.sens_out = sens->out; C.sens_rtol = sens->rtol; C.sens_error_control = sens->natol > 0 ? 1 : 0;
     int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;
@@ -268,7 +287,7 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   // DSH_REBIN_STEPS=k: a segment ends for a member after k trips of its step loop instead (all wavefronts of a segment then do the same number of trips: no
   // waiting for the slowest member of a segment); the host launches segments until no member is left, then one launch that only writes the results.
   const int rebin_steps = [] { const char* e = std::getenv("DSH_REBIN_STEPS"); return e && *e ? std::atoi(e) : 0; }();
-  if (!sens && (rebin_steps > 0 || (rebin > 0 && n_eval > rebin)) && !is_jit_model(model) && C.r.o.group == 1 && nb >= 128) {
+  if (!sens && !steps && (rebin_steps > 0 || (rebin > 0 && n_eval > rebin)) && !is_jit_model(model) && C.r.o.group == 1 && nb >= 128) {
     double* seg_dbl = nullptr; int* seg_int = nullptr; unsigned long long *keys = nullptr, *keys_out = nullptr; int *idx_iota = nullptr, *lane_member = nullptr; void* cub_tmp = nullptr;
     AdaptiveConsts* seg_consts = nullptr; unsigned int* remaining = nullptr;
     size_t cub_bytes = 0;

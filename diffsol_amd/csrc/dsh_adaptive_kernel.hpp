@@ -28,6 +28,11 @@ struct AdaptiveConsts {
   double* sens_out;
   double sens_rtol, sens_atol[4];
   int sens_error_control, sens_pad;
+  // OdeSolverMethod::solve (method.rs:227-258 over :881-961): steps_cap > 0 makes the kernel write the state after EVERY accepted step instead of interpolating at
+  // save points — column 0 = (t0, y0), then one column per internal step, the last one at the stop time t_eval[0] (or at a member's event) — into
+  // y_out [steps_cap][N][nb] and steps_t_out [steps_cap][nb]; ncols_out = the columns the member produced (columns beyond steps_cap are counted, not stored).
+  double* steps_t_out;
+  int steps_cap, steps_pad;
 };
 constexpr int kSegDbl = 128, kSegInt = 32;  // slots per member (upper bounds for n <= 4)
 
@@ -464,6 +469,16 @@ DSH_UNROLL_N
 
   int col = 0;
   double te_next = t_eval[0];  // t_eval[col], kept in a register: it is compared after every step
+  const bool steps_mode = !SEG && !SENS && C.steps_cap > 0;  // every accepted step out (see AdaptiveConsts::steps_cap)
+  auto steps_write = [&](double tw, const double (&yw)[N]) __attribute__((always_inline)) {
+    if (col < C.steps_cap && active) {
+      C.steps_t_out[(int64_t)col * nb + b] = tw;
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = yw[i];
+    }
+    col++;
+  };
+  if (steps_mode && fresh) steps_write(t, y);  // write_out before the first step (method.rs:900)
   // solve_dense (method.rs:467-520): t_eval[0] >= t0 is checked on the host; set_stop_time(t_eval.last())
   if (fresh) {
     const int r = handle_tstop();
@@ -889,6 +904,9 @@ DSH_UNROLL_N
     if (reason == 2) reason = 0;  // the reference unwraps / ignores this inside step()
     // ================================================================ solve_dense (method.rs:467-520): interpolated output
     const double upto = reason == 3 ? t_root : t;
+    if (steps_mode) {  // OdeSolverMethod::solve: InternalTimestep / TstopReached -> write_out (method.rs:907-921); a root is written below, at the root
+      if (reason != 3) steps_write(t, y);  // state.y (the converged Newton iterate), not D[0] (the same value summed in another order)
+    } else
     while (col < C.r.n_eval && te_next <= upto) {
       double yv[N];
       interpolate(te_next, yv);
@@ -928,6 +946,7 @@ DSH_UNROLL_N
 DSH_UNROLL_N
         for (int i = 0; i < N; ++i) y[i] = yr[i];
         Mdl::rhs(t, y, p, dyr);
+        if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {
           has_tstop = true;  // set_stop_time (bdf.rs:1591-1600): on the OLD differences and order, like the reference (the step size may change here)
           { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
@@ -950,6 +969,12 @@ DSH_UNROLL_N
         }
       }
     }
+    if (reason == 3 && steps_mode) {  // method.rs:922-947 without a reset: state_mut_back(t_root), write_out, RootFound
+      double yv[N];
+      interpolate(t_root, yv);
+      steps_write(t_root, yv);
+      done = true;
+    } else
     if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
       if (col < C.r.n_eval) {
         double yv[N];
@@ -988,6 +1013,7 @@ DSH_UNROLL_N
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
     // columns that were never reached (root stop or error exit): NaN
+    if (!steps_mode)
     for (; col < C.r.n_eval; ++col) {
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");

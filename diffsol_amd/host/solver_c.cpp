@@ -226,22 +226,8 @@ bool prepare_member_order(dshs_solver* s) {
   return true;
 }
 
-// lazy: status_host is fetched only when a member failed (totals[5] != 0; it is all zero otherwise) and root_idx_host only for models with root
-// functions (all -1 otherwise): the common case of dshs_solve_dense then moves no per-member bookkeeping over PCIe at all.
-void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
-                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals, bool lazy = false, double* sens_host = nullptr) {
-  const ResidentPick pk = pick_resident(s, group);
-  if (s->problem.sens && (!pk.ok || !sens_host))
-    throw LaError(DSH_E_UNSUPPORTED, "device-resident integration with forward sensitivities: dshs_solve_dense_adaptive_sens, BDF, static ODE models with parameter "
-                                     "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
-  if (!pk.ok)
-    throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
-                                     "run-time-sized ODE models with n <= 140: BDF)");
-  const int model = pk.model;
-  const int64_t size = pk.size;
-  const int method = pk.method;
-  const bool wave_member = pk.wave_member;
-  const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
+// the solver's OdeSolverOptions / InitialConditionSolverOptions as the device-resident integrators take them
+dsh_adaptive_options adaptive_options_of(const dshs_solver* s, int group, int deterministic_pow) {
   const OdeSolverOptions& oo = s->problem.ode_options;
   const InitialConditionSolverOptions& ic = s->problem.ic_options;
   dsh_adaptive_options o;
@@ -270,6 +256,26 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
   o.ic_armijo_constant = ic.armijo_constant;
   o.group = group;
   o.deterministic_pow = deterministic_pow;
+  return o;
+}
+
+// lazy: status_host is fetched only when a member failed (totals[5] != 0; it is all zero otherwise) and root_idx_host only for models with root
+// functions (all -1 otherwise): the common case of dshs_solve_dense then moves no per-member bookkeeping over PCIe at all.
+void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, int deterministic_pow, double* y_host, double* y_dev, int32_t* stats_host,
+                  int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals, bool lazy = false, double* sens_host = nullptr) {
+  const ResidentPick pk = pick_resident(s, group);
+  if (s->problem.sens && (!pk.ok || !sens_host))
+    throw LaError(DSH_E_UNSUPPORTED, "device-resident integration with forward sensitivities: dshs_solve_dense_adaptive_sens, BDF, static ODE models with parameter "
+                                     "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
+  if (!pk.ok)
+    throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
+                                     "run-time-sized ODE models with n <= 140: BDF)");
+  const int model = pk.model;
+  const int64_t size = pk.size;
+  const int method = pk.method;
+  const bool wave_member = pk.wave_member;
+  const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
+  dsh_adaptive_options o = adaptive_options_of(s, group, deterministic_pow);
   dsh_ctx* c = s->ctx.raw();
   const bool sorted = group == 1 && prepare_member_order(s);
   const double* params_dev = sorted ? (const double*)s->p_sorted_dev : s->problem.eqn->params().ptr();
@@ -696,6 +702,52 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
     int64_t tot[6];
     s->resident_roots_valid = false;  // this call hands the per-member events to the caller's arrays; dshs_root_info falls back to the host solver's
     run_resident(s, t_eval, nt, group, deterministic_pow, y_host, y_dev, stats_host, status_host, t_root_host, root_idx_host, ncols_host, tot);
+    for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
+    s->last_mode = group;
+    return 0;
+  });
+}
+
+// OdeSolverMethod::solve (method.rs:227-258) on the device-resident BDF: every member's accepted steps out of one launch (dsh_bdf_solve_adaptive_steps), in the caller's
+// member order; the problem is the solver's OdeSolverProblem, nothing of the lock-step solver state is touched.
+int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int group, int deterministic_pow, double* y_host, double* t_host, int32_t* ncols_host,
+                        int32_t* stats_host, int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int64_t* totals) {
+  return guarded([&]() {
+    if (!y_host || !t_host || !ncols_host || max_cols < 2) throw LaError(DSH_E_INVALID, "dshs_solve_adaptive: y_host, t_host, ncols_host and max_cols >= 2 are needed");
+    if (s->method != DSHS_METHOD_BDF || s->problem.sens) throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: BDF without forward sensitivities (dshs_solve walks the host-driven path for the rest)");
+    const ResidentPick pk = pick_resident(s, group);
+    if (!pk.ok || pk.wave_member || !dsh_model_has_adaptive_steps(pk.model, pk.size))
+      throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: the model has no register-resident BDF (static models with n <= 4); dshs_solve returns every step of the host-driven lock-step solver");
+    const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
+    const dsh_adaptive_options o = adaptive_options_of(s, group, deterministic_pow);
+    dsh_ctx* c = s->ctx.raw();
+    void *y_dev = nullptr, *t_dev = nullptr, *stats_dev = nullptr, *status_dev = nullptr, *troot_dev = nullptr, *ridx_dev = nullptr, *ncols_dev = nullptr;
+    struct Release {
+      dsh_ctx* c; std::vector<void**> bufs;
+      ~Release() { for (void** q : bufs) if (*q) dsh_free(c, *q); }
+    } release{c, {&y_dev, &t_dev, &stats_dev, &status_dev, &troot_dev, &ridx_dev, &ncols_dev}};
+    check(dsh_malloc(c, (int64_t)sizeof(double) * max_cols * n * nb, 0, &y_dev), "solve_adaptive out");
+    check(dsh_malloc(c, (int64_t)sizeof(double) * max_cols * nb, 0, &t_dev), "solve_adaptive times");
+    check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ncols_dev), "solve_adaptive ncols");
+    if (stats_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * 5 * nb, 0, &stats_dev), "solve_adaptive stats");
+    if (status_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &status_dev), "solve_adaptive status");
+    if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "solve_adaptive t_root");
+    if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "solve_adaptive root_idx");
+    int64_t tot[6] = {0};
+    check(dsh_bdf_solve_adaptive_steps(c, pk.model, pk.size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_final,
+                                       max_cols, (double*)y_dev, (double*)t_dev, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
+                                       (int32_t*)ncols_dev, tot), "dsh_bdf_solve_adaptive_steps");
+    check(dsh_d2h(c, ncols_host, ncols_dev, (int64_t)sizeof(int32_t) * nb), "solve_adaptive ncols");
+    int32_t most = 0;
+    for (int64_t b = 0; b < nb; ++b) most = std::max(most, ncols_host[b]);
+    const int64_t used = std::min<int64_t>(most, max_cols);  // columns nobody wrote stay untouched on the host
+    for (int64_t k = 0; k < used; ++k) check(dsh_vec_download(c, n, nb, (const double*)y_dev + (size_t)(k * n * nb), y_host + (size_t)(k * n * nb)), "solve_adaptive download");
+    check(dsh_d2h(c, t_host, t_dev, (int64_t)sizeof(double) * used * nb), "solve_adaptive times");
+    if (stats_host) check(dsh_d2h(c, stats_host, stats_dev, (int64_t)sizeof(int32_t) * 5 * nb), "solve_adaptive stats");
+    if (status_host) check(dsh_d2h(c, status_host, status_dev, (int64_t)sizeof(int32_t) * nb), "solve_adaptive status");
+    if (t_root_host) check(dsh_d2h(c, t_root_host, troot_dev, (int64_t)sizeof(double) * nb), "solve_adaptive t_root");
+    if (root_idx_host) check(dsh_d2h(c, root_idx_host, ridx_dev, (int64_t)sizeof(int32_t) * nb), "solve_adaptive root_idx");
+    s->resident_roots_valid = false;
     for (int k = 0; k < 6; ++k) { s->last_totals[k] = tot[k]; if (totals) totals[k] = tot[k]; }
     s->last_mode = group;
     return 0;

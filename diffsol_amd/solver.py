@@ -219,6 +219,22 @@ class Solver:
         tot = dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))
         return (out, tot, m) if want_member_stats else (out, tot)
 
+    def solve_adaptive(self, t_final, max_cols=1024, group=1, deterministic_pow=True):
+        """OdeSolverMethod::solve (method.rs:227-258) on the device-resident BDF (dshs_solve_adaptive): the state of every member after EVERY accepted step, the whole
+        ensemble in one launch.  Returns (y [max_cols, nbatch, n], t [max_cols, nbatch], member dict(ncols, stats [5, nbatch], status, t_root, root_idx), totals dict);
+        member b's solution is y[:ncols[b], b], t[:ncols[b], b] (column 0 = the initial state, the last one at t_final or at the member's event); ncols[b] > max_cols:
+        call again with more room."""
+        nb = self.nbatch
+        y = np.full((max_cols, nb, self.n), np.nan)
+        t = np.full((max_cols, nb), np.nan)
+        m = dict(ncols=np.empty(nb, dtype=np.int32), stats=np.empty((5, nb), dtype=np.int32), status=np.empty(nb, dtype=np.int32), t_root=np.empty(nb),
+                 root_idx=np.empty(nb, dtype=np.int32))
+        totals = (C.c_int64 * 6)()
+        i32 = lambda a: a.ctypes.data_as(_ffi.c_i32p)
+        check(self._L.dshs_solve_adaptive(self._h, float(t_final), int(max_cols), int(group), int(deterministic_pow), y.ctypes.data_as(_ffi.c_dp), t.ctypes.data_as(_ffi.c_dp),
+                                          i32(m["ncols"]), i32(m["stats"]), i32(m["status"]), m["t_root"].ctypes.data_as(_ffi.c_dp), i32(m["root_idx"]), totals), host=True)
+        return y, t, m, dict(zip(self.ADAPTIVE_TOTALS, [int(v) for v in totals]))
+
     def solve_dense_adaptive_sens(self, t_eval, group=1, deterministic_pow=True, want_member_stats=False):
         """solve_dense_sensitivities (sensitivities.rs:114-260) on the device-resident BDF with forward sensitivities (dshs_solve_dense_adaptive_sens): states AND
         the sensitivities of every parameter at t_eval from one launch; the solver must have been created with sens=True.

@@ -416,6 +416,18 @@ int dsh_model_has_adaptive(int model, int64_t size);
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                            int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
+/* OdeSolverMethod::solve (crates/diffsol/src/ode_solver/method.rs:227-258 over :881-961) inside ONE launch of the register-resident BDF: every member's state after
+ * EVERY accepted step instead of interpolated save points.  Column 0 is (t0, y0) (write_out before the first step), then one column per InternalTimestep, the last
+ * one at the stop time t_final (TstopReached) or — models with root functions — at the member's event (state_mut_back(t_root), RootFound); a configured reset
+ * operator writes the reset state at the root time and goes on (method.rs:927-941).  group = 1: every member its own columns and count; group = 64: the 64
+ * members of a wavefront share them (the reference's batched semantics).  y_out: max_cols x n x nb, t_out: max_cols x nb (device, batch-fastest);
+ * ncols[b]: the columns member b PRODUCED — columns beyond max_cols are counted, not stored, so ncols[b] > max_cols says "call again with more room" (the
+ * reference grows its matrix instead, method.rs:977-980).  Static models with n <= 4, built-in or run-time-compiled (dsh_model_has_adaptive_steps); other
+ * arguments as dsh_bdf_solve_adaptive. */
+int dsh_model_has_adaptive_steps(int model, int64_t size);
+int dsh_bdf_solve_adaptive_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                 double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                 int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* HYBRID models (a reset operator: OdeEquations::reset, DiffSL reset_i) in the register-resident form (n <= 4, identity mass): dsh_bdf_solve_adaptive and
  * dsh_sdirk_solve_resident (runge_kutta.rs:396-464, sdirk.rs:368-374) handle every event inside the launch the way the reference's solve_dense does when a reset is configured (method.rs:774-797): the save points up to the root from the step's
  * polynomial, state moved back to the root (bdf.rs:1232-1262), y <- reset(y, t), dy <- f(y, t) (bdf.rs:1017-1020), stop time armed again, restart from the modified

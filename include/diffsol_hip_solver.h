@@ -147,6 +147,14 @@ int dshs_solve_dense_adaptive(dshs_solver* s, const double* t_eval, int64_t nt, 
                               double* y_host, double* y_dev, int32_t* stats_host,
                               int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int32_t* ncols_host, int64_t* totals);
 
+/* OdeSolverMethod::solve (method.rs:227-258: the state after every accepted step, not at save points) entirely on the device: every member's steps out of ONE
+ * launch of the register-resident BDF (dsh_bdf_solve_adaptive_steps; static models with n <= 4, built-in or from DiffSL — DSH_E_UNSUPPORTED otherwise: dshs_solve
+ * returns every step of the host-driven lock-step solver).  group = 1: every member its own times; group = 64: shared per wavefront.  y_host: [max_cols][b][state],
+ * t_host: [max_cols][b]; ncols_host[b]: columns member b produced — column 0 = (t0, y0), the last one at t_final or at the member's event (t_root_host /
+ * root_idx_host) — ncols > max_cols: not all of them were stored, call again with more room.  stats_host / status_host as dshs_solve_dense_adaptive. */
+int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int group /* 1 | 64 */, int deterministic_pow, double* y_host, double* t_host,
+                        int32_t* ncols_host, int32_t* stats_host, int32_t* status_host, double* t_root_host, int32_t* root_idx_host, int64_t* totals);
+
 /* dshs_solve_dense_adaptive for a solver created with forward sensitivities (dshs_create_sens): states and sensitivities at t_eval from ONE launch
  * (dsh_bdf_solve_adaptive_sens; BDF, static ODE models with parameter derivatives, n <= 4, no root functions — DSH_E_UNSUPPORTED otherwise: such problems
  * integrate their sensitivities host-driven, dshs_solve_dense + dshs_interpolate_sens).  The reference's solve_dense_sensitivities (sensitivities.rs:114-260)

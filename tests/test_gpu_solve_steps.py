@@ -1,0 +1,116 @@
+"""OdeSolverMethod::solve — the state after EVERY accepted step (crates/diffsol/src/ode_solver/method.rs:227-258 over :881-961) — on the device-resident BDF
+(VERDICT r3 missing 5: the resident path only had solve_dense): dsh_bdf_solve_adaptive_steps / dshs_solve_adaptive / Solver.solve_adaptive.  The checker restates the
+reference's loop over the oracle's stepping solver, one independent IVP per member (group = 1) or one 64-member batch (group = 64): write_out, set_stop_time, step
+until TstopReached / RootFound, write_out after every step.  With the deterministic pow on both sides every time and every state bit agree."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import diffsol_amd
+    return diffsol_amd
+
+
+@pytest.fixture
+def det_pow(O):
+    O.set_det_pow(True)
+    yield
+    O.set_det_pow(False)
+
+
+def reference_solve(O, model, p, t_final, **kw):
+    """method.rs:881-961 for a batch (p: [nbatch, np]) without a reset operator: (times, states [ncols, nbatch, n], root (t, idx) or None)"""
+    s = O.OracleSolver(model, p, nbatch=p.shape[0], **kw)
+    st = s.state()
+    ts, ys = [st["t"]], [st["y"].copy()]
+    s.set_stop_time(t_final)
+    root = None
+    while True:
+        r = s.step()
+        if r == 1:  # RootFound: state_mut_back(t_root) — the interpolated state at the root — then write_out
+            t_root, idx = s.root_info()
+            ts.append(t_root); ys.append(s.interpolate(t_root).copy())
+            root = (t_root, idx)
+            break
+        st = s.state()
+        ts.append(st["t"]); ys.append(st["y"].copy())
+        if r == 2:
+            break
+    return np.array(ts), np.array(ys), root
+
+
+def robertson_p(rng, nb):
+    return np.stack([0.04 * 2 ** rng.uniform(-1, 1, nb), 1e4 * 2 ** rng.uniform(-1, 1, nb), 3e7 * 2 ** rng.uniform(-1, 1, nb)], axis=1)
+
+
+def test_every_accepted_step_of_every_member_equals_the_reference_loop_bit_for_bit(H, O, det_pow):
+    rng = np.random.default_rng(2026)
+    nb = 300
+    p = robertson_p(rng, nb)
+    kw = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **kw)
+    y, t, m, tot = s.solve_adaptive(4e3, max_cols=400, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all() and (m["ncols"] <= 400).all()
+    assert (m["ncols"] == m["stats"][0] + 1).all()  # one column per accepted step + the initial state
+    for b in list(range(0, nb, 23)) + [nb - 1]:
+        ts, ys, root = reference_solve(O, O.MODEL_ROBERTSON_ODE, p[b:b + 1], 4e3, model_size=1, **kw)
+        nc = m["ncols"][b]
+        assert nc == len(ts) and root is None
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+        assert t[0, b] == 0.0 and t[nc - 1, b] == 4e3  # (columns behind ncols[b] are unspecified)
+    # the columns of solve are the columns solve_dense interpolates between: same counters as the save-point run to the same stop time
+    _, tot_d = s.solve_dense_adaptive([4e3], group=1)
+    assert tot_d["number_of_steps"] == tot["number_of_steps"] and tot_d["number_of_nonlinear_solver_iterations"] == tot["number_of_nonlinear_solver_iterations"]
+
+
+def test_lock_step_groups_share_their_columns_like_one_batched_solve(H, O, det_pow):
+    rng = np.random.default_rng(7)
+    nb = 64 + 37  # a full wavefront and a ragged one
+    p = robertson_p(rng, nb)
+    kw = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **kw)
+    y, t, m, tot = s.solve_adaptive(40.0, max_cols=200, group=64)
+    assert tot["failed_members"] == 0
+    for lo, hi in ((0, 64), (64, nb)):
+        ts, ys, _ = reference_solve(O, O.MODEL_ROBERTSON_ODE, p[lo:hi], 40.0, model_size=1, **kw)
+        nc = len(ts)
+        assert (m["ncols"][lo:hi] == nc).all()
+        assert np.array_equal(t[:nc, lo:hi], np.repeat(ts[:, None], hi - lo, axis=1)) and np.array_equal(y[:nc, lo:hi], ys)
+
+
+def test_too_little_room_is_reported_and_events_end_a_members_columns_at_its_root(H, O, det_pow):
+    rng = np.random.default_rng(3)
+    nb = 70
+    p = robertson_p(rng, nb)
+    kw = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6])
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **kw)
+    y, t, m, _ = s.solve_adaptive(4e3, max_cols=50, group=1)
+    assert (m["ncols"] > 50).all()  # counted, not stored
+    y2, t2, m2, _ = s.solve_adaptive(4e3, max_cols=int(m["ncols"].max()), group=1)
+    assert np.array_equal(m2["ncols"], m["ncols"]) and np.array_equal(y2[:50], y) and np.array_equal(t2[:50], t)
+    # a model with a root function: dy/dt = y (1 - y / k), stop at y = 0.5 k
+    from diffsol_amd import diffsl as fe
+    import diffsl_models as D
+    LOGISTIC = "in = [r, k]\nr { 1 }\nk { 1 }\nu_i { y = 0.1 }\nF_i { (r * y) * (1 - (y / k)) }\nstop_i { y - 0.5 * k }\n"
+    mdl, mid = fe.DiffslModel(LOGISTIC), D.host_model(O, LOGISTIC)
+    pl = np.stack([rng.uniform(0.5, 2.0, nb), rng.uniform(0.8, 1.6, nb)], axis=1)
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    sl = H.Solver(mdl, pl, nbatch=nb, **tol)
+    y, t, m, tot = sl.solve_adaptive(50.0, max_cols=300, group=1)
+    assert tot["failed_members"] == 0 and (m["root_idx"] == 0).all()
+    for b in range(0, nb, 9):
+        ts, ys, root = reference_solve(O, mid, pl[b:b + 1], 50.0, **tol)
+        nc = m["ncols"][b]
+        assert root is not None and nc == len(ts) and m["t_root"][b] == root[0] == t[nc - 1, b]
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0])
+        assert abs(y[nc - 1, b, 0] - 0.5 * pl[b, 1]) < 1e-6
+
+
+def test_forms_without_a_register_resident_kernel_refuse(H):
+    rng = np.random.default_rng(1)
+    s = H.Solver("heat1d", rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, model_size=20, rtol=1e-6, atol=[1e-6])
+    with pytest.raises(Exception, match="register-resident"):
+        s.solve_adaptive(0.1, max_cols=64)
