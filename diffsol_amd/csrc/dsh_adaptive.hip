@@ -125,11 +125,13 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
 }  // namespace
 extern "C" {
 // hybrid models whose events are handled INSIDE dsh_bdf_solve_adaptive (move back to the root, apply the reset, restart at first order, go on to the last save
-// point): register-resident form, n <= 4, identity mass, with root functions
+// point): register-resident form (n <= 4) or banded lane-per-member form, identity mass, with root functions
 int dsh_model_has_adaptive_reset(int model, int64_t size) {
   if (is_jit_model(model)) {
     const JitInfo* ji = jit_info(model);
-    return ji && ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4 && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? 1 : 0;
+    if (!(ji && ji->has_reset && !ji->has_mass && ji->nroots > 0)) return 0;
+    // register-resident form (n <= 4), or the banded lane-per-member form (k_bdf_lane_banded: the same event handling on per-lane memory; BDF)
+    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || ji->form == DSH_JIT_FORM_STATIC_BANDED ? 1 : 0;
   }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {

@@ -743,6 +743,41 @@ DSH_LB_STREAM
       col++;
       if (col < C.r.n_eval) te_next = t_eval[col];
     }
+    if constexpr (model_has_reset<Mdl>::value && !MASS && Mdl::NROOTS > 0) {
+      if (reason == 3) {
+        // A reset operator is configured (hybrid model; solve_dense, method.rs:774-797), as in k_bdf_adaptive: the state goes back to the root (state_mut_back,
+        // bdf.rs:1232-1262: the step's polynomial at t_root), y <- reset(y, t), dy <- f(y, t) (apply_reset, bdf.rs:1017-1020 over state.rs:279-306), the stop time is
+        // armed again — on the OLD differences and order, like the reference, so the step size may change here — and the next step restarts from the modified
+        // state at first order (the `is_state_modified` branch of Bdf::step, bdf.rs:1290-1318).  The save points up to the root were written above.
+        interpolate_to(t_root, [&](int i, double v) __attribute__((always_inline)) { w[i] = v; });
+        t = t_root;
+        Mdl::reset(t, *reinterpret_cast<const double (*)[N]>(w), p, *reinterpret_cast<double (*)[N]>(y));
+        Mdl::rhs(t, *reinterpret_cast<const double (*)[N]>(y), p, *reinterpret_cast<double (*)[N]>(w));
+        if (t < tstop) {
+          has_tstop = true;  // set_stop_time (bdf.rs:1591-1600)
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          Mdl::root(t, *reinterpret_cast<const double (*)[N]>(y), p, g0);  // RootFinder::init
+          rf_t0 = t;
+          n_equal_steps = 0;
+          order = 1;  // initialise_diff_to_first_order: columns 0 and 1 only, the others keep what they hold
+          {
+            double* const D0 = Drow(0);
+            double* const D1 = Drow(1);
+DSH_LB_STREAM
+            for (int i = 0; i < N; ++i) { D0[i] = y[i]; D1[i] = w[i] * h; }
+          }
+          opc = h * sAlpha[1];
+          jacobian_updates(h * sAlpha[1], JState::StepSuccess);
+          has_prev_err = false;
+          predicted = false;
+          if (has_tstop) { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          reason = 0;
+        } else {
+          done = true;  // the event sits on the last save point: TstopReached
+          reason = 0;
+        }
+      }
+    }
     if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
       if (col < C.r.n_eval) {
         const int64_t c0 = (int64_t)col * N;
