@@ -53,9 +53,10 @@ constexpr int lb_chunk(int n, int want) {
 // bits as the oracle's dense solve.  md: the diagonal of M (0 = algebraic row).  y / dy in-out; Jb, Lf, Uf, P: the kernel's band / factor storage, free at
 // this point.  Returns false for InitialConditionDidNotConverge.
 template <class Mdl, bool WAVE, bool BA>
-__device__ __forceinline__ bool set_consistent_banded(double t0, const double (&p)[Mdl::NP], double* y, double* dy, const double* md, const double* atol_g, int64_t nb,
+__device__ __forceinline__ bool set_consistent_banded(double t0, const double (&p)[Mdl::NP], double* y, double* dy, const double* md, const double* Mb, const double* atol_g, int64_t nb,
                                                       int64_t b, double rtol, const ResidentConsts& C, double* Jb, double* Lf, double* Uf, int* P) {
   constexpr int N = Mdl::N, K = model_band_k<Mdl>::value;
+  constexpr bool MBAND = model_mass_band_k<Mdl>::value > 0;  // M banded, its band in Mb (layout of Jb); else diag(md)
   const dsh_adaptive_options& o = C.o;
   auto AT = [&](int i) __attribute__((always_inline)) -> double { return BA ? atol_g[i] : atol_g[(int64_t)i * nb + b]; };
   bool any_alg = false;
@@ -65,11 +66,23 @@ __device__ __forceinline__ bool set_consistent_banded(double t0, const double (&
   Mdl::jac_band(t0, *reinterpret_cast<const double (*)[N]>(y), p, *reinterpret_cast<double (*)[(2 * K + 1) * N]>(Jb));
   alignas(16) double y0[N], x[N], yerr[N], delta[N], x0[N], delta0[N];
   for (int i = 0; i < N; ++i) { y0[i] = y[i]; x[i] = md[i] == 0.0 ? y[i] : dy[i]; yerr[i] = x[i]; delta[i] = 0.0; }
-  // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out — with a diagonal neg_mass the gemv leaves (-m_i) x_i + out_i
+  // InitOp::call_inplace (:103-115): y0[alg] = x[alg]; out = f(y0); out = neg_mass x + out — with a diagonal neg_mass the gemv leaves (-m_i) x_i + out_i; with a banded
+  // one (neg_mass = -M restricted to differential rows AND columns, init.rs:46-63) the nonzero terms of the row in ascending column order (the gemv's order; its
+  // zero terms change nothing)
   auto fun = [&](const double* xx, double* out) __attribute__((always_inline)) {
     for (int i = 0; i < N; ++i) if (md[i] == 0.0) y0[i] = xx[i];
     Mdl::rhs(t0, *reinterpret_cast<const double (*)[N]>(y0), p, *reinterpret_cast<double (*)[N]>(out));
-    for (int i = 0; i < N; ++i) if (md[i] != 0.0) out[i] = (md[i] * (-1.0)) * xx[i] + out[i];
+    if constexpr (MBAND) {
+      for (int i = 0; i < N; ++i)
+        if (md[i] != 0.0) {
+          double acc = out[i];
+          for (int col = (i - K > 0 ? i - K : 0); col <= (i + K < N - 1 ? i + K : N - 1); ++col)
+            if (md[col] != 0.0) acc = (Mb[(col - i + K) * N + i] * (-1.0)) * xx[col] + acc;
+          out[i] = acc;
+        }
+    } else {
+      for (int i = 0; i < N; ++i) if (md[i] != 0.0) out[i] = (md[i] * (-1.0)) * xx[i] + out[i];
+    }
   };
   auto norm_of = [&](const double* v) __attribute__((always_inline)) -> double {  // Convergence::norm against yerr
     double acc = 0.0;
@@ -87,7 +100,8 @@ __device__ __forceinline__ bool set_consistent_banded(double t0, const double (&
     bool sing = false;
     band_factor_lane_fn<N, K>([&](int i, int col) -> double {
       if (md[col] == 0.0) return Jb[(col - i + K) * N + i];
-      return i == col ? md[col] * (-1.0) : 0.0;
+      if constexpr (MBAND) return md[i] == 0.0 ? 0.0 : Mb[(col - i + K) * N + i] * (-1.0);  // -M_u: differential rows and columns only
+      else return i == col ? md[col] * (-1.0) : 0.0;
     }, Lf, Uf, P, sing);
     conv.reset();
     double ls_norm = 1.0;
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BAN
   constexpr int N = Mdl::N, NP = Mdl::NP;
   constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
   constexpr int K = model_band_k<Mdl>::value, RW = K + 1, CW = 2 * K + 1;
-  static_assert(K > 0, "k_bdf_lane_banded: banded models");  // a mass matrix must be DIAGONAL (checked where the model is made: mass bandwidths 0, 0)
+  static_assert(K > 0, "k_bdf_lane_banded: banded models");  // a mass matrix is diagonal (the fast paths) or banded within K (model_mass_band_k)
   const AdaptiveConsts& C = *Cp;
   const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
@@ -193,7 +207,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BAN
   // M x == diag(md) x bit for bit (model_mass_rows_scaled): the residual entry is formed where the sweep consumes it, (md_i == 0 ? 0 : md_i (x_i + psi_i)) + (-c) f_i —
   // the arithmetic of the generated mass_gemv row (literal 0 / x_i / coefficient * x_i, then + beta y_i) without the two extra passes over per-lane memory
   constexpr bool MSCALED = MASS && model_mass_rows_scaled<Mdl>::value;
-  alignas(16) double md[MASS ? N : 1];  // models with a (diagonal) mass matrix: its diagonal
+  alignas(16) double md[MASS ? N : 1];  // models with a mass matrix: its diagonal (0 = algebraic row)
+  constexpr bool MBAND = MASS && model_mass_band_k<Mdl>::value > 0;
+  static_assert(!MBAND || (model_mass_band_k<Mdl>::value <= K && !MSCALED), "the mass matrix's band must fit the factored band");
+  alignas(16) double Mb[MBAND ? CW * N : 1];  // banded mass matrix: entry (i, col) at Mb[(col - i + K) * N + i], like Jb
   double* const yp = xy;
   double* const X = xy + N;
   int cur = 0;
@@ -209,11 +226,25 @@ DSH_UNROLL_N
     Mdl::init(t, p, y);
     Mdl::rhs(t, y, p, w);
     if constexpr (MASS) {
-      // the diagonal of M: M applied to a vector of ones (a diagonal matrix's row sums are its diagonal)
       alignas(16) double tmpv[N];
-      for (int i = 0; i < N; ++i) { tmpv[i] = 1.0; md[i] = 0.0; }
-      Mdl::mass_gemv(t, *reinterpret_cast<const double (*)[N]>(tmpv), p, 0.0, *reinterpret_cast<double (*)[N]>(md));
-      if (!group_all<WAVE>(set_consistent_banded<Mdl, WAVE, BA>(t, p, y, w, md, atol_g, nb, b, rtol, C.r, Jb, Lf, Uf, P))) status = kRsInitialConditionDidNotConverge;
+      if constexpr (MBAND) {
+        // the band of M from CW products with 0/1 vectors (columns c, c + CW, ... at once: within the band of a row at most one of them is met)
+        alignas(16) double col_of[N];
+        for (int e = 0; e < CW * N; ++e) Mb[e] = 0.0;
+        for (int c = 0; c < CW; ++c) {
+          for (int i = 0; i < N; ++i) { tmpv[i] = i % CW == c ? 1.0 : 0.0; col_of[i] = 0.0; }
+          Mdl::mass_gemv(t, *reinterpret_cast<const double (*)[N]>(tmpv), p, 0.0, *reinterpret_cast<double (*)[N]>(col_of));
+          for (int i = 0; i < N; ++i)
+            for (int col = (i - K > 0 ? i - K : 0); col <= (i + K < N - 1 ? i + K : N - 1); ++col)
+              if (col % CW == c) Mb[(col - i + K) * N + i] = col_of[i];
+        }
+        for (int i = 0; i < N; ++i) md[i] = Mb[K * N + i];
+      } else {
+        // the diagonal of M: M applied to a vector of ones (a diagonal matrix's row sums are its diagonal)
+        for (int i = 0; i < N; ++i) { tmpv[i] = 1.0; md[i] = 0.0; }
+        Mdl::mass_gemv(t, *reinterpret_cast<const double (*)[N]>(tmpv), p, 0.0, *reinterpret_cast<double (*)[N]>(md));
+      }
+      if (!group_all<WAVE>(set_consistent_banded<Mdl, WAVE, BA>(t, p, y, w, md, Mb, atol_g, nb, b, rtol, C.r, Jb, Lf, Uf, P))) status = kRsInitialConditionDidNotConverge;
     }
     h = initial_step_size<Mdl, WAVE>(t, C.r.h0, y, w, p, atol_arr, rtol, 1, det);
   }
@@ -233,7 +264,7 @@ DSH_LB_STREAM
     if (jac_stale) { Mdl::jac_band(tt, y, p, Jb); jac_stale = false; }
     bool sing = false;
     if constexpr (MASS)  // J (-c) + M (op/bdf.rs:273-300), M diagonal
-      band_factor_lane_fn<N, K>([&](int i, int col) -> double { return Jb[(col - i + K) * N + i] * (-opc) + (i == col ? md[i] : 0.0); }, Lf, Uf, P, sing);
+      band_factor_lane_fn<N, K>([&](int i, int col) -> double { return Jb[(col - i + K) * N + i] * (-opc) + (MBAND ? Mb[(col - i + K) * N + i] : (i == col ? md[i] : 0.0)); }, Lf, Uf, P, sing);
     else
     band_factor_lane<N, K>(Jb, opc, Lf, Uf, P, sing);
   };

@@ -184,6 +184,9 @@ template <class M> struct model_has_reset<M, model_void_t<decltype(&M::reset)>> 
 template <class M, class = void> struct model_band_k { static constexpr int value = 0; };
 template <class M> struct model_band_k<M, model_void_t<decltype(M::BAND_K)>> { static constexpr int value = M::BAND_K; };
 // a banded model with a DIAGONAL mass matrix may state that M x == diag(M 1) x bit for bit (rows: 0, x_i, or coefficient * x_i; the DiffSL front end checks it)
+// bandwidth of the mass matrix of a banded model (0: diagonal); the lane-per-member BDF then keeps M's band next to the Jacobian's
+template <class M, class = void> struct model_mass_band_k { static constexpr int value = 0; };
+template <class M> struct model_mass_band_k<M, model_void_t<decltype(M::MASS_BAND_K)>> { static constexpr int value = M::MASS_BAND_K; };
 template <class M, class = void> struct model_mass_rows_scaled { static constexpr bool value = false; };
 template <class M> struct model_mass_rows_scaled<M, model_void_t<decltype(M::MASS_ROWS_SCALED)>> { static constexpr bool value = M::MASS_ROWS_SCALED; };
 

@@ -55,8 +55,8 @@ class DiffslModel:
         self.model_id = mid.value
         self.lane_model_id = None
         jkl, jku = d["band"][0], d["band"][1]
-        diag_mass = (not self.has_mass) or (d["band"][2] == 0 and d["band"][3] == 0)  # the lane-per-member banded kernels take a diagonal mass matrix
-        if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and diag_mass and max(jkl, jku) <= 4 and self.nroots <= 8:
+        mass_k = max(d["band"][2], d["band"][3]) if self.has_mass else 0  # the lane-per-member banded kernels take a banded mass matrix (round 4; diagonal: the fast path)
+        if lane_resident and form == FORM_DYNAMIC and self.n <= 64 and mass_k <= 4 and max(jkl, jku) <= 4 and self.nroots <= 8:
             # banded Jacobian: the same model once more in the lane-per-member form; per-member device-resident BDF solves run on it (compiled on first use)
             lane_src = generate(code, TARGET_HIP_STATIC, model_index)[0]
             lid = C.c_int()
