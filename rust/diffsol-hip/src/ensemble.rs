@@ -153,6 +153,64 @@ pub fn solve_dense_ensemble(problem: &OdeSolverProblem<HipModelEquations>, metho
     Ok(out)
 }
 
+/// What `OdeSolverMethod::solve` returns, for every member of an ensemble: the state after every accepted step.
+pub struct EnsembleStepsSolution {
+    /// `nstates x max_cols` batched matrix: member b's solution is the first `ncols[b]` columns of its slice (column 0 = the initial state)
+    pub ys: HipMat,
+    /// `max_cols x nbatch` times, batch-fastest on the host as well: member b's time of column k at `ts[k * nbatch + b]`
+    pub ts: Vec<f64>,
+    /// columns member b PRODUCED (more than `max_cols`: not all of them were stored — call again with more room)
+    pub ncols: Vec<i32>,
+    pub status: Vec<i32>,
+    pub t_root: Vec<f64>,
+    pub root_index: Vec<i32>,
+    pub totals: [i64; 6],
+}
+
+/// `problem.bdf()` + `solve(t_final)` (method.rs:227-258: the state after EVERY accepted step) for every member, in one launch of the register-resident BDF
+/// (`dsh_bdf_solve_adaptive_steps`; static models with n <= 4).  Uses the problem's tolerances, options, t0 and h0.
+pub fn solve_ensemble(problem: &OdeSolverProblem<HipModelEquations>, t_final: f64, max_cols: usize, mode: EnsembleMode) -> Result<EnsembleStepsSolution, LaError> {
+    let eqn = &problem.eqn;
+    let ctx = eqn.ctx.clone();
+    let (nb, n) = (ctx.nbatch(), eqn.nstates);
+    if unsafe { ffi::dsh_model_has_adaptive_steps(eqn.model, eqn.size) } == 0 {
+        return Err(LaError::Other("solve_ensemble: the model has no register-resident BDF (static models with n <= 4); Bdf::solve on HipVec / HipMat / HipLU walks the same steps host-driven".into()));
+    }
+    let o = adaptive_options(problem, mode);
+    let ys = HipMat::zeros(n, max_cols, ctx.clone());
+    let c = ctx.ptr();
+    let alloc = |bytes: usize| -> *mut c_void {
+        let mut p = ptr::null_mut();
+        check(unsafe { ffi::dsh_malloc(c, bytes as i64, 0, &mut p) }, "dsh_malloc");
+        p
+    };
+    let (ts_d, status_d, troot_d, ridx_d, ncols_d) = (alloc(8 * max_cols * nb), alloc(4 * nb), alloc(8 * nb), alloc(4 * nb), alloc(4 * nb));
+    let mut totals = [0i64; 6];
+    let atol = &problem.atol;
+    let rc = unsafe {
+        ffi::dsh_bdf_solve_adaptive_steps(
+            c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
+            ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+        )
+    };
+    let fetch = |dev: *mut c_void, host: *mut c_void, bytes: usize| check(unsafe { ffi::dsh_d2h(c, host, dev, bytes as i64) }, "dsh_d2h");
+    let mut out = EnsembleStepsSolution { ys, ts: vec![0.0; max_cols * nb], ncols: vec![0; nb], status: vec![0; nb], t_root: vec![0.0; nb], root_index: vec![0; nb], totals };
+    if rc >= 0 {
+        fetch(ts_d, out.ts.as_mut_ptr() as *mut c_void, 8 * max_cols * nb);
+        fetch(ncols_d, out.ncols.as_mut_ptr() as *mut c_void, 4 * nb);
+        fetch(status_d, out.status.as_mut_ptr() as *mut c_void, 4 * nb);
+        fetch(troot_d, out.t_root.as_mut_ptr() as *mut c_void, 8 * nb);
+        fetch(ridx_d, out.root_index.as_mut_ptr() as *mut c_void, 4 * nb);
+    }
+    for p in [ts_d, status_d, troot_d, ridx_d, ncols_d] {
+        unsafe { ffi::dsh_free(c, p) };
+    }
+    if rc < 0 {
+        return Err(LaError::Other(last_error()));
+    }
+    Ok(out)
+}
+
 /// States and forward sensitivities of a whole ensemble at `t_eval` from one launch.
 pub struct EnsembleSensSolution {
     /// `nstates x t_eval.len()` batched matrix of the states
