@@ -198,7 +198,11 @@ int dsh_mat_gemm(dsh_ctx* ctx, int64_t m, int64_t n, int64_t k, int64_t nbatch, 
 int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out);
 void dsh_lu_destroy(dsh_lu* lu);
 /* set_linearisation after op.matrix_inplace: partial-pivot LU of all nbatch systems in ONE launch
- * (replaces the serial `for b in 0..nbatch { cusolverDnDgetrf }` loop, lu.rs:80-95).  `a` (n*n*nbatch, device) is not modified. */
+ * (replaces the serial `for b in 0..nbatch { cusolverDnDgetrf }` loop, lu.rs:80-95).  `a` (n*n*nbatch, device) is not modified.
+ * BIT PARITY: every kernel behind this call produces the factors, pivots and solutions of the CPU path bit for bit EXCEPT the default dense kernel for
+ * 288 <= n <= 1024 (the FP64 matrix-core kernel of dsh_lu_tiled.hpp): same pivots, factors within ~2e-13 of the largest entry (fused multiply-adds, the
+ * matrix cores' summation order, a reciprocal instead of a division per pivot); it also keeps a second n*ldw*nbatch working copy per handle.
+ * DSH_LU_EXACT=1 (read per call) selects the bit-exact blocked kernel for that range instead (2.5 - 6x slower, profiles/r04_lu_bench.md). */
 int dsh_lu_factor(dsh_lu* lu, const double* a);
 /* solve_in_place, nrhs = 1, all systems in ONE launch (replaces the getrs host loop, lu.rs:127-145) */
 int dsh_lu_solve(const dsh_lu* lu, double* b);
