@@ -100,13 +100,14 @@ DSH_UNROLL_N
   // ---- forward sensitivities (runge_kutta.rs:196-232 new_augmented, :691-748 the sensitivity half of do_stage_sdirk, :812-822 error norm, :1237-1330
   // interpolate_sens; RkState::new_with_sensitivities_and_consistent state.rs:1032-1083).  Per-lane arrays in scratch memory, indexed by the parameter at run time.
   constexpr int NPS = SENS ? NP : 1, NS = SENS ? N : 1, SS = SENS ? S : 1;
-  static_assert(!SENS || (!Mdl::HAS_MASS && model_band_k<Mdl>::value == 0 && Mdl::NROOTS == 0),
-                "device-resident forward sensitivities: register-resident ODE models without root functions");
+  // banded lane-per-member models (model_band_k > 0: the state in per-lane memory) take the same code — the sensitivity arrays are per-lane memory too, the
+  // sensitivity solves run on the banded factors (round 4; runge_kutta.rs:691-748 for the PDE / battery models)
+  static_assert(!SENS || (!Mdl::HAS_MASS && Mdl::NROOTS == 0), "device-resident forward sensitivities: ODE models without root functions");
   double sv[NPS][NS], dsv[NPS][NS], old_sv[NPS][NS], old_dsv[NPS][NS], sdiff[NPS][SS][NS];
   double s_atol[NS];
   if constexpr (SENS) {
 DSH_UNROLL_N
-    for (int i = 0; i < N; ++i) s_atol[i] = T.sens_atol[i];
+    for (int i = 0; i < N; ++i) s_atol[i] = T.sens_atol[(T.sens_pad || i >= 4) ? 0 : i];  // sens_pad: one tolerance for every state (models with more than 4)
     for (int j = 0; j < NP; ++j) {
       double ev[NP], s0[N], jm[N], dfdp[N];
 #pragma unroll
@@ -381,7 +382,10 @@ DSH_UNROLL_N
                   const double fr = jm[r] + dfdp[r];
                   delta[r] = 1.0 * ks[r] + beta * fr;
                 }
-                if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) break;
+                bool s_ok;
+                if constexpr (BANDED) s_ok = band_solve_lane<N, BK>(Lf, Uf, P, delta);
+                else s_ok = lu_solve_reg<N>(A, P, delta);
+                if (!group_all<WAVE>(s_ok)) break;
 DSH_UNROLL_N
                 for (int r = 0; r < N; ++r) ks[r] = ks[r] - delta[r];
                 const ConvStatus st = conv.check_new_iteration(sqrt(group_norm<WAVE>(wms<N>(delta, sv[j], atol, rtol))));

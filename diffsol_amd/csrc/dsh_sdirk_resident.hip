@@ -67,7 +67,7 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_adaptive_sens(model, size)) {
-    set_error("dsh_sdirk_solve_resident_sens: the model has no device-resident integrator with forward sensitivities (register-resident ODE model with parameter derivatives, n <= 4, no root functions)");
+    set_error("dsh_sdirk_solve_resident_sens: the model has no device-resident integrator with forward sensitivities (identity-mass ODE model with parameter derivatives and no root functions: register-resident n <= 4, or the banded lane-per-member form)");
     return DSH_E_UNSUPPORTED;
   }
   const SdirkSensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
@@ -102,6 +102,10 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
     int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;
     if (dsh_model_info(model, size, &ns, &npar_, &hm_, &nroots_) != DSH_OK) return DSH_E_INVALID;
     DSH_REQUIRE(sens->natol == 0 || sens->natol == 1 || sens->natol == ns, "sens_atol must have length 1 or nstates");
+    bool uniform = true;
+    for (int64_t i = 1; i < sens->natol; ++i) uniform = uniform && sens->atol_host[i] == sens->atol_host[0];
+    DSH_REQUIRE(ns <= 4 || uniform, "device-resident sensitivities of models with more than 4 states take one sens_atol for every state");
+    T.sens_pad = (ns > 4 || sens->natol <= 1) ? 1 : 0;  // 1: sens_atol[0] for every state
     for (int64_t i = 0; i < 4 && i < ns; ++i) T.sens_atol[i] = sens->natol == 0 ? 0.0 : (sens->natol == 1 ? sens->atol_host[0] : sens->atol_host[i]);
   }
   double* t_eval_dev = nullptr;

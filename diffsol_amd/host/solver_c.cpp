@@ -109,9 +109,9 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     int m = 0; int64_t sz = 0;
     if (for_auto || s->problem.eqn->has_reset()) return r;
     if (s->problem.eqn->fused_model(&m, &sz) && dsh_model_has_adaptive_sens(m, sz)) { r.ok = true; r.model = m; r.size = sz; return r; }
-    // run-time-sized model with a banded lane-per-member twin: state and sensitivity arrays in per-lane memory (BDF)
+    // run-time-sized model with a banded lane-per-member twin: state and sensitivity arrays in per-lane memory
     int twin = -1;
-    if (r.method == 0 && s->problem.eqn->registry_model(&m, &sz) && (twin = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_sens(twin, 0)) { r.ok = true; r.model = twin; r.size = 0; }
+    if (s->problem.eqn->registry_model(&m, &sz) && (twin = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_sens(twin, 0) && dsh_model_has_resident(r.method, twin, 0)) { r.ok = true; r.model = twin; r.size = 0; }  // BDF, TR-BDF2, ESDIRK34
     return r;
   }
   if (s->problem.eqn->has_reset()) {
