@@ -51,7 +51,7 @@ DSH_UNROLL_N
   constexpr int BK = model_band_k<Mdl>::value;
   constexpr bool BANDED = BK > 0;
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
-  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && !BANDED && Mdl::NROOTS > 0;  // hybrid models: events handled in the launch
+  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && Mdl::NROOTS > 0;  // hybrid models: events handled in the launch (the banded lane-per-member form included)
   constexpr int LN = BANDED ? 1 : N;
   __shared__ double sJ[LN * LN][64];
   double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];

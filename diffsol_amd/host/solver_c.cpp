@@ -119,9 +119,9 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     // event, so those models stay on the host-driven solve_dense, which applies the reset and continues
     int m = 0; int64_t sz = 0;
     if (s->problem.eqn->fused_model(&m, &sz) && dsh_model_has_adaptive_reset(m, sz)) { r.ok = true; r.model = m; r.size = sz; return r; }  // BDF, TR-BDF2 and ESDIRK34 alike
-    // run-time-sized banded model: its lane-per-member twin carries the reset through the events as well (BDF: k_bdf_lane_banded)
+    // run-time-sized banded model: its lane-per-member twin carries the reset through the events as well (k_bdf_lane_banded; k_sdirk_resident's banded branch)
     int tw = -1;
-    if (r.method == 0 && s->problem.eqn->registry_model(&m, &sz) && (tw = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_reset(tw, 0)) { r.ok = true; r.model = tw; r.size = 0; }
+    if (s->problem.eqn->registry_model(&m, &sz) && (tw = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_reset(tw, 0) && dsh_model_has_resident(r.method, tw, 0)) { r.ok = true; r.model = tw; r.size = 0; }
     return r;
   }
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it

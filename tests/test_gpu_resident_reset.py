@@ -84,7 +84,8 @@ def test_a_lockstep_group_of_identical_hybrid_members_resets_together(H, O, det_
     assert np.array_equal(mm["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
 
 
-def test_banded_models_carry_their_resets_through_the_lane_per_member_bdf(H, O, det_pow):
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_banded_models_carry_their_resets_through_the_lane_per_member_bdf(H, O, det_pow, method):
     """VERDICT r3 missing 4: resets outside the register-resident forms.  A run-time-sized banded DiffSL model (heat conduction along a rod of 16 cells, heated at the
     left end; n > 8, so its device-resident form is the lane-per-member BDF on per-lane memory, k_bdf_lane_banded) with a reset operator: whenever the right end
     reaches its threshold the rod is quenched (every cell scaled down).  Every member has its own event times; counters, every output bit and every member's last
@@ -109,9 +110,11 @@ def test_banded_models_carry_their_resets_through_the_lane_per_member_bdf(H, O, 
     p = np.stack([rng.uniform(20.0, 60.0, nb), rng.uniform(1.0, 3.0, nb)], axis=1)
     t_eval = [0.0, 0.3, 1.1, 2.0, 3.7, 5.0]
     tol = dict(rtol=1e-6, atol=[1e-8])
-    s = H.Solver(m, p, nbatch=nb, **tol)
+    hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    s = H.Solver(m, p, nbatch=nb, method=hm, **tol)
     y, tot, mm = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
-    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, **tol)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, method=om, **tol)
     lr = O.solve_dense_independent.last_roots
     assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
     assert (lr["root_idx"] == 0).sum() >= nb // 2, "the test wants members with events"
