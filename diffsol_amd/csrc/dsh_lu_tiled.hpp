@@ -192,6 +192,9 @@ template <int RS> using tl_col = typename tl_colvec<RS>::type;
 template <int RS>
 __device__ __forceinline__ double tl_slot(const tl_col<RS>& c, int ss) { return c[ss]; }
 
+// start-up stagger (experiment, profiles/r04_lu_bench.md): workgroup b waits (b & 3) * tl_stagger_ticks ticks of the 100 MHz clock before it starts, so that the CUs do not
+// go through their panel / update phases in step (all in the update at once = HBM contention); 0 = off
+static __device__ int tl_stagger_ticks = 0;
 constexpr int kTlLaP = 49;                // pitch of L11A in LDS
 constexpr int kTlUs = 2400, kTlUsP = 48;  // offset (doubles) of Us in the dynamic LDS (behind L11A [48][49]) and its pitch (conflict-free operand reads)
 

@@ -586,6 +586,10 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
   __shared__ int s_hdr[8], s_flags[1];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tl_stagger_ticks > 0 && (blockIdx.x & 3) != 0 && blockIdx.x < 256) {  // the first round of workgroups only: the ones that follow inherit their CU's phase
+    const unsigned long long t0s = wall_clock64(), waits = (unsigned long long)(blockIdx.x & 3) * (unsigned long long)tl_stagger_ticks;
+    while (wall_clock64() - t0s < waits) __builtin_amdgcn_s_sleep(64);
+  }
   double* const W = w_all + (size_t)blockIdx.x * n * ldw;
   double* const F = f_all + (size_t)blockIdx.x * n * n;
   int32_t* const PIV = piv_all + (size_t)blockIdx.x * n;

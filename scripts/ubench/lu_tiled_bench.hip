@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
   const int reps = argc > 3 ? atoi(argv[3]) : 3;
   const char* kind = argc > 4 ? argv[4] : "dense";
   const int distinct = 4;
+  { const char* e = getenv("TL_STAGGER_US"); const int ticks = e ? atoi(e) * 100 : 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(dsh::tl_stagger_ticks), &ticks, sizeof ticks)); }
   const int ldw = dsh::tiled_ldw(n);
   std::mt19937_64 rng(1234 + n);
   std::normal_distribution<double> nd(0.0, 1.0);
