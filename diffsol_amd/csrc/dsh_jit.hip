@@ -356,6 +356,10 @@ int dsh_model_compile(const char* source, int form, int64_t n, int64_t nparams, 
   rec->source = source;
   rec->info.has_sens = rec->source.find("DSH_JIT_HAS_SENS") != std::string::npos ? 1 : 0;
   rec->info.has_reset = rec->source.find("DSH_JIT_HAS_RESET") != std::string::npos ? 1 : 0;
+  if (rec->source.find("DSH_JIT_JAC_NNZ") != std::string::npos) {
+    const size_t at = rec->source.find("constexpr int kJitJacNnz = ");
+    if (at != std::string::npos) rec->info.jac_nnz = std::atoll(rec->source.c_str() + at + 27);
+  }
   // the stated dimensions must be the ones the source was generated with
   if (form != DSH_JIT_FORM_DYNAMIC)
     rec->source += "\nstatic_assert(dsh::JitModel::N == " + std::to_string(n) + " && dsh::JitModel::NP == " + std::to_string(nparams) + " && dsh::JitModel::NROOTS == " +

@@ -12,6 +12,7 @@ struct JitInfo {
   int64_t n = 0, np = 0, nroots = 0, nout = 0;
   int has_mass = 0;
   int has_reset = 0; // the source carries a reset operator (marker DSH_JIT_HAS_RESET)
+  int64_t jac_nnz = 0; // dynamic form: structural nonzeros of f_y listed in the source (marker DSH_JIT_JAC_NNZ): the dense Jacobian is assembled from them alone
   int has_sens = 0;  // the source carries sens_mul / init_sens_mul (marker DSH_JIT_HAS_SENS written by the front end)
   int jac_kl = -1, jac_ku = -1, mass_kl = -1, mass_ku = -1;
   int twin = -1;  // the same model in the banded lane-per-member form (dsh_model_set_twin): used for device-resident per-member solves  // structural bandwidths declared with dsh_model_set_band (-1: dense / unknown)

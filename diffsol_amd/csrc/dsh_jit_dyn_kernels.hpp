@@ -41,6 +41,18 @@ extern "C" __global__ void k_jit_dyn_jacobian(int64_t nb, double t, const double
     jac[idx] = jit_component(t, (long)i, X, V, P, true);
   }
 }
+// the same entries for the structural nonzeros of f_y only (kJitJacRow / kJitJacCol, written by the front end for large sparse models); the caller zeroes `jac` first
+extern "C" __global__ void k_jit_dyn_jacobian_sparse(int64_t nb, double t, const double* __restrict__ x, const double* __restrict__ p, double* __restrict__ jac) {
+  const int64_t total = (int64_t)kJitJacNnz * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, b = idx % nb;
+    const int64_t i = kJitJacRow[e], j = kJitJacCol[e];
+    const JitVec X{x, nb, b};
+    const JitDir V{nullptr, nb, b, j};
+    const JitVec P{p, nb, b};
+    jac[(j * kJitN + i) * nb + b] = jit_component(t, (long)i, X, V, P, true);
+  }
+}
 extern "C" __global__ void k_jit_dyn_init(int64_t nb, double t, const double* __restrict__ p, double* __restrict__ y) {
   const int64_t total = (int64_t)kJitN * nb;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
