@@ -480,6 +480,10 @@ int dsh_model_precompile(int model_id, int family) {
     const int64_t n = rec->info.n;
     const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
     units.push_back({"dsh_jit_wave_member.hpp", name, {name}});
+    if (rec->info.has_sens && !rec->info.has_mass && rec->info.nroots == 0 && rec->info.np <= 16) {  // with forward sensitivities (dsh_bdf_solve_wave_member_sens)
+      const std::string sname = name.substr(0, name.size() - 1) + ", true>";
+      units.push_back({"dsh_jit_wave_member.hpp", sname, {sname}});
+    }
   }
   else if (!st && family == 3 && rec->info.n <= (rec->info.has_mass ? 48 : 64) && rec->info.nroots <= 2) {  // wavefront-per-member TR-BDF2 / ESDIRK34
     const int64_t n = rec->info.n;

@@ -42,9 +42,38 @@ int dsh_model_has_wave_member(int model, int64_t size) {
   return n >= 1 && n <= 64 ? 1 : (n <= kTeamMaxN ? 2 : 0);
 }
 
+struct WmSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
+static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                      double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens);
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
+}
+// forward sensitivities in the wavefront-per-member BDF (k_bdf_wave_member<.., SENS>): run-time-compiled dense ODE models with parameter derivatives, n <= 64, at most
+// kWmMaxSensParams parameters, no mass matrix, no root functions
+int dsh_model_has_wave_member_sens(int model, int64_t size) {
+  if (!is_jit_model(model) || dsh_model_has_wave_member(model, size) != 1) return 0;
+  const JitInfo* ji = jit_info(model);
+  return ji && ji->has_sens && !ji->has_mass && ji->nroots == 0 && ji->np <= kWmMaxSensParams ? 1 : 0;
+}
+int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                   double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
+                                   int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
+  DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
+  if (!dsh_model_has_wave_member_sens(model, size)) {
+    set_error("dsh_bdf_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 64, at most 16 parameters, no mass matrix, no root functions");
+    return DSH_E_UNSUPPORTED;
+  }
+  for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernel takes one sens_atol for every state");
+  const WmSensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
+  return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, nullptr, nullptr, nullptr, totals_host, &sp);
+}
+static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                      double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
@@ -59,6 +88,8 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   if (rc != DSH_OK) return rc;
   DSH_REQUIRE(np <= (wm_kind == 2 ? (n <= 128 ? 128 : 192) : 64) && nroots <= 2, "wave-member kernel: at most 64 parameters (workgroup form: one per thread) and 2 root functions");
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
+  C.sens_out = sens ? sens->out : nullptr; C.sens_rtol = sens ? sens->rtol : 0.0; C.sens_atol = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
+  C.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.sens_pad = 1;
   C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
@@ -128,13 +159,13 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
   } else {
   int has_mass = 0;
   (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
-  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : (sens ? 64 : 0)));  // xs | ps | sJ | (sM | xs2)  (sensitivities: xs2)
 #define DSH_WM_LAUNCH(NPV)                                                                                                                              \
   hipLaunchKernelGGL((k_bdf_wave_member<NPV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
                      (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
   DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
-    const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ">";
+    const std::string name = std::string("dsh::k_bdf_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + (sens ? ", true>" : ">");
     rc = jit_launch(ctx, model, "dsh_jit_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64), (unsigned)lds_bytes, nb, p, atol, ab,
                     (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }

@@ -201,3 +201,36 @@ def test_banded_lane_per_member_sdirk_with_sensitivities(H, O, det_pow, method, 
         assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
         assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3))), "sensitivities differ"
         assert np.abs(sens).max() > 0
+
+
+@pytest.mark.parametrize("error_control", [None, (1e-6, [1e-7])])
+def test_wavefront_per_member_bdf_with_sensitivities_of_dense_models(H, O, det_pow, error_control):
+    """VERDICT r3 missing 2, second half: forward sensitivities in the wavefront-per-member form (dense run-time-compiled models the register-resident and the banded
+    lane forms do not cover).  k_bdf_wave_member<.., SENS>: a component per lane, J s through the published vectors, the sensitivity solves on the state equations'
+    factors, sdiff_j one row per lane.  Coupled oscillators with a dense coupling block (n = 12 and 20, three parameters) and a dense linear system with one
+    parameter: every counter and every bit of states and sensitivities equal the oracle's solve_dense_sensitivities per member on the host twin."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl as fe
+    from diffsol_amd import _ffi
+    rng = np.random.default_rng(8)
+    nb = 70
+    dense = ("in = [k]\nk { 1.0 }\nA_ij { (0:10, 0:10): -0.05, (0..10, 0..10): -1.0 }\nu_i { (0:10): 1.0 }\nlin_i { A_ij * u_j }\nF_i { k * lin_i + 0.1 * k * k }\n")
+    cases = [(D.oscillators(6), np.stack([rng.uniform(20, 60, nb), rng.uniform(0.5, 2.0, nb), rng.uniform(0.005, 0.02, nb)], axis=1), [0.02, 0.1, 0.3], dict(rtol=1e-6, atol=[1e-8])),
+             (D.oscillators(10), np.stack([rng.uniform(20, 60, nb), rng.uniform(0.5, 2.0, nb), rng.uniform(0.005, 0.02, nb)], axis=1), [0.05, 0.2], dict(rtol=1e-5, atol=[1e-7])),
+             (dense, rng.uniform(0.5, 2.0, (nb, 1)), [0.1, 0.7, 2.0], dict(rtol=1e-7, atol=[1e-9]))]
+    L = _ffi.load_device_lib()
+    for code, p, te, tol in cases:
+        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is None and L.dsh_model_has_wave_member_sens(m.model_id, 0) == 1
+        kw = dict(sens_rtol=error_control[0], sens_atol=error_control[1]) if error_control else {}
+        s = H.Solver(m, p, nbatch=nb, sens=True, **kw, **tol)
+        y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=1, want_member_stats=True)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=1, **kw, **tol)
+        assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
+        assert np.array_equal(mm["stats"].T, sto), "counters differ"
+        assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
+        assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3))), "sensitivities differ"
+        assert np.abs(sens).max() > 0
+    # lock-step groups and models with root functions have no such kernel: refused, not silently routed elsewhere
+    with pytest.raises(Exception):
+        s.solve_dense_adaptive_sens(te, group=64)
