@@ -446,6 +446,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
       col++;
     }
+    if constexpr (kWmResets) {
+      if (reason == 3) {
+        // A reset operator is configured, as in k_sdirk_resident: state_mut_back(t_root) (runge_kutta.rs:396-434), apply_reset (sdirk.rs:368-374 over state.rs:279-306:
+        // y <- reset(y, t), dy <- f(y, t)), the stop time armed again, then Rk::start_step's branch for a mutated state (:444-464: root finder re-initialised, stop
+        // time checked once more) — a one-step method restarts from (t, y, dy, h) as they are
+        const double yb = interpolate(t_root);
+        t = t_root;
+        __syncthreads();
+        xs[ln] = yb;
+        __syncthreads();
+        y = rowlive ? wm_reset_component(t, (int64_t)ln, Xf, Pf) : 0.0;
+        dy = rhs_of(y, t);
+        if (t < tstop) {
+          has_tstop = true;
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          root_of(y, t, g0);
+          rf_t0 = t;
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+        } else done = true;
+        reason = 0;
+      }
+    }
     if (reason == 3) {
       if (col < C.n_eval) {
         const double yv = interpolate(t_root);

@@ -51,6 +51,13 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
   return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
 }
+// hybrid models whose events are handled INSIDE the wavefront-per-member kernels (BDF, TR-BDF2, ESDIRK34: the reset applied at every event, then on to the last save
+// point): run-time-compiled models with a reset operator, root functions and no mass matrix, n <= 64
+int dsh_model_has_wave_member_reset(int model, int64_t size) {
+  if (!is_jit_model(model) || dsh_model_has_wave_member(model, size) != 1) return 0;
+  const JitInfo* ji = jit_info(model);
+  return ji && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? 1 : 0;
+}
 // forward sensitivities in the wavefront-per-member BDF (k_bdf_wave_member<.., SENS>): run-time-compiled dense ODE models with parameter derivatives, n <= 64, at most
 // kWmMaxSensParams parameters, no mass matrix, no root functions
 int dsh_model_has_wave_member_sens(int model, int64_t size) {

@@ -29,7 +29,15 @@ __device__ __forceinline__ double wm_mass_component(double t, int64_t i, XF X, P
 // component i of (df/dp) v (init = false) or of (du0/dp) v (init = true): forward sensitivities (k_bdf_wave_member<.., SENS>)
 template <class XF, class VF, class PF>
 __device__ __forceinline__ double wm_sens_component(double t, int64_t i, XF X, VF V, PF P, bool init) { return jit_sens_component(t, (long)i, X, V, P, init); }
+// hybrid models (DiffSL reset_i): component i of the state after an event; the kernels then apply it at every event and go on (solve_dense with a reset operator,
+// method.rs:774-797) instead of stopping — models without a mass matrix
+constexpr bool kWmResets = kJitHasReset && !kJitHasMass;
+template <class XF, class PF>
+__device__ __forceinline__ double wm_reset_component(double t, int64_t i, XF X, PF P) { return jit_reset_component(t, (long)i, X, P); }
 #else
+constexpr bool kWmResets = false;
+template <class XF, class PF>
+__device__ __forceinline__ double wm_reset_component(double, int64_t i, XF X, PF) { return X(i); }
 template <class XF, class VF, class PF>
 __device__ __forceinline__ double wm_sens_component(double, int64_t, XF, VF, PF, bool) { return 0.0; }  // the built-in run-time-sized models carry no parameter derivatives here
 constexpr bool kWmHasMass = false;
@@ -792,6 +800,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
       col++;
+    }
+    if constexpr (kWmResets) {
+      if (reason == 3) {
+        // A reset operator is configured, as in k_bdf_adaptive / k_bdf_lane_banded: the state goes back to the root (state_mut_back, bdf.rs:1232-1262), y <- reset(y, t),
+        // dy <- f(y, t) (bdf.rs:1017-1020 over state.rs:279-306), the stop time is armed again on the OLD differences and order, and the next step restarts from the
+        // modified state at first order (bdf.rs:1290-1318).  The save points up to the root were written above.
+        const double yb = interpolate(t_root);
+        t = t_root;
+        __syncthreads();
+        xs[ln] = yb;
+        __syncthreads();
+        y = rowlive ? wm_reset_component(t, (int64_t)ln, Xf, Pf) : 0.0;
+        const double dyr = rhs_of(y, t);
+        if (t < tstop) {
+          has_tstop = true;  // set_stop_time (bdf.rs:1591-1600)
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          root_of(y, t, g0);  // RootFinder::init
+          rf_t0 = t;
+          n_equal_steps = 0;
+          order = 1;  // initialise_diff_to_first_order: columns 0 and 1 only, the others keep what they hold
+          D[0] = y; D[1] = dyr * h;
+          opc = h * C.alpha[1];
+          jacobian_updates(h * C.alpha[1], JState::StepSuccess);
+          has_prev_err = false;
+          if (has_tstop) { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          reason = 0;
+        } else {
+          done = true;  // the event sits on the last save point: TstopReached
+          reason = 0;
+        }
+      }
     }
     if (reason == 3) {
       if (col < C.r.n_eval) {

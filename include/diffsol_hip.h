@@ -480,6 +480,10 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
  * One wavefront per member, a component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
  * stay out of the error test).  Other arguments as dsh_bdf_solve_adaptive_sens. */
 int dsh_model_has_wave_member_sens(int model, int64_t size);
+/* 1: the wavefront-per-member kernels (dsh_bdf_solve_wave_member, dsh_sdirk_solve_wave_member) carry this HYBRID model through all its events inside the launch —
+ * reset applied at every root, then on to the last save point (solve_dense with a reset operator, method.rs:774-797); t_root / root_idx report a member's LAST event.
+ * Run-time-compiled models with reset_i, stop_i and no mass matrix, n <= 64. */
+int dsh_model_has_wave_member_reset(int model, int64_t size);
 int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                    double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
                                    int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host);
