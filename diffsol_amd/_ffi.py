@@ -164,6 +164,7 @@ DEVICE_ABI = {
     "dsh_sdirk_solve_resident_sens": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_model_has_wave_member_sens": (cint, [cint, i64]),
     "dsh_model_has_wave_member_reset": (cint, [cint, i64]),
+    "dsh_sdirk_solve_wave_member_sens": (cint, [vp, cint, i64, cint, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_wave_member_sens": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive_sens": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, dbl, c_dp, i64, vp, vp, vp, vp, c_i64p]),
     "dsh_model_has_adaptive_steps": (cint, [cint, i64]),

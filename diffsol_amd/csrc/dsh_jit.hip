@@ -490,6 +490,10 @@ int dsh_model_precompile(int model_id, int family) {
     for (int S = 3; S <= 4; ++S) {
       const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + ">";
       units.push_back({"dsh_jit_sdirk_wave_member.hpp", name, {name}});
+      if (rec->info.has_sens && !rec->info.has_mass && rec->info.nroots == 0 && rec->info.np <= 16) {  // with forward sensitivities (dsh_sdirk_solve_wave_member_sens)
+        const std::string sname = name.substr(0, name.size() - 1) + ", true>";
+        units.push_back({"dsh_jit_sdirk_wave_member.hpp", sname, {sname}});
+      }
     }
   }
   else if (!st) { set_error("dsh_model_precompile: run-time-sized models have the operator kernels and (n <= 64) the wavefront-per-member integrators"); return DSH_E_UNSUPPORTED; }

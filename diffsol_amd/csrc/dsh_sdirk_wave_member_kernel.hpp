@@ -13,7 +13,9 @@ struct WaveSdirkConsts {
   int model, n, np, nroots;
 };
 
-template <int NP, int S>
+// SENS: forward sensitivities of every parameter alongside (run-time-compiled ODE models without a mass matrix and without root functions, at most kWmMaxSensParams
+// parameters): k_sdirk_resident<.., SENS>'s sensitivity code (runge_kutta.rs:196-232, :691-748, :812-822, :1237-1330) with a component per lane.
+template <int NP, int S, bool SENS = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sdirk_wave_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                          const WaveSdirkConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ y_out,
                                                          int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double* ps = lds + 64;
   double* sJ = lds + 128;
   double* sM = sJ + (size_t)Cp->n * 64;
-  double* xs2 = sM + (size_t)Cp->n * 64;
+  double* xs2 = kWmHasMass ? sM + (size_t)Cp->n * 64 : sM;  // (SENS: the direction of J v)
   const SdirkConsts& T = Cp->T;
   const ResidentConsts& C = T.r;
   const dsh_adaptive_options& o = C.o;
@@ -102,6 +104,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int j = 0; j < S; ++j) diff[j] = 0.0;
   double old_y = y, old_dy = dy, old_t = t;
   (void)old_dy;
+  // ---- forward sensitivities: RkState::new_with_sensitivities_and_consistent (state.rs:1032-1083), Rk::new_augmented (runge_kutta.rs:196-232)
+  static_assert(!SENS || !kWmHasMass, "device-resident forward sensitivities: ODE models without a mass matrix");
+  constexpr int SP = SENS ? kWmMaxSensParams : 1, SS = SENS ? S : 1;
+  double sv[SP], dsv[SP], old_sv[SP], old_dsv[SP], sdiff[SP][SS];
+  const int nsp = SENS ? Cp->np : 0;
+  auto X2f = [&](int64_t q) { return xs2[q]; };
+  const double s_atol = T.sens_atol[0];
+  auto wms_sens = [&](double v_mine, double w_mine) __attribute__((always_inline)) -> double {
+    const double term = rowlive ? v_mine / (fabs(w_mine) * T.sens_rtol + s_atol) : 0.0;
+    return seq_sum<NP>(term * term, n) / (double)n;
+  };
+  if constexpr (SENS) {
+    for (int j = 0; j < nsp; ++j) {
+      auto Ej = [&](int64_t q) { return q == j ? 1.0 : 0.0; };
+      __syncthreads();
+      xs[ln] = y;
+      __syncthreads();
+      const double s0 = rowlive ? wm_sens_component(t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+      const double dfdp = rowlive ? wm_sens_component(t, (int64_t)ln, Xf, Ej, Pf, false) : 0.0;  // SensRhs::update_state(y0, t0)
+      xs2[ln] = s0;
+      __syncthreads();
+      const double jm = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, X2f, Pf, true) : 0.0;  // SensRhs::call_inplace: J(y0) s_j + (df/dp)_j
+      const double d0 = jm + dfdp;
+      sv[j] = s0; dsv[j] = d0; old_sv[j] = s0; old_dsv[j] = d0;
+#pragma unroll
+      for (int m = 0; m < S; ++m) sdiff[j][m] = 0.0;
+    }
+  }
   double g0[2] = {1.0, 1.0};
   double rf_t0 = t;
   auto root_of = [&](double x_mine, double tt, double (&g)[2]) __attribute__((always_inline)) {
@@ -185,6 +215,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       n_setups++;
     }
   };
+  if constexpr (SENS) {
+    // Sdirk::new_augmented ends with jacobian_updates(h, Checkpoint) (sdirk.rs:251): with sensitivities the first linearisation is made at construction, at t0 and —
+    // phi still being zero — about gamma y0 (requested here, carried out at the top of the first solve like every other request)
+    if (status == kRsOk) {
+      request_reset(true, y, t);
+      ju.update_rhs_jacobian(h);
+      ju.update_jacobian(h);
+      conv.eta = C.eta_reset;
+      n_setups++;
+    }
+  }
   bool has_tstop = true;
   const double tstop = t_eval[C.n_eval - 1];
   auto handle_tstop = [&]() __attribute__((always_inline)) -> int {  // runge_kutta.rs:752-781: 0 nothing, 1 reached, 2 StopTimeBeforeCurrentTime
@@ -248,7 +289,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double fac = 1.0, error_norm = 0.0;
     double k = 0.0;  // the stage increment being solved for, my component
     while (true) {
-      if (skip_first) diff[0] = hh * dy;  // start_step_attempt (runge_kutta.rs:505-516)
+      if (skip_first) {
+        diff[0] = hh * dy;  // start_step_attempt (runge_kutta.rs:505-516)
+        if constexpr (SENS)
+          for (int j = 0; j < nsp; ++j) sdiff[j][0] = hh * dsv[j];  // "sensitivities too" (:518-523)
+      }
       // The one place where a requested linearisation is carried out.  Requests are made after a step, after a failed attempt (both come back here
       // before the next Newton solve) and by the Checkpoint of the very first solve — whose stage (the first one that runs) and phi are known here.
       if (!is_jacobian_set) {
@@ -304,7 +349,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (solved) {
           old_y = op_c * k + 1.0 * phi;  // get_f_eval
           diff[i] = k;
-        } else {
+          if constexpr (SENS) {
+            // the sensitivity half of do_stage_sdirk (:691-748): SensRhs linearised about this stage's state (old_state.y = f_eval, ts); per parameter phi and the stage
+            // predictor from ITS difference array, a Newton solve of F(k) = k - h (J (phi + c k) + (df/dp)_j) with the factors of the state equations and the shared
+            // Convergence (the norm against s_j with the states' tolerances); the iteration count is added before the failure test
+            for (int j = 0; j < nsp && solved; ++j) {
+              auto Ej = [&](int64_t q) { return q == j ? 1.0 : 0.0; };
+              __syncthreads();
+              xs[ln] = old_y;
+              __syncthreads();
+              const double dfdp = rowlive ? wm_sens_component(ts, (int64_t)ln, Xf, Ej, Pf, false) : 0.0;
+              double sphi;
+              if (i == 0) sphi = sv[j] * 1.0;
+              else {
+                double acc = 1.0 * sdiff[j][0] * T.a[0 * S + i] + 1.0 * sv[j];
+#pragma unroll
+                for (int m = 1; m < i; ++m) acc = 1.0 * sdiff[j][m] * T.a[m * S + i] + acc;
+                sphi = acc;
+              }
+              double ks;
+              if (i == 0) ks = hh * dsv[j];
+              else if (i == 1) ks = sdiff[j][0];
+              else {
+                const double cc = (T.c[i] - T.c[i - 2]) / (T.c[i - 1] - T.c[i - 2]);
+                ks = (-cc) * sdiff[j][i - 2] + (1.0 + cc) * sdiff[j][i - 1];
+              }
+              conv.reset();
+              bool s_solved = false;
+              for (int it = 0; it < conv.max_iter; ++it) {
+                const double tmp2 = op_c * ks + 1.0 * sphi;
+                __syncthreads();
+                xs2[ln] = tmp2;
+                __syncthreads();
+                const double jm = rowlive ? wm_component(model, (int64_t)n, ts, (int64_t)ln, Xf, X2f, Pf, true) : 0.0;
+                const double fr = jm + dfdp;
+                double sdelta = 1.0 * ks + (-op_h) * fr;
+                if (!lu_solve(sdelta)) break;
+                ks = ks - sdelta;
+                const ConvStatus st = conv.check_new_iteration(sqrt(wms_wave(sdelta, sv[j])));
+                if (st == ConvStatus::Converged) { s_solved = true; break; }
+                if (st == ConvStatus::Diverged) break;
+              }
+              n_newton += conv.niter;
+              if (!s_solved) { solved = false; break; }
+              old_sv[j] = op_c * ks + 1.0 * sphi; old_dsv[j] = ks; sdiff[j][i] = ks;
+            }
+          }
+        }
+        if (!solved) {
           if (!updated_jacobian) {
             updated_jacobian = true;
             jacobian_updates(hh, JState::FirstConvergenceFail);
@@ -337,6 +429,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
       if (!lu_solve(err)) { status = kRsTooManyNonlinearSolverFailures; break; }
       error_norm = fmax(0.0, wms_wave(err, y));
+      if constexpr (SENS) {
+        if (T.sens_error_control)  // runge_kutta.rs:812-822 — no linear solve on the sensitivity error estimates
+          for (int j = 0; j < nsp; ++j) {
+            double se = 1.0 * sdiff[j][0] * T.d[0];
+#pragma unroll
+            for (int m = 1; m < S; ++m) se = 1.0 * sdiff[j][m] * T.d[m] + se;
+            error_norm = fmax(error_norm, wms_sens(se, sv[j]));
+          }
+      }
       const double maxiter = (double)conv.max_iter, niter = (double)conv.niter;
       const double safety_factor = (2.0 * maxiter + 1.0) / (2.0 * maxiter + niter);
       {  // Rk::factor (runge_kutta.rs:466-495)
@@ -370,6 +471,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       const double ny = old_y, ndy = k * inv_h;
       old_y = y; old_dy = dy;
       y = ny; dy = ndy;
+      if constexpr (SENS)  // old_ds_j *= 1/h; swap(old_s, s); swap(old_ds, ds)
+        for (int j = 0; j < nsp; ++j) {
+          const double ns_ = old_sv[j], nds = old_dsv[j] * inv_h;
+          old_sv[j] = sv[j]; old_dsv[j] = dsv[j];
+          sv[j] = ns_; dsv[j] = nds;
+        }
       const double nt = t + hh;
       old_t = t;
       t = nt;
@@ -444,6 +551,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     while (col < C.n_eval && t_eval[col] <= upto) {
       const double yv = interpolate(t_eval[col]);
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
+      if constexpr (SENS) {  // interpolate_sens_inplace (runge_kutta.rs:1237-1330): the state's interpolant on (old_s, s, sdiff_j)
+        const double tt = t_eval[col];
+        const double dt = t - old_t;
+        const double theta = dt == 0.0 ? 1.0 : (tt - old_t) / dt;
+        double bf[S];
+        if (T.has_beta) {
+          double thetav[kMaxPoly];
+          thetav[0] = theta;
+#pragma unroll
+          for (int q = 1; q < kMaxPoly; ++q) thetav[q] = theta * thetav[q - 1];
+#pragma unroll
+          for (int i = 0; i < S; ++i) {
+            double acc = 1.0 * T.beta[0 * S + i] * thetav[0];
+#pragma unroll
+            for (int q = 1; q < kMaxPoly; ++q) if (q < T.poly_order) acc = 1.0 * T.beta[q * S + i] * thetav[q] + acc;
+            bf[i] = acc;
+          }
+        }
+        for (int j = 0; j < nsp; ++j) {
+          double ret;
+          if (T.has_beta) {
+            double acc = 1.0 * sdiff[j][0] * bf[0] + 1.0 * old_sv[j];
+#pragma unroll
+            for (int m = 1; m < S; ++m) acc = 1.0 * sdiff[j][m] * bf[m] + acc;
+            ret = acc;
+          } else {
+            double r = sv[j] - old_sv[j];
+            r = (1.0 * (theta - 1.0)) * sdiff[j][0] + (1.0 - 2.0 * theta) * r;
+            r = (1.0 * theta) * sdiff[j][S - 1] + 1.0 * r;
+            r = (1.0 - theta) * old_sv[j] + (theta * (theta - 1.0)) * r;
+            r = theta * sv[j] + 1.0 * r;
+            ret = r;
+          }
+          if (rowlive) T.sens_out[(((int64_t)col * nsp + j) * n + ln) * nb + b] = ret;
+        }
+      }
       col++;
     }
     if constexpr (kWmResets) {
@@ -479,8 +622,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (reason == 1) done = true;
   }
   const int ncols = col;
-  for (; col < C.n_eval; ++col)
+  for (; col < C.n_eval; ++col) {
     if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = __builtin_nan("");
+    if constexpr (SENS)
+      for (int j = 0; j < nsp; ++j)
+        if (rowlive) T.sens_out[(((int64_t)col * nsp + j) * n + ln) * nb + b] = __builtin_nan("");
+  }
   if (ln == 0) {
     if (ncols_out != nullptr) ncols_out[b] = ncols;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");

@@ -199,9 +199,31 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
 // has_wave_member for the SDIRK methods: the wavefront-per-member models (n <= 64); the workgroup-per-member form is BDF only
 int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size) == 1 ? 1 : 0; }
 
+static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                        double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens);
 int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                 double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                                 int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  return sdirk_solve_wave_member_impl(ctx, model, size, method, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
+}
+// forward sensitivities in the wavefront-per-member TR-BDF2 / ESDIRK34 (k_sdirk_wave_member<.., SENS>): the models of dsh_model_has_wave_member_sens
+int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                     double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
+                                     const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
+  DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
+  if (!dsh_model_has_wave_member_sens(model, size)) {
+    set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 64, at most 16 parameters, no mass matrix, no root functions");
+    return DSH_E_UNSUPPORTED;
+  }
+  for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernels take one sens_atol for every state");
+  const WmSensSpec sp{sens_out, sens_rtol, sens_atol_host, nsens_atol};
+  return sdirk_solve_wave_member_impl(ctx, model, size, method, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, nullptr, nullptr, nullptr, totals_host, &sp);
+}
+static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                        double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
+                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(method == 1 || method == 2, "method: 1 TR-BDF2, 2 ESDIRK34");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
@@ -216,6 +238,8 @@ int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int metho
   if (rc != DSH_OK) return rc;
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   fill_tableau(method, C.T);
+  C.T.sens_out = sens ? sens->out : nullptr; C.T.sens_rtol = sens ? sens->rtol : 0.0; C.T.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.T.sens_pad = 1;
+  for (int q = 0; q < 4; ++q) C.T.sens_atol[q] = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
   C.T.r.rtol = rtol; C.T.r.t0 = t0; C.T.r.h0 = h0; C.T.r.n_eval = (int)n_eval;
   C.T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   C.T.r.eta_reset = std::pow(20.0, 1.25);
@@ -235,7 +259,7 @@ int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int metho
   DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
   int has_mass = 0;
   (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
-  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : 0));  // xs | ps | sJ | (sM | xs2)
+  const size_t lds_bytes = sizeof(double) * (128 + (size_t)n * 64 + (has_mass ? (size_t)n * 64 + 64 : (sens ? 64 : 0)));  // xs | ps | sJ | (sM | xs2)  (sensitivities: xs2)
   const int ab = atol_nb == 1 ? 1 : 0;
   const int S = C.T.s;
 #define DSH_WS_LAUNCH(NPV, SV)                                                                                                                                  \
@@ -244,7 +268,7 @@ int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int metho
 #define DSH_WS_LAUNCH_S(NPV) do { if (S == 3) DSH_WS_LAUNCH(NPV, 3); else DSH_WS_LAUNCH(NPV, 4); } while (0)
   DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
-    const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + ">";
+    const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + (sens ? ", true>" : ">");
     rc = jit_launch(ctx, model, "dsh_jit_sdirk_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64), (unsigned)lds_bytes, nb, p, atol, ab,
                     (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }

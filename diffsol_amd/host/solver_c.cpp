@@ -112,8 +112,8 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     // run-time-sized model with a banded lane-per-member twin: state and sensitivity arrays in per-lane memory
     int twin = -1;
     if (s->problem.eqn->registry_model(&m, &sz) && (twin = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_sens(twin, 0) && dsh_model_has_resident(r.method, twin, 0)) { r.ok = true; r.model = twin; r.size = 0; return r; }  // BDF, TR-BDF2, ESDIRK34
-    // dense run-time-compiled model: one wavefront per member (BDF, per member)
-    if (r.method == 0 && group == 1 && s->problem.eqn->registry_model(&m, &sz) && dsh_model_has_wave_member_sens(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+    // dense run-time-compiled model: one wavefront per member (per-member control)
+    if (group == 1 && s->problem.eqn->registry_model(&m, &sz) && dsh_model_has_wave_member_sens(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }  // BDF, TR-BDF2, ESDIRK34
     return r;
   }
   if (s->problem.eqn->has_reset()) {
@@ -308,7 +308,11 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
     check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_dev), "adaptive sens out");
     if (sorted) check(dsh_malloc(c, (int64_t)sizeof(double) * nt * npar * n * nb, 0, &sens_sorted), "adaptive sens out (sorted)");
     const std::vector<double> sa = s->problem.sens_error_control ? s->problem.sens_atol.clone_as_vec() : std::vector<double>();
-    if (wave_member)
+    if (wave_member && method != 0)
+      rc = dsh_sdirk_solve_wave_member_sens(c, model, size, method, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
+                                            s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
+                                            (int32_t*)status_dev, totals);
+    else if (wave_member)
       rc = dsh_bdf_solve_wave_member_sens(c, model, size, nb, params_dev, s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o, t_eval, nt,
                                           s->problem.sens_rtol, sa.data(), (int64_t)sa.size(), out, (double*)(sorted ? sens_sorted : sens_dev), (int32_t*)stats_dev,
                                           (int32_t*)status_dev, totals);

@@ -484,6 +484,11 @@ int dsh_model_has_wave_member_sens(int model, int64_t size);
  * reset applied at every root, then on to the last save point (solve_dense with a reset operator, method.rs:774-797); t_root / root_idx report a member's LAST event.
  * Run-time-compiled models with reset_i, stop_i and no mass matrix, n <= 64. */
 int dsh_model_has_wave_member_reset(int model, int64_t size);
+/* dsh_sdirk_solve_wave_member with forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:691-748) for the models of
+ * dsh_model_has_wave_member_sens; arguments as dsh_sdirk_solve_resident_sens. */
+int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                     double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
+                                     const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host);
 int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                    double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
                                    int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host);

@@ -238,11 +238,10 @@ pub fn solve_dense_sensitivities_ensemble(
     let twin = unsafe { ffi::dsh_model_lane_twin(eqn.model, eqn.size) };
     let (model, size) = if twin >= 0 && unsafe { ffi::dsh_model_has_adaptive_sens(twin, 0) } != 0 { (twin, 0) } else { (eqn.model, eqn.size) };
     let wave_member = unsafe { ffi::dsh_model_has_adaptive_sens(model, size) } == 0
-        && method == Method::Bdf
         && mode == EnsembleMode::PerMember
         && unsafe { ffi::dsh_model_has_wave_member_sens(eqn.model, eqn.size) } != 0;
     if !wave_member && unsafe { ffi::dsh_model_has_adaptive_sens(model, size) } == 0 {
-        return Err(LaError::Other("no device-resident integrator with forward sensitivities for this model (ODE model with parameter derivatives and no root functions: register-resident n <= 4, banded lane form, or dense n <= 64 with BDF per member)".into()));
+        return Err(LaError::Other("no device-resident integrator with forward sensitivities for this model (ODE model with parameter derivatives and no root functions: register-resident n <= 4, banded lane form, or dense n <= 64 per member)".into()));
     }
     let o = adaptive_options(problem, mode);
     let ys = HipMat::zeros(n, nt, ctx.clone());
@@ -258,7 +257,14 @@ pub fn solve_dense_sensitivities_ensemble(
     let mut totals = [0i64; 6];
     let atol = &problem.atol;
     let (srtol, satol): (f64, &[f64]) = sens_tol.unwrap_or((0.0, &[]));
-    let rc = if wave_member {
+    let rc = if wave_member && method != Method::Bdf {
+        unsafe {
+            ffi::dsh_sdirk_solve_wave_member_sens(
+                c, eqn.model, eqn.size, method as i32, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(),
+                nt as i64, srtol, satol.as_ptr(), satol.len() as i64, ys.ptr(), sens_d as *mut f64, stats_d as *mut i32, status_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else if wave_member {
         unsafe {
             ffi::dsh_bdf_solve_wave_member_sens(
                 c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_eval.as_ptr(), nt as i64, srtol,

@@ -203,10 +203,11 @@ def test_banded_lane_per_member_sdirk_with_sensitivities(H, O, det_pow, method, 
         assert np.abs(sens).max() > 0
 
 
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
 @pytest.mark.parametrize("error_control", [None, (1e-6, [1e-7])])
-def test_wavefront_per_member_bdf_with_sensitivities_of_dense_models(H, O, det_pow, error_control):
+def test_wavefront_per_member_bdf_with_sensitivities_of_dense_models(H, O, det_pow, error_control, method):
     """VERDICT r3 missing 2, second half: forward sensitivities in the wavefront-per-member form (dense run-time-compiled models the register-resident and the banded
-    lane forms do not cover).  k_bdf_wave_member<.., SENS>: a component per lane, J s through the published vectors, the sensitivity solves on the state equations'
+    lane forms do not cover).  k_bdf_wave_member<.., SENS> / k_sdirk_wave_member<.., SENS>: a component per lane, J s through the published vectors, the sensitivity solves on the state equations'
     factors, sdiff_j one row per lane.  Coupled oscillators with a dense coupling block (n = 12 and 20, three parameters) and a dense linear system with one
     parameter: every counter and every bit of states and sensitivities equal the oracle's solve_dense_sensitivities per member on the host twin."""
     import diffsl_models as D
@@ -223,9 +224,11 @@ def test_wavefront_per_member_bdf_with_sensitivities_of_dense_models(H, O, det_p
         m, mid = fe.DiffslModel(code), D.host_model(O, code)
         assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is None and L.dsh_model_has_wave_member_sens(m.model_id, 0) == 1
         kw = dict(sens_rtol=error_control[0], sens_atol=error_control[1]) if error_control else {}
-        s = H.Solver(m, p, nbatch=nb, sens=True, **kw, **tol)
+        hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+        om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+        s = H.Solver(m, p, nbatch=nb, sens=True, method=hm, **kw, **tol)
         y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=1, want_member_stats=True)
-        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=1, **kw, **tol)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=1, method=om, **kw, **tol)
         assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
         assert np.array_equal(mm["stats"].T, sto), "counters differ"
         assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
