@@ -548,6 +548,36 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
       col++;
     }
+    if constexpr (kWmResets) {
+      if (reason == 3) {
+        // A reset operator is configured: as in k_bdf_wave_member — state back to the root, y <- reset(y, t), dy <- f(y, t), stop time armed again on the old differences
+        // and order, restart at first order (method.rs:774-797; bdf.rs:1232-1262, :1017-1020, :1290-1318)
+        const double yb = interpolate(t_root);
+        t = t_root;
+        __syncthreads();
+        xs[ln] = yb;
+        __syncthreads();
+        y = rowlive ? wm_reset_component(t, (int64_t)ln, Xf, Pf) : 0.0;
+        const double dyr = rhs_of(y, t);
+        if (t < tstop) {
+          has_tstop = true;
+          { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          root_of(y, t, g0);
+          rf_t0 = t;
+          n_equal_steps = 0;
+          order = 1;
+          D[0] = y; D[1] = dyr * h;
+          opc = h * C.alpha[1];
+          jacobian_updates(h * C.alpha[1], JState::StepSuccess);
+          has_prev_err = false;
+          if (has_tstop) { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
+          reason = 0;
+        } else {
+          done = true;
+          reason = 0;
+        }
+      }
+    }
     if (reason == 3) {
       if (col < C.r.n_eval) {
         const double yv = interpolate(t_root);

@@ -54,9 +54,10 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
 // hybrid models whose events are handled INSIDE the wavefront-per-member kernels (BDF, TR-BDF2, ESDIRK34: the reset applied at every event, then on to the last save
 // point): run-time-compiled models with a reset operator, root functions and no mass matrix, n <= 64
 int dsh_model_has_wave_member_reset(int model, int64_t size) {
-  if (!is_jit_model(model) || dsh_model_has_wave_member(model, size) != 1) return 0;
+  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 1: a wavefront per member (n <= 64); 2: a workgroup per member (64 < n <= 140; BDF)
+  if (kind == 0) return 0;
   const JitInfo* ji = jit_info(model);
-  return ji && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? 1 : 0;
+  return ji && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? kind : 0;
 }
 // forward sensitivities in the wavefront-per-member BDF (k_bdf_wave_member<.., SENS>): run-time-compiled dense ODE models with parameter derivatives, n <= 64, at most
 // kWmMaxSensParams parameters, no mass matrix, no root functions

@@ -125,7 +125,10 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     int tw = -1;
     if (s->problem.eqn->registry_model(&m, &sz) && (tw = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_reset(tw, 0) && dsh_model_has_resident(r.method, tw, 0)) { r.ok = true; r.model = tw; r.size = 0; return r; }
     // dense run-time-compiled hybrid model: the wavefront-per-member kernels handle the events inside the launch as well (per member)
-    if (group == 1 && s->problem.eqn->registry_model(&m, &sz) && dsh_model_has_wave_member_reset(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+    if (group == 1 && s->problem.eqn->registry_model(&m, &sz)) {
+      const int kind = dsh_model_has_wave_member_reset(m, sz);  // 2: the workgroup-per-member form, BDF only
+      if (kind == 1 || (kind == 2 && r.method == 0)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+    }
     return r;
   }
   int twin = -1;  // a run-time-sized model may carry its banded lane-per-member form: per-member / wavefront-group solves use it

@@ -482,7 +482,8 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
 int dsh_model_has_wave_member_sens(int model, int64_t size);
 /* 1: the wavefront-per-member kernels (dsh_bdf_solve_wave_member, dsh_sdirk_solve_wave_member) carry this HYBRID model through all its events inside the launch —
  * reset applied at every root, then on to the last save point (solve_dense with a reset operator, method.rs:774-797); t_root / root_idx report a member's LAST event.
- * Run-time-compiled models with reset_i, stop_i and no mass matrix, n <= 64. */
+ * Run-time-compiled models with reset_i, stop_i and no mass matrix; returns 1 for n <= 64 (a wavefront per member: BDF, TR-BDF2, ESDIRK34), 2 for 64 < n <= 140 (a
+ * workgroup per member: BDF). */
 int dsh_model_has_wave_member_reset(int model, int64_t size);
 /* dsh_sdirk_solve_wave_member with forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:691-748) for the models of
  * dsh_model_has_wave_member_sens; arguments as dsh_sdirk_solve_resident_sens. */
