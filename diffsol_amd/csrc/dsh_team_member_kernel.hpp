@@ -118,7 +118,8 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
   return !singular;
 }
 
-template <int W>
+// SENS: forward sensitivities of every parameter alongside, as in k_bdf_wave_member<.., SENS> (run-time-compiled ODE models without root functions; bdf.rs:370-432, :934-989)
+template <int W, bool SENS = false>
 __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
                                                        int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
@@ -199,6 +200,40 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   for (int j = 0; j < kNC; ++j) { D[j] = 0.0; Dt[j] = 0.0; }
   D[0] = y; D[1] = f0 * h;
   double opc = h * C.alpha[1];
+  // ---- forward sensitivities: new_with_sensitivities_and_consistent (state.rs:1032-1083), new_augmented (bdf.rs:384-432): sdiff_j[:, 0] = s_j, sdiff_j[:, 1] = h ds_j
+  constexpr int SP = SENS ? kWmMaxSensParams : 1, SC = SENS ? kNC : 1;
+  double S[SP][SC], s_cur[SP], s_delta[SP];
+  double s_c = 0.0;  // BdfCallable::c of the sensitivity operator: 0 until the first _update_step_size (op/bdf.rs:61)
+  const int nsp = SENS ? C.np : 0;
+  auto X2f = [&](int64_t k) { return xs2[k]; };
+  // (1/n) sum_i (v_i / (|w_i| sens_rtol + sens_atol))^2, summed in index order
+  auto wms_sens = [&](double v_mine, double w_mine) __attribute__((always_inline)) -> double {
+    const double term = rowlive ? v_mine / (fabs(w_mine) * C.sens_rtol + C.sens_atol) : 0.0;
+    __syncthreads();
+    red[ln] = term * term;
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += red[i];
+    return acc / (double)n;
+  };
+  if constexpr (SENS) {
+    for (int j = 0; j < nsp; ++j) {
+      auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+      __syncthreads();
+      xs[ln] = y;
+      __syncthreads();
+      const double s0 = rowlive ? wm_sens_component(t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+      const double dfdp = rowlive ? wm_sens_component(t, (int64_t)ln, Xf, Ej, Pf, false) : 0.0;  // SensRhs::update_state(y0, t0): column j of df/dp
+      xs2[ln] = s0;
+      __syncthreads();
+      const double jm = rowlive ? wm_component(model, (int64_t)n, t, (int64_t)ln, Xf, X2f, Pf, true) : 0.0;  // SensRhs::call_inplace: J(y0) s_j + (df/dp)_j
+      const double ds = jm + dfdp;
+#pragma unroll
+      for (int k = 0; k < kNC; ++k) S[j][k] = 0.0;
+      S[j][0] = s0; S[j][1] = ds * h;
+      s_cur[j] = s0; s_delta[j] = 0.0;
+    }
+  }
   bool jac_stale = true;
   // The factorisation is by far the largest piece of code of this kernel: every request for a new linearisation only records what the reference
   // would have used (the value of c at that moment; state and time do not change before the next Newton solve) and the one inlined copy of
@@ -279,6 +314,31 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     }
 #pragma unroll
     for (int j = 0; j < kNC; ++j) { const double tmp = D[j]; D[j] = Dt[j]; Dt[j] = tmp; }
+    if constexpr (SENS) {
+      // bdf.rs:546-548: every sdiff goes through the SAME scratch matrix as the states' differences, so the columns behind `order` are handed down the chain
+      for (int q = 0; q < nsp; ++q) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          if (j <= order) {
+            double ru[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              double acc = R[0][k] * U[j * 6 + 0];
+#pragma unroll
+              for (int m = 1; m < 6; ++m) if (m <= order) acc = R[m][k] * U[j * 6 + m] + acc;
+              ru[k] = acc;
+            }
+            double acc = S[q][0] * ru[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k) if (k <= order) acc = S[q][k] * ru[k] + acc;
+            Dt[j] = acc;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kNC; ++j) { const double tmp = S[q][j]; S[q][j] = Dt[j]; Dt[j] = tmp; }
+      }
+      s_c = new_h * C.alpha[order];
+    }
     opc = new_h * C.alpha[order];
     h = new_h;
     eta = C.r.eta_reset_ts;
@@ -408,6 +468,65 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
         if (converged) { solved = true; break; }
       }
       n_newton += niter;
+      if constexpr (SENS) {
+        // sensitivity_solve (bdf.rs:934-989), as in k_bdf_wave_member: per parameter the predictor / psi of its difference array and a Newton solve of
+        // F(s) = (s - s0 + psi) - c_s (J s + (df/dp)_j) with the factors of the state equations and the SHARED Convergence
+        if (solved) {
+          for (int j = 0; j < nsp && solved; ++j) {
+            auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+            __syncthreads();
+            xs[ln] = yp;
+            __syncthreads();
+            const double dfdp = rowlive ? wm_sens_component(t_predict, (int64_t)ln, Xf, Ej, Pf, false) : 0.0;
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k <= order) sacc = sacc + S[j][k];
+            double q = C.gamma[1] * S[j][1];
+#pragma unroll
+            for (int k = 2; k < 6; ++k) if (k <= order) q = C.gamma[k] * S[j][k] + 1.0 * q;
+            q = q * C.alpha[order];
+            q = q - sacc;
+            const double sp = sacc, spsi = q;
+            double xsv = sacc;
+            int sn = 0;
+            bool s_has_old = false, s_solved = false;
+            double s_old_norm = 0.0;
+            for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
+              __syncthreads();
+              xs2[ln] = xsv;
+              __syncthreads();
+              const double jm = rowlive ? wm_component(model, (int64_t)n, t_predict, (int64_t)ln, Xf, X2f, Pf, true) : 0.0;
+              __syncthreads();  // xs2 is the solve's exchange buffer next
+              const double fr = jm + dfdp;
+              double delta = 1.0 * (xsv + spsi) + (-s_c) * fr;
+              const bool lu_ok = team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, delta);
+              if (!lu_ok) break;
+              xsv = xsv - delta;
+              const double norm = sqrt(wms_wave(delta, sp));
+              sn += 1;
+              bool diverged = false;
+              if (s_has_old) {
+                const double rate = sn == 2 ? norm / s_old_norm : rpow(norm / s_old_norm, 1.0 / (double)(sn - 1), det);
+                if (rate > 0.9) diverged = true;
+                else if (powi_rt(rate, o.max_nonlinear_solver_iterations - sn) / (1.0 - rate) * norm > o.nonlinear_solver_tolerance) diverged = true;
+                else eta = rate / (1.0 - rate);
+              } else {
+                const double min_eta = 1e4 * kEps;
+                if (eta < min_eta) eta = min_eta;
+                eta = rpow(eta, 0.8, det);
+              }
+              const bool converged = !diverged && eta * norm < o.nonlinear_solver_tolerance;
+              if (sn == 1) { s_has_old = true; s_old_norm = norm; }
+              if (diverged) break;
+              if (converged) { s_solved = true; break; }
+            }
+            niter = sn;  // Convergence::niter is the last solve's: the safety factor below reads it
+            if (!s_solved) { solved = false; break; }  // `?` before the iteration count is added
+            n_newton += sn;
+            s_cur[j] = xsv; s_delta[j] = xsv - sp;
+          }
+        }
+      }
       if (!solved) {
         n_nl_fails += 1;
         if (n_nl_fails > o.max_nonlinear_solver_failures) { status = kRsTooManyNonlinearSolverFailures; break; }
@@ -425,6 +544,10 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
       }
       const double ydelta = x - yp;
       error_norm = fmax(0.0, wms_wave(ydelta, y) * C.ec2[order - 1]);
+      if constexpr (SENS) {
+        if (C.sens_error_control)  // bdf.rs:844-858 — error_const2[order], not [order - 1]
+          for (int j = 0; j < nsp; ++j) error_norm = fmax(error_norm, wms_sens(s_delta[j], s_cur[j]) * C.ec2[order]);
+      }
       const double maxiter = (double)o.max_nonlinear_solver_iterations;
       safety = 0.9 * (2.0 * maxiter + 1.0) / (2.0 * maxiter + (double)niter);
       if (error_norm <= 1.0) {
@@ -437,6 +560,20 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
         double upper = ydelta;
 #pragma unroll
         for (int j = 5; j >= 0; --j) if (j <= order) { const double v = D[j] + 1.0 * upper; D[j] = v; upper = v; }
+        if constexpr (SENS) {  // update_differences_and_integrate_out (bdf.rs:628-643): _update_diff on every sensitivity difference array
+          for (int q = 0; q < nsp; ++q) {
+            const double sd = s_delta[q];
+            double sk1 = 0.0;
+#pragma unroll
+            for (int j = 2; j < 7; ++j) if (j == order + 1) sk1 = S[q][j];
+            const double sk2 = sd - sk1;
+#pragma unroll
+            for (int j = 2; j < kNC; ++j) { if (j == order + 2) S[q][j] = sk2; if (j == order + 1) S[q][j] = sd; }
+            double up = sd;
+#pragma unroll
+            for (int j = 5; j >= 0; --j) if (j <= order) { const double v = S[q][j] + 1.0 * up; S[q][j] = v; up = v; }
+          }
+        }
         y = yp;
         t = t_predict;
         break;
@@ -461,8 +598,20 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
 #pragma unroll
       for (int j = 1; j < kNC; ++j) { if (j == order) vm = D[j]; if (j == order + 2) vp = D[j]; }
       const double inf = __builtin_huge_val();
-      const double error_m_norm = order > 1 ? wms_wave(vm, y) * C.ec2[order - 1] : inf;
-      const double error_p_norm = order < kMaxOrder ? wms_wave(vp, y) * C.ec2[order + 1] : inf;
+      double error_m_norm = order > 1 ? wms_wave(vm, y) * C.ec2[order - 1] : inf;
+      double error_p_norm = order < kMaxOrder ? wms_wave(vp, y) * C.ec2[order + 1] : inf;
+      if constexpr (SENS) {  // predict_error_control with the augmented system (bdf.rs:871-932): the `error_norm.max(err)` chain from zero, then the sensitivities' terms
+        if (order > 1) error_m_norm = fmax(0.0, error_m_norm);
+        if (order < kMaxOrder) error_p_norm = fmax(0.0, error_p_norm);
+        if (C.sens_error_control)
+          for (int q = 0; q < nsp; ++q) {
+            double cm = 0.0, cp = 0.0;
+#pragma unroll
+            for (int j = 1; j < kNC; ++j) { if (j == order) cm = S[q][j]; if (j == order + 2) cp = S[q][j]; }
+            if (order > 1) error_m_norm = fmax(error_m_norm, wms_sens(cm, s_cur[q]) * C.ec2[order - 1]);
+            if (order < kMaxOrder) error_p_norm = fmax(error_p_norm, wms_sens(cp, s_cur[q]) * C.ec2[order + 1]);
+          }
+      }
       const double pi_i = o.pi_control_integral, pi_p = o.pi_control_proportional;
       const double f0c = pi_controller_raw(error_m_norm, has_prev_err, prev_err, pi_i, pi_p, order, det);
       const double f1c = pi_controller_raw(error_norm, has_prev_err, prev_err, pi_i, pi_p, order + 1, det);
@@ -546,6 +695,22 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     while (col < C.r.n_eval && t_eval[col] <= upto) {
       const double yv = interpolate(t_eval[col]);
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
+      if constexpr (SENS) {  // interpolate_sens (bdf.rs:1162-1215): the same polynomial on every sensitivity difference array
+        const double te = t_eval[col];
+        for (int q = 0; q < nsp; ++q) {
+          double time_factor = 1.0;
+          double sv = S[q][0];
+#pragma unroll
+          for (int j = 0; j < kMaxOrder; ++j) {
+            if (j < order) {
+              const double jt = (double)j;
+              time_factor *= (te - (t - h * jt)) / (h * (1.0 + jt));
+              sv = time_factor * S[q][j + 1] + 1.0 * sv;
+            }
+          }
+          if (rowlive) C.sens_out[(((int64_t)col * nsp + q) * n + ln) * nb + b] = sv;
+        }
+      }
       col++;
     }
     if constexpr (kWmResets) {
@@ -589,8 +754,12 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     if (reason == 1) done = true;
   }
   const int ncols = col;
-  for (; col < C.r.n_eval; ++col)
+  for (; col < C.r.n_eval; ++col) {
     if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = __builtin_nan("");
+    if constexpr (SENS)
+      for (int q = 0; q < nsp; ++q)
+        if (rowlive) C.sens_out[(((int64_t)col * nsp + q) * n + ln) * nb + b] = __builtin_nan("");
+  }
   if (ln == 0) {
     if (ncols_out != nullptr) ncols_out[b] = ncols;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");

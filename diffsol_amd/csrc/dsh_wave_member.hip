@@ -62,9 +62,10 @@ int dsh_model_has_wave_member_reset(int model, int64_t size) {
 // forward sensitivities in the wavefront-per-member BDF (k_bdf_wave_member<.., SENS>): run-time-compiled dense ODE models with parameter derivatives, n <= 64, at most
 // kWmMaxSensParams parameters, no mass matrix, no root functions
 int dsh_model_has_wave_member_sens(int model, int64_t size) {
-  if (!is_jit_model(model) || dsh_model_has_wave_member(model, size) != 1) return 0;
+  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 2: the workgroup-per-member BDF (64 < n <= 140)
+  if (kind == 0) return 0;
   const JitInfo* ji = jit_info(model);
-  return ji && ji->has_sens && !ji->has_mass && ji->nroots == 0 && ji->np <= kWmMaxSensParams ? 1 : 0;
+  return ji && ji->has_sens && !ji->has_mass && ji->nroots == 0 && ji->np <= kWmMaxSensParams ? kind : 0;
 }
 int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                    double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
@@ -72,7 +73,7 @@ int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_wave_member_sens(model, size)) {
-    set_error("dsh_bdf_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 64, at most 16 parameters, no mass matrix, no root functions");
+    set_error("dsh_bdf_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 140, at most 16 parameters, no mass matrix, no root functions");
     return DSH_E_UNSUPPORTED;
   }
   for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernel takes one sens_atol for every state");
@@ -145,7 +146,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     DSH_HIP_CHECK(timing_begin(ctx));
     if (is_jit_model(model)) {
-      const std::string name = std::string("dsh::k_bdf_team_member<") + (waves == 2 ? "2" : "3") + ">";
+      const std::string name = std::string("dsh::k_bdf_team_member<") + (waves == 2 ? "2" : "3") + (sens ? ", true>" : ">");
       rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
                       (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
       if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -214,7 +215,7 @@ int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int 
                                      const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
-  if (!dsh_model_has_wave_member_sens(model, size)) {
+  if (dsh_model_has_wave_member_sens(model, size) != 1) {
     set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 64, at most 16 parameters, no mass matrix, no root functions");
     return DSH_E_UNSUPPORTED;
   }

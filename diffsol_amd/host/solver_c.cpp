@@ -113,7 +113,10 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     int twin = -1;
     if (s->problem.eqn->registry_model(&m, &sz) && (twin = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_sens(twin, 0) && dsh_model_has_resident(r.method, twin, 0)) { r.ok = true; r.model = twin; r.size = 0; return r; }  // BDF, TR-BDF2, ESDIRK34
     // dense run-time-compiled model: one wavefront per member (per-member control)
-    if (group == 1 && s->problem.eqn->registry_model(&m, &sz) && dsh_model_has_wave_member_sens(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }  // BDF, TR-BDF2, ESDIRK34
+    if (group == 1 && s->problem.eqn->registry_model(&m, &sz)) {
+      const int kind = dsh_model_has_wave_member_sens(m, sz);  // 1: BDF, TR-BDF2, ESDIRK34; 2 (64 < n <= 140): BDF
+      if (kind == 1 || (kind == 2 && r.method == 0)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+    }
     return r;
   }
   if (s->problem.eqn->has_reset()) {

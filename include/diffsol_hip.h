@@ -476,8 +476,8 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* dsh_bdf_solve_wave_member with FORWARD SENSITIVITIES of every parameter (problem.bdf_sens(), bdf.rs:370-432, :934-989) for dense run-time-compiled ODE models the
- * register-resident and the banded lane forms do not cover: n <= 64, at most 16 parameters, no mass matrix, no root functions (dsh_model_has_wave_member_sens).
- * One wavefront per member, a component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
+ * register-resident and the banded lane forms do not cover: n <= 140, at most 16 parameters, no mass matrix, no root functions (dsh_model_has_wave_member_sens: 1 for
+ * n <= 64 — one wavefront per member, BDF and the SDIRK methods — 2 for 64 < n <= 140 — one workgroup per member, BDF).  A component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
  * stay out of the error test).  Other arguments as dsh_bdf_solve_adaptive_sens. */
 int dsh_model_has_wave_member_sens(int model, int64_t size);
 /* 1: the wavefront-per-member kernels (dsh_bdf_solve_wave_member, dsh_sdirk_solve_wave_member) carry this HYBRID model through all its events inside the launch —
