@@ -242,6 +242,70 @@ __global__ __launch_bounds__(64) void k_squared_norm_wide(int64_t n, int64_t nb,
   block_publish(bits, 0ull, 0ull, rec, seq);
 }
 
+// Third form of the same norm, for the same ensembles: one WORKGROUP of four wavefronts per 8 members.  k_squared_norm_wide is one wavefront, one instruction
+// stream: its loads, its 64 divisions per lane and its additions stand in line (26 us at n = 512 x 4096).  Here the 256 lanes are 32 row groups x 8 members, each
+// lane has 16 rows of a 512-row block in flight at once and divides 16 times; the terms go to LDS in [row][member] order and 8 lanes of wavefront 0 add them up in
+// index order — same terms, same order of additions: the same bits.  SUB as in k_squared_norm_wide.
+constexpr int kNormTeamThreads = 256, kNormTeamRows = 512;
+template <bool BY, bool BA, bool SUB = false>
+__global__ __launch_bounds__(kNormTeamThreads) void k_squared_norm_team(int64_t n, int64_t nb, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ atol,
+                                                                        double rtol, unsigned long long* rec, unsigned int seq, double* __restrict__ per_batch,
+                                                                        const double* xin = nullptr, double* xout = nullptr) {
+  constexpr int S = 8, G = kNormTeamThreads / S, RB = kNormTeamRows, QL = RB / G;
+  __shared__ double sT[RB * S];  // term of row t, member s at t * S + s
+  const int tid = threadIdx.x, s = tid % S, g = tid / S;
+  const int64_t b0 = (int64_t)blockIdx.x * S + s;
+  const bool valid = b0 < nb;
+  const int64_t b = valid ? b0 : nb - 1;
+  double acc = 0.0;
+  for (int64_t r0 = 0; r0 < n; r0 += RB) {
+    double xa[QL], ya[QL], aa[QL], ia[SUB ? QL : 1];
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const int64_t r = min(r0 + q * G + g, n - 1);  // clamped: components past the end are not added
+      xa[q] = x[r * nb + b];
+      if constexpr (SUB) ia[q] = xin[r * nb + b];
+      ya[q] = BY ? y[r] : y[r * nb + b];
+      aa[q] = BA ? atol[r] : atol[r * nb + b];
+    }
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      if constexpr (SUB) { const int64_t r = r0 + q * G + g; if (valid && r < n) xout[r * nb + b] = ia[q] - xa[q]; }
+      const double term = xa[q] / (fabs(ya[q]) * rtol + aa[q]);
+      sT[(q * G + g) * S + s] = term * term;
+    }
+    __syncthreads();
+    if (tid < S) {
+      const int cnt = (int)min((int64_t)RB, n - r0);
+      int t = 0;
+      for (; t + 16 <= cnt; t += 16) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sT[(t + k) * S + s];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+      }
+      for (; t < cnt; ++t) acc += sT[t * S + s];
+    }
+    __syncthreads();
+  }
+  unsigned long long bits = 0ull;
+  if (tid < S && valid) {
+    const double nrm = acc / (double)n;
+    if (per_batch) per_batch[b0] = nrm;
+    bits = d2u(nrm);
+  }
+  block_publish(bits, 0ull, 0ull, rec, seq);
+}
+
+// which of the two small-ensemble forms (DSH_NORM_TEAM=0 / 1 forces one).  Measured at n = 512 x 4096 (profiles/r04_c3_kernel_stats.md): with the Newton update
+// in the same pass (SUB: four vectors) 23.7 us against 26.1; the norm alone 15.4 against 14.1 — both forms are one memory pass followed by what is left of the
+// 512-addition chain, so the workgroup form is taken for the fused update only, from 256 rows on
+static bool norm_team(int64_t n, bool sub) {
+  static const int env = [] { const char* e = std::getenv("DSH_NORM_TEAM"); return e && *e ? std::atoi(e) : -1; }();
+  return env >= 0 ? env != 0 : (sub && n >= 256);
+}
+
 __global__ void k_norm(int64_t n, int64_t nb, const double* __restrict__ x, int k, unsigned long long* rec, unsigned int seq) {
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long bits = 0ull;
@@ -444,6 +508,13 @@ int vec_sub_squared_norm_launch(dsh_ctx* ctx, int64_t n, int64_t nb, const doubl
   if (rc != DSH_OK) return rc;
   double* none = nullptr;
   if (wide) {
+    if (norm_team(n, true)) {
+      const dim3 tb(kNormTeamThreads);
+      if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_team<false, false, true>), g, tb, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+      else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_team<true, false, true>), g, tb, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+      else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_team<false, true, true>), g, tb, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+      else hipLaunchKernelGGL((k_squared_norm_team<true, true, true>), g, tb, 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
+    } else
     if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<false, false, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
     else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<true, false, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
     else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_wide<false, true, true>), g, dim3(64), 0, ctx->stream, n, nb, delta, y, atol, rtol, rec, seq, none, xin, xout);
@@ -475,6 +546,13 @@ int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, c
   if (rc != DSH_OK) return rc;
   bool by = ynb == 1 && nb != 1, ba = anb == 1 && nb != 1;
   if (wide) {
+    if (norm_team(n, false)) {
+      const dim3 tb(kNormTeamThreads);
+      if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_team<false, false>), g, tb, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+      else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_team<true, false>), g, tb, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+      else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_team<false, true>), g, tb, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+      else hipLaunchKernelGGL((k_squared_norm_team<true, true>), g, tb, 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
+    } else
     if (!by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<false, false>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
     else if (by && !ba) hipLaunchKernelGGL((k_squared_norm_wide<true, false>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);
     else if (!by && ba) hipLaunchKernelGGL((k_squared_norm_wide<false, true>), g, dim3(64), 0, ctx->stream, n, nb, x, y, atol, rtol, rec, seq, per_batch_dev);

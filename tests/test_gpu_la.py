@@ -276,10 +276,10 @@ def test_matrix_ops_match_numpy(H, ctx1, nb):
     assert np.allclose(ref, x @ ru[0], rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("n,nb", [(128, 8), (130, 3), (512, 37), (1000, 9), (161, 64)])
+@pytest.mark.parametrize("n,nb", [(128, 8), (130, 3), (512, 37), (1000, 9), (161, 64), (256, 5), (513, 12), (1537, 3)])
 def test_norm_of_long_vectors_in_small_ensembles_keeps_the_sequential_summation_bits(H, ctx1, n, nb):
     """n >= 128 and at most 16 384 members run k_squared_norm_wide (8 members per wavefront, the terms of 32 components computed on all 64 lanes, the additions in
-    index order on one row group): every member's value bit for bit the sequential sum, for member counts and lengths that are not multiples of the tile; all four
+    index order on one row group), from 256 components on k_squared_norm_team (a workgroup per 8 members, 512-row blocks): every member's value bit for bit the sequential sum, for member counts and lengths that are not multiples of the tile; all four
     broadcast combinations of y and atol; per-member atol; NaN propagation."""
     rng = np.random.default_rng(n + nb)
     c = ctx1.clone_with_nbatch(nb)
