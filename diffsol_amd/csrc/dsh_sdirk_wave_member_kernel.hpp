@@ -3,7 +3,7 @@
 // pieces of k_bdf_wave_member (dsh_wave_member_kernel.hpp): lane i holds component i of the state, of every stage increment and its row of the LU
 // factors; the state is published through LDS for the model's component functions; norms are summed in index order.  Launch code: dsh_wave_member.hip.
 #pragma once
-#include "dsh_wave_member_kernel.hpp"
+#include "dsh_team_member_kernel.hpp"
 #include "dsh_sdirk_kernel.hpp"
 
 namespace dsh {
@@ -15,17 +15,30 @@ struct WaveSdirkConsts {
 
 // SENS: forward sensitivities of every parameter alongside (run-time-compiled ODE models without a mass matrix and without root functions, at most kWmMaxSensParams
 // parameters): k_sdirk_resident<.., SENS>'s sensitivity code (runge_kutta.rs:196-232, :691-748, :812-822, :1237-1330) with a component per lane.
-template <int NP, int S, bool SENS = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sdirk_wave_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
+// TW > 0: ONE WORKGROUP of TW wavefronts per member (64 < n <= 140, identity mass) — the same integrator on k_bdf_team_member's pieces (dsh_team_member_kernel.hpp):
+// thread i holds component i, the factors of M - (c h) f' live in LDS (team_lu_factor / team_lu_solve), the cached Jacobian in global scratch (jac_scratch, n^2 doubles
+// per member), norms are summed in index order from LDS.  NP is then only the size of an unused register row.
+template <int NP, int S, bool SENS = false, int TW = 0>
+__global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sdirk_wave_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                          const WaveSdirkConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ y_out,
                                                          int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
-                                                         int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
-  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64] | with a mass matrix: sM[n][64] | xs2[64]
+                                                         int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals,
+                                                         double* __restrict__ jac_scratch) {
+  constexpr bool TEAM = TW > 0;
+  constexpr int TT = TEAM ? 64 * TW : 64;  // threads = rows
+  static_assert(!TEAM || !kWmHasMass, "the workgroup-per-member form takes identity-mass models");
+  extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64] | with a mass matrix: sM[n][64] | xs2[64];  TEAM: xs[TT] | xs2[TT] | ps[TT] | cand[2 TW] | perm[TT] (int) | A[n][P]
   double* xs = lds;
-  double* ps = lds + 64;
-  double* sJ = lds + 128;
+  double* ps = TEAM ? lds + 2 * TT : lds + 64;
+  double* sJ = TEAM ? jac_scratch + (size_t)blockIdx.x * Cp->n * Cp->n : lds + 128;  // TEAM: entry (ln, j) at j * n + ln
   double* sM = sJ + (size_t)Cp->n * 64;
-  double* xs2 = kWmHasMass ? sM + (size_t)Cp->n * 64 : sM;  // (SENS: the direction of J v)
+  double* xs2 = TEAM ? lds + TT : (kWmHasMass ? sM + (size_t)Cp->n * 64 : sM);  // (SENS: the direction of J v; TEAM: also the LU solve's exchange and the norms' terms)
+  double* const cand = lds + 3 * TT;
+  int* const perm = reinterpret_cast<int*>(lds + 3 * TT + 2 * (TEAM ? TW : 1));
+  double* const A = lds + 3 * TT + 2 * (TEAM ? TW : 1) + TT / 2;
+  const int P = team_pitch(Cp->n);
+  bool lu_singular = false;
+  (void)cand; (void)perm; (void)A; (void)P; (void)lu_singular;
   const SdirkConsts& T = Cp->T;
   const ResidentConsts& C = T.r;
   const dsh_adaptive_options& o = C.o;
@@ -47,9 +60,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __syncthreads();
     return rowlive ? wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, V0, Pf, false) : 0.0;
   };
+  // (1/n) sum of squares in index order; TEAM: every thread the same sequential sum over the terms in LDS
+  auto sum_terms = [&](double term) __attribute__((always_inline)) -> double {
+    if constexpr (TEAM) {
+      __syncthreads();
+      xs2[ln] = term * term;
+      __syncthreads();
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i) acc += xs2[i];
+      return acc / (double)n;
+    } else {
+      return seq_sum<NP>(term * term, n) / (double)n;
+    }
+  };
   auto wms_wave = [&](double v_mine, double w_mine) __attribute__((always_inline)) -> double {
     const double term = rowlive ? v_mine / (fabs(w_mine) * rtol + atol) : 0.0;
-    return seq_sum<NP>(term * term, n) / (double)n;
+    return sum_terms(term);
   };
 
   // ------------------------------------------------------------ RkState::new_and_consistent(problem, tableau.order()): identity mass, set_step_size
@@ -60,9 +86,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   double a[NP];  // my row of the LU factors (InitOp's during the consistent initialisation, of M - (c h) f' afterwards)
   int pos = ln, myinv = ln;
   auto lu_solve = [&](double& v) __attribute__((always_inline)) -> bool {
-    const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
-    v = __shfl(v, myinv, 64);
-    return ok;
+    if constexpr (TEAM) {
+      __syncthreads();  // xs2 may still be read as the direction of a Jacobian product
+      return team_lu_solve<TW>(A, P, n, ln, rowlive, perm, xs2, lu_singular, v);  // unknown i comes back to thread i
+    } else {
+      const bool ok = wave_lu_solve_rows<NP>(a, n, rowlive, pos, v);
+      v = __shfl(v, myinv, 64);
+      return ok;
+    }
   };
   if constexpr (kWmHasMass) {  // DAEs: consistent initial state (shared with k_bdf_wave_member)
     auto factor_init = [&]() __attribute__((always_inline)) {
@@ -113,7 +144,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const double s_atol = T.sens_atol[0];
   auto wms_sens = [&](double v_mine, double w_mine) __attribute__((always_inline)) -> double {
     const double term = rowlive ? v_mine / (fabs(w_mine) * T.sens_rtol + s_atol) : 0.0;
-    return seq_sum<NP>(term * term, n) / (double)n;
+    return sum_terms(term);
   };
   if constexpr (SENS) {
     for (int j = 0; j < nsp; ++j) {
@@ -179,12 +210,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       __syncthreads();
       for (int j = 0; j < n; ++j) {
         auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-        sJ[j * 64 + ln] = rowlive ? wm_component(model, (int64_t)n, lin_t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
+        if constexpr (TEAM) { if (rowlive) sJ[(size_t)j * n + ln] = wm_component(model, (int64_t)n, lin_t, (int64_t)ln, Xf, Ej, Pf, true); }
+        else sJ[j * 64 + ln] = rowlive ? wm_component(model, (int64_t)n, lin_t, (int64_t)ln, Xf, Ej, Pf, true) : 0.0;
         if constexpr (kWmHasMass) sM[j * 64 + ln] = rowlive ? wm_mass_component(lin_t, (int64_t)ln, Ej, Pf) : 0.0;  // the mass matrix is evaluated with the Jacobian (op/sdirk.rs:266-296)
       }
       eval_pending = false;
     }
     const double beta = -(op_c * factor_h);
+    if constexpr (TEAM) {  // A = J * beta + I, my row; the factorisation in LDS
+      if (rowlive)
+        for (int j = 0; j < n; ++j) A[j * P + ln] = sJ[(size_t)j * n + ln] * beta + (j == ln ? 1.0 : 0.0);
+      team_lu_factor<TW>(A, P, n, ln, rowlive, cand, perm, lu_singular);
+      factor_pending = false;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       double m = j == ln ? 1.0 : 0.0;

@@ -199,7 +199,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
 }
 
 // has_wave_member for the SDIRK methods: the wavefront-per-member models (n <= 64); the workgroup-per-member form is BDF only
-int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size) == 1 ? 1 : 0; }
+int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_has_wave_member(model, size); }  // 1: a wavefront per member; 2: a workgroup per member (k_sdirk_wave_member<.., TW>)
 
 static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                         double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
@@ -215,8 +215,8 @@ int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int 
                                      const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
-  if (dsh_model_has_wave_member_sens(model, size) != 1) {
-    set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 64, at most 16 parameters, no mass matrix, no root functions");
+  if (!dsh_model_has_wave_member_sens(model, size)) {
+    set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 140, at most 16 parameters, no mass matrix, no root functions");
     return DSH_E_UNSUPPORTED;
   }
   for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernels take one sens_atol for every state");
@@ -232,7 +232,8 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  if (!dsh_model_has_wave_member_sdirk(model, size)) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  const int wm_kind = dsh_model_has_wave_member_sdirk(model, size);  // 2: one workgroup per member (64 < n <= 140, identity mass)
+  if (!wm_kind) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; 64 < n <= 140 without one) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveSdirkConsts C;
   int64_t n = 0, np = 0, nroots = 0;
@@ -266,13 +267,43 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   const int S = C.T.s;
 #define DSH_WS_LAUNCH(NPV, SV)                                                                                                                                  \
   hipLaunchKernelGGL((k_sdirk_wave_member<NPV, SV>), dim3((unsigned)nb), dim3(64), lds_bytes, ctx->stream, nb, p, atol, ab, (const WaveSdirkConsts*)consts_dev, \
-                     (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+                     (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, (double*)nullptr)
 #define DSH_WS_LAUNCH_S(NPV) do { if (S == 3) DSH_WS_LAUNCH(NPV, 3); else DSH_WS_LAUNCH(NPV, 4); } while (0)
+  double* jac_scratch = nullptr;
   DSH_HIP_CHECK(timing_begin(ctx));
+  if (wm_kind == 2) {
+    // one workgroup per member (64 < n <= 140): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member) — k_sdirk_wave_member<.., TW>
+    const int waves = n <= 128 ? 2 : 3;
+    const size_t lds_team = sizeof(double) * team_lds_doubles((int)n, waves);
+    rc = dsh_malloc(ctx, (int64_t)sizeof(double) * n * n * nb, 0, (void**)&jac_scratch);
+    if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+    if (is_jit_model(model)) {
+      const std::string name = std::string("dsh::k_sdirk_wave_member<16, ") + std::to_string(S) + (sens ? ", true, " : ", false, ") + (waves == 2 ? "2>" : "3>");
+      rc = jit_launch(ctx, model, "dsh_jit_sdirk_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
+                      (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, jac_scratch);
+      if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+    } else {
+      static bool attr_dev[64] = {false};
+      bool& attr = attr_dev[ctx->device & 63];
+      if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdirk_wave_member<16, 3, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdirk_wave_member<16, 3, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdirk_wave_member<16, 4, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdirk_wave_member<16, 4, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+      }
+#define DSH_TS_LAUNCH(SV, TWV)                                                                                                                                          \
+  hipLaunchKernelGGL((k_sdirk_wave_member<16, SV, false, TWV>), dim3((unsigned)nb), dim3(64 * TWV), lds_team, ctx->stream, nb, p, atol, ab, (const WaveSdirkConsts*)consts_dev, \
+                     (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, jac_scratch)
+      if (S == 3) { if (waves == 2) DSH_TS_LAUNCH(3, 2); else DSH_TS_LAUNCH(3, 3); }
+      else { if (waves == 2) DSH_TS_LAUNCH(4, 2); else DSH_TS_LAUNCH(4, 3); }
+#undef DSH_TS_LAUNCH
+    }
+  } else
   if (is_jit_model(model)) {
     const std::string name = std::string("dsh::k_sdirk_wave_member<") + (n <= 16 ? "16" : n <= 32 ? "32" : n <= 48 ? "48" : "64") + ", " + std::to_string(S) + (sens ? ", true>" : ">");
     rc = jit_launch(ctx, model, "dsh_jit_sdirk_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64), (unsigned)lds_bytes, nb, p, atol, ab,
-                    (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+                    (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, (double*)nullptr);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
   } else if (n <= 16) DSH_WS_LAUNCH_S(16);
   else if (n <= 32) DSH_WS_LAUNCH_S(32);
@@ -286,6 +317,7 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   DSH_HIP_CHECK(hipMemcpyAsync(totals, totals_dev, sizeof(unsigned long long) * 6, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   DSH_HIP_CHECK(timing_collect(ctx));
+  if (jac_scratch) dsh_free(ctx, jac_scratch);
   dsh_free(ctx, t_eval_dev);
   dsh_free(ctx, totals_dev);
   dsh_free(ctx, consts_dev);

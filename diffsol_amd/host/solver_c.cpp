@@ -114,8 +114,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     if (s->problem.eqn->registry_model(&m, &sz) && (twin = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_sens(twin, 0) && dsh_model_has_resident(r.method, twin, 0)) { r.ok = true; r.model = twin; r.size = 0; return r; }  // BDF, TR-BDF2, ESDIRK34
     // dense run-time-compiled model: one wavefront per member (per-member control)
     if (group == 1 && s->problem.eqn->registry_model(&m, &sz)) {
-      const int kind = dsh_model_has_wave_member_sens(m, sz);  // 1: BDF, TR-BDF2, ESDIRK34; 2 (64 < n <= 140): BDF
-      if (kind == 1 || (kind == 2 && r.method == 0)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+      if (dsh_model_has_wave_member_sens(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }  // 1: a wavefront, 2 (64 < n <= 140): a workgroup per member; BDF, TR-BDF2, ESDIRK34
     }
     return r;
   }
@@ -129,8 +128,7 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     if (s->problem.eqn->registry_model(&m, &sz) && (tw = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_reset(tw, 0) && dsh_model_has_resident(r.method, tw, 0)) { r.ok = true; r.model = tw; r.size = 0; return r; }
     // dense run-time-compiled hybrid model: the wavefront-per-member kernels handle the events inside the launch as well (per member)
     if (group == 1 && s->problem.eqn->registry_model(&m, &sz)) {
-      const int kind = dsh_model_has_wave_member_reset(m, sz);  // 2: the workgroup-per-member form, BDF only
-      if (kind == 1 || (kind == 2 && r.method == 0)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }
+      if (dsh_model_has_wave_member_reset(m, sz)) { r.ok = true; r.wave_member = true; r.model = m; r.size = sz; }  // 1: a wavefront, 2: a workgroup per member; BDF, TR-BDF2, ESDIRK34
     }
     return r;
   }

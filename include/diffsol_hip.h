@@ -469,7 +469,7 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
  * (dsh_team_member_kernel.hpp: thread = state component, the LU of M - cJ in the CU's 160 KB LDS): dsh_model_has_wave_member returns 1 for the wavefront form,
  * 2 for the workgroup form, 0 for neither; dsh_bdf_solve_wave_member takes both.
  * dsh_sdirk_solve_wave_member: the same for TR-BDF2 (method 1) / ESDIRK34 (method 2) — Sdirk::step (sdirk.rs:409-543) over Rk (runge_kutta.rs:466-960),
- * the same models (dsh_model_has_wave_member_sdirk), DAEs included.
+ * the same models (dsh_model_has_wave_member_sdirk: 1 a wavefront per member, 2 a workgroup per member — 64 < n <= 140, identity mass), DAEs included.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
 int dsh_model_has_wave_member(int model, int64_t size);
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
@@ -477,13 +477,13 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* dsh_bdf_solve_wave_member with FORWARD SENSITIVITIES of every parameter (problem.bdf_sens(), bdf.rs:370-432, :934-989) for dense run-time-compiled ODE models the
  * register-resident and the banded lane forms do not cover: n <= 140, at most 16 parameters, no mass matrix, no root functions (dsh_model_has_wave_member_sens: 1 for
- * n <= 64 — one wavefront per member, BDF and the SDIRK methods — 2 for 64 < n <= 140 — one workgroup per member, BDF).  A component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
+ * n <= 64 — one wavefront per member — 2 for 64 < n <= 140 — one workgroup per member; BDF and the SDIRK methods).  A component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
  * stay out of the error test).  Other arguments as dsh_bdf_solve_adaptive_sens. */
 int dsh_model_has_wave_member_sens(int model, int64_t size);
 /* 1: the wavefront-per-member kernels (dsh_bdf_solve_wave_member, dsh_sdirk_solve_wave_member) carry this HYBRID model through all its events inside the launch —
  * reset applied at every root, then on to the last save point (solve_dense with a reset operator, method.rs:774-797); t_root / root_idx report a member's LAST event.
- * Run-time-compiled models with reset_i, stop_i and no mass matrix; returns 1 for n <= 64 (a wavefront per member: BDF, TR-BDF2, ESDIRK34), 2 for 64 < n <= 140 (a
- * workgroup per member: BDF). */
+ * Run-time-compiled models with reset_i, stop_i and no mass matrix; returns 1 for n <= 64 (a wavefront per member), 2 for 64 < n <= 140 (a
+ * workgroup per member); BDF, TR-BDF2, ESDIRK34. */
 int dsh_model_has_wave_member_reset(int model, int64_t size);
 /* dsh_sdirk_solve_wave_member with forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:691-748) for the models of
  * dsh_model_has_wave_member_sens; arguments as dsh_sdirk_solve_resident_sens. */

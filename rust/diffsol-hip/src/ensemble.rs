@@ -241,7 +241,7 @@ pub fn solve_dense_sensitivities_ensemble(
         && mode == EnsembleMode::PerMember
         && unsafe { ffi::dsh_model_has_wave_member_sens(eqn.model, eqn.size) } != 0;
     if !wave_member && unsafe { ffi::dsh_model_has_adaptive_sens(model, size) } == 0 {
-        return Err(LaError::Other("no device-resident integrator with forward sensitivities for this model (ODE model with parameter derivatives and no root functions: register-resident n <= 4, banded lane form, or dense n <= 64 per member — BDF: n <= 140)".into()));
+        return Err(LaError::Other("no device-resident integrator with forward sensitivities for this model (ODE model with parameter derivatives and no root functions: register-resident n <= 4, banded lane form, or dense n <= 140 per member)".into()));
     }
     let o = adaptive_options(problem, mode);
     let ys = HipMat::zeros(n, nt, ctx.clone());

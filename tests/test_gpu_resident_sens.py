@@ -239,10 +239,11 @@ def test_wavefront_per_member_bdf_with_sensitivities_of_dense_models(H, O, det_p
         s.solve_dense_adaptive_sens(te, group=64)
 
 
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
 @pytest.mark.parametrize("error_control", [None, (1e-6, [1e-7])])
-def test_workgroup_per_member_bdf_with_sensitivities(H, O, det_pow, error_control):
-    """Forward sensitivities in the workgroup-per-member BDF (k_bdf_team_member<.., SENS>; dense run-time-compiled models with 64 < n <= 140): the wavefront-per-member
-    kernel's sensitivity code on the factors held in LDS.  Forty coupled oscillators (n = 80, three parameters) and a dense linear system with 100 states: every
+def test_workgroup_per_member_bdf_with_sensitivities(H, O, det_pow, error_control, method):
+    """Forward sensitivities in the workgroup-per-member forms (k_bdf_team_member<.., SENS>, k_sdirk_wave_member<.., SENS, TW>; dense run-time-compiled models with
+    64 < n <= 140): the wavefront-per-member kernels' sensitivity code on the factors held in LDS.  Forty coupled oscillators (n = 80, three parameters) and a dense linear system with 100 states: every
     counter and every bit of states and sensitivities equal the oracle's solve_dense_sensitivities per member on the host twin."""
     import diffsl_models as D
     from diffsol_amd import diffsl as fe
@@ -257,14 +258,13 @@ def test_workgroup_per_member_bdf_with_sensitivities(H, O, det_pow, error_contro
         m, mid = fe.DiffslModel(code), D.host_model(O, code)
         assert m.form == fe.FORM_DYNAMIC and m.lane_model_id is None and L.dsh_model_has_wave_member_sens(m.model_id, 0) == 2
         kw = dict(sens_rtol=error_control[0], sens_atol=error_control[1]) if error_control else {}
-        s = H.Solver(m, p, nbatch=nb, sens=True, method=H.METHOD_BDF, **kw, **tol)
+        hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+        om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+        s = H.Solver(m, p, nbatch=nb, sens=True, method=hm, **kw, **tol)
         y, sens, tot, mm = s.solve_dense_adaptive_sens(te, group=1, want_member_stats=True)
-        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=1, method=O.METHOD_BDF, **kw, **tol)
+        yo, so, sto, failed = O.solve_dense_independent_sens(mid, np.asarray(p, dtype=float), te, nthreads=8, group=1, method=om, **kw, **tol)
         assert failed == 0 and tot["failed_members"] == 0 and (mm["status"] == 0).all()
         assert np.array_equal(mm["stats"].T, sto), "counters differ"
         assert np.array_equal(y, np.transpose(yo, (1, 0, 2))), "states differ"
         assert np.array_equal(sens, np.transpose(so, (0, 2, 1, 3))), "sensitivities differ"
         assert np.abs(sens).max() > 0
-    # the SDIRK methods have no workgroup-per-member form
-    with pytest.raises(Exception):
-        H.Solver(m, p, nbatch=nb, sens=True, method=H.METHOD_TR_BDF2, **tol).solve_dense_adaptive_sens(te, group=1)

@@ -29,11 +29,13 @@ def det_pow(O):
     O.set_det_pow(False)
 
 
-def _pair(H, O, model, oracle_model, p, t_eval, size, **tol):
+def _pair(H, O, model, oracle_model, p, t_eval, size, method="bdf", **tol):
     nb = len(p)
-    s = H.Solver(model, p, nbatch=nb, model_size=size, **tol)
+    hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"bdf": O.METHOD_BDF, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    s = H.Solver(model, p, nbatch=nb, model_size=size, method=hm, **tol)
     y, tot, m = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
-    yo, so, failed = O.solve_dense_independent(oracle_model, np.asarray(p, dtype=float), t_eval, model_size=size, nthreads=8, **tol)
+    yo, so, failed = O.solve_dense_independent(oracle_model, np.asarray(p, dtype=float), t_eval, model_size=size, nthreads=8, method=om, **tol)
     yo = np.transpose(yo, (1, 0, 2))
     assert failed == 0 and (m["status"] == 0).all()
     assert np.array_equal(m["stats"].T, so), "counters differ"
@@ -51,6 +53,24 @@ def test_gaussian_decay_between_64_and_140_states_is_bit_identical_to_the_oracle
     rng = np.random.default_rng(n)
     nb = 9
     _pair(H, O, "gaussian_decay", ORACLE_MODEL["gaussian_decay"], rng.uniform(0.5, 2.0, (nb, n)), [0.5, 1.0, 2.0], n, rtol=1e-6, atol=[1e-6])
+
+
+@pytest.mark.parametrize("method,n", [("tr_bdf2", 65), ("esdirk34", 70), ("tr_bdf2", 129), ("esdirk34", 140)])
+def test_gaussian_decay_between_64_and_140_states_with_the_sdirk_methods(H, O, det_pow, method, n):
+    """TR-BDF2 / ESDIRK34 in the workgroup-per-member form (k_sdirk_wave_member<.., TW>: the wavefront-per-member SDIRK integrator on the factors in LDS), two and
+    three wavefronts per member: counters and every output bit equal the oracle's per-member solves."""
+    rng = np.random.default_rng(n + 1)
+    nb = 9
+    _pair(H, O, "gaussian_decay", ORACLE_MODEL["gaussian_decay"], rng.uniform(0.5, 2.0, (nb, n)), [0.5, 1.0, 2.0], n, method=method, rtol=1e-6, atol=[1e-6])
+
+
+@pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
+def test_robertson_blocks_90_states_with_the_sdirk_methods(H, O, det_pow, method, monkeypatch):
+    monkeypatch.setenv("DSH_RESIDENT_LANE", "0")
+    rng = np.random.default_rng(77)
+    nb = 7
+    p = np.stack([0.04 * 2 ** rng.uniform(-1, 1, nb), 1e4 * 2 ** rng.uniform(-1, 1, nb), 3e7 * 2 ** rng.uniform(-1, 1, nb)], axis=1)
+    _pair(H, O, "robertson_ode", ORACLE_MODEL["robertson_ode"], p, [0.4, 4.0, 40.0], 30, method=method, rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 30)
 
 
 @pytest.mark.parametrize("groups", [30, 43])
