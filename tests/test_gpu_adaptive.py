@@ -100,7 +100,7 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s3 = H.Solver("gaussian_decay", [[1.0] * 70], nbatch=1, model_size=70, method=1)  # run-time sized, dense Jacobian, n = 70: no lane-per-member form and too large for the wavefront-per-member kernels
+    s3 = H.Solver("gaussian_decay", [[1.0] * 150], nbatch=1, model_size=150, method=1)  # run-time sized, dense Jacobian, n = 150: no lane-per-member form and too large for the wavefront- / workgroup-per-member kernels
     with pytest.raises(H.DiffsolHipError) as e:
         s3.solve_dense_adaptive([0.1])
     assert e.value.code == -6
@@ -390,9 +390,9 @@ def test_banded_models_up_to_512_states_have_a_device_resident_lane_per_member_f
     D = rng.uniform(0.5, 2.0, (70, 1))
     _bitwise_pair(H, O, "heat1d", D, [0.01, 0.1, 0.3], 100, group, method, rtol=1e-6, atol=[1e-6])
     s = H.Solver("heat1d", D, nbatch=70, model_size=100, rtol=1e-6, atol=[1e-6], method=[H.METHOD_BDF, H.METHOD_TR_BDF2, H.METHOD_ESDIRK34][method])
-    # AUTO for a small ensemble of such a model: BDF takes the workgroup-per-member form (64 < n <= 140, dense LU in LDS; round 4), the SDIRK methods stay
-    # host-driven lock-step; beyond 140 states every method stays host-driven until the ensemble is large enough for the lane-per-member twin to pay
-    assert s.ensemble_mode()[1] == (1 if method == 0 else 0)
+    # AUTO for a small ensemble of such a model: the workgroup-per-member form (64 < n <= 140, dense LU in LDS; round 4: BDF, then TR-BDF2 / ESDIRK34);
+    # beyond 140 states every method stays host-driven until the ensemble is large enough for the lane-per-member twin to pay
+    assert s.ensemble_mode()[1] == 1
     s2 = H.Solver("heat1d", rng.uniform(0.5, 2.0, (70, 1)), nbatch=70, model_size=200, rtol=1e-6, atol=[1e-6], method=[H.METHOD_BDF, H.METHOD_TR_BDF2, H.METHOD_ESDIRK34][method])
     assert s2.ensemble_mode()[1] == 0
 
