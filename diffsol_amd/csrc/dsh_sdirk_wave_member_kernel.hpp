@@ -36,7 +36,7 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
   double* const cand = lds + 3 * TT;
   int* const perm = reinterpret_cast<int*>(lds + 3 * TT + 2 * (TEAM ? TW : 1));
   double* const A = lds + 3 * TT + 2 * (TEAM ? TW : 1) + TT / 2;
-  const int P = team_pitch(Cp->n);
+  constexpr int P = team_pitch_w(TEAM ? TW : 2);
   bool lu_singular = false;
   (void)cand; (void)perm; (void)A; (void)P; (void)lu_singular;
   const SdirkConsts& T = Cp->T;
@@ -66,9 +66,7 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
       __syncthreads();
       xs2[ln] = term * term;
       __syncthreads();
-      double acc = 0.0;
-      for (int i = 0; i < n; ++i) acc += xs2[i];
-      return acc / (double)n;
+      return team_seq_sum(xs2, n) / (double)n;
     } else {
       return seq_sum<NP>(term * term, n) / (double)n;
     }

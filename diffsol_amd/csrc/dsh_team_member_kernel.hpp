@@ -18,9 +18,32 @@
 namespace dsh {
 
 constexpr int kTeamMaxN = 140;
-__host__ __device__ inline int team_pitch(int n) { return (n & 1) ? n : n + 1; }
-__host__ __device__ inline size_t team_lds_doubles(int n, int waves) { return (size_t)(3 * 64 * waves + 2 * waves + 32 * waves) + (size_t)n * team_pitch(n); }
+// pitch of the factors in LDS: ONE odd value per workgroup shape (two wavefronts: n <= 128; three: n <= 140), a compile-time constant — with a run-time pitch every
+// LDS access of the factorisation carries its own index arithmetic (scripts/team_member_prof.sh: 620 cycles per eight columns of a pivot step's update)
+__host__ __device__ constexpr int team_pitch_w(int waves) { return waves <= 2 ? 129 : 141; }
+__host__ __device__ inline size_t team_lds_doubles(int n, int waves) { return (size_t)(3 * 64 * waves + 2 * waves + 32 * waves) + (size_t)n * team_pitch_w(waves); }
 
+// sum of n terms held in LDS, in index order, the reads of eight terms issued together (one read per round trip: 94 cycles per term)
+__device__ __forceinline__ double team_seq_sum(const double* __restrict__ red, int n) {
+  double acc = 0.0;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    double t8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t8[u] = red[i + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += t8[u];
+  }
+  for (; i < n; ++i) acc += red[i];
+  return acc;
+}
+
+#ifdef DSH_TEAM_MEMBER_PROF
+__device__ unsigned long long g_tlu[4];  // thread 0 of workgroup 0: cycles in the pivot search, the interchange, the update (its barrier = the slowest thread)
+#define TLU_MARK(q) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_tlu[q] += now_ - tlu_t0; tlu_t0 = now_; }
+#else
+#define TLU_MARK(q)
+#endif
 // LU of the n x n matrix in LDS (A[c * P + r], thread t = row t) with partial pivoting and physical row interchanges; perm[k] = original row at position k.
 // Workgroup-uniform control flow; all W wavefronts must call it together.
 template <int W>
@@ -29,6 +52,9 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
   perm[ln] = ln;
   singular = false;
   __syncthreads();  // every row of A is in LDS, perm is the identity
+#ifdef DSH_TEAM_MEMBER_PROF
+  unsigned long long tlu_t0 = clock64();
+#endif
   for (int k = 0; k < n; ++k) {
     double best = -1.0;
     int p = n;
@@ -36,6 +62,7 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
     group_argmax(best, p, 64);  // largest magnitude, smallest row on ties, over this wavefront
     if (lane == 0) { cand[2 * wave] = best; cand[2 * wave + 1] = (double)p; }
     __syncthreads();
+    TLU_MARK(0)
     double b0 = cand[0];
     int p0 = (int)cand[1];
 #pragma unroll
@@ -50,12 +77,23 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
       if (ln == 0) { const int q = perm[k]; perm[k] = perm[p]; perm[p] = q; }
     }
     __syncthreads();
+    TLU_MARK(1)
     if (elim && rowlive && ln > k) {
       const double l = A[k * P + ln] * (1.0 / diag);
       A[k * P + ln] = l;
-      for (int c = k + 1; c < n; ++c) A[c * P + ln] = (-A[c * P + k]) * l + A[c * P + ln];
+      // eight columns at a time, their loads issued together: one column per LDS round trip costs 10 000 cycles per pivot step at n = 120 (scripts/team_member_prof.sh)
+      int c = k + 1;
+      for (; c + 8 <= n; c += 8) {
+        double pk[8], mine[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { pk[u] = A[(c + u) * P + k]; mine[u] = A[(c + u) * P + ln]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) A[(c + u) * P + ln] = (-pk[u]) * l + mine[u];
+      }
+      for (; c < n; ++c) A[c * P + ln] = (-A[c * P + k]) * l + A[c * P + ln];
     }
     __syncthreads();
+    TLU_MARK(2)
   }
 }
 
@@ -75,11 +113,17 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
     const int k0 = 64 * B;
     if (k0 < n) {
       if (wave == B) {
-        for (int kk = 0; kk < 64; ++kk) {
-          const int k = k0 + kk;
-          if (k + 1 < n) {
-            const double coeff = group_bcast<64>(v, kk);
-            if (rowlive && ln > k) v = (-coeff) * A[k * P + ln] + v;
+        for (int kk0 = 0; kk0 < 64; kk0 += 8) {  // the factors of eight steps are read ahead of the chain (they do not depend on it)
+          double a8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int k = k0 + kk0 + u; a8[u] = (k + 1 < n && rowlive && ln > k) ? A[k * P + ln] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + kk0 + u;
+            if (k + 1 < n) {
+              const double coeff = group_bcast<64>(v, kk0 + u);
+              if (rowlive && ln > k) v = (-coeff) * a8[u] + v;
+            }
           }
         }
       }
@@ -88,7 +132,13 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
         if (wave == B) xch[ln] = v;
         __syncthreads();
         if (wave > B && rowlive)
-          for (int k = k0; k < k0 + 64; ++k) v = (-xch[k]) * A[k * P + ln] + v;
+          for (int kb = k0; kb < k0 + 64; kb += 8) {
+            double x8[8], a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x8[u] = xch[kb + u]; a8[u] = A[(kb + u) * P + ln]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v = (-x8[u]) * a8[u] + v;
+          }
       }
     }
   }
@@ -99,19 +149,36 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
     if (k0 < n) {
       const int k1 = n < k0 + 64 ? n : k0 + 64;
       if (wave == B) {
-        for (int k = k1 - 1; k >= k0; --k) {
-          const double diag = A[k * P + k];
-          const double coeff = group_bcast<64>(v, k - k0) / diag;
-          if (ln == k) v = coeff;
-          else if (rowlive && ln < k) v = (-coeff) * A[k * P + ln] + v;
+        for (int kt = k1 - 1; kt >= k0; kt -= 8) {  // eight steps' diagonal and column entries read ahead of the chain
+          double d8[8], a8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int k = kt - u; d8[u] = k >= k0 ? A[k * P + k] : 1.0; a8[u] = (k >= k0 && rowlive && ln < k) ? A[k * P + ln] : 0.0; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = kt - u;
+            if (k >= k0) {
+              const double coeff = group_bcast<64>(v, k - k0) / d8[u];
+              if (ln == k) v = coeff;
+              else if (rowlive && ln < k) v = (-coeff) * a8[u] + v;
+            }
+          }
         }
       }
       if (B > 0) {
         __syncthreads();
         if (wave == B) xch[ln] = v;
         __syncthreads();
-        if (wave < B)
-          for (int k = k1 - 1; k >= k0; --k) v = (-xch[k]) * A[k * P + ln] + v;
+        if (wave < B) {
+          int k = k1 - 1;
+          for (; k - 7 >= k0; k -= 8) {
+            double x8[8], a8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x8[u] = xch[k - u]; a8[u] = A[(k - u) * P + ln]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v = (-x8[u]) * a8[u] + v;
+          }
+          for (; k >= k0; --k) v = (-xch[k]) * A[k * P + ln] + v;
+        }
       }
     }
   }
@@ -119,6 +186,16 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
 }
 
 // SENS: forward sensitivities of every parameter alongside, as in k_bdf_wave_member<.., SENS> (run-time-compiled ODE models without root functions; bdf.rs:370-432, :934-989)
+// -DDSH_TEAM_MEMBER_PROF: thread 0 of workgroup 0 accumulates the cycles of the phases of its member's solve and prints them (scripts/team_member_prof.sh)
+#ifdef DSH_TEAM_MEMBER_PROF
+#define TMP_DECL unsigned long long tmp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmp_t0 = clock64(), tmp_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tmp_begin = tmp_t0;
+#define TMP_MARK(k) { const unsigned long long now_ = clock64(); tmp_acc[k] += now_ - tmp_t0; tmp_cnt[k] += 1; tmp_t0 = now_; }
+#define TMP_PRINT if (blockIdx.x == 0 && threadIdx.x == 0) printf("team member prof (cycles, member 0, n = %d): total %llu | jacobian %llu (%llu) | factor %llu (%llu) | rhs %llu (%llu) | solve %llu (%llu) | norm %llu (%llu) | step-size change %llu (%llu) | rest %llu\n", n, clock64() - tmp_begin, tmp_acc[0], tmp_cnt[0], tmp_acc[1], tmp_cnt[1], tmp_acc[2], tmp_cnt[2], tmp_acc[3], tmp_cnt[3], tmp_acc[4], tmp_cnt[4], tmp_acc[5], tmp_cnt[5], tmp_acc[7]); if (blockIdx.x == 0 && threadIdx.x == 0) printf("  inside the factorisations (cycles): pivot search %llu | interchange %llu | update %llu\n", g_tlu[0], g_tlu[1], g_tlu[2]);
+#else
+#define TMP_DECL
+#define TMP_MARK(k)
+#define TMP_PRINT
+#endif
 template <int W, bool SENS = false>
 __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
@@ -134,7 +211,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   double* cand = lds + 3 * T;          // pivot candidates of the wavefronts: value, row  (ps: up to T parameters — gaussian_decay has one per state)
   int* perm = reinterpret_cast<int*>(lds + 3 * T + 2 * W);  // original row at every position of P A = L U
   double* A = lds + 3 * T + 2 * W + T / 2;                  // the LU factors of M - c J, column-major, pitch P, rows at their final positions
-  const int P = team_pitch(Cp->n);
+  constexpr int P = team_pitch_w(W);
   double* sJ = jac_scratch + (size_t)blockIdx.x * Cp->n * Cp->n;  // the member's cached Jacobian: global scratch (L2 / MALL resident), entry (ln, j) at j * n + ln
   const WaveMemberConsts& C = *Cp;
   const dsh_adaptive_options& o = C.r.o;
@@ -163,9 +240,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     __syncthreads();
     red[ln] = term * term;
     __syncthreads();
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += red[i];  // every thread the same sequential sum (Vector::squared_norm's order)
-    return acc / (double)n;
+    return team_seq_sum(red, n) / (double)n;  // every thread the same sequential sum (Vector::squared_norm's order)
   };
 
   // ------------------------------------------------------------ new_and_consistent (identity mass: nothing to make consistent) + set_step_size
@@ -174,6 +249,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   double y = rowlive ? wm_init_value(model, (int64_t)n, (int64_t)ln, t, Pf) : 0.0;
   double f0 = rhs_of(y, t);
   bool lu_singular = false;
+  TMP_DECL
   {
     const bool is_neg_h = C.r.h0 < 0.0;
     const double d0 = sqrt(wms_wave(y, y)), d1 = sqrt(wms_wave(f0, y));
@@ -212,9 +288,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     __syncthreads();
     red[ln] = term * term;
     __syncthreads();
-    double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += red[i];
-    return acc / (double)n;
+    return team_seq_sum(red, n) / (double)n;
   };
   if constexpr (SENS) {
     for (int j = 0; j < nsp; ++j) {
@@ -252,11 +326,13 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
         if (rowlive) sJ[(size_t)j * n + ln] = wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, Ej, Pf, true);
       }
       jac_stale = false;
+      TMP_MARK(0)
     }
     // A = J * (-c) + I (scale_add_and_assign with the dense identity mass), my row; then the factorisation in LDS
     if (rowlive)
       for (int j = 0; j < n; ++j) A[j * P + ln] = sJ[(size_t)j * n + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0);
     team_lu_factor<W>(A, P, n, ln, rowlive, cand, perm, lu_singular);
+    TMP_MARK(1)
   };
   n_setups = 1;
   // RootFinder::init
@@ -285,6 +361,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   double t_predict = t;
 
   auto update_step_size = [&](double factor, double& new_h_out) __attribute__((always_inline)) -> bool {
+    TMP_MARK(7)
     const double new_h = factor * h;
     n_equal_steps = 0;
     double R[6][6];
@@ -343,6 +420,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     h = new_h;
     eta = C.r.eta_reset_ts;
     new_h_out = new_h;
+    TMP_MARK(5)
     return fabs(h) < o.min_timestep;
   };
   auto predict_forward = [&]() __attribute__((always_inline)) {
@@ -427,6 +505,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     int niter = 0;
     predict_forward();
     while (true) {
+      TMP_MARK(7)
       if (reset_pending) { reset_jacobian(y, t); reset_pending = false; }
       x = yp;
       niter = 0;
@@ -434,7 +513,9 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
       double old_norm = 0.0;
       bool solved = false;
       for (int it = 0; it < o.max_nonlinear_solver_iterations; ++it) {
+        TMP_MARK(7)
         const double f = rhs_of(x, t_predict);
+        TMP_MARK(2)
         const double tmpv = x + psi;
         double delta;
         if constexpr (kWmHasMass) {  // F(y) = M (y - y0 + psi) - c f(y): M's row times the published vector, then + (-c) f (mass_gemv with beta = -c)
@@ -447,9 +528,11 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
           delta = 1.0 * tmpv + (-opc) * f;  // F(y) = (y - y0 + psi) - c f(y)
         }
         const bool lu_ok = team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, delta);  // unknown i comes back to thread i
+        TMP_MARK(3)
         if (!lu_ok) break;
         x = x - delta;
         const double norm = sqrt(wms_wave(delta, yp));
+        TMP_MARK(4)
         niter += 1;
         bool diverged = false;
         if (has_old) {
@@ -753,6 +836,8 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     }
     if (reason == 1) done = true;
   }
+  TMP_MARK(7)
+  TMP_PRINT
   const int ncols = col;
   for (; col < C.r.n_eval; ++col) {
     if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = __builtin_nan("");
