@@ -45,6 +45,8 @@ class DiffslModel:
         self.model_index = int(model_index)
         _, d, self.defaults = generate(code, TARGET_HOST_C, model_index)
         if form is None:
+            # static form (compile-time n: the fused host-driven kernels, and the register-resident integrators up to n = 4) for small models; a model with 5 <= n <= 8
+            # that should run per member on the device is compiled with form=FORM_DYNAMIC (the wavefront-per-member kernels take run-time-sized models)
             form = FORM_STATIC if d["n"] <= 8 and d["nroots"] <= 1 else FORM_DYNAMIC
         self.form = form
         self.source, d, _ = generate(code, TARGET_HIP_STATIC if form == FORM_STATIC else TARGET_HIP_DYNAMIC, model_index)

@@ -278,8 +278,9 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
     throw LaError(DSH_E_UNSUPPORTED, "device-resident integration with forward sensitivities: dshs_solve_dense_adaptive_sens, BDF, static ODE models with parameter "
                                      "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
   if (!pk.ok)
-    throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4: BDF/TR-BDF2/ESDIRK34; "
-                                     "run-time-sized ODE models with n <= 140: BDF)");
+    throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4 and banded lane-per-member forms: "
+                                     "BDF/TR-BDF2/ESDIRK34; run-time-sized models with n <= 140 (n <= 48 with a mass matrix): per member (group 1), BDF/TR-BDF2/ESDIRK34; a DiffSL model "
+                                     "with 5 <= n <= 8 states is compiled in the static form by default, which has no such kernel: compile it with form = FORM_DYNAMIC)");
   const int model = pk.model;
   const int64_t size = pk.size;
   const int method = pk.method;

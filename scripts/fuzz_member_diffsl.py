@@ -47,7 +47,7 @@ for seed in range(first, first + ncases):
     om = [O.METHOD_BDF, O.METHOD_TR_BDF2, O.METHOD_ESDIRK34][method]
     tag = f"seed {seed}: {kind} n {n} method {method} nb {nb} rtol {rtol:.1e} atol {atol[0]:.1e}"
     try:
-        m, mid = fe.DiffslModel(code), D.host_model(O, code)
+        m, mid = fe.DiffslModel(code, form=fe.FORM_DYNAMIC if n <= 8 else None), D.host_model(O, code)  # n <= 8: the default (static) form has no per-member kernel above n = 4
         if kind == "sens":
             ec = bool(rng.integers(0, 2))
             kw = dict(sens_rtol=float(10.0 ** rng.uniform(-6, -4)), sens_atol=[float(10.0 ** rng.uniform(-8, -6))]) if ec else {}
