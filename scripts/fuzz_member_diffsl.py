@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised parity sweep of the per-member device forms of DENSE run-time-compiled (DiffSL) models against independent oracle solves, bit for bit:
-one wavefront per member (n <= 64: BDF, TR-BDF2, ESDIRK34) and one workgroup per member (64 < n <= 140: BDF), as plain ODE models, as hybrid models
+one wavefront per member (n <= 64) and one workgroup per member (64 < n <= 140), BDF / TR-BDF2 / ESDIRK34, as plain ODE models, as hybrid models
 (stop_i + reset_i: every member its own event times) and with forward sensitivities (with and without sensitivity error control); random sizes, couplings,
 tolerances, parameters and output times.      python scripts/fuzz_member_diffsl.py [ncases] [first_seed]     (GPU only)"""
 import os
@@ -26,7 +26,7 @@ for seed in range(first, first + ncases):
     kind = ["plain", "hybrid", "sens"][seed % 3]
     big = bool(rng.integers(0, 2))
     n = int(rng.integers(65, 141)) if big else int(rng.integers(5, 65))
-    method = 0 if big else int(rng.integers(0, 3))
+    method = int(rng.integers(0, 3))  # (the workgroup-per-member form has all three methods since k_sdirk_wave_member<.., TW>)
     nb = int(rng.integers(6, 40))
     rtol = float(10.0 ** rng.uniform(-7, -4))
     atol = [float(10.0 ** rng.uniform(-9, -6))]
