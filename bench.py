@@ -29,6 +29,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_START = time.perf_counter()
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -59,6 +60,109 @@ def kernel_source_hash():
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+DETAIL_FILE = "bench_detail.json"
+LINE_LIMIT = 4096  # the driver keeps an 8 KB tail of stdout: the LAST line must fit with room to spare (a 23.7 KB line did not parse)
+
+
+def _sig(x, nd=5):
+    """floats to nd significant digits (the compact line only; the detail file keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}") if np.isfinite(x) else None
+    return x
+
+
+def _pick(d, keys):
+    return {k: _sig(d.get(k)) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(rec):
+    """The contract line: every key the driver / judge reads (metric, value, unit, n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype,
+    data, config, roofline, cpu_baseline) with short strings, the other BASELINE configs as `configs: {name: [ms_per_solve, roofline_frac, bound, cpu_steps_per_s]}`,
+    the extra passes as one number each.  Everything else lives in bench_detail.json (also printed on an earlier stdout line)."""
+    out = {k: _sig(rec.get(k)) for k in ("metric", "value", "unit", "newton_solves_per_sec", "lu_refactors_per_sec", "n_gpus", "ranks", "steps", "warmup", "ms_per_step",
+                                         "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in rec}
+    cfg = rec.get("config") or {}
+    out["config"] = _pick(cfg, ("members_per_gpu", "members_total", "t_final", "method", "ensemble_mode", "mean_steps_per_member", "parallelism", "backend", "gather",
+                                "gathered_bytes_per_solve"))
+    out["config"]["workload"] = str(cfg.get("workload_short") or cfg.get("workload", ""))[:200]
+    if "checks" in rec:
+        out["checks"] = {k: _sig(v) for k, v in rec["checks"].items()}
+    roof = rec.get("roofline")
+    if isinstance(roof, dict):
+        r = _pick(roof, ("bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "traffic", "fp64_tflops", "counters_from"))
+        r["kernel"] = str(roof.get("kernel", ""))[:80]
+        if isinstance(roof.get("lane_ops"), dict):
+            r["lane_ops_frac"] = _sig(roof["lane_ops"].get("frac"))
+        if isinstance(roof.get("hbm"), dict):
+            r["algorithmic_hbm_bytes"] = roof["hbm"].get("algorithmic_bytes_per_launch")
+        if roof.get("achieved") is None and roof.get("note"):
+            r["note"] = str(roof["note"])[:160]
+        out["roofline"] = r
+    elif "roofline" in rec:
+        out["roofline"] = None
+    cpu = rec.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        c = _pick(cpu, ("value", "unit", "cores", "usable_cpus", "kind", "newton_solves_per_sec", "parallel_efficiency", "seconds"))
+        c["threads"] = cpu.get("cores")
+        c["sample"] = str(cpu.get("sample_short") or cpu.get("sample", ""))[:160]
+        if isinstance(cpu.get("single_core"), dict):
+            c["single_core_value"] = _sig(cpu["single_core"].get("value"))
+            c["single_core_seconds"] = _sig(cpu["single_core"].get("seconds"))
+        out["cpu_baseline"] = c
+    ex = {}
+    for k in ("per_member", "fast_variant", "host_lockstep", "large_ensemble", "trait_path"):
+        v = rec.get(k)
+        if isinstance(v, dict):
+            ex[k + "_ms"] = _sig(v.get("ms_per_step")) if "error" not in v else "error"
+    if ex:
+        out["extras"] = ex
+    cfgs = rec.get("configs")
+    if isinstance(cfgs, dict):
+        out["configs_columns"] = ["ms_per_solve", "roofline_frac", "bound", "cpu_steps_per_s"]
+        cc = {}
+        for name, v in cfgs.items():
+            if not isinstance(v, dict):
+                continue
+            if "error" in v or "skipped" in v:
+                cc[name] = [None, None, ("error: " + str(v.get("error"))[:60]) if "error" in v else "skipped", None]
+                continue
+            rf = v.get("roofline") or {}
+            cc[name] = [_sig(v.get("ms_per_solve")), _sig(rf.get("frac")), rf.get("bound"), _sig((v.get("cpu_baseline") or {}).get("value"))]
+            rff = v.get("roofline_factor")
+            if isinstance(rff, dict):
+                cc[name + ":factor"] = [_sig(rff.get("avg_launch_us", 0.0) / 1e3), _sig(rff.get("frac")), rff.get("bound"), None]
+        out["configs"] = cc
+    if "bench_seconds" in rec:
+        out["bench_seconds"] = _sig(rec["bench_seconds"])
+    out["detail"] = DETAIL_FILE
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:  # never print a line the driver cannot hold: drop the optional blocks, keep the contract keys
+        for k in ("extras", "configs_columns", "checks"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    assert len(line) <= LINE_LIMIT, len(line)
+    return line
+
+
+def emit(rec):
+    """full record -> bench_detail.json (+ gpurun_out/ when it exists) and an earlier stdout line; the compact contract line LAST."""
+    full = json.dumps(rec)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
+    print("bench_detail: " + full)
+    print(compact_line(rec))
+    sys.stdout.flush()
 
 
 def robertson_params(nb, seed=12345):
@@ -140,7 +244,12 @@ def cpu_baseline(params, sample):
     fast = hasattr(O, "solve_ensemble_independent_fast")
     run = O.solve_ensemble_independent_fast if fast else O.solve_ensemble_independent
     n1 = max(1, min(sample, 2000 if fast else 200))
-    r1 = run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
+    run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)  # page in, leave the idle clock
+    while True:  # single-core denominator from a sample of >= 0.5 s (a cold, tiny sample gave parallel efficiencies above 1)
+        r1 = run(O.MODEL_ROBERTSON_ODE, p[:n1], nthreads=1, **kw)
+        if r1["seconds"] >= 0.5 or n1 >= sample:
+            break
+        n1 = min(sample, max(2 * n1, int(n1 * 0.6 / max(r1["seconds"], 1e-3))))
     single = r1["steps"] / r1["seconds"]
 
     def go(c):
@@ -156,7 +265,8 @@ def cpu_baseline(params, sample):
                   f"({'oracle_fast.hpp: stack-array build of the' if fast else ''} C++ restatement of diffsol Bdf+NalgebraLU), std::threads with a static partition; "
                   f"thread count swept, best reported",
         "single_core": {"value": single, "unit": "ODE steps/s", "cores": 1, "seconds_per_solve": r1["seconds"] / n1,
-                        "newton_solves_per_sec": r1["newton_iterations"] / r1["seconds"], "sample": f"first {n1} members, one thread"},
+                        "newton_solves_per_sec": r1["newton_iterations"] / r1["seconds"], "seconds": r1["seconds"], "sample": f"first {n1} members, one thread"},
+        "sample_short": f"first {sample} members of the same sweep, independent BDF solves (C++ restatement of Bdf+NalgebraLU), best of a thread sweep",
         "reference_published": {"seconds_per_solve": PUBLISHED_SINGLE_SOLVE_S,
                                 "what": "diffsol BDF+nalgebra LU via pydiffsol, robertson_ode n=3, rtol=atol=1e-4, one EPYC 7343 core "
                                         "(book/src/benchmarks/python_results.csv:2); t_final/output grid of that benchmark are defined outside the "
@@ -228,18 +338,23 @@ def cfg_cpu(model, p, t_eval, method, what, single_n, **kw):
         t0 = time.perf_counter()
         _, st, failed = O.solve_dense_independent(model, pp, t_eval, method=method, nthreads=c, **kw)
         return int(st[:, 0].sum()), int(st[:, 1].sum()), time.perf_counter() - t0, failed
-    u1, n1, s1, _ = run(p[:single_n], 1)
+    run(p[:min(single_n, 8)], 1)  # page in
+    while True:  # single-core denominator from a sample of >= 0.5 s
+        u1, n1, s1, _ = run(p[:single_n], 1)
+        if s1 >= 0.5 or single_n >= p.shape[0]:
+            break
+        single_n = min(p.shape[0], max(2 * single_n, int(single_n * 0.6 / max(s1, 1e-3))))
     single = u1 / s1
     counts = [c for c in thread_counts(lim) if c <= p.shape[0]] or [min(cores, p.shape[0])]
     if len(counts) > 3:
         counts = counts[-3:]  # bounded: the three largest thread counts
     best, rows = cpu_sweep(lambda c: run(p, c)[:3], single, counts, lim)
     return {"value": best["value"], "unit": "ODE steps/s", "cores": best["threads"], "usable_cpus": usable_cpus(lim), "kind": "port", "newton_solves_per_sec": best["newton_solves_per_sec"],
-            "seconds": best["seconds"], "seconds_per_solve_single_core": s1 / single_n, "parallel_efficiency": best["parallel_efficiency"],
+            "seconds": best["seconds"], "seconds_per_solve_single_core": s1 / single_n, "single_core_seconds": s1, "parallel_efficiency": best["parallel_efficiency"],
             "thread_sweep": rows, "sample": f"{what}: first {p.shape[0]} members, one independent solve_dense per member (oracle restatement), best of the thread sweep"}
 
 
-def bench_configs(device, want_cpu, quick=False):
+def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
     """BASELINE configs[2..4] on one GPU, each with its own roofline entry (dominant kernel, live launch durations from HIP-event brackets on the solver's stream)
     and CPU leg.  Every entry is guarded: a failing config reports {"error": ...} and the line still prints."""
     import diffsol_amd as H
@@ -249,6 +364,9 @@ def bench_configs(device, want_cpu, quick=False):
 
     def guarded(name, fn):
         t0 = time.perf_counter()
+        if budget_s and t0 - T_START > budget_s:  # the contract line must come out within the driver's patience: later configs are reported as skipped, not run
+            out[name] = {"skipped": f"time budget: {t0 - T_START:.0f} s since start > --time-budget {budget_s:g} s"}
+            return
         try:
             out[name] = fn()
         except Exception as e:  # noqa: BLE001
@@ -326,8 +444,6 @@ def bench_configs(device, want_cpu, quick=False):
             rec["cpu_baseline"] = cpu_memo["c3"]
         return rec
 
-    guarded("c3_banded", lambda: c3(False))
-    guarded("c3_dense", lambda: c3(True))
 
     # ---------------------------------------------------------------- C4
     # algorithmic bytes (SURVEY §8(d) with the banded factors): per accepted step read + write the difference array 2 x 8 n (q + 3) at the mean order q = 4, write
@@ -379,9 +495,6 @@ def bench_configs(device, want_cpu, quick=False):
         del s, outb
         return rec
 
-    for nb in ((4096,) if quick else (32768, 262144)):
-        guarded(f"c4_ode_{nb}", lambda nb=nb: c4(nb, False))
-        guarded(f"c4_dae_{nb}", lambda nb=nb: c4(nb, True))
 
     # ---------------------------------------------------------------- C5
     def c5(group):
@@ -427,8 +540,17 @@ def bench_configs(device, want_cpu, quick=False):
         del s, outb
         return rec
 
+    # most informative first: a time budget that runs out drops the tail of this list
+    nb4 = 4096 if quick else 32768
+    guarded("c3_banded", lambda: c3(False))
+    guarded(f"c4_ode_{nb4}", lambda: c4(nb4, False))
     guarded("c5_per_member", lambda: c5(1))
+    guarded(f"c4_dae_{nb4}", lambda: c4(nb4, True))
+    guarded("c3_dense", lambda: c3(True))
     guarded("c5_group64", lambda: c5(64))
+    if not quick:
+        guarded("c4_ode_262144", lambda: c4(262144, False))
+        guarded("c4_dae_262144", lambda: c4(262144, True))
     return out
 
 
@@ -499,6 +621,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra passes (host-driven lock-step, per-member control, 1.6M members)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[2..4] (the `configs` object) and the pure trait-path pass")
     ap.add_argument("--quick-configs", action="store_true", help="configs at reduced ensemble sizes (smoke test of the bench itself; never a measurement)")
+    ap.add_argument("--time-budget", type=float, default=75.0,
+                    help="seconds since process start after which no further BASELINE config of the `configs` object is started (reported as skipped); 0 = no limit")
     ap.add_argument("--cpu-sample", type=int, default=400_000)
     ap.add_argument("--large-nb", type=int, default=1_600_000)
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
@@ -758,6 +882,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "cpu-stub (test hook: launcher/aggregation path only, not a measurement)" if stub else "synthetic",
             "config": {
+                "workload_short": "BASELINE configs[1]: Robertson (n=3, f64) ensemble, 100k members per GPU, BDF, batched dense LU, t in [0,4e5], 7 save points",
                 "workload": "BASELINE.json configs[1]: Robertson stiff ODE (n=3, fp64) ensemble, 100k parameter-sweep members per GPU, BDF, "
                             "batched dense LU, t in [0, 4e5], rtol 1e-4, atol (1e-8,1e-14,1e-6), output at 7 decades",
                 "members_per_gpu": nb, "members_total": n_total, "t_final": T_EVAL[-1], "method": "bdf",
@@ -827,9 +952,9 @@ def main():
                 rec["trait_path"] = bench_trait_path(params[lo:hi], local_rank, 3)
             except Exception as e:  # noqa: BLE001
                 rec["trait_path"] = {"error": str(e)[:300]}
-            rec["configs"] = bench_configs(local_rank, not args.no_cpu_baseline, quick=args.quick_configs)
-        print(json.dumps(rec))
-        sys.stdout.flush()
+            rec["configs"] = bench_configs(local_rank, not args.no_cpu_baseline, quick=args.quick_configs, budget_s=args.time_budget)
+        rec["bench_seconds"] = time.perf_counter() - T_START
+        emit(rec)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -906,7 +1031,7 @@ def main_c4(args, rank, local_rank, world, stub):
     el, steps, newton, failed = [float(v) for v in a.tolist()]
     ok = bool(torch.isfinite(y[0]).all().item()) and y.shape[-1] == n_total
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "ODE steps/sec (and Newton solves/sec) per ensemble", "value": steps / el, "unit": "accepted ODE steps/s summed over ensemble members",
             "newton_solves_per_sec": newton / el, "n_gpus": world, "ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
@@ -916,8 +1041,7 @@ def main_c4(args, rank, local_rank, world, stub):
                        "members_total": n_total, "members_per_gpu": hi - lo, "parallelism": f"ensemble-shard x{world}",
                        "gather": "none" if world == 1 and comm is None else ("dsh_gather_batch_axis (library-bound RCCL)" if comm is not None else "torch.distributed all_gather_into_tensor (RCCL)"),
                        "gathered_bytes_per_solve": 8 * len(t_eval) * n * n_total},
-            "checks": {"finite_and_complete": ok, "failed_members": int(failed)}}))
-        sys.stdout.flush()
+            "checks": {"finite_and_complete": ok, "failed_members": int(failed)}})
     if comm is not None:
         comm.close()
     if world > 1:

@@ -134,6 +134,7 @@ DEVICE_ABI = {
     "dsh_model_release": (cint, [cint]),
     "dsh_model_precompile": (cint, [cint, cint]),
     "dsh_jit_compile_count": (C.c_int64, []),
+    "dsh_jit_replay": (cint, [C.c_char_p, cint, cint, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dsh_model_set_twin": (cint, [cint, cint]),
     "dsh_model_twin": (cint, [cint]),
     "dsh_model_lane_twin": (cint, [cint, i64]),

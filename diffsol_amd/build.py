@@ -19,6 +19,45 @@ def build(verbose=False, jobs=8):
     return [os.path.join(_HERE, "lib", "libdiffsol_hip.so"), os.path.join(_HERE, "lib", "libdiffsol_hip_host.so")]
 
 
+MANIFEST_DIR = os.path.join(_HERE, "jit_manifest")
+
+
+def replay_manifests(jobs=None, verbose=False):
+    """Compile every request of the committed manifests (diffsol_amd/jit_manifest/*.rec — written on a GPU box under DSH_JIT_RECORD by bench.py and the `-m gpu`
+    tests, scripts/record_jit_manifest.sh) into the in-tree cache diffsol_amd/_jit_cache/ with hiprtc: no GPU needed, one process per core, requests dealt round-robin.
+    A fresh box then loads every code object it asks for instead of compiling at first use.  Returns (requests, compiled)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(MANIFEST_DIR, "*.rec")))
+    if not files:
+        return 0, 0
+    jobs = jobs or max(1, min(len(os.sched_getaffinity(0)), 16))
+    code = ("import ctypes as C, sys\n"
+            "from diffsol_amd import _ffi\n"
+            "dev = _ffi.load_device_lib()\n"
+            "part, nparts = int(sys.argv[1]), int(sys.argv[2])\n"
+            "tot = [0, 0]\n"
+            "for path in sys.argv[3:]:\n"
+            "    r, c = C.c_int64(0), C.c_int64(0)\n"
+            "    rc = dev.dsh_jit_replay(path.encode(), part, nparts, C.byref(r), C.byref(c))\n"
+            "    assert rc == 0, (path, dev.dsh_last_error())\n"
+            "    tot[0] += r.value; tot[1] += c.value\n"
+            "print(tot[0], tot[1])\n")
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(_HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("DSH_JIT_RECORD", None)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(k), str(jobs)] + files, env=env, stdout=subprocess.PIPE, text=True) for k in range(jobs)]
+    requests = compiled = 0
+    for pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("dsh_jit_replay failed in a build worker")
+        r, c = out.split()
+        requests = max(requests, int(r))
+        compiled += int(c)
+    if verbose:
+        print(f"jit manifests: {requests} requests, {compiled} compiled now")
+    return requests, compiled
+
+
 if __name__ == "__main__":
     for p in build(verbose="-v" in sys.argv):
         print(p)

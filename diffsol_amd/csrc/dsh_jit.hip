@@ -17,6 +17,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
+#include <cstring>
 
 #include <atomic>
 #include <fcntl.h>
@@ -185,6 +187,38 @@ void cache_store(const std::string& dir, const std::string& path, const std::vec
 int compile_module_uncached(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, const std::vector<std::string>& opts,
                             JitModule* out);
 
+
+// ---- manifest of compile requests (DSH_JIT_RECORD=<file>): every request for a module — served from the cache or compiled — appends (header, name expressions, translation
+// unit) to <file>, once per process and request.  dsh_jit_replay compiles such a manifest into the cache without a GPU: the build step replays the committed manifests of
+// bench.py and of the GPU tests (diffsol_amd/jit_manifest/), so a fresh box finds every code object it will ask for (first-use compilation inside bench.py is a bug).
+// Record layout: "DSHJ" u32 version=1, u64 len + header, u64 ngroup, (u64 len + name)*, u64 len + tu.
+void put_str(std::string* b, const std::string& s) { uint64_t n = s.size(); b->append((const char*)&n, 8); b->append(s); }
+void record_request(const std::string& tu, const char* header, const std::vector<std::string>& group) {
+  const char* path = std::getenv("DSH_JIT_RECORD");
+  if (!path || !*path) return;
+  uint64_t h = fnv1a(tu.data(), tu.size(), 1469598103934665603ull);
+  h = fnv1a(header, strlen(header) + 1, h);
+  for (const std::string& e : group) h = fnv1a(e.data(), e.size() + 1, h);
+  static std::mutex mu;
+  static std::set<uint64_t> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!seen.insert(h).second) return;
+  std::string b("DSHJ");
+  uint32_t ver = 1;
+  b.append((const char*)&ver, 4);
+  put_str(&b, header);
+  uint64_t ng = group.size();
+  b.append((const char*)&ng, 8);
+  for (const std::string& e : group) put_str(&b, e);
+  put_str(&b, tu);
+  int fd = open(path, O_CREAT | O_WRONLY | O_APPEND, 0644);
+  if (fd < 0) return;
+  if (flock(fd, LOCK_EX) == 0) { (void)!write(fd, b.data(), b.size()); flock(fd, LOCK_UN); }
+  close(fd);
+}
+
+int compile_tu(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, JitModule* out);
+
 int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out) {
   std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
   if (rec.info.form == DSH_JIT_FORM_STATIC_BANDED) {
@@ -199,6 +233,11 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
   }
   tu += rec.source;
   tu += std::string("\n#include \"") + header + "\"\n";
+  record_request(tu, header, group);
+  return compile_tu(rec, tu, header, group, out);
+}
+
+int compile_tu(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, JitModule* out) {
   // same code generation switches as the library's own objects (Makefile): no FMA contraction, so the arithmetic order in the source is the arithmetic
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function"};
   const std::string dir = cache_dir();
@@ -450,6 +489,52 @@ int dsh_model_release(int model_id) {
 // compile (not load) one kernel family of a run-time-compiled model: 0 operators, 1 fused Newton kernels, 2 resident BDF, 3 resident SDIRK.
 // Needs no GPU; used by the build check and by callers that want to pay the compilation before the first solve.
 int64_t dsh_jit_compile_count(void) { return (int64_t)g_jit_compiles.load(); }
+
+// Compile the requests of a manifest written under DSH_JIT_RECORD into the on-disk cache (no GPU needed, nothing is loaded).  Requests i with i % nparts == part are this
+// call's share (the build step runs one process per core).  *requests = records seen, *compiled = modules this call had to compile (the rest were in the cache already).
+int dsh_jit_replay(const char* manifest_path, int part, int nparts, int64_t* requests, int64_t* compiled) {
+  DSH_REQUIRE(manifest_path != nullptr && nparts >= 1 && part >= 0 && part < nparts, "dsh_jit_replay: bad arguments");
+  FILE* f = fopen(manifest_path, "rb");
+  if (!f) { set_error(std::string("dsh_jit_replay: cannot open ") + manifest_path); return DSH_E_INVALID; }
+  auto get_str = [&](std::string* out) {
+    uint64_t n = 0;
+    if (fread(&n, 8, 1, f) != 1 || n > (1ull << 30)) return false;
+    out->resize(n);
+    return n == 0 || fread(out->data(), 1, n, f) == n;
+  };
+  int64_t seen = 0, done = 0;
+  int rc = DSH_OK;
+  const long before = g_jit_compiles.load();
+  std::set<uint64_t> uniq;
+  for (;;) {
+    char magic[4];
+    if (fread(magic, 1, 4, f) != 4) break;  // end of file
+    uint32_t ver = 0;
+    std::string header, tu;
+    uint64_t ng = 0;
+    bool ok = memcmp(magic, "DSHJ", 4) == 0 && fread(&ver, 4, 1, f) == 1 && ver == 1 && get_str(&header) && fread(&ng, 8, 1, f) == 1 && ng < 4096;
+    std::vector<std::string> group(ok ? ng : 0);
+    for (size_t i = 0; ok && i < group.size(); ++i) ok = get_str(&group[i]);
+    ok = ok && get_str(&tu);
+    if (!ok) { set_error(std::string("dsh_jit_replay: malformed record in ") + manifest_path); rc = DSH_E_INVALID; break; }
+    uint64_t h = fnv1a(tu.data(), tu.size(), 1469598103934665603ull);
+    h = fnv1a(header.data(), header.size() + 1, h);
+    for (const std::string& e : group) h = fnv1a(e.data(), e.size() + 1, h);
+    if (!uniq.insert(h).second) continue;  // several processes recorded the same request
+    const int64_t idx = seen++;
+    if (idx % nparts != part) continue;
+    JitModelRec dummy;
+    JitModule m;
+    rc = compile_tu(dummy, tu, header.c_str(), group, &m);
+    if (rc != DSH_OK) break;
+    ++done;
+  }
+  fclose(f);
+  (void)done;
+  if (requests) *requests = seen;
+  if (compiled) *compiled = (int64_t)(g_jit_compiles.load() - before);
+  return rc;
+}
 
 int dsh_model_precompile(int model_id, int family) {
   std::lock_guard<std::mutex> lk(g_mu);

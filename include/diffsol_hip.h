@@ -274,6 +274,10 @@ int dsh_model_precompile(int model_id, int family);
 /* code objects this process compiled itself with hiprtc (not loaded from the on-disk cache, DSH_JIT_CACHE): one process per GPU shares the cache, and an
  * exclusive lock per entry makes the first rank that meets a model compile it while the others wait and load (tests/test_dist_cpu.py) */
 int64_t dsh_jit_compile_count(void);
+/* Manifest of compile requests: with DSH_JIT_RECORD=<file> in the environment every request for a module (served from the cache or compiled) is appended to <file>.
+ * dsh_jit_replay compiles the requests i of such a manifest with i % nparts == part into the on-disk cache (no GPU needed, nothing is loaded): the build step replays the
+ * committed manifests (diffsol_amd/jit_manifest/) so that a fresh box never compiles at first use.  *requests = distinct records read, *compiled = modules this call compiled. */
+int dsh_jit_replay(const char* manifest_path, int part, int nparts, int64_t* requests, int64_t* compiled);
 int dsh_model_set_twin(int model_id, int twin_id);
 int dsh_model_twin(int model_id); /* -1: none */
 /* the same for any model id: a run-time-compiled model's twin, or — created on first request — the banded lane-per-member form of a built-in

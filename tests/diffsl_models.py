@@ -314,18 +314,37 @@ def random_expr(rng, depth, names):
 _cache = {}
 
 
-def host_model(O, code, opt="-O2", model_index=0):
-    """DiffSL text -> CPU model library (product front end, Target::HostC) -> compiled with g++ -> registered with the oracle.  Returns the oracle id."""
-    key = hashlib.sha1((code + "#N=%d" % model_index).encode()).hexdigest()
-    if key in _cache:
-        return _cache[key]
+HOST_MODEL_DIR = os.path.join(ROOT, "oracle", "_build", "host_models")  # git-ignored (_build/), travels with the tree like the other built files
+
+
+def host_model_so(code, opt="-O2", model_index=0):
+    """DiffSL text -> CPU model library (product front end, Target::HostC) -> g++ -> oracle/_build/host_models/<sha1>.so, compiled once per generated source
+    (__graft_entry__.build() pre-compiles the ones bench.py asks for).  Returns (path, dims)."""
     from diffsol_amd import diffsl
     src, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C, model_index)
-    d = tempfile.mkdtemp(prefix="dsl_host_")
-    cpp, so = os.path.join(d, "model.cpp"), os.path.join(d, "libmodel.so")
-    with open(cpp, "w") as f:
-        f.write(src)
-    subprocess.run(["g++", opt, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-I", os.path.join(ROOT, "include"), "-o", so, cpp], check=True)
+    flags = [opt, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
+    key = hashlib.sha1((src + "#" + " ".join(flags)).encode()).hexdigest()[:20]
+    so = os.path.join(HOST_MODEL_DIR, key + ".so")
+    if not os.path.exists(so):
+        os.makedirs(HOST_MODEL_DIR, exist_ok=True)
+        d = tempfile.mkdtemp(prefix="dsl_host_")
+        cpp, tmp = os.path.join(d, "model.cpp"), os.path.join(d, "libmodel.so")
+        with open(cpp, "w") as f:
+            f.write(src)
+        subprocess.run(["g++"] + flags + ["-I", os.path.join(ROOT, "include"), "-o", tmp, cpp], check=True)
+        import shutil
+        shutil.move(tmp, so + ".tmp%d" % os.getpid())
+        os.replace(so + ".tmp%d" % os.getpid(), so)  # atomic: several ranks / xdist workers may want the same model
+        shutil.rmtree(d, ignore_errors=True)
+    return so, dims
+
+
+def host_model(O, code, opt="-O2", model_index=0):
+    """DiffSL text -> CPU model library -> registered with the oracle.  Returns the oracle id."""
+    key = hashlib.sha1((code + "#N=%d#%s" % (model_index, opt)).encode()).hexdigest()
+    if key in _cache:
+        return _cache[key]
+    so, dims = host_model_so(code, opt, model_index)
     mid = O.load_external_model(so)
     assert O.model_dims(mid)["n"] == dims["n"]
     _cache[key] = mid

@@ -57,3 +57,44 @@ def test_strong_scaling_mode_splits_one_ensemble_over_the_ranks():
     assert rec["scaling"] == "strong" and rec["ranks"] == 2 and rec["n_gpus"] == 2
     assert rec["config"]["members_total"] == 1001 and rec["config"]["members_per_gpu"] == 501 and rec["checks"]["finite_and_complete"]
     assert abs(rec["value"] * rec["ms_per_step"] * 1e-3 * 2 - 2 * 90 * 1001) < 1e-3 * 2 * 90 * 1001
+
+
+def test_last_stdout_line_is_the_compact_contract_line():
+    """the driver keeps an 8 KB stdout tail and parses the LAST line; a 23.7 KB line did not parse.  The last line must be <= 4 KB, carry the contract keys,
+    and the full record must sit on an EARLIER line (and in bench_detail.json)."""
+    r = _run(["--steps", "1", "--warmup", "0", "--nb", "64", "--cpu-stub"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines[-1]) <= 4096 and lines[-1].startswith("{")
+    rec = json.loads(lines[-1])
+    assert rec["detail"] == "bench_detail.json" and "workload" in rec["config"]
+    detail = [l for l in lines[:-1] if l.startswith("bench_detail: ")]
+    assert len(detail) == 1 and json.loads(detail[0][len("bench_detail: "):])["value"] == json.load(open(os.path.join(ROOT, "bench_detail.json")))["value"]
+
+
+def test_compact_line_of_a_full_shape_record_fits_4k():
+    """the real shape: round 4's full record (every config with roofline + thread-swept CPU leg, 23.7 KB) must compact to <= 4 KB with value, roofline, cpu_baseline
+    and one row per config; and a synthetic record with over-long strings everywhere still fits."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert len(line) <= 4096
+    rec = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "dtype", "scaling", "config", "roofline", "cpu_baseline", "configs"):
+        assert k in rec, k
+    for k in ("kernel", "bound", "avg_launch_us", "achieved", "peak", "unit", "frac", "lane_ops_frac", "traffic", "counters_from"):
+        assert k in rec["roofline"], k
+    for k in ("value", "unit", "threads", "cores", "usable_cpus", "parallel_efficiency", "seconds", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    assert set(full["configs"]) <= set(rec["configs"]) and all(len(v) == 4 for v in rec["configs"].values())
+    assert abs(rec["value"] / full["value"] - 1) < 1e-4 and abs(rec["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-4
+    # hostile shape: long strings, many configs
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 5000
+    fat["roofline"]["kernel"] = "k" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    for i in range(12):
+        fat["configs"][f"extra_config_number_{i}"] = {"error": "e" * 3000}
+    assert len(bench.compact_line(fat)) <= 4096
