@@ -33,6 +33,7 @@ DEVICE_ABI = {
     "dsh_ctx_create": (cint, [cint, vp, C.POINTER(vp)]),
     "dsh_ctx_destroy": (None, [vp]),
     "dsh_ctx_sync": (cint, [vp]),
+    "dsh_ctx_bind_thread": (cint, [vp]),
     "dsh_ctx_stream": (vp, [vp]),
     "dsh_ctx_device": (cint, [vp]),
     "dsh_ctx_set_block": (cint, [vp, cint]),

@@ -22,12 +22,23 @@ def build(verbose=False, jobs=8):
 MANIFEST_DIR = os.path.join(_HERE, "jit_manifest")
 
 
-def replay_manifests(jobs=None, verbose=False):
+def replay_manifests(jobs=None, verbose=False, only=None):
     """Compile every request of the committed manifests (diffsol_amd/jit_manifest/*.rec — written on a GPU box under DSH_JIT_RECORD by bench.py and the `-m gpu`
     tests, scripts/record_jit_manifest.sh) into the in-tree cache diffsol_amd/_jit_cache/ with hiprtc: no GPU needed, one process per core, requests dealt round-robin.
     A fresh box then loads every code object it asks for instead of compiling at first use.  Returns (requests, compiled)."""
     import glob
-    files = sorted(glob.glob(os.path.join(MANIFEST_DIR, "*.rec")))
+    import gzip
+    import shutil
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix="dsh_manifest_")
+    files = []
+    for gz in sorted(glob.glob(os.path.join(MANIFEST_DIR, "*.rec.gz"))):  # committed gzip-compressed (the translation units are text: 21 MB -> 1 MB)
+        if only and os.path.basename(gz).split(".")[0] not in only:
+            continue
+        out = os.path.join(tmpdir, os.path.basename(gz)[:-3])
+        with gzip.open(gz, "rb") as fi, open(out, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        files.append(out)
     if not files:
         return 0, 0
     jobs = jobs or max(1, min(len(os.sched_getaffinity(0)), 16))
@@ -53,6 +64,7 @@ def replay_manifests(jobs=None, verbose=False):
         r, c = out.split()
         requests = max(requests, int(r))
         compiled += int(c)
+    shutil.rmtree(tmpdir, ignore_errors=True)
     if verbose:
         print(f"jit manifests: {requests} requests, {compiled} compiled now")
     return requests, compiled

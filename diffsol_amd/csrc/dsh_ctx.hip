@@ -159,6 +159,7 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   hipDeviceProp_t prop;
   DSH_HIP_CHECK(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;
+  ctx->pool_limit = prop.totalGlobalMem / 4;
   ctx->pool = new std::multimap<size_t, void*>();
   ctx->live = new std::map<void*, size_t>();
   {
@@ -187,6 +188,14 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   if (ctx->ev_start) { (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop); }
   if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+// A context (and everything created from it) may move between host threads but is used by ONE thread at a time.  The current HIP device is per-thread state:
+// a thread that takes a context over calls this once before its first use (the Rust shim does it from HipContext::ptr() when the calling thread changes).
+int dsh_ctx_bind_thread(dsh_ctx* ctx) {
+  DSH_REQUIRE(ctx != nullptr, "null context");
+  DSH_HIP_CHECK(hipSetDevice(ctx->device));
+  return DSH_OK;
 }
 
 int dsh_ctx_sync(dsh_ctx* ctx) {
@@ -268,7 +277,22 @@ int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out) {
     ctx->pool_bytes -= want;
   } else {
     DSH_HIP_CHECK(hipSetDevice(ctx->device));
-    DSH_HIP_CHECK(hipMalloc(&p, want));
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && !ctx->pool->empty()) {
+      // out of memory with blocks still parked (a sweep over ensemble sizes leaves dead sizes behind — the cache only reuses exact matches): give every parked
+      // block back to the runtime and try once more.  The parked blocks may still be read by work in flight, hence the synchronise.
+      (void)hipGetLastError();
+      DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+      for (auto& kv : *ctx->pool) (void)hipFree(kv.second);
+      ctx->pool->clear();
+      ctx->pool_bytes = 0;
+      e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("dsh_malloc: hipMalloc of " + std::to_string(want) + " bytes failed: " + hipGetErrorString(e));
+      return DSH_E_HIP;
+    }
   }
   (*ctx->live)[p] = want;
   if (zero && nbytes > 0) DSH_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)nbytes, ctx->stream));
@@ -285,8 +309,7 @@ int dsh_free(dsh_ctx* ctx, void* p) {
   }
   const size_t sz = it->second;
   ctx->live->erase(it);
-  constexpr size_t kMaxPoolBytes = (size_t)64 << 30;  // 288 GB of HBM: keep up to 64 GiB parked per context
-  if (ctx->pool_bytes + sz > kMaxPoolBytes) {
+  if (ctx->pool_bytes + sz > ctx->pool_limit) {  // a quarter of the device's memory (72 GB of the 288 GB of an MI355X) may stay parked per context
     DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     DSH_HIP_CHECK(hipFree(p));
     return DSH_OK;

@@ -76,6 +76,7 @@ struct dsh_ctx {
   std::multimap<size_t, void*>* pool = nullptr;
   std::map<void*, size_t>* live = nullptr;
   size_t pool_bytes = 0;
+  size_t pool_limit = (size_t)64 << 30;  // parked bytes above which dsh_free returns blocks to the runtime: a quarter of the device's memory (set by dsh_ctx_create)
   // optional HIP-event timing of the dominant (fused Newton iteration) kernel on this context's stream
   bool timing = false;
   int timing_target = 0;  // which launches the brackets go around (DSH_TIMING_*): 0 = the device-resident integrators / the fused Newton launch, 1 = dsh_lu_solve, 2 = dsh_lu_factor

@@ -54,6 +54,11 @@ int dsh_version(void);
 int dsh_ctx_create(int device, void* stream, dsh_ctx** out);
 void dsh_ctx_destroy(dsh_ctx* ctx);
 int dsh_ctx_sync(dsh_ctx* ctx);
+/* THREADING CONTRACT: a context and every object created from it (vectors, matrices, LU handles, solvers) may be MOVED between host threads, but are used by one
+ * thread at a time — the library keeps per-context state (reduction records, scratch, the stream-ordered allocation cache) without locks, exactly as the reference's
+ * CudaVec relies on its one in-order CudaStream (context/cuda.rs:41-44).  dsh_last_error is per thread.  The current HIP device is per-thread state: a thread that
+ * takes a context over calls dsh_ctx_bind_thread once before its first use. */
+int dsh_ctx_bind_thread(dsh_ctx* ctx);
 void* dsh_ctx_stream(dsh_ctx* ctx);
 int dsh_ctx_device(dsh_ctx* ctx);
 /* threads per workgroup for one-lane-per-system kernels (default 64; tuning knob, power of two in [64,1024]) */

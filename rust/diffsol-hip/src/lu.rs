@@ -19,8 +19,10 @@ pub struct HipLU {
     linearisation_set: bool,
     structure: i32,
 }
-// one host thread per solver (like the reference); the factors live on the context's stream
-// (no `Send`: one thread per context, see context.rs)
+// one host thread at a time per solver (like the reference); the factors live on the context's stream.
+// SAFETY: the `dsh_lu` handle belongs to the context of `matrix`; it moves with the solver under the contract of context.rs.  (`LinearSolver` itself only asks for
+// `Default`, linear_solver/mod.rs:19, but a solver object that owns its linear solver is moved as a whole.)
+unsafe impl Send for HipLU {}
 
 impl Default for HipLU {
     fn default() -> Self {

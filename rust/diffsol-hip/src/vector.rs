@@ -26,7 +26,8 @@ pub struct DeviceBuf {
     pub(crate) nbytes: usize,
     pub(crate) ctx: HipContext,
 }
-// (no `Send`: one thread per context, see context.rs)
+// SAFETY: the allocation belongs to the context it was made from; it moves with it under the contract of context.rs (used by one thread at a time).
+unsafe impl Send for DeviceBuf {}
 impl DeviceBuf {
     pub(crate) fn new(nbytes: usize, zero: bool, ctx: &HipContext) -> Self {
         let mut p: *mut c_void = ptr::null_mut();

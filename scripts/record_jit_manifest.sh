@@ -7,9 +7,9 @@ what=${1:-all}
 mkdir -p gpurun_out/jit_manifest
 if [ "$what" = bench ] || [ "$what" = all ]; then
   rm -f gpurun_out/jit_manifest/bench.rec
-  /usr/bin/time -v env DSH_JIT_RECORD=$PWD/gpurun_out/jit_manifest/bench.rec python bench.py --steps 20 --warmup 5 > gpurun_out/bench_record.out 2> gpurun_out/bench_record.err
-  echo "bench rc=$?"; tail -1 gpurun_out/bench_record.out | head -c 4200; echo
-  grep -E "Elapsed|Maximum resident" gpurun_out/bench_record.err
+  t0=$(date +%s.%N)
+  DSH_JIT_RECORD=$PWD/gpurun_out/jit_manifest/bench.rec python bench.py --steps 20 --warmup 5 > gpurun_out/bench_record.out 2> gpurun_out/bench_record.err
+  echo "bench rc=$? wall=$(echo "$(date +%s.%N) - $t0" | bc) s"; tail -1 gpurun_out/bench_record.out | head -c 4200; echo
 fi
 if [ "$what" = tests ] || [ "$what" = all ]; then
   rm -f gpurun_out/jit_manifest/tests.rec
