@@ -22,7 +22,7 @@ def build(verbose=False, jobs=8):
 MANIFEST_DIR = os.path.join(_HERE, "jit_manifest")
 
 
-def replay_manifests(jobs=None, verbose=False, only=None):
+def replay_manifests(jobs=None, verbose=False, only=None, budget_s=420.0):
     """Compile every request of the committed manifests (diffsol_amd/jit_manifest/*.rec — written on a GPU box under DSH_JIT_RECORD by bench.py and the `-m gpu`
     tests, scripts/record_jit_manifest.sh) into the in-tree cache diffsol_amd/_jit_cache/ with hiprtc: no GPU needed, one process per core, requests dealt round-robin.
     A fresh box then loads every code object it asks for instead of compiling at first use.  Returns (requests, compiled)."""
@@ -42,31 +42,42 @@ def replay_manifests(jobs=None, verbose=False, only=None):
     if not files:
         return 0, 0
     jobs = jobs or max(1, min(len(os.sched_getaffinity(0)), 16))
-    code = ("import ctypes as C, sys\n"
+    # worker k compiles requests k, k + jobs, ... of every manifest, one dsh_jit_replay call per request, and starts no new one after the deadline (what is left is
+    # compiled at first use, as before)
+    code = ("import ctypes as C, sys, time\n"
             "from diffsol_amd import _ffi\n"
             "dev = _ffi.load_device_lib()\n"
-            "part, nparts = int(sys.argv[1]), int(sys.argv[2])\n"
-            "tot = [0, 0]\n"
-            "for path in sys.argv[3:]:\n"
+            "k, jobs, deadline = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])\n"
+            "tot = [0, 0, 0]\n"
+            "for path in sys.argv[4:]:\n"
             "    r, c = C.c_int64(0), C.c_int64(0)\n"
-            "    rc = dev.dsh_jit_replay(path.encode(), part, nparts, C.byref(r), C.byref(c))\n"
-            "    assert rc == 0, (path, dev.dsh_last_error())\n"
-            "    tot[0] += r.value; tot[1] += c.value\n"
-            "print(tot[0], tot[1])\n")
+            "    assert dev.dsh_jit_replay(path.encode(), (1 << 30) - 1, 1 << 30, C.byref(r), C.byref(c)) == 0, (path, dev.dsh_last_error())\n"
+            "    n = r.value\n"
+            "    tot[0] += n\n"
+            "    for i in range(k, n, jobs):\n"
+            "        if time.time() > deadline:\n"
+            "            tot[2] += 1\n"
+            "            continue\n"
+            "        assert dev.dsh_jit_replay(path.encode(), i, n, C.byref(r), C.byref(c)) == 0, (path, i, dev.dsh_last_error())\n"
+            "        tot[1] += c.value\n"
+            "print(tot[0], tot[1], tot[2])\n")
     env = dict(os.environ, PYTHONPATH=os.path.dirname(_HERE) + os.pathsep + os.environ.get("PYTHONPATH", ""))
     env.pop("DSH_JIT_RECORD", None)
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(k), str(jobs)] + files, env=env, stdout=subprocess.PIPE, text=True) for k in range(jobs)]
-    requests = compiled = 0
+    import time
+    deadline = time.time() + budget_s
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(k), str(jobs), repr(deadline)] + files, env=env, stdout=subprocess.PIPE, text=True) for k in range(jobs)]
+    requests = compiled = skipped = 0
     for pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError("dsh_jit_replay failed in a build worker")
-        r, c = out.split()
+        r, c, sk = out.split()
         requests = max(requests, int(r))
         compiled += int(c)
+        skipped += int(sk)
     shutil.rmtree(tmpdir, ignore_errors=True)
     if verbose:
-        print(f"jit manifests: {requests} requests, {compiled} compiled now")
+        print(f"jit manifests: {requests} requests, {compiled} compiled now, {skipped} left for first use (time budget {budget_s:g} s)")
     return requests, compiled
 
 

@@ -525,9 +525,8 @@ int dsh_jit_replay(const char* manifest_path, int part, int nparts, int64_t* req
     if (idx % nparts != part) continue;
     JitModelRec dummy;
     JitModule m;
-    rc = compile_tu(dummy, tu, header.c_str(), group, &m);
-    if (rc != DSH_OK) break;
-    ++done;
+    // a request that does not compile is skipped: the recorded runs contain the tests' deliberately malformed models (rejected by dsh_model_compile at run time too)
+    if (compile_tu(dummy, tu, header.c_str(), group, &m) == DSH_OK) ++done;
   }
   fclose(f);
   (void)done;
