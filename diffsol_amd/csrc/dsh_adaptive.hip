@@ -199,11 +199,16 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   if (nb == 0) return DSH_OK;
   AdaptiveConsts C;
   std::memset((void*)&C, 0, sizeof C);  // the block is compared byte-wise with the cached copy below
-  C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
+  C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval; C.r.member_lanes = 0;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
   if (C.r.o.max_steps <= 0) C.r.o.max_steps = 10000000;
   DSH_REQUIRE(C.r.o.group == 1 || C.r.o.group == 64, "adaptive group must be 1 (per member) or 64 (wavefront lock-step)");
+  {
+    // per-member control of the register-resident kernel: DSH_MEMBER_LANES = 32 | 16 | 8 puts that many members on a wavefront (profiles/r05_member_lanes.md); 0 / unset: 64
+    static const int member_lanes_env = [] { const char* e = std::getenv("DSH_MEMBER_LANES"); const int v = e && *e ? std::atoi(e) : 0; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
+    C.r.member_lanes = (C.r.o.group == 1 && !is_jit_model(model) && !sens && !steps) ? member_lanes_env : 0;
+  }
   if (steps) { C.steps_t_out = steps->t_out; C.steps_cap = (int)steps->cap; }
   if (sens) {
     C.sens_out = sens->out; C.sens_rtol = sens->rtol; C.sens_error_control = sens->natol > 0 ? 1 : 0;
@@ -276,7 +281,8 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
   rc = dsh_malloc(ctx, (int64_t)(sizeof(unsigned long long) * 8), 1, (void**)&totals_dev);
   if (rc != DSH_OK) { if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } return rc; }
   const bool ba = atol_nb == 1 && nb != 1;
-  const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
+  const int per_wave = C.r.member_lanes > 0 ? C.r.member_lanes : 64;
+  const dim3 grid((unsigned)((nb + per_wave - 1) / per_wave)), blk(64);
   bool launched = false;
   DSH_HIP_CHECK(timing_begin(ctx));
 #ifdef DSH_EXPERIMENTS

@@ -70,9 +70,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_ADAPTIVE
   constexpr int N = Mdl::N, NP = Mdl::NP;
   constexpr int NR = Mdl::NROOTS > 0 ? Mdl::NROOTS : 1;
   const AdaptiveConsts& C = *Cp;
-  const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = bglobal < nb;  // lanes past the ensemble shadow a live member (no stores) so that the whole wavefront reaches every reduction
-  int64_t b_ = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;  // shadow the wavefront's first member: invisible in the group max
+  const int ML = (!WAVE && !SEG && C.r.member_lanes > 0) ? C.r.member_lanes : 64;  // members per wavefront under per-member control (see ResidentConsts)
+  const int64_t bglobal = (int64_t)blockIdx.x * ML + threadIdx.x;
+  const bool active = (int)threadIdx.x < ML && bglobal < nb;  // the other lanes shadow a live member (no stores) so that the whole wavefront reaches every reduction
+  int64_t b_ = active ? bglobal : (int64_t)blockIdx.x * ML;  // shadow the wavefront's first member: invisible in the group max
   if constexpr (SEG) { if (C.seg_lane_member != nullptr) b_ = C.seg_lane_member[b_]; }  // segmented runs: the member this lane works for in this launch
   const int64_t b = b_;
   const bool fresh = !SEG || C.seg_fresh != 0;  // not a resumed launch

@@ -165,6 +165,19 @@ static int sdirk_newton_staged(dsh_ctx* ctx, int model, int64_t size, int64_t nb
   double* delta = ctx->f64_scratch;
   if (!model_dyn_sdirk_residual(ctx, model, size, nb, t, c, h, phi, k_in, p, delta)) { set_error("newton iteration: model has no staged form"); return DSH_E_UNSUPPORTED; }
   unsigned int gs = 0, ss = 0, gn = 0, sn = 0;
+  {  // banded factors, small ensemble: the Newton update and the norm ride in the solve's launch (k_lu_band_solve_team<.., EPI>); one record carries both results
+    bool fused = false;
+    rc = lu_solve_norm_launch(lu, delta, k_in, k_out, error_y, nb, atol, anb, rtol, &gs, &ss, &fused);
+    if (rc != DSH_OK) return rc;
+    if (fused) {
+      rc = fetch_records(ctx, gs, ss);
+      if (rc != DSH_OK) return rc;
+      out[0] = bits_to_double(ctx->res_m0);
+      out[1] = 0.0;
+      out[2] = (double)ctx->res_cnt;
+      return DSH_OK;
+    }
+  }
   rc = lu_solve_launch(lu, delta, &gs, &ss);
   if (rc != DSH_OK) return rc;
   rc = vec_sub_squared_norm_launch(ctx, n, nb, delta, k_in, k_out, error_y, nb, atol, anb, rtol, &gn, &sn);
@@ -189,6 +202,21 @@ int dsh_lu_solve_squared_norm(const dsh_lu* lu, double* x, const double* y, int6
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) { *out_norm = 0.0; return DSH_OK; }
   unsigned int gs = 0, ss = 0;
+  {
+    bool fused = false;
+    int rcf = lu_solve_norm_launch(lu, x, nullptr, nullptr, y, ynb, atol, anb, rtol, &gs, &ss, &fused);
+    if (rcf != DSH_OK) return rcf;
+    if (fused) {
+      rcf = fetch_records(ctx, gs, ss);
+      if (rcf != DSH_OK) return rcf;
+      *out_norm = bits_to_double(ctx->res_m0);
+      if (ctx->res_cnt != 0ull) {
+        set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+        return DSH_E_SINGULAR;
+      }
+      return DSH_OK;
+    }
+  }
   int rc = lu_solve_launch(lu, x, &gs, &ss);
   if (rc != DSH_OK) return rc;
   rc = dsh_vec_squared_norm(ctx, n, nb, x, y, ynb, atol, anb, rtol, out_norm, nullptr);  // waits for its own records: the solve's are there by then

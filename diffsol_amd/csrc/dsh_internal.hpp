@@ -131,6 +131,8 @@ int fetch_records(dsh_ctx* ctx, int64_t nblocks, unsigned int seq, int64_t first
 bool model_has_staged_newton(int model, int64_t size);
 bool model_dyn_sdirk_residual(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, double h, const double* phi, const double* k, const double* p, double* out);
 int lu_solve_launch(const dsh_lu* lu, double* rhs, unsigned int* gx, unsigned int* seq);
+int lu_solve_norm_launch(const dsh_lu* lu, double* rhs, const double* xin, double* xout, const double* y, int64_t ynb, const double* atol, int64_t anb, double rtol,
+                         unsigned int* gx, unsigned int* seq, bool* fused);
 int vec_sub_squared_norm_launch(dsh_ctx* ctx, int64_t n, int64_t nb, const double* delta, const double* xin, double* xout, const double* y, int64_t ynb,
                                 const double* atol, int64_t anb, double rtol, unsigned int* gx, unsigned int* seq);
 int ensure_i32_scratch(dsh_ctx* ctx, int64_t len);

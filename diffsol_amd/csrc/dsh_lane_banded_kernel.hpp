@@ -28,6 +28,9 @@ namespace dsh {
 #ifndef DSH_LANE_BANDED_WAVES_PER_EU
 #define DSH_LANE_BANDED_WAVES_PER_EU 3
 #endif
+#ifndef DSH_LANE_BANDED_PAD
+#define DSH_LANE_BANDED_PAD 0  // extra doubles at the end of the difference arrays: changes the size of the per-lane scratch frame (and with it the address pattern of the wavefronts)
+#endif
 #ifndef DSH_LANE_BANDED_UNROLL
 #define DSH_LANE_BANDED_UNROLL 4
 #endif
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DSH_LANE_BAN
   __syncthreads();
 
   // ---- per-lane memory (scratch: interleaved by lane in hardware, every access one coalesced 512-byte transaction per wavefront)
-  alignas(16) double Dm[2 * kNC * N];                       // diff and diff_tmp: row j of the current one at Dm[(cur * kNC + j) * N]
+  alignas(16) double Dm[2 * kNC * N + DSH_LANE_BANDED_PAD];                       // diff and diff_tmp: row j of the current one at Dm[(cur * kNC + j) * N]
   alignas(16) double Jb[CW * N], Lf[K * N], Uf[CW * N];     // band of f_y, banded LU factors of I - c f_y
   int P[N];
   alignas(16) double y[N], xy[2 * N], psi[N], w[N];         // state, (y_predict | Newton iterate), psi_neg_y0, work vector (f, then the solve in place)

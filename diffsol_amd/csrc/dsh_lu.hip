@@ -382,6 +382,46 @@ namespace dsh {
 // together with a later reduction (the staged SDIRK Newton iteration, dsh_fused.hip)
 int lu_solve_launch(const dsh_lu* lu, double* rhs, unsigned int* gx, unsigned int* seq) { return lu_solve_launch_impl(lu, rhs, false, gx, seq); }
 }  // namespace dsh
+namespace dsh {
+// The banded solve with its caller's next pass fused in (k_lu_band_solve_team<.., EPI>): x <- A^-1 x, the squared norm of x against y / atol / rtol in the launch's
+// record (res_m0, next to the zero-pivot count res_cnt) and, when xin is given, xout = xin - x.  *fused = false (nothing enqueued) where the workgroup form of the
+// banded solve does not apply — the caller then runs the separate launches.  Same bits either way.  DSH_LU_SOLVE_EPI=0 disables.
+int lu_solve_norm_launch(const dsh_lu* lu, double* rhs, const double* xin, double* xout, const double* y, int64_t ynb, const double* atol, int64_t anb, double rtol,
+                         unsigned int* gx, unsigned int* seq_out, bool* fused) {
+  *fused = false;
+  dsh_ctx* ctx = lu->ctx;
+  if (!lu->factored) { set_error("dsh_lu_solve: LU not initialised"); return DSH_E_NOT_SETUP; }
+  const int64_t n = lu->n, nb = lu->nbatch;
+  static const int epi_env = [] { const char* e = std::getenv("DSH_LU_SOLVE_EPI"); return e && *e ? std::atoi(e) : 1; }();
+  static const int wide_env = [] { const char* e = std::getenv("DSH_LU_BAND_WIDE"); return e && *e ? std::atoi(e) : -1; }();
+  const bool wide = (wide_env >= 0 ? wide_env != 0 : (n >= 128 && nb <= 16384)) && n * nb < (1ll << 28);
+  if (!epi_env || !(n > 8 && lu->band_k >= 1 && lu->band_k <= 2) || !wide || wide_env == 2 || nb > 4096) return DSH_OK;
+  if (ctx->solve_mode == DSH_SOLVE_REORDERED && lu->band_k == 1 && n >= 32 && n <= 1024) return DSH_OK;  // the opt-in reordered solve keeps its own kernel
+  if (!((ynb == 1 || ynb == nb) && (anb == 1 || anb == nb))) return DSH_OK;
+  const size_t dyn = lu->band_k == 1 ? band_team_epi_lds_bytes<1, 16>(n) : band_team_epi_lds_bytes<2, 16>(n);
+  if (dyn > (size_t)96 * 1024) return DSH_OK;  // the squares of the whole vector live in LDS: n <= ~700 at 16 systems per workgroup
+  band_epi_args ea;
+  ea.xin = xin; ea.xout = xout; ea.y = y; ea.atol = atol; ea.rtol = rtol; ea.by = (ynb == 1 && nb != 1) ? 1 : 0; ea.ba = (anb == 1 && nb != 1) ? 1 : 0;
+  { static const int xv = [] { const char* e = std::getenv("DSH_TEAM_EPI_X"); return e && *e ? std::atoi(e) : 0; }(); ea.xvar = xv; }
+  return timed_call(ctx, DSH_TIMING_LU_SOLVE, [&]() -> int {
+    unsigned long long* rec; unsigned int seq;
+    const dim3 g = grid_for(nb, 16);
+    int rc = begin_records(ctx, g.x, &rec, &seq);
+    if (rc != DSH_OK) return rc;
+#define DSH_TEAM_EPI(KK)                                                                                                                                          \
+  do {                                                                                                                                                            \
+    static bool attr_set = false;                                                                                                                                 \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_lu_band_solve_team<KK, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); (void)hipGetLastError(); attr_set = true; } \
+    hipLaunchKernelGGL((k_lu_band_solve_team<KK, 16, true>), g, dim3(kTeamThreads), dyn, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq, ea); \
+  } while (0)
+    if (lu->band_k == 1) DSH_TEAM_EPI(1); else DSH_TEAM_EPI(2);
+#undef DSH_TEAM_EPI
+    DSH_HIP_CHECK(hipGetLastError());
+    *gx = g.x; *seq_out = seq; *fused = true;
+    return DSH_OK;
+  });
+}
+}  // namespace dsh
 extern "C" {
 static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsigned int* gx_out, unsigned int* seq_out) {
   dsh_ctx* ctx = lu->ctx;

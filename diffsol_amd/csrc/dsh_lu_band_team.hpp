@@ -55,9 +55,29 @@ __device__ unsigned long long g_team_stamp[2][8];
 #define TEAM_PROF_STORE(slot)
 #endif
 
+// EPI (round 5): what the caller does with the solution next, in the shadow of the chain — the weighted mean-square norm of the solution (Vector::squared_norm against
+// y / atol / rtol: the Newton iteration's convergence norm, the SDIRK error estimate) and, optionally, the Newton update xout = xin - solution (NoLineSearch::
+// take_optimal_step).  The backward loaders fetch y, atol (and xin) of the rows they fetch U for; the lanes that store a chunk's solution form
+// term = x / (|y| rtol + atol), keep term * term in LDS ([row][system], the whole vector: n x SYS doubles) and store the update; when the sweep is over, one lane per
+// system adds the n squares in index order — the terms, the order of the additions and the division by n of k_squared_norm: the same bits — and the norm leaves in the
+// launch's record (max over the systems) next to the zero-pivot count.  Replaces a second launch that read three to four vectors (23.7 us at 512 x 4096) by ~3 us of
+// additions at the end of this one.
+struct band_epi_args {
+  const double* xin;   // nullptr: norm only
+  double* xout;
+  const double* y;     // n x nb, or n (by != 0)
+  const double* atol;  // n x nb, or n (ba != 0)
+  double rtol;
+  int by, ba;
+  int xvar;  // TEMP experiment bits
+};
+constexpr int kTeamEpiPlanes = 3;  // y, atol, xin of a chunk's rows
 template <int K, int SYS>
+constexpr size_t band_team_epi_lds_bytes(int64_t n) { return sizeof(double) * ((size_t)2 * kTeamEpiPlanes * band_team_cfg<K, SYS>::CH * SYS + (size_t)n * SYS); }
+
+template <int K, int SYS, bool EPI = false>
 __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, int64_t nb, const double* __restrict__ fac, const int32_t* __restrict__ piv,
-                                                                     double* __restrict__ rhs, unsigned long long* rec, unsigned int seq) {
+                                                                     double* __restrict__ rhs, unsigned long long* rec, unsigned int seq, band_epi_args ea = band_epi_args()) {
   using Cfg = band_team_cfg<K, SYS>;
   constexpr int S = SYS, R = Cfg::R, C = Cfg::C, CH = Cfg::CH, Q = Cfg::Q, FO = Cfg::FO, BO = Cfg::BO, MO = Cfg::MO, RF = Cfg::RF, RB = Cfg::RB;
   constexpr int G = kTeamLoaders / S;  // row groups
@@ -73,6 +93,10 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
 #define TEAM_OUT(sl, t, s) sOut[sl][t][s]
 #endif
   __shared__ int sMoved[2][4];  // forward: did any system of the workgroup interchange in the chunk (one word per loader wavefront)
+  extern __shared__ double sDynTeam[];  // EPI: [2][kTeamEpiPlanes][CH][S] operands of the epilogue, then [n][S] squared terms
+  double* const sE = sDynTeam;
+  double* const sSq = sDynTeam + 2 * kTeamEpiPlanes * CH * S;
+  auto SE = [&](int sl, int o, int t, int ss) __attribute__((always_inline)) -> double& { return sE[((sl * kTeamEpiPlanes + o) * CH + t) * S + ss]; };
   TEAM_STAMP(0)
   const int tid = threadIdx.x;
   const bool loader = tid < kTeamLoaders;
@@ -265,7 +289,11 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
 
   // ================================================================ backward with U (bandwidth 2K): chunk c covers rows n-1 - (c*CH + t)
   if (loader) {
-    double pb[RB][BO][Q];
+    constexpr int BE = BO + (EPI ? kTeamEpiPlanes : 0);
+    double pb[RB][BE][Q];
+    int rowq[Q];  // EPI: row i of the chunk issued next (negative past the top of the matrix)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) rowq[q] = ni - 1 - (q * G + g);
     // U(i-d, i) lives at fac[(d*n + i-d)*nb + b] = (fac + (d*n - d)*nb)[i*nb + b]: one offset per row serves every diagonal; a row above the matrix
     // (i - d < 0, its value is never used) is clamped to row 0 of its diagonal by a single max
     const double* ubase[C];
@@ -275,20 +303,32 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
     int offi[Q];  // byte offset of row i = n-1 - (c*CH + q*G + g), for the chunk issued next; negative past the top of the matrix
 #pragma unroll
     for (int q = 0; q < Q; ++q) offi[q] = (ni - 1 - (q * G + g)) * (int)nb8 + (int)b8;
-    auto issue = [&](double (&pd)[BO][Q]) __attribute__((always_inline)) {
+    auto issue = [&](double (&pd)[BE][Q]) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
 #pragma unroll
         for (int d = 0; d < C; ++d) pd[d][q] = ld_f64(ubase[d], (uint32_t)max(offi[q], ulo[d]));
         pd[C][q] = ld_f64(rhs, (uint32_t)max(offi[q] - C * (int)nb8, (int)b8));
+        if constexpr (EPI) {  // the epilogue's operands of row i itself (clamped like the others; rows above the matrix are never used)
+          const uint32_t oi = (uint32_t)max(offi[q], (int)b8);
+          const int ri = max(rowq[q], 0);
+          pd[BO][q] = ea.by ? ea.y[ri] : ld_f64(ea.y, oi);
+          pd[BO + 1][q] = ea.ba ? ea.atol[ri] : ld_f64(ea.atol, oi);
+          pd[BO + 2][q] = ea.xin ? ld_f64(ea.xin, oi) : 0.0;
+          rowq[q] -= CH;
+        }
         offi[q] -= CH * (int)nb8;
       }
     };
-    auto land = [&](double (&pd)[BO][Q], int c) __attribute__((always_inline)) {
+    auto land = [&](double (&pd)[BE][Q], int c) __attribute__((always_inline)) {
       const int sl = c & 1;
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int t = q * G + g;
+        if constexpr (EPI) {
+#pragma unroll
+          for (int o = 0; o < kTeamEpiPlanes; ++o) SE(sl, o, t, s) = pd[BO + o][q];  // read back by this same lane when it stores the chunk's results
+        }
 #pragma unroll
         for (int o = 0; o < BO; ++o) sOp[sl][o][t][s] = pd[o][q];
         // the denominator half of the division, off the chain; a diagonal the split division cannot vouch for hands the chain a NaN: its quotient then fails
@@ -304,7 +344,15 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int t = q * G + g, i = ni - 1 - (c * CH + t);
-        if (valid && i >= 0) st_f64(rhs, (uint32_t)i * nb8 + b8, TEAM_OUT(sl, t, s));
+        const double xs = TEAM_OUT(sl, t, s);
+        if (valid && i >= 0) st_f64(rhs, (uint32_t)i * nb8 + b8, xs);
+        if constexpr (EPI) {
+          if (i >= 0) {
+            const double term = (ea.xvar & 2) ? xs : xs / (fabs(SE(sl, 0, t, s)) * ea.rtol + SE(sl, 1, t, s));  // Vector::squared_norm's term (nalgebra_serial.rs:395-408)
+            sSq[i * S + s] = term * term;
+            if (ea.xin != nullptr && valid) st_f64(ea.xout, (uint32_t)i * nb8 + b8, SE(sl, 2, t, s) - xs);  // xn -= delta (line_search.rs:57-68)
+          }
+        }
       }
     };
 #pragma unroll
@@ -446,7 +494,33 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
     TEAM_PROF_STORE(2)
     TEAM_STAMP(4)
   }
-  block_publish(0ull, 0ull, (chain && valid) ? bad : 0ull, rec, seq);
+  unsigned long long nbits = 0ull;
+  if constexpr (EPI) {
+    __syncthreads();  // every chunk's squares are in LDS
+    if (tid < S && !(ea.xvar & 1)) {    // one lane per system: the n additions in index order, sixteen LDS reads in flight at a time
+      double acc = 0.0;
+      int i = 0;
+      if (ni >= 16) {  // the additions are one dependent chain (~8 cycles each): the next sixteen squares are read from LDS while the current sixteen are added
+        double v[16], w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sSq[k * S + s];
+        for (; i + 32 <= ni; i += 16) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) w[k] = sSq[(i + 16 + k) * S + s];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc += v[k];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+        i += 16;
+      }
+      for (; i < ni; ++i) acc += sSq[i * S + s];
+      if (valid) nbits = d2u(acc / (double)n);
+    }
+  }
+  block_publish(nbits, 0ull, (chain && valid) ? bad : 0ull, rec, seq);
 }
 
 }  // namespace dsh

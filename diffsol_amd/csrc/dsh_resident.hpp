@@ -38,6 +38,7 @@ struct ResidentConsts {
   double ls_steptol;               // eps^(2/3)          (line_search.rs:100)
   dsh_adaptive_options o;
   int n_eval;
+  int member_lanes;  // per-member control (group 1) of the lane-per-member kernels: lanes of every wavefront that carry a member (0 = all 64); the other lanes shadow the first
 };
 
 // weighted mean square, sequential like Vector::squared_norm (nalgebra_serial.rs:395-408)

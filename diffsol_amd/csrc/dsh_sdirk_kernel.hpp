@@ -38,9 +38,11 @@ __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64
   const SdirkConsts& T = *Cp;
   const ResidentConsts& C = T.r;
   const dsh_adaptive_options& o = C.o;
-  const int64_t bglobal = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = bglobal < nb;  // lanes past the ensemble shadow the wavefront's first member (no stores): invisible in the group reductions
-  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * blockDim.x;
+  // per-member control may run with fewer than 64 members per wavefront (C.member_lanes: more wavefronts per SIMD, a wavefront pays for the union of fewer paths)
+  const int ML = (!WAVE && C.member_lanes > 0) ? C.member_lanes : 64;
+  const int64_t bglobal = (int64_t)blockIdx.x * ML + threadIdx.x;
+  const bool active = (int)threadIdx.x < ML && bglobal < nb;  // the other lanes shadow the wavefront's first member (no stores): invisible in the group reductions
+  const int64_t b = active ? bglobal : (int64_t)blockIdx.x * ML;
   const int ln = threadIdx.x;
   const double rtol = C.rtol;
   double p[NP], atol[N];

@@ -89,10 +89,15 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
   if (nb == 0) return DSH_OK;
   SdirkConsts T;
   std::memset((void*)&T, 0, sizeof T);
-  T.r.rtol = rtol; T.r.t0 = t0; T.r.h0 = h0; T.r.n_eval = (int)n_eval;
+  T.r.rtol = rtol; T.r.t0 = t0; T.r.h0 = h0; T.r.n_eval = (int)n_eval; T.r.member_lanes = 0;
   if (opts) T.r.o = *opts; else dsh_adaptive_default_options(&T.r.o);
   if (T.r.o.max_steps <= 0) T.r.o.max_steps = 10000000;
   DSH_REQUIRE(T.r.o.group == 1 || T.r.o.group == 64, "group must be 1 (per member) or 64 (wavefront lock-step)");
+  {
+    // per-member control: DSH_MEMBER_LANES = 32 | 16 | 8 puts that many members on a wavefront (measured in profiles/r05_member_lanes.md); 0 / unset: 64
+    static const int member_lanes_env = [] { const char* e = std::getenv("DSH_MEMBER_LANES"); const int v = e && *e ? std::atoi(e) : 0; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
+    T.r.member_lanes = (T.r.o.group == 1 && !is_jit_model(model)) ? member_lanes_env : 0;
+  }
   T.r.eta_reset = std::pow(20.0, 1.25);
   T.r.eta_reset_ts = std::pow(100.0, 1.25);
   T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
@@ -121,7 +126,8 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
   DSH_HIP_CHECK(hipMemcpyAsync(t_eval_dev, t_eval_host, sizeof(double) * n_eval, hipMemcpyHostToDevice, ctx->stream));
   const bool ba = atol_nb == 1 && nb != 1;
   const bool wave = T.r.o.group == 64;
-  const dim3 grid((unsigned)((nb + 63) / 64)), blk(64);
+  const int per_wave = T.r.member_lanes > 0 ? T.r.member_lanes : 64;
+  const dim3 grid((unsigned)((nb + per_wave - 1) / per_wave)), blk(64);
   DSH_HIP_CHECK(timing_begin(ctx));
   if (is_jit_model(model)) {
     const std::string name = std::string("dsh::k_sdirk_resident<dsh::JitModel, ") + (ba ? "true" : "false") + ", " + (wave ? "true" : "false") + ", " + (method == 1 ? "3" : "4") + (sens ? ", true>" : ">");

@@ -99,7 +99,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   C.sens_out = sens ? sens->out : nullptr; C.sens_rtol = sens ? sens->rtol : 0.0; C.sens_atol = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
   C.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.sens_pad = 1;
-  C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval;
+  C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval; C.r.member_lanes = 0;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);
   if (C.r.o.max_steps <= 0) C.r.o.max_steps = 10000000;
@@ -243,7 +243,7 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   fill_tableau(method, C.T);
   C.T.sens_out = sens ? sens->out : nullptr; C.T.sens_rtol = sens ? sens->rtol : 0.0; C.T.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.T.sens_pad = 1;
   for (int q = 0; q < 4; ++q) C.T.sens_atol[q] = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
-  C.T.r.rtol = rtol; C.T.r.t0 = t0; C.T.r.h0 = h0; C.T.r.n_eval = (int)n_eval;
+  C.T.r.rtol = rtol; C.T.r.t0 = t0; C.T.r.h0 = h0; C.T.r.n_eval = (int)n_eval; C.T.r.member_lanes = 0;
   C.T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   C.T.r.eta_reset = std::pow(20.0, 1.25);
   C.T.r.eta_reset_ts = std::pow(100.0, 1.25);

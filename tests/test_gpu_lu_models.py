@@ -656,3 +656,39 @@ def test_band_only_jacobian_evaluation_writes_the_bits_of_the_dense_one(H, ctx1,
     assert L.dsh_model_has_band_jacobian(H.MODELS["robertson_ode"], 1) == 0 and L.dsh_model_has_band_jacobian(H.MODELS["rlc"], 0) == 0  # register-resident forms
     assert L.dsh_model_jacobian_band(c._h, H.MODELS["robertson_ode"], 1, nb, 0.0, X.ptr, P.ptr, 2, 2, Jb.ptr) < 0
     assert L.dsh_model_jacobian_band(c._h, H.MODELS[name], size, nb, 0.0, X.ptr, P.ptr, kl.value - 1, ku.value, Jb.ptr) < 0  # narrower than the declared band
+
+
+@pytest.mark.parametrize("n,k,nb", [(130, 1, 5), (512, 1, 16), (512, 1, 37), (300, 2, 9), (640, 1, 3), (900, 1, 4), (256, 3, 6)])
+@pytest.mark.parametrize("ynb_full", [True, False])
+def test_banded_solve_with_the_norm_fused_into_its_launch_gives_the_bits_of_solve_then_norm(H, O, n, k, nb, ynb_full):
+    """dsh_lu_solve_squared_norm on banded factors of a small ensemble runs ONE launch (k_lu_band_solve_team<.., EPI>: the loaders of the backward sweep form the
+    norm's terms, one lane per system adds them in index order at the end): the solution must equal dsh_lu_solve's and the norm Vector::squared_norm's sequential
+    sum, bit for bit.  n = 900 (the squares do not fit LDS) and K = 3 take the two-launch fallback: same bits."""
+    rng = np.random.default_rng(7 * n + 13 * k + nb)
+    c = H.HipContext(nbatch=nb)
+    a = _banded(rng, nb, n, k, k, False)
+    a[:, np.arange(n), np.arange(n)] += 0.5  # real interchanges, no near-singular pivots
+    b = rng.standard_normal((nb, n))
+    y = rng.standard_normal((nb, n)) if ynb_full else rng.standard_normal((1, n))
+    atol = np.abs(rng.standard_normal(n)) * 1e-3 + 1e-6
+    rtol = 1e-4
+    lu = H.HipLU(c, n)
+    lu.factor(H.HipMat.from_array(a, c))
+    assert lu.band_width() == k
+    x_sep = H.HipVec.from_vec(b, c)
+    lu.solve_in_place(x_sep)
+    xs = np.asarray(x_sep.clone_as_vec()).reshape(nb, n)
+    assert np.array_equal(xs, O.lu_solve(a, b)[0])
+    x = H.HipVec.from_vec(b, c)
+    yv = H.HipVec.from_vec(y, c if ynb_full else c.clone_with_nbatch(1))
+    av = H.HipVec.from_vec(atol[None, :], c.clone_with_nbatch(1))
+    out = C.c_double(0.0)
+    L = c._L
+    rc = L.dsh_lu_solve_squared_norm(lu._h, x.ptr, yv.ptr, yv.nb, av.ptr, 1, rtol, C.byref(out))
+    assert rc == 0, L.dsh_last_error()
+    assert np.array_equal(np.asarray(x.clone_as_vec()).reshape(nb, n), xs)
+    term = xs / (np.abs(y) * rtol + atol[None, :])
+    sq = term * term
+    seq = np.cumsum(sq, axis=1)[:, -1] / float(n)  # cumsum adds in index order, like Vector::squared_norm (nalgebra_serial.rs:395-408)
+    assert out.value == seq.max()
+    assert out.value == x_sep.squared_norm(yv, av, rtol)  # and the stand-alone norm kernel's value
