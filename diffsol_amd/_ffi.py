@@ -136,6 +136,8 @@ DEVICE_ABI = {
     "dsh_model_precompile": (cint, [cint, cint]),
     "dsh_jit_compile_count": (C.c_int64, []),
     "dsh_jit_replay": (cint, [C.c_char_p, cint, cint, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dsh_model_set_member_twin_source": (cint, [cint, C.c_char_p, i64, i64, i64, i64]),
+    "dsh_model_member_twin": (cint, [cint]),
     "dsh_model_set_twin": (cint, [cint, cint]),
     "dsh_model_twin": (cint, [cint]),
     "dsh_model_lane_twin": (cint, [cint, i64]),
@@ -148,6 +150,9 @@ DEVICE_ABI = {
     "dsh_bdf_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_bdf_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_reduction_wait": (cint, [vp, i64, c_dp]),
+    "dsh_sdirk_begin_attempt": (cint, [vp, i64, i64, dbl, dbl, vp, vp, vp, vp, vp]),
+    "dsh_sdirk_next_stage": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, vp, c_dp, dbl, dbl]),
+    "dsh_sdirk_finish_error": (cint, [vp, i64, i64, cint, dbl, vp, vp, vp, vp, c_dp, vp]),
     "dsh_sdirk_newton_iter": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp]),
     "dsh_sdirk_newton_iter_async": (cint, [vp, cint, i64, i64, dbl, dbl, dbl, cint, vp, vp, vp, vp, vp, vp, vp, i64, dbl, c_i64p]),
     "dsh_jac_factor": (cint, [vp, cint, i64, i64, dbl, dbl, vp, vp, cint, vp, vp, vp]),

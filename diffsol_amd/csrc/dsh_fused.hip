@@ -363,6 +363,99 @@ int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
   return DSH_OK;
 }
 
+}  // extern "C"
+namespace {
+// ---- SDIRK stage bookkeeping in single passes (round 5).  Between two Newton solves the host-driven Sdirk::step runs a handful of elementwise / tiny-gemv operations over
+// the n x nbatch vectors (runge_kutta.rs:505-516, 610-689, 783-800; op/sdirk.rs:174-203): each was one launch and one pass over memory.  The kernels below do the
+// operations that follow each other with no host decision in between in ONE pass — per element the same expressions in the same order as the separate kernels
+// (k_axpby_to: alpha * x + beta * y0;  k_gemv: alpha * A(0) * X(0) + beta * yin, then alpha * A(j) * X(j) + acc;  FAxpy0: alpha * x): the same bits.
+struct sdirk_coef { double v[8]; };
+constexpr int kStageBlock = 256;
+inline dim3 stage_grid(int64_t total) { int64_t b = (total + kStageBlock - 1) / kStageBlock; if (b > 8192) b = 8192; if (b < 1) b = 1; return dim3((unsigned)b); }
+
+// start of a step attempt with an explicit first stage: diff[:,0] = h dy (start_step_attempt), phi = y0 + diff[:,0] a10 (set_phi of stage 1), k = diff[:,0] (its predictor)
+__global__ void k_sdirk_begin_attempt(int64_t total, double h, double a10, const double* __restrict__ dy, const double* __restrict__ y0, double* __restrict__ diff0,
+                                      double* __restrict__ phi, double* __restrict__ k) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const double alpha = 1.0, beta = 1.0;
+    const double d0 = h * dy[idx];
+    diff0[idx] = d0;
+    phi[idx] = alpha * d0 * a10 + beta * y0[idx];
+    k[idx] = d0;
+  }
+}
+// stage i has converged (k = its increment), stage i + 1 follows: y_stage = c k + phi (get_f_eval), diff[:,i] = k, phi = y0 + diff[:,0..=i] a (set_phi of stage i + 1),
+// k = pa diff[:,i-1] + pb diff[:,i] (its predictor, runge_kutta.rs:610-629; stage i + 1 >= 2)
+__global__ void k_sdirk_next_stage(int64_t total, int i, double c, double* __restrict__ k, double* __restrict__ phi, const double* __restrict__ y0, double* __restrict__ y_stage,
+                                   double* __restrict__ diff, sdirk_coef a, double pa, double pb) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const double alpha = 1.0, beta = 1.0;
+    const double xv = k[idx];
+    y_stage[idx] = c * xv + beta * phi[idx];
+    diff[(int64_t)i * total + idx] = xv;
+    double prev = 0.0;  // diff[:, i-1]
+    double acc = 0.0;
+    for (int j = 0; j <= i; ++j) {
+      const double aj = j < i ? diff[(int64_t)j * total + idx] : xv;
+      if (j == i - 1) prev = aj;
+      acc = j == 0 ? alpha * aj * a.v[0] + beta * y0[idx] : alpha * aj * a.v[j] + acc;
+    }
+    phi[idx] = acc;
+    k[idx] = pa * prev + pb * xv;
+  }
+}
+// the last stage has converged: y_stage = c k + phi, diff[:,s-1] = k, err = diff d (the error estimate before its filter solve, runge_kutta.rs:783-800)
+__global__ void k_sdirk_finish_error(int64_t total, int s, double c, const double* __restrict__ k, const double* __restrict__ phi, double* __restrict__ y_stage,
+                                     double* __restrict__ diff, sdirk_coef d, double* __restrict__ err) {
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const double alpha = 1.0, beta = 1.0;
+    const double xv = k[idx];
+    y_stage[idx] = c * xv + beta * phi[idx];
+    diff[(int64_t)(s - 1) * total + idx] = xv;
+    double acc = 0.0;
+    for (int j = 0; j < s; ++j) {
+      const double aj = j < s - 1 ? diff[(int64_t)j * total + idx] : xv;
+      acc = j == 0 ? alpha * aj * d.v[0] : alpha * aj * d.v[j] + acc;
+    }
+    err[idx] = acc;
+  }
+}
+}  // namespace
+extern "C" {
+
+int dsh_sdirk_begin_attempt(dsh_ctx* ctx, int64_t n, int64_t nb, double h, double a10, const double* dy, const double* y0, double* diff0, double* phi, double* k) {
+  DSH_REQUIRE(dy && y0 && diff0 && phi && k, "null argument");
+  const int64_t total = n * nb;
+  if (total == 0) return DSH_OK;
+  hipLaunchKernelGGL(k_sdirk_begin_attempt, stage_grid(total), dim3(kStageBlock), 0, ctx->stream, total, h, a10, dy, y0, diff0, phi, k);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+int dsh_sdirk_next_stage(dsh_ctx* ctx, int64_t n, int64_t nb, int stage, double c, double* k, double* phi, const double* y0, double* y_stage, double* diff,
+                         const double* a_next_host, double pred_a, double pred_b) {
+  DSH_REQUIRE(k && phi && y0 && y_stage && diff && a_next_host, "null argument");
+  DSH_REQUIRE(stage >= 1 && stage < 7, "dsh_sdirk_next_stage: the finished stage must be 1 ... 6");
+  const int64_t total = n * nb;
+  if (total == 0) return DSH_OK;
+  sdirk_coef a;
+  for (int j = 0; j < 8; ++j) a.v[j] = j <= stage ? a_next_host[j] : 0.0;
+  hipLaunchKernelGGL(k_sdirk_next_stage, stage_grid(total), dim3(kStageBlock), 0, ctx->stream, total, stage, c, k, phi, y0, y_stage, diff, a, pred_a, pred_b);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+int dsh_sdirk_finish_error(dsh_ctx* ctx, int64_t n, int64_t nb, int nstages, double c, const double* k, const double* phi, double* y_stage, double* diff,
+                           const double* d_host, double* err) {
+  DSH_REQUIRE(k && phi && y_stage && diff && d_host && err, "null argument");
+  DSH_REQUIRE(nstages >= 1 && nstages <= 8, "dsh_sdirk_finish_error: 1 ... 8 stages");
+  const int64_t total = n * nb;
+  if (total == 0) return DSH_OK;
+  sdirk_coef d;
+  for (int j = 0; j < 8; ++j) d.v[j] = j < nstages ? d_host[j] : 0.0;
+  hipLaunchKernelGGL(k_sdirk_finish_error, stage_grid(total), dim3(kStageBlock), 0, ctx->stream, total, nstages, c, k, phi, y_stage, diff, d, err);
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+
 int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
                         double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
                         int want_norms, double* out) {

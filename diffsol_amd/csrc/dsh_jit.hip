@@ -41,6 +41,12 @@ struct JitModelRec {
   JitInfo info;
   std::string source;
   std::map<std::string, std::unique_ptr<JitModule>> modules;  // by header + group key
+  // a static model with 5 <= n <= 8 has no device-resident integrator of its own: the same model in the run-time-sized form (dsh_model_set_member_twin_source), compiled
+  // on the first per-member request (dsh_model_member_twin) — the wavefront-per-member kernels take it
+  std::string member_twin_source;
+  int64_t member_twin_dims[4] = {0, 0, 0, 0};  // n, nparams, nroots, nout
+  int member_twin = -1;
+  bool member_twin_failed = false;
 };
 
 std::mutex g_mu;
@@ -477,7 +483,55 @@ int dsh_model_twin(int model_id) {
   return rec ? rec->info.twin : -1;
 }
 
+// The run-time-sized form of a static model, for per-member device-resident solves (the static form has them up to n = 4 only): the source is kept, the compilation
+// happens at the first request.  DiffSL front ends (diffsol_amd/diffsl.py, host/diffsol_c.cpp, rust/diffsol-hip/src/diffsl.rs) call this for static models with n >= 5.
+int dsh_model_set_member_twin_source(int model_id, const char* source, int64_t n, int64_t nparams, int64_t nroots, int64_t nout) {
+  DSH_REQUIRE(source != nullptr && n >= 1 && nparams >= 1 && nroots >= 0 && nout >= 0, "bad arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  if (!rec) { set_error("dsh_model_set_member_twin_source: unknown model id"); return DSH_E_INVALID; }
+  DSH_REQUIRE(rec->info.form == DSH_JIT_FORM_STATIC && rec->info.n == n && rec->info.np == nparams, "the twin must be the same model (static form, same dimensions)");
+  rec->member_twin_source = source;
+  rec->member_twin_dims[0] = n; rec->member_twin_dims[1] = nparams; rec->member_twin_dims[2] = nroots; rec->member_twin_dims[3] = nout;
+  rec->member_twin = -1; rec->member_twin_failed = false;
+  return DSH_OK;
+}
+// -1: the model has no such twin (not a static run-time-compiled model with a registered source, or the source did not compile: dsh_last_error says why)
+int dsh_model_member_twin(int model_id) {
+  if (!is_jit_model(model_id)) return -1;
+  std::string src;
+  int64_t d[4];
+  int has_mass = 0, band[4];
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    JitModelRec* rec = find_model(model_id);
+    if (!rec || rec->member_twin_source.empty() || rec->member_twin_failed) return -1;
+    if (rec->member_twin >= 0) return rec->member_twin;
+    src = rec->member_twin_source;
+    for (int k = 0; k < 4; ++k) d[k] = rec->member_twin_dims[k];
+    has_mass = rec->info.has_mass;
+    band[0] = rec->info.jac_kl; band[1] = rec->info.jac_ku; band[2] = rec->info.mass_kl; band[3] = rec->info.mass_ku;
+  }
+  int id = -1;
+  const int rc = dsh_model_compile(src.c_str(), DSH_JIT_FORM_DYNAMIC, d[0], d[1], d[2], d[3], has_mass, &id);  // takes the registry lock itself
+  std::lock_guard<std::mutex> lk(g_mu);
+  JitModelRec* rec = find_model(model_id);
+  if (rc != DSH_OK || !rec) { if (rec) rec->member_twin_failed = true; return -1; }
+  if (JitModelRec* tw = find_model(id)) { tw->info.jac_kl = band[0]; tw->info.jac_ku = band[1]; tw->info.mass_kl = band[2]; tw->info.mass_ku = band[3]; }
+  rec->member_twin = id;
+  return id;
+}
+
 int dsh_model_release(int model_id) {
+  {
+    int tw = -1;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      JitModelRec* rec = find_model(model_id);
+      if (rec) { tw = rec->member_twin; rec->member_twin = -1; }
+    }
+    if (tw >= 0) (void)dsh_model_release(tw);
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_models.find(model_id);
   if (it == g_models.end()) { set_error("dsh_model_release: unknown model id"); return DSH_E_INVALID; }

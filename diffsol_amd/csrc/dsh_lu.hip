@@ -399,10 +399,9 @@ int lu_solve_norm_launch(const dsh_lu* lu, double* rhs, const double* xin, doubl
   if (ctx->solve_mode == DSH_SOLVE_REORDERED && lu->band_k == 1 && n >= 32 && n <= 1024) return DSH_OK;  // the opt-in reordered solve keeps its own kernel
   if (!((ynb == 1 || ynb == nb) && (anb == 1 || anb == nb))) return DSH_OK;
   const size_t dyn = lu->band_k == 1 ? band_team_epi_lds_bytes<1, 16>(n) : band_team_epi_lds_bytes<2, 16>(n);
-  if (dyn > (size_t)96 * 1024) return DSH_OK;  // the squares of the whole vector live in LDS: n <= ~700 at 16 systems per workgroup
+  if (dyn > (size_t)96 * 1024) return DSH_OK;  // the squares of the whole vector live in LDS: n <= 768 at 16 systems per workgroup
   band_epi_args ea;
   ea.xin = xin; ea.xout = xout; ea.y = y; ea.atol = atol; ea.rtol = rtol; ea.by = (ynb == 1 && nb != 1) ? 1 : 0; ea.ba = (anb == 1 && nb != 1) ? 1 : 0;
-  { static const int xv = [] { const char* e = std::getenv("DSH_TEAM_EPI_X"); return e && *e ? std::atoi(e) : 0; }(); ea.xvar = xv; }
   return timed_call(ctx, DSH_TIMING_LU_SOLVE, [&]() -> int {
     unsigned long long* rec; unsigned int seq;
     const dim3 g = grid_for(nb, 16);

@@ -15,12 +15,19 @@
 // One s_barrier per chunk hands the slots over (two slots: the chain reads one while the loaders fill the other).
 // Layouts and arithmetic: see k_lu_band_solve / k_lu_band_solve_wide; the stripped / general variants of a step are theirs.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "dsh_lu_band.hpp"
 
 namespace dsh {
 
 constexpr int kTeamLoaders = 256;  // loader lanes (4 wavefronts)
 constexpr int kTeamThreads = kTeamLoaders + 64;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) in turn: the stages of one unrolled trip with their index as a compile-time constant
+template <class F, int... I>
+__device__ __forceinline__ void team_for_each_stage(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>()), ...); }
 
 // hands the LDS slots over: LDS traffic only — __syncthreads() would also wait for the loaders' loads in flight (vmcnt(0)) and drain the prefetch every chunk
 __device__ __forceinline__ void team_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -69,11 +76,10 @@ struct band_epi_args {
   const double* atol;  // n x nb, or n (ba != 0)
   double rtol;
   int by, ba;
-  int xvar;  // TEMP experiment bits
 };
 constexpr int kTeamEpiPlanes = 3;  // y, atol, xin of a chunk's rows
 template <int K, int SYS>
-constexpr size_t band_team_epi_lds_bytes(int64_t n) { return sizeof(double) * ((size_t)2 * kTeamEpiPlanes * band_team_cfg<K, SYS>::CH * SYS + (size_t)n * SYS); }
+constexpr size_t band_team_epi_lds_bytes(int64_t n) { return sizeof(double) * ((size_t)n * SYS); }
 
 template <int K, int SYS, bool EPI = false>
 __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, int64_t nb, const double* __restrict__ fac, const int32_t* __restrict__ piv,
@@ -93,10 +99,8 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
 #define TEAM_OUT(sl, t, s) sOut[sl][t][s]
 #endif
   __shared__ int sMoved[2][4];  // forward: did any system of the workgroup interchange in the chunk (one word per loader wavefront)
-  extern __shared__ double sDynTeam[];  // EPI: [2][kTeamEpiPlanes][CH][S] operands of the epilogue, then [n][S] squared terms
-  double* const sE = sDynTeam;
-  double* const sSq = sDynTeam + 2 * kTeamEpiPlanes * CH * S;
-  auto SE = [&](int sl, int o, int t, int ss) __attribute__((always_inline)) -> double& { return sE[((sl * kTeamEpiPlanes + o) * CH + t) * S + ss]; };
+  extern __shared__ double sDynTeam[];  // EPI: [n][S] squared terms of the norm
+  double* const sSq = sDynTeam;
   TEAM_STAMP(0)
   const int tid = threadIdx.x;
   const bool loader = tid < kTeamLoaders;
@@ -104,6 +108,7 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
   const int s = loader ? tid % S : lane % S;  // system within the workgroup
   const int g = tid / S;                      // loader: row group
   const bool chain = !loader && lane < S;
+  if (!loader) __builtin_amdgcn_s_setprio(3);  // the chain wavefront shares its SIMD with one loader wavefront: when both can issue, the chain goes first
   const int64_t b0 = (int64_t)blockIdx.x * S + s;
   const bool valid = b0 < nb;
   const int64_t b = valid ? b0 : nb - 1;  // lanes past the ensemble shadow the last system (no stores)
@@ -291,6 +296,8 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
   if (loader) {
     constexpr int BE = BO + (EPI ? kTeamEpiPlanes : 0);
     double pb[RB][BE][Q];
+    const double* const xin_or_rhs = (EPI && ea.xin != nullptr) ? ea.xin : rhs;
+    const bool sub = EPI && ea.xin != nullptr;
     int rowq[Q];  // EPI: row i of the chunk issued next (negative past the top of the matrix)
 #pragma unroll
     for (int q = 0; q < Q; ++q) rowq[q] = ni - 1 - (q * G + g);
@@ -310,24 +317,30 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
         for (int d = 0; d < C; ++d) pd[d][q] = ld_f64(ubase[d], (uint32_t)max(offi[q], ulo[d]));
         pd[C][q] = ld_f64(rhs, (uint32_t)max(offi[q] - C * (int)nb8, (int)b8));
         if constexpr (EPI) {  // the epilogue's operands of row i itself (clamped like the others; rows above the matrix are never used)
+          // no branches here: a join between the loads would make the compiler wait for every load in flight (the prefetch queue is the point of this wavefront).
+          // Broadcast operands differ in the offset only; without a Newton update xin is the right-hand side itself (loaded, never used)
           const uint32_t oi = (uint32_t)max(offi[q], (int)b8);
-          const int ri = max(rowq[q], 0);
-          pd[BO][q] = ea.by ? ea.y[ri] : ld_f64(ea.y, oi);
-          pd[BO + 1][q] = ea.ba ? ea.atol[ri] : ld_f64(ea.atol, oi);
-          pd[BO + 2][q] = ea.xin ? ld_f64(ea.xin, oi) : 0.0;
+          const uint32_t orow = (uint32_t)max(rowq[q], 0) * 8u;
+          pd[BO][q] = ld_f64(ea.y, ea.by ? orow : oi);
+          pd[BO + 1][q] = ld_f64(ea.atol, ea.ba ? orow : oi);
+          pd[BO + 2][q] = ld_f64(xin_or_rhs, oi);
           rowq[q] -= CH;
         }
         offi[q] -= CH * (int)nb8;
       }
     };
-    auto land = [&](double (&pd)[BE][Q], int c) __attribute__((always_inline)) {
+    // EPI: the epilogue's operands of a chunk stay in this lane's registers from the landing to the store of the chunk's results two steps later (the same lane does
+    // both): two sets in turn, the set index a compile-time constant (RB is even, so the parity of a chunk is the parity of its stage in the unrolled trip)
+    static_assert(!EPI || RB % 2 == 0, "the epilogue's register sets alternate with the stages of a trip");
+    double ek[2][EPI ? kTeamEpiPlanes : 1][Q];
+    auto land = [&](double (&pd)[BE][Q], int c, auto par) __attribute__((always_inline)) {
       const int sl = c & 1;
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int t = q * G + g;
         if constexpr (EPI) {
 #pragma unroll
-          for (int o = 0; o < kTeamEpiPlanes; ++o) SE(sl, o, t, s) = pd[BO + o][q];  // read back by this same lane when it stores the chunk's results
+          for (int o = 0; o < kTeamEpiPlanes; ++o) ek[decltype(par)::value][o][q] = pd[BO + o][q];
         }
 #pragma unroll
         for (int o = 0; o < BO; ++o) sOp[sl][o][t][s] = pd[o][q];
@@ -336,11 +349,12 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
         sOp[sl][C + 1][t][s] = div_den_ok(pd[0][q]) ? div_refined_rcp(pd[0][q]) : __builtin_nan("");
       }
     };
-    auto drain = [&](int c) __attribute__((always_inline)) {
+    auto drain = [&](int c, auto par) __attribute__((always_inline)) {
 #ifdef DSH_TEAM_X_WGLOBAL
       return;
 #endif
       const int sl = c & 1;
+      constexpr int PAR = decltype(par)::value;
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int t = q * G + g, i = ni - 1 - (c * CH + t);
@@ -348,34 +362,38 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
         if (valid && i >= 0) st_f64(rhs, (uint32_t)i * nb8 + b8, xs);
         if constexpr (EPI) {
           if (i >= 0) {
-            const double term = (ea.xvar & 2) ? xs : xs / (fabs(SE(sl, 0, t, s)) * ea.rtol + SE(sl, 1, t, s));  // Vector::squared_norm's term (nalgebra_serial.rs:395-408)
+            const double term = xs / (fabs(ek[PAR][0][q]) * ea.rtol + ek[PAR][1][q]);  // Vector::squared_norm's term (nalgebra_serial.rs:395-408)
             sSq[i * S + s] = term * term;
-            if (ea.xin != nullptr && valid) st_f64(ea.xout, (uint32_t)i * nb8 + b8, SE(sl, 2, t, s) - xs);  // xn -= delta (line_search.rs:57-68)
+            if (sub & valid) st_f64(ea.xout, (uint32_t)i * nb8 + b8, ek[PAR][2][q] - xs);  // xn -= delta (line_search.rs:57-68)
           }
         }
       }
     };
 #pragma unroll
     for (int d = 0; d < RB; ++d) issue(pb[d]);
-    land(pb[0], 0);
+    land(pb[0], 0, std::integral_constant<int, 0>());
     issue(pb[0]);
     team_barrier();
     TEAM_PROF_DECL
     for (int c0 = 0; c0 < nch; c0 += RB) {
-#pragma unroll
-      for (int d = 0; d < RB; ++d) {
-        const int c = c0 + d;
+      // one stage of a trip: chunk c = c0 + D is run by the chain; the loaders store chunk c - 1 and hand chunk c + 1 over (both of parity (D + 1) & 1)
+      auto stage = [&](auto dd) __attribute__((always_inline)) {
+        constexpr int D = decltype(dd)::value;
+        const int c = c0 + D;
         TEAM_PROF_BUSY_BEGIN
-        if (c >= 1 && c - 1 < nch) drain(c - 1);
-        const int nx = (d + 1) % RB;
-        land(pb[nx], c + 1);
+        if (c >= 1 && c - 1 < nch) drain(c - 1, std::integral_constant<int, (D + 1) & 1>());
+        constexpr int nx = (D + 1) % RB;
+        land(pb[nx], c + 1, std::integral_constant<int, (D + 1) & 1>());
         issue(pb[nx]);
         TEAM_PROF_BUSY_END
         team_barrier();
-      }
+      };
+      team_for_each_stage(stage, std::make_integer_sequence<int, RB>());
     }
     if (tid < 64) { TEAM_PROF_STORE(6) }
-    if (((nch + RB - 1) / RB) * RB == nch) drain(nch - 1);
+    if (((nch + RB - 1) / RB) * RB == nch) {
+      if ((nch - 1) & 1) drain(nch - 1, std::integral_constant<int, 1>()); else drain(nch - 1, std::integral_constant<int, 0>());
+    }
   } else {
     double w[C];
     if (chain) {
@@ -497,24 +515,29 @@ __global__ __launch_bounds__(kTeamThreads) void k_lu_band_solve_team(int64_t n, 
   unsigned long long nbits = 0ull;
   if constexpr (EPI) {
     __syncthreads();  // every chunk's squares are in LDS
-    if (tid < S && !(ea.xvar & 1)) {    // one lane per system: the n additions in index order, sixteen LDS reads in flight at a time
+    if (tid < S) {    // one lane per system: the n additions in index order, sixteen LDS reads in flight at a time
       double acc = 0.0;
       int i = 0;
-      if (ni >= 16) {  // the additions are one dependent chain (~8 cycles each): the next sixteen squares are read from LDS while the current sixteen are added
-        double v[16], w[16];
+      if (ni >= 32) {  // the additions are one dependent chain (~8 cycles each): two register sets of sixteen squares in turn, each refilled from LDS while the other is added
+        double va[16], vb[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = sSq[k * S + s];
-        for (; i + 32 <= ni; i += 16) {
+        for (int k = 0; k < 16; ++k) va[k] = sSq[k * S + s];
+        for (; i + 32 <= ni; i += 32) {
 #pragma unroll
-          for (int k = 0; k < 16; ++k) w[k] = sSq[(i + 16 + k) * S + s];
+          for (int k = 0; k < 16; ++k) vb[k] = sSq[(i + 16 + k) * S + s];
 #pragma unroll
-          for (int k = 0; k < 16; ++k) acc += v[k];
+          for (int k = 0; k < 16; ++k) acc += va[k];
+          const int nx = i + 32 + 16 <= ni ? i + 32 : 0;  // the set after next (re-reads rows 0..15 when there is none: never added)
 #pragma unroll
-          for (int k = 0; k < 16; ++k) v[k] = w[k];
+          for (int k = 0; k < 16; ++k) va[k] = sSq[(nx + k) * S + s];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc += vb[k];
         }
+        if (i + 16 <= ni) {  // va holds rows i .. i+15
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc += v[k];
-        i += 16;
+          for (int k = 0; k < 16; ++k) acc += va[k];
+          i += 16;
+        }
       }
       for (; i < ni; ++i) acc += sSq[i * S + s];
       if (valid) nbits = d2u(acc / (double)n);

@@ -67,6 +67,11 @@ class DiffslModel:
             check(self._L.dsh_model_set_twin(self.model_id, self.lane_model_id))
         self.band = d["band"]  # (jac_kl, jac_ku, mass_kl, mass_ku): structural bandwidths, declared so that banded models are assembled / factored on the band
         check(self._L.dsh_model_set_band(self.model_id, *self.band))
+        if form == FORM_STATIC and self.n >= 5:
+            # the register-resident integrators stop at n = 4: per-member device solves of this model run on its run-time-sized form (the wavefront-per-member kernels),
+            # compiled by the library at the first such request
+            dyn_src = generate(code, TARGET_HIP_DYNAMIC, model_index)[0]
+            check(self._L.dsh_model_set_member_twin_source(self.model_id, dyn_src.encode(), self.n, self.nparams, self.nroots, self.nout))
 
     def precompile(self, family):
         """Compile a kernel family now instead of at its first launch (needs no GPU)."""

@@ -294,6 +294,10 @@ OdeWrapper* diffsol_ode_new_jit(const char* code, int32_t jit_backend, int32_t m
     if (rc != 0) { C_ERROR(std::string(dsh_last_error())); return nullptr; }
     ode->model = id;
     dsh_model_set_band(id, (int)dims[6], (int)dims[7], (int)dims[8], (int)dims[9]);
+    if (is_static && ode->n >= 5) {  // per-member device solves of a static model with 5 <= n <= 8 run on its run-time-sized form, compiled at the first such request
+      const std::string dyn = diffsl::generate(c, diffsl::Target::HipDynamic);
+      (void)dsh_model_set_member_twin_source(id, dyn.c_str(), ode->n, ode->np, ode->nroots, ode->nout);
+    }
     // out_i { u_i } (the outputs are the states, component by component): solve_fwd_sens then needs no output derivatives
     ode->out_is_state = (int64_t)c.out.size() == ode->n;
     for (size_t i = 0; i < c.out.size() && ode->out_is_state; ++i) {

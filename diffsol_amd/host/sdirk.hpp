@@ -238,7 +238,15 @@ class Sdirk : public OdeSolverMethod {
     const int start = skip_first_stage() ? 1 : 0;
     double fac = 1.0, error_norm = 0.0;
     while (true) {
+      prepared_stage_ = -1;
+      error_ready_ = false;
       if (skip_first_stage()) {  // start_step_attempt (runge_kutta.rs:505-534), "sensitivities too"
+        if (single_pass_stages()) {
+          // diff[:,0] = h dy, and with it what stage 1 starts with — phi = y + diff[:,0] a10 (set_phi) and its predictor k = diff[:,0] — in one pass
+          check(dsh_sdirk_begin_attempt(ctx().raw(), n(), nb(), h, tab_.A(1, 0), state_.dy.ptr(), state_.y.ptr(), diff_.column_mut(0).p, op_.phi().ptr(), old_state_.dy.ptr()),
+                "dsh_sdirk_begin_attempt");
+          prepared_stage_ = 1;
+        } else
         diff_.column_mut(0).axpy(h, state_.dy, 0.0);
         for (size_t j = 0; j < sdiff_.size(); ++j) sdiff_[j].column_mut(0).axpy(h, ds_[j], 0.0);
       }
@@ -264,7 +272,7 @@ class Sdirk : public OdeSolverMethod {
       }
       if (failed) continue;
       // error_norm (runge_kutta.rs:783-800) filtered through one more LU solve (sdirk.rs:474-495)
-      diff_.gemv(1.0, d_vec_, 0.0, error_);
+      if (!error_ready_) diff_.gemv(1.0, d_vec_, 0.0, error_);  // (the last stage's single pass has formed it already)
       if (pr_.eqn->has_mass()) {
         error_tmp_.copy_from(error_);
         op_.current_mass().gemv(1.0, error_tmp_, 0.0, error_);
@@ -435,6 +443,13 @@ class Sdirk : public OdeSolverMethod {
   int64_t nb() const { return pr_.context().nbatch(); }
   const HipContext& ctx() const { return pr_.context(); }
   bool skip_first_stage() const { return tab_.A(0, 0) == 0.0; }
+  // the stage bookkeeping between two Newton solves as single passes (dsh_sdirk_begin_attempt / _next_stage / _finish_error): state equations only, every operand a
+  // full n x nbatch vector.  DSH_SDIRK_SINGLE_PASS=0 keeps the trait operations (same bits; tests compare).
+  bool single_pass_stages() const {
+    static const bool on = [] { const char* e = std::getenv("DSH_SDIRK_SINGLE_PASS"); return !(e && e[0] == '0'); }();
+    return on && pr_.use_fused_kernels && !s_op_ && tab_.s >= 2 && tab_.s <= 8 && state_.y.nb() == nb() && state_.dy.nb() == nb() && old_state_.y.nb() == nb() &&
+           old_state_.dy.nb() == nb() && error_.nb() == nb();
+  }
 
   // reset_jacobian(op, x, t) with x := state.y, linearised at phi + c*x (the reference's quirk, op/sdirk.rs:186-195, :266-276)
   void reset_jacobian(double t) {
@@ -494,8 +509,11 @@ class Sdirk : public OdeSolverMethod {
 
   NlError do_stage_sdirk(int i, double h) {  // runge_kutta.rs:631-689
     const double t = state_.t + tab_.c[(size_t)i] * h;
-    op_.set_phi(diff_.columns(0, i), state_.y, a_rows_[(size_t)i]);
-    predict_stage_sdirk(i, h, state_.dy, old_state_.dy);
+    if (prepared_stage_ != i) {  // (else the previous stage's single pass has stored phi and the predictor)
+      op_.set_phi(diff_.columns(0, i), state_.y, a_rows_[(size_t)i]);
+      predict_stage_sdirk(i, h, state_.dy, old_state_.dy);
+    }
+    prepared_stage_ = -1;
     if (!nonlinear_solver_.is_jacobian_set()) {
       reset_jacobian(t);
       record_linear_solver_setup(statistics_, SolverState::Checkpoint);
@@ -503,6 +521,20 @@ class Sdirk : public OdeSolverMethod {
     NlError r = (fused_ || staged_) ? newton_fused(t) : nonlinear_solver_.solve_in_place(op_, old_state_.dy, t, state_.y, convergence_, line_search_);
     statistics_.number_of_nonlinear_solver_iterations += convergence_.niter();
     if (r != NlError::Ok) return r;
+    if (single_pass_stages() && i >= 1 && i + 1 < tab_.s) {
+      // get_f_eval + the copy into diff[:,i] + set_phi and the predictor of stage i + 1 (runge_kutta.rs:672-676, 610-629; op/sdirk.rs:174-203) in one pass
+      double a_next[8] = {0.0};
+      for (int j = 0; j <= i; ++j) a_next[j] = tab_.A(i + 1, j);
+      const double cp = (tab_.c[(size_t)i + 1] - tab_.c[(size_t)i - 1]) / (tab_.c[(size_t)i] - tab_.c[(size_t)i - 1]);
+      check(dsh_sdirk_next_stage(ctx().raw(), n(), nb(), i, op_.c(), old_state_.dy.ptr(), op_.phi().ptr(), state_.y.ptr(), old_state_.y.ptr(), diff_.ptr(), a_next, -cp, 1.0 + cp),
+            "dsh_sdirk_next_stage");
+      prepared_stage_ = i + 1;
+    } else if (single_pass_stages() && i >= 1 && i + 1 == tab_.s) {
+      // the last stage: get_f_eval + the copy + the error estimate diff d (runge_kutta.rs:783-800) in one pass
+      check(dsh_sdirk_finish_error(ctx().raw(), n(), nb(), tab_.s, op_.c(), old_state_.dy.ptr(), op_.phi().ptr(), old_state_.y.ptr(), diff_.ptr(), tab_.d.data(), error_.ptr()),
+            "dsh_sdirk_finish_error");
+      error_ready_ = true;
+    } else
     if (old_state_.dy.nb() == nb() && old_state_.y.nb() == nb()) op_.get_f_eval_and_store(old_state_.dy, old_state_.y, diff_.column_mut(i).p);
     else {
       op_.get_f_eval(old_state_.dy, old_state_.y);
@@ -579,6 +611,8 @@ class Sdirk : public OdeSolverMethod {
   double minimum_timestep_, maximum_timestep_growth_, minimum_timestep_growth_, maximum_timestep_shrink_, minimum_timestep_shrink_;
   int maximum_error_test_failures_, maximum_newton_fails_;
   bool fused_ = false, staged_ = false;
+  int prepared_stage_ = -1;   // stage whose phi and predictor the previous single pass has already stored (-1: none)
+  bool error_ready_ = false;  // error_ = diff d formed by the last stage's single pass
   int model_ = -1;
   int64_t model_size_ = 0;
   // forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens())

@@ -144,6 +144,11 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = model; r.size = size;
   } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) != 0 : dsh_model_has_wave_member_sdirk(model, size) != 0)) {
     r.ok = true; r.wave_member = true; r.model = model; r.size = size;
+  } else if (group == 1 && !for_auto && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_member_twin(model)) >= 0 &&
+             (r.method == 0 ? dsh_model_has_wave_member(twin, 0) != 0 : dsh_model_has_wave_member_sdirk(twin, 0) != 0)) {
+    // a static DiffSL model with 5 <= n <= 8: its run-time-sized twin, compiled by this first explicit per-member request (the automatic mode keeps such a model on
+    // the host-driven fused kernels it was compiled for)
+    r.ok = true; r.wave_member = true; r.model = twin; r.size = 0;
   }
   return r;
 }
@@ -279,8 +284,8 @@ void run_resident(dshs_solver* s, const double* t_eval, int64_t nt, int group, i
                                      "derivatives (n <= 4, no root functions); other problems integrate their sensitivities host-driven (dshs_solve_dense + dshs_interpolate_sens)");
   if (!pk.ok)
     throw LaError(DSH_E_UNSUPPORTED, "solve_dense_adaptive: no device-resident kernel for this model/method (static models with n <= 4 and banded lane-per-member forms: "
-                                     "BDF/TR-BDF2/ESDIRK34; run-time-sized models with n <= 140 (n <= 48 with a mass matrix): per member (group 1), BDF/TR-BDF2/ESDIRK34; a DiffSL model "
-                                     "with 5 <= n <= 8 states is compiled in the static form by default, which has no such kernel: compile it with form = FORM_DYNAMIC)");
+                                     "BDF/TR-BDF2/ESDIRK34; run-time-sized models with n <= 140 (n <= 48 with a mass matrix): per member (group 1), BDF/TR-BDF2/ESDIRK34; a static model "
+                                     "with 5 <= n <= 8 states runs per member through its run-time-sized twin, dsh_model_set_member_twin_source)");
   const int model = pk.model;
   const int64_t size = pk.size;
   const int method = pk.method;

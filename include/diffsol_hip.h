@@ -283,6 +283,10 @@ int64_t dsh_jit_compile_count(void);
  * dsh_jit_replay compiles the requests i of such a manifest with i % nparts == part into the on-disk cache (no GPU needed, nothing is loaded): the build step replays the
  * committed manifests (diffsol_amd/jit_manifest/) so that a fresh box never compiles at first use.  *requests = distinct records read, *compiled = modules this call compiled. */
 int dsh_jit_replay(const char* manifest_path, int part, int nparts, int64_t* requests, int64_t* compiled);
+/* A static model (n <= 8) has device-resident integrators up to n = 4; for 5 <= n <= 8 the DiffSL front ends register the same model in the run-time-sized form
+ * (DSH_JIT_FORM_DYNAMIC source) and the library compiles it at the first per-member request: dsh_model_member_twin returns its id (-1: none). */
+int dsh_model_set_member_twin_source(int model_id, const char* source, int64_t nstates, int64_t nparams, int64_t nroots, int64_t nout);
+int dsh_model_member_twin(int model_id);
 int dsh_model_set_twin(int model_id, int twin_id);
 int dsh_model_twin(int model_id); /* -1: none */
 /* the same for any model id: a run-time-compiled model's twin, or — created on first request — the banded lane-per-member form of a built-in
@@ -355,6 +359,17 @@ int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
 /* Jacobian refresh: [rhs_jac = J(x,t) if recompute_rhs_jac; mass_jac = M(t) if the model has a mass matrix];
  * A = mass_jac + (-c)*rhs_jac; LU-factor A into `lu` — one launch, A never touches HBM
  * (BdfCallable::jacobian_inplace op/bdf.rs:273-300 + CudaLU::set_linearisation lu.rs:59-97). */
+/* Sdirk::step's bookkeeping between two Newton solves, single passes (round 5; each equals the sequence of Vector / Matrix trait operations it replaces, bit for bit):
+ *   dsh_sdirk_begin_attempt  diff[:,0] = h dy (start_step_attempt, runge_kutta.rs:505-516); phi = y0 + diff[:,0] a10 (set_phi, op/sdirk.rs:174-184); k = diff[:,0] (predictor)
+ *   dsh_sdirk_next_stage     stage `stage` converged with increment k: y_stage = c k + phi (get_f_eval :197-203); diff[:,stage] = k; phi = y0 + diff[:,0..=stage] a_next;
+ *                            k = pred_a diff[:,stage-1] + pred_b diff[:,stage] (predict_stage_sdirk, runge_kutta.rs:610-629)
+ *   dsh_sdirk_finish_error   the last stage converged: y_stage = c k + phi; diff[:,s-1] = k; err = diff[:,0..s) d (runge_kutta.rs:783-800)
+ * diff: n x s x nbatch, column-major per member, batch-fastest; every vector n x nbatch; coefficients on the host. */
+int dsh_sdirk_begin_attempt(dsh_ctx* ctx, int64_t n, int64_t nbatch, double h, double a10, const double* dy, const double* y0, double* diff0, double* phi, double* k);
+int dsh_sdirk_next_stage(dsh_ctx* ctx, int64_t n, int64_t nbatch, int stage, double c, double* k, double* phi, const double* y0, double* y_stage, double* diff,
+                         const double* a_next_host, double pred_a, double pred_b);
+int dsh_sdirk_finish_error(dsh_ctx* ctx, int64_t n, int64_t nbatch, int nstages, double c, const double* k, const double* phi, double* y_stage, double* diff,
+                           const double* d_host, double* err);
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nbatch, double t, double c, const double* x, const double* p,
                    int recompute_rhs_jac, double* rhs_jac, double* mass_jac, dsh_lu* lu);
 int dsh_model_has_fused(int model, int64_t size);

@@ -59,6 +59,16 @@ pub fn compile(code: &str) -> Result<DiffslInfo, LaError> {
         return Err(LaError::Other(last_error()));
     }
     unsafe { ffi::dsh_model_set_band(id, dims[6] as c_int, dims[7] as c_int, dims[8] as c_int, dims[9] as c_int) };
+    if is_static && dims[0] >= 5 {
+        // the register-resident integrators stop at n = 4: per-member device solves of this model run on its run-time-sized form, which the library compiles
+        // at the first such request (dsh_model_member_twin)
+        let mut dyn_src: *mut c_char = ptr::null_mut();
+        let mut d2 = [0i64; 10];
+        if unsafe { dshs_diffsl_generate(c.as_ptr(), DSHS_DIFFSL_HIP_DYNAMIC, &mut dyn_src, d2.as_mut_ptr(), ptr::null_mut(), 0) } == 0 {
+            unsafe { ffi::dsh_model_set_member_twin_source(id, dyn_src, dims[0], dims[1], dims[2], dims[3]) };
+            unsafe { dshs_free_string(dyn_src) };
+        }
+    }
     defaults.truncate(dims[1] as usize);
     Ok(DiffslInfo { model_id: id, nstates: dims[0] as usize, nparams: dims[1] as usize, nroots: dims[2] as usize, nout: dims[3] as usize, has_mass: dims[4] != 0, defaults })
 }

@@ -42,3 +42,11 @@ def timed(f):
 t1, k1 = timed(lambda: L.dsh_lu_solve(lu._h, x.ptr))
 t2, k2 = timed(lambda: L.dsh_lu_solve_squared_norm(lu._h, x.ptr, y.ptr, nb, a.ptr, 1, 1e-6, C.byref(out)))
 print(f"DSH_LU_SOLVE_EPI={os.environ.get('DSH_LU_SOLVE_EPI')} DSH_TEAM_EPI_X={os.environ.get('DSH_TEAM_EPI_X')}: dsh_lu_solve {t1:.2f} us ({k1}); solve launch of dsh_lu_solve_squared_norm {t2:.2f} us ({k2})")
+# the Newton-update form of the epilogue (xout = xin - delta): the staged SDIRK Newton iteration of heat1d, the solve launch bracketed alone (timing target 1)
+k = H.HipVec.from_vec(rng.standard_normal((nb, n)) * 1e-3, c)
+phi = H.HipVec.from_vec(rng.standard_normal((nb, n)), c)
+p = H.HipVec.from_vec(rng.uniform(0.5, 2.0, (nb, 1)), c)
+o3 = (C.c_double * 3)()
+MODEL_HEAT1D = 7
+t3, k3 = timed(lambda: L.dsh_sdirk_newton_iter(c._h, MODEL_HEAT1D, n, nb, 0.0, 1e-3, 2e-4, k.ptr, k.ptr, phi.ptr, p.ptr, lu._h, y.ptr, a.ptr, 1, 1e-6, o3))
+print(f"  solve launch of dsh_sdirk_newton_iter (update + norm epilogue) {t3:.2f} us ({k3})")

