@@ -30,12 +30,12 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
   extern __shared__ double lds[];  // xs[64] | ps[64] | sJ[n][64] | with a mass matrix: sM[n][64] | xs2[64];  TEAM: xs[TT] | xs2[TT] | ps[TT] | cand[2 TW] | perm[TT] (int) | A[n][P]
   double* xs = lds;
   double* ps = TEAM ? lds + 2 * TT : lds + 64;
-  double* sJ = TEAM ? jac_scratch + (size_t)blockIdx.x * Cp->n * Cp->n : lds + 128;  // TEAM: entry (ln, j) at j * n + ln
+  double* sJ = TEAM ? jac_scratch + (size_t)blockIdx.x * team_scratch_doubles(Cp->n, TEAM ? TW : 2) : lds + 128;  // TEAM: entry (ln, j) at j * n + ln
   double* sM = sJ + (size_t)Cp->n * 64;
   double* xs2 = TEAM ? lds + TT : (kWmHasMass ? sM + (size_t)Cp->n * 64 : sM);  // (SENS: the direction of J v; TEAM: also the LU solve's exchange and the norms' terms)
   double* const cand = lds + 3 * TT;
   int* const perm = reinterpret_cast<int*>(lds + 3 * TT + 2 * (TEAM ? TW : 1));
-  double* const A = lds + 3 * TT + 2 * (TEAM ? TW : 1) + TT / 2;
+  double* const A = (TEAM && team_global_factors(TW)) ? sJ + (size_t)Cp->n * Cp->n : lds + 3 * TT + 2 * (TEAM ? TW : 1) + TT / 2;  // n > 140: the factors in global scratch
   constexpr int P = team_pitch_w(TEAM ? TW : 2);
   bool lu_singular = false;
   (void)cand; (void)perm; (void)A; (void)P; (void)lu_singular;

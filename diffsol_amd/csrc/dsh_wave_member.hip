@@ -25,7 +25,7 @@ using namespace dsh;
 
 extern "C" {
 
-// 1: one wavefront per member (n <= 64; BDF and the SDIRK methods); 2: one workgroup per member (64 < n <= 140, identity mass; BDF — dsh_team_member_kernel.hpp); 0: neither
+// 1: one wavefront per member (n <= 64; BDF and the SDIRK methods); 2: one workgroup per member (64 < n <= 320, identity mass; BDF — dsh_team_member_kernel.hpp); 0: neither
 int dsh_model_has_wave_member(int model, int64_t size) {
   if (is_jit_model(model)) {  // run-time-sized DiffSL model: at most two stop conditions, one lane per component
     const JitInfo* ji = jit_info(model);
@@ -54,7 +54,7 @@ int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
 // hybrid models whose events are handled INSIDE the wavefront-per-member kernels (BDF, TR-BDF2, ESDIRK34: the reset applied at every event, then on to the last save
 // point): run-time-compiled models with a reset operator, root functions and no mass matrix, n <= 64
 int dsh_model_has_wave_member_reset(int model, int64_t size) {
-  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 1: a wavefront per member (n <= 64); 2: a workgroup per member (64 < n <= 140; BDF)
+  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 1: a wavefront per member (n <= 64); 2: a workgroup per member (64 < n <= 320; BDF)
   if (kind == 0) return 0;
   const JitInfo* ji = jit_info(model);
   return ji && ji->has_reset && !ji->has_mass && ji->nroots > 0 ? kind : 0;
@@ -62,7 +62,7 @@ int dsh_model_has_wave_member_reset(int model, int64_t size) {
 // forward sensitivities in the wavefront-per-member BDF (k_bdf_wave_member<.., SENS>): run-time-compiled dense ODE models with parameter derivatives, n <= 64, at most
 // kWmMaxSensParams parameters, no mass matrix, no root functions
 int dsh_model_has_wave_member_sens(int model, int64_t size) {
-  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 2: the workgroup-per-member BDF (64 < n <= 140)
+  const int kind = is_jit_model(model) ? dsh_model_has_wave_member(model, size) : 0;  // 2: the workgroup-per-member BDF (64 < n <= 320)
   if (kind == 0) return 0;
   const JitInfo* ji = jit_info(model);
   return ji && ji->has_sens && !ji->has_mass && ji->nroots == 0 && ji->np <= kWmMaxSensParams ? kind : 0;
@@ -73,7 +73,7 @@ int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_wave_member_sens(model, size)) {
-    set_error("dsh_bdf_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 140, at most 16 parameters, no mass matrix, no root functions");
+    set_error("dsh_bdf_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 320, at most 16 parameters, no mass matrix, no root functions");
     return DSH_E_UNSUPPORTED;
   }
   for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernel takes one sens_atol for every state");
@@ -89,13 +89,13 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
   const int wm_kind = dsh_model_has_wave_member(model, size);
-  if (!wm_kind) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; identity mass: n <= 140, one workgroup per member) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  if (!wm_kind) { set_error("dsh_bdf_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; identity mass: n <= 320, one workgroup per member) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveMemberConsts C;
   int64_t n = 0, np = 0, nroots = 0;
   int rc = dsh_model_info(model, size, &n, &np, nullptr, &nroots);
   if (rc != DSH_OK) return rc;
-  DSH_REQUIRE(np <= (wm_kind == 2 ? (n <= 128 ? 128 : 192) : 64) && nroots <= 2, "wave-member kernel: at most 64 parameters (workgroup form: one per thread) and 2 root functions");
+  DSH_REQUIRE(np <= (wm_kind == 2 ? 64 * team_waves((int)n) : 64) && nroots <= 2, "wave-member kernel: at most 64 parameters (workgroup form: one per thread) and 2 root functions");
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   C.sens_out = sens ? sens->out : nullptr; C.sens_rtol = sens ? sens->rtol : 0.0; C.sens_atol = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
   C.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.sens_pad = 1;
@@ -139,14 +139,14 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   const int ab = atol_nb == 1 ? 1 : 0;
   double* jac_scratch = nullptr;
   if (wm_kind == 2) {
-    // one workgroup per member (64 < n <= 140): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
-    const int waves = n <= 128 ? 2 : 3;
+    // one workgroup per member (64 < n <= 320): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
+    const int waves = team_waves((int)n);
     const size_t lds_team = sizeof(double) * team_lds_doubles((int)n, waves);
-    rc = dsh_malloc(ctx, (int64_t)sizeof(double) * n * n * nb, 0, (void**)&jac_scratch);
+    rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     DSH_HIP_CHECK(timing_begin(ctx));
     if (is_jit_model(model)) {
-      const std::string name = std::string("dsh::k_bdf_team_member<") + (waves == 2 ? "2" : "3") + (sens ? ", true>" : ">");
+      const std::string name = std::string("dsh::k_bdf_team_member<") + std::to_string(waves) + (sens ? ", true>" : ">");
       rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
                       (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
       if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -158,12 +158,11 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
       }
-      if (waves == 2)
-        hipLaunchKernelGGL((k_bdf_team_member<2>), dim3((unsigned)nb), dim3(128), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev,
-                           (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
-      else
-        hipLaunchKernelGGL((k_bdf_team_member<3>), dim3((unsigned)nb), dim3(192), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev,
-                           (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
+#define DSH_TM_LAUNCH(WV)                                                                                                                                  \
+  hipLaunchKernelGGL((k_bdf_team_member<WV>), dim3((unsigned)nb), dim3(64 * WV), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
+                     (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+      if (waves == 2) DSH_TM_LAUNCH(2); else if (waves == 3) DSH_TM_LAUNCH(3); else if (waves == 4) DSH_TM_LAUNCH(4); else DSH_TM_LAUNCH(5);
+#undef DSH_TM_LAUNCH
     }
   } else {
   int has_mass = 0;
@@ -216,7 +215,7 @@ int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int 
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_wave_member_sens(model, size)) {
-    set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 140, at most 16 parameters, no mass matrix, no root functions");
+    set_error("dsh_sdirk_solve_wave_member_sens: needs a run-time-compiled ODE model with parameter derivatives, n <= 320, at most 16 parameters, no mass matrix, no root functions");
     return DSH_E_UNSUPPORTED;
   }
   for (int64_t i = 1; i < nsens_atol; ++i) DSH_REQUIRE(sens_atol_host[i] == sens_atol_host[0], "the wavefront-per-member kernels take one sens_atol for every state");
@@ -232,8 +231,8 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
   for (int64_t q = 0; q + 1 < n_eval; ++q) DSH_REQUIRE(t_eval_host[q] <= t_eval_host[q + 1], "t_eval must be increasing (InvalidTEval)");
   DSH_REQUIRE(t_eval_host[0] >= t0, "t_eval[0] before t0 (InvalidTEval)");
-  const int wm_kind = dsh_model_has_wave_member_sdirk(model, size);  // 2: one workgroup per member (64 < n <= 140, identity mass)
-  if (!wm_kind) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; 64 < n <= 140 without one) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
+  const int wm_kind = dsh_model_has_wave_member_sdirk(model, size);  // 2: one workgroup per member (64 < n <= 320, identity mass)
+  if (!wm_kind) { set_error("dsh_sdirk_solve_wave_member: needs a run-time-sized model (built-in or DiffSL) with n <= 64 (n <= 48 with a mass matrix; 64 < n <= 320 without one) and at most two stop conditions"); return DSH_E_UNSUPPORTED; }
   if (nb == 0) return DSH_OK;
   WaveSdirkConsts C;
   int64_t n = 0, np = 0, nroots = 0;
@@ -272,13 +271,13 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   double* jac_scratch = nullptr;
   DSH_HIP_CHECK(timing_begin(ctx));
   if (wm_kind == 2) {
-    // one workgroup per member (64 < n <= 140): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member) — k_sdirk_wave_member<.., TW>
-    const int waves = n <= 128 ? 2 : 3;
+    // one workgroup per member (64 < n <= 320): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member) — k_sdirk_wave_member<.., TW>
+    const int waves = team_waves((int)n);
     const size_t lds_team = sizeof(double) * team_lds_doubles((int)n, waves);
-    rc = dsh_malloc(ctx, (int64_t)sizeof(double) * n * n * nb, 0, (void**)&jac_scratch);
+    rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     if (is_jit_model(model)) {
-      const std::string name = std::string("dsh::k_sdirk_wave_member<16, ") + std::to_string(S) + (sens ? ", true, " : ", false, ") + (waves == 2 ? "2>" : "3>");
+      const std::string name = std::string("dsh::k_sdirk_wave_member<16, ") + std::to_string(S) + (sens ? ", true, " : ", false, ") + std::to_string(waves) + ">";
       rc = jit_launch(ctx, model, "dsh_jit_sdirk_wave_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
                       (const WaveSdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, jac_scratch);
       if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -295,8 +294,8 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
 #define DSH_TS_LAUNCH(SV, TWV)                                                                                                                                          \
   hipLaunchKernelGGL((k_sdirk_wave_member<16, SV, false, TWV>), dim3((unsigned)nb), dim3(64 * TWV), lds_team, ctx->stream, nb, p, atol, ab, (const WaveSdirkConsts*)consts_dev, \
                      (const double*)t_eval_dev, y_out, stats, status, t_root, root_idx, ncols, totals_dev, jac_scratch)
-      if (S == 3) { if (waves == 2) DSH_TS_LAUNCH(3, 2); else DSH_TS_LAUNCH(3, 3); }
-      else { if (waves == 2) DSH_TS_LAUNCH(4, 2); else DSH_TS_LAUNCH(4, 3); }
+      if (S == 3) { if (waves == 2) DSH_TS_LAUNCH(3, 2); else if (waves == 3) DSH_TS_LAUNCH(3, 3); else if (waves == 4) DSH_TS_LAUNCH(3, 4); else DSH_TS_LAUNCH(3, 5); }
+      else { if (waves == 2) DSH_TS_LAUNCH(4, 2); else if (waves == 3) DSH_TS_LAUNCH(4, 3); else if (waves == 4) DSH_TS_LAUNCH(4, 4); else DSH_TS_LAUNCH(4, 5); }
 #undef DSH_TS_LAUNCH
     }
   } else
