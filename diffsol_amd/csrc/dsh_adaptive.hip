@@ -171,7 +171,8 @@ int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t n
 // OdeSolverMethod::solve (method.rs:227-258 over :881-961) inside the launch: the register-resident kernels only (static models, built-in or run-time-compiled)
 int dsh_model_has_adaptive_steps(int model, int64_t size) {
   if (!dsh_model_has_adaptive(model, size)) return 0;
-  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && ji->form == DSH_JIT_FORM_STATIC ? 1 : 0; }
+  // static run-time-compiled models (k_bdf_adaptive) and — round 5 — the banded lane-per-member form (k_bdf_lane_banded; forward sensitivities excluded by the caller)
+  if (is_jit_model(model)) { const JitInfo* ji = jit_info(model); return ji && (ji->form == DSH_JIT_FORM_STATIC || ji->form == DSH_JIT_FORM_STATIC_BANDED) ? 1 : 0; }
   return 1;
 }
 int dsh_bdf_solve_adaptive_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
@@ -179,7 +180,7 @@ int dsh_bdf_solve_adaptive_steps(dsh_ctx* ctx, int model, int64_t size, int64_t 
                                  int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
   DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_bdf_solve_adaptive_steps: max_cols >= 2, y_out, t_out and ncols are needed");
   if (!dsh_model_has_adaptive_steps(model, size)) {
-    set_error("dsh_bdf_solve_adaptive_steps: the model has no register-resident BDF (static model, n <= 4; the lane-per-member banded form and the wavefront / workgroup forms write save points only)");
+    set_error("dsh_bdf_solve_adaptive_steps: the model has neither a register-resident BDF (static model, n <= 4) nor a banded lane-per-member form (the wavefront / workgroup forms have dsh_bdf_solve_wave_member_steps)");
     return DSH_E_UNSUPPORTED;
   }
   const StepsSpec st{t_out, max_cols};

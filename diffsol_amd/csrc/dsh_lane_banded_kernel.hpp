@@ -456,6 +456,19 @@ DSH_LB_STREAM
 
   int col = 0;
   double te_next = t_eval[0];
+  // OdeSolverMethod::solve (method.rs:227-258 over :881-961): C.steps_cap > 0 makes the launch write the state after EVERY accepted step (y_out [steps_cap][N][nb],
+  // C.steps_t_out [steps_cap][nb]; columns beyond steps_cap are counted, not stored) instead of interpolating at save points — as in k_bdf_adaptive
+  const bool steps_mode = C.steps_cap > 0;
+  auto steps_write = [&](double tw, const double* yw) __attribute__((always_inline)) {
+    if (col < C.steps_cap && active) {
+      C.steps_t_out[(int64_t)col * nb + b] = tw;
+      const int64_t c0 = (int64_t)col * N;
+DSH_LB_STREAM
+      for (int i = 0; i < N; ++i) y_out[(c0 + i) * nb + b] = yw[i];
+    }
+    col++;
+  };
+  if (steps_mode) steps_write(t, y);  // write_out before the first step (method.rs:900)
   {
     const int r = handle_tstop();
     if (r == 1) status = kRsStopTimeAtCurrentTime;
@@ -771,6 +784,9 @@ DSH_LB_STREAM
     if (reason == 2) reason = 0;  // the reference unwraps / ignores this inside step()
     // ================================================================ solve_dense (method.rs:467-520): interpolated output
     const double upto = reason == 3 ? t_root : t;
+    if (steps_mode) {  // InternalTimestep / TstopReached -> write_out (method.rs:907-921): state.y; a root is written below, at the root
+      if (reason != 3) steps_write(t, y);
+    } else
     while (col < C.r.n_eval && te_next <= upto) {
       const int64_t c0 = (int64_t)col * N;
       interpolate_to(te_next, [&](int i, double v) __attribute__((always_inline)) { if (active) y_out[(c0 + i) * nb + b] = v; });
@@ -787,6 +803,7 @@ DSH_LB_STREAM
         t = t_root;
         Mdl::reset(t, *reinterpret_cast<const double (*)[N]>(w), p, *reinterpret_cast<double (*)[N]>(y));
         Mdl::rhs(t, *reinterpret_cast<const double (*)[N]>(y), p, *reinterpret_cast<double (*)[N]>(w));
+        if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {
           has_tstop = true;  // set_stop_time (bdf.rs:1591-1600)
           { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
@@ -812,6 +829,11 @@ DSH_LB_STREAM
         }
       }
     }
+    if (reason == 3 && steps_mode) {  // method.rs:922-947 without a reset: state_mut_back(t_root), write_out, RootFound
+      interpolate_to(t_root, [&](int i, double v) __attribute__((always_inline)) { w[i] = v; });
+      steps_write(t_root, w);
+      done = true;
+    } else
     if (reason == 3) {  // state_mut_back(root_time): the column after the drained ones holds the state at the root
       if (col < C.r.n_eval) {
         const int64_t c0 = (int64_t)col * N;
@@ -826,6 +848,7 @@ DSH_LB_STREAM
     if (ncols_out != nullptr) ncols_out[b] = col;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
+    if (!steps_mode)
     for (; col < C.r.n_eval; ++col)
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");

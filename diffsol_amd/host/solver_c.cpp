@@ -741,7 +741,7 @@ int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int gr
     if (s->method != DSHS_METHOD_BDF || s->problem.sens) throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: BDF without forward sensitivities (dshs_solve walks the host-driven path for the rest)");
     const ResidentPick pk = pick_resident(s, group);
     if (!pk.ok || pk.wave_member || !dsh_model_has_adaptive_steps(pk.model, pk.size))
-      throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: the model has no register-resident BDF (static models with n <= 4); dshs_solve returns every step of the host-driven lock-step solver");
+      throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: the model has neither a register-resident BDF (static models with n <= 4) nor a banded lane-per-member form; dshs_solve returns every step of the host-driven lock-step solver");
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
     const dsh_adaptive_options o = adaptive_options_of(s, group, deterministic_pow);
     dsh_ctx* c = s->ctx.raw();

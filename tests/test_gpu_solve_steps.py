@@ -109,8 +109,41 @@ def test_too_little_room_is_reported_and_events_end_a_members_columns_at_its_roo
         assert abs(y[nc - 1, b, 0] - 0.5 * pl[b, 1]) < 1e-6
 
 
-def test_forms_without_a_register_resident_kernel_refuse(H):
+@pytest.mark.parametrize("model,size,t_final,group", [("heat1d", 20, 0.05, 1), ("spm", 20, 1200.0, 1), ("heat1d", 64, 0.02, 64)])
+def test_banded_lane_per_member_form_returns_every_accepted_step(H, O, det_pow, model, size, t_final, group):
+    """VERDICT r4 missing 3: OdeSolverMethod::solve outside the register-resident forms.  k_bdf_lane_banded (state in per-lane memory, banded LU; BASELINE config 4's
+    kernel) writes the state after every accepted step: times and states equal the reference's loop over the oracle's stepping solver, bit for bit — per member, and per
+    64-member lock-step group (the single-particle model's voltage cut-offs end a member's columns at its root)."""
+    from helpers import ORACLE_MODEL
+    rng = np.random.default_rng(size + group)
+    nb = 70 if group == 1 else 64 + 9
+    p = rng.uniform(0.6, 1.4, (nb, 1))
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    s = H.Solver(model, p, nbatch=nb, model_size=size, **tol)
+    y, t, m, tot = s.solve_adaptive(t_final, max_cols=400, group=group)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all() and (m["ncols"] <= 400).all()
+    if group == 1:
+        for b in list(range(0, nb, 13)) + [nb - 1]:
+            ts, ys, root = reference_solve(O, ORACLE_MODEL[model], p[b:b + 1], t_final, model_size=size, **tol)
+            nc = m["ncols"][b]
+            assert nc == len(ts), (b, nc, len(ts))
+            assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+            assert (root is None) == (m["root_idx"][b] < 0)
+            if root is not None:
+                assert m["t_root"][b] == root[0] == t[nc - 1, b]
+    else:
+        for lo, hi in ((0, 64), (64, nb)):
+            ts, ys, _ = reference_solve(O, ORACLE_MODEL[model], p[lo:hi], t_final, model_size=size, **tol)
+            nc = len(ts)
+            assert (m["ncols"][lo:hi] == nc).all()
+            assert np.array_equal(t[:nc, lo:hi], np.repeat(ts[:, None], hi - lo, axis=1)) and np.array_equal(y[:nc, lo:hi], ys)
+    # the columns of solve are the steps solve_dense interpolates between
+    _, tot_d = s.solve_dense_adaptive([t_final], group=group)
+    assert tot_d["number_of_steps"] == tot["number_of_steps"]
+
+
+def test_forms_without_a_step_writing_kernel_refuse(H):
     rng = np.random.default_rng(1)
-    s = H.Solver("heat1d", rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, model_size=20, rtol=1e-6, atol=[1e-6])
-    with pytest.raises(Exception, match="register-resident"):
+    s = H.Solver("gaussian_decay", rng.uniform(0.5, 2.0, (8, 30)), nbatch=8, model_size=30, rtol=1e-6, atol=[1e-6])  # dense, n = 30: the wavefront-per-member form
+    with pytest.raises(Exception, match="register-resident|lane-per-member"):
         s.solve_adaptive(0.1, max_cols=64)
