@@ -43,9 +43,20 @@ int dsh_model_has_wave_member(int model, int64_t size) {
 }
 
 struct WmSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
+struct WmStepsSpec { double* t_out; int64_t cap; };  // OdeSolverMethod::solve: every accepted step out (WaveMemberConsts::steps_cap)
 static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                       double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens);
+                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens,
+                                      const WmStepsSpec* steps = nullptr);
+// OdeSolverMethod::solve (method.rs:227-258 over :881-961) inside the launch of the wavefront- / workgroup-per-member BDF: the state after every accepted step of every
+// member (y_out [max_cols][n][nb], t_out [max_cols][nb], ncols[b] = the columns member b produced; columns beyond max_cols are counted, not stored), to t_final
+int dsh_bdf_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                    double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                    int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_bdf_solve_wave_member_steps: max_cols >= 2, y_out, t_out and ncols are needed");
+  const WmStepsSpec st{t_out, max_cols};
+  return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
+}
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
@@ -82,7 +93,8 @@ int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_
 }
 static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                       double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens) {
+                                      int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens,
+                                      const WmStepsSpec* steps) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
   DSH_REQUIRE(atol_nb == 1 || atol_nb == nb, "atol must be broadcast (nbatch 1) or per member");
@@ -99,6 +111,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   C.sens_out = sens ? sens->out : nullptr; C.sens_rtol = sens ? sens->rtol : 0.0; C.sens_atol = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
   C.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.sens_pad = 1;
+  C.steps_t_out = steps ? steps->t_out : nullptr; C.steps_cap = steps ? (int)steps->cap : 0; C.steps_pad = 0;
   C.r.rtol = rtol; C.r.t0 = t0; C.r.h0 = h0; C.r.n_eval = (int)n_eval; C.r.member_lanes = 0;
   C.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   if (opts) C.r.o = *opts; else dsh_adaptive_default_options(&C.r.o);

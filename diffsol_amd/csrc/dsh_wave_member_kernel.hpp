@@ -63,6 +63,10 @@ struct WaveMemberConsts {
   double* sens_out;
   double sens_rtol, sens_atol;
   int sens_error_control, sens_pad;
+  // OdeSolverMethod::solve (method.rs:227-258 over :881-961), as in AdaptiveConsts: steps_cap > 0 makes the launch write the state after EVERY accepted step
+  // (y_out [steps_cap][n][nb], steps_t_out [steps_cap][nb]; columns beyond steps_cap are counted, not stored) instead of interpolating at save points
+  double* steps_t_out;
+  int steps_cap, steps_pad;
 };
 constexpr int kWmMaxSensParams = 16;  // parameters whose sensitivities a lane keeps (np x 10 doubles of per-lane memory)
 
@@ -497,6 +501,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   };
 
   int col = 0;
+  const bool steps_mode = !SENS && C.steps_cap > 0;  // every accepted step out (WaveMemberConsts::steps_cap)
+  auto steps_write = [&](double tw, double yv_mine) __attribute__((always_inline)) {
+    if (col < C.steps_cap) {
+      if (ln == 0) C.steps_t_out[(int64_t)col * nb + b] = tw;
+      if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv_mine;
+    }
+    col++;
+  };
+  if (steps_mode) steps_write(t, y);  // write_out before the first step (method.rs:900)
   {
     const int r = handle_tstop();
     if (r == 1) status = kRsStopTimeAtCurrentTime;
@@ -780,6 +793,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (reason == 0 && has_tstop) reason = handle_tstop();
     if (reason == 2) reason = 0;
     const double upto = reason == 3 ? t_root : t;
+    if (steps_mode) {  // InternalTimestep / TstopReached -> write_out (method.rs:907-921): state.y; a root is written below, at the root
+      if (reason != 3) steps_write(t, y);
+    } else
     while (col < C.r.n_eval && t_eval[col] <= upto) {
       const double yv = interpolate(t_eval[col]);
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
@@ -813,6 +829,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
         y = rowlive ? wm_reset_component(t, (int64_t)ln, Xf, Pf) : 0.0;
         const double dyr = rhs_of(y, t);
+        if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {
           has_tstop = true;  // set_stop_time (bdf.rs:1591-1600)
           { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
@@ -832,6 +849,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
       }
     }
+    if (reason == 3 && steps_mode) {  // method.rs:922-947 without a reset: state_mut_back(t_root), write_out, RootFound
+      const double yv = interpolate(t_root);
+      steps_write(t_root, yv);
+      done = true;
+    } else
     if (reason == 3) {
       if (col < C.r.n_eval) {
         const double yv = interpolate(t_root);
@@ -843,6 +865,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (reason == 1) done = true;
   }
   const int ncols = col;
+  if (!steps_mode)
   for (; col < C.r.n_eval; ++col) {
     if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = __builtin_nan("");
     if constexpr (SENS)

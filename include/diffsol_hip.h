@@ -489,24 +489,29 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
  * With group = 64 the members of a wavefront must agree on the crossing (status 20 otherwise, where the reference panics, vector/cuda.rs:1166-1171). */
 /* Device-resident BDF for run-time-sized models with n <= 64 (built-in or DiffSL; DiffSL models with a mass matrix — DAEs, made consistent on the device — n <= 48; the fallback for models without a banded lane-per-member form): ONE WAVEFRONT per member, lane = state component, the LU of
  * M - cJ in the wavefront's registers, per-member step sizes / orders / event stops, no host in the loop (dsh_wave_member.hip).
- * Identity-mass models with 64 < n <= 140 (dense Jacobians: the sizes between the wavefront form and the host-driven path) run ONE WORKGROUP per member instead
+ * Identity-mass models with 64 < n <= 320 (dense Jacobians: the sizes between the wavefront form and the host-driven path) run ONE WORKGROUP per member instead
  * (dsh_team_member_kernel.hpp: thread = state component, the LU of M - cJ in the CU's 160 KB LDS): dsh_model_has_wave_member returns 1 for the wavefront form,
  * 2 for the workgroup form, 0 for neither; dsh_bdf_solve_wave_member takes both.
  * dsh_sdirk_solve_wave_member: the same for TR-BDF2 (method 1) / ESDIRK34 (method 2) — Sdirk::step (sdirk.rs:409-543) over Rk (runge_kutta.rs:466-960),
- * the same models (dsh_model_has_wave_member_sdirk: 1 a wavefront per member, 2 a workgroup per member — 64 < n <= 140, identity mass), DAEs included.
+ * the same models (dsh_model_has_wave_member_sdirk: 1 a wavefront per member, 2 a workgroup per member — 64 < n <= 320, identity mass), DAEs included.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
 int dsh_model_has_wave_member(int model, int64_t size);
+/* OdeSolverMethod::solve (method.rs:227-258) inside the launch of the wavefront- / workgroup-per-member BDF: every accepted step of every member out (arguments as
+ * dsh_bdf_solve_adaptive_steps; the models of dsh_model_has_wave_member, n <= 320) */
+int dsh_bdf_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
+                                    double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                    int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 /* dsh_bdf_solve_wave_member with FORWARD SENSITIVITIES of every parameter (problem.bdf_sens(), bdf.rs:370-432, :934-989) for dense run-time-compiled ODE models the
  * register-resident and the banded lane forms do not cover: n <= 140, at most 16 parameters, no mass matrix, no root functions (dsh_model_has_wave_member_sens: 1 for
- * n <= 64 — one wavefront per member — 2 for 64 < n <= 140 — one workgroup per member; BDF and the SDIRK methods).  A component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
+ * n <= 64 — one wavefront per member — 2 for 64 < n <= 320 — one workgroup per member; BDF and the SDIRK methods).  A component per lane; sens_out: n_eval x np x n x nb (device, batch-fastest); sens_atol: one value (nsens_atol = 0: the sensitivities
  * stay out of the error test).  Other arguments as dsh_bdf_solve_adaptive_sens. */
 int dsh_model_has_wave_member_sens(int model, int64_t size);
 /* 1: the wavefront-per-member kernels (dsh_bdf_solve_wave_member, dsh_sdirk_solve_wave_member) carry this HYBRID model through all its events inside the launch —
  * reset applied at every root, then on to the last save point (solve_dense with a reset operator, method.rs:774-797); t_root / root_idx report a member's LAST event.
- * Run-time-compiled models with reset_i, stop_i and no mass matrix; returns 1 for n <= 64 (a wavefront per member), 2 for 64 < n <= 140 (a
+ * Run-time-compiled models with reset_i, stop_i and no mass matrix; returns 1 for n <= 64 (a wavefront per member), 2 for 64 < n <= 320 (a
  * workgroup per member); BDF, TR-BDF2, ESDIRK34. */
 int dsh_model_has_wave_member_reset(int model, int64_t size);
 /* dsh_sdirk_solve_wave_member with forward sensitivities (problem.tr_bdf2_sens() / esdirk34_sens(); runge_kutta.rs:691-748) for the models of

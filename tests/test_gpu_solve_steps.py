@@ -142,8 +142,27 @@ def test_banded_lane_per_member_form_returns_every_accepted_step(H, O, det_pow, 
     assert tot_d["number_of_steps"] == tot["number_of_steps"]
 
 
+@pytest.mark.parametrize("n", [30, 100, 200])
+def test_wavefront_and_workgroup_per_member_forms_return_every_accepted_step(H, O, det_pow, n):
+    """k_bdf_wave_member (n <= 64: a wavefront per member), k_bdf_team_member (a workgroup per member; n = 200 with the factors in global scratch): dense models,
+    per-member control, every accepted step out — times and states equal the reference's loop over the oracle's stepping solver."""
+    from helpers import ORACLE_MODEL
+    rng = np.random.default_rng(n)
+    nb = 11
+    p = rng.uniform(0.5, 2.0, (nb, n))
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    s = H.Solver("gaussian_decay", p, nbatch=nb, model_size=n, **tol)
+    y, t, m, tot = s.solve_adaptive(1.5, max_cols=300, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all() and (m["ncols"] <= 300).all()
+    for b in (0, nb // 2, nb - 1):
+        ts, ys, root = reference_solve(O, ORACLE_MODEL["gaussian_decay"], p[b:b + 1], 1.5, model_size=n, **tol)
+        nc = m["ncols"][b]
+        assert nc == len(ts) and root is None
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+
+
 def test_forms_without_a_step_writing_kernel_refuse(H):
     rng = np.random.default_rng(1)
-    s = H.Solver("gaussian_decay", rng.uniform(0.5, 2.0, (8, 30)), nbatch=8, model_size=30, rtol=1e-6, atol=[1e-6])  # dense, n = 30: the wavefront-per-member form
-    with pytest.raises(Exception, match="register-resident|lane-per-member"):
+    s = H.Solver("heat1d", rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, model_size=20, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)  # the SDIRK kernels write save points only
+    with pytest.raises(Exception, match="BDF"):
         s.solve_adaptive(0.1, max_cols=64)
