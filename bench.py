@@ -322,14 +322,17 @@ def rlc_params(nb, i_thresh):
 
 
 def _counters(name, key, sources):
-    """committed PMC summary of a config's kernel (profiles/r04_pmc_configs.json), refused when the kernel's sources changed since it was taken"""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
-    except Exception:
-        return None
-    if not d or d.get("kernel_source_sha16") != source_hash(sources):
-        return None
-    return d
+    """committed PMC summary of a config's kernel (profiles/r05_pmc_configs.json, else the name given), refused when the kernel's sources changed since it was taken"""
+    for cand in ("r05_pmc_configs.json", name):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", cand))).get(key)
+        except Exception:
+            continue
+        if d and d.get("kernel_source_sha16") == source_hash(sources):
+            d = dict(d)
+            d["file"] = "profiles/" + cand
+            return d
+    return None
 
 
 def cfg_cpu(model, p, t_eval, method, what, single_n, **kw):
@@ -439,11 +442,12 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
         else:
             K = 1
             by = nb * (8 * n * (3 * K + 1) + 4 * n + 16 * n)
-            rec["roofline"] = {"bound": "hbm", "kernel": "dsh_lu_solve (k_lu_band_solve_team<1,16>: banded forward + backward substitution)", "launches_timed": ns,
+            rec["roofline"] = {"bound": "hbm", "kernel": "k_lu_band_solve_team<1,16,EPI>: banded solve + norm (+ Newton update) in one launch", "launches_timed": ns,
                                "avg_launch_us": 1e3 * ms_s / max(ns, 1), "algorithmic_bytes_per_launch": by, "achieved": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": by / (ms_s * 1e-3 / max(ns, 1)) / 1e9 / HBM_PEAK_GBS, "share_of_solve_wall": ms_s * 1e-3 / wall,
                                "measured": "HIP events on the solver stream around every dsh_lu_solve launch of one whole solve", "kernel_source_sha16": source_hash(CFG_SOURCES["c3_banded"]),
-                               "note": "the chain of one wavefront's dependent FP64 operations bounds this kernel (profiles/r03_band_solve.md), not HBM"}
+                               "note": "the chain of one wavefront's dependent FP64 operations bounds this kernel (profiles/r03_band_solve.md), not HBM; bytes = the solve's own "
+                                       "(factors, pivots, right-hand side in and out) — the fused epilogue's y / x_in / x_out ride along"}
         if want_cpu:
             if "c3" not in cpu_memo:  # the reference's CPU path has one route for this config (NalgebraLU on the dense matrix): one measurement serves both GPU routes
                 ns_cpu = max(1, min(nb, 4 * int(usable_cpus(cpu_limits()))))
@@ -495,7 +499,10 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
         pm = _counters("r04_pmc_configs.json", "c4_dae" if dae else "c4_ode", CFG_SOURCES["c4"])
         if pm and pm.get("members") == nb:
             rec["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
-            rec["roofline"]["counters_from"] = "profiles/r04_pmc_configs.json"
+            rec["roofline"]["counters_from"] = pm.get("file")
+            if pm.get("hbm_bytes_per_launch"):  # against what the kernel actually moves (calibrated counters, profiles/r05_c4_traffic.md): the rate its access pattern sustains
+                rec["roofline"]["traffic_gbs"] = pm["hbm_bytes_per_launch"] / (ms * 1e-3 / max(nl, 1)) / 1e9
+                rec["roofline"]["traffic_frac_of_8TBs"] = rec["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         if want_cpu and nb == 32768:
             mid = DM.host_model(O, DM.spm_dae(20)) if dae else O.MODEL_SPM
             ns_cpu = 8192 if dae else 32768
@@ -538,7 +545,7 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
             valu, f64 = pm["valu_insts_per_launch"], pm.get("f64_insts_per_launch") or 0
             rec["roofline"].update({"achieved": valu * 64 / avg_s / 1e12, "frac": valu * 64 / avg_s / 1e12 / VALU_PEAK_TLANEOPS, "valu_wave_instructions_per_launch": valu,
                                     "issue_slot_frac": (4 * f64 + 2 * (valu - f64)) / (SIMD_CYCLES_PER_S * avg_s), "traffic": pm.get("hbm_bytes_per_launch"),
-                                    "counters_from": "profiles/r04_pmc_configs.json"})
+                                    "counters_from": pm.get("file")})
         else:
             rec["roofline"].update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC summary of this kernel build under profiles/ (scripts/profile_configs.sh)"})
         if want_cpu:
@@ -805,7 +812,7 @@ def main():
 
         extras["per_member"] = dict(mode_pass(ENSEMBLE_PER_MEMBER, False), note="every member its own step-size/order history (diffsol's CPU semantics for a sweep)")
         try:  # its roofline entry, from the committed counters of the same kernel (MODE=member scripts/profile_r03.sh); refused when the kernel sources changed since
-            pm_name = next((f for f in ("r04_pmc_per_member.json", "r03_pmc_per_member.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_per_member.json")
+            pm_name = next((f for f in ("r05_pmc_per_member.json", "r04_pmc_per_member.json", "r03_pmc_per_member.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_pmc_per_member.json")
             pm = json.load(open(os.path.join(ROOT, "profiles", pm_name))).get("bench_kernel", {})
             if pm.get("kernel_source_sha16") == kernel_source_hash() and pm.get("members") == nb and world == 1:
                 t_s = extras["per_member"]["ms_per_step"] * 1e-3
@@ -906,7 +913,7 @@ def main():
             avg_s = kernel_ms * 1e-3 / launches
             pmc = {}
             stale = None
-            pmc_name = next((f for f in ("r04_pmc_resident.json", "r03_pmc_resident.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r04_pmc_resident.json")
+            pmc_name = next((f for f in ("r05_pmc_resident.json", "r04_pmc_resident.json", "r03_pmc_resident.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_pmc_resident.json")
             path = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(path):
                 try:
@@ -916,7 +923,7 @@ def main():
                 if pmc:
                     pmc["file"] = "profiles/" + pmc_name
                     if pmc.get("kernel_source_sha16") != kernel_source_hash():  # counters of another kernel: no fraction rather than a stale one
-                        stale = f"profiles/{pmc_name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r04.sh"
+                        stale = f"profiles/{pmc_name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r05.sh"
                         pmc = {}
             algo_hbm = 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * (hi - lo)
             roof = {"bound": "valu", "kernel": "dsh::k_bdf_adaptive<RobertsonOde1, BA=true, WAVE=true> (the whole ensemble solve, one launch)",

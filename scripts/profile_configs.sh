@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 PMC passes over the device-resident kernels of BASELINE configs 4 and 5 (bench.py's `configs` rooflines):
+# PMC passes (round tag RND, default r05) over the device-resident kernels of BASELINE configs 4 and 5 (bench.py's `configs` rooflines):
 #   bash scripts/profile_configs.sh c4_ode|c4_dae|c5_per_member|c5_group64 [nb]
 # separate rocprofv3 --pmc passes (every one under its own timeout) + a kernel trace; summary in gpurun_out/r04/pmc_<cfg>.json; scripts/publish_configs_profile.py
 # merges the summaries into profiles/r04_pmc_configs.json (stamped with the kernel-source hash bench.py checks).
@@ -7,7 +7,8 @@ set -u
 export TMPDIR=/tmp
 CFG=$1
 NB=${2:-}
-OUT=$PWD/gpurun_out/r04
+RND=${RND:-r05}
+OUT=$PWD/gpurun_out/$RND
 mkdir -p $OUT
 P="python scripts/config_once.py $CFG $NB"
 W=/tmp/prof_$CFG

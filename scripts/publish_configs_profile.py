@@ -10,14 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import CFG_SOURCES, source_hash
 
-path = os.path.join(ROOT, "profiles", "r04_pmc_configs.json")
+RND = os.environ.get("RND", "r05")
+path = os.path.join(ROOT, "profiles", f"{RND}_pmc_configs.json")
 out = json.load(open(path)) if os.path.exists(path) else {}
 out["_note"] = ("rocprofv3 --kernel-trace --pmc <counters> -- python scripts/config_once.py <cfg> <members> (scripts/profile_configs.sh; one MI355X; separate passes: SQ instruction "
                 "counters, SQ wait/active counters, FETCH_SIZE, WRITE_SIZE; means over the dispatches).  HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                 "(MI355X_MICROARCH.md's gfx950 read correction).  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.")
 for arg in sys.argv[1:]:
     cfg, nb = arg.split(":")
-    d = json.load(open(os.path.join(ROOT, "gpurun_out", "r04", f"pmc_{cfg}.json")))
+    d = json.load(open(os.path.join(ROOT, "gpurun_out", RND, f"pmc_{cfg}.json")))
     name, k = max(d["kernels"].items(), key=lambda kv: kv[1].get("SQ_INSTS_VALU", 0))
     tr = [r for r in d.get("kernel_trace", []) if r["name"][:60] == name[:60]]
     out[cfg] = {"kernel": name, "members": int(nb), "kernel_source_sha16": source_hash(CFG_SOURCES["c4" if cfg.startswith("c4") else "c5"]),
