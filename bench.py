@@ -1017,7 +1017,7 @@ def main_c4(args, rank, local_rank, world, stub):
                 idt = torch.frombuffer(bytearray(CabiCommunicator.unique_id()), dtype=torch.uint8).to(dev)
             if world > 1:
                 dist.broadcast(idt, src=0)
-            comm = CabiCommunicator(s.context_handle(), rank, world, bytes(idt.cpu().numpy().tobytes()))
+            comm = CabiCommunicator(s.context_handle(), rank, world, bytes(idt.cpu().numpy().tobytes()), owner=s)
     out = torch.empty((len(t_eval), n, hi - lo), dtype=torch.float64, device=dev)
     full = torch.empty((len(t_eval), n, n_total), dtype=torch.float64, device=dev) if comm is not None else None
 

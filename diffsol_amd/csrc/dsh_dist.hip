@@ -82,7 +82,8 @@ __global__ void k_unpack(const double* __restrict__ recv, double* __restrict__ o
 }  // namespace
 
 struct dsh_dist {
-  dsh_ctx* ctx = nullptr;
+  dsh_ctx* ctx = nullptr;   // used while gathering (the solver's stream); never touched by dsh_dist_destroy — the context may be gone by then
+  int device = 0;           // the context's device, cached at init
   int rank = 0, world = 1;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;   // the collective's own stream
@@ -119,7 +120,7 @@ int dsh_dist_init(dsh_ctx* ctx, int rank, int world, const unsigned char* id128,
   if (!rccl().ok) { set_error("dsh_dist: librccl could not be loaded (DSH_RCCL_LIB names it explicitly)"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipSetDevice(ctx->device));
   dsh_dist* d = new dsh_dist();
-  d->ctx = ctx; d->rank = rank; d->world = world;
+  d->ctx = ctx; d->device = ctx->device; d->rank = rank; d->world = world;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   int rc = rccl_check(rccl().CommInitRank(&d->comm, world, id, rank), "ncclCommInitRank");
@@ -137,7 +138,7 @@ int dsh_dist_init(dsh_ctx* ctx, int rank, int world, const unsigned char* id128,
 
 void dsh_dist_destroy(dsh_dist* d) {
   if (!d) return;
-  (void)hipSetDevice(d->ctx->device);
+  (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   if (d->comm) (void)rccl().CommDestroy(d->comm);
   (void)hipFree(d->send);
@@ -202,19 +203,22 @@ int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, 
     for (int64_t l0 = 0; l0 < lead; l0 += 65535) {
       const int64_t ll = std::min<int64_t>(65535, lead - l0);
       rc = dsh_dist_pack_shard(d->ctx, d->stream, local + l0 * nl, ll, nl, m, d->send + l0 * m);
-      if (rc != DSH_OK) return rc;
+      if (rc != DSH_OK) { (void)hipStreamSynchronize(d->stream); return rc; }  // nothing of a failed gather stays queued behind the caller's back
     }
     src = d->send;
   }
   rc = rccl_check(rccl().AllGather(src, d->recv, send_len, ncclFloat64, d->comm, d->stream), "ncclAllGather");
-  if (rc != DSH_OK) return rc;
+  if (rc != DSH_OK) { (void)hipStreamSynchronize(d->stream); return rc; }
   // recv is [world][lead][m]: unpack in row blocks (the grid's y extent)
   for (int64_t l0 = 0; l0 < lead; l0 += 65535) {
     const int64_t ll = std::min<int64_t>(65535, lead - l0);
     hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n_total + 255) / 256), (unsigned)ll), dim3(256), 0, d->stream, d->recv + l0 * m, out + l0 * n_total, lead, n_total, d->world, m);
   }
-  DSH_HIP_CHECK(hipGetLastError());
-  DSH_HIP_CHECK(hipEventRecord(d->done, d->stream));
+  if (hipGetLastError() != hipSuccess || hipEventRecord(d->done, d->stream) != hipSuccess) {
+    (void)hipStreamSynchronize(d->stream);
+    set_error("dsh_gather_batch_axis_async: the unpack launch / completion event failed");
+    return DSH_E_HIP;
+  }
   d->pending = true;
   return DSH_OK;
 }

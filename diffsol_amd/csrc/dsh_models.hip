@@ -144,7 +144,8 @@ int jit_model_op(dsh_ctx* ctx, int model, Op op, int64_t nb, double t, const dou
     case Op::JacMul: return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_rhs", ew_grid(n * nb), dim3(kBlock), 0, nb, t, x, p, op == Op::JacMul ? v : (const double*)nullptr, y);
     case Op::Jacobian:
       if (ji->jac_nnz > 0 && !(std::getenv("DSH_JAC_SPARSE") && std::getenv("DSH_JAC_SPARSE")[0] == '0')) {
-        // large sparse model: zero the matrix, then the structural nonzeros only (the same evaluation per entry; the n^2 - nnz others are the +0 the dense form computes as 0 * x)
+        // large sparse model: zero the matrix, then the structural nonzeros only (the same evaluation per entry; the n^2 - nnz others are the +0 the dense form computes as
+        // 0 * x for FINITE states — with a non-finite state the dense form's 0 * inf is NaN where this one writes 0: the two agree on every state an integrator accepts)
         DSH_HIP_CHECK(hipMemsetAsync(y, 0, sizeof(double) * (size_t)(n * n * nb), ctx->stream));
         return jit_launch(ctx, model, hdr, "ops", none, "k_jit_dyn_jacobian_sparse", ew_grid(ji->jac_nnz * nb), dim3(kBlock), 0, nb, t, x, p, y);
       }

@@ -38,8 +38,11 @@ int dsh_model_has_wave_member(int model, int64_t size) {
         (model == DSH_MODEL_ROBERTSON_ODE && size > 1)))
     return 0;
   int64_t n = 0;
-  if (dsh_model_info(model, size, &n, nullptr, nullptr, nullptr) != DSH_OK) return 0;
-  return n >= 1 && n <= 64 ? 1 : (n <= kTeamMaxN ? 2 : 0);
+  int has_mass = 0;
+  if (dsh_model_info(model, size, &n, nullptr, &has_mass, nullptr) != DSH_OK) return 0;
+  if (n < 1) return 0;
+  if (n <= 64) return 1;
+  return !has_mass && n <= kTeamMaxN ? 2 : 0;  // the workgroup form takes identity-mass models
 }
 
 struct WmSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };

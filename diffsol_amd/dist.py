@@ -101,10 +101,12 @@ class CabiCommunicator:
     of libdiffsol_hip.so uses.  `unique_id` (128 bytes) comes from rank 0's CabiCommunicator.unique_id() and reaches the other ranks by any side channel (here: the
     launcher's store, a file, an environment variable)."""
 
-    def __init__(self, ctx_handle, rank, world, unique_id):
+    def __init__(self, ctx_handle, rank, world, unique_id, owner=None):
+        """owner: the Solver (or context object) `ctx_handle` came from — kept alive as long as the communicator, whose gathers run behind that context's stream"""
         import ctypes as C
 
         from . import _ffi
+        self._owner = owner
         self._L = _ffi.load_device_lib()
         self._h = _ffi.vp()
         assert len(unique_id) == 128

@@ -64,15 +64,19 @@ int dsh_ctx_device(dsh_ctx* ctx);
 /* threads per workgroup for one-lane-per-system kernels (default 64; tuning knob, power of two in [64,1024]) */
 int dsh_ctx_set_block(dsh_ctx* ctx, int threads);
 
-/* HIP-event timing of the fused Newton-iteration kernel (the dominant kernel) on the context's own stream: when enabled every
- * dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch is bracketed by two events; get_timing returns the number of launches and
- * the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figure. */
 /* 1 when the library was built with -DDSH_EXPERIMENTS (make EXPERIMENTS=1): the measured-slower kernel variants and their DSH_REBIN / DSH_REBIN_STEPS /
  * DSH_MEMBER_SCHED / DSH_LANE_BANDED_V1 / DSH_LU_STREAM_THREADS knobs exist; 0 in the shipped library (the knobs are then ignored). */
 int dsh_experiments_enabled(void);
+/* HIP-event timing of the dominant kernel on the context's own stream: when enabled every launch of the target (dsh_ctx_set_timing_target; default the
+ * device-resident integrators and the fused dsh_bdf_newton_iter / dsh_sdirk_newton_iter launch) is bracketed by two events; dsh_ctx_get_timing returns the number
+ * of launches and the summed kernel time in milliseconds since timing was (re-)enabled.  Used by bench.py for the live roofline figures. */
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
 /* Which launches the event brackets go around while timing is enabled (resets the accumulated time): the device-resident integrators and the fused Newton launch
  * (default), every dsh_lu_solve launch, or every dsh_lu_factor call (staging copy + factor kernel for the matrix-core kernel).  bench.py's per-config rooflines. */
+#define DSH_TIMING_RESIDENT 0
+#define DSH_TIMING_LU_SOLVE 1
+#define DSH_TIMING_LU_FACTOR 2
+int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target);
 /* Order of operations of the linear solves issued on this context.  DSH_SOLVE_EXACT (default): the reference's getrs order — solutions bit-identical to the CPU
  * path.  DSH_SOLVE_REORDERED (opt-in, like dsh_adaptive_options.deterministic_pow = 2): banded solves of small ensembles (K = 1, n <= 1024, <= 16384 systems) run as
  * chunked affine maps (csrc/dsh_lu_band_affine.hpp: 1/8 of the dependent chain, another association of the same sums, reciprocal instead of division) — equal to
@@ -81,10 +85,6 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable);
 #define DSH_SOLVE_REORDERED 1
 int dsh_ctx_set_solve_mode(dsh_ctx* ctx, int mode);
 int dsh_ctx_get_solve_mode(const dsh_ctx* ctx);
-#define DSH_TIMING_RESIDENT 0
-#define DSH_TIMING_LU_SOLVE 1
-#define DSH_TIMING_LU_FACTOR 2
-int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target);
 /* How blocking reductions wait for the device: poll != 0 (default; env DSH_SYNC_MODE=sync flips it) spins on the sequence tags of the
  * per-workgroup result records the kernels write into pinned host memory; poll == 0 uses hipStreamSynchronize. */
 int dsh_ctx_set_poll(dsh_ctx* ctx, int poll);

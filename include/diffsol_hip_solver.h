@@ -179,7 +179,9 @@ void dshs_free_string(char* s);
 /* The reference's DiffSL model index (DiffSlContext::model_index, ode_equations/diffsl.rs:52,115,406-411; the scalar `N` of a DiffSL text, 0 unless
  * set_params_and_model changes it).  It is a compile-time constant of the generated model: another index is another compiled model.
  * dshs_diffsl_generate_indexed passes it explicitly.  dshs_diffsl_set_model_index arms it ONE-SHOT for the next text this thread compiles through an entry
- * that has no index argument (dshs_diffsl_generate, diffsol_ode_new_jit): that call consumes it, every later call compiles with index 0 again. */
+ * that has no index argument (dshs_diffsl_generate, diffsol_ode_new_jit): that call consumes it, every later call compiles with index 0 again.
+ * A caller that runs dshs_diffsl_generate TWICE for one model (dimensions first, then the source with its defaults) must therefore use
+ * dshs_diffsl_generate_indexed for both calls — an armed index would serve the first call only and the second would describe model 0. */
 int dshs_diffsl_generate_indexed(const char* code, int target, int model_index, char** source_out, int64_t* dims, double* defaults_out, int64_t defaults_cap);
 int dshs_diffsl_set_model_index(int model_index);
 

@@ -4,6 +4,8 @@ Part 1 replays the literal known-answer cases of the reference's backend-generic
 (crates/diffsol-la/src/vector/mod.rs:705-1135 `test_batched_*`, matrix/mod.rs) — inputs and expected outputs are the reference's.
 Part 2 checks every op on seeded random data against a numpy statement of the same semantics at ragged / non-multiple-of-64 sizes,
 bit-exactly (the kernels do no re-association)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -279,7 +281,7 @@ def test_matrix_ops_match_numpy(H, ctx1, nb):
 @pytest.mark.parametrize("n,nb", [(128, 8), (130, 3), (512, 37), (1000, 9), (161, 64), (256, 5), (513, 12), (1537, 3)])
 def test_norm_of_long_vectors_in_small_ensembles_keeps_the_sequential_summation_bits(H, ctx1, n, nb):
     """n >= 128 and at most 16 384 members run k_squared_norm_wide (8 members per wavefront, the terms of 32 components computed on all 64 lanes, the additions in
-    index order on one row group), from 256 components on k_squared_norm_team (a workgroup per 8 members, 512-row blocks): every member's value bit for bit the sequential sum, for member counts and lengths that are not multiples of the tile; all four
+    index order on one row group), from 128 components on k_squared_norm_wide (k_squared_norm_team, the workgroup form, is the default only with the fused Newton update; the subprocess test below forces it): every member's value bit for bit the sequential sum, for member counts and lengths that are not multiples of the tile; all four
     broadcast combinations of y and atol; per-member atol; NaN propagation."""
     rng = np.random.default_rng(n + nb)
     c = ctx1.clone_with_nbatch(nb)
@@ -307,3 +309,50 @@ def test_norm_of_long_vectors_in_small_ensembles_keeps_the_sequential_summation_
     xn = x.copy()
     xn[nb // 2, n - 1] = np.nan
     assert np.isnan(V(H, xn, c).squared_norm(V(H, y, c), V(H, atol1, ctx1), rtol))
+
+
+_NORM_TEAM_SCRIPT = """
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import diffsol_amd as H
+n, nb = 700, 21
+rng = np.random.default_rng(3)
+c = H.HipContext(nbatch=nb)
+x = rng.standard_normal((nb, n)); y = rng.standard_normal((nb, n)); a = np.abs(rng.standard_normal(n)) * 1e-3 + 1e-6
+X, Y, A = H.HipVec.from_vec(x, c), H.HipVec.from_vec(y, c), H.HipVec.from_vec(a[None, :], c.clone_with_nbatch(1))
+got = X.squared_norm(Y, A, 1e-4)
+t = x / (np.abs(y) * 1e-4 + a[None, :])
+ref = (np.cumsum(t * t, axis=1)[:, -1] / n).max()
+assert got == ref, (got, ref)
+# the SUB form (Newton update + norm in one pass): the staged SDIRK Newton iteration of heat1d with the banded solve's own epilogue switched off
+n2 = 512
+L = c._L
+band = np.zeros((nb, n2, n2)); i = np.arange(n2)
+band[:, i, i] = 2.0 + rng.random((nb, n2)); band[:, i[:-1], i[:-1] + 1] = -rng.random((nb, n2 - 1)); band[:, i[1:], i[1:] - 1] = -rng.random((nb, n2 - 1))
+lu = H.HipLU(c, n2); lu.factor(H.HipMat.from_array(band, c))
+k0 = rng.standard_normal((nb, n2)) * 1e-3
+K, PHI, P, YE = H.HipVec.from_vec(k0, c), H.HipVec.from_vec(rng.standard_normal((nb, n2)), c), H.HipVec.from_vec(rng.uniform(0.5, 2.0, (nb, 1)), c), H.HipVec.from_vec(rng.standard_normal((nb, n2)), c)
+A2 = H.HipVec.from_vec(np.full((1, n2), 1e-6), c.clone_with_nbatch(1))
+out = (C.c_double * 3)()
+assert L.dsh_sdirk_newton_iter(c._h, 7, n2, nb, 0.0, 1e-3, 2e-4, K.ptr, K.ptr, PHI.ptr, P.ptr, lu._h, YE.ptr, A2.ptr, 1, 1e-6, out) == 0
+np.save(sys.argv[1], np.concatenate([np.asarray(K.clone_as_vec()).ravel(), [out[0]]]))
+"""
+
+
+def test_workgroup_form_of_the_norm_plain_and_with_the_newton_update_gives_the_sequential_sums_bits(tmp_path):
+    """k_squared_norm_team without the fused update is never the default (DSH_NORM_TEAM is read once per process), so it ran in no test.  A subprocess forces
+    it: the plain norm against numpy's in-order sum, and the SUB form (update + norm, reached with the banded solve's epilogue off) against the default path's iterate
+    and norm — bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "norm_team.py"
+    script.write_text(_NORM_TEAM_SCRIPT.format(root=root))
+    outs = []
+    for env_extra in ({"DSH_NORM_TEAM": "1", "DSH_LU_SOLVE_EPI": "0"}, {"DSH_NORM_TEAM": "0", "DSH_LU_SOLVE_EPI": "0"}, {}):
+        out = tmp_path / ("o%d.npy" % len(outs))
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
