@@ -129,14 +129,15 @@ extern "C" {
 int dsh_model_has_adaptive_reset(int model, int64_t size) {
   if (is_jit_model(model)) {
     const JitInfo* ji = jit_info(model);
-    if (!(ji && ji->has_reset && !ji->has_mass && ji->nroots > 0)) return 0;
-    // register-resident form (n <= 4), or the banded lane-per-member form (k_bdf_lane_banded: the same event handling on per-lane memory; BDF)
-    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || ji->form == DSH_JIT_FORM_STATIC_BANDED ? 1 : 0;
+    if (!(ji && ji->has_reset && ji->nroots > 0)) return 0;
+    // register-resident form (n <= 4; round 5: with a mass matrix too — hybrid DAEs, made consistent again after every reset), or the banded lane-per-member form
+    // (k_bdf_lane_banded: the same event handling on per-lane memory; identity mass; BDF)
+    return (ji->form == DSH_JIT_FORM_STATIC && ji->n <= 4) || (ji->form == DSH_JIT_FORM_STATIC_BANDED && !ji->has_mass) ? 1 : 0;
   }
   bool ok = false;
   dispatch_static_model(model, size, [&](auto mdl) {
     using Mdl = decltype(mdl);
-    ok = model_has_reset<Mdl>::value && Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS > 0 && model_band_k<Mdl>::value == 0;
+    ok = model_has_reset<Mdl>::value && Mdl::N <= 4 && Mdl::NROOTS > 0 && model_band_k<Mdl>::value == 0;
   });
   return ok ? 1 : 0;
 }

@@ -109,7 +109,8 @@ DSH_UNROLL_N
   constexpr bool BANDED = BK > 0;
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
   // hybrid models (a reset operator: OdeEquations::reset, DiffSL reset_i) apply the reset at every event and go on, as the reference's solve_dense does
-  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && !BANDED && Mdl::NROOTS > 0;
+  // (round 5: also with a mass matrix — hybrid DAEs: the state is made consistent again after the reset, apply_reset_with_mass, state.rs:279-306)
+  constexpr bool kResets = model_has_reset<Mdl>::value && !BANDED && Mdl::NROOTS > 0;
   constexpr bool DTP = BANDED || DSH_ADAPTIVE_DT_PRIVATE != 0;  // the swap partner of D in per-lane memory
   constexpr int LN = BANDED ? 1 : N;
   __shared__ double sDt[DTP ? 1 : kNC * LN][64];
@@ -942,10 +943,35 @@ DSH_UNROLL_N
         // from the modified state at first order (bdf.rs:1290-1318).  The save points up to the root were written from the step's polynomial above.
         double yb[N], yr[N], dyr[N];
         interpolate(t_root, yb);
+        if constexpr (Mdl::HAS_MASS) {
+          // state_mut_back stores the derivative of the step's polynomial at the root in state.dy (interpolate_derivative_from_diff, bdf.rs:784-811): the starting
+          // guess of the differential unknowns of set_consistent below
+          double pi = 1.0, d_pi = 0.0;
+DSH_UNROLL_N
+          for (int i = 0; i < N; ++i) dyr[i] = 0.0;
+#pragma unroll
+          for (int j = 0; j < kMaxOrder; ++j) {
+            if (j < order) {
+              const double i_t = (double)j;
+              const double denom = h * (1.0 + i_t);
+              const double w = (t_root - (t - h * i_t)) / denom;
+              const double dw = 1.0 / denom;
+              const double new_d_pi = d_pi * w + pi * dw;
+              pi *= w;
+              d_pi = new_d_pi;
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) dyr[i] = d_pi * D[j + 1][i] + 1.0 * dyr[i];
+            }
+          }
+        }
         t = t_root;
         Mdl::reset(t, yb, p, yr);
 DSH_UNROLL_N
         for (int i = 0; i < N; ++i) y[i] = yr[i];
+        if constexpr (Mdl::HAS_MASS) {
+          // apply_reset_with_mass (state.rs:279-306): (y, dy) consistent with the algebraic equations again — Newton on InitOp WITHOUT line search, whatever ic_options say
+          if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, dyr, atol, rtol, C.r, true))) { status = kRsInitialConditionDidNotConverge; break; }
+        } else
         Mdl::rhs(t, y, p, dyr);
         if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {

