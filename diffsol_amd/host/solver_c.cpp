@@ -143,7 +143,9 @@ ResidentPick pick_resident(const dshs_solver* s, int group, bool for_auto = fals
     r.ok = true; r.model = twin; r.size = 0;
   } else if (s->problem.eqn->fused_model(&model, &size) && dsh_model_has_resident(r.method, model, size)) {
     r.ok = true; r.model = model; r.size = size;
-  } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) != 0 : dsh_model_has_wave_member_sdirk(model, size) != 0)) {
+  } else if (group == 1 && s->problem.eqn->registry_model(&model, &size) && (r.method == 0 ? dsh_model_has_wave_member(model, size) != 0 : dsh_model_has_wave_member_sdirk(model, size) != 0) &&
+             (!for_auto || s->problem.eqn->nstates() <= 140)) {
+    // (the automatic mode takes the workgroup form up to the LDS sizes; 140 < n <= 320 — factors in global scratch, correct but slow — on explicit request only)
     r.ok = true; r.wave_member = true; r.model = model; r.size = size;
   } else if (group == 1 && !for_auto && s->problem.eqn->registry_model(&model, &size) && (twin = dsh_model_member_twin(model)) >= 0 &&
              (r.method == 0 ? dsh_model_has_wave_member(twin, 0) != 0 : dsh_model_has_wave_member_sdirk(twin, 0) != 0)) {

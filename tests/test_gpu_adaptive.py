@@ -100,7 +100,7 @@ def test_adaptive_exponential_decay_counters_and_analytic_solution(H, O):
 
 
 def test_adaptive_rejects_unsupported_models_and_bad_t_eval(H):
-    s3 = H.Solver("gaussian_decay", [[1.0] * 150], nbatch=1, model_size=150, method=1)  # run-time sized, dense Jacobian, n = 150: no lane-per-member form and too large for the wavefront- / workgroup-per-member kernels
+    s3 = H.Solver("gaussian_decay", [[1.0] * 330], nbatch=1, model_size=330, method=1)  # run-time sized, dense Jacobian, n = 330: no lane-per-member form and too large for the wavefront- / workgroup-per-member kernels (n <= 320)
     with pytest.raises(H.DiffsolHipError) as e:
         s3.solve_dense_adaptive([0.1])
     assert e.value.code == -6
