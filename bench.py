@@ -138,6 +138,8 @@ def compact_line(rec):
         out["configs"] = cc
     if "bench_seconds" in rec:
         out["bench_seconds"] = _sig(rec["bench_seconds"])
+    if "jit_compiles_this_run" in rec:
+        out["jit_compiles_this_run"] = rec["jit_compiles_this_run"]
     out["detail"] = DETAIL_FILE
     line = json.dumps(out, separators=(",", ":"))
     if len(line) > LINE_LIMIT:  # never print a line the driver cannot hold: drop the optional blocks, keep the contract keys
@@ -969,6 +971,12 @@ def main():
                 rec["trait_path"] = {"error": str(e)[:300]}
             rec["configs"] = bench_configs(local_rank, not args.no_cpu_baseline, quick=args.quick_configs, budget_s=args.time_budget)
         rec["bench_seconds"] = time.perf_counter() - T_START
+        if not stub:
+            try:  # modules hiprtc compiled during THIS run (0 when build() has replayed the committed manifests: first-use compilation inside the bench is a bug)
+                from diffsol_amd import _ffi
+                rec["jit_compiles_this_run"] = int(_ffi.load_device_lib().dsh_jit_compile_count())
+            except Exception:
+                pass
         emit(rec)
     if world > 1:
         dist.barrier()

@@ -22,7 +22,7 @@ def build(verbose=False, jobs=8):
 MANIFEST_DIR = os.path.join(_HERE, "jit_manifest")
 
 
-def replay_manifests(jobs=None, verbose=False, only=None, budget_s=420.0):
+def replay_manifests(jobs=None, verbose=False, only=None, budget_s=420.0, preload_torch=False):
     """Compile every request of the committed manifests (diffsol_amd/jit_manifest/*.rec — written on a GPU box under DSH_JIT_RECORD by bench.py and the `-m gpu`
     tests, scripts/record_jit_manifest.sh) into the in-tree cache diffsol_amd/_jit_cache/ with hiprtc: no GPU needed, one process per core, requests dealt round-robin.
     A fresh box then loads every code object it asks for instead of compiling at first use.  Returns (requests, compiled)."""
@@ -44,7 +44,11 @@ def replay_manifests(jobs=None, verbose=False, only=None, budget_s=420.0):
     jobs = jobs or max(1, min(len(os.sched_getaffinity(0)), 16))
     # worker k compiles requests k, k + jobs, ... of every manifest, one dsh_jit_replay call per request, and starts no new one after the deadline (what is left is
     # compiled at first use, as before)
-    code = ("import ctypes as C, sys, time\n"
+    # preload_torch: PyTorch-ROCm bundles its own HIP runtime / hiprtc (another ROCm release than /opt/rocm); a process that imports torch first resolves the library's
+    # HIP symbols there, so its cache key (toolchain versions are part of it) and its code generator differ from a plain process's.  bench.py imports torch: its
+    # manifest is replayed in both environments.
+    code = (("import torch\n" if preload_torch else "") +
+            "import ctypes as C, sys, time\n"
             "from diffsol_amd import _ffi\n"
             "dev = _ffi.load_device_lib()\n"
             "k, jobs, deadline = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])\n"

@@ -257,7 +257,9 @@ int compile_tu(const JitModelRec& rec, const std::string& tu, const char* header
     char name[64];
     snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
     path = dir + name;
-    if (cache_load(path, group, out)) return DSH_OK;
+    const bool hit = cache_load(path, group, out);
+    if (std::getenv("DSH_JIT_DEBUG")) fprintf(stderr, "dsh_jit: %s %s (headers fingerprint %016llx, %s)\n", hit ? "hit " : "MISS", path.c_str(), (unsigned long long)headers_fingerprint(), header);
+    if (hit) return DSH_OK;
   }
   for (const std::string& o : include_options()) opts.push_back(o);
   // One process per GPU: eight ranks that meet the same model on a cold cache would each spend the minutes hiprtc takes on it.  An exclusive lock on
