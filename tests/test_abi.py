@@ -197,3 +197,50 @@ def test_the_remaining_names_of_the_reference_c_api_exist_and_behave(built, tmp_
     (tmp_path / "bad.hip").write_text("#define DIFFSOL_EXTERNAL_STATES 9\n#define DIFFSOL_EXTERNAL_INPUTS 1\n")
     assert L.diffsol_ode_new_external_dynamic(str(tmp_path / "bad.hip").encode(), capi.MATRIX_HIP_DENSE, 0, 0, None, 0, None, 0, None, 0) is None
     assert b"8 states" in L.diffsol_last_error_message()
+
+
+_JIT_MANIFEST_SCRIPT = """
+import ctypes as C, os, sys
+sys.path.insert(0, {root!r})
+import diffsol_amd
+from diffsol_amd import _ffi
+dev = _ffi.load_device_lib()
+mode = sys.argv[1]
+if mode == "request":   # ask for one module the way a solve does (the lane-per-member BDF of heat1d, n = 12)
+    twin = dev.dsh_model_lane_twin(diffsol_amd.MODELS["heat1d"], 12)
+    assert twin >= 1000 and dev.dsh_model_precompile(twin, 2) == 0, dev.dsh_last_error()
+    print("compiled", dev.dsh_jit_compile_count())
+else:                   # replay a manifest into the cache
+    r, c = C.c_int64(0), C.c_int64(0)
+    assert dev.dsh_jit_replay(sys.argv[2].encode(), 0, 1, C.byref(r), C.byref(c)) == 0, dev.dsh_last_error()
+    print("replayed", r.value, c.value)
+"""
+
+
+def test_jit_request_manifest_round_trip_record_replay_then_no_compilation(tmp_path):
+    """first-use compilation inside bench.py is a bug.  The mechanism behind build(): DSH_JIT_RECORD writes every module request to a manifest,
+    dsh_jit_replay compiles a manifest into the cache without a GPU, and a process that then asks for the same module compiles nothing."""
+    import subprocess
+    import sys
+    script = tmp_path / "jit.py"
+    script.write_text(_JIT_MANIFEST_SCRIPT.format(root=ROOT))
+    manifest = tmp_path / "requests.rec"
+
+    def run(args, cache, record=None):
+        env = dict(os.environ, DSH_JIT_CACHE=str(cache))
+        env.pop("DSH_JIT_RECORD", None)
+        if record:
+            env["DSH_JIT_RECORD"] = str(record)
+        r = subprocess.run([sys.executable, str(script)] + args, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.split()
+
+    out = run(["request"], tmp_path / "cache_a", record=manifest)          # a cold cache: the request compiles, and is recorded
+    assert out[0] == "compiled" and int(out[1]) == 1 and manifest.stat().st_size > 200
+    assert manifest.read_bytes()[:4] == b"DSHJ"
+    out = run(["replay", str(manifest)], tmp_path / "cache_b")             # another cold cache: the replay compiles the recorded request
+    assert out[0] == "replayed" and int(out[1]) == 1 and int(out[2]) == 1
+    out = run(["request"], tmp_path / "cache_b")                            # ... and the request now finds its code object
+    assert out[0] == "compiled" and int(out[1]) == 0
+    out = run(["replay", str(manifest)], tmp_path / "cache_b")             # a second replay has nothing to do
+    assert int(out[1]) == 1 and int(out[2]) == 0

@@ -356,3 +356,26 @@ def test_workgroup_form_of_the_norm_plain_and_with_the_newton_update_gives_the_s
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_a_context_moves_to_another_host_thread(H):
+    """The threading contract of include/diffsol_hip.h (what the Rust shim's `unsafe impl Send` rests on): a context and its objects may move between host threads,
+    used by one thread at a time; the thread that takes it over binds the device first (dsh_ctx_bind_thread).  A vector made on the main thread is used, and its
+    norm read, on a worker thread, then again on the main thread."""
+    import threading
+    c = H.HipContext(nbatch=5)
+    x = H.HipVec.from_vec(np.arange(15.0).reshape(5, 3), c)
+    got = {}
+
+    def worker():
+        assert c._L.dsh_ctx_bind_thread(c._h) == 0
+        x.axpy(2.0, x, 1.0)  # x <- 3 x
+        got["norm"] = x.norm(1)
+        got["vals"] = np.asarray(x.clone_as_vec()).reshape(5, 3)
+
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert np.array_equal(got["vals"], 3.0 * np.arange(15.0).reshape(5, 3)) and got["norm"] == (3.0 * np.arange(15.0).reshape(5, 3)).sum(axis=1).max()
+    assert c._L.dsh_ctx_bind_thread(c._h) == 0
+    x.axpy(1.0, x, 1.0)
+    assert np.array_equal(np.asarray(x.clone_as_vec()).reshape(5, 3), 6.0 * np.arange(15.0).reshape(5, 3))
