@@ -57,7 +57,10 @@ __device__ unsigned long long g_tlu[4];  // thread 0 of workgroup 0: cycles in t
 // LU of the n x n matrix in LDS (A[c * P + r], thread t = row t) with partial pivoting and physical row interchanges; perm[k] = original row at position k.
 // Workgroup-uniform control flow; all W wavefronts must call it together.
 template <int W>
+__device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular);
+template <int W>
 __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular) {
+  if constexpr (team_global_factors(W)) { team_lu_factor_panel<W>(A, P, n, ln, rowlive, cand, perm, singular); return; }  // factors in global scratch: one round trip of the trailing matrix per panel
   const int wave = ln >> 6, lane = ln & 63;
   perm[ln] = ln;
   singular = false;
@@ -107,12 +110,116 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
   }
 }
 
+// The same factorisation in PANELS of kTeamPanel pivots (LAPACK getrf's blocking), for the factors in GLOBAL scratch (n > 140): the unblocked form streams the whole
+// trailing matrix through the memory system once per pivot — n^3 / 3 x 24 bytes = 216 MB per factorisation at n = 300, nothing of it cached with thousands of members
+// in flight: the route was HBM-bound (profiles/r05_member_lanes.md).  Per element the operations of the unblocked elimination in their order — a_rc takes
+// (-u_kc) l_rk + a_rc for k = 0, 1, 2, ... whatever the grouping: the same bits.
+//   1. the panel's pivots are searched, interchanged (whole rows, as before) and eliminated inside the panel's own columns only;
+//   2. U12: the pivot rows' entries in every later column take the panel's earlier pivots — thread j does column k1 + j by itself and writes the final entries back;
+//   3. the rows below the panel update every later column with all of the panel's pivots at once: the trailing matrix makes one round trip per PANEL.
+// (In LDS this form measured no gain — 0.349 against 0.351 s at n = 120 — and is not used there.)
+constexpr int kTeamPanel = 8;
+template <int W>
+__device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular) {
+  constexpr int PW = kTeamPanel;
+  const int wave = ln >> 6, lane = ln & 63;
+  perm[ln] = ln;
+  singular = false;
+  __syncthreads();  // every row of A is stored, perm is the identity
+  for (int k0 = 0; k0 < n; k0 += PW) {
+    const int k1 = k0 + PW < n ? k0 + PW : n;
+    unsigned elim_mask = 0u;  // pivots of this panel that eliminate (a zero pivot leaves the rows where they are and eliminates nothing, lu_factor_reg does the same)
+    for (int k = k0; k < k1; ++k) {
+      double best = -1.0;
+      int p = n;
+      if (rowlive && ln >= k) { const double v = fabs(A[k * P + ln]); if (v > best) { best = v; p = ln; } }
+      group_argmax(best, p, 64);
+      if (lane == 0) { cand[2 * wave] = best; cand[2 * wave + 1] = (double)p; }
+      __syncthreads();
+      double b0 = cand[0];
+      int p0 = (int)cand[1];
+#pragma unroll
+      for (int w = 1; w < W; ++w) argmax_take(b0, p0, cand[2 * w], (int)cand[2 * w + 1]);
+      p = p0;
+      if (p >= n) p = k;  // NaN column: keep the diagonal like the sequential scan
+      const double diag = A[k * P + p];
+      const bool elim = diag != 0.0;
+      if (!elim) { singular = true; p = k; }
+      if (elim) elim_mask |= 1u << (k - k0);
+      if (elim && p != k) {  // interchange rows k and p: thread c takes column c
+        if (ln < n) { const double u = A[ln * P + k]; A[ln * P + k] = A[ln * P + p]; A[ln * P + p] = u; }
+        if (ln == 0) { const int q = perm[k]; perm[k] = perm[p]; perm[p] = q; }
+      }
+      __syncthreads();
+      if (elim && rowlive && ln > k) {
+        const double l = A[k * P + ln] * (1.0 / diag);
+        A[k * P + ln] = l;
+        for (int c = k + 1; c < k1; ++c) A[c * P + ln] = (-A[c * P + k]) * l + A[c * P + ln];
+      }
+      __syncthreads();
+    }
+    if (k1 >= n) break;
+    // ---- U12: thread j finishes the pivot rows' entries of column k1 + j (row k0 + u takes the pivots k0 + v, v < u, in order); n - k1 <= threads
+    {
+      const int c = k1 + ln;
+      if (c < n) {
+        double t[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) t[u] = k0 + u < k1 ? A[c * P + k0 + u] : 0.0;
+#pragma unroll
+        for (int u = 1; u < PW; ++u) {
+          if (k0 + u < k1) {
+#pragma unroll
+            for (int v = 0; v < u; ++v)
+              if (elim_mask & (1u << v)) t[u] = (-t[v]) * A[(k0 + v) * P + k0 + u] + t[u];  // l_{k0+u, k0+v}: the same address in every lane
+          }
+        }
+#pragma unroll
+        for (int u = 1; u < PW; ++u) if (k0 + u < k1) A[c * P + k0 + u] = t[u];
+      }
+    }
+    __syncthreads();
+    // ---- rows below the panel: every later column takes the panel's pivots in order
+    if (rowlive && ln >= k1) {
+      double lr[PW];
+#pragma unroll
+      for (int u = 0; u < PW; ++u) lr[u] = k0 + u < k1 ? A[(k0 + u) * P + ln] : 0.0;
+      int c = k1;
+      for (; c + 4 <= n; c += 4) {  // four columns at a time, their reads issued together
+        double pu[4][PW], mine[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          mine[q] = A[(c + q) * P + ln];
+#pragma unroll
+          for (int u = 0; u < PW; ++u) pu[q][u] = A[(c + q) * P + (k0 + u < k1 ? k0 + u : k0)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int u = 0; u < PW; ++u)
+            if (k0 + u < k1 && (elim_mask & (1u << u))) mine[q] = (-pu[q][u]) * lr[u] + mine[q];
+          A[(c + q) * P + ln] = mine[q];
+        }
+      }
+      for (; c < n; ++c) {
+        double m1 = A[c * P + ln];
+#pragma unroll
+        for (int u = 0; u < PW; ++u)
+          if (k0 + u < k1 && (elim_mask & (1u << u))) m1 = (-A[c * P + k0 + u]) * lr[u] + m1;
+        A[c * P + ln] = m1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Solve with the factors above: on entry thread t holds component t of the right-hand side, on return unknown t.  xch: T doubles of LDS.  Returns false when a
 // pivot is zero (the factorisation recorded it), like wave_lu_solve_rows.  Per element: the column-oriented substitutions of lu_solve_reg / the oracle.
 template <int W>
 __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int P, int n, int ln, bool rowlive, const int* __restrict__ perm, double* __restrict__ xch,
                                               bool singular, double& v) {
   const int wave = ln >> 6;
+  constexpr int SC = 8;  // steps whose factors are read ahead of the dependent chain (32 for the factors in global scratch measured no gain: 3.74 against 3.61 s at n = 300)
   __syncthreads();
   xch[ln] = v;
   __syncthreads();
@@ -123,12 +230,12 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
     const int k0 = 64 * B;
     if (k0 < n) {
       if (wave == B) {
-        for (int kk0 = 0; kk0 < 64; kk0 += 8) {  // the factors of eight steps are read ahead of the chain (they do not depend on it)
-          double a8[8];
+        for (int kk0 = 0; kk0 < 64; kk0 += SC) {  // the factors of SC steps are read ahead of the chain (they do not depend on it)
+          double a8[SC];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int k = k0 + kk0 + u; a8[u] = (k + 1 < n && rowlive && ln > k) ? A[k * P + ln] : 0.0; }
+          for (int u = 0; u < SC; ++u) { const int k = k0 + kk0 + u; a8[u] = (k + 1 < n && rowlive && ln > k) ? A[k * P + ln] : 0.0; }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < SC; ++u) {
             const int k = k0 + kk0 + u;
             if (k + 1 < n) {
               const double coeff = group_bcast<64>(v, kk0 + u);
@@ -142,12 +249,12 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
         if (wave == B) xch[ln] = v;
         __syncthreads();
         if (wave > B && rowlive)
-          for (int kb = k0; kb < k0 + 64; kb += 8) {
-            double x8[8], a8[8];
+          for (int kb = k0; kb < k0 + 64; kb += SC) {
+            double x8[SC], a8[SC];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { x8[u] = xch[kb + u]; a8[u] = A[(kb + u) * P + ln]; }
+            for (int u = 0; u < SC; ++u) { x8[u] = xch[kb + u]; a8[u] = A[(kb + u) * P + ln]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v = (-x8[u]) * a8[u] + v;
+            for (int u = 0; u < SC; ++u) v = (-x8[u]) * a8[u] + v;
           }
       }
     }
@@ -159,12 +266,12 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
     if (k0 < n) {
       const int k1 = n < k0 + 64 ? n : k0 + 64;
       if (wave == B) {
-        for (int kt = k1 - 1; kt >= k0; kt -= 8) {  // eight steps' diagonal and column entries read ahead of the chain
-          double d8[8], a8[8];
+        for (int kt = k1 - 1; kt >= k0; kt -= SC) {  // SC steps' diagonal and column entries read ahead of the chain
+          double d8[SC], a8[SC];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int k = kt - u; d8[u] = k >= k0 ? A[k * P + k] : 1.0; a8[u] = (k >= k0 && rowlive && ln < k) ? A[k * P + ln] : 0.0; }
+          for (int u = 0; u < SC; ++u) { const int k = kt - u; d8[u] = k >= k0 ? A[k * P + k] : 1.0; a8[u] = (k >= k0 && rowlive && ln < k) ? A[k * P + ln] : 0.0; }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < SC; ++u) {
             const int k = kt - u;
             if (k >= k0) {
               const double coeff = group_bcast<64>(v, k - k0) / d8[u];
@@ -180,12 +287,12 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
         __syncthreads();
         if (wave < B) {
           int k = k1 - 1;
-          for (; k - 7 >= k0; k -= 8) {
-            double x8[8], a8[8];
+          for (; k - (SC - 1) >= k0; k -= SC) {
+            double x8[SC], a8[SC];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { x8[u] = xch[k - u]; a8[u] = A[(k - u) * P + ln]; }
+            for (int u = 0; u < SC; ++u) { x8[u] = xch[k - u]; a8[u] = A[(k - u) * P + ln]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v = (-x8[u]) * a8[u] + v;
+            for (int u = 0; u < SC; ++u) v = (-x8[u]) * a8[u] + v;
           }
           for (; k >= k0; --k) v = (-xch[k]) * A[k * P + ln] + v;
         }

@@ -14,7 +14,9 @@ else
   DSH_RESIDENT_LANE=0 DSH_LIB_DIR=$PWD/$d python - <<'PY'
 import numpy as np, time
 import diffsol_amd as H
-for model, size, n, tol in (("robertson_ode", 40, 120, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 40)), ("gaussian_decay", 120, 120, dict(rtol=1e-6, atol=[1e-6]))):
+import os
+CASES = {"120": (("robertson_ode", 40, 120, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 40)), ("gaussian_decay", 120, 120, dict(rtol=1e-6, atol=[1e-6]))), "300": (("robertson_ode", 100, 300, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * 100)),)}
+for model, size, n, tol in CASES[os.environ.get("TEAM_PROF_N", "120")]:
     rng = np.random.default_rng(12345)
     nb = 256
     if model == "robertson_ode":
