@@ -118,7 +118,7 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
 //   2. U12: the pivot rows' entries in every later column take the panel's earlier pivots — thread j does column k1 + j by itself and writes the final entries back;
 //   3. the rows below the panel update every later column with all of the panel's pivots at once: the trailing matrix makes one round trip per PANEL.
 // (In LDS this form measured no gain — 0.349 against 0.351 s at n = 120 — and is not used there.)
-constexpr int kTeamPanel = 8;
+constexpr int kTeamPanel = 8;  // (16 measured 3.56 against 3.61 s at n = 300 and slower at n = 150)
 template <int W>
 __device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular) {
   constexpr int PW = kTeamPanel;
