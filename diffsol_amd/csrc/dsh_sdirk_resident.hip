@@ -95,8 +95,11 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
   DSH_REQUIRE(T.r.o.group == 1 || T.r.o.group == 64, "group must be 1 (per member) or 64 (wavefront lock-step)");
   {
     // per-member control: DSH_MEMBER_LANES = 32 | 16 | 8 puts that many members on a wavefront (measured in profiles/r05_member_lanes.md); 0 / unset: 64
-    static const int member_lanes_env = [] { const char* e = std::getenv("DSH_MEMBER_LANES"); const int v = e && *e ? std::atoi(e) : 0; return (v == 8 || v == 16 || v == 32) ? v : 0; }();
-    T.r.member_lanes = (T.r.o.group == 1 && !is_jit_model(model)) ? member_lanes_env : 0;
+    static const int member_lanes_env = [] { const char* e = std::getenv("DSH_MEMBER_LANES"); const int v = e && *e ? std::atoi(e) : -1; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : -1; }();
+    // default: 32 members per wavefront while that still leaves at most two wavefronts per SIMD (the kernel's register occupancy) on the chip's 1024 SIMDs — the wavefront
+    // pays for the union of 32 paths instead of 64 (config 5, 65 536 members: 21.1 -> 19.9 ms, same bits) —, 64 beyond (more wavefronts would queue)
+    const int auto_lanes = (nb > 64 && (nb + 31) / 32 <= 2 * 4 * (int64_t)ctx->num_cu) ? 32 : 0;
+    T.r.member_lanes = (T.r.o.group == 1 && !is_jit_model(model)) ? (member_lanes_env > 0 ? (member_lanes_env == 64 ? 0 : member_lanes_env) : auto_lanes) : 0;
   }
   T.r.eta_reset = std::pow(20.0, 1.25);
   T.r.eta_reset_ts = std::pow(100.0, 1.25);
