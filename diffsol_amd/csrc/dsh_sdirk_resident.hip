@@ -98,7 +98,10 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
     static const int member_lanes_env = [] { const char* e = std::getenv("DSH_MEMBER_LANES"); const int v = e && *e ? std::atoi(e) : -1; return (v == 8 || v == 16 || v == 32 || v == 64) ? v : -1; }();
     // default: 32 members per wavefront while that still leaves at most two wavefronts per SIMD (the kernel's register occupancy) on the chip's 1024 SIMDs — the wavefront
     // pays for the union of 32 paths instead of 64 (config 5, 65 536 members: 21.1 -> 19.9 ms, same bits) —, 64 beyond (more wavefronts would queue)
-    const int auto_lanes = (nb > 64 && (nb + 31) / 32 <= 2 * 4 * (int64_t)ctx->num_cu) ? 32 : 0;
+    // (measured, RLC / ESDIRK34 with events, ms at 64 | 32 members per wavefront: 16 384 members 21.4 | 22.7, 32 768: 20.8 | 19.7, 49 152: 21.0 | 19.8, 65 536: 20.8 | 19.7 —
+    // the kernel lasts as long as its slowest member's chain whatever the ensemble size; the halved wavefronts pay from half a wavefront per SIMD on)
+    const int64_t simds = 4 * (int64_t)ctx->num_cu;
+    const int auto_lanes = ((nb + 63) / 64 * 2 >= simds && (nb + 31) / 32 <= 2 * simds) ? 32 : 0;
     T.r.member_lanes = (T.r.o.group == 1 && !is_jit_model(model)) ? (member_lanes_env > 0 ? (member_lanes_env == 64 ? 0 : member_lanes_env) : auto_lanes) : 0;
   }
   T.r.eta_reset = std::pow(20.0, 1.25);

@@ -18,10 +18,10 @@ from bench import rlc_params, robertson_params, T_EVAL, RTOL, ATOL
 ml = os.environ.get("DSH_MEMBER_LANES", "64")
 for name in (sys.argv[1:] or ["c5", "c2"]):
     if name == "c5":
-        nb, t_eval = 65536, np.linspace(0.1, 1.0, 10)
+        nb, t_eval = int(os.environ.get("C5_NB", "65536")), np.linspace(0.1, 1.0, 10)
         s = H.Solver("rlc", rlc_params(nb, 0.03), nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34)
     else:
-        nb, t_eval = 100000, np.asarray(T_EVAL)
+        nb, t_eval = int(os.environ.get("C2_NB", "100000")), np.asarray(T_EVAL)
         s = H.Solver("robertson_ode", robertson_params(nb), nbatch=nb, model_size=1, rtol=RTOL, atol=ATOL)
     out = torch.full((len(t_eval), s.n, nb), float("nan"), dtype=torch.float64, device="cuda:0")
     s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=out.data_ptr(), group=1)
