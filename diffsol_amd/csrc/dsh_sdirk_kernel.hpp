@@ -21,6 +21,10 @@ struct SdirkConsts {
   double* sens_out;                    // n_eval x NP x N x nb
   double sens_rtol, sens_atol[4];
   int sens_error_control, sens_pad;
+  // OdeSolverMethod::solve (method.rs:227-258 over :881-961), as in AdaptiveConsts: steps_cap > 0 makes the launch write the state after EVERY accepted step
+  // (y_out [steps_cap][N][nb], steps_t_out [steps_cap][nb]; columns beyond steps_cap are counted, not stored) instead of interpolating at save points
+  double* steps_t_out;
+  int steps_cap, steps_pad;
 };
 
 // the run-time-compiled banded form (state in per-lane memory) is built for a fixed occupancy like the BDF kernel (dsh_jit.hip defines the macro)
@@ -250,6 +254,16 @@ DSH_UNROLL_N
   int col = 0;
   double t_root = 0.0;
   int root_idx = -1;
+  const bool steps_mode = !SENS && T.steps_cap > 0;  // every accepted step out (SdirkConsts::steps_cap)
+  auto steps_write = [&](double tw, const double (&yw)[N]) __attribute__((always_inline)) {
+    if (col < T.steps_cap && active) {
+      T.steps_t_out[(int64_t)col * nb + b] = tw;
+DSH_UNROLL_N
+      for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = yw[i];
+    }
+    col++;
+  };
+  if (steps_mode && status == kRsOk) steps_write(t, y);  // write_out before the first step (method.rs:900)
   {  // set_stop_time (runge_kutta.rs:436-447); t_eval[0] >= t0 is checked on the host
     const int r = handle_tstop();
     if (r == 1 && status == kRsOk) status = kRsStopTimeAtCurrentTime;
@@ -527,6 +541,9 @@ DSH_UNROLL_N
     }
     // ================================================================ solve_dense (method.rs:467-520)
     const double upto = reason == 3 ? t_root : t;
+    if (steps_mode) {  // InternalTimestep / TstopReached -> write_out (method.rs:907-921): state.y; a root is written below, at the root
+      if (reason != 3) steps_write(t, y);
+    } else
     while (col < C.n_eval && t_eval[col] <= upto) {
       double yv[N];
       interpolate(t_eval[col], yv);
@@ -641,6 +658,7 @@ DSH_UNROLL_N
           if (!group_all<WAVE>(set_consistent<Mdl, WAVE>(t, p, y, dy, atol, rtol, C, true))) { status = kRsInitialConditionDidNotConverge; break; }
         } else
         Mdl::rhs(t, y, p, dy);
+        if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {
           has_tstop = true;
           { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
@@ -651,6 +669,12 @@ DSH_UNROLL_N
         reason = 0;
       }
     }
+    if (reason == 3 && steps_mode) {  // method.rs:922-947 without a reset: state_mut_back(t_root), write_out, RootFound
+      double yv[N];
+      interpolate(t_root, yv);
+      steps_write(t_root, yv);
+      done = true;
+    } else
     if (reason == 3) {  // state_mut_back(root_time); the column after the drained ones holds the state at the root
       if (col < C.n_eval) {
         double yv[N];
@@ -665,6 +689,7 @@ DSH_UNROLL_N
   }
   if (active) {
     if (ncols_out != nullptr) ncols_out[b] = col;
+    if (!steps_mode)
     for (; col < C.n_eval; ++col) {  // columns that were never reached (root stop or error exit): NaN
 DSH_UNROLL_N
       for (int i = 0; i < N; ++i) y_out[((int64_t)col * N + i) * nb + b] = __builtin_nan("");

@@ -45,13 +45,15 @@ int dsh_model_has_resident(int method, int model, int64_t size) {
 }  // extern "C"
 namespace {
 struct SdirkSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
+struct SdirkStepsSpec { double* t_out; int64_t cap; };  // OdeSolverMethod::solve: every accepted step out (SdirkConsts::steps_cap)
 template <class Mdl> constexpr bool sdirk_sens_ok() {
   if constexpr (model_has_sens<Mdl>::value) return Mdl::N <= 4 && !Mdl::HAS_MASS && Mdl::NROOTS == 0 && model_band_k<Mdl>::value == 0;
   else return false;
 }
 int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                               double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens);
+                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens,
+                              const SdirkStepsSpec* steps = nullptr);
 }  // namespace
 extern "C" {
 int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
@@ -59,6 +61,15 @@ int dsh_sdirk_solve_resident(dsh_ctx* ctx, int method, int model, int64_t size, 
                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
   return sdirk_solve_resident_impl(ctx, method, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols,
                                    totals_host, nullptr);
+}
+// OdeSolverMethod::solve (method.rs:227-258 over :881-961) inside the launch of the device-resident TR-BDF2 / ESDIRK34: the state after every accepted step of every member
+// (arguments as dsh_bdf_solve_adaptive_steps; the models of dsh_model_has_resident(method, ..))
+int dsh_sdirk_solve_resident_steps(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                   double t0, double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                   int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_sdirk_solve_resident_steps: max_cols >= 2, y_out, t_out and ncols are needed");
+  const SdirkStepsSpec st{t_out, max_cols};
+  return sdirk_solve_resident_impl(ctx, method, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
 }
 // TR-BDF2 / ESDIRK34 with forward sensitivities in the same launch (dsh_bdf_solve_adaptive_sens is the BDF): the same models (dsh_model_has_adaptive_sens)
 int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
@@ -78,7 +89,8 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
 namespace {
 int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                               double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens) {
+                              int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const SdirkSensSpec* sens,
+                              const SdirkStepsSpec* steps) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(method == 1 || method == 2, "method must be 1 (TR-BDF2) or 2 (ESDIRK34)");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
@@ -108,6 +120,7 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
   T.r.eta_reset_ts = std::pow(100.0, 1.25);
   T.r.ls_steptol = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   fill_tableau(method, T);
+  if (steps) { T.steps_t_out = steps->t_out; T.steps_cap = (int)steps->cap; }
   if (sens) {
     T.sens_out = sens->out; T.sens_rtol = sens->rtol; T.sens_error_control = sens->natol > 0 ? 1 : 0;
     int64_t ns = 0, npar_ = 0, nroots_ = 0; int hm_ = 0;

@@ -495,6 +495,10 @@ int dsh_sdirk_solve_resident_sens(dsh_ctx* ctx, int method, int model, int64_t s
  * dsh_sdirk_solve_wave_member: the same for TR-BDF2 (method 1) / ESDIRK34 (method 2) — Sdirk::step (sdirk.rs:409-543) over Rk (runge_kutta.rs:466-960),
  * the same models (dsh_model_has_wave_member_sdirk: 1 a wavefront per member, 2 a workgroup per member — 64 < n <= 320, identity mass), DAEs included.
  * Arguments and outputs as dsh_sdirk_solve_resident (opts->group is ignored: control is always per member). */
+/* the same for the device-resident TR-BDF2 (method 1) / ESDIRK34 (method 2): every accepted step of every member out (the models of dsh_model_has_resident) */
+int dsh_sdirk_solve_resident_steps(dsh_ctx* ctx, int method, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                   double t0, double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
+                                   int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 int dsh_model_has_wave_member(int model, int64_t size);
 /* OdeSolverMethod::solve (method.rs:227-258) inside the launch of the wavefront- / workgroup-per-member BDF: every accepted step of every member out (arguments as
  * dsh_bdf_solve_adaptive_steps; the models of dsh_model_has_wave_member, n <= 320) */

@@ -21,8 +21,10 @@ def det_pow(O):
     O.set_det_pow(False)
 
 
-def reference_solve(O, model, p, t_final, **kw):
+def reference_solve(O, model, p, t_final, method=None, **kw):
     """method.rs:881-961 for a batch (p: [nbatch, np]) without a reset operator: (times, states [ncols, nbatch, n], root (t, idx) or None)"""
+    if method is not None:
+        kw = dict(kw, method=method)
     s = O.OracleSolver(model, p, nbatch=p.shape[0], **kw)
     st = s.state()
     ts, ys = [st["t"]], [st["y"].copy()]
@@ -161,8 +163,44 @@ def test_wavefront_and_workgroup_per_member_forms_return_every_accepted_step(H, 
         assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
 
 
+@pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
+@pytest.mark.parametrize("case", ["robertson", "logistic_root", "heat20"])
+def test_resident_sdirk_kernels_return_every_accepted_step(H, O, det_pow, method, case):
+    """OdeSolverMethod::solve for TR-BDF2 / ESDIRK34 inside the launch of k_sdirk_resident (register-resident models, and the banded lane-per-member form of heat1d):
+    times and states of every accepted step equal the reference's loop over the oracle's stepping solver; an event ends a member's columns at its root."""
+    from helpers import ORACLE_MODEL
+    hm = {"tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    rng = np.random.default_rng(len(case) + len(method))
+    nb = 70
+    if case == "robertson":
+        p, t_final, kw, hmodel, omodel, size = robertson_p(rng, nb), 40.0, dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6]), "robertson_ode", O.MODEL_ROBERTSON_ODE, 1
+    elif case == "heat20":
+        p, t_final, kw, hmodel, omodel, size = rng.uniform(0.6, 1.4, (nb, 1)), 0.05, dict(rtol=1e-6, atol=[1e-6]), "heat1d", ORACLE_MODEL["heat1d"], 20
+    else:
+        from diffsol_amd import diffsl as fe
+        import diffsl_models as D
+        LOGISTIC = "in = [r, k]\nr { 1 }\nk { 1 }\nu_i { y = 0.1 }\nF_i { (r * y) * (1 - (y / k)) }\nstop_i { y - 0.5 * k }\n"
+        p, t_final, kw, size = np.stack([rng.uniform(0.5, 2.0, nb), rng.uniform(0.8, 1.2, nb)], axis=1), 50.0, dict(rtol=1e-6, atol=[1e-8]), 0
+        hmodel, omodel = fe.DiffslModel(LOGISTIC), D.host_model(O, LOGISTIC)
+    skw = dict(kw) if size == 0 else dict(kw, model_size=size)
+    s = H.Solver(hmodel, p, nbatch=nb, method=hm, **skw)
+    y, t, m, tot = s.solve_adaptive(t_final, max_cols=500, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all() and (m["ncols"] <= 500).all()
+    for b in list(range(0, nb, 17)) + [nb - 1]:
+        ts, ys, root = reference_solve(O, omodel, p[b:b + 1], t_final, method=om, **skw)
+        nc = m["ncols"][b]
+        assert nc == len(ts), (b, nc, len(ts))
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+        assert (root is None) == (m["root_idx"][b] < 0)
+        if root is not None:
+            assert m["t_root"][b] == root[0] == t[nc - 1, b]
+    if case == "logistic_root":
+        assert (m["root_idx"] == 0).all()
+
+
 def test_forms_without_a_step_writing_kernel_refuse(H):
     rng = np.random.default_rng(1)
-    s = H.Solver("heat1d", rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, model_size=20, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)  # the SDIRK kernels write save points only
-    with pytest.raises(Exception, match="BDF"):
+    s = H.Solver("gaussian_decay", rng.uniform(0.5, 2.0, (8, 30)), nbatch=8, model_size=30, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)  # dense n = 30: the wavefront-per-member TR-BDF2 writes save points only
+    with pytest.raises(Exception, match="writes every step"):
         s.solve_adaptive(0.1, max_cols=64)
