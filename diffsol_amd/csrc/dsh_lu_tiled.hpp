@@ -33,7 +33,12 @@ constexpr int kTlPW = 64;     // panel width
 constexpr int kTlLC = 16;     // columns of multipliers kept in LDS at a time (a sub-panel is flushed to W in two halves)
 constexpr int kTlL11P = 49;   // pitch of the staged L11 (rows 16..63, columns 0..47: the blocks below the diagonal blocks)
 constexpr int kTlMaxN = 1024;
-inline int tiled_ldw(int64_t n) { return (int)((n + 63) / 64 * 64); }  // pitch of the row-major working copy
+constexpr int kTlL21P = 66;   // pitch of the staged L21 chunk [64][kTlL21P] of the column-dealt trailing phase (operand reads free of bank conflicts)
+// pitch of the row-major working copy.  DSH_TL_LDW_PAD (doubles, a multiple of 16) adds to it: experiment on memory-channel conflicts of a 4 KB pitch
+inline int tiled_ldw(int64_t n) {
+  static const int pad = [] { const char* e = getenv("DSH_TL_LDW_PAD"); return e ? atoi(e) & ~15 : 0; }();
+  return (int)((n + 63) / 64 * 64) + pad;
+}
 typedef double tl_d4 __attribute__((ext_vector_type(4)));
 typedef double tl_d2 __attribute__((ext_vector_type(2)));
 // The panel and the trailing phase are functions of their own (register allocation); their pointer arguments would be generic, and a FLAT store counts
@@ -209,21 +214,27 @@ namespace dsh { namespace tl_one {
 #include "dsh_lu_tiled_impl.hpp"
 } }
 #undef DSH_TL_LAYOUT8
+#undef DSH_TL_COLS
+#undef DSH_TL_FUSED_STAGE
 // two workgroups of four wavefronts per CU, 16-column sub-panels (n <= 512)
 #define DSH_TL_LAYOUT8 1
 namespace dsh { namespace tl_two {
 #include "dsh_lu_tiled_impl.hpp"
 } }
 #undef DSH_TL_LAYOUT8
+#undef DSH_TL_COLS
+#undef DSH_TL_FUSED_STAGE
 
 namespace dsh {
-// Which layout factors a system of n rows: two workgroups per CU pay while the trailing update is the smaller part of the work (measured on 4096 systems,
-// profiles/r04_lu_bench.md: n = 320 9.9 against 11.7 ms, n = 384 14.9 against 15.8, n = 448 20.9 against 20.1, n = 512 29.8 against 27.1).  DSH_LU_TILED_LAYOUT=1|2 forces one.
+// Which layout factors a system of n rows.  Round 4: two workgroups per CU paid only while the trailing update was the smaller part of the work (n <= 416) — their 80 KB of
+// LDS held a U12 chunk of 64 columns.  Round 5: the two-workgroup layout runs the column-dealt trailing phase (no U12 in LDS), stages its later sub-panels without the round
+// trip through W and wins up to its limit of 512 rows (4096 systems, profiles/r05_lu_bench.md: n = 320 8.0 against 10.7 ms, n = 512 20.6 against 26.3).
+// DSH_LU_TILED_LAYOUT=1|2 forces one.
 inline int tiled_layout(int64_t n) {
   if (n > 512) return 1;
   static const int forced = [] { const char* e = getenv("DSH_LU_TILED_LAYOUT"); return e ? atoi(e) : 0; }();
   if (forced == 1 || forced == 2) return forced;
-  return n <= 416 ? 2 : 1;
+  return 2;
 }
 inline int tiled_threads(int64_t n) { return n > 512 ? tl_one::tiled_threads(n) : (tiled_layout(n) == 2 ? tl_two::tiled_threads(n) : tl_one::tiled_threads(n)); }
 inline size_t tiled_lds_bytes(int64_t n) { return n > 512 ? tl_one::tiled_lds_bytes(n) : (tiled_layout(n) == 2 ? tl_two::tiled_lds_bytes(n) : tl_one::tiled_lds_bytes(n)); }

@@ -14,6 +14,31 @@
 #define DSH_TL_RT8 3
 #define DSH_TL_PF8 2
 #endif
+// Trailing phase: DSH_TL_COLS = 1 deals the COLUMNS to the wavefronts (tl_trailing_cols: no U12 chunk in LDS, so it does not care that a workgroup of the two-per-CU
+// layout has 80 KB), 0 keeps the chunked form (tl_trailing).  Measured (profiles/r05_lu_bench.md): the column form makes the two-workgroup layout the faster one at
+// n = 512 (25.4 against 27.4 ms for 4096 systems) and loses 4 % in the one-workgroup layout, so each layout gets its own.  DSH_TL_CT: column tiles per wavefront
+// (4 spills: 16 doubles of U12 per tile stay in registers next to the operands one row tile ahead).
+// DSH_TL_FUSED_STAGE: the later sub-panels of a panel take the earlier ones' eliminations on the way into the stage instead of through W (tl_panel).  Pays in the
+// two-workgroup layout (four sub-panels of 16: 24.1 -> 23.3 ms at 512 x 4096), costs with 16 row slots per lane (962 x 256: 8.6 -> 9.0 ms): per layout.
+#ifndef DSH_TL_STAGE_TU
+#define DSH_TL_STAGE_TU 1
+#endif
+#ifdef DSH_TL_FUSED_STAGE_FORCE
+#define DSH_TL_FUSED_STAGE DSH_TL_FUSED_STAGE_FORCE
+#else
+#define DSH_TL_FUSED_STAGE DSH_TL_LAYOUT8
+#endif
+#ifndef DSH_TL_FINISH_T
+#define DSH_TL_FINISH_T 1
+#endif
+#ifndef DSH_TL_CT
+#define DSH_TL_CT 3
+#endif
+#ifdef DSH_TL_COLS_FORCE
+#define DSH_TL_COLS DSH_TL_COLS_FORCE
+#else
+#define DSH_TL_COLS DSH_TL_LAYOUT8
+#endif
 #ifndef DSH_TL_RT16
 #define DSH_TL_RT16 3
 #define DSH_TL_PF16 2
@@ -27,6 +52,7 @@ template <> struct tl_cfg<8> {
   static constexpr int kCH = DSH_TL_LAYOUT8 ? 64 : 208;      // columns per chunk (tiles of 16; U12 is one tile per wavefront at a time)
   static constexpr int kRT = DSH_TL_RT8;                     // row tiles per wavefront whose L21 operand stays in registers
   static constexpr int kPF = DSH_TL_PF8;                     // column tiles of C in flight ahead of the one being multiplied
+  static constexpr int kCT = DSH_TL_CT;                      // column tiles per wavefront of the column-dealt trailing phase
 };
 template <> struct tl_cfg<16> {
   static constexpr int kWaves = 8;
@@ -36,6 +62,7 @@ template <> struct tl_cfg<16> {
   static constexpr int kCH = 208;      // 13 tiles of 16
   static constexpr int kRT = DSH_TL_RT16;
   static constexpr int kPF = DSH_TL_PF16;
+  static constexpr int kCT = DSH_TL_CT;
 };
 inline int tiled_threads(int64_t n) { return 64 * (n <= 512 ? tl_cfg<8>::kWaves : tl_cfg<16>::kWaves); }
 // dynamic LDS (doubles): [0, 16 P) Lbuf during the pivot steps (P = 64 RS rows) / the operands of the matrix-core phases otherwise (panel: L11A, U'; trailing:
@@ -304,6 +331,146 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
     const int cb = jb + SW * sp;
     const int ws = (n - cb) < SW ? (n - cb) : SW;
     if (ws <= 0) break;
+#if DSH_TL_FUSED_STAGE
+    tl_col<RS> a[CPW];
+    // element (column c of the 16 in LDS, row) of the transposing stage T: the row index is permuted inside its aligned block of 32 by the column, so that the
+    // matrix-core layout (16 lanes = 16 columns of one row) and the two thread-per-row / column-per-wavefront layouts are all free of bank conflicts
+    auto tsw = [&](int c, int row) { return c * P + (row ^ (c << 1)); };
+    if (sp > 0) {
+      // ---- the columns cb..cb+SW-1 take the D = SW sp eliminations of the panel's earlier sub-panels on the matrix cores, ON THE WAY into the stage: U' = L11A^-1 B
+      // for the pivot rows (blocked substitution; EVERY wavefront solves it, so that U' is where the update wants its B operand: in the accumulators), then
+      // B - L_A U' of the rows still unfinished goes straight into T — no round trip of the sub-panel through W (rows finished since the panel began are not
+      // staged; the flush writes these columns of every staged row anyway).
+      const int D = SW * sp, nd = D / 16;
+      double* const la = dyn;         // [D][kTlLaP]
+      const int q = lane >> 4, j = lane & 15;
+      for (int idx = tid; idx < D * D; idx += NT) {
+        const int k = idx / D, i = idx - k * D;
+        if (i < (k & ~15)) la[k * kTlLaP + i] = W[(size_t)s_prow[k] * ldw + jb + i];
+      }
+      __syncthreads();
+      tl_d4 X[NCT][MAXD];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int c0 = 16 * ct;
+        tl_d4 B[MAXD];
+#pragma unroll
+        for (int rb = 0; rb < MAXD; ++rb)
+          if (rb < nd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j];
+          }
+#pragma unroll
+        for (int rb = 0; rb < MAXD; ++rb) {
+          if (rb < nd) {
+#pragma unroll
+            for (int cbk = 0; cbk < rb; ++cbk)
+#pragma unroll
+              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 * rb + j) * kTlLaP + 16 * cbk + 4 * kb + q], X[ct][cbk][kb], B[rb], 0, 0, 0);
+            tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(invd[rb * 272 + j * 17 + 4 * kb + q], B[rb][kb], acc, 0, 0, 0);
+            X[ct][rb] = acc;
+          } else {
+            X[ct][rb] = tl_d4{0.0, 0.0, 0.0, 0.0};
+          }
+        }
+      }
+      __syncthreads();  // L11A is dead: T lies over it; every wavefront has read the pivot rows' entries, one writes U' over them
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        if (wave == ct % NW) {
+#pragma unroll
+          for (int rb = 0; rb < MAXD; ++rb)
+            if (rb < nd) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + 16 * ct + j] = X[ct][rb][r];
+            }
+        }
+      mark(4);
+      const int nrt = (m_in + 15) / 16;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {  // finished rows and rows beyond n enter as zeros
+          const int row = tid + NT * i;
+          if (!(row < n && s_pos[row] >= cb)) {
+#pragma unroll
+            for (int c = 0; c < HC; ++c) dyn[tsw(c, row)] = 0.0;
+          }
+        }
+        // the row tiles dealt to the wavefronts, TU of them at a time: their loads are all in flight before the first is multiplied
+        constexpr int TU = DSH_TL_STAGE_TU;
+        for (int tile0 = wave; tile0 < nrt; tile0 += NW * TU) {
+          double aneg[TU][4 * MAXD];
+          tl_d4 acc[TU];
+          int rows[TU][4];
+          unsigned ok[TU];
+#pragma unroll
+          for (int u = 0; u < TU; ++u) {
+            const int tile = tile0 + NW * u;
+            ok[u] = 0;
+            if (tile < nrt) {
+              const size_t arow = (size_t)s_rowlist[16 * tile + j] * ldw;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                rows[u][r] = s_rowlist[16 * tile + 4 * r + q];
+                acc[u][r] = W[(size_t)rows[u][r] * ldw + cb + 16 * h + j];
+                if (16 * tile + 4 * r + q < m_in && s_pos[rows[u][r]] >= cb) ok[u] |= 1u << r;
+              }
+#pragma unroll
+              for (int kb = 0; kb < 4 * MAXD; ++kb) aneg[u][kb] = kb < 4 * nd ? -W[arow + jb + 4 * kb + q] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int kb = 0; kb < 4 * MAXD; ++kb)
+            if (kb < 4 * nd) {
+#pragma unroll
+              for (int u = 0; u < TU; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(aneg[u][kb], X[h][kb >> 2][kb & 3], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+          for (int u = 0; u < TU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (ok[u] & (1u << r)) dyn[tsw(j, rows[u][r])] = acc[u][r];
+        }
+        __syncthreads();
+        mark(9);
+#pragma unroll
+        for (int jj = 0; jj < CPW / NH; ++jj)
+#pragma unroll
+          for (int s = 0; s < RS; ++s) a[(CPW / NH) * h + jj][s] = dyn[tsw(wave + NW * jj, lane + 64 * s)];
+        __syncthreads();
+        mark(10);
+      }
+    } else {
+      mark(4);
+      // ---- stage of the panel's first sub-panel: thread per row in, column per wavefront out
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {  // HC columns of one row at a time (registers); finished rows and rows beyond n enter as zeros
+          const int row = tid + NT * i;
+          const bool live = row < n && s_pos[row] >= cb;
+          double b[HC];
+          if (live) {
+            const tl_gd2* src = reinterpret_cast<const tl_gd2*>(W + (size_t)row * ldw + cb + HC * h);
+#pragma unroll
+            for (int c = 0; c < HC; c += 2) { const tl_d2 v = src[c >> 1]; b[c] = v[0]; b[c + 1] = v[1]; }
+          }
+#pragma unroll
+          for (int c = 0; c < HC; ++c) dyn[tsw(c, row)] = live ? b[c] : 0.0;
+        }
+        __syncthreads();
+        mark(9);
+#pragma unroll
+        for (int jj = 0; jj < CPW / NH; ++jj)
+#pragma unroll
+          for (int s = 0; s < RS; ++s) a[(CPW / NH) * h + jj][s] = dyn[tsw(wave + NW * jj, lane + 64 * s)];
+        __syncthreads();
+        mark(10);
+      }
+    }
+#else
     if (sp > 0) {
       // ---- the columns cb..cb+SW-1 take the D = SW sp eliminations of the panel's earlier sub-panels, on the matrix cores (LDS broadcast reads made the
       // vector form of this 50 us per panel): the blocks of L11A below its diagonal blocks to LDS (the inverses of the diagonal blocks are there since
@@ -402,6 +569,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
         mark(10);
       }
     }
+#endif
     mark(5);
     // ---- the pivot steps
     const int pbase = SW * sp;
@@ -564,6 +732,184 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The trailing phase with the COLUMNS dealt to the wavefronts (round 5).  A wavefront takes CPW <= kCT adjacent column tiles: it computes their U12 by the
+// blocked substitution — the accumulators it ends up with ARE the B operands of the update (see dsh_lu_tiled.hpp) — keeps them in registers (16 doubles per
+// column tile), writes them to F, and then walks down the row tiles of the active rows: L21 operand of the row tile (16 doubles, straight from W: every
+// wavefront of the workgroup walks the same row tiles, so all but the first read hits the CU's cache), the C tiles, 16 matrix-core instructions per tile,
+// store.  No U12 chunk in LDS, no barrier inside the phase (the wavefronts' tiles are disjoint, what they read — pivot rows, the panel's columns — nobody
+// writes), and a wavefront's C accesses are CPW x 128 adjacent bytes of a row.  With fewer column groups than wavefronts the row tiles of a group are dealt to
+// several wavefronts (each repeats the group's U12: 40 instructions per tile; one writes F).
+template <int RS, int CPW>
+__device__ __forceinline__ void tl_colgroup(tl_gdouble* __restrict__ W, tl_gdouble* __restrict__ F, double* __restrict__ l21s, const double* __restrict__ l11,
+                                            const double* __restrict__ invd, const int* s_prow, const unsigned short* s_rowlist, int n, int ldw, int jb, int c_first, int rs,
+                                            int rsplit, int nrt, int m2, int wave, int lane, bool active) {
+  const int q = lane >> 4, j = lane & 15;
+  tl_gchar* const Wb = reinterpret_cast<tl_gchar*>(W);
+  tl_d4 X[CPW][4];
+  if (active) {
+    const double* const dinv_l = invd + j * 17 + q;
+    const double* const l11_l = l11 + j * kTlL11P + q;
+    unsigned prow_off[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) prow_off[e] = (unsigned)s_prow[4 * e + q] * (unsigned)ldw * 8u;  // rows 16 rb + 4 r + q, e = 4 rb + r
+#pragma unroll
+    for (int ct = 0; ct < CPW; ++ct) {
+      const int c0 = c_first + 16 * ct;
+      tl_d4 B[4];
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B[rb][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (prow_off[4 * rb + r] + (unsigned)(c0 + j) * 8u));
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int cbk = 0; cbk < rb; ++cbk) {
+          double lo[4];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) lo[kb] = -l11_l[16 * (rb - 1) * kTlL11P + 16 * cbk + 4 * kb];
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo[kb], X[ct][cbk][kb], B[rb], 0, 0, 0);
+        }
+        double di[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) di[kb] = dinv_l[rb * 272 + 4 * kb];
+        tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(di[kb], B[rb][kb], acc, 0, 0, 0);
+        X[ct][rb] = acc;
+      }
+      if (rs == 0 && c0 + j < n) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) F[(size_t)(c0 + j) * n + jb + 16 * rb + 4 * r + q] = X[ct][rb][r];
+      }
+    }
+  }
+  // ---- the update.  The L21 operand goes through LDS, 64 rows at a time: a row is read ONCE per workgroup as 512 adjacent bytes (wavefront w: rows w, w + NW, ...
+  // of the chunk; the next chunk's rows are in flight while this one is multiplied) and every wavefront takes its 16 x 4 operand pieces out of LDS.  Read per
+  // wavefront straight from W the same operand is 16 loads of 16 lines each per row tile — measured (DSH_TL_X_NOA): a fifth of the whole factorisation's time went
+  // into those line look-ups.  The C tiles of the next row tile are in flight while one is multiplied.
+  constexpr int NW = tl_cfg<RS>::kWaves, SR = 64 / NW, LP = kTlL21P;
+  const unsigned colb = (unsigned)(c_first + j) * 8u;
+  const int nchunk = (nrt + 3) / 4;
+  double st[SR];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < SR; ++i) {
+      int idx = 64 * chunk + wave + NW * i;
+      idx = idx < m2 ? idx : m2 - 1;
+      st[i] = -W[(size_t)s_rowlist[idx] * ldw + jb + lane];
+    }
+  };
+  tl_d4 c_cur[CPW], c_nxt[CPW];
+  unsigned ro_cur[4], ro_nxt[4];
+  unsigned v_cur = 0, v_nxt = 0;
+  auto fetch = [&](int tile) {
+    v_nxt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      ro_nxt[r] = (unsigned)s_rowlist[16 * tile + 4 * r + q] * (unsigned)ldw * 8u + colb;
+      if (16 * tile + 4 * r + q < m2) v_nxt |= 1u << r;
+    }
+#pragma unroll
+    for (int ct = 0; ct < CPW; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c_nxt[ct][r] = *reinterpret_cast<const tl_gdouble*>(Wb + (ro_nxt[r] + 128u * (unsigned)ct));
+  };
+  stage_load(0);
+  int tile = rs;
+  if (active && tile < nrt) fetch(tile);
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+#pragma unroll
+    for (int i = 0; i < SR; ++i) l21s[(wave + NW * i) * LP + lane] = st[i];
+    __syncthreads();
+    if (chunk + 1 < nchunk) stage_load(chunk + 1);
+    if (active) {
+      const int tend = 4 * chunk + 4 < nrt ? 4 * chunk + 4 : nrt;
+      for (; tile < tend; tile += rsplit) {
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct) c_cur[ct] = c_nxt[ct];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ro_cur[r] = ro_nxt[r];
+        v_cur = v_nxt;
+        if (tile + rsplit < nrt) fetch(tile + rsplit);
+        const double* const ap = l21s + (16 * (tile & 3) + j) * LP + q;
+        double a[16];
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) a[kb] = ap[4 * kb];
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+          for (int ct = 0; ct < CPW; ++ct) c_cur[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], X[ct][kb >> 2][kb & 3], c_cur[ct], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CPW; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (v_cur & (1u << r)) *reinterpret_cast<tl_gdouble*>(Wb + (ro_cur[r] + 128u * (unsigned)ct)) = c_cur[ct][r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RS>
+__device__ __noinline__ void tl_trailing_cols(double* __restrict__ W_generic_, double* __restrict__ F_generic_, double* dyn_, const int* s_prow_, const unsigned short* s_rowlist_,
+                                              unsigned long long* phase_clocks_, int n_, int ldw_, int jb_, int nct_, int m2_) {
+  using C = tl_cfg<RS>;
+  double* const W_generic = tl_uni(W_generic_);
+  double* const F_generic = tl_uni(F_generic_);
+  double* const dyn = tl_uni(dyn_);
+  const int* const s_prow = tl_uni(s_prow_);
+  const unsigned short* const s_rowlist = tl_uni(s_rowlist_);
+  unsigned long long* const phase_clocks = tl_uni(phase_clocks_);
+  const int n = tl_uni(n_), ldw = tl_uni(ldw_), jb = tl_uni(jb_), nct = tl_uni(nct_), m2 = tl_uni(m2_);
+  constexpr int NW = C::kWaves, CT = C::kCT;
+  tl_gdouble* const W = (tl_gdouble*)W_generic;
+  tl_gdouble* const F = (tl_gdouble*)F_generic;
+  const double* const l11 = dyn + 64 * C::kLDP;
+  const double* const invd = dyn + tl_invd<RS>();
+  const int tid = threadIdx.x, wave = tl_uni(tid >> 6), lane = tid & 63;
+  const bool prof = phase_clocks != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long tprev = prof ? wall_clock64() : 0ull;
+  const int nrt = (m2 + 15) / 16;
+  const int ntc = (nct - jb - kTlPW) / 16;
+  const int npass = (ntc + NW * CT - 1) / (NW * CT);
+  int t0 = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int tp = (ntc - t0 + (npass - pass) - 1) / (npass - pass);  // column tiles of this pass (<= NW CT)
+    // tiles per wavefront: the choice that leaves the busiest wavefront the least work (row tiles x column tiles + its U12)
+    int cpw = 1, best = 0x7fffffff;
+#pragma unroll
+    for (int c = 1; c <= CT; ++c) {
+      const int g = (tp + c - 1) / c;
+      if (g > NW) continue;
+      const int rsp = NW / g;
+      const int cost = ((nrt + rsp - 1) / rsp) * 2 * c + 5 * c;
+      if (cost <= best) { best = cost; cpw = c; }
+    }
+    const int ncg = (tp + cpw - 1) / cpw, rsplit = NW / ncg;
+    const int cg = wave % ncg, rs = wave / ncg;
+    const bool active = rs < rsplit;
+    const int tfirst = t0 + cg * cpw;
+    const int mine = !active ? 0 : ((tp - cg * cpw) < cpw ? (tp - cg * cpw) : cpw);
+    const int c_first = jb + kTlPW + 16 * tfirst;
+    // every wavefront takes part in the staging of L21 and its barriers, with or without columns of its own
+    switch (mine) {
+      case 0: tl_colgroup<RS, 1>(W, F, dyn, l11, invd, s_prow, s_rowlist, n, ldw, jb, c_first, rs, rsplit, nrt, m2, wave, lane, false); break;
+      case 1: tl_colgroup<RS, 1>(W, F, dyn, l11, invd, s_prow, s_rowlist, n, ldw, jb, c_first, rs, rsplit, nrt, m2, wave, lane, true); break;
+      case 2: tl_colgroup<RS, 2>(W, F, dyn, l11, invd, s_prow, s_rowlist, n, ldw, jb, c_first, rs, rsplit, nrt, m2, wave, lane, true); break;
+      case 3: tl_colgroup<RS, 3>(W, F, dyn, l11, invd, s_prow, s_rowlist, n, ldw, jb, c_first, rs, rsplit, nrt, m2, wave, lane, true); break;
+      default:
+        if constexpr (CT >= 4) tl_colgroup<RS, 4>(W, F, dyn, l11, invd, s_prow, s_rowlist, n, ldw, jb, c_first, rs, rsplit, nrt, m2, wave, lane, true);
+        break;
+    }
+    t0 += tp;
+  }
+  if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[3] += now - tprev; }
+}
+
 // RS = rows per lane of the panel's register layout: 8 for n <= 512 (two workgroups per CU), 16 for n <= 1024
 template <int RS>
 __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(int n, int ldw, double* __restrict__ w_all, double* __restrict__ f_all, int32_t* __restrict__ piv_all,
@@ -639,6 +985,33 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
         l11[(k - 16) * kTlL11P + i] = i < k ? W[(size_t)s_prow[k] * ldw + jb + i] : (i == k ? 1.0 : 0.0);
       }
     }
+#if DSH_TL_FINISH_T
+    // the finished rows' entries in the columns 0 .. jb + pw - 1 (their L part and U11) to F, 64 columns at a time through a [64][65] tile in LDS (the panel's
+    // buffers are dead, l11 and invd lie behind it): a row is read as 512 adjacent bytes and a column of F is written as 512 adjacent bytes — the direct form
+    // (a thread per column, 16 stores of one double each to 64 different lines per wavefront) was bound by the number of lines its stores touch
+    {
+      double* const tile = dyn;
+      constexpr int KPW = kTlPW / NW;  // rows / columns of a block per wavefront
+      for (int cb0 = 0; cb0 < jb + pw; cb0 += 64) {
+        const bool incol = cb0 + lane < jb + pw;
+        double v[KPW];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          const int k = wave + NW * i;
+          v[i] = (k < pw && incol) ? W[(size_t)s_prow[k] * ldw + cb0 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) tile[(wave + NW * i) * 65 + lane] = v[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+          const int cc = cb0 + wave + NW * i;
+          if (cc < jb + pw && lane < pw) F[(size_t)cc * n + jb + lane] = tile[lane * 65 + wave + NW * i];
+        }
+        __syncthreads();
+      }
+    }
+#else
     for (int c = tid; c < jb + pw; c += NT) {
       double* const dst = F + (size_t)c * n + jb;
       for (int k0 = 0; k0 < pw; k0 += 16) {
@@ -649,13 +1022,18 @@ __global__ __launch_bounds__(64 * tl_cfg<RS>::kWaves, 2) void k_lu_factor_tiled(
         for (int k = 0; k < 16; ++k) if (k0 + k < pw) dst[k0 + k] = v[k];
       }
     }
+#endif
     if (tid < pw) PIV[jb + tid] = s_ipiv[tid];
     __syncthreads();
     if (m2 > 0 && tid < 16) s_rowlist[m2 + tid] = s_rowlist[m2 - 1];  // padding of the last row tile: a valid row, never stored
     if (!trailing) { mark(1); continue; }
     __syncthreads();
     mark(1);
+#if DSH_TL_COLS
+    tl_trailing_cols<RS>(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
+#else
     tl_trailing<RS>(W, F, dyn, s_prow, s_rowlist, phase_clocks, n, ldw, jb, nct, m2);
+#endif
     if (prof) tprev = wall_clock64();
   }
   if (tid == 0 && s_flags[0] != 0) publish_singular(singular_word, 1ull, epoch);
