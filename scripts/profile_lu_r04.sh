@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 counters of the matrix-core dense LU (k_lu_factor_tiled, dsh_lu_tiled.hpp) at 512 x 4096 and 962 x 256: kernel trace + separate --pmc passes
+# Counters (rounds 4, 5: RND=r05) of the matrix-core dense LU (k_lu_factor_tiled, dsh_lu_tiled.hpp) at 512 x 4096 and 962 x 256: kernel trace + separate --pmc passes
 # (SQ wait / active split, instruction mix, FETCH_SIZE, WRITE_SIZE).  Run through gpurun from the repo root; outputs under gpurun_out/r04/lu_*.
 set -u
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r04
+OUT=$PWD/gpurun_out/${RND:-r04}
 mkdir -p $OUT
 for cfg in "512 4096" "962 256"; do
   set -- $cfg; N=$1; NB=$2; TAG=lu_${N}
