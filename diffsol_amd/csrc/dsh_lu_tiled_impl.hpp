@@ -740,6 +740,9 @@ __device__ __noinline__ void tl_trailing(double* __restrict__ W_generic_, double
 // store.  No U12 chunk in LDS, no barrier inside the phase (the wavefronts' tiles are disjoint, what they read — pivot rows, the panel's columns — nobody
 // writes), and a wavefront's C accesses are CPW x 128 adjacent bytes of a row.  With fewer column groups than wavefronts the row tiles of a group are dealt to
 // several wavefronts (each repeats the group's U12: 40 instructions per tile; one writes F).
+// Barrier for data that went through LDS only: __syncthreads() also waits for every global load and STORE in flight (vmcnt(0)) — in the trailing phase that drained
+// the C tiles' prefetch and made every chunk wait for the write latency of the tiles just stored.
+__device__ __forceinline__ void tl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int RS, int CPW>
 __device__ __forceinline__ void tl_colgroup(tl_gdouble* __restrict__ W, tl_gdouble* __restrict__ F, double* __restrict__ l21s, const double* __restrict__ l11,
                                             const double* __restrict__ invd, const int* s_prow, const unsigned short* s_rowlist, int n, int ldw, int jb, int c_first, int rs,
@@ -824,7 +827,7 @@ __device__ __forceinline__ void tl_colgroup(tl_gdouble* __restrict__ W, tl_gdoub
   for (int chunk = 0; chunk < nchunk; ++chunk) {
 #pragma unroll
     for (int i = 0; i < SR; ++i) l21s[(wave + NW * i) * LP + lane] = st[i];
-    __syncthreads();
+    tl_lds_barrier();
     if (chunk + 1 < nchunk) stage_load(chunk + 1);
     if (active) {
       const int tend = 4 * chunk + 4 < nrt ? 4 * chunk + 4 : nrt;
@@ -850,7 +853,7 @@ __device__ __forceinline__ void tl_colgroup(tl_gdouble* __restrict__ W, tl_gdoub
             if (v_cur & (1u << r)) *reinterpret_cast<tl_gdouble*>(Wb + (ro_cur[r] + 128u * (unsigned)ct)) = c_cur[ct][r];
       }
     }
-    __syncthreads();
+    tl_lds_barrier();
   }
 }
 
@@ -907,6 +910,7 @@ __device__ __noinline__ void tl_trailing_cols(double* __restrict__ W_generic_, d
     }
     t0 += tp;
   }
+  __syncthreads();  // the tiles stored above are read by other wavefronts from here on
   if (prof) { const unsigned long long now = wall_clock64(); phase_clocks[3] += now - tprev; }
 }
 
