@@ -324,7 +324,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
   constexpr int MAXD = (kTlPW - SW) / 16;  // diagonal blocks in front of the last sub-panel
   tl_gdouble* const W = (tl_gdouble*)W_generic;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* const Us = dyn + kTlUs;  // [<= 48][kTlUsP]: dead before the stage writes T over it
+  [[maybe_unused]] double* const Us = dyn + kTlUs;  // [<= 48][kTlUsP]: dead before the stage writes T over it (unused by the fused stage)
   const double* const invd = dyn + tl_invd<RS>();
 #pragma nounroll
   for (int sp = 0; sp < kTlPW / SW; ++sp) {
