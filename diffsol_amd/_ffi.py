@@ -178,6 +178,7 @@ DEVICE_ABI = {
     "dsh_bdf_solve_adaptive_steps": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, dbl, i64, vp, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_sdirk_solve_resident_steps": (cint, [vp, cint, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, dbl, i64, vp, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_wave_member_steps": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, dbl, i64, vp, vp, vp, vp, vp, vp, vp, c_i64p]),
+    "dsh_sdirk_solve_wave_member_steps": (cint, [vp, cint, i64, cint, i64, vp, vp, i64, dbl, dbl, dbl, vp, dbl, i64, vp, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_solve_adaptive": (cint, [vp, cint, i64, i64, vp, vp, i64, dbl, dbl, dbl, vp, c_dp, i64, vp, vp, vp, vp, vp, vp, c_i64p]),
     "dsh_bdf_prepare_step": (cint, [vp, i64, i64, cint, vp, vp, c_dp, c_dp, dbl, vp, vp]),
     "dsh_bdf_accept_newton_async": (cint, [vp, cint, i64, i64, cint, dbl, vp, vp, vp, vp, vp, vp, i64, dbl, c_dp, dbl, vp, dbl, dbl, cint, vp, vp, vp, c_i64p, c_i64p]),

@@ -722,6 +722,7 @@ DSH_UNROLL_N
 #if !defined(__HIPCC_RTC__)
 // Tableau::tr_bdf2 / esdirk34 (tableau.rs:41-160), column-major a (host side)
 inline void fill_tableau(int method, SdirkConsts& T) {
+  T.steps_t_out = nullptr; T.steps_cap = 0; T.steps_pad = 0;  // save points unless the caller asks for every step
   for (double& v : T.a) v = 0.0;
   for (double& v : T.beta) v = 0.0;
   if (method == 1) {

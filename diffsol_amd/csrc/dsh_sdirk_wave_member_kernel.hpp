@@ -307,6 +307,15 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
   int col = 0;
   double t_root = 0.0;
   int root_idx = -1;
+  const bool steps_mode = !SENS && T.steps_cap > 0;  // every accepted step out (SdirkConsts::steps_cap), as in k_sdirk_adaptive
+  auto steps_write = [&](double tw, double yv_mine) __attribute__((always_inline)) {
+    if (col < T.steps_cap) {
+      if (ln == 0) T.steps_t_out[(int64_t)col * nb + b] = tw;
+      if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv_mine;
+    }
+    col++;
+  };
+  if (steps_mode && status == kRsOk) steps_write(t, y);  // write_out before the first step (method.rs:900)
   {
     const int r = handle_tstop();
     if (r == 1 && status == kRsOk) status = kRsStopTimeAtCurrentTime;
@@ -585,6 +594,9 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
     }
     // ================================================================ solve_dense (method.rs:467-520)
     const double upto = reason == 3 ? t_root : t;
+    if (steps_mode) {  // InternalTimestep / TstopReached -> write_out (method.rs:907-921): state.y; a root is written below, at the root
+      if (reason != 3) steps_write(t, y);
+    } else
     while (col < C.n_eval && t_eval[col] <= upto) {
       const double yv = interpolate(t_eval[col]);
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv;
@@ -638,6 +650,7 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
         __syncthreads();
         y = rowlive ? wm_reset_component(t, (int64_t)ln, Xf, Pf) : 0.0;
         dy = rhs_of(y, t);
+        if (steps_mode) steps_write(t, y);  // method.rs:931-932: the reset state at the root time
         if (t < tstop) {
           has_tstop = true;
           { const int r = handle_tstop(); if (r == 1) { status = kRsStopTimeAtCurrentTime; break; } if (r == 2) { status = kRsStopTimeBeforeCurrentTime; break; } }
@@ -648,6 +661,10 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
         reason = 0;
       }
     }
+    if (reason == 3 && steps_mode) {  // method.rs:922-947 without a reset: state_mut_back(t_root), write_out, RootFound
+      steps_write(t_root, interpolate(t_root));
+      done = true;
+    } else
     if (reason == 3) {
       if (col < C.n_eval) {
         const double yv = interpolate(t_root);
@@ -659,6 +676,7 @@ __global__ __launch_bounds__(TW > 0 ? 64 * TW : 64) __attribute__((amdgpu_waves_
     if (reason == 1) done = true;
   }
   const int ncols = col;
+  if (!steps_mode)
   for (; col < C.n_eval; ++col) {
     if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = __builtin_nan("");
     if constexpr (SENS)

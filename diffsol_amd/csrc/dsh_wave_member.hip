@@ -218,7 +218,17 @@ int dsh_model_has_wave_member_sdirk(int model, int64_t size) { return dsh_model_
 
 static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                         double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens);
+                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens,
+                                        const WmStepsSpec* steps = nullptr);
+// OdeSolverMethod::solve (method.rs:227-258 over :881-961) inside the launch of the wavefront- / workgroup-per-member TR-BDF2 / ESDIRK34: the arguments of
+// dsh_bdf_solve_wave_member_steps plus the method
+int dsh_sdirk_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                      double t0, double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out,
+                                      int32_t* stats, int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_sdirk_solve_wave_member_steps: max_cols >= 2, y_out, t_out and ncols are needed");
+  const WmStepsSpec st{t_out, max_cols};
+  return sdirk_solve_wave_member_impl(ctx, model, size, method, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
+}
 int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                 double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                                 int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
@@ -240,7 +250,8 @@ int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int 
 }
 static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                         double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
-                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens) {
+                                        int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host, const WmSensSpec* sens,
+                                        const WmStepsSpec* steps) {
   DSH_REQUIRE(ctx != nullptr, "ctx is null");
   DSH_REQUIRE(method == 1 || method == 2, "method: 1 TR-BDF2, 2 ESDIRK34");
   DSH_REQUIRE(n_eval >= 1 && t_eval_host != nullptr, "t_eval must hold at least one time");
@@ -256,6 +267,7 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
   if (rc != DSH_OK) return rc;
   C.model = model; C.n = (int)n; C.np = (int)np; C.nroots = (int)nroots;
   fill_tableau(method, C.T);
+  if (steps) { C.T.steps_t_out = steps->t_out; C.T.steps_cap = (int)steps->cap; }
   C.T.sens_out = sens ? sens->out : nullptr; C.T.sens_rtol = sens ? sens->rtol : 0.0; C.T.sens_error_control = sens && sens->natol > 0 ? 1 : 0; C.T.sens_pad = 1;
   for (int q = 0; q < 4; ++q) C.T.sens_atol[q] = sens && sens->natol > 0 ? sens->atol_host[0] : 0.0;
   C.T.r.rtol = rtol; C.T.r.t0 = t0; C.T.r.h0 = h0; C.T.r.n_eval = (int)n_eval; C.T.r.member_lanes = 0;

@@ -743,8 +743,8 @@ int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int gr
     if (!y_host || !t_host || !ncols_host || max_cols < 2) throw LaError(DSH_E_INVALID, "dshs_solve_adaptive: y_host, t_host, ncols_host and max_cols >= 2 are needed");
     if (s->problem.sens) throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: without forward sensitivities (dshs_solve walks the host-driven path for the rest)");
     const ResidentPick pk = pick_resident(s, group);
-    const bool sdirk = s->method != DSHS_METHOD_BDF;  // TR-BDF2 / ESDIRK34: the lane-per-member kernels (register-resident and banded forms); the wavefront forms write save points only: BDF
-    if (!pk.ok || (sdirk && pk.wave_member) || (!sdirk && !pk.wave_member && !dsh_model_has_adaptive_steps(pk.model, pk.size)) || (pk.wave_member && s->problem.eqn->has_mass()))
+    const bool sdirk = s->method != DSHS_METHOD_BDF;  // TR-BDF2 / ESDIRK34
+    if (!pk.ok || (!sdirk && !pk.wave_member && !dsh_model_has_adaptive_steps(pk.model, pk.size)) || (pk.wave_member && s->problem.eqn->has_mass()))
       throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: no device-resident integrator that writes every step for this model and method (register-resident static models, banded lane-per-member forms, "
                                        "wavefront / workgroup per member without a mass matrix); dshs_solve returns every step of the host-driven lock-step solver");
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
@@ -763,6 +763,11 @@ int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int gr
     if (t_root_host) check(dsh_malloc(c, (int64_t)sizeof(double) * nb, 0, &troot_dev), "solve_adaptive t_root");
     if (root_idx_host) check(dsh_malloc(c, (int64_t)sizeof(int32_t) * nb, 0, &ridx_dev), "solve_adaptive root_idx");
     int64_t tot[6] = {0};
+    if (sdirk && pk.wave_member)
+      check(dsh_sdirk_solve_wave_member_steps(c, pk.model, pk.size, pk.method, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
+                                              t_final, max_cols, (double*)y_dev, (double*)t_dev, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,
+                                              (int32_t*)ncols_dev, tot), "dsh_sdirk_solve_wave_member_steps");
+    else
     if (sdirk)
       check(dsh_sdirk_solve_resident_steps(c, pk.method, pk.model, pk.size, nb, s->problem.eqn->params().ptr(), s->problem.atol.ptr(), 1, s->problem.rtol, s->problem.t0, s->problem.h0, &o,
                                            t_final, max_cols, (double*)y_dev, (double*)t_dev, (int32_t*)stats_dev, (int32_t*)status_dev, (double*)troot_dev, (int32_t*)ridx_dev,

@@ -505,6 +505,10 @@ int dsh_model_has_wave_member(int model, int64_t size);
 int dsh_bdf_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                     double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
                                     int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
+/* the same inside the wavefront- / workgroup-per-member TR-BDF2 (method 1) / ESDIRK34 (method 2) */
+int dsh_sdirk_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
+                                      double t0, double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out,
+                                      int32_t* stats, int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host);

@@ -164,6 +164,30 @@ def test_wavefront_and_workgroup_per_member_forms_return_every_accepted_step(H, 
 
 
 @pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
+@pytest.mark.parametrize("n", [30, 100, 200])
+def test_wavefront_and_workgroup_per_member_sdirk_return_every_accepted_step(H, O, det_pow, method, n):
+    """OdeSolverMethod::solve inside k_sdirk_wave_member (a wavefront per member for n <= 64, a workgroup per member beyond; n = 200 with the factors in global scratch)
+    for TR-BDF2 / ESDIRK34 (dsh_sdirk_solve_wave_member_steps): times and states of every accepted step equal the reference's loop over the oracle's stepping solver."""
+    from helpers import ORACLE_MODEL
+    hm = {"tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    rng = np.random.default_rng(n + len(method))
+    nb = 11
+    p = rng.uniform(0.5, 2.0, (nb, n))
+    tol = dict(rtol=1e-6, atol=[1e-6])
+    s = H.Solver("gaussian_decay", p, nbatch=nb, model_size=n, method=hm, **tol)
+    y, t, m, tot = s.solve_adaptive(1.5, max_cols=400, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all() and (m["ncols"] <= 400).all()
+    for b in (0, nb // 2, nb - 1):
+        ts, ys, root = reference_solve(O, ORACLE_MODEL["gaussian_decay"], p[b:b + 1], 1.5, model_size=n, method=om, **tol)
+        nc = m["ncols"][b]
+        assert nc == len(ts) and root is None
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+    _, tot_d = s.solve_dense_adaptive([1.5], group=1)
+    assert tot_d["number_of_steps"] == tot["number_of_steps"]
+
+
+@pytest.mark.parametrize("method", ["tr_bdf2", "esdirk34"])
 @pytest.mark.parametrize("case", ["robertson", "logistic_root", "heat20"])
 def test_resident_sdirk_kernels_return_every_accepted_step(H, O, det_pow, method, case):
     """OdeSolverMethod::solve for TR-BDF2 / ESDIRK34 inside the launch of k_sdirk_resident (register-resident models, and the banded lane-per-member form of heat1d):
@@ -200,7 +224,11 @@ def test_resident_sdirk_kernels_return_every_accepted_step(H, O, det_pow, method
 
 
 def test_forms_without_a_step_writing_kernel_refuse(H):
+    from diffsol_amd import diffsl as fe
+    # five decays and one algebraic sum (n = 6, a mass matrix, dense): served by the wavefront-per-member kernels, which write every step for identity-mass models only
+    DAE6 = ("in = [k]\nk { 1 }\nu_i { a = 1, b = 1, c = 1, d = 1, e = 1, z = 5 }\ndudt_i { da = 0, db = 0, dc = 0, dd = 0, de = 0, dz = 0 }\n"
+            "M_i { da, db, dc, dd, de, 0 }\nF_i { -k * a, -2 * k * b, -3 * k * c, -4 * k * d, -5 * k * e, z - (a + b + c + d + e) }\n")
     rng = np.random.default_rng(1)
-    s = H.Solver("gaussian_decay", rng.uniform(0.5, 2.0, (8, 30)), nbatch=8, model_size=30, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)  # dense n = 30: the wavefront-per-member TR-BDF2 writes save points only
+    s = H.Solver(fe.DiffslModel(DAE6), rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, rtol=1e-6, atol=[1e-8])
     with pytest.raises(Exception, match="writes every step"):
         s.solve_adaptive(0.1, max_cols=64)
