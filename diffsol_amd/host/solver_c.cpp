@@ -744,9 +744,9 @@ int dshs_solve_adaptive(dshs_solver* s, double t_final, int64_t max_cols, int gr
     if (s->problem.sens) throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: without forward sensitivities (dshs_solve walks the host-driven path for the rest)");
     const ResidentPick pk = pick_resident(s, group);
     const bool sdirk = s->method != DSHS_METHOD_BDF;  // TR-BDF2 / ESDIRK34
-    if (!pk.ok || (!sdirk && !pk.wave_member && !dsh_model_has_adaptive_steps(pk.model, pk.size)) || (pk.wave_member && s->problem.eqn->has_mass()))
+    if (!pk.ok || (!sdirk && !pk.wave_member && !dsh_model_has_adaptive_steps(pk.model, pk.size)))
       throw LaError(DSH_E_UNSUPPORTED, "dshs_solve_adaptive: no device-resident integrator that writes every step for this model and method (register-resident static models, banded lane-per-member forms, "
-                                       "wavefront / workgroup per member without a mass matrix); dshs_solve returns every step of the host-driven lock-step solver");
+                                       "wavefront / workgroup per member); dshs_solve returns every step of the host-driven lock-step solver");
     const int64_t n = s->problem.eqn->nstates(), nb = s->ctx.nbatch();
     const dsh_adaptive_options o = adaptive_options_of(s, group, deterministic_pow);
     dsh_ctx* c = s->ctx.raw();

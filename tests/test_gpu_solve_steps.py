@@ -223,12 +223,29 @@ def test_resident_sdirk_kernels_return_every_accepted_step(H, O, det_pow, method
         assert (m["root_idx"] == 0).all()
 
 
-def test_forms_without_a_step_writing_kernel_refuse(H):
+DAE6 = ("in = [k]\nk { 1 }\nu_i { a = 1, b = 1, c = 1, d = 1, e = 1, z = 5 }\ndudt_i { da = 0, db = 0, dc = 0, dd = 0, de = 0, dz = 0 }\n"
+        "M_i { da, db, dc, dd, de, 0 }\nF_i { -k * a, -2 * k * b, -3 * k * c, -4 * k * d, -5 * k * e, z - (a + b + c + d + e) }\n")
+
+
+@pytest.mark.parametrize("method", ["bdf", "tr_bdf2", "esdirk34"])
+def test_wavefront_per_member_dae_returns_every_accepted_step(H, O, det_pow, method):
+    """Five decays and one algebraic sum (n = 6, a mass matrix, dense: served by the wavefront-per-member kernels through the run-time-sized twin): every accepted step
+    equals the reference's loop over the oracle's stepping solver."""
     from diffsol_amd import diffsl as fe
-    # five decays and one algebraic sum (n = 6, a mass matrix, dense): served by the wavefront-per-member kernels, which write every step for identity-mass models only
-    DAE6 = ("in = [k]\nk { 1 }\nu_i { a = 1, b = 1, c = 1, d = 1, e = 1, z = 5 }\ndudt_i { da = 0, db = 0, dc = 0, dd = 0, de = 0, dz = 0 }\n"
-            "M_i { da, db, dc, dd, de, 0 }\nF_i { -k * a, -2 * k * b, -3 * k * c, -4 * k * d, -5 * k * e, z - (a + b + c + d + e) }\n")
-    rng = np.random.default_rng(1)
-    s = H.Solver(fe.DiffslModel(DAE6), rng.uniform(0.5, 2.0, (8, 1)), nbatch=8, rtol=1e-6, atol=[1e-8])
-    with pytest.raises(Exception, match="writes every step"):
-        s.solve_adaptive(0.1, max_cols=64)
+    import diffsl_models as D
+    hm = {"bdf": H.METHOD_BDF, "tr_bdf2": H.METHOD_TR_BDF2, "esdirk34": H.METHOD_ESDIRK34}[method]
+    om = {"bdf": None, "tr_bdf2": O.METHOD_TR_BDF2, "esdirk34": O.METHOD_ESDIRK34}[method]
+    rng = np.random.default_rng(3)
+    nb = 9
+    p = rng.uniform(0.5, 2.0, (nb, 1))
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    s = H.Solver(fe.DiffslModel(DAE6), p, nbatch=nb, method=hm, **tol)
+    y, t, m, tot = s.solve_adaptive(1.0, max_cols=400, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all()
+    mid = D.host_model(O, DAE6)
+    for b in (0, 4, nb - 1):
+        ts, ys, root = reference_solve(O, mid, p[b:b + 1], 1.0, method=om, **tol)
+        nc = m["ncols"][b]
+        assert nc == len(ts) and root is None
+        assert np.array_equal(t[:nc, b], ts) and np.array_equal(y[:nc, b], ys[:, 0]), f"member {b}"
+        assert np.max(np.abs(y[:nc, b, 5] - y[:nc, b, :5].sum(axis=1))) < 1e-4  # the algebraic row, to the tolerances
