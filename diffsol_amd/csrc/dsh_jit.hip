@@ -235,6 +235,7 @@ int compile_module(const JitModelRec& rec, const char* header, const std::vector
     if (!(nu && nu[0] == '0')) tu += "#define DSH_NOUNROLL_N 1\n";
     tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : "3") + "\n";  // k_bdf_lane_banded, same workload: 0.192 / 0.137 / 0.141 / 0.158 / 0.160 s at 2 / 3 / 4 / 6 / 8
     if (const char* un = std::getenv("DSH_LANE_BANDED_UNROLL")) if (*un) tu += std::string("#define DSH_LANE_BANDED_UNROLL ") + un + "\n";  // tuning knob
+    if (const char* cs = std::getenv("DSH_LANE_BANDED_CHUNK_SCALE")) if (*cs) tu += std::string("#define DSH_LANE_BANDED_CHUNK_SCALE ") + cs + "\n";  // tuning knob
     if (const char* pd = std::getenv("DSH_LANE_BANDED_PAD")) if (*pd) tu += std::string("#define DSH_LANE_BANDED_PAD ") + pd + "\n";  // tuning knob: extra doubles in the per-lane frame
     tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }

@@ -29,6 +29,8 @@ else:
     group = 1 if cfg == "c5_per_member" else 64
     t_eval = np.linspace(0.1, 1.0, 10)
     s = H.Solver("rlc", rlc_params(nb, 0.03 if group == 1 else 1e3), nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34)
+import time
 for _ in range(K):
+    t0 = time.perf_counter()
     _, tot = s.solve_dense_adaptive(t_eval, want_host=False, group=group)
-    print(cfg, nb, tot)
+    print(cfg, nb, "wall ms %.2f" % (1e3 * (time.perf_counter() - t0)), tot)
