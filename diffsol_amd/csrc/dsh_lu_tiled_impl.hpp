@@ -878,10 +878,15 @@ __device__ __noinline__ void tl_trailing_cols(double* __restrict__ W_generic_, d
   unsigned long long tprev = prof ? wall_clock64() : 0ull;
   const int nrt = (m2 + 15) / 16;
   const int ntc = (nct - jb - kTlPW) / 16;
-  const int npass = (ntc + NW * CT - 1) / (NW * CT);
-  int t0 = 0;
+  // A wavefront's share is ceil(ntc / NW) column tiles, taken <= CT at a time: the passes are cut in whole tiles PER WAVEFRONT (28 tiles, 4 wavefronts, CT = 3: passes of
+  // 12, 8, 8 tiles = 3 + 2 + 2 per wavefront; cut evenly — 10, 9, 9 — every pass costs its busiest wavefront 3)
+  const int units = (ntc + NW - 1) / NW;
+  const int npass = (units + CT - 1) / CT;
+  int t0 = 0, units_left = units;
   for (int pass = 0; pass < npass; ++pass) {
-    const int tp = (ntc - t0 + (npass - pass) - 1) / (npass - pass);  // column tiles of this pass (<= NW CT)
+    const int cu = (units_left + (npass - pass) - 1) / (npass - pass);
+    units_left -= cu;
+    const int tp = (ntc - t0) < cu * NW ? (ntc - t0) : cu * NW;  // column tiles of this pass (<= NW CT)
     // tiles per wavefront: the choice that leaves the busiest wavefront the least work (row tiles x column tiles + its U12)
     int cpw = 1, best = 0x7fffffff;
 #pragma unroll
