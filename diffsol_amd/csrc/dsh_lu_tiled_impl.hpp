@@ -344,6 +344,10 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
       const int D = SW * sp, nd = D / 16;
       double* const la = dyn;         // [D][kTlLaP]
       const int q = lane >> 4, j = lane & 15;
+      // Inside every block of 16 eliminations the matrix-core index 4 g + q (k-block g, lane quarter q) stands for elimination 4 q + g: a lane then needs FOUR ADJACENT
+      // multipliers of a row per block (two 16-byte loads) instead of four at a stride of four (four 8-byte loads that touch the same lines four times over).  U' is solved in
+      // the same labelling (rows of its blocks, rows and columns of L11A and of the inverses), so operands and accumulators agree.
+      const int pj = 4 * (j & 3) + (j >> 2);
       for (int idx = tid; idx < D * D; idx += NT) {
         const int k = idx / D, i = idx - k * D;
         if (i < (k & ~15)) la[k * kTlLaP + i] = W[(size_t)s_prow[k] * ldw + jb + i];
@@ -358,7 +362,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
         for (int rb = 0; rb < MAXD; ++rb)
           if (rb < nd) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + c0 + j];
+            for (int r = 0; r < 4; ++r) B[rb][r] = W[(size_t)s_prow[16 * rb + 4 * q + r] * ldw + cb + c0 + j];
           }
 #pragma unroll
         for (int rb = 0; rb < MAXD; ++rb) {
@@ -366,10 +370,10 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
 #pragma unroll
             for (int cbk = 0; cbk < rb; ++cbk)
 #pragma unroll
-              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 * rb + j) * kTlLaP + 16 * cbk + 4 * kb + q], X[ct][cbk][kb], B[rb], 0, 0, 0);
+              for (int kb = 0; kb < 4; ++kb) B[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[(16 * rb + pj) * kTlLaP + 16 * cbk + 4 * q + kb], X[ct][cbk][kb], B[rb], 0, 0, 0);
             tl_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(invd[rb * 272 + j * 17 + 4 * kb + q], B[rb][kb], acc, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(invd[rb * 272 + pj * 17 + 4 * q + kb], B[rb][kb], acc, 0, 0, 0);
             X[ct][rb] = acc;
           } else {
             X[ct][rb] = tl_d4{0.0, 0.0, 0.0, 0.0};
@@ -384,7 +388,7 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
           for (int rb = 0; rb < MAXD; ++rb)
             if (rb < nd) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) W[(size_t)s_prow[16 * rb + 4 * r + q] * ldw + cb + 16 * ct + j] = X[ct][rb][r];
+              for (int r = 0; r < 4; ++r) W[(size_t)s_prow[16 * rb + 4 * q + r] * ldw + cb + 16 * ct + j] = X[ct][rb][r];
             }
         }
       mark(4);
@@ -419,7 +423,14 @@ __device__ __noinline__ void tl_panel(double* __restrict__ W_generic_, int ldw_,
                 if (16 * tile + 4 * r + q < m_in && s_pos[rows[u][r]] >= cb) ok[u] |= 1u << r;
               }
 #pragma unroll
-              for (int kb = 0; kb < 4 * MAXD; ++kb) aneg[u][kb] = kb < 4 * nd ? -W[arow + jb + 4 * kb + q] : 0.0;
+              for (int rb = 0; rb < MAXD; ++rb)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                  tl_d2 v = {0.0, 0.0};
+                  if (rb < nd) v = *reinterpret_cast<const tl_gd2*>(W + arow + jb + 16 * rb + 4 * q + 2 * e);
+                  aneg[u][4 * rb + 2 * e] = -v[0];
+                  aneg[u][4 * rb + 2 * e + 1] = -v[1];
+                }
             }
           }
 #pragma unroll
