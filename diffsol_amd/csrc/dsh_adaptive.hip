@@ -155,11 +155,13 @@ int dsh_model_has_adaptive_sens(int model, int64_t size) {
 int dsh_bdf_solve_adaptive(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                            double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats, int32_t* status,
                            double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   return bdf_solve_adaptive_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
 }
 int dsh_bdf_solve_adaptive_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                 double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
                                 int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_adaptive_sens(model, size)) {
@@ -179,6 +181,7 @@ int dsh_model_has_adaptive_steps(int model, int64_t size) {
 int dsh_bdf_solve_adaptive_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                  double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
                                  int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_bdf_solve_adaptive_steps: max_cols >= 2, y_out, t_out and ncols are needed");
   if (!dsh_model_has_adaptive_steps(model, size)) {
     set_error("dsh_bdf_solve_adaptive_steps: the model has neither a register-resident BDF (static model, n <= 4) nor a banded lane-per-member form (the wavefront / workgroup forms have dsh_bdf_solve_wave_member_steps)");

@@ -154,6 +154,7 @@ int dsh_ctx_create(int device, void* stream, dsh_ctx** out) {
   DSH_HIP_CHECK(hipSetDevice(device));
   dsh_ctx* ctx = new dsh_ctx();
   ctx->device = device;
+  ctx->last_thread = std::this_thread::get_id();
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->owns_stream = false; }
   else { DSH_HIP_CHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->owns_stream = true; }
   hipDeviceProp_t prop;
@@ -190,27 +191,32 @@ void dsh_ctx_destroy(dsh_ctx* ctx) {
   delete ctx;
 }
 
-// A context (and everything created from it) may move between host threads but is used by ONE thread at a time.  The current HIP device is per-thread state:
-// a thread that takes a context over calls this once before its first use (the Rust shim does it from HipContext::ptr() when the calling thread changes).
+// A context (and everything created from it) may move between host threads.  Every entry point takes the context's lock (DSH_ENTER) and re-binds the calling
+// thread's current HIP device when the thread changed, so concurrent callers are serialised and this call is only needed by code that issues its own HIP calls
+// on the context's stream from a new thread.
 int dsh_ctx_bind_thread(dsh_ctx* ctx) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx != nullptr, "null context");
   DSH_HIP_CHECK(hipSetDevice(ctx->device));
   return DSH_OK;
 }
 
 int dsh_ctx_sync(dsh_ctx* ctx) {
+  DSH_ENTER(ctx);
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return DSH_OK;
 }
 void* dsh_ctx_stream(dsh_ctx* ctx) { return (void*)ctx->stream; }
 int dsh_ctx_device(dsh_ctx* ctx) { return ctx->device; }
 int dsh_ctx_set_block(dsh_ctx* ctx, int threads) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(threads >= 64 && threads <= 1024 && (threads & (threads - 1)) == 0, "block must be a power of two in [64,1024]");
   ctx->block = threads;
   return DSH_OK;
 }
 
 int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
+  DSH_ENTER(ctx);
   if (enable && !ctx->ev_start) {
     DSH_HIP_CHECK(hipEventCreate(&ctx->ev_start));
     DSH_HIP_CHECK(hipEventCreate(&ctx->ev_stop));
@@ -238,12 +244,14 @@ int dsh_ctx_set_timing(dsh_ctx* ctx, int enable) {
   return DSH_OK;
 }
 int dsh_ctx_set_solve_mode(dsh_ctx* ctx, int mode) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx != nullptr && (mode == DSH_SOLVE_EXACT || mode == DSH_SOLVE_REORDERED), "dsh_ctx_set_solve_mode: unknown mode");
   ctx->solve_mode = mode;
   return DSH_OK;
 }
 int dsh_ctx_get_solve_mode(const dsh_ctx* ctx) { return ctx ? ctx->solve_mode : -1; }
 int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(target >= DSH_TIMING_RESIDENT && target <= DSH_TIMING_LU_FACTOR, "dsh_ctx_set_timing_target: unknown target");
   ctx->timing_target = target;
   ctx->timed_ms = 0.0;
@@ -252,21 +260,25 @@ int dsh_ctx_set_timing_target(dsh_ctx* ctx, int target) {
   return DSH_OK;
 }
 int dsh_ctx_get_timing_overhead(dsh_ctx* ctx, double* empty_bracket_ms, double* device_clock_total_ms) {
+  DSH_ENTER(ctx);
   if (empty_bracket_ms) *empty_bracket_ms = ctx->bracket_overhead_ms;
   if (device_clock_total_ms) *device_clock_total_ms = ctx->timed_clock_ms;
   return DSH_OK;
 }
 int dsh_ctx_set_poll(dsh_ctx* ctx, int poll) {
+  DSH_ENTER(ctx);
   ctx->poll = poll != 0;
   return DSH_OK;
 }
 int dsh_ctx_get_timing(dsh_ctx* ctx, int64_t* launches, double* total_ms) {
+  DSH_ENTER(ctx);
   if (launches) *launches = ctx->timed_launches;
   if (total_ms) *total_ms = ctx->timed_ms;
   return DSH_OK;
 }
 
 int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(nbytes >= 0 && out, "bad arguments");
   const size_t want = nbytes > 0 ? (size_t)nbytes : 8;
   void* p = nullptr;
@@ -300,6 +312,7 @@ int dsh_malloc(dsh_ctx* ctx, int64_t nbytes, int zero, void** out) {
   return DSH_OK;
 }
 int dsh_free(dsh_ctx* ctx, void* p) {
+  DSH_ENTER(ctx);
   if (!p) return DSH_OK;
   auto it = ctx->live->find(p);
   if (it == ctx->live->end()) {  // not ours (or already freed): fall back to the runtime
@@ -319,28 +332,33 @@ int dsh_free(dsh_ctx* ctx, void* p) {
   return DSH_OK;
 }
 int dsh_memset_zero(dsh_ctx* ctx, void* p, int64_t nbytes) {
+  DSH_ENTER(ctx);
   if (nbytes > 0) DSH_HIP_CHECK(hipMemsetAsync(p, 0, (size_t)nbytes, ctx->stream));
   return DSH_OK;
 }
 int dsh_h2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  DSH_ENTER(ctx);
   if (nbytes <= 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return DSH_OK;
 }
 int dsh_d2h(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  DSH_ENTER(ctx);
   if (nbytes <= 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return DSH_OK;
 }
 int dsh_d2d(dsh_ctx* ctx, void* dst, const void* src, int64_t nbytes) {
+  DSH_ENTER(ctx);
   if (nbytes <= 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, ctx->stream));
   return DSH_OK;
 }
 
 int dsh_vec_upload(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* host, double* dev) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(n >= 0 && nbatch >= 1, "bad shape");
   if (n == 0) return DSH_OK;
   if (nbatch == 1 || n == 1) return dsh_h2d(ctx, dev, host, sizeof(double) * n * nbatch);
@@ -352,6 +370,7 @@ int dsh_vec_upload(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* host, 
   return DSH_OK;
 }
 int dsh_vec_download(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* dev, double* host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(n >= 0 && nbatch >= 1, "bad shape");
   if (n == 0) return DSH_OK;
   if (nbatch == 1 || n == 1) return dsh_d2h(ctx, host, dev, sizeof(double) * n * nbatch);
@@ -364,16 +383,19 @@ int dsh_vec_download(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* dev,
 }
 
 int dsh_vec_get_index(dsh_ctx* ctx, int64_t nbatch, const double* v, int64_t i, int64_t b, double* out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(b >= 0 && b < nbatch && i >= 0, "index out of range");
   return dsh_d2h(ctx, out, v + i * nbatch + b, sizeof(double));
 }
 int dsh_vec_set_index(dsh_ctx* ctx, int64_t nbatch, double* v, int64_t i, int64_t b, double value) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(b >= 0 && b < nbatch && i >= 0, "index out of range");
   return dsh_h2d(ctx, v + i * nbatch + b, &value, sizeof(double));
 }
 // One member of a batched vector as a contiguous vector with nbatch = 1 and back (Vector::get_batch / get_batch_mut, vector/mod.rs:227-231): with the
 // batch-fastest layout member b is the stride-nbatch slice v[i * nbatch + b]; a stream-ordered strided copy, no kernel.
 int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double* v, int64_t b, double* dst) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx != nullptr && b >= 0 && b < nbatch && n >= 0, "batch index out of range");
   if (n == 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpy2DAsync(dst, sizeof(double), v + b, sizeof(double) * (size_t)nbatch, sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -383,6 +405,7 @@ int dsh_vec_extract_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, const double*
 // device-resident solves run the ensemble sorted by parameters (members with similar parameters take similar paths: a wavefront of neighbours diverges
 // less) and hand results back in the caller's order with the inverse permutation.
 int dsh_permute_members(dsh_ctx* ctx, int64_t rows, int64_t nbatch, int elem_bytes, const void* src, const int32_t* idx_dev, void* dst) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx != nullptr && rows >= 0 && nbatch >= 1 && (elem_bytes == 4 || elem_bytes == 8) && src != dst, "dsh_permute_members: bad argument");
   if (rows == 0) return DSH_OK;
   const int64_t total = rows * nbatch;
@@ -393,6 +416,7 @@ int dsh_permute_members(dsh_ctx* ctx, int64_t rows, int64_t nbatch, int elem_byt
   return DSH_OK;
 }
 int dsh_vec_insert_batch(dsh_ctx* ctx, int64_t n, int64_t nbatch, double* v, int64_t b, const double* src) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx != nullptr && b >= 0 && b < nbatch && n >= 0, "batch index out of range");
   if (n == 0) return DSH_OK;
   DSH_HIP_CHECK(hipMemcpy2DAsync(v + b, sizeof(double) * (size_t)nbatch, src, sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));

@@ -116,6 +116,7 @@ int dsh_dist_unique_id(unsigned char* id128) {
 }
 
 int dsh_dist_init(dsh_ctx* ctx, int rank, int world, const unsigned char* id128, dsh_dist** out) {
+  DSH_ENTER(ctx);
   if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !id128) { set_error("dsh_dist_init: bad arguments"); return DSH_E_INVALID; }
   if (!rccl().ok) { set_error("dsh_dist: librccl could not be loaded (DSH_RCCL_LIB names it explicitly)"); return DSH_E_UNSUPPORTED; }
   DSH_HIP_CHECK(hipSetDevice(ctx->device));
@@ -154,6 +155,7 @@ int dsh_dist_world(const dsh_dist* d) { return d ? d->world : -1; }
 
 // the two copies on their own (also what the GPU tier drives with synthetic buffers for world sizes the box does not have)
 int dsh_dist_pack_shard(dsh_ctx* ctx, void* stream, const double* local, int64_t lead, int64_t nb_local, int64_t m, double* send) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx && (local || nb_local == 0) && send && lead >= 0 && nb_local >= 0 && m >= nb_local, "dsh_dist_pack_shard: bad arguments");  // an empty shard (more ranks than members) has no buffer
   if (lead == 0 || m == 0) return DSH_OK;
   DSH_REQUIRE(lead <= 65535, "dsh_dist_pack_shard: more than 65535 rows (save points x states) per call");
@@ -162,6 +164,7 @@ int dsh_dist_pack_shard(dsh_ctx* ctx, void* stream, const double* local, int64_t
   return DSH_OK;
 }
 int dsh_dist_unpack_gathered(dsh_ctx* ctx, void* stream, const double* recv, int64_t lead, int64_t n_total, int world, double* out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ctx && recv && out && lead >= 0 && n_total >= 0 && world >= 1, "dsh_dist_unpack_gathered: bad arguments");
   if (lead == 0 || n_total == 0) return DSH_OK;
   DSH_REQUIRE(lead <= 65535, "dsh_dist_unpack_gathered: more than 65535 rows (save points x states) per call");
@@ -174,6 +177,7 @@ int dsh_dist_unpack_gathered(dsh_ctx* ctx, void* stream, const double* recv, int
 // All-gather of this rank's [lead][hi - lo] along the batch axis into out [lead][n_total] (every rank gets all of it), issued behind everything the solver's
 // stream holds at the time of the call and run on the communicator's stream: returns at once.  `local` and `out` must stay untouched until dsh_gather_wait.
 int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out) {
+  DSH_ENTER(d ? d->ctx : nullptr);
   if (!d || !out || lead < 0 || n_total < 0) { set_error("dsh_gather_batch_axis: bad arguments"); return DSH_E_INVALID; }
   if (d->pending) { set_error("dsh_gather_batch_axis_async: the previous gather of this communicator has not been waited for (dsh_gather_wait)"); return DSH_E_INVALID; }
   int64_t lo = 0, hi = 0;
@@ -224,6 +228,7 @@ int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, 
 }
 // host waits until the gathered trajectories are in `out` (and `local` may be overwritten by the next solve)
 int dsh_gather_wait(dsh_dist* d) {
+  DSH_ENTER(d ? d->ctx : nullptr);
   if (!d) { set_error("dsh_gather_wait: null communicator"); return DSH_E_INVALID; }
   if (!d->pending) return DSH_OK;
   DSH_HIP_CHECK(hipEventSynchronize(d->done));
@@ -231,6 +236,7 @@ int dsh_gather_wait(dsh_dist* d) {
   return DSH_OK;
 }
 int dsh_gather_batch_axis(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out) {
+  DSH_ENTER(d ? d->ctx : nullptr);
   const int rc = dsh_gather_batch_axis_async(d, local, lead, n_total, out);
   return rc != DSH_OK ? rc : dsh_gather_wait(d);
 }

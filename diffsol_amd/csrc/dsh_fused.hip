@@ -117,6 +117,7 @@ static int newton_launch(dsh_ctx* ctx, bool is_sdirk, int model, int64_t size, i
 
 // ticket = seq << 32 | first group << 28 | groups << 24 | workgroups; out receives 3 doubles per record group
 int dsh_reduction_wait(dsh_ctx* ctx, int64_t ticket, double* out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(out != nullptr, "out is null");
   const unsigned int seq = (unsigned int)((uint64_t)ticket >> 32);
   const int groups = (int)((ticket >> 24) & 0xf), first = (int)((ticket >> 28) & 0xf);
@@ -135,11 +136,13 @@ int dsh_reduction_wait(dsh_ctx* ctx, int64_t ticket, double* out) {
 int dsh_bdf_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, int nit, const double* y_in, double* y_out,
                               const double* psi_neg_y0, const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol,
                               int64_t anb, double rtol, int64_t* ticket) {
+  DSH_ENTER(ctx);
   return newton_launch(ctx, false, model, size, nb, t, c, 0.0, nit, y_in, y_out, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, ticket);
 }
 int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* y_in, double* y_out, const double* psi_neg_y0,
                         const double* p, const dsh_lu* lu, const double* error_y, const double* y_old, const double* atol, int64_t anb, double rtol,
                         double* out) {
+  DSH_ENTER(ctx);
   int64_t ticket = 0;
   int rc = newton_launch(ctx, false, model, size, nb, t, c, 0.0, 1, y_in, y_out, psi_neg_y0, p, lu, error_y, y_old, atol, anb, rtol, &ticket);
   if (rc != DSH_OK) return rc;
@@ -148,6 +151,7 @@ int dsh_bdf_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, doubl
 int dsh_sdirk_newton_iter_async(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, int nit, const double* k_in, double* k_out,
                                 const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
                                 int64_t* ticket) {
+  DSH_ENTER(ctx);
   return newton_launch(ctx, true, model, size, nb, t, c, h, nit, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, ticket);
 }
 // Run-time-sized registry models without a mass matrix (heat1d, spm, ...: no register-resident specialisation): the same iteration as three launches
@@ -196,6 +200,7 @@ static int sdirk_newton_staged(dsh_ctx* ctx, int model, int64_t size, int64_t nb
 // x <- A^-1 x with the factors of `lu`, then max_b mean_i (x_i / (|y_i| rtol + atol_i))^2: the error estimate of the SDIRK step (sdirk.rs:474-495 filtered
 // through the Newton matrix, runge_kutta.rs:783-800) as two launches and ONE wait for both results.  DSH_E_SINGULAR like dsh_lu_solve.
 int dsh_lu_solve_squared_norm(const dsh_lu* lu, double* x, const double* y, int64_t ynb, const double* atol, int64_t anb, double rtol, double* out_norm) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(lu != nullptr && x != nullptr && out_norm != nullptr, "null argument");
   dsh_ctx* ctx = lu->ctx;
   if (!lu->factored) { set_error("dsh_lu_solve_squared_norm: LU not initialised"); return DSH_E_NOT_SETUP; }
@@ -233,6 +238,7 @@ int dsh_lu_solve_squared_norm(const dsh_lu* lu, double* x, const double* y, int6
 int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double h, double c, const double* k_in, double* k_out,
                           const double* phi, const double* p, const dsh_lu* lu, const double* error_y, const double* atol, int64_t anb, double rtol,
                           double* out) {
+  DSH_ENTER(ctx);
   if (dsh_model_has_staged_newton(model, size)) return sdirk_newton_staged(ctx, model, size, nb, t, h, c, k_in, k_out, phi, p, lu, error_y, atol, anb, rtol, out);
   int64_t ticket = 0;
   int rc = newton_launch(ctx, true, model, size, nb, t, c, h, 1, k_in, k_out, phi, p, lu, error_y, nullptr, atol, anb, rtol, &ticket);
@@ -242,6 +248,7 @@ int dsh_sdirk_newton_iter(dsh_ctx* ctx, int model, int64_t size, int64_t nb, dou
 
 int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, double c, const double* x, const double* p, int recompute, double* rhs_jac,
                    double* mass_jac, dsh_lu* lu) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(lu != nullptr && rhs_jac != nullptr, "null argument");
   { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
   lu->singular_epoch += 1;  // the kernel adds (epoch << 32 | 1) per singular system: no reset launch needed between factorisations
@@ -266,6 +273,7 @@ int dsh_jac_factor(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, 
 
 int dsh_bdf_prepare_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, const double* diff, double* diff_tmp, const double* ru_host,
                          const double* gamma_host, double alpha, double* y_predict, double* psi_neg_y0) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
   BdfCoeffs cf;
   for (int k = 0; k < 36; ++k) cf.ru[k] = 0.0;
@@ -312,6 +320,7 @@ static int accept_launch(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double 
 int dsh_bdf_accept_step_async(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
                               double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
                               int64_t* ticket) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(ticket != nullptr, "ticket is null");
   if (n * nb == 0) { *ticket = 0; return DSH_OK; }
   return accept_launch(ctx, n, nb, order, h, diff, y_predict, y_new, y, dy, atol, anb, rtol, gamma_host, alpha, psi_neg_y0_next, ticket);
@@ -321,6 +330,7 @@ int dsh_bdf_accept_newton_async(dsh_ctx* ctx, int model, int64_t size, int64_t n
                                 double* y, double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha,
                                 double* psi_neg_y0_next, double t_next, double c, int nit, double* y_out, const double* p, const dsh_lu* lu,
                                 int64_t* accept_ticket, int64_t* newton_ticket) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(accept_ticket != nullptr && newton_ticket != nullptr && lu != nullptr && psi_neg_y0_next != nullptr, "null argument");
   DSH_REQUIRE(order >= 1 && order <= 5, "order must be in 1..5");
   DSH_REQUIRE(nit >= 1 && nit <= 4, "nit must be in 1..4");
@@ -424,6 +434,7 @@ __global__ void k_sdirk_finish_error(int64_t total, int s, double c, const doubl
 extern "C" {
 
 int dsh_sdirk_begin_attempt(dsh_ctx* ctx, int64_t n, int64_t nb, double h, double a10, const double* dy, const double* y0, double* diff0, double* phi, double* k) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(dy && y0 && diff0 && phi && k, "null argument");
   const int64_t total = n * nb;
   if (total == 0) return DSH_OK;
@@ -433,6 +444,7 @@ int dsh_sdirk_begin_attempt(dsh_ctx* ctx, int64_t n, int64_t nb, double h, doubl
 }
 int dsh_sdirk_next_stage(dsh_ctx* ctx, int64_t n, int64_t nb, int stage, double c, double* k, double* phi, const double* y0, double* y_stage, double* diff,
                          const double* a_next_host, double pred_a, double pred_b) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(k && phi && y0 && y_stage && diff && a_next_host, "null argument");
   DSH_REQUIRE(stage >= 1 && stage < 7, "dsh_sdirk_next_stage: the finished stage must be 1 ... 6");
   const int64_t total = n * nb;
@@ -445,6 +457,7 @@ int dsh_sdirk_next_stage(dsh_ctx* ctx, int64_t n, int64_t nb, int stage, double 
 }
 int dsh_sdirk_finish_error(dsh_ctx* ctx, int64_t n, int64_t nb, int nstages, double c, const double* k, const double* phi, double* y_stage, double* diff,
                            const double* d_host, double* err) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(k && phi && y_stage && diff && d_host && err, "null argument");
   DSH_REQUIRE(nstages >= 1 && nstages <= 8, "dsh_sdirk_finish_error: 1 ... 8 stages");
   const int64_t total = n * nb;
@@ -459,6 +472,7 @@ int dsh_sdirk_finish_error(dsh_ctx* ctx, int64_t n, int64_t nb, int nstages, dou
 int dsh_bdf_accept_step(dsh_ctx* ctx, int64_t n, int64_t nb, int order, double h, double* diff, double* y_predict, const double* y_new, double* y,
                         double* dy, const double* atol, int64_t anb, double rtol, const double* gamma_host, double alpha, double* psi_neg_y0_next,
                         int want_norms, double* out) {
+  DSH_ENTER(ctx);
   if (n * nb == 0) return DSH_OK;
   int64_t ticket = 0;
   int rc = accept_launch(ctx, n, nb, order, h, diff, y_predict, y_new, y, dy, atol, anb, rtol, gamma_host, alpha, psi_neg_y0_next, &ticket);

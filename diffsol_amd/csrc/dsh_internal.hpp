@@ -4,6 +4,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <vector>
 #include <string>
 
@@ -55,6 +57,11 @@ void set_error(const std::string& msg);
 }  // namespace dsh
 
 struct dsh_ctx {
+  // Every extern "C" entry point that touches a context holds this for the duration of the call (DSH_ENTER below): the record ring, the scratch buffers and the
+  // allocation cache need no further locks, and two host threads that use clones of one context (safe Rust can do that: HipContext / HipVec are Clone + Send) are
+  // serialised call by call on the context's one in-order stream instead of racing.  Recursive: entry points call each other.
+  std::recursive_mutex mu;
+  std::thread::id last_thread;  // the thread whose HIP device binding is known to be this context's device (the current device is per-thread state)
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
@@ -121,6 +128,22 @@ extern "C" __attribute__((visibility("hidden"))) int lu_ensure_storage(dsh_lu* l
 
 
 namespace dsh {
+
+// Scope guard of an entry point: takes the context's lock and, when the calling thread is not the one that used the context last, binds this thread's current HIP
+// device to the context's (what dsh_ctx_bind_thread did on request; a context re-created at the same address on another thread is covered too).
+struct ctx_guard {
+  dsh_ctx* c;
+  explicit ctx_guard(const dsh_ctx* cc) : c(const_cast<dsh_ctx*>(cc)) {
+    if (!c) return;
+    c->mu.lock();
+    const std::thread::id me = std::this_thread::get_id();
+    if (c->last_thread != me) { (void)hipSetDevice(c->device); c->last_thread = me; }
+  }
+  ~ctx_guard() { if (c) c->mu.unlock(); }
+  ctx_guard(const ctx_guard&) = delete;
+  ctx_guard& operator=(const ctx_guard&) = delete;
+};
+#define DSH_ENTER(ctxptr) ::dsh::ctx_guard _dsh_ctx_guard(ctxptr)
 
 // Start a reducing launch of `nblocks` workgroups: makes sure the record buffer is large enough and returns the device pointer the
 // kernel writes to plus the sequence tag it must stamp.

@@ -494,9 +494,18 @@ int dsh_model_set_member_twin_source(int model_id, const char* source, int64_t n
   JitModelRec* rec = find_model(model_id);
   if (!rec) { set_error("dsh_model_set_member_twin_source: unknown model id"); return DSH_E_INVALID; }
   DSH_REQUIRE(rec->info.form == DSH_JIT_FORM_STATIC && rec->info.n == n && rec->info.np == nparams, "the twin must be the same model (static form, same dimensions)");
+  const int old_twin = rec->member_twin;  // a twin compiled from the previous source is released, not forgotten
   rec->member_twin_source = source;
   rec->member_twin_dims[0] = n; rec->member_twin_dims[1] = nparams; rec->member_twin_dims[2] = nroots; rec->member_twin_dims[3] = nout;
   rec->member_twin = -1; rec->member_twin_failed = false;
+  if (old_twin >= 0) {
+    auto it = g_models.find(old_twin);
+    if (it != g_models.end()) {
+      for (auto& kv : it->second->modules)
+        if (kv.second && kv.second->module) (void)hipModuleUnload(kv.second->module);
+      g_models.erase(it);
+    }
+  }
   return DSH_OK;
 }
 // -1: the model has no such twin (not a static run-time-compiled model with a registered source, or the source did not compile: dsh_last_error says why)
@@ -517,12 +526,23 @@ int dsh_model_member_twin(int model_id) {
   }
   int id = -1;
   const int rc = dsh_model_compile(src.c_str(), DSH_JIT_FORM_DYNAMIC, d[0], d[1], d[2], d[3], has_mass, &id);  // takes the registry lock itself
-  std::lock_guard<std::mutex> lk(g_mu);
-  JitModelRec* rec = find_model(model_id);
-  if (rc != DSH_OK || !rec) { if (rec) rec->member_twin_failed = true; return -1; }
-  if (JitModelRec* tw = find_model(id)) { tw->info.jac_kl = band[0]; tw->info.jac_ku = band[1]; tw->info.mass_kl = band[2]; tw->info.mass_ku = band[3]; }
-  rec->member_twin = id;
-  return id;
+  // the registry lock was dropped for the compilation: the parent may have vanished, another first request may have won, the source may have been replaced —
+  // the twin compiled here is then released instead of leaked
+  int loser = -1, ret = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    JitModelRec* rec = find_model(model_id);
+    if (rc != DSH_OK) { if (rec && rec->member_twin < 0 && rec->member_twin_source == src) rec->member_twin_failed = true; return rec && rec->member_twin >= 0 ? rec->member_twin : -1; }
+    if (!rec || rec->member_twin_source != src) { loser = id; ret = -1; }
+    else if (rec->member_twin >= 0) { loser = id; ret = rec->member_twin; }
+    else {
+      if (JitModelRec* tw = find_model(id)) { tw->info.jac_kl = band[0]; tw->info.jac_ku = band[1]; tw->info.mass_kl = band[2]; tw->info.mass_ku = band[3]; }
+      rec->member_twin = id;
+      ret = id;
+    }
+  }
+  if (loser >= 0) (void)dsh_model_release(loser);
+  return ret;
 }
 
 int dsh_model_release(int model_id) {

@@ -86,6 +86,7 @@ __global__ void k_lu_solve_multi_reg(int64_t nb, int64_t nrhs, const double* __r
 extern "C" {
 
 int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(n >= 0 && nbatch >= 1 && out, "bad arguments");
   dsh_lu* lu = new dsh_lu();
   lu->ctx = ctx; lu->n = n; lu->nbatch = nbatch;
@@ -132,6 +133,7 @@ double* dsh_lu_factors(dsh_lu* lu) { return lu_ensure_storage(lu) == DSH_OK ? lu
 int32_t* dsh_lu_pivots(dsh_lu* lu) { return lu_ensure_storage(lu) == DSH_OK ? lu->pivots : nullptr; }
 int dsh_lu_system_major(const dsh_lu* lu) { return lu->system_major ? 1 : 0; }
 int dsh_lu_set_structure(dsh_lu* lu, int structure) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(lu != nullptr && (structure == DSH_LU_STRUCTURE_AUTO || structure == DSH_LU_STRUCTURE_DENSE), "bad arguments");
   lu->structure = structure;
   return DSH_OK;
@@ -139,6 +141,7 @@ int dsh_lu_set_structure(dsh_lu* lu, int structure) {
 int dsh_lu_band_width(const dsh_lu* lu) { return lu->band_k; }
 
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) return DSH_OK;
@@ -164,10 +167,11 @@ static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
   return timed_call(lu->ctx, DSH_TIMING_LU_FACTOR, [&] { return lu_factor_core(lu, a, declared_k); });
 }
 
-int dsh_lu_factor(dsh_lu* lu, const double* a) { return lu_factor_impl(lu, a, -1); }
+int dsh_lu_factor(dsh_lu* lu, const double* a) { DSH_ENTER(lu ? lu->ctx : nullptr); return lu_factor_impl(lu, a, -1); }
 // An LU handle for banded systems only: (3k + 1) n doubles of factor storage per system instead of n^2 (config 3: 13 KB instead of 2 MB; heat1d n = 512 x
 // 65 536 members: 0.9 GB instead of 137 GB).  Takes dsh_lu_factor_packed with max(kl, ku) <= k; the solve is dsh_lu_solve as for any handle.
 int dsh_lu_create_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int k, dsh_lu** out) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(k >= 1 && k <= 4, "dsh_lu_create_banded: k must be in 1..4");
   DSH_REQUIRE(n >= 16, "dsh_lu_create_banded: n must be at least 16 (smaller systems use the dense kernels)");
   int rc = dsh_lu_create(ctx, n, nbatch, out);
@@ -178,6 +182,7 @@ int dsh_lu_create_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int k, dsh_lu*
 }
 // Factor a band container (dsh_mat_band_*: entry (i, j) at ((j - i + kl) n + i) nbatch + b): the eliminations of dsh_lu_factor_banded on the same entries
 int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(lu != nullptr && band != nullptr && kl >= 0 && ku >= 0, "bad arguments");
   const int k = std::max(1, std::max(kl, ku));
   DSH_REQUIRE(k <= 4, "dsh_lu_factor_packed: bandwidths up to 4");
@@ -200,6 +205,7 @@ int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku) {
   return DSH_OK;
 }
 int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(kl >= 0 && ku >= 0, "bandwidths must be non-negative");
   return lu_factor_impl(lu, a, std::max(1, std::max(kl, ku)));
 }
@@ -375,7 +381,7 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
 static int lu_solve_launch_impl(const dsh_lu* lu, double* rhs, bool wait, unsigned int* gx_out, unsigned int* seq_out) {
   return timed_call(lu->ctx, DSH_TIMING_LU_SOLVE, [&] { return lu_solve_launch_core(lu, rhs, wait, gx_out, seq_out); });
 }
-int dsh_lu_solve(const dsh_lu* lu, double* rhs) { return lu_solve_launch_impl(lu, rhs, true, nullptr, nullptr); }
+int dsh_lu_solve(const dsh_lu* lu, double* rhs) { DSH_ENTER(lu ? lu->ctx : nullptr); return lu_solve_launch_impl(lu, rhs, true, nullptr, nullptr); }
 }  // extern "C"
 namespace dsh {
 // the solve enqueued only: the zero-pivot count arrives in the launch's records (fetch_records(ctx, *gx, *seq): res_cnt) — for callers that redeem it
@@ -400,6 +406,18 @@ int lu_solve_norm_launch(const dsh_lu* lu, double* rhs, const double* xin, doubl
   if (!((ynb == 1 || ynb == nb) && (anb == 1 || anb == nb))) return DSH_OK;
   const size_t dyn = lu->band_k == 1 ? band_team_epi_lds_bytes<1, 16>(n) : band_team_epi_lds_bytes<2, 16>(n);
   if (dyn > (size_t)96 * 1024) return DSH_OK;  // the squares of the whole vector live in LDS: n <= 768 at 16 systems per workgroup
+  {  // more than 64 KB of dynamic LDS needs the attribute, which applies per DEVICE (a process-wide flag left the second GPU of a process without it);
+     // a device that refuses it takes the two launches (*fused stays false) instead of failing the launch
+    static signed char attr_dev[64][2] = {};  // 0 not tried, 1 set, -1 refused
+    signed char& at = attr_dev[ctx->device & 63][lu->band_k - 1];
+    if (at == 0) {
+      const hipError_t e = lu->band_k == 1 ? hipFuncSetAttribute((const void*)k_lu_band_solve_team<1, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)
+                                           : hipFuncSetAttribute((const void*)k_lu_band_solve_team<2, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+      (void)hipGetLastError();
+      at = e == hipSuccess ? 1 : -1;
+    }
+    if (at < 0 && dyn > (size_t)64 * 1024) return DSH_OK;
+  }
   band_epi_args ea;
   ea.xin = xin; ea.xout = xout; ea.y = y; ea.atol = atol; ea.rtol = rtol; ea.by = (ynb == 1 && nb != 1) ? 1 : 0; ea.ba = (anb == 1 && nb != 1) ? 1 : 0;
   return timed_call(ctx, DSH_TIMING_LU_SOLVE, [&]() -> int {
@@ -409,8 +427,6 @@ int lu_solve_norm_launch(const dsh_lu* lu, double* rhs, const double* xin, doubl
     if (rc != DSH_OK) return rc;
 #define DSH_TEAM_EPI(KK)                                                                                                                                          \
   do {                                                                                                                                                            \
-    static bool attr_set = false;                                                                                                                                 \
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_lu_band_solve_team<KK, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); (void)hipGetLastError(); attr_set = true; } \
     hipLaunchKernelGGL((k_lu_band_solve_team<KK, 16, true>), g, dim3(kTeamThreads), dyn, ctx->stream, n, nb, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq, ea); \
   } while (0)
     if (lu->band_k == 1) DSH_TEAM_EPI(1); else DSH_TEAM_EPI(2);
@@ -565,6 +581,7 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
 }
 
 int dsh_lu_solve_multi(const dsh_lu* lu, double* rhs, int64_t nrhs) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(lu != nullptr && nrhs >= 0, "bad arguments");
   if (!lu->factored) { set_error("dsh_lu_solve_multi: LU not initialised"); return DSH_E_NOT_SETUP; }
   const int64_t n = lu->n, nb = lu->nbatch;
@@ -599,6 +616,7 @@ int dsh_lu_solve_multi(const dsh_lu* lu, double* rhs, int64_t nrhs) {
 }
 
 int dsh_lu_info(const dsh_lu* lu, int64_t* n_singular) {
+  DSH_ENTER(lu ? lu->ctx : nullptr);
   unsigned long long h = 0;
   DSH_HIP_CHECK(hipMemcpyAsync(&h, lu->singular, sizeof(h), hipMemcpyDeviceToHost, lu->ctx->stream));
   DSH_HIP_CHECK(hipStreamSynchronize(lu->ctx->stream));

@@ -132,6 +132,7 @@ __global__ void k_gemm(int64_t m, int64_t n, int64_t k, int64_t nb, double alpha
 extern "C" {
 
 int dsh_mat_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, const double* v, int64_t vnb, double* mat) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(vnb, nb);
   int64_t total = n * n * nb;
   if (total == 0) return DSH_OK;
@@ -141,6 +142,7 @@ int dsh_mat_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, const double* v, 
   return DSH_OK;
 }
 int dsh_mat_band_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, const double* v, int64_t vnb, double* band) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(vnb, nb);
   DSH_REQUIRE(kl >= 0 && ku >= 0 && band != nullptr, "bad arguments");
   const int64_t total = (int64_t)(kl + ku + 1) * n * nb;
@@ -151,6 +153,7 @@ int dsh_mat_band_from_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int 
   return DSH_OK;
 }
 int dsh_mat_band_gemv(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, double alpha, const double* band, const double* x, int64_t xnb, double beta, double* y) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(xnb, nb);
   DSH_REQUIRE(kl >= 0 && ku >= 0 && band && x && y, "bad arguments");
   if (n * nb == 0) return DSH_OK;
@@ -159,17 +162,20 @@ int dsh_mat_band_gemv(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, doubl
   return DSH_OK;
 }
 int dsh_mat_get_diagonal(dsh_ctx* ctx, int64_t n, int64_t nb, const double* mat, double* v) {
+  DSH_ENTER(ctx);
   if (n * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_get_diagonal, ew_grid(n * nb), dim3(kBlock), 0, ctx->stream, n, nb, mat, v);
   DSH_HIP_CHECK(hipGetLastError());
   return DSH_OK;
 }
 int dsh_mat_set_column(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double* mat, int64_t j, const double* v, int64_t vnb) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(j >= 0 && j < ncols, "column index out of bounds");
   return dsh_vec_copy(ctx, nrows, nb, v, vnb, mat + j * nrows * nb);
 }
 int dsh_mat_scale_add_assign(dsh_ctx* ctx, int64_t nelem, int64_t nb, double* self, const double* x, int64_t xnb, double beta, const double* y,
                              int64_t ynb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(xnb, nb); DSH_CHECK_NB(ynb, nb);
   int64_t total = nelem * nb;
   if (total == 0) return DSH_OK;
@@ -184,6 +190,7 @@ int dsh_mat_scale_add_assign(dsh_ctx* ctx, int64_t nelem, int64_t nb, double* se
 }
 int dsh_mat_scale_add_assign_banded(dsh_ctx* ctx, int64_t n, int64_t nb, int kl, int ku, double* self, const double* x, int64_t xnb, double beta, const double* y,
                                     int64_t ynb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(xnb, nb); DSH_CHECK_NB(ynb, nb);
   DSH_REQUIRE(kl >= 0 && ku >= 0 && kl < n && ku < n, "bandwidths out of range");
   const int64_t total = (int64_t)(kl + ku + 1) * n * nb;
@@ -199,6 +206,7 @@ int dsh_mat_scale_add_assign_banded(dsh_ctx* ctx, int64_t n, int64_t nb, int kl,
 }
 int dsh_mat_set_data_with_indices(dsh_ctx* ctx, int64_t nelem_self, int64_t nelem_data, int64_t nb, double* self, const int32_t* dst_idx,
                                   const int32_t* src_idx, int64_t nidx, const double* data) {
+  DSH_ENTER(ctx);
   (void)nelem_self; (void)nelem_data;
   if (nidx * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_set_data_with_indices, ew_grid(nidx * nb), dim3(kBlock), 0, ctx->stream, nidx, nb, self, dst_idx, src_idx, data);
@@ -206,6 +214,7 @@ int dsh_mat_set_data_with_indices(dsh_ctx* ctx, int64_t nelem_self, int64_t nele
   return DSH_OK;
 }
 int dsh_mat_column_axpy(dsh_ctx* ctx, int64_t nrows, int64_t nb, double* mat, double alpha, int64_t j, int64_t i) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(i != j, "column index cannot be the same");
   DSH_REQUIRE(i >= 0 && j >= 0, "column index out of bounds");
   int64_t total = nrows * nb;
@@ -216,6 +225,7 @@ int dsh_mat_column_axpy(dsh_ctx* ctx, int64_t nrows, int64_t nb, double* mat, do
 }
 int dsh_mat_gemv_from(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* a, int64_t anb, const double* x, int64_t xnb,
                       double beta, const double* y0, double* y) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(anb, nb); DSH_CHECK_NB(xnb, nb);
   int64_t total = nrows * nb;
   if (total == 0) return DSH_OK;
@@ -230,10 +240,12 @@ int dsh_mat_gemv_from(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, do
 }
 int dsh_mat_gemv(dsh_ctx* ctx, int64_t nrows, int64_t ncols, int64_t nb, double alpha, const double* a, int64_t anb, const double* x, int64_t xnb,
                  double beta, double* y) {
+  DSH_ENTER(ctx);
   return dsh_mat_gemv_from(ctx, nrows, ncols, nb, alpha, a, anb, x, xnb, beta, nullptr, y);
 }
 int dsh_mat_gemm(dsh_ctx* ctx, int64_t m, int64_t n, int64_t k, int64_t nb, double alpha, const double* a, int64_t anb, const double* bm, int64_t bnb,
                  double beta, double* c) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(anb, nb); DSH_CHECK_NB(bnb, nb);
   int64_t total = m * n * nb;
   if (total == 0) return DSH_OK;

@@ -200,6 +200,7 @@ int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, 
 }
 
 int dsh_model_rhs(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* y) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Rhs, nb, t, x, p, nullptr, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::Rhs>(ctx, model, size, nb, t, x, p, nullptr, 0.0, y, &handled);
@@ -228,6 +229,7 @@ bool model_dyn_sdirk_residual(dsh_ctx* ctx, int model, int64_t size, int64_t nb,
 }  // namespace dsh
 extern "C" {
 int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, const double* v, double* y) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::JacMul, nb, t, x, p, v, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::JacMul>(ctx, model, size, nb, t, x, p, v, 0.0, y, &handled);
@@ -239,6 +241,7 @@ int dsh_model_jac_mul(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double 
   return DSH_OK;
 }
 int dsh_model_jacobian(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* jac) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Jacobian, nb, t, x, p, nullptr, 0.0, jac);
   bool handled = false;
   int rc = launch_static<Op::Jacobian>(ctx, model, size, nb, t, x, p, nullptr, 0.0, jac, &handled);
@@ -257,6 +260,7 @@ int dsh_model_has_band_jacobian(int model, int64_t size) {
   return !is_jit_model(model) && is_dynamic_model(model, size) && dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 ? 1 : 0;
 }
 int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, int kl, int ku, double* jac) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(!is_jit_model(model) && is_dynamic_model(model, size), "dsh_model_jacobian_band: run-time-sized registry models only");
   int jl = -1, ju = -1, ml = -1, mu = -1;
   DSH_REQUIRE(dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 && kl >= jl && ku >= ju, "dsh_model_jacobian_band: the band must cover the declared one");
@@ -267,6 +271,7 @@ int dsh_model_jacobian_band(dsh_ctx* ctx, int model, int64_t size, int64_t nb, d
 }
 // the same entries into a band container of bandwidths (kl, ku): (kl + ku + 1) n doubles per member, every one of them written
 int dsh_model_jacobian_band_packed(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, int kl, int ku, double* band) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(!is_jit_model(model) && is_dynamic_model(model, size), "dsh_model_jacobian_band_packed: run-time-sized registry models only");
   int jl = -1, ju = -1, ml = -1, mu = -1;
   DSH_REQUIRE(dsh_model_band(model, size, &jl, &ju, &ml, &mu) == DSH_OK && jl >= 0 && ju >= 0 && kl >= jl && ku >= ju, "dsh_model_jacobian_band_packed: the band must cover the declared one");
@@ -284,6 +289,7 @@ int dsh_model_has_reset(int model, int64_t size) {
   return ji && ji->has_reset && ji->form != DSH_JIT_FORM_STATIC_BANDED ? 1 : 0;
 }
 int dsh_model_reset(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* y) {
+  DSH_ENTER(ctx);
   if (!dsh_model_has_reset(model, size)) { set_error("dsh_model_reset: model has no reset operator"); return DSH_E_UNSUPPORTED; }
   return jit_model_op(ctx, model, Op::Reset, nb, t, x, p, nullptr, 0.0, y);
 }
@@ -295,18 +301,21 @@ int dsh_model_has_sens(int model, int64_t size) {
   return ok ? 1 : 0;
 }
 int dsh_model_rhs_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* sens) {
+  DSH_ENTER(ctx);
   if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_rhs_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::RhsSens, nb, t, x, p, nullptr, 0.0, sens);
   bool handled = false;
   return launch_static<Op::RhsSens>(ctx, model, size, nb, t, x, p, nullptr, 0.0, sens, &handled);
 }
 int dsh_model_init_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* sens0) {
+  DSH_ENTER(ctx);
   if (!dsh_model_has_sens(model, size)) { set_error("dsh_model_init_sens: model has no parameter sensitivities"); return DSH_E_UNSUPPORTED; }
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::InitSens, nb, t, p, p, nullptr, 0.0, sens0);  // x is not read by du0/dp
   bool handled = false;
   return launch_static<Op::InitSens>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, sens0, &handled);
 }
 int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double beta, double* y) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::MassGemv, nb, t, x, p, nullptr, beta, y);
   bool handled = false;
   int rc = launch_static<Op::MassGemv>(ctx, model, size, nb, t, x, p, nullptr, beta, y, &handled);
@@ -317,6 +326,7 @@ int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, doubl
   return dsh_vec_axpy(ctx, n, nb, 1.0, x, nb, beta, y);
 }
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* mass) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::MassMatrix, nb, t, nullptr, p, nullptr, 0.0, mass);
   bool handled = false;
   int rc = launch_static<Op::MassMatrix>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, mass, &handled);
@@ -325,6 +335,7 @@ int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, dou
   return DSH_E_UNSUPPORTED;
 }
 int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* y) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Init, nb, t, nullptr, p, nullptr, 0.0, y);
   bool handled = false;
   int rc = launch_static<Op::Init>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, y, &handled);
@@ -336,6 +347,7 @@ int dsh_model_init(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, 
   return DSH_OK;
 }
 int dsh_model_root(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* g) {
+  DSH_ENTER(ctx);
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Root, nb, t, x, p, nullptr, 0.0, g);
   int64_t nroots = 0;
   int rc = dsh_model_info(model, size, nullptr, nullptr, nullptr, &nroots);
@@ -378,6 +390,7 @@ int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_
 
 // out_i of a DiffSL model (calc_out): out is nout x nb, batch-fastest.  The registry models have no out_i (their output is the state).
 int dsh_model_out(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* x, const double* p, double* out) {
+  DSH_ENTER(ctx);
   (void)size;
   if (is_jit_model(model)) return jit_model_op(ctx, model, Op::Out, nb, t, x, p, nullptr, 0.0, out);
   set_error("dsh_model_out: the built-in models have no out_i");

@@ -54,6 +54,31 @@ __device__ unsigned long long g_tlu[4];  // thread 0 of workgroup 0: cycles in t
 #else
 #define TLU_MARK(q)
 #endif
+// Pivot of elimination step k over the W wavefronts (largest magnitude, smallest row on ties): the wavefront's winning lane publishes the SIGNED entry, so every
+// thread has the pivot value from LDS and nobody reads A[k * P + p] while thread k interchanges that very entry (a wavefront that came late read the
+// already swapped value — with the factors in global scratch the window was two memory round trips wide).  Returns p (n: no candidate — a NaN column).
+template <int W>
+__device__ __forceinline__ int team_pivot(const double* __restrict__ A, int P, int n, int k, int ln, bool rowlive, double* __restrict__ cand, double& diag) {
+  const int wave = ln >> 6, lane = ln & 63;
+  double best = -1.0, vs = 0.0;
+  int p = n;
+  if (rowlive && ln >= k) { vs = A[k * P + ln]; const double v = fabs(vs); if (v > best) { best = v; p = ln; } }
+  group_argmax(best, p, 64);  // largest magnitude, smallest row on ties, over this wavefront
+  if (p < n ? ln == p : lane == 0) { cand[2 * wave] = vs; cand[2 * wave + 1] = (double)p; }
+  __syncthreads();
+  double s0 = cand[0];
+  int p0 = (int)cand[1];
+  double b0 = p0 < n ? fabs(s0) : -1.0;
+#pragma unroll
+  for (int w = 1; w < W; ++w) {
+    const double sw = cand[2 * w];
+    const int pw = (int)cand[2 * w + 1];
+    const double bw = pw < n ? fabs(sw) : -1.0;
+    if (bw > b0 || (bw == b0 && pw < p0)) { b0 = bw; p0 = pw; s0 = sw; }
+  }
+  diag = p0 < n ? s0 : A[k * P + k];  // NaN column: keep the diagonal like the sequential scan (no interchange follows, nothing to race with)
+  return p0 < n ? p0 : k;
+}
 // LU of the n x n matrix in LDS (A[c * P + r], thread t = row t) with partial pivoting and physical row interchanges; perm[k] = original row at position k.
 // Workgroup-uniform control flow; all W wavefronts must call it together.
 template <int W>
@@ -61,7 +86,6 @@ __device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int
 template <int W>
 __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular) {
   if constexpr (team_global_factors(W)) { team_lu_factor_panel<W>(A, P, n, ln, rowlive, cand, perm, singular); return; }  // factors in global scratch: one round trip of the trailing matrix per panel
-  const int wave = ln >> 6, lane = ln & 63;
   perm[ln] = ln;
   singular = false;
   __syncthreads();  // every row of A is in LDS, perm is the identity
@@ -69,20 +93,9 @@ __device__ __forceinline__ void team_lu_factor(double* __restrict__ A, int P, in
   unsigned long long tlu_t0 = clock64();
 #endif
   for (int k = 0; k < n; ++k) {
-    double best = -1.0;
-    int p = n;
-    if (rowlive && ln >= k) { const double v = fabs(A[k * P + ln]); if (v > best) { best = v; p = ln; } }
-    group_argmax(best, p, 64);  // largest magnitude, smallest row on ties, over this wavefront
-    if (lane == 0) { cand[2 * wave] = best; cand[2 * wave + 1] = (double)p; }
-    __syncthreads();
+    double diag;
+    int p = team_pivot<W>(A, P, n, k, ln, rowlive, cand, diag);
     TLU_MARK(0)
-    double b0 = cand[0];
-    int p0 = (int)cand[1];
-#pragma unroll
-    for (int w = 1; w < W; ++w) argmax_take(b0, p0, cand[2 * w], (int)cand[2 * w + 1]);
-    p = p0;
-    if (p >= n) p = k;  // NaN column: keep the diagonal like the sequential scan
-    const double diag = A[k * P + p];
     const bool elim = diag != 0.0;  // a zero pivot leaves the rows where they are (lu_factor_reg does the same)
     if (!elim) { singular = true; p = k; }
     if (elim && p != k) {  // interchange rows k and p: thread c takes column c
@@ -122,7 +135,6 @@ constexpr int kTeamPanel = 8;  // (16 measured 3.56 against 3.61 s at n = 300 an
 template <int W>
 __device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int P, int n, int ln, bool rowlive, double* __restrict__ cand, int* __restrict__ perm, bool& singular) {
   constexpr int PW = kTeamPanel;
-  const int wave = ln >> 6, lane = ln & 63;
   perm[ln] = ln;
   singular = false;
   __syncthreads();  // every row of A is stored, perm is the identity
@@ -130,19 +142,8 @@ __device__ __forceinline__ void team_lu_factor_panel(double* __restrict__ A, int
     const int k1 = k0 + PW < n ? k0 + PW : n;
     unsigned elim_mask = 0u;  // pivots of this panel that eliminate (a zero pivot leaves the rows where they are and eliminates nothing, lu_factor_reg does the same)
     for (int k = k0; k < k1; ++k) {
-      double best = -1.0;
-      int p = n;
-      if (rowlive && ln >= k) { const double v = fabs(A[k * P + ln]); if (v > best) { best = v; p = ln; } }
-      group_argmax(best, p, 64);
-      if (lane == 0) { cand[2 * wave] = best; cand[2 * wave + 1] = (double)p; }
-      __syncthreads();
-      double b0 = cand[0];
-      int p0 = (int)cand[1];
-#pragma unroll
-      for (int w = 1; w < W; ++w) argmax_take(b0, p0, cand[2 * w], (int)cand[2 * w + 1]);
-      p = p0;
-      if (p >= n) p = k;  // NaN column: keep the diagonal like the sequential scan
-      const double diag = A[k * P + p];
+      double diag;
+      int p = team_pivot<W>(A, P, n, k, ln, rowlive, cand, diag);
       const bool elim = diag != 0.0;
       if (!elim) { singular = true; p = k; }
       if (elim) elim_mask |= 1u << (k - k0);

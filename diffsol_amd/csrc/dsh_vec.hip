@@ -353,30 +353,37 @@ __global__ void k_root_finding(int64_t n, int64_t nb, const double* __restrict__
 extern "C" {
 
 int dsh_vec_add(dsh_ctx* ctx, int64_t n, int64_t nb, const double* lhs, int64_t lnb, const double* rhs, int64_t rnb, double* ret) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(lnb, nb); DSH_CHECK_NB(rnb, nb);
   return launch_ternary(ctx, n, nb, lhs, lnb, rhs, rnb, ret, FAdd{});
 }
 int dsh_vec_sub(dsh_ctx* ctx, int64_t n, int64_t nb, const double* lhs, int64_t lnb, const double* rhs, int64_t rnb, double* ret) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(lnb, nb); DSH_CHECK_NB(rnb, nb);
   return launch_ternary(ctx, n, nb, lhs, lnb, rhs, rnb, ret, FSub{});
 }
 int dsh_vec_add_assign(dsh_ctx* ctx, int64_t n, int64_t nb, double* lhs, const double* rhs, int64_t rnb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(rnb, nb);
   return launch_binary(ctx, n, nb, lhs, rhs, rnb, FAdd{});
 }
 int dsh_vec_sub_assign(dsh_ctx* ctx, int64_t n, int64_t nb, double* lhs, const double* rhs, int64_t rnb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(rnb, nb);
   return launch_binary(ctx, n, nb, lhs, rhs, rnb, FSub{});
 }
 int dsh_vec_mul_assign(dsh_ctx* ctx, int64_t n, int64_t nb, double* lhs, const double* rhs, int64_t rnb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(rnb, nb);
   return launch_binary(ctx, n, nb, lhs, rhs, rnb, FMul{});
 }
 int dsh_vec_div_assign(dsh_ctx* ctx, int64_t n, int64_t nb, double* lhs, const double* rhs, int64_t rnb) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(rnb, nb);
   return launch_binary(ctx, n, nb, lhs, rhs, rnb, FDiv{});
 }
 int dsh_vec_mul_assign_scalar(dsh_ctx* ctx, int64_t n, int64_t nb, double* v, double s) {
+  DSH_ENTER(ctx);
   int64_t total = n * nb;
   if (total == 0) return DSH_OK;
   hipLaunchKernelGGL((k_unary<FScale>), ew_grid(total), dim3(kEwBlock), 0, ctx->stream, total, (const double*)v, v, FScale{s});
@@ -384,6 +391,7 @@ int dsh_vec_mul_assign_scalar(dsh_ctx* ctx, int64_t n, int64_t nb, double* v, do
   return DSH_OK;
 }
 int dsh_vec_mul_scalar(dsh_ctx* ctx, int64_t n, int64_t nb, const double* v, double s, double* res) {
+  DSH_ENTER(ctx);
   int64_t total = n * nb;
   if (total == 0) return DSH_OK;
   hipLaunchKernelGGL((k_unary<FScale>), ew_grid(total), dim3(kEwBlock), 0, ctx->stream, total, v, res, FScale{s});
@@ -391,6 +399,7 @@ int dsh_vec_mul_scalar(dsh_ctx* ctx, int64_t n, int64_t nb, const double* v, dou
   return DSH_OK;
 }
 int dsh_vec_axpy(dsh_ctx* ctx, int64_t n, int64_t nb, double alpha, const double* x, int64_t xnb, double beta, double* y) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(xnb, nb);
   if (beta == 0.0) return launch_binary(ctx, n, nb, y, x, xnb, FAxpy0{alpha});
   return launch_binary(ctx, n, nb, y, x, xnb, FAxpy{alpha, beta});
@@ -405,6 +414,7 @@ __global__ void k_axpby_to(int64_t total, double alpha, const double* __restrict
   }
 }
 int dsh_vec_axpby_to(dsh_ctx* ctx, int64_t n, int64_t nb, double alpha, const double* x, double beta, const double* y0, double* out, double* copy_x_to) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(x && y0 && out, "null argument");
   DSH_REQUIRE(out != x && out != copy_x_to, "dsh_vec_axpby_to: out must not alias x or the copy");
   const int64_t total = n * nb;
@@ -414,6 +424,7 @@ int dsh_vec_axpby_to(dsh_ctx* ctx, int64_t n, int64_t nb, double alpha, const do
   return DSH_OK;
 }
 int dsh_vec_batched_axpy(dsh_ctx* ctx, int64_t n, int64_t nb, const double* alpha_host, const double* x, int64_t xnb, double beta, double* y) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(xnb, nb);
   int64_t total = n * nb;
   if (total == 0) return DSH_OK;
@@ -427,11 +438,13 @@ int dsh_vec_batched_axpy(dsh_ctx* ctx, int64_t n, int64_t nb, const double* alph
   return DSH_OK;
 }
 int dsh_vec_copy(dsh_ctx* ctx, int64_t n, int64_t nb, const double* src, int64_t snb, double* dst) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(snb, nb);
   if (snb == nb) return dsh_d2d(ctx, dst, src, sizeof(double) * n * nb);
   return launch_binary(ctx, n, nb, dst, src, snb, FAxpy0{1.0});
 }
 int dsh_vec_fill(dsh_ctx* ctx, int64_t n, int64_t nb, double* v, double value) {
+  DSH_ENTER(ctx);
   int64_t total = n * nb;
   if (total == 0) return DSH_OK;
   hipLaunchKernelGGL((k_generate<FConst>), ew_grid(total), dim3(kEwBlock), 0, ctx->stream, total, v, FConst{value});
@@ -439,11 +452,13 @@ int dsh_vec_fill(dsh_ctx* ctx, int64_t n, int64_t nb, double* v, double value) {
   return DSH_OK;
 }
 int dsh_vec_set_index_all(dsh_ctx* ctx, int64_t nb, double* v, int64_t i, double value) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(i >= 0, "index out of range");
   return dsh_vec_fill(ctx, 1, nb, v + i * nb, value);
 }
 
 int dsh_vec_gather(dsh_ctx* ctx, int64_t n_src, int64_t nb, const double* src, const int32_t* idx, int64_t nidx, double* dst) {
+  DSH_ENTER(ctx);
   (void)n_src;
   if (nidx * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_gather, ew_grid(nidx * nb), dim3(kEwBlock), 0, ctx->stream, nidx, nb, src, idx, dst);
@@ -451,6 +466,7 @@ int dsh_vec_gather(dsh_ctx* ctx, int64_t n_src, int64_t nb, const double* src, c
   return DSH_OK;
 }
 int dsh_vec_scatter(dsh_ctx* ctx, int64_t n_dst, int64_t nb, const double* src, const int32_t* idx, int64_t nidx, double* dst) {
+  DSH_ENTER(ctx);
   (void)n_dst;
   if (nidx * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_scatter, ew_grid(nidx * nb), dim3(kEwBlock), 0, ctx->stream, nidx, nb, src, idx, dst);
@@ -458,6 +474,7 @@ int dsh_vec_scatter(dsh_ctx* ctx, int64_t n_dst, int64_t nb, const double* src, 
   return DSH_OK;
 }
 int dsh_vec_copy_from_indices(dsh_ctx* ctx, int64_t n, int64_t nb, const double* src, const int32_t* idx, int64_t nidx, double* dst) {
+  DSH_ENTER(ctx);
   (void)n;
   if (nidx * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_copy_from_indices, ew_grid(nidx * nb), dim3(kEwBlock), 0, ctx->stream, nidx, nb, src, idx, dst);
@@ -465,6 +482,7 @@ int dsh_vec_copy_from_indices(dsh_ctx* ctx, int64_t n, int64_t nb, const double*
   return DSH_OK;
 }
 int dsh_vec_assign_at_indices(dsh_ctx* ctx, int64_t n, int64_t nb, const int32_t* idx, int64_t nidx, double value, double* dst) {
+  DSH_ENTER(ctx);
   (void)n;
   if (nidx * nb == 0) return DSH_OK;
   hipLaunchKernelGGL(k_assign_at_indices, ew_grid(nidx * nb), dim3(kEwBlock), 0, ctx->stream, nidx, nb, idx, value, dst);
@@ -473,6 +491,7 @@ int dsh_vec_assign_at_indices(dsh_ctx* ctx, int64_t n, int64_t nb, const int32_t
 }
 
 int dsh_vec_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, int k, double* out_max) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(k >= 1 && out_max, "bad arguments");
   if (n == 0) { *out_max = 0.0; return DSH_OK; }
   unsigned long long* rec; unsigned int seq;
@@ -533,6 +552,7 @@ extern "C" {
 
 int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, const double* y, int64_t ynb, const double* atol, int64_t anb,
                          double rtol, double* out_max, double* per_batch_dev) {
+  DSH_ENTER(ctx);
   DSH_CHECK_NB(ynb, nb); DSH_CHECK_NB(anb, nb);
   DSH_REQUIRE(out_max != nullptr, "out_max is null");
   if (n == 0) { *out_max = 0.0; return DSH_OK; }  // vector/cuda.rs:1365-1367
@@ -570,6 +590,7 @@ int dsh_vec_squared_norm(dsh_ctx* ctx, int64_t n, int64_t nb, const double* x, c
 }
 
 int dsh_vec_root_finding(dsh_ctx* ctx, int64_t n, int64_t nb, const double* g0, const double* g1, int* found, double* frac, int* idx) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(found && frac && idx, "null output");
   if (n == 0) { *found = 0; *frac = 0.0; *idx = -1; return DSH_OK; }
   int rc = ensure_i32_scratch(ctx, 2 * nb);

@@ -56,6 +56,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
 int dsh_bdf_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                     double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out, int32_t* stats,
                                     int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_bdf_solve_wave_member_steps: max_cols >= 2, y_out, t_out and ncols are needed");
   const WmStepsSpec st{t_out, max_cols};
   return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
@@ -63,6 +64,7 @@ int dsh_bdf_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int64
 int dsh_bdf_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                               double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                               int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   return bdf_solve_wave_member_impl(ctx, model, size, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
 }
 // hybrid models whose events are handled INSIDE the wavefront-per-member kernels (BDF, TR-BDF2, ESDIRK34: the reset applied at every event, then on to the last save
@@ -84,6 +86,7 @@ int dsh_model_has_wave_member_sens(int model, int64_t size) {
 int dsh_bdf_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
                                    double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol, const double* sens_atol_host,
                                    int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_wave_member_sens(model, size)) {
@@ -225,6 +228,7 @@ static int sdirk_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, i
 int dsh_sdirk_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                       double t0, double h0, const dsh_adaptive_options* opts, double t_final, int64_t max_cols, double* y_out, double* t_out,
                                       int32_t* stats, int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(max_cols >= 2 && max_cols <= 0x7fffffff && y_out != nullptr && t_out != nullptr && ncols != nullptr, "dsh_sdirk_solve_wave_member_steps: max_cols >= 2, y_out, t_out and ncols are needed");
   const WmStepsSpec st{t_out, max_cols};
   return sdirk_solve_wave_member_impl(ctx, model, size, method, nb, p, atol, atol_nb, rtol, t0, h0, opts, &t_final, 1, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr, &st);
@@ -232,12 +236,14 @@ int dsh_sdirk_solve_wave_member_steps(dsh_ctx* ctx, int model, int64_t size, int
 int dsh_sdirk_solve_wave_member(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                 double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double* y_out, int32_t* stats,
                                 int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   return sdirk_solve_wave_member_impl(ctx, model, size, method, nb, p, atol, atol_nb, rtol, t0, h0, opts, t_eval_host, n_eval, y_out, stats, status, t_root, root_idx, ncols, totals_host, nullptr);
 }
 // forward sensitivities in the wavefront-per-member TR-BDF2 / ESDIRK34 (k_sdirk_wave_member<.., SENS>): the models of dsh_model_has_wave_member_sens
 int dsh_sdirk_solve_wave_member_sens(dsh_ctx* ctx, int model, int64_t size, int method, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol,
                                      double t0, double h0, const dsh_adaptive_options* opts, const double* t_eval_host, int64_t n_eval, double sens_rtol,
                                      const double* sens_atol_host, int64_t nsens_atol, double* y_out, double* sens_out, int32_t* stats, int32_t* status, int64_t* totals_host) {
+  DSH_ENTER(ctx);
   DSH_REQUIRE(sens_out != nullptr, "sens_out is null");
   DSH_REQUIRE(nsens_atol == 0 || sens_atol_host != nullptr, "sens_atol is null");
   if (!dsh_model_has_wave_member_sens(model, size)) {

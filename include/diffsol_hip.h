@@ -54,10 +54,12 @@ int dsh_version(void);
 int dsh_ctx_create(int device, void* stream, dsh_ctx** out);
 void dsh_ctx_destroy(dsh_ctx* ctx);
 int dsh_ctx_sync(dsh_ctx* ctx);
-/* THREADING CONTRACT: a context and every object created from it (vectors, matrices, LU handles, solvers) may be MOVED between host threads, but are used by one
- * thread at a time — the library keeps per-context state (reduction records, scratch, the stream-ordered allocation cache) without locks, exactly as the reference's
- * CudaVec relies on its one in-order CudaStream (context/cuda.rs:41-44).  dsh_last_error is per thread.  The current HIP device is per-thread state: a thread that
- * takes a context over calls dsh_ctx_bind_thread once before its first use. */
+/* THREADING CONTRACT: a context and every object created from it (vectors, matrices, LU handles, solvers) may be MOVED between host threads, and clones of one
+ * context may be USED from several threads: every entry point that takes a context (or an object made from one) holds the context's lock for the duration of the
+ * call and re-binds the calling thread's current HIP device when the thread changed, so concurrent callers are serialised call by call onto the context's one
+ * in-order stream (the reference's CudaVec relies on its Arc<CudaStream> the same way, context/cuda.rs:41-44).  Per-context state (reduction records, scratch,
+ * the stream-ordered allocation cache) is only touched under that lock.  dsh_last_error is per thread.  dsh_ctx_bind_thread is kept for callers that issue
+ * their own HIP calls on dsh_ctx_stream from a new thread. */
 int dsh_ctx_bind_thread(dsh_ctx* ctx);
 void* dsh_ctx_stream(dsh_ctx* ctx);
 int dsh_ctx_device(dsh_ctx* ctx);

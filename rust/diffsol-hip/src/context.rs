@@ -5,13 +5,14 @@
 //! THREADING CONTRACT (include/diffsol_hip.h): `Vector` requires `Clone + Send` (diffsol-la/src/vector/mod.rs:163-177), `Matrix` requires
 //! `Clone + Send + 'static` (matrix/mod.rs:169-170) and `OdeSolverState` requires `Send` (diffsol/src/ode_solver/state.rs:880), so `HipContext` — a field
 //! of every `HipVec` / `HipMat` / `HipIndex` — must be `Send`: the handle is an `Arc<CtxHandle>` and `CtxHandle` / `DeviceBuf` / `HipLU` carry
-//! `unsafe impl Send`.  The invariant those impls rest on: a context and every object created from it may be MOVED to another thread (a solver built on
-//! one thread and run on another, a problem handed to a worker), but they are used by ONE THREAD AT A TIME — the C context keeps its reduction records,
-//! scratch buffers and allocation cache without locks.  This is the contract of the reference's CUDA backend too: `CudaContext` is an `Arc<CudaStream>`
-//! (context/cuda.rs:41-44) and every `CudaVec` operation enqueues on that one stream without further synchronisation.  `Arc<T>: Send` needs `T: Sync`
-//! as well; `CtxHandle` exposes no `&self` operation except through the FFI calls the invariant above serialises.  Ensembles on several GPUs use one
-//! process per device.  The current HIP device is per-thread state: `ptr()` re-binds it (`dsh_ctx_bind_thread`) when the calling thread
-//! differs from the one that used the context last.
+//! `unsafe impl Send`.  Safe Rust can clone a context or a vector, move the clone to another thread and use both at once; the soundness of those impls
+//! therefore cannot rest on a documented "one thread at a time" rule.  It rests on the C library: every `extern "C"` entry point that takes a `dsh_ctx`
+//! (or a `dsh_lu` / `dsh_dist` made from one) holds the context's recursive mutex for the duration of the call (`DSH_ENTER`, csrc/dsh_internal.hpp), so the
+//! record ring, the scratch buffers and the allocation cache are never touched by two threads at once, and concurrent callers are serialised call by
+//! call onto the context's one in-order stream — the same position the reference's `Arc<CudaStream>` (context/cuda.rs:41-44) puts its `CudaVec`
+//! operations in.  The current HIP device is per-thread state: the same guard re-binds it when the calling thread is not the one that used the context
+//! last (keyed on the thread, inside the context object itself — a context destroyed and re-created at the same address starts with its creator's
+//! thread id, so there is no stale pointer comparison on this side).  Ensembles on several GPUs use one process per device.
 use crate::error::{check, last_error};
 use crate::ffi;
 use diffsol_la::error::LaError;
@@ -22,8 +23,8 @@ use std::sync::Arc;
 
 #[derive(Debug)]
 pub(crate) struct CtxHandle(pub(crate) *mut ffi::dsh_ctx);
-// SAFETY: see the threading contract above — moved between threads, used by one thread at a time; the C library holds no thread-affine state in a context
-// (its last-error string is thread-local, the HIP device binding is refreshed by `HipContext::ptr`).
+// SAFETY: see the threading contract above — every FFI call on the handle is serialised by the context's own lock inside the C library and re-binds the HIP
+// device of the calling thread; the library holds no other thread-affine state in a context (its last-error string is thread-local).
 unsafe impl Send for CtxHandle {}
 unsafe impl Sync for CtxHandle {}
 impl Drop for CtxHandle {
@@ -38,11 +39,6 @@ pub struct HipContext {
     pub(crate) nbatch: usize,
 }
 
-thread_local! {
-    /// the context this thread bound its HIP device for last (null: none yet)
-    static BOUND: std::cell::Cell<*mut ffi::dsh_ctx> = const { std::cell::Cell::new(ptr::null_mut()) };
-}
-
 impl HipContext {
     /// Context on HIP device `device` with its own non-blocking stream (replaces `CudaContext::new`, context/cuda.rs:48-68).
     pub fn new(device: i32) -> Result<Self, LaError> {
@@ -55,19 +51,11 @@ impl HipContext {
         if rc < 0 {
             return Err(LaError::Other(format!("dsh_ctx_create: {}", last_error())));
         }
-        BOUND.with(|b| b.set(h));
         Ok(Self { raw: Arc::new(CtxHandle(h)), nbatch: 1 })
     }
-    /// The C handle for an FFI call.  A thread that has not used this context last re-binds its current HIP device first (the device is per-thread state).
+    /// The C handle for an FFI call.  The library locks the context and re-binds the calling thread's HIP device inside every entry point (threading contract above).
     pub(crate) fn ptr(&self) -> *mut ffi::dsh_ctx {
-        let h = self.raw.0;
-        BOUND.with(|b| {
-            if b.get() != h {
-                check(unsafe { ffi::dsh_ctx_bind_thread(h) }, "dsh_ctx_bind_thread");
-                b.set(h);
-            }
-        });
-        h
+        self.raw.0
     }
     /// Block until everything enqueued on the context's stream has finished.
     pub fn synchronize(&self) {
@@ -81,7 +69,7 @@ impl HipContext {
 
 impl Default for HipContext {
     /// Device 0 — what `Matrix::is_sparse()` and the builders reach for.  Panics without a HIP device: there is no CPU fallback.  One default context per
-    /// thread: two threads that each build a problem from `Default` never share a context, so the one-thread-at-a-time contract holds without the caller's help.
+    /// thread: two threads that each build a problem from `Default` never share a context, so they do not contend for one stream either.
     fn default() -> Self {
         thread_local! {
             static DEFAULT: HipContext = HipContext::new(0).expect("diffsol-hip needs a HIP device (no CPU fallback)");

@@ -167,14 +167,31 @@ pub struct EnsembleStepsSolution {
     pub totals: [i64; 6],
 }
 
-/// `problem.bdf()` + `solve(t_final)` (method.rs:227-258: the state after EVERY accepted step) for every member, in one launch of the register-resident BDF
-/// (`dsh_bdf_solve_adaptive_steps`; static models with n <= 4).  Uses the problem's tolerances, options, t0 and h0.
-pub fn solve_ensemble(problem: &OdeSolverProblem<HipModelEquations>, t_final: f64, max_cols: usize, mode: EnsembleMode) -> Result<EnsembleStepsSolution, LaError> {
+/// `problem.bdf()/tr_bdf2()/esdirk34()` + `solve(t_final)` (method.rs:227-258: the state after EVERY accepted step) for every member, in one launch.  Routed like
+/// `dshs_solve_adaptive` (host/solver_c.cpp): the banded lane-per-member twin of a run-time-sized model or the register-resident kernels (static models, n <= 4) through
+/// `dsh_bdf_solve_adaptive_steps` / `dsh_sdirk_solve_resident_steps`; dense run-time-sized models per member (n <= 320) through `dsh_bdf_solve_wave_member_steps` /
+/// `dsh_sdirk_solve_wave_member_steps` (one wavefront or one workgroup per member: control is always per member there).  Uses the problem's tolerances, options, t0 and h0.
+pub fn solve_ensemble(problem: &OdeSolverProblem<HipModelEquations>, method: Method, t_final: f64, max_cols: usize, mode: EnsembleMode) -> Result<EnsembleStepsSolution, LaError> {
     let eqn = &problem.eqn;
     let ctx = eqn.ctx.clone();
     let (nb, n) = (ctx.nbatch(), eqn.nstates);
-    if unsafe { ffi::dsh_model_has_adaptive_steps(eqn.model, eqn.size) } == 0 {
-        return Err(LaError::Other("solve_ensemble: the model has no register-resident BDF (static models with n <= 4); Bdf::solve on HipVec / HipMat / HipLU walks the same steps host-driven".into()));
+    // which kernel family writes every step for this model and method (the order of solve_dense_ensemble above)
+    let twin = unsafe { ffi::dsh_model_lane_twin(eqn.model, eqn.size) };
+    let (model, size) = if twin >= 0 && unsafe { ffi::dsh_model_has_resident(method as i32, twin, 0) } != 0 { (twin, 0) } else { (eqn.model, eqn.size) };
+    let resident = if method == Method::Bdf {
+        unsafe { ffi::dsh_model_has_adaptive_steps(model, size) } != 0
+    } else {
+        unsafe { ffi::dsh_model_has_resident(method as i32, model, size) } != 0
+    };
+    let wave_member = !resident
+        && mode == EnsembleMode::PerMember
+        && (if method == Method::Bdf { unsafe { ffi::dsh_model_has_wave_member(eqn.model, eqn.size) } } else { unsafe { ffi::dsh_model_has_wave_member_sdirk(eqn.model, eqn.size) } }) != 0;
+    if !resident && !wave_member {
+        return Err(LaError::Other(
+            "solve_ensemble: no device-resident integrator that writes every step for this model and method (register-resident static models, banded lane-per-member forms, \
+             wavefront / workgroup per member with EnsembleMode::PerMember); Bdf::solve / Sdirk::solve on HipVec / HipMat / HipLU walk the same steps host-driven"
+                .into(),
+        ));
     }
     let o = adaptive_options(problem, mode);
     let ys = HipMat::zeros(n, max_cols, ctx.clone());
@@ -187,11 +204,35 @@ pub fn solve_ensemble(problem: &OdeSolverProblem<HipModelEquations>, t_final: f6
     let (ts_d, status_d, troot_d, ridx_d, ncols_d) = (alloc(8 * max_cols * nb), alloc(4 * nb), alloc(8 * nb), alloc(4 * nb), alloc(4 * nb));
     let mut totals = [0i64; 6];
     let atol = &problem.atol;
-    let rc = unsafe {
-        ffi::dsh_bdf_solve_adaptive_steps(
-            c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), atol.context().nbatch() as i64, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
-            ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
-        )
+    let anb = atol.context().nbatch() as i64;
+    let rc = if wave_member && method != Method::Bdf {
+        unsafe {
+            ffi::dsh_sdirk_solve_wave_member_steps(
+                c, eqn.model, eqn.size, method as i32, nb as i64, eqn.p.ptr(), atol.ptr(), anb, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
+                ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else if wave_member {
+        unsafe {
+            ffi::dsh_bdf_solve_wave_member_steps(
+                c, eqn.model, eqn.size, nb as i64, eqn.p.ptr(), atol.ptr(), anb, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
+                ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else if method != Method::Bdf {
+        unsafe {
+            ffi::dsh_sdirk_solve_resident_steps(
+                c, method as i32, model, size, nb as i64, eqn.p.ptr(), atol.ptr(), anb, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
+                ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
+    } else {
+        unsafe {
+            ffi::dsh_bdf_solve_adaptive_steps(
+                c, model, size, nb as i64, eqn.p.ptr(), atol.ptr(), anb, problem.rtol, problem.t0, problem.h0, &o, t_final, max_cols as i64, ys.ptr(),
+                ts_d as *mut f64, ptr::null_mut(), status_d as *mut i32, troot_d as *mut f64, ridx_d as *mut i32, ncols_d as *mut i32, totals.as_mut_ptr(),
+            )
+        }
     };
     let fetch = |dev: *mut c_void, host: *mut c_void, bytes: usize| check(unsafe { ffi::dsh_d2h(c, host, dev, bytes as i64) }, "dsh_d2h");
     let mut out = EnsembleStepsSolution { ys, ts: vec![0.0; max_cols * nb], ncols: vec![0; nb], status: vec![0; nb], t_root: vec![0.0; nb], root_index: vec![0; nb], totals };

@@ -26,7 +26,7 @@ pub struct DeviceBuf {
     pub(crate) nbytes: usize,
     pub(crate) ctx: HipContext,
 }
-// SAFETY: the allocation belongs to the context it was made from; it moves with it under the contract of context.rs (used by one thread at a time).
+// SAFETY: the allocation belongs to the context it was made from; it moves with it under the contract of context.rs (every call on it is serialised by its context's lock).
 unsafe impl Send for DeviceBuf {}
 impl DeviceBuf {
     pub(crate) fn new(nbytes: usize, zero: bool, ctx: &HipContext) -> Self {

@@ -78,6 +78,11 @@ def test_every_ffi_call_in_the_shim_matches_a_declaration():
     optional |= {n for n in decl if n.startswith("dsh_mat_band_")}
     needed = {n for n in decl if re.match(r"dsh_(vec|mat|lu)_", n)} - optional
     assert needed <= used, sorted(needed - used)
+    # above the seam: every device-resident integrator entry family of the header (solve_dense, solve = every step, forward sensitivities) has a caller in
+    # ensemble.rs (the three round-5 `*_steps` families were "C ABI only")
+    resident = {n for n in decl if re.match(r"dsh_(bdf|sdirk)_solve_(adaptive|resident|wave_member)(_steps|_sens)?$", n)}
+    assert len(resident) == 12, sorted(resident)
+    assert resident <= set(fn for fn, _ in _calls(_read("ensemble.rs"))), sorted(resident - used)
 
 
 def _impl_block(text, header_regex):
