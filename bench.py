@@ -38,13 +38,16 @@ T_EVAL = [0.4 * 10 ** k for k in range(0, 7)]  # 0.4 ... 4e5
 RTOL, ATOL = 1e-4, [1e-8, 1e-14, 1e-6]
 N_STATES, N_PARAMS = 3, 3
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz — a wavefront's VALU instruction issues over 2 cycles (32 lanes/clk), an FP64 one over 4
-# (78.6 TFLOP/s FP64 vector = 16 lanes/clk x 2 flop); HBM3E 8.0 TB/s spec.
+# (FP64 vector peak derived from that, not printed in the guide: 16 lanes/clk x 2 flop x 1024 SIMDs x 2.4 GHz = 78.6 TFLOP/s); HBM3E 8.0 TB/s spec.
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
 HBM_PEAK_GBS = 8000.0
 PUBLISHED_SINGLE_SOLVE_S = 3.115e-05  # /root/reference book/src/benchmarks/python_results.csv:2 (robertson_ode n=3, BDF, rtol=atol=1e-4, EPYC 7343)
 # Host-driven fused Newton launch (extra key `host_lockstep`): reads 8n^2+4n (LU+piv) + 8(4n+np) = 204 B per member, writes 8n per iteration.
 NEWTON_READ_BYTES, NEWTON_WRITE_BYTES_PER_ITER = 204, 24
+# SURVEY 8(d) algorithmic bytes per unit for n = 3, np = 3, q = 3: full fused Newton iteration 8n^2+4n+8(5n+np) = 228; accepted step 2*8*n*(q+3)+16n+8n = 360;
+# LU refactorisation 8n^2 read + 8n^2 + 4n written = 156
+MODEL_8D_NEWTON_BYTES, MODEL_8D_STEP_BYTES, MODEL_8D_REFACTOR_BYTES = 228, 360, 156
 
 
 KERNEL_SOURCES = ["diffsol_amd/csrc/dsh_adaptive_kernel.hpp", "diffsol_amd/csrc/dsh_resident.hpp", "diffsol_amd/csrc/dsh_device.hpp", "diffsol_amd/csrc/dsh_lu_dev.hpp",
@@ -93,7 +96,10 @@ def compact_line(rec):
         out["checks"] = {k: _sig(v) for k, v in rec["checks"].items()}
     roof = rec.get("roofline")
     if isinstance(roof, dict):
-        r = _pick(roof, ("bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "traffic", "fp64_tflops", "counters_from"))
+        r = _pick(roof, ("bound", "avg_launch_us", "launches_timed", "achieved", "peak", "unit", "frac", "fp64_frac", "hbm_frac_actual", "hbm_model_8d_frac", "traffic", "fp64_tflops",
+                         "counters_from"))
+        if roof.get("hbm_model_8d_frac") is not None:
+            r["hbm_model_8d_note"] = "8(d) model assumes LU/state in HBM; they are in registers, so >1 is expected"
         r["kernel"] = str(roof.get("kernel", ""))[:80]
         if isinstance(roof.get("lane_ops"), dict):
             r["lane_ops_frac"] = _sig(roof["lane_ops"].get("frac"))
@@ -278,7 +284,7 @@ def cpu_baseline(params, sample):
                   f"thread count swept, best reported",
         "single_core": {"value": single, "unit": "ODE steps/s", "cores": 1, "seconds_per_solve": r1["seconds"] / n1,
                         "newton_solves_per_sec": r1["newton_iterations"] / r1["seconds"], "seconds": r1["seconds"], "sample": f"first {n1} members, one thread"},
-        "sample_short": f"first {sample} members of the same sweep, independent BDF solves (C++ restatement of Bdf+NalgebraLU), best of a thread sweep",
+        "sample_short": f"{sample} members, same distribution/seed as the GPU's {NB_PER_GPU} (longer draw; rate per member-step compared), independent BDF solves, best thread count",
         "reference_published": {"seconds_per_solve": PUBLISHED_SINGLE_SOLVE_S,
                                 "what": "diffsol BDF+nalgebra LU via pydiffsol, robertson_ode n=3, rtol=atol=1e-4, one EPYC 7343 core "
                                         "(book/src/benchmarks/python_results.csv:2); t_final/output grid of that benchmark are defined outside the "
@@ -296,7 +302,9 @@ def cpu_baseline(params, sample):
 # cut-offs armed, 32 768 (one GPU's shard of the 8-GPU job) and 262 144 members; C5 series RLC DAE n = 4 x 65 536, R ~ U[50, 200], C ~ logU[5e-4, 2e-3],
 # ESDIRK34, t in [0, 1], root i_R = i_thresh.
 TIMING_RESIDENT, TIMING_LU_SOLVE, TIMING_LU_FACTOR = 0, 1, 2
-FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 matrix (= vector) peak
+# FP64 peak, DERIVED (MI355X_MICROARCH.md prints no FP64 row): 256 CUs x 4 SIMDs x 16 FP64 lanes/clk x 2 flop (FMA) x 2.4 GHz = 78.6 TFLOP/s — half the
+# guide's 157.3 TFLOP/s FP32 vector figure (SIMD-32), and the rate of v_mfma_f64_16x16x4_f64 as well (one instruction = 2048 flop per 64 cycles and SIMD).
+FP64_MATRIX_PEAK_TFLOPS = 256 * 4 * 16 * 2 * 2.4e9 / 1e12
 CFG_SOURCES = {
     "c3_banded": ["diffsol_amd/csrc/dsh_lu_band_team.hpp", "diffsol_amd/csrc/dsh_lu_band.hpp"],
     "c3_dense": ["diffsol_amd/csrc/dsh_lu_tiled.hpp", "diffsol_amd/csrc/dsh_lu_coop.hpp"],
@@ -312,6 +320,19 @@ def source_hash(files):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def latest_profile(suffix):
+    """newest committed round of a profile summary: profiles/rNN_<suffix> with the largest NN (None when there is none).  bench.py reads counters only from the newest
+    file of a kind and refuses them when the kernel's sources changed since (tests/test_profiles_fresh.py fails the CPU tier in that case: re-run scripts/profile_r06.sh)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.basename(f))
+    return best[1] if best else None
 
 
 def heat_params(nb):
@@ -330,8 +351,10 @@ def rlc_params(nb, i_thresh):
 
 
 def _counters(name, key, sources):
-    """committed PMC summary of a config's kernel (profiles/r05_pmc_configs.json, else the name given), refused when the kernel's sources changed since it was taken"""
-    for cand in ("r05_pmc_configs.json", name):
+    """committed PMC summary of a config's kernel (the newest profiles/rNN_pmc_configs.json), refused when the kernel's sources changed since it was taken"""
+    for cand in (latest_profile("pmc_configs.json"),):
+        if not cand:
+            continue
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", cand))).get(key)
         except Exception:
@@ -820,7 +843,7 @@ def main():
 
         extras["per_member"] = dict(mode_pass(ENSEMBLE_PER_MEMBER, False), note="every member its own step-size/order history (diffsol's CPU semantics for a sweep)")
         try:  # its roofline entry, from the committed counters of the same kernel (MODE=member scripts/profile_r03.sh); refused when the kernel sources changed since
-            pm_name = next((f for f in ("r05_pmc_per_member.json", "r04_pmc_per_member.json", "r03_pmc_per_member.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_pmc_per_member.json")
+            pm_name = latest_profile("pmc_per_member.json") or "r06_pmc_per_member.json"
             pm = json.load(open(os.path.join(ROOT, "profiles", pm_name))).get("bench_kernel", {})
             if pm.get("kernel_source_sha16") == kernel_source_hash() and pm.get("members") == nb and world == 1:
                 t_s = extras["per_member"]["ms_per_step"] * 1e-3
@@ -921,7 +944,7 @@ def main():
             avg_s = kernel_ms * 1e-3 / launches
             pmc = {}
             stale = None
-            pmc_name = next((f for f in ("r05_pmc_resident.json", "r04_pmc_resident.json", "r03_pmc_resident.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "r05_pmc_resident.json")
+            pmc_name = latest_profile("pmc_resident.json") or "r06_pmc_resident.json"
             path = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(path):
                 try:
@@ -931,7 +954,7 @@ def main():
                 if pmc:
                     pmc["file"] = "profiles/" + pmc_name
                     if pmc.get("kernel_source_sha16") != kernel_source_hash():  # counters of another kernel: no fraction rather than a stale one
-                        stale = f"profiles/{pmc_name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r05.sh"
+                        stale = f"profiles/{pmc_name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, this tree has {kernel_source_hash()}: re-run scripts/profile_r06.sh"
                         pmc = {}
             algo_hbm = 8 * (N_PARAMS + N_STATES * len(T_EVAL)) * (hi - lo)
             roof = {"bound": "valu", "kernel": "dsh::k_bdf_adaptive<RobertsonOde1, BA=true, WAVE=true> (the whole ensemble solve, one launch)",
@@ -960,7 +983,21 @@ def main():
                         roof["fp64_tflops"] = pmc["f64_flop_per_launch"] / avg_s / 1e12
                 roof["traffic"] = pmc.get("hbm_bytes_per_launch")
                 roof["counters_from"] = pmc.get("file")
-            else:
+                # the four fractions side by side: `frac` = VALU issue cycles (the bound); fp64_frac = FP64 flop against the derived 78.6 TFLOP/s;
+                # hbm_frac_actual = counter traffic against 8 TB/s (the state never leaves registers: ~0.001 by design); hbm_model_8d_frac = SURVEY 8(d)'s byte model
+                # (LU, state and history re-read from HBM per unit of work), which this kernel does not follow and which therefore exceeds 1
+                if roof.get("fp64_tflops"):
+                    roof["fp64_frac"] = roof["fp64_tflops"] / FP64_MATRIX_PEAK_TFLOPS
+                if roof["traffic"]:
+                    roof["hbm_frac_actual"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
+            if True:  # the 8(d) model needs no counters: units executed by one launch of this rank (the totals are sums over ranks and timed solves)
+                per = 1.0 / args.steps / world
+                model_bytes = (member_newton * MODEL_8D_NEWTON_BYTES + member_steps * MODEL_8D_STEP_BYTES + member_setups * MODEL_8D_REFACTOR_BYTES) * per
+                roof["hbm_model_8d_bytes_per_launch"] = model_bytes
+                roof["hbm_model_8d_frac"] = model_bytes / avg_s / 1e9 / HBM_PEAK_GBS
+                roof["hbm_model_8d_note"] = ("SURVEY 8(d) bytes (228 B per Newton iteration, 360 B per accepted step, 156 B per refactorisation) assume LU/state/history in HBM; "
+                                             "here they live in registers, so the model does not apply (> 1 is expected) — hbm_frac_actual is the measured traffic")
+            if not valu:
                 roof.update({"achieved": None, "frac": None, "traffic": None, "note": stale or "no PMC summary for this ensemble size under profiles/"})
             rec["roofline"] = roof
         else:

@@ -23,6 +23,8 @@ MODEL_HEAT1D = 7
 MODEL_RLC = 8
 MODEL_EXPONENTIAL_DECAY_ROOT = 9
 MODEL_SPM = 10
+MODEL_HEAT2D = 11   # n = size^2, DAE, p = [diffusion scale]
+MODEL_FOODWEB = 12  # n = 2 size^2, DAE, p = [alpha, beta]
 
 METHOD_BDF = 0
 METHOD_TR_BDF2 = 1

@@ -30,6 +30,8 @@ enum ModelId : int {
   MODEL_RLC = 8,                          // n=4 DAE, p=[R,L,C,V0,omega,ithresh]
   MODEL_EXPONENTIAL_DECAY_ROOT = 9,       // exponential decay with root x0-0.6
   MODEL_SPM = 10,                         // single-particle battery model, n=2+2*size (size shells per particle, 20 in spm.ds), p=[I]
+  MODEL_HEAT2D = 11,                      // 2-D heat equation on a size x size grid, n=size^2, DAE (boundary rows algebraic), p=[diffusion scale] (1 = the reference), band size
+  MODEL_FOODWEB = 12,                     // predator-prey food web on a size x size grid, n=2 size^2, DAE (predators algebraic), p=[alpha, beta] ((50, 1000) = the reference), band 2 size
 };
 
 struct Model {
@@ -296,6 +298,121 @@ struct Spm : Model {
   }
 };
 
+// 2-D heat equation, 5-point differences on an m x m grid of the unit square, Dirichlet 0 boundary values kept as algebraic equations (res_i = u_i):
+// crates/diffsol/src/ode_equations/test_models/heat2d.rs:105-123 (rhs), :125-149 (jac_mul), :151-183 (init), :185-205 (mass).  The reference has no parameter;
+// p[0] scales the diffusion coefficient (p[0] = 1: p[0] / (dx dx) is the reference's 1 / (dx dx) to the bit) so that an ensemble has distinct members.
+// Half-bandwidth of f_y: m (the 5-point stencil's +-m neighbours) — the `Sunmatrix_Band` case of book/src/benchmarks/sundials.md:27-28.
+struct Heat2d : Model {
+  int m;
+  explicit Heat2d(int mgrid) : m(mgrid) { if (m < 3) throw std::runtime_error("oracle: heat2d needs a grid of at least 3 x 3"); n = m * m; np = 1; has_mass = true; }
+  void stencil(const double* u, const double* p, double* y) const {
+    for (int i = 0; i < n; ++i) y[i] = u[i];  // y.copy_from(x): the boundary equations
+    const double mm = (double)m, four = 4.0;
+    const double dx = 1.0 / (mm - 1.0);
+    const double coeff = p[0] / (dx * dx);
+    for (int j = 1; j < m - 1; ++j) {
+      const int offset = m * j;
+      for (int i = 1; i < m - 1; ++i) {
+        const int loc = offset + i;
+        y[loc] = coeff * (u[loc - 1] + u[loc + 1] + u[loc - m] + u[loc + m] - four * u[loc]);
+      }
+    }
+  }
+  void rhs(const double* x, const double* p, double, double* y) const override { stencil(x, p, y); }
+  void jac_mul(const double*, const double* p, double, const double* v, double* y) const override { stencil(v, p, y); }
+  void mass(const double* x, const double*, double, double beta, double* y) const override {
+    for (int j = 0; j < m; ++j)
+      for (int i = 0; i < m; ++i) {
+        const int loc = m * j + i;
+        if (j == 0 || j == m - 1 || i == 0 || i == m - 1) y[loc] *= beta;
+        else y[loc] = x[loc] + beta * y[loc];
+      }
+  }
+  void init(const double*, double, double* uu) const override {
+    const double mm = (double)m, one = 1.0, sixteen = 16.0;
+    const double dx = one / (mm - one);
+    for (int j = 0; j < m; ++j) {
+      const double yfact = dx * (double)j;
+      for (int i = 0; i < m; ++i) {
+        const double xfact = dx * (double)i;
+        const int loc = m * j + i;
+        uu[loc] = (j == 0 || j == m - 1 || i == 0 || i == m - 1) ? 0.0 : sixteen * xfact * (one - xfact) * yfact * (one - yfact);
+      }
+    }
+  }
+  // heat2d.rs:200-205: out = (||x||_2 dx)^2 — not part of the integration (the tests below form it from the states)
+};
+
+// Food web: predator-prey interaction with diffusion on the unit square (the Sundials idaFoodWeb example), one prey and one predator species, nx x nx grid,
+// species interleaved (loc = 2 jx + 2 nx jy), homogeneous Neumann boundaries by mirror points, predators algebraic:
+// crates/diffsol/src/ode_equations/test_models/foodweb.rs:9-22 (constants), :232-273 (coefficients), :342-366 (init), :419-494 (rhs), :502-582 (jac_mul), :639-655 (mass).
+// p = (ALPHA, BETA) of the growth-rate field b(x, y) = 1 + alpha x y + beta sin(4 pi x) sin(4 pi y) ((50, 1000) in the reference).  The sines use the portable
+// dsh_det_sin of include/diffsol_detpow.h (the device has no libm; within 1 ulp of it).  Half-bandwidth of f_y: 2 nx.
+struct Foodweb : Model {
+  int nx;
+  static constexpr int NS = 2;
+  double acoef[2][2], bcoef[2], cox[2], coy[2];
+  explicit Foodweb(int nx_) : nx(nx_) {
+    if (nx < 2) throw std::runtime_error("oracle: foodweb needs a grid of at least 2 x 2");
+    n = NS * nx * nx; np = 2; has_mass = true;
+    const double AA = 1.0, EE = 10000.0, GG = 0.5e-6, BB = 1.0, DPREY = 1.0, DPRED = 0.05;
+    const double DX = 1.0 / ((double)nx - 1.0), DY = 1.0 / ((double)nx - 1.0);
+    acoef[0][1] = -GG; acoef[1][0] = EE; acoef[0][0] = -AA; acoef[1][1] = -AA;
+    bcoef[0] = BB; bcoef[1] = -BB;
+    cox[0] = DPREY / (DX * DX); cox[1] = DPRED / (DX * DX);
+    coy[0] = DPREY / (DY * DY); coy[1] = DPRED / (DY * DY);
+  }
+  void apply(const double* x, const double* p, const double* v, double* y) const {  // v == nullptr: f(x); else J(x) v
+    const int nsmx = NS * nx;
+    const double dx = 1.0 / ((double)nx - 1.0), dy = 1.0 / ((double)nx - 1.0);
+    const double* u = v ? v : x;
+    for (int jy = 0; jy < nx; ++jy) {
+      const double yy = (double)jy * dy;
+      const int idyu = jy != nx - 1 ? nsmx : -nsmx, idyl = jy != 0 ? nsmx : -nsmx;
+      for (int jx = 0; jx < nx; ++jx) {
+        const double xx = (double)jx * dx;
+        const int idxu = jx != nx - 1 ? NS : -NS, idxl = jx != 0 ? NS : -NS;
+        const int loc = NS * jx + nsmx * jy, locxu = loc + idxu, locxl = loc - idxl, locyu = loc + idyu, locyl = loc - idyl;
+        double rates[NS], drates[NS];
+        for (int is = 0; is < NS; ++is) {
+          double dp = 0.0, ddp = 0.0;
+          for (int js = 0; js < NS; ++js) { dp += acoef[is][js] * x[loc + js]; if (v) ddp += acoef[is][js] * v[loc + js]; }
+          rates[is] = dp; drates[is] = ddp;
+        }
+        const double fac = 1.0 + p[0] * xx * yy + p[1] * dsh_det_sin(4.0 * 3.14159265358979323846 * xx) * dsh_det_sin(4.0 * 3.14159265358979323846 * yy);
+        for (int is = 0; is < NS; ++is) {
+          if (v) drates[is] = x[loc + is] * drates[is] + v[loc + is] * (bcoef[is] * fac + rates[is]);
+          else rates[is] = x[loc + is] * (bcoef[is] * fac + rates[is]);
+        }
+        for (int is = 0; is < NS; ++is) {
+          const double dcyli = u[loc + is] - u[locyl + is], dcyui = u[locyu + is] - u[loc + is];
+          const double dcxli = u[loc + is] - u[locxl + is], dcxui = u[locxu + is] - u[loc + is];
+          y[loc + is] = coy[is] * (dcyui - dcyli) + cox[is] * (dcxui - dcxli) + (v ? drates[is] : rates[is]);
+        }
+      }
+    }
+  }
+  void rhs(const double* x, const double* p, double, double* y) const override { apply(x, p, nullptr, y); }
+  void jac_mul(const double* x, const double* p, double, const double* v, double* y) const override { apply(x, p, v, y); }
+  void mass(const double* x, const double*, double, double beta, double* y) const override {
+    for (int i = 0; i < n; ++i) y[i] = (i % NS) < 1 ? x[i] + beta * y[i] : beta * y[i];
+  }
+  void init(const double*, double, double* y) const override {
+    const double dx = 1.0 / ((double)nx - 1.0), dy = 1.0 / ((double)nx - 1.0);
+    for (int jy = 0; jy < nx; ++jy) {
+      const double yy = (double)jy * dy;
+      for (int jx = 0; jx < nx; ++jx) {
+        const double xx = (double)jx * dx;
+        double xyfactor = 16.0 * xx * (1.0 - xx) * yy * (1.0 - yy);
+        xyfactor = xyfactor * xyfactor;
+        const int loc = NS * nx * jy + NS * jx;
+        y[loc] = 10.0 + 1.0 * xyfactor;
+        y[loc + 1] = 1.0e5;
+      }
+    }
+  }
+};
+
 // A user model compiled to a shared library with the external-model C ABI (dsl_dims, dsl_rhs, dsl_jac_mul, dsl_mass_gemv, dsl_init, dsl_root):
 // the CPU twin of a run-time-compiled device model, so the oracle can integrate exactly the model the GPU integrates.  This is the role of the
 // reference's compiled DiffSL module behind DiffSl<M, CG> (crates/diffsol/src/ode_equations/diffsl.rs: rhs, rhs_grad, mass, set_u0, calc_stop).
@@ -355,6 +472,8 @@ inline std::unique_ptr<Model> make_model(int id, int size) {
     case MODEL_HEAT1D: return std::make_unique<Heat1d>(size);
     case MODEL_RLC: return std::make_unique<Rlc>(size != 0);
     case MODEL_SPM: return std::make_unique<Spm>(size);
+    case MODEL_HEAT2D: return std::make_unique<Heat2d>(size <= 0 ? 10 : size);
+    case MODEL_FOODWEB: return std::make_unique<Foodweb>(size <= 0 ? 10 : size);
     default: throw std::runtime_error("oracle: unknown model id");
   }
 }

@@ -11,6 +11,9 @@ What is extracted (data only — numbers out of literal tables / insta snapshots
       (OdeSolverStatistics + rhs OpStatistics after `test_ode_solver(...)`)
   * the BdfCallable / SdirkCallable unit KATs (crates/diffsol/src/op/bdf.rs:318-361, op/sdirk.rs:338-389)
   * BDF method constants (kappa table bdf.rs:253-260) and the tableaus' defining constants (tableau.rs:41-159)
+  * round 6: the 2-D PDE test models of the banded-solver row — solution tables of heat2d (test_models/heat2d.rs:274-287: the model's out
+      (||u||_2 dx)^2 at 12 times) and foodweb (test_models/foodweb.rs:996-1050: the corner values of both species at 7 times), and the solver counters of
+      test_bdf_faer_sparse_heat2d / test_bdf_faer_sparse_foodweb (bdf.rs:2424-2490)
 """
 import json
 import os
@@ -32,6 +35,17 @@ def parse_table(src, start_marker):
     rows = []
     for m in re.finditer(r"\(vec!\[([^\]]+)\],\s*([-+0-9.eE]+)\)", block):
         vals = [float(v) for v in m.group(1).split(",")]
+        rows.append({"t": float(m.group(2)), "y": vals})
+    return rows
+
+
+def parse_table_multiline(src, start_marker):
+    """the same for tables whose rows rustfmt broke over several lines: ( vec![ a, b, ], t, )"""
+    i = src.index(start_marker)
+    block = src[i:src.index("];", i)]
+    rows = []
+    for m in re.finditer(r"\(\s*vec!\[([^\]]+)\],\s*([-+0-9.eE]+),?\s*\)", block):
+        vals = [float(v) for v in m.group(1).split(",") if v.strip()]
         rows.append({"t": float(m.group(2)), "y": vals})
     return rows
 
@@ -80,6 +94,18 @@ def main():
     for group in ("bdf_snapshots", "sdirk_snapshots"):
         for name, c in kats[group].items():
             assert len(c) == 13, (name, c)
+
+    # round 6: the reference's 2-D PDE test models (banded Jacobians, half-bandwidth 10 and 20).  Their snapshots are taken with FaerSparseLU and a coloured sparse
+    # Jacobian: the ten OdeSolverStatistics counters do not depend on that (up to rounding in the linear solves), number_of_jac_muls does — only the solver counters
+    # and the rhs call / matrix evaluation counts are kept for the banded (dense-container) path
+    kats["pde2d_snapshots"] = parse_snapshots(bdf, ["test_bdf_faer_sparse_heat2d", "test_bdf_faer_sparse_foodweb"])
+    assert len(kats["pde2d_snapshots"]["test_bdf_faer_sparse_heat2d"]) == 13 and len(kats["pde2d_snapshots"]["test_bdf_faer_sparse_foodweb"]) == 10
+    kats["heat2d_table"] = {"source": "test_models/heat2d.rs:267-287", "what": "out = (||u||_2 dx)^2, dx = 1/(mgrid-1)", "mgrid": 10, "problem_rtol": 1e-7, "problem_atol": [1e-7],
+                            "rtol": 1e-5, "atol": [1e-5], "points": parse_table(read("ode_equations/test_models/heat2d.rs"), "let data = vec![")}
+    kats["foodweb_table"] = {"source": "test_models/foodweb.rs:988-1050", "what": "out = (c1 top-left, c1 bottom-right, c2 top-left, c2 bottom-right)", "nx": 10,
+                             "problem_rtol": 1e-5, "problem_atol": [1e-5], "h0": 1.0, "rtol": 1e-4, "atol": [1e-4] * 4,
+                             "points": parse_table_multiline(read("ode_equations/test_models/foodweb.rs"), "let data = vec![")}
+    assert len(kats["heat2d_table"]["points"]) == 12 and len(kats["foodweb_table"]["points"]) == 7 and all(len(r["y"]) == 4 for r in kats["foodweb_table"]["points"])
 
     # test-problem definitions that go with the snapshots (arguments of the reference's problem constructors)
     kats["snapshot_problems"] = {

@@ -1,7 +1,8 @@
 import numpy as np
 
 ORACLE_MODEL = {"exponential_decay": 0, "exponential_decay_with_algebraic": 1, "exponential_decay_with_algebraic_batched": 2, "robertson_ode": 3,
-                "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9, "spm": 10}
+                "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9, "spm": 10,
+                "heat2d": 11, "foodweb": 12}
 METHOD = {"bdf": 0, "tr_bdf2": 1, "esdirk34": 2}
 
 
@@ -24,3 +25,16 @@ def times_of(kats, spec_t):
     if isinstance(spec_t, str):
         return [pt["t"] for pt in kats[spec_t]["points"]]
     return list(spec_t)
+
+
+def heat2d_out(y, mgrid):
+    """heat2d.rs:200-205: out = (||u||_2 dx)^2 of a state (last axis = states)"""
+    dx = 1.0 / (mgrid - 1.0)
+    return (np.linalg.norm(np.asarray(y, dtype=float), axis=-1) * dx) ** 2
+
+
+def foodweb_out(y, nx):
+    """foodweb.rs:699-712: (c1 top-left, c1 bottom-right, c2 top-left, c2 bottom-right) of a state (last axis = states, species interleaved)"""
+    y = np.asarray(y, dtype=float)
+    br = 2 * (nx - 1) + 2 * nx * (nx - 1)
+    return np.stack([y[..., 0], y[..., br], y[..., 1], y[..., br + 1]], axis=-1)

@@ -3,7 +3,7 @@ integer work counters of the insta snapshots, SUNDIALS solution tables, analytic
 import numpy as np
 import pytest
 
-from helpers import METHOD, ORACLE_MODEL, robertson_params, times_of, weighted_error_norm
+from helpers import METHOD, ORACLE_MODEL, foodweb_out, heat2d_out, robertson_params, times_of, weighted_error_norm
 
 BDF_CASES = ["bdf_test_nalgebra_exponential_decay", "test_bdf_nalgebra_exponential_decay_algebraic", "test_bdf_nalgebra_robertson",
              "test_bdf_nalgebra_robertson_ode", "test_bdf_nalgebra_dydt_y2", "test_bdf_nalgebra_gaussian_decay"]
@@ -488,3 +488,65 @@ def test_complete_pivoting_lu_of_the_faer_solver_variant(O):
     sing = np.array([[[1.0, 2.0, 3.0], [2.0, 4.0, 6.0], [1.0, 0.0, 1.0]]])
     assert O.lu_solve_fullpiv(sing, np.ones((1, 3)))[1] == 1
 
+
+
+# ------------------------------------------------------------------ round 6: the reference's 2-D PDE test models (banded Jacobians)
+SOLVER_COUNTERS = ["number_of_linear_solver_setups", "number_of_steps", "number_of_error_test_failures", "number_of_nonlinear_solver_iterations",
+                   "number_of_nonlinear_solver_fails", "number_of_linear_solver_setups_from_checkpoint", "number_of_linear_solver_setups_from_first_convergence_fail",
+                   "number_of_linear_solver_setups_from_second_convergence_fail", "number_of_linear_solver_setups_from_error_test_fail",
+                   "number_of_linear_solver_setups_from_step_success"]
+
+
+def _pde2d(O, kats, which, det_pow=False):
+    tab = kats[which + "_table"]
+    size = tab["mgrid"] if which == "heat2d" else tab["nx"]
+    p = [1.0] if which == "heat2d" else [50.0, 1000.0]
+    O.set_det_pow(det_pow)
+    try:
+        s = O.OracleSolver(ORACLE_MODEL[which], p, model_size=size, rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["bdf"])
+        t = [pt["t"] for pt in tab["points"]]
+        y0 = s.state()["y"][0].copy()  # the state the solver starts from: made consistent for the DAEs (state.rs:84-162)
+        y, _ = s.solve_to_points(t[1:])
+    finally:
+        O.set_det_pow(False)
+    return tab, size, s, np.concatenate([y0[None], y[:, 0]], axis=0)
+
+
+@pytest.mark.parametrize("det_pow", [False, True])
+@pytest.mark.parametrize("which,snap", [("heat2d", "test_bdf_faer_sparse_heat2d"), ("foodweb", "test_bdf_faer_sparse_foodweb")])
+def test_oracle_reproduces_the_solver_counters_of_the_2d_pde_snapshots(O, kats, which, snap, det_pow):
+    """bdf.rs:2424-2490: heat2d (n = 100, band 10, boundary rows algebraic) and foodweb (n = 200, band 20, predators algebraic, consistent initialisation, 13 Newton
+    failures) through BDF.  The reference pins them with FaerSparseLU and a coloured sparse Jacobian; the ten OdeSolverStatistics counters do not depend on the linear
+    algebra (the dense partial-pivot LU of the oracle reproduces every one of them), the rhs call and matrix evaluation counts of heat2d neither; number_of_jac_muls
+    does (n per dense matrix evaluation instead of one per colour) and is not compared."""
+    _, _, s, _ = _pde2d(O, kats, which, det_pow)
+    expected = kats["pde2d_snapshots"][snap]
+    got = s.stats()
+    assert {k: got[k] for k in SOLVER_COUNTERS} == {k: expected[k] for k in SOLVER_COUNTERS}
+    for k in ("number_of_calls", "number_of_matrix_evals"):
+        if k in expected:
+            assert got[k] == expected[k]
+
+
+def test_oracle_heat2d_table(O, kats):
+    """heat2d.rs:267-287: out = (||u||_2 dx)^2 at 12 times, the reference's acceptance norm (< 20 at rtol = atol = 1e-5)"""
+    tab, m, _, y = _pde2d(O, kats, "heat2d")
+    for k, pt in enumerate(tab["points"]):
+        assert weighted_error_norm(heat2d_out(y[k], m)[None], pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+
+
+def test_oracle_foodweb_table(O, kats):
+    """foodweb.rs:988-1050: corner values of prey and predator at 7 times; t = 0 is the state AFTER the consistent initialisation (predators 99999 / 99949, not the flat 1e5)"""
+    tab, nx, _, y = _pde2d(O, kats, "foodweb")
+    for k, pt in enumerate(tab["points"]):
+        assert weighted_error_norm(foodweb_out(y[k], nx), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+
+
+def test_the_2d_pde_jacobians_have_the_declared_bandwidth(O):
+    """half-bandwidth mgrid of heat2d and 2 nx of foodweb (what the banded LU is told), from the oracle's column-by-column Jacobians"""
+    for model, size, p, k in ((ORACLE_MODEL["heat2d"], 6, [1.3], 6), (ORACLE_MODEL["foodweb"], 5, [50.0, 1000.0], 10)):
+        n = O.model_dims(model, size)["n"]
+        x = O.model_init(model, p, model_size=size) * (1.0 + 0.01 * np.arange(n))
+        J = np.stack([O.model_jac_mul(model, x, p, np.eye(n)[j], model_size=size) for j in range(n)], axis=1)
+        i, j = np.nonzero(J)
+        assert np.abs(i - j).max() == k and np.count_nonzero(J) <= n * (2 * 2 + 2)
