@@ -385,7 +385,11 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     const std::string tail = std::string(ba ? "true" : "false") + ", " + (C.r.o.group == 64 ? "true" : "false") + (sens ? ", false, true>" : ">");  // SENS: <.., SEG = false, SENS = true>
     const std::string name = sched ? std::string("dsh::k_bdf_member_sched<dsh::JitModel, ") + (ba ? "true" : "false") + ">"
                              : lane_v2 ? "dsh::k_bdf_lane_banded<dsh::JitModel, " + tail : "dsh::k_bdf_adaptive<dsh::JitModel, " + tail;
-    rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : (lane_v2 ? "dsh_lane_banded_kernel.hpp" : "dsh_adaptive_kernel.hpp"), name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
+    // the banded lane kernel has two code objects: below four wavefronts per SIMD-quartet of the device (nb / (CUs x 64) < 4: one GPU's 32 768-member share of BASELINE
+    // config 4 is 2) the small-ensemble build (dsh_jit.hip compile_module: one wavefront per SIMD, deeper unrolling, doubled chunks); DSH_LANE_BANDED_SMALL=0 / 1 forces
+    static const int small_env = [] { const char* e = std::getenv("DSH_LANE_BANDED_SMALL"); return e && *e ? std::atoi(e) : -1; }();
+    const bool small = lane_v2 && !sched && (small_env >= 0 ? small_env != 0 : nb < (int64_t)4 * 64 * ctx->num_cu);
+    rc = jit_launch(ctx, model, sched ? "dsh_member_sched_kernel.hpp" : (lane_v2 ? "dsh_lane_banded_kernel.hpp" : "dsh_adaptive_kernel.hpp"), small ? name + "#small" : name, {name}, name, grid, blk, 0, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out,
                     stats, status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) { if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } dsh_free(ctx, totals_dev); return rc; }
     launched = true;

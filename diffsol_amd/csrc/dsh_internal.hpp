@@ -120,6 +120,11 @@ struct dsh_lu {
   // pivots batch-fastest.
   int structure = 0;
   int band_k = 0;
+  // general band (dsh_lu_gband.hpp, max(kl, ku) in 5 .. 64): >= 0 when the current factors are in its system-major layout ((2 kl + ku + 1) n doubles per system, pivots
+  // [b][k]); band_k is 0 then
+  int gb_kl = -1, gb_ku = -1;
+  double* gb_work = nullptr;  // staged system-major copy of the operand's band (k_gband_stage), gb_work_len doubles, grown on demand
+  int64_t gb_work_len = 0;
   int packed_k = 0;  // > 0: a handle made by dsh_lu_create_banded — `factors` holds (3 packed_k + 1) n doubles per system and takes banded factorisations with K <= packed_k only
   int* band_probe = nullptr;
 };

@@ -225,17 +225,26 @@ void record_request(const std::string& tu, const char* header, const std::vector
 
 int compile_tu(const JitModelRec& rec, const std::string& tu, const char* header, const std::vector<std::string>& group, JitModule* out);
 
-int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out) {
+// group_key ending in "#small": the SMALL-ENSEMBLE code object of the banded lane-per-member BDF — below four wavefronts per SIMD-quartet the kernel
+// is bound by one wavefront's dependent chain, not by bandwidth: one wavefront per SIMD, loops over the state unrolled 8-fold, doubled streaming chunks
+// (profiles/r05_c4_knobs.log: 12.1 -> 10.9 ms and 36.4 -> 33.0 ms at 32 768 members of the battery model; slower at 262 144).  Same source, same bits; the
+// environment knobs still override.
+int compile_module(const JitModelRec& rec, const char* header, const std::vector<std::string>& group, JitModule* out, const std::string& group_key = std::string()) {
   std::string tu = "#include <hip/hip_runtime.h>\n#include \"diffsol_detpow.h\"\n";
   if (rec.info.form == DSH_JIT_FORM_STATIC_BANDED) {
+    const bool small = group_key.size() >= 6 && group_key.compare(group_key.size() - 6, 6, "#small") == 0;
     const char* w = std::getenv("DSH_BANDED_WAVES_PER_EU");  // tuning knob
     // loops over the state components stay rolled (the arrays live in per-lane memory anyway): the 42-state battery model compiles in 13 s instead of 43 s
     // and integrates 262 144 members in 0.245 s instead of 0.308 s.  DSH_BANDED_NOUNROLL=0 unrolls them like the register-resident kernels.
     const char* nu = std::getenv("DSH_BANDED_NOUNROLL");
     if (!(nu && nu[0] == '0')) tu += "#define DSH_NOUNROLL_N 1\n";
-    tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : "3") + "\n";  // k_bdf_lane_banded, same workload: 0.192 / 0.137 / 0.141 / 0.158 / 0.160 s at 2 / 3 / 4 / 6 / 8
-    if (const char* un = std::getenv("DSH_LANE_BANDED_UNROLL")) if (*un) tu += std::string("#define DSH_LANE_BANDED_UNROLL ") + un + "\n";  // tuning knob
-    if (const char* cs = std::getenv("DSH_LANE_BANDED_CHUNK_SCALE")) if (*cs) tu += std::string("#define DSH_LANE_BANDED_CHUNK_SCALE ") + cs + "\n";  // tuning knob
+    tu += std::string("#define DSH_LANE_BANDED_WAVES_PER_EU ") + (w && *w ? w : (small ? "1" : "3")) + "\n";  // k_bdf_lane_banded, same workload: 0.192 / 0.137 / 0.141 / 0.158 / 0.160 s at 2 / 3 / 4 / 6 / 8
+    const char* un = std::getenv("DSH_LANE_BANDED_UNROLL");  // tuning knob
+    if (un && *un) tu += std::string("#define DSH_LANE_BANDED_UNROLL ") + un + "\n";
+    else if (small) tu += "#define DSH_LANE_BANDED_UNROLL 8\n";
+    const char* cs = std::getenv("DSH_LANE_BANDED_CHUNK_SCALE");  // tuning knob
+    if (cs && *cs) tu += std::string("#define DSH_LANE_BANDED_CHUNK_SCALE ") + cs + "\n";
+    else if (small) tu += "#define DSH_LANE_BANDED_CHUNK_SCALE 2\n";
     if (const char* pd = std::getenv("DSH_LANE_BANDED_PAD")) if (*pd) tu += std::string("#define DSH_LANE_BANDED_PAD ") + pd + "\n";  // tuning knob: extra doubles in the per-lane frame
     tu += std::string("#define DSH_ADAPTIVE_WAVES_PER_EU ") + (w && *w ? w : "4") + "\n";  // measured on the 42-state battery model, 262 144 members: 0.45 / 0.37 / 0.39 / 0.31 / 0.33 / 0.33 s at 1 / 2 / 3 / 4 / 6 / 8
   }
@@ -369,7 +378,7 @@ int jit_get_function(int model, const char* header, const std::string& group_key
   auto& slot = rec->modules[key];
   if (!slot) {
     auto m = std::make_unique<JitModule>();
-    int rc = compile_module(*rec, header, group, m.get());
+    int rc = compile_module(*rec, header, group, m.get(), group_key);
     if (rc != DSH_OK) { rec->modules.erase(key); return rc; }
     slot = std::move(m);
   }
@@ -627,12 +636,15 @@ int dsh_model_precompile(int model_id, int family) {
     if (family == 2) units.push_back({"dsh_lane_banded_kernel.hpp", "dsh::k_bdf_lane_banded<dsh::JitModel, true, false>"});
     else for (int s = 3; s <= 4; ++s) units.push_back({"dsh_sdirk_kernel.hpp", "dsh::k_sdirk_resident<dsh::JitModel, true, false, " + std::to_string(s) + ">"});
     for (const auto& u : units) {
-      const std::string key = std::string(u.first) + "|" + u.second;
-      if (rec->modules.count(key) && rec->modules[key]) continue;
-      auto m = std::make_unique<JitModule>();
-      int rc = compile_module(*rec, u.first, {u.second}, m.get());
-      if (rc != DSH_OK) return rc;
-      rec->modules[key] = std::move(m);
+      for (int variant = 0; variant < (family == 2 ? 2 : 1); ++variant) {  // the BDF has a second code object for small ensembles (compile_module: "#small")
+        const std::string gkey = u.second + (variant ? "#small" : "");
+        const std::string key = std::string(u.first) + "|" + gkey;
+        if (rec->modules.count(key) && rec->modules[key]) continue;
+        auto m = std::make_unique<JitModule>();
+        int rc = compile_module(*rec, u.first, {u.second}, m.get(), gkey);
+        if (rc != DSH_OK) return rc;
+        rec->modules[key] = std::move(m);
+      }
     }
     return DSH_OK;
   }

@@ -14,6 +14,7 @@
 #include "dsh_lu_coop.hpp"
 #include "dsh_lu_wave.hpp"
 #include "dsh_lu_band.hpp"
+#include "dsh_lu_gband.hpp"
 #include "dsh_lu_band_team.hpp"
 #include "dsh_lu_band_affine.hpp"
 #include "dsh_lu_tiled.hpp"
@@ -83,6 +84,48 @@ __global__ void k_lu_solve_multi_reg(int64_t nb, int64_t nrhs, const double* __r
 
 }  // namespace
 
+namespace {
+constexpr int64_t kGbMaxN = 1024;  // the solve keeps the right-hand side in registers: 16 per lane
+// factor every system's band (kl, ku) with the one-wavefront-per-system kernel; the operand is a dense container or (packed) a band container of bandwidths (pkl, pku)
+int gband_factor_launch(dsh_lu* lu, const double* a, int kl, int ku, bool packed, int pkl, int pku) {
+  dsh_ctx* ctx = lu->ctx;
+  const int64_t n = lu->n, nb = lu->nbatch;
+  lu->factored = true;  // (the caller has advanced lu->singular_epoch)
+  lu->band_k = 0;
+  lu->gb_kl = kl; lu->gb_ku = ku;
+  const int Wb = kl + ku + 1;
+  const int64_t need = n * Wb * nb;
+  if (lu->gb_work_len < need) {
+    if (lu->gb_work) (void)dsh_free(ctx, lu->gb_work);
+    lu->gb_work = nullptr; lu->gb_work_len = 0;
+    if (dsh_malloc(ctx, (int64_t)sizeof(double) * need, 0, (void**)&lu->gb_work) != DSH_OK) { lu->gb_work = nullptr; return DSH_E_HIP; }
+    lu->gb_work_len = need;
+  }
+  const dim3 sg((unsigned)((nb + 31) / 32), (unsigned)((n * Wb + 31) / 32));
+  if (packed) hipLaunchKernelGGL((k_gband_stage<true>), sg, dim3(256), 0, ctx->stream, (int)n, nb, kl, ku, a, pkl, pku, lu->gb_work);
+  else hipLaunchKernelGGL((k_gband_stage<false>), sg, dim3(256), 0, ctx->stream, (int)n, nb, kl, ku, a, pkl, pku, lu->gb_work);
+  const int waves = gband_factor_waves(kl, ku);
+  const size_t lds = gband_window_bytes(kl, ku) * (size_t)waves;
+  const unsigned grid = (unsigned)((nb + waves - 1) / waves);
+  const int cpl = (Wb + 63) / 64;
+#define DSH_GB_FACTOR(CPLV)                                                                                                                                       \
+  do {                                                                                                                                                            \
+    if (lds > (size_t)64 * 1024) {                                                                                                                                \
+      static signed char attr_dev[64] = {0};                                                                                                                      \
+      signed char& at = attr_dev[ctx->device & 63];                                                                                                               \
+      if (at == 0) { at = hipFuncSetAttribute((const void*)k_lu_gband_factor<CPLV>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024) == hipSuccess ? 1 : -1; (void)hipGetLastError(); } \
+      if (at < 0) { set_error("dsh_lu: the device refuses 72 KB of LDS for the general banded factorisation"); return DSH_E_HIP; }                               \
+    }                                                                                                                                                             \
+    hipLaunchKernelGGL((k_lu_gband_factor<CPLV>), dim3(grid), dim3(64 * waves), lds, ctx->stream, (int)n, nb, kl, ku, (const double*)lu->gb_work, lu->factors,    \
+                       lu->pivots, lu->singular, lu->singular_epoch);                                                                                             \
+  } while (0)
+  if (cpl == 1) DSH_GB_FACTOR(1); else if (cpl == 2) DSH_GB_FACTOR(2); else DSH_GB_FACTOR(3);
+#undef DSH_GB_FACTOR
+  DSH_HIP_CHECK(hipGetLastError());
+  return DSH_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int dsh_lu_create(dsh_ctx* ctx, int64_t n, int64_t nbatch, dsh_lu** out) {
@@ -125,6 +168,7 @@ void dsh_lu_destroy(dsh_lu* lu) {
   (void)dsh_free(lu->ctx, lu->factors);
   (void)dsh_free(lu->ctx, lu->pivots);
   (void)dsh_free(lu->ctx, lu->work);
+  (void)dsh_free(lu->ctx, lu->gb_work);
   (void)hipFree(lu->singular);
   (void)hipFree(lu->band_probe);
   delete lu;
@@ -138,7 +182,7 @@ int dsh_lu_set_structure(dsh_lu* lu, int structure) {
   lu->structure = structure;
   return DSH_OK;
 }
-int dsh_lu_band_width(const dsh_lu* lu) { return lu->band_k; }
+int dsh_lu_band_width(const dsh_lu* lu) { return lu->gb_kl >= 0 ? std::max(lu->gb_kl, lu->gb_ku) : lu->band_k; }
 
 int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   DSH_ENTER(lu ? lu->ctx : nullptr);
@@ -146,7 +190,7 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   const int64_t n = lu->n, nb = lu->nbatch;
   if (n == 0) return DSH_OK;
   { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
-  if (lu->band_k > 0) { set_error("dsh_lu_download: the current factors are banded (dsh_lu_band_width); factor with DSH_LU_STRUCTURE_DENSE to download dense factors"); return DSH_E_UNSUPPORTED; }
+  if (lu->band_k > 0 || lu->gb_kl >= 0) { set_error("dsh_lu_download: the current factors are banded (dsh_lu_band_width); factor with DSH_LU_STRUCTURE_DENSE to download dense factors"); return DSH_E_UNSUPPORTED; }
   if (lu->system_major) {  // already [b][col][row] / [b][k]
     if (factors_host) { int rc = dsh_d2h(ctx, factors_host, lu->factors, sizeof(double) * n * n * nb); if (rc != DSH_OK) return rc; }
     if (pivots_host) { int rc = dsh_d2h(ctx, pivots_host, lu->pivots, sizeof(int32_t) * n * nb); if (rc != DSH_OK) return rc; }
@@ -162,9 +206,9 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host) {
   return DSH_OK;
 }
 
-static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k);
-static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k) {
-  return timed_call(lu->ctx, DSH_TIMING_LU_FACTOR, [&] { return lu_factor_core(lu, a, declared_k); });
+static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k, int declared_kl, int declared_ku);
+static int lu_factor_impl(dsh_lu* lu, const double* a, int declared_k, int declared_kl = -1, int declared_ku = -1) {
+  return timed_call(lu->ctx, DSH_TIMING_LU_FACTOR, [&] { return lu_factor_core(lu, a, declared_k, declared_kl, declared_ku); });
 }
 
 int dsh_lu_factor(dsh_lu* lu, const double* a) { DSH_ENTER(lu ? lu->ctx : nullptr); return lu_factor_impl(lu, a, -1); }
@@ -172,7 +216,7 @@ int dsh_lu_factor(dsh_lu* lu, const double* a) { DSH_ENTER(lu ? lu->ctx : nullpt
 // 65 536 members: 0.9 GB instead of 137 GB).  Takes dsh_lu_factor_packed with max(kl, ku) <= k; the solve is dsh_lu_solve as for any handle.
 int dsh_lu_create_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int k, dsh_lu** out) {
   DSH_ENTER(ctx);
-  DSH_REQUIRE(k >= 1 && k <= 4, "dsh_lu_create_banded: k must be in 1..4");
+  DSH_REQUIRE(k >= 1 && k <= kGbMaxK, "dsh_lu_create_banded: k must be in 1..64");
   DSH_REQUIRE(n >= 16, "dsh_lu_create_banded: n must be at least 16 (smaller systems use the dense kernels)");
   int rc = dsh_lu_create(ctx, n, nbatch, out);
   if (rc != DSH_OK) return rc;
@@ -185,15 +229,23 @@ int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku) {
   DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(lu != nullptr && band != nullptr && kl >= 0 && ku >= 0, "bad arguments");
   const int k = std::max(1, std::max(kl, ku));
-  DSH_REQUIRE(k <= 4, "dsh_lu_factor_packed: bandwidths up to 4");
+  DSH_REQUIRE(k <= kGbMaxK, "dsh_lu_factor_packed: bandwidths up to 64");
   DSH_REQUIRE(lu->n >= 16, "dsh_lu_factor_packed: n must be at least 16");
   if (lu->packed_k > 0 && k > lu->packed_k) { set_error("dsh_lu_factor_packed: the operand is wider than the handle's factor storage"); return DSH_E_INVALID; }
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
+  if (k > 4) {  // general bandwidth: one wavefront per system (dsh_lu_gband.hpp)
+    DSH_REQUIRE(lu->packed_k > 0 || (int64_t)(2 * kl + ku + 1) <= n, "dsh_lu_factor_packed: the band's factors do not fit a dense handle's storage");
+    DSH_REQUIRE(n <= kGbMaxN, "dsh_lu_factor_packed: general bandwidths (k > 4) up to n = 1024");
+    { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
+    lu->singular_epoch += 1;
+    return gband_factor_launch(lu, band, kl, ku, true, kl, ku);
+  }
   { const int rc = lu_ensure_storage(lu); if (rc != DSH_OK) return rc; }
   lu->singular_epoch += 1;
   lu->factored = true;
   lu->band_k = k;
+  lu->gb_kl = lu->gb_ku = -1;
   const dim3 bg = grid_for(nb, 64), bblk(64);
   switch (k) {
     case 1: hipLaunchKernelGGL((k_lu_band_factor<1, true>), bg, bblk, 0, ctx->stream, n, nb, band, lu->factors, lu->pivots, lu->singular, lu->singular_epoch, kl, ku); break;
@@ -207,10 +259,10 @@ int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku) {
 int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku) {
   DSH_ENTER(lu ? lu->ctx : nullptr);
   DSH_REQUIRE(kl >= 0 && ku >= 0, "bandwidths must be non-negative");
-  return lu_factor_impl(lu, a, std::max(1, std::max(kl, ku)));
+  return lu_factor_impl(lu, a, std::max(1, std::max(kl, ku)), kl, ku);
 }
 
-static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
+static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k, int declared_kl, int declared_ku) {
   if (lu->packed_k > 0) { set_error("this LU handle was made by dsh_lu_create_banded: it takes band containers (dsh_lu_factor_packed), not dense operands"); return DSH_E_UNSUPPORTED; }
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
@@ -226,10 +278,14 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
     DSH_LU_FACTOR_CASE(5) DSH_LU_FACTOR_CASE(6) DSH_LU_FACTOR_CASE(7) DSH_LU_FACTOR_CASE(8)
     default: {
       lu->band_k = 0;
+      lu->gb_kl = lu->gb_ku = -1;
       static const bool check_declared = [] { const char* e = getenv("DSH_CHECK_BAND"); return e && atoi(e) != 0; }();
       if (lu->structure == DSH_LU_STRUCTURE_AUTO && n >= 16) {  // dense container of a narrow band?
-        int k = declared_k;
-        if (k < 0 || k > 4 || check_declared) {  // not declared by the caller (or declared too wide — a declaration is an upper bound): one read of the operand decides
+        int k = declared_k, gkl = declared_kl, gku = declared_ku;  // the general banded kernels take the two bandwidths separately
+        static const bool gband_on = [] { const char* e = getenv("DSH_LU_GBAND"); return !e || atoi(e) != 0; }();  // DSH_LU_GBAND=0: the dense kernels for every band wider than 4
+        // a declared band wider than 4 is taken at its word by the general banded kernels (a declaration is an upper bound; DSH_CHECK_BAND verifies it)
+        const bool declared_general = gband_on && k > 4 && k <= kGbMaxK && gkl >= 0 && gku >= 0 && n <= kGbMaxN && (int64_t)(2 * gkl + gku + 1) * 2 <= n;
+        if (k < 0 || (k > 4 && !declared_general) || check_declared) {  // not declared by the caller (or declared too wide — a declaration is an upper bound): one read of the operand decides
           DSH_HIP_CHECK(hipMemsetAsync(lu->band_probe, 0, 2 * sizeof(int), ctx->stream));
           int64_t pblocks = (n * n * nb + 255) / 256;
           if (pblocks > 8192) pblocks = 8192;
@@ -239,7 +295,12 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k) {
           DSH_HIP_CHECK(hipStreamSynchronize(ctx->stream));
           const int probed = std::max(1, std::max(h[0], h[1]));
           if (k >= 0 && probed > k) { set_error("dsh_lu_factor_banded: the operand has entries outside the declared band (DSH_CHECK_BAND)"); return DSH_E_INVALID; }
-          if (k < 0 || k > 4) k = probed;
+          if (k < 0 || (k > 4 && !declared_general)) { k = probed; gkl = h[0]; gku = h[1]; }
+        }
+        if (gband_on && k > 4 && k <= kGbMaxK && gkl >= 0 && gku >= 0 && n <= kGbMaxN && (int64_t)(2 * gkl + gku + 1) * 2 <= n) {
+          const int rc = gband_factor_launch(lu, a, gkl, gku, false, 0, 0);
+          if (rc != DSH_OK) return rc;
+          break;
         }
         if (k <= 4) {
           lu->band_k = k;
@@ -445,6 +506,23 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
   if (n == 0) return DSH_OK;
   unsigned long long* rec; unsigned int seq;
   dim3 g = grid_for(nb, ctx->block), blk(ctx->block);
+  if (n > 8 && lu->gb_kl >= 0) {  // general banded factors: one wavefront per system, the right-hand side in registers
+    g = dim3((unsigned)((nb + kGbSolveWaves - 1) / kGbSolveWaves));
+    int rc = begin_records(ctx, g.x, &rec, &seq);
+    if (rc != DSH_OK) return rc;
+#define DSH_GB_SOLVE(MBV) hipLaunchKernelGGL((k_lu_gband_solve<MBV>), g, dim3(64 * kGbSolveWaves), 0, ctx->stream, (int)n, nb, lu->gb_kl, lu->gb_ku, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
+    if (n <= 128) DSH_GB_SOLVE(2); else if (n <= 256) DSH_GB_SOLVE(4); else if (n <= 512) DSH_GB_SOLVE(8); else DSH_GB_SOLVE(16);
+#undef DSH_GB_SOLVE
+    DSH_HIP_CHECK(hipGetLastError());
+    if (!wait) { *gx_out = g.x; *seq_out = seq; return DSH_OK; }
+    rc = fetch_records(ctx, g.x, seq);
+    if (rc != DSH_OK) return rc;
+    if (ctx->res_cnt != 0ull) {
+      set_error("dsh_lu_solve: zero pivot in " + std::to_string((long long)ctx->res_cnt) + " system(s) (LuSolveFailed)");
+      return DSH_E_SINGULAR;
+    }
+    return DSH_OK;
+  }
   if (n > 8 && lu->band_k > 0) {  // banded factors: one lane per system
     // small ensembles, long chains: one workgroup per 16-64 systems, a chain wavefront fed through LDS by four loader wavefronts (k_lu_band_solve_team: same
     // bits, the memory traffic off the chain wavefront's instruction stream); DSH_LU_BAND_WIDE=2 selects the round-2 kernel instead (8 systems per wavefront,

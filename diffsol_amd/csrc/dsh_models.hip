@@ -107,8 +107,26 @@ __global__ void k_dyn_root(int model, int64_t n, int64_t nb, double t, const dou
   for (int r = 0; r < nr; ++r) g[(int64_t)r * nb + b] = gg[r];
 }
 
+// y = M x + beta y for the run-time-sized registry models with a (diagonal, 0 / 1) mass matrix: the reference's closures entry by entry (x + beta y, or beta y on an algebraic row)
+__global__ void k_dyn_mass_gemv(int model, int64_t n, int64_t nb, const double* __restrict__ x, double beta, double* __restrict__ y) {
+  int64_t total = n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / nb;
+    y[idx] = dyn_mass_diag(model, n, i) != 0.0 ? x[idx] + beta * y[idx] : beta * y[idx];
+  }
+}
+// the dense n x n mass matrix (what LinearOp::matrix assembles from gemv with unit vectors: 1 * e_j + 0 * y)
+__global__ void k_dyn_mass_matrix(int model, int64_t n, int64_t nb, double* __restrict__ mass) {
+  int64_t total = n * n * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = idx / nb, i = e % n, j = e / n;
+    mass[idx] = i == j ? dyn_mass_diag(model, n, i) : 0.0;
+  }
+}
+bool dyn_model_has_mass(int model) { return model == DSH_MODEL_HEAT2D || model == DSH_MODEL_FOODWEB; }
+
 bool is_dynamic_model(int model, int64_t size) {
-  return model == DSH_MODEL_DYDT_Y2 || model == DSH_MODEL_GAUSSIAN_DECAY || model == DSH_MODEL_HEAT1D || model == DSH_MODEL_SPM ||
+  return model == DSH_MODEL_DYDT_Y2 || model == DSH_MODEL_GAUSSIAN_DECAY || model == DSH_MODEL_HEAT1D || model == DSH_MODEL_SPM || model == DSH_MODEL_HEAT2D || model == DSH_MODEL_FOODWEB ||
          (model == DSH_MODEL_ROBERTSON_ODE && size > 1);
 }
 
@@ -188,6 +206,8 @@ int dsh_model_info(int model, int64_t size, int64_t* nstates, int64_t* nparams, 
       case DSH_MODEL_HEAT1D: n = size; np = 1; break;
       case DSH_MODEL_ROBERTSON_ODE: n = 3 * size; np = 3; break;
       case DSH_MODEL_SPM: n = 2 + 2 * (size <= 0 ? 20 : size); np = 1; nr = 2; break;
+      case DSH_MODEL_HEAT2D: { const int64_t m = size <= 0 ? 10 : size; DSH_REQUIRE(m >= 3, "heat2d: a grid of at least 3 x 3"); n = m * m; np = 1; hm = 1; break; }
+      case DSH_MODEL_FOODWEB: { const int64_t m = size <= 0 ? 10 : size; DSH_REQUIRE(m >= 2, "foodweb: a grid of at least 2 x 2"); n = 2 * m * m; np = 2; hm = 1; break; }
       default: set_error("dsh_model_info: unknown model id"); return DSH_E_INVALID;
     }
     DSH_REQUIRE(n > 0, "model size must be positive");
@@ -320,9 +340,14 @@ int dsh_model_mass_gemv(dsh_ctx* ctx, int model, int64_t size, int64_t nb, doubl
   bool handled = false;
   int rc = launch_static<Op::MassGemv>(ctx, model, size, nb, t, x, p, nullptr, beta, y, &handled);
   if (rc != DSH_OK || handled) return rc;
-  // run-time-sized models have identity mass: y = x + beta*y
   DSH_REQUIRE(is_dynamic_model(model, size), "unknown model id");
   int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+  if (dyn_model_has_mass(model)) {  // heat2d / foodweb: diagonal 0 / 1 mass
+    hipLaunchKernelGGL(k_dyn_mass_gemv, ew_grid(n * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, x, beta, y);
+    DSH_HIP_CHECK(hipGetLastError());
+    return DSH_OK;
+  }
+  // the other run-time-sized models have identity mass: y = x + beta*y
   return dsh_vec_axpy(ctx, n, nb, 1.0, x, nb, beta, y);
 }
 int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, double t, const double* p, double* mass) {
@@ -331,6 +356,12 @@ int dsh_model_mass_matrix(dsh_ctx* ctx, int model, int64_t size, int64_t nb, dou
   bool handled = false;
   int rc = launch_static<Op::MassMatrix>(ctx, model, size, nb, t, nullptr, p, nullptr, 0.0, mass, &handled);
   if (rc != DSH_OK || handled) return rc;
+  if (is_dynamic_model(model, size) && dyn_model_has_mass(model)) {
+    int64_t n; dsh_model_info(model, size, &n, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_dyn_mass_matrix, ew_grid(n * n * nb), dim3(kBlock), 0, ctx->stream, model, n, nb, mass);
+    DSH_HIP_CHECK(hipGetLastError());
+    return DSH_OK;
+  }
   set_error("dsh_model_mass_matrix: model has no mass matrix");
   return DSH_E_UNSUPPORTED;
 }
@@ -378,6 +409,8 @@ int dsh_model_band(int model, int64_t size, int* jac_kl, int* jac_ku, int* mass_
       case DSH_MODEL_HEAT1D: case DSH_MODEL_SPM: jl = ju = 1; break;
       case DSH_MODEL_DYDT_Y2: case DSH_MODEL_GAUSSIAN_DECAY: jl = ju = 0; break;
       case DSH_MODEL_ROBERTSON_ODE: jl = ju = 2; break;
+      case DSH_MODEL_HEAT2D: jl = ju = (int)(size <= 0 ? 10 : size); break;       // the 5-point stencil's +-m neighbours
+      case DSH_MODEL_FOODWEB: jl = ju = (int)(2 * (size <= 0 ? 10 : size)); break;  // two species per grid point
       default: break;
     }
   }

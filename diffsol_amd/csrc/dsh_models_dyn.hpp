@@ -9,6 +9,8 @@
 
 namespace dsh {
 
+__host__ __device__ inline int64_t dyn_isqrt(int64_t v) { int64_t r = (int64_t)(sqrt((double)v) + 0.5); while (r * r > v) --r; while ((r + 1) * (r + 1) <= v) ++r; return r; }
+
 // value of component i of f(x) (or of J(x) v when `v` is given) for the dynamic models; X(i)/V(i) read system b
 template <class XF, class VF, class PF>
 __device__ __forceinline__ double dyn_component(int model, int64_t n, double t, int64_t i, XF X, VF V, PF P, bool jac) {
@@ -40,6 +42,36 @@ __device__ __forceinline__ double dyn_component(int model, int64_t n, double t, 
       if (!jac && k == m - 1) acc += (pos ? 4.106800547504748e-12 * 243644455.17866704 : 3.2835305549534856e-12 * -520607810.21082705) * P(0);
       return acc;
     }
+    case DSH_MODEL_HEAT2D: {  // test_models/heat2d.rs:105-123 (rhs), :125-149 (jac_mul): 5-point differences on an m x m grid, boundary rows res_i = u_i
+      const int64_t m = dyn_isqrt(n), jy = i / m, ix = i % m;
+      auto U = [&](int64_t k) { return jac ? V(k) : X(k); };
+      if (jy == 0 || jy == m - 1 || ix == 0 || ix == m - 1) return U(i);  // y.copy_from(x): the boundary equations
+      const double mm = (double)m, four = 4.0;
+      const double dx = 1.0 / (mm - 1.0);
+      const double coeff = P(0) / (dx * dx);  // P(0) = 1: the reference's 1 / (dx dx)
+      return coeff * (U(i - 1) + U(i + 1) + U(i - m) + U(i + m) - four * U(i));
+    }
+    case DSH_MODEL_FOODWEB: {  // test_models/foodweb.rs:419-494 (rhs), :502-582 (jac_mul): species interleaved, Neumann boundaries by mirror points
+      const int64_t nx = dyn_isqrt(n / 2), nsmx = 2 * nx;
+      const int64_t is = i & 1, loc = i - is, jx = (loc / 2) % nx, jy = (loc / 2) / nx;
+      const double dx = 1.0 / ((double)nx - 1.0), dy = 1.0 / ((double)nx - 1.0);
+      const double yy = (double)jy * dy, xx = (double)jx * dx;
+      const int64_t idyu = jy != nx - 1 ? nsmx : -nsmx, idyl = jy != 0 ? nsmx : -nsmx, idxu = jx != nx - 1 ? 2 : -2, idxl = jx != 0 ? 2 : -2;
+      const int64_t locxu = loc + idxu, locxl = loc - idxl, locyu = loc + idyu, locyl = loc - idyl;
+      const double AA = 1.0, EE = 10000.0, GG = 0.5e-6, BB = 1.0, DPREY = 1.0, DPRED = 0.05;
+      const double a0 = is == 0 ? -AA : EE, a1 = is == 0 ? -GG : -AA;  // acoef[is][0], acoef[is][1]
+      const double bco = is == 0 ? BB : -BB;
+      const double cox = (is == 0 ? DPREY : DPRED) / (dx * dx), coy = (is == 0 ? DPREY : DPRED) / (dy * dy);
+      double dp = 0.0, ddp = 0.0;
+      dp += a0 * X(loc); dp += a1 * X(loc + 1);
+      if (jac) { ddp += a0 * V(loc); ddp += a1 * V(loc + 1); }
+      const double fac = 1.0 + P(0) * xx * yy + P(1) * dsh_det_sin(4.0 * 3.14159265358979323846 * xx) * dsh_det_sin(4.0 * 3.14159265358979323846 * yy);
+      const double rate = jac ? X(i) * ddp + V(i) * (bco * fac + dp) : X(i) * (bco * fac + dp);
+      auto U = [&](int64_t k) { return jac ? V(k) : X(k); };
+      const double dcyli = U(i) - U(locyl + is), dcyui = U(locyu + is) - U(i);
+      const double dcxli = U(i) - U(locxl + is), dcxui = U(locxu + is) - U(i);
+      return coy * (dcyui - dcyli) + cox * (dcxui - dcxli) + rate;
+    }
     case DSH_MODEL_ROBERTSON_ODE: {  // test_models/robertson_ode.rs:71-90
       int64_t g = (i / 3) * 3, r = i % 3;
       if (!jac) {
@@ -64,8 +96,34 @@ __device__ __forceinline__ double dyn_init_value(int model, int64_t n, int64_t i
     case DSH_MODEL_HEAT1D: { double h = 1.0 / (double)(n + 1); double xx = (double)(i + 1) * h; return xx < 0.5 ? 2.0 * xx : 2.0 * (1.0 - xx); }
     case DSH_MODEL_ROBERTSON_ODE: return (i % 3 == 0) ? 1.0 : 0.0;
     case DSH_MODEL_SPM: return i < 2 ? 0.0 : (i < 2 + (n - 2) / 2 ? 0.8000000000000016 : 0.6000000000000001);  // spm.ds u_i
+    case DSH_MODEL_HEAT2D: {  // heat2d.rs:151-183
+      const int64_t m = dyn_isqrt(n), jy = i / m, ix = i % m;
+      if (jy == 0 || jy == m - 1 || ix == 0 || ix == m - 1) return 0.0;
+      const double mm = (double)m, one = 1.0, sixteen = 16.0;
+      const double dx = one / (mm - one);
+      const double yfact = dx * (double)jy, xfact = dx * (double)ix;
+      return sixteen * xfact * (one - xfact) * yfact * (one - yfact);
+    }
+    case DSH_MODEL_FOODWEB: {  // foodweb.rs:342-366: prey from a polynomial, predators flat 1e5 (corrected by the consistent initialisation)
+      if (i & 1) return 1.0e5;
+      const int64_t nx = dyn_isqrt(n / 2), jx = (i / 2) % nx, jy = (i / 2) / nx;
+      const double dx = 1.0 / ((double)nx - 1.0), dy = 1.0 / ((double)nx - 1.0);
+      const double yy = (double)jy * dy, xx = (double)jx * dx;
+      double xyfactor = 16.0 * xx * (1.0 - xx) * yy * (1.0 - yy);
+      xyfactor = xyfactor * xyfactor;
+      return 10.0 + 1.0 * xyfactor;
+    }
   }
   return 0.0;
+}
+
+// diagonal of the mass matrix of the run-time-sized registry models that have one (heat2d.rs:185-205: boundary rows algebraic; foodweb.rs:639-655: predators algebraic)
+__device__ __forceinline__ double dyn_mass_diag(int model, int64_t n, int64_t i) {
+  switch (model) {
+    case DSH_MODEL_HEAT2D: { const int64_t m = dyn_isqrt(n), jy = i / m, ix = i % m; return (jy == 0 || jy == m - 1 || ix == 0 || ix == m - 1) ? 0.0 : 1.0; }
+    case DSH_MODEL_FOODWEB: return (i & 1) ? 0.0 : 1.0;
+  }
+  return 1.0;
 }
 
 // ---- terminal voltage of the single-particle model (spm.ds varying2..5, out_i) and its two stop conditions

@@ -13,6 +13,7 @@ METHOD_BDF, METHOD_TR_BDF2, METHOD_ESDIRK34 = 0, 1, 2
 MODELS = {
     "exponential_decay": 0, "exponential_decay_with_algebraic": 1, "exponential_decay_with_algebraic_batched": 2, "robertson_ode": 3,
     "robertson": 4, "dydt_y2": 5, "gaussian_decay": 6, "heat1d": 7, "rlc": 8, "exponential_decay_with_root": 9, "spm": 10,
+    "heat2d": 11, "foodweb": 12,
 }
 
 STAT_NAMES = [

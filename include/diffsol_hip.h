@@ -260,6 +260,8 @@ int dsh_lu_download(dsh_lu* lu, double* factors_host, int32_t* pivots_host);
 #define DSH_MODEL_RLC 8                         /* n=4 DAE, p=[R,L,C,V0,omega,ithresh]; size!=0 adds root iR-ithresh  examples/electrical-circuits/src/main.rs:10-41 */
 #define DSH_MODEL_EXPONENTIAL_DECAY_ROOT 9      /* exponential decay + root x0-0.6  test_models/exponential_decay.rs:98-100 */
 #define DSH_MODEL_SPM 10                        /* single-particle battery model, n=2+2*size (size=0 -> 20 shells), p=[I], roots V-3.105, 4.1-V  book/src/primer/src/spm.ds */
+#define DSH_MODEL_HEAT2D 11                     /* 2-D heat equation, size x size grid, n=size^2, DAE (boundary rows algebraic), p=[diffusion scale] (1 = the reference), band size   test_models/heat2d.rs:105-205 */
+#define DSH_MODEL_FOODWEB 12                    /* predator-prey food web, size x size grid, n=2 size^2, DAE (predators algebraic), p=[alpha,beta] ((50,1000) = the reference), band 2 size   test_models/foodweb.rs:232-655 */
 
 /* ---- Run-time-compiled models: the device side of OdeBuilder::build_from_diffsl (crates/diffsol/src/ode_equations/diffsl.rs —
  * the reference JIT-compiles DiffSL to host code with Cranelift/LLVM).  `source` is the model as generated by dshs_diffsl_generate

@@ -28,6 +28,10 @@ pub enum Model {
     Rlc = ffi::DSH_MODEL_RLC as isize,
     ExponentialDecayRoot = ffi::DSH_MODEL_EXPONENTIAL_DECAY_ROOT as isize,
     Spm = ffi::DSH_MODEL_SPM as isize,
+    /// 2-D heat equation (test_models/heat2d.rs), `size x size` grid, boundary rows algebraic, half-bandwidth `size`: factored by the general banded LU
+    Heat2d = ffi::DSH_MODEL_HEAT2D as isize,
+    /// predator-prey food web (test_models/foodweb.rs), `size x size` grid, predators algebraic, half-bandwidth `2 size`
+    Foodweb = ffi::DSH_MODEL_FOODWEB as isize,
 }
 
 /// Operator call counters like the reference's `OpStatistics` (op/mod.rs:95-128).

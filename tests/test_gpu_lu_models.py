@@ -112,7 +112,8 @@ def test_lu_cooperative_kernels_report_singular_members(H, ctx1, n):
 
 
 MODEL_CASES = [("exponential_decay", 0, 2), ("exponential_decay_with_algebraic", 0, 1), ("robertson_ode", 1, 3), ("robertson_ode", 3, 3), ("robertson", 0, 3),
-               ("dydt_y2", 10, 0), ("gaussian_decay", 10, 10), ("heat1d", 16, 1), ("rlc", 0, 6), ("spm", 20, 1), ("spm", 5, 1)]
+               ("dydt_y2", 10, 0), ("gaussian_decay", 10, 10), ("heat1d", 16, 1), ("rlc", 0, 6), ("spm", 20, 1), ("spm", 5, 1),
+               ("heat2d", 6, 1), ("heat2d", 10, 1), ("foodweb", 5, 2), ("foodweb", 10, 2)]
 
 
 @pytest.mark.parametrize("name,size,np_", MODEL_CASES)
@@ -327,7 +328,7 @@ def test_banded_operands_in_dense_containers_are_solved_by_the_banded_kernels_wi
     assert np.array_equal(x2.clone_as_vec(), O.lu_solve(a, b2)[0])
     wide = _banded(rng, nb, n, 5, 0, True)
     lu.factor(H.HipMat.from_array(wide, c))
-    assert lu.band_width() == 0
+    assert lu.band_width() == (5 if 2 * (2 * 5 + 0 + 1) <= n else 0)  # round 6: wider bands go to the general banded kernels where their factors pay (tests/test_gpu_lu_gband.py)
     x3 = H.HipVec.from_vec(b, c)
     lu.solve_in_place(x3)
     assert np.array_equal(x3.clone_as_vec(), O.lu_solve(wide, b)[0])
