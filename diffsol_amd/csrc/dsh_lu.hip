@@ -314,13 +314,13 @@ static int lu_factor_core(dsh_lu* lu, const double* a, int declared_k, int decla
           break;
         }
       }
-      // Default for 288 <= n <= 1024: the matrix-core kernel on a row-major working copy (dsh_lu_tiled.hpp): same pivots, factors within rounding of the
+      // Default for 256 <= n <= 1024: the matrix-core kernel on a row-major working copy (dsh_lu_tiled.hpp): same pivots, factors within rounding of the
       // exact kernels' (fused multiply-adds, the matrix cores' summation order).  DSH_LU_EXACT=1 keeps the kernels below, bit-identical to the CPU path;
       // DSH_LU_TILED_MIN moves the lower end (measured crossover with the exact blocked kernel: 13.3 vs 16.8 ms at 256 x 4096, 33.4 vs 19.0 ms at 320 x 4096).  Both read per call so that tests can compare.
       {
         const char* ex = getenv("DSH_LU_EXACT");
         const char* tm = getenv("DSH_LU_TILED_MIN");
-        const int64_t tiled_min = tm && *tm ? atoll(tm) : 288;
+        const int64_t tiled_min = tm && *tm ? atoll(tm) : 256;  // round 6: 256 (5.3 against 13.3 ms at 256 x 4096 for the exact blocked kernel, DESIGN 16.11 lead 1)
         if (!(ex && ex[0] == '1') && n >= std::max<int64_t>(tiled_min, 65) && n <= kTlMaxN) {
           const int ldw = tiled_ldw(n);
           if (!lu->work) {
@@ -510,8 +510,9 @@ static int lu_solve_launch_core(const dsh_lu* lu, double* rhs, bool wait, unsign
     g = dim3((unsigned)((nb + kGbSolveWaves - 1) / kGbSolveWaves));
     int rc = begin_records(ctx, g.x, &rec, &seq);
     if (rc != DSH_OK) return rc;
-#define DSH_GB_SOLVE(MBV) hipLaunchKernelGGL((k_lu_gband_solve<MBV>), g, dim3(64 * kGbSolveWaves), 0, ctx->stream, (int)n, nb, lu->gb_kl, lu->gb_ku, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
-    if (n <= 128) DSH_GB_SOLVE(2); else if (n <= 256) DSH_GB_SOLVE(4); else if (n <= 512) DSH_GB_SOLVE(8); else DSH_GB_SOLVE(16);
+#define DSH_GB_SOLVE(MBV, W3V) hipLaunchKernelGGL((k_lu_gband_solve<MBV, W3V>), g, dim3(64 * kGbSolveWaves), gband_solve_lds_bytes(W3V), ctx->stream, (int)n, nb, lu->gb_kl, lu->gb_ku, (const double*)lu->factors, (const int32_t*)lu->pivots, rhs, rec, seq)
+    if (lu->gb_kl + lu->gb_ku > 64) { if (n <= 128) DSH_GB_SOLVE(2, true); else if (n <= 256) DSH_GB_SOLVE(4, true); else if (n <= 512) DSH_GB_SOLVE(8, true); else DSH_GB_SOLVE(16, true); }
+    else { if (n <= 128) DSH_GB_SOLVE(2, false); else if (n <= 256) DSH_GB_SOLVE(4, false); else if (n <= 512) DSH_GB_SOLVE(8, false); else DSH_GB_SOLVE(16, false); }
 #undef DSH_GB_SOLVE
     DSH_HIP_CHECK(hipGetLastError());
     if (!wait) { *gx_out = g.x; *seq_out = seq; return DSH_OK; }

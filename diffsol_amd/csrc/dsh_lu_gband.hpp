@@ -16,8 +16,9 @@
 // the neighbours of a row lie n nb 8 bytes apart (3.3 MB at n = 100 x 4096 members): one DRAM page and one TLB entry per lane and step, 10 us per elimination
 // step (measured, profiles/r06_band_general.md).  Row j+kl+1 is fetched from the staged copy one step ahead.  One wavefront only ever talks to itself through
 // LDS: the synchronisation is a wave-level fence, no s_barrier.
-// Solves: the right-hand side stays in REGISTERS, element i in lane i % 64 (register i / 64); the pivot element of a step is broadcast with v_readlane, the
-// multipliers / U column of the step are read as contiguous runs (coalesced) and prefetched eight steps ahead, off the dependent chain.
+// Solves: the right-hand side stays in REGISTERS, element i in lane i % 64 (register i / 64); the pivot element of a step is broadcast with v_readlane; the
+// multipliers / U columns of a run of steps are one contiguous piece of the factor storage, fetched with full-width loads while the previous run's chain
+// executes and handed to the lanes through LDS.
 //
 // Factor layout (system-major, S = (2 kl + ku + 1) n doubles per system):  L: multiplier of row j+r at step j at  j * kl + (r - 1), r = 1 .. kl;
 // U BY COLUMNS: U(i - d, i) at  n * kl + i * (kl + ku + 1) + d, d = 0 .. kl+ku (d = 0: the diagonal) — what the backward substitution reads per step is one
@@ -195,15 +196,26 @@ __global__ __launch_bounds__(256) void k_lu_gband_factor(int n, int64_t nb, int 
   if (lane == 0 && sing) publish_singular(singular_count, sing, epoch);
 }
 
-// x <- A^-1 x for every system; MB = registers of the right-hand side per lane (n <= 64 MB).  Launch: ceil(nb / kGbSolveWaves) workgroups of 64 * kGbSolveWaves
-// threads.  The record of a workgroup carries the number of its systems that met a zero diagonal (LuSolveFailed).
-template <int MB>
+// x <- A^-1 x for every system; MB = registers of the right-hand side per lane (n <= 64 MB); W3: kl + ku > 64 (a column of U reaches three registers of the
+// right-hand side).  Launch: ceil(nb / kGbSolveWaves) workgroups of 64 * kGbSolveWaves threads, gband_solve_lds_bytes of LDS.  The record of a workgroup carries the
+// number of its systems that met a zero diagonal (LuSolveFailed).
+// Operand traffic: the multipliers of SB consecutive steps (and the U columns of SB consecutive steps) are ONE contiguous run of the factor storage.  A wavefront
+// fetches the next run with full-width loads (every lane 8 bytes, <= GQ instructions) while the chain of the current run executes, parks it in LDS, and the lanes
+// pick their operands of four steps at a time from there.  (First version: every lane fetched its own operand of every step from global memory — 10 - 20 live
+// lanes per load instruction, 600 load instructions per system at n = 100: bound by the issue rate of the vector memory pipeline at 1.0 - 1.5 TB/s.)
+template <bool W3> struct gband_solve_cfg { static constexpr int GQ = W3 ? 9 : 5; };  // registers per lane of one staged run: 576 / 320 doubles
+__host__ __device__ inline int gband_solve_sb(int width, int cap_doubles) { int sb = (cap_doubles / (width > 0 ? width : 1)) / 4 * 4; return sb < 4 ? 4 : (sb > 32 ? 32 : sb); }
+inline size_t gband_solve_lds_bytes(bool w3) { return sizeof(double) * 64 * (size_t)(w3 ? 9 : 5) * kGbSolveWaves; }
+template <int MB, bool W3>
 __global__ __launch_bounds__(64 * kGbSolveWaves) void k_lu_gband_solve(int n, int64_t nb, int kl, int ku, const double* __restrict__ fac, const int32_t* __restrict__ piv,
                                                                       double* __restrict__ rhs, unsigned long long* rec, unsigned int seq) {
-  constexpr int CH = 8;  // steps whose operands are fetched together
+  constexpr int CH = 4;                         // steps whose operands are read from LDS together
+  constexpr int GQ = gband_solve_cfg<W3>::GQ;   // a staged run is at most 64 GQ doubles
+  extern __shared__ double gb_stage_all[];
   const int Wc = kl + ku + 1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * kGbSolveWaves + wave;
+  double* stage = gb_stage_all + (size_t)wave * 64 * GQ;
   unsigned long long bad = 0ull;
   if (b < nb) {
     const double* Lc = fac + (size_t)b * gband_factor_doubles(n, kl, ku);
@@ -217,80 +229,124 @@ __global__ __launch_bounds__(64 * kGbSolveWaves) void k_lu_gband_solve(int n, in
       v[m] = row < n ? rhs[(int64_t)row * nb + b] : 0.0;
       pv[m] = row < n ? pvp[row] : row;
     }
+    double G[GQ];
+    auto gload = [&](const double* src, int len) {  // the next run into registers: lane, lane + 64, ... (len <= 64 GQ; len <= 0: nothing)
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) { const int e = lane + 64 * q; G[q] = e < len ? src[e] : 0.0; }
+    };
+    auto gpark = [&](int len) {  // ... and from the registers into this wavefront's LDS
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) { const int e = lane + 64 * q; if (e < len) stage[e] = G[q]; }
+    };
     // ---- forward: interchange j <-> piv[j], then rows j+1 .. j+kl take (-x_j) l + v
+    if (kl > 0) {
+      const int SB = gband_solve_sb(kl, 64 * (W3 ? 8 : 4));  // steps per staged run of multipliers (kl <= 64: at least 4)
+      gload(Lc, min(SB, n) * kl);
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const int jbase = 64 * m;
-      if (jbase < n) {
-        const int jend = min(64, n - jbase);
-        for (int jj0 = 0; jj0 < jend; jj0 += CH) {
-          double la[CH], lb[CH];
+      for (int m = 0; m < MB; ++m) {
+        const int jbase = 64 * m;
+        if (jbase < n) {
+          const int jend = min(64, n - jbase);
+          for (int c0 = 0; c0 < jend; c0 += SB) {  // run: steps jbase + c0 .. jbase + c1 - 1
+            const int c1 = min(c0 + SB, jend);
+            gband_wave_sync();  // the previous run's readers are done
+            gpark((c1 - c0) * kl);
+            gband_wave_sync();
+            {  // the run after this one (it may belong to the next block of 64 steps)
+              const int j_next = jbase + c1;
+              const int cnt = c1 < jend ? min(SB, jend - c1) : (j_next < n ? min(SB, min(64, n - j_next)) : 0);
+              gload(Lc + (size_t)j_next * kl, cnt * kl);
+            }
+            for (int jj0 = c0; jj0 < c1; jj0 += CH) {
+              double la[CH], lb[CH];
 #pragma unroll
-          for (int s = 0; s < CH; ++s) {
-            const int jj = jj0 + s, j = jbase + jj;
-            const int ra = lane - jj, rb = lane + 64 - jj;  // row - j for this lane's element of register m / m + 1
-            const bool oka = jj < jend && ra >= 1 && ra <= kl && j + ra < n, okb = jj < jend && rb <= kl && j + rb < n;
-            la[s] = oka ? Lc[(size_t)j * kl + ra - 1] : 0.0;
-            lb[s] = okb ? Lc[(size_t)j * kl + rb - 1] : 0.0;
-          }
+              for (int s = 0; s < CH; ++s) {
+                const int jj = jj0 + s, j = jbase + jj;
+                const int ra = lane - jj, rb = lane + 64 - jj;  // row - j for this lane's element of register m / m + 1
+                const bool oka = jj < c1 && ra >= 1 && ra <= kl && j + ra < n, okb = jj < c1 && rb <= kl && j + rb < n;
+                la[s] = oka ? stage[(jj - c0) * kl + ra - 1] : 0.0;
+                lb[s] = okb ? stage[(jj - c0) * kl + rb - 1] : 0.0;
+              }
 #pragma unroll
-          for (int s = 0; s < CH; ++s) {
-            const int jj = jj0 + s, j = jbase + jj;
-            if (jj < jend) {
-              const int p = __builtin_amdgcn_readlane(pv[m], jj);
-              if (p != j) {
-                const double vj = gband_readlane(v[m], jj);
-                if ((p >> 6) == m) {
-                  const double vp = gband_readlane(v[m], p & 63);
-                  v[m] = gband_writelane(v[m], vp, jj);
-                  v[m] = gband_writelane(v[m], vj, p & 63);
-                } else if (m + 1 < MB) {
-                  const double vp = gband_readlane(v[m + 1 < MB ? m + 1 : m], p & 63);
-                  v[m] = gband_writelane(v[m], vp, jj);
-                  v[m + 1 < MB ? m + 1 : m] = gband_writelane(v[m + 1 < MB ? m + 1 : m], vj, p & 63);
+              for (int s = 0; s < CH; ++s) {
+                const int jj = jj0 + s, j = jbase + jj;
+                if (jj < c1) {
+                  const int p = __builtin_amdgcn_readlane(pv[m], jj);
+                  if (p != j) {
+                    const double vj = gband_readlane(v[m], jj);
+                    if ((p >> 6) == m) {
+                      const double vp = gband_readlane(v[m], p & 63);
+                      v[m] = gband_writelane(v[m], vp, jj);
+                      v[m] = gband_writelane(v[m], vj, p & 63);
+                    } else if (m + 1 < MB) {
+                      const double vp = gband_readlane(v[m + 1 < MB ? m + 1 : m], p & 63);
+                      v[m] = gband_writelane(v[m], vp, jj);
+                      v[m + 1 < MB ? m + 1 : m] = gband_writelane(v[m + 1 < MB ? m + 1 : m], vj, p & 63);
+                    }
+                  }
+                  const double x = gband_readlane(v[m], jj);
+                  const int ra = lane - jj, rb = lane + 64 - jj;
+                  if (ra >= 1 && ra <= kl && j + ra < n) v[m] = (-x) * la[s] + v[m];
+                  if (m + 1 < MB) { if (rb <= kl && j + rb < n) v[m + 1 < MB ? m + 1 : m] = (-x) * lb[s] + v[m + 1 < MB ? m + 1 : m]; }
                 }
               }
-              const double x = gband_readlane(v[m], jj);
-              const int ra = lane - jj, rb = lane + 64 - jj;
-              if (ra >= 1 && ra <= kl && j + ra < n) v[m] = (-x) * la[s] + v[m];
-              if (m + 1 < MB) { if (rb <= kl && j + rb < n) v[m + 1 < MB ? m + 1 : m] = (-x) * lb[s] + v[m + 1 < MB ? m + 1 : m]; }
             }
           }
         }
       }
-    }
+    }  // (kl = 0: no multipliers and no interchanges — piv[j] = j)
     // ---- backward, column oriented like the dense solve: x_i = v_i / u_ii, then rows i-1 .. i-(kl+ku) take (-x_i) u_ri + v
-    bool stop = false;
+    {
+      const int SB = gband_solve_sb(Wc, 64 * GQ);  // steps per staged run of U columns
+      bool stop = false;
+      {  // first run: the top steps of the last block of 64
+        const int mtop = (n - 1) >> 6, jtop = (n - 1) - 64 * mtop, c_lo = max(jtop - SB + 1, 0);
+        gload(Uc + (size_t)(64 * mtop + c_lo) * Wc, (jtop - c_lo + 1) * Wc);
+      }
 #pragma unroll
-    for (int m = MB - 1; m >= 0; --m) {
-      const int jbase = 64 * m;
-      if (jbase < n && !stop) {
-        const int jtop = min(63, n - 1 - jbase);
-        for (int jj0 = jtop; jj0 >= 0 && !stop; jj0 -= CH) {
-          double ua[CH], ub[CH], uc[CH], dg[CH];
+      for (int m = MB - 1; m >= 0; --m) {
+        const int jbase = 64 * m;
+        if (jbase < n && !stop) {
+          const int jtop = min(63, n - 1 - jbase);
+          for (int c_hi = jtop; c_hi >= 0 && !stop; c_hi -= SB) {  // run: steps jbase + c_hi down to jbase + c_lo
+            const int c_lo = max(c_hi - SB + 1, 0);
+            gband_wave_sync();
+            gpark((c_hi - c_lo + 1) * Wc);
+            gband_wave_sync();
+            {  // the run after this one
+              int nhi, nlo, nbase;
+              if (c_lo > 0) { nbase = jbase; nhi = c_lo - 1; nlo = max(nhi - SB + 1, 0); }
+              else { nbase = jbase - 64; nhi = 63; nlo = max(nhi - SB + 1, 0); }
+              gload(Uc + (size_t)(nbase >= 0 ? nbase + nlo : 0) * Wc, nbase >= 0 ? (nhi - nlo + 1) * Wc : 0);
+            }
+            for (int jj0 = c_hi; jj0 >= c_lo && !stop; jj0 -= CH) {
+              double ua[CH], ub[CH], uc[W3 ? CH : 1], dg[CH];
 #pragma unroll
-          for (int s = 0; s < CH; ++s) {
-            const int jj = jj0 - s, i = jbase + jj;
-            const int da = jj - lane, db = jj + 64 - lane, dc = jj + 128 - lane;  // i - row for this lane's element of register m / m-1 / m-2
-            const bool oka = jj >= 0 && da >= 1 && da < Wc, okb = jj >= 0 && m >= 1 && db < Wc, okc = jj >= 0 && m >= 2 && dc < Wc;
-            ua[s] = oka ? Uc[(size_t)i * Wc + da] : 0.0;
-            ub[s] = okb ? Uc[(size_t)i * Wc + db] : 0.0;
-            uc[s] = okc ? Uc[(size_t)i * Wc + dc] : 0.0;
-            dg[s] = jj >= 0 ? Uc[(size_t)i * Wc] : 1.0;
-          }
+              for (int s = 0; s < CH; ++s) {
+                const int jj = jj0 - s;
+                const int da = jj - lane, db = jj + 64 - lane, dc = jj + 128 - lane;  // i - row for this lane's element of register m / m-1 / m-2
+                const bool in = jj >= c_lo;
+                const double* col = stage + (in ? (jj - c_lo) * Wc : 0);
+                ua[s] = (in && da >= 1 && da < Wc) ? col[da] : 0.0;
+                ub[s] = (in && m >= 1 && db < Wc) ? col[db] : 0.0;
+                if constexpr (W3) uc[s] = (in && m >= 2 && dc < Wc) ? col[dc] : 0.0;
+                dg[s] = in ? col[0] : 1.0;
+              }
 #pragma unroll
-          for (int s = 0; s < CH; ++s) {
-            const int jj = jj0 - s;
-            if (jj >= 0 && !stop) {
-              const double diag = dg[s];
-              if (diag == 0.0) { bad = 1ull; stop = true; }  // the dense solve breaks here as well (LuSolveFailed)
-              else {
-                const double x = gband_readlane(v[m], jj) / diag;
-                v[m] = gband_writelane(v[m], x, jj);
-                const int da = jj - lane, db = jj + 64 - lane, dc = jj + 128 - lane;
-                if (da >= 1 && da < Wc) v[m] = (-x) * ua[s] + v[m];
-                if (m >= 1) { if (db < Wc) v[m >= 1 ? m - 1 : 0] = (-x) * ub[s] + v[m >= 1 ? m - 1 : 0]; }
-                if (m >= 2) { if (dc < Wc) v[m >= 2 ? m - 2 : 0] = (-x) * uc[s] + v[m >= 2 ? m - 2 : 0]; }
+              for (int s = 0; s < CH; ++s) {
+                const int jj = jj0 - s;
+                if (jj >= c_lo && !stop) {
+                  const double diag = dg[s];
+                  if (diag == 0.0) { bad = 1ull; stop = true; }  // the dense solve breaks here as well (LuSolveFailed)
+                  else {
+                    const double x = gband_readlane(v[m], jj) / diag;
+                    v[m] = gband_writelane(v[m], x, jj);
+                    const int da = jj - lane, db = jj + 64 - lane, dc = jj + 128 - lane;
+                    if (da >= 1 && da < Wc) v[m] = (-x) * ua[s] + v[m];
+                    if (m >= 1) { if (db < Wc) v[m >= 1 ? m - 1 : 0] = (-x) * ub[s] + v[m >= 1 ? m - 1 : 0]; }
+                    if constexpr (W3) { if (m >= 2) { if (dc < Wc) v[m >= 2 ? m - 2 : 0] = (-x) * uc[s] + v[m >= 2 ? m - 2 : 0]; } }
+                  }
+                }
               }
             }
           }

@@ -121,6 +121,34 @@ def test_adaptive_full_size_ensemble_invariants(H):
     assert 150 * nb < tot["number_of_steps"] < 400 * nb
 
 
+def test_fast_arithmetic_variant_at_full_size_makes_the_step_decisions_of_the_exact_kernel(H, O):
+    """tier-level parity evidence for the opt-in `deterministic_pow = 2` build (bench.py's `fast_variant` extra: contracted multiply-adds,
+    reciprocal-math division, ocml pow) on BASELINE config 2 at its full 100 000 members in wavefront lock-step groups: every member's five counters (steps, Newton
+    iterations, LU setups, error-test failures, Newton failures) equal the exact kernel's — the two builds take the same step-size, order and refactorisation decisions in
+    all 1563 groups — and every state above its absolute tolerance is within 1e-9 relative of the exact kernel's, which is bit-identical to the oracle (first and last
+    group checked here against the oracle, the whole tier in tests/test_gpu_solvers.py)."""
+    nb = 100_000
+    p = robertson_params(nb)
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, **ROB)
+    ye, tote, me = s.solve_dense_adaptive(T_EVAL, group=64, deterministic_pow=1, want_member_stats=True)
+    yf, totf, mf = s.solve_dense_adaptive(T_EVAL, group=64, deterministic_pow=2, want_member_stats=True)
+    assert tote["failed_members"] == 0 and totf["failed_members"] == 0
+    assert np.array_equal(me["stats"], mf["stats"]) and np.array_equal(me["status"], mf["status"])
+    assert totf["number_of_steps"] == tote["number_of_steps"] and totf["number_of_nonlinear_solver_iterations"] == tote["number_of_nonlinear_solver_iterations"]
+    big = np.abs(ye) > np.asarray(ROB["atol"])[None, None, :]
+    assert (np.abs(yf - ye)[big] / np.abs(ye)[big]).max() < 1e-9
+    assert not np.array_equal(yf, ye)  # it IS another arithmetic
+    O.set_det_pow(True)
+    try:
+        for lo, hi in ((0, 64), (99_968, 100_000)):
+            yo, _, failed = O.solve_dense_independent(ORACLE_MODEL["robertson_ode"], p[lo:hi], T_EVAL, model_size=1, group=64, **ROB)
+            assert failed == 0 and np.array_equal(ye[:, lo:hi], np.transpose(yo, (1, 0, 2)))
+            bo = np.abs(np.transpose(yo, (1, 0, 2))) > np.asarray(ROB["atol"])[None, None, :]
+            assert (np.abs(yf[:, lo:hi] - np.transpose(yo, (1, 0, 2)))[bo] / np.abs(np.transpose(yo, (1, 0, 2)))[bo]).max() < 1e-9
+    finally:
+        O.set_det_pow(False)
+
+
 # ------------------------------------------------------------------ device-resident TR-BDF2 / ESDIRK34 (dsh_sdirk_solve_resident)
 @pytest.mark.parametrize("group", [1, 64])
 @pytest.mark.parametrize("method", [1, 2])

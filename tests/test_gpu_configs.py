@@ -76,6 +76,25 @@ def test_config3_dense_mode_on_the_default_matrix_core_lu_stays_within_rounding_
     assert np.abs(y[1] - heat_fourier(512, D, 0.5)).max() < 2e-5
 
 
+def test_config3_dense_mode_64_members_default_lu_against_the_exact_lu(H, monkeypatch):
+    """the DEFAULT dense LU is the kernel bench.py's `c3_dense` row times, and 8 members were thin evidence for it.  64 members of the C3 sweep,
+    n = 512, TR-BDF2 to t = 0.5 with the default matrix-core LU against the same run with the exact blocked LU (DSH_LU_EXACT=1: bit-identical to the oracle — the test
+    above for 8 members, the banded == dense comparison below at full size): every counter equal (the same step sequence), states within 1e-9 relative."""
+    monkeypatch.setenv("DSH_LU_STRUCTURE", "dense")
+    D = heat_params(4096)[:64]
+    kw = dict(nbatch=64, model_size=512, rtol=1e-6, atol=[1e-6], method=H.METHOD_TR_BDF2)
+    times = [0.01, 0.1, 0.5]
+    monkeypatch.setenv("DSH_LU_EXACT", "1")
+    se = H.Solver("heat1d", D[:, None], **kw)
+    ye, _ = se.solve_to_points(times)
+    monkeypatch.delenv("DSH_LU_EXACT", raising=False)
+    sd = H.Solver("heat1d", D[:, None], **kw)
+    yd, _ = sd.solve_to_points(times)
+    assert sd.stats() == se.stats()
+    assert np.max(np.abs(yd - ye)) <= 1e-9 * np.max(np.abs(ye)) and not np.array_equal(yd, ye)
+    assert np.abs(yd[2] - heat_fourier(512, D, 0.5)).max() < 2e-5
+
+
 @pytest.fixture(scope="module")
 def config3_full(H):
     out = {}

@@ -574,7 +574,7 @@ def test_opt_in_matrix_core_trailing_update_agrees_with_the_bit_exact_factorisat
     assert np.max(np.abs(np.einsum("bij,bj->bi", a, x1) - b)) <= 1e-10 * n
 
 
-@pytest.mark.parametrize("n,nb", [(288, 5), (289, 3), (300, 4), (352, 7), (448, 3), (496, 9), (512, 6), (513, 2), (600, 3), (962, 2), (1024, 2)])
+@pytest.mark.parametrize("n,nb", [(256, 6), (257, 3), (272, 5), (288, 5), (289, 3), (300, 4), (352, 7), (448, 3), (496, 9), (512, 6), (513, 2), (600, 3), (962, 2), (1024, 2)])
 @pytest.mark.parametrize("kind", ["random", "dominant"])
 def test_default_matrix_core_lu_keeps_the_pivots_and_agrees_with_the_oracle_to_rounding(H, O, ctx1, monkeypatch, n, nb, kind):
     """The default dense LU for 288 <= n <= 1024 (dsh_lu_tiled.hpp: row-major working copy, rows never move, register-resident panels, U12 and the trailing
