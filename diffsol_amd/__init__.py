@@ -12,10 +12,10 @@ from . import _ffi
 from ._ffi import DiffsolHipError, lib_paths, load_device_lib, load_host_lib
 from .la import HipContext, HipIndex, HipLU, HipMat, HipMatView, HipVec
 from .solver import (ENSEMBLE_AUTO, ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT, METHOD_BDF, METHOD_ESDIRK34, METHOD_TR_BDF2, MODELS,
-                     STAT_NAMES, OdeBuilder, Solver, set_deterministic_pow)
+                     STAT_NAMES, ARITH_EXACT, ARITH_FAST, OdeBuilder, Solver, get_resident_arithmetic, set_deterministic_pow, set_resident_arithmetic)
 
 __all__ = [
     "DiffsolHipError", "lib_paths", "load_device_lib", "load_host_lib", "HipContext", "HipVec", "HipMat", "HipMatView", "HipIndex", "HipLU", "OdeBuilder", "Solver",
     "METHOD_BDF", "METHOD_TR_BDF2", "METHOD_ESDIRK34", "MODELS", "STAT_NAMES", "ENSEMBLE_AUTO", "ENSEMBLE_LOCKSTEP", "ENSEMBLE_PER_MEMBER",
-    "ENSEMBLE_WAVEFRONT", "set_deterministic_pow",
+    "ENSEMBLE_WAVEFRONT", "set_deterministic_pow", "set_resident_arithmetic", "get_resident_arithmetic", "ARITH_EXACT", "ARITH_FAST",
 ]

@@ -219,6 +219,8 @@ HOST_ABI = {
     "dshs_is_fused": (cint, [vp]),
     "dshs_set_ensemble_mode": (cint, [vp, cint]),
     "dshs_set_deterministic_pow": (cint, [cint]),
+    "dshs_set_resident_arithmetic": (cint, [cint]),
+    "dshs_get_resident_arithmetic": (cint, []),
     "dshs_get_ensemble_mode": (cint, [vp, c_ip, c_ip]),
     "dshs_last_solve_info": (cint, [vp, c_ip, c_i64p]),
     "dshs_step": (cint, [vp, c_ip]),

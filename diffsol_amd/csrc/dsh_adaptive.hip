@@ -394,10 +394,12 @@ int bdf_solve_adaptive_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, c
     if (rc != DSH_OK) { if (!cached) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, consts_dev); } dsh_free(ctx, totals_dev); return rc; }
     launched = true;
   } else
-  if (!sens && C.r.o.deterministic_pow == 2) {
-    // the opt-in fast-arithmetic variant (dsh_adaptive_fast.hip): static models; everything else about the call is the same
-    launched = adaptive_fast_launch(model, size, ba, C.r.o.group == 64, grid, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
-                                    status, t_root, root_idx, ncols, totals_dev);
+  if (!sens && C.r.o.deterministic_pow == 2 &&
+      // the fast-arithmetic variant (dsh_adaptive_fast.hip): static models with n <= 4; everything else about the call is the same.  A model without that build
+      // falls through to the exact kernel below (its `det` is "deterministic_pow != 0")
+      adaptive_fast_launch(model, size, ba, C.r.o.group == 64, grid, ctx->stream, nb, p, atol, (const AdaptiveConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
+                           status, t_root, root_idx, ncols, totals_dev)) {
+    launched = true;
   } else if (sens) {
     launched = dispatch_static_model(model, size, [&](auto mdl) {
       using Mdl = decltype(mdl);

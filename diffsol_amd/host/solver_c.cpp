@@ -49,6 +49,7 @@ struct dshs_solver {
   // Which integrator solve_dense runs (include/diffsol_hip_solver.h DSHS_ENSEMBLE_*); -1 = auto.
   int ensemble_mode = -1;
   int last_mode = 0;              // mode the last solve_dense actually ran in
+  int last_arith = 1;             // arithmetic of the last device-resident solve_dense: 1 exact, 2 fast (dshs_set_resident_arithmetic)
   int64_t last_totals[6] = {0, 0, 0, 0, 0, 0};
   std::vector<int32_t> scratch_status, scratch_ridx;
   std::vector<double> member_troot;  // root time of every member after a device-resident solve_dense (NaN: none)
@@ -242,6 +243,11 @@ bool prepare_member_order(dshs_solver* s) {
   check(dsh_h2d(c, s->inv_dev, inv.data(), (int64_t)sizeof(int32_t) * nb), "member order");
   check(dsh_permute_members(c, np, nb, 8, s->problem.eqn->params().ptr(), (const int32_t*)s->perm_dev, s->p_sorted_dev), "member order");
   return true;
+}
+
+static int& resident_arith_flag() {
+  static int mode = [] { const char* e = std::getenv("DSH_RESIDENT_ARITH"); return e && std::string(e) == "exact" ? DSHS_ARITH_EXACT : DSHS_ARITH_FAST; }();
+  return mode;
 }
 
 // the solver's OdeSolverOptions / InitialConditionSolverOptions as the device-resident integrators take them
@@ -656,7 +662,11 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       if (has_roots) { ridx.resize((size_t)nb); s->member_troot.assign((size_t)nb, std::nan("")); }
       else { ridx.clear(); s->member_troot.clear(); }
       s->resident_roots_valid = false;
-      run_resident(s, t_eval, nt, mode, 1, y_host, y_dev, nullptr, status.data(), has_roots ? s->member_troot.data() : nullptr, has_roots ? ridx.data() : nullptr, nullptr,
+      // arithmetic: the fast build where it exists (BDF of a static model, no sensitivities: dsh_adaptive.hip falls back to the exact kernel otherwise), unless the
+      // process asked for the exact kernel (dshs_set_resident_arithmetic / DSH_RESIDENT_ARITH=exact — what the bitwise parity tier pins)
+      const int arith = resident_arith_flag() == DSHS_ARITH_FAST && s->method == DSHS_METHOD_BDF && !s->problem.sens ? 2 : 1;
+      s->last_arith = arith;
+      run_resident(s, t_eval, nt, mode, arith, y_host, y_dev, nullptr, status.data(), has_roots ? s->member_troot.data() : nullptr, has_roots ? ridx.data() : nullptr, nullptr,
                    s->last_totals, /*lazy=*/true);  // lazy: status is downloaded only if a member failed (else left untouched)
       s->resident_roots_valid = true;
       int64_t failed = 0, rooted = 0;
@@ -695,6 +705,17 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
     return 0;
   });
 }
+
+// Arithmetic of the device-resident BDF that dshs_solve_dense launches in its default (non-lock-step) modes: DSHS_ARITH_FAST (default since round 6) = the
+// build of dsh_adaptive_fast.hip where one exists (static models with n <= 4, no forward sensitivities: contracted multiply-adds, reciprocal-math division, ocml
+// pow), else the exact kernel; DSHS_ARITH_EXACT = always the exact kernel (bit-identical to the CPU oracle).  Environment DSH_RESIDENT_ARITH=exact|fast sets the
+// process default; the explicit entry points (dshs_solve_dense_adaptive, dshs_solve_adaptive, ...) take their arithmetic as an argument and ignore this.
+int dshs_set_resident_arithmetic(int mode) {
+  if (mode != DSHS_ARITH_EXACT && mode != DSHS_ARITH_FAST) return -1;
+  resident_arith_flag() = mode;
+  return 0;
+}
+int dshs_get_resident_arithmetic(void) { return resident_arith_flag(); }
 
 int dshs_set_deterministic_pow(int on) {
   det_pow_flag() = on != 0;

@@ -29,6 +29,19 @@ STOP_INTERNAL_TIMESTEP, STOP_ROOT_FOUND, STOP_TSTOP_REACHED = 0, 1, 2
 ENSEMBLE_AUTO, ENSEMBLE_LOCKSTEP, ENSEMBLE_PER_MEMBER, ENSEMBLE_WAVEFRONT = -1, 0, 1, 64
 
 
+ARITH_EXACT, ARITH_FAST = 1, 2
+
+
+def set_resident_arithmetic(mode):
+    """dshs_set_resident_arithmetic: ARITH_FAST (library default) | ARITH_EXACT — the arithmetic of the device-resident BDF behind Solver.solve_dense in its
+    default ensemble modes (include/diffsol_hip_solver.h).  The bitwise parity tier runs with ARITH_EXACT (tests/conftest.py: DSH_RESIDENT_ARITH=exact)."""
+    check(_ffi.load_host_lib().dshs_set_resident_arithmetic(int(mode)), host=True)
+
+
+def get_resident_arithmetic():
+    return int(_ffi.load_host_lib().dshs_get_resident_arithmetic())
+
+
 def set_deterministic_pow(on):
     """dshs_set_deterministic_pow: pow() of the host-driven integrators = include/diffsol_detpow.h (the device-resident integrators' pow) instead of libm."""
     check(_ffi.load_host_lib().dshs_set_deterministic_pow(1 if on else 0), host=True)

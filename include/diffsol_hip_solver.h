@@ -132,6 +132,15 @@ int dshs_set_ensemble_mode(dshs_solver* s, int mode);
  * arithmetic; 1 = include/diffsol_detpow.h, the pow of the device-resident integrators — then DSHS_ENSEMBLE_LOCKSTEP and the device-resident
  * wavefront mode give the same bits for ensembles of <= 64 members (one group). */
 int dshs_set_deterministic_pow(int on);
+/* Process-wide: arithmetic of the device-resident BDF launched by dshs_solve_dense in its non-lock-step modes (the explicit *_adaptive entry points take theirs as
+ * an argument).  DSHS_ARITH_FAST (default; environment DSH_RESIDENT_ARITH=fast): the fast-arithmetic build where one exists — static models with n <= 4, BDF, no
+ * forward sensitivities: contracted multiply-adds, reciprocal-math division, ocml pow (dsh_adaptive_options.deterministic_pow = 2).  Same algorithm and, on
+ * BASELINE config 2 at full size, the same step / order / refactorisation decisions for every member; states within 1e-9 relative of the exact kernel
+ * (tests/test_gpu_adaptive.py).  DSHS_ARITH_EXACT (DSH_RESIDENT_ARITH=exact): always the exact kernel, bit-identical to the CPU oracle (deterministic_pow = 1). */
+#define DSHS_ARITH_EXACT 1
+#define DSHS_ARITH_FAST 2
+int dshs_set_resident_arithmetic(int mode);
+int dshs_get_resident_arithmetic(void);
 int dshs_get_ensemble_mode(const dshs_solver* s, int* requested, int* resolved);
 /* mode the last solve_dense ran in and its counters summed over members: totals[6] = steps, Newton iterations, LU setups, error-test failures,
  * Newton failures, failed members (lock-step: the solver's counters x nbatch). */

@@ -13,6 +13,10 @@ if ROOT not in sys.path:
 # dsh_lu_factor).  The default mode — the matrix-core kernel of dsh_lu_tiled.hpp, tested to a tolerance — is exercised by the tests that delete the
 # variable again (test_gpu_lu_models.py, test_gpu_configs.py).
 os.environ.setdefault("DSH_LU_EXACT", "1")
+# Likewise the device-resident BDF behind Solver.solve_dense: the library default since round 6 is the fast-arithmetic build (contracted multiply-adds,
+# reciprocal-math division, ocml pow — same decisions, states within 1e-9), the bitwise tier pins the exact kernel; the default is exercised by
+# tests/test_gpu_adaptive.py::test_the_library_default_arithmetic_of_solve_dense_* (which switch it with dshs_set_resident_arithmetic).
+os.environ.setdefault("DSH_RESIDENT_ARITH", "exact")
 
 
 def pytest_configure(config):

@@ -149,6 +149,49 @@ def test_fast_arithmetic_variant_at_full_size_makes_the_step_decisions_of_the_ex
         O.set_det_pow(False)
 
 
+def test_the_library_default_arithmetic_of_solve_dense_is_the_fast_build_and_exact_on_request(H, O):
+    """Round 6: Solver.solve_dense (dshs_solve_dense) in its device-resident modes launches the FAST-arithmetic BDF by default where that build exists
+    (dshs_set_resident_arithmetic / DSH_RESIDENT_ARITH; this tier pins `exact` in conftest.py).  ARITH_FAST gives the bits of solve_dense_adaptive(deterministic_pow=2),
+    ARITH_EXACT those of deterministic_pow=1 (= the oracle's); models or methods without a fast build (TR-BDF2 here) run the exact kernel under either setting."""
+    assert H.get_resident_arithmetic() == H.ARITH_EXACT  # conftest.py
+    nb = 640
+    p = robertson_params(nb, seed=11)
+    s = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, ensemble_mode=H.ENSEMBLE_WAVEFRONT, **ROB)
+    ye, _ = s.solve_dense_adaptive(T_EVAL, group=64, deterministic_pow=1)
+    yf, _ = s.solve_dense_adaptive(T_EVAL, group=64, deterministic_pow=2)
+    try:
+        y_exact = s.solve_dense(T_EVAL)[0]
+        H.set_resident_arithmetic(H.ARITH_FAST)
+        y_fast = s.solve_dense(T_EVAL)[0]
+        s2 = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, ensemble_mode=H.ENSEMBLE_WAVEFRONT, method=H.METHOD_TR_BDF2, **ROB)
+        y_sd_fast = s2.solve_dense(T_EVAL)[0]
+        H.set_resident_arithmetic(H.ARITH_EXACT)
+        y_sd_exact = s2.solve_dense(T_EVAL)[0]
+    finally:
+        H.set_resident_arithmetic(H.ARITH_EXACT)
+    assert np.array_equal(y_exact, ye) and np.array_equal(y_fast, yf) and not np.array_equal(yf, ye)
+    assert np.array_equal(y_sd_fast, y_sd_exact)
+    big = np.abs(ye) > np.asarray(ROB["atol"])[None, None, :]
+    assert (np.abs(yf - ye)[big] / np.abs(ye)[big]).max() < 1e-9
+
+
+def test_the_default_arithmetic_stays_within_1e6_relative_of_independent_cpu_solves_at_tight_tolerances(H, O):
+    """north_star's bar for the path bench.py times (library default arithmetic, wavefront lock-step groups): at tolerances where the integration error is below it,
+    every state within 1e-6 relative of the oracle's independent libm-pow solves of the same groups."""
+    p = robertson_params(256, seed=4)
+    tight = dict(rtol=1e-9, atol=[1e-13, 1e-17, 1e-11])
+    s = H.Solver("robertson_ode", p, nbatch=len(p), model_size=1, ensemble_mode=H.ENSEMBLE_WAVEFRONT, **tight)
+    try:
+        H.set_resident_arithmetic(H.ARITH_FAST)
+        y = s.solve_dense(T_EVAL[:5])[0]
+    finally:
+        H.set_resident_arithmetic(H.ARITH_EXACT)
+    yo, _, failed = O.solve_dense_independent(ORACLE_MODEL["robertson_ode"], np.asarray(p, dtype=float), T_EVAL[:5], model_size=1, nthreads=8, group=64, **tight)
+    yo = np.transpose(yo, (1, 0, 2))
+    big = np.abs(yo) > 1e-7
+    assert failed == 0 and (np.abs(y - yo)[big] / np.abs(yo)[big]).max() < 1e-6
+
+
 # ------------------------------------------------------------------ device-resident TR-BDF2 / ESDIRK34 (dsh_sdirk_solve_resident)
 @pytest.mark.parametrize("group", [1, 64])
 @pytest.mark.parametrize("method", [1, 2])
