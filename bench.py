@@ -403,6 +403,7 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
     """BASELINE configs[2..4] on one GPU, each with its own roofline entry (dominant kernel, live launch durations from HIP-event brackets on the solver's stream)
     and CPU leg.  Every entry is guarded: a failing config reports {"error": ...} and the line still prints."""
     import diffsol_amd as H
+    ARITH = 2 if H.get_resident_arithmetic() == H.ARITH_FAST else 1  # the library's default arithmetic of the device-resident integrators (fast builds where they exist)
     from diffsol_amd import diffsl
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     out = {}
@@ -508,13 +509,13 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
             s = H.Solver("spm", cur, nbatch=nb, model_size=20, rtol=1e-6, atol=[1e-6], device=device)
         import torch
         outb = torch.empty((len(t_eval), s.n, nb), dtype=torch.float64, device=f"cuda:{device}")
-        t0 = time.perf_counter(); s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr()); first = time.perf_counter() - t0
+        t0 = time.perf_counter(); s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), deterministic_pow=ARITH); first = time.perf_counter() - t0
         walls = []
         for _ in range(3):
-            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr()); walls.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), deterministic_pow=ARITH); walls.append(time.perf_counter() - t0)
         wall = min(walls)
         s.set_kernel_timing(True); s.set_kernel_timing_target(TIMING_RESIDENT)
-        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True)
+        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True, deterministic_pow=ARITH)
         nl, ms = s.kernel_timing()
         s.set_kernel_timing(False)
         steps, newton = tot["number_of_steps"], tot["number_of_nonlinear_solver_iterations"]
@@ -554,18 +555,23 @@ def bench_configs(device, want_cpu, quick=False, budget_s=0.0):
         s = H.Solver("rlc", p, nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34, device=device)
         import torch
         outb = torch.empty((len(t_eval), s.n, nb), dtype=torch.float64, device=f"cuda:{device}")
-        s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group)
+        s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group, deterministic_pow=ARITH)
         walls = []
         for _ in range(5):
-            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group); walls.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); _, tot = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group, deterministic_pow=ARITH); walls.append(time.perf_counter() - t0)
         wall = min(walls)
+        _, tot_exact = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group, deterministic_pow=1)
+        t0 = time.perf_counter(); s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), group=group, deterministic_pow=1); wall_exact = time.perf_counter() - t0
         s.set_kernel_timing(True); s.set_kernel_timing_target(TIMING_RESIDENT)
-        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True, group=group)
+        _, tot, mm = s.solve_dense_adaptive(t_eval, want_host=False, dev_ptr=outb.data_ptr(), want_member_stats=True, group=group, deterministic_pow=ARITH)
         nl, ms = s.kernel_timing()
         s.set_kernel_timing(False)
         steps, newton = tot["number_of_steps"], tot["number_of_nonlinear_solver_iterations"]
         rec = {"workload": f"BASELINE configs[4]: series RLC DAE n=4 x {nb}, ESDIRK34, rtol=atol=1e-6, t in [0, 1], root i_R = {i_thresh:g}; device-resident, "
                            + ("every member its own steps and its own event" if group == 1 else "wavefront lock-step groups of 64 (threshold out of reach)"),
+               "arithmetic": "fast build (library default): same counters as the exact kernel" if ARITH == 2 else "exact",
+               "exact_kernel_ms_per_solve": 1e3 * wall_exact, "same_totals_as_exact_kernel": bool(tot_exact["number_of_steps"] == tot["number_of_steps"] and
+                                                                                             tot_exact["number_of_nonlinear_solver_iterations"] == tot["number_of_nonlinear_solver_iterations"]),
                "ms_per_solve": 1e3 * wall, "ode_steps_per_sec": steps / wall, "newton_solves_per_sec": (newton + steps) / wall, "newton_iterations_per_sec": newton / wall,
                "mean_steps_per_member": steps / nb, "failed_members": tot["failed_members"], "members_stopped_by_event": int((mm["root_idx"] >= 0).sum()),
                "roofline": {"bound": "valu", "kernel": f"dsh::k_sdirk_resident<RlcModel, ESDIRK34, group {group}> (the whole ensemble solve, one launch; state in registers)", "launches_timed": nl,

@@ -33,7 +33,11 @@ struct SdirkConsts {
 #else
 #define DSH_SDIRK_OCCUPANCY
 #endif
-template <class Mdl, bool BA, bool WAVE, int S, bool SENS = false>
+// FAST (dsh_adaptive_options::deterministic_pow == 2; instantiated only in dsh_sdirk_fast.hip, which is compiled with -ffp-contract=fast -freciprocal-math): a tag that
+// gives the fast-arithmetic build of the same source its own symbols — multiply-adds fused, divisions by reciprocal + refinement.  Same algorithm; on BASELINE config 5
+// at full size the same step / Newton / refactorisation decisions for every member, states and event times within 1e-9 (tests/test_gpu_configs.py); 18 - 20 % shorter
+// dependent chain (profiles/r06_c5_fast.md).  Not bit-comparable with the oracle: the parity tier runs the exact instantiation.
+template <class Mdl, bool BA, bool WAVE, int S, bool SENS = false, bool FAST = false>
 __global__ __launch_bounds__(64) DSH_SDIRK_OCCUPANCY void k_sdirk_resident(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, const SdirkConsts* __restrict__ Cp,
                                                        const double* __restrict__ t_eval, double* __restrict__ y_out, int32_t* __restrict__ stats_out,
                                                        int32_t* __restrict__ status_out, double* __restrict__ t_root_out, int32_t* __restrict__ root_idx_out,

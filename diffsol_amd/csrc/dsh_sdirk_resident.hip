@@ -22,6 +22,11 @@
 
 using namespace dsh;
 
+namespace dsh {
+bool sdirk_fast_launch(int method, int model, int64_t size, bool ba, bool wave, dim3 grid, hipStream_t stream, int64_t nb, const double* p, const double* atol,
+                       const SdirkConsts* consts, const double* t_eval, double* y_out, int32_t* stats, int32_t* status, double* t_root, int32_t* root_idx, int32_t* ncols,
+                       unsigned long long* totals);  // dsh_sdirk_fast.hip
+}
 
 extern "C" {
 
@@ -156,6 +161,10 @@ int sdirk_solve_resident_impl(dsh_ctx* ctx, int method, int model, int64_t size,
     rc = jit_launch(ctx, model, "dsh_sdirk_kernel.hpp", name, {name}, name, grid, blk, 0, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats,
                     status, t_root, root_idx, ncols, totals_dev);
     if (rc != DSH_OK) return rc;
+  } else if (!sens && T.r.o.deterministic_pow == 2 &&
+             // the fast-arithmetic build (dsh_sdirk_fast.hip): static models with n <= 4; a model without it falls through to the exact kernel below
+             sdirk_fast_launch(method, model, size, ba, wave, grid, ctx->stream, nb, p, atol, (const SdirkConsts*)consts_dev, (const double*)t_eval_dev, y_out, stats, status,
+                               t_root, root_idx, ncols, totals_dev)) {
   } else if (sens) {
     dispatch_static_model(model, size, [&](auto mdl) {
       using Mdl = decltype(mdl);

@@ -664,7 +664,7 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
       s->resident_roots_valid = false;
       // arithmetic: the fast build where it exists (BDF of a static model, no sensitivities: dsh_adaptive.hip falls back to the exact kernel otherwise), unless the
       // process asked for the exact kernel (dshs_set_resident_arithmetic / DSH_RESIDENT_ARITH=exact — what the bitwise parity tier pins)
-      const int arith = resident_arith_flag() == DSHS_ARITH_FAST && s->method == DSHS_METHOD_BDF && !s->problem.sens ? 2 : 1;
+      const int arith = resident_arith_flag() == DSHS_ARITH_FAST && !s->problem.sens ? 2 : 1;  // (2 where no fast build exists: the exact kernel with the portable pow, as 1)
       s->last_arith = arith;
       run_resident(s, t_eval, nt, mode, arith, y_host, y_dev, nullptr, status.data(), has_roots ? s->member_troot.data() : nullptr, has_roots ? ridx.data() : nullptr, nullptr,
                    s->last_totals, /*lazy=*/true);  // lazy: status is downloaded only if a member failed (else left untouched)
@@ -706,9 +706,9 @@ int dshs_solve_dense(dshs_solver* s, const double* t_eval, int64_t nt, double* y
   });
 }
 
-// Arithmetic of the device-resident BDF that dshs_solve_dense launches in its default (non-lock-step) modes: DSHS_ARITH_FAST (default since round 6) = the
-// build of dsh_adaptive_fast.hip where one exists (static models with n <= 4, no forward sensitivities: contracted multiply-adds, reciprocal-math division, ocml
-// pow), else the exact kernel; DSHS_ARITH_EXACT = always the exact kernel (bit-identical to the CPU oracle).  Environment DSH_RESIDENT_ARITH=exact|fast sets the
+// Arithmetic of the device-resident integrators that dshs_solve_dense launches in its default (non-lock-step) modes: DSHS_ARITH_FAST (default since round 6) = the
+// builds of dsh_adaptive_fast.hip (BDF) / dsh_sdirk_fast.hip (TR-BDF2, ESDIRK34) where one exists (static models with n <= 4, no forward sensitivities: contracted
+// multiply-adds, reciprocal-math division), else the exact kernel; DSHS_ARITH_EXACT = always the exact kernel (bit-identical to the CPU oracle).  Environment DSH_RESIDENT_ARITH=exact|fast sets the
 // process default; the explicit entry points (dshs_solve_dense_adaptive, dshs_solve_adaptive, ...) take their arithmetic as an argument and ignore this.
 int dshs_set_resident_arithmetic(int mode) {
   if (mode != DSHS_ARITH_EXACT && mode != DSHS_ARITH_FAST) return -1;

@@ -32,5 +32,6 @@ else:
 import time
 for _ in range(K):
     t0 = time.perf_counter()
-    _, tot = s.solve_dense_adaptive(t_eval, want_host=False, group=group)
+    # the library's default arithmetic (fast builds where they exist) unless DSH_RESIDENT_ARITH=exact: what bench.py's rows and their counters are taken with
+    _, tot = s.solve_dense_adaptive(t_eval, want_host=False, group=group, deterministic_pow=2 if H.get_resident_arithmetic() == H.ARITH_FAST else 1)
     print(cfg, nb, "wall ms %.2f" % (1e3 * (time.perf_counter() - t0)), tot)

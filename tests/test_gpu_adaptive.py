@@ -152,7 +152,7 @@ def test_fast_arithmetic_variant_at_full_size_makes_the_step_decisions_of_the_ex
 def test_the_library_default_arithmetic_of_solve_dense_is_the_fast_build_and_exact_on_request(H, O):
     """Round 6: Solver.solve_dense (dshs_solve_dense) in its device-resident modes launches the FAST-arithmetic BDF by default where that build exists
     (dshs_set_resident_arithmetic / DSH_RESIDENT_ARITH; this tier pins `exact` in conftest.py).  ARITH_FAST gives the bits of solve_dense_adaptive(deterministic_pow=2),
-    ARITH_EXACT those of deterministic_pow=1 (= the oracle's); models or methods without a fast build (TR-BDF2 here) run the exact kernel under either setting."""
+    ARITH_EXACT those of deterministic_pow=1 (= the oracle's); models without a fast build (a run-time-compiled banded model here) run the exact kernel under either setting."""
     assert H.get_resident_arithmetic() == H.ARITH_EXACT  # conftest.py
     nb = 640
     p = robertson_params(nb, seed=11)
@@ -163,10 +163,11 @@ def test_the_library_default_arithmetic_of_solve_dense_is_the_fast_build_and_exa
         y_exact = s.solve_dense(T_EVAL)[0]
         H.set_resident_arithmetic(H.ARITH_FAST)
         y_fast = s.solve_dense(T_EVAL)[0]
-        s2 = H.Solver("robertson_ode", p, nbatch=nb, model_size=1, ensemble_mode=H.ENSEMBLE_WAVEFRONT, method=H.METHOD_TR_BDF2, **ROB)
-        y_sd_fast = s2.solve_dense(T_EVAL)[0]
+        # a model without a fast build: the banded lane-per-member form of heat1d (run-time compiled)
+        s2 = H.Solver("heat1d", np.linspace(0.5, 2.0, 64)[:, None], nbatch=64, model_size=20, rtol=1e-6, atol=[1e-6], ensemble_mode=H.ENSEMBLE_PER_MEMBER)
+        y_sd_fast = s2.solve_dense([0.01, 0.1])[0]
         H.set_resident_arithmetic(H.ARITH_EXACT)
-        y_sd_exact = s2.solve_dense(T_EVAL)[0]
+        y_sd_exact = s2.solve_dense([0.01, 0.1])[0]
     finally:
         H.set_resident_arithmetic(H.ARITH_EXACT)
     assert np.array_equal(y_exact, ye) and np.array_equal(y_fast, yf) and not np.array_equal(yf, ye)

@@ -227,6 +227,30 @@ def rlc_params(nb, thresh):
     return np.stack([R, np.ones(nb), Cc, np.full(nb, 10.0), np.full(nb, 100.0), np.full(nb, thresh)], axis=1)
 
 
+@pytest.mark.parametrize("group", [1, 64])
+def test_config5_fast_arithmetic_build_makes_the_decisions_of_the_exact_kernel_at_full_size(H, group):
+    """Round 6: the fast-arithmetic build of the device-resident ESDIRK34 (dsh_sdirk_fast.hip; `deterministic_pow = 2`, the library default of solve_dense since this
+    round) on BASELINE configs[4] at its full 65 536 members against the exact kernel (bit-identical to the oracle: the test below): every member's five counters,
+    its number of output columns and the index of its event are equal — the same step-size, refactorisation and event decisions in every wavefront —, states within 1e-9 relative + 1e-11 and event
+    times within 1e-9 relative (north_star: 1e-6)."""
+    nb = 65536
+    p = rlc_params(nb, 0.03 if group == 1 else 1e3)
+    s = H.Solver("rlc", p, nbatch=nb, model_size=1, rtol=1e-6, atol=[1e-6], method=H.METHOD_ESDIRK34)
+    t_eval = np.linspace(0.005, 1.0, 12)
+    ye, tote, me = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group, deterministic_pow=1)
+    yf, totf, mf = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=group, deterministic_pow=2)
+    assert tote["failed_members"] == 0 and totf["failed_members"] == 0
+    assert np.array_equal(me["stats"], mf["stats"]) and np.array_equal(me["ncols"], mf["ncols"]) and np.array_equal(me["root_idx"], mf["root_idx"])
+    hit = me["root_idx"] >= 0
+    if group == 1:
+        assert hit.sum() > 0.3 * nb
+        assert np.max(np.abs(mf["t_root"][hit] - me["t_root"][hit]) / me["t_root"][hit]) < 1e-9
+    live = np.isfinite(ye)
+    assert np.array_equal(live, np.isfinite(yf))
+    assert np.all(np.abs(yf - ye)[live] <= 1e-9 * np.abs(ye)[live] + 1e-11)  # 1e-9 relative, with a floor five decades below atol for the oscillating currents' zero crossings (measured: 2.3e-12)
+    assert not np.array_equal(yf[live], ye[live])  # it IS another arithmetic
+
+
 def test_config5_rlc_65536_members_esdirk34_with_per_member_events(H, O, det_pow):
     """BASELINE configs[4] at full size: 65 536 series-RLC DAEs (singular mass), ESDIRK34, t in [0, 1], root iR - 0.03 A armed: every member stops at
     its own crossing (what the reference's batched root finding cannot do).  Properties over all members: the algebraic equations of the DAE hold at
