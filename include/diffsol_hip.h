@@ -228,9 +228,11 @@ int32_t* dsh_lu_pivots(dsh_lu* lu);
 int dsh_lu_system_major(const dsh_lu* lu);
 /* Banded matrices in dense containers (PDE-type and compartment models; SURVEY 8(f) row 4 — the reference has no banded solver,
  * book/src/benchmarks/sundials.md:27-28).  With DSH_LU_STRUCTURE_AUTO (default for n >= 16; env DSH_LU_STRUCTURE=dense switches the default)
- * dsh_lu_factor reads the operand once to find its bandwidth over all systems and, if max(kl, ku) <= 4, factors and solves only the band
- * (LAPACK dgbtrf-style partial pivoting, one lane per system).  Every non-trivial operation of the dense elimination is performed in the same
- * order, so solutions are BIT-IDENTICAL to the dense kernels'; only time and traffic change.  dsh_lu_band_width: K of the current factors, 0 = dense. */
+ * dsh_lu_factor reads the operand once to find its bandwidths (kl, ku) over all systems and factors and solves only the band (LAPACK dgbtrf-style
+ * partial pivoting with kl fill-in diagonals): max(kl, ku) <= 4 with one lane per system and the window in registers (dsh_lu_band.hpp); 4 < max(kl, ku) <= 64,
+ * n <= 1024 and (2 kl + ku + 1) 2 <= n with one WAVEFRONT per system and the window in LDS (dsh_lu_gband.hpp, round 6: the 2-D PDE models heat2d / foodweb;
+ * DSH_LU_GBAND=0 disables).  Every non-trivial operation of the dense elimination is performed in the same order, so solutions are BIT-IDENTICAL to the dense
+ * kernels'; only time and traffic change.  dsh_lu_band_width: max(kl, ku) of the current factors, 0 = dense. */
 #define DSH_LU_STRUCTURE_AUTO 0
 #define DSH_LU_STRUCTURE_DENSE 1
 int dsh_lu_set_structure(dsh_lu* lu, int structure);
@@ -238,7 +240,7 @@ int dsh_lu_set_structure(dsh_lu* lu, int structure);
  * |i - j| > max(kl, ku) are not read.  DSH_CHECK_BAND=1 (debug) probes anyway and fails if the declaration is wrong. */
 int dsh_lu_factor_banded(dsh_lu* lu, const double* a, int kl, int ku);
 /* An LU handle for banded systems only: (3k + 1) n doubles of factor storage per system instead of n^2; takes dsh_lu_factor_packed with max(kl, ku) <= k
- * (1 <= k <= 4, n >= 16); dsh_lu_solve as for any handle; dense operands are refused. */
+ * (1 <= k <= 64, n >= 16; k > 4: n <= 1024); dsh_lu_solve as for any handle; dense operands are refused. */
 int dsh_lu_create_banded(dsh_ctx* ctx, int64_t n, int64_t nbatch, int k, dsh_lu** out);
 /* Factor a band container: the eliminations of dsh_lu_factor_banded on the same entries (bit-identical factors and solutions).  Works on any handle. */
 int dsh_lu_factor_packed(dsh_lu* lu, const double* band, int kl, int ku);
