@@ -659,12 +659,12 @@ def test_band_only_jacobian_evaluation_writes_the_bits_of_the_dense_one(H, ctx1,
     assert L.dsh_model_jacobian_band(c._h, H.MODELS[name], size, nb, 0.0, X.ptr, P.ptr, kl.value - 1, ku.value, Jb.ptr) < 0  # narrower than the declared band
 
 
-@pytest.mark.parametrize("n,k,nb", [(130, 1, 5), (512, 1, 16), (512, 1, 37), (300, 2, 9), (640, 1, 3), (900, 1, 4), (256, 3, 6)])
+@pytest.mark.parametrize("n,k,nb", [(130, 1, 5), (512, 1, 16), (512, 1, 37), (300, 2, 9), (640, 1, 3), (900, 1, 4), (256, 3, 6), (100, 10, 9), (300, 21, 5)])
 @pytest.mark.parametrize("ynb_full", [True, False])
 def test_banded_solve_with_the_norm_fused_into_its_launch_gives_the_bits_of_solve_then_norm(H, O, n, k, nb, ynb_full):
     """dsh_lu_solve_squared_norm on banded factors of a small ensemble runs ONE launch (k_lu_band_solve_team<.., EPI>: the loaders of the backward sweep form the
     norm's terms, one lane per system adds them in index order at the end): the solution must equal dsh_lu_solve's and the norm Vector::squared_norm's sequential
-    sum, bit for bit.  n = 900 (the squares do not fit LDS) and K = 3 take the two-launch fallback: same bits."""
+    sum, bit for bit.  n = 900 (the squares do not fit LDS), K = 3 and the general banded factors (k = 10, 21: one wavefront per system) take the two-launch fallback: same bits."""
     rng = np.random.default_rng(7 * n + 13 * k + nb)
     c = H.HipContext(nbatch=nb)
     a = _banded(rng, nb, n, k, k, False)
