@@ -180,6 +180,38 @@ def test_config4_spm_32768_members_with_voltage_cutoffs(H, O, det_pow):
     assert np.array_equal(m["root_idx"][pick], ref["root_idx"]) and np.array_equal(m["ncols"][pick], ref["ncols"])
 
 
+@pytest.mark.parametrize("dae", [False, True])
+def test_config4_whole_262144_member_ensemble_on_one_gpu_equals_its_shards_and_the_oracle(H, O, det_pow, dae):
+    """bench.py's `c4_*_262144` rows (the whole 8-GPU ensemble of BASELINE configs[3] on one GPU) were guarded by `finite` / `failed_members` only.
+    The 262 144-member launch — the DEFAULT code object of the banded lane BDF; every smaller ensemble of this tier runs the small-ensemble one — must give, member for
+    member, the bits of the 32 768-member shard launch (members are independent problems under per-member control: rank 0's shard of the 8-GPU job) and of the oracle
+    on a random sample drawn from the whole ensemble (states, counters, stop times); capacity = I t at every live save point."""
+    import diffsl_models as DM
+    from diffsol_amd import diffsl as fe
+    nb, shard = 262144, 32768
+    cur = spm_currents(nb)
+    t_eval = np.linspace(360.0, 3600.0, 10)
+    code = DM.spm_dae(20) if dae else None
+    mk = (lambda c: H.Solver(fe.DiffslModel(code), c[:, None], nbatch=len(c), rtol=1e-6, atol=[1e-6])) if dae else \
+         (lambda c: H.Solver("spm", c[:, None], nbatch=len(c), model_size=20, rtol=1e-6, atol=[1e-6]))
+    y, tot, m = mk(cur).solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    assert tot["failed_members"] == 0 and (m["status"] == 0).all()
+    hit = m["root_idx"] >= 0
+    for k, t in enumerate(t_eval):
+        live = (~hit) | (m["t_root"] >= t)
+        assert np.allclose(y[k, live, 0], cur[live] * t / 3600.0, rtol=1e-5)
+    ys, _, ms = mk(cur[:shard]).solve_dense_adaptive(t_eval, want_member_stats=True, group=1)
+    assert np.array_equal(y[:, :shard], ys, equal_nan=True) and np.array_equal(m["stats"][:, :shard], ms["stats"])
+    assert np.array_equal(m["t_root"][:shard], ms["t_root"], equal_nan=True) and np.array_equal(m["ncols"][:shard], ms["ncols"])
+    pick = np.sort(np.random.default_rng(8).choice(nb, 16, replace=False))
+    oid = DM.host_model(O, code) if dae else ORACLE_MODEL["spm"]
+    kw = {} if dae else {"model_size": 20}
+    yo, so, failed = O.solve_dense_independent(oid, cur[pick, None], t_eval, nthreads=8, rtol=1e-6, atol=[1e-6], **kw)
+    ref = O.solve_dense_independent.last_roots
+    assert failed == 0 and np.array_equal(y[:, pick], np.transpose(yo, (1, 0, 2)), equal_nan=True)
+    assert np.array_equal(m["stats"].T[pick], so) and np.array_equal(m["t_root"][pick], ref["t_root"], equal_nan=True) and np.array_equal(m["ncols"][pick], ref["ncols"])
+
+
 def test_config4_as_worded_singular_mass_spm_dae_32768_members(H, O, det_pow):
     """BASELINE configs[3] in its own words — "SPM DAE (singular mass matrix)": the battery model with the terminal voltage as an ALGEBRAIC state
     (tests/diffsl_models.py spm_dae(20): n = 43, M = diag(1.., 0, ..1), bandwidth 2), one GPU's shard of 32 768 members on the lane-per-member banded BDF
