@@ -2,8 +2,9 @@
 //! (or solves) every member, where the reference's `CudaLU` loops over the members on the host with one cusolverDnDgetrf / Dgetrs call each
 //! (linear_solver/cuda/lu.rs:59-191: the O(nbatch) serial launches per Newton iteration that dominate its batched path).
 //! Partial pivoting (LAPACK getrf semantics, what nalgebra's LU and cuSOLVER do); a zero pivot is reported by `solve_in_place` as `LuSolveFailed`.
-//! Operands that are banded inside their dense container (bandwidth <= 4: finite-difference PDEs, the single-particle model) are found by a probe
-//! pass and factored by the banded kernels — same bits, O(n) work; `set_structure(ffi::DSH_LU_STRUCTURE_DENSE)` keeps the dense kernels.
+//! Operands that are banded inside their dense container are found by a probe pass and factored by the banded kernels — half-bandwidth <= 4 (1-D
+//! finite-difference PDEs, the single-particle model) one lane per member, 5 .. 64 (2-D PDE discretisations: heat2d, foodweb) one wavefront per member —
+//! same bits, O(n k^2) work; `set_structure(ffi::DSH_LU_STRUCTURE_DENSE)` keeps the dense kernels.
 use crate::error::{check, to_la_error};
 use crate::ffi;
 use crate::matrix::HipMat;

@@ -27,7 +27,7 @@ CASES = [(64, 5, 5), (100, 10, 10), (200, 20, 20), (128, 7, 3), (129, 3, 9), (13
 @pytest.mark.parametrize("dominant", [True, False])
 def test_general_band_in_dense_containers_has_the_bits_of_the_dense_lu(H, O, n, kl, ku, dominant):
     """dsh_lu_factor probes (kl, ku) and the one-wavefront-per-system kernels eliminate the band only; the solution equals the oracle's dense LU and the dense
-    kernels' bit for bit.  Ragged ensembles (the last workgroup partly idle, the XCD-aware dealing of systems to workgroups), several right-hand sides."""
+    kernels' bit for bit.  Ragged ensembles (the last workgroup partly idle), several right-hand sides, the handle switching between structures."""
     nb = 37 if n <= 300 else (11 if n <= 600 else 5)
     c = H.HipContext(nbatch=nb)
     rng = np.random.default_rng(100000 * n + 100 * kl + ku)
