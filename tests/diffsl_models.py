@@ -381,3 +381,58 @@ u_i {{ (0:{m}): x = 1.0, ({m}:{2 * m}): z = 0.0 }}
 sx_i {{ S_ij * x_j }}
 F_i {{ (0:{m}): -w * z_i - a * x_i - eps * sx_i, ({m}:{2 * m}): w * x_i - a * z_i }}
 """
+
+
+def heat2d(m, scale_input=True):
+    """test_models/heat2d.rs:19-100 (heat2d_diffsl_problem) as the reference's test builds it: the closure model's Jacobian, mass matrix and initial state written
+    out as sparse DiffSL tensors — D_ij (5-point stencil rows 1/dx^2 (1, 1, -4, 1, 1), identity rows on the boundary), Mass_ij (diagonal 1 / 0), init_i — and
+    F_i = D_ij y_j, M_i = Mass_ij dydt_j, out_i = dx^2 y_j y_j.  Entries column by column like `triplet_iter` of the reference's CSC matrix.  scale_input: an input
+    `s` (default 1) multiplies F so that ensembles have distinct members (the reference's text has no input)."""
+    n = m * m
+    dx = 1.0 / (m - 1.0)
+    coeff = 1.0 / (dx * dx)
+    four = 4.0
+    bnd = lambda loc: (loc // m in (0, m - 1)) or (loc % m in (0, m - 1))
+    cols = {}
+    for loc in range(n):
+        if bnd(loc):
+            cols.setdefault(loc, []).append((loc, 1.0))
+        else:
+            for j, v in ((loc - m, coeff), (loc - 1, coeff), (loc, coeff * (0.0 - four)), (loc + 1, coeff), (loc + m, coeff)):
+                cols.setdefault(j, []).append((loc, v))
+    d_rows = ",\n".join(f"  ({i}, {j}): {v!r}" for j in sorted(cols) for i, v in sorted(cols[j]))
+    mass = ",\n".join(f"  ({i}, {i}): {0 if bnd(i) else 1}" for i in range(n))
+    init = []
+    for loc in range(n):
+        jy, ix = divmod(loc, m)
+        yfact, xfact = dx * jy, dx * ix
+        init.append(0.0 if bnd(loc) else 16.0 * xfact * (1.0 - xfact) * yfact * (1.0 - yfact))
+    init_rows = ",\n".join(f"  {v!r}" for v in init)
+    head = "in = [s]\ns { 1.0 }\n" if scale_input else ""
+    f_expr = "s * (D_ij * y_j)" if scale_input else "D_ij * y_j"
+    return f"""
+{head}D_ij {{
+{d_rows}
+}}
+Mass_ij {{
+{mass}
+}}
+init_i {{
+{init_rows}
+}}
+u_i {{
+  y = init_i,
+}}
+dudt_i {{
+  (0:{n}): dydt = 0,
+}}
+M_i {{
+  Mass_ij * dydt_j,
+}}
+F_i {{
+  {f_expr},
+}}
+out_i {{
+  {dx * dx!r} * y_j * y_j,
+}}
+"""

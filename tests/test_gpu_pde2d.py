@@ -129,3 +129,36 @@ def test_heat2d_with_tr_bdf2_and_esdirk34(H, O):
         y, _ = s.solve_to_points([0.01, 0.05])
         yo, _ = o.solve_to_points([0.01, 0.05])
         assert np.array_equal(y, yo) and s.stats() == o.stats()
+
+
+def test_the_references_diffsl_form_of_heat2d_on_the_device(H, O, kats):
+    """test_bdf_faer_sparse_heat2d_diffsl on the GPU: the reference's generated DiffSL text (sparse D_ij, Mass_ij, init_i; tests/diffsl_models.py::heat2d) compiled by
+    the product's front end and hiprtc, integrated by the host-driven BDF with the front end's structural band (10, 10) declared — M - cJ assembled on the band and
+    factored by the general banded LU.  Outputs and all counters equal the oracle's run of the SAME generated model (its host twin) bit for bit; the closure
+    snapshot's ten solver counters; the reference's table; an ensemble of 21 members with distinct diffusion scales bitwise."""
+    import diffsl_models as DM
+    from diffsol_amd import diffsl as fe
+    code = DM.heat2d(10)
+    model = fe.DiffslModel(code)
+    assert model.n == 100 and model.has_mass and tuple(model.band) == (10, 10, 0, 0)
+    tab = kats["heat2d_table"]
+    kw = dict(rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["bdf"])
+    t = [pt["t"] for pt in tab["points"]]
+    s = H.Solver(model, [[1.0]], **kw)
+    y, _ = s.solve_to_points(t[1:])
+    mid = DM.host_model(O, code)
+    o = O.OracleSolver(mid, [1.0], **kw)
+    yo, _ = o.solve_to_points(t[1:])
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    expected = kats["pde2d_snapshots"]["test_bdf_faer_sparse_heat2d"]
+    assert {k: s.stats()[k] for k in SOLVER_COUNTERS} == {k: expected[k] for k in SOLVER_COUNTERS}
+    for k, pt in enumerate(tab["points"][1:]):
+        assert weighted_error_norm(heat2d_out(y[k, 0], 10)[None], pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+    nb = 21
+    p = np.linspace(0.7, 1.4, nb)[:, None]
+    kw2 = dict(nbatch=nb, rtol=1e-6, atol=[1e-6], h0=1.0, method=METHOD["bdf"])
+    s2 = H.Solver(fe.DiffslModel(code), p, **kw2)
+    o2 = O.OracleSolver(mid, p, **kw2)
+    y2, _ = s2.solve_to_points([0.01, 0.05])
+    yo2, _ = o2.solve_to_points([0.01, 0.05])
+    assert np.array_equal(y2, yo2) and s2.stats() == o2.stats()

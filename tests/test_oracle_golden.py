@@ -550,3 +550,30 @@ def test_the_2d_pde_jacobians_have_the_declared_bandwidth(O):
         J = np.stack([O.model_jac_mul(model, x, p, np.eye(n)[j], model_size=size) for j in range(n)], axis=1)
         i, j = np.nonzero(J)
         assert np.abs(i - j).max() == k and np.count_nonzero(J) <= n * (2 * 2 + 2)
+
+
+def test_the_references_diffsl_form_of_heat2d_through_the_front_end(O, kats):
+    """test_bdf_faer_sparse_heat2d_diffsl (bdf.rs:2449-2458; text built by heat2d_diffsl_problem, heat2d.rs:19-100): the closure model's Jacobian, mass matrix and
+    initial state written out as sparse DiffSL tensors.  tests/diffsl_models.py::heat2d builds that text, the product's DiffSL front end turns it into the oracle's
+    host model: same dimensions, mass, initial state and — to rounding: a sparse matrix-vector product sums the five stencil terms in another order — right-hand side
+    as the closure restatement; the structural band (10, 10) is found; BDF takes the closure snapshot's step sequence (all ten solver counters) and the model's OWN
+    out_i = dx^2 y_j y_j meets the reference's solution table."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl
+    code = D.heat2d(10)
+    _, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C, 0)
+    assert (dims["n"], dims["nparams"], dims["nout"], dims["has_mass"]) == (100, 1, 1, True) and tuple(dims["band"]) == (10, 10, 0, 0)
+    mid, ref = D.host_model(O, code), ORACLE_MODEL["heat2d"]
+    rng = np.random.default_rng(1)
+    x, yv = rng.standard_normal(100), rng.standard_normal(100)
+    a, b = O.model_rhs(mid, x, [1.0], 0.0), O.model_rhs(ref, x, [1.0], 0.0, 10)
+    assert np.allclose(a, b, rtol=0, atol=1e-12 * np.abs(b).max()) and np.array_equal(O.model_init(mid, [1.0]), O.model_init(ref, [1.0], 0.0, 10))
+    assert np.array_equal(O.model_mass_gemv(mid, x, [1.0], yv, -0.3), O.model_mass_gemv(ref, x, [1.0], yv, -0.3, model_size=10))
+    tab = kats["heat2d_table"]
+    s = O.OracleSolver(mid, [1.0], rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["bdf"])
+    t = [pt["t"] for pt in tab["points"]]
+    y, _ = s.solve_to_points(t[1:])
+    expected = kats["pde2d_snapshots"]["test_bdf_faer_sparse_heat2d"]
+    assert {k: s.stats()[k] for k in SOLVER_COUNTERS} == {k: expected[k] for k in SOLVER_COUNTERS}
+    for k, pt in enumerate(tab["points"][1:]):
+        assert weighted_error_norm(O.model_out(mid, y[k, 0], [1.0]), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
