@@ -436,3 +436,89 @@ out_i {{
   {dx * dx!r} * y_j * y_j,
 }}
 """
+
+
+def foodweb(nx):
+    """test_models/foodweb.rs:26-146 (foodweb_diffsl_problem): the food web as the reference's test writes it in DiffSL — the two species in separate blocks (c1 = prey,
+    c2 = predators), the 5-point diffusion operator with Neumann mirror points as a sparse D_ij (the Jacobian of FoodWebDiff, foodweb.rs:900-940), the grid coordinates
+    as vectors, reaction terms element-wise with sin / pow, predators algebraic, corner values as out_i."""
+    n = nx * nx
+    dx = 1.0 / (nx - 1.0)
+    cox = coy = 1.0 / (dx * dx)
+    rows = {}
+    for jy in range(nx):
+        idyu = nx if jy != nx - 1 else -nx
+        idyl = nx if jy != 0 else -nx
+        for jx in range(nx):
+            idxu = 1 if jx != nx - 1 else -1
+            idxl = 1 if jx != 0 else -1
+            loc = jx + nx * jy
+            r = rows.setdefault(loc, {})
+            for j, v in ((loc + idyu, coy), (loc, -coy), (loc, -coy), (loc - idyl, coy), (loc + idxu, cox), (loc, -cox), (loc, -cox), (loc - idxl, cox)):
+                r[j] = r.get(j, 0.0) + v
+    cols = {}
+    for i, r in rows.items():
+        for j, v in r.items():
+            cols.setdefault(j, []).append((i, v))
+    d_rows = ",\n".join(f"  ({i}, {j}): {v!r}" for j in sorted(cols) for i, v in sorted(cols[j]))
+    xx = ",\n".join(f"  {(loc % nx) * dx!r}" for loc in range(n))
+    yy = ",\n".join(f"  {(loc // nx) * dx!r}" for loc in range(n))
+    return f"""
+AA {{ 1.0 }}
+EE {{ 10000.0 }}
+GG {{ 0.5e-6 }}
+BB {{ 1.0 }}
+ALPHA {{ 50.0 }}
+BETA {{ 1000.0 }}
+PI {{ 3.141592653589793 }}
+DPREY {{ 1.0 }}
+DPRED {{ 0.05 }}
+D_ij {{
+{d_rows}
+}}
+xx_i {{
+{xx}
+}}
+yy_i {{
+{yy}
+}}
+tl_i {{
+  (0): 1.0,
+  (1:{n}): 0.0,
+}}
+br_i {{
+  (0:{n - 1}): 0.0,
+  ({n - 1}): 1.0,
+}}
+b_i {{
+  (1.0 + ALPHA * xx_i * yy_i + BETA * sin(4.0 * PI * xx_i) * sin(4.0 * PI * yy_i))
+}}
+u_i {{
+  c1 = 10.0 + pow(16.0 * xx_i * (1.0 - xx_i) * yy_i * (1.0 - yy_i), 2),
+  ({n}:{2 * n}): c2 = 1.0e5,
+}}
+dudt_i {{
+  (0:{n}): dc1dt = 0,
+  ({n}:{2 * n}): dc2dt = 0,
+}}
+M_i {{
+  dc1dt_i,
+  ({n}:{2 * n}): 0,
+}}
+c1diff_i {{
+  DPREY * D_ij * c1_j,
+}}
+c2diff_i {{
+  DPRED * D_ij * c2_j,
+}}
+F_i {{
+  c1diff_i + c1_i * (BB * b_i - AA * c1_i - GG * c2_i),
+  c2diff_i + c2_i * (-BB * b_i + EE * c1_i - AA * c2_i),
+}}
+out_i {{
+  tl_j * c1_j,
+  br_j * c1_j,
+  tl_j * c2_j,
+  br_j * c2_j,
+}}
+"""

@@ -162,3 +162,28 @@ def test_the_references_diffsl_form_of_heat2d_on_the_device(H, O, kats):
     y2, _ = s2.solve_to_points([0.01, 0.05])
     yo2, _ = o2.solve_to_points([0.01, 0.05])
     assert np.array_equal(y2, yo2) and s2.stats() == o2.stats()
+
+
+def test_the_references_diffsl_form_of_foodweb_on_the_device(H, O, kats):
+    """test_bdf_faer_sparse_foodweb_diffsl on the GPU: the reference's generated DiffSL text (tests/diffsl_models.py::foodweb — separate species blocks, sparse diffusion
+    operator, sin / pow tensors, algebraic predators, a dense-band Jacobian of half-bandwidth 100: the dense LU) compiled by the front end and hiprtc; the consistent
+    initialisation and BDF on the device equal the oracle's run of the generated host twin bit for bit, counters included, and the model's out_i meets the reference's table."""
+    import diffsl_models as DM
+    from diffsol_amd import diffsl as fe
+    code = DM.foodweb(10)
+    model = fe.DiffslModel(code)
+    assert model.n == 200 and model.has_mass
+    tab = kats["foodweb_table"]
+    kw = dict(rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["bdf"])
+    t = [pt["t"] for pt in tab["points"]]
+    s = H.Solver(model, [[0.0]], **kw)
+    y0 = s.state()["y"][0].copy()
+    y, _ = s.solve_to_points(t[1:])
+    mid = DM.host_model(O, code)
+    o = O.OracleSolver(mid, [0.0], **kw)
+    yo0 = o.state()["y"][0].copy()
+    yo, _ = o.solve_to_points(t[1:])
+    assert np.array_equal(y0, yo0) and np.array_equal(y, yo) and s.stats() == o.stats()
+    ys = np.concatenate([y0[None], y[:, 0]], axis=0)
+    for k, pt in enumerate(tab["points"]):
+        assert weighted_error_norm(O.model_out(mid, ys[k], [0.0]), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt

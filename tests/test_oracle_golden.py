@@ -577,3 +577,27 @@ def test_the_references_diffsl_form_of_heat2d_through_the_front_end(O, kats):
     assert {k: s.stats()[k] for k in SOLVER_COUNTERS} == {k: expected[k] for k in SOLVER_COUNTERS}
     for k, pt in enumerate(tab["points"][1:]):
         assert weighted_error_norm(O.model_out(mid, y[k, 0], [1.0]), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+
+
+def test_the_references_diffsl_form_of_foodweb_through_the_front_end(O, kats):
+    """test_bdf_faer_sparse_foodweb_diffsl (bdf.rs:2479-2488; text built by foodweb_diffsl_problem, foodweb.rs:26-146): species in separate blocks, the Neumann diffusion
+    operator as a sparse D_ij, sin / pow in element-wise tensors, predators algebraic, corner values as out_i.  tests/diffsl_models.py::foodweb builds that text; through
+    the product's front end the consistent initialisation lands on the table's t = 0 row (predators 99999 / 99949) and BDF meets every row of the reference's table
+    through the model's own out_i."""
+    import diffsl_models as D
+    from diffsol_amd import diffsl
+    code = D.foodweb(10)
+    _, dims, _ = diffsl.generate(code, diffsl.TARGET_HOST_C, 0)
+    assert (dims["n"], dims["nout"], dims["has_mass"], dims["no_inputs"]) == (200, 4, True, True) and tuple(dims["band"])[:2] == (100, 100)
+    mid = D.host_model(O, code)
+    tab = kats["foodweb_table"]
+    s = O.OracleSolver(mid, [0.0], rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["bdf"])
+    t = [pt["t"] for pt in tab["points"]]
+    y0 = s.state()["y"][0].copy()
+    y, _ = s.solve_to_points(t[1:])
+    ys = np.concatenate([y0[None], y[:, 0]], axis=0)
+    for k, pt in enumerate(tab["points"]):
+        assert weighted_error_norm(O.model_out(mid, ys[k], [0.0]), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+    # the block layout against the interleaved closure model: the same initial state (foodweb.rs:1149-1216 compares the two to 1e-3)
+    y_closure = O.model_init(ORACLE_MODEL["foodweb"], [50.0, 1000.0], 0.0, 10)
+    assert np.allclose(O.model_init(mid, [0.0])[:100], y_closure[0::2], rtol=1e-14) and np.array_equal(O.model_init(mid, [0.0])[100:], y_closure[1::2])
