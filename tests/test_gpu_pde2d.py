@@ -187,3 +187,18 @@ def test_the_references_diffsl_form_of_foodweb_on_the_device(H, O, kats):
     ys = np.concatenate([y0[None], y[:, 0]], axis=0)
     for k, pt in enumerate(tab["points"]):
         assert weighted_error_norm(O.model_out(mid, ys[k], [0.0]), pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
+
+
+def test_the_references_tr_bdf2_heat2d_problem_on_the_device(H, O, kats):
+    """test_tr_bdf2_faer_sparse_heat2d (sdirk.rs:995-1000) on the GPU: TR-BDF2 over the trait operations with the general banded LU, the table's problem tolerances —
+    bitwise against the oracle, the table within the reference's norm"""
+    tab = kats["heat2d_table"]
+    kw = dict(model_size=10, rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["tr_bdf2"])
+    t = [pt["t"] for pt in tab["points"]]
+    s = H.Solver("heat2d", [1.0], fused=False, **kw)
+    o = O.OracleSolver(ORACLE_MODEL["heat2d"], [1.0], **kw)
+    y, _ = s.solve_to_points(t[1:])
+    yo, _ = o.solve_to_points(t[1:])
+    assert np.array_equal(y, yo) and s.stats() == o.stats()
+    for k, pt in enumerate(tab["points"][1:]):
+        assert weighted_error_norm(heat2d_out(y[k, 0], 10)[None], pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt

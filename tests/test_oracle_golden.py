@@ -601,3 +601,13 @@ def test_the_references_diffsl_form_of_foodweb_through_the_front_end(O, kats):
     # the block layout against the interleaved closure model: the same initial state (foodweb.rs:1149-1216 compares the two to 1e-3)
     y_closure = O.model_init(ORACLE_MODEL["foodweb"], [50.0, 1000.0], 0.0, 10)
     assert np.allclose(O.model_init(mid, [0.0])[:100], y_closure[0::2], rtol=1e-14) and np.array_equal(O.model_init(mid, [0.0])[100:], y_closure[1::2])
+
+
+def test_oracle_heat2d_table_with_tr_bdf2(O, kats):
+    """test_tr_bdf2_faer_sparse_heat2d (sdirk.rs:995-1000): TR-BDF2 on the 2-D heat DAE against the same solution table"""
+    tab = kats["heat2d_table"]
+    s = O.OracleSolver(ORACLE_MODEL["heat2d"], [1.0], model_size=10, rtol=tab["problem_rtol"], atol=tab["problem_atol"], h0=1.0, method=METHOD["tr_bdf2"])
+    t = [pt["t"] for pt in tab["points"]]
+    y, _ = s.solve_to_points(t[1:])
+    for k, pt in enumerate(tab["points"][1:]):
+        assert weighted_error_norm(heat2d_out(y[k, 0], 10)[None], pt["y"], tab["atol"], tab["rtol"]) < 20.0, pt
