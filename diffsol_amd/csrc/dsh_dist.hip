@@ -228,7 +228,8 @@ int dsh_gather_batch_axis_async(dsh_dist* d, const double* local, int64_t lead, 
 }
 // host waits until the gathered trajectories are in `out` (and `local` may be overwritten by the next solve)
 int dsh_gather_wait(dsh_dist* d) {
-  DSH_ENTER(d ? d->ctx : nullptr);
+  // no context lock here: the wait touches the communicator's own event only, must not hold up another thread's launches on the solver's context while it blocks
+  // (the overlap of a gather with the next solve is the point), and may be called after the context is gone
   if (!d) { set_error("dsh_gather_wait: null communicator"); return DSH_E_INVALID; }
   if (!d->pending) return DSH_OK;
   DSH_HIP_CHECK(hipEventSynchronize(d->done));
@@ -236,7 +237,6 @@ int dsh_gather_wait(dsh_dist* d) {
   return DSH_OK;
 }
 int dsh_gather_batch_axis(dsh_dist* d, const double* local, int64_t lead, int64_t n_total, double* out) {
-  DSH_ENTER(d ? d->ctx : nullptr);
   const int rc = dsh_gather_batch_axis_async(d, local, lead, n_total, out);
   return rc != DSH_OK ? rc : dsh_gather_wait(d);
 }

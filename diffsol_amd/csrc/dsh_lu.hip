@@ -90,15 +90,19 @@ constexpr int64_t kGbMaxN = 1024;  // the solve keeps the right-hand side in reg
 int gband_factor_launch(dsh_lu* lu, const double* a, int kl, int ku, bool packed, int pkl, int pku) {
   dsh_ctx* ctx = lu->ctx;
   const int64_t n = lu->n, nb = lu->nbatch;
-  lu->factored = true;  // (the caller has advanced lu->singular_epoch)
-  lu->band_k = 0;
-  lu->gb_kl = kl; lu->gb_ku = ku;
   const int Wb = kl + ku + 1;
   const int64_t need = n * Wb * nb;
+  lu->factored = false;  // until the launches below are queued: a failure must not leave the handle claiming factors it does not have
+  lu->band_k = 0;
+  lu->gb_kl = lu->gb_ku = -1;
   if (lu->gb_work_len < need) {
     if (lu->gb_work) (void)dsh_free(ctx, lu->gb_work);
     lu->gb_work = nullptr; lu->gb_work_len = 0;
-    if (dsh_malloc(ctx, (int64_t)sizeof(double) * need, 0, (void**)&lu->gb_work) != DSH_OK) { lu->gb_work = nullptr; return DSH_E_HIP; }
+    if (dsh_malloc(ctx, (int64_t)sizeof(double) * need, 0, (void**)&lu->gb_work) != DSH_OK) {
+      lu->gb_work = nullptr;
+      set_error("dsh_lu: out of device memory for the staged band of the general banded factorisation (" + std::to_string((long long)(need >> 17)) + " MiB)");
+      return DSH_E_HIP;
+    }
     lu->gb_work_len = need;
   }
   const dim3 sg((unsigned)((nb + 31) / 32), (unsigned)((n * Wb + 31) / 32));
@@ -122,6 +126,8 @@ int gband_factor_launch(dsh_lu* lu, const double* a, int kl, int ku, bool packed
   if (cpl == 1) DSH_GB_FACTOR(1); else if (cpl == 2) DSH_GB_FACTOR(2); else DSH_GB_FACTOR(3);
 #undef DSH_GB_FACTOR
   DSH_HIP_CHECK(hipGetLastError());
+  lu->factored = true;  // (the caller has advanced lu->singular_epoch)
+  lu->gb_kl = kl; lu->gb_ku = ku;
   return DSH_OK;
 }
 }  // namespace
