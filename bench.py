@@ -1011,13 +1011,13 @@ def main():
                     roof["fp64_frac"] = roof["fp64_tflops"] / FP64_MATRIX_PEAK_TFLOPS
                 if roof["traffic"]:
                     roof["hbm_frac_actual"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
-            if True:  # the 8(d) model needs no counters: units executed by one launch of this rank (the totals are sums over ranks and timed solves)
-                per = 1.0 / args.steps / world
-                model_bytes = (member_newton * MODEL_8D_NEWTON_BYTES + member_steps * MODEL_8D_STEP_BYTES + member_setups * MODEL_8D_REFACTOR_BYTES) * per
-                roof["hbm_model_8d_bytes_per_launch"] = model_bytes
-                roof["hbm_model_8d_frac"] = model_bytes / avg_s / 1e9 / HBM_PEAK_GBS
-                roof["hbm_model_8d_note"] = ("SURVEY 8(d) bytes (228 B per Newton iteration, 360 B per accepted step, 156 B per refactorisation) assume LU/state/history in HBM; "
-                                             "here they live in registers, so the model does not apply (> 1 is expected) — hbm_frac_actual is the measured traffic")
+            # the 8(d) model needs no counters: units executed by one launch of this rank (the totals are sums over ranks and timed solves)
+            per = 1.0 / args.steps / world
+            model_bytes = (member_newton * MODEL_8D_NEWTON_BYTES + member_steps * MODEL_8D_STEP_BYTES + member_setups * MODEL_8D_REFACTOR_BYTES) * per
+            roof["hbm_model_8d_bytes_per_launch"] = model_bytes
+            roof["hbm_model_8d_frac"] = model_bytes / avg_s / 1e9 / HBM_PEAK_GBS
+            roof["hbm_model_8d_note"] = ("SURVEY 8(d) bytes (228 B per Newton iteration, 360 B per accepted step, 156 B per refactorisation) assume LU/state/history in HBM; "
+                                         "here they live in registers, so the model does not apply (> 1 is expected) — hbm_frac_actual is the measured traffic")
             if not valu:
                 roof.update({"achieved": None, "frac": None, "traffic": None, "note": stale or "no PMC summary for this ensemble size under profiles/"})
             rec["roofline"] = roof
