@@ -14,6 +14,7 @@
 // The BDF logic below is k_bdf_wave_member's text with the wavefront primitives replaced (generated from it once, then maintained here).
 #pragma once
 #include "dsh_wave_member_kernel.hpp"
+#include "dsh_team_reg_lu.hpp"
 
 namespace dsh {
 
@@ -30,6 +31,8 @@ __host__ __device__ constexpr int team_pitch_w(int waves) { return waves <= 2 ? 
 __host__ __device__ inline size_t team_lds_doubles(int n, int waves) {
   return (size_t)(3 * 64 * waves + 2 * waves + 32 * waves) + (team_global_factors(waves) ? (size_t)0 : (size_t)n * team_pitch_w(waves));
 }
+// the register-resident LU (64 < n <= 128, dsh_team_reg_lu.hpp): xs | xs2 | ps | cand of the integrator, then the LU's workspace
+__host__ __device__ constexpr size_t team_rl_lds_doubles(int NL) { return (size_t)(3 * 128 + 4) + (size_t)trg_lds_doubles(NL); }
 // global scratch per member: the cached Jacobian (n^2) and, beyond the LDS sizes, the factors (n x pitch)
 __host__ __device__ inline size_t team_scratch_doubles(int n, int waves) { return (size_t)n * n + (team_global_factors(waves) ? (size_t)n * team_pitch_w(waves) : (size_t)0); }
 
@@ -314,8 +317,10 @@ __device__ __forceinline__ bool team_lu_solve(const double* __restrict__ A, int 
 #define TMP_MARK(k)
 #define TMP_PRINT
 #endif
-template <int W, bool SENS = false>
-__global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
+// RL > 0: 64 < n <= RL <= 128 with the factors in REGISTERS (dsh_team_reg_lu.hpp; W = 2): 256 threads, thread t and thread t + 128 both carry row t & 127 of the
+// integrator's vectors (the same values, computed twice) and one column half each of the Jacobian and of M - c J
+template <int W, bool SENS, int RL>
+__device__ __forceinline__ void bdf_team_member_body(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
                                                        int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
                                                        int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
@@ -332,12 +337,16 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   double* sJ = jac_scratch + (size_t)blockIdx.x * team_scratch_doubles(Cp->n, W);  // the member's cached Jacobian: global scratch (L2 / MALL resident), entry (ln, j) at j * n + ln
   // the LU factors of M - c J, column-major, pitch P, rows at their final positions: in LDS, or (n > 140) in the member's global scratch behind the Jacobian
   double* A = team_global_factors(W) ? sJ + (size_t)Cp->n * Cp->n : lds + 3 * T + 2 * W + T / 2;
+  double* wk = lds + 3 * T + 2 * W;  // RL: the workspace of the register-resident LU
+  double a_rl[RL > 0 ? 64 : 1], rl_d = 1.0, rl_r = 1.0;  // RL: my half of my row of M - c J / of its factors; the diagonal of my position and div_refined_rcp of it
   const WaveMemberConsts& C = *Cp;
   const dsh_adaptive_options& o = C.r.o;
   const bool det = o.deterministic_pow != 0;
   const int n = C.n, model = C.model;
   const int64_t b = blockIdx.x;
-  const int ln = threadIdx.x;
+  const int ln = RL > 0 ? (int)(threadIdx.x & 127) : (int)threadIdx.x;
+  const int half = RL > 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
+  const bool lead = threadIdx.x == 0;
   const bool rowlive = ln < n;
   const double rtol = C.r.rtol;
   const double atol = rowlive ? (atol_broadcast ? atol_g[ln] : atol_g[(int64_t)ln * nb + b]) : 1.0;
@@ -436,6 +445,28 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   int n_setups = 0, n_steps = 0, n_err_fails = 0, n_newton = 0, n_nl_fails = 0;
   // reset_jacobian: J(x, t) row by row into LDS when stale, A = J * (-c) + I, LU in registers
   auto reset_jacobian = [&](double x_mine, double tt) __attribute__((always_inline)) {
+    if constexpr (RL > 0) {
+      if (jac_stale) {
+        __syncthreads();
+        xs[ln] = x_mine;
+        __syncthreads();
+        const int jend = n < 64 * half + 64 ? n : 64 * half + 64;
+        for (int j = 64 * half; j < jend; ++j) {  // my column half (written and read by this thread only)
+          auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
+          if (rowlive) sJ[(size_t)j * n + ln] = wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, Ej, Pf, true);
+        }
+        jac_stale = false;
+        TMP_MARK(0)
+      }
+#pragma unroll
+      for (int jj = 0; jj < 64; ++jj) {
+        const int j = 64 * half + jj;
+        a_rl[jj] = (rowlive && j < n) ? sJ[(size_t)j * n + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0) : 0.0;
+      }
+      team_reg_lu_factor<RL>(a_rl, n, (int)threadIdx.x, wk, lu_singular, rl_d, rl_r);
+      TMP_MARK(1)
+      return;
+    }
     if (jac_stale) {
       __syncthreads();
       xs[ln] = x_mine;
@@ -452,6 +483,10 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
       for (int j = 0; j < n; ++j) A[j * P + ln] = sJ[(size_t)j * n + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0);
     team_lu_factor<W>(A, P, n, ln, rowlive, cand, perm, lu_singular);
     TMP_MARK(1)
+  };
+  auto lu_solve = [&](double& rhs) __attribute__((always_inline)) -> bool {
+    if constexpr (RL > 0) return team_reg_lu_solve(a_rl, n, (int)threadIdx.x, wk, lu_singular, rl_d, rl_r, rhs);
+    else return team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, rhs);
   };
   n_setups = 1;
   // RootFinder::init
@@ -611,7 +646,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
   const bool steps_mode = !SENS && C.steps_cap > 0;  // every accepted step out (WaveMemberConsts::steps_cap)
   auto steps_write = [&](double tw, double yv_mine) __attribute__((always_inline)) {
     if (col < C.steps_cap) {
-      if (ln == 0) C.steps_t_out[(int64_t)col * nb + b] = tw;
+      if (lead) C.steps_t_out[(int64_t)col * nb + b] = tw;
       if (rowlive) y_out[((int64_t)col * n + ln) * nb + b] = yv_mine;
     }
     col++;
@@ -634,7 +669,19 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     predict_forward();
     while (true) {
       TMP_MARK(7)
-      if (reset_pending) { reset_jacobian(y, t); reset_pending = false; }
+      if (reset_pending) {
+        if constexpr (RL > 0) {
+          // The scalars of Bdf::step are the same in every thread but computed from sums read out of LDS: to the compiler they are per-lane values, and next to a
+          // thread's 128 registers of M - c J there is no room for them (scratch traffic inside the elimination loops).  Read back from lane 0 they are scalars.
+          auto sd = [](double& v) __attribute__((always_inline)) { v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+          auto si = [](int& v) __attribute__((always_inline)) { v = __builtin_amdgcn_readfirstlane(v); };
+          sd(t); sd(h); sd(opc); sd(c_reset); sd(h_at_last_jac); sd(eta); sd(prev_err); sd(t_predict); sd(rf_t0); sd(t_root); sd(g0[0]); sd(g0[1]); sd(safety); sd(error_norm);
+          si(order); si(n_setups); si(n_steps); si(n_err_fails); si(n_newton); si(n_nl_fails); si(steps_since_jac); si(steps_since_rhs_jac); si(n_equal_steps); si(col);
+          si(status); si(root_idx); si(niter);
+        }
+        reset_jacobian(y, t);
+        reset_pending = false;
+      }
       x = yp;
       niter = 0;
       bool has_old = false;
@@ -655,7 +702,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
         } else {
           delta = 1.0 * tmpv + (-opc) * f;  // F(y) = (y - y0 + psi) - c f(y)
         }
-        const bool lu_ok = team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, delta);  // unknown i comes back to thread i
+        const bool lu_ok = lu_solve(delta);  // unknown i comes back to thread i
         TMP_MARK(3)
         if (!lu_ok) break;
         x = x - delta;
@@ -710,7 +757,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
               __syncthreads();  // xs2 is the solve's exchange buffer next
               const double fr = jm + dfdp;
               double delta = 1.0 * (xsv + spsi) + (-s_c) * fr;
-              const bool lu_ok = team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, delta);
+              const bool lu_ok = lu_solve(delta);
               if (!lu_ok) break;
               xsv = xsv - delta;
               const double norm = sqrt(wms_wave(delta, sp));
@@ -983,7 +1030,7 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
       for (int q = 0; q < nsp; ++q)
         if (rowlive) C.sens_out[(((int64_t)col * nsp + q) * n + ln) * nb + b] = __builtin_nan("");
   }
-  if (ln == 0) {
+  if (lead) {
     if (ncols_out != nullptr) ncols_out[b] = ncols;
     if (t_root_out != nullptr) t_root_out[b] = root_idx >= 0 ? t_root : __builtin_nan("");
     if (root_idx_out != nullptr) root_idx_out[b] = root_idx;
@@ -1002,6 +1049,22 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
     atomicAdd(&totals[4], (unsigned long long)n_nl_fails);
     if (status != kRsOk) atomicAdd(&totals[5], 1ull);
   }
+}
+
+template <int W, bool SENS = false>
+__global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
+                                                       const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
+                                                       int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
+                                                       int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
+  bdf_team_member_body<W, SENS, 0>(nb, p_g, atol_g, atol_broadcast, Cp, t_eval, jac_scratch, y_out, stats_out, status_out, t_root_out, root_idx_out, ncols_out, totals);
+}
+// 64 < n <= NL <= 128, the factors in registers: four wavefronts, two per SIMD (256 registers a thread), two members on a CU
+template <int NL>
+__global__ __launch_bounds__(kTrgThreads, 2) void k_bdf_team_member_rl(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
+                                                       const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
+                                                       int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
+                                                       int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
+  bdf_team_member_body<2, false, NL>(nb, p_g, atol_g, atol_broadcast, Cp, t_eval, jac_scratch, y_out, stats_out, status_out, t_root_out, root_idx_out, ncols_out, totals);
 }
 
 }  // namespace dsh

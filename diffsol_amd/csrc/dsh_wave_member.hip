@@ -11,6 +11,8 @@
 //   * linear solves: wave_lu_solve_rows — the rows stay where the factorisation left them, no interchange of the right-hand side
 // Arithmetic is the oracle's operation for operation; pow() and the model's tanh/asinh/exp are ocml's (tests state the tolerance).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "dsh_internal.hpp"
@@ -45,6 +47,8 @@ int dsh_model_has_wave_member(int model, int64_t size) {
   return !has_mass && n <= kTeamMaxN ? 2 : 0;  // the workgroup form takes identity-mass models
 }
 
+// the register-resident LU of the workgroup-per-member BDF (64 < n <= 128) — on unless DSH_TEAM_REG_LU=0 (read at every launch: the tests compare the two forms)
+static bool team_reg_lu_on() { const char* e = getenv("DSH_TEAM_REG_LU"); return !(e && e[0] == '0'); }
 struct WmSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
 struct WmStepsSpec { double* t_out; int64_t cap; };  // OdeSolverMethod::solve: every accepted step out (WaveMemberConsts::steps_cap)
 static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
@@ -160,15 +164,43 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   if (wm_kind == 2) {
     // one workgroup per member (64 < n <= 320): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
     const int waves = team_waves((int)n);
-    const size_t lds_team = sizeof(double) * team_lds_doubles((int)n, waves);
+    // 64 < n <= 128 without sensitivities: the factors in the registers of four wavefronts (dsh_team_reg_lu.hpp; DSH_TEAM_REG_LU=0: in LDS, two wavefronts, as before).
+    // NL, the compile-time bound on n: n rounded up to 8 for a run-time-compiled model (its module is its own), four steps for the built-in ones.
+    const bool reg_lu = !sens && n <= kTrgMaxN && team_reg_lu_on();
+    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : 128))));
+    const size_t lds_team = sizeof(double) * (reg_lu ? team_rl_lds_doubles(NL) : team_lds_doubles((int)n, waves));
     rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     DSH_HIP_CHECK(timing_begin(ctx));
     if (is_jit_model(model)) {
-      const std::string name = std::string("dsh::k_bdf_team_member<") + std::to_string(waves) + (sens ? ", true>" : ">");
-      rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(64 * waves), (unsigned)lds_team, nb, p, atol, ab,
+      const std::string name = reg_lu ? std::string("dsh::k_bdf_team_member_rl<") + std::to_string(NL) + ">"
+                                      : std::string("dsh::k_bdf_team_member<") + std::to_string(waves) + (sens ? ", true>" : ">");
+      rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(reg_lu ? kTrgThreads : 64 * waves), (unsigned)lds_team, nb, p, atol, ab,
                       (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
       if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
+    } else if (reg_lu) {
+      static bool attr_rl_dev[64] = {false};
+      bool& attr = attr_rl_dev[ctx->device & 63];
+      if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<112>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+      }
+#define DSH_TMR_LAUNCH(NLV)                                                                                                                                              \
+  hipLaunchKernelGGL((k_bdf_team_member_rl<NLV>), dim3((unsigned)nb), dim3(kTrgThreads), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
+                     (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
+      if (getenv("DSH_TEAM_DEBUG")) {  // how many members share a CU (two when the workspace fits twice)
+        int occ = 0;
+        if (NL == 128) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<128>, kTrgThreads, lds_team);
+        else if (NL == 112) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<112>, kTrgThreads, lds_team);
+        else if (NL == 96) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<96>, kTrgThreads, lds_team);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<80>, kTrgThreads, lds_team);
+        fprintf(stderr, "k_bdf_team_member_rl<%d>: n = %d, %zu bytes of LDS, %d workgroups per CU\n", NL, (int)n, lds_team, occ);
+      }
+      if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else DSH_TMR_LAUNCH(128);
+#undef DSH_TMR_LAUNCH
     } else {
       static bool attr_dev[64] = {false};
       bool& attr = attr_dev[ctx->device & 63];

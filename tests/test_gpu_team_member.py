@@ -1,5 +1,5 @@
-"""Device-resident BDF for dense run-time-sized models with 64 < n <= 140: one WORKGROUP per member, M - cJ and its LU in the CU's LDS
-(csrc/dsh_team_member_kernel.hpp; VERDICT r3 missing 1 — the reference's Bdf::step is size-generic, bdf.rs:1277-1589).  Parity bar: every member's counters
+"""Device-resident BDF for dense run-time-sized models with 64 < n <= 320: one WORKGROUP per member, M - cJ and its LU in registers (n <= 128, csrc/dsh_team_reg_lu.hpp),
+in the CU's LDS (n <= 140) or in global scratch (csrc/dsh_team_member_kernel.hpp; VERDICT r3 missing 1 — the reference's Bdf::step is size-generic, bdf.rs:1277-1589).  Parity bar: every member's counters
 and every output bit equal the oracle's independent solve_dense per member (deterministic pow on both sides), as for the wavefront-per-member kernels."""
 import numpy as np
 import pytest
@@ -107,6 +107,51 @@ def test_dense_coupled_oscillators_from_diffsl_with_row_interchanges(H, O, det_p
     assert np.array_equal(mm["stats"].T, so), "counters differ"
     assert np.array_equal(y, yo), "states differ"
     assert so[:, 2].min() >= 3  # several refactorisations per member: the LU ran with different c
+
+
+@pytest.mark.parametrize("groups", [22, 27, 32, 40, 42])
+def test_the_register_resident_lu_has_the_bits_of_the_oracle_and_of_the_lds_resident_lu(H, O, det_pow, groups, monkeypatch):
+    """64 < n <= 128: M - cJ and its factors in the registers of four wavefronts (csrc/dsh_team_reg_lu.hpp; 2 x 2 blocks of 64 x 64, two members on a CU) — the default —
+    against the oracle, and the LDS-resident form (DSH_TEAM_REG_LU=0, two wavefronts) against both: n = 66 .. 126 covers every compile-time column bound of the built-in
+    models (80 / 96 / 112 / 128), second row blocks from 2 to 62 rows, and the pivoted 3 x 3 blocks of robertson_ode."""
+    monkeypatch.setenv("DSH_RESIDENT_LANE", "0")
+    rng = np.random.default_rng(1000 + groups)
+    nb = 5
+    p = np.stack([0.04 * 2 ** rng.uniform(-1, 1, nb), 1e4 * 2 ** rng.uniform(-1, 1, nb), 3e7 * 2 ** rng.uniform(-1, 1, nb)], axis=1)
+    t_eval = [0.4, 4.0, 40.0, 400.0]
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * groups)
+    s, m = _pair(H, O, "robertson_ode", ORACLE_MODEL["robertson_ode"], p, t_eval, groups, **tol)
+    y1, _, m1 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    monkeypatch.setenv("DSH_TEAM_REG_LU", "0")
+    y0, _, m0 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    assert np.array_equal(y0, y1) and np.array_equal(m0["stats"], m1["stats"])
+
+
+@pytest.mark.parametrize("m", [36, 60, 64])
+def test_dense_coupled_oscillators_from_diffsl_through_the_register_resident_lu(H, O, det_pow, m, monkeypatch):
+    """the DiffSL oscillators (dense Jacobian, row interchanges in every factorisation) at n = 72 / 120 / 128: hiprtc's instantiation of k_bdf_team_member_rl<n rounded
+    up to 8> against the oracle on the host twin, and against the LDS-resident form"""
+    import diffsl_models as D
+    from diffsol_amd import diffsl
+    code = D.oscillators(m)
+    model = diffsl.DiffslModel(code)
+    mid = D.host_model(O, code)
+    rng = np.random.default_rng(500 + m)
+    nb = 5
+    p = np.stack([rng.uniform(20.0, 80.0, nb), rng.uniform(0.5, 2.0, nb), rng.uniform(0.005, 0.02, nb)], axis=1)
+    t_eval = [0.05, 0.2, 0.5]
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    s = H.Solver(model, p, nbatch=nb, **tol)
+    assert s.n == 2 * m
+    y, tot, mm = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, **tol)
+    yo = np.transpose(yo, (1, 0, 2))
+    assert failed == 0 and (mm["status"] == 0).all()
+    assert np.array_equal(mm["stats"].T, so), "counters differ"
+    assert np.array_equal(y, yo), "states differ"
+    monkeypatch.setenv("DSH_TEAM_REG_LU", "0")
+    y0, _, m0 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    assert np.array_equal(y0, y) and np.array_equal(m0["stats"], mm["stats"])
 
 
 @pytest.mark.parametrize("n", [141, 200, 256, 257, 320])
