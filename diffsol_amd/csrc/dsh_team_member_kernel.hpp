@@ -37,15 +37,27 @@ __host__ __device__ constexpr size_t team_rl_lds_doubles(int NL) { return (size_
 __host__ __device__ inline size_t team_scratch_doubles(int n, int waves) { return (size_t)n * n + (team_global_factors(waves) ? (size_t)n * team_pitch_w(waves) : (size_t)0); }
 
 // sum of n terms held in LDS, in index order, the reads of eight terms issued together (one read per round trip: 94 cycles per term)
+// (the next eight are requested before the current eight are added: the additions are one dependent chain, the reads need not wait inside it — a norm of n = 120 terms
+// the reads of a batch no longer stand between two additions; there are five to eight norms per step)
 __device__ __forceinline__ double team_seq_sum(const double* __restrict__ red, int n) {
   double acc = 0.0;
   int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    double t8[8];
+  if (n >= 8) {
+    double cur[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t8[u] = red[i + u];
+    for (int u = 0; u < 8; ++u) cur[u] = red[u];
+    for (; i + 16 <= n; i += 8) {
+      double nxt[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += t8[u];
+      for (int u = 0; u < 8; ++u) nxt[u] = red[i + 8 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += cur[u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += cur[u];
+    i += 8;
   }
   for (; i < n; ++i) acc += red[i];
   return acc;

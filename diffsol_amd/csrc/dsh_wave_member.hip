@@ -165,9 +165,10 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
     // one workgroup per member (64 < n <= 320): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
     const int waves = team_waves((int)n);
     // 64 < n <= 128 without sensitivities: the factors in the registers of four wavefronts (dsh_team_reg_lu.hpp; DSH_TEAM_REG_LU=0: in LDS, two wavefronts, as before).
-    // NL, the compile-time bound on n: n rounded up to 8 for a run-time-compiled model (its module is its own), four steps for the built-in ones.
+    // NL, the compile-time bound on n: n rounded up to 8 for a run-time-compiled model (its module is its own), five steps for the built-in ones
+    // (120: the reference's own benchmark size, robertson_ode x 40).
     const bool reg_lu = !sens && n <= kTrgMaxN && team_reg_lu_on();
-    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : 128))));
+    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : (n <= 120 ? 120 : 128)))));
     const size_t lds_team = sizeof(double) * (reg_lu ? team_rl_lds_doubles(NL) : team_lds_doubles((int)n, waves));
     rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -185,6 +186,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<112>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<120>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
       }
@@ -194,12 +196,13 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
       if (getenv("DSH_TEAM_DEBUG")) {  // how many members share a CU (two when the workspace fits twice)
         int occ = 0;
         if (NL == 128) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<128>, kTrgThreads, lds_team);
+        else if (NL == 120) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<120>, kTrgThreads, lds_team);
         else if (NL == 112) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<112>, kTrgThreads, lds_team);
         else if (NL == 96) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<96>, kTrgThreads, lds_team);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<80>, kTrgThreads, lds_team);
         fprintf(stderr, "k_bdf_team_member_rl<%d>: n = %d, %zu bytes of LDS, %d workgroups per CU\n", NL, (int)n, lds_team, occ);
       }
-      if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else DSH_TMR_LAUNCH(128);
+      if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else if (NL == 120) DSH_TMR_LAUNCH(120); else DSH_TMR_LAUNCH(128);
 #undef DSH_TMR_LAUNCH
     } else {
       static bool attr_dev[64] = {false};

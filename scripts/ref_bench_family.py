@@ -4,7 +4,7 @@ python_results.csv), BDF, rtol = atol = tol for tol in (1e-4, 1e-8), run as ENSE
 has for that size, next to the published single-solve time of diffsol's CPU path (one EPYC 7343 core; the t_final / output grid of that benchmark live outside the
 reference tree, so the published point is indicative — ours: t in [0, 4e5], 7 save points, bench.py's horizon).
 
-    python scripts/ref_bench_family.py [nb]      -> gpurun_out/r04/ref_family.json + a markdown table on stdout"""
+    python scripts/ref_bench_family.py [nb]      -> gpurun_out/r06/ref_family.json + a markdown table on stdout"""
 import json
 import os
 import sys
@@ -30,7 +30,7 @@ for groups in (1, 10, 20, 40, 100):
         else:
             routes = [("banded lane per member (block-diagonal Jacobian declared)", {"DSH_RESIDENT_LANE": "1"}, 1)]
             if n <= 140:
-                routes.append(("wavefront per member" if n <= 64 else "workgroup per member (LU in LDS)", {"DSH_RESIDENT_LANE": "0"}, 1))
+                routes.append(("wavefront per member" if n <= 64 else ("workgroup per member (LU in registers)" if n <= 128 else "workgroup per member (LU in LDS)"), {"DSH_RESIDENT_LANE": "0"}, 1))
         for name, env, group in routes:
             for k, v in env.items():
                 os.environ[k] = v
@@ -62,8 +62,8 @@ for groups in (1, 10, 20, 40, 100):
             except Exception as e:  # noqa: BLE001
                 rows.append(dict(ngroups=groups, n=n, tol=tol, route="host-driven lock-step", error=str(e)[:200]))
             print(json.dumps(rows[-1]), flush=True)
-os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
-json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "r04", "ref_family.json"), "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r06"), exist_ok=True)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "r06", "ref_family.json"), "w"), indent=1)
 lines = ["| ngroups | n | tol | route | members | wall (s) | s / member | steps / member | published diffsol CPU s / solve | members solved per published CPU-solve time |",
          "|---|---|---|---|---|---|---|---|---|---|"]
 for r in rows:
@@ -73,5 +73,5 @@ for r in rows:
     pub = r["published_diffsol_cpu_seconds_per_solve"]
     lines.append(f"| {r['ngroups']} | {r['n']} | {r['tol']:g} | {r['route']} | {r['members']} | {r['wall_s']:.4f} | {r['seconds_per_member']:.3e} | {r['steps_per_member']:.0f} | "
                  + (f"{pub:.3e} | {pub / r['seconds_per_member']:.1f} |" if pub else " | |"))
-open(os.path.join(ROOT, "gpurun_out", "r04", "ref_family.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "gpurun_out", "r06", "ref_family.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
