@@ -462,17 +462,17 @@ __device__ __forceinline__ void bdf_team_member_body(int64_t nb, const double* _
         __syncthreads();
         xs[ln] = x_mine;
         __syncthreads();
-        const int jend = n < 64 * half + 64 ? n : 64 * half + 64;
-        for (int j = 64 * half; j < jend; ++j) {  // my column half (written and read by this thread only)
+        for (int jj = 0; jj < 64; ++jj) {  // my columns (the elimination's layout, trg_gcol; written and read by this thread only)
+          const int j = trg_gcol(half, jj);
           auto Ej = [&](int64_t k) { return k == j ? 1.0 : 0.0; };
-          if (rowlive) sJ[(size_t)j * n + ln] = wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, Ej, Pf, true);
+          if (rowlive && j < n) sJ[(size_t)j * n + ln] = wm_component(model, (int64_t)n, tt, (int64_t)ln, Xf, Ej, Pf, true);
         }
         jac_stale = false;
         TMP_MARK(0)
       }
 #pragma unroll
       for (int jj = 0; jj < 64; ++jj) {
-        const int j = 64 * half + jj;
+        const int j = trg_gcol(half, jj);
         a_rl[jj] = (rowlive && j < n) ? sJ[(size_t)j * n + ln] * (-c_reset) + (j == ln ? 1.0 : 0.0) : 0.0;
       }
       team_reg_lu_factor<RL>(a_rl, n, (int)threadIdx.x, wk, lu_singular, rl_d, rl_r);

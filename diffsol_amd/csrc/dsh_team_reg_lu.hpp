@@ -89,30 +89,41 @@ __device__ __forceinline__ int trg_argmax(double ck, bool active, int pos, int n
   return (int)trg_wave_min_u32((key == best && best != 0ull) ? (unsigned int)pos : (unsigned int)n);
 }
 
-// the owner of pivot row k in column half H archives its part of the row: columns from the even column at or left of the pivot on
+// Columns during the ELIMINATION are dealt to the two column halves in blocks of eight, alternately: half H holds the global blocks 2 q + H (q = 0 .. 7) at its
+// local columns 8 q .. 8 q + 7.  With contiguous halves the second half carries all 64 of its columns through each of the first 64 pivots — the single lane
+// that publishes its part of the pivot row and the update of those columns are the slow side of every one of those steps — while the first half runs out of
+// work; dealt in blocks both halves hold half of what is left at every pivot.  The substitutions want contiguous halves (a diagonal block inside one
+// wavefront): the exchange that moves the rows to their positions at the end also moves the column blocks (trg_exchange).
+__host__ __device__ constexpr int trg_gcol(int H, int j) { return 16 * (j >> 3) + 8 * H + (j & 7); }  // global column of local column j of half H
+
+// the owner of pivot row k in column half H archives its part of the row: its columns from local column J0 on, in the pivot's own block from the even
+// column at or left of the pivot on
 template <int H, int HB, int KB0, int NL>
 __device__ __forceinline__ void trg_archive_row(const double (&a)[64], double* __restrict__ archk, int k) {
   const int je = k & ~1;
+  constexpr int J0 = H == HB ? KB0 : (H > HB ? KB0 : KB0 + 8);
 #pragma unroll
-  for (int j = H > HB ? 0 : KB0; j < 64; j += 2) {
-    if (64 * H + j < NL) {
-      if (H > HB || j >= KB0 + 8 || 64 * HB + j >= je) *reinterpret_cast<double2*>(archk + 64 * H + j) = make_double2(a[j], a[j + 1]);
+  for (int j = J0; j < 64; j += 2) {
+    if (trg_gcol(H, j) < NL) {
+      if (H != HB || j >= KB0 + 8 || trg_gcol(H, j) >= je) *reinterpret_cast<double2*>(archk + trg_gcol(H, j)) = make_double2(a[j], a[j + 1]);
     }
   }
 }
 
-// One elimination step inside the block of eight pivots that starts at local column KB0 of column half HB, for the two wavefronts of column half H
-// (compile time: each half runs its own straight-line copy of the factorisation; the workgroup barriers pair up across the copies).  kk: the pivot's index
-// inside the block (uniform).
+// One elimination step inside global block B of eight pivots (held by column half HB = B & 1 at its local columns KB0 = 8 (B >> 1) ..), for the two wavefronts
+// of column half H (compile time: each half runs its own straight-line copy of the factorisation; the workgroup barriers pair up across the copies).
+// kk: the pivot's index inside the block (uniform).
 // EVERY lane takes the multiplier and the update — also the rows that are finished (position <= k) and the rows beyond n — and a zero pivot goes through the
 // same instructions: any path on which the row stays as it is (a predicated region, an early return, a loop that may run zero times) makes the compiler
 // keep two copies of the row — the value before and after — 440 registers, or 900 bytes of scratch at the 256 that two wavefronts per SIMD leave.
 //   * what a finished row loses — its U part, columns right of its own pivot — was archived in LDS when it became the pivot row (that is also what the other
 //     rows read it from) and comes back from there at the end; its L part (columns left of its own pivot) is not touched by later steps;
 //   * a zero pivot eliminates nothing: the multiplier becomes +0 and the pivot row is read from a row of +0 — (-(+0)) (+0) + a = (-0) + a = a for every a.
-template <int H, int HB, int KB0, int NL>
+template <int H, int B, int NL>
 __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row, int lane, int rb, bool rowlive, double* __restrict__ w, int& pos, bool& singular, double& colk, TrgProf& pf) {
-  const int k = 64 * HB + KB0 + kk;
+  constexpr int HB = B & 1, KB0 = 8 * (B >> 1);
+  constexpr int J0 = H == HB ? KB0 + 8 : (H > HB ? KB0 : KB0 + 8);  // my first local column right of the pivot's block
+  const int k = 8 * B + kk;
   double* cand = w + 8 * (k & 1);
   double* colbuf = w + kTrgOffCol + 128 * (k & 1);
   double* archk = w + trg_off_arch(NL) + trg_arch_base(k, NL);  // column j of pivot row k: archk[j] (16-byte aligned for even j)
@@ -120,11 +131,9 @@ __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row
   // selects becomes ONE load through a phi / select of eight addresses, and the whole row stays in scratch
   const double ck = colk;
   TRG_T0
-  if constexpr (H >= HB) {
-    if (pos == k) trg_archive_row<H, HB, KB0, NL>(a, archk, k);  // on the assumption that the diagonal is the pivot
-  }
+  if (pos == k) trg_archive_row<H, HB, KB0, NL>(a, archk, k);  // on the assumption that the diagonal is the pivot
   if constexpr (H == HB) {  // the two wavefronts that hold column k: candidates
-    if constexpr (HB == 0 && NL > 64) colbuf[row] = ck;  // the other column half makes its multipliers from it
+    colbuf[row] = ck;  // the other column half makes its multipliers from it
     const bool active = rowlive && pos >= k;
     const int p = trg_argmax(ck, active, pos, n);
     // the winner also publishes 1 / its entry: the division leaves the path behind the barrier (the wavefronts of the other column half wait there)
@@ -139,7 +148,7 @@ __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row
   const double2 c01 = *reinterpret_cast<const double2*>(cand), c23 = *reinterpret_cast<const double2*>(cand + 2), c45 = *reinterpret_cast<const double2*>(cand + 4),
                 c67 = *reinterpret_cast<const double2*>(cand + 6);
   double ckk = 0.0;
-  if constexpr (H > HB) ckk = colbuf[row];
+  if constexpr (H != HB) ckk = colbuf[row];
   double s0 = c01.x, r0 = c45.y;
   int p0 = (int)c01.y;
   {
@@ -155,9 +164,7 @@ __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row
   if (!elim) singular = true;
   if (p != k) {  // workgroup-uniform: an interchange; the real pivot row replaces the one published above (no definition of a[] in here)
     if (pos == p) pos = k; else if (pos == k) pos = p;
-    if constexpr (H >= HB) {
-      if (pos == k) trg_archive_row<H, HB, KB0, NL>(a, archk, k);
-    }
+    if (pos == k) trg_archive_row<H, HB, KB0, NL>(a, archk, k);
     __syncthreads();
   }
   TRG_MARK(3)
@@ -168,62 +175,78 @@ __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row
     l = elim ? ck * rinv : 0.0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) a[KB0 + c] = (kk == c && elim) ? l : a[KB0 + c];
-  } else if constexpr (H > HB) {
+  } else {
     l = elim ? ckk * rinv : 0.0;
   }
   TRG_MARK(2)
-  if constexpr (H == HB) {
-    {  // the block's own columns: only those right of the pivot take the update (selects on a uniform condition)
+  if constexpr (H == HB) {  // the block's own columns: only those right of the pivot take the update (selects on a uniform condition)
+    double2 u2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u2[q] = *reinterpret_cast<const double2*>(src + trg_gcol(H, KB0) + 2 * q);
+    const double u[8] = {u2[0].x, u2[0].y, u2[1].x, u2[1].y, u2[2].x, u2[2].y, u2[3].x, u2[3].y};
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+      const double upd = (-u[c]) * l + a[KB0 + c];
+      a[KB0 + c] = c > kk ? upd : a[KB0 + c];
+      colk = c == kk + 1 ? upd : colk;
+    }
+  }
+#pragma unroll
+  for (int j0 = J0; j0 < 64; j0 += 8) {
+    if (trg_gcol(H, j0) < NL) {
       double2 u2[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) u2[q] = *reinterpret_cast<const double2*>(src + 64 * HB + KB0 + 2 * q);
+      for (int q = 0; q < 4; ++q) u2[q] = *reinterpret_cast<const double2*>(src + trg_gcol(H, j0) + 2 * q);
       const double u[8] = {u2[0].x, u2[0].y, u2[1].x, u2[1].y, u2[2].x, u2[2].y, u2[3].x, u2[3].y};
 #pragma unroll
-      for (int c = 1; c < 8; ++c) {
-        const double upd = (-u[c]) * l + a[KB0 + c];
-        a[KB0 + c] = c > kk ? upd : a[KB0 + c];
-        colk = c == kk + 1 ? upd : colk;
-      }
-    }
-#pragma unroll
-    for (int j0 = KB0 + 8; j0 < 64; j0 += 8) {
-      if (64 * HB + j0 < NL) {
-        double2 u2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) u2[q] = *reinterpret_cast<const double2*>(src + 64 * HB + j0 + 2 * q);
-        const double u[8] = {u2[0].x, u2[0].y, u2[1].x, u2[1].y, u2[2].x, u2[2].y, u2[3].x, u2[3].y};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[j0 + c] = (-u[c]) * l + a[j0 + c];
-        DSH_TRG_SCHED_FENCE
-      }
-    }
-  } else if constexpr (H > HB) {
-#pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {
-      if (64 + j0 < NL) {
-        double2 u2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) u2[q] = *reinterpret_cast<const double2*>(src + 64 + j0 + 2 * q);
-        const double u[8] = {u2[0].x, u2[0].y, u2[1].x, u2[1].y, u2[2].x, u2[2].y, u2[3].x, u2[3].y};
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[j0 + c] = (-u[c]) * l + a[j0 + c];
-        DSH_TRG_SCHED_FENCE
-      }
+      for (int c = 0; c < 8; ++c) a[j0 + c] = (-u[c]) * l + a[j0 + c];
     }
   }
   TRG_MARK(4)
 }
 
-template <int H, int HB, int KB0, int NL>
+template <int H, int B, int NL>
 __device__ __forceinline__ void trg_block(double (&a)[64], int n, int row, int lane, int rb, bool rowlive, double* __restrict__ w, int& pos, bool& singular, TrgProf& pf) {
-  constexpr int kbase = 64 * HB + KB0;
+  constexpr int kbase = 8 * B;
   if constexpr (kbase < NL) {
     if (kbase >= n) return;  // (NL may exceed n by more than a block; this bypass costs no second copy of the row — the per-step ones did)
     const int kend = n - kbase < 8 ? n - kbase : 8;
-    double colk = H == HB ? a[KB0] : 0.0;
+    double colk = H == (B & 1) ? a[8 * (B >> 1)] : 0.0;
     int kk = 0;
 #pragma nounroll
-    do { trg_step<H, HB, KB0, NL>(a, n, kk, row, lane, rb, rowlive, w, pos, singular, colk, pf); } while (++kk < kend);
+    do { trg_step<H, B, NL>(a, n, kk, row, lane, rb, rowlive, w, pos, singular, colk, pf); } while (++kk < kend);
+  }
+}
+
+// The exchange at the end of the factorisation: every row to its final position AND every column block from the dealt layout of the elimination to the
+// contiguous halves of the substitutions, in place.  Slot r of half y (its local columns 8 r ..) takes global block 8 y + r, which half x = r & 1 holds in its
+// slot t = 4 y + (r >> 1): written as four bits, (x t2 t1 t0) is (y r2 r1 r0) rotated — so the slots fall into the cycles of that rotation ({0}, {15}, {5, 10},
+// {1, 2, 4, 8}, {3, 6, 12, 9}, {7, 14, 13, 11}), and a cycle whose slots all go through LDS in the same pass (everyone writes, barrier, everyone reads) is
+// exchanged in place.  W columns of every slot of the cycle per pass: as many as the buffer (2 CH column vectors of 129) takes.
+template <int H, int NL, int NODES, int N0, int N1, int N2, int N3>
+__device__ __forceinline__ void trg_exchange_cycle(double (&a)[64], int row, int pos, double* __restrict__ exch) {
+  constexpr int node[4] = {N0, N1, N2, N3};
+  constexpr int W = 2 * trg_chunk(NL) / NODES < 8 ? 2 * trg_chunk(NL) / NODES : 8;  // columns of a slot per pass
+#pragma unroll
+  for (int c0 = 0; c0 < 8; c0 += W) {
+#pragma unroll
+    for (int i = 0; i < NODES; ++i) {  // destination slot (y, r) = node i: its source is slot t of half x
+      const int y = node[i] >> 3, r = node[i] & 7, x = r & 1, t = 4 * y + (r >> 1);
+      if (H == x && 8 * (8 * y + r) < NL) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) exch[(i * W + c) * kTrgPitch + pos] = a[8 * t + c0 + c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NODES; ++i) {
+      const int y = node[i] >> 3, r = node[i] & 7;
+      if (H == y && 8 * (8 * y + r) < NL) {
+#pragma unroll
+        for (int c = 0; c < W; ++c) a[8 * r + c0 + c] = exch[(i * W + c) * kTrgPitch + row];
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -231,30 +254,21 @@ template <int H, int NL>
 __device__ __forceinline__ void trg_factor_half(double (&a)[64], int n, int row, int lane, int rb, bool rowlive, double* __restrict__ w, int& pos, bool& singular,
                                                 double& dself, double& rself) {
   TrgProf pf;
-#define DSH_TRG_BLOCK(HB, KB0) trg_block<H, HB, KB0, NL>(a, n, row, lane, rb, rowlive, w, pos, singular, pf);
-  DSH_TRG_BLOCK(0, 0) DSH_TRG_BLOCK(0, 8) DSH_TRG_BLOCK(0, 16) DSH_TRG_BLOCK(0, 24) DSH_TRG_BLOCK(0, 32) DSH_TRG_BLOCK(0, 40) DSH_TRG_BLOCK(0, 48) DSH_TRG_BLOCK(0, 56)
-  DSH_TRG_BLOCK(1, 0) DSH_TRG_BLOCK(1, 8) DSH_TRG_BLOCK(1, 16) DSH_TRG_BLOCK(1, 24) DSH_TRG_BLOCK(1, 32) DSH_TRG_BLOCK(1, 40) DSH_TRG_BLOCK(1, 48) DSH_TRG_BLOCK(1, 56)
+#define DSH_TRG_BLOCK(B) trg_block<H, B, NL>(a, n, row, lane, rb, rowlive, w, pos, singular, pf);
+  DSH_TRG_BLOCK(0) DSH_TRG_BLOCK(1) DSH_TRG_BLOCK(2) DSH_TRG_BLOCK(3) DSH_TRG_BLOCK(4) DSH_TRG_BLOCK(5) DSH_TRG_BLOCK(6) DSH_TRG_BLOCK(7)
+  DSH_TRG_BLOCK(8) DSH_TRG_BLOCK(9) DSH_TRG_BLOCK(10) DSH_TRG_BLOCK(11) DSH_TRG_BLOCK(12) DSH_TRG_BLOCK(13) DSH_TRG_BLOCK(14) DSH_TRG_BLOCK(15)
 #undef DSH_TRG_BLOCK
   TRG_FLUSH
-  // every row to its final position: all columns through LDS, CH of each half per pass (the U part that arrives is meaningless) ...
-  constexpr int CH = trg_chunk(NL);
+  // every row to its final position, every column block to the half that holds it in the substitutions (the U part that arrives is meaningless) ...
   int* perm = reinterpret_cast<int*>(w + kTrgOffPerm);
   double* exch = w + kTrgOffExch;
   __syncthreads();
   if (H == 0) perm[pos] = row;
-#pragma unroll
-  for (int c0 = 0; c0 < 64; c0 += CH) {
-    if (64 * H + c0 < NL) {
-#pragma unroll
-      for (int c = 0; c < CH; ++c) exch[(H * CH + c) * kTrgPitch + pos] = a[c0 + c];
-    }
-    __syncthreads();
-    if (64 * H + c0 < NL) {
-#pragma unroll
-      for (int c = 0; c < CH; ++c) a[c0 + c] = exch[(H * CH + c) * kTrgPitch + row];
-    }
-    __syncthreads();
-  }
+  trg_exchange_cycle<H, NL, 2, 0, 15, 0, 0>(a, row, pos, exch);
+  trg_exchange_cycle<H, NL, 2, 5, 10, 0, 0>(a, row, pos, exch);
+  trg_exchange_cycle<H, NL, 4, 1, 2, 4, 8>(a, row, pos, exch);
+  trg_exchange_cycle<H, NL, 4, 3, 6, 12, 9>(a, row, pos, exch);
+  trg_exchange_cycle<H, NL, 4, 7, 14, 13, 11>(a, row, pos, exch);
   // ... and the U part of position `row` from the archive; the diagonal entry of my position and the half of a division by it that depends on it alone
   const double* archr = w + trg_off_arch(NL) + trg_arch_base(row < NL ? row : 0, NL);
 #pragma unroll
@@ -268,8 +282,8 @@ __device__ __forceinline__ void trg_factor_half(double (&a)[64], int n, int row,
   rself = div_refined_rcp(dself);
 }
 
-// LU with partial pivoting of the n x n matrix whose row (tid & 127), columns 64 (tid >> 7) .. + 63 thread tid holds in a[] (entries beyond n: anything).
-// On return thread tid holds the same part of the row at POSITION tid & 127 of P A = L U (L below, U on and above the diagonal), perm[] (LDS) the original
+// LU with partial pivoting of the n x n matrix whose row (tid & 127) thread tid holds in a[]: local column j = global column trg_gcol(tid >> 7, j) (entries beyond n:
+// anything).  On return thread tid holds columns 64 (tid >> 7) .. + 63 of the row at POSITION tid & 127 of P A = L U (L below, U on and above the diagonal), perm[] (LDS) the original
 // row at every position, dself / rself the diagonal entry of that position and div_refined_rcp of it.  All 256 threads must call it together;
 // w: trg_lds_doubles(NL) of LDS.
 template <int NL>

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kTrgThreads, TRG_WPE) void k_reg(int n, int nfac, i
   bool singular = false;
   for (int f = 0; f < nfac; ++f) {
 #pragma unroll
-    for (int j = 0; j < 64; ++j) a[j] = (rowlive && 64 * h + j < n) ? M[s * n * n + (size_t)(64 * h + j) * n + row] : 0.0;
+    for (int j = 0; j < 64; ++j) a[j] = (rowlive && trg_gcol(h, j) < n) ? M[s * n * n + (size_t)trg_gcol(h, j) * n + row] : 0.0;  // the elimination's column layout
 #ifndef TRG_NO_FACTOR
     team_reg_lu_factor<TRG_NL>(a, n, tid, w, singular, dself, rself);
 #endif
