@@ -133,8 +133,8 @@ int main(int argc, char** argv) {
 #ifdef DSH_TRG_PROF
   { unsigned long long pr[4][8]; CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(dsh::g_trg), sizeof pr));
     const double steps = 35.0 * n;  // factorisations of workgroup 0 in the launches above x pivots
-    for (int q = 0; q < 4; ++q) printf("  cycles per pivot step, wavefront %d (rb %d, h %d): publish + search %.0f | barrier %.0f | candidates, interchange %.0f | multiplier %.0f | update %.0f\n", q, q & 1, q >> 1,
-                                       pr[q][0] / steps, pr[q][1] / steps, pr[q][3] / steps, pr[q][2] / steps, pr[q][4] / steps);
+    for (int q = 0; q < 4; ++q) printf("  cycles per pivot step, wavefront %d (rb %d, h %d): publish + search %.0f | LDS writes done %.0f | barrier %.0f | candidates, interchange, multiplier %.0f | update %.0f\n", q, q & 1, q >> 1,
+                                       pr[q][0] / steps, pr[q][2] / steps, pr[q][1] / steps, pr[q][3] / steps, pr[q][4] / steps);
     unsigned long long ps[4][8]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(dsh::g_trs), sizeof ps));
     const double solves = 5.0 * nsol;
     for (int q = 0; q < 4; ++q) printf("  cycles per solve, wavefront %d (rb %d, h %d): gather P b %.0f | fwd block 0 %.0f | rows 64.. take y[0..63] %.0f | fwd + back block 1 %.0f | rows 0..63 take x[64..] %.0f | back block 0 %.0f | barriers and waits %.0f\n", q, q & 1, q >> 1,
