@@ -161,14 +161,18 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
   const int ab = atol_nb == 1 ? 1 : 0;
   double* jac_scratch = nullptr;
-  if (wm_kind == 2) {
-    // one workgroup per member (64 < n <= 320): the factors in LDS, the cached Jacobians in global scratch (n^2 doubles per member)
+  // 48 < n <= 64, identity mass, no sensitivities: the workgroup form with the LU in registers too — the wavefront-per-member kernel's elimination (one lane per row, a
+  // jump per pivot into straight-line code) needs more than the 512 registers a wavefront can have next to the integrator's state at NP = 64 (2.5 KB of scratch, most of
+  // its traffic inside the elimination: 227 us per factorisation at n = 60 inside that kernel against 90 us here; profiles/r06_team_reg_lu.md)
+  const bool small_team = wm_kind == 1 && n > 48 && !has_mass && !sens && team_reg_lu_on();
+  if (wm_kind == 2 || small_team) {
+    // one workgroup per member (48 < n <= 320): the factors in registers (n <= 128) / LDS / global scratch, the cached Jacobians in global scratch (n^2 doubles per member)
     const int waves = team_waves((int)n);
     // 64 < n <= 128 without sensitivities: the factors in the registers of four wavefronts (dsh_team_reg_lu.hpp; DSH_TEAM_REG_LU=0: in LDS, two wavefronts, as before).
     // NL, the compile-time bound on n: n rounded up to 8 for a run-time-compiled model (its module is its own), five steps for the built-in ones
     // (120: the reference's own benchmark size, robertson_ode x 40).
     const bool reg_lu = !sens && n <= kTrgMaxN && team_reg_lu_on();
-    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : (n <= 120 ? 120 : 128)))));
+    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 64 ? 64 : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : (n <= 120 ? 120 : 128))))));
     const size_t lds_team = sizeof(double) * (reg_lu ? team_rl_lds_doubles(NL) : team_lds_doubles((int)n, waves));
     rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -183,6 +187,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
       static bool attr_rl_dev[64] = {false};
       bool& attr = attr_rl_dev[ctx->device & 63];
       if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<112>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -199,10 +204,11 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
         else if (NL == 120) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<120>, kTrgThreads, lds_team);
         else if (NL == 112) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<112>, kTrgThreads, lds_team);
         else if (NL == 96) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<96>, kTrgThreads, lds_team);
+        else if (NL == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<64>, kTrgThreads, lds_team);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<80>, kTrgThreads, lds_team);
         fprintf(stderr, "k_bdf_team_member_rl<%d>: n = %d, %zu bytes of LDS, %d workgroups per CU\n", NL, (int)n, lds_team, occ);
       }
-      if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else if (NL == 120) DSH_TMR_LAUNCH(120); else DSH_TMR_LAUNCH(128);
+      if (NL == 64) DSH_TMR_LAUNCH(64); else if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else if (NL == 120) DSH_TMR_LAUNCH(120); else DSH_TMR_LAUNCH(128);
 #undef DSH_TMR_LAUNCH
     } else {
       static bool attr_dev[64] = {false};

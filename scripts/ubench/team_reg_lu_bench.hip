@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
   const int nb = argc > 2 ? atoi(argv[2]) : 256;
   const std::string kind = argc > 3 ? argv[3] : "dense";
   const int nsol = argc > 4 ? atoi(argv[4]) : 4;
-  if (n <= 64 || n > TRG_NL) { printf("64 < n <= %d\n", TRG_NL); return 2; }
+  if (n < 9 || n > TRG_NL) { printf("8 < n <= %d\n", TRG_NL); return 2; }
   std::vector<double> M((size_t)nb * n * n), B((size_t)nb * nsol * n);
   uint64_t z = 987654321ull + n;
   auto rnd = [&] { z = z * 6364136223846793005ull + 1442695040888963407ull; return (double)(z >> 11) / 9007199254740992.0 - 0.5; };

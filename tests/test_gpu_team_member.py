@@ -127,6 +127,51 @@ def test_the_register_resident_lu_has_the_bits_of_the_oracle_and_of_the_lds_resi
     assert np.array_equal(y0, y1) and np.array_equal(m0["stats"], m1["stats"])
 
 
+@pytest.mark.parametrize("groups", [17, 20, 21])
+def test_identity_mass_models_with_49_to_64_states_take_the_workgroup_form_with_the_lu_in_registers(H, O, det_pow, groups, monkeypatch):
+    """48 < n <= 64 without a mass matrix: the wavefront-per-member kernel's one-lane-per-row elimination does not fit a wavefront's registers next to the integrator's
+    state at these sizes, so the ensemble runs in the workgroup form (k_bdf_team_member_rl<64>; the second row block is empty).  robertson_ode x 17 / 20 / 21 (n = 51 / 60 /
+    63) against the oracle, and against the wavefront-per-member kernel (DSH_TEAM_REG_LU=0)."""
+    monkeypatch.setenv("DSH_RESIDENT_LANE", "0")
+    rng = np.random.default_rng(2000 + groups)
+    nb = 5
+    p = np.stack([0.04 * 2 ** rng.uniform(-1, 1, nb), 1e4 * 2 ** rng.uniform(-1, 1, nb), 3e7 * 2 ** rng.uniform(-1, 1, nb)], axis=1)
+    t_eval = [0.4, 4.0, 40.0, 400.0]
+    tol = dict(rtol=1e-4, atol=[1e-8, 1e-14, 1e-6] * groups)
+    s, m = _pair(H, O, "robertson_ode", ORACLE_MODEL["robertson_ode"], p, t_eval, groups, **tol)
+    y1, _, m1 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    monkeypatch.setenv("DSH_TEAM_REG_LU", "0")
+    y0, _, m0 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    assert np.array_equal(y0, y1) and np.array_equal(m0["stats"], m1["stats"])
+
+
+@pytest.mark.parametrize("m", [25, 32])
+def test_dense_coupled_oscillators_from_diffsl_with_50_and_64_states(H, O, det_pow, m, monkeypatch):
+    """the DiffSL oscillators at n = 50 / 64 (row interchanges in every factorisation): hiprtc's k_bdf_team_member_rl<56 / 64> against the oracle and against the
+    wavefront-per-member kernel"""
+    import diffsl_models as D
+    from diffsol_amd import diffsl
+    code = D.oscillators(m)
+    model = diffsl.DiffslModel(code)
+    mid = D.host_model(O, code)
+    rng = np.random.default_rng(700 + m)
+    nb = 5
+    p = np.stack([rng.uniform(20.0, 80.0, nb), rng.uniform(0.5, 2.0, nb), rng.uniform(0.005, 0.02, nb)], axis=1)
+    t_eval = [0.05, 0.2, 0.5]
+    tol = dict(rtol=1e-6, atol=[1e-8])
+    s = H.Solver(model, p, nbatch=nb, **tol)
+    assert s.n == 2 * m
+    y, tot, mm = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    yo, so, failed = O.solve_dense_independent(mid, p, t_eval, nthreads=8, **tol)
+    yo = np.transpose(yo, (1, 0, 2))
+    assert failed == 0 and (mm["status"] == 0).all()
+    assert np.array_equal(mm["stats"].T, so), "counters differ"
+    assert np.array_equal(y, yo), "states differ"
+    monkeypatch.setenv("DSH_TEAM_REG_LU", "0")
+    y0, _, m0 = s.solve_dense_adaptive(t_eval, want_member_stats=True, group=1, deterministic_pow=True)
+    assert np.array_equal(y0, y) and np.array_equal(m0["stats"], mm["stats"])
+
+
 @pytest.mark.parametrize("m", [36, 60, 64])
 def test_dense_coupled_oscillators_from_diffsl_through_the_register_resident_lu(H, O, det_pow, m, monkeypatch):
     """the DiffSL oscillators (dense Jacobian, row interchanges in every factorisation) at n = 72 / 120 / 128: hiprtc's instantiation of k_bdf_team_member_rl<n rounded
