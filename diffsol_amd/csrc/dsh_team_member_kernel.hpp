@@ -356,8 +356,9 @@ __device__ __forceinline__ void bdf_team_member_body(int64_t nb, const double* _
   const bool det = o.deterministic_pow != 0;
   const int n = C.n, model = C.model;
   const int64_t b = blockIdx.x;
-  const int ln = RL > 0 ? (int)(threadIdx.x & 127) : (int)threadIdx.x;
-  const int half = RL > 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7)) : 0;
+  constexpr int RBN = RL > 0 ? trg_rbn(RL) : 2;  // RL <= 64: one row block (128 threads: thread t and t + 64 carry row t & 63)
+  const int ln = RL > 0 ? (int)(threadIdx.x & (64 * RBN - 1)) : (int)threadIdx.x;
+  const int half = RL > 0 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> (5 + RBN))) : 0;
   const bool lead = threadIdx.x == 0;
   const bool rowlive = ln < n;
   const double rtol = C.r.rtol;
@@ -497,7 +498,7 @@ __device__ __forceinline__ void bdf_team_member_body(int64_t nb, const double* _
     TMP_MARK(1)
   };
   auto lu_solve = [&](double& rhs) __attribute__((always_inline)) -> bool {
-    if constexpr (RL > 0) return team_reg_lu_solve(a_rl, n, (int)threadIdx.x, wk, lu_singular, rl_d, rl_r, rhs);
+    if constexpr (RL > 0) return team_reg_lu_solve<RL>(a_rl, n, (int)threadIdx.x, wk, lu_singular, rl_d, rl_r, rhs);
     else return team_lu_solve<W>(A, P, n, ln, rowlive, perm, xs2, lu_singular, rhs);
   };
   n_setups = 1;
@@ -1070,9 +1071,9 @@ __global__ __launch_bounds__(64 * W) void k_bdf_team_member(int64_t nb, const do
                                                        int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {
   bdf_team_member_body<W, SENS, 0>(nb, p_g, atol_g, atol_broadcast, Cp, t_eval, jac_scratch, y_out, stats_out, status_out, t_root_out, root_idx_out, ncols_out, totals);
 }
-// 64 < n <= NL <= 128, the factors in registers: four wavefronts, two per SIMD (256 registers a thread), two members on a CU
+// n <= NL <= 128, the factors in registers: four wavefronts (NL <= 64: two), two per SIMD (256 registers a thread), two (four) members on a CU
 template <int NL>
-__global__ __launch_bounds__(kTrgThreads, 2) void k_bdf_team_member_rl(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
+__global__ __launch_bounds__(trg_threads(NL), 2) void k_bdf_team_member_rl(int64_t nb, const double* __restrict__ p_g, const double* __restrict__ atol_g, int atol_broadcast,
                                                        const WaveMemberConsts* __restrict__ Cp, const double* __restrict__ t_eval, double* __restrict__ jac_scratch, double* __restrict__ y_out,
                                                        int32_t* __restrict__ stats_out, int32_t* __restrict__ status_out, double* __restrict__ t_root_out,
                                                        int32_t* __restrict__ root_idx_out, int32_t* __restrict__ ncols_out, unsigned long long* __restrict__ totals) {

@@ -63,6 +63,9 @@ __host__ __device__ constexpr int trg_chunk(int NL) { return NL > 120 ? 4 : 8; }
 __host__ __device__ constexpr int trg_off_arch(int NL) { return kTrgOffExch + 2 * trg_chunk(NL) * kTrgPitch; }
 __host__ __device__ constexpr int trg_lds_doubles(int NL) { return trg_off_arch(NL) + NL * NL / 2 + NL; }
 __host__ __device__ constexpr int trg_nl(int n) { return (n + 7) & ~7; }
+// NL <= 64: ONE row block — two wavefronts (128 threads: thread t and t + 64 carry row t & 63 and one column half each), four members per CU
+__host__ __device__ constexpr int trg_rbn(int NL) { return NL <= 64 ? 1 : 2; }
+__host__ __device__ constexpr int trg_threads(int NL) { return 128 * trg_rbn(NL); }
 // first slot of pivot row k in the archive, minus its first stored column (k & ~1): column j of row k sits at trg_arch_base(k, NL) + j
 __device__ __forceinline__ int trg_arch_base(int k, int NL) {
   const int q = k >> 1;
@@ -159,7 +162,7 @@ __device__ __forceinline__ void trg_step(double (&a)[64], int n, int kk, int row
   if constexpr (H != HB) ckk = colbuf[row];
   double s0 = c01.x, r0 = c45.y;
   int p0 = (int)c01.y;
-  {
+  if constexpr (trg_rbn(NL) == 2) {  // the second row block's candidate
     double b0 = p0 < n ? fabs(s0) : -1.0;
     const double s1 = c23.x;
     const int p1 = (int)c23.y;
@@ -297,8 +300,9 @@ __device__ __forceinline__ void trg_factor_half(double (&a)[64], int n, int row,
 template <int NL>
 __device__ __forceinline__ void team_reg_lu_factor(double (&a)[64], int n, int tid, double* __restrict__ w, bool& singular, double& dself, double& rself) {
   static_assert(NL % 8 == 0 && NL >= 8 && NL <= kTrgMaxN, "NL <= 128, a multiple of 8");
+  constexpr int RBN = trg_rbn(NL);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wavefront's number as a scalar: the branch on the column half is a scalar branch
-  const int row = tid & 127, lane = tid & 63, rb = wv & 1, h = wv >> 1;
+  const int row = tid & (64 * RBN - 1), lane = tid & 63, rb = wv & (RBN - 1), h = wv >> (RBN - 1);
   const bool rowlive = row < n;
   int pos = row;
   singular = false;
@@ -361,9 +365,11 @@ __device__ __forceinline__ void trg_back_block(const double (&a)[64], int m, int
 
 // Solve with the factors above: on entry every thread of row r (both column halves) holds component r of the right-hand side, on return unknown r.
 // Returns false when a pivot was zero, like team_lu_solve.  The column-oriented substitutions of lu_solve_reg / the oracle, per element in their order.
+template <int NL>
 __device__ __forceinline__ bool team_reg_lu_solve(const double (&a)[64], int n, int tid, double* __restrict__ w, bool singular, double dself, double rself, double& v) {
+  constexpr int RBN = trg_rbn(NL);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wavefront's number as a scalar: the branches on rb / h below are scalar branches
-  const int row = tid & 127, lane = tid & 63, rb = wv & 1, h = wv >> 1;
+  const int row = tid & (64 * RBN - 1), lane = tid & 63, rb = wv & (RBN - 1), h = wv >> (RBN - 1);
   const bool rowlive = row < n;
   const int* perm = reinterpret_cast<const int*>(w + kTrgOffPerm);
   double* xch = w + kTrgOffExch;
@@ -377,6 +383,16 @@ __device__ __forceinline__ bool team_reg_lu_solve(const double (&a)[64], int n, 
   __syncthreads();
   v = rowlive ? xch[perm[row]] : 0.0;  // (P b) at my position
   TRS_MARK(0)
+  if constexpr (RBN == 1) {  // one row block: both substitutions inside the wavefront that holds columns 0 .. 63
+    if (h == 0) {
+      trg_fwd_block(a, m0, lane, v);
+      trg_back_block(a, m0, lane, dself, rself, v);
+      ybuf[lane] = v;
+    }
+    __syncthreads();
+    v = ybuf[row];
+    return !singular;
+  }
   // ---- L y = P b: positions 0 .. 63 inside wavefront (0, 0)
   if (rb == 0 && h == 0) {
     trg_fwd_block(a, m0, lane, v);

@@ -49,6 +49,8 @@ int dsh_model_has_wave_member(int model, int64_t size) {
 
 // the register-resident LU of the workgroup-per-member BDF (64 < n <= 128) — on unless DSH_TEAM_REG_LU=0 (read at every launch: the tests compare the two forms)
 static bool team_reg_lu_on() { const char* e = getenv("DSH_TEAM_REG_LU"); return !(e && e[0] == '0'); }
+// identity-mass models above this size take the workgroup form (two wavefronts, the LU in registers) instead of the wavefront-per-member kernel; DSH_TEAM_SMALL_MIN overrides
+static int team_small_min() { const char* e = getenv("DSH_TEAM_SMALL_MIN"); const int v = e ? atoi(e) : 32; return v < 8 ? 8 : (v > 64 ? 64 : v); }
 struct WmSensSpec { double* out; double rtol; const double* atol_host; int64_t natol; };
 struct WmStepsSpec { double* t_out; int64_t cap; };  // OdeSolverMethod::solve: every accepted step out (WaveMemberConsts::steps_cap)
 static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int64_t nb, const double* p, const double* atol, int64_t atol_nb, double rtol, double t0,
@@ -161,10 +163,10 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
   (void)dsh_model_info(model, size, nullptr, nullptr, &has_mass, nullptr);
   const int ab = atol_nb == 1 ? 1 : 0;
   double* jac_scratch = nullptr;
-  // 48 < n <= 64, identity mass, no sensitivities: the workgroup form with the LU in registers too — the wavefront-per-member kernel's elimination (one lane per row, a
+  // 32 < n <= 64, identity mass, no sensitivities: the workgroup form with the LU in registers too (faster from n = 33 on: 1024 members 11.9 -> 7.5 ms there, 13.9 -> 8.8 ms at n = 48) — the wavefront-per-member kernel's elimination (one lane per row, a
   // jump per pivot into straight-line code) needs more than the 512 registers a wavefront can have next to the integrator's state at NP = 64 (2.5 KB of scratch, most of
   // its traffic inside the elimination: 227 us per factorisation at n = 60 inside that kernel against 90 us here; profiles/r06_team_reg_lu.md)
-  const bool small_team = wm_kind == 1 && n > 48 && !has_mass && !sens && team_reg_lu_on();
+  const bool small_team = wm_kind == 1 && n > team_small_min() && !has_mass && !sens && team_reg_lu_on();
   if (wm_kind == 2 || small_team) {
     // one workgroup per member (48 < n <= 320): the factors in registers (n <= 128) / LDS / global scratch, the cached Jacobians in global scratch (n^2 doubles per member)
     const int waves = team_waves((int)n);
@@ -172,7 +174,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
     // NL, the compile-time bound on n: n rounded up to 8 for a run-time-compiled model (its module is its own), five steps for the built-in ones
     // (120: the reference's own benchmark size, robertson_ode x 40).
     const bool reg_lu = !sens && n <= kTrgMaxN && team_reg_lu_on();
-    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 64 ? 64 : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : (n <= 120 ? 120 : 128))))));
+    const int NL = !reg_lu ? 0 : (is_jit_model(model) ? trg_nl((int)n) : (n <= 48 ? 48 : (n <= 64 ? 64 : (n <= 80 ? 80 : (n <= 96 ? 96 : (n <= 112 ? 112 : (n <= 120 ? 120 : 128)))))));
     const size_t lds_team = sizeof(double) * (reg_lu ? team_rl_lds_doubles(NL) : team_lds_doubles((int)n, waves));
     rc = dsh_malloc(ctx, (int64_t)(sizeof(double) * team_scratch_doubles((int)n, waves)) * nb, 0, (void**)&jac_scratch);
     if (rc != DSH_OK) { dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
@@ -180,13 +182,14 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
     if (is_jit_model(model)) {
       const std::string name = reg_lu ? std::string("dsh::k_bdf_team_member_rl<") + std::to_string(NL) + ">"
                                       : std::string("dsh::k_bdf_team_member<") + std::to_string(waves) + (sens ? ", true>" : ">");
-      rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(reg_lu ? kTrgThreads : 64 * waves), (unsigned)lds_team, nb, p, atol, ab,
+      rc = jit_launch(ctx, model, "dsh_jit_team_member.hpp", name, {name}, name, dim3((unsigned)nb), dim3(reg_lu ? trg_threads(NL) : 64 * waves), (unsigned)lds_team, nb, p, atol, ab,
                       (const WaveMemberConsts*)consts_dev, (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev);
       if (rc != DSH_OK) { dsh_free(ctx, jac_scratch); dsh_free(ctx, t_eval_dev); dsh_free(ctx, totals_dev); dsh_free(ctx, consts_dev); return rc; }
     } else if (reg_lu) {
       static bool attr_rl_dev[64] = {false};
       bool& attr = attr_rl_dev[ctx->device & 63];
       if (!attr) {
+        DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<80>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSH_HIP_CHECK(hipFuncSetAttribute((const void*)k_bdf_team_member_rl<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -196,7 +199,7 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
         attr = true;
       }
 #define DSH_TMR_LAUNCH(NLV)                                                                                                                                              \
-  hipLaunchKernelGGL((k_bdf_team_member_rl<NLV>), dim3((unsigned)nb), dim3(kTrgThreads), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
+  hipLaunchKernelGGL((k_bdf_team_member_rl<NLV>), dim3((unsigned)nb), dim3(trg_threads(NLV)), lds_team, ctx->stream, nb, p, atol, ab, (const WaveMemberConsts*)consts_dev, \
                      (const double*)t_eval_dev, jac_scratch, y_out, stats, status, t_root, root_idx, ncols, totals_dev)
       if (getenv("DSH_TEAM_DEBUG")) {  // how many members share a CU (two when the workspace fits twice)
         int occ = 0;
@@ -204,11 +207,11 @@ static int bdf_solve_wave_member_impl(dsh_ctx* ctx, int model, int64_t size, int
         else if (NL == 120) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<120>, kTrgThreads, lds_team);
         else if (NL == 112) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<112>, kTrgThreads, lds_team);
         else if (NL == 96) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<96>, kTrgThreads, lds_team);
-        else if (NL == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<64>, kTrgThreads, lds_team);
+        else if (NL == 64) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<64>, trg_threads(64), lds_team);
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bdf_team_member_rl<80>, kTrgThreads, lds_team);
         fprintf(stderr, "k_bdf_team_member_rl<%d>: n = %d, %zu bytes of LDS, %d workgroups per CU\n", NL, (int)n, lds_team, occ);
       }
-      if (NL == 64) DSH_TMR_LAUNCH(64); else if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else if (NL == 120) DSH_TMR_LAUNCH(120); else DSH_TMR_LAUNCH(128);
+      if (NL == 48) DSH_TMR_LAUNCH(48); else if (NL == 64) DSH_TMR_LAUNCH(64); else if (NL == 80) DSH_TMR_LAUNCH(80); else if (NL == 96) DSH_TMR_LAUNCH(96); else if (NL == 112) DSH_TMR_LAUNCH(112); else if (NL == 120) DSH_TMR_LAUNCH(120); else DSH_TMR_LAUNCH(128);
 #undef DSH_TMR_LAUNCH
     } else {
       static bool attr_dev[64] = {false};

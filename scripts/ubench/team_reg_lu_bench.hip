@@ -51,10 +51,11 @@ __global__ __launch_bounds__(128) void k_ref(int n, int nfac, int nsol, const do
   }
 }
 
-__global__ __launch_bounds__(kTrgThreads, TRG_WPE) void k_reg(int n, int nfac, int nsol, const double* __restrict__ M, const double* __restrict__ B, double* __restrict__ X,
+__global__ __launch_bounds__(trg_threads(TRG_NL), TRG_WPE) void k_reg(int n, int nfac, int nsol, const double* __restrict__ M, const double* __restrict__ B, double* __restrict__ X,
                                                      double* __restrict__ F, int* __restrict__ PM, int* __restrict__ SG) {
   extern __shared__ double w[];
-  const int tid = threadIdx.x, row = tid & 127, h = tid >> 7;
+  constexpr int RBN = trg_rbn(TRG_NL);
+  const int tid = threadIdx.x, row = tid & (64 * RBN - 1), h = tid >> (5 + RBN);
   const bool rowlive = row < n;
   const size_t s = blockIdx.x;
   double a[64], dself = 1.0, rself = 1.0;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(kTrgThreads, TRG_WPE) void k_reg(int n, int nfac, i
   for (int q = 0; q < nsol; ++q) {
     double v = rowlive ? B[(s * nsol + q) * n + row] : 0.0;
 #ifndef TRG_NO_SOLVE
-    team_reg_lu_solve(a, n, tid, w, singular, dself, rself, v);
+    team_reg_lu_solve<TRG_NL>(a, n, tid, w, singular, dself, rself, v);
 #endif
     if (rowlive && h == 0) X[(s * nsol + q) * n + row] = v;
   }
@@ -111,14 +112,14 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ref_lds));
   const size_t reg_lds = (size_t)trg_lds_doubles(TRG_NL) * 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_reg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds));
-  { int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_reg, kTrgThreads, reg_lds)); printf("registers form: %zu bytes of LDS, %d workgroups per CU\n", reg_lds, occ); }
+  { int occ = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_reg, trg_threads(TRG_NL), reg_lds)); printf("registers form: %zu bytes of LDS, %d workgroups per CU\n", reg_lds, occ); }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto run = [&](int which, int nfac, int ns) -> float {
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
       hipEventRecord(e0);
       if (which == 0) hipLaunchKernelGGL(k_ref, dim3(nb), dim3(128), ref_lds, 0, n, nfac, ns, dM, dB, dX[0], dF[0], dP[0], dS[0]);
-      else hipLaunchKernelGGL(k_reg, dim3(nb), dim3(kTrgThreads), reg_lds, 0, n, nfac, ns, dM, dB, dX[1], dF[1], dP[1], dS[1]);
+      else hipLaunchKernelGGL(k_reg, dim3(nb), dim3(trg_threads(TRG_NL)), reg_lds, 0, n, nfac, ns, dM, dB, dX[1], dF[1], dP[1], dS[1]);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
@@ -128,7 +129,7 @@ int main(int argc, char** argv) {
     const float t1 = run(which, 1, 0), t5 = run(which, 5, 0), ts = run(which, 1, nsol);
     CK(hipDeviceSynchronize());
     printf("%s n=%d systems=%d %s: factor %.1f us per launch of one factorisation each ((5x - 1x)/4 = %.1f us), %d solves + 1 factorisation %.1f us -> %.1f us per solve\n",
-           which ? "registers (4 wavefronts)" : "LDS       (2 wavefronts)", n, nb, kind.c_str(), t1 * 1e3, (t5 - t1) / 4 * 1e3, nsol, ts * 1e3, (ts - t1) / nsol * 1e3);
+           which ? (trg_rbn(TRG_NL) == 2 ? "registers (4 wavefronts)" : "registers (2 wavefronts)") : "LDS       (2 wavefronts)", n, nb, kind.c_str(), t1 * 1e3, (t5 - t1) / 4 * 1e3, nsol, ts * 1e3, (ts - t1) / nsol * 1e3);
   }
 #ifdef DSH_TRG_PROF
   { unsigned long long pr[4][8]; CK(hipMemcpyFromSymbol(pr, HIP_SYMBOL(dsh::g_trg), sizeof pr));

@@ -127,10 +127,10 @@ def test_the_register_resident_lu_has_the_bits_of_the_oracle_and_of_the_lds_resi
     assert np.array_equal(y0, y1) and np.array_equal(m0["stats"], m1["stats"])
 
 
-@pytest.mark.parametrize("groups", [17, 20, 21])
-def test_identity_mass_models_with_49_to_64_states_take_the_workgroup_form_with_the_lu_in_registers(H, O, det_pow, groups, monkeypatch):
-    """48 < n <= 64 without a mass matrix: the wavefront-per-member kernel's one-lane-per-row elimination does not fit a wavefront's registers next to the integrator's
-    state at these sizes, so the ensemble runs in the workgroup form (k_bdf_team_member_rl<64>; the second row block is empty).  robertson_ode x 17 / 20 / 21 (n = 51 / 60 /
+@pytest.mark.parametrize("groups", [11, 13, 16, 17, 20, 21])
+def test_identity_mass_models_with_33_to_64_states_take_the_workgroup_form_with_the_lu_in_registers(H, O, det_pow, groups, monkeypatch):
+    """32 < n <= 64 without a mass matrix: the wavefront-per-member kernel's one-lane-per-row elimination does not fit a wavefront's registers next to the integrator's
+    state at these sizes, so the ensemble runs in the workgroup form with ONE row block (k_bdf_team_member_rl<48 | 64>: two wavefronts).  robertson_ode x 11 ... 21 (n = 33 ...
     63) against the oracle, and against the wavefront-per-member kernel (DSH_TEAM_REG_LU=0)."""
     monkeypatch.setenv("DSH_RESIDENT_LANE", "0")
     rng = np.random.default_rng(2000 + groups)
