@@ -30,7 +30,7 @@ for groups in (1, 10, 20, 40, 100):
         else:
             routes = [("banded lane per member (block-diagonal Jacobian declared)", {"DSH_RESIDENT_LANE": "1"}, 1)]
             if n <= 140:
-                routes.append(("wavefront per member" if n <= 64 else ("workgroup per member (LU in registers)" if n <= 128 else "workgroup per member (LU in LDS)"), {"DSH_RESIDENT_LANE": "0"}, 1))
+                routes.append(("wavefront per member" if n <= 32 else ("workgroup per member (LU in registers)" if n <= 128 else "workgroup per member (LU in LDS)"), {"DSH_RESIDENT_LANE": "0"}, 1))
         for name, env, group in routes:
             for k, v in env.items():
                 os.environ[k] = v
