@@ -658,6 +658,10 @@ int dsh_model_precompile(int model_id, int family) {
       const std::string sname = name.substr(0, name.size() - 1) + ", true>";
       units.push_back({"dsh_jit_wave_member.hpp", sname, {sname}});
     }
+    if (!rec->info.has_mass && n > 32) {  // what dsh_bdf_solve_wave_member launches for an identity-mass model of this size (dsh_wave_member.hip: small_team): the workgroup form, LU in registers
+      const std::string rname = "dsh::k_bdf_team_member_rl<" + std::to_string((n + 7) / 8 * 8) + ">";
+      units.push_back({"dsh_jit_team_member.hpp", rname, {rname}});
+    }
   }
   else if (!st && family == 3 && rec->info.n <= (rec->info.has_mass ? 48 : 64) && rec->info.nroots <= 2) {  // wavefront-per-member TR-BDF2 / ESDIRK34
     const int64_t n = rec->info.n;
